@@ -1,0 +1,428 @@
+/* oracle/hhv_oracle.c -- TEST INFRASTRUCTURE: plain-C restatement of the reference hot path.
+ *
+ * See hhv_oracle.h for the rules (checker only; never linked into or called by the product).
+ * Compile with -ffp-contract=off: the reference's pinned build has no fused multiply-adds
+ * (SURVEY.md 8c), every binary fp32 operation below is rounded on its own, left to right.
+ *
+ * Restated reference code (file:line in /root/reference):
+ *   hho_log2f4               src/hhutil-inl.h:501-541   (LOG_POLY_DEGREE 4)
+ *   hho_fast_log2            src/util-inl.h:108-130
+ *   hho_dot20_vec            src/hhviterbi.h:126-161    (Viterbi::ScalarProd20Vec)
+ *   hho_dot20_scalar         src/hhhit-inl.h:125-131    (ScalarProd20, the branch every build takes)
+ *   hho_align                src/hhviterbialgorithm.cpp:29-497 (+ batch padding of
+ *                            src/hhhmmsimd.cpp:137-152)
+ *   hho_backtrace            src/hhviterbi.cpp:83-160
+ *   hho_score_for_backtrace  src/hhviterbi.cpp:195-281, src/hhviterbi.h:193-211 (ScoreSS)
+ *   hho_exclude_alignment    src/hhviterbi.cpp:61-77    (VITERBI_PATH_WIDTH = 40, src/hhdecl.h:50)
+ */
+#include "hhv_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static inline uint32_t f2u(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  return u;
+}
+static inline float u2f(uint32_t u) {
+  float x;
+  memcpy(&x, &u, 4);
+  return x;
+}
+/* x86 MAXPS(a,b): a > b ? a : b (returns b when equal or unordered) */
+static inline float mx(float a, float b) { return a > b ? a : b; }
+
+/* src/hhutil-inl.h:509-541 */
+float hho_log2f4(float x) {
+  const uint32_t i = f2u(x);
+  const float e = (float)((int32_t)((i & 0x7F800000u) >> 23) - 127);
+  const float m = u2f((i & 0x007FFFFFu) | 0x3F800000u);
+  /* POLY3(m, c0, c1, c2, c3): ((c3*m + c2)*m + c1)*m + c0, each step mul then add */
+  float p = -0.107254423828329604454f * m;
+  p = p + 0.688243882994381274313f;
+  p = p * m;
+  p = p + -1.75647175389045657003f;
+  p = p * m;
+  p = p + 2.61761038894603480148f;
+  p = p * (m - 1.0f);
+  return p + e;
+}
+
+/* src/util-inl.h:108-130.  The table is built exactly like the reference builds it; in the
+ * reference translation units log(float) resolves to the float overload (logf), which is what the
+ * pinning test tests/test_oracle_vs_reference.py::test_fast_log2_table confirms. */
+static float lg2_tab[1025];
+static float diff_tab[1025];
+static int lg2_init = 0;
+static void fast_log2_init(void) {
+  float prev = 0.0f;
+  lg2_tab[0] = 0.0f;
+  for (int i = 1; i <= 1024; ++i) {
+    lg2_tab[i] = (float)((double)logf((float)(1024 + i)) * 1.442695041 - (double)10.0f);
+    diff_tab[i - 1] = (float)((double)(lg2_tab[i] - prev) * 1.2352E-4);
+    prev = lg2_tab[i];
+  }
+  lg2_init = 1;
+}
+float hho_fast_log2(float x) {
+  if (x <= 0) return -100000;
+  if (!lg2_init) {
+#pragma omp critical(hho_lg2)
+    {
+      if (!lg2_init) fast_log2_init();
+    }
+  }
+  const uint32_t u = f2u(x);
+  const int a = (int)((u & 0x7F800000u) >> 23) - 0x7f;
+  const int b = (int)((u & 0x007FE000u) >> 13);
+  const int c = (int)(u & 0x00001FFFu);
+  return ((float)a + lg2_tab[b]) + diff_tab[b] * (float)c;
+}
+
+/* src/hhviterbi.h:126-161 */
+float hho_dot20_vec(const float *q, const float *t) {
+  float r0 = t[0] * q[0];
+  float r1 = t[1] * q[1];
+  float r2 = t[2] * q[2];
+  float r3 = t[3] * q[3];
+  for (int k = 4; k < 20; k += 4) {
+    r0 = t[k + 0] * q[k + 0] + r0;
+    r1 = t[k + 1] * q[k + 1] + r1;
+    r2 = t[k + 2] * q[k + 2] + r2;
+    r3 = t[k + 3] * q[k + 3] + r3;
+  }
+  r0 = r0 + r1;
+  r2 = r2 + r3;
+  return r0 + r2;
+}
+
+/* src/hhhit-inl.h:125-131.  The intrinsics branch above it (:85-123) is guarded by `#ifdef SSE`,
+ * a macro that no header or build file of the reference defines (lib/simd/simd.h only defines
+ * AVX2/AVX512 and the SSE_* size constants), so every build runs this plain left-to-right sum.
+ * Pinned against the compiled reference in tests/test_oracle_vs_reference.py. */
+float hho_dot20_scalar(const float *q, const float *t) {
+  float r = t[0] * q[0];
+  for (int k = 1; k < 20; k++) r = r + t[k] * q[k];
+  return r;
+}
+
+static float ss_cell(const hho_params *par, const hho_ss *ss, int i, int j, int Lt) {
+  if (!ss || ss->ss_hmm_mode == HHO_NO_SS) return 0.0f;
+  /* index tables of HMMSimd::MapHMMVector, src/hhhmmsimd.cpp:132-135,150-151 (padding -> 0) */
+  unsigned char pred_index = 0, dssp_index = 0;
+  if (j <= Lt) {
+    pred_index = (unsigned char)((unsigned char)ss->t_ss_pred[j] * HHO_MAXCF + ss->t_ss_conf[j]);
+    dssp_index = (unsigned char)ss->t_ss_dssp[j];
+  }
+  const float *score;
+  unsigned char idx;
+  if (ss->ss_hmm_mode == HHO_PRED_PRED) {
+    score = ss->S33 + (((size_t)ss->q_ss_pred[i] * HHO_MAXCF + ss->q_ss_conf[i]) * HHO_NSSPRED * HHO_MAXCF);
+    idx = pred_index;
+  } else if (ss->ss_hmm_mode == HHO_DSSP_PRED) {
+    score = ss->S73 + ((size_t)ss->q_ss_dssp[i] * HHO_NSSPRED * HHO_MAXCF);
+    idx = pred_index;
+  } else {
+    score = ss->S37 + (((size_t)ss->q_ss_pred[i] * HHO_MAXCF + ss->q_ss_conf[i]) * HHO_NDSSP);
+    idx = dssp_index;
+  }
+  return par->ssw * score[idx];
+}
+
+int hho_align(const hho_params *par, const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr,
+              int Lt, int Lbatch, const unsigned char *celloff, const hho_ss *ss, float *score_out, int *i2_out,
+              int *j2_out, unsigned char *bt) {
+  if (Lbatch < Lt) return -1;
+  const int W = Lbatch + 1;
+  const float smin = par->local ? 0.0f : -FLT_MAX; /* :77 */
+  const int use_ss = (par->ss_mode == 2 && ss && ss->ss_hmm_mode != HHO_NO_SS); /* src/hhviterbi.cpp:175 */
+  float *buf = (float *)malloc(sizeof(float) * 5 * (size_t)W);
+  if (!buf) return -2;
+  float *sMM = buf, *sDG = buf + W, *sMI = buf + 2 * W, *sGD = buf + 3 * W, *sIM = buf + 4 * W;
+  static const float zero20[20] = {0};
+  if (bt) memset(bt, 0, (size_t)(Lq + 1) * W);
+
+  /* :144-153 */
+  for (int j = 0; j <= Lbatch; ++j) {
+    sMM[j] = (float)(-j) * par->egt;
+    sDG[j] = sMI[j] = sGD[j] = sIM[j] = -FLT_MAX;
+  }
+  float score = -FLT_MAX;
+  int bi = 0, bj = 0;
+  float mm_ij = 0.0f; /* :134 sMM_i_j = simdf32_set(0) */
+  int j = 0;
+  for (int i = 1; i <= Lq; ++i) {
+    /* :161-173 */
+    float d_MM = (float)(-(i - 1)) * par->egq;
+    float d_IM = -FLT_MAX, d_MI = -FLT_MAX, d_DG = -FLT_MAX, d_GD = -FLT_MAX;
+    sMM[0] = (float)(-i) * par->egq;
+    sDG[0] = sMI[0] = sGD[0] = sIM[0] = -FLT_MAX;
+    /* :182-188 */
+    const float q_m2m = qtr[(i - 1) * 7 + HHO_M2M];
+    const float q_m2d = qtr[(i - 1) * 7 + HHO_M2D];
+    const float q_d2m = qtr[(i - 1) * 7 + HHO_D2M];
+    const float q_d2d = qtr[(i - 1) * 7 + HHO_D2D];
+    const float q_i2m = qtr[(i - 1) * 7 + HHO_I2M];
+    const float q_i2i = qtr[i * 7 + HHO_I2I];
+    const float q_m2i = qtr[i * 7 + HHO_M2I];
+    const int findMax = (par->local || i == Lq); /* :192 */
+    for (j = 1; j <= Lbatch; ++j) {
+      /* :222-228 with the padding of src/hhhmmsimd.cpp:137-152 */
+      float t_m2m, t_m2d, t_d2m, t_d2d, t_i2m, t_i2i, t_m2i;
+      if (j - 1 <= Lt) {
+        const float *r = ttr + (size_t)(j - 1) * 7;
+        t_m2m = r[HHO_M2M];
+        t_m2d = r[HHO_M2D];
+        t_d2m = r[HHO_D2M];
+        t_d2d = r[HHO_D2D];
+        t_i2m = r[HHO_I2M];
+      } else {
+        t_m2m = t_m2d = t_d2m = t_d2d = t_i2m = -FLT_MAX;
+      }
+      if (j <= Lt) {
+        t_i2i = ttr[(size_t)j * 7 + HHO_I2I];
+        t_m2i = ttr[(size_t)j * 7 + HHO_M2I];
+      } else {
+        t_i2i = t_m2i = -FLT_MAX;
+      }
+      const float *tpj = (j <= Lt) ? tp + (size_t)j * 20 : zero20;
+
+      /* :241-273 */
+      unsigned char b;
+      const float c1 = (d_MM + q_m2m) + t_m2m;
+      b = (c1 > smin) ? 2 : 0;
+      float mm = mx(smin, c1);
+      const float c2 = (d_GD + q_m2m) + t_d2m;
+      if (c2 > mm) b |= 3;
+      mm = mx(mm, c2);
+      const float c3 = (d_IM + q_i2m) + t_m2m;
+      if (c3 > mm && b < 4) b = 4;
+      mm = mx(mm, c3);
+      const float c4 = (d_DG + q_d2m) + t_m2m;
+      if (c4 > mm && b < 5) b = 5;
+      mm = mx(mm, c4);
+      const float c5 = (d_MI + q_m2m) + t_i2m;
+      if (c5 > mm && b < 6) b = 6;
+      mm = mx(mm, c5);
+
+      /* :277-283 */
+      float Si = hho_log2f4(hho_dot20_vec(qp + (size_t)i * 20, tpj));
+      if (use_ss) Si = ss_cell(par, ss, i, j, Lt) + Si;
+      Si = Si + par->shift;
+      mm = mm + Si;
+
+      /* :288-298: neighbours from the row buffer, diagonal carries read before the overwrite */
+      const float l_MM = sMM[j - 1], l_GD = sGD[j - 1], l_IM = sIM[j - 1];
+      const float u_MM = sMM[j], u_DG = sDG[j], u_MI = sMI[j];
+      d_MM = sMM[j];
+      d_DG = sDG[j];
+      d_MI = sMI[j];
+      d_GD = sGD[j];
+      d_IM = sIM[j];
+
+      /* :307-366 */
+      float a, c;
+      a = l_MM + t_m2d;
+      c = l_GD + t_d2d;
+      if (a > c) b ^= 8;
+      float gd = mx(a, c);
+      a = (l_MM + q_m2i) + t_m2m;
+      c = (l_IM + q_i2i) + t_m2m;
+      if (a > c) b ^= 16;
+      float im = mx(a, c);
+      a = u_MM + q_m2d;
+      c = u_DG + q_d2d;
+      if (a > c) b ^= 32;
+      float dg = mx(a, c);
+      a = (u_MM + q_m2m) + t_m2i;
+      c = (u_MI + q_m2m) + t_i2i;
+      if (a > c) b ^= 64;
+      float mi = mx(a, c);
+
+      /* :373-392 (only the -DVITERBI_CELLOFF build, i.e. when the matrix carries a mask) */
+      if (celloff) {
+        const int off = (j <= Lt) ? celloff[(size_t)i * (Lt + 1) + j] : 0;
+        const float add = off ? -FLT_MAX : 0.0f;
+        mm = mm + add;
+        gd = gd + add;
+        im = im + add;
+        dg = dg + add;
+        mi = mi + add;
+      }
+
+      /* :396-417 */
+      sMM[j] = mm;
+      sDG[j] = dg;
+      sMI[j] = mi;
+      sGD[j] = gd;
+      sIM[j] = im;
+      if (bt) bt[(size_t)i * W + j] = b;
+
+      /* :423-455 */
+      if (findMax) {
+        if (mm > score) {
+          score = mm;
+          bi = i;
+          bj = j;
+        }
+      }
+      mm_ij = mm;
+    }
+    /* :462-486 (j-1 == last column of the batch) */
+    if (!par->local) {
+      if (mm_ij > score) {
+        score = mm_ij;
+        bi = i;
+        bj = j - 1;
+      }
+    }
+  }
+  free(buf);
+  *score_out = score;
+  *i2_out = bi;
+  *j2_out = bj;
+  return 0;
+}
+
+/* src/hhviterbi.cpp:83-160 */
+int hho_backtrace(const unsigned char *bt, int pitch, int i2, int j2, int *i_steps, int *j_steps, signed char *states,
+                  int cap, int *nsteps, int *matched_cols) {
+  int step = 0, matched = 0;
+  int i = i2, j = j2;
+  int state = HHO_MM;
+#define BT(ii, jj) bt[(size_t)(ii) * pitch + (jj)]
+  while (state != HHO_STOP) {
+    step++;
+    if (step >= cap) return -1;
+    states[step] = (signed char)state;
+    i_steps[step] = i;
+    j_steps[step] = j;
+    switch (state) {
+      case HHO_MM:
+        matched++;
+        if (i <= 1 || j <= 1) {
+          state = HHO_STOP;
+        } else {
+          state = BT(i, j) & 7;
+          i--;
+          j--;
+        }
+        break;
+      case HHO_GD:
+        if (j <= 1) state = HHO_STOP;
+        else {
+          if (BT(i, j) & 8) state = HHO_MM;
+          j--;
+        }
+        break;
+      case HHO_IM:
+        if (j <= 1) state = HHO_STOP;
+        else {
+          if (BT(i, j) & 16) state = HHO_MM;
+          j--;
+        }
+        break;
+      case HHO_DG:
+        if (i <= 1) state = HHO_STOP;
+        else {
+          if (BT(i, j) & 32) state = HHO_MM;
+          i--;
+        }
+        break;
+      case HHO_MI:
+        if (i <= 1) state = HHO_STOP;
+        else {
+          if (BT(i, j) & 64) state = HHO_MM;
+          i--;
+        }
+        break;
+      default: /* :139-144 illegal state value: stop */
+        state = HHO_STOP;
+        break;
+    }
+  }
+#undef BT
+  states[step] = HHO_MM; /* :147 */
+  *nsteps = step;
+  *matched_cols = matched;
+  return 0;
+}
+
+static float score_ss_cell(const hho_params *par, const hho_ss *ss, int i, int j) {
+  /* src/hhviterbi.h:193-211 (ScoreSS with ssm = ss_hmm_mode) */
+  if (!ss) return 0.0f;
+  switch (ss->ss_hmm_mode) {
+    case HHO_PRED_DSSP:
+      return par->ssw * ss->S37[((size_t)ss->q_ss_pred[i] * HHO_MAXCF + ss->q_ss_conf[i]) * HHO_NDSSP + ss->t_ss_dssp[j]];
+    case HHO_DSSP_PRED:
+      return par->ssw *
+             ss->S73[((size_t)ss->q_ss_dssp[i] * HHO_NSSPRED + ss->t_ss_pred[j]) * HHO_MAXCF + ss->t_ss_conf[j]];
+    case HHO_PRED_PRED:
+      return par->ssw * ss->S33[(((size_t)ss->q_ss_pred[i] * HHO_MAXCF + ss->q_ss_conf[i]) * HHO_NSSPRED +
+                                 ss->t_ss_pred[j]) * HHO_MAXCF + ss->t_ss_conf[j]];
+    default:
+      return 0.0f;
+  }
+}
+
+/* src/hhviterbi.cpp:195-281 */
+int hho_score_for_backtrace(const hho_params *par, const float *qp, const float *tp, const hho_ss *ss,
+                            const int *i_steps, const int *j_steps, const signed char *states, int nsteps,
+                            float viterbi_score, float *S, float *hit_score, float *score_ss_out) {
+  float score_ss = 0.0f;
+  float score = viterbi_score;
+  for (int step = 1; step <= nsteps; step++) {
+    if (states[step] == HHO_MM) {
+      S[step] = hho_fast_log2(hho_dot20_scalar(qp + (size_t)i_steps[step] * 20, tp + (size_t)j_steps[step] * 20));
+      score_ss += score_ss_cell(par, ss, i_steps[step], j_steps[step]);
+    } else {
+      S[step] = 0.0f;
+    }
+  }
+  if (par->ss_mode == 2) score -= score_ss;
+  float Scorr = 0;
+  if (nsteps) {
+    for (int step = 2; step <= nsteps; step++) Scorr += S[step] * S[step - 1];
+    for (int step = 3; step <= nsteps; step++) Scorr += S[step] * S[step - 2];
+    for (int step = 4; step <= nsteps; step++) Scorr += S[step] * S[step - 3];
+    for (int step = 5; step <= nsteps; step++) Scorr += S[step] * S[step - 4];
+    score += par->corr * Scorr;
+  }
+  *hit_score = score;
+  *score_ss_out = score_ss;
+  return 0;
+}
+
+/* src/hhviterbi.cpp:61-77 */
+int hho_exclude_alignment(int Lq, int Lt, const int *i_steps, const int *j_steps, int nsteps, unsigned char *mask) {
+  const int PW = 40;
+  for (int step = 1; step < nsteps; step++) {
+    const int i = i_steps[step], j = j_steps[step];
+    const int ilo = i - PW > 1 ? i - PW : 1, ihi = i + PW < Lq ? i + PW : Lq;
+    for (int ii = ilo; ii <= ihi; ++ii) mask[(size_t)ii * (Lt + 1) + j] = 1;
+    const int jlo = j - PW > 1 ? j - PW : 1, jhi = j + PW < Lt ? j + PW : Lt;
+    for (int jj = jlo; jj <= jhi; ++jj) mask[(size_t)i * (Lt + 1) + jj] = 1;
+  }
+  return 0;
+}
+
+double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
+                       const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2) {
+  struct timespec t0, t1;
+  if (threads < 1) threads = 1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (int k = 0; k < N; k++) {
+    hho_align(par, qp, qtr, Lq, p[k], tr[k], L[k], L[k], NULL, NULL, &score[k], &i2[k], &j2[k], NULL);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

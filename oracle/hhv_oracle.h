@@ -1,0 +1,78 @@
+/* oracle/hhv_oracle.h -- TEST INFRASTRUCTURE (CPU restatement of the reference algorithm).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker.  The product (hh-suite_amd/) never includes, links or calls it.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-for-bit against the reference
+ * itself (oracle/_ref/libhhref.so, built from /root/reference by oracle/Makefile) in
+ * tests/test_oracle_vs_reference.py, and against the committed fixtures in tests/golden/ that
+ * were generated from that reference build (tests/golden/make_golden.py).
+ *
+ * Data convention ("prepared tensors" = what Viterbi::Align sees after PrepareTemplateHMM):
+ *   p  : (L+1) x 20 floats, row 0 unused
+ *   tr : (L+1) x 7 floats, reference enum order M2M,M2I,M2D,I2M,I2I,D2M,D2D (src/hhdecl.h:68)
+ */
+#ifndef HHV_ORACLE_H
+#define HHV_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { HHO_M2M = 0, HHO_M2I = 1, HHO_M2D = 2, HHO_I2M = 3, HHO_I2I = 4, HHO_D2M = 5, HHO_D2D = 6 };
+enum { HHO_STOP = 0, HHO_MM = 2, HHO_GD = 3, HHO_IM = 4, HHO_DG = 5, HHO_MI = 6 };
+enum { HHO_NO_SS = 0, HHO_PRED_DSSP = 1, HHO_DSSP_PRED = 2, HHO_PRED_PRED = 4 };
+enum { HHO_NDSSP = 8, HHO_NSSPRED = 4, HHO_MAXCF = 11 };
+
+typedef struct {
+  int local;   /* par.loc */
+  float egq;   /* penalty_gap_query */
+  float egt;   /* penalty_gap_template */
+  float shift; /* par.shift */
+  float corr;  /* par.corr */
+  float ssw;   /* par.ssw */
+  int ss_mode; /* par.ssm; 2 == Hit::SCORE_ALIGNMENT */
+} hho_params;
+
+/* secondary-structure inputs (all nullable when ss_hmm_mode == HHO_NO_SS) */
+typedef struct {
+  int ss_hmm_mode;
+  const signed char *q_ss_pred, *q_ss_conf, *q_ss_dssp; /* [Lq+1] */
+  const signed char *t_ss_pred, *t_ss_conf, *t_ss_dssp; /* [Lt+1] */
+  const float *S73, *S33, *S37;                         /* [8][4][11], [4][11][4][11], [4][11][8] */
+} hho_ss;
+
+float hho_log2f4(float x);
+float hho_fast_log2(float x);
+float hho_dot20_vec(const float *q, const float *t); /* Viterbi::ScalarProd20Vec order */
+float hho_dot20_scalar(const float *q, const float *t); /* ScalarProd20 order (plain C branch) */
+
+/* One pair.  Lbatch >= Lt emulates the SIMD batch of the reference: columns Lt+1..Lbatch are the
+ * padding MapHMMVector writes (p=0, tr=-FLT_MAX) and the global-mode "last column" is Lbatch.
+ * Lbatch == Lt is the single-length batch (MapOneHMM).
+ * celloff: nullable, (Lq+1) x (Lt+1) bytes, non-zero = excluded cell.
+ * bt: nullable, (Lq+1) x (Lbatch+1) bytes, receives the backtrace bytes (rows/cols 0 zeroed). */
+int hho_align(const hho_params *par, const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr,
+              int Lt, int Lbatch, const unsigned char *celloff, const hho_ss *ss, float *score, int *i2, int *j2,
+              unsigned char *bt);
+
+/* Viterbi::Backtrace.  bt has row pitch `pitch`.  Arrays are 1-based with `cap` entries. */
+int hho_backtrace(const unsigned char *bt, int pitch, int i2, int j2, int *i_steps, int *j_steps, signed char *states,
+                  int cap, int *nsteps, int *matched_cols);
+
+/* Viterbi::ScoreForBacktrace.  S: cap >= nsteps+1 floats. */
+int hho_score_for_backtrace(const hho_params *par, const float *qp, const float *tp, const hho_ss *ss,
+                            const int *i_steps, const int *j_steps, const signed char *states, int nsteps,
+                            float viterbi_score, float *S, float *hit_score, float *score_ss);
+
+/* Viterbi::ExcludeAlignment: ORs the +-40 cross mask of one path into mask ((Lq+1) x (Lt+1)). */
+int hho_exclude_alignment(int Lq, int Lt, const int *i_steps, const int *j_steps, int nsteps, unsigned char *mask);
+
+/* Convenience for the CPU baseline ("port" kind): N templates, score/i2/j2 only, OpenMP over
+ * templates.  Returns wall seconds. */
+double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
+                       const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

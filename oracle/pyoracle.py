@@ -1,0 +1,345 @@
+"""ctypes loaders for the two CPU checkers -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+  Oracle  -> oracle/liboracle.so      (plain-C restatement, oracle/hhv_oracle.c)
+  Ref     -> oracle/_ref/libhhref.so  (the reference's own translation units + ref_harness.cpp)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libhhref.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_ubyte_p = C.POINTER(C.c_ubyte)
+c_byte_p = C.POINTER(C.c_byte)
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def _ubp(a):
+    return a.ctypes.data_as(c_ubyte_p)
+
+
+def _bp(a):
+    return a.ctypes.data_as(c_byte_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HhoParams(C.Structure):
+    _fields_ = [("local", C.c_int), ("egq", C.c_float), ("egt", C.c_float), ("shift", C.c_float),
+                ("corr", C.c_float), ("ssw", C.c_float), ("ss_mode", C.c_int)]
+
+
+class HhoSS(C.Structure):
+    _fields_ = [("ss_hmm_mode", C.c_int),
+                ("q_ss_pred", c_byte_p), ("q_ss_conf", c_byte_p), ("q_ss_dssp", c_byte_p),
+                ("t_ss_pred", c_byte_p), ("t_ss_conf", c_byte_p), ("t_ss_dssp", c_byte_p),
+                ("S73", c_float_p), ("S33", c_float_p), ("S37", c_float_p)]
+
+
+def make_params(local=0, egq=0.0, egt=0.0, shift=-0.03, corr=0.1, ssw=0.11, ss_mode=2):
+    """Defaults of the reference: src/hhdecl.cpp:86-98 (shift, corr, egq, egt, ssw, ssm)."""
+    return dict(local=int(local), egq=float(egq), egt=float(egt), shift=float(shift), corr=float(corr),
+                ssw=float(ssw), ss_mode=int(ss_mode))
+
+
+class SSInfo:
+    """Secondary-structure inputs for the ...AndSS variants (all int8 arrays of length L+1)."""
+
+    def __init__(self, mode, q_pred, q_conf, q_dssp, S73, S33, S37):
+        self.mode = int(mode)
+        self.q_pred = np.ascontiguousarray(q_pred, dtype=np.int8)
+        self.q_conf = np.ascontiguousarray(q_conf, dtype=np.int8)
+        self.q_dssp = np.ascontiguousarray(q_dssp, dtype=np.int8)
+        self.S73 = _f32(S73).reshape(8, 4, 11)
+        self.S33 = _f32(S33).reshape(4, 11, 4, 11)
+        self.S37 = _f32(S37).reshape(4, 11, 8)
+
+
+class AlignOut:
+    pass
+
+
+class Oracle:
+    def __init__(self, path=ORACLE_SO):
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.hho_log2f4.restype = C.c_float
+        L.hho_log2f4.argtypes = [C.c_float]
+        L.hho_fast_log2.restype = C.c_float
+        L.hho_fast_log2.argtypes = [C.c_float]
+        L.hho_dot20_vec.restype = C.c_float
+        L.hho_dot20_vec.argtypes = [c_float_p, c_float_p]
+        L.hho_dot20_scalar.restype = C.c_float
+        L.hho_dot20_scalar.argtypes = [c_float_p, c_float_p]
+        L.hho_align.restype = C.c_int
+        L.hho_align.argtypes = [C.POINTER(HhoParams), c_float_p, c_float_p, C.c_int, c_float_p, c_float_p, C.c_int,
+                                C.c_int, c_ubyte_p, C.POINTER(HhoSS), c_float_p, c_int_p, c_int_p, c_ubyte_p]
+        L.hho_backtrace.restype = C.c_int
+        L.hho_backtrace.argtypes = [c_ubyte_p, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_byte_p, C.c_int,
+                                    c_int_p, c_int_p]
+        L.hho_score_for_backtrace.restype = C.c_int
+        L.hho_score_for_backtrace.argtypes = [C.POINTER(HhoParams), c_float_p, c_float_p, C.POINTER(HhoSS), c_int_p,
+                                              c_int_p, c_byte_p, C.c_int, C.c_float, c_float_p, c_float_p, c_float_p]
+        L.hho_exclude_alignment.restype = C.c_int
+        L.hho_exclude_alignment.argtypes = [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_ubyte_p]
+        L.hho_bench_align.restype = C.c_double
+        L.hho_bench_align.argtypes = [C.POINTER(HhoParams), c_float_p, c_float_p, C.c_int, C.c_int, c_int_p,
+                                      C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_int, c_float_p, c_int_p,
+                                      c_int_p]
+
+    # -- unit probes
+    def log2f4(self, x):
+        return self.lib.hho_log2f4(C.c_float(x))
+
+    def fast_log2(self, x):
+        return self.lib.hho_fast_log2(C.c_float(x))
+
+    def dot20_vec(self, q, t):
+        q, t = _f32(q), _f32(t)
+        return self.lib.hho_dot20_vec(_fp(q), _fp(t))
+
+    def dot20_scalar(self, q, t):
+        q, t = _f32(q), _f32(t)
+        return self.lib.hho_dot20_scalar(_fp(q), _fp(t))
+
+    @staticmethod
+    def _ss_struct(ss, t_ss):
+        if ss is None:
+            return None, None
+        tp, tc, td = (np.ascontiguousarray(a, dtype=np.int8) for a in t_ss)
+        s = HhoSS(ss.mode, _bp(ss.q_pred), _bp(ss.q_conf), _bp(ss.q_dssp), _bp(tp), _bp(tc), _bp(td), _fp(ss.S73),
+                  _fp(ss.S33), _fp(ss.S37))
+        return s, (tp, tc, td)
+
+    def align(self, par, qp, qtr, tp, ttr, Lbatch=None, celloff=None, ss=None, t_ss=None, want_bt=True,
+              want_path=False):
+        """One pair through the restatement; returns AlignOut(score, i2, j2, bt, [path fields])."""
+        qp, qtr, tp, ttr = _f32(qp), _f32(qtr), _f32(tp), _f32(ttr)
+        Lq, Lt = qp.shape[0] - 1, tp.shape[0] - 1
+        Lb = Lt if Lbatch is None else int(Lbatch)
+        P = HhoParams(**par)
+        sst, keep = self._ss_struct(ss, t_ss)
+        score = C.c_float()
+        i2, j2 = C.c_int(), C.c_int()
+        bt = np.zeros((Lq + 1, Lb + 1), dtype=np.uint8) if (want_bt or want_path) else None
+        co = None
+        if celloff is not None:
+            co = np.ascontiguousarray(celloff, dtype=np.uint8)
+            assert co.shape == (Lq + 1, Lt + 1)
+        rc = self.lib.hho_align(C.byref(P), _fp(qp), _fp(qtr), Lq, _fp(tp), _fp(ttr), Lt, Lb,
+                                _ubp(co) if co is not None else None, C.byref(sst) if sst is not None else None,
+                                C.byref(score), C.byref(i2), C.byref(j2), _ubp(bt) if bt is not None else None)
+        assert rc == 0, rc
+        o = AlignOut()
+        o.score, o.i2, o.j2, o.bt = np.float32(score.value), i2.value, j2.value, bt
+        if want_path:
+            cap = o.i2 + o.j2 + 2
+            o.i_steps = np.zeros(cap, dtype=np.int32)
+            o.j_steps = np.zeros(cap, dtype=np.int32)
+            o.states = np.zeros(cap, dtype=np.int8)
+            ns, mc = C.c_int(), C.c_int()
+            rc = self.lib.hho_backtrace(_ubp(bt), Lb + 1, o.i2, o.j2, _ip(o.i_steps), _ip(o.j_steps), _bp(o.states),
+                                        cap, C.byref(ns), C.byref(mc))
+            assert rc == 0, rc
+            o.nsteps, o.matched_cols = ns.value, mc.value
+            o.S = np.zeros(cap, dtype=np.float32)
+            hs, sss = C.c_float(), C.c_float()
+            self.lib.hho_score_for_backtrace(C.byref(P), _fp(qp), _fp(tp), C.byref(sst) if sst is not None else None,
+                                             _ip(o.i_steps), _ip(o.j_steps), _bp(o.states), o.nsteps,
+                                             C.c_float(float(o.score)), _fp(o.S), C.byref(hs), C.byref(sss))
+            o.hit_score, o.score_ss = np.float32(hs.value), np.float32(sss.value)
+        return o
+
+    def exclude_alignment(self, Lq, Lt, i_steps, j_steps, nsteps, mask=None):
+        if mask is None:
+            mask = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
+        i_steps = np.ascontiguousarray(i_steps, dtype=np.int32)
+        j_steps = np.ascontiguousarray(j_steps, dtype=np.int32)
+        self.lib.hho_exclude_alignment(Lq, Lt, _ip(i_steps), _ip(j_steps), int(nsteps), _ubp(mask))
+        return mask
+
+    def bench_align(self, par, qp, qtr, tps, ttrs, threads=1):
+        qp, qtr = _f32(qp), _f32(qtr)
+        tps = [_f32(a) for a in tps]
+        ttrs = [_f32(a) for a in ttrs]
+        N = len(tps)
+        L = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        pp = (c_float_p * N)(*[_fp(a) for a in tps])
+        tt = (c_float_p * N)(*[_fp(a) for a in ttrs])
+        score = np.zeros(N, dtype=np.float32)
+        i2 = np.zeros(N, dtype=np.int32)
+        j2 = np.zeros(N, dtype=np.int32)
+        P = HhoParams(**par)
+        sec = self.lib.hho_bench_align(C.byref(P), _fp(qp), _fp(qtr), qp.shape[0] - 1, N, _ip(L), pp, tt,
+                                       int(threads), _fp(score), _ip(i2), _ip(j2))
+        return sec, score, i2, j2
+
+
+class Ref:
+    """The reference itself (Viterbi::Align & co) behind oracle/ref_harness.cpp."""
+
+    def __init__(self, path=REF_SO):
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.ref_vecsize.restype = C.c_int
+        for n in ("ref_log2f4", "ref_fast_log2"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [C.c_float]
+        for n in ("ref_scalarprod20", "ref_scalarprod20vec"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [c_float_p, c_float_p]
+        L.ref_create.restype = C.c_void_p
+        L.ref_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
+                                 c_float_p, c_float_p, c_float_p]
+        L.ref_destroy.argtypes = [C.c_void_p]
+        L.ref_set_query.restype = C.c_int
+        L.ref_set_query.argtypes = [C.c_void_p, c_float_p, c_float_p, C.c_int, c_byte_p, c_byte_p, c_byte_p]
+        L.ref_align_batch.restype = C.c_int
+        L.ref_align_batch.argtypes = [
+            C.c_void_p, C.c_int, C.c_int, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
+            C.POINTER(c_byte_p), C.POINTER(c_byte_p), C.POINTER(c_byte_p), C.c_int, C.POINTER(c_ubyte_p),
+            c_float_p, c_int_p, c_int_p, C.POINTER(c_ubyte_p), C.c_int, C.c_int, c_int_p, c_int_p,
+            C.POINTER(c_int_p), C.POINTER(c_int_p), C.POINTER(c_byte_p), C.POINTER(c_float_p), c_float_p, c_float_p]
+        L.ref_exclude_alignment.restype = C.c_int
+        L.ref_exclude_alignment.argtypes = [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_ubyte_p]
+        L.ref_bench_align.restype = C.c_double
+        L.ref_bench_align.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, c_float_p,
+                                      c_float_p, C.c_int, C.c_int, c_int_p, C.POINTER(c_float_p),
+                                      C.POINTER(c_float_p), C.c_int, c_float_p, c_int_p, c_int_p,
+                                      C.POINTER(C.c_double)]
+        self.V = L.ref_vecsize()
+
+    def log2f4(self, x):
+        return self.lib.ref_log2f4(C.c_float(x))
+
+    def fast_log2(self, x):
+        return self.lib.ref_fast_log2(C.c_float(x))
+
+    def dot20_vec(self, q, t):
+        q, t = _f32(q), _f32(t)
+        return self.lib.ref_scalarprod20vec(_fp(q), _fp(t))
+
+    def dot20_scalar(self, q, t):
+        q, t = _f32(q), _f32(t)
+        return self.lib.ref_scalarprod20(_fp(q), _fp(t))
+
+    def align_batch(self, par, qp, qtr, tps, ttrs, replicate=False, celloffs=None, ss=None, t_sss=None,
+                    want_bt=True, want_path=False):
+        """One reference batch (<= V templates).  Returns a list of AlignOut (bt has Ltb+1 columns)."""
+        qp, qtr = _f32(qp), _f32(qtr)
+        tps = [_f32(a) for a in tps]
+        ttrs = [_f32(a) for a in ttrs]
+        n = len(tps)
+        assert 1 <= n <= self.V
+        Lq = qp.shape[0] - 1
+        Ls = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        Ltb = int(Ls.max())
+        maxres = max(Lq, Ltb) + 2
+        if ss is not None:
+            h = self.lib.ref_create(maxres, par["local"], par["egq"], par["egt"], par["corr"], par["shift"],
+                                    par["ss_mode"], par["ssw"], _fp(ss.S73), _fp(ss.S33), _fp(ss.S37))
+            self.lib.ref_set_query(h, _fp(qp), _fp(qtr), Lq, _bp(ss.q_pred), _bp(ss.q_conf), _bp(ss.q_dssp))
+            mode = ss.mode
+        else:
+            h = self.lib.ref_create(maxres, par["local"], par["egq"], par["egt"], par["corr"], par["shift"],
+                                    par["ss_mode"], par["ssw"], None, None, None)
+            self.lib.ref_set_query(h, _fp(qp), _fp(qtr), Lq, None, None, None)
+            mode = 0
+        pp = (c_float_p * n)(*[_fp(a) for a in tps])
+        tt = (c_float_p * n)(*[_fp(a) for a in ttrs])
+        keep = []
+        if t_sss is not None:
+            arrs = [[np.ascontiguousarray(x, dtype=np.int8) for x in t] for t in t_sss]
+            keep.append(arrs)
+            sp = (c_byte_p * n)(*[_bp(a[0]) for a in arrs])
+            sc = (c_byte_p * n)(*[_bp(a[1]) for a in arrs])
+            sd = (c_byte_p * n)(*[_bp(a[2]) for a in arrs])
+        else:
+            sp = sc = sd = None
+        co = None
+        if celloffs is not None:
+            cos = [None if m is None else np.ascontiguousarray(m, dtype=np.uint8) for m in celloffs]
+            keep.append(cos)
+            co = (c_ubyte_p * n)(*[(_ubp(m) if m is not None else None) for m in cos])
+        score = np.zeros(n, dtype=np.float32)
+        i2 = np.zeros(n, dtype=np.int32)
+        j2 = np.zeros(n, dtype=np.int32)
+        bts = [np.zeros((Lq + 1, Ltb + 1), dtype=np.uint8) for _ in range(n)]
+        btp = (c_ubyte_p * n)(*[_ubp(b) for b in bts])
+        cap = Lq + Ltb + 4
+        nsteps = np.zeros(n, dtype=np.int32)
+        mcols = np.zeros(n, dtype=np.int32)
+        isl = [np.zeros(cap, dtype=np.int32) for _ in range(n)]
+        jsl = [np.zeros(cap, dtype=np.int32) for _ in range(n)]
+        stl = [np.zeros(cap, dtype=np.int8) for _ in range(n)]
+        Sl = [np.zeros(cap, dtype=np.float32) for _ in range(n)]
+        hit = np.zeros(n, dtype=np.float32)
+        sss = np.zeros(n, dtype=np.float32)
+        rc = self.lib.ref_align_batch(
+            h, n, int(bool(replicate)), _ip(Ls), pp, tt, sp, sc, sd, mode, co, _fp(score), _ip(i2), _ip(j2),
+            btp if (want_bt or want_path) else None, int(bool(want_path)), cap, _ip(nsteps), _ip(mcols),
+            (c_int_p * n)(*[_ip(a) for a in isl]), (c_int_p * n)(*[_ip(a) for a in jsl]),
+            (c_byte_p * n)(*[_bp(a) for a in stl]), (c_float_p * n)(*[_fp(a) for a in Sl]), _fp(hit), _fp(sss))
+        self.lib.ref_destroy(h)
+        assert rc == Ltb, rc
+        outs = []
+        for e in range(n):
+            o = AlignOut()
+            o.score, o.i2, o.j2, o.bt = score[e], int(i2[e]), int(j2[e]), bts[e]
+            if want_path:
+                o.nsteps, o.matched_cols = int(nsteps[e]), int(mcols[e])
+                o.i_steps, o.j_steps, o.states, o.S = isl[e], jsl[e], stl[e], Sl[e]
+                o.hit_score, o.score_ss = hit[e], sss[e]
+            outs.append(o)
+        return outs
+
+    def exclude_alignment(self, Lq, Lt, i_steps, j_steps, nsteps):
+        mask = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
+        i_steps = np.ascontiguousarray(i_steps, dtype=np.int32)
+        j_steps = np.ascontiguousarray(j_steps, dtype=np.int32)
+        self.lib.ref_exclude_alignment(Lq, Lt, _ip(i_steps), _ip(j_steps), int(nsteps), _ubp(mask))
+        return mask
+
+    def bench_align(self, par, qp, qtr, tps, ttrs, threads=1):
+        """The reference's batch loop (V templates per Align call), timed.  Returns
+        (wall_seconds, map_seconds_summed_over_threads, score, i2, j2)."""
+        qp, qtr = _f32(qp), _f32(qtr)
+        tps = [_f32(a) for a in tps]
+        ttrs = [_f32(a) for a in ttrs]
+        N = len(tps)
+        L = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        maxres = max(qp.shape[0] - 1, int(L.max())) + 2
+        pp = (c_float_p * N)(*[_fp(a) for a in tps])
+        tt = (c_float_p * N)(*[_fp(a) for a in ttrs])
+        score = np.zeros(N, dtype=np.float32)
+        i2 = np.zeros(N, dtype=np.int32)
+        j2 = np.zeros(N, dtype=np.int32)
+        mapsec = C.c_double()
+        sec = self.lib.ref_bench_align(maxres, par["local"], par["egq"], par["egt"], par["corr"], par["shift"],
+                                       _fp(qp), _fp(qtr), qp.shape[0] - 1, N, _ip(L), pp, tt, int(threads),
+                                       _fp(score), _ip(i2), _ip(j2), C.byref(mapsec))
+        return sec, mapsec.value, score, i2, j2
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def have_oracle():
+    return os.path.exists(ORACLE_SO)
