@@ -1,0 +1,50 @@
+# Top-level build: the product library (HIP, gfx950 only), the CPU checkers and the test emulator.
+#   make            -> everything
+#   make lib        -> hh-suite_amd/lib/libhhviterbi_hip.so   (the C-ABI drop-in, include/hhviterbi_hip.h)
+#   make oracle     -> oracle/liboracle.so (+ oracle/_ref/libhhref.so when /root/reference is present)
+#   make emul       -> tests/emul/libwave_emul.so             (host lock-step emulation, test only)
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+# -ffp-contract=off: the reference build has no FMA; contraction would change low bits.
+# -fno-slp-vectorize: keeps hipcc from pairing scalar fp32 ops into v_pk_* + register shuffles.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off $(HHV_EXTRA_HIPFLAGS) -fPIC -Wall -Wno-unused-result
+CSRC     := hh-suite_amd/csrc
+LIBDIR   := hh-suite_amd/lib
+OBJDIR   := build/obj
+LIB      := $(LIBDIR)/libhhviterbi_hip.so
+OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_pack.o
+HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
+
+all: lib oracle emul
+
+lib: $(LIB)
+
+$(OBJDIR)/hhv_kernels.o: $(CSRC)/hhv_kernels.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
+$(OBJDIR)/hhv_topk.o: $(CSRC)/hhv_topk.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OBJDIR)/hhv_api.o: $(CSRC)/hhv_api.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(OBJDIR)/hhv_pack.o: $(CSRC)/hhv_pack.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle all
+
+emul: tests/emul/libwave_emul.so
+tests/emul/libwave_emul.so: tests/emul/wave_emul.cpp $(CSRC)/viterbi_lane.h
+	g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -o $@ $<
+
+clean:
+	rm -rf build $(LIBDIR) tests/emul/libwave_emul.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle emul clean

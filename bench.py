@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""bench.py -- Viterbi DP-cells/s of the MI355X engine on BASELINE.json's workload.
+
+One "step" = one pass of the hot path (Viterbi::Align for every template of the resident set:
+hhv_align_async through the C ABI) over one batch of synthetic prepared profiles that already live
+in HBM, followed by the device-side top-K of the step's results; with N > 1 ranks the template
+database is sharded (weak scaling: --templates per GPU) and the K best records of every rank are
+exchanged with ONE all_gather over RCCL (torch.distributed backend "nccl").
+
+Prints ONE JSON line on rank 0 (contract in the task description), carrying `roofline` (dominant
+kernel = hhv_stream_kernel, timed live with HIP events on the library's stream) and `cpu_baseline`
+(the reference's own Viterbi::Align batch loop, oracle/_ref, on the box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "hh-suite_amd"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (fp32, non-packed)
+REC_BYTES = 112
+OPS_PER_CELL = 92          # SURVEY.md 8d / BASELINE.md 5: fp32 operations per DP cell of the reference
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--templates", type=int, default=100000, help="templates per GPU (north-star 1-GPU headline: 100k)")
+    ap.add_argument("--lq", type=int, default=300)
+    ap.add_argument("--lt", type=int, default=300)
+    ap.add_argument("--topk", type=int, default=500)
+    ap.add_argument("--local", type=int, default=0)
+    ap.add_argument("--backtrace", type=int, default=0, help="1 = BASELINE configs[2] (backtrace + hit list)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs1", action="store_true")
+    return ap.parse_args()
+
+
+def gen_stream(torch, device, n, Lt, seed, pb):
+    """Synthetic prepared templates generated on the GPU straight into the packed record stream
+    (DESIGN.md section 2): per template a header + Lt column records; + terminal header + pad.
+    Same distribution family as pyhhv/synth.py (peaky columns mixed with the background, divided by
+    the null model; transitions like AddTransitionPseudocounts leaves them)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    recs_per = Lt + 1
+    total = n * recs_per + 1 + 256
+    rec = torch.zeros((total, 28), dtype=torch.float32, device=device)
+    meta = rec.view(torch.int32)
+    body = rec[: n * recs_per].view(n, recs_per, 28)
+    mbody = meta[: n * recs_per].view(n, recs_per, 28)
+    pbt = torch.tensor(pb, dtype=torch.float32, device=device)
+    chunk = 8192
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        m = b - a
+        u = torch.rand((m, Lt, 20), generator=g, device=device)
+        gg = u.pow(6.0) + 1e-9
+        gg = gg / gg.sum(dim=2, keepdim=True)
+        f = 0.7 * gg + 0.3 * pbt
+        f = f / f.sum(dim=2, keepdim=True)
+        body[a:b, 1:, 0:20] = f / pbt
+        t = torch.rand((m, Lt + 1, 4), generator=g, device=device)
+        pI = 0.01 + 0.04 * t[..., 0]
+        pD = 0.01 + 0.04 * t[..., 1]
+        pII = 0.25 + 0.3 * t[..., 2]
+        pDD = 0.25 + 0.3 * t[..., 3]
+        m2m = torch.log2(1.0 - pI - pD)
+        m2i = torch.log2(pI) * 0.6
+        m2d = torch.log2(pD) * 0.6
+        i2m = torch.log2(1.0 - pII)
+        i2i = torch.log2(pII) * 0.6
+        d2m = torch.log2(1.0 - pDD)
+        d2d = torch.log2(pDD) * 0.6
+        # column 0 and column Lt: no M->I / M->D, no D->D out of Lt (src/hhhmm.cpp:1755-1785)
+        m2m[:, 0] = 0.0
+        m2i[:, 0] = -100000.0
+        m2d[:, 0] = -100000.0
+        m2i[:, Lt] = -100000.0
+        # record j (1..Lt): tr[j-1][M2M,M2D,D2M,D2D,I2M], tr[j][I2I,M2I]
+        body[a:b, 1:, 20] = m2m[:, :Lt]
+        body[a:b, 1:, 21] = m2d[:, :Lt]
+        body[a:b, 1:, 22] = d2m[:, :Lt]
+        body[a:b, 1:, 23] = d2d[:, :Lt]
+        body[a:b, 1:, 24] = i2m[:, :Lt]
+        body[a:b, 1:, 25] = i2i[:, 1:]
+        body[a:b, 1:, 26] = m2i[:, 1:]
+        del u, gg, f, t
+    idx = torch.arange(n, dtype=torch.int32, device=device)
+    mbody[:, 0, 27] = -2 ** 31
+    mbody[:, 0, 0] = idx
+    mbody[:, 0, 1] = Lt
+    j = torch.arange(1, Lt + 1, dtype=torch.int32, device=device)
+    mbody[:, 1:, 27] = j
+    mbody[:, Lt, 27] = Lt | 0x40000000
+    meta[n * recs_per, 27] = -2 ** 31
+    meta[n * recs_per, 0] = -1
+    return rec
+
+
+def unpack_templates(rec_host, n, Lt):
+    """Packed records (host numpy) -> prepared AoS profiles (p[(Lt+1),20], tr[(Lt+1),7]) holding every
+    value the DP reads."""
+    body = rec_host[: n * (Lt + 1)].reshape(n, Lt + 1, 28)
+    tps, ttrs = [], []
+    for k in range(n):
+        p = np.zeros((Lt + 1, 20), dtype=np.float32)
+        tr = np.zeros((Lt + 1, 7), dtype=np.float32)
+        p[1:] = body[k, 1:, 0:20]
+        tr[:Lt, 0] = body[k, 1:, 20]
+        tr[:Lt, 2] = body[k, 1:, 21]
+        tr[:Lt, 5] = body[k, 1:, 22]
+        tr[:Lt, 6] = body[k, 1:, 23]
+        tr[:Lt, 3] = body[k, 1:, 24]
+        tr[1:, 4] = body[k, 1:, 25]
+        tr[1:, 1] = body[k, 1:, 26]
+        tps.append(p)
+        ttrs.append(tr)
+    return tps, ttrs
+
+
+def main():
+    args = parse()
+    import torch
+    from pyhhv import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    Lq, Lt, n = args.lq, args.lt, args.templates
+    qf, qtr = synth.make_query(0x51000000, Lq)
+    rec = gen_stream(torch, device, n, Lt, 0x5EED0000 + rank, synth.PB)
+    torch.cuda.synchronize()
+
+    ctx = capi.Context(local=args.local, device=local_rank)
+    ctx.set_query(qf, qtr)
+    Ls = np.full(n, Lt, dtype=np.int32)
+    ts = ctx.adopt_device_stream(Ls, rec.data_ptr())
+    cells_per_rank = ts.cells()
+    K = args.topk
+    topk_buf = torch.zeros((K, 9), dtype=torch.int32, device=device)       # K hhv_hit records (36 B each)
+    gathered = torch.zeros((world * K, 9), dtype=torch.int32, device=device) if world > 1 else None
+    bt = bool(args.backtrace)
+
+    kernel_ms = []
+
+    def step():
+        ctx.align_async(ts, backtrace=bt)
+        if bt:
+            ctx.hits(ts, fetch=False)
+        ctx.topk(ts, K, d_out=topk_buf.data_ptr(), fetch=False, raw=not bt)
+        kernel_ms.append(ctx.last_kernel_ms())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, topk_buf)
+            # identical merge on every rank: K best of world*K records by (score desc, rank, index)
+            sc = gathered[:, 0].view(torch.float32)
+            order = torch.argsort(sc, descending=True, stable=True)[:K]
+            _ = gathered[order]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_cells = cells_per_rank * world
+    value = total_cells * args.steps / dt
+    k_ms = float(np.mean(kernel_ms))
+    algo_bytes = (n * (Lt + 1) + 1) * REC_BYTES + n * 16 + 64 * ((Lq + 63) // 64) * REC_BYTES
+    if bt:
+        algo_bytes += n * Lq * Lt  # 1 backtrace byte per cell
+    achieved_gbs = algo_bytes / (k_ms * 1e-3) / 1e9
+    kernel_cells_s = cells_per_rank / (k_ms * 1e-3)
+
+    out = {
+        "metric": "viterbi_dp_cells_per_s",
+        "value": value,
+        "unit": "cells/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "templates_per_s": n * world * args.steps / dt,
+        "config": {
+            "workload": "Lq%d_vs_%dx_Lt%d_%s_%s" % (Lq, n * world, Lt, "local" if args.local else "global",
+                                                     "backtrace_hits_top%d" % K if bt else "score_only_top%d" % K),
+            "templates_per_gpu": n, "Lq": Lq, "Lt": Lt, "topk": K,
+            "parallelism": "template-db-shard x%d, one RCCL all_gather of top-K" % world if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "hhv_stream_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
+            "note": "the path is VALU-issue bound, not HBM bound (SURVEY.md 8d): see roofline_valu",
+        },
+        "roofline_valu": {
+            "bound": "valu_fp32_issue", "achieved": kernel_cells_s * OPS_PER_CELL / 1e12, "peak": VALU_PEAK_LANEOPS / 1e12,
+            "unit": "T lane-ops/s", "frac": kernel_cells_s * OPS_PER_CELL / VALU_PEAK_LANEOPS,
+            "ops_per_cell": OPS_PER_CELL, "kernel_cells_per_s": kernel_cells_s,
+        },
+    }
+
+    if rank == 0 and not args.no_configs1 and n >= 10000 and not bt:
+        # BASELINE configs[1]: the same query vs the first 10k templates of the resident stream
+        ts10 = ctx.adopt_device_stream(np.full(10000, Lt, dtype=np.int32), rec.data_ptr())
+        for _ in range(2):
+            ctx.align_async(ts10)
+        ctx.sync()
+        t1 = time.perf_counter()
+        reps = 5
+        ms10 = []
+        for _ in range(reps):
+            ctx.align_async(ts10)
+            ms10.append(ctx.last_kernel_ms())
+        ctx.sync()
+        d10 = time.perf_counter() - t1
+        out["configs1_10k_templates"] = {"cells_per_s": 10000 * Lq * Lt * reps / d10, "kernel_ms": float(np.mean(ms10))}
+        ts10.free()
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, rec, ctx, ts, qf, qtr, n, Lq, Lt)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    ts.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, rec, ctx, ts, qf, qtr, n, Lq, Lt):
+    """The reference's own batch loop (Viterbi::Align, 8 AVX2 lanes per call, OpenMP over batches as in
+    src/hhviterbirunner.cpp:122) on a bounded sample of the SAME templates, on this box's host cores.
+    Also cross-checks the GPU results of the sample against it (bit-exact endpoints, equal scores)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    cores = os.cpu_count() or 1
+    par = pyoracle.make_params(local=args.local)
+    use_ref = pyoracle.have_ref()
+    eng = pyoracle.Ref() if use_ref else pyoracle.Oracle()
+    # size the sample from a short probe
+    probe = min(n, 256)
+    host = rec[: probe * (Lt + 1)].cpu().numpy()
+    tps, ttrs = unpack_templates(host, probe, Lt)
+    r = eng.bench_align(par, qf, qtr, tps, ttrs, threads=cores)
+    sec = r[0]
+    rate = probe * Lq * Lt / max(sec, 1e-9)
+    sample = int(min(n, max(probe, args.cpu_seconds * rate / (Lq * Lt))))
+    sample = max(8, sample - sample % 8)
+    host = rec[: sample * (Lt + 1)].cpu().numpy()
+    tps, ttrs = unpack_templates(host, sample, Lt)
+    r = eng.bench_align(par, qf, qtr, tps, ttrs, threads=cores)
+    sec, score, i2, j2 = r[0], r[-3], r[-2], r[-1]
+    r1 = eng.bench_align(par, qf, qtr, tps[: max(8, sample // cores // 8 * 8)], ttrs[: max(8, sample // cores // 8 * 8)],
+                         threads=1)
+    gpu = ctx.align(ts)
+    ok_idx = bool(np.array_equal(gpu["i2"][:sample], i2) and np.array_equal(gpu["j2"][:sample], j2))
+    ok_score = bool(np.all(gpu["score"][:sample] == score))
+    maxdiff = float(np.max(np.abs(gpu["score"][:sample].astype(np.float64) - score.astype(np.float64))))
+    return {
+        "value": sample * Lq * Lt / sec, "unit": "cells/s", "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "sample": "first %d templates of the benchmark set (Lq=%d, Lt=%d), Viterbi::Align AVX2 8 lanes/call, "
+                  "OpenMP dynamic over batches, %d threads, %.2f s" % (sample, Lq, Lt, cores, sec),
+        "single_thread_cells_per_s": max(8, sample // cores // 8 * 8) * Lq * Lt / r1[0],
+        "gpu_matches_cpu_on_sample": {"endpoints_bit_exact": ok_idx, "scores_equal": ok_score, "max_abs_score_diff": maxdiff},
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,620 @@
+// hhv_api.cpp -- C-ABI host layer of libhhviterbi_hip.so (declared in include/hhviterbi_hip.h).
+// Owns device memory, the packed template sets, the wave partition of the template stream and the
+// kernel launches.  There is deliberately no CPU compute path here: every entry point that needs
+// arithmetic launches a HIP kernel and fails with HHV_E_DEVICE when no device is usable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hhviterbi_hip.h"
+#include "hhv_internal.h"
+#include "hhv_pack.h"
+#include "viterbi_lane.h"
+
+using namespace hhv;
+
+static_assert(sizeof(hhv_result) == sizeof(DevResult), "hhv_result layout");
+static_assert(sizeof(hhv_hit) == sizeof(DevHit), "hhv_hit layout");
+static_assert(HHV_STREAM_PAD == STREAM_PAD_RECS, "stream pad");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorOutOfMemory ? HHV_E_MEMORY : HHV_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+}  // namespace
+
+struct hhv_ctx {
+  hhv_params par;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  int num_cus = 0;
+  // query
+  int Lq = 0, R = 0;
+  float* d_qpack = nullptr;  // [64*R][28]
+  float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring
+  // fast_log2 tables (src/util-inl.h:108-130)
+  float* d_lg2 = nullptr;
+  float* d_diff = nullptr;
+};
+
+struct hhv_tset {
+  hhv_ctx* ctx = nullptr;
+  int32_t n = 0;
+  std::vector<int32_t> L;
+  std::vector<int64_t> rec_off;  // [n+1]: header record of template k; rec_off[n] = terminal header
+  int64_t n_records = 0;         // rec_off[n] + 1
+  float* d_records = nullptr;
+  bool owns_records = false;
+  int64_t* d_rec_off = nullptr;
+  int32_t* d_L = nullptr;
+  DevResult* d_results = nullptr;
+  // wave partition
+  int n_waves = 0;
+  int64_t* d_wave_rec = nullptr;
+  // backtrace bytes
+  uint64_t* d_bt = nullptr;
+  bool bt_valid = false;
+  int bt_Lq = 0, bt_R = 0;
+  // trace outputs
+  std::vector<int64_t> path_off;
+  int path_Lq = -1;
+  int64_t* d_path_off = nullptr;
+  int32_t* d_i_steps = nullptr;
+  int32_t* d_j_steps = nullptr;
+  int8_t* d_states = nullptr;
+  float* d_S = nullptr;
+  DevHit* d_hits = nullptr;
+  bool hits_valid = false;
+  // top-k scratch
+  DevHit* d_topk = nullptr;
+  int topk_cap = 0;
+  uint64_t* d_keys = nullptr;
+  uint64_t* d_sorted = nullptr;
+  void* d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  DevHit* d_raw_hits = nullptr;
+};
+
+namespace hhv {
+size_t topk_temp_bytes(int n);
+void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t stream);
+int topk_device(const DevHit* d_hits, int n, int k, DevHit* d_out, uint64_t* keys, uint64_t* sorted, void* temp,
+                size_t temp_bytes, hipStream_t stream, std::string* err);
+}
+
+extern "C" {
+
+int hhv_abi_version(void) { return HHV_ABI_VERSION; }
+const char* hhv_last_error(void) { return g_err.c_str(); }
+
+int32_t hhv_record_bytes(void) { return REC_DW * (int32_t)sizeof(float); }
+
+int hhv_pack_profile(const float* p, const float* tr, int32_t L, int32_t index, float* out) {
+  if (!p || !tr || !out || L < 1) return fail(HHV_E_ARG, "hhv_pack_profile: bad argument");
+  if (index >= 0) pack_template(p, tr, L, index, out);
+  else pack_columns(p, tr, L, out);
+  return HHV_OK;
+}
+
+// src/util-inl.h:108-130: lg2[i] = log(float(1024+i))*1.442695041 - 10.0f with the float overload of
+// log (logf), diff[i-1] = (lg2[i]-prev)*1.2352E-4 -- bit-identical tables are part of the contract
+// (checked against the compiled reference in tests/test_oracle_vs_reference.py via the oracle).
+int hhv_fast_log2_tables(float* lg2, float* diff) {
+  if (!lg2 || !diff) return fail(HHV_E_ARG, "hhv_fast_log2_tables: null");
+  float prev = 0.0f;
+  lg2[0] = 0.0f;
+  diff[1024] = 0.0f;
+  for (int i = 1; i <= 1024; ++i) {
+    lg2[i] = (float)((double)logf((float)(1024 + i)) * 1.442695041 - (double)10.0f);
+    diff[i - 1] = (float)((double)(lg2[i] - prev) * 1.2352E-4);
+    prev = lg2[i];
+  }
+  return HHV_OK;
+}
+
+int hhv_create(hhv_ctx** out, const hhv_params* par) {
+  if (!out || !par) return fail(HHV_E_ARG, "hhv_create: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(HHV_E_DEVICE, "hhv_create: no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  if (par->device < 0 || par->device >= ndev) return fail(HHV_E_ARG, "hhv_create: device %d of %d", par->device, ndev);
+  HIP_TRY(hipSetDevice(par->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, par->device));
+  hhv_ctx* c = new (std::nothrow) hhv_ctx();
+  if (!c) return fail(HHV_E_MEMORY, "hhv_create: out of host memory");
+  c->par = *par;
+  c->num_cus = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    hhv_destroy(c);
+    return fail(HHV_E_DEVICE, "hhv_create: stream/event creation failed");
+  }
+  std::vector<float> lg2(1025), diff(1025);
+  hhv_fast_log2_tables(lg2.data(), diff.data());
+  if (hipMalloc(&c->d_lg2, 1025 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&c->d_diff, 1025 * sizeof(float)) != hipSuccess ||
+      hipMemcpy(c->d_lg2, lg2.data(), 1025 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->d_diff, diff.data(), 1025 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    hhv_destroy(c);
+    return fail(HHV_E_DEVICE, "hhv_create: table upload failed");
+  }
+  *out = c;
+  return HHV_OK;
+}
+
+void hhv_destroy(hhv_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->par.device);
+  dfree(c->d_qpack);
+  dfree(c->d_qp);
+  dfree(c->d_lg2);
+  dfree(c->d_diff);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
+  if (!c || !p || !tr) return fail(HHV_E_ARG, "hhv_set_query: null argument");
+  if (Lq < 1) return fail(HHV_E_ARG, "hhv_set_query: Lq = %d", Lq);
+  const int R = (Lq + LANES - 1) / LANES;
+  if (R > MAX_R)
+    return fail(HHV_E_LIMIT, "hhv_set_query: Lq = %d exceeds the single-pass limit of %d rows", Lq, MAX_R * LANES);
+  HIP_TRY(hipSetDevice(c->par.device));
+  std::vector<float> qpack((size_t)LANES * R * REC_DW, 0.0f);
+  pack_columns(p, tr, Lq, qpack.data());
+  dfree(c->d_qpack);
+  dfree(c->d_qp);
+  HIP_TRY(hipMalloc(&c->d_qpack, qpack.size() * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->d_qp, (size_t)(Lq + 1) * 20 * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(c->d_qpack, qpack.data(), qpack.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_qp, p, (size_t)(Lq + 1) * 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->Lq = Lq;
+  c->R = R;
+  return HHV_OK;
+}
+
+static int tset_init_common(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_t* L) {
+  ts->ctx = c;
+  ts->n = n;
+  ts->L.assign(L, L + n);
+  ts->rec_off.resize((size_t)n + 1);
+  int64_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1 || L[k] > 0xFFFF) return fail(HHV_E_ARG, "template %d: L = %d out of range [1, 65535]", k, L[k]);
+    ts->rec_off[k] = off;
+    off += (int64_t)L[k] + 1;
+  }
+  ts->rec_off[n] = off;
+  ts->n_records = off + 1;
+  HIP_TRY(hipMalloc(&ts->d_rec_off, (size_t)(n + 1) * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&ts->d_L, (size_t)n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&ts->d_results, (size_t)n * sizeof(DevResult)));
+  HIP_TRY(hipMemcpy(ts->d_rec_off, ts->rec_off.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ts->d_L, ts->L.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  return HHV_OK;
+}
+
+int hhv_upload_templates(hhv_ctx* c, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
+                         hhv_tset** out) {
+  if (!c || !L || !p || !tr || !out) return fail(HHV_E_ARG, "hhv_upload_templates: null argument");
+  if (n < 1) return fail(HHV_E_ARG, "hhv_upload_templates: n = %d", n);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_tset* ts = new (std::nothrow) hhv_tset();
+  if (!ts) return fail(HHV_E_MEMORY, "out of host memory");
+  int rc = tset_init_common(c, ts, n, L);
+  if (rc != HHV_OK) {
+    hhv_tset_free(ts);
+    return rc;
+  }
+  const size_t total = (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW;
+  if (hipMalloc(&ts->d_records, total * sizeof(float)) != hipSuccess) {
+    hhv_tset_free(ts);
+    return fail(HHV_E_MEMORY, "hhv_upload_templates: device allocation of %zu bytes failed", total * sizeof(float));
+  }
+  ts->owns_records = true;
+  // pack and upload in slabs of <= 64 MiB of pinned-size staging
+  const size_t slab_recs = (64u << 20) / (REC_DW * sizeof(float));
+  std::vector<float> stage;
+  int k = 0;
+  while (k < n) {
+    const int k0 = k;
+    size_t recs = 0;
+    while (k < n && (recs == 0 || recs + (size_t)L[k] + 1 <= slab_recs)) {
+      recs += (size_t)L[k] + 1;
+      ++k;
+    }
+    stage.resize(recs * REC_DW);
+    size_t o = 0;
+    for (int t = k0; t < k; ++t) {
+      if (!p[t] || !tr[t]) {
+        hhv_tset_free(ts);
+        return fail(HHV_E_ARG, "hhv_upload_templates: template %d has a null profile", t);
+      }
+      pack_template(p[t], tr[t], L[t], t, stage.data() + o);
+      o += ((size_t)L[t] + 1) * REC_DW;
+    }
+    if (hipMemcpy(ts->d_records + (size_t)ts->rec_off[k0] * REC_DW, stage.data(), stage.size() * sizeof(float),
+                  hipMemcpyHostToDevice) != hipSuccess) {
+      hhv_tset_free(ts);
+      return fail(HHV_E_DEVICE, "hhv_upload_templates: H2D copy failed");
+    }
+  }
+  // terminal header + zeroed slack
+  std::vector<float> tail((size_t)(1 + STREAM_PAD_RECS) * REC_DW, 0.0f);
+  write_header(tail.data(), -1, 0);
+  if (hipMemcpy(ts->d_records + (size_t)ts->rec_off[n] * REC_DW, tail.data(), tail.size() * sizeof(float),
+                hipMemcpyHostToDevice) != hipSuccess) {
+    hhv_tset_free(ts);
+    return fail(HHV_E_DEVICE, "hhv_upload_templates: H2D copy failed");
+  }
+  *out = ts;
+  return HHV_OK;
+}
+
+int hhv_adopt_device_stream(hhv_ctx* c, int32_t n, const int32_t* L, const void* d_records, hhv_tset** out) {
+  if (!c || !L || !d_records || !out) return fail(HHV_E_ARG, "hhv_adopt_device_stream: null argument");
+  if (n < 1) return fail(HHV_E_ARG, "hhv_adopt_device_stream: n = %d", n);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_tset* ts = new (std::nothrow) hhv_tset();
+  if (!ts) return fail(HHV_E_MEMORY, "out of host memory");
+  int rc = tset_init_common(c, ts, n, L);
+  if (rc != HHV_OK) {
+    hhv_tset_free(ts);
+    return rc;
+  }
+  ts->d_records = (float*)d_records;
+  ts->owns_records = false;
+  *out = ts;
+  return HHV_OK;
+}
+
+void hhv_tset_free(hhv_tset* ts) {
+  if (!ts) return;
+  if (ts->ctx) (void)hipSetDevice(ts->ctx->par.device);
+  if (ts->owns_records) dfree(ts->d_records);
+  dfree(ts->d_rec_off);
+  dfree(ts->d_L);
+  dfree(ts->d_results);
+  dfree(ts->d_wave_rec);
+  dfree(ts->d_bt);
+  dfree(ts->d_path_off);
+  dfree(ts->d_i_steps);
+  dfree(ts->d_j_steps);
+  dfree(ts->d_states);
+  dfree(ts->d_S);
+  dfree(ts->d_hits);
+  dfree(ts->d_topk);
+  dfree(ts->d_keys);
+  dfree(ts->d_sorted);
+  dfree(ts->d_sort_temp);
+  dfree(ts->d_raw_hits);
+  delete ts;
+}
+
+int32_t hhv_tset_size(const hhv_tset* ts) { return ts ? ts->n : 0; }
+int64_t hhv_tset_records(const hhv_tset* ts) { return ts ? ts->n_records : 0; }
+int64_t hhv_tset_cells(const hhv_tset* ts, int32_t Lq) {
+  if (!ts) return 0;
+  int64_t s = 0;
+  for (int32_t l : ts->L) s += (int64_t)Lq * l;
+  return s;
+}
+
+// Contiguous template ranges with ~equal record counts, one per wave.  All waves are resident at
+// once (n_waves = CUs x blocks/CU the variant's VGPR/LDS budget admits), so there is no tail.
+static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_waves) {
+  if (ts->n_waves == n_waves && ts->d_wave_rec) return HHV_OK;
+  dfree(ts->d_wave_rec);
+  std::vector<int64_t> wr((size_t)n_waves + 1);
+  const int64_t total = ts->rec_off[ts->n];
+  int k = 0;
+  for (int w = 0; w < n_waves; ++w) {
+    const int64_t target = (int64_t)(((__int128)total * w) / n_waves);
+    while (k < ts->n && ts->rec_off[k] < target) ++k;
+    wr[w] = ts->rec_off[k];
+  }
+  wr[n_waves] = total;
+  HIP_TRY(hipMalloc(&ts->d_wave_rec, wr.size() * sizeof(int64_t)));
+  HIP_TRY(hipMemcpyAsync(ts->d_wave_rec, wr.data(), wr.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  ts->n_waves = n_waves;
+  return HHV_OK;
+}
+
+static int ensure_bt(hhv_ctx* c, hhv_tset* ts) {
+  if (ts->d_bt && ts->bt_R == c->R) return HHV_OK;
+  dfree(ts->d_bt);
+  const size_t bytes = (size_t)ts->n_records * LANES * sizeof(uint64_t);
+  if (hipMalloc(&ts->d_bt, bytes) != hipSuccess)
+    return fail(HHV_E_MEMORY, "backtrace buffer of %zu bytes does not fit on the device", bytes);
+  HIP_TRY(hipMemsetAsync(ts->d_bt, 0, bytes, c->stream));
+  ts->bt_R = c->R;
+  ts->bt_valid = false;
+  return HHV_OK;
+}
+
+int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
+  if (!c || !ts) return fail(HHV_E_ARG, "hhv_align: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_align: template set belongs to another context");
+  if (c->Lq < 1) return fail(HHV_E_STATE, "hhv_align: no query set");
+  // Secondary-structure scoring: the reference runs the no-SS kernel whenever a batch carries no SS
+  // information (src/hhviterbi.cpp:175); profiles uploaded through this ABI carry none, so that is
+  // the kernel built here (the ...AndSS variants are SURVEY.md 8a row A5, not yet built).
+  HIP_TRY(hipSetDevice(c->par.device));
+  const bool celloff = (flags & HHV_ALIGN_CELLOFF) != 0;
+  const bool bt = celloff || (flags & HHV_ALIGN_BACKTRACE) != 0;
+  const bool local = c->par.local != 0;
+  int blocks_per_cu = 0, vgprs = 0;
+  int rc = stream_kernel_occupancy(c->R, local, bt, celloff, &blocks_per_cu, &vgprs);
+  if (rc != 0 || blocks_per_cu < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
+  const int n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu, ts->n));
+  rc = ensure_partition(c, ts, n_waves);
+  if (rc != HHV_OK) return rc;
+  if (bt) {
+    rc = ensure_bt(c, ts);
+    if (rc != HHV_OK) return rc;
+  }
+  StreamArgs a;
+  a.records = ts->d_records;
+  a.wave_rec = ts->d_wave_rec;
+  a.qpack = c->d_qpack;
+  a.results = d_out ? (DevResult*)d_out : ts->d_results;
+  a.bt = ts->d_bt;
+  a.egq = c->par.egq;
+  a.egt = c->par.egt;
+  a.shift = c->par.shift;
+  a.Lq = c->Lq;
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  rc = launch_stream(c->R, local, bt, celloff, a, n_waves, c->stream);
+  if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  c->ev_valid = true;
+  if (d_out) {
+    HIP_TRY(hipMemcpyAsync(ts->d_results, d_out, (size_t)ts->n * sizeof(DevResult), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (bt) {
+    ts->bt_valid = true;
+    ts->bt_Lq = c->Lq;
+  }
+  ts->hits_valid = false;
+  return HHV_OK;
+}
+
+int hhv_sync(hhv_ctx* c) {
+  if (!c) return fail(HHV_E_ARG, "hhv_sync: null");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HHV_OK;
+}
+
+void* hhv_stream(hhv_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int hhv_last_kernel_ms(hhv_ctx* c, float* ms) {
+  if (!c || !ms) return fail(HHV_E_ARG, "hhv_last_kernel_ms: null");
+  if (!c->ev_valid) return fail(HHV_E_STATE, "hhv_last_kernel_ms: no launch yet");
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return HHV_OK;
+}
+
+int hhv_align(hhv_ctx* c, hhv_tset* ts, uint32_t flags, hhv_result* out) {
+  int rc = hhv_align_async(c, ts, flags, nullptr);
+  if (rc != HHV_OK) return rc;
+  if (out) {
+    HIP_TRY(hipMemcpyAsync(out, ts->d_results, (size_t)ts->n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HHV_OK;
+}
+
+int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
+  if (!c || !ts) return fail(HHV_E_ARG, "hhv_set_celloff: null argument");
+  if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_set_celloff: template %d of %d", k, ts->n);
+  if (c->Lq < 1) return fail(HHV_E_STATE, "hhv_set_celloff: no query set");
+  HIP_TRY(hipSetDevice(c->par.device));
+  int rc = ensure_bt(c, ts);
+  if (rc != HHV_OK) return rc;
+  const int Lt = ts->L[k], Lq = c->Lq, R = c->R;
+  // entries of columns 1..Lt: [Lt][64] x 8 bytes; only bit 7 of each byte is an input of the kernel
+  std::vector<uint64_t> e((size_t)Lt * LANES, 0);
+  if (mask) {
+    for (int i = 1; i <= Lq; ++i) {
+      const int g = (i - 1) / R, r = (i - 1) % R;
+      const uint8_t* row = mask + (size_t)i * (Lt + 1);
+      for (int j = 1; j <= Lt; ++j)
+        if (row[j]) e[(size_t)(j - 1) * LANES + g] |= (uint64_t)0x80 << (8 * r);
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(ts->d_bt + (size_t)(ts->rec_off[k] + 1) * LANES, e.data(), e.size() * sizeof(uint64_t),
+                         hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  ts->bt_valid = false;
+  return HHV_OK;
+}
+
+int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
+  if (!c || !ts || !out) return fail(HHV_E_ARG, "hhv_backtrace_matrix: null argument");
+  if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_backtrace_matrix: template %d of %d", k, ts->n);
+  if (!ts->bt_valid || !ts->d_bt) return fail(HHV_E_STATE, "hhv_backtrace_matrix: no backtrace computed");
+  HIP_TRY(hipSetDevice(c->par.device));
+  const int Lt = ts->L[k], Lq = ts->bt_Lq, R = ts->bt_R;
+  std::vector<uint64_t> e((size_t)Lt * LANES);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(e.data(), ts->d_bt + (size_t)(ts->rec_off[k] + 1) * LANES, e.size() * sizeof(uint64_t),
+                    hipMemcpyDeviceToHost));
+  memset(out, 0, (size_t)(Lq + 1) * (Lt + 1));
+  for (int i = 1; i <= Lq; ++i) {
+    const int g = (i - 1) / R, r = (i - 1) % R;
+    uint8_t* row = out + (size_t)i * (Lt + 1);
+    for (int j = 1; j <= Lt; ++j) row[j] = (uint8_t)(e[(size_t)(j - 1) * LANES + g] >> (8 * r));
+  }
+  return HHV_OK;
+}
+
+static int ensure_paths(hhv_ctx* c, hhv_tset* ts) {
+  if (ts->path_Lq == c->Lq && ts->d_hits) return HHV_OK;
+  dfree(ts->d_path_off);
+  dfree(ts->d_i_steps);
+  dfree(ts->d_j_steps);
+  dfree(ts->d_states);
+  dfree(ts->d_S);
+  dfree(ts->d_hits);
+  ts->path_off.resize((size_t)ts->n + 1);
+  int64_t off = 0;
+  for (int k = 0; k < ts->n; ++k) {
+    ts->path_off[k] = off;
+    off += (int64_t)c->Lq + ts->L[k] + 2;  // BacktraceResult arrays: i2 + j2 + 2 entries (src/hhviterbi.cpp:90-93)
+  }
+  ts->path_off[ts->n] = off;
+  HIP_TRY(hipMalloc(&ts->d_path_off, ts->path_off.size() * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&ts->d_i_steps, (size_t)off * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&ts->d_j_steps, (size_t)off * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&ts->d_states, (size_t)off * sizeof(int8_t)));
+  HIP_TRY(hipMalloc(&ts->d_S, (size_t)off * sizeof(float)));
+  HIP_TRY(hipMalloc(&ts->d_hits, (size_t)ts->n * sizeof(DevHit)));
+  HIP_TRY(hipMemcpy(ts->d_path_off, ts->path_off.data(), ts->path_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  ts->path_Lq = c->Lq;
+  return HHV_OK;
+}
+
+static int run_trace(hhv_ctx* c, hhv_tset* ts) {
+  if (!ts->bt_valid || !ts->d_bt || ts->bt_Lq != c->Lq)
+    return fail(HHV_E_STATE, "hhv_hits: needs a preceding hhv_align with HHV_ALIGN_BACKTRACE for the current query");
+  int rc = ensure_paths(c, ts);
+  if (rc != HHV_OK) return rc;
+  TraceArgs a;
+  a.records = ts->d_records;
+  a.rec_off = ts->d_rec_off;
+  a.L = ts->d_L;
+  a.qp = c->d_qp;
+  a.results = ts->d_results;
+  a.bt = ts->d_bt;
+  a.lg2 = c->d_lg2;
+  a.diff = c->d_diff;
+  a.hits = ts->d_hits;
+  a.i_steps = ts->d_i_steps;
+  a.j_steps = ts->d_j_steps;
+  a.states = ts->d_states;
+  a.S = ts->d_S;
+  a.path_off = ts->d_path_off;
+  a.corr = c->par.corr;
+  a.ss_mode = c->par.ss_mode;
+  a.Lq = c->Lq;
+  a.R = ts->bt_R;
+  a.n = ts->n;
+  rc = launch_trace(a, c->stream);
+  if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  ts->hits_valid = true;
+  return HHV_OK;
+}
+
+int hhv_hits(hhv_ctx* c, hhv_tset* ts, hhv_hit* hits) {
+  if (!c || !ts) return fail(HHV_E_ARG, "hhv_hits: null argument");
+  HIP_TRY(hipSetDevice(c->par.device));
+  int rc = run_trace(c, ts);
+  if (rc != HHV_OK) return rc;
+  if (hits) HIP_TRY(hipMemcpyAsync(hits, ts->d_hits, (size_t)ts->n * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HHV_OK;
+}
+
+int hhv_hit_path(hhv_ctx* c, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps, int8_t* states,
+                 float* S, int32_t* nsteps) {
+  if (!c || !ts || !nsteps) return fail(HHV_E_ARG, "hhv_hit_path: null argument");
+  if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_hit_path: template %d of %d", k, ts->n);
+  if (!ts->hits_valid) return fail(HHV_E_STATE, "hhv_hit_path: call hhv_hits first");
+  HIP_TRY(hipSetDevice(c->par.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  DevHit h;
+  HIP_TRY(hipMemcpy(&h, ts->d_hits + k, sizeof(h), hipMemcpyDeviceToHost));
+  *nsteps = h.nsteps;
+  const int m = std::min(cap, h.nsteps + 1);
+  if (m <= 0) return HHV_OK;
+  const int64_t po = ts->path_off[k];
+  if (i_steps) HIP_TRY(hipMemcpy(i_steps, ts->d_i_steps + po, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (j_steps) HIP_TRY(hipMemcpy(j_steps, ts->d_j_steps + po, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (states) HIP_TRY(hipMemcpy(states, ts->d_states + po, (size_t)m * sizeof(int8_t), hipMemcpyDeviceToHost));
+  if (S) HIP_TRY(hipMemcpy(S, ts->d_S + po, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+  if (i_steps) i_steps[0] = 0;
+  if (j_steps) j_steps[0] = 0;
+  if (states) states[0] = 0;
+  if (S) S[0] = 0.0f;
+  return HHV_OK;
+}
+
+int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, void* d_out, int32_t* n_out) {
+  if (!c || !ts) return fail(HHV_E_ARG, "hhv_topk: null argument");
+  if (k < 1) return fail(HHV_E_ARG, "hhv_topk: k = %d", k);
+  const bool raw = (flags & HHV_TOPK_RAW) != 0;
+  if (!raw && !ts->hits_valid) return fail(HHV_E_STATE, "hhv_topk: call hhv_hits first (or pass HHV_TOPK_RAW)");
+  HIP_TRY(hipSetDevice(c->par.device));
+  const int kk = std::min(k, ts->n);
+  if (ts->topk_cap < k) {
+    dfree(ts->d_topk);
+    HIP_TRY(hipMalloc(&ts->d_topk, (size_t)k * sizeof(DevHit)));
+    ts->topk_cap = k;
+  }
+  if (!ts->d_keys) {
+    HIP_TRY(hipMalloc(&ts->d_keys, (size_t)ts->n * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&ts->d_sorted, (size_t)ts->n * sizeof(uint64_t)));
+    ts->sort_temp_bytes = topk_temp_bytes(ts->n);
+    HIP_TRY(hipMalloc(&ts->d_sort_temp, ts->sort_temp_bytes));
+  }
+  const DevHit* src = ts->d_hits;
+  if (raw) {
+    if (!ts->d_raw_hits) HIP_TRY(hipMalloc(&ts->d_raw_hits, (size_t)ts->n * sizeof(DevHit)));
+    results_to_hits(ts->d_results, ts->n, ts->d_raw_hits, c->stream);
+    src = ts->d_raw_hits;
+  }
+  DevHit* dst = d_out ? (DevHit*)d_out : ts->d_topk;
+  std::string err;
+  if (topk_device(src, ts->n, kk, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
+                  &err) != 0)
+    return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
+  if (kk < k) HIP_TRY(hipMemsetAsync(dst + kk, 0xFF, (size_t)(k - kk) * sizeof(DevHit), c->stream));
+  if (out) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_out) *n_out = kk;
+  return HHV_OK;
+}
+
+}  // extern "C"

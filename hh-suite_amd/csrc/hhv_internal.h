@@ -1,0 +1,65 @@
+// hhv_internal.h -- structures shared between the HIP kernels and the C-ABI host layer.
+#pragma once
+#include <stdint.h>
+
+namespace hhv {
+
+constexpr int LANES = 64;          // wavefront width on gfx950
+constexpr int MAX_R = 8;           // query rows per lane -> single pass handles Lq <= 512
+constexpr int CHUNK_RECS = 64;     // records per LDS refill (7 x 1 KiB global_load_lds_dwordx4)
+constexpr int RING_CHUNKS = 3;     // live window spans <= 2 chunks, the third is in flight
+constexpr int RING_RECS = CHUNK_RECS * RING_CHUNKS;
+constexpr int STREAM_PAD_RECS = 256;  // slack after the terminal header (chunk over-read)
+constexpr int BT_ENTRY_BYTES = 8;  // one backtrace entry = the R (<= 8) bytes of one lane at one column
+
+struct DevResult {  // matches hhv_result
+  float score;
+  int32_t i2, j2;
+  int32_t index;
+};
+
+struct DevHit {  // matches hhv_hit
+  float score;
+  float viterbi_score;
+  int32_t index;
+  int32_t i1, j1, i2, j2;
+  int32_t nsteps;
+  int32_t matched_cols;
+};
+
+struct StreamArgs {
+  const float* records;      // [n_records + pad][28]
+  const int64_t* wave_rec;   // [n_waves + 1] first record of each wave's template range
+  const float* qpack;        // [64*R][28]
+  DevResult* results;        // [n_templates]
+  uint64_t* bt;              // [n_records][64] backtrace entries (BT / CELLOFF variants)
+  float egq, egt, shift;
+  int32_t Lq;
+};
+
+struct TraceArgs {
+  const float* records;
+  const int64_t* rec_off;    // [n+1] header record of template k
+  const int32_t* L;          // [n]
+  const float* qp;           // query profile AoS [(Lq+1)][20]
+  const DevResult* results;
+  const uint64_t* bt;
+  const float* lg2;          // fast_log2 tables (util-inl.h:108-130): lg2[1025], diff[1025]
+  const float* diff;
+  DevHit* hits;
+  int32_t* i_steps;          // [path_off[k] .. ) per template, capacity Lq + L[k] + 2
+  int32_t* j_steps;
+  int8_t* states;
+  float* S;
+  const int64_t* path_off;   // [n+1]
+  float corr;
+  int32_t ss_mode;
+  int32_t Lq, R, n;
+};
+
+// launchers implemented in hhv_kernels.hip
+int launch_stream(int R, bool local, bool bt, bool celloff, const StreamArgs& a, int n_waves, void* stream);
+int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, int* blocks_per_cu, int* vgprs);
+int launch_trace(const TraceArgs& a, void* stream);
+
+}  // namespace hhv

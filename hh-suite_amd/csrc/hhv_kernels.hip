@@ -1,0 +1,320 @@
+// hhv_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4).  No MFMA: the hot path is
+// a max-plus recurrence plus a 20-term fp32 dot product whose rounding order is part of the contract.
+//
+// Kernel 1  hhv_stream_kernel<R, LOCAL, BT, CELLOFF>   the Viterbi DP (replaces Viterbi::Align,
+//           src/hhviterbialgorithm.cpp:29-497): one 64-lane wavefront = one systolic array, see
+//           viterbi_lane.h.  The wave's template stream is staged through a 21 KiB LDS ring with
+//           global_load_lds_dwordx4 (HBM -> LDS without touching VGPRs), lanes read their record
+//           with 7 conflict-free ds_read_b128 (28-dword stride = 16 distinct 4-bank slots), the
+//           lane-to-lane hand-off is 7 v_mov_b32_dpp wave_shr:1 per step.
+// Kernel 2  hhv_trace_kernel   Viterbi::Backtrace + Viterbi::ScoreForBacktrace
+//           (src/hhviterbi.cpp:83-160,195-281), one lane per template (pointer chase, O(Lq+Lt)).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (fp contraction would change results).
+#include <hip/hip_runtime.h>
+
+#include "hhv_internal.h"
+#include "viterbi_lane.h"
+
+namespace hhv {
+
+__device__ __forceinline__ float dpp_shr1(float old, float src) {
+  // v_mov_b32_dpp wave_shr:1 : lane n <- lane n-1, lane 0 keeps `old`
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xF, 0xF,
+                                         false));
+}
+__device__ __forceinline__ int dpp_shr1(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, false);
+}
+
+// one 64-record chunk: 7 wave-wide 16-byte-per-lane loads straight into LDS
+__device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int chunk, float4* ring, int lane) {
+  const float4* g = src + (size_t)chunk * (CHUNK_RECS * 7) + lane;
+  float4* l = ring + (chunk % RING_CHUNKS) * (CHUNK_RECS * 7);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * LANES),
+                                     (__attribute__((address_space(3))) void*)(l + k * LANES), 16, 0, 0);
+  }
+}
+
+template <int R, bool LOCAL, bool BT, bool CELLOFF>
+__global__ void __launch_bounds__(LANES) hhv_stream_kernel(StreamArgs a) {
+  __shared__ float4 ring[RING_RECS * 7];
+  const int lane = threadIdx.x;
+  const int64_t rb = a.wave_rec[blockIdx.x];
+  const int64_t re = a.wave_rec[blockIdx.x + 1];
+  if (re <= rb) return;
+  const int M = (int)(re - rb) + 1;  // the range's records plus the next header (finalizes the last template)
+
+  Params P;
+  P.egq = a.egq;
+  P.egt = a.egt;
+  P.shift = a.shift;
+  P.Lq = a.Lq;
+  const int i0 = lane * R + 1;
+  const int g_last = (a.Lq - 1) / R;
+  const int r_last = (a.Lq - 1) % R;
+
+  const float4* src = (const float4*)a.records + rb * 7;
+  const int nchunks = (M + CHUNK_RECS - 1) / CHUNK_RECS;
+  load_chunk(src, 0, ring, lane);
+  load_chunk(src, 1, ring, lane);  // the stream is padded: over-reading past M is harmless
+
+  QRows<R> q;
+  q.load(a.qpack + (size_t)lane * R * REC_DW);
+  LaneState<R> st;
+  st.reset();
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int slot = (lane == 0) ? 0 : RING_RECS - lane;  // ring slot of record s - lane
+  for (int s = 0; s < M + LANES - 1; ++s) {
+    if ((s & (CHUNK_RECS - 1)) == 0 && s > 0) {
+      // chunk c = s/64 was issued 64 steps ago: make sure it has landed, then refill the slot that
+      // held chunk c-2 (its last reader, lane 63, finished at step 64c-2) with chunk c+1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int c = s / CHUNK_RECS;
+      if (c + 1 < nchunks) load_chunk(src, c + 1, ring, lane);
+    }
+    const int r = s - lane;
+    const bool active = (r >= 0) && (r < M);
+
+    float rec[REC_DW];
+    {
+      const float4* p = ring + slot * 7;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float4 v = p[k];
+        rec[4 * k + 0] = v.x;
+        rec[4 * k + 1] = v.y;
+        rec[4 * k + 2] = v.z;
+        rec[4 * k + 3] = v.w;
+      }
+    }
+    const int32_t meta = __builtin_bit_cast(int32_t, rec[REC_META]);
+
+    // hand-off from lane g-1 (full EXEC here); lane 0 takes the DP boundary row 0
+    const Incoming bnd = boundary_incoming(meta, P);
+    Incoming in;
+    in.MM = dpp_shr1(bnd.MM, st.MM[R - 1]);
+    in.GD = dpp_shr1(bnd.GD, st.GD[R - 1]);
+    in.IM = dpp_shr1(bnd.IM, st.IM[R - 1]);
+    in.DG = dpp_shr1(bnd.DG, st.DG[R - 1]);
+    in.MI = dpp_shr1(bnd.MI, st.MI[R - 1]);
+    in.fs = dpp_shr1(bnd.fs, st.fs);
+    in.fpos = dpp_shr1(bnd.fpos, st.fpos);
+
+    if (active) {
+      if (meta < 0) {
+        TemplateResult res;
+        const int new_tid = __builtin_bit_cast(int32_t, rec[0]);
+        if (lane_header<R, LOCAL>(st, in, i0, new_tid, P, lane == g_last, res)) {
+          DevResult o;
+          o.score = res.score;
+          o.i2 = res.i2;
+          o.j2 = res.j2;
+          o.index = res.tid;
+          a.results[res.tid] = o;
+        }
+      } else {
+        const int j = meta & META_JMASK;
+        uint64_t cell = 0;
+        uint64_t* bte = nullptr;
+        if (BT || CELLOFF) bte = a.bt + ((size_t)(rb + r) * LANES + lane);
+        if (CELLOFF) cell = *bte;
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF>(st, q, in, rec, j, i0, r_last, P, cell);
+        if (BT) *bte = bytes;
+      }
+    }
+    slot = (slot + 1 == RING_RECS) ? 0 : slot + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backtrace + rescoring, one lane per template.
+
+// src/util-inl.h:108-130 (tables built on the host exactly like the reference builds them)
+__device__ __forceinline__ float fast_log2_dev(float x, const float* __restrict__ lg2, const float* __restrict__ diff) {
+  if (x <= 0) return -100000;
+  const uint32_t u = f2bits(x);
+  const int aa = (int)((u & 0x7F800000u) >> 23) - 0x7f;
+  const int b = (int)((u & 0x007FE000u) >> 13);
+  const int c = (int)(u & 0x00001FFFu);
+  return ((float)aa + lg2[b]) + diff[b] * (float)c;
+}
+
+// src/hhhit-inl.h:125-131: plain left-to-right sum (the SSE branch above it is never compiled)
+__device__ __forceinline__ float dot20_scalar_dev(const float* __restrict__ q, const float* __restrict__ t) {
+  float r = t[0] * q[0];
+#pragma unroll
+  for (int k = 1; k < 20; ++k) r = r + t[k] * q[k];
+  return r;
+}
+
+__global__ void __launch_bounds__(256) hhv_trace_kernel(TraceArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.n) return;
+  const DevResult res = a.results[k];
+  const int64_t rec0 = a.rec_off[k];
+  const int R = a.R;
+  const int64_t po = a.path_off[k];
+  int32_t* i_steps = a.i_steps + po;
+  int32_t* j_steps = a.j_steps + po;
+  int8_t* states = a.states + po;
+  float* S = a.S + po;
+
+  // --- Viterbi::Backtrace, src/hhviterbi.cpp:83-160
+  int step = 0, matched = 0;
+  int i = res.i2, j = res.j2;
+  int state = 2;  // MM
+  while (state != 0) {
+    step++;
+    states[step] = (int8_t)state;
+    i_steps[step] = i;
+    j_steps[step] = j;
+    uint32_t b = 0;
+    if (i >= 1 && j >= 1) {
+      const int g = (i - 1) / R, rr = (i - 1) - g * R;
+      b = (uint32_t)(a.bt[(size_t)(rec0 + j) * LANES + g] >> (8 * rr)) & 0xFFu;
+    }
+    switch (state) {
+      case 2:  // MM
+        matched++;
+        if (i <= 1 || j <= 1) state = 0;
+        else {
+          state = b & 7;
+          i--;
+          j--;
+        }
+        break;
+      case 3:  // GD
+        if (j <= 1) state = 0;
+        else {
+          if (b & 8) state = 2;
+          j--;
+        }
+        break;
+      case 4:  // IM
+        if (j <= 1) state = 0;
+        else {
+          if (b & 16) state = 2;
+          j--;
+        }
+        break;
+      case 5:  // DG
+        if (i <= 1) state = 0;
+        else {
+          if (b & 32) state = 2;
+          i--;
+        }
+        break;
+      case 6:  // MI
+        if (i <= 1) state = 0;
+        else {
+          if (b & 64) state = 2;
+          i--;
+        }
+        break;
+      default:  // :139-144
+        state = 0;
+        break;
+    }
+  }
+  states[step] = 2;  // :147
+  const int nsteps = step;
+
+  // --- Viterbi::ScoreForBacktrace, src/hhviterbi.cpp:195-281 (no secondary-structure term: score_ss = 0)
+  float score = res.score;
+  for (int s = 1; s <= nsteps; ++s) {
+    if (states[s] == 2) {
+      const float* qp = a.qp + (size_t)i_steps[s] * 20;
+      const float* tp = a.records + (size_t)(rec0 + j_steps[s]) * REC_DW;
+      S[s] = fast_log2_dev(dot20_scalar_dev(qp, tp), a.lg2, a.diff);
+    } else {
+      S[s] = 0.0f;
+    }
+  }
+  if (a.ss_mode == 2) score -= 0.0f;
+  float Scorr = 0;
+  for (int s = 2; s <= nsteps; ++s) Scorr += S[s] * S[s - 1];
+  for (int s = 3; s <= nsteps; ++s) Scorr += S[s] * S[s - 2];
+  for (int s = 4; s <= nsteps; ++s) Scorr += S[s] * S[s - 3];
+  for (int s = 5; s <= nsteps; ++s) Scorr += S[s] * S[s - 4];
+  score += a.corr * Scorr;
+
+  DevHit h;
+  h.score = score;
+  h.viterbi_score = res.score;
+  h.index = k;
+  h.i1 = i_steps[nsteps];
+  h.j1 = j_steps[nsteps];
+  h.i2 = res.i2;
+  h.j2 = res.j2;
+  h.nsteps = nsteps;
+  h.matched_cols = matched;
+  a.hits[k] = h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch helpers
+
+template <int R, bool LOCAL, bool BT, bool CELLOFF>
+static void* kernel_ptr() {
+  return (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF>;
+}
+
+template <int R>
+static void* pick_variant(bool local, bool bt, bool celloff) {
+  if (celloff) return local ? kernel_ptr<R, true, true, true>() : kernel_ptr<R, false, true, true>();
+  if (bt) return local ? kernel_ptr<R, true, true, false>() : kernel_ptr<R, false, true, false>();
+  return local ? kernel_ptr<R, true, false, false>() : kernel_ptr<R, false, false, false>();
+}
+
+static void* pick(int R, bool local, bool bt, bool celloff) {
+  switch (R) {
+    case 1: return pick_variant<1>(local, bt, celloff);
+    case 2: return pick_variant<2>(local, bt, celloff);
+    case 3: return pick_variant<3>(local, bt, celloff);
+    case 4: return pick_variant<4>(local, bt, celloff);
+    case 5: return pick_variant<5>(local, bt, celloff);
+    case 6: return pick_variant<6>(local, bt, celloff);
+    case 7: return pick_variant<7>(local, bt, celloff);
+    case 8: return pick_variant<8>(local, bt, celloff);
+  }
+  return nullptr;
+}
+
+int launch_stream(int R, bool local, bool bt, bool celloff, const StreamArgs& a, int n_waves, void* stream) {
+  void* fn = pick(R, local, bt, celloff);
+  if (!fn) return -1;
+  StreamArgs args = a;
+  void* kargs[] = {&args};
+  hipError_t e = hipLaunchKernel(fn, dim3(n_waves), dim3(LANES), kargs, 0, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, int* blocks_per_cu, int* vgprs) {
+  void* fn = pick(R, local, bt, celloff);
+  if (!fn) return -1;
+  int nb = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, LANES, 0);
+  if (e != hipSuccess) return -(int)e;
+  hipFuncAttributes fa;
+  e = hipFuncGetAttributes(&fa, fn);
+  if (e != hipSuccess) return -(int)e;
+  if (blocks_per_cu) *blocks_per_cu = nb;
+  if (vgprs) *vgprs = fa.numRegs;
+  return 0;
+}
+
+int launch_trace(const TraceArgs& a, void* stream) {
+  const int threads = 256;
+  const int blocks = (a.n + threads - 1) / threads;
+  hipLaunchKernelGGL(hhv_trace_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace hhv

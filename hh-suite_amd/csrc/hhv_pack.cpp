@@ -1,0 +1,54 @@
+// hhv_pack.cpp -- host side of the device data layout: prepared profiles (the arrays the
+// reference keeps in HMM::p / HMM::tr, /root/reference src/hhhmm.h:143-150) -> 28-dword column
+// records.  Replaces the AoS -> lane-interleaved SoA mapping of HMMSimd::MapHMMVector
+// (src/hhhmmsimd.cpp:86-160): the same seven transition slots a DP cell touches
+// (src/hhviterbialgorithm.cpp:222-228: slots 2..6 of column j-1, slots 0..1 of column j) are
+// stored next to the 20 profile values of column j, so one cell operand set is one 112-byte record.
+#include "hhv_pack.h"
+
+#include <string.h>
+
+#include "viterbi_lane.h"
+
+namespace hhv {
+
+// reference enum order of tr[][7], src/hhdecl.h:68
+enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };
+
+void pack_columns(const float* p, const float* tr, int L, float* out) {
+  for (int k = 1; k <= L; ++k) {
+    float* w = out + (size_t)(k - 1) * REC_DW;
+    memcpy(w, p + (size_t)k * 20, 20 * sizeof(float));
+    const float* a = tr + (size_t)(k - 1) * 7;
+    const float* b = tr + (size_t)k * 7;
+    w[REC_M2M] = a[T_M2M];
+    w[REC_M2D] = a[T_M2D];
+    w[REC_D2M] = a[T_D2M];
+    w[REC_D2D] = a[T_D2D];
+    w[REC_I2M] = a[T_I2M];
+    w[REC_I2I] = b[T_I2I];
+    w[REC_M2I] = b[T_M2I];
+    w[REC_META] = 0.0f;
+  }
+}
+
+static inline void put_i32(float* dst, int32_t v) { memcpy(dst, &v, 4); }
+
+void write_header(float* rec, int32_t index, int32_t L) {
+  memset(rec, 0, REC_DW * sizeof(float));
+  put_i32(rec + 0, index);
+  put_i32(rec + 1, L);
+  put_i32(rec + REC_META, META_HDR);
+}
+
+void pack_template(const float* p, const float* tr, int L, int32_t index, float* out) {
+  write_header(out, index, L);
+  pack_columns(p, tr, L, out + REC_DW);
+  for (int j = 1; j <= L; ++j) {
+    int32_t meta = j;
+    if (j == L) meta |= META_LAST;
+    put_i32(out + (size_t)j * REC_DW + REC_META, meta);
+  }
+}
+
+}  // namespace hhv

@@ -1,0 +1,15 @@
+// hhv_pack.h -- host packer of the 28-dword column records (see hhv_pack.cpp, viterbi_lane.h).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace hhv {
+
+// columns 1..L of an HMM given as p[(L+1)*20], tr[(L+1)*7] -> out[L*28] (meta = 0)
+void pack_columns(const float* p, const float* tr, int L, float* out);
+// header record of a template (index, L); index -1 = terminal header
+void write_header(float* rec, int32_t index, int32_t L);
+// header + L column records with meta (j, LAST flag) -> out[(L+1)*28]
+void pack_template(const float* p, const float* tr, int L, int32_t index, float* out);
+
+}  // namespace hhv

@@ -1,0 +1,347 @@
+// viterbi_lane.h -- per-lane arithmetic of the systolic Viterbi engine.
+//
+// Design: one wavefront is a 64-stage systolic array.  Lane g owns the R
+// consecutive QUERY rows i = g*R+1 .. g*R+R (profile columns and transitions of those rows live in
+// the lane's VGPRs for the whole kernel) and the wave streams template columns through the lanes:
+// at step s lane g processes stream record r = s - g.  A record is either a template header
+// (column 0: finalize the previous template, initialise the DP boundary) or one template column j.
+// The only cross-lane traffic per step is the bottom-row state of lane g-1 (5 floats + the running
+// best), fetched with a DPP wave_shr:1; everything else is lane local.
+//
+// The arithmetic restates, operation for operation and in the same association, the reference's
+//   Viterbi::AlignWithOutCellOff / AlignWithCellOff  src/hhviterbialgorithm.cpp:144-494
+//   Viterbi::ScalarProd20Vec                          src/hhviterbi.h:126-161
+//   log2f4 (LOG_POLY_DEGREE 4)                        src/hhutil-inl.h:501-541
+// Must be compiled with -ffp-contract=off (the reference build has no FMA).
+//
+// This header is compiled by hipcc into the product kernel and by g++ into tests/emul (a host-side
+// lock-step emulation of one wavefront used to debug the schedule without a GPU; test code only).
+#pragma once
+#include <float.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HHV_DEV __device__ __forceinline__
+#define HHV_MEM __device__ __forceinline__
+#else
+#define HHV_DEV static inline
+#define HHV_MEM inline
+#endif
+
+namespace hhv {
+
+// ---- packed column record (28 dwords = 112 B), same layout for query rows and template columns ----
+//  [0..19] p[k][a]                          profile column k
+//  [20..24] tr[k-1][M2M,M2D,D2M,D2D,I2M]    transitions leaving column k-1
+//  [25..26] tr[k][I2I,M2I]                  insert transitions of column k
+//  [27]     meta (template stream only)
+// This is the operand set of one DP cell: src/hhviterbialgorithm.cpp:182-188 (query side) and
+// :222-228 (template side) read exactly slots 2..6 of column k-1 and slots 0..1 of column k.
+constexpr int REC_DW = 28;
+constexpr int REC_M2M = 20, REC_M2D = 21, REC_D2M = 22, REC_D2D = 23, REC_I2M = 24, REC_I2I = 25, REC_M2I = 26,
+              REC_META = 27;
+constexpr int32_t META_HDR = (int32_t)0x80000000;  // header record: [0] = template index, [1] = Lt
+constexpr int32_t META_LAST = 0x40000000;          // column record of j == Lt
+constexpr int32_t META_JMASK = 0x00FFFFFF;
+
+constexpr float NEG_MAX = -FLT_MAX;
+
+HHV_DEV float bits2f(uint32_t u) {
+  union { uint32_t u; float f; } x;
+  x.u = u;
+  return x.f;
+}
+HHV_DEV uint32_t f2bits(float f) {
+  union { uint32_t u; float f; } x;
+  x.f = f;
+  return x.u;
+}
+HHV_DEV float fmax2(float a, float b) {
+#if defined(__HIPCC__)
+  return __builtin_fmaxf(a, b);  // v_max_f32 / v_max3_f32; no NaNs occur on this path
+#else
+  return a > b ? a : b;
+#endif
+}
+
+// src/hhutil-inl.h:509-541, one rounding per operation
+HHV_DEV float log2f4(float x) {
+  const uint32_t i = f2bits(x);
+  const float e = (float)((int32_t)((i & 0x7F800000u) >> 23) - 127);
+  const float m = bits2f((i & 0x007FFFFFu) | 0x3F800000u);
+  float p = -0.107254423828329604454f * m;
+  p = p + 0.688243882994381274313f;
+  p = p * m;
+  p = p + -1.75647175389045657003f;
+  p = p * m;
+  p = p + 2.61761038894603480148f;
+  p = p * (m - 1.0f);
+  return p + e;
+}
+
+// src/hhviterbi.h:126-161: four partial accumulators, (r0+r1)+(r2+r3)
+HHV_DEV float dot20(const float* q, const float* t) {
+  float r0 = t[0] * q[0];
+  float r1 = t[1] * q[1];
+  float r2 = t[2] * q[2];
+  float r3 = t[3] * q[3];
+#pragma unroll
+  for (int k = 4; k < 20; k += 4) {
+    r0 = t[k + 0] * q[k + 0] + r0;
+    r1 = t[k + 1] * q[k + 1] + r1;
+    r2 = t[k + 2] * q[k + 2] + r2;
+    r3 = t[k + 3] * q[k + 3] + r3;
+  }
+  r0 = r0 + r1;
+  r2 = r2 + r3;
+  return r0 + r2;
+}
+
+struct Params {
+  float egq, egt, shift;
+  int Lq;
+};
+
+// query rows owned by one lane (row i = i0 + r)
+template <int R>
+struct QRows {
+  float p[R][20];
+  float m2m[R], m2d[R], d2m[R], d2d[R], i2m[R];  // of row i-1
+  float i2i[R], m2i[R];                          // of row i
+  HHV_MEM void load(const float* rows /* R consecutive 28-dword records */) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float* w = rows + r * REC_DW;
+#pragma unroll
+      for (int a = 0; a < 20; ++a) p[r][a] = w[a];
+      m2m[r] = w[REC_M2M];
+      m2d[r] = w[REC_M2D];
+      d2m[r] = w[REC_D2M];
+      d2d[r] = w[REC_D2D];
+      i2m[r] = w[REC_I2M];
+      i2i[r] = w[REC_I2I];
+      m2i[r] = w[REC_M2I];
+    }
+  }
+};
+
+// what lane g reads from lane g-1 at the top of every step (lane 0: the DP boundary row 0)
+struct Incoming {
+  float MM, GD, IM, DG, MI;  // state of row i0-1 at the column lane g-1 has just finished
+  float fs;                  // finalized best of lanes < g (valid on header steps)
+  int fpos;                  // (i2 << 16) | j2
+};
+
+template <int R>
+struct LaneState {
+  float MM[R], GD[R], IM[R], DG[R], MI[R];  // own rows, column j-1 (the previous step)
+  float dMM, dGD, dIM, dDG, dMI;            // row i0-1, column j-1 (top-row diagonal)
+  float bs[R];                              // running best per row ...
+  int bj[R];                                // ... and its column (local mode: every row; global: row Lq only, slot 0)
+  float fs;                                 // finalized best over lanes <= g for the template just finished
+  int fpos;
+  int tid;   // template index of the template being processed (-1 before the first header)
+  int jlast; // column index of the last processed column record
+  HHV_MEM void reset() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      MM[r] = GD[r] = IM[r] = DG[r] = MI[r] = NEG_MAX;
+      bs[r] = NEG_MAX;
+      bj[r] = 0;
+    }
+    dMM = dGD = dIM = dDG = dMI = NEG_MAX;
+    fs = NEG_MAX;
+    fpos = 0;
+    tid = -1;
+    jlast = 0;
+  }
+};
+
+// boundary row 0 as seen by lane 0 (src/hhviterbialgorithm.cpp:144-153,161): MM(0,j) = -j*egt, the rest
+// -FLT_MAX.  On a header step the value becomes the diagonal of cell (1,1), which the reference
+// initialises as -(i-1)*egq = -0*egq (:161).
+HHV_DEV Incoming boundary_incoming(int32_t meta, const Params& P) {
+  Incoming in;
+  if (meta < 0) in.MM = (float)(-0) * P.egq;
+  else in.MM = (float)(-(meta & META_JMASK)) * P.egt;
+  in.GD = in.IM = in.DG = in.MI = NEG_MAX;
+  in.fs = NEG_MAX;
+  in.fpos = 0;
+  return in;
+}
+
+struct TemplateResult {
+  float score;
+  int i2, j2;
+  int tid;
+};
+
+// Header record: finish the previous template (combine this lane's best with the prefix best that
+// flows down the lanes; the lane owning row Lq emits the result) and set the column-0 boundary
+// (:161-173: MM(i,0) = -i*egq, other states -FLT_MAX).  Returns true if `res` must be written.
+template <int R, bool LOCAL>
+HHV_DEV bool lane_header(LaneState<R>& st, const Incoming& in, int i0, int new_tid, const Params& P, bool is_last_lane,
+                         TemplateResult& res) {
+  bool emit = false;
+  if (st.tid >= 0) {
+    // best over own rows in row order, strict '>' (ties keep the smaller row, then the smaller column:
+    // the reference's row-major scan with strict '>' at :423-455,462-486)
+    float s = NEG_MAX;
+    int pos = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 + r;
+      float cs;
+      int cj;
+      if (LOCAL) {
+        cs = st.bs[r];
+        cj = st.bj[r];
+      } else {
+        // global: rows < Lq contribute their last-column cell (still held in MM[r]); row Lq its best column
+        if (i == P.Lq) {
+          cs = st.bs[0];
+          cj = st.bj[0];
+        } else {
+          cs = st.MM[r];
+          cj = st.jlast;
+        }
+      }
+      const bool take = (i <= P.Lq) && (cs > s);
+      s = take ? cs : s;
+      pos = take ? ((i << 16) | cj) : pos;
+    }
+    // rows of lanes < g come first in scan order: keep theirs unless strictly beaten
+    const bool own = s > in.fs;
+    st.fs = own ? s : in.fs;
+    st.fpos = own ? pos : in.fpos;
+    if (is_last_lane) {
+      res.score = st.fs;
+      res.i2 = st.fpos >> 16;
+      res.j2 = st.fpos & 0xFFFF;
+      res.tid = st.tid;
+      emit = true;
+    }
+  }
+  st.tid = new_tid;
+  st.jlast = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    st.MM[r] = (float)(-(i0 + r)) * P.egq;
+    st.GD[r] = st.IM[r] = st.DG[r] = st.MI[r] = NEG_MAX;
+    st.bs[r] = NEG_MAX;
+    st.bj[r] = 0;
+  }
+  st.dMM = in.MM;
+  st.dGD = in.GD;
+  st.dIM = in.IM;
+  st.dDG = in.DG;
+  st.dMI = in.MI;
+  return emit;
+}
+
+// One template column j for the R rows of this lane.
+//   rec      : the 28-dword column record
+//   cellbits : CELLOFF only - byte r bit 7 set = cell (i0+r, j) excluded (same byte matrix the
+//              backtrace is written to, src/hhviterbialgorithm.cpp:373-392)
+//   returns  : BT only - byte r = backtrace byte of cell (i0+r, j) (bit layout src/hhviterbimatrix.h:35-48)
+template <int R, bool LOCAL, bool BT, bool CELLOFF>
+HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const float* rec, int j, int i0,
+                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits) {
+  const float smin = LOCAL ? 0.0f : NEG_MAX;
+  const float tM2M = rec[REC_M2M], tM2D = rec[REC_M2D], tD2M = rec[REC_D2M], tD2D = rec[REC_D2D],
+              tI2M = rec[REC_I2M], tI2I = rec[REC_I2I], tM2I = rec[REC_M2I];
+  float dMM = st.dMM, dGD = st.dGD, dIM = st.dIM, dDG = st.dDG, dMI = st.dMI;  // (i-1, j-1)
+  float uMM = in.MM, uDG = in.DG, uMI = in.MI;                                 // (i-1, j)
+  uint64_t bytes = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float lMM = st.MM[r], lGD = st.GD[r], lIM = st.IM[r], oDG = st.DG[r], oMI = st.MI[r];  // (i, j-1)
+    // :241-273
+    const float c1 = (dMM + q.m2m[r]) + tM2M;
+    const float c2 = (dGD + q.m2m[r]) + tD2M;
+    const float c3 = (dIM + q.i2m[r]) + tM2M;
+    const float c4 = (dDG + q.d2m[r]) + tM2M;
+    const float c5 = (dMI + q.m2m[r]) + tI2M;
+    float mm;
+    uint32_t b = 0;
+    if (BT) {
+      b = (c1 > smin) ? 2u : 0u;
+      mm = fmax2(smin, c1);
+      b = (c2 > mm) ? 3u : b;
+      mm = fmax2(mm, c2);
+      b = (c3 > mm) ? 4u : b;
+      mm = fmax2(mm, c3);
+      b = (c4 > mm) ? 5u : b;
+      mm = fmax2(mm, c4);
+      b = (c5 > mm) ? 6u : b;
+      mm = fmax2(mm, c5);
+    } else {
+      mm = fmax2(fmax2(fmax2(fmax2(fmax2(smin, c1), c2), c3), c4), c5);
+    }
+    // :277-283
+    const float S = log2f4(dot20(q.p[r], rec)) + P.shift;
+    mm = mm + S;
+    // :307-366
+    const float ga = lMM + tM2D, gb = lGD + tD2D;
+    float gd = fmax2(ga, gb);
+    const float ia = (lMM + q.m2i[r]) + tM2M, ib = (lIM + q.i2i[r]) + tM2M;
+    float im = fmax2(ia, ib);
+    const float da = uMM + q.m2d[r], db = uDG + q.d2d[r];
+    float dg = fmax2(da, db);
+    const float ma = (uMM + q.m2m[r]) + tM2I, mb = (uMI + q.m2m[r]) + tI2I;
+    float mi = fmax2(ma, mb);
+    if (BT) {
+      b |= (ga > gb) ? 8u : 0u;
+      b |= (ia > ib) ? 16u : 0u;
+      b |= (da > db) ? 32u : 0u;
+      b |= (ma > mb) ? 64u : 0u;
+      bytes |= (uint64_t)b << (8 * r);
+    }
+    if (CELLOFF) {  // :373-392: the masked build adds -FLT_MAX or +0.0f to all five states of every cell
+      const float add = ((cellbits >> (8 * r)) & 0x80u) ? NEG_MAX : 0.0f;
+      mm = mm + add;
+      gd = gd + add;
+      im = im + add;
+      dg = dg + add;
+      mi = mi + add;
+    }
+    if (LOCAL) {  // :423-455, strict '>' keeps the earliest column of a row
+      const bool up = mm > st.bs[r];
+      st.bs[r] = up ? mm : st.bs[r];
+      st.bj[r] = up ? j : st.bj[r];
+    }
+    // roll: this row's column j-1 values are the next row's diagonal, its new values the next row's "up"
+    dMM = lMM;
+    dGD = lGD;
+    dIM = lIM;
+    dDG = oDG;
+    dMI = oMI;
+    uMM = mm;
+    uDG = dg;
+    uMI = mi;
+    st.MM[r] = mm;
+    st.GD[r] = gd;
+    st.IM[r] = im;
+    st.DG[r] = dg;
+    st.MI[r] = mi;
+  }
+  if (!LOCAL) {
+    // global alignment: row Lq is maximised over all columns (:192,423); r_last is wave uniform
+    float v = st.MM[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) v = (r == r_last) ? st.MM[r] : v;
+    const bool up = v > st.bs[0];
+    st.bs[0] = up ? v : st.bs[0];
+    st.bj[0] = up ? j : st.bj[0];
+  }
+  st.jlast = j;
+  st.dMM = in.MM;
+  st.dGD = in.GD;
+  st.dIM = in.IM;
+  st.dDG = in.DG;
+  st.dMI = in.MI;
+  return bytes;
+}
+
+}  // namespace hhv

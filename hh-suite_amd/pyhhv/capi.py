@@ -1,0 +1,232 @@
+"""ctypes binding of libhhviterbi_hip.so (include/hhviterbi_hip.h) -- thin, no arithmetic here.
+
+The library is the product; this module only marshals numpy arrays into the C ABI so that the
+parity tests and bench.py can call it exactly the way a C/C++ host would.  It fails loudly when
+the shared object is missing (there is no Python or CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("HHV_LIB", os.path.join(os.path.dirname(HERE), "lib", "libhhviterbi_hip.so"))
+
+HHV_ALIGN_BACKTRACE = 1
+HHV_ALIGN_CELLOFF = 2
+HHV_STREAM_PAD = 256
+REC_DW = 28
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+
+
+class HhvParams(C.Structure):
+    _fields_ = [("device", C.c_int32), ("local", C.c_int32), ("egq", C.c_float), ("egt", C.c_float),
+                ("shift", C.c_float), ("corr", C.c_float), ("ssw", C.c_float), ("ss_mode", C.c_int32)]
+
+
+RESULT_DTYPE = np.dtype([("score", np.float32), ("i2", np.int32), ("j2", np.int32), ("index", np.int32)])
+HIT_DTYPE = np.dtype([("score", np.float32), ("viterbi_score", np.float32), ("index", np.int32),
+                      ("i1", np.int32), ("j1", np.int32), ("i2", np.int32), ("j2", np.int32),
+                      ("nsteps", np.int32), ("matched_cols", np.int32)])
+
+# every symbol include/hhviterbi_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
+    "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_upload_templates", "hhv_adopt_device_stream",
+    "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
+    "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
+    "hhv_hit_path", "hhv_topk",
+]
+
+
+class HhvError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HhvError("libhhviterbi_hip.so not built (%s): run `make lib` / __graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.hhv_abi_version.restype = C.c_int
+    L.hhv_last_error.restype = C.c_char_p
+    L.hhv_record_bytes.restype = C.c_int32
+    L.hhv_pack_profile.argtypes = [c_float_p, c_float_p, C.c_int32, C.c_int32, c_float_p]
+    L.hhv_fast_log2_tables.argtypes = [c_float_p, c_float_p]
+    L.hhv_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(HhvParams)]
+    L.hhv_destroy.argtypes = [C.c_void_p]
+    L.hhv_destroy.restype = None
+    L.hhv_set_query.argtypes = [C.c_void_p, c_float_p, c_float_p, C.c_int32]
+    L.hhv_upload_templates.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
+                                       C.POINTER(C.c_void_p)]
+    L.hhv_adopt_device_stream.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.hhv_tset_free.argtypes = [C.c_void_p]
+    L.hhv_tset_free.restype = None
+    L.hhv_tset_size.argtypes = [C.c_void_p]
+    L.hhv_tset_size.restype = C.c_int32
+    L.hhv_tset_cells.argtypes = [C.c_void_p, C.c_int32]
+    L.hhv_tset_cells.restype = C.c_int64
+    L.hhv_tset_records.argtypes = [C.c_void_p]
+    L.hhv_tset_records.restype = C.c_int64
+    L.hhv_align.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.hhv_align_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.hhv_sync.argtypes = [C.c_void_p]
+    L.hhv_stream.argtypes = [C.c_void_p]
+    L.hhv_stream.restype = C.c_void_p
+    L.hhv_last_kernel_ms.argtypes = [C.c_void_p, c_float_p]
+    L.hhv_set_celloff.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.hhv_backtrace_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.hhv_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hhv_hit_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, c_int_p]
+    L.hhv_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, c_int_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise HhvError("hhv error %d: %s" % (rc, load().hhv_last_error().decode()))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def pack_profile(p, tr, index=-1):
+    """Product packer (host only): index >= 0 -> (L+1, 28) header+columns, index < 0 -> (L, 28)."""
+    p, tr = _f32(p), _f32(tr)
+    L = p.shape[0] - 1
+    out = np.zeros(((L + 1) if index >= 0 else L, REC_DW), dtype=np.float32)
+    _check(load().hhv_pack_profile(p.ctypes.data_as(c_float_p), tr.ctypes.data_as(c_float_p), L, index,
+                                   out.ctypes.data_as(c_float_p)))
+    return out
+
+
+def fast_log2_tables():
+    lg2 = np.zeros(1025, dtype=np.float32)
+    diff = np.zeros(1025, dtype=np.float32)
+    _check(load().hhv_fast_log2_tables(lg2.ctypes.data_as(c_float_p), diff.ctypes.data_as(c_float_p)))
+    return lg2, diff
+
+
+class TemplateSet:
+    def __init__(self, ctx, handle, Ls):
+        self.ctx, self.h, self.L = ctx, handle, np.asarray(Ls, dtype=np.int32)
+        self.n = len(self.L)
+
+    def free(self):
+        if self.h:
+            load().hhv_tset_free(self.h)
+            self.h = None
+
+    def cells(self):
+        return int(load().hhv_tset_cells(self.h, self.ctx.Lq))
+
+    def records(self):
+        return int(load().hhv_tset_records(self.h))
+
+
+class Context:
+    """One hhv_ctx = the per-thread Viterbi object of the reference (src/hhviterbirunner.h:21-34)."""
+
+    def __init__(self, local=0, egq=0.0, egt=0.0, shift=-0.03, corr=0.1, ssw=0.11, ss_mode=2, device=0):
+        self.lib = load()
+        self.par = HhvParams(int(device), int(local), float(egq), float(egt), float(shift), float(corr), float(ssw),
+                             int(ss_mode))
+        h = C.c_void_p()
+        _check(self.lib.hhv_create(C.byref(h), C.byref(self.par)))
+        self.h = h
+        self.Lq = 0
+
+    def close(self):
+        if self.h:
+            self.lib.hhv_destroy(self.h)
+            self.h = None
+
+    def set_query(self, p, tr):
+        p, tr = _f32(p), _f32(tr)
+        self.Lq = p.shape[0] - 1
+        _check(self.lib.hhv_set_query(self.h, p.ctypes.data_as(c_float_p), tr.ctypes.data_as(c_float_p), self.Lq))
+
+    def upload(self, tps, ttrs):
+        tps = [_f32(a) for a in tps]
+        ttrs = [_f32(a) for a in ttrs]
+        n = len(tps)
+        Ls = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        pp = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in tps])
+        tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in ttrs])
+        h = C.c_void_p()
+        _check(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, C.byref(h)))
+        return TemplateSet(self, h, Ls)
+
+    def adopt_device_stream(self, Ls, device_ptr):
+        Ls = np.ascontiguousarray(Ls, dtype=np.int32)
+        h = C.c_void_p()
+        _check(self.lib.hhv_adopt_device_stream(self.h, len(Ls), Ls.ctypes.data_as(c_int_p), C.c_void_p(device_ptr),
+                                                C.byref(h)))
+        return TemplateSet(self, h, Ls)
+
+    def align(self, ts, backtrace=False, celloff=False):
+        flags = (HHV_ALIGN_BACKTRACE if backtrace else 0) | (HHV_ALIGN_CELLOFF if celloff else 0)
+        out = np.zeros(ts.n, dtype=RESULT_DTYPE)
+        _check(self.lib.hhv_align(self.h, ts.h, flags, out.ctypes.data))
+        return out
+
+    def align_async(self, ts, backtrace=False, celloff=False, d_out=None):
+        flags = (HHV_ALIGN_BACKTRACE if backtrace else 0) | (HHV_ALIGN_CELLOFF if celloff else 0)
+        _check(self.lib.hhv_align_async(self.h, ts.h, flags, C.c_void_p(d_out) if d_out else None))
+
+    def sync(self):
+        _check(self.lib.hhv_sync(self.h))
+
+    def stream(self):
+        return self.lib.hhv_stream(self.h)
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(self.lib.hhv_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def set_celloff(self, ts, k, mask):
+        if mask is None:
+            _check(self.lib.hhv_set_celloff(self.h, ts.h, int(k), None))
+            return
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape == (self.Lq + 1, int(ts.L[k]) + 1)
+        _check(self.lib.hhv_set_celloff(self.h, ts.h, int(k), m.ctypes.data))
+
+    def backtrace_matrix(self, ts, k):
+        out = np.zeros((self.Lq + 1, int(ts.L[k]) + 1), dtype=np.uint8)
+        _check(self.lib.hhv_backtrace_matrix(self.h, ts.h, int(k), out.ctypes.data))
+        return out
+
+    def hits(self, ts, fetch=True):
+        out = np.zeros(ts.n, dtype=HIT_DTYPE) if fetch else None
+        _check(self.lib.hhv_hits(self.h, ts.h, out.ctypes.data if fetch else None))
+        return out
+
+    def hit_path(self, ts, k):
+        cap = self.Lq + int(ts.L[k]) + 2
+        i_steps = np.zeros(cap, dtype=np.int32)
+        j_steps = np.zeros(cap, dtype=np.int32)
+        states = np.zeros(cap, dtype=np.int8)
+        S = np.zeros(cap, dtype=np.float32)
+        ns = C.c_int32()
+        _check(self.lib.hhv_hit_path(self.h, ts.h, int(k), cap, i_steps.ctypes.data, j_steps.ctypes.data,
+                                     states.ctypes.data, S.ctypes.data, C.byref(ns)))
+        return ns.value, i_steps, j_steps, states, S
+
+    def topk(self, ts, k, d_out=None, fetch=True, raw=False):
+        out = np.zeros(k, dtype=HIT_DTYPE) if fetch else None
+        n = C.c_int32()
+        _check(self.lib.hhv_topk(self.h, ts.h, int(k), 1 if raw else 0, out.ctypes.data if fetch else None,
+                                 C.c_void_p(d_out) if d_out else None, C.byref(n)))
+        return (out[:n.value] if fetch else None), n.value

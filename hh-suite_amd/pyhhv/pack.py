@@ -1,0 +1,99 @@
+"""numpy mirror of the device data layout -- used by the tests and the bench to
+build / decode packed buffers; the product's own packer is hh-suite_amd/csrc/hhv_pack.cpp and the
+two are checked against each other in tests/test_layout.py.
+
+Column record (28 dwords) of column k of an HMM given as p[(L+1),20], tr[(L+1),7]
+(enum order M2M,M2I,M2D,I2M,I2I,D2M,D2D, /root/reference src/hhdecl.h:68):
+    [0..19]  p[k][a]
+    [20..24] tr[k-1][M2M], tr[k-1][M2D], tr[k-1][D2M], tr[k-1][D2D], tr[k-1][I2M]
+    [25..26] tr[k][I2I], tr[k][M2I]
+    [27]     meta: int32  j | LAST(bit30) for columns,  bit31 set for headers ([0]=template index, [1]=L)
+"""
+import numpy as np
+
+M2M, M2I, M2D, I2M, I2I, D2M, D2D = range(7)
+REC_DW = 28
+META_HDR = np.int32(-2 ** 31)
+META_LAST = np.int32(0x40000000)
+LANES = 64
+
+
+def rows_for(Lq):
+    """Query rows per lane: smallest R with 64*R >= Lq."""
+    return max(1, -(-int(Lq) // LANES))
+
+
+def pack_columns(p, tr):
+    """(L,28) float32 records of columns 1..L (meta left 0)."""
+    p = np.asarray(p, dtype=np.float32)
+    tr = np.asarray(tr, dtype=np.float32)
+    L = p.shape[0] - 1
+    rec = np.zeros((L, REC_DW), dtype=np.float32)
+    rec[:, 0:20] = p[1:]
+    rec[:, 20] = tr[:-1, M2M]
+    rec[:, 21] = tr[:-1, M2D]
+    rec[:, 22] = tr[:-1, D2M]
+    rec[:, 23] = tr[:-1, D2D]
+    rec[:, 24] = tr[:-1, I2M]
+    rec[:, 25] = tr[1:, I2I]
+    rec[:, 26] = tr[1:, M2I]
+    return rec
+
+
+def pack_query(p, tr, R=None):
+    """(64*R, 28) float32: row i-1 of the array = query row i; rows > Lq are zero."""
+    Lq = p.shape[0] - 1
+    if R is None:
+        R = rows_for(Lq)
+    out = np.zeros((LANES * R, REC_DW), dtype=np.float32)
+    out[:Lq] = pack_columns(p, tr)
+    return out
+
+
+def pack_stream(tps, ttrs):
+    """Concatenated template stream: per template a header record then L column records, plus one
+    terminal header.  Returns (records[(sum(L+1)+1), 28] float32, rec_off[n+1] int64)."""
+    n = len(tps)
+    Ls = np.array([t.shape[0] - 1 for t in tps], dtype=np.int64)
+    rec_off = np.zeros(n + 1, dtype=np.int64)
+    rec_off[1:] = np.cumsum(Ls + 1)
+    total = int(rec_off[-1]) + 1
+    rec = np.zeros((total, REC_DW), dtype=np.float32)
+    meta = rec.view(np.int32)
+    for k in range(n):
+        o = int(rec_off[k])
+        L = int(Ls[k])
+        meta[o, 27] = META_HDR
+        meta[o, 0] = k
+        meta[o, 1] = L
+        rec[o + 1:o + 1 + L] = pack_columns(tps[k], ttrs[k])
+        meta[o + 1:o + 1 + L, 27] = np.arange(1, L + 1, dtype=np.int32)
+        meta[o + L, 27] |= META_LAST
+    o = int(rec_off[-1])
+    meta[o, 27] = META_HDR
+    meta[o, 0] = -1
+    meta[o, 1] = 0
+    return rec, rec_off
+
+
+def bt_to_matrix(bt_entries, rec_off_k, Lq, Lt, R, entry_bytes=8):
+    """Device backtrace layout -> reference layout (Lq+1, Lt+1) bytes.
+    bt_entries: flat uint8 view of the [record][lane][entry_bytes] buffer."""
+    e = np.asarray(bt_entries, dtype=np.uint8).reshape(-1, LANES, entry_bytes)
+    out = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
+    blk = e[rec_off_k + 1: rec_off_k + 1 + Lt]          # (Lt, 64, eb) : column j-1, lane, row-in-lane
+    for i in range(1, Lq + 1):
+        g, r = (i - 1) // R, (i - 1) % R
+        out[i, 1:] = blk[:, g, r]
+    return out
+
+
+def matrix_to_bt(mask, rec_off_k, R, bt_entries, entry_bytes=8, bit=0x80):
+    """Scatter a (Lq+1, Lt+1) 0/1 cell-off mask into bit 7 of the device backtrace buffer."""
+    e = np.asarray(bt_entries).reshape(-1, LANES, entry_bytes)
+    Lq, Lt = mask.shape[0] - 1, mask.shape[1] - 1
+    for i in range(1, Lq + 1):
+        g, r = (i - 1) // R, (i - 1) % R
+        col = e[rec_off_k + 1: rec_off_k + 1 + Lt, g, r]
+        col[:] = np.where(mask[i, 1:] != 0, col | bit, col & ~np.uint8(bit))
+    return bt_entries

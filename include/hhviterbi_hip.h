@@ -1,0 +1,165 @@
+/* hhviterbi_hip.h -- C ABI of the MI355X Viterbi HMM-HMM alignment engine (libhhviterbi_hip.so).
+ *
+ * Drop-in boundary for the batched Viterbi stage of HH-suite.  Each entry point replaces one piece
+ * of the reference's C++ interface (file:line in soedinglab/hh-suite v3.3.0):
+ *
+ *   hhv_create / hhv_destroy   Viterbi::Viterbi(maxres, local, egq, egt, corr, min_overlap, shift,
+ *                              ss_mode, ssw, S73, S33, S37)            src/hhviterbi.h:53-56,
+ *                              constructed per thread in ViterbiConsumerThread  src/hhviterbirunner.h:21-34
+ *   hhv_set_query              HMMSimd::MapOneHMM(q)                   src/hhhmmsimd.cpp:73-79,
+ *                              called from HHblits::run                src/hhblits.cpp:1136
+ *   hhv_upload_templates       HMMSimd::MapHMMVector(templates)        src/hhhmmsimd.cpp:86-160,
+ *                              called per batch from ViterbiRunner::alignment  src/hhviterbirunner.cpp:151
+ *   hhv_align                  Viterbi::Align(q, t, matrix, n, ss_mode) -> ViterbiResult{i[],j[],score[]}
+ *                                                                      src/hhviterbi.cpp:163-191, src/hhviterbi.h:21-32
+ *   hhv_set_celloff            ViterbiMatrix::setCellOff(i,j,elem,true) / Viterbi::ExcludeAlignment
+ *                                                                      src/hhviterbimatrix-inl.h:28-35, src/hhviterbi.cpp:61-77
+ *   hhv_backtrace              Viterbi::Backtrace(matrix, elem, i[], j[]) -> BacktraceResult
+ *                                                                      src/hhviterbi.cpp:83-160, src/hhviterbi.h:34-40
+ *   hhv_hits / hhv_hit_path    Viterbi::ScoreForBacktrace(...) -> BacktraceScore and the Hit fields filled in
+ *                              ViterbiConsumerThread::align            src/hhviterbi.cpp:195-281, src/hhviterbirunner.cpp:35-62
+ *   hhv_topk                   (new) device-side selection of the K best hits by Hit.score, the
+ *                              per-GPU half of the sharded top-K merge
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++/torch types.  Host pointers unless a parameter is
+ *     documented as a DEVICE pointer.
+ *   - every function returns HHV_OK (0) or a negative hhv_status; the library never calls exit()
+ *     (the reference exits with the codes of src/hhsearch.h:6); hhv_last_error() gives the text.
+ *   - "prepared profiles" = what Viterbi::Align sees after PrepareTemplateHMM
+ *     (src/hhfunc.cpp:165-202):  p[(L+1)*20] row 0 unused,  tr[(L+1)*7] log2 scores in the enum
+ *     order M2M,M2I,M2D,I2M,I2I,D2M,D2D (src/hhdecl.h:68).
+ *   - one hhv_ctx is used from one host thread at a time; several contexts may coexist (one per
+ *     GPU / per OpenMP thread, like the per-thread Viterbi objects of the reference).
+ *   - there is no CPU fallback: without a usable HIP device hhv_create fails with HHV_E_DEVICE.
+ */
+#ifndef HHVITERBI_HIP_H
+#define HHVITERBI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HHV_ABI_VERSION 1
+
+typedef enum {
+  HHV_OK = 0,
+  HHV_E_ARG = -1,     /* bad argument (reference: exit(4)/(6)) */
+  HHV_E_DEVICE = -2,  /* no HIP device / HIP runtime error */
+  HHV_E_MEMORY = -3,  /* host or device allocation failed (reference: exit(3)) */
+  HHV_E_STATE = -4,   /* call order (no query set, no backtrace computed, ...) */
+  HHV_E_LIMIT = -5    /* size beyond what this build supports */
+} hhv_status;
+
+/* Viterbi::Viterbi arguments that the hot path consumes (src/hhviterbirunner.h:32-33) */
+typedef struct {
+  int32_t device;   /* HIP device ordinal */
+  int32_t local;    /* par.loc: 1 = local (Smith-Waterman like), 0 = global */
+  float egq;        /* par.egq  end-gap penalty query */
+  float egt;        /* par.egt  end-gap penalty template */
+  float shift;      /* par.shift */
+  float corr;       /* par.corr */
+  float ssw;        /* par.ssw (secondary-structure weight; SS scoring is not built yet: must be unused) */
+  int32_t ss_mode;  /* par.ssm  (2 = Hit::SCORE_ALIGNMENT) */
+} hhv_params;
+
+/* one lane of the reference's ViterbiResult (src/hhviterbi.h:21-32) */
+typedef struct {
+  float score;
+  int32_t i2;
+  int32_t j2;
+  int32_t index; /* template index inside the set */
+} hhv_result;
+
+/* the Hit fields ViterbiConsumerThread::align fills (src/hhviterbirunner.cpp:35-62) */
+typedef struct {
+  float score;          /* BacktraceScore.score: Viterbi score - score_ss + corr * Scorr */
+  float viterbi_score;  /* raw ViterbiResult.score */
+  int32_t index;        /* template index inside the set */
+  int32_t i1, j1;       /* i_steps[nsteps], j_steps[nsteps] (alignment start) */
+  int32_t i2, j2;       /* alignment end */
+  int32_t nsteps;
+  int32_t matched_cols;
+} hhv_hit;
+
+typedef struct hhv_ctx hhv_ctx;
+typedef struct hhv_tset hhv_tset;
+
+/* flags of hhv_align */
+#define HHV_ALIGN_BACKTRACE 1u /* keep the backtrace bytes (needed by hhv_backtrace / hhv_hits / hhv_topk) */
+#define HHV_ALIGN_CELLOFF 2u   /* honour the masks installed with hhv_set_celloff (implies BACKTRACE) */
+
+int hhv_abi_version(void);
+const char* hhv_last_error(void); /* thread local */
+
+/* Host-side helpers (no device needed) that expose the packed layout of DESIGN.md section 2:
+ * hhv_record_bytes() = size of one packed column record (112);
+ * hhv_pack_profile(): index >= 0 -> header record + L column records with stream meta into
+ * out[(L+1)*28]; index < 0 -> the L bare column records (the query layout) into out[L*28];
+ * hhv_fast_log2_tables(): the lg2[1025]/diff[1025] tables of fast_log2 (src/util-inl.h:108-130). */
+int32_t hhv_record_bytes(void);
+int hhv_pack_profile(const float* p, const float* tr, int32_t L, int32_t index, float* out);
+int hhv_fast_log2_tables(float* lg2, float* diff);
+
+int hhv_create(hhv_ctx** out, const hhv_params* par);
+void hhv_destroy(hhv_ctx* ctx);
+
+/* query: p[(Lq+1)*20], tr[(Lq+1)*7] */
+int hhv_set_query(hhv_ctx* ctx, const float* p, const float* tr, int32_t Lq);
+
+/* n prepared template profiles -> resident packed set in HBM.  L[k] >= 1. */
+int hhv_upload_templates(hhv_ctx* ctx, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
+                         hhv_tset** out);
+/* Adopt an already packed DEVICE buffer (zero copy).  d_records holds the record stream described
+ * in DESIGN.md section 2: for each template a header record followed by L[k] column records, one
+ * terminal header, then >= HHV_STREAM_PAD records of slack; 28 floats per record.  The buffer must
+ * outlive the set. */
+#define HHV_STREAM_PAD 256
+int hhv_adopt_device_stream(hhv_ctx* ctx, int32_t n, const int32_t* L, const void* d_records, hhv_tset** out);
+void hhv_tset_free(hhv_tset* ts);
+int32_t hhv_tset_size(const hhv_tset* ts);
+int64_t hhv_tset_cells(const hhv_tset* ts, int32_t Lq); /* sum over templates of Lq*L[k] */
+/* number of stream records (sum(L+1)+1) and size of one packed record in bytes */
+int64_t hhv_tset_records(const hhv_tset* ts);
+
+/* Viterbi::Align for every template of the set.  out (host, n entries, nullable) receives
+ * score/i2/j2 in template order.  Synchronous. */
+int hhv_align(hhv_ctx* ctx, hhv_tset* ts, uint32_t flags, hhv_result* out);
+/* Same, asynchronous on the context's stream, results stay on the device: d_out is a DEVICE
+ * pointer to n hhv_result (nullable = internal buffer only).  hhv_sync waits. */
+int hhv_align_async(hhv_ctx* ctx, hhv_tset* ts, uint32_t flags, void* d_out);
+int hhv_sync(hhv_ctx* ctx);
+/* the HIP stream (hipStream_t) the context launches on, for callers that time with HIP events */
+void* hhv_stream(hhv_ctx* ctx);
+/* duration in milliseconds of the last hhv_align* DP kernel launch, from HIP events recorded
+ * around the launch on the context's stream (valid after hhv_sync) */
+int hhv_last_kernel_ms(hhv_ctx* ctx, float* ms);
+
+/* cell-off mask of template k for the next hhv_align with HHV_ALIGN_CELLOFF: mask[(Lq+1)*(L[k]+1)],
+ * non-zero = excluded.  NULL clears. */
+int hhv_set_celloff(hhv_ctx* ctx, hhv_tset* ts, int32_t k, const uint8_t* mask);
+/* raw backtrace byte matrix of template k in the reference layout: out[(Lq+1)*(L[k]+1)] */
+int hhv_backtrace_matrix(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint8_t* out);
+
+/* Viterbi::Backtrace + Viterbi::ScoreForBacktrace for all templates, on the device (needs a
+ * preceding hhv_align with HHV_ALIGN_BACKTRACE).  hits (host, n entries, nullable). */
+int hhv_hits(hhv_ctx* ctx, hhv_tset* ts, hhv_hit* hits);
+/* path of template k: arrays of cap entries, 1-based like BacktraceResult (index 0 unused,
+ * step 1 = alignment end); S = per-step column scores (BacktraceScore.S).  Needs hhv_hits. */
+int hhv_hit_path(hhv_ctx* ctx, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps,
+                 int8_t* states, float* S, int32_t* nsteps);
+/* K best hits by hit score (descending, ties by smaller index), selected on the device.
+ * flags: 0 = rank by Hit.score (needs hhv_hits); HHV_TOPK_RAW = rank by the raw Viterbi score of the
+ * last hhv_align (score-only searches: the records carry viterbi_score, i2, j2, index; path fields 0).
+ * out: host, k entries (nullable); d_out: DEVICE pointer to k hhv_hit records (nullable) - the buffer a
+ * multi-GPU caller hands to its all-gather; entries beyond *n_out are filled with 0xFF bytes. */
+#define HHV_TOPK_RAW 1u
+int hhv_topk(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, void* d_out, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HHVITERBI_HIP_H */

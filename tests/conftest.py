@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "hh-suite_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests must FAIL (not skip) on a GPU box if the HIP library is missing; they are only
+    # deselected by the driver's `-m "not gpu"` here on the CPU container.
+    pass
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from pyoracle import Oracle, have_oracle
+    if not have_oracle():
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from pyoracle import Ref, have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref/libhhref.so not built (needs /root/reference at build time)")
+    return Ref()

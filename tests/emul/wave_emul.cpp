@@ -1,0 +1,104 @@
+// tests/emul/wave_emul.cpp -- TEST INFRASTRUCTURE (never part of the product library).
+//
+// Host-side lock-step emulation of ONE wavefront of the systolic Viterbi kernel: the same
+// per-lane code (hh-suite_amd/csrc/viterbi_lane.h) is stepped for 64 lanes, with the DPP
+// wave_shr:1 exchange replaced by reading lane g-1's state before it is updated (lanes are
+// visited 63 -> 0 inside a step).  It lets the schedule, the boundary handling and the result
+// plumbing be debugged against the oracle on the CPU-only build container; GPU parity itself is
+// established by the -m gpu tests through the C ABI.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../hh-suite_amd/csrc/viterbi_lane.h"
+
+using namespace hhv;
+
+template <int R, bool LOCAL, bool BT, bool CELLOFF>
+static int run_wave(const float* qpack, const float* records, long M, Params P, TemplateResult* results, int n_results,
+                    uint64_t* bt /* M x 64 entries, in/out */) {
+  std::vector<LaneState<R>> st(64);
+  std::vector<QRows<R>> q(64);
+  for (int g = 0; g < 64; ++g) {
+    st[g].reset();
+    q[g].load(qpack + (size_t)g * R * REC_DW);
+  }
+  const int g_last = (P.Lq - 1) / R;
+  const int r_last = (P.Lq - 1) % R;
+  int emitted = 0;
+  for (long s = 0; s < M + 63; ++s) {
+    for (int g = 63; g >= 0; --g) {
+      const long r = s - g;
+      if (r < 0 || r >= M) continue;
+      const float* rec = records + (size_t)r * REC_DW;
+      int32_t meta;
+      memcpy(&meta, rec + REC_META, 4);
+      Incoming in;
+      if (g == 0) {
+        in = boundary_incoming(meta, P);
+      } else {
+        const LaneState<R>& a = st[g - 1];
+        in.MM = a.MM[R - 1];
+        in.GD = a.GD[R - 1];
+        in.IM = a.IM[R - 1];
+        in.DG = a.DG[R - 1];
+        in.MI = a.MI[R - 1];
+        in.fs = a.fs;
+        in.fpos = a.fpos;
+      }
+      const int i0 = g * R + 1;
+      if (meta < 0) {
+        int32_t new_tid;
+        memcpy(&new_tid, rec + 0, 4);
+        TemplateResult res;
+        if (lane_header<R, LOCAL>(st[g], in, i0, new_tid, P, g == g_last, res)) {
+          if (res.tid >= 0 && res.tid < n_results) results[res.tid] = res;
+          emitted++;
+        }
+      } else {
+        const int j = meta & META_JMASK;
+        uint64_t cell = 0;
+        if (CELLOFF) cell = bt[(size_t)r * 64 + g];
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF>(st[g], q[g], in, rec, j, i0, r_last, P, cell);
+        if (BT) bt[(size_t)r * 64 + g] = bytes;
+      }
+    }
+  }
+  return emitted;
+}
+
+template <int R>
+static int dispatch(int local, int want_bt, int celloff, const float* qpack, const float* records, long M, Params P,
+                    TemplateResult* results, int n_results, uint64_t* bt) {
+  if (celloff) {
+    return local ? run_wave<R, true, true, true>(qpack, records, M, P, results, n_results, bt)
+                 : run_wave<R, false, true, true>(qpack, records, M, P, results, n_results, bt);
+  }
+  if (want_bt) {
+    return local ? run_wave<R, true, true, false>(qpack, records, M, P, results, n_results, bt)
+                 : run_wave<R, false, true, false>(qpack, records, M, P, results, n_results, bt);
+  }
+  return local ? run_wave<R, true, false, false>(qpack, records, M, P, results, n_results, bt)
+               : run_wave<R, false, false, false>(qpack, records, M, P, results, n_results, bt);
+}
+
+extern "C" int hhv_emul_wave(int R, int local, int want_bt, int celloff, const float* qpack, const float* records,
+                             long M, float egq, float egt, float shift, int Lq, TemplateResult* results,
+                             int n_results, uint64_t* bt) {
+  Params P;
+  P.egq = egq;
+  P.egt = egt;
+  P.shift = shift;
+  P.Lq = Lq;
+  switch (R) {
+    case 1: return dispatch<1>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 2: return dispatch<2>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 3: return dispatch<3>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 4: return dispatch<4>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 5: return dispatch<5>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 6: return dispatch<6>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 7: return dispatch<7>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 8: return dispatch<8>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+  }
+  return -1;
+}

@@ -1,0 +1,84 @@
+"""Systolic schedule on the CPU: the product's per-lane code (hh-suite_amd/csrc/viterbi_lane.h)
+stepped in lock-step for 64 lanes by tests/emul/wave_emul.cpp must reproduce the oracle bit for bit
+(scores up to the sign of zero, endpoints and every backtrace byte exactly)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import same_float, workload
+from pyhhv import pack
+from pyoracle import make_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "emul", "libwave_emul.so")
+
+
+class TR(C.Structure):
+    _fields_ = [("score", C.c_float), ("i2", C.c_int), ("j2", C.c_int), ("tid", C.c_int)]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    if not os.path.exists(SO):
+        subprocess.check_call(["make", "-C", ROOT, "emul"])
+    lib = C.CDLL(SO)
+    lib.hhv_emul_wave.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_float,
+                                                  C.c_int, C.POINTER(TR), C.c_int, C.c_void_p]
+    return lib
+
+
+def run(emul, par, qf, qtr, tps, ttrs, want_bt, bt_in=None):
+    Lq = qf.shape[0] - 1
+    R = pack.rows_for(Lq)
+    qpack = pack.pack_query(qf, qtr, R)
+    rec, off = pack.pack_stream(tps, ttrs)
+    M = rec.shape[0]
+    n = len(tps)
+    res = (TR * n)()
+    bt = np.zeros((M, 64), dtype=np.uint64) if bt_in is None else bt_in
+    em = emul.hhv_emul_wave(R, par["local"], int(want_bt), int(bt_in is not None), qpack.ctypes.data, rec.ctypes.data,
+                            M, par["egq"], par["egt"], par["shift"], Lq, res, n, bt.ctypes.data)
+    assert em == n
+    return res, bt, off, R
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_schedule_matches_oracle(emul, oracle, case):
+    rng = np.random.default_rng(case)
+    Lq = int(rng.integers(5, 330)) if case < 14 else (431 if case == 14 else 512)
+    par = make_params(local=case % 2, egq=0.0 if case % 4 < 2 else 0.3, egt=0.0 if case % 4 < 2 else 0.1)
+    n = int(rng.integers(1, 7))
+    qf, qtr, tps, ttrs = workload(case, Lq, n, 1, 200)
+    for want_bt in (0, 1):
+        res, bt, off, R = run(emul, par, qf, qtr, tps, ttrs, want_bt)
+        for e in range(n):
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_bt=True)
+            assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2), (case, e)
+            if want_bt:
+                m = pack.bt_to_matrix(bt.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R)
+                assert np.array_equal(m[1:, 1:], a.bt[1:, 1:])
+
+
+def test_schedule_celloff(emul, oracle):
+    for local in (0, 1):
+        par = make_params(local=local)
+        qf, qtr, tps, ttrs = workload(40 + local, 150, 3, 80, 170, homolog_every=1)
+        Lq = 150
+        R = pack.rows_for(Lq)
+        rec, off = pack.pack_stream(tps, ttrs)
+        bt = np.zeros((rec.shape[0], 64), dtype=np.uint64)
+        masks = []
+        for e in range(3):
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True)
+            m = oracle.exclude_alignment(Lq, tps[e].shape[0] - 1, a.i_steps, a.j_steps, a.nsteps)
+            masks.append(m)
+            pack.matrix_to_bt(m, int(off[e]), R, bt.view(np.uint8))
+        res, bt2, off, R = run(emul, par, qf, qtr, tps, ttrs, 1, bt_in=bt)
+        for e in range(3):
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], celloff=masks[e], want_bt=True)
+            assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2)
+            m = pack.bt_to_matrix(bt2.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R)
+            assert np.array_equal(m[1:, 1:], a.bt[1:, 1:])

@@ -1,0 +1,168 @@
+"""GPU parity (run with -m gpu on the MI355X box): the HIP engine, called through the C ABI, against
+the oracle on the same seeded inputs.  Integer outputs (endpoints, backtrace bytes, paths) are
+bit-exact; float scores are compared as IEEE values and additionally within the north-star
+tolerance of 1e-4."""
+import numpy as np
+import pytest
+
+from common import same_float, workload
+from pyoracle import make_params
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: scores within 1e-4 of the reference CPU path
+
+
+@pytest.fixture(scope="module")
+def hhv():
+    from pyhhv import capi
+    capi.load()
+    return capi
+
+
+def ctx_for(hhv, par):
+    return hhv.Context(local=par["local"], egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"],
+                       ssw=par["ssw"], ss_mode=par["ss_mode"])
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_score_only_matches_oracle(hhv, oracle, case):
+    rng = np.random.default_rng(case)
+    Lq = [5, 64, 65, 128, 200, 256, 257, 300, 320, 321, 431, 512][case]
+    par = make_params(local=case % 2, egq=0.0 if case % 4 < 2 else 0.3, egt=0.0 if case % 4 < 2 else 0.1)
+    n = int(rng.integers(3, 40))
+    qf, qtr, tps, ttrs = workload(case, Lq, n, 1, 260)
+    c = ctx_for(hhv, par)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    res = c.align(ts)
+    for e in range(n):
+        a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_bt=False)
+        assert res["index"][e] == e
+        assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]), (case, e)
+        assert same_float(a.score, res["score"][e]) and abs(float(a.score) - float(res["score"][e])) <= TOL
+    ts.free()
+    c.close()
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_backtrace_hits_match_oracle(hhv, oracle, case):
+    rng = np.random.default_rng(50 + case)
+    Lq = [40, 100, 200, 300, 320, 431][case]
+    par = make_params(local=case % 2, egq=0.0 if case % 4 < 2 else 0.2, egt=0.0 if case % 4 < 2 else 0.1)
+    n = int(rng.integers(4, 24))
+    qf, qtr, tps, ttrs = workload(50 + case, Lq, n, 5, 330)
+    c = ctx_for(hhv, par)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    res = c.align(ts, backtrace=True)
+    hits = c.hits(ts)
+    for e in range(n):
+        a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True)
+        assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and same_float(a.score, res["score"][e])
+        m = c.backtrace_matrix(ts, e)
+        assert np.array_equal(m[1:, 1:], a.bt[1:, 1:]), (case, e)
+        h = hits[e]
+        assert h["index"] == e and h["nsteps"] == a.nsteps and h["matched_cols"] == a.matched_cols
+        assert (h["i1"], h["j1"]) == (a.i_steps[a.nsteps], a.j_steps[a.nsteps])
+        assert same_float(h["score"], a.hit_score) and abs(float(h["score"]) - float(a.hit_score)) <= TOL
+        ns, i_s, j_s, st, S = c.hit_path(ts, e)
+        assert ns == a.nsteps
+        assert np.array_equal(i_s[1:ns + 1], a.i_steps[1:ns + 1])
+        assert np.array_equal(j_s[1:ns + 1], a.j_steps[1:ns + 1])
+        assert np.array_equal(st[1:ns + 1], a.states[1:ns + 1])
+        assert np.array_equal(S[1:ns + 1], a.S[1:ns + 1])
+    # top-K: by hit score descending, ties by index
+    k = min(5, n)
+    top, nv = c.topk(ts, k)
+    order = sorted(range(n), key=lambda e: (-float(hits["score"][e]), e))[:k]
+    assert nv == k and list(top["index"]) == order
+    ts.free()
+    c.close()
+
+
+def test_celloff_second_round(hhv, oracle):
+    """Alt-alignment round 2 (src/hhviterbirunner.cpp:104,152-164): mask the first path, re-align."""
+    for local in (0, 1):
+        par = make_params(local=local)
+        Lq = 150
+        qf, qtr, tps, ttrs = workload(40 + local, Lq, 5, 80, 170, homolog_every=1)
+        c = ctx_for(hhv, par)
+        c.set_query(qf, qtr)
+        ts = c.upload(tps, ttrs)
+        c.align(ts, backtrace=True)
+        c.hits(ts)
+        masks = []
+        for e in range(5):
+            ns, i_s, j_s, st, S = c.hit_path(ts, e)
+            m = oracle.exclude_alignment(Lq, tps[e].shape[0] - 1, i_s, j_s, ns)
+            masks.append(m)
+        for e in range(5):
+            c.set_celloff(ts, e, masks[e])
+        res = c.align(ts, celloff=True)
+        hits = c.hits(ts)
+        for e in range(5):
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], celloff=masks[e], want_path=True)
+            assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and same_float(a.score, res["score"][e])
+            assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:])
+            assert same_float(hits["score"][e], a.hit_score) and hits["nsteps"][e] == a.nsteps
+        ts.free()
+        c.close()
+
+
+def test_many_templates_partitioning(hhv, oracle):
+    """More templates than resident waves, ragged lengths: exercises the wave partition, chunk refills
+    (streams much longer than the 192-record LDS ring) and the header/finalize plumbing."""
+    par = make_params(local=0)
+    Lq = 300
+    n = 3000
+    rng = np.random.default_rng(7)
+    from pyhhv import synth
+    qf, qtr = synth.make_query(4242, Lq)
+    base = [synth.make_template(9000 + k, int(rng.integers(20, 400))) for k in range(64)]
+    idx = rng.integers(0, 64, n)
+    tps = [base[i][0] for i in idx]
+    ttrs = [base[i][1] for i in idx]
+    c = ctx_for(hhv, par)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    res = c.align(ts)
+    ref = [oracle.align(par, qf, qtr, base[i][0], base[i][1], want_bt=False) for i in range(64)]
+    for e in range(n):
+        a = ref[idx[e]]
+        assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and same_float(a.score, res["score"][e]), e
+    # determinism: a second run is bitwise identical
+    res2 = c.align(ts)
+    assert np.array_equal(res.view(np.uint8), res2.view(np.uint8))
+    ts.free()
+    c.close()
+
+
+def test_headline_shape_sample(hhv, oracle):
+    """BASELINE configs[1] shape (Lq=300 vs Lt=300, global, score-only): a seeded sample of templates
+    checked against the oracle, plus size-independent properties on the whole set."""
+    par = make_params(local=0)
+    from pyhhv import synth
+    Lq = Lt = 300
+    n = 2048
+    qf, qtr = synth.make_query(1, Lq)
+    tps, ttrs = [], []
+    for k in range(n):
+        kk = k % 256
+        p, tr = synth.make_template(100 + kk, Lt) if kk % 3 else synth.make_homolog(100 + kk, qf, L=Lt)
+        tps.append(p)
+        ttrs.append(tr)
+    c = ctx_for(hhv, par)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    res = c.align(ts)
+    for e in list(range(0, n, 97)):
+        a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_bt=False)
+        assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and same_float(a.score, res["score"][e])
+    # identical templates -> identical results wherever they sit in the stream
+    for f in ("score", "i2", "j2"):
+        assert np.array_equal(res[f][256:], res[f][:-256])
+    # global alignment ends in the last row or the last column
+    assert np.all((res["i2"] == Lq) | (res["j2"] == Lt))
+    ts.free()
+    c.close()

@@ -1,0 +1,114 @@
+// tools/valu_ubench.hip -- VALU issue-rate microbenchmark for gfx950 (measurement aid, not product).
+// For each instruction kind: 8 independent register chains, 4096 instructions per lane-loop, launched
+// with W waves per SIMD.  Prints wave-instructions per cycle per CU and the implied cycles per
+// wave64 instruction per SIMD.  Used to price the per-cell instruction mix of the Viterbi kernel
+// (DESIGN.md section 5).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP8(X) X X X X X X X X
+#define BODY(OP)                                                                                   \
+  asm volatile(REP8(OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n"    \
+                    OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n")   \
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)    \
+               : "v"(b));
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
+  float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+  float b = seed * 0.5f + threadIdx.x * 1e-9f;
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 0) { BODY("v_add_f32") }
+    if (KIND == 1) { BODY("v_mul_f32") }
+    if (KIND == 2) { BODY("v_max_f32") }
+    if (KIND == 3) { BODY("v_fma_f32 %0, %0, %8, %0 ;") }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// packed fp32: 64-bit register pairs
+typedef float float2v __attribute__((ext_vector_type(2)));
+#define BODYPK(OP)                                                                                 \
+  asm volatile(REP8(OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n"    \
+                    OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n")   \
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)    \
+               : "v"(b));
+template <int KIND>
+__global__ void __launch_bounds__(256) kpk(float* out, int iters, float seed) {
+  float2v a0 = {seed, seed}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+  float2v b = {seed * 0.5f, seed * 0.25f};
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 0) { BODYPK("v_pk_add_f32") }
+    if (KIND == 1) { BODYPK("v_pk_mul_f32") }
+  }
+  float2v s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+}
+
+// mixed: v_mov_b32, v_cndmask, v_cvt, v_bfe, dpp
+template <int KIND>
+__global__ void __launch_bounds__(256) kmisc(float* out, int iters, float seed) {
+  float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+  float b = seed * 0.5f + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 0) asm volatile(REP8("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    if (KIND == 1) asm volatile(REP8("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+    if (KIND == 2) asm volatile(REP8("v_cvt_f32_i32 %0, %0\n v_cvt_f32_i32 %1, %1\n v_cvt_f32_i32 %2, %2\n v_cvt_f32_i32 %3, %3\n v_cvt_f32_i32 %4, %4\n v_cvt_f32_i32 %5, %5\n v_cvt_f32_i32 %6, %6\n v_cvt_f32_i32 %7, %7\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    if (KIND == 3) asm volatile(REP8("v_mov_b32_dpp %0, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    if (KIND == 4) asm volatile(REP8("v_max3_f32 %0, %0, %8, %1\n v_max3_f32 %1, %1, %8, %2\n v_max3_f32 %2, %2, %8, %3\n v_max3_f32 %3, %3, %8, %4\n v_max3_f32 %4, %4, %8, %5\n v_max3_f32 %5, %5, %8, %6\n v_max3_f32 %6, %6, %8, %7\n v_max3_f32 %7, %7, %8, %0\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+template <typename F>
+static void run(const char* name, F launch, int width) {
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  const int cus = prop.multiProcessorCount;
+  float* out;
+  hipMalloc(&out, (size_t)cus * 8 * 256 * sizeof(float));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int iters = 2000;
+  for (int wps : {1, 2, 4, 8}) {
+    const int blocks = cus * wps;  // 256 threads = 4 waves = one per SIMD
+    launch(blocks, out, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    launch(blocks, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double inst = (double)blocks * 4 * iters * 64.0;  // wave-instructions
+    const double clk = prop.clockRate * 1e3;                // Hz
+    const double ipc_cu = inst / (ms * 1e-3) / clk / cus;
+    printf("%-16s waves/SIMD=%d  %.3f ms  %.2f wave-inst/clk/CU  -> %.2f clk per wave-inst per SIMD  (%.1f T lane-ops/s x%d)\n",
+           name, wps, ms, ipc_cu, 4.0 / ipc_cu, inst * 64 * width / (ms * 1e-3) / 1e12, width);
+  }
+  hipFree(out);
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  printf("device %s  CUs %d  clock %.0f MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1e3);
+  run("v_add_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(k<0>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_mul_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(k<1>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_max_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(k<2>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_pk_add_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(kpk<0>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 2);
+  run("v_pk_mul_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(kpk<1>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 2);
+  run("v_mov_b32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<0>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_cndmask_b32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<1>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_cvt_f32_i32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<2>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_mov_b32_dpp", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<3>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_max3_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<4>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  return 0;
+}
