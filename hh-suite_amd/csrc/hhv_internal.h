@@ -6,8 +6,8 @@ namespace hhv {
 
 constexpr int LANES = 64;          // wavefront width on gfx950
 constexpr int MAX_R = 8;           // query rows per lane -> single pass handles Lq <= 512
-constexpr int CHUNK_RECS = 64;     // records per LDS refill (7 x 1 KiB global_load_lds_dwordx4)
-constexpr int RING_CHUNKS = 3;     // live window spans <= 2 chunks, the third is in flight
+constexpr int CHUNK_RECS = 32;     // records per LDS refill (3.5 x 1 KiB global_load_lds_dwordx4)
+constexpr int RING_CHUNKS = 4;     // the 64-record live window spans <= 3 chunks, the fourth is in flight
 constexpr int RING_RECS = CHUNK_RECS * RING_CHUNKS;
 constexpr int STREAM_PAD_RECS = 256;  // slack after the terminal header (chunk over-read)
 constexpr int BT_ENTRY_BYTES = 8;  // one backtrace entry = the R (<= 8) bytes of one lane at one column

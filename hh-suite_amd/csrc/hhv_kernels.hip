@@ -3,7 +3,7 @@
 //
 // Kernel 1  hhv_stream_kernel<R, LOCAL, BT, CELLOFF>   the Viterbi DP (replaces Viterbi::Align,
 //           src/hhviterbialgorithm.cpp:29-497): one 64-lane wavefront = one systolic array, see
-//           viterbi_lane.h.  The wave's template stream is staged through a 21 KiB LDS ring with
+//           viterbi_lane.h.  The wave's template stream is staged through a 14 KiB LDS ring with
 //           global_load_lds_dwordx4 (HBM -> LDS without touching VGPRs), lanes read their record
 //           with 7 conflict-free ds_read_b128 (28-dword stride = 16 distinct 4-bank slots), the
 //           lane-to-lane hand-off is 7 v_mov_b32_dpp wave_shr:1 per step.
@@ -28,14 +28,19 @@ __device__ __forceinline__ int dpp_shr1(int old, int src) {
   return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, false);
 }
 
-// one 64-record chunk: 7 wave-wide 16-byte-per-lane loads straight into LDS
+// one 32-record chunk (3584 B): 3 wave-wide 16-byte-per-lane loads + one half-wave load, straight into LDS
 __device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int chunk, float4* ring, int lane) {
-  const float4* g = src + (size_t)chunk * (CHUNK_RECS * 7) + lane;
-  float4* l = ring + (chunk % RING_CHUNKS) * (CHUNK_RECS * 7);
+  constexpr int CHUNK_F4 = CHUNK_RECS * 7;  // 224 float4
+  const float4* g = src + (size_t)chunk * CHUNK_F4 + lane;
+  float4* l = ring + (chunk & (RING_CHUNKS - 1)) * CHUNK_F4;
 #pragma unroll
-  for (int k = 0; k < 7; ++k) {
+  for (int k = 0; k < 3; ++k) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * LANES),
                                      (__attribute__((address_space(3))) void*)(l + k * LANES), 16, 0, 0);
+  }
+  if (lane < 32) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 3 * LANES),
+                                     (__attribute__((address_space(3))) void*)(l + 3 * LANES), 16, 0, 0);
   }
 }
 
@@ -61,6 +66,7 @@ __global__ void __launch_bounds__(LANES) hhv_stream_kernel(StreamArgs a) {
   const int nchunks = (M + CHUNK_RECS - 1) / CHUNK_RECS;
   load_chunk(src, 0, ring, lane);
   load_chunk(src, 1, ring, lane);  // the stream is padded: over-reading past M is harmless
+  static_assert((RING_RECS & (RING_RECS - 1)) == 0 && RING_CHUNKS == 4 && CHUNK_RECS == 32, "ring geometry");
 
   QRows<R> q;
   q.load(a.qpack + (size_t)lane * R * REC_DW);
@@ -69,11 +75,11 @@ __global__ void __launch_bounds__(LANES) hhv_stream_kernel(StreamArgs a) {
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  int slot = (lane == 0) ? 0 : RING_RECS - lane;  // ring slot of record s - lane
   for (int s = 0; s < M + LANES - 1; ++s) {
     if ((s & (CHUNK_RECS - 1)) == 0 && s > 0) {
-      // chunk c = s/64 was issued 64 steps ago: make sure it has landed, then refill the slot that
-      // held chunk c-2 (its last reader, lane 63, finished at step 64c-2) with chunk c+1
+      // chunk c = s/32 was issued 32 steps ago: make sure it has landed, then refill the slot that
+      // held chunk c-3 (its last reader, lane 63, finished at step 32(c-2)+62 < 32c) with chunk c+1.
+      // The live window [s-63, s] spans chunks c-2..c, so the ring holds 4 chunks = 128 records.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int c = s / CHUNK_RECS;
       if (c + 1 < nchunks) load_chunk(src, c + 1, ring, lane);
@@ -83,7 +89,7 @@ __global__ void __launch_bounds__(LANES) hhv_stream_kernel(StreamArgs a) {
 
     float rec[REC_DW];
     {
-      const float4* p = ring + slot * 7;
+      const float4* p = ring + ((s - lane) & (RING_RECS - 1)) * 7;
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const float4 v = p[k];
@@ -128,7 +134,6 @@ __global__ void __launch_bounds__(LANES) hhv_stream_kernel(StreamArgs a) {
         if (BT) *bte = bytes;
       }
     }
-    slot = (slot + 1 == RING_RECS) ? 0 : slot + 1;
   }
 }
 

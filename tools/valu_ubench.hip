@@ -60,6 +60,16 @@ __global__ void __launch_bounds__(256) kmisc(float* out, int iters, float seed) 
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
     if (KIND == 3) asm volatile(REP8("v_mov_b32_dpp %0, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n")
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    if (KIND == 5) asm volatile("s_mov_b64 s[10:11], 0x5555\n" REP8("v_cndmask_b32_e64 %0, %0, %8, s[10:11]\n v_cndmask_b32_e64 %1, %1, %8, s[10:11]\n v_cndmask_b32_e64 %2, %2, %8, s[10:11]\n v_cndmask_b32_e64 %3, %3, %8, s[10:11]\n v_cndmask_b32_e64 %4, %4, %8, s[10:11]\n v_cndmask_b32_e64 %5, %5, %8, s[10:11]\n v_cndmask_b32_e64 %6, %6, %8, s[10:11]\n v_cndmask_b32_e64 %7, %7, %8, s[10:11]\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s10", "s11");
+    if (KIND == 6) asm volatile(REP8("v_cmp_gt_f32_e64 s[10:11], %0, %8\n v_cmp_gt_f32_e64 s[12:13], %1, %8\n v_cmp_gt_f32_e64 s[14:15], %2, %8\n v_cmp_gt_f32_e64 s[16:17], %3, %8\n v_cmp_gt_f32_e64 s[10:11], %4, %8\n v_cmp_gt_f32_e64 s[12:13], %5, %8\n v_cmp_gt_f32_e64 s[14:15], %6, %8\n v_cmp_gt_f32_e64 s[16:17], %7, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17");
+    if (KIND == 7) asm volatile(REP8("v_bfe_u32 %0, %0, 3, 8\n v_bfe_u32 %1, %1, 3, 8\n v_bfe_u32 %2, %2, 3, 8\n v_bfe_u32 %3, %3, 3, 8\n v_bfe_u32 %4, %4, 3, 8\n v_bfe_u32 %5, %5, 3, 8\n v_bfe_u32 %6, %6, 3, 8\n v_bfe_u32 %7, %7, 3, 8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    if (KIND == 8) asm volatile(REP8("v_and_or_b32 %0, %0, %8, 1.0\n v_and_or_b32 %1, %1, %8, 1.0\n v_and_or_b32 %2, %2, %8, 1.0\n v_and_or_b32 %3, %3, %8, 1.0\n v_and_or_b32 %4, %4, %8, 1.0\n v_and_or_b32 %5, %5, %8, 1.0\n v_and_or_b32 %6, %6, %8, 1.0\n v_and_or_b32 %7, %7, %8, 1.0\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    if (KIND == 9) asm volatile(REP8("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
     if (KIND == 4) asm volatile(REP8("v_max3_f32 %0, %0, %8, %1\n v_max3_f32 %1, %1, %8, %2\n v_max3_f32 %2, %2, %8, %3\n v_max3_f32 %3, %3, %8, %4\n v_max3_f32 %4, %4, %8, %5\n v_max3_f32 %5, %5, %8, %6\n v_max3_f32 %6, %6, %8, %7\n v_max3_f32 %7, %7, %8, %0\n")
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
   }
@@ -76,7 +86,7 @@ static void run(const char* name, F launch, int width) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const int iters = 2000;
+  const int iters = 20000;
   for (int wps : {1, 2, 4, 8}) {
     const int blocks = cus * wps;  // 256 threads = 4 waves = one per SIMD
     launch(blocks, out, 10);
@@ -109,6 +119,11 @@ int main() {
   run("v_cndmask_b32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<1>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
   run("v_cvt_f32_i32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<2>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
   run("v_mov_b32_dpp", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<3>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_cndmask_e64_s", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<5>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_cmp_gt_f32_e64", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<6>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_bfe_u32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<7>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_and_or_b32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<8>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+  run("v_fma_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<9>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
   run("v_max3_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<4>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
   return 0;
 }
