@@ -131,7 +131,7 @@ def unpack_templates(rec_host, n, Lt):
 def main():
     args = parse()
     import torch
-    from pyhhv import capi, synth
+    from pyhhv import capi, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -161,7 +161,7 @@ def main():
     cells_per_rank = ts.cells()
     K = args.topk
     topk_buf = torch.zeros((K, 9), dtype=torch.int32, device=device)       # K hhv_hit records (36 B each)
-    gathered = torch.zeros((world * K, 9), dtype=torch.int32, device=device) if world > 1 else None
+    gids = torch.arange(n, dtype=torch.int64, device=device) + rank * n    # global template ids of this shard
     bt = bool(args.backtrace)
 
     kernel_ms = []
@@ -172,12 +172,9 @@ def main():
             ctx.hits(ts, fetch=False)
         ctx.topk(ts, K, d_out=topk_buf.data_ptr(), fetch=False, raw=not bt)
         kernel_ms.append(ctx.last_kernel_ms())
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, topk_buf)
-            # identical merge on every rank: K best of world*K records by (score desc, rank, index)
-            sc = gathered[:, 0].view(torch.float32)
-            order = torch.argsort(sc, descending=True, stable=True)[:K]
-            _ = gathered[order]
+        # hit-list exchange: ONE all_gather of K records per rank over RCCL, identical merge everywhere
+        recs = shard.to_global_ids(torch, topk_buf, gids)
+        return shard.exchange_and_merge(torch, dist if world > 1 else None, recs, K)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (tools/profile.sh) into profiles/<tag>_summary.{txt,json}:
+per-kernel statistics of the bench command and per-launch PMC values of the dominant kernel, with the
+gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section) applied and stated."""
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+KERNEL = "hhv_stream_kernel"
+
+
+def rows(pattern):
+    out = []
+    for f in glob.glob(os.path.join(src, pattern), recursive=True):
+        with open(f) as fh:
+            out += list(csv.DictReader(fh))
+    return out
+
+
+summary = {"tag": tag, "kernel": KERNEL}
+lines = []
+stats = rows("stats/**/*kernel_stats.csv")
+lines.append("== rocprofv3 --kernel-trace --stats (python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-configs1)")
+lines.append("%-70s %8s %14s %14s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+for r in sorted(stats, key=lambda r: -float(r.get("TotalDurationNs", 0)))[:12]:
+    name = r["Name"]
+    short = name if len(name) < 70 else name[:67] + "..."
+    lines.append("%-70s %8s %14s %14.0f %8.2f" % (short, r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
+                                                 float(r["Percentage"])))
+    if KERNEL in name:
+        summary["stats"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                            "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
+
+pmc = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+    for r in rows(sub + "/**/*counter_collection.csv"):
+        if KERNEL not in r.get("Kernel_Name", ""):
+            continue
+        pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+lines.append("")
+lines.append("== PMC per launch of %s (mean over profiled launches)" % KERNEL)
+pm = {k: sum(v) / len(v) for k, v in pmc.items()}
+for k in sorted(pm):
+    lines.append("%-28s %20.1f   (%d launches)" % (k, pm[k], len(pmc[k])))
+summary["pmc_mean_per_launch"] = pm
+if "FETCH_SIZE" in pm:
+    # rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half
+    # their size (128-B requests tallied as 64 B): doubled here, as the guide prescribes.
+    fetch = pm["FETCH_SIZE"] * 1024.0 * 2.0
+    summary["hbm_read_bytes_per_launch_corrected"] = fetch
+    lines.append("HBM read bytes/launch  (FETCH_SIZE KiB x 1024 x 2 gfx950 correction) = %.0f" % fetch)
+if "WRITE_SIZE" in pm:
+    wr = pm["WRITE_SIZE"] * 1024.0
+    summary["hbm_write_bytes_per_launch"] = wr
+    lines.append("HBM write bytes/launch (WRITE_SIZE KiB x 1024, uncalibrated)         = %.0f" % wr)
+if "hbm_read_bytes_per_launch_corrected" in summary:
+    summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch_corrected"] + summary.get("hbm_write_bytes_per_launch", 0.0)
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+with open(os.path.join(root, "profiles", tag + "_summary.txt"), "w") as f:
+    f.write("\n".join(lines) + "\n")
+with open(os.path.join(root, "profiles", tag + "_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+print("\n".join(lines))
