@@ -205,6 +205,17 @@ def main():
     achieved_gbs = algo_bytes / (k_ms * 1e-3) / 1e9
     kernel_cells_s = cells_per_rank / (k_ms * 1e-3)
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC profile (profiles/, collected with
+    # tools/profile.sh on this same command: separate --pmc passes, FETCH_SIZE doubled as the guide prescribes)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_summary.json")) as f:
+            prof = json.load(f)
+        if n == 100000 and Lq == 300 and Lt == 300 and not bt:
+            traffic = prof.get("traffic_bytes_per_launch")
+    except Exception:
+        pass
+
     out = {
         "metric": "viterbi_dp_cells_per_s",
         "value": value,
@@ -227,7 +238,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/r1_summary.json (rocprofv3 PMC, bytes per launch)" if traffic else None,
             "kernel": "hhv_stream_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
             "note": "the path is VALU-issue bound, not HBM bound (SURVEY.md 8d): see roofline_valu",
         },

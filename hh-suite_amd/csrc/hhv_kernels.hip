@@ -44,8 +44,11 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int c
   }
 }
 
+// Occupancy: VALU issue needs >= 2 waves per SIMD to reach its rate on gfx950 (a lone wave issues one
+// VOP2 every ~6.3 clk, two waves one every ~2.5 clk: tools/valu_ubench).  Up to R = 5 rows per lane the
+// kernel is held to <= 256 VGPRs (2 waves/SIMD; the backtrace variants spill a few dwords to scratch).
 template <int R, bool LOCAL, bool BT, bool CELLOFF>
-__global__ void __launch_bounds__(LANES) hhv_stream_kernel(StreamArgs a) {
+__global__ void __launch_bounds__(LANES, (R <= 5 ? 2 : 1)) hhv_stream_kernel(StreamArgs a) {
   __shared__ float4 ring[RING_RECS * 7];
   const int lane = threadIdx.x;
   const int64_t rb = a.wave_rec[blockIdx.x];
