@@ -15,9 +15,15 @@ LIB      := $(LIBDIR)/libhhviterbi_hip.so
 OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_pack.o
 HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
 
+RUNNER   := $(LIBDIR)/libhhv_runner.so
+
 all: lib oracle emul
 
-lib: $(LIB)
+lib: $(LIB) $(RUNNER)
+
+# C++ host layer above the C ABI (mirror of the reference's ViterbiRunner); plain g++, links only the C ABI
+$(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h include/hhviterbi_hip.h $(LIB)
+	g++ -O2 -std=c++14 -fPIC -shared -Wall -o $@ hh-suite_amd/host/viterbi_runner.cpp -L$(LIBDIR) -lhhviterbi_hip -Wl,-rpath,'$$ORIGIN'
 
 $(OBJDIR)/hhv_kernels.o: $(CSRC)/hhv_kernels.hip $(HDRS)
 	@mkdir -p $(OBJDIR)

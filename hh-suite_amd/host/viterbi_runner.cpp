@@ -1,0 +1,198 @@
+// viterbi_runner.cpp -- see viterbi_runner.h.  Host glue only; every number comes out of the C ABI.
+#include "viterbi_runner.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace hhv {
+
+namespace {
+const int VITERBI_PATH_WIDTH = 40;  // src/hhdecl.h:50
+
+void check(int rc, const char* what) {
+  if (rc != HHV_OK) throw Error(rc, std::string(what) + ": " + hhv_last_error());
+}
+
+struct CtxGuard {
+  hhv_ctx* c = nullptr;
+  ~CtxGuard() {
+    if (c) hhv_destroy(c);
+  }
+};
+struct SetGuard {
+  hhv_tset* t = nullptr;
+  ~SetGuard() {
+    if (t) hhv_tset_free(t);
+  }
+};
+}  // namespace
+
+void ExcludeAlignment(std::vector<uint8_t>& mask, int Lq, int Lt, const int32_t* i_steps, const int32_t* j_steps,
+                      int nsteps) {
+  const size_t W = (size_t)Lt + 1;
+  for (int step = 1; step < nsteps; ++step) {  // the last step is skipped, like the reference (:65)
+    const int i = i_steps[step], j = j_steps[step];
+    for (int ii = std::max(i - VITERBI_PATH_WIDTH, 1); ii <= std::min(i + VITERBI_PATH_WIDTH, Lq); ++ii)
+      mask[(size_t)ii * W + j] = 1;
+    for (int jj = std::max(j - VITERBI_PATH_WIDTH, 1); jj <= std::min(j + VITERBI_PATH_WIDTH, Lt); ++jj)
+      mask[(size_t)i * W + jj] = 1;
+  }
+}
+
+std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& q,
+                                          const std::vector<Profile>& templates) {
+  std::vector<Hit> ret_hits;
+  const int n = (int)templates.size();
+  if (n == 0) return ret_hits;
+  if (!q.p || !q.tr || q.L < 1) throw Error(HHV_E_ARG, "ViterbiRunner::alignment: empty query");
+
+  hhv_params hp;
+  hp.device = device_;
+  hp.local = par.loc;
+  hp.egq = par.egq;
+  hp.egt = par.egt;
+  hp.shift = par.shift;
+  hp.corr = par.corr;
+  hp.ssw = par.ssw;
+  hp.ss_mode = par.ssm;
+  CtxGuard ctx;
+  check(hhv_create(&ctx.c, &hp), "hhv_create");
+  check(hhv_set_query(ctx.c, q.p, q.tr, q.L), "hhv_set_query");
+
+  // the database block stays resident for all alternative-alignment rounds
+  std::vector<int32_t> L(n);
+  std::vector<const float*> pp(n), tt(n);
+  for (int k = 0; k < n; ++k) {
+    L[k] = templates[k].L;
+    pp[k] = templates[k].p;
+    tt[k] = templates[k].tr;
+  }
+  SetGuard all;
+  check(hhv_upload_templates(ctx.c, n, L.data(), pp.data(), tt.data(), &all.t), "hhv_upload_templates");
+
+  // excludeAlignments (src/hhviterbirunner.cpp:100,262-268): accumulated mask per template
+  std::vector<std::vector<uint8_t> > masks(n);
+  std::vector<int> to_align(n);
+  for (int k = 0; k < n; ++k) to_align[k] = k;
+
+  for (int alignment = 0; alignment < par.altali && !to_align.empty(); ++alignment) {
+    // round 0 runs on the resident set; later rounds on the (usually much smaller) surviving subset
+    SetGuard sub;
+    hhv_tset* ts = all.t;
+    const int m = (int)to_align.size();
+    if (alignment > 0) {
+      std::vector<int32_t> Ls(m);
+      std::vector<const float*> ps(m), trs(m);
+      for (int t = 0; t < m; ++t) {
+        Ls[t] = L[to_align[t]];
+        ps[t] = pp[to_align[t]];
+        trs[t] = tt[to_align[t]];
+      }
+      check(hhv_upload_templates(ctx.c, m, Ls.data(), ps.data(), trs.data(), &sub.t), "hhv_upload_templates");
+      ts = sub.t;
+      for (int t = 0; t < m; ++t)
+        check(hhv_set_celloff(ctx.c, ts, t, masks[to_align[t]].data()), "hhv_set_celloff");
+    }
+    std::vector<hhv_hit> hits(m);
+    check(hhv_align(ctx.c, ts, alignment > 0 ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, nullptr), "hhv_align");
+    check(hhv_hits(ctx.c, ts, hits.data()), "hhv_hits");
+
+    std::vector<int> next;
+    for (int t = 0; t < m; ++t) {
+      const int k = to_align[t];
+      const hhv_hit& h = hits[t];
+      Hit hit;
+      hit.entry = k;
+      hit.irep = alignment + 1;                       // :257
+      hit.lastrep = (h.score <= par.smin) ? 1 : 0;    // :37
+      hit.score = h.score;
+      hit.score_ss = 0.0f;
+      hit.score_aass = -h.score;                      // hhviterbi.cpp:252
+      hit.i1 = h.i1;
+      hit.j1 = h.j1;
+      hit.i2 = h.i2;
+      hit.j2 = h.j2;
+      hit.nsteps = h.nsteps;
+      hit.matched_cols = h.matched_cols;
+      const int cap = h.nsteps + 1;
+      hit.i.resize(cap);
+      hit.j.resize(cap);
+      hit.states.resize(cap);
+      hit.S.resize(cap);
+      hit.S_ss.assign(cap, 0.0f);
+      int32_t ns = 0;
+      check(hhv_hit_path(ctx.c, ts, t, cap, hit.i.data(), hit.j.data(), hit.states.data(), hit.S.data(), &ns),
+            "hhv_hit_path");
+      if (h.score > par.smin) {                       // :260-268
+        next.push_back(k);
+        if (masks[k].empty()) masks[k].assign((size_t)(q.L + 1) * (L[k] + 1), 0);
+        ExcludeAlignment(masks[k], q.L, L[k], hit.i.data(), hit.j.data(), hit.nsteps);
+      }
+      ret_hits.push_back(std::move(hit));
+    }
+    to_align.swap(next);
+  }
+  return ret_hits;
+}
+
+}  // namespace hhv
+
+// ---- C shim so that the parity tests (ctypes) can drive the C++ class ------------------------------
+extern "C" {
+
+struct hhvr_hit {
+  int32_t entry, irep, lastrep;
+  float score;
+  int32_t i1, j1, i2, j2, nsteps, matched_cols;
+};
+
+// Runs hhv::ViterbiRunner::alignment.  hits_out: cap_hits records; path arrays: per hit `path_cap`
+// entries at offset h*path_cap.  Returns the number of hits or a negative hhv_status.
+int hhvr_alignment(int device, int loc, float egq, float egt, float shift, float corr, float ssw, int ssm, int altali,
+                   float smin, const float* qp, const float* qtr, int Lq, int n, const int32_t* L,
+                   const float* const* p, const float* const* tr, hhvr_hit* hits_out, int cap_hits, int path_cap,
+                   int32_t* i_steps, int32_t* j_steps, int8_t* states, float* S) {
+  try {
+    hhv::Parameters par;
+    par.loc = loc;
+    par.egq = egq;
+    par.egt = egt;
+    par.shift = shift;
+    par.corr = corr;
+    par.ssw = ssw;
+    par.ssm = ssm;
+    par.altali = altali;
+    par.smin = smin;
+    hhv::Profile q;
+    q.L = Lq;
+    q.p = qp;
+    q.tr = qtr;
+    std::vector<hhv::Profile> ts(n);
+    for (int k = 0; k < n; ++k) {
+      ts[k].L = L[k];
+      ts[k].p = p[k];
+      ts[k].tr = tr[k];
+    }
+    hhv::ViterbiRunner runner(device);
+    std::vector<hhv::Hit> hits = runner.alignment(par, q, ts);
+    const int m = (int)hits.size();
+    for (int h = 0; h < m && h < cap_hits; ++h) {
+      const hhv::Hit& x = hits[h];
+      hhvr_hit o = {x.entry, x.irep, x.lastrep, x.score, x.i1, x.j1, x.i2, x.j2, x.nsteps, x.matched_cols};
+      hits_out[h] = o;
+      const int c = std::min(path_cap, x.nsteps + 1);
+      if (i_steps) memcpy(i_steps + (size_t)h * path_cap, x.i.data(), c * sizeof(int32_t));
+      if (j_steps) memcpy(j_steps + (size_t)h * path_cap, x.j.data(), c * sizeof(int32_t));
+      if (states) memcpy(states + (size_t)h * path_cap, x.states.data(), c);
+      if (S) memcpy(S + (size_t)h * path_cap, x.S.data(), c * sizeof(float));
+    }
+    return m;
+  } catch (const hhv::Error& e) {
+    return e.status;
+  } catch (...) {
+    return HHV_E_MEMORY;
+  }
+}
+
+}  // extern "C"

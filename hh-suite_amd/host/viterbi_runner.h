@@ -1,0 +1,80 @@
+// viterbi_runner.h -- C++ host layer ABOVE the C ABI: the MI355X counterpart of the reference's
+// ViterbiRunner (src/hhviterbirunner.h:50-58, src/hhviterbirunner.cpp:75-210).  It talks to the GPU
+// only through include/hhviterbi_hip.h; it contains no DP arithmetic.
+//
+// Same control flow as ViterbiRunner::alignment:
+//   for alignment = 0 .. par.altali-1                                   (:104)
+//     align every template still in the work list                       (:122-168)
+//       - templates that already produced hits are masked with the +-40 cross around every earlier
+//         path (exclude_alignments -> Viterbi::ExcludeAlignment, :152-155,273-289; hhviterbi.cpp:61-77)
+//     one Hit per template with irep = alignment+1                      (:35-62, :257)
+//     templates whose Hit.score > par.smin enter the next round         (:260-268)
+// Differences, by design: templates are uploaded once and stay resident (no per-batch MapHMMVector),
+// a round is one kernel launch instead of n/8 Align calls, hits are returned in template order per
+// round (the reference's order depends on OpenMP scheduling), errors are exceptions of type
+// hhv::Error carrying the C ABI status instead of exit().
+#pragma once
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hhviterbi_hip.h"
+
+namespace hhv {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+// the members of the reference's Parameters that the Viterbi stage consumes
+// (src/hhviterbirunner.h:32-33 and src/hhviterbirunner.cpp:104,260; defaults src/hhdecl.cpp:86-98)
+struct Parameters {
+  int loc = 1;          // par.loc
+  float egq = 0.0f;     // par.egq
+  float egt = 0.0f;     // par.egt
+  float shift = -0.03f; // par.shift
+  float corr = 0.1f;    // par.corr
+  float ssw = 0.11f;    // par.ssw
+  int ssm = 2;          // par.ssm
+  int altali = 4;       // par.altali
+  float smin = 20.0f;   // par.smin
+};
+
+// a prepared profile HMM (after PrepareQueryHMM / PrepareTemplateHMM): p[(L+1)*20], tr[(L+1)*7]
+struct Profile {
+  int L = 0;
+  const float* p = nullptr;
+  const float* tr = nullptr;
+};
+
+// the Hit fields ViterbiConsumerThread::align fills (src/hhviterbirunner.cpp:35-62)
+struct Hit {
+  int entry = -1;  // index of the template in the input list (reference: HHEntry* entry)
+  int irep = 0;    // index of the alternative alignment, 1-based (:257)
+  int lastrep = 0; // score <= smin (:37)
+  float score = 0, score_ss = 0, score_aass = 0;
+  int i1 = 0, j1 = 0, i2 = 0, j2 = 0, nsteps = 0, matched_cols = 0;
+  std::vector<int32_t> i, j;   // 1-based path arrays, index 0 unused, step 1 = alignment end
+  std::vector<int8_t> states;
+  std::vector<float> S, S_ss;
+};
+
+// Viterbi::ExcludeAlignment (src/hhviterbi.cpp:61-77): OR the +-VITERBI_PATH_WIDTH cross of one path
+// into mask[(Lq+1)*(Lt+1)]
+void ExcludeAlignment(std::vector<uint8_t>& mask, int Lq, int Lt, const int32_t* i_steps, const int32_t* j_steps,
+                      int nsteps);
+
+class ViterbiRunner {
+ public:
+  explicit ViterbiRunner(int device = 0) : device_(device) {}
+  // fetch_paths: also copy the per-hit path arrays (needed for alt rounds > 1 anyway)
+  std::vector<Hit> alignment(const Parameters& par, const Profile& q, const std::vector<Profile>& templates);
+
+ private:
+  int device_;
+};
+
+}  // namespace hhv

@@ -230,3 +230,52 @@ class Context:
         _check(self.lib.hhv_topk(self.h, ts.h, int(k), 1 if raw else 0, out.ctypes.data if fetch else None,
                                  C.c_void_p(d_out) if d_out else None, C.byref(n)))
         return (out[:n.value] if fetch else None), n.value
+
+
+# ---- C++ runner (hh-suite_amd/host/viterbi_runner.cpp) through its C shim --------------------------
+RUNNER_PATH = os.path.join(os.path.dirname(HERE), "lib", "libhhv_runner.so")
+RUNNER_HIT_DTYPE = np.dtype([("entry", np.int32), ("irep", np.int32), ("lastrep", np.int32), ("score", np.float32),
+                             ("i1", np.int32), ("j1", np.int32), ("i2", np.int32), ("j2", np.int32),
+                             ("nsteps", np.int32), ("matched_cols", np.int32)])
+_runner = None
+
+
+def load_runner():
+    global _runner
+    if _runner is None:
+        if not os.path.exists(RUNNER_PATH):
+            raise HhvError("libhhv_runner.so not built (%s)" % RUNNER_PATH)
+        load()
+        _runner = C.CDLL(RUNNER_PATH)
+        _runner.hhvr_alignment.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                           C.c_int, C.c_int, C.c_float, c_float_p, c_float_p, C.c_int, C.c_int,
+                                           c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return _runner
+
+
+def runner_alignment(qp, qtr, tps, ttrs, loc=1, egq=0.0, egt=0.0, shift=-0.03, corr=0.1, ssw=0.11, ssm=2, altali=4,
+                     smin=20.0, device=0):
+    """hhv::ViterbiRunner::alignment -> (hits structured array, i_steps, j_steps, states, S) with one row per hit."""
+    lib = load_runner()
+    qp, qtr = _f32(qp), _f32(qtr)
+    tps = [_f32(a) for a in tps]
+    ttrs = [_f32(a) for a in ttrs]
+    n = len(tps)
+    Lq = qp.shape[0] - 1
+    Ls = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+    pp = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in tps])
+    tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in ttrs])
+    cap = n * altali
+    pcap = Lq + int(Ls.max()) + 2
+    hits = np.zeros(cap, dtype=RUNNER_HIT_DTYPE)
+    i_s = np.zeros((cap, pcap), dtype=np.int32)
+    j_s = np.zeros((cap, pcap), dtype=np.int32)
+    st = np.zeros((cap, pcap), dtype=np.int8)
+    S = np.zeros((cap, pcap), dtype=np.float32)
+    m = lib.hhvr_alignment(device, loc, egq, egt, shift, corr, ssw, ssm, altali, smin, qp.ctypes.data_as(c_float_p),
+                           qtr.ctypes.data_as(c_float_p), Lq, n, Ls.ctypes.data_as(c_int_p), pp, tt, hits.ctypes.data,
+                           cap, pcap, i_s.ctypes.data, j_s.ctypes.data, st.ctypes.data, S.ctypes.data)
+    if m < 0:
+        raise HhvError("hhvr_alignment failed: %d: %s" % (m, load().hhv_last_error().decode()))
+    return hits[:m], i_s[:m], j_s[:m], st[:m], S[:m]

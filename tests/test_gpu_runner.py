@@ -1,0 +1,54 @@
+"""C++ host layer (hh-suite_amd/host/viterbi_runner.cpp = mirror of ViterbiRunner::alignment,
+/root/reference src/hhviterbirunner.cpp:75-210) against the same control flow executed with the oracle:
+alternative-alignment rounds with accumulated ExcludeAlignment masks, irep / lastrep / smin logic."""
+import numpy as np
+import pytest
+
+from common import same_float, workload
+from pyoracle import make_params
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_rounds(oracle, par, qf, qtr, tps, ttrs, altali, smin):
+    """ViterbiRunner::alignment (:104-189) with the oracle standing in for Viterbi::Align & co."""
+    Lq = qf.shape[0] - 1
+    n = len(tps)
+    masks = [None] * n
+    todo = list(range(n))
+    out = []
+    for r in range(altali):
+        nxt = []
+        for k in todo:
+            a = oracle.align(par, qf, qtr, tps[k], ttrs[k], celloff=masks[k] if r > 0 else None, want_path=True)
+            out.append((k, r + 1, a))
+            if float(a.hit_score) > smin:
+                nxt.append(k)
+                m = masks[k] if masks[k] is not None else np.zeros((Lq + 1, tps[k].shape[0]), dtype=np.uint8)
+                masks[k] = oracle.exclude_alignment(Lq, tps[k].shape[0] - 1, a.i_steps, a.j_steps, a.nsteps, mask=m)
+        todo = nxt
+        if not todo:
+            break
+    return out
+
+
+@pytest.mark.parametrize("local", [1, 0])
+def test_runner_alt_alignments(oracle, local):
+    from pyhhv import capi
+    par = make_params(local=local)
+    Lq = 180
+    qf, qtr, tps, ttrs = workload(60 + local, Lq, 10, 90, 220, homolog_every=2)
+    altali, smin = 4, 20.0
+    hits, i_s, j_s, st, S = capi.runner_alignment(qf, qtr, tps, ttrs, loc=local, altali=altali, smin=smin)
+    want = reference_rounds(oracle, par, qf, qtr, tps, ttrs, altali, smin)
+    assert len(hits) == len(want)
+    assert len(hits) > len(tps), "workload must trigger at least one alternative alignment"
+    for h, (k, irep, a), ii, jj, ss, sc in zip(hits, want, i_s, j_s, st, S):
+        assert (h["entry"], h["irep"]) == (k, irep)
+        assert same_float(h["score"], a.hit_score)
+        assert h["lastrep"] == int(float(a.hit_score) <= smin)
+        ns = a.nsteps
+        assert (h["i2"], h["j2"], h["nsteps"], h["matched_cols"]) == (a.i2, a.j2, ns, a.matched_cols)
+        assert (h["i1"], h["j1"]) == (a.i_steps[ns], a.j_steps[ns])
+        assert np.array_equal(ii[1:ns + 1], a.i_steps[1:ns + 1]) and np.array_equal(jj[1:ns + 1], a.j_steps[1:ns + 1])
+        assert np.array_equal(ss[1:ns + 1], a.states[1:ns + 1]) and np.array_equal(sc[1:ns + 1], a.S[1:ns + 1])
