@@ -137,24 +137,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
-                                device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        # backend "nccl" IS RCCL on ROCm; HHV_BENCH_BACKEND=gloo only exists to exercise the multi-rank code
+        # path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)
+        backend = os.environ.get("HHV_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", world_size=world, rank=rank, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, world_size=world, rank=rank)
 
     Lq, Lt, n = args.lq, args.lt, args.templates
     qf, qtr = synth.make_query(0x51000000, Lq)
     rec = gen_stream(torch, device, n, Lt, 0x5EED0000 + rank, synth.PB)
     torch.cuda.synchronize()
 
-    ctx = capi.Context(local=args.local, device=local_rank)
+    ctx = capi.Context(local=args.local, device=dev_index)
     ctx.set_query(qf, qtr)
     Ls = np.full(n, Lt, dtype=np.int32)
     ts = ctx.adopt_device_stream(Ls, rec.data_ptr())

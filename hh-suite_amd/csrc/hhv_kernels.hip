@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(LANES, (R <= 5 ? 2 : 1)) hhv_stream_kernel(Str
       if (meta < 0) {
         TemplateResult res;
         const int new_tid = __builtin_bit_cast(int32_t, rec[0]);
-        if (lane_header<R, LOCAL>(st, in, i0, new_tid, P, lane == g_last, res)) {
+        if (lane_header<R, LOCAL, !BT>(st, q, in, i0, new_tid, P, lane == g_last, res)) {
           DevResult o;
           o.score = res.score;
           o.i2 = res.i2;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(LANES, (R <= 5 ? 2 : 1)) hhv_stream_kernel(Str
         uint64_t* bte = nullptr;
         if (BT || CELLOFF) bte = a.bt + ((size_t)(rb + r) * LANES + lane);
         if (CELLOFF) cell = *bte;
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF>(st, q, in, rec, j, i0, r_last, P, cell);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT>(st, q, in, rec, j, i0, r_last, P, cell);
         if (BT) *bte = bytes;
       }
     }

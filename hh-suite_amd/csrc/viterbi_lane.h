@@ -137,6 +137,9 @@ template <int R>
 struct LaneState {
   float MM[R], GD[R], IM[R], DG[R], MI[R];  // own rows, column j-1 (the previous step)
   float dMM, dGD, dIM, dDG, dMI;            // row i0-1, column j-1 (top-row diagonal)
+  // SHARE variants: (MM(i-1,j-1) + q.M2M(i-1)) and (MI(i-1,j-1) + q.M2M(i-1)).  The same two sums feed MI(i,j-1)
+  // one step earlier (:358-366) and MM(i,j) now (:241-273), so they are computed once and carried.
+  float aMM[R], aMI[R];
   float bs[R];                              // running best per row ...
   int bj[R];                                // ... and its column (local mode: every row; global: row Lq only, slot 0)
   float fs;                                 // finalized best over lanes <= g for the template just finished
@@ -147,6 +150,7 @@ struct LaneState {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       MM[r] = GD[r] = IM[r] = DG[r] = MI[r] = NEG_MAX;
+      aMM[r] = aMI[r] = NEG_MAX;
       bs[r] = NEG_MAX;
       bj[r] = 0;
     }
@@ -180,9 +184,9 @@ struct TemplateResult {
 // Header record: finish the previous template (combine this lane's best with the prefix best that
 // flows down the lanes; the lane owning row Lq emits the result) and set the column-0 boundary
 // (:161-173: MM(i,0) = -i*egq, other states -FLT_MAX).  Returns true if `res` must be written.
-template <int R, bool LOCAL>
-HHV_DEV bool lane_header(LaneState<R>& st, const Incoming& in, int i0, int new_tid, const Params& P, bool is_last_lane,
-                         TemplateResult& res) {
+template <int R, bool LOCAL, bool SHARE>
+HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in, int i0, int new_tid, const Params& P,
+                         bool is_last_lane, TemplateResult& res) {
   bool emit = false;
   if (st.tid >= 0) {
     // best over own rows in row order, strict '>' (ties keep the smaller row, then the smaller column:
@@ -237,6 +241,13 @@ HHV_DEV bool lane_header(LaneState<R>& st, const Incoming& in, int i0, int new_t
   st.dIM = in.IM;
   st.dDG = in.DG;
   st.dMI = in.MI;
+  if (SHARE) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      st.aMM[r] = (r ? st.MM[r - 1] : in.MM) + q.m2m[r];
+      st.aMI[r] = (r ? st.MI[r - 1] : in.MI) + q.m2m[r];
+    }
+  }
   return emit;
 }
 
@@ -245,24 +256,30 @@ HHV_DEV bool lane_header(LaneState<R>& st, const Incoming& in, int i0, int new_t
 //   cellbits : CELLOFF only - byte r bit 7 set = cell (i0+r, j) excluded (same byte matrix the
 //              backtrace is written to, src/hhviterbialgorithm.cpp:373-392)
 //   returns  : BT only - byte r = backtrace byte of cell (i0+r, j) (bit layout src/hhviterbimatrix.h:35-48)
-template <int R, bool LOCAL, bool BT, bool CELLOFF>
+//
+// The R cells are evaluated in three phases so that every state register can be updated in place
+// (no loop-carried copies): A (rows bottom-up) everything that reads only column j-1 state - the five
+// MM candidates, GD and IM; B the R emission scores (independent dot products = the ILP of the
+// kernel); C (rows top-down) MM += S, then DG and MI which chain through the row above.
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE>
 HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const float* rec, int j, int i0,
                              int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits) {
   const float smin = LOCAL ? 0.0f : NEG_MAX;
   const float tM2M = rec[REC_M2M], tM2D = rec[REC_M2D], tD2M = rec[REC_D2M], tD2D = rec[REC_D2D],
               tI2M = rec[REC_I2M], tI2I = rec[REC_I2I], tM2I = rec[REC_M2I];
-  float dMM = st.dMM, dGD = st.dGD, dIM = st.dIM, dDG = st.dDG, dMI = st.dMI;  // (i-1, j-1)
-  float uMM = in.MM, uDG = in.DG, uMI = in.MI;                                 // (i-1, j)
-  uint64_t bytes = 0;
+  float cmax[R];
+  uint32_t bits[R];
+  // ---- phase A, rows R-1 .. 0: reads (i-1, j-1) = old state of the row above and (i, j-1) = own old state
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float lMM = st.MM[r], lGD = st.GD[r], lIM = st.IM[r], oDG = st.DG[r], oMI = st.MI[r];  // (i, j-1)
+  for (int r = R - 1; r >= 0; --r) {
+    const float dMM = r ? st.MM[r - 1] : st.dMM, dGD = r ? st.GD[r - 1] : st.dGD, dIM = r ? st.IM[r - 1] : st.dIM,
+                dDG = r ? st.DG[r - 1] : st.dDG, dMI = r ? st.MI[r - 1] : st.dMI;
     // :241-273
-    const float c1 = (dMM + q.m2m[r]) + tM2M;
+    const float c1 = (SHARE ? st.aMM[r] : (dMM + q.m2m[r])) + tM2M;
     const float c2 = (dGD + q.m2m[r]) + tD2M;
     const float c3 = (dIM + q.i2m[r]) + tM2M;
     const float c4 = (dDG + q.d2m[r]) + tM2M;
-    const float c5 = (dMI + q.m2m[r]) + tI2M;
+    const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
     float mm;
     uint32_t b = 0;
     if (BT) {
@@ -279,21 +296,41 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     } else {
       mm = fmax2(fmax2(fmax2(fmax2(fmax2(smin, c1), c2), c3), c4), c5);
     }
-    // :277-283
-    const float S = log2f4(dot20(q.p[r], rec)) + P.shift;
-    mm = mm + S;
-    // :307-366
-    const float ga = lMM + tM2D, gb = lGD + tD2D;
-    float gd = fmax2(ga, gb);
-    const float ia = (lMM + q.m2i[r]) + tM2M, ib = (lIM + q.i2i[r]) + tM2M;
-    float im = fmax2(ia, ib);
-    const float da = uMM + q.m2d[r], db = uDG + q.d2d[r];
-    float dg = fmax2(da, db);
-    const float ma = (uMM + q.m2m[r]) + tM2I, mb = (uMI + q.m2m[r]) + tI2I;
-    float mi = fmax2(ma, mb);
+    cmax[r] = mm;
+    // :307-332 (GD and IM read only the cell to the left)
+    const float lMM = st.MM[r];
+    const float ga = lMM + tM2D, gb = st.GD[r] + tD2D;
+    const float ia = (lMM + q.m2i[r]) + tM2M, ib = (st.IM[r] + q.i2i[r]) + tM2M;
     if (BT) {
       b |= (ga > gb) ? 8u : 0u;
       b |= (ia > ib) ? 16u : 0u;
+    }
+    bits[r] = b;
+    st.GD[r] = fmax2(ga, gb);
+    st.IM[r] = fmax2(ia, ib);
+  }
+  // ---- phase B: :277-283
+  float S[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) S[r] = log2f4(dot20(q.p[r], rec)) + P.shift;
+  // ---- phase C, rows 0 .. R-1: (i-1, j) = new state of the row above
+  float uMM = in.MM, uDG = in.DG, uMI = in.MI;
+  uint64_t bytes = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float mm = cmax[r] + S[r];
+    // :340-366
+    const float da = uMM + q.m2d[r], db = uDG + q.d2d[r];
+    float dg = fmax2(da, db);
+    const float sa = uMM + q.m2m[r], sb = uMI + q.m2m[r];
+    const float ma = sa + tM2I, mb = sb + tI2I;
+    float mi = fmax2(ma, mb);
+    if (SHARE) {
+      st.aMM[r] = sa;
+      st.aMI[r] = sb;
+    }
+    if (BT) {
+      uint32_t b = bits[r];
       b |= (da > db) ? 32u : 0u;
       b |= (ma > mb) ? 64u : 0u;
       bytes |= (uint64_t)b << (8 * r);
@@ -301,8 +338,8 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     if (CELLOFF) {  // :373-392: the masked build adds -FLT_MAX or +0.0f to all five states of every cell
       const float add = ((cellbits >> (8 * r)) & 0x80u) ? NEG_MAX : 0.0f;
       mm = mm + add;
-      gd = gd + add;
-      im = im + add;
+      st.GD[r] = st.GD[r] + add;
+      st.IM[r] = st.IM[r] + add;
       dg = dg + add;
       mi = mi + add;
     }
@@ -311,20 +348,12 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
       st.bs[r] = up ? mm : st.bs[r];
       st.bj[r] = up ? j : st.bj[r];
     }
-    // roll: this row's column j-1 values are the next row's diagonal, its new values the next row's "up"
-    dMM = lMM;
-    dGD = lGD;
-    dIM = lIM;
-    dDG = oDG;
-    dMI = oMI;
+    st.MM[r] = mm;
+    st.DG[r] = dg;
+    st.MI[r] = mi;
     uMM = mm;
     uDG = dg;
     uMI = mi;
-    st.MM[r] = mm;
-    st.GD[r] = gd;
-    st.IM[r] = im;
-    st.DG[r] = dg;
-    st.MI[r] = mi;
   }
   if (!LOCAL) {
     // global alignment: row Lq is maximised over all columns (:192,423); r_last is wave uniform

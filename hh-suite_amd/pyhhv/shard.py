@@ -65,9 +65,12 @@ def exchange_and_merge(torch, dist, local_records, K, group=None):
     world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
     if world == 1:
         return merge_records(torch, local_records, K)
-    gathered = torch.empty((world * K, REC_I32), dtype=torch.int32, device=local_records.device)
-    dist.all_gather_into_tensor(gathered, local_records.contiguous(), group=group)
-    return merge_records(torch, gathered, K)
+    src = local_records.contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":   # debug path only (see bench.py HHV_BENCH_BACKEND)
+        src = src.cpu()
+    gathered = torch.empty((world * K, REC_I32), dtype=torch.int32, device=src.device)
+    dist.all_gather_into_tensor(gathered, src, group=group)
+    return merge_records(torch, gathered.to(local_records.device), K)
 
 
 def to_global_ids(torch, records, global_ids):

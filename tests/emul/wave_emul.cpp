@@ -51,7 +51,7 @@ static int run_wave(const float* qpack, const float* records, long M, Params P, 
         int32_t new_tid;
         memcpy(&new_tid, rec + 0, 4);
         TemplateResult res;
-        if (lane_header<R, LOCAL>(st[g], in, i0, new_tid, P, g == g_last, res)) {
+        if (lane_header<R, LOCAL, !BT>(st[g], q[g], in, i0, new_tid, P, g == g_last, res)) {
           if (res.tid >= 0 && res.tid < n_results) results[res.tid] = res;
           emitted++;
         }
@@ -59,7 +59,7 @@ static int run_wave(const float* qpack, const float* records, long M, Params P, 
         const int j = meta & META_JMASK;
         uint64_t cell = 0;
         if (CELLOFF) cell = bt[(size_t)r * 64 + g];
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF>(st[g], q[g], in, rec, j, i0, r_last, P, cell);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT>(st[g], q[g], in, rec, j, i0, r_last, P, cell);
         if (BT) bt[(size_t)r * 64 + g] = bytes;
       }
     }
