@@ -59,9 +59,9 @@ struct hhv_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
   int num_cus = 0;
-  // query
-  int Lq = 0, R = 0;
-  float* d_qpack = nullptr;  // [64*R][28]
+  // query: P passes of 64*R rows each (P = 1 up to Lq = 320)
+  int Lq = 0, R = 0, P = 0;
+  float* d_qpack = nullptr;  // [P*64*R][28]
   float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring
   // fast_log2 tables (src/util-inl.h:108-130)
   float* d_lg2 = nullptr;
@@ -82,10 +82,13 @@ struct hhv_tset {
   // wave partition
   int n_waves = 0;
   int64_t* d_wave_rec = nullptr;
-  // backtrace bytes
+  // backtrace bytes: [pass][record][lane] entries
   uint64_t* d_bt = nullptr;
   bool bt_valid = false;
-  int bt_Lq = 0, bt_R = 0;
+  int bt_Lq = 0, bt_R = 0, bt_P = 0;
+  // carry between the passes of a long query
+  float4* d_carry = nullptr;
+  float* d_carry_mi = nullptr;
   // trace outputs
   std::vector<int64_t> path_off;
   int path_Lq = -1;
@@ -193,11 +196,23 @@ void hhv_destroy(hhv_ctx* c) {
 int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   if (!c || !p || !tr) return fail(HHV_E_ARG, "hhv_set_query: null argument");
   if (Lq < 1) return fail(HHV_E_ARG, "hhv_set_query: Lq = %d", Lq);
-  const int R = (Lq + LANES - 1) / LANES;
-  if (R > MAX_R)
-    return fail(HHV_E_LIMIT, "hhv_set_query: Lq = %d exceeds the single-pass limit of %d rows", Lq, MAX_R * LANES);
+  if (Lq > 0x7FFF) return fail(HHV_E_LIMIT, "hhv_set_query: Lq = %d exceeds 32767", Lq);
+  // strips of 64*R rows (R <= 5 keeps the kernel at 2 waves/SIMD): fewest padded rows, then fewest passes
+  int R = 1, P = 0;
+  {
+    long best_rows = -1;
+    for (int r = 1; r <= MAX_R; ++r) {
+      const int p = (Lq + LANES * r - 1) / (LANES * r);
+      const long rows = (long)p * LANES * r;
+      if (best_rows < 0 || rows < best_rows || (rows == best_rows && p < P)) {
+        best_rows = rows;
+        R = r;
+        P = p;
+      }
+    }
+  }
   HIP_TRY(hipSetDevice(c->par.device));
-  std::vector<float> qpack((size_t)LANES * R * REC_DW, 0.0f);
+  std::vector<float> qpack((size_t)P * LANES * R * REC_DW, 0.0f);
   pack_columns(p, tr, Lq, qpack.data());
   dfree(c->d_qpack);
   dfree(c->d_qp);
@@ -208,6 +223,7 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->Lq = Lq;
   c->R = R;
+  c->P = P;
   return HHV_OK;
 }
 
@@ -317,6 +333,8 @@ void hhv_tset_free(hhv_tset* ts) {
   dfree(ts->d_results);
   dfree(ts->d_wave_rec);
   dfree(ts->d_bt);
+  dfree(ts->d_carry);
+  dfree(ts->d_carry_mi);
   dfree(ts->d_path_off);
   dfree(ts->d_i_steps);
   dfree(ts->d_j_steps);
@@ -362,13 +380,14 @@ static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_waves) {
 }
 
 static int ensure_bt(hhv_ctx* c, hhv_tset* ts) {
-  if (ts->d_bt && ts->bt_R == c->R) return HHV_OK;
+  if (ts->d_bt && ts->bt_R == c->R && ts->bt_P == c->P) return HHV_OK;
   dfree(ts->d_bt);
-  const size_t bytes = (size_t)ts->n_records * LANES * sizeof(uint64_t);
+  const size_t bytes = (size_t)c->P * ts->n_records * LANES * sizeof(uint64_t);
   if (hipMalloc(&ts->d_bt, bytes) != hipSuccess)
     return fail(HHV_E_MEMORY, "backtrace buffer of %zu bytes does not fit on the device", bytes);
   HIP_TRY(hipMemsetAsync(ts->d_bt, 0, bytes, c->stream));
   ts->bt_R = c->R;
+  ts->bt_P = c->P;
   ts->bt_valid = false;
   return HHV_OK;
 }
@@ -404,9 +423,26 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.egt = c->par.egt;
   a.shift = c->par.shift;
   a.Lq = c->Lq;
+  a.carry = nullptr;
+  a.carry_mi = nullptr;
+  a.bt_pass_stride = ts->n_records * LANES;
+  if (c->P > 1) {
+    if (!ts->d_carry) {
+      HIP_TRY(hipMalloc(&ts->d_carry, (size_t)ts->n_records * sizeof(float4)));
+      HIP_TRY(hipMalloc(&ts->d_carry_mi, (size_t)ts->n_records * sizeof(float)));
+    }
+    a.carry = ts->d_carry;
+    a.carry_mi = ts->d_carry_mi;
+  }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  rc = launch_stream(c->R, local, bt, celloff, a, n_waves, c->stream);
-  if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  for (int pass = 0; pass < c->P; ++pass) {
+    a.qpack = c->d_qpack + (size_t)pass * LANES * c->R * REC_DW;
+    a.row_base = pass * LANES * c->R;
+    a.pass_first = pass == 0;
+    a.pass_last = pass == c->P - 1;
+    rc = launch_stream(c->R, local, bt, celloff, a, n_waves, c->stream);
+    if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->ev_valid = true;
   if (d_out) {
@@ -454,19 +490,23 @@ int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
   int rc = ensure_bt(c, ts);
   if (rc != HHV_OK) return rc;
   const int Lt = ts->L[k], Lq = c->Lq, R = c->R;
-  // entries of columns 1..Lt: [Lt][64] x 8 bytes; only bit 7 of each byte is an input of the kernel
-  std::vector<uint64_t> e((size_t)Lt * LANES, 0);
-  if (mask) {
-    for (int i = 1; i <= Lq; ++i) {
-      const int g = (i - 1) / R, r = (i - 1) % R;
-      const uint8_t* row = mask + (size_t)i * (Lt + 1);
-      for (int j = 1; j <= Lt; ++j)
-        if (row[j]) e[(size_t)(j - 1) * LANES + g] |= (uint64_t)0x80 << (8 * r);
+  // per pass: entries of columns 1..Lt: [Lt][64] x 8 bytes; only bit 7 of each byte is an input of the kernel
+  std::vector<uint64_t> e((size_t)Lt * LANES);
+  for (int pass = 0; pass < c->P; ++pass) {
+    std::fill(e.begin(), e.end(), 0);
+    if (mask) {
+      const int ilo = pass * LANES * R + 1, ihi = std::min(Lq, (pass + 1) * LANES * R);
+      for (int i = ilo; i <= ihi; ++i) {
+        const int g = (i - ilo) / R, r = (i - ilo) % R;
+        const uint8_t* row = mask + (size_t)i * (Lt + 1);
+        for (int j = 1; j <= Lt; ++j)
+          if (row[j]) e[(size_t)(j - 1) * LANES + g] |= (uint64_t)0x80 << (8 * r);
+      }
     }
+    HIP_TRY(hipMemcpyAsync(ts->d_bt + (size_t)pass * ts->n_records * LANES + (size_t)(ts->rec_off[k] + 1) * LANES,
+                           e.data(), e.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
   }
-  HIP_TRY(hipMemcpyAsync(ts->d_bt + (size_t)(ts->rec_off[k] + 1) * LANES, e.data(), e.size() * sizeof(uint64_t),
-                         hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
   ts->bt_valid = false;
   return HHV_OK;
 }
@@ -479,13 +519,16 @@ int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
   const int Lt = ts->L[k], Lq = ts->bt_Lq, R = ts->bt_R;
   std::vector<uint64_t> e((size_t)Lt * LANES);
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpy(e.data(), ts->d_bt + (size_t)(ts->rec_off[k] + 1) * LANES, e.size() * sizeof(uint64_t),
-                    hipMemcpyDeviceToHost));
   memset(out, 0, (size_t)(Lq + 1) * (Lt + 1));
-  for (int i = 1; i <= Lq; ++i) {
-    const int g = (i - 1) / R, r = (i - 1) % R;
-    uint8_t* row = out + (size_t)i * (Lt + 1);
-    for (int j = 1; j <= Lt; ++j) row[j] = (uint8_t)(e[(size_t)(j - 1) * LANES + g] >> (8 * r));
+  for (int pass = 0; pass < ts->bt_P; ++pass) {
+    HIP_TRY(hipMemcpy(e.data(), ts->d_bt + (size_t)pass * ts->n_records * LANES + (size_t)(ts->rec_off[k] + 1) * LANES,
+                      e.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const int ilo = pass * LANES * R + 1, ihi = std::min(Lq, (pass + 1) * LANES * R);
+    for (int i = ilo; i <= ihi; ++i) {
+      const int g = (i - ilo) / R, r = (i - ilo) % R;
+      uint8_t* row = out + (size_t)i * (Lt + 1);
+      for (int j = 1; j <= Lt; ++j) row[j] = (uint8_t)(e[(size_t)(j - 1) * LANES + g] >> (8 * r));
+    }
   }
   return HHV_OK;
 }
@@ -541,6 +584,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.Lq = c->Lq;
   a.R = ts->bt_R;
   a.n = ts->n;
+  a.bt_pass_stride = ts->n_records * LANES;
   rc = launch_trace(a, c->stream);
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   ts->hits_valid = true;

@@ -1,11 +1,12 @@
 // hhv_internal.h -- structures shared between the HIP kernels and the C-ABI host layer.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 namespace hhv {
 
 constexpr int LANES = 64;          // wavefront width on gfx950
-constexpr int MAX_R = 8;           // query rows per lane -> single pass handles Lq <= 512
+constexpr int MAX_R = 5;           // query rows per lane (<= 256 VGPRs, 2 waves/SIMD); one pass covers 64*R rows
 constexpr int CHUNK_RECS = 32;     // records per LDS refill (3.5 x 1 KiB global_load_lds_dwordx4)
 constexpr int RING_CHUNKS = 4;     // the 64-record live window spans <= 3 chunks, the fourth is in flight
 constexpr int RING_RECS = CHUNK_RECS * RING_CHUNKS;
@@ -35,6 +36,13 @@ struct StreamArgs {
   uint64_t* bt;              // [n_records][64] backtrace entries (BT / CELLOFF variants)
   float egq, egt, shift;
   int32_t Lq;
+  // multi-pass strips (Lq > 64*R): pass p handles query rows row_base+1 .. row_base+64*R
+  int32_t row_base;          // p * 64 * R
+  int32_t pass_first;        // lane 0 takes the DP boundary row 0 (else: the carry of the previous pass)
+  int32_t pass_last;         // the lane owning row Lq emits the result (else: lane 63 writes the carry)
+  float4* carry;             // [n_records] bottom-row state {MM,GD,IM,DG} of the previous / for the next pass ...
+  float* carry_mi;           // ... and MI
+  int64_t bt_pass_stride;    // backtrace entries per pass = n_records * 64
 };
 
 struct TraceArgs {
@@ -55,6 +63,7 @@ struct TraceArgs {
   float corr;
   int32_t ss_mode;
   int32_t Lq, R, n;
+  int64_t bt_pass_stride;    // backtrace entries per pass (rows are split in passes of 64*R)
 };
 
 // launchers implemented in hhv_kernels.hip

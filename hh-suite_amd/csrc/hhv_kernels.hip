@@ -48,7 +48,7 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int c
 // VOP2 every ~6.3 clk, two waves one every ~2.5 clk: tools/valu_ubench).  Up to R = 5 rows per lane the
 // kernel is held to <= 256 VGPRs (2 waves/SIMD; the backtrace variants spill a few dwords to scratch).
 template <int R, bool LOCAL, bool BT, bool CELLOFF>
-__global__ void __launch_bounds__(LANES, (R <= 5 ? 2 : 1)) hhv_stream_kernel(StreamArgs a) {
+__global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   __shared__ float4 ring[RING_RECS * 7];
   const int lane = threadIdx.x;
   const int64_t rb = a.wave_rec[blockIdx.x];
@@ -61,9 +61,12 @@ __global__ void __launch_bounds__(LANES, (R <= 5 ? 2 : 1)) hhv_stream_kernel(Str
   P.egt = a.egt;
   P.shift = a.shift;
   P.Lq = a.Lq;
-  const int i0 = lane * R + 1;
-  const int g_last = (a.Lq - 1) / R;
-  const int r_last = (a.Lq - 1) % R;
+  const int i0 = a.row_base + lane * R + 1;
+  // the lane that emits results: owner of row Lq in the last pass, lane 63 otherwise
+  const int g_last = a.pass_last ? (a.Lq - a.row_base - 1) / R : LANES - 1;
+  const int r_last = (a.Lq - a.row_base - 1) % R;
+  const bool first = a.pass_first != 0;
+  const bool carry_out = a.pass_last == 0;
 
   const float4* src = (const float4*)a.records + rb * 7;
   const int nchunks = (M + CHUNK_RECS - 1) / CHUNK_RECS;
@@ -104,8 +107,24 @@ __global__ void __launch_bounds__(LANES, (R <= 5 ? 2 : 1)) hhv_stream_kernel(Str
     }
     const int32_t meta = __builtin_bit_cast(int32_t, rec[REC_META]);
 
-    // hand-off from lane g-1 (full EXEC here); lane 0 takes the DP boundary row 0
-    const Incoming bnd = boundary_incoming(meta, P);
+    // hand-off from lane g-1 (full EXEC here); lane 0 takes the DP boundary row 0, or - in later passes of
+    // a long query - the bottom row the previous pass left for this record (and its running best)
+    Incoming bnd = boundary_incoming(meta, P);
+    if (!first) {
+      if (lane == 0 && active) {
+        const float4 c = a.carry[rb + r];
+        bnd.MM = c.x;
+        bnd.GD = c.y;
+        bnd.IM = c.z;
+        bnd.DG = c.w;
+        bnd.MI = a.carry_mi[rb + r];
+        if (meta < 0 && st.tid >= 0) {
+          const DevResult pr = a.results[st.tid];
+          bnd.fs = pr.score;
+          bnd.fpos = (pr.i2 << 16) | pr.j2;
+        }
+      }
+    }
     Incoming in;
     in.MM = dpp_shr1(bnd.MM, st.MM[R - 1]);
     in.GD = dpp_shr1(bnd.GD, st.GD[R - 1]);
@@ -131,10 +150,16 @@ __global__ void __launch_bounds__(LANES, (R <= 5 ? 2 : 1)) hhv_stream_kernel(Str
         const int j = meta & META_JMASK;
         uint64_t cell = 0;
         uint64_t* bte = nullptr;
-        if (BT || CELLOFF) bte = a.bt + ((size_t)(rb + r) * LANES + lane);
+        if (BT || CELLOFF) bte = a.bt + ((size_t)(a.row_base / (LANES * R)) * a.bt_pass_stride + (size_t)(rb + r) * LANES + lane);
         if (CELLOFF) cell = *bte;
         const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT>(st, q, in, rec, j, i0, r_last, P, cell);
         if (BT) *bte = bytes;
+      }
+      if (carry_out) {
+        if (lane == LANES - 1) {
+          a.carry[rb + r] = make_float4(st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1]);
+          a.carry_mi[rb + r] = st.MI[R - 1];
+        }
       }
     }
   }
@@ -184,8 +209,9 @@ __global__ void __launch_bounds__(256) hhv_trace_kernel(TraceArgs a) {
     j_steps[step] = j;
     uint32_t b = 0;
     if (i >= 1 && j >= 1) {
-      const int g = (i - 1) / R, rr = (i - 1) - g * R;
-      b = (uint32_t)(a.bt[(size_t)(rec0 + j) * LANES + g] >> (8 * rr)) & 0xFFu;
+      const int strip = (i - 1) / R, rr = (i - 1) - strip * R;  // strip = pass * 64 + lane
+      const int pass = strip / LANES, g = strip - pass * LANES;
+      b = (uint32_t)(a.bt[(size_t)pass * a.bt_pass_stride + (size_t)(rec0 + j) * LANES + g] >> (8 * rr)) & 0xFFu;
     }
     switch (state) {
       case 2:  // MM
@@ -287,9 +313,6 @@ static void* pick(int R, bool local, bool bt, bool celloff) {
     case 3: return pick_variant<3>(local, bt, celloff);
     case 4: return pick_variant<4>(local, bt, celloff);
     case 5: return pick_variant<5>(local, bt, celloff);
-    case 6: return pick_variant<6>(local, bt, celloff);
-    case 7: return pick_variant<7>(local, bt, celloff);
-    case 8: return pick_variant<8>(local, bt, celloff);
   }
   return nullptr;
 }

@@ -18,9 +18,23 @@ META_LAST = np.int32(0x40000000)
 LANES = 64
 
 
+MAX_R = 5
+
+
+def strips_for(Lq):
+    """(R, P): query rows per lane and number of passes of 64*R rows (hhv_set_query's rule: fewest
+    padded rows, then fewest passes; R <= 5 keeps the kernel at 2 waves per SIMD)."""
+    best = None
+    for r in range(1, MAX_R + 1):
+        p = -(-int(Lq) // (LANES * r))
+        rows = p * LANES * r
+        if best is None or rows < best[0] or (rows == best[0] and p < best[2]):
+            best = (rows, r, p)
+    return best[1], best[2]
+
+
 def rows_for(Lq):
-    """Query rows per lane: smallest R with 64*R >= Lq."""
-    return max(1, -(-int(Lq) // LANES))
+    return strips_for(Lq)[0]
 
 
 def pack_columns(p, tr):
@@ -40,12 +54,14 @@ def pack_columns(p, tr):
     return rec
 
 
-def pack_query(p, tr, R=None):
-    """(64*R, 28) float32: row i-1 of the array = query row i; rows > Lq are zero."""
+def pack_query(p, tr, R=None, P=None):
+    """(P*64*R, 28) float32: row i-1 of the array = query row i; rows > Lq are zero."""
     Lq = p.shape[0] - 1
     if R is None:
-        R = rows_for(Lq)
-    out = np.zeros((LANES * R, REC_DW), dtype=np.float32)
+        R, P = strips_for(Lq)
+    if P is None:
+        P = -(-Lq // (LANES * R))
+    out = np.zeros((P * LANES * R, REC_DW), dtype=np.float32)
     out[:Lq] = pack_columns(p, tr)
     return out
 
@@ -79,21 +95,22 @@ def pack_stream(tps, ttrs):
 def bt_to_matrix(bt_entries, rec_off_k, Lq, Lt, R, entry_bytes=8):
     """Device backtrace layout -> reference layout (Lq+1, Lt+1) bytes.
     bt_entries: flat uint8 view of the [record][lane][entry_bytes] buffer."""
-    e = np.asarray(bt_entries, dtype=np.uint8).reshape(-1, LANES, entry_bytes)
+    P = -(-Lq // (LANES * R))
+    e = np.asarray(bt_entries, dtype=np.uint8).reshape(P, -1, LANES, entry_bytes)   # [pass][record][lane][row]
     out = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
-    blk = e[rec_off_k + 1: rec_off_k + 1 + Lt]          # (Lt, 64, eb) : column j-1, lane, row-in-lane
     for i in range(1, Lq + 1):
-        g, r = (i - 1) // R, (i - 1) % R
-        out[i, 1:] = blk[:, g, r]
+        strip, r = (i - 1) // R, (i - 1) % R
+        out[i, 1:] = e[strip // LANES, rec_off_k + 1: rec_off_k + 1 + Lt, strip % LANES, r]
     return out
 
 
 def matrix_to_bt(mask, rec_off_k, R, bt_entries, entry_bytes=8, bit=0x80):
     """Scatter a (Lq+1, Lt+1) 0/1 cell-off mask into bit 7 of the device backtrace buffer."""
-    e = np.asarray(bt_entries).reshape(-1, LANES, entry_bytes)
     Lq, Lt = mask.shape[0] - 1, mask.shape[1] - 1
+    P = -(-Lq // (LANES * R))
+    e = np.asarray(bt_entries).reshape(P, -1, LANES, entry_bytes)
     for i in range(1, Lq + 1):
-        g, r = (i - 1) // R, (i - 1) % R
-        col = e[rec_off_k + 1: rec_off_k + 1 + Lt, g, r]
+        strip, r = (i - 1) // R, (i - 1) % R
+        col = e[strip // LANES, rec_off_k + 1: rec_off_k + 1 + Lt, strip % LANES, r]
         col[:] = np.where(mask[i, 1:] != 0, col | bit, col & ~np.uint8(bit))
     return bt_entries

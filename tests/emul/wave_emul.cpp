@@ -14,17 +14,23 @@
 
 using namespace hhv;
 
+// One pass over the wave's stream (mirrors hhv_stream_kernel, incl. the multi-pass carry of long queries).
+struct Carry {
+  float MM, GD, IM, DG, MI;
+};
+
 template <int R, bool LOCAL, bool BT, bool CELLOFF>
-static int run_wave(const float* qpack, const float* records, long M, Params P, TemplateResult* results, int n_results,
-                    uint64_t* bt /* M x 64 entries, in/out */) {
+static int run_pass(const float* qpack, const float* records, long M, Params P, TemplateResult* results, int n_results,
+                    uint64_t* bt /* M x 64 entries of this pass, in/out */, int row_base, bool first, bool last,
+                    std::vector<Carry>& carry) {
   std::vector<LaneState<R>> st(64);
   std::vector<QRows<R>> q(64);
   for (int g = 0; g < 64; ++g) {
     st[g].reset();
     q[g].load(qpack + (size_t)g * R * REC_DW);
   }
-  const int g_last = (P.Lq - 1) / R;
-  const int r_last = (P.Lq - 1) % R;
+  const int g_last = last ? (P.Lq - row_base - 1) / R : 63;
+  const int r_last = (P.Lq - row_base - 1) % R;
   int emitted = 0;
   for (long s = 0; s < M + 63; ++s) {
     for (int g = 63; g >= 0; --g) {
@@ -36,6 +42,17 @@ static int run_wave(const float* qpack, const float* records, long M, Params P, 
       Incoming in;
       if (g == 0) {
         in = boundary_incoming(meta, P);
+        if (!first) {
+          in.MM = carry[r].MM;
+          in.GD = carry[r].GD;
+          in.IM = carry[r].IM;
+          in.DG = carry[r].DG;
+          in.MI = carry[r].MI;
+          if (meta < 0 && st[0].tid >= 0 && st[0].tid < n_results) {
+            in.fs = results[st[0].tid].score;
+            in.fpos = (results[st[0].tid].i2 << 16) | results[st[0].tid].j2;
+          }
+        }
       } else {
         const LaneState<R>& a = st[g - 1];
         in.MM = a.MM[R - 1];
@@ -46,7 +63,7 @@ static int run_wave(const float* qpack, const float* records, long M, Params P, 
         in.fs = a.fs;
         in.fpos = a.fpos;
       }
-      const int i0 = g * R + 1;
+      const int i0 = row_base + g * R + 1;
       if (meta < 0) {
         int32_t new_tid;
         memcpy(&new_tid, rec + 0, 4);
@@ -62,43 +79,58 @@ static int run_wave(const float* qpack, const float* records, long M, Params P, 
         const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT>(st[g], q[g], in, rec, j, i0, r_last, P, cell);
         if (BT) bt[(size_t)r * 64 + g] = bytes;
       }
+      if (!last && g == 63) {
+        Carry c = {st[g].MM[R - 1], st[g].GD[R - 1], st[g].IM[R - 1], st[g].DG[R - 1], st[g].MI[R - 1]};
+        carry[r] = c;
+      }
     }
+  }
+  return emitted;
+}
+
+// qpack holds passes * 64 * R rows; bt holds passes planes of M x 64 entries
+template <int R, bool LOCAL, bool BT, bool CELLOFF>
+static int run_wave(const float* qpack, const float* records, long M, Params P, TemplateResult* results, int n_results,
+                    uint64_t* bt, int passes) {
+  std::vector<Carry> carry(M);
+  int emitted = 0;
+  for (int p = 0; p < passes; ++p) {
+    emitted = run_pass<R, LOCAL, BT, CELLOFF>(qpack + (size_t)p * 64 * R * REC_DW, records, M, P, results, n_results,
+                                              bt ? bt + (size_t)p * M * 64 : nullptr, p * 64 * R, p == 0, p == passes - 1,
+                                              carry);
   }
   return emitted;
 }
 
 template <int R>
 static int dispatch(int local, int want_bt, int celloff, const float* qpack, const float* records, long M, Params P,
-                    TemplateResult* results, int n_results, uint64_t* bt) {
+                    TemplateResult* results, int n_results, uint64_t* bt, int passes) {
   if (celloff) {
-    return local ? run_wave<R, true, true, true>(qpack, records, M, P, results, n_results, bt)
-                 : run_wave<R, false, true, true>(qpack, records, M, P, results, n_results, bt);
+    return local ? run_wave<R, true, true, true>(qpack, records, M, P, results, n_results, bt, passes)
+                 : run_wave<R, false, true, true>(qpack, records, M, P, results, n_results, bt, passes);
   }
   if (want_bt) {
-    return local ? run_wave<R, true, true, false>(qpack, records, M, P, results, n_results, bt)
-                 : run_wave<R, false, true, false>(qpack, records, M, P, results, n_results, bt);
+    return local ? run_wave<R, true, true, false>(qpack, records, M, P, results, n_results, bt, passes)
+                 : run_wave<R, false, true, false>(qpack, records, M, P, results, n_results, bt, passes);
   }
-  return local ? run_wave<R, true, false, false>(qpack, records, M, P, results, n_results, bt)
-               : run_wave<R, false, false, false>(qpack, records, M, P, results, n_results, bt);
+  return local ? run_wave<R, true, false, false>(qpack, records, M, P, results, n_results, bt, passes)
+               : run_wave<R, false, false, false>(qpack, records, M, P, results, n_results, bt, passes);
 }
 
 extern "C" int hhv_emul_wave(int R, int local, int want_bt, int celloff, const float* qpack, const float* records,
                              long M, float egq, float egt, float shift, int Lq, TemplateResult* results,
-                             int n_results, uint64_t* bt) {
+                             int n_results, uint64_t* bt, int passes) {
   Params P;
   P.egq = egq;
   P.egt = egt;
   P.shift = shift;
   P.Lq = Lq;
   switch (R) {
-    case 1: return dispatch<1>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
-    case 2: return dispatch<2>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
-    case 3: return dispatch<3>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
-    case 4: return dispatch<4>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
-    case 5: return dispatch<5>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
-    case 6: return dispatch<6>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
-    case 7: return dispatch<7>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
-    case 8: return dispatch<8>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt);
+    case 1: return dispatch<1>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
+    case 2: return dispatch<2>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
+    case 3: return dispatch<3>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
+    case 4: return dispatch<4>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
+    case 5: return dispatch<5>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
   }
   return -1;
 }

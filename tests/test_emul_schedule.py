@@ -26,29 +26,29 @@ def emul():
         subprocess.check_call(["make", "-C", ROOT, "emul"])
     lib = C.CDLL(SO)
     lib.hhv_emul_wave.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_float,
-                                                  C.c_int, C.POINTER(TR), C.c_int, C.c_void_p]
+                                                  C.c_int, C.POINTER(TR), C.c_int, C.c_void_p, C.c_int]
     return lib
 
 
 def run(emul, par, qf, qtr, tps, ttrs, want_bt, bt_in=None):
     Lq = qf.shape[0] - 1
-    R = pack.rows_for(Lq)
-    qpack = pack.pack_query(qf, qtr, R)
+    R, P = pack.strips_for(Lq)
+    qpack = pack.pack_query(qf, qtr, R, P)
     rec, off = pack.pack_stream(tps, ttrs)
     M = rec.shape[0]
     n = len(tps)
     res = (TR * n)()
-    bt = np.zeros((M, 64), dtype=np.uint64) if bt_in is None else bt_in
+    bt = np.zeros((P, M, 64), dtype=np.uint64) if bt_in is None else bt_in
     em = emul.hhv_emul_wave(R, par["local"], int(want_bt), int(bt_in is not None), qpack.ctypes.data, rec.ctypes.data,
-                            M, par["egq"], par["egt"], par["shift"], Lq, res, n, bt.ctypes.data)
+                            M, par["egq"], par["egt"], par["shift"], Lq, res, n, bt.ctypes.data, P)
     assert em == n
     return res, bt, off, R
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", range(20))
 def test_schedule_matches_oracle(emul, oracle, case):
     rng = np.random.default_rng(case)
-    Lq = int(rng.integers(5, 330)) if case < 14 else (431 if case == 14 else 512)
+    Lq = int(rng.integers(5, 330)) if case < 14 else [431, 512, 321, 700, 1000, 1281][case - 14]
     par = make_params(local=case % 2, egq=0.0 if case % 4 < 2 else 0.3, egt=0.0 if case % 4 < 2 else 0.1)
     n = int(rng.integers(1, 7))
     qf, qtr, tps, ttrs = workload(case, Lq, n, 1, 200)
@@ -66,10 +66,11 @@ def test_schedule_celloff(emul, oracle):
     for local in (0, 1):
         par = make_params(local=local)
         qf, qtr, tps, ttrs = workload(40 + local, 150, 3, 80, 170, homolog_every=1)
-        Lq = 150
-        R = pack.rows_for(Lq)
+        Lq = 150 if local else 400
+        qf, qtr, tps, ttrs = workload(40 + local, Lq, 3, 80, 170, homolog_every=1)
+        R, P = pack.strips_for(Lq)
         rec, off = pack.pack_stream(tps, ttrs)
-        bt = np.zeros((rec.shape[0], 64), dtype=np.uint64)
+        bt = np.zeros((P, rec.shape[0], 64), dtype=np.uint64)
         masks = []
         for e in range(3):
             a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True)

@@ -25,10 +25,10 @@ def ctx_for(hhv, par):
                        ssw=par["ssw"], ss_mode=par["ss_mode"])
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(16))
 def test_score_only_matches_oracle(hhv, oracle, case):
     rng = np.random.default_rng(case)
-    Lq = [5, 64, 65, 128, 200, 256, 257, 300, 320, 321, 431, 512][case]
+    Lq = [5, 64, 65, 128, 200, 256, 257, 300, 320, 321, 431, 512, 700, 961, 1300, 2000][case]
     par = make_params(local=case % 2, egq=0.0 if case % 4 < 2 else 0.3, egt=0.0 if case % 4 < 2 else 0.1)
     n = int(rng.integers(3, 40))
     qf, qtr, tps, ttrs = workload(case, Lq, n, 1, 260)
@@ -45,10 +45,10 @@ def test_score_only_matches_oracle(hhv, oracle, case):
     c.close()
 
 
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(8))
 def test_backtrace_hits_match_oracle(hhv, oracle, case):
     rng = np.random.default_rng(50 + case)
-    Lq = [40, 100, 200, 300, 320, 431][case]
+    Lq = [40, 100, 200, 300, 320, 431, 650, 1100][case]
     par = make_params(local=case % 2, egq=0.0 if case % 4 < 2 else 0.2, egt=0.0 if case % 4 < 2 else 0.1)
     n = int(rng.integers(4, 24))
     qf, qtr, tps, ttrs = workload(50 + case, Lq, n, 5, 330)
@@ -83,9 +83,8 @@ def test_backtrace_hits_match_oracle(hhv, oracle, case):
 
 def test_celloff_second_round(hhv, oracle):
     """Alt-alignment round 2 (src/hhviterbirunner.cpp:104,152-164): mask the first path, re-align."""
-    for local in (0, 1):
+    for local, Lq in ((0, 150), (1, 150), (1, 400), (0, 700)):
         par = make_params(local=local)
-        Lq = 150
         qf, qtr, tps, ttrs = workload(40 + local, Lq, 5, 80, 170, homolog_every=1)
         c = ctx_for(hhv, par)
         c.set_query(qf, qtr)

@@ -23,7 +23,8 @@ def test_pack_query_matches_numpy_mirror():
         p, tr = synth.make_query(seed, L)
         a = capi.pack_profile(p, tr, index=-1)
         q = pack.pack_query(p, tr)
-        assert q.shape[0] == 64 * pack.rows_for(L)
+        R, P = pack.strips_for(L)
+        assert q.shape[0] == 64 * R * P and 64 * R * P >= L and R <= 5
         assert np.array_equal(a.view(np.int32), q[:L].view(np.int32))
         assert not q[L:].any()
 
