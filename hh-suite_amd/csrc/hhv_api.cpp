@@ -197,15 +197,17 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   if (!c || !p || !tr) return fail(HHV_E_ARG, "hhv_set_query: null argument");
   if (Lq < 1) return fail(HHV_E_ARG, "hhv_set_query: Lq = %d", Lq);
   if (Lq > 0x7FFF) return fail(HHV_E_LIMIT, "hhv_set_query: Lq = %d exceeds 32767", Lq);
-  // strips of 64*R rows (R <= 5 keeps the kernel at 2 waves/SIMD): fewest padded rows, then fewest passes
+  // strips of 64*R rows (R <= 5 keeps the kernel at 2 waves/SIMD).  Cost of a pass per stream record ~ a fixed
+  // per-step overhead (LDS read, DPP hand-off, loop) of ~0.7 cell-equivalents plus R cells: pick the (R, P)
+  // minimising P * (0.7 + R), ties -> fewer passes.
   int R = 1, P = 0;
   {
-    long best_rows = -1;
+    double best = -1.0;
     for (int r = 1; r <= MAX_R; ++r) {
       const int p = (Lq + LANES * r - 1) / (LANES * r);
-      const long rows = (long)p * LANES * r;
-      if (best_rows < 0 || rows < best_rows || (rows == best_rows && p < P)) {
-        best_rows = rows;
+      const double cost = p * (0.7 + r);
+      if (best < 0 || cost < best - 1e-9 || (cost < best + 1e-9 && p < P)) {
+        best = cost;
         R = r;
         P = p;
       }
@@ -404,7 +406,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   const bool bt = celloff || (flags & HHV_ALIGN_BACKTRACE) != 0;
   const bool local = c->par.local != 0;
   int blocks_per_cu = 0, vgprs = 0;
-  int rc = stream_kernel_occupancy(c->R, local, bt, celloff, &blocks_per_cu, &vgprs);
+  int rc = stream_kernel_occupancy(c->R, local, bt, celloff, c->P > 1, &blocks_per_cu, &vgprs);
   if (rc != 0 || blocks_per_cu < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
   const int n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu, ts->n));
   rc = ensure_partition(c, ts, n_waves);
@@ -440,7 +442,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.row_base = pass * LANES * c->R;
     a.pass_first = pass == 0;
     a.pass_last = pass == c->P - 1;
-    rc = launch_stream(c->R, local, bt, celloff, a, n_waves, c->stream);
+    rc = launch_stream(c->R, local, bt, celloff, c->P > 1, a, n_waves, c->stream);
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));

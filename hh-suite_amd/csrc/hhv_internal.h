@@ -67,8 +67,8 @@ struct TraceArgs {
 };
 
 // launchers implemented in hhv_kernels.hip
-int launch_stream(int R, bool local, bool bt, bool celloff, const StreamArgs& a, int n_waves, void* stream);
-int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, int* blocks_per_cu, int* vgprs);
+int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, const StreamArgs& a, int n_waves, void* stream);
+int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, int* blocks_per_cu, int* vgprs);
 int launch_trace(const TraceArgs& a, void* stream);
 
 }  // namespace hhv

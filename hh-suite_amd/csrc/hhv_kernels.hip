@@ -7,8 +7,9 @@
 //           global_load_lds_dwordx4 (HBM -> LDS without touching VGPRs), lanes read their record
 //           with 7 conflict-free ds_read_b128 (28-dword stride = 16 distinct 4-bank slots), the
 //           lane-to-lane hand-off is 7 v_mov_b32_dpp wave_shr:1 per step.
-// Kernel 2  hhv_trace_kernel   Viterbi::Backtrace + Viterbi::ScoreForBacktrace
-//           (src/hhviterbi.cpp:83-160,195-281), one lane per template (pointer chase, O(Lq+Lt)).
+// Kernel 2a hhv_trace_kernel   Viterbi::Backtrace (src/hhviterbi.cpp:83-160), one lane per template
+//           (serial pointer chase, O(Lq+Lt) dependent byte loads).
+// Kernel 2b hhv_rescore_kernel Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), one wave per template.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (fp contraction would change results).
 #include <hip/hip_runtime.h>
@@ -47,7 +48,8 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int c
 // Occupancy: VALU issue needs >= 2 waves per SIMD to reach its rate on gfx950 (a lone wave issues one
 // VOP2 every ~6.3 clk, two waves one every ~2.5 clk: tools/valu_ubench).  Up to R = 5 rows per lane the
 // kernel is held to <= 256 VGPRs (2 waves/SIMD; the backtrace variants spill a few dwords to scratch).
-template <int R, bool LOCAL, bool BT, bool CELLOFF>
+// MULTI = the query needs more than one pass of 64*R rows (the carry hand-over code is compiled out otherwise).
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI>
 __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   __shared__ float4 ring[RING_RECS * 7];
   const int lane = threadIdx.x;
@@ -63,10 +65,10 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   P.Lq = a.Lq;
   const int i0 = a.row_base + lane * R + 1;
   // the lane that emits results: owner of row Lq in the last pass, lane 63 otherwise
-  const int g_last = a.pass_last ? (a.Lq - a.row_base - 1) / R : LANES - 1;
+  const int g_last = (!MULTI || a.pass_last) ? (a.Lq - a.row_base - 1) / R : LANES - 1;
   const int r_last = (a.Lq - a.row_base - 1) % R;
-  const bool first = a.pass_first != 0;
-  const bool carry_out = a.pass_last == 0;
+  const bool first = !MULTI || a.pass_first != 0;
+  const bool carry_out = MULTI && a.pass_last == 0;
 
   const float4* src = (const float4*)a.records + rb * 7;
   const int nchunks = (M + CHUNK_RECS - 1) / CHUNK_RECS;
@@ -150,7 +152,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         const int j = meta & META_JMASK;
         uint64_t cell = 0;
         uint64_t* bte = nullptr;
-        if (BT || CELLOFF) bte = a.bt + ((size_t)(a.row_base / (LANES * R)) * a.bt_pass_stride + (size_t)(rb + r) * LANES + lane);
+        if (BT || CELLOFF)
+          bte = a.bt + ((MULTI ? (size_t)(a.row_base / (LANES * R)) * a.bt_pass_stride : 0) + (size_t)(rb + r) * LANES + lane);
         if (CELLOFF) cell = *bte;
         const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT>(st, q, in, rec, j, i0, r_last, P, cell);
         if (BT) *bte = bytes;
@@ -186,7 +189,8 @@ __device__ __forceinline__ float dot20_scalar_dev(const float* __restrict__ q, c
   return r;
 }
 
-__global__ void __launch_bounds__(256) hhv_trace_kernel(TraceArgs a) {
+// Kernel 2a: Viterbi::Backtrace (src/hhviterbi.cpp:83-160) - a serial pointer chase, one lane per template.
+__global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.n) return;
   const DevResult res = a.results[k];
@@ -196,9 +200,7 @@ __global__ void __launch_bounds__(256) hhv_trace_kernel(TraceArgs a) {
   int32_t* i_steps = a.i_steps + po;
   int32_t* j_steps = a.j_steps + po;
   int8_t* states = a.states + po;
-  float* S = a.S + po;
 
-  // --- Viterbi::Backtrace, src/hhviterbi.cpp:83-160
   int step = 0, matched = 0;
   int i = res.i2, j = res.j2;
   int state = 2;  // MM
@@ -257,68 +259,95 @@ __global__ void __launch_bounds__(256) hhv_trace_kernel(TraceArgs a) {
     }
   }
   states[step] = 2;  // :147
-  const int nsteps = step;
+  DevHit h;
+  h.score = res.score;  // completed by hhv_rescore_kernel
+  h.viterbi_score = res.score;
+  h.index = k;
+  h.i1 = i_steps[step];
+  h.j1 = j_steps[step];
+  h.i2 = res.i2;
+  h.j2 = res.j2;
+  h.nsteps = step;
+  h.matched_cols = matched;
+  a.hits[k] = h;
+}
 
-  // --- Viterbi::ScoreForBacktrace, src/hhviterbi.cpp:195-281 (no secondary-structure term: score_ss = 0)
-  float score = res.score;
-  for (int s = 1; s <= nsteps; ++s) {
+// Kernel 2b: Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), one wavefront per template: the per-step
+// column scores S are independent (lanes stride over the steps); the four correlation sums are then
+// accumulated by one lane in exactly the reference's order (:241-249), reading S from LDS.
+constexpr int RESCORE_LDS_FLOATS = 4096;
+__global__ void __launch_bounds__(64) hhv_rescore_kernel(TraceArgs a) {
+  __shared__ float sS[RESCORE_LDS_FLOATS];
+  const int k = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t rec0 = a.rec_off[k];
+  const int64_t po = a.path_off[k];
+  const int32_t* i_steps = a.i_steps + po;
+  const int32_t* j_steps = a.j_steps + po;
+  const int8_t* states = a.states + po;
+  float* S = a.S + po;
+  const int nsteps = a.hits[k].nsteps;
+  const bool in_lds = nsteps + 1 <= RESCORE_LDS_FLOATS;
+  for (int s = 1 + lane; s <= nsteps; s += LANES) {
+    float v = 0.0f;
     if (states[s] == 2) {
       const float* qp = a.qp + (size_t)i_steps[s] * 20;
       const float* tp = a.records + (size_t)(rec0 + j_steps[s]) * REC_DW;
-      S[s] = fast_log2_dev(dot20_scalar_dev(qp, tp), a.lg2, a.diff);
-    } else {
-      S[s] = 0.0f;
+      v = fast_log2_dev(dot20_scalar_dev(qp, tp), a.lg2, a.diff);
     }
+    S[s] = v;
+    if (in_lds) sS[s] = v;
   }
-  if (a.ss_mode == 2) score -= 0.0f;
-  float Scorr = 0;
-  for (int s = 2; s <= nsteps; ++s) Scorr += S[s] * S[s - 1];
-  for (int s = 3; s <= nsteps; ++s) Scorr += S[s] * S[s - 2];
-  for (int s = 4; s <= nsteps; ++s) Scorr += S[s] * S[s - 3];
-  for (int s = 5; s <= nsteps; ++s) Scorr += S[s] * S[s - 4];
-  score += a.corr * Scorr;
-
-  DevHit h;
-  h.score = score;
-  h.viterbi_score = res.score;
-  h.index = k;
-  h.i1 = i_steps[nsteps];
-  h.j1 = j_steps[nsteps];
-  h.i2 = res.i2;
-  h.j2 = res.j2;
-  h.nsteps = nsteps;
-  h.matched_cols = matched;
-  a.hits[k] = h;
+  __syncthreads();
+  if (lane == 0) {
+    float score = a.hits[k].viterbi_score;
+    if (a.ss_mode == 2) score -= 0.0f;  // no secondary-structure term on this path: score_ss = 0 (:238)
+    float Scorr = 0;
+    if (in_lds) {
+      for (int s = 2; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 1];
+      for (int s = 3; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 2];
+      for (int s = 4; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 3];
+      for (int s = 5; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 4];
+    } else {
+      __threadfence_block();
+      for (int s = 2; s <= nsteps; ++s) Scorr += S[s] * S[s - 1];
+      for (int s = 3; s <= nsteps; ++s) Scorr += S[s] * S[s - 2];
+      for (int s = 4; s <= nsteps; ++s) Scorr += S[s] * S[s - 3];
+      for (int s = 5; s <= nsteps; ++s) Scorr += S[s] * S[s - 4];
+    }
+    score += a.corr * Scorr;
+    a.hits[k].score = score;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 
 template <int R, bool LOCAL, bool BT, bool CELLOFF>
-static void* kernel_ptr() {
-  return (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF>;
+static void* kernel_ptr(bool multi) {
+  return multi ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, true> : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, false>;
 }
 
 template <int R>
-static void* pick_variant(bool local, bool bt, bool celloff) {
-  if (celloff) return local ? kernel_ptr<R, true, true, true>() : kernel_ptr<R, false, true, true>();
-  if (bt) return local ? kernel_ptr<R, true, true, false>() : kernel_ptr<R, false, true, false>();
-  return local ? kernel_ptr<R, true, false, false>() : kernel_ptr<R, false, false, false>();
+static void* pick_variant(bool local, bool bt, bool celloff, bool multi) {
+  if (celloff) return local ? kernel_ptr<R, true, true, true>(multi) : kernel_ptr<R, false, true, true>(multi);
+  if (bt) return local ? kernel_ptr<R, true, true, false>(multi) : kernel_ptr<R, false, true, false>(multi);
+  return local ? kernel_ptr<R, true, false, false>(multi) : kernel_ptr<R, false, false, false>(multi);
 }
 
-static void* pick(int R, bool local, bool bt, bool celloff) {
+static void* pick(int R, bool local, bool bt, bool celloff, bool multi) {
   switch (R) {
-    case 1: return pick_variant<1>(local, bt, celloff);
-    case 2: return pick_variant<2>(local, bt, celloff);
-    case 3: return pick_variant<3>(local, bt, celloff);
-    case 4: return pick_variant<4>(local, bt, celloff);
-    case 5: return pick_variant<5>(local, bt, celloff);
+    case 1: return pick_variant<1>(local, bt, celloff, multi);
+    case 2: return pick_variant<2>(local, bt, celloff, multi);
+    case 3: return pick_variant<3>(local, bt, celloff, multi);
+    case 4: return pick_variant<4>(local, bt, celloff, multi);
+    case 5: return pick_variant<5>(local, bt, celloff, multi);
   }
   return nullptr;
 }
 
-int launch_stream(int R, bool local, bool bt, bool celloff, const StreamArgs& a, int n_waves, void* stream) {
-  void* fn = pick(R, local, bt, celloff);
+int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, const StreamArgs& a, int n_waves, void* stream) {
+  void* fn = pick(R, local, bt, celloff, multi);
   if (!fn) return -1;
   StreamArgs args = a;
   void* kargs[] = {&args};
@@ -326,8 +355,8 @@ int launch_stream(int R, bool local, bool bt, bool celloff, const StreamArgs& a,
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, int* blocks_per_cu, int* vgprs) {
-  void* fn = pick(R, local, bt, celloff);
+int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, int* blocks_per_cu, int* vgprs) {
+  void* fn = pick(R, local, bt, celloff, multi);
   if (!fn) return -1;
   int nb = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, LANES, 0);
@@ -341,9 +370,9 @@ int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, int* block
 }
 
 int launch_trace(const TraceArgs& a, void* stream) {
-  const int threads = 256;
-  const int blocks = (a.n + threads - 1) / threads;
-  hipLaunchKernelGGL(hhv_trace_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  // 64 templates per wave for the chase (latency bound: many small blocks spread over all CUs)
+  hipLaunchKernelGGL(hhv_trace_kernel, dim3((a.n + LANES - 1) / LANES), dim3(LANES), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(hhv_rescore_kernel, dim3(a.n), dim3(LANES), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

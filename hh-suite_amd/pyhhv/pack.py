@@ -22,14 +22,15 @@ MAX_R = 5
 
 
 def strips_for(Lq):
-    """(R, P): query rows per lane and number of passes of 64*R rows (hhv_set_query's rule: fewest
-    padded rows, then fewest passes; R <= 5 keeps the kernel at 2 waves per SIMD)."""
+    """(R, P): query rows per lane and number of passes of 64*R rows -- hhv_set_query's rule: minimise
+    P * (0.7 + R) (0.7 cell-equivalents of per-step overhead), ties -> fewer passes; R <= 5 keeps the
+    kernel at 2 waves per SIMD."""
     best = None
     for r in range(1, MAX_R + 1):
         p = -(-int(Lq) // (LANES * r))
-        rows = p * LANES * r
-        if best is None or rows < best[0] or (rows == best[0] and p < best[2]):
-            best = (rows, r, p)
+        cost = p * (0.7 + r)
+        if best is None or cost < best[0] - 1e-9 or (cost < best[0] + 1e-9 and p < best[2]):
+            best = (cost, r, p)
     return best[1], best[2]
 
 
