@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--templates", type=int, default=100000, help="templates per GPU (north-star 1-GPU headline: 100k)")
     ap.add_argument("--lq", type=int, default=300)
     ap.add_argument("--lt", type=int, default=300)
+    ap.add_argument("--lengths", default="fixed", choices=["fixed", "zipf"],
+                    help="zipf = BASELINE configs[4]: L_t = 49 + k, k ~ Zipf(1.2) truncated to 50..1000")
     ap.add_argument("--topk", type=int, default=500)
     ap.add_argument("--local", type=int, default=0)
     ap.add_argument("--backtrace", type=int, default=0, help="1 = BASELINE configs[2] (backtrace + hit list)")
@@ -45,84 +47,85 @@ def parse():
     return ap.parse_args()
 
 
-def gen_stream(torch, device, n, Lt, seed, pb):
+def gen_stream(torch, device, Ls, seed, pb):
     """Synthetic prepared templates generated on the GPU straight into the packed record stream
-    (DESIGN.md section 2): per template a header + Lt column records; + terminal header + pad.
-    Same distribution family as pyhhv/synth.py (peaky columns mixed with the background, divided by
-    the null model; transitions like AddTransitionPseudocounts leaves them)."""
+    (DESIGN.md section 2): per template a header + L[k] column records; + terminal header + pad.
+    Works for ragged lengths (config 5).  Same distribution family as pyhhv/synth.py (peaky columns mixed
+    with the background, divided by the null model; transitions like AddTransitionPseudocounts leaves them).
+    Returns (records tensor, rec_off int64 numpy)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    recs_per = Lt + 1
-    total = n * recs_per + 1 + 256
+    Ls = np.asarray(Ls, dtype=np.int64)
+    n = Ls.shape[0]
+    rec_off = np.zeros(n + 1, dtype=np.int64)
+    rec_off[1:] = np.cumsum(Ls + 1)
+    nrec = int(rec_off[-1])
+    total = nrec + 1 + 256
     rec = torch.zeros((total, 28), dtype=torch.float32, device=device)
     meta = rec.view(torch.int32)
-    body = rec[: n * recs_per].view(n, recs_per, 28)
-    mbody = meta[: n * recs_per].view(n, recs_per, 28)
     pbt = torch.tensor(pb, dtype=torch.float32, device=device)
-    chunk = 8192
-    for a in range(0, n, chunk):
-        b = min(n, a + chunk)
+    off_t = torch.from_numpy(rec_off).to(device)
+    L_t = torch.from_numpy(Ls).to(device)
+    chunk = 1 << 21
+    for a in range(0, nrec, chunk):
+        b = min(nrec, a + chunk)
         m = b - a
-        u = torch.rand((m, Lt, 20), generator=g, device=device)
+        u = torch.rand((m, 20), generator=g, device=device)
         gg = u.pow(6.0) + 1e-9
-        gg = gg / gg.sum(dim=2, keepdim=True)
+        gg = gg / gg.sum(dim=1, keepdim=True)
         f = 0.7 * gg + 0.3 * pbt
-        f = f / f.sum(dim=2, keepdim=True)
-        body[a:b, 1:, 0:20] = f / pbt
-        t = torch.rand((m, Lt + 1, 4), generator=g, device=device)
-        pI = 0.01 + 0.04 * t[..., 0]
-        pD = 0.01 + 0.04 * t[..., 1]
-        pII = 0.25 + 0.3 * t[..., 2]
-        pDD = 0.25 + 0.3 * t[..., 3]
-        m2m = torch.log2(1.0 - pI - pD)
-        m2i = torch.log2(pI) * 0.6
-        m2d = torch.log2(pD) * 0.6
-        i2m = torch.log2(1.0 - pII)
-        i2i = torch.log2(pII) * 0.6
-        d2m = torch.log2(1.0 - pDD)
-        d2d = torch.log2(pDD) * 0.6
-        # column 0 and column Lt: no M->I / M->D, no D->D out of Lt (src/hhhmm.cpp:1755-1785)
-        m2m[:, 0] = 0.0
-        m2i[:, 0] = -100000.0
-        m2d[:, 0] = -100000.0
-        m2i[:, Lt] = -100000.0
-        # record j (1..Lt): tr[j-1][M2M,M2D,D2M,D2D,I2M], tr[j][I2I,M2I]
-        body[a:b, 1:, 20] = m2m[:, :Lt]
-        body[a:b, 1:, 21] = m2d[:, :Lt]
-        body[a:b, 1:, 22] = d2m[:, :Lt]
-        body[a:b, 1:, 23] = d2d[:, :Lt]
-        body[a:b, 1:, 24] = i2m[:, :Lt]
-        body[a:b, 1:, 25] = i2i[:, 1:]
-        body[a:b, 1:, 26] = m2i[:, 1:]
+        f = f / f.sum(dim=1, keepdim=True)
+        rec[a:b, 0:20] = f / pbt
+        t = torch.rand((m, 8), generator=g, device=device)
+        # record j: tr[j-1][M2M,M2D,D2M,D2D,I2M] from the "previous column" draws, tr[j][I2I,M2I] from its own
+        pI, pD, pII, pDD = 0.01 + 0.04 * t[:, 0], 0.01 + 0.04 * t[:, 1], 0.25 + 0.3 * t[:, 2], 0.25 + 0.3 * t[:, 3]
+        rec[a:b, 20] = torch.log2(1.0 - pI - pD)
+        rec[a:b, 21] = torch.log2(pD) * 0.6
+        rec[a:b, 22] = torch.log2(1.0 - pDD)
+        rec[a:b, 23] = torch.log2(pDD) * 0.6
+        rec[a:b, 24] = torch.log2(1.0 - pII)
+        rec[a:b, 25] = torch.log2(0.25 + 0.3 * t[:, 4]) * 0.6
+        rec[a:b, 26] = torch.log2(0.01 + 0.04 * t[:, 5]) * 0.6
         del u, gg, f, t
-    idx = torch.arange(n, dtype=torch.int32, device=device)
-    mbody[:, 0, 27] = -2 ** 31
-    mbody[:, 0, 0] = idx
-    mbody[:, 0, 1] = Lt
-    j = torch.arange(1, Lt + 1, dtype=torch.int32, device=device)
-    mbody[:, 1:, 27] = j
-    mbody[:, Lt, 27] = Lt | 0x40000000
-    meta[n * recs_per, 27] = -2 ** 31
-    meta[n * recs_per, 0] = -1
-    return rec
+    # per-record template id and column index
+    pos = torch.arange(nrec, dtype=torch.int64, device=device)
+    tid = torch.searchsorted(off_t, pos, right=True) - 1
+    j = (pos - off_t[tid]).to(torch.int32)
+    Lr = L_t[tid].to(torch.int32)
+    is_hdr = j == 0
+    # column 1 carries tr[0]: M2M = 0, no M->D out of column 0; column L: no M->I out of L (src/hhhmm.cpp:1755-1785)
+    first = j == 1
+    rec[:nrec, 20][first] = 0.0
+    rec[:nrec, 21][first] = -100000.0
+    last = j == Lr
+    rec[:nrec, 26][last] = -100000.0
+    meta[:nrec, 27] = torch.where(last, j | 0x40000000, j)
+    rec[:nrec][is_hdr] = 0.0
+    meta[:nrec, 27][is_hdr] = -2 ** 31
+    meta[:nrec, 0][is_hdr] = tid[is_hdr].to(torch.int32)
+    meta[:nrec, 1][is_hdr] = Lr[is_hdr]
+    meta[nrec, 27] = -2 ** 31
+    meta[nrec, 0] = -1
+    return rec, rec_off
 
 
-def unpack_templates(rec_host, n, Lt):
-    """Packed records (host numpy) -> prepared AoS profiles (p[(Lt+1),20], tr[(Lt+1),7]) holding every
-    value the DP reads."""
-    body = rec_host[: n * (Lt + 1)].reshape(n, Lt + 1, 28)
+def unpack_templates(rec_host, rec_off, Ls, n):
+    """Packed records (host numpy, first n templates) -> prepared AoS profiles (p[(L+1),20], tr[(L+1),7])
+    holding every value the DP reads."""
     tps, ttrs = [], []
     for k in range(n):
+        Lt = int(Ls[k])
+        body = rec_host[int(rec_off[k]): int(rec_off[k]) + Lt + 1]
         p = np.zeros((Lt + 1, 20), dtype=np.float32)
         tr = np.zeros((Lt + 1, 7), dtype=np.float32)
-        p[1:] = body[k, 1:, 0:20]
-        tr[:Lt, 0] = body[k, 1:, 20]
-        tr[:Lt, 2] = body[k, 1:, 21]
-        tr[:Lt, 5] = body[k, 1:, 22]
-        tr[:Lt, 6] = body[k, 1:, 23]
-        tr[:Lt, 3] = body[k, 1:, 24]
-        tr[1:, 4] = body[k, 1:, 25]
-        tr[1:, 1] = body[k, 1:, 26]
+        p[1:] = body[1:, 0:20]
+        tr[:Lt, 0] = body[1:, 20]
+        tr[:Lt, 2] = body[1:, 21]
+        tr[:Lt, 5] = body[1:, 22]
+        tr[:Lt, 6] = body[1:, 23]
+        tr[:Lt, 3] = body[1:, 24]
+        tr[1:, 4] = body[1:, 25]
+        tr[1:, 1] = body[1:, 26]
         tps.append(p)
         ttrs.append(tr)
     return tps, ttrs
@@ -156,12 +159,15 @@ def main():
 
     Lq, Lt, n = args.lq, args.lt, args.templates
     qf, qtr = synth.make_query(0x51000000, Lq)
-    rec = gen_stream(torch, device, n, Lt, 0x5EED0000 + rank, synth.PB)
+    if args.lengths == "zipf":
+        Ls = synth.zipf_lengths(0x21F + rank, n).astype(np.int32)
+    else:
+        Ls = np.full(n, Lt, dtype=np.int32)
+    rec, rec_off = gen_stream(torch, device, Ls, 0x5EED0000 + rank, synth.PB)
     torch.cuda.synchronize()
 
     ctx = capi.Context(local=args.local, device=dev_index)
     ctx.set_query(qf, qtr)
-    Ls = np.full(n, Lt, dtype=np.int32)
     ts = ctx.adopt_device_stream(Ls, rec.data_ptr())
     cells_per_rank = ts.cells()
     K = args.topk
@@ -204,9 +210,9 @@ def main():
     total_cells = cells_per_rank * world
     value = total_cells * args.steps / dt
     k_ms = float(np.mean(kernel_ms))
-    algo_bytes = (n * (Lt + 1) + 1) * REC_BYTES + n * 16 + 64 * ((Lq + 63) // 64) * REC_BYTES
+    algo_bytes = (int(rec_off[-1]) + 1) * REC_BYTES + n * 16 + 64 * ((Lq + 63) // 64) * REC_BYTES
     if bt:
-        algo_bytes += n * Lq * Lt  # 1 backtrace byte per cell
+        algo_bytes += cells_per_rank  # 1 backtrace byte per cell
     achieved_gbs = algo_bytes / (k_ms * 1e-3) / 1e9
     kernel_cells_s = cells_per_rank / (k_ms * 1e-3)
 
@@ -216,7 +222,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r1_summary.json")) as f:
             prof = json.load(f)
-        if n == 100000 and Lq == 300 and Lt == 300 and not bt:
+        if n == 100000 and Lq == 300 and Lt == 300 and not bt and args.lengths == "fixed":
             traffic = prof.get("traffic_bytes_per_launch")
     except Exception:
         pass
@@ -236,7 +242,8 @@ def main():
         "data": "synthetic",
         "templates_per_s": n * world * args.steps / dt,
         "config": {
-            "workload": "Lq%d_vs_%dx_Lt%d_%s_%s" % (Lq, n * world, Lt, "local" if args.local else "global",
+            "workload": "Lq%d_vs_%dx_Lt%s_%s_%s" % (Lq, n * world, Lt if args.lengths == "fixed" else "zipf50-1000",
+                                                     "local" if args.local else "global",
                                                      "backtrace_hits_top%d" % K if bt else "score_only_top%d" % K),
             "templates_per_gpu": n, "Lq": Lq, "Lt": Lt, "topk": K,
             "parallelism": "template-db-shard x%d, one RCCL all_gather of top-K" % world if world > 1 else "single GPU",
@@ -255,7 +262,7 @@ def main():
         },
     }
 
-    if rank == 0 and not args.no_configs1 and n >= 10000 and not bt:
+    if rank == 0 and not args.no_configs1 and n >= 10000 and not bt and args.lengths == "fixed":
         # BASELINE configs[1]: the same query vs the first 10k templates of the resident stream
         ts10 = ctx.adopt_device_stream(np.full(10000, Lt, dtype=np.int32), rec.data_ptr())
         for _ in range(2):
@@ -273,7 +280,7 @@ def main():
         ts10.free()
 
     if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, rec, ctx, ts, qf, qtr, n, Lq, Lt)
+        out["cpu_baseline"] = cpu_baseline(args, rec, rec_off, Ls, ctx, ts, qf, qtr, n, Lq)
 
     if world > 1:
         dist.barrier()
@@ -285,7 +292,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, rec, ctx, ts, qf, qtr, n, Lq, Lt):
+def cpu_baseline(args, rec, rec_off, Ls, ctx, ts, qf, qtr, n, Lq):
     """The reference's own batch loop (Viterbi::Align, 8 AVX2 lanes per call, OpenMP over batches as in
     src/hhviterbirunner.cpp:122) on a bounded sample of the SAME templates, on this box's host cores.
     Also cross-checks the GPU results of the sample against it (bit-exact endpoints, equal scores)."""
@@ -296,30 +303,38 @@ def cpu_baseline(args, rec, ctx, ts, qf, qtr, n, Lq, Lt):
     use_ref = pyoracle.have_ref()
     eng = pyoracle.Ref() if use_ref else pyoracle.Oracle()
     # size the sample from a short probe
-    probe = min(n, 256)
-    host = rec[: probe * (Lt + 1)].cpu().numpy()
-    tps, ttrs = unpack_templates(host, probe, Lt)
+    Lmean = float(np.mean(Ls))
+    if args.lengths != "fixed" and not args.local and use_ref:
+        # global mode + mixed-length SIMD batches hits the reference's batch-composition quirk;
+        # the parity definition there is the single-length batch = the restatement
+        eng, use_ref = pyoracle.Oracle(), False
+    probe = min(n, 1024)
+    host = rec[: int(rec_off[probe])].cpu().numpy()
+    tps, ttrs = unpack_templates(host, rec_off, Ls, probe)
     r = eng.bench_align(par, qf, qtr, tps, ttrs, threads=cores)
     sec = r[0]
-    rate = probe * Lq * Lt / max(sec, 1e-9)
-    sample = int(min(n, max(probe, args.cpu_seconds * rate / (Lq * Lt))))
+    rate = probe * Lq * Lmean / max(sec, 1e-9)
+    sample = int(min(n, max(probe, args.cpu_seconds * rate / (Lq * Lmean))))
     sample = max(8, sample - sample % 8)
-    host = rec[: sample * (Lt + 1)].cpu().numpy()
-    tps, ttrs = unpack_templates(host, sample, Lt)
+    host = rec[: int(rec_off[sample])].cpu().numpy()
+    tps, ttrs = unpack_templates(host, rec_off, Ls, sample)
     r = eng.bench_align(par, qf, qtr, tps, ttrs, threads=cores)
     sec, score, i2, j2 = r[0], r[-3], r[-2], r[-1]
-    r1 = eng.bench_align(par, qf, qtr, tps[: max(8, sample // cores // 8 * 8)], ttrs[: max(8, sample // cores // 8 * 8)],
-                         threads=1)
+    n1 = max(8, min(sample, 512))
+    r1 = eng.bench_align(par, qf, qtr, tps[:n1], ttrs[:n1], threads=1)
+    sample_cells = float(Lq) * float(np.sum(Ls[:sample]))
     gpu = ctx.align(ts)
     ok_idx = bool(np.array_equal(gpu["i2"][:sample], i2) and np.array_equal(gpu["j2"][:sample], j2))
     ok_score = bool(np.all(gpu["score"][:sample] == score))
     maxdiff = float(np.max(np.abs(gpu["score"][:sample].astype(np.float64) - score.astype(np.float64))))
     return {
-        "value": sample * Lq * Lt / sec, "unit": "cells/s", "cores": cores,
+        "value": sample_cells / sec, "unit": "cells/s", "cores": cores,
         "kind": "reference" if use_ref else "port",
-        "sample": "first %d templates of the benchmark set (Lq=%d, Lt=%d), Viterbi::Align AVX2 8 lanes/call, "
-                  "OpenMP dynamic over batches, %d threads, %.2f s" % (sample, Lq, Lt, cores, sec),
-        "single_thread_cells_per_s": max(8, sample // cores // 8 * 8) * Lq * Lt / r1[0],
+        "sample": "first %d templates of the benchmark set (Lq=%d, mean Lt=%.0f), %s, "
+                  "OpenMP dynamic over batches, %d threads, %.2f s" % (
+                      sample, Lq, Lmean, "Viterbi::Align AVX2 8 lanes/call" if use_ref else "scalar C restatement",
+                      cores, sec),
+        "single_thread_cells_per_s": float(Lq) * float(np.sum(Ls[:n1])) / r1[0],
         "gpu_matches_cpu_on_sample": {"endpoints_bit_exact": ok_idx, "scores_equal": ok_score, "max_abs_score_diff": maxdiff},
     }
 
