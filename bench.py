@@ -171,7 +171,7 @@ def main():
     ts = ctx.adopt_device_stream(Ls, rec.data_ptr())
     cells_per_rank = ts.cells()
     K = args.topk
-    topk_buf = torch.zeros((K, 9), dtype=torch.int32, device=device)       # K hhv_hit records (36 B each)
+    topk_buf = torch.zeros((K, shard.REC_I32), dtype=torch.int32, device=device)   # K hhv_hit records (40 B each)
     gids = torch.arange(n, dtype=torch.int64, device=device) + rank * n    # global template ids of this shard
     bt = bool(args.backtrace)
 

@@ -66,6 +66,14 @@ struct hhv_ctx {
   // fast_log2 tables (src/util-inl.h:108-130)
   float* d_lg2 = nullptr;
   float* d_diff = nullptr;
+  // secondary structure
+  std::vector<float> S73, S33, S37;                    // host copies of the score tables
+  std::vector<int8_t> q_pred, q_conf, q_dssp;          // [Lq+1], empty = absent
+  int ss_hmm_mode = 0;                                 // HMM::NO_SS_INFORMATION
+  bool ss_dirty = true;
+  float* d_ss_table = nullptr;                         // ssw * table of the current mode
+  int32_t* d_ss_q_off = nullptr;                       // [P*64*R]
+  int ss_t_shift = 0, ss_t_mask = 0;
 };
 
 struct hhv_tset {
@@ -187,6 +195,8 @@ void hhv_destroy(hhv_ctx* c) {
   dfree(c->d_qp);
   dfree(c->d_lg2);
   dfree(c->d_diff);
+  dfree(c->d_ss_table);
+  dfree(c->d_ss_q_off);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -226,6 +236,79 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   c->Lq = Lq;
   c->R = R;
   c->P = P;
+  c->q_pred.clear();
+  c->q_conf.clear();
+  c->q_dssp.clear();
+  c->ss_dirty = true;
+  return HHV_OK;
+}
+
+int hhv_set_ss_tables(hhv_ctx* c, const float* S73, const float* S33, const float* S37) {
+  if (!c || !S73 || !S33 || !S37) return fail(HHV_E_ARG, "hhv_set_ss_tables: null argument");
+  c->S73.assign(S73, S73 + 8 * 4 * 11);
+  c->S33.assign(S33, S33 + 4 * 11 * 4 * 11);
+  c->S37.assign(S37, S37 + 4 * 11 * 8);
+  c->ss_dirty = true;
+  return HHV_OK;
+}
+
+int hhv_set_query_ss(hhv_ctx* c, const int8_t* ss_pred, const int8_t* ss_conf, const int8_t* ss_dssp) {
+  if (!c) return fail(HHV_E_ARG, "hhv_set_query_ss: null argument");
+  if (c->Lq < 1) return fail(HHV_E_STATE, "hhv_set_query_ss: call hhv_set_query first");
+  const size_t m = (size_t)c->Lq + 1;
+  c->q_pred.clear();
+  c->q_conf.clear();
+  c->q_dssp.clear();
+  if (ss_pred) c->q_pred.assign(ss_pred, ss_pred + m);
+  if (ss_conf) c->q_conf.assign(ss_conf, ss_conf + m);
+  if (ss_dssp) c->q_dssp.assign(ss_dssp, ss_dssp + m);
+  c->ss_dirty = true;
+  return HHV_OK;
+}
+
+int hhv_set_ss_mode(hhv_ctx* c, int32_t mode) {
+  if (!c) return fail(HHV_E_ARG, "hhv_set_ss_mode: null argument");
+  if (mode != 0 && mode != 1 && mode != 2 && mode != 4)
+    return fail(HHV_E_ARG, "hhv_set_ss_mode: %d is not one of 0 (none), 1 (PRED_DSSP), 2 (DSSP_PRED), 4 (PRED_PRED)", mode);
+  if (mode != 0 && c->S33.empty()) return fail(HHV_E_STATE, "hhv_set_ss_mode: call hhv_set_ss_tables first");
+  c->ss_hmm_mode = mode;
+  c->ss_dirty = true;
+  return HHV_OK;
+}
+
+// (Re)build the device-side SS operands of the current mode: the premultiplied table ssw*S (the reference
+// multiplies per cell, src/hhviterbialgorithm.cpp:209 - the same single fp32 product) and the per-row offsets
+//   PRED_PRED: S33[q_pred][q_conf][t_pred][t_conf]  row (q_pred*11+q_conf)*44, column pred_index   (:199-200)
+//   DSSP_PRED: S73[q_dssp][t_pred][t_conf]          row q_dssp*44,              column pred_index   (:201-202)
+//   PRED_DSSP: S37[q_pred][q_conf][t_dssp]          row (q_pred*11+q_conf)*8,   column dssp_index   (:203-204)
+static int ensure_ss(hhv_ctx* c) {
+  if (!c->ss_dirty) return HHV_OK;
+  dfree(c->d_ss_table);
+  dfree(c->d_ss_q_off);
+  c->ss_dirty = false;
+  if (c->ss_hmm_mode == 0 || c->Lq < 1) return HHV_OK;
+  const std::vector<float>& T = c->ss_hmm_mode == 4 ? c->S33 : (c->ss_hmm_mode == 2 ? c->S73 : c->S37);
+  std::vector<float> tab(T.size());
+  for (size_t k = 0; k < T.size(); ++k) tab[k] = c->par.ssw * T[k];
+  const size_t rows = (size_t)c->P * LANES * c->R;
+  std::vector<int32_t> off(rows, 0);
+  for (int i = 1; i <= c->Lq; ++i) {
+    const int pred = c->q_pred.empty() ? 0 : (unsigned char)c->q_pred[i], conf = c->q_conf.empty() ? 0 : c->q_conf[i];
+    const int dssp = c->q_dssp.empty() ? 0 : (unsigned char)c->q_dssp[i];
+    int o;
+    if (c->ss_hmm_mode == 4) o = (pred * 11 + conf) * 44;
+    else if (c->ss_hmm_mode == 2) o = dssp * 44;
+    else o = (pred * 11 + conf) * 8;
+    if (o < 0 || (size_t)o + (c->ss_hmm_mode == 1 ? 8 : 44) > T.size())
+      return fail(HHV_E_ARG, "query secondary-structure code out of range at row %d", i);
+    off[i - 1] = o;
+  }
+  c->ss_t_shift = c->ss_hmm_mode == 1 ? META_DSSP_SHIFT : META_PRED_SHIFT;
+  c->ss_t_mask = c->ss_hmm_mode == 1 ? META_DSSP_MASK : META_PRED_MASK;
+  HIP_TRY(hipMalloc(&c->d_ss_table, tab.size() * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->d_ss_q_off, off.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(c->d_ss_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_ss_q_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return HHV_OK;
 }
 
@@ -252,6 +335,12 @@ static int tset_init_common(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_t* 
 
 int hhv_upload_templates(hhv_ctx* c, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
                          hhv_tset** out) {
+  return hhv_upload_templates_ss(c, n, L, p, tr, nullptr, nullptr, nullptr, out);
+}
+
+int hhv_upload_templates_ss(hhv_ctx* c, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
+                            const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp,
+                            hhv_tset** out) {
   if (!c || !L || !p || !tr || !out) return fail(HHV_E_ARG, "hhv_upload_templates: null argument");
   if (n < 1) return fail(HHV_E_ARG, "hhv_upload_templates: n = %d", n);
   *out = nullptr;
@@ -287,7 +376,16 @@ int hhv_upload_templates(hhv_ctx* c, int32_t n, const int32_t* L, const float* c
         hhv_tset_free(ts);
         return fail(HHV_E_ARG, "hhv_upload_templates: template %d has a null profile", t);
       }
-      pack_template(p[t], tr[t], L[t], t, stage.data() + o);
+      for (int j = 1; j <= L[t]; ++j) {
+        const int pr = ss_pred && ss_pred[t] ? ss_pred[t][j] : 0, cf = ss_conf && ss_conf[t] ? ss_conf[t][j] : 0;
+        const int ds = ss_dssp && ss_dssp[t] ? ss_dssp[t][j] : 0;
+        if (pr < 0 || pr > 3 || cf < 0 || cf > 10 || ds < 0 || ds > 7) {
+          hhv_tset_free(ts);
+          return fail(HHV_E_ARG, "template %d column %d: secondary-structure code out of range", t, j);
+        }
+      }
+      pack_template(p[t], tr[t], L[t], t, stage.data() + o, ss_pred ? ss_pred[t] : nullptr,
+                    ss_conf ? ss_conf[t] : nullptr, ss_dssp ? ss_dssp[t] : nullptr);
       o += ((size_t)L[t] + 1) * REC_DW;
     }
     if (hipMemcpy(ts->d_records + (size_t)ts->rec_off[k0] * REC_DW, stage.data(), stage.size() * sizeof(float),
@@ -398,15 +496,16 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   if (!c || !ts) return fail(HHV_E_ARG, "hhv_align: null argument");
   if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_align: template set belongs to another context");
   if (c->Lq < 1) return fail(HHV_E_STATE, "hhv_align: no query set");
-  // Secondary-structure scoring: the reference runs the no-SS kernel whenever a batch carries no SS
-  // information (src/hhviterbi.cpp:175); profiles uploaded through this ABI carry none, so that is
-  // the kernel built here (the ...AndSS variants are SURVEY.md 8a row A5, not yet built).
   HIP_TRY(hipSetDevice(c->par.device));
   const bool celloff = (flags & HHV_ALIGN_CELLOFF) != 0;
   const bool bt = celloff || (flags & HHV_ALIGN_BACKTRACE) != 0;
   const bool local = c->par.local != 0;
+  int rc = ensure_ss(c);
+  if (rc != HHV_OK) return rc;
+  // src/hhviterbi.cpp:175: the ...AndSS kernels run only for ssm == SCORE_ALIGNMENT and a non-zero ss_hmm_mode
+  const bool ss = c->par.ss_mode == 2 && c->ss_hmm_mode != 0;
   int blocks_per_cu = 0, vgprs = 0;
-  int rc = stream_kernel_occupancy(c->R, local, bt, celloff, c->P > 1, &blocks_per_cu, &vgprs);
+  rc = stream_kernel_occupancy(c->R, local, bt, celloff, c->P > 1, ss, &blocks_per_cu, &vgprs);
   if (rc != 0 || blocks_per_cu < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
   const int n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu, ts->n));
   rc = ensure_partition(c, ts, n_waves);
@@ -428,6 +527,10 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.carry = nullptr;
   a.carry_mi = nullptr;
   a.bt_pass_stride = ts->n_records * LANES;
+  a.ss_table = ss ? c->d_ss_table : nullptr;
+  a.ss_q_off = ss ? c->d_ss_q_off : nullptr;
+  a.ss_t_shift = c->ss_t_shift;
+  a.ss_t_mask = c->ss_t_mask;
   if (c->P > 1) {
     if (!ts->d_carry) {
       HIP_TRY(hipMalloc(&ts->d_carry, (size_t)ts->n_records * sizeof(float4)));
@@ -442,7 +545,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.row_base = pass * LANES * c->R;
     a.pass_first = pass == 0;
     a.pass_last = pass == c->P - 1;
-    rc = launch_stream(c->R, local, bt, celloff, c->P > 1, a, n_waves, c->stream);
+    rc = launch_stream(c->R, local, bt, celloff, c->P > 1, ss, a, n_waves, c->stream);
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -587,6 +690,12 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.R = ts->bt_R;
   a.n = ts->n;
   a.bt_pass_stride = ts->n_records * LANES;
+  rc = ensure_ss(c);
+  if (rc != HHV_OK) return rc;
+  a.ss_table = c->ss_hmm_mode ? c->d_ss_table : nullptr;
+  a.ss_q_off = c->ss_hmm_mode ? c->d_ss_q_off : nullptr;
+  a.ss_t_shift = c->ss_t_shift;
+  a.ss_t_mask = c->ss_t_mask;
   rc = launch_trace(a, c->stream);
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   ts->hits_valid = true;

@@ -22,6 +22,7 @@ struct DevResult {  // matches hhv_result
 struct DevHit {  // matches hhv_hit
   float score;
   float viterbi_score;
+  float score_ss;
   int32_t index;
   int32_t i1, j1, i2, j2;
   int32_t nsteps;
@@ -43,6 +44,10 @@ struct StreamArgs {
   float4* carry;             // [n_records] bottom-row state {MM,GD,IM,DG} of the previous / for the next pass ...
   float* carry_mi;           // ... and MI
   int64_t bt_pass_stride;    // backtrace entries per pass = n_records * 64
+  // secondary-structure term (SS variants): ss(i,j) = ss_table[ss_q_off[i-1] + ((meta_j >> ss_t_shift) & ss_t_mask)]
+  const float* ss_table;     // ssw * S33 / S73 / S37, premultiplied on the host (same fp32 product as the reference)
+  const int32_t* ss_q_off;   // [P*64*R] table row offset of query row i at index i-1
+  int32_t ss_t_shift, ss_t_mask;
 };
 
 struct TraceArgs {
@@ -64,11 +69,14 @@ struct TraceArgs {
   int32_t ss_mode;
   int32_t Lq, R, n;
   int64_t bt_pass_stride;    // backtrace entries per pass (rows are split in passes of 64*R)
+  const float* ss_table;     // null: no secondary-structure information (score_ss = 0)
+  const int32_t* ss_q_off;
+  int32_t ss_t_shift, ss_t_mask;
 };
 
 // launchers implemented in hhv_kernels.hip
-int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, const StreamArgs& a, int n_waves, void* stream);
-int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, int* blocks_per_cu, int* vgprs);
+int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
+int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);
 int launch_trace(const TraceArgs& a, void* stream);
 
 }  // namespace hhv

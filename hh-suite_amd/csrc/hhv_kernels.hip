@@ -49,7 +49,8 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int c
 // VOP2 every ~6.3 clk, two waves one every ~2.5 clk: tools/valu_ubench).  Up to R = 5 rows per lane the
 // kernel is held to <= 256 VGPRs (2 waves/SIMD; the backtrace variants spill a few dwords to scratch).
 // MULTI = the query needs more than one pass of 64*R rows (the carry hand-over code is compiled out otherwise).
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI>
+// SS = secondary-structure term added to the emission score (the reference's ...AndSS builds).
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS>
 __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   __shared__ float4 ring[RING_RECS * 7];
   const int lane = threadIdx.x;
@@ -80,6 +81,11 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   q.load(a.qpack + (size_t)lane * R * REC_DW);
   LaneState<R> st;
   st.reset();
+  int ss_qoff[R];
+  if (SS) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) ss_qoff[r] = a.ss_q_off[i0 - 1 + r];
+  }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -155,7 +161,13 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         if (BT || CELLOFF)
           bte = a.bt + ((MULTI ? (size_t)(a.row_base / (LANES * R)) * a.bt_pass_stride : 0) + (size_t)(rb + r) * LANES + lane);
         if (CELLOFF) cell = *bte;
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT>(st, q, in, rec, j, i0, r_last, P, cell);
+        float ssv[R];
+        if (SS) {
+          const int tidx = (meta >> a.ss_t_shift) & a.ss_t_mask;
+#pragma unroll
+          for (int r = 0; r < R; ++r) ssv[r] = a.ss_table[ss_qoff[r] + tidx];
+        }
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT, SS>(st, q, in, rec, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
       if (carry_out) {
@@ -262,6 +274,7 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   DevHit h;
   h.score = res.score;  // completed by hhv_rescore_kernel
   h.viterbi_score = res.score;
+  h.score_ss = 0.0f;
   h.index = k;
   h.i1 = i_steps[step];
   h.j1 = j_steps[step];
@@ -301,7 +314,18 @@ __global__ void __launch_bounds__(64) hhv_rescore_kernel(TraceArgs a) {
   __syncthreads();
   if (lane == 0) {
     float score = a.hits[k].viterbi_score;
-    if (a.ss_mode == 2) score -= 0.0f;  // no secondary-structure term on this path: score_ss = 0 (:238)
+    // :225-238: score_ss = sum over MM steps of ScoreSS(q,t,i,j) in step order; subtracted when ssm == 2
+    float score_ss = 0.0f;
+    if (a.ss_table) {
+      for (int s = 1; s <= nsteps; ++s) {
+        if (states[s] == 2 && i_steps[s] >= 1 && j_steps[s] >= 1) {
+          const int32_t meta = __builtin_bit_cast(int32_t, a.records[(size_t)(rec0 + j_steps[s]) * REC_DW + REC_META]);
+          score_ss += a.ss_table[a.ss_q_off[i_steps[s] - 1] + ((meta >> a.ss_t_shift) & a.ss_t_mask)];
+        }
+      }
+    }
+    if (a.ss_mode == 2) score -= score_ss;
+    a.hits[k].score_ss = score_ss;
     float Scorr = 0;
     if (in_lds) {
       for (int s = 2; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 1];
@@ -324,30 +348,35 @@ __global__ void __launch_bounds__(64) hhv_rescore_kernel(TraceArgs a) {
 // host-side launch helpers
 
 template <int R, bool LOCAL, bool BT, bool CELLOFF>
-static void* kernel_ptr(bool multi) {
-  return multi ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, true> : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, false>;
+static void* kernel_ptr(bool multi, bool ss) {
+  if (ss)
+    return multi ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, true, true>
+                 : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, false, true>;
+  return multi ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, true, false>
+               : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, false, false>;
 }
 
 template <int R>
-static void* pick_variant(bool local, bool bt, bool celloff, bool multi) {
-  if (celloff) return local ? kernel_ptr<R, true, true, true>(multi) : kernel_ptr<R, false, true, true>(multi);
-  if (bt) return local ? kernel_ptr<R, true, true, false>(multi) : kernel_ptr<R, false, true, false>(multi);
-  return local ? kernel_ptr<R, true, false, false>(multi) : kernel_ptr<R, false, false, false>(multi);
+static void* pick_variant(bool local, bool bt, bool celloff, bool multi, bool ss) {
+  if (celloff) return local ? kernel_ptr<R, true, true, true>(multi, ss) : kernel_ptr<R, false, true, true>(multi, ss);
+  if (bt) return local ? kernel_ptr<R, true, true, false>(multi, ss) : kernel_ptr<R, false, true, false>(multi, ss);
+  return local ? kernel_ptr<R, true, false, false>(multi, ss) : kernel_ptr<R, false, false, false>(multi, ss);
 }
 
-static void* pick(int R, bool local, bool bt, bool celloff, bool multi) {
+static void* pick(int R, bool local, bool bt, bool celloff, bool multi, bool ss) {
   switch (R) {
-    case 1: return pick_variant<1>(local, bt, celloff, multi);
-    case 2: return pick_variant<2>(local, bt, celloff, multi);
-    case 3: return pick_variant<3>(local, bt, celloff, multi);
-    case 4: return pick_variant<4>(local, bt, celloff, multi);
-    case 5: return pick_variant<5>(local, bt, celloff, multi);
+    case 1: return pick_variant<1>(local, bt, celloff, multi, ss);
+    case 2: return pick_variant<2>(local, bt, celloff, multi, ss);
+    case 3: return pick_variant<3>(local, bt, celloff, multi, ss);
+    case 4: return pick_variant<4>(local, bt, celloff, multi, ss);
+    case 5: return pick_variant<5>(local, bt, celloff, multi, ss);
   }
   return nullptr;
 }
 
-int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, const StreamArgs& a, int n_waves, void* stream) {
-  void* fn = pick(R, local, bt, celloff, multi);
+int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves,
+                  void* stream) {
+  void* fn = pick(R, local, bt, celloff, multi, ss);
   if (!fn) return -1;
   StreamArgs args = a;
   void* kargs[] = {&args};
@@ -355,8 +384,9 @@ int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, const St
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, int* blocks_per_cu, int* vgprs) {
-  void* fn = pick(R, local, bt, celloff, multi);
+int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu,
+                            int* vgprs) {
+  void* fn = pick(R, local, bt, celloff, multi, ss);
   if (!fn) return -1;
   int nb = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, LANES, 0);

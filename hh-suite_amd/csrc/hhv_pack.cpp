@@ -41,12 +41,18 @@ void write_header(float* rec, int32_t index, int32_t L) {
   put_i32(rec + REC_META, META_HDR);
 }
 
-void pack_template(const float* p, const float* tr, int L, int32_t index, float* out) {
+void pack_template(const float* p, const float* tr, int L, int32_t index, float* out, const int8_t* ss_pred,
+                   const int8_t* ss_conf, const int8_t* ss_dssp) {
   write_header(out, index, L);
   pack_columns(p, tr, L, out + REC_DW);
   for (int j = 1; j <= L; ++j) {
     int32_t meta = j;
     if (j == L) meta |= META_LAST;
+    // src/hhhmmsimd.cpp:132-135: pred_index = (unsigned char) ss_pred * MAXCF + ss_conf, dssp_index = ss_dssp
+    const int pred = ss_pred ? (unsigned char)ss_pred[j] : 0, conf = ss_conf ? ss_conf[j] : 0;
+    const int dssp = ss_dssp ? (unsigned char)ss_dssp[j] : 0;
+    meta |= (int32_t)((unsigned char)(pred * 11 + conf) & META_PRED_MASK) << META_PRED_SHIFT;
+    meta |= (int32_t)(dssp & META_DSSP_MASK) << META_DSSP_SHIFT;
     put_i32(out + (size_t)j * REC_DW + REC_META, meta);
   }
 }

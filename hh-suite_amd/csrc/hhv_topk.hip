@@ -35,6 +35,7 @@ __global__ void results_to_hits_kernel(const DevResult* __restrict__ res, int n,
   DevHit h;
   h.score = r.score;
   h.viterbi_score = r.score;
+  h.score_ss = 0.0f;
   h.index = k;
   h.i1 = h.j1 = 0;
   h.i2 = r.i2;

@@ -43,7 +43,11 @@ constexpr int REC_M2M = 20, REC_M2D = 21, REC_D2M = 22, REC_D2D = 23, REC_I2M = 
               REC_META = 27;
 constexpr int32_t META_HDR = (int32_t)0x80000000;  // header record: [0] = template index, [1] = Lt
 constexpr int32_t META_LAST = 0x40000000;          // column record of j == Lt
-constexpr int32_t META_JMASK = 0x00FFFFFF;
+constexpr int32_t META_JMASK = 0x0000FFFF;         // j (template lengths are limited to 65535)
+// secondary-structure indices of template column j, exactly the per-column bytes HMMSimd::MapHMMVector
+// precomputes (src/hhhmmsimd.cpp:132-135): pred_index = ss_pred*MAXCF + ss_conf (0..43), dssp_index = ss_dssp (0..7)
+constexpr int META_PRED_SHIFT = 16, META_PRED_MASK = 0x3F;
+constexpr int META_DSSP_SHIFT = 22, META_DSSP_MASK = 0x7;
 
 constexpr float NEG_MAX = -FLT_MAX;
 
@@ -261,9 +265,11 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
 // (no loop-carried copies): A (rows bottom-up) everything that reads only column j-1 state - the five
 // MM candidates, GD and IM; B the R emission scores (independent dot products = the ILP of the
 // kernel); C (rows top-down) MM += S, then DG and MI which chain through the row above.
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE>
+//   ssv      : SS only - ssv[r] = ssw * S[q_ss(i0+r)][t_ss(j)], the secondary-structure term of the ...AndSS
+//              builds (src/hhviterbialgorithm.cpp:194-213,278-280), added as ss + log2f4(..) like the reference
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS>
 HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const float* rec, int j, int i0,
-                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits) {
+                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv) {
   const float smin = LOCAL ? 0.0f : NEG_MAX;
   const float tM2M = rec[REC_M2M], tM2D = rec[REC_M2D], tD2M = rec[REC_D2M], tD2D = rec[REC_D2D],
               tI2M = rec[REC_I2M], tI2I = rec[REC_I2I], tM2I = rec[REC_M2I];
@@ -312,7 +318,11 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   // ---- phase B: :277-283
   float S[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) S[r] = log2f4(dot20(q.p[r], rec)) + P.shift;
+  for (int r = 0; r < R; ++r) {
+    float v = log2f4(dot20(q.p[r], rec));
+    if (SS) v = ssv[r] + v;
+    S[r] = v + P.shift;
+  }
   // ---- phase C, rows 0 .. R-1: (i-1, j) = new state of the row above
   float uMM = in.MM, uDG = in.DG, uMI = in.MI;
   uint64_t bytes = 0;

@@ -107,7 +107,7 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
       hit.irep = alignment + 1;                       // :257
       hit.lastrep = (h.score <= par.smin) ? 1 : 0;    // :37
       hit.score = h.score;
-      hit.score_ss = 0.0f;
+      hit.score_ss = h.score_ss;
       hit.score_aass = -h.score;                      // hhviterbi.cpp:252
       hit.i1 = h.i1;
       hit.j1 = h.j1;

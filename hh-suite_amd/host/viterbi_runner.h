@@ -62,6 +62,16 @@ struct Hit {
   std::vector<float> S, S_ss;
 };
 
+// The ss_hmm_mode ViterbiConsumerThread::align derives for a batch (src/hhviterbirunner.cpp:14-22), restated
+// literally: consensus = AND over the batch of HMM::computeScoreSSMode(q, t) (src/hhhmm.cpp:1967-1973); the
+// selection chain can only ever return 0 or PRED_PRED (4) - PRED_DSSP / DSSP_PRED are discarded.
+inline int SelectSSMode(int consensus_ss_hmm_mode) {
+  int ss_hmm_mode = (consensus_ss_hmm_mode & 1 /*PRED_DSSP*/);
+  ss_hmm_mode = (ss_hmm_mode == 0) ? consensus_ss_hmm_mode & 2 /*DSSP_PRED*/ : 0;
+  ss_hmm_mode = (ss_hmm_mode == 0) ? consensus_ss_hmm_mode & 4 /*PRED_PRED*/ : 0;
+  return ss_hmm_mode;
+}
+
 // Viterbi::ExcludeAlignment (src/hhviterbi.cpp:61-77): OR the +-VITERBI_PATH_WIDTH cross of one path
 // into mask[(Lq+1)*(Lt+1)]
 void ExcludeAlignment(std::vector<uint8_t>& mask, int Lq, int Lt, const int32_t* i_steps, const int32_t* j_steps,

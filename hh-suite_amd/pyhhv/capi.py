@@ -27,14 +27,15 @@ class HhvParams(C.Structure):
 
 
 RESULT_DTYPE = np.dtype([("score", np.float32), ("i2", np.int32), ("j2", np.int32), ("index", np.int32)])
-HIT_DTYPE = np.dtype([("score", np.float32), ("viterbi_score", np.float32), ("index", np.int32),
+HIT_DTYPE = np.dtype([("score", np.float32), ("viterbi_score", np.float32), ("score_ss", np.float32), ("index", np.int32),
                       ("i1", np.int32), ("j1", np.int32), ("i2", np.int32), ("j2", np.int32),
                       ("nsteps", np.int32), ("matched_cols", np.int32)])
 
 # every symbol include/hhviterbi_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
-    "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_upload_templates", "hhv_adopt_device_stream",
+    "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
+    "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
@@ -66,6 +67,12 @@ def load():
     L.hhv_set_query.argtypes = [C.c_void_p, c_float_p, c_float_p, C.c_int32]
     L.hhv_upload_templates.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
                                        C.POINTER(C.c_void_p)]
+    c_i8pp = C.POINTER(C.c_void_p)
+    L.hhv_upload_templates_ss.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
+                                          c_i8pp, c_i8pp, c_i8pp, C.POINTER(C.c_void_p)]
+    L.hhv_set_ss_tables.argtypes = [C.c_void_p, c_float_p, c_float_p, c_float_p]
+    L.hhv_set_query_ss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hhv_set_ss_mode.argtypes = [C.c_void_p, C.c_int32]
     L.hhv_adopt_device_stream.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.c_void_p, C.POINTER(C.c_void_p)]
     L.hhv_tset_free.argtypes = [C.c_void_p]
     L.hhv_tset_free.restype = None
@@ -156,7 +163,8 @@ class Context:
         self.Lq = p.shape[0] - 1
         _check(self.lib.hhv_set_query(self.h, p.ctypes.data_as(c_float_p), tr.ctypes.data_as(c_float_p), self.Lq))
 
-    def upload(self, tps, ttrs):
+    def upload(self, tps, ttrs, t_ss=None):
+        """t_ss: optional list of (ss_pred, ss_conf, ss_dssp) int8 arrays per template (entries may be None)."""
         tps = [_f32(a) for a in tps]
         ttrs = [_f32(a) for a in ttrs]
         n = len(tps)
@@ -164,8 +172,29 @@ class Context:
         pp = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in tps])
         tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in ttrs])
         h = C.c_void_p()
-        _check(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, C.byref(h)))
+        if t_ss is None:
+            _check(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, C.byref(h)))
+        else:
+            keep = [[None if x is None else np.ascontiguousarray(x, dtype=np.int8) for x in t] for t in t_ss]
+            arrs = []
+            for col in range(3):
+                arrs.append((C.c_void_p * n)(*[(k[col].ctypes.data if k[col] is not None else None) for k in keep]))
+            _check(self.lib.hhv_upload_templates_ss(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, arrs[0], arrs[1],
+                                                    arrs[2], C.byref(h)))
         return TemplateSet(self, h, Ls)
+
+    def set_ss_tables(self, S73, S33, S37):
+        S73, S33, S37 = _f32(S73).reshape(-1), _f32(S33).reshape(-1), _f32(S37).reshape(-1)
+        assert S73.size == 352 and S33.size == 1936 and S37.size == 352
+        _check(self.lib.hhv_set_ss_tables(self.h, S73.ctypes.data_as(c_float_p), S33.ctypes.data_as(c_float_p),
+                                          S37.ctypes.data_as(c_float_p)))
+
+    def set_query_ss(self, ss_pred=None, ss_conf=None, ss_dssp=None):
+        a = [None if x is None else np.ascontiguousarray(x, dtype=np.int8) for x in (ss_pred, ss_conf, ss_dssp)]
+        _check(self.lib.hhv_set_query_ss(self.h, *[(x.ctypes.data if x is not None else None) for x in a]))
+
+    def set_ss_mode(self, mode):
+        _check(self.lib.hhv_set_ss_mode(self.h, int(mode)))
 
     def adopt_device_stream(self, Ls, device_ptr):
         Ls = np.ascontiguousarray(Ls, dtype=np.int32)

@@ -67,9 +67,11 @@ def pack_query(p, tr, R=None, P=None):
     return out
 
 
-def pack_stream(tps, ttrs):
+def pack_stream(tps, ttrs, t_ss=None):
     """Concatenated template stream: per template a header record then L column records, plus one
-    terminal header.  Returns (records[(sum(L+1)+1), 28] float32, rec_off[n+1] int64)."""
+    terminal header.  t_ss: optional per-template (ss_pred, ss_conf, ss_dssp) arrays -> meta bits 16-21
+    (pred_index = ss_pred*11 + ss_conf) and 22-24 (ss_dssp).
+    Returns (records[(sum(L+1)+1), 28] float32, rec_off[n+1] int64)."""
     n = len(tps)
     Ls = np.array([t.shape[0] - 1 for t in tps], dtype=np.int64)
     rec_off = np.zeros(n + 1, dtype=np.int64)
@@ -86,6 +88,9 @@ def pack_stream(tps, ttrs):
         rec[o + 1:o + 1 + L] = pack_columns(tps[k], ttrs[k])
         meta[o + 1:o + 1 + L, 27] = np.arange(1, L + 1, dtype=np.int32)
         meta[o + L, 27] |= META_LAST
+        if t_ss is not None and t_ss[k] is not None:
+            pr, cf, ds = (np.asarray(x, dtype=np.int32) for x in t_ss[k])
+            meta[o + 1:o + 1 + L, 27] |= (((pr[1:] * 11 + cf[1:]) & 0x3F) << 16) | ((ds[1:] & 7) << 22)
     o = int(rec_off[-1])
     meta[o, 27] = META_HDR
     meta[o, 0] = -1

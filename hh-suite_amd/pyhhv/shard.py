@@ -4,7 +4,7 @@ One process per GPU.  Every template is independent of every other (the referenc
 batches as independent OpenMP iterations, /root/reference src/hhviterbirunner.cpp:122), so the DP
 itself needs no communication: each rank aligns its own shard.  The only exchange is the final hit
 list: every rank selects its K best records on the device (hhv_topk), ONE all_gather moves K fixed
-size records per rank (K=500 -> 18 KB per rank; latency bound on xGMI), and every rank performs the
+size records per rank (K=500 -> 20 KB per rank; latency bound on xGMI), and every rank performs the
 same deterministic merge (score descending, ties by global template id ascending).
 
 This module holds only the partitioning and the exchange/merge logic; it works on any
@@ -12,7 +12,8 @@ torch.distributed backend ("nccl" = RCCL on the GPUs, "gloo" in the CPU tests).
 """
 import numpy as np
 
-REC_I32 = 9  # one hhv_hit record = 9 x 4 bytes: score, viterbi_score, index, i1, j1, i2, j2, nsteps, matched_cols
+REC_I32 = 10  # one hhv_hit record = 10 x 4 bytes: score, viterbi_score, score_ss, index, i1, j1, i2, j2, nsteps, matched_cols
+COL_INDEX = 3
 
 
 def shard_templates(lengths, world):
@@ -43,11 +44,11 @@ def shard_templates(lengths, world):
 
 
 def merge_records(torch, records, K):
-    """records: (m, 9) int32 tensor of hhv_hit records whose `index` field already holds GLOBAL template
+    """records: (m, 10) int32 tensor of hhv_hit records whose `index` field already holds GLOBAL template
     ids (invalid padding records carry index < 0).  Returns the K best, sorted by score descending,
     ties by global id ascending -- identical on every rank."""
     score = records[:, 0].contiguous().view(torch.float32)
-    gid = records[:, 2].to(torch.int64)
+    gid = records[:, COL_INDEX].to(torch.int64)
     valid = gid >= 0
     # composite ordering: primary score desc, secondary gid asc (stable sorts, secondary key first)
     big = torch.iinfo(torch.int64).max
@@ -60,7 +61,7 @@ def merge_records(torch, records, K):
 
 
 def exchange_and_merge(torch, dist, local_records, K, group=None):
-    """local_records: (K, 9) int32 tensor (device of the backend), global ids in column 2, padding = -1.
+    """local_records: (K, 10) int32 tensor (device of the backend), global ids in the index column, padding = -1.
     ONE all_gather of K records per rank, then the common merge."""
     world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
     if world == 1:
@@ -74,13 +75,13 @@ def exchange_and_merge(torch, dist, local_records, K, group=None):
 
 
 def to_global_ids(torch, records, global_ids):
-    """Replace the local template index (column 2) by the global id; padding (0xFF.. records) -> -1."""
-    idx = records[:, 2].to(torch.int64)
+    """Replace the local template index by the global id; padding (0xFF.. records) -> -1."""
+    idx = records[:, COL_INDEX].to(torch.int64)
     ok = (idx >= 0) & (idx < global_ids.shape[0])
     out = records.clone()
     if global_ids.shape[0] == 0:
-        out[:, 2] = -1
+        out[:, COL_INDEX] = -1
         return out
     gid = torch.where(ok, global_ids[idx.clamp(0, global_ids.shape[0] - 1)], torch.full_like(idx, -1))
-    out[:, 2] = gid.to(torch.int32)
+    out[:, COL_INDEX] = gid.to(torch.int32)
     return out

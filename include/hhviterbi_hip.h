@@ -18,6 +18,10 @@
  *                                                                      src/hhviterbi.cpp:83-160, src/hhviterbi.h:34-40
  *   hhv_hits / hhv_hit_path    Viterbi::ScoreForBacktrace(...) -> BacktraceScore and the Hit fields filled in
  *                              ViterbiConsumerThread::align            src/hhviterbi.cpp:195-281, src/hhviterbirunner.cpp:35-62
+ *   hhv_set_ss_tables / hhv_set_query_ss / hhv_upload_templates_ss / hhv_set_ss_mode
+ *                              the secondary-structure inputs of Viterbi::Align...AndSS: S73/S33/S37 of the
+ *                              Viterbi constructor, HMM::ss_pred/ss_conf/ss_dssp (src/hhhmm.h:151-154), and the
+ *                              ss_hmm_mode argument of Viterbi::Align (src/hhviterbi.cpp:163-177)
  *   hhv_topk                   (new) device-side selection of the K best hits by Hit.score, the
  *                              per-GPU half of the sharded top-K merge
  *
@@ -62,7 +66,7 @@ typedef struct {
   float egt;        /* par.egt  end-gap penalty template */
   float shift;      /* par.shift */
   float corr;       /* par.corr */
-  float ssw;        /* par.ssw (secondary-structure weight; SS scoring is not built yet: must be unused) */
+  float ssw;        /* par.ssw  secondary-structure weight */
   int32_t ss_mode;  /* par.ssm  (2 = Hit::SCORE_ALIGNMENT) */
 } hhv_params;
 
@@ -78,6 +82,7 @@ typedef struct {
 typedef struct {
   float score;          /* BacktraceScore.score: Viterbi score - score_ss + corr * Scorr */
   float viterbi_score;  /* raw ViterbiResult.score */
+  float score_ss;       /* BacktraceScore.score_ss: sum of ScoreSS over the matched columns */
   int32_t index;        /* template index inside the set */
   int32_t i1, j1;       /* i_steps[nsteps], j_steps[nsteps] (alignment start) */
   int32_t i2, j2;       /* alignment end */
@@ -110,9 +115,25 @@ void hhv_destroy(hhv_ctx* ctx);
 /* query: p[(Lq+1)*20], tr[(Lq+1)*7] */
 int hhv_set_query(hhv_ctx* ctx, const float* p, const float* tr, int32_t Lq);
 
+/* secondary structure (all optional; without them the engine runs the reference's no-SS kernels).
+ * tables: S73[8][4][11], S33[4][11][4][11], S37[4][11][8] (NDSSP, NSSPRED, MAXCF of src/hhdecl.h:53-55);
+ * query arrays [Lq+1] (call after hhv_set_query; NULL = absent);
+ * mode: the ss_hmm_mode Viterbi::Align receives - 0 HMM::NO_SS_INFORMATION, 1 PRED_DSSP, 2 DSSP_PRED,
+ * 4 PRED_PRED (src/hhhmm.h:58-61).  Like the reference, the SS term enters the DP only when
+ * par.ss_mode == 2 (src/hhviterbi.cpp:175); hhv_hits always reports score_ss for the mode. */
+int hhv_set_ss_tables(hhv_ctx* ctx, const float* S73, const float* S33, const float* S37);
+int hhv_set_query_ss(hhv_ctx* ctx, const int8_t* ss_pred, const int8_t* ss_conf, const int8_t* ss_dssp);
+int hhv_set_ss_mode(hhv_ctx* ctx, int32_t ss_hmm_mode);
+
 /* n prepared template profiles -> resident packed set in HBM.  L[k] >= 1. */
 int hhv_upload_templates(hhv_ctx* ctx, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
                          hhv_tset** out);
+/* Same with secondary-structure records: ss_pred[k] / ss_conf[k] / ss_dssp[k] are [L[k]+1] arrays in the
+ * reference's encoding (HMM::ss_pred 0..3, ss_conf 0..10, ss_dssp 0..7, src/hhhmm.h:151-154); the array of
+ * pointers or any entry may be NULL (= no such record, zeros). */
+int hhv_upload_templates_ss(hhv_ctx* ctx, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
+                            const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp,
+                            hhv_tset** out);
 /* Adopt an already packed DEVICE buffer (zero copy).  d_records holds the record stream described
  * in DESIGN.md section 2: for each template a header record followed by L[k] column records, one
  * terminal header, then >= HHV_STREAM_PAD records of slack; 28 floats per record.  The buffer must

@@ -19,10 +19,18 @@ struct Carry {
   float MM, GD, IM, DG, MI;
 };
 
+// secondary-structure inputs of the emulation (null table = no SS): the premultiplied table ssw*S, the
+// table row offset of every query row and where the template index sits in the record meta
+struct SSArgs {
+  const float* table;
+  const int32_t* q_off;  // [passes*64*R]
+  int t_shift, t_mask;
+};
+
 template <int R, bool LOCAL, bool BT, bool CELLOFF>
 static int run_pass(const float* qpack, const float* records, long M, Params P, TemplateResult* results, int n_results,
                     uint64_t* bt /* M x 64 entries of this pass, in/out */, int row_base, bool first, bool last,
-                    std::vector<Carry>& carry) {
+                    std::vector<Carry>& carry, const SSArgs& ss) {
   std::vector<LaneState<R>> st(64);
   std::vector<QRows<R>> q(64);
   for (int g = 0; g < 64; ++g) {
@@ -76,7 +84,15 @@ static int run_pass(const float* qpack, const float* records, long M, Params P, 
         const int j = meta & META_JMASK;
         uint64_t cell = 0;
         if (CELLOFF) cell = bt[(size_t)r * 64 + g];
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT>(st[g], q[g], in, rec, j, i0, r_last, P, cell);
+        uint64_t bytes;
+        if (ss.table) {
+          float ssv[R];
+          const int tidx = (meta >> ss.t_shift) & ss.t_mask;
+          for (int r = 0; r < R; ++r) ssv[r] = ss.table[ss.q_off[i0 - 1 + r] + tidx];
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT, true>(st[g], q[g], in, rec, j, i0, r_last, P, cell, ssv);
+        } else {
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT, false>(st[g], q[g], in, rec, j, i0, r_last, P, cell, nullptr);
+        }
         if (BT) bt[(size_t)r * 64 + g] = bytes;
       }
       if (!last && g == 63) {
@@ -91,46 +107,48 @@ static int run_pass(const float* qpack, const float* records, long M, Params P, 
 // qpack holds passes * 64 * R rows; bt holds passes planes of M x 64 entries
 template <int R, bool LOCAL, bool BT, bool CELLOFF>
 static int run_wave(const float* qpack, const float* records, long M, Params P, TemplateResult* results, int n_results,
-                    uint64_t* bt, int passes) {
+                    uint64_t* bt, int passes, const SSArgs& ss) {
   std::vector<Carry> carry(M);
   int emitted = 0;
   for (int p = 0; p < passes; ++p) {
     emitted = run_pass<R, LOCAL, BT, CELLOFF>(qpack + (size_t)p * 64 * R * REC_DW, records, M, P, results, n_results,
                                               bt ? bt + (size_t)p * M * 64 : nullptr, p * 64 * R, p == 0, p == passes - 1,
-                                              carry);
+                                              carry, ss);
   }
   return emitted;
 }
 
 template <int R>
 static int dispatch(int local, int want_bt, int celloff, const float* qpack, const float* records, long M, Params P,
-                    TemplateResult* results, int n_results, uint64_t* bt, int passes) {
+                    TemplateResult* results, int n_results, uint64_t* bt, int passes, const SSArgs& ss) {
   if (celloff) {
-    return local ? run_wave<R, true, true, true>(qpack, records, M, P, results, n_results, bt, passes)
-                 : run_wave<R, false, true, true>(qpack, records, M, P, results, n_results, bt, passes);
+    return local ? run_wave<R, true, true, true>(qpack, records, M, P, results, n_results, bt, passes, ss)
+                 : run_wave<R, false, true, true>(qpack, records, M, P, results, n_results, bt, passes, ss);
   }
   if (want_bt) {
-    return local ? run_wave<R, true, true, false>(qpack, records, M, P, results, n_results, bt, passes)
-                 : run_wave<R, false, true, false>(qpack, records, M, P, results, n_results, bt, passes);
+    return local ? run_wave<R, true, true, false>(qpack, records, M, P, results, n_results, bt, passes, ss)
+                 : run_wave<R, false, true, false>(qpack, records, M, P, results, n_results, bt, passes, ss);
   }
-  return local ? run_wave<R, true, false, false>(qpack, records, M, P, results, n_results, bt, passes)
-               : run_wave<R, false, false, false>(qpack, records, M, P, results, n_results, bt, passes);
+  return local ? run_wave<R, true, false, false>(qpack, records, M, P, results, n_results, bt, passes, ss)
+               : run_wave<R, false, false, false>(qpack, records, M, P, results, n_results, bt, passes, ss);
 }
 
 extern "C" int hhv_emul_wave(int R, int local, int want_bt, int celloff, const float* qpack, const float* records,
                              long M, float egq, float egt, float shift, int Lq, TemplateResult* results,
-                             int n_results, uint64_t* bt, int passes) {
+                             int n_results, uint64_t* bt, int passes, const float* ss_table, const int32_t* ss_q_off,
+                             int ss_t_shift, int ss_t_mask) {
+  SSArgs ss = {ss_table, ss_q_off, ss_t_shift, ss_t_mask};
   Params P;
   P.egq = egq;
   P.egt = egt;
   P.shift = shift;
   P.Lq = Lq;
   switch (R) {
-    case 1: return dispatch<1>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
-    case 2: return dispatch<2>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
-    case 3: return dispatch<3>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
-    case 4: return dispatch<4>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
-    case 5: return dispatch<5>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes);
+    case 1: return dispatch<1>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes, ss);
+    case 2: return dispatch<2>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes, ss);
+    case 3: return dispatch<3>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes, ss);
+    case 4: return dispatch<4>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes, ss);
+    case 5: return dispatch<5>(local, want_bt, celloff, qpack, records, M, P, results, n_results, bt, passes, ss);
   }
   return -1;
 }

@@ -25,7 +25,7 @@ def test_header_symbols_exported():
 def test_struct_sizes():
     from pyhhv import capi
     assert capi.RESULT_DTYPE.itemsize == 16
-    assert capi.HIT_DTYPE.itemsize == 36
+    assert capi.HIT_DTYPE.itemsize == 40
 
 
 def test_no_cpu_fallback():

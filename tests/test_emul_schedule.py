@@ -26,21 +26,37 @@ def emul():
         subprocess.check_call(["make", "-C", ROOT, "emul"])
     lib = C.CDLL(SO)
     lib.hhv_emul_wave.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_float,
-                                                  C.c_int, C.POINTER(TR), C.c_int, C.c_void_p, C.c_int]
+                                                  C.c_int, C.POINTER(TR), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     return lib
 
 
-def run(emul, par, qf, qtr, tps, ttrs, want_bt, bt_in=None):
+def ss_operands(par, ss, Lq, R, P):
+    """Premultiplied table + per-row offsets + (shift, mask) exactly like hhv_api.cpp::ensure_ss."""
+    T = {4: ss.S33, 2: ss.S73, 1: ss.S37}[ss.mode].reshape(-1)
+    tab = (np.float32(par["ssw"]) * T).astype(np.float32)
+    off = np.zeros(P * 64 * R, dtype=np.int32)
+    for i in range(1, Lq + 1):
+        pr, cf, ds = int(ss.q_pred[i]), int(ss.q_conf[i]), int(ss.q_dssp[i])
+        off[i - 1] = {4: (pr * 11 + cf) * 44, 2: ds * 44, 1: (pr * 11 + cf) * 8}[ss.mode]
+    shift, mask = (22, 7) if ss.mode == 1 else (16, 0x3F)
+    return tab, off, shift, mask
+
+
+def run(emul, par, qf, qtr, tps, ttrs, want_bt, bt_in=None, ss=None, t_ss=None):
     Lq = qf.shape[0] - 1
     R, P = pack.strips_for(Lq)
     qpack = pack.pack_query(qf, qtr, R, P)
-    rec, off = pack.pack_stream(tps, ttrs)
+    rec, off = pack.pack_stream(tps, ttrs, t_ss)
     M = rec.shape[0]
     n = len(tps)
     res = (TR * n)()
     bt = np.zeros((P, M, 64), dtype=np.uint64) if bt_in is None else bt_in
+    ssargs = (None, None, 0, 0)
+    if ss is not None:
+        tab, qoff, shift, mask = ss_operands(par, ss, Lq, R, P)   # keep the arrays alive across the call
+        ssargs = (tab.ctypes.data, qoff.ctypes.data, shift, mask)
     em = emul.hhv_emul_wave(R, par["local"], int(want_bt), int(bt_in is not None), qpack.ctypes.data, rec.ctypes.data,
-                            M, par["egq"], par["egt"], par["shift"], Lq, res, n, bt.ctypes.data, P)
+                            M, par["egq"], par["egt"], par["shift"], Lq, res, n, bt.ctypes.data, P, *ssargs)
     assert em == n
     return res, bt, off, R
 
@@ -83,3 +99,26 @@ def test_schedule_celloff(emul, oracle):
             assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2)
             m = pack.bt_to_matrix(bt2.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R)
             assert np.array_equal(m[1:, 1:], a.bt[1:, 1:])
+
+
+def test_schedule_secondary_structure(emul, oracle):
+    """...AndSS variants for the three ss_hmm_modes, single and multi pass."""
+    from pyoracle import SSInfo
+    rng = np.random.default_rng(5)
+    S73 = rng.normal(0, 1, (8, 4, 11)).astype(np.float32)
+    S33 = rng.normal(0, 1, (4, 11, 4, 11)).astype(np.float32)
+    S37 = rng.normal(0, 1, (4, 11, 8)).astype(np.float32)
+    for Lq, local in ((80, 1), (330, 0)):
+        par = make_params(local=local, ss_mode=2)
+        qf, qtr, tps, ttrs = workload(9 + Lq, Lq, 3, 40, 100, homolog_every=1)
+        for mode in (1, 2, 4):
+            ss = SSInfo(mode, rng.integers(0, 4, Lq + 1), rng.integers(0, 11, Lq + 1), rng.integers(0, 8, Lq + 1),
+                        S73, S33, S37)
+            t_ss = [(rng.integers(0, 4, p.shape[0]), rng.integers(0, 11, p.shape[0]), rng.integers(0, 8, p.shape[0]))
+                    for p in tps]
+            res, bt, off, R = run(emul, par, qf, qtr, tps, ttrs, 1, ss=ss, t_ss=t_ss)
+            for e in range(3):
+                a = oracle.align(par, qf, qtr, tps[e], ttrs[e], ss=ss, t_ss=t_ss[e], want_bt=True)
+                assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2), (Lq, mode, e)
+                m = pack.bt_to_matrix(bt.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R)
+                assert np.array_equal(m[1:, 1:], a.bt[1:, 1:])

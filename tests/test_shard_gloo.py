@@ -43,7 +43,7 @@ def local_records(o, par, qf, qtr, tps, ttrs, ids, K):
     rows.sort(key=lambda r: (-r[0], r[1]))
     for t, (s, loc, i2, j2) in enumerate(rows[:K]):
         bits = np.float32(s).view(np.int32)
-        rec[t] = [bits, bits, loc, 0, 0, i2, j2, 0, 0]
+        rec[t] = [bits, bits, 0, loc, 0, 0, i2, j2, 0, 0]
     return rec
 
 
@@ -77,7 +77,7 @@ def test_two_rank_topk_merge(tmp_path):
     qf, qtr, tps, ttrs = make_db(n)
     scores = [float(o.align(par, qf, qtr, tps[g], ttrs[g], want_bt=False).score) for g in range(n)]
     want = sorted(range(n), key=lambda g: (-scores[g], g))[:K]
-    assert list(m0[:, 2]) == want
+    assert list(m0[:, shard.COL_INDEX]) == want
     assert np.array_equal(m0[:, 0].view(np.float32), np.array([scores[g] for g in want], dtype=np.float32))
 
 
@@ -95,9 +95,9 @@ def test_shard_partition_properties():
 
 
 def test_merge_tie_break():
-    rec = torch.tensor([[np.float32(1.5).view(np.int32), 0, 9, 0, 0, 0, 0, 0, 0],
-                        [np.float32(2.5).view(np.int32), 0, 4, 0, 0, 0, 0, 0, 0],
-                        [np.float32(1.5).view(np.int32), 0, 3, 0, 0, 0, 0, 0, 0],
-                        [-1, -1, -1, -1, -1, -1, -1, -1, -1]], dtype=torch.int32)
+    rec = torch.tensor([[np.float32(1.5).view(np.int32), 0, 0, 9, 0, 0, 0, 0, 0, 0],
+                        [np.float32(2.5).view(np.int32), 0, 0, 4, 0, 0, 0, 0, 0, 0],
+                        [np.float32(1.5).view(np.int32), 0, 0, 3, 0, 0, 0, 0, 0, 0],
+                        [-1] * 10], dtype=torch.int32)
     m = shard.merge_records(torch, rec, 3)
-    assert list(m[:, 2]) == [4, 3, 9]
+    assert list(m[:, shard.COL_INDEX]) == [4, 3, 9]
