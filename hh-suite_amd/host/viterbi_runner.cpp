@@ -40,6 +40,39 @@ void ExcludeAlignment(std::vector<uint8_t>& mask, int Lq, int Lt, const int32_t*
   }
 }
 
+namespace {
+// strint (src/util.cpp:133-151): next integer in the string, a leading '-' negates; -> false when none is left
+bool next_int(const std::string& s, size_t& pos, int& out) {
+  while (pos < s.size() && !(s[pos] >= '0' && s[pos] <= '9')) ++pos;
+  if (pos >= s.size()) return false;
+  const bool neg = pos > 0 && s[pos - 1] == '-';
+  long v = 0;
+  while (pos < s.size() && s[pos] >= '0' && s[pos] <= '9') v = v * 10 + (s[pos++] - '0');
+  out = (int)(neg ? -v : v);
+  return true;
+}
+}  // namespace
+
+void ExcludeRegions(std::vector<uint8_t>& mask, int Lq, int Lt, const std::string& exclstr) {
+  size_t pos = 0;
+  int a, b;
+  while (next_int(exclstr, pos, a) && next_int(exclstr, pos, b)) {
+    const int i0 = std::max(1, std::abs(a)), i1 = std::min(std::abs(b), Lq);
+    for (int i = i0; i <= i1; ++i)
+      for (int j = 1; j <= Lt; ++j) mask[(size_t)i * (Lt + 1) + j] = 1;
+  }
+}
+
+void ExcludeTemplateRegions(std::vector<uint8_t>& mask, int Lq, int Lt, const std::string& exclstr) {
+  size_t pos = 0;
+  int a, b;
+  while (next_int(exclstr, pos, a) && next_int(exclstr, pos, b)) {
+    const int j0 = std::max(1, std::abs(a)), j1 = std::min(std::abs(b), Lt);
+    for (int j = j0; j <= j1; ++j)
+      for (int i = 1; i <= Lq; ++i) mask[(size_t)i * (Lt + 1) + j] = 1;
+  }
+}
+
 std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& q,
                                           const std::vector<Profile>& templates) {
   std::vector<Hit> ret_hits;
@@ -75,6 +108,16 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
   std::vector<std::vector<uint8_t> > masks(n);
   std::vector<int> to_align(n);
   for (int k = 0; k < n; ++k) to_align[k] = k;
+  // -excl / -template_excl regions are masked in every round, including the first (:157-164)
+  const bool regions = !par.exclstr.empty() || !par.template_exclstr.empty();
+  if (regions) {
+    for (int k = 0; k < n; ++k) {
+      masks[k].assign((size_t)(q.L + 1) * (L[k] + 1), 0);
+      if (!par.exclstr.empty()) ExcludeRegions(masks[k], q.L, L[k], par.exclstr);
+      if (!par.template_exclstr.empty()) ExcludeTemplateRegions(masks[k], q.L, L[k], par.template_exclstr);
+      check(hhv_set_celloff(ctx.c, all.t, k, masks[k].data()), "hhv_set_celloff");
+    }
+  }
 
   for (int alignment = 0; alignment < par.altali && !to_align.empty(); ++alignment) {
     // round 0 runs on the resident set; later rounds on the (usually much smaller) surviving subset
@@ -95,7 +138,8 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
         check(hhv_set_celloff(ctx.c, ts, t, masks[to_align[t]].data()), "hhv_set_celloff");
     }
     std::vector<hhv_hit> hits(m);
-    check(hhv_align(ctx.c, ts, alignment > 0 ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, nullptr), "hhv_align");
+    check(hhv_align(ctx.c, ts, (alignment > 0 || regions) ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, nullptr),
+          "hhv_align");
     check(hhv_hits(ctx.c, ts, hits.data()), "hhv_hits");
 
     std::vector<int> next;
@@ -150,7 +194,7 @@ struct hhvr_hit {
 // Runs hhv::ViterbiRunner::alignment.  hits_out: cap_hits records; path arrays: per hit `path_cap`
 // entries at offset h*path_cap.  Returns the number of hits or a negative hhv_status.
 int hhvr_alignment(int device, int loc, float egq, float egt, float shift, float corr, float ssw, int ssm, int altali,
-                   float smin, const float* qp, const float* qtr, int Lq, int n, const int32_t* L,
+                   float smin, const char* exclstr, const char* template_exclstr, const float* qp, const float* qtr, int Lq, int n, const int32_t* L,
                    const float* const* p, const float* const* tr, hhvr_hit* hits_out, int cap_hits, int path_cap,
                    int32_t* i_steps, int32_t* j_steps, int8_t* states, float* S) {
   try {
@@ -164,6 +208,8 @@ int hhvr_alignment(int device, int loc, float egq, float egt, float shift, float
     par.ssm = ssm;
     par.altali = altali;
     par.smin = smin;
+    if (exclstr) par.exclstr = exclstr;
+    if (template_exclstr) par.template_exclstr = template_exclstr;
     hhv::Profile q;
     q.L = Lq;
     q.p = qp;

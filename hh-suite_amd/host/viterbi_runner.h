@@ -41,6 +41,8 @@ struct Parameters {
   int ssm = 2;          // par.ssm
   int altali = 4;       // par.altali
   float smin = 20.0f;   // par.smin
+  std::string exclstr;           // par.exclstr          ("-excl 10-20,40-55": query rows never aligned)
+  std::string template_exclstr;  // par.template_exclstr (same for template columns)
 };
 
 // a prepared profile HMM (after PrepareQueryHMM / PrepareTemplateHMM): p[(L+1)*20], tr[(L+1)*7]
@@ -76,6 +78,12 @@ inline int SelectSSMode(int consensus_ss_hmm_mode) {
 // into mask[(Lq+1)*(Lt+1)]
 void ExcludeAlignment(std::vector<uint8_t>& mask, int Lq, int Lt, const int32_t* i_steps, const int32_t* j_steps,
                       int nsteps);
+
+// ViterbiRunner::exclude_regions / exclude_template_regions (src/hhviterbirunner.cpp:291-329): every pair of
+// integers found in the string (parsed like strint, src/util.cpp:133-151, sign ignored) switches off the query
+// rows i0..i1 (resp. template columns j0..j1) of mask[(Lq+1)*(Lt+1)]
+void ExcludeRegions(std::vector<uint8_t>& mask, int Lq, int Lt, const std::string& exclstr);
+void ExcludeTemplateRegions(std::vector<uint8_t>& mask, int Lq, int Lt, const std::string& exclstr);
 
 class ViterbiRunner {
  public:

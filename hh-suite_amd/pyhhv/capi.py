@@ -277,14 +277,15 @@ def load_runner():
         load()
         _runner = C.CDLL(RUNNER_PATH)
         _runner.hhvr_alignment.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                           C.c_int, C.c_int, C.c_float, c_float_p, c_float_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_float, C.c_char_p, C.c_char_p, c_float_p, c_float_p,
+                                           C.c_int, C.c_int,
                                            c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return _runner
 
 
 def runner_alignment(qp, qtr, tps, ttrs, loc=1, egq=0.0, egt=0.0, shift=-0.03, corr=0.1, ssw=0.11, ssm=2, altali=4,
-                     smin=20.0, device=0):
+                     smin=20.0, device=0, exclstr=None, template_exclstr=None):
     """hhv::ViterbiRunner::alignment -> (hits structured array, i_steps, j_steps, states, S) with one row per hit."""
     lib = load_runner()
     qp, qtr = _f32(qp), _f32(qtr)
@@ -302,7 +303,9 @@ def runner_alignment(qp, qtr, tps, ttrs, loc=1, egq=0.0, egt=0.0, shift=-0.03, c
     j_s = np.zeros((cap, pcap), dtype=np.int32)
     st = np.zeros((cap, pcap), dtype=np.int8)
     S = np.zeros((cap, pcap), dtype=np.float32)
-    m = lib.hhvr_alignment(device, loc, egq, egt, shift, corr, ssw, ssm, altali, smin, qp.ctypes.data_as(c_float_p),
+    m = lib.hhvr_alignment(device, loc, egq, egt, shift, corr, ssw, ssm, altali, smin,
+                           exclstr.encode() if exclstr else None,
+                           template_exclstr.encode() if template_exclstr else None, qp.ctypes.data_as(c_float_p),
                            qtr.ctypes.data_as(c_float_p), Lq, n, Ls.ctypes.data_as(c_int_p), pp, tt, hits.ctypes.data,
                            cap, pcap, i_s.ctypes.data, j_s.ctypes.data, st.ctypes.data, S.ctypes.data)
     if m < 0:

@@ -10,17 +10,29 @@ from pyoracle import make_params
 pytestmark = pytest.mark.gpu
 
 
-def reference_rounds(oracle, par, qf, qtr, tps, ttrs, altali, smin):
+def region_mask(Lq, Lt, excl, texcl):
+    m = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
+    for a, b in excl:
+        m[max(1, a):min(b, Lq) + 1, 1:] = 1
+    for a, b in texcl:
+        m[1:, max(1, a):min(b, Lt) + 1] = 1
+    return m
+
+
+def reference_rounds(oracle, par, qf, qtr, tps, ttrs, altali, smin, excl=(), texcl=()):
     """ViterbiRunner::alignment (:104-189) with the oracle standing in for Viterbi::Align & co."""
     Lq = qf.shape[0] - 1
     n = len(tps)
     masks = [None] * n
+    regions = bool(excl or texcl)
+    if regions:
+        masks = [region_mask(Lq, t.shape[0] - 1, excl, texcl) for t in tps]
     todo = list(range(n))
     out = []
     for r in range(altali):
         nxt = []
         for k in todo:
-            a = oracle.align(par, qf, qtr, tps[k], ttrs[k], celloff=masks[k] if r > 0 else None, want_path=True)
+            a = oracle.align(par, qf, qtr, tps[k], ttrs[k], celloff=masks[k] if (r > 0 or regions) else None, want_path=True)
             out.append((k, r + 1, a))
             if float(a.hit_score) > smin:
                 nxt.append(k)
@@ -52,3 +64,18 @@ def test_runner_alt_alignments(oracle, local):
         assert (h["i1"], h["j1"]) == (a.i_steps[ns], a.j_steps[ns])
         assert np.array_equal(ii[1:ns + 1], a.i_steps[1:ns + 1]) and np.array_equal(jj[1:ns + 1], a.j_steps[1:ns + 1])
         assert np.array_equal(ss[1:ns + 1], a.states[1:ns + 1]) and np.array_equal(sc[1:ns + 1], a.S[1:ns + 1])
+
+
+def test_runner_excluded_regions(oracle):
+    """-excl / -template_excl (src/hhviterbirunner.cpp:157-164,291-329): masked already in the first round."""
+    from pyhhv import capi
+    par = make_params(local=1)
+    Lq = 150
+    qf, qtr, tps, ttrs = workload(71, Lq, 6, 90, 200, homolog_every=1)
+    hits, i_s, j_s, st, S = capi.runner_alignment(qf, qtr, tps, ttrs, loc=1, altali=2, smin=20.0,
+                                                  exclstr="10-25,100-120", template_exclstr="40-60")
+    want = reference_rounds(oracle, par, qf, qtr, tps, ttrs, 2, 20.0, excl=((10, 25), (100, 120)), texcl=((40, 60),))
+    assert len(hits) == len(want)
+    for h, (k, irep, a) in zip(hits, want):
+        assert (h["entry"], h["irep"]) == (k, irep) and same_float(h["score"], a.hit_score)
+        assert (h["i2"], h["j2"], h["nsteps"]) == (a.i2, a.j2, a.nsteps)
