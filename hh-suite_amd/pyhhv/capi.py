@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
     "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
-    "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
+    "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
 ]
@@ -74,6 +74,9 @@ def load():
     L.hhv_set_query_ss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_set_ss_mode.argtypes = [C.c_void_p, C.c_int32]
     L.hhv_adopt_device_stream.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.hhv_db_write.argtypes = [C.c_char_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p,
+                               C.c_void_p, C.c_void_p]
+    L.hhv_db_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
     L.hhv_tset_free.argtypes = [C.c_void_p]
     L.hhv_tset_free.restype = None
     L.hhv_tset_size.argtypes = [C.c_void_p]
@@ -115,6 +118,18 @@ def pack_profile(p, tr, index=-1):
     _check(load().hhv_pack_profile(p.ctypes.data_as(c_float_p), tr.ctypes.data_as(c_float_p), L, index,
                                    out.ctypes.data_as(c_float_p)))
     return out
+
+
+def db_write(path, tps, ttrs):
+    """hhv_db_write: pack host profiles into a binary template database file (no device needed)."""
+    tps = [_f32(a) for a in tps]
+    ttrs = [_f32(a) for a in ttrs]
+    n = len(tps)
+    Ls = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+    pp = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in tps])
+    tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in ttrs])
+    _check(load().hhv_db_write(path.encode(), n, Ls.ctypes.data_as(c_int_p), pp, tt, None, None, None))
+    return Ls
 
 
 def fast_log2_tables():
@@ -195,6 +210,11 @@ class Context:
 
     def set_ss_mode(self, mode):
         _check(self.lib.hhv_set_ss_mode(self.h, int(mode)))
+
+    def db_open(self, path, Ls):
+        h = C.c_void_p()
+        _check(self.lib.hhv_db_open(self.h, path.encode(), C.byref(h)))
+        return TemplateSet(self, h, Ls)
 
     def adopt_device_stream(self, Ls, device_ptr):
         Ls = np.ascontiguousarray(Ls, dtype=np.int32)

@@ -140,6 +140,14 @@ int hhv_upload_templates_ss(hhv_ctx* ctx, int32_t n, const int32_t* L, const flo
  * outlive the set. */
 #define HHV_STREAM_PAD 256
 int hhv_adopt_device_stream(hhv_ctx* ctx, int32_t n, const int32_t* L, const void* d_records, hhv_tset** out);
+/* Binary packed template database: the record stream plus its length table in one file, so that
+ * a search mmaps/reads it straight into HBM instead of parsing and re-packing HMM text per query.
+ * File = 64-byte header {magic "HHVPDB01", int32 n, int32 record_dwords (28), int64 n_records, zero pad},
+ * int32 L[n], then n_records * 28 floats (header/column records incl. the terminal header).
+ * hhv_db_write packs host profiles to `path`; hhv_db_open loads a file into a resident set. */
+int hhv_db_write(const char* path, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
+                 const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp);
+int hhv_db_open(hhv_ctx* ctx, const char* path, hhv_tset** out);
 void hhv_tset_free(hhv_tset* ts);
 int32_t hhv_tset_size(const hhv_tset* ts);
 int64_t hhv_tset_cells(const hhv_tset* ts, int32_t Lq); /* sum over templates of Lq*L[k] */

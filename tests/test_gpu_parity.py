@@ -165,3 +165,22 @@ def test_headline_shape_sample(hhv, oracle):
     assert np.all((res["i2"] == Lq) | (res["j2"] == Lt))
     ts.free()
     c.close()
+
+
+def test_packed_db_roundtrip(hhv, oracle, tmp_path):
+    """hhv_db_write -> hhv_db_open gives the same results as uploading the profiles directly."""
+    par = make_params(local=1)
+    qf, qtr, tps, ttrs = workload(91, 120, 12, 30, 200)
+    path = str(tmp_path / "db.hhvpdb")
+    Ls = hhv.db_write(path, tps, ttrs)
+    c = ctx_for(hhv, par)
+    c.set_query(qf, qtr)
+    a = c.upload(tps, ttrs)
+    b = c.db_open(path, Ls)
+    ra, rb = c.align(a), c.align(b)
+    assert np.array_equal(ra.view(np.uint8), rb.view(np.uint8))
+    o = oracle.align(par, qf, qtr, tps[3], ttrs[3], want_bt=False)
+    assert (o.i2, o.j2) == (rb["i2"][3], rb["j2"][3]) and same_float(o.score, rb["score"][3])
+    a.free()
+    b.free()
+    c.close()

@@ -61,3 +61,19 @@ def test_bt_layout_roundtrip():
     pack.matrix_to_bt(mask, 0, R, buf)
     back = pack.bt_to_matrix(buf, 0, Lq, Lt, R)
     assert np.array_equal((back >> 7) & 1, mask)
+
+
+def test_packed_db_file_matches_stream(tmp_path):
+    """hhv_db_write: file = header + L table + exactly the record stream of the numpy mirror."""
+    tps, ttrs = zip(*[synth.make_template(50 + k, 5 + 7 * k) for k in range(6)])
+    path = str(tmp_path / "db.hhvpdb")
+    Ls = capi.db_write(path, tps, ttrs)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"HHVPDB01"
+    n, recdw = np.frombuffer(raw[8:16], dtype=np.int32)
+    nrec = int(np.frombuffer(raw[16:24], dtype=np.int64)[0])
+    assert (n, recdw) == (6, 28) and nrec == int((Ls + 1).sum()) + 1
+    assert np.array_equal(np.frombuffer(raw[64:64 + 4 * n], dtype=np.int32), Ls)
+    body = np.frombuffer(raw[64 + 4 * n:], dtype=np.int32).reshape(nrec, 28)
+    rec, off = pack.pack_stream(list(tps), list(ttrs))
+    assert np.array_equal(body, rec.view(np.int32))
