@@ -1,0 +1,87 @@
+// oracle/ref_hmm_harness.cpp -- TEST INFRASTRUCTURE (fixture generation only, build container only).
+//
+// Turns a real .hhm file (the reference ships data/query.hhm) into *prepared* profiles with the
+// reference's own code, so that the parity fixtures include genuine HH-suite profile columns and
+// transition scores (not only synthetic ones).  Compiled by oracle/Makefile from the reference's
+// own sources where they lie (src/hhhmm.cpp, hhutil.cpp, util.cpp, hhdecl.cpp, hhmatrices.cpp,
+// src/cs/aa.cc) into oracle/_ref/libhhref_hmm.so; nothing is copied.
+//
+// It calls, in the order of PrepareQueryHMM / PrepareTemplateHMM (src/hhfunc.cpp:121-160,165-202,
+// "-nocontxt" branch = substitution-matrix pseudocounts, the only mode that works without the
+// context_data.crf blob listed in .MISSING_LARGE_BLOBS):
+//   SetSubstitutionMatrix            src/hhmatrices.cpp:20-75
+//   HMM::Read                        src/hhhmm.cpp:202-694
+//   HMM::AddTransitionPseudocounts   src/hhhmm.cpp:1722-1806
+//   HMM::PreparePseudocounts         src/hhhmm.cpp:1811-1815
+//   HMM::AddAminoAcidPseudocounts    src/hhhmm.cpp:1874-1964
+//   HMM::CalculateAminoAcidBackground src/hhhmm.cpp:1854-1868
+//   HMM::IncludeNullModelInHMM       src/hhhmm.cpp:2059-2144   (template side)
+#include <cstdio>
+#include <cstring>
+
+#include "hhdecl.h"
+#include "hhhmm.h"
+#include "hhmatrices.h"
+#include "hhutil.h"
+
+extern "C" {
+
+// role 0: prepare as query; role 1: prepare as template against the (already prepared) query file
+// out_p: maxL+1 rows x 20, out_tr: maxL+1 rows x 7 (enum order).  Returns L, or a negative error.
+int ref_prepare_hhm(const char* query_path, const char* template_path, int maxres, float* q_p, float* q_tr,
+                    float* t_p, float* t_tr, int* Lq, int* Lt) {
+  Log::reporting_level() = WARNING;
+  Parameters par(0, NULL);
+  par.maxres = maxres;
+  par.nocontxt = 1;
+  float pb[21];
+  float P[20][20], R[20][20], S[20][20], Sim[20][20];
+  SetSubstitutionMatrix(par.matrix, pb, P, R, S, Sim);
+
+  HMM* q = new HMM(MAXSEQDIS, maxres);
+  FILE* f = fopen(query_path, "r");
+  if (!f) return -1;
+  char path[NAMELEN] = "";
+  if (!q->Read(f, par.maxcol, par.nseqdis, pb, path)) {
+    fclose(f);
+    return -2;
+  }
+  fclose(f);
+  // PrepareQueryHMM, input_format == 0, par.nocontxt
+  q->AddTransitionPseudocounts(par.gapd, par.gape, par.gapf, par.gapg, par.gaph, par.gapi, par.gapb, par.gapb);
+  q->PreparePseudocounts(R);
+  q->AddAminoAcidPseudocounts(par.pc_hhm_nocontext_mode, par.pc_hhm_nocontext_a, par.pc_hhm_nocontext_b,
+                              par.pc_hhm_nocontext_c);
+  q->CalculateAminoAcidBackground(pb);
+  *Lq = q->L;
+  for (int i = 0; i <= q->L; ++i) {
+    for (int a = 0; a < 20; ++a) q_p[i * 20 + a] = (i == 0) ? 0.0f : q->p[i][a];
+    for (int k = 0; k < 7; ++k) q_tr[i * 7 + k] = q->tr[i][k];
+  }
+
+  HMM* t = new HMM(MAXSEQDIS, maxres);
+  f = fopen(template_path, "r");
+  if (!f) return -3;
+  if (!t->Read(f, par.maxcol, par.nseqdis, pb, path)) {
+    fclose(f);
+    return -4;
+  }
+  fclose(f);
+  // PrepareTemplateHMM, format == 0
+  t->AddTransitionPseudocounts(par.gapd, par.gape, par.gapf, par.gapg, par.gaph, par.gapi, par.gapb, par.gapb);
+  t->PreparePseudocounts(R);
+  t->AddAminoAcidPseudocounts(par.pc_hhm_nocontext_mode, par.pc_hhm_nocontext_a, par.pc_hhm_nocontext_b,
+                              par.pc_hhm_nocontext_c);
+  t->CalculateAminoAcidBackground(pb);
+  t->IncludeNullModelInHMM(q, t, par.columnscore, par.half_window_size_local_aa_bg_freqs, pb);
+  *Lt = t->L;
+  for (int i = 0; i <= t->L; ++i) {
+    for (int a = 0; a < 20; ++a) t_p[i * 20 + a] = (i == 0) ? 0.0f : t->p[i][a];
+    for (int k = 0; k < 7; ++k) t_tr[i * 7 + k] = t->tr[i][k];
+  }
+  delete q;
+  delete t;
+  return 0;
+}
+
+}  // extern "C"
