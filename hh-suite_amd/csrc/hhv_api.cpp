@@ -138,16 +138,18 @@ int hhv_pack_profile(const float* p, const float* tr, int32_t L, int32_t index, 
   return HHV_OK;
 }
 
-// src/util-inl.h:108-130: lg2[i] = log(float(1024+i))*1.442695041 - 10.0f with the float overload of
-// log (logf), diff[i-1] = (lg2[i]-prev)*1.2352E-4 -- bit-identical tables are part of the contract
-// (checked against the compiled reference in tests/test_oracle_vs_reference.py via the oracle).
+// src/util-inl.h:108-130: lg2[i] = log(float(1024+i))*1.442695041 - 10.0f, diff[i-1] = (lg2[i]-prev)*1.2352E-4.
+// The reference initialises this table in whichever translation unit calls fast_log2 first; in a real run that
+// is hhhmm.cpp (HMM::AddTransitionPseudocounts during PrepareQueryHMM), where log(float) binds to the DOUBLE
+// log - not hhviterbi.cpp, where it would bind to logf.  The double flavour is therefore the one the Viterbi
+// rescoring sees in hhsearch/hhblits, and the one built here (pinned through the oracle against oracle/_ref).
 int hhv_fast_log2_tables(float* lg2, float* diff) {
   if (!lg2 || !diff) return fail(HHV_E_ARG, "hhv_fast_log2_tables: null");
   float prev = 0.0f;
   lg2[0] = 0.0f;
   diff[1024] = 0.0f;
   for (int i = 1; i <= 1024; ++i) {
-    lg2[i] = (float)((double)logf((float)(1024 + i)) * 1.442695041 - (double)10.0f);
+    lg2[i] = (float)(log((double)(float)(1024 + i)) * 1.442695041 - (double)10.0f);
     diff[i - 1] = (float)((double)(lg2[i] - prev) * 1.2352E-4);
     prev = lg2[i];
   }

@@ -56,9 +56,13 @@ float hho_log2f4(float x) {
   return p + e;
 }
 
-/* src/util-inl.h:108-130.  The table is built exactly like the reference builds it; in the
- * reference translation units log(float) resolves to the float overload (logf), which is what the
- * pinning test tests/test_oracle_vs_reference.py::test_fast_log2_table confirms. */
+/* src/util-inl.h:108-130.  The lookup table lives in function-local statics that the FIRST caller in the
+ * process initialises, and `log(float(1024+i))` is compiled per translation unit: it binds to double
+ * log(double) inside hhhmm.cpp but to logf inside hhviterbi.cpp.  In every real hhsearch/hhblits/hhalign run
+ * the first call is HMM::AddTransitionPseudocounts (src/hhhmm.cpp:1722-1806, from PrepareQueryHMM,
+ * src/hhfunc.cpp:129), long before the Viterbi stage - so the table ScoreForBacktrace sees is the
+ * double-log one restated here.  oracle/_ref reproduces that call order (ref_init_fast_log2_like_hhsearch) and
+ * tests/test_oracle_vs_reference.py::test_fast_log2_table pins all 1024 entries. */
 static float lg2_tab[1025];
 static float diff_tab[1025];
 static int lg2_init = 0;
@@ -66,7 +70,7 @@ static void fast_log2_init(void) {
   float prev = 0.0f;
   lg2_tab[0] = 0.0f;
   for (int i = 1; i <= 1024; ++i) {
-    lg2_tab[i] = (float)((double)logf((float)(1024 + i)) * 1.442695041 - (double)10.0f);
+    lg2_tab[i] = (float)(log((double)(float)(1024 + i)) * 1.442695041 - (double)10.0f);
     diff_tab[i - 1] = (float)((double)(lg2_tab[i] - prev) * 1.2352E-4);
     prev = lg2_tab[i];
   }

@@ -44,13 +44,7 @@
 #include "hhhmmsimd.h"
 #include "hhhit.h"
 
-// The only non-libstdc++ symbol the four reference objects leave undefined
-// (declared in src/hhutil.h:20, defined in src/hhutil.cpp which we do not link).
-int MemoryError(const char arrayname[], const char* file, const int line, const char* func) {
-  fprintf(stderr, "ref_harness: MemoryError %s %s:%d %s\n", arrayname, file, line, func);
-  abort();
-  return 3;
-}
+extern "C" void ref_init_fast_log2_like_hhsearch();  // ref_hmm_harness.cpp
 
 namespace {
 
@@ -149,7 +143,10 @@ float ref_log2f4(float x) {
   simdf32_store(out, r);
   return out[0];
 }
-float ref_fast_log2(float x) { return fast_log2(x); }
+float ref_fast_log2(float x) {
+  ref_init_fast_log2_like_hhsearch();
+  return fast_log2(x);
+}
 // scalar (SSE-ordered) product used when re-scoring the backtrace; q,t must hold 20 floats
 float ref_scalarprod20(const float* q, const float* t) {
   float qa[20] __attribute__((aligned(32)));
@@ -178,6 +175,7 @@ void* ref_create(int maxres, int local, float egq, float egt, float corr, float 
   // (default 2 = INFO) before touching the Viterbi code.  At >= DEBUG1 ScoreForBacktrace would call
   // PrintDebug, which dereferences sequence arrays our HMM shells do not have.
   Log::reporting_level() = INFO;
+  ref_init_fast_log2_like_hhsearch();
   RefCtx* c = new RefCtx();
   c->maxres = maxres;
   c->local = local;

@@ -26,6 +26,26 @@
 
 extern "C" {
 
+// fast_log2 (src/util-inl.h:108-130) keeps its lookup table in function-local statics that the FIRST caller
+// in the process initialises - and the initialiser is compiled per translation unit: inside hhhmm.cpp
+// `log(float(1024+i))` binds to double log(double), inside hhviterbi.cpp to logf.  Every real hhsearch /
+// hhblits / hhalign run prepares the query with HMM::AddTransitionPseudocounts (src/hhfunc.cpp:129 ->
+// src/hhhmm.cpp:1722-1806, which calls fast_log2) long before the Viterbi stage, so the table the Viterbi
+// rescoring sees is hhhmm.cpp's.  This function makes the harness process behave the same way.
+void ref_init_fast_log2_like_hhsearch() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (Log::reporting_level() > INFO) Log::reporting_level() = INFO;  // the apps lower the DEBUG4 default from -v
+  HMM h(2, 8);
+  h.L = 1;
+  for (int i = 0; i < 8; ++i) {
+    h.Neff_M[i] = h.Neff_I[i] = h.Neff_D[i] = 1.0f;
+    for (int k = 0; k < 7; ++k) h.tr[i][k] = -1.0f;
+  }
+  h.AddTransitionPseudocounts(0.15f, 1.0f, 0.6f, 0.6f, 0.6f, 0.6f, 1.0f, 1.0f);
+}
+
 // role 0: prepare as query; role 1: prepare as template against the (already prepared) query file
 // out_p: maxL+1 rows x 20, out_tr: maxL+1 rows x 7 (enum order).  Returns L, or a negative error.
 int ref_prepare_hhm(const char* query_path, const char* template_path, int maxres, float* q_p, float* q_tr,

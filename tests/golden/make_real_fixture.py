@@ -26,7 +26,7 @@ HHM = "/root/reference/data/query.hhm"
 
 
 def main():
-    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhhref_hmm.so"))
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhhref.so"))
     maxres = 2000
     qp = np.zeros((maxres, 20), np.float32)
     qtr = np.zeros((maxres, 7), np.float32)
