@@ -117,6 +117,23 @@ struct hhv_tset {
   DevHit* d_raw_hits = nullptr;
 };
 
+struct hhv_rawset {
+  hhv_ctx* ctx = nullptr;
+  int32_t n = 0;
+  std::vector<int32_t> L;
+  std::vector<int64_t> rec_off;
+  int64_t n_cols = 0;
+  float* d_raw = nullptr;
+  float* d_neff_hmm = nullptr;
+  float* d_p_tmp = nullptr;
+  float* d_tr_tmp = nullptr;
+  float* d_pav = nullptr;
+  float* d_pb = nullptr;
+  float* d_R = nullptr;
+  float* d_qpav = nullptr;
+  bool prepared = false;
+};
+
 namespace hhv {
 size_t topk_temp_bytes(int n);
 void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t stream);
@@ -423,6 +440,169 @@ int hhv_adopt_device_stream(hhv_ctx* c, int32_t n, const int32_t* L, const void*
   ts->d_records = (float*)d_records;
   ts->owns_records = false;
   *out = ts;
+  return HHV_OK;
+}
+
+// ---- on-device PrepareTemplateHMM (N2) ---------------------------------------------------------------
+int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
+                             const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
+                             const int8_t* const* ss_conf, const int8_t* const* ss_dssp, hhv_rawset** out) {
+  if (!c || !L || !f || !tr || !neff || !neff_hmm || !out) return fail(HHV_E_ARG, "hhv_upload_raw_templates: null argument");
+  if (n < 1) return fail(HHV_E_ARG, "hhv_upload_raw_templates: n = %d", n);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_rawset* rs = new (std::nothrow) hhv_rawset();
+  if (!rs) return fail(HHV_E_MEMORY, "out of host memory");
+  rs->ctx = c;
+  rs->n = n;
+  rs->L.assign(L, L + n);
+  rs->rec_off.resize((size_t)n + 1);
+  int64_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1 || L[k] > 0xFFFF || !f[k] || !tr[k] || !neff[k]) {
+      delete rs;
+      return fail(HHV_E_ARG, "raw template %d invalid", k);
+    }
+    rs->rec_off[k] = off;
+    off += (int64_t)L[k] + 1;
+  }
+  rs->rec_off[n] = off;
+  rs->n_cols = off;
+  std::vector<float> host((size_t)off * RAW_DW, 0.0f);
+  for (int k = 0; k < n; ++k) {
+    for (int i = 0; i <= L[k]; ++i) {
+      float* w = host.data() + (size_t)(rs->rec_off[k] + i) * RAW_DW;
+      memcpy(w + RAW_F, f[k] + (size_t)i * 20, 20 * sizeof(float));
+      memcpy(w + RAW_TR, tr[k] + (size_t)i * 7, 7 * sizeof(float));
+      memcpy(w + RAW_NEFF, neff[k] + (size_t)i * 3, 3 * sizeof(float));
+      int32_t meta = i;
+      if (i >= 1) {
+        const int pr = ss_pred && ss_pred[k] ? (unsigned char)ss_pred[k][i] : 0, cf = ss_conf && ss_conf[k] ? ss_conf[k][i] : 0;
+        const int ds = ss_dssp && ss_dssp[k] ? (unsigned char)ss_dssp[k][i] : 0;
+        meta |= (int32_t)((unsigned char)(pr * 11 + cf) & META_PRED_MASK) << META_PRED_SHIFT;
+        meta |= (int32_t)(ds & META_DSSP_MASK) << META_DSSP_SHIFT;
+      }
+      memcpy(w + RAW_J, &meta, 4);
+      const int32_t Lk = L[k];
+      memcpy(w + RAW_L, &Lk, 4);
+    }
+  }
+  bool ok = hipMalloc(&rs->d_raw, host.size() * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_neff_hmm, (size_t)n * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_p_tmp, (size_t)off * 20 * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_tr_tmp, (size_t)off * 8 * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_pav, (size_t)n * 20 * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_pb, 20 * sizeof(float)) == hipSuccess && hipMalloc(&rs->d_R, 400 * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_qpav, 20 * sizeof(float)) == hipSuccess &&
+            hipMemcpy(rs->d_raw, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(rs->d_neff_hmm, neff_hmm, (size_t)n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    hhv_rawset_free(rs);
+    return fail(HHV_E_MEMORY, "hhv_upload_raw_templates: device allocation/copy failed");
+  }
+  *out = rs;
+  return HHV_OK;
+}
+
+void hhv_rawset_free(hhv_rawset* rs) {
+  if (!rs) return;
+  if (rs->ctx) (void)hipSetDevice(rs->ctx->par.device);
+  dfree(rs->d_raw);
+  dfree(rs->d_neff_hmm);
+  dfree(rs->d_p_tmp);
+  dfree(rs->d_tr_tmp);
+  dfree(rs->d_pav);
+  dfree(rs->d_pb);
+  dfree(rs->d_R);
+  dfree(rs->d_qpav);
+  delete rs;
+}
+
+int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out) {
+  if (!c || !rs || !par || !q_pav || !out) return fail(HHV_E_ARG, "hhv_prepare_templates: null argument");
+  if (rs->ctx != c) return fail(HHV_E_ARG, "hhv_prepare_templates: raw set belongs to another context");
+  if (par->pcm < 0 || par->pcm > 2) return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm = %d (only 0, 1, 2)", par->pcm);
+  if (par->pcm == 2 && par->pcc != 1.0f)
+    return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcc = %g; only the default pcc = 1 avoids libm pow() and is built", par->pcc);
+  if (par->columnscore < 0 || par->columnscore > 3)
+    return fail(HHV_E_LIMIT, "hhv_prepare_templates: columnscore = %d (only 0..3)", par->columnscore);
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_tset* ts = *out;
+  if (!ts) {
+    ts = new (std::nothrow) hhv_tset();
+    if (!ts) return fail(HHV_E_MEMORY, "out of host memory");
+    int rc = tset_init_common(c, ts, rs->n, rs->L.data());
+    if (rc == HHV_OK && hipMalloc(&ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
+      rc = fail(HHV_E_MEMORY, "hhv_prepare_templates: device allocation failed");
+    if (rc != HHV_OK) {
+      hhv_tset_free(ts);
+      return rc;
+    }
+    ts->owns_records = true;
+    std::vector<float> tail((size_t)(1 + STREAM_PAD_RECS) * REC_DW, 0.0f);
+    write_header(tail.data(), -1, 0);
+    HIP_TRY(hipMemcpy(ts->d_records + (size_t)ts->rec_off[rs->n] * REC_DW, tail.data(), tail.size() * sizeof(float),
+                      hipMemcpyHostToDevice));
+  } else if (ts->n != rs->n || ts->n_records != rs->n_cols + 1) {
+    return fail(HHV_E_ARG, "hhv_prepare_templates: *out was not created from this raw set");
+  }
+  HIP_TRY(hipMemcpyAsync(rs->d_pb, par->pb, 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(rs->d_R, par->R, 400 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(rs->d_qpav, q_pav, 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  PrepArgs a;
+  a.raw = rs->d_raw;
+  a.n_cols = rs->n_cols;
+  a.rec_off = ts->d_rec_off;
+  a.L = ts->d_L;
+  a.neff_hmm = rs->d_neff_hmm;
+  a.pb = rs->d_pb;
+  a.R = rs->d_R;
+  a.q_pav = rs->d_qpav;
+  a.lg2 = c->d_lg2;
+  a.diff = c->d_diff;
+  a.p_tmp = rs->d_p_tmp;
+  a.tr_tmp = rs->d_tr_tmp;
+  a.records = ts->d_records;
+  a.pav_out = rs->d_pav;
+  a.gapd = par->gapd;
+  a.gape = par->gape;
+  a.gapf = par->gapf;
+  a.gapg = par->gapg;
+  a.gaph = par->gaph;
+  a.gapi = par->gapi;
+  a.gapb = par->gapb;
+  a.pcm = par->pcm;
+  a.pca = par->pca;
+  a.pcb = par->pcb;
+  a.columnscore = par->columnscore;
+  const int rc = launch_prepare(a, rs->n, c->stream);
+  if (rc != 0) {
+    if (!*out) hhv_tset_free(ts);
+    return fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  rs->prepared = true;
+  ts->bt_valid = false;
+  ts->hits_valid = false;
+  *out = ts;
+  return HHV_OK;
+}
+
+int hhv_rawset_pav(hhv_ctx* c, hhv_rawset* rs, float* pav) {
+  if (!c || !rs || !pav) return fail(HHV_E_ARG, "hhv_rawset_pav: null argument");
+  if (!rs->prepared) return fail(HHV_E_STATE, "hhv_rawset_pav: call hhv_prepare_templates first");
+  HIP_TRY(hipSetDevice(c->par.device));
+  HIP_TRY(hipMemcpy(pav, rs->d_pav, (size_t)rs->n * 20 * sizeof(float), hipMemcpyDeviceToHost));
+  return HHV_OK;
+}
+
+int hhv_tset_records_of(hhv_ctx* c, hhv_tset* ts, int32_t k, float* out) {
+  if (!c || !ts || !out) return fail(HHV_E_ARG, "hhv_tset_records_of: null argument");
+  if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_tset_records_of: template %d of %d", k, ts->n);
+  HIP_TRY(hipSetDevice(c->par.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out, ts->d_records + (size_t)ts->rec_off[k] * REC_DW, (size_t)(ts->L[k] + 1) * REC_DW * sizeof(float),
+                    hipMemcpyDeviceToHost));
   return HHV_OK;
 }
 

@@ -74,6 +74,38 @@ struct TraceArgs {
   int32_t ss_t_shift, ss_t_mask;
 };
 
+// raw (unprepared) template column, 32 dwords: the fields of the reference's HMM after HMM::Read
+constexpr int RAW_DW = 32;
+constexpr int RAW_F = 0;      // [0..19]  f[i][a]
+constexpr int RAW_TR = 20;    // [20..26] tr[i][7], enum order M2M,M2I,M2D,I2M,I2I,D2M,D2D
+constexpr int RAW_NEFF = 27;  // [27..29] Neff_M[i], Neff_I[i], Neff_D[i]
+constexpr int RAW_J = 30;     // int: column index i | (ss meta bits 16..24, see viterbi_lane.h) in RAW_SS
+constexpr int RAW_L = 31;     // int: L of the template
+constexpr int RAW_SS = 30;    // the secondary-structure bits share the dword with the column index
+
+struct PrepArgs {
+  const float* raw;          // [n_cols][32]
+  int64_t n_cols;            // sum(L+1)
+  const int64_t* rec_off;    // [n+1]
+  const int32_t* L;          // [n]
+  const float* neff_hmm;     // [n]
+  const float* pb;           // [20]
+  const float* R;            // [20][20]
+  const float* q_pav;        // [20]
+  const float* lg2;
+  const float* diff;
+  float* p_tmp;              // [n_cols][20]
+  float* tr_tmp;             // [n_cols][8]
+  float* records;            // output stream
+  float* pav_out;            // [n][20] or null
+  float gapd, gape, gapf, gapg, gaph, gapi, gapb;
+  int32_t pcm;
+  float pca, pcb;
+  int32_t columnscore;
+};
+
+int launch_prepare(const PrepArgs& a, int n_templates, void* stream);
+
 // launchers implemented in hhv_kernels.hip
 int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
 int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);

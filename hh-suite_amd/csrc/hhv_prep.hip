@@ -1,0 +1,194 @@
+// hhv_prep.hip -- on-device PrepareTemplateHMM: raw template HMMs (as HMM::Read leaves
+// them) -> prepared, packed record stream, once per query, so that a search never touches template data on
+// the host.  Restates, operation for operation (fp32/fp64 mix included), the reference's
+//   HMM::AddTransitionPseudocounts    src/hhhmm.cpp:1722-1806   (fpow2 src/util-inl.h:190-215, fast_log2 :108-130)
+//   HMM::PreparePseudocounts          src/hhhmm.cpp:1811-1815   (ScalarProd20, plain branch, src/hhhit-inl.h:125-131)
+//   HMM::AddAminoAcidPseudocounts     src/hhhmm.cpp:1874-1964   (pcm 0, 1, 2 with pcc == 1)
+//   HMM::CalculateAminoAcidBackground src/hhhmm.cpp:1854-1868   (NormalizeTo1 src/util-inl.h:277-291)
+//   HMM::IncludeNullModelInHMM        src/hhhmm.cpp:2059-2144   (columnscore 0..3)
+// in the order of PrepareTemplateHMM (src/hhfunc.cpp:165-202, HHM format).
+//
+// Kernel P1: one lane per raw column (elementwise: transitions, g = R*f, p = (1-tau) f + tau g).
+// Kernel P2: one wave per template: lanes 0..19 accumulate pav[a] over the columns in the reference's order,
+//            then all lanes divide by the null model and emit the packed 28-dword records (+ header).
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#include "hhv_internal.h"
+#include "viterbi_lane.h"
+
+namespace hhv {
+
+// src/util-inl.h:190-215
+__device__ __forceinline__ float fpow2_dev(float x) {
+  if (x >= FLT_MAX_EXP) return FLT_MAX;
+  if (x <= FLT_MIN_EXP) return 0.0f;
+  const float tx = (x - 0.5f) + (float)(3 << 22);
+  const int lx = (int)(f2bits(tx) - 0x4b400000u);
+  const float dx = x - (float)lx;
+  float y = dx * 0.0134929f;
+  y = 0.0520749f + y;
+  y = dx * y;
+  y = 0.241404f + y;
+  y = dx * y;
+  y = 0.693019f + y;
+  y = dx * y;
+  y = 1.0f + y;
+  return bits2f(f2bits(y) + ((uint32_t)lx << 23));
+}
+
+__device__ __forceinline__ float fast_log2_p(float x, const float* __restrict__ lg2, const float* __restrict__ diff) {
+  if (x <= 0) return -100000;
+  const uint32_t u = f2bits(x);
+  const int aa = (int)((u & 0x7F800000u) >> 23) - 0x7f;
+  const int b = (int)((u & 0x007FE000u) >> 13);
+  const int c = (int)(u & 0x00001FFFu);
+  return ((float)aa + lg2[b]) + diff[b] * (float)c;
+}
+
+// reference enum order of tr[][7], src/hhdecl.h:68
+enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };
+
+__global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.n_cols) return;
+  const float* raw = a.raw + (size_t)c * RAW_DW;
+  const int i = __builtin_bit_cast(int32_t, raw[RAW_J]) & META_JMASK;
+  const int L = __builtin_bit_cast(int32_t, raw[RAW_L]);
+  float* P = a.p_tmp + (size_t)c * 20;
+  float* T = a.tr_tmp + (size_t)c * 8;
+
+  // ---- AddTransitionPseudocounts (:1743-1785)
+  float t[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) t[k] = raw[RAW_TR + k];
+  if (a.gapb > 0) {
+    float pM2D, pM2I;
+    pM2D = pM2I = (float)((double)a.gapd * 0.0286);
+    const float pM2M = 1 - pM2D - pM2I;
+    const float pI2I = (float)(1.0 * (double)a.gape / ((double)(a.gape - 1) + 1.0 / 0.75));
+    const float pI2M = 1 - pI2I;
+    const float pD2D = pI2I;
+    const float pD2M = 1 - pD2D;
+    const float nM = raw[RAW_NEFF + 0], nI = raw[RAW_NEFF + 1], nD = raw[RAW_NEFF + 2];
+    float p0 = (nM - 1) * fpow2_dev(t[T_M2M]) + a.gapb * pM2M;
+    float p1 = (nM - 1) * fpow2_dev(t[T_M2D]) + a.gapb * pM2D;
+    float p2 = (nM - 1) * fpow2_dev(t[T_M2I]) + a.gapb * pM2I;
+    if (i == 0 || i == L) p1 = p2 = 0;
+    float sum = p0 + p1 + p2 + FLT_MIN;
+    t[T_M2M] = fast_log2_p(p0 / sum, a.lg2, a.diff);
+    t[T_M2D] = fast_log2_p(p1 / sum, a.lg2, a.diff) * a.gapf;
+    t[T_M2I] = fast_log2_p(p2 / sum, a.lg2, a.diff) * a.gapg;
+    p0 = nI * fpow2_dev(t[T_I2M]) + a.gapb * pI2M;
+    p1 = nI * fpow2_dev(t[T_I2I]) + a.gapb * pI2I;
+    sum = p0 + p1 + FLT_MIN;
+    t[T_I2M] = fast_log2_p(p0 / sum, a.lg2, a.diff);
+    t[T_I2I] = fast_log2_p(p1 / sum, a.lg2, a.diff) * a.gapi;
+    p0 = nD * fpow2_dev(t[T_D2M]) + a.gapb * pD2M;
+    p1 = nD * fpow2_dev(t[T_D2D]) + a.gapb * pD2D;
+    if (i == L) p1 = 0;
+    sum = p0 + p1 + FLT_MIN;
+    t[T_D2M] = fast_log2_p(p0 / sum, a.lg2, a.diff);
+    t[T_D2D] = fast_log2_p(p1 / sum, a.lg2, a.diff) * a.gaph;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) T[k] = t[k];
+
+  // ---- PreparePseudocounts + AddAminoAcidPseudocounts (columns 1..L)
+  if (i >= 1) {
+    float f[20];
+#pragma unroll
+    for (int b = 0; b < 20; ++b) f[b] = raw[RAW_F + b];
+    float tau = 0.0f;
+    if (a.pcm == 1) tau = a.pca;
+    if (a.pcm == 2) tau = (float)fmin(1.0, (double)a.pca / (1. + (double)(raw[RAW_NEFF + 0] / a.pcb)));
+    for (int aa = 0; aa < 20; ++aa) {
+      if (a.pcm == 0) {
+        P[aa] = f[aa];
+      } else {
+        const float* Ra = a.R + aa * 20;
+        float g = f[0] * Ra[0];  // ScalarProd20(R[a], f[i]): tj[0]*qi[0] + tj[1]*qi[1] + ... left to right
+#pragma unroll
+        for (int b = 1; b < 20; ++b) g = g + f[b] * Ra[b];
+        P[aa] = (float)((1. - (double)tau) * (double)f[aa] + (double)(tau * g));
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
+  __shared__ float s_pav[20];
+  __shared__ float s_pnul[20];
+  const int k = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t c0 = a.rec_off[k];
+  const int L = a.L[k];
+  // ---- CalculateAminoAcidBackground (:1854-1868): 20 independent sequential sums over the columns
+  if (lane < 20) {
+    float pav = a.pb[lane] * 100.0f / a.neff_hmm[k];
+    for (int i = 1; i <= L; ++i) pav += a.p_tmp[(size_t)(c0 + i) * 20 + lane];
+    s_pav[lane] = pav;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float sum = 0.0f;
+    for (int q = 0; q < 20; ++q) sum += s_pav[q];
+    if (sum != 0.0f) {
+      const float fac = (float)(1.0 / (double)sum);
+      for (int q = 0; q < 20; ++q) s_pav[q] *= fac;
+    }
+  }
+  __syncthreads();
+  // ---- IncludeNullModelInHMM (:2069-2093)
+  if (lane < 20) {
+    float pn;
+    switch (a.columnscore) {
+      case 1: pn = (float)(0.5 * (double)(a.q_pav[lane] + s_pav[lane])); break;
+      case 2: pn = s_pav[lane]; break;
+      case 3: pn = a.q_pav[lane]; break;
+      default: pn = a.pb[lane]; break;
+    }
+    s_pnul[lane] = pn;
+    if (a.pav_out) a.pav_out[(size_t)k * 20 + lane] = s_pav[lane];
+  }
+  __syncthreads();
+  // ---- emit the packed stream: header + L column records (layout: viterbi_lane.h)
+  float* hdr = a.records + (size_t)c0 * REC_DW;
+  if (lane < REC_DW) {
+    float v = 0.0f;
+    if (lane == 0) v = __builtin_bit_cast(float, (int32_t)k);
+    if (lane == 1) v = __builtin_bit_cast(float, (int32_t)L);
+    if (lane == REC_META) v = __builtin_bit_cast(float, META_HDR);
+    hdr[lane] = v;
+  }
+  for (int64_t e = lane; e < (int64_t)L * REC_DW; e += LANES) {
+    const int j = (int)(e / REC_DW) + 1;
+    const int w = (int)(e - (int64_t)(j - 1) * REC_DW);
+    float v;
+    if (w < 20) {
+      v = a.p_tmp[(size_t)(c0 + j) * 20 + w] / s_pnul[w];
+    } else if (w < REC_META) {
+      // [20..24] tr[j-1][M2M,M2D,D2M,D2D,I2M], [25..26] tr[j][I2I,M2I]
+      const int src_col = (w <= REC_I2M) ? j - 1 : j;
+      const int slot = (w == REC_M2M) ? T_M2M : (w == REC_M2D) ? T_M2D : (w == REC_D2M) ? T_D2M
+                     : (w == REC_D2D) ? T_D2D : (w == REC_I2M) ? T_I2M : (w == REC_I2I) ? T_I2I : T_M2I;
+      v = a.tr_tmp[(size_t)(c0 + src_col) * 8 + slot];
+    } else {
+      int32_t meta = j | (__builtin_bit_cast(int32_t, a.raw[(size_t)(c0 + j) * RAW_DW + RAW_SS]) & 0x01FF0000);
+      if (j == L) meta |= META_LAST;
+      v = __builtin_bit_cast(float, meta);
+    }
+    a.records[(size_t)(c0 + j) * REC_DW + w] = v;
+  }
+}
+
+int launch_prepare(const PrepArgs& a, int n_templates, void* stream) {
+  const int threads = 256;
+  const int64_t blocks = (a.n_cols + threads - 1) / threads;
+  hipLaunchKernelGGL(hhv_prep_columns_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(hhv_prep_finalize_kernel, dim3(n_templates), dim3(LANES), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace hhv

@@ -36,10 +36,29 @@ ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
     "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
+    "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
 ]
+
+
+class HhvPrepParams(C.Structure):
+    _fields_ = [("gapd", C.c_float), ("gape", C.c_float), ("gapf", C.c_float), ("gapg", C.c_float),
+                ("gaph", C.c_float), ("gapi", C.c_float), ("gapb", C.c_float), ("pcm", C.c_int32),
+                ("pca", C.c_float), ("pcb", C.c_float), ("pcc", C.c_float), ("columnscore", C.c_int32),
+                ("pb", C.c_float * 20), ("R", C.c_float * 400)]
+
+
+def prep_params(pb, R, gap=(0.15, 1.0, 0.6, 0.6, 0.6, 0.6, 1.0), pc=(2, 1.0, 1.5, 1.0), columnscore=1):
+    """Defaults of the reference: src/hhdecl.cpp:64-67,74-80,98."""
+    P = HhvPrepParams()
+    (P.gapd, P.gape, P.gapf, P.gapg, P.gaph, P.gapi, P.gapb) = [float(x) for x in gap]
+    P.pcm, P.pca, P.pcb, P.pcc = int(pc[0]), float(pc[1]), float(pc[2]), float(pc[3])
+    P.columnscore = int(columnscore)
+    P.pb[:] = [float(x) for x in np.asarray(pb).reshape(-1)]
+    P.R[:] = [float(x) for x in np.asarray(R).reshape(-1)]
+    return P
 
 
 class HhvError(RuntimeError):
@@ -74,6 +93,14 @@ def load():
     L.hhv_set_query_ss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_set_ss_mode.argtypes = [C.c_void_p, C.c_int32]
     L.hhv_adopt_device_stream.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    vpp = C.POINTER(C.c_void_p)
+    L.hhv_upload_raw_templates.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
+                                           C.POINTER(c_float_p), c_float_p, vpp, vpp, vpp, C.POINTER(C.c_void_p)]
+    L.hhv_rawset_free.argtypes = [C.c_void_p]
+    L.hhv_rawset_free.restype = None
+    L.hhv_prepare_templates.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(HhvPrepParams), c_float_p, C.POINTER(C.c_void_p)]
+    L.hhv_rawset_pav.argtypes = [C.c_void_p, C.c_void_p, c_float_p]
+    L.hhv_tset_records_of.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, c_float_p]
     L.hhv_db_write.argtypes = [C.c_char_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p,
                                C.c_void_p, C.c_void_p]
     L.hhv_db_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
@@ -210,6 +237,42 @@ class Context:
 
     def set_ss_mode(self, mode):
         _check(self.lib.hhv_set_ss_mode(self.h, int(mode)))
+
+    def upload_raw(self, fs, trs, neffs, neff_hmm):
+        """hhv_upload_raw_templates: raw HMMs (f[(L+2),20], tr[(L+1),7], neff[(L+1),3], Neff_HMM) -> raw set handle."""
+        fs = [_f32(a) for a in fs]
+        trs = [_f32(a) for a in trs]
+        neffs = [_f32(a) for a in neffs]
+        n = len(fs)
+        Ls = np.array([a.shape[0] - 1 for a in trs], dtype=np.int32)
+        nh = _f32(neff_hmm)
+        ff = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in fs])
+        tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in trs])
+        nn = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in neffs])
+        h = C.c_void_p()
+        _check(self.lib.hhv_upload_raw_templates(self.h, n, Ls.ctypes.data_as(c_int_p), ff, tt, nn,
+                                                 nh.ctypes.data_as(c_float_p), None, None, None, C.byref(h)))
+        return h, Ls
+
+    def prepare(self, raw, Ls, params, q_pav, ts=None):
+        """hhv_prepare_templates -> TemplateSet (created on the first call, refilled afterwards)."""
+        q_pav = _f32(q_pav)
+        h = C.c_void_p(ts.h.value) if ts is not None else C.c_void_p()
+        _check(self.lib.hhv_prepare_templates(self.h, raw, C.byref(params), q_pav.ctypes.data_as(c_float_p), C.byref(h)))
+        return ts if ts is not None else TemplateSet(self, h, Ls)
+
+    def rawset_pav(self, raw, n):
+        pav = np.zeros((n, 20), dtype=np.float32)
+        _check(self.lib.hhv_rawset_pav(self.h, raw, pav.ctypes.data_as(c_float_p)))
+        return pav
+
+    def rawset_free(self, raw):
+        self.lib.hhv_rawset_free(raw)
+
+    def records_of(self, ts, k):
+        out = np.zeros((int(ts.L[k]) + 1, REC_DW), dtype=np.float32)
+        _check(self.lib.hhv_tset_records_of(self.h, ts.h, int(k), out.ctypes.data_as(c_float_p)))
+        return out
 
     def db_open(self, path, Ls):
         h = C.c_void_p()

@@ -133,3 +133,39 @@ def zipf_lengths(seed, n, lo=50, hi=1000, s=1.2):
     u = uniform(seed, n, 11).astype(np.float64)
     k = np.searchsorted(cdf, u, side="right") + 1
     return (lo - 1 + np.minimum(k, K)).astype(np.int32)
+
+
+def make_raw_hmm(seed, L):
+    """Raw (unprepared) profile HMM as HMM::Read leaves it (src/hhhmm.cpp:202-694): f[(L+2),20] match-state
+    frequencies without pseudocounts (sparse: absent residues carry 2^-99.999 like '*' entries of an .hhm
+    file), tr[(L+1),7] raw log2 transitions ('*' = -99.999), neff[(L+1),3] = Neff_M, Neff_I, Neff_D, Neff_HMM."""
+    u = uniform(seed, (L + 2) * 20, 21).reshape(L + 2, 20).astype(np.float64)
+    g = np.power(u, 8.0)
+    g[g < 0.02] = 0.0
+    g[np.arange(L + 2), np.argmax(u, axis=1)] += 0.05
+    f = g / g.sum(axis=1, keepdims=True)
+    f = np.where(f > 0, f, 2.0 ** -99.999).astype(np.float32)
+    f[0, :] = 0.0
+    f[L + 1, :] = 0.0
+    t = uniform(seed, (L + 1) * 8, 22).reshape(L + 1, 8).astype(np.float64)
+    pI, pD = 0.002 + 0.06 * t[:, 0], 0.002 + 0.06 * t[:, 1]
+    pII, pDD = 0.1 + 0.6 * t[:, 2], 0.1 + 0.6 * t[:, 3]
+    tr = np.zeros((L + 1, 7), dtype=np.float64)
+    tr[:, M2M] = np.log2(1 - pI - pD)
+    tr[:, M2I] = np.log2(pI)
+    tr[:, M2D] = np.log2(pD)
+    tr[:, I2M] = np.log2(1 - pII)
+    tr[:, I2I] = np.log2(pII)
+    tr[:, D2M] = np.log2(1 - pDD)
+    tr[:, D2D] = np.log2(pDD)
+    star = t[:, 4] < 0.3                     # columns without observed inserts/deletes
+    tr[star, M2I] = tr[star, M2D] = -99.999
+    tr[star, I2I] = tr[star, D2D] = -99.999
+    tr[star, M2M] = tr[star, I2M] = tr[star, D2M] = 0.0
+    tr[0] = [0.0, -99.999, -99.999, 0.0, -99.999, 0.0, -99.999]
+    neff = np.zeros((L + 1, 3), dtype=np.float32)
+    neff[:, 0] = 1.0 + 9.0 * t[:, 5]
+    neff[:, 1] = np.where(star, 0.0, 3.0 * t[:, 6])
+    neff[:, 2] = np.where(star, 0.0, 3.0 * t[:, 7])
+    neff_hmm = np.float32(neff[1:, 0].mean())
+    return f, tr.astype(np.float32), neff, neff_hmm

@@ -140,6 +140,35 @@ int hhv_upload_templates_ss(hhv_ctx* ctx, int32_t n, const int32_t* L, const flo
  * outlive the set. */
 #define HHV_STREAM_PAD 256
 int hhv_adopt_device_stream(hhv_ctx* ctx, int32_t n, const int32_t* L, const void* d_records, hhv_tset** out);
+/* ---- on-device template preparation ------------------------------------------------
+ * Raw templates = the HMM fields HMM::Read leaves (src/hhhmm.cpp:202-694), before any pseudocounts:
+ *   f[k]    [(L+2)*20]  match-state frequencies, rows 0..L+1 (rows 0 and L+1 unused)
+ *   tr[k]   [(L+1)*7]   log2 transitions, enum order M2M,M2I,M2D,I2M,I2I,D2M,D2D
+ *   neff[k] [(L+1)*3]   Neff_M, Neff_I, Neff_D per column;   neff_hmm[k] = Neff_HMM
+ * hhv_prepare_templates runs PrepareTemplateHMM (src/hhfunc.cpp:165-202, HHM format: transition
+ * pseudocounts, substitution-matrix amino-acid pseudocounts, background, null model) for every template on
+ * the device and produces a resident set for hhv_align; with columnscore = 1 (the default) the result depends
+ * on the query's average composition q_pav (HMM::pav after PrepareQueryHMM), so it is called once per query.
+ * *out == NULL creates the set, otherwise the set created by an earlier call for the same raw set is refilled. */
+typedef struct hhv_rawset hhv_rawset;
+typedef struct {
+  float gapd, gape, gapf, gapg, gaph, gapi, gapb; /* par.gap*        defaults 0.15 1 .6 .6 .6 .6 1 (src/hhdecl.cpp:74-80) */
+  int32_t pcm;                                    /* par.pc_hhm_nocontext_mode  (0, 1, 2)            (src/hhdecl.cpp:64) */
+  float pca, pcb, pcc;                            /* par.pc_hhm_nocontext_a/b/c 1.0 1.5 1.0; pcc must be 1 on the device */
+  int32_t columnscore;                            /* par.columnscore 0..3, default 1                 (src/hhdecl.cpp:98) */
+  float pb[20];                                   /* background frequencies  (SetSubstitutionMatrix, src/hhmatrices.cpp:53-58) */
+  float R[400];                                   /* R[a][b] = P(a|b)        (src/hhmatrices.cpp:66-69) */
+} hhv_prep_params;
+int hhv_upload_raw_templates(hhv_ctx* ctx, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
+                             const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
+                             const int8_t* const* ss_conf, const int8_t* const* ss_dssp, hhv_rawset** out);
+void hhv_rawset_free(hhv_rawset* rs);
+int hhv_prepare_templates(hhv_ctx* ctx, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out);
+/* average composition pav[n*20] of the prepared templates of the last hhv_prepare_templates (diagnostics/tests) */
+int hhv_rawset_pav(hhv_ctx* ctx, hhv_rawset* rs, float* pav);
+/* the prepared packed records of template k of a set ((L[k]+1)*28 floats: header + columns), device -> host */
+int hhv_tset_records_of(hhv_ctx* ctx, hhv_tset* ts, int32_t k, float* out);
+
 /* Binary packed template database: the record stream plus its length table in one file, so that
  * a search mmaps/reads it straight into HBM instead of parsing and re-packing HMM text per query.
  * File = 64-byte header {magic "HHVPDB01", int32 n, int32 record_dwords (28), int64 n_records, zero pad},

@@ -418,6 +418,115 @@ int hho_exclude_alignment(int Lq, int Lt, const int *i_steps, const int *j_steps
   return 0;
 }
 
+/* src/util-inl.h:190-215 */
+float hho_fpow2(float x) {
+  if (x >= FLT_MAX_EXP) return FLT_MAX;
+  if (x <= FLT_MIN_EXP) return 0.0f;
+  const float tx = (x - 0.5f) + (float)(3 << 22);
+  const int lx = (int)(f2u(tx) - 0x4b400000u);
+  const float dx = x - (float)lx;
+  float y = dx * 0.0134929f;
+  y = 0.0520749f + y;
+  y = dx * y;
+  y = 0.241404f + y;
+  y = dx * y;
+  y = 0.693019f + y;
+  y = dx * y;
+  y = 1.0f + y;
+  return u2f(f2u(y) + ((uint32_t)lx << 23));
+}
+
+int hho_prepare(int role, int L, const float *f, const float *tr, const float *neff, float Neff_HMM, const float *pb,
+                const float *R, const float *q_pav, const float *gap, const float *pc, int columnscore, float *p,
+                float *tr_out, float *pav) {
+  const float gapd = gap[0], gape = gap[1], gapf = gap[2], gapg = gap[3], gaph = gap[4], gapi = gap[5], gapb = gap[6];
+  memcpy(tr_out, tr, sizeof(float) * 7 * (size_t)(L + 1));
+  /* ---- AddTransitionPseudocounts, src/hhhmm.cpp:1722-1806 */
+  if (gapb > 0) {
+    float pM2D, pM2I;
+    pM2D = pM2I = (float)((double)gapd * 0.0286);
+    const float pM2M = 1 - pM2D - pM2I;
+    const float pI2I = (float)(1.0 * (double)gape / ((double)(gape - 1) + 1.0 / 0.75));
+    const float pI2M = 1 - pI2I;
+    const float pD2D = (float)(1.0 * (double)gape / ((double)(gape - 1) + 1.0 / 0.75));
+    const float pD2M = 1 - pD2D;
+    for (int i = 0; i <= L; ++i) {
+      float *t = tr_out + (size_t)i * 7;
+      const float nM = neff[i * 3 + 0], nI = neff[i * 3 + 1], nD = neff[i * 3 + 2];
+      float p0 = (nM - 1) * hho_fpow2(t[HHO_M2M]) + gapb * pM2M;
+      float p1 = (nM - 1) * hho_fpow2(t[HHO_M2D]) + gapb * pM2D;
+      float p2 = (nM - 1) * hho_fpow2(t[HHO_M2I]) + gapb * pM2I;
+      if (i == 0) p1 = p2 = 0;
+      if (i == L) p1 = p2 = 0;
+      float sum = p0 + p1 + p2 + FLT_MIN;
+      t[HHO_M2M] = hho_fast_log2(p0 / sum);
+      t[HHO_M2D] = hho_fast_log2(p1 / sum) * gapf;
+      t[HHO_M2I] = hho_fast_log2(p2 / sum) * gapg;
+      p0 = nI * hho_fpow2(t[HHO_I2M]) + gapb * pI2M;
+      p1 = nI * hho_fpow2(t[HHO_I2I]) + gapb * pI2I;
+      sum = p0 + p1 + FLT_MIN;
+      t[HHO_I2M] = hho_fast_log2(p0 / sum);
+      t[HHO_I2I] = hho_fast_log2(p1 / sum) * gapi;
+      p0 = nD * hho_fpow2(t[HHO_D2M]) + gapb * pD2M;
+      p1 = nD * hho_fpow2(t[HHO_D2D]) + gapb * pD2D;
+      if (i == L) p1 = 0;
+      sum = p0 + p1 + FLT_MIN;
+      t[HHO_D2M] = hho_fast_log2(p0 / sum);
+      t[HHO_D2D] = hho_fast_log2(p1 / sum) * gaph;
+    }
+  }
+  /* ---- PreparePseudocounts (:1811-1815) + AddAminoAcidPseudocounts (:1874-1964) */
+  const int pcm = (int)pc[0];
+  const float pca = pc[1], pcb = pc[2], pcc = pc[3];
+  if (pcm < 0 || pcm > 2) return -1;
+  memset(p, 0, sizeof(float) * 20 * (size_t)(L + 2));
+  for (int i = 1; i <= L; ++i) {
+    const float *fi = f + (size_t)i * 20;
+    float tau = 0.0f;
+    if (pcm == 1) tau = pca;
+    if (pcm == 2) {
+      if (pcc == 1.0f) tau = (float)fmin(1.0, (double)pca / (1. + (double)(neff[i * 3] / pcb)));
+      else tau = (float)fmin(1.0, (double)pca / (1. + pow((double)(neff[i * 3] / pcb), (double)pcc)));
+    }
+    for (int a = 0; a < 20; ++a) {
+      if (pcm == 0) {
+        p[(size_t)i * 20 + a] = fi[a];
+      } else {
+        const float g = hho_dot20_scalar(R + a * 20, fi); /* ScalarProd20(R[a], f[i]) */
+        p[(size_t)i * 20 + a] = (float)((1. - (double)tau) * (double)fi[a] + (double)(tau * g));
+      }
+    }
+  }
+  /* ---- CalculateAminoAcidBackground, :1854-1868 */
+  for (int a = 0; a < 20; ++a) pav[a] = pb[a] * 100.0f / Neff_HMM;
+  for (int i = 1; i <= L; ++i)
+    for (int a = 0; a < 20; ++a) pav[a] += p[(size_t)i * 20 + a];
+  {
+    float sum = 0.0f;
+    for (int k = 0; k < 20; k++) sum += pav[k];
+    if (sum != 0.0f) {
+      const float fac = (float)(1.0 / (double)sum);
+      for (int k = 0; k < 20; k++) pav[k] *= fac;
+    }
+  }
+  for (int a = 0; a < 20; ++a) p[a] = p[(size_t)(L + 1) * 20 + a] = pav[a];
+  /* ---- IncludeNullModelInHMM, :2059-2144 */
+  if (role == 1) {
+    float pnul[20];
+    for (int a = 0; a < 20; ++a) {
+      switch (columnscore) {
+        case 1: pnul[a] = (float)(0.5 * (double)(q_pav[a] + pav[a])); break;
+        case 2: pnul[a] = pav[a]; break;
+        case 3: pnul[a] = q_pav[a]; break;
+        default: pnul[a] = pb[a]; break;
+      }
+    }
+    for (int j = 0; j <= L + 1; ++j)
+      for (int a = 0; a < 20; ++a) p[(size_t)j * 20 + a] /= pnul[a];
+  }
+  return 0;
+}
+
 double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
                        const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2) {
   struct timespec t0, t1;

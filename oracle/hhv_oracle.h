@@ -67,6 +67,21 @@ int hho_score_for_backtrace(const hho_params *par, const float *qp, const float 
 /* Viterbi::ExcludeAlignment: ORs the +-40 cross mask of one path into mask ((Lq+1) x (Lt+1)). */
 int hho_exclude_alignment(int Lq, int Lt, const int *i_steps, const int *j_steps, int nsteps, unsigned char *mask);
 
+/* fpow2 (src/util-inl.h:190-215) */
+float hho_fpow2(float x);
+
+/* PrepareQueryHMM (role 0) / PrepareTemplateHMM (role 1), src/hhfunc.cpp:121-160,165-202 with input format 0 and
+ * substitution-matrix pseudocounts (-nocontxt): AddTransitionPseudocounts, PreparePseudocounts,
+ * AddAminoAcidPseudocounts, CalculateAminoAcidBackground and - templates - IncludeNullModelInHMM
+ * (src/hhhmm.cpp:1722-1806,1811-1815,1874-1964,1854-1868,2059-2144).
+ * Raw inputs: f[(L+2)*20], tr[(L+1)*7] (as HMM::Read leaves them), neff[(L+1)*3] = Neff_M,Neff_I,Neff_D, Neff_HMM;
+ * pb[20], R[20*20] from SetSubstitutionMatrix; gap = {gapd,gape,gapf,gapg,gaph,gapi,gapb}; pc = {pcm,pca,pcb,pcc};
+ * q_pav[20] = average composition of the prepared query (role 1).
+ * Outputs: p[(L+2)*20], tr_out[(L+1)*7], pav[20]. */
+int hho_prepare(int role, int L, const float *f, const float *tr, const float *neff, float Neff_HMM, const float *pb,
+                const float *R, const float *q_pav, const float *gap, const float *pc, int columnscore, float *p,
+                float *tr_out, float *pav);
+
 /* Convenience for the CPU baseline ("port" kind): N templates, score/i2/j2 only, OpenMP over
  * templates.  Returns wall seconds. */
 double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,

@@ -337,6 +337,75 @@ class Ref:
         return sec, mapsec.value, score, i2, j2
 
 
+DEFAULT_GAP = np.array([0.15, 1.0, 0.6, 0.6, 0.6, 0.6, 1.0], dtype=np.float32)   # gapd gape gapf gapg gaph gapi gapb
+DEFAULT_PC = np.array([2, 1.0, 1.5, 1.0], dtype=np.float32)                      # pcm pca pcb pcc
+
+
+def _prep_common(f, tr, neff):
+    f, tr, neff = _f32(f), _f32(tr), _f32(neff)
+    L = tr.shape[0] - 1
+    assert f.shape == (L + 2, 20) and neff.shape == (L + 1, 3)
+    return f, tr, neff, L
+
+
+def oracle_prepare(orc, role, f, tr, neff, neff_hmm, pb, R, q_pav=None, gap=DEFAULT_GAP, pc=DEFAULT_PC, columnscore=1):
+    """hho_prepare: PrepareQueryHMM (role 0) / PrepareTemplateHMM (role 1) restated. -> (p[(L+2),20], tr, pav)."""
+    f, tr, neff, L = _prep_common(f, tr, neff)
+    pb, R = _f32(pb), _f32(R).reshape(-1)
+    qp = _f32(np.zeros(20) if q_pav is None else q_pav)
+    gap, pc = _f32(gap), _f32(pc)
+    p = np.zeros((L + 2, 20), dtype=np.float32)
+    tro = np.zeros((L + 1, 7), dtype=np.float32)
+    pav = np.zeros(20, dtype=np.float32)
+    fn = orc.lib.hho_prepare
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, C.c_float, c_float_p, c_float_p, c_float_p,
+                   c_float_p, c_float_p, C.c_int, c_float_p, c_float_p, c_float_p]
+    rc = fn(role, L, _fp(f), _fp(tr), _fp(neff), float(neff_hmm), _fp(pb), _fp(R), _fp(qp), _fp(gap), _fp(pc),
+            int(columnscore), _fp(p), _fp(tro), _fp(pav))
+    assert rc == 0, rc
+    return p, tro, pav
+
+
+def ref_prepare(ref, role, f, tr, neff, neff_hmm, q_pav=None, gap=DEFAULT_GAP, pc=DEFAULT_PC, columnscore=1):
+    """The reference's own PrepareQueryHMM / PrepareTemplateHMM call sequence (oracle/ref_hmm_harness.cpp)."""
+    f, tr, neff, L = _prep_common(f, tr, neff)
+    qp = _f32(np.zeros(20) if q_pav is None else q_pav)
+    gap, pc = _f32(gap), _f32(pc)
+    p = np.zeros((L + 2, 20), dtype=np.float32)
+    tro = np.zeros((L + 1, 7), dtype=np.float32)
+    pav = np.zeros(20, dtype=np.float32)
+    fn = ref.lib.ref_prepare_raw
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, C.c_float, c_float_p, c_float_p, c_float_p,
+                   C.c_int, c_float_p, c_float_p, c_float_p]
+    rc = fn(role, L, _fp(f), _fp(tr), _fp(neff), float(neff_hmm), _fp(qp), _fp(gap), _fp(pc), int(columnscore), _fp(p),
+            _fp(tro), _fp(pav))
+    assert rc == 0, rc
+    return p, tro, pav
+
+
+def ref_substitution_matrix(ref):
+    pb = np.zeros(20, dtype=np.float32)
+    R = np.zeros((20, 20), dtype=np.float32)
+    ref.lib.ref_substitution_matrix.argtypes = [c_float_p, c_float_p]
+    ref.lib.ref_substitution_matrix(_fp(pb), _fp(R))
+    return pb, R
+
+
+def ref_read_hhm_raw(ref, path, maxres=25000):
+    f = np.zeros((maxres + 2, 20), dtype=np.float32)
+    tr = np.zeros((maxres + 1, 7), dtype=np.float32)
+    neff = np.zeros((maxres + 1, 3), dtype=np.float32)
+    nh, L = C.c_float(), C.c_int()
+    fn = ref.lib.ref_read_hhm_raw
+    fn.argtypes = [C.c_char_p, C.c_int, c_float_p, c_float_p, c_float_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    rc = fn(path.encode(), maxres, _fp(f), _fp(tr), _fp(neff), C.byref(nh), C.byref(L))
+    assert rc == 0, rc
+    L = L.value
+    return f[:L + 2].copy(), tr[:L + 1].copy(), neff[:L + 1].copy(), np.float32(nh.value)
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 

@@ -104,4 +104,93 @@ int ref_prepare_hhm(const char* query_path, const char* template_path, int maxre
   return 0;
 }
 
+// ---- raw (unprepared) HMMs: the inputs of PrepareQueryHMM / PrepareTemplateHMM ------------------------
+// Raw layout: f[(L+2)*20] (rows 0..L+1), tr[(L+1)*7] raw log2 transitions as HMM::Read leaves them,
+// neff[(L+1)*3] = Neff_M, Neff_I, Neff_D per column, Neff_HMM.
+int ref_read_hhm_raw(const char* path, int maxres, float* f, float* tr, float* neff, float* Neff_HMM, int* L) {
+  if (Log::reporting_level() > WARNING) Log::reporting_level() = WARNING;
+  Parameters par(0, NULL);
+  par.maxres = maxres;
+  float pb[21];
+  float P[20][20], R[20][20], S[20][20], Sim[20][20];
+  SetSubstitutionMatrix(par.matrix, pb, P, R, S, Sim);
+  HMM* h = new HMM(MAXSEQDIS, maxres);
+  FILE* fp = fopen(path, "r");
+  if (!fp) return -1;
+  char pth[NAMELEN] = "";
+  if (!h->Read(fp, par.maxcol, par.nseqdis, pb, pth)) {
+    fclose(fp);
+    return -2;
+  }
+  fclose(fp);
+  *L = h->L;
+  *Neff_HMM = h->Neff_HMM;
+  for (int i = 0; i <= h->L + 1; ++i)
+    for (int a = 0; a < 20; ++a) f[i * 20 + a] = h->f[i][a];
+  for (int i = 0; i <= h->L; ++i) {
+    for (int k = 0; k < 7; ++k) tr[i * 7 + k] = h->tr[i][k];
+    neff[i * 3 + 0] = h->Neff_M[i];
+    neff[i * 3 + 1] = h->Neff_I[i];
+    neff[i * 3 + 2] = h->Neff_D[i];
+  }
+  delete h;
+  return 0;
+}
+
+float ref_fpow2(float x) { return fpow2(x); }
+
+// the substitution matrix side products the preparation needs (Gonnet default): pb[20], R[20][20]
+int ref_substitution_matrix(float* pb_out, float* R_out) {
+  Parameters par(0, NULL);
+  float pb[21];
+  float P[20][20], R[20][20], S[20][20], Sim[20][20];
+  SetSubstitutionMatrix(par.matrix, pb, P, R, S, Sim);
+  memcpy(pb_out, pb, 20 * sizeof(float));
+  memcpy(R_out, R, 400 * sizeof(float));
+  return 0;
+}
+
+// role 0: PrepareQueryHMM (src/hhfunc.cpp:121-160, input_format 0, -nocontxt); role 1: PrepareTemplateHMM
+// (src/hhfunc.cpp:165-202, format 0) against a query whose average composition is q_pav[20].
+// gap = {gapd, gape, gapf, gapg, gaph, gapi, gapb}; pc = {pcm, pca, pcb, pcc}.
+// out_p[(L+2)*20] (rows 0 and L+1 = background, as the reference leaves them), out_tr[(L+1)*7], out_pav[20].
+int ref_prepare_raw(int role, int L, const float* f, const float* tr, const float* neff, float Neff_HMM,
+                    const float* q_pav, const float* gap, const float* pc, int columnscore, float* out_p,
+                    float* out_tr, float* out_pav) {
+  if (Log::reporting_level() > WARNING) Log::reporting_level() = WARNING;
+  Parameters par(0, NULL);
+  float pb[21];
+  float P[20][20], R[20][20], S[20][20], Sim[20][20];
+  SetSubstitutionMatrix(par.matrix, pb, P, R, S, Sim);
+  const int maxres = L + 3;
+  HMM* h = new HMM(MAXSEQDIS, maxres);
+  h->L = L;
+  h->Neff_HMM = Neff_HMM;
+  for (int i = 0; i <= L + 1; ++i)
+    for (int a = 0; a < 20; ++a) h->f[i][a] = f[i * 20 + a];
+  for (int i = 0; i <= L; ++i) {
+    for (int k = 0; k < 7; ++k) h->tr[i][k] = tr[i * 7 + k];
+    h->Neff_M[i] = neff[i * 3 + 0];
+    h->Neff_I[i] = neff[i * 3 + 1];
+    h->Neff_D[i] = neff[i * 3 + 2];
+  }
+  h->AddTransitionPseudocounts(gap[0], gap[1], gap[2], gap[3], gap[4], gap[5], gap[6], gap[6]);
+  h->PreparePseudocounts(R);
+  h->AddAminoAcidPseudocounts((char)pc[0], pc[1], pc[2], pc[3]);
+  h->CalculateAminoAcidBackground(pb);
+  if (role == 1) {
+    HMM* q = new HMM(MAXSEQDIS, 8);
+    for (int a = 0; a < 20; ++a) q->pav[a] = q_pav[a];
+    h->IncludeNullModelInHMM(q, h, columnscore, par.half_window_size_local_aa_bg_freqs, pb);
+    delete q;
+  }
+  for (int i = 0; i <= L + 1; ++i)
+    for (int a = 0; a < 20; ++a) out_p[i * 20 + a] = h->p[i][a];
+  for (int i = 0; i <= L; ++i)
+    for (int k = 0; k < 7; ++k) out_tr[i * 7 + k] = h->tr[i][k];
+  for (int a = 0; a < 20; ++a) out_pav[a] = h->pav[a];
+  delete h;
+  return 0;
+}
+
 }  // extern "C"

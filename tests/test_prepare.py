@@ -1,0 +1,117 @@
+"""On-device PrepareTemplateHMM.
+CPU: the oracle's restatement (hho_prepare) is pinned bit for bit to the reference's own
+     AddTransitionPseudocounts / PreparePseudocounts / AddAminoAcidPseudocounts /
+     CalculateAminoAcidBackground / IncludeNullModelInHMM (oracle/ref_hmm_harness.cpp) on synthetic raw
+     HMMs and on the real data/query.hhm (committed as tests/golden/query_hhm_raw.npz).
+GPU: hhv_prepare_templates must emit exactly the packed records of the oracle-prepared profiles, and a
+     search on device-prepared templates must equal a search on host-prepared ones."""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from pyhhv import pack, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def gonnet():
+    z = np.load(os.path.join(HERE, "golden", "gonnet_pb_R.npz"))
+    return z["pb"], z["R"]
+
+
+def raw_query_hhm():
+    z = np.load(os.path.join(HERE, "golden", "query_hhm_raw.npz"))
+    return z["f"], z["tr"], z["neff"], np.float32(z["neff_hmm"])
+
+
+def test_fixture_matches_reference(ref):
+    pb, R = gonnet()
+    pb2, R2 = po.ref_substitution_matrix(ref)
+    assert np.array_equal(pb, pb2) and np.array_equal(R, R2)
+
+
+def test_fpow2_bitexact(oracle, ref):
+    import ctypes as C
+    for lib, name in ((oracle.lib, "hho_fpow2"), (ref.lib, "ref_fpow2")):
+        getattr(lib, name).restype = C.c_float
+        getattr(lib, name).argtypes = [C.c_float]
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-130, 130, 4000), rng.uniform(-2, 2, 2000), [0, 1, -1, 127.99, 128, -125, -125.01, -99.999]])
+    for x in xs.astype(np.float32):
+        a, b = oracle.lib.hho_fpow2(float(x)), ref.lib.ref_fpow2(float(x))
+        assert np.float32(a).tobytes() == np.float32(b).tobytes(), x
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_prepare_restatement_bitexact_synthetic(oracle, ref, seed):
+    pb, R = gonnet()
+    L = 5 + seed * 17
+    f, tr, neff, nh = synth.make_raw_hmm(100 + seed, L)
+    pc = np.array([[2, 1.0, 1.5, 1.0], [0, 1, 1.5, 1], [1, 0.4, 1.5, 1.0], [2, 0.9, 2.0, 1.0]][seed % 4], np.float32)
+    gap = po.DEFAULT_GAP.copy()
+    if seed % 5 == 0:
+        gap[0], gap[1] = 0.3, 0.8
+    rq = po.ref_prepare(ref, 0, f, tr, neff, nh, gap=gap, pc=pc)
+    oq = po.oracle_prepare(oracle, 0, f, tr, neff, nh, pb, R, gap=gap, pc=pc)
+    f2, tr2, neff2, nh2 = synth.make_raw_hmm(900 + seed, L + 3)
+    rt = po.ref_prepare(ref, 1, f2, tr2, neff2, nh2, q_pav=rq[2], gap=gap, pc=pc, columnscore=seed % 4)
+    ot = po.oracle_prepare(oracle, 1, f2, tr2, neff2, nh2, pb, R, q_pav=oq[2], gap=gap, pc=pc, columnscore=seed % 4)
+    for a, b in list(zip(rq, oq)) + list(zip(rt, ot)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_prepare_restatement_bitexact_real_hhm(oracle, ref):
+    pb, R = gonnet()
+    f, tr, neff, nh = raw_query_hhm()
+    rq = po.ref_prepare(ref, 0, f, tr, neff, nh)
+    oq = po.oracle_prepare(oracle, 0, f, tr, neff, nh, pb, R)
+    rt = po.ref_prepare(ref, 1, f, tr, neff, nh, q_pav=rq[2])
+    ot = po.oracle_prepare(oracle, 1, f, tr, neff, nh, pb, R, q_pav=oq[2])
+    for a, b in list(zip(rq, oq)) + list(zip(rt, ot)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # and the prepared tensors are the ones of the committed real-profile fixture
+    z = np.load(os.path.join(HERE, "golden", "query_hhm_prepared.npz"))
+    assert np.array_equal(oq[0][1:-1], z["qp"][1:]) and np.array_equal(oq[1], z["qtr"])
+    assert np.array_equal(ot[0][1:-1], z["tp"][1:]) and np.array_equal(ot[1], z["ttr"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("columnscore,pcm", [(1, 2), (0, 2), (2, 1), (3, 0)])
+def test_gpu_prepare_matches_oracle(oracle, columnscore, pcm):
+    from pyhhv import capi
+    pb, R = gonnet()
+    rng = np.random.default_rng(columnscore * 10 + pcm)
+    fq, trq, nq, nhq = raw_query_hhm()
+    q_p, q_tr, q_pav = po.oracle_prepare(oracle, 0, fq, trq, nq, nhq, pb, R)
+    raws = [synth.make_raw_hmm(300 + k, int(rng.integers(1, 200))) for k in range(20)] + [(fq, trq, nq, nhq)]
+    pc = (pcm, 0.7 if pcm == 1 else 1.0, 1.5, 1.0)
+    c = capi.Context(local=1)
+    c.set_query(q_p[:-1], q_tr)
+    raw, Ls = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+    par = capi.prep_params(pb, R, pc=pc, columnscore=columnscore)
+    ts = c.prepare(raw, Ls, par, q_pav)
+    pav = c.rawset_pav(raw, len(raws))
+    host_p, host_tr = [], []
+    for k, (f, tr, neff, nh) in enumerate(raws):
+        p, tro, pv = po.oracle_prepare(oracle, 1, f, tr, neff, nh, pb, R, q_pav=q_pav, pc=np.array(pc, np.float32),
+                                       columnscore=columnscore)
+        host_p.append(np.ascontiguousarray(p[:-1]))
+        host_tr.append(tro)
+        want = capi.pack_profile(host_p[-1], tro, index=k)
+        got = c.records_of(ts, k)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), k
+        assert np.array_equal(pav[k].view(np.uint32), pv.view(np.uint32))
+    # search on device-prepared templates == search on host-prepared templates
+    ts2 = c.upload(host_p, host_tr)
+    r1, r2 = c.align(ts), c.align(ts2)
+    assert np.array_equal(r1.view(np.uint8), r2.view(np.uint8))
+    # refill for a second query composition: results follow the new null model
+    ts = c.prepare(raw, Ls, par, np.roll(q_pav, 3), ts=ts)
+    if columnscore in (1, 3):
+        assert not np.array_equal(c.records_of(ts, 0)[1:, :20], capi.pack_profile(host_p[0], host_tr[0], index=0)[1:, :20])
+    c.rawset_free(raw)
+    ts.free()
+    ts2.free()
+    c.close()
