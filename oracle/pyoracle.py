@@ -367,7 +367,7 @@ def oracle_prepare(orc, role, f, tr, neff, neff_hmm, pb, R, q_pav=None, gap=DEFA
     return p, tro, pav
 
 
-def ref_prepare(ref, role, f, tr, neff, neff_hmm, q_pav=None, gap=DEFAULT_GAP, pc=DEFAULT_PC, columnscore=1):
+def ref_prepare(ref, role, f, tr, neff, neff_hmm, q_pav=None, gap=DEFAULT_GAP, pc=DEFAULT_PC, columnscore=1, pb=None):
     """The reference's own PrepareQueryHMM / PrepareTemplateHMM call sequence (oracle/ref_hmm_harness.cpp)."""
     f, tr, neff, L = _prep_common(f, tr, neff)
     qp = _f32(np.zeros(20) if q_pav is None else q_pav)
@@ -378,9 +378,10 @@ def ref_prepare(ref, role, f, tr, neff, neff_hmm, q_pav=None, gap=DEFAULT_GAP, p
     fn = ref.lib.ref_prepare_raw
     fn.restype = C.c_int
     fn.argtypes = [C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, C.c_float, c_float_p, c_float_p, c_float_p,
-                   C.c_int, c_float_p, c_float_p, c_float_p]
-    rc = fn(role, L, _fp(f), _fp(tr), _fp(neff), float(neff_hmm), _fp(qp), _fp(gap), _fp(pc), int(columnscore), _fp(p),
-            _fp(tro), _fp(pav))
+                   C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]
+    pbo = None if pb is None else _f32(pb)
+    rc = fn(role, L, _fp(f), _fp(tr), _fp(neff), float(neff_hmm), _fp(qp), _fp(gap), _fp(pc), int(columnscore),
+            _fp(pbo) if pbo is not None else None, _fp(p), _fp(tro), _fp(pav))
     assert rc == 0, rc
     return p, tro, pav
 
@@ -398,12 +399,14 @@ def ref_read_hhm_raw(ref, path, maxres=25000):
     tr = np.zeros((maxres + 1, 7), dtype=np.float32)
     neff = np.zeros((maxres + 1, 3), dtype=np.float32)
     nh, L = C.c_float(), C.c_int()
+    pb = np.zeros(20, dtype=np.float32)
     fn = ref.lib.ref_read_hhm_raw
-    fn.argtypes = [C.c_char_p, C.c_int, c_float_p, c_float_p, c_float_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    rc = fn(path.encode(), maxres, _fp(f), _fp(tr), _fp(neff), C.byref(nh), C.byref(L))
+    fn.argtypes = [C.c_char_p, C.c_int, c_float_p, c_float_p, c_float_p, C.POINTER(C.c_float), C.POINTER(C.c_int),
+                   c_float_p]
+    rc = fn(path.encode(), maxres, _fp(f), _fp(tr), _fp(neff), C.byref(nh), C.byref(L), _fp(pb))
     assert rc == 0, rc
     L = L.value
-    return f[:L + 2].copy(), tr[:L + 1].copy(), neff[:L + 1].copy(), np.float32(nh.value)
+    return f[:L + 2].copy(), tr[:L + 1].copy(), neff[:L + 1].copy(), np.float32(nh.value), pb
 
 
 def have_ref():

@@ -107,7 +107,10 @@ int ref_prepare_hhm(const char* query_path, const char* template_path, int maxre
 // ---- raw (unprepared) HMMs: the inputs of PrepareQueryHMM / PrepareTemplateHMM ------------------------
 // Raw layout: f[(L+2)*20] (rows 0..L+1), tr[(L+1)*7] raw log2 transitions as HMM::Read leaves them,
 // neff[(L+1)*3] = Neff_M, Neff_I, Neff_D per column, Neff_HMM.
-int ref_read_hhm_raw(const char* path, int maxres, float* f, float* tr, float* neff, float* Neff_HMM, int* L) {
+// pb_out[20]: the background AFTER the read - HMM::Read overwrites the caller's pb with the NULL line of the
+// file (src/hhhmm.cpp:536-546), and that is the pb the subsequent preparation of this HMM uses in the reference.
+int ref_read_hhm_raw(const char* path, int maxres, float* f, float* tr, float* neff, float* Neff_HMM, int* L,
+                     float* pb_out) {
   if (Log::reporting_level() > WARNING) Log::reporting_level() = WARNING;
   Parameters par(0, NULL);
   par.maxres = maxres;
@@ -125,6 +128,7 @@ int ref_read_hhm_raw(const char* path, int maxres, float* f, float* tr, float* n
   fclose(fp);
   *L = h->L;
   *Neff_HMM = h->Neff_HMM;
+  if (pb_out) memcpy(pb_out, pb, 20 * sizeof(float));
   for (int i = 0; i <= h->L + 1; ++i)
     for (int a = 0; a < 20; ++a) f[i * 20 + a] = h->f[i][a];
   for (int i = 0; i <= h->L; ++i) {
@@ -154,14 +158,16 @@ int ref_substitution_matrix(float* pb_out, float* R_out) {
 // (src/hhfunc.cpp:165-202, format 0) against a query whose average composition is q_pav[20].
 // gap = {gapd, gape, gapf, gapg, gaph, gapi, gapb}; pc = {pcm, pca, pcb, pcc}.
 // out_p[(L+2)*20] (rows 0 and L+1 = background, as the reference leaves them), out_tr[(L+1)*7], out_pav[20].
+// pb_in: nullable override of the background (e.g. the NULL line an .hhm read left behind)
 int ref_prepare_raw(int role, int L, const float* f, const float* tr, const float* neff, float Neff_HMM,
-                    const float* q_pav, const float* gap, const float* pc, int columnscore, float* out_p,
-                    float* out_tr, float* out_pav) {
+                    const float* q_pav, const float* gap, const float* pc, int columnscore, const float* pb_in,
+                    float* out_p, float* out_tr, float* out_pav) {
   if (Log::reporting_level() > WARNING) Log::reporting_level() = WARNING;
   Parameters par(0, NULL);
   float pb[21];
   float P[20][20], R[20][20], S[20][20], Sim[20][20];
   SetSubstitutionMatrix(par.matrix, pb, P, R, S, Sim);
+  if (pb_in) memcpy(pb, pb_in, 20 * sizeof(float));
   const int maxres = L + 3;
   HMM* h = new HMM(MAXSEQDIS, maxres);
   h->L = L;

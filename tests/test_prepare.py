@@ -21,9 +21,12 @@ def gonnet():
     return z["pb"], z["R"]
 
 
-def raw_query_hhm():
+def raw_query_hhm(with_pb=False):
+    """data/query.hhm as HMM::Read leaves it; pb_file = the NULL line of the file, which HMM::Read writes over the
+    caller's background array (src/hhhmm.cpp:536-546) and which the reference therefore uses afterwards."""
     z = np.load(os.path.join(HERE, "golden", "query_hhm_raw.npz"))
-    return z["f"], z["tr"], z["neff"], np.float32(z["neff_hmm"])
+    out = (z["f"], z["tr"], z["neff"], np.float32(z["neff_hmm"]))
+    return out + (z["pb_file"],) if with_pb else out
 
 
 def test_fixture_matches_reference(ref):
@@ -63,11 +66,11 @@ def test_prepare_restatement_bitexact_synthetic(oracle, ref, seed):
 
 
 def test_prepare_restatement_bitexact_real_hhm(oracle, ref):
-    pb, R = gonnet()
-    f, tr, neff, nh = raw_query_hhm()
-    rq = po.ref_prepare(ref, 0, f, tr, neff, nh)
+    _, R = gonnet()
+    f, tr, neff, nh, pb = raw_query_hhm(with_pb=True)
+    rq = po.ref_prepare(ref, 0, f, tr, neff, nh, pb=pb)
     oq = po.oracle_prepare(oracle, 0, f, tr, neff, nh, pb, R)
-    rt = po.ref_prepare(ref, 1, f, tr, neff, nh, q_pav=rq[2])
+    rt = po.ref_prepare(ref, 1, f, tr, neff, nh, q_pav=rq[2], pb=pb)
     ot = po.oracle_prepare(oracle, 1, f, tr, neff, nh, pb, R, q_pav=oq[2])
     for a, b in list(zip(rq, oq)) + list(zip(rt, ot)):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
