@@ -50,6 +50,10 @@ __device__ __forceinline__ float fast_log2_p(float x, const float* __restrict__ 
 enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };
 
 __global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
+  // R[20][20] is read 400 times per column with wave-uniform indices: stage it in LDS (broadcast reads)
+  __shared__ float sR[400];
+  for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
+  __syncthreads();
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.n_cols) return;
   const float* raw = a.raw + (size_t)c * RAW_DW;
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
       if (a.pcm == 0) {
         P[aa] = f[aa];
       } else {
-        const float* Ra = a.R + aa * 20;
+        const float* Ra = sR + aa * 20;
         float g = f[0] * Ra[0];  // ScalarProd20(R[a], f[i]): tj[0]*qi[0] + tj[1]*qi[1] + ... left to right
 #pragma unroll
         for (int b = 1; b < 20; ++b) g = g + f[b] * Ra[b];
@@ -126,7 +130,21 @@ __global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
   // ---- CalculateAminoAcidBackground (:1854-1868): 20 independent sequential sums over the columns
   if (lane < 20) {
     float pav = a.pb[lane] * 100.0f / a.neff_hmm[k];
-    for (int i = 1; i <= L; ++i) pav += a.p_tmp[(size_t)(c0 + i) * 20 + lane];
+    const float* col = a.p_tmp + (size_t)(c0 + 1) * 20 + lane;
+    int i = 1;
+    // the additions are strictly sequential (fp32 order of the reference); the loads are batched ahead of them
+    for (; i + 7 <= L; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)u * 20];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pav += v[u];
+      col += 8 * 20;
+    }
+    for (; i <= L; ++i) {
+      pav += *col;
+      col += 20;
+    }
     s_pav[lane] = pav;
   }
   __syncthreads();
@@ -161,24 +179,26 @@ __global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
     if (lane == REC_META) v = __builtin_bit_cast(float, META_HDR);
     hdr[lane] = v;
   }
-  for (int64_t e = lane; e < (int64_t)L * REC_DW; e += LANES) {
-    const int j = (int)(e / REC_DW) + 1;
-    const int w = (int)(e - (int64_t)(j - 1) * REC_DW);
-    float v;
-    if (w < 20) {
-      v = a.p_tmp[(size_t)(c0 + j) * 20 + w] / s_pnul[w];
-    } else if (w < REC_META) {
-      // [20..24] tr[j-1][M2M,M2D,D2M,D2D,I2M], [25..26] tr[j][I2I,M2I]
-      const int src_col = (w <= REC_I2M) ? j - 1 : j;
-      const int slot = (w == REC_M2M) ? T_M2M : (w == REC_M2D) ? T_M2D : (w == REC_D2M) ? T_D2M
-                     : (w == REC_D2D) ? T_D2D : (w == REC_I2M) ? T_I2M : (w == REC_I2I) ? T_I2I : T_M2I;
-      v = a.tr_tmp[(size_t)(c0 + src_col) * 8 + slot];
-    } else {
-      int32_t meta = j | (__builtin_bit_cast(int32_t, a.raw[(size_t)(c0 + j) * RAW_DW + RAW_SS]) & 0x01FF0000);
-      if (j == L) meta |= META_LAST;
-      v = __builtin_bit_cast(float, meta);
+  // two records per iteration: lanes 0..27 -> column j, lanes 32..59 -> column j+1
+  const int w = lane & 31;
+  if (w < REC_DW) {
+    for (int j = 1 + (lane >> 5); j <= L; j += 2) {
+      float v;
+      if (w < 20) {
+        v = a.p_tmp[(size_t)(c0 + j) * 20 + w] / s_pnul[w];
+      } else if (w < REC_META) {
+        // [20..24] tr[j-1][M2M,M2D,D2M,D2D,I2M], [25..26] tr[j][I2I,M2I]
+        const int src_col = (w <= REC_I2M) ? j - 1 : j;
+        const int slot = (w == REC_M2M) ? T_M2M : (w == REC_M2D) ? T_M2D : (w == REC_D2M) ? T_D2M
+                       : (w == REC_D2D) ? T_D2D : (w == REC_I2M) ? T_I2M : (w == REC_I2I) ? T_I2I : T_M2I;
+        v = a.tr_tmp[(size_t)(c0 + src_col) * 8 + slot];
+      } else {
+        int32_t meta = j | (__builtin_bit_cast(int32_t, a.raw[(size_t)(c0 + j) * RAW_DW + RAW_SS]) & 0x01FF0000);
+        if (j == L) meta |= META_LAST;
+        v = __builtin_bit_cast(float, meta);
+      }
+      a.records[(size_t)(c0 + j) * REC_DW + w] = v;
     }
-    a.records[(size_t)(c0 + j) * REC_DW + w] = v;
   }
 }
 
