@@ -527,6 +527,71 @@ int hho_prepare(int role, int L, const float *f, const float *tr, const float *n
   return 0;
 }
 
+/* ---- prefilter kernels -------------------------------------------------------------------------------------- */
+static inline int sat_add8(int a, int b) { return a + b > 255 ? 255 : a + b; }
+static inline int sat_sub8(int a, int b) { return a - b < 0 ? 0 : a - b; }
+static inline int imax2(int a, int b) { return a > b ? a : b; }
+
+/* src/hhprefilter.cpp:214-278: along every diagonal S = max(0, min(255, S + q(i,x_j)) - offset); the padding
+ * positions of the striped profile only carry values forward and never create a new maximum */
+int hho_ungapped_score(const unsigned char *profile, int Lq, const unsigned char *seq, int Ldb, int score_offset) {
+  int smax = 0;
+  unsigned char *prev = (unsigned char *)calloc((size_t)Lq + 1, 1), *cur = (unsigned char *)calloc((size_t)Lq + 1, 1);
+  for (int j = 0; j < Ldb; ++j) {
+    const unsigned char *q = profile + (size_t)seq[j] * Lq;
+    for (int i = 0; i < Lq; ++i) {
+      const int diag = i ? prev[i - 1] : 0;
+      const int s = sat_sub8(sat_add8(diag, q[i]), score_offset);
+      cur[i] = (unsigned char)s;
+      smax = imax2(smax, s);
+    }
+    unsigned char *t = prev;
+    prev = cur;
+    cur = t;
+  }
+  free(prev);
+  free(cur);
+  return smax;
+}
+
+/* src/hhprefilter.cpp:70-212, restated position by position (p = query position):
+ *   base   = max(0, min(255, H(p-1, j-1) + q(p, x_j)) - bias)
+ *   Hpre   = max(base, E(p, j), Fin(p))        Fin: F chain restarted at every stripe segment start (p % W == 0)
+ *   E(p, j+1) = max(E(p,j) - ge, Hpre - go)    (NOT from the lazy-F corrected H, :171 comment of the reference)
+ *   H(p, j)   = max(Hpre, Ffull(p))            Ffull: the F chain over the whole column (the lazy-F loop)
+ * all with unsigned saturation; the result is the maximum H. */
+int hho_sw_score(const unsigned char *profile, int Lq, const unsigned char *seq, int Ldb, int gap_init, int gap_extend,
+                 int bias, int vec_bytes) {
+  const int W = (Lq + vec_bytes - 1) / vec_bytes;
+  unsigned char *Hprev = (unsigned char *)calloc((size_t)Lq + 1, 1), *Hcur = (unsigned char *)calloc((size_t)Lq + 1, 1);
+  unsigned char *E = (unsigned char *)calloc((size_t)Lq + 1, 1);
+  int best = 0;
+  for (int j = 0; j < Ldb; ++j) {
+    const unsigned char *q = profile + (size_t)seq[j] * Lq;
+    int fin = 0, ffull = 0;
+    for (int p = 0; p < Lq; ++p) {
+      if (p % W == 0) fin = 0;
+      const int diag = p ? Hprev[p - 1] : 0;
+      const int base = sat_sub8(sat_add8(diag, q[p]), bias);
+      const int hpre = imax2(imax2(base, E[p]), fin);
+      const int h = imax2(hpre, ffull);
+      Hcur[p] = (unsigned char)h;
+      best = imax2(best, h);
+      const int hgo = sat_sub8(hpre, gap_init);
+      E[p] = (unsigned char)imax2(sat_sub8(E[p], gap_extend), hgo);
+      fin = imax2(sat_sub8(fin, gap_extend), hgo);
+      ffull = imax2(sat_sub8(ffull, gap_extend), sat_sub8(h, gap_init));
+    }
+    unsigned char *t = Hprev;
+    Hprev = Hcur;
+    Hcur = t;
+  }
+  free(Hprev);
+  free(Hcur);
+  free(E);
+  return best;
+}
+
 double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
                        const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2) {
   struct timespec t0, t1;
