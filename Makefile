@@ -12,7 +12,7 @@ CSRC     := hh-suite_amd/csrc
 LIBDIR   := hh-suite_amd/lib
 OBJDIR   := build/obj
 LIB      := $(LIBDIR)/libhhviterbi_hip.so
-OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_pack.o
+OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_prefilter.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_pack.o
 HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
 
 RUNNER   := $(LIBDIR)/libhhv_runner.so
@@ -22,8 +22,8 @@ all: lib oracle emul
 lib: $(LIB) $(RUNNER)
 
 # C++ host layer above the C ABI (mirror of the reference's ViterbiRunner); plain g++, links only the C ABI
-$(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h include/hhviterbi_hip.h $(LIB)
-	g++ -O2 -std=c++14 -fPIC -shared -Wall -o $@ hh-suite_amd/host/viterbi_runner.cpp -L$(LIBDIR) -lhhviterbi_hip -Wl,-rpath,'$$ORIGIN'
+$(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/prefilter.h include/hhviterbi_hip.h $(LIB)
+	g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared -Wall -Iinclude -o $@ hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/prefilter.cpp -L$(LIBDIR) -lhhviterbi_hip -Wl,-rpath,'$$ORIGIN'
 
 $(OBJDIR)/hhv_kernels.o: $(CSRC)/hhv_kernels.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
@@ -31,6 +31,9 @@ $(OBJDIR)/hhv_kernels.o: $(CSRC)/hhv_kernels.hip $(HDRS)
 $(OBJDIR)/hhv_prep.o: $(CSRC)/hhv_prep.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
+$(OBJDIR)/hhv_prefilter.o: $(CSRC)/hhv_prefilter.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(OBJDIR)/hhv_topk.o: $(CSRC)/hhv_topk.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -606,6 +606,106 @@ int hhv_tset_records_of(hhv_ctx* c, hhv_tset* ts, int32_t k, float* out) {
   return HHV_OK;
 }
 
+// ---- HHblits prefilter kernels (N3) ----------------------------------------------------------------------
+struct hhv_pfdb {
+  hhv_ctx* ctx = nullptr;
+  int32_t n = 0;
+  int64_t total = 0;
+  unsigned char* d_seqs = nullptr;
+  int64_t* d_off = nullptr;
+};
+
+int hhv_prefilter_upload_db(hhv_ctx* c, int32_t n_db, const uint8_t* seqs, const int64_t* offsets, hhv_pfdb** out) {
+  if (!c || !seqs || !offsets || !out || n_db < 1) return fail(HHV_E_ARG, "hhv_prefilter_upload_db: bad argument");
+  *out = nullptr;
+  for (int k = 0; k < n_db; ++k)
+    if (offsets[k + 1] < offsets[k]) return fail(HHV_E_ARG, "hhv_prefilter_upload_db: offsets not monotone at %d", k);
+  const int64_t total = offsets[n_db];
+  for (int64_t b = offsets[0]; b < total; ++b)
+    if (seqs[b] > 219) return fail(HHV_E_ARG, "hhv_prefilter_upload_db: state %d > 219 at byte %lld", seqs[b], (long long)b);
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_pfdb* db = new (std::nothrow) hhv_pfdb();
+  if (!db) return fail(HHV_E_MEMORY, "out of host memory");
+  db->ctx = c;
+  db->n = n_db;
+  db->total = total;
+  if (hipMalloc(&db->d_seqs, (size_t)std::max<int64_t>(total, 1)) != hipSuccess ||
+      hipMalloc(&db->d_off, (size_t)(n_db + 1) * sizeof(int64_t)) != hipSuccess ||
+      hipMemcpy(db->d_seqs, seqs, (size_t)total, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(db->d_off, offsets, (size_t)(n_db + 1) * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+    hhv_prefilter_free_db(db);
+    return fail(HHV_E_MEMORY, "hhv_prefilter_upload_db: device allocation/copy failed");
+  }
+  *out = db;
+  return HHV_OK;
+}
+
+void hhv_prefilter_free_db(hhv_pfdb* db) {
+  if (!db) return;
+  if (db->ctx) (void)hipSetDevice(db->ctx->par.device);
+  dfree(db->d_seqs);
+  dfree(db->d_off);
+  delete db;
+}
+
+int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32_t Lq, int32_t score_offset,
+                         int32_t gapped, int32_t gap_init, int32_t gap_extend, const int32_t* subset, int32_t n_subset,
+                         int32_t* scores) {
+  if (!c || !db || !profile || !scores) return fail(HHV_E_ARG, "hhv_prefilter_scores: null argument");
+  if (db->ctx != c) return fail(HHV_E_ARG, "hhv_prefilter_scores: database belongs to another context");
+  if (Lq < 1) return fail(HHV_E_ARG, "hhv_prefilter_scores: Lq = %d", Lq);
+  const int W = (Lq + 31) / 32;  // 32 unsigned bytes per AVX2 vector of the reference (VECSIZE_INT * 4)
+  const size_t lds = (size_t)220 * W * 32 + (size_t)8 * 3 * W * 32;
+  if (lds > 160 * 1024) return fail(HHV_E_LIMIT, "hhv_prefilter_scores: Lq = %d needs %zu bytes of LDS (limit 160 KiB)", Lq, lds);
+  if (score_offset < 0 || score_offset > 255 || gap_init < 0 || gap_extend < 0)
+    return fail(HHV_E_ARG, "hhv_prefilter_scores: parameter out of range");
+  const int64_t n_jobs = subset ? n_subset : db->n;
+  if (n_jobs < 1) return HHV_OK;
+  if (subset)
+    for (int k = 0; k < n_subset; ++k)
+      if (subset[k] < 0 || subset[k] >= db->n) return fail(HHV_E_ARG, "hhv_prefilter_scores: subset[%d] = %d", k, subset[k]);
+  HIP_TRY(hipSetDevice(c->par.device));
+  unsigned char* d_prof = nullptr;
+  int32_t* d_subset = nullptr;
+  int32_t* d_scores = nullptr;
+  int rc = HHV_OK;
+  if (hipMalloc(&d_prof, (size_t)220 * Lq) != hipSuccess || hipMalloc(&d_scores, (size_t)n_jobs * sizeof(int32_t)) != hipSuccess ||
+      (subset && hipMalloc(&d_subset, (size_t)n_jobs * sizeof(int32_t)) != hipSuccess))
+    rc = fail(HHV_E_MEMORY, "hhv_prefilter_scores: device allocation failed");
+  if (rc == HHV_OK && (hipMemcpyAsync(d_prof, profile, (size_t)220 * Lq, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                       (subset && hipMemcpyAsync(d_subset, subset, (size_t)n_jobs * sizeof(int32_t), hipMemcpyHostToDevice,
+                                                 c->stream) != hipSuccess)))
+    rc = fail(HHV_E_DEVICE, "hhv_prefilter_scores: H2D copy failed");
+  if (rc == HHV_OK) {
+    PrefilterArgs a;
+    a.profile = d_prof;
+    a.seqs = db->d_seqs;
+    a.offsets = db->d_off;
+    a.subset = d_subset;
+    a.scores = d_scores;
+    a.n_jobs = n_jobs;
+    a.Lq = Lq;
+    a.W = W;
+    a.offset = score_offset;
+    a.gap_init = gap_init;
+    a.gap_extend = gap_extend;
+    const int blocks_per_cu = std::max<int>(1, (int)((160 * 1024) / lds));
+    const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_jobs + 7) / 8, (int64_t)c->num_cus * blocks_per_cu));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    const int lr = launch_prefilter(a, gapped != 0, n_blocks, lds, c->stream);
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    if (lr != 0) rc = fail(HHV_E_DEVICE, "prefilter kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
+  }
+  if (rc == HHV_OK && (hipMemcpyAsync(scores, d_scores, (size_t)n_jobs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                       hipStreamSynchronize(c->stream) != hipSuccess))
+    rc = fail(HHV_E_DEVICE, "hhv_prefilter_scores: D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+  dfree(d_prof);
+  dfree(d_subset);
+  dfree(d_scores);
+  return rc;
+}
+
 // ---- binary packed template database (N1) -------------------------------------------------------
 namespace {
 struct DbHeader {

@@ -106,6 +106,17 @@ struct PrepArgs {
 
 int launch_prepare(const PrepArgs& a, int n_templates, void* stream);
 
+struct PrefilterArgs {
+  const unsigned char* profile;  // plain [220][Lq]
+  const unsigned char* seqs;     // concatenated column-state sequences
+  const int64_t* offsets;        // [n_db + 1]
+  const int32_t* subset;         // [n_jobs] sequence ids, or null = all
+  int32_t* scores;               // [n_jobs]
+  int64_t n_jobs;
+  int32_t Lq, W, offset, gap_init, gap_extend;
+};
+int launch_prefilter(const PrefilterArgs& a, bool gapped, int n_blocks, size_t lds_bytes, void* stream);
+
 // launchers implemented in hhv_kernels.hip
 int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
 int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
+    "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
@@ -101,6 +102,11 @@ def load():
     L.hhv_prepare_templates.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(HhvPrepParams), c_float_p, C.POINTER(C.c_void_p)]
     L.hhv_rawset_pav.argtypes = [C.c_void_p, C.c_void_p, c_float_p]
     L.hhv_tset_records_of.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, c_float_p]
+    L.hhv_prefilter_upload_db.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.hhv_prefilter_free_db.argtypes = [C.c_void_p]
+    L.hhv_prefilter_free_db.restype = None
+    L.hhv_prefilter_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_db_write.argtypes = [C.c_char_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p,
                                C.c_void_p, C.c_void_p]
     L.hhv_db_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
@@ -274,6 +280,28 @@ class Context:
         _check(self.lib.hhv_tset_records_of(self.h, ts.h, int(k), out.ctypes.data_as(c_float_p)))
         return out
 
+    def prefilter_upload_db(self, seqs, offsets):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        h = C.c_void_p()
+        _check(self.lib.hhv_prefilter_upload_db(self.h, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, C.byref(h)))
+        return (h, len(offsets) - 1)
+
+    def prefilter_free_db(self, db):
+        self.lib.hhv_prefilter_free_db(db[0])
+
+    def prefilter_scores(self, db, profile, score_offset, gapped=False, gap_init=24, gap_extend=4, subset=None):
+        profile = np.ascontiguousarray(profile, dtype=np.uint8)
+        assert profile.shape[0] == 220
+        n = db[1] if subset is None else len(subset)
+        out = np.zeros(n, dtype=np.int32)
+        sub = None if subset is None else np.ascontiguousarray(subset, dtype=np.int32)
+        _check(self.lib.hhv_prefilter_scores(self.h, db[0], profile.ctypes.data, profile.shape[1], int(score_offset),
+                                             int(bool(gapped)), int(gap_init), int(gap_extend),
+                                             sub.ctypes.data if sub is not None else None, 0 if sub is None else len(sub),
+                                             out.ctypes.data))
+        return out
+
     def db_open(self, path, Ls):
         h = C.c_void_p()
         _check(self.lib.hhv_db_open(self.h, path.encode(), C.byref(h)))
@@ -364,6 +392,17 @@ def load_runner():
                                            C.c_int, C.c_int,
                                            c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _runner.hhvr_prefilter_db.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    _runner.hhvr_prefilter_select_first.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    _runner.hhvr_prefilter_select_second.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _runner.hhvr_prefilter_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    _runner.hhvr_read_context_library.argtypes = [C.c_char_p, C.c_void_p]
+    _runner.hhvr_flog2.argtypes = [C.c_float]
+    _runner.hhvr_flog2.restype = C.c_float
+    _runner.hhvr_fpow2.argtypes = [C.c_float]
+    _runner.hhvr_fpow2.restype = C.c_float
     return _runner
 
 
@@ -394,3 +433,80 @@ def runner_alignment(qp, qtr, tps, ttrs, loc=1, egq=0.0, egt=0.0, shift=-0.03, c
     if m < 0:
         raise HhvError("hhvr_alignment failed: %d: %s" % (m, load().hhv_last_error().decode()))
     return hits[:m], i_s[:m], j_s[:m], st[:m], S[:m]
+
+
+# ---- hhv::Prefilter (host/prefilter.h): HHblits prefilter around the two GPU kernels -------------------------
+PREFILTER_DEFAULTS = dict(gap_open=20, gap_extend=4, score_offset=50, bit_factor=4, smax_thresh=10, min_hits=100,
+                          maxnumdb=20000, evalue_thresh=1000.0, evalue_coarse_thresh=100000.0)
+
+
+def read_context_library(path):
+    """hhv::ReadContextLibrary -> (219, 20) float64 central-column probabilities of a cs219 library file."""
+    out = np.zeros((219, 20), dtype=np.float64)
+    if load_runner().hhvr_read_context_library(str(path).encode(), out.ctypes.data) != 219:
+        raise HhvError("cannot read context library %s" % path)
+    return out
+
+
+def prefilter_profile(q_p, pav, lib, score_offset=50, bit_factor=4):
+    """hhv::PrefilterQueryProfile: q_p (Lq,20) rows p[0..Lq-1], pav (20,), lib (219,20) -> (220, Lq) uint8."""
+    q_p, pav = _f32(q_p), _f32(pav)
+    lib = np.ascontiguousarray(lib, dtype=np.float64)
+    Lq = q_p.shape[0]
+    out = np.zeros((220, Lq), dtype=np.uint8)
+    load_runner().hhvr_prefilter_profile(q_p.ctypes.data, pav.ctypes.data, lib.ctypes.data, Lq, score_offset, bit_factor,
+                                         out.ctypes.data)
+    return out
+
+
+def _prefilter_pars(kw):
+    par = dict(PREFILTER_DEFAULTS)
+    par.update(kw)
+    ipar = np.array([par[k] for k in ("gap_open", "gap_extend", "score_offset", "bit_factor", "smax_thresh", "min_hits",
+                                      "maxnumdb")], dtype=np.int32)
+    dpar = np.array([par["evalue_thresh"], par["evalue_coarse_thresh"]], dtype=np.float64)
+    return ipar, dpar
+
+
+def prefilter_select_first(ungapped, lengths, Lq, **kw):
+    """hhv::Prefilter::SelectFirst (host-only arithmetic): kernel scores -> ids that go on to Smith-Waterman."""
+    ipar, dpar = _prefilter_pars(kw)
+    ungapped = np.ascontiguousarray(ungapped, dtype=np.int32)
+    lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+    out = np.zeros(len(lengths), dtype=np.int32)
+    m = load_runner().hhvr_prefilter_select_first(ungapped.ctypes.data, lengths.ctypes.data, len(lengths), Lq, ipar.ctypes.data,
+                                                  dpar.ctypes.data, out.ctypes.data)
+    return out[:m]
+
+
+def prefilter_select_second(sw, subset, lengths, Lq, **kw):
+    """hhv::Prefilter::SelectSecond (host-only arithmetic): SW scores of subset -> (selected ids, e-values)."""
+    ipar, dpar = _prefilter_pars(kw)
+    sw = np.ascontiguousarray(sw, dtype=np.int32)
+    subset = np.ascontiguousarray(subset, dtype=np.int32)
+    lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+    ids = np.zeros(len(subset), dtype=np.int32)
+    ev = np.zeros(len(subset), dtype=np.float64)
+    m = load_runner().hhvr_prefilter_select_second(sw.ctypes.data, subset.ctypes.data, len(subset), lengths.ctypes.data,
+                                                   len(lengths), Lq, ipar.ctypes.data, dpar.ctypes.data, ids.ctypes.data,
+                                                   ev.ctypes.data)
+    return ids[:m], ev[:m]
+
+
+def prefilter_db(ctx, seqs, offsets, lib, q_p, pav, **kw):
+    """hhv::Prefilter::prefilter_db -> (selected ids in reference order, e-values, number that passed stage 1)."""
+    ipar, dpar = _prefilter_pars(kw)
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    lib = np.ascontiguousarray(lib, dtype=np.float64)
+    q_p, pav = _f32(q_p), _f32(pav)
+    n_db = len(offsets) - 1
+    ids = np.zeros(n_db, dtype=np.int32)
+    ev = np.zeros(n_db, dtype=np.float64)
+    p1 = C.c_int32(0)
+    m = load_runner().hhvr_prefilter_db(ctx.h, n_db, seqs.ctypes.data, offsets.ctypes.data, lib.ctypes.data, q_p.ctypes.data,
+                                        pav.ctypes.data, q_p.shape[0], ipar.ctypes.data, dpar.ctypes.data, ids.ctypes.data,
+                                        ev.ctypes.data, n_db, C.byref(p1))
+    if m < 0:
+        raise HhvError("hhvr_prefilter_db failed: %d: %s" % (m, load().hhv_last_error().decode()))
+    return ids[:m], ev[:m], p1.value

@@ -169,6 +169,21 @@ int hhv_rawset_pav(hhv_ctx* ctx, hhv_rawset* rs, float* pav);
 /* the prepared packed records of template k of a set ((L[k]+1)*28 floats: header + columns), device -> host */
 int hhv_tset_records_of(hhv_ctx* ctx, hhv_tset* ts, int32_t k, float* out);
 
+/* ---- HHblits prefilter kernels ---------------------------------------------------------
+ * Prefilter::ungapped_sse_score / Prefilter::swStripedByte (src/hhprefilter.cpp:214-278, 70-212) of one query
+ * column-state profile against a resident database of column-state (cs219) sequences.
+ *   db:       n_db sequences concatenated, bytes 0..219 (219 = the ANY state), offsets[n_db+1]
+ *   profile:  plain [220][Lq] bytes - the values Prefilter::stripe_query_profile computes (:386-425), before striping
+ *   gapped=0: ungapped score with score_offset;  gapped=1: Smith-Waterman with gap_init (= gap open + extend),
+ *             gap_extend and bias = score_offset, scores identical to the AVX2 build of the reference (32-byte stripes)
+ *   subset:   nullable list of sequence ids (the survivors of the first filter); scores[n_subset or n_db] on the host */
+typedef struct hhv_pfdb hhv_pfdb;
+int hhv_prefilter_upload_db(hhv_ctx* ctx, int32_t n_db, const uint8_t* seqs, const int64_t* offsets, hhv_pfdb** out);
+void hhv_prefilter_free_db(hhv_pfdb* db);
+int hhv_prefilter_scores(hhv_ctx* ctx, hhv_pfdb* db, const uint8_t* profile, int32_t Lq, int32_t score_offset,
+                         int32_t gapped, int32_t gap_init, int32_t gap_extend, const int32_t* subset, int32_t n_subset,
+                         int32_t* scores);
+
 /* Binary packed template database: the record stream plus its length table in one file, so that
  * a search mmaps/reads it straight into HBM instead of parsing and re-packing HMM text per query.
  * File = 64-byte header {magic "HHVPDB01", int32 n, int32 record_dwords (28), int64 n_records, zero pad},

@@ -84,3 +84,142 @@ def test_gpu_prefilter_scores_match_oracle(oracle, seed):
     assert np.array_equal(gap, o_gap[subset])
     c.prefilter_free_db(db)
     c.close()
+
+
+# ---- host side: flog2 / fpow2, context library, query profile, the two selection steps of prefilter_db ------------
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF_CS219 = "/root/reference/data/cs219.lib"
+
+
+def _fixture():
+    d = np.load(os.path.join(GOLD, "cs219_probs.npz"))
+    q = np.load(os.path.join(GOLD, "query_hhm_prepared.npz"))
+    return d["lib"], d["q_profile"], d["pav"], np.ascontiguousarray(q["qp"][:-1])
+
+
+def make_db(prof, n_db, seed):
+    """Column-state database around a byte profile (220, Lq): a third of the sequences follow the best state of a
+    query window with mutation rates 0.15..0.95 and a few indels, the rest is random."""
+    rng = np.random.default_rng(seed)
+    Lq = prof.shape[1]
+    best = prof[:219].argmax(axis=0)
+    lens = rng.integers(20, 500, n_db)
+    offs = np.zeros(n_db + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    seqs = rng.integers(0, 219, offs[-1]).astype(np.uint8)
+    for n in range(0, n_db, 3):
+        mut = rng.uniform(0.15, 0.95)
+        q, t, L = int(rng.integers(0, Lq // 2)), int(rng.integers(0, 10)), lens[n]
+        while t < L and q < Lq:
+            r = rng.random()
+            if r < 0.02:
+                q += int(rng.integers(1, 5))
+            elif r < 0.04:
+                t += int(rng.integers(1, 5))
+            else:
+                if rng.random() > mut:
+                    seqs[offs[n] + t] = best[q]
+                t += 1
+                q += 1
+    seqs[rng.integers(0, len(seqs), 50)] = 219   # the ANY state occurs too
+    return seqs, offs, lens.astype(np.int32)
+
+
+def ref_prefilter_db(ref, qp, pav, seqs, offs, **kw):
+    from pyhhv import capi
+    par = dict(capi.PREFILTER_DEFAULTS)
+    par.update(kw)
+    n_db = len(offs) - 1
+    out = np.zeros(n_db, dtype=np.int32)
+    f = ref.lib.ref_prefilter_db
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                  C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    f.restype = C.c_int
+    m = f(qp.ctypes.data, pav.ctypes.data, qp.shape[0], seqs.ctypes.data, offs.ctypes.data, n_db, 4, par["gap_open"],
+          par["gap_extend"], par["score_offset"], par["bit_factor"], par["evalue_thresh"], par["evalue_coarse_thresh"],
+          par["smax_thresh"], par["min_hits"], par["maxnumdb"], out.ctypes.data, n_db)
+    return out[:m]
+
+
+def test_flog2_fpow2_bitwise(ref):
+    from pyhhv import capi
+    r = capi.load_runner()
+    ref.lib.ref_flog2.argtypes = [C.c_float]
+    ref.lib.ref_flog2.restype = C.c_float
+    ref.lib.ref_fpow2.argtypes = [C.c_float]
+    ref.lib.ref_fpow2.restype = C.c_float
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([np.exp(rng.uniform(-30, 12, 4000)), np.arange(1, 600), [0.0, -1.0, 1.0, 2.0 ** -126]]).astype(np.float32)
+    for x in xs:
+        assert np.float32(r.hhvr_flog2(x)).tobytes() == np.float32(ref.lib.ref_flog2(x)).tobytes(), x
+    for x in np.concatenate([rng.uniform(-140, 140, 4000), np.arange(-60, 3)]).astype(np.float32):
+        assert np.float32(r.hhvr_fpow2(x)).tobytes() == np.float32(ref.lib.ref_fpow2(x)).tobytes(), x
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CS219), reason="reference data not present")
+def test_context_library_parser_matches_reference():
+    from pyhhv import capi
+    lib, _, _, _ = _fixture()
+    assert np.array_equal(capi.read_context_library(REF_CS219), lib)
+
+
+def test_query_profile_matches_golden():
+    from pyhhv import capi
+    lib, q_profile, pav, qp = _fixture()
+    got = capi.prefilter_profile(qp, pav, lib, 50, 4)
+    assert got.shape == q_profile.shape and np.array_equal(got, q_profile)
+    assert np.all(got[219] == 49)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_query_profile_matches_reference_live(ref, seed):
+    from pyhhv import capi, synth
+    lib = _fixture()[0]
+    Lq = [17, 64, 250][seed]
+    qp = np.ascontiguousarray(synth.make_query(900 + seed, Lq)[0][:-1])
+    pav = synth.PB.copy()
+    want = np.zeros((220, Lq), dtype=np.uint8)
+    ref.lib.ref_prefilter_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    ref.lib.ref_prefilter_profile(qp.ctypes.data, pav.ctypes.data, Lq, 50 - seed, 4 - seed % 2, want.ctypes.data)
+    assert np.array_equal(capi.prefilter_profile(qp, pav, lib, 50 - seed, 4 - seed % 2), want)
+
+
+SELECT_CASES = [dict(), dict(min_hits=5), dict(min_hits=5, maxnumdb=7), dict(min_hits=30, smax_thresh=40),
+                dict(min_hits=3, evalue_thresh=1e-3, evalue_coarse_thresh=10.0), dict(min_hits=2000)]
+
+
+@pytest.mark.parametrize("case", range(len(SELECT_CASES)))
+def test_selection_steps_match_reference_prefilter_db(oracle, ref, case):
+    """SelectFirst / SelectSecond on the oracle's kernel scores == the reference's whole prefilter_db."""
+    from pyhhv import capi
+    kw = SELECT_CASES[case]
+    lib, prof, pav, qp = _fixture()
+    Lq = qp.shape[0]
+    seqs, offs, lens = make_db(prof, 900, 40 + case)
+    want = ref_prefilter_db(ref, qp, pav, seqs, offs, **kw)
+    n = len(lens)
+    ung = np.array([oracle.lib.hho_ungapped_score(u8(prof), Lq, u8(seqs[offs[k]:offs[k + 1]].copy()), int(lens[k]), 50)
+                    for k in range(n)], dtype=np.int32)
+    subset = capi.prefilter_select_first(ung, lens, Lq, **kw)
+    sw = np.array([oracle.lib.hho_sw_score(u8(prof), Lq, u8(seqs[offs[k]:offs[k + 1]].copy()), int(lens[k]), 24, 4, 50, 32)
+                   for k in subset], dtype=np.int32)
+    ids, ev = capi.prefilter_select_second(sw, subset, lens, Lq, **kw)
+    assert len(want) > 0 and np.array_equal(ids, want)
+    assert len(ev) == len(ids)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(SELECT_CASES)))
+def test_gpu_prefilter_db_matches_reference(ref, case):
+    from pyhhv import capi
+    kw = SELECT_CASES[case]
+    lib, prof, pav, qp = _fixture()
+    seqs, offs, lens = make_db(prof, 3000, 70 + case)
+    want = ref_prefilter_db(ref, qp, pav, seqs, offs, **kw)
+    c = capi.Context()
+    ids, ev, passed1 = capi.prefilter_db(c, seqs, offs, lib, qp, pav, **kw)
+    c.close()
+    assert np.array_equal(ids, want)
+    assert passed1 >= len(ids) and np.all(ev >= 0)
