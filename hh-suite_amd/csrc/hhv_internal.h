@@ -108,14 +108,20 @@ int launch_prepare(const PrepArgs& a, int n_templates, void* stream);
 
 struct PrefilterArgs {
   const unsigned char* profile;  // plain [220][Lq]
-  const unsigned char* seqs;     // concatenated column-state sequences
+  const unsigned char* striped;  // [220][W][32] like the reference's qc (generic kernel without LDS profile), or null
+  const unsigned char* seqs;     // concatenated column-state sequences (4-byte aligned base, padded by 16 bytes)
   const int64_t* offsets;        // [n_db + 1]
   const int32_t* subset;         // [n_jobs] sequence ids, or null = all
-  int32_t* scores;               // [n_jobs]
+  const int32_t* order;          // [n_jobs] job -> slot, longest sequence first, or null
+  int32_t* scores;               // [n_jobs], indexed by slot
   int64_t n_jobs;
   int32_t Lq, W, offset, gap_init, gap_extend;
 };
-int launch_prefilter(const PrefilterArgs& a, bool gapped, int n_blocks, size_t lds_bytes, void* stream);
+// fast kernels: W = cells per lane (ungapped: ceil(Lq/64) <= 8, Smith-Waterman: ceil(Lq/32) <= 16), profile as int8 in LDS
+size_t prefilter_fast_lds(bool gapped, int W);
+int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream);
+// generic kernel: a.W = ceil(Lq/32); prof_lds = striped profile built in LDS, else read from a.striped
+int launch_prefilter_generic(const PrefilterArgs& a, bool gapped, bool prof_lds, int n_blocks, size_t lds_bytes, void* stream);
 
 // launchers implemented in hhv_kernels.hip
 int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);

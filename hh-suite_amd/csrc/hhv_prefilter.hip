@@ -4,49 +4,261 @@
 // for one query column-state profile against a resident database of column-state sequences.
 //
 // The reference vectorises along the QUERY with 32 unsigned bytes per AVX2 register ("striped": vector
-// element k of segment row j is query position k*W + j, W = ceil(Lq/32)).  Here a 32-lane half-wavefront IS
-// that vector: lane k owns the k-th stripe element, one cell per lane per inner iteration, so the recurrence -
-// including the properties that depend on the striping (E is updated before the lazy-F correction, the F
-// chain is restarted per segment in the main loop) - is reproduced by construction, with 32-bit lanes doing
-// the saturating uint8 arithmetic.  The query profile sits striped in LDS (one broadcast-free byte per lane),
-// the H/E columns of each sequence in LDS too; a 256-thread block runs 8 sequences at a time.
+// element k of segment row j is query position k*W + j, W = ceil(Lq/32)).
+//
+//  * Smith-Waterman: a 32-lane half-wavefront IS that vector.  Lane k owns stripe element k and keeps its W cells
+//    of H and E in VGPRs (W is a template parameter, the j loop is unrolled), so the recurrence - including what
+//    depends on the striping: E is updated before the lazy-F correction, the F chain restarts per segment in the
+//    main loop - is reproduced by construction with 32-bit lanes doing the saturating uint8 arithmetic.  The
+//    register shift of the reference (simdi8_shiftl) is one DPP wave_shr.
+//  * The gapless score max_ij S(i,j), S(i,j) = sat(S(i-1,j-1) + q(i,x_j) - offset), does not depend on the striping
+//    at all (each diagonal is an independent saturating chain), so a whole 64-lane wavefront takes one sequence,
+//    W = ceil(Lq/64) cells per lane in VGPRs, the residue x_j is wave-uniform (scalar loads).
+//
+// Both fast kernels keep the query profile in LDS as SIGNED bytes q - offset, lane-major ([state][lane][W padded to
+// 4]), so one ds_read_b32/b64/b128 fetches all W operands of a lane and each cell is add(SDWA byte) + med3 (+ max).
+// They need q - offset to fit int8 and the profile to fit LDS (Lq <= 512); anything else takes the generic kernel
+// (state in LDS, profile in LDS or global), which is the direct transcription of the AVX2 loops.
 #include <hip/hip_runtime.h>
 
 #include "hhv_internal.h"
 
 namespace hhv {
 
-__device__ __forceinline__ int shift_in_half(int v, int k) {
-  // simdi8_shiftl(x, 1): element k <- element k-1, element 0 <- 0 (within the 32-lane half)
-  const int up = __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+// clamp(x, 0, cap) with a wave-uniform cap: one VOP3 (cap rides the constant bus)
+__device__ __forceinline__ int med3i(int x, int cap) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(cap));
+  return r;
+}
+__device__ __forceinline__ int sat_sub(int a, int b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
+__device__ __forceinline__ int sbyte(uint32_t w, int b) { return (int)(signed char)(w >> (8 * b)); }
+
+// whole-wave shift by one lane, lane 0 <- 0
+__device__ __forceinline__ int wave_shr1_zero(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
+// simdi8_shiftl(x, 1) on a 32-lane half: element k <- element k-1, element 0 <- 0
+__device__ __forceinline__ int half_shr1_zero(int v, int k) {
+  const int up = __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
   return k == 0 ? 0 : up;
 }
 
-template <bool GAPPED>
-__global__ void __launch_bounds__(256) hhv_prefilter_kernel(PrefilterArgs a) {
+// profile -> LDS, lane-major signed bytes: word[(x * LANES + k) * WQ + q4] holds cells t = 4*q4 .. 4*q4+3 of lane k,
+// cell t = query position k*W + t; padding cells hold 0 (= the reference's padding value `offset`, minus offset)
+template <int LANES, int W>
+__device__ __forceinline__ void fill_profile_lds(uint32_t* sprof, const PrefilterArgs& a, int nthreads) {
+  constexpr int WQ = (W + 3) / 4;
+  for (int e = threadIdx.x; e < 220 * LANES * WQ; e += nthreads) {
+    const int q4 = e % WQ, k = (e / WQ) % LANES, x = e / (WQ * LANES);
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int t = q4 * 4 + b, pos = k * W + t;
+      const int v = (t < W && pos < a.Lq) ? (int)a.profile[(size_t)x * a.Lq + pos] - a.offset : 0;
+      w |= (uint32_t)(v & 0xff) << (8 * b);
+    }
+    sprof[e] = w;
+  }
+}
+
+template <int WQ>
+__device__ __forceinline__ void read_cells(const uint32_t* p, uint32_t (&w)[WQ]) {
+  if (WQ == 1) {
+    w[0] = p[0];
+  } else if (WQ == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    w[0] = v.x;
+    w[1] = v.y;
+  } else if (WQ == 3) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = p[2];
+  } else {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = v.z;
+    w[3] = v.w;
+  }
+}
+
+// bytes lo..hi-1 of a sequence word are residues, the others belong to the neighbours / the padding: they become the
+// null state 220+1 = PF_NULL whose profile row is all zero (shifts the diagonals, never raises a score)
+constexpr int PF_NULL = 220;
+__device__ __forceinline__ uint32_t mask_word(uint32_t word, int lo, int hi) {
+  const uint32_t keep = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+  return (word & keep) | (0xDCDCDCDCu & ~keep);
+}
+
+// ---- gapless score: one wavefront per sequence ----------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WQ = (W + 3) / 4;
+  uint32_t* sprof = reinterpret_cast<uint32_t*>(smem);
+  fill_profile_lds<64, W>(sprof, a, 1024);
+  for (int e = threadIdx.x; e < 64 * WQ; e += 1024) sprof[PF_NULL * 64 * WQ + e] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int cap = 255 - a.offset;
+  const int wave = blockIdx.x * 16 + (threadIdx.x >> 6), n_waves = gridDim.x * 16;
+  const uint32_t* mine = sprof + lane * WQ;
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(a.seqs);
+
+  for (int64_t job = wave; job < a.n_jobs; job += n_waves) {
+    const int slot = __builtin_amdgcn_readfirstlane(a.order ? a.order[job] : (int)job);
+    const int sid = __builtin_amdgcn_readfirstlane(a.subset ? a.subset[slot] : slot);
+    const int64_t beg = a.offsets[sid], end = a.offsets[sid + 1];
+    // the sequence as aligned dwords w0 .. w0+nw-1; lane l keeps dword (chunk*64 + l), the next chunk is in flight
+    const int64_t w0 = beg >> 2;
+    const int nw = __builtin_amdgcn_readfirstlane((int)(((end + 3) >> 2) - w0));
+    const int head = __builtin_amdgcn_readfirstlane((int)(beg & 3));
+    const int tail = __builtin_amdgcn_readfirstlane((int)(end - ((w0 + nw - 1) << 2)));  // residues in the last word
+    int S[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) S[t] = 0;
+    int vmax = 0;
+    uint32_t chunk_next = words[w0 + max(min(lane, nw - 1), 0)];
+    for (int c0 = 0; c0 < nw; c0 += 64) {
+      const uint32_t chunk = chunk_next;
+      chunk_next = words[w0 + min(c0 + 64 + lane, nw - 1)];
+      const int n_here = min(64, nw - c0);
+      for (int wl = 0; wl < n_here; ++wl) {
+        uint32_t word = __builtin_amdgcn_readlane(chunk, wl);
+        const int wi = c0 + wl;
+        if (wi == 0 || wi == nw - 1) word = mask_word(word, wi == 0 ? head : 0, wi == nw - 1 ? tail : 4);
+        uint32_t p[4][WQ];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) read_cells<WQ>(mine + ((word >> (8 * b)) & 0xff) * (64 * WQ), p[b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int carry = wave_shr1_zero(S[W - 1]);
+#pragma unroll
+          for (int t = W - 1; t >= 1; --t) S[t] = med3i(S[t - 1] + sbyte(p[b][t >> 2], t & 3), cap);
+          S[0] = med3i(carry + sbyte(p[b][0], 0), cap);
+#pragma unroll
+          for (int t = 0; t < W; ++t) vmax = max(vmax, S[t]);
+        }
+      }
+    }
+    for (int o = 32; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0) a.scores[slot] = vmax;
+  }
+}
+
+// ---- striped Smith-Waterman: one 32-lane half per sequence, H and E in registers ---------------------------------
+template <int W>
+__global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WQ = (W + 3) / 4;
+  uint32_t* sprof = reinterpret_cast<uint32_t*>(smem);
+  fill_profile_lds<32, W>(sprof, a, 512);
+  __syncthreads();
+  const int k = threadIdx.x & 31;
+  const int hsel = threadIdx.x & 32;  // which half of the wave
+  const int cap = 255 - a.offset, go = a.gap_init, ge = a.gap_extend;
+  const int64_t half_id = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 5), n_halves = (int64_t)gridDim.x * 16;
+  const uint32_t* mine = sprof + k * WQ;
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(a.seqs);
+
+  for (int64_t job = half_id; job < a.n_jobs; job += n_halves) {
+    const int slot = a.order ? a.order[job] : (int)job;
+    const int sid = a.subset ? a.subset[slot] : slot;
+    const int64_t beg = a.offsets[sid];
+    const int len = (int)(a.offsets[sid + 1] - beg);
+    const int64_t w0 = beg >> 2;
+    const int nw = (int)(((beg + len + 3) >> 2) - w0);
+    const int head = (int)(beg & 3);
+    int H[W], E[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) H[t] = E[t] = 0;
+    int vmax = 0;
+    // element k of the half keeps dword (chunk*32 + k) of the sequence, the next chunk is in flight
+    uint32_t chunk = 0, chunk_next = words[w0 + min(k, max(nw - 1, 0))];
+    for (int i = 0; i < len; ++i) {
+      const int bpos = head + i;  // byte position relative to word w0
+      if ((bpos & 127) == 0 || i == 0) {
+        chunk = chunk_next;
+        chunk_next = words[w0 + min((bpos >> 7) * 32 + 32 + k, max(nw - 1, 0))];
+      }
+      const uint32_t word = (uint32_t)__shfl((int)chunk, (bpos >> 2) & 31, 32);
+      const int x = (word >> (8 * (bpos & 3))) & 0xff;
+      uint32_t p[WQ];
+      read_cells<WQ>(mine + x * (32 * WQ), p);
+      int F = 0;
+      int h = half_shr1_zero(H[W - 1], k);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        h = med3i(h + sbyte(p[j >> 2], j & 3), cap);  // adds(H, profile), subs(H, bias)
+        h = max(max(h, E[j]), F);
+        vmax = max(vmax, h);
+        const int old = H[j];
+        H[j] = h;
+        const int t = sat_sub(h, go);
+        E[j] = max(sat_sub(E[j], ge), t);
+        F = max(sat_sub(F, ge), t);
+        h = old;
+      }
+      // lazy-F loop (:176-203); a half leaves it for good as soon as none of its 32 elements needs a correction
+      F = half_shr1_zero(F, k);
+      bool active = true;
+      for (;;) {
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          if (!done) {
+            const bool need = sat_sub(F, sat_sub(H[j], go)) != 0;
+            const bool any = ((__ballot(need && active) >> hsel) & 0xFFFFFFFFull) != 0;
+            active = active && any;
+            if (__ballot(active) == 0) {
+              done = true;
+            } else if (active) {
+              H[j] = max(H[j], F);
+              vmax = max(vmax, H[j]);
+              F = sat_sub(F, ge);
+            }
+          }
+        }
+        if (done) break;
+        const int Fs = half_shr1_zero(F, k);
+        if (active) F = Fs;
+      }
+    }
+    for (int o = 16; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o, 32));
+    if (k == 0) a.scores[slot] = vmax;
+  }
+}
+
+// ---- generic kernel: H/E columns in LDS, profile striped like the reference in LDS or global --------------------
+template <bool GAPPED, bool PROF_LDS>
+__global__ void __launch_bounds__(256) hhv_pf_generic_kernel(PrefilterArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W;
-  const int lane = threadIdx.x & 63;
-  const int k = threadIdx.x & 31;        // stripe element
-  const int half = threadIdx.x >> 5;     // 0..7: sequence slot inside the block
-  unsigned char* sprof = smem;                                   // [220][W][32]
-  unsigned char* state = smem + (size_t)220 * W * 32 + (size_t)half * 3 * W * 32;
-  // stripe the plain [220][Lq] profile exactly like Prefilter::stripe_query_profile (:386-425)
-  for (int e = threadIdx.x; e < 220 * W * 32; e += 256) {
-    const int kk = e & 31, j = (e >> 5) % W, x = (e >> 5) / W;
-    const int p = kk * W + j;
-    sprof[e] = (p >= a.Lq) ? (unsigned char)a.offset : a.profile[(size_t)x * a.Lq + p];
+  const int k = threadIdx.x & 31;     // stripe element
+  const int half = threadIdx.x >> 5;  // 0..7: sequence slot inside the block
+  unsigned char* sprof = smem;        // [220][W][32] when PROF_LDS
+  unsigned char* state = smem + (PROF_LDS ? (size_t)220 * W * 32 : 0) + (size_t)half * 3 * W * 32;
+  if (PROF_LDS) {
+    // stripe the plain [220][Lq] profile exactly like Prefilter::stripe_query_profile (:386-425)
+    for (int e = threadIdx.x; e < 220 * W * 32; e += 256) {
+      const int kk = e & 31, j = (e >> 5) % W, x = (e >> 5) / W;
+      const int p = kk * W + j;
+      sprof[e] = (p >= a.Lq) ? (unsigned char)a.offset : a.profile[(size_t)x * a.Lq + p];
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  const unsigned char* prof = PROF_LDS ? sprof : a.striped;
   const int go = a.gap_init, ge = a.gap_extend, bias = a.offset;
-  (void)lane;
 
-  for (int64_t slot = (int64_t)blockIdx.x * 8 + half; slot < a.n_jobs; slot += (int64_t)gridDim.x * 8) {
-    const int sid = a.subset ? a.subset[slot] : (int)slot;
+  for (int64_t job = (int64_t)blockIdx.x * 8 + half; job < a.n_jobs; job += (int64_t)gridDim.x * 8) {
+    const int slot = a.order ? a.order[job] : (int)job;
+    const int sid = a.subset ? a.subset[slot] : slot;
     const unsigned char* seq = a.seqs + a.offsets[sid];
     const int len = (int)(a.offsets[sid + 1] - a.offsets[sid]);
-    unsigned char* Ha = state;               // pvHStore
-    unsigned char* Hb = state + W * 32;      // pvHLoad
+    unsigned char* Ha = state;           // pvHStore
+    unsigned char* Hb = state + W * 32;  // pvHLoad
     unsigned char* E = state + 2 * W * 32;
     for (int j = 0; j < W; ++j) {
       Ha[j * 32 + k] = 0;
@@ -55,10 +267,10 @@ __global__ void __launch_bounds__(256) hhv_prefilter_kernel(PrefilterArgs a) {
     }
     int vmax = 0;
     for (int i = 0; i < len; ++i) {
-      const unsigned char* P = sprof + (size_t)seq[i] * W * 32;
+      const unsigned char* P = prof + (size_t)seq[i] * W * 32;
       if (GAPPED) {
         int F = 0;
-        int H = shift_in_half(Ha[(W - 1) * 32 + k], k);
+        int H = half_shr1_zero(Ha[(W - 1) * 32 + k], k);
         unsigned char* t = Hb;  // swap the two H buffers (:129-132)
         Hb = Ha;
         Ha = t;
@@ -79,7 +291,7 @@ __global__ void __launch_bounds__(256) hhv_prefilter_kernel(PrefilterArgs a) {
         // lazy-F loop (:176-203)
         int j = 0;
         H = Ha[k];
-        F = shift_in_half(F, k);
+        F = half_shr1_zero(F, k);
         bool need = max(0, F - max(0, H - go)) != 0;
         while (((__ballot(need) >> (threadIdx.x & 32)) & 0xFFFFFFFFull) != 0) {
           H = max(H, F);
@@ -89,14 +301,14 @@ __global__ void __launch_bounds__(256) hhv_prefilter_kernel(PrefilterArgs a) {
           ++j;
           if (j >= W) {
             j = 0;
-            F = shift_in_half(F, k);
+            F = half_shr1_zero(F, k);
           }
           H = Ha[j * 32 + k];
           need = max(0, F - max(0, H - go)) != 0;
         }
       } else {
         // ungapped (:246-274): s_curr = Ha, s_prev = Hb
-        int S = shift_in_half(Ha[(W - 1) * 32 + k], k);
+        int S = half_shr1_zero(Ha[(W - 1) * 32 + k], k);
         unsigned char* t = Hb;
         Hb = Ha;
         Ha = t;
@@ -115,16 +327,47 @@ __global__ void __launch_bounds__(256) hhv_prefilter_kernel(PrefilterArgs a) {
   }
 }
 
-int launch_prefilter(const PrefilterArgs& a, bool gapped, int n_blocks, size_t lds_bytes, void* stream) {
-  if (gapped) {
-    (void)hipFuncSetAttribute((const void*)hhv_prefilter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(hhv_prefilter_kernel<true>, dim3(n_blocks), dim3(256), lds_bytes, (hipStream_t)stream, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)hhv_prefilter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(hhv_prefilter_kernel<false>, dim3(n_blocks), dim3(256), lds_bytes, (hipStream_t)stream, a);
-  }
-  hipError_t e = hipGetLastError();
+// ---- launchers ----------------------------------------------------------------------------------------------------
+template <typename K>
+static int launch_one(K kernel, const PrefilterArgs& a, int n_blocks, int threads, size_t lds, void* stream) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(threads), lds, (hipStream_t)stream, a);
+  const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
+}
+
+size_t prefilter_fast_lds(bool gapped, int W) { return (size_t)(gapped ? 220 * 32 : 221 * 64) * ((W + 3) / 4) * 4; }
+
+int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream) {
+  const size_t lds = prefilter_fast_lds(gapped, W);
+  if (!gapped) {
+    switch (W) {
+#define HHV_PF_CASE(w) \
+  case w:              \
+    return launch_one(hhv_pf_ungapped_kernel<w>, a, n_blocks, 1024, lds, stream);
+      HHV_PF_CASE(1) HHV_PF_CASE(2) HHV_PF_CASE(3) HHV_PF_CASE(4) HHV_PF_CASE(5) HHV_PF_CASE(6) HHV_PF_CASE(7) HHV_PF_CASE(8)
+#undef HHV_PF_CASE
+    }
+    return -(int)hipErrorInvalidValue;
+  }
+  switch (W) {
+#define HHV_PF_CASE(w) \
+  case w:              \
+    return launch_one(hhv_pf_sw_kernel<w>, a, n_blocks, 512, lds, stream);
+    HHV_PF_CASE(1) HHV_PF_CASE(2) HHV_PF_CASE(3) HHV_PF_CASE(4) HHV_PF_CASE(5) HHV_PF_CASE(6) HHV_PF_CASE(7) HHV_PF_CASE(8)
+    HHV_PF_CASE(9) HHV_PF_CASE(10) HHV_PF_CASE(11) HHV_PF_CASE(12) HHV_PF_CASE(13) HHV_PF_CASE(14) HHV_PF_CASE(15)
+    HHV_PF_CASE(16)
+#undef HHV_PF_CASE
+  }
+  return -(int)hipErrorInvalidValue;
+}
+
+int launch_prefilter_generic(const PrefilterArgs& a, bool gapped, bool prof_lds, int n_blocks, size_t lds, void* stream) {
+  if (gapped)
+    return prof_lds ? launch_one(hhv_pf_generic_kernel<true, true>, a, n_blocks, 256, lds, stream)
+                    : launch_one(hhv_pf_generic_kernel<true, false>, a, n_blocks, 256, lds, stream);
+  return prof_lds ? launch_one(hhv_pf_generic_kernel<false, true>, a, n_blocks, 256, lds, stream)
+                  : launch_one(hhv_pf_generic_kernel<false, false>, a, n_blocks, 256, lds, stream);
 }
 
 }  // namespace hhv
