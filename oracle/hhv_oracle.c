@@ -592,6 +592,311 @@ int hho_sw_score(const unsigned char *profile, int Lq, const unsigned char *seq,
   return best;
 }
 
+/* ==== MAC realignment ======================================================================== */
+enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 }; /* src/hhdecl.h:68 */
+#define MAC_PATHWIDTH 40 /* FWD_BKW_PATHWITDH, src/hhdecl.h:37 */
+
+int hho_mac_celloff(int Lq, int Lt, int par_min_overlap, int vi1, int vj1, int vi2, int vj2, int v_nsteps, const int *v_i,
+                    const int *v_j, int n_prev, const int *prev_off, const int *prev_i, const int *prev_j, unsigned char *mask) {
+  const int pitch = Lt + 1;
+#define CO(i, j) mask[(size_t)(i) * pitch + (j)]
+  memset(mask, 0, (size_t)(Lq + 1) * pitch);
+  /* Viterbi::InitializeForAlignment, two different HMMs (src/hhviterbi.cpp:337-357) */
+  const int lmin = Lq < Lt ? Lq : Lt;
+  int mo;
+  if (par_min_overlap == 0) {
+    mo = (int)(0.333f * lmin) + 1;
+    if (mo > 60) mo = 60;
+  } else {
+    mo = (int)(0.8f * lmin);
+    if (par_min_overlap < mo) mo = par_min_overlap;
+  }
+  for (int i = 0; i < mo; ++i)
+    for (int j = i - mo + Lt + 1; j <= Lt; ++j)
+      if (j >= 0) CO(i, j) = 1;
+  for (int i = Lq - mo + 1; i <= Lq; ++i)
+    for (int j = 1; j < i + mo - Lq; ++j)
+      if (i >= 0 && j <= Lt) CO(i, j) = 1;
+  /* maskViterbiAlignment (src/hhposteriordecoder.cpp:205-240): overwrites every cell 1..Lq x 1..Lt */
+  for (int i = 1; i <= Lq; ++i)
+    for (int j = 1; j <= Lt; ++j) CO(i, j) = !((i < vi1 && j < vj1) || (i > vi2 && j > vj2));
+  for (int step = v_nsteps; step >= 1; --step) {
+    const int lo = v_i[step] - MAC_PATHWIDTH > 1 ? v_i[step] - MAC_PATHWIDTH : 1;
+    const int hi = v_i[step] + MAC_PATHWIDTH < Lq ? v_i[step] + MAC_PATHWIDTH : Lq;
+    for (int i = lo; i <= hi; ++i) CO(i, v_j[step]) = 0;
+  }
+  for (int step = v_nsteps; step >= 1; --step) {
+    const int lo = v_j[step] - MAC_PATHWIDTH > 1 ? v_j[step] - MAC_PATHWIDTH : 1;
+    const int hi = v_j[step] + MAC_PATHWIDTH < Lt ? v_j[step] + MAC_PATHWIDTH : Lt;
+    for (int j = lo; j <= hi; ++j) CO(v_i[step], j) = 0;
+  }
+  /* excludeMACAlignment (:245-262) for every earlier MAC alignment of this template */
+  for (int k = 0; k < n_prev; ++k)
+    for (int s = prev_off[k]; s < prev_off[k + 1]; ++s) {
+      const int i = prev_i[s], j = prev_j[s];
+      for (int ii = (i - 2 > 1 ? i - 2 : 1); ii <= (i + 2 < Lq ? i + 2 : Lq); ++ii) CO(ii, j) = 1;
+      for (int jj = (j - 2 > 1 ? j - 2 : 1); jj <= (j + 2 < Lt ? j + 2 : Lt); ++jj) CO(i, jj) = 1;
+    }
+  for (int j = 0; j <= Lt; ++j) CO(0, j) = 0; /* row/column 0 are never read by the DP */
+  for (int i = 0; i <= Lq; ++i) CO(i, 0) = 0;
+#undef CO
+  return 0;
+}
+
+typedef struct {
+  double mm, gd, im, dg, mi;
+} mac_col; /* PosteriorMatrixCol, src/hhposteriordecoder.h:75-81 */
+
+int hho_mac_forward(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                    float shift, const unsigned char *celloff, float *fwd, double *scale, double *Pforward) {
+  const int pitch = Lt + 1;
+  mac_col *curr = (mac_col *)calloc((size_t)Lt + 3, sizeof(mac_col)), *prev = (mac_col *)calloc((size_t)Lt + 3, sizeof(mac_col));
+  if (!curr || !prev) return -1;
+#define QT(i, a) qtr[(size_t)(i) * 7 + (a)]
+#define TT(j, a) ttr[(size_t)(j) * 7 + (a)]
+#define PF(i, j) hho_dot20_scalar(qp + (size_t)(i) * 20, tp + (size_t)(j) * 20) /* ProbFwd, src/hhhit-inl.h:125 */
+  double pmin = local ? 1.0 : 0.0;
+  const double Cshift = pow(2.0, shift);
+  double scale_prod = 1.0;
+  memset(fwd, 0, sizeof(float) * (size_t)(Lq + 1) * pitch);
+  /* row 1 (:21-41) */
+  curr[0].mm = curr[0].im = curr[0].gd = 0.0;
+  for (int j = 1; j <= Lt; ++j) {
+    if (celloff[pitch + j]) {
+      curr[j].mm = curr[j].mi = curr[j].dg = curr[j].im = curr[j].gd = 0.0;
+    } else {
+      curr[j].mm = PF(1, j) * Cshift;
+      curr[j].mi = curr[j].dg = 0.0;
+      curr[j].im = curr[j - 1].mm * QT(1, T_M2I) * TT(j - 1, T_M2M) + curr[j - 1].im * QT(1, T_I2I) * TT(j - 1, T_M2M);
+      curr[j].gd = curr[j - 1].mm * TT(j - 1, T_M2D) + curr[j - 1].gd * TT(j - 1, T_D2D);
+    }
+  }
+  for (int j = 0; j <= Lt; ++j) {
+    fwd[pitch + j] = (float)curr[j].mm; /* row 0 of p_mm is never read */
+    prev[j] = curr[j];
+  }
+  scale[0] = scale[1] = scale[2] = 1.0;
+  for (int i = 2; i <= Lq; ++i) {
+    if (scale_prod < DBL_MIN * 100)
+      scale_prod = 0.0;
+    else
+      scale_prod *= scale[i];
+    /* first column (:67-83) */
+    if (celloff[(size_t)i * pitch + 1]) {
+      curr[1].mm = curr[1].mi = curr[1].dg = curr[1].im = curr[1].gd = 0.0;
+    } else {
+      curr[1].mm = scale_prod * 1.0f * PF(i, 1) * Cshift; /* fpow2(ScoreSS) = fpow2(0) = 1.0f */
+      curr[1].im = curr[1].gd = 0.0;
+      curr[1].mi = scale[i] * (prev[1].mm * QT(i - 1, T_M2M) * TT(1, T_M2I) + prev[1].mi * QT(i - 1, T_M2M) * TT(1, T_I2I));
+      curr[1].dg = scale[i] * (prev[1].mm * QT(i - 1, T_M2D) + prev[1].dg * QT(i - 1, T_D2D));
+    }
+    double Pmax = 0;
+    memset(curr + 2, 0, (size_t)Lt * sizeof(mac_col));
+    for (int j = 2; j <= Lt; ++j) {
+      if (celloff[(size_t)i * pitch + j]) continue;
+      curr[j].mm = PF(i, j) * Cshift * 1.0f * scale[i] *
+                   (pmin + prev[j - 1].mm * QT(i - 1, T_M2M) * TT(j - 1, T_M2M) + prev[j - 1].gd * QT(i - 1, T_M2M) * TT(j - 1, T_D2M) +
+                    prev[j - 1].im * QT(i - 1, T_I2M) * TT(j - 1, T_M2M) + prev[j - 1].dg * QT(i - 1, T_D2M) * TT(j - 1, T_M2M) +
+                    prev[j - 1].mi * QT(i - 1, T_M2M) * TT(j - 1, T_I2M));
+      curr[j].gd = (curr[j - 1].mm * TT(j - 1, T_M2D) + curr[j - 1].gd * TT(j - 1, T_D2D));
+      curr[j].im = (curr[j - 1].mm * QT(i, T_M2I) * TT(j - 1, T_M2M) + curr[j - 1].im * QT(i, T_I2I) * TT(j - 1, T_M2M));
+      curr[j].dg = scale[i] * (prev[j].mm * QT(i - 1, T_M2D) + prev[j].dg * QT(i - 1, T_D2D));
+      curr[j].mi = scale[i] * (prev[j].mm * QT(i - 1, T_M2M) * TT(j, T_M2I) + prev[j].mi * QT(i - 1, T_M2M) * TT(j, T_I2I));
+      Pmax = fmax(Pmax, curr[j].mm);
+    }
+    for (int j = 0; j <= Lt; ++j) fwd[(size_t)i * pitch + j] = (float)curr[j].mm;
+    mac_col *tmp = prev;
+    prev = curr;
+    curr = tmp;
+    pmin *= scale[i];
+    if (pmin < DBL_MIN * 100) pmin = 0.0;
+    scale[i + 1] = 1.0 / (Pmax + 1.0);
+  }
+  /* total forward probability (:162-182) */
+  double Pf;
+  if (local) {
+    Pf = 1.0;
+    for (int i = 1; i <= Lq; ++i) {
+      for (int j = 1; j <= Lt; ++j) Pf += fwd[(size_t)i * pitch + j];
+      Pf *= scale[i + 1];
+    }
+  } else {
+    Pf = 0.0;
+    for (int i = 1; i < Lq; ++i) Pf = (Pf + fwd[(size_t)i * pitch + Lt] * scale[i + 1]);
+    for (int j = 1; j <= Lt; ++j) Pf += fwd[(size_t)Lq * pitch + j];
+    Pf *= scale[Lq + 1];
+  }
+  *Pforward = Pf;
+  free(curr);
+  free(prev);
+  return 0;
+}
+
+int hho_mac_backward(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                     float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post) {
+  const int pitch = Lt + 1;
+  mac_col *curr = (mac_col *)calloc((size_t)Lt + 3, sizeof(mac_col)), *prev = (mac_col *)calloc((size_t)Lt + 3, sizeof(mac_col));
+  if (!curr || !prev) return -1;
+  const double Cshift = pow(2.0, shift);
+  double scale_prod = scale[Lq + 1];
+  for (int j = Lt; j >= 1; --j) {
+    float *pv = post + (size_t)Lq * pitch + j;
+    if (celloff[(size_t)Lq * pitch + j]) {
+      *pv = 0.0f;
+      prev[j].mm = 0.0;
+    } else {
+      prev[j].mm = scale[Lq + 1];
+      *pv = (float)(*pv * scale[Lq + 1] / Pforward);
+    }
+    prev[j].mi = prev[j].dg = 0.0;
+  }
+  double pmin = local ? scale[Lq + 1] : 0.0;
+  for (int i = Lq - 1; i >= 1; --i) {
+    scale_prod *= scale[i + 1];
+    if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
+    float *row = post + (size_t)i * pitch;
+    if (celloff[(size_t)i * pitch + Lt]) {
+      row[Lt] = 0.0f;
+      curr[Lt].mm = 0.0;
+    } else {
+      curr[Lt].mm = scale_prod;
+      row[Lt] = (float)(row[Lt] * scale_prod / Pforward);
+    }
+    pmin *= scale[i + 1];
+    if (pmin < DBL_MIN * 100) pmin = 0.0;
+    curr[Lt].im = curr[Lt].mi = curr[Lt].dg = curr[Lt].gd = 0.0;
+    if (Lt > 1) memset(curr + 1, 0, (size_t)(Lt - 1) * sizeof(mac_col));
+    for (int j = Lt - 1; j >= 1; --j) {
+      if (celloff[(size_t)i * pitch + j]) continue;
+      const double pmatch = prev[j + 1].mm * PF(i + 1, j + 1) * 1.0f * Cshift * scale[i + 1];
+      curr[j].mm = (+pmin + pmatch * QT(i, T_M2M) * TT(j, T_M2M) + curr[j + 1].gd * TT(j, T_M2D) +
+                    curr[j + 1].im * QT(i, T_M2I) * TT(j, T_M2M) + prev[j].dg * QT(i, T_M2D) * scale[i + 1] +
+                    prev[j].mi * QT(i, T_M2M) * TT(j, T_M2I) * scale[i + 1]);
+      curr[j].gd = (+pmatch * QT(i, T_M2M) * TT(j, T_D2M) + curr[j + 1].gd * TT(j, T_D2D));
+      curr[j].im = (+pmatch * QT(i, T_I2M) * TT(j, T_M2M) + curr[j + 1].im * QT(i, T_I2I) * TT(j, T_M2M));
+      curr[j].dg = (+pmatch * QT(i, T_D2M) * TT(j, T_M2M) + prev[j].dg * QT(i, T_D2D) * scale[i + 1]);
+      curr[j].mi = (+pmatch * QT(i, T_M2M) * TT(j, T_I2M) + prev[j].mi * QT(i, T_M2M) * TT(j, T_I2I) * scale[i + 1]);
+    }
+    /* multiplyPosteriorValue takes a float: F (float) * (float)(B / Pforward) (:122-124, hhposteriormatrix.h:43) */
+    for (int j = 1; j <= Lt - 1; ++j) row[j] *= (float)(curr[j].mm / Pforward);
+    mac_col *tmp = prev;
+    prev = curr;
+    curr = tmp;
+  }
+  free(curr);
+  free(prev);
+  return 0;
+}
+#undef QT
+#undef TT
+#undef PF
+
+enum { MAC_STOP = 0, MAC_MM = 2, MAC_IM = 4, MAC_MI = 6 }; /* ViterbiMatrix::STOP/MM/IM/MI, src/hhviterbimatrix.h */
+
+int hho_mac_dp(const float *post, const unsigned char *celloff, int Lq, int Lt, int local, float mact, unsigned char *bmm,
+               int *i2, int *j2) {
+  const int pitch = Lt + 1;
+  float *S_prev = (float *)calloc((size_t)Lt + 2, sizeof(float)), *S_curr = (float *)calloc((size_t)Lt + 2, sizeof(float));
+  if (!S_prev || !S_curr) return -1;
+  float score_MAC = -FLT_MAX;
+  *i2 = *j2 = 0;
+  memset(bmm, 0, (size_t)(Lq + 1) * pitch);
+  bmm[0] = MAC_STOP;
+  for (int i = 1; i <= Lq; ++i) {
+    const int jmax = Lt; /* hit.min_overlap = 0 (:54): jmin = 1, jmax = t.L */
+    S_curr[0] = 0.0;
+    for (int j = 1; j <= Lt; ++j) {
+      if (celloff[(size_t)i * pitch + j]) {
+        S_curr[j] = -FLT_MIN;
+        bmm[(size_t)i * pitch + j] = MAC_STOP;
+        continue;
+      }
+      const float p = post[(size_t)i * pitch + j];
+      const float term1 = p - mact;
+      const float term2 = S_prev[j - 1] + p - mact;
+      const float term3 = (float)(S_prev[j] - 0.5 * mact);
+      const float term4 = (float)(S_curr[j - 1] - 0.5 * mact);
+      float mxv;
+      unsigned char val;
+      if (term1 > term2) {
+        mxv = term1;
+        val = MAC_STOP;
+      } else {
+        mxv = term2;
+        val = MAC_MM;
+      }
+      if (term3 > mxv) {
+        mxv = term3;
+        val = MAC_MI;
+      }
+      if (term4 > mxv) {
+        mxv = term4;
+        val = MAC_IM;
+      }
+      S_curr[j] = mxv;
+      bmm[(size_t)i * pitch + j] = val;
+      if (mxv > score_MAC && (local || i == Lq)) {
+        *i2 = i;
+        *j2 = j;
+        score_MAC = mxv;
+      }
+    }
+    if (!local && S_curr[jmax] > score_MAC) {
+      *i2 = i;
+      *j2 = jmax;
+      score_MAC = S_curr[jmax];
+    }
+    for (int j = 0; j <= Lt; ++j) S_prev[j] = S_curr[j];
+  }
+  free(S_prev);
+  free(S_curr);
+  return 0;
+}
+
+int hho_mac_backtrace(unsigned char *bmm, const float *post, const float *qp, const float *tp, int Lq, int Lt, int i2, int j2,
+                      int *i_steps, int *j_steps, signed char *states, float *S, float *P, int *nsteps, int *matched_cols,
+                      float *sum_of_probs) {
+  const int pitch = Lt + 1;
+  for (int i = 0; i <= Lq; ++i) bmm[(size_t)i * pitch + 1] = MAC_STOP; /* :124-125 */
+  for (int j = 1; j <= Lt; ++j) bmm[pitch + j] = MAC_STOP;
+  int matched = 1, step = 0, i = i2, j = j2, state = MAC_MM;
+  if (bmm[(size_t)i * pitch + j] != MAC_MM) {
+    step = 0;
+    i_steps[0] = i;
+    j_steps[0] = j;
+  } else {
+    while (state != MAC_STOP) {
+      step++;
+      states[step] = (signed char)(state = bmm[(size_t)i * pitch + j]);
+      i_steps[step] = i;
+      j_steps[step] = j;
+      if (state == MAC_MM) matched++;
+      switch (state) {
+        case MAC_MM: i--; j--; break;
+        case MAC_IM: j--; break;
+        case MAC_MI: i--; break;
+        case MAC_STOP: break;
+        default: state = 0; break;
+      }
+    }
+  }
+  states[step] = MAC_MM;
+  *nsteps = step;
+  *matched_cols = matched;
+  float sum = 0.0f;
+  for (int s = 1; s <= step; ++s) {
+    if (states[s] == MAC_MM) {
+      S[s] = hho_fast_log2(hho_dot20_scalar(qp + (size_t)i_steps[s] * 20, tp + (size_t)j_steps[s] * 20));
+      P[s] = post[(size_t)i_steps[s] * pitch + j_steps[s]];
+      sum += P[s]; /* t.nss_dssp < 0: every aligned pair counts (:224) */
+    } else {
+      S[s] = P[s] = 0.0f;
+    }
+  }
+  *sum_of_probs = sum;
+  return 0;
+}
+
 double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
                        const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2) {
   struct timespec t0, t1;

@@ -93,6 +93,28 @@ int hho_ungapped_score(const unsigned char *profile, int Lq, const unsigned char
 int hho_sw_score(const unsigned char *profile, int Lq, const unsigned char *seq, int Ldb, int gap_init, int gap_extend,
                  int bias, int vec_bytes);
 
+/* ---- MAC realignment: PosteriorDecoder::realign, src/hhposteriordecoder.cpp:86-119 -----------------
+ * Inputs are the prepared p arrays ((L+1)*20) and LINEAR transitions ((L+1)*7, after Log2LinTransitionProbs and the
+ * boundary assignments of initializeQueryHMMTransitions / initializeForAlignment); matrices are (Lq+1)*(Lt+1) row-major.
+ *   hho_mac_celloff   Viterbi::InitializeForAlignment (non-self, src/hhviterbi.cpp:337-357) + maskViterbiAlignment
+ *                     (:205-240) + excludeMACAlignment (:245-262): the cell-off mask realign() builds
+ *   hho_mac_forward   forwardAlgorithm (src/hhforwardalgorithm.cpp:10-160): scaled F_MM as float, scale[Lq+2], Pforward
+ *   hho_mac_backward  backwardAlgorithm (src/hhbackwardalgorithm.cpp:10-135): turns `fwd` into posteriors in place
+ *   hho_mac_dp        macAlgorithm (src/hhmacalgorithm.cpp:18-179): backtrace codes + end point
+ *   hho_mac_backtrace backtraceMAC (src/hhbacktracemac.cpp:113-205): path, per-step S and posterior, sum_of_probs
+ * Secondary-structure scoring is not restated (ssm2 = 0: ScoreSS = 0 and fpow2(0) = 1 exactly). */
+int hho_mac_celloff(int Lq, int Lt, int par_min_overlap, int vi1, int vj1, int vi2, int vj2, int v_nsteps, const int *v_i,
+                    const int *v_j, int n_prev, const int *prev_off, const int *prev_i, const int *prev_j, unsigned char *mask);
+int hho_mac_forward(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                    float shift, const unsigned char *celloff, float *fwd, double *scale, double *Pforward);
+int hho_mac_backward(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                     float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post);
+int hho_mac_dp(const float *post, const unsigned char *celloff, int Lq, int Lt, int local, float mact, unsigned char *bmm,
+               int *i2, int *j2);
+int hho_mac_backtrace(unsigned char *bmm, const float *post, const float *qp, const float *tp, int Lq, int Lt, int i2, int j2,
+                      int *i_steps, int *j_steps, signed char *states, float *S, float *P, int *nsteps, int *matched_cols,
+                      float *sum_of_probs);
+
 /* Convenience for the CPU baseline ("port" kind): N templates, score/i2/j2 only, OpenMP over
  * templates.  Returns wall seconds. */
 double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,

@@ -415,3 +415,108 @@ def have_ref():
 
 def have_oracle():
     return os.path.exists(ORACLE_SO)
+
+
+# ---- MAC realignment ------------------------------------------------------------------------
+class MacOut:
+    pass
+
+
+def _mac_buffers(Lq, Lt):
+    o = MacOut()
+    n = (Lq + 1, Lt + 1)
+    o.q_tr_lin = np.zeros((Lq + 1, 7), np.float32)
+    o.t_tr_lin = np.zeros((Lt + 1, 7), np.float32)
+    o.celloff = np.zeros(n, np.uint8)
+    o.forward = np.zeros(n, np.float32)
+    o.posterior = np.zeros(n, np.float32)
+    o.bmm = np.zeros(n, np.uint8)
+    o.scale = np.zeros(Lq + 2, np.float64)
+    o.Pforward = C.c_double()
+    o.scalars = np.zeros(6, np.int32)
+    o.sum_of_probs = C.c_float()
+    cap = Lq + Lt + 2
+    o.i_steps = np.zeros(cap, np.int32)
+    o.j_steps = np.zeros(cap, np.int32)
+    o.states = np.zeros(cap, np.int8)
+    o.S = np.zeros(cap, np.float32)
+    o.P = np.zeros(cap, np.float32)
+    return o
+
+
+def _mac_finish(o):
+    o.Pforward = o.Pforward.value
+    o.sum_of_probs = np.float32(o.sum_of_probs.value)
+    o.nsteps, o.i1, o.j1, o.i2, o.j2, o.matched_cols = [int(v) for v in o.scalars]
+    return o
+
+
+def _prev_lists(prev):
+    off = np.zeros(len(prev) + 1, np.int32)
+    for k, (a, _) in enumerate(prev):
+        off[k + 1] = off[k] + len(a)
+    pi = np.concatenate([np.asarray(a, np.int32) for a, _ in prev] + [np.zeros(0, np.int32)]).astype(np.int32)
+    pj = np.concatenate([np.asarray(b, np.int32) for _, b in prev] + [np.zeros(0, np.int32)]).astype(np.int32)
+    return off, np.ascontiguousarray(pi), np.ascontiguousarray(pj)
+
+
+def ref_mac_realign(ref, qp, qtr, tp, ttr, vit, local=1, shift=-0.03, mact=0.3501, corr=0.1, min_overlap=0, prev=()):
+    """PosteriorDecoder::realign of the reference on prepared tensors (log2 transitions) and a Viterbi hit `vit`
+    (AlignOut with path).  prev: list of (alt_i, alt_j) of earlier MAC alignments of the same template."""
+    qp, qtr, tp, ttr = _f32(qp), _f32(qtr), _f32(tp), _f32(ttr)
+    Lq, Lt = qp.shape[0] - 1, tp.shape[0] - 1
+    o = _mac_buffers(Lq, Lt)
+    off, pi, pj = _prev_lists(list(prev))
+    ns = vit.nsteps
+    f = ref.lib.ref_mac_realign
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                  C.c_void_p, C.c_void_p] + [C.c_void_p] * 15
+    vi = np.ascontiguousarray(vit.i_steps, np.int32)
+    vj = np.ascontiguousarray(vit.j_steps, np.int32)
+    rc = f(qp.ctypes.data, qtr.ctypes.data, Lq, tp.ctypes.data, ttr.ctypes.data, Lt, int(local), shift, mact, corr,
+           min_overlap, int(vi[ns]), int(vj[ns]), vit.i2, vit.j2, ns, vi.ctypes.data, vj.ctypes.data, len(off) - 1,
+           off.ctypes.data, pi.ctypes.data, pj.ctypes.data, o.q_tr_lin.ctypes.data, o.t_tr_lin.ctypes.data,
+           o.celloff.ctypes.data, o.forward.ctypes.data, o.posterior.ctypes.data, o.bmm.ctypes.data, o.scale.ctypes.data,
+           C.addressof(o.Pforward), o.scalars.ctypes.data, C.addressof(o.sum_of_probs), o.i_steps.ctypes.data,
+           o.j_steps.ctypes.data, o.states.ctypes.data, o.S.ctypes.data, o.P.ctypes.data)
+    assert rc == 0
+    return _mac_finish(o)
+
+
+def oracle_mac_realign(orc, qp, q_tr_lin, tp, t_tr_lin, vit, local=1, shift=-0.03, mact=0.3501, min_overlap=0, prev=()):
+    """The oracle's restatement of realign(): same outputs as ref_mac_realign; transitions are LINEAR here."""
+    qp, q_tr_lin, tp, t_tr_lin = _f32(qp), _f32(q_tr_lin), _f32(tp), _f32(t_tr_lin)
+    Lq, Lt = qp.shape[0] - 1, tp.shape[0] - 1
+    o = _mac_buffers(Lq, Lt)
+    o.q_tr_lin, o.t_tr_lin = q_tr_lin, t_tr_lin
+    off, pi, pj = _prev_lists(list(prev))
+    ns = vit.nsteps
+    vi = np.ascontiguousarray(vit.i_steps, np.int32)
+    vj = np.ascontiguousarray(vit.j_steps, np.int32)
+    L = orc.lib
+    V = C.c_void_p
+    L.hho_mac_celloff.argtypes = [C.c_int] * 8 + [V, V, C.c_int, V, V, V, V]
+    L.hho_mac_forward.argtypes = [V, V, C.c_int, V, V, C.c_int, C.c_int, C.c_float, V, V, V, V]
+    L.hho_mac_backward.argtypes = [V, V, C.c_int, V, V, C.c_int, C.c_int, C.c_float, V, V, C.c_double, V]
+    L.hho_mac_dp.argtypes = [V, V, C.c_int, C.c_int, C.c_int, C.c_float, V, V, V]
+    L.hho_mac_backtrace.argtypes = [V, V, V, V, C.c_int, C.c_int, C.c_int, C.c_int] + [V] * 8
+    assert L.hho_mac_celloff(Lq, Lt, min_overlap, int(vi[ns]), int(vj[ns]), vit.i2, vit.j2, ns, vi.ctypes.data, vj.ctypes.data,
+                             len(off) - 1, off.ctypes.data, pi.ctypes.data, pj.ctypes.data, o.celloff.ctypes.data) == 0
+    assert L.hho_mac_forward(qp.ctypes.data, q_tr_lin.ctypes.data, Lq, tp.ctypes.data, t_tr_lin.ctypes.data, Lt, int(local),
+                             shift, o.celloff.ctypes.data, o.forward.ctypes.data, o.scale.ctypes.data,
+                             C.addressof(o.Pforward)) == 0
+    o.posterior[:] = o.forward
+    assert L.hho_mac_backward(qp.ctypes.data, q_tr_lin.ctypes.data, Lq, tp.ctypes.data, t_tr_lin.ctypes.data, Lt, int(local),
+                              shift, o.celloff.ctypes.data, o.scale.ctypes.data, o.Pforward.value, o.posterior.ctypes.data) == 0
+    i2, j2 = C.c_int(), C.c_int()
+    assert L.hho_mac_dp(o.posterior.ctypes.data, o.celloff.ctypes.data, Lq, Lt, int(local), mact, o.bmm.ctypes.data,
+                        C.addressof(i2), C.addressof(j2)) == 0
+    ns_o, mc = C.c_int(), C.c_int()
+    assert L.hho_mac_backtrace(o.bmm.ctypes.data, o.posterior.ctypes.data, qp.ctypes.data, tp.ctypes.data, Lq, Lt, i2.value,
+                               j2.value, o.i_steps.ctypes.data, o.j_steps.ctypes.data, o.states.ctypes.data, o.S.ctypes.data,
+                               o.P.ctypes.data, C.addressof(ns_o), C.addressof(mc), C.addressof(o.sum_of_probs)) == 0
+    n = ns_o.value
+    o.scalars[:] = [n, o.i_steps[n], o.j_steps[n], i2.value, j2.value, mc.value]
+    return _mac_finish(o)

@@ -1,0 +1,143 @@
+// oracle/ref_mac_harness.cpp -- TEST INFRASTRUCTURE: the reference's MAC realignment
+//   PosteriorDecoder::realign            src/hhposteriordecoder.cpp:86-119
+//     initializeForAlignment / maskViterbiAlignment / excludeMACAlignment   :151-262
+//     forwardAlgorithm   src/hhforwardalgorithm.cpp:10-219
+//     backwardAlgorithm  src/hhbackwardalgorithm.cpp:10-135
+//     macAlgorithm       src/hhmacalgorithm.cpp:18-179
+//     backtraceMAC       src/hhbacktracemac.cpp:113-272
+// run on two prepared HMMs given as tensors (the same p / log2-tr arrays the Viterbi harness takes) and a
+// Viterbi hit (end points + path).  The harness does what PosteriorDecoderRunner::executeComputation does around
+// realign (src/hhposteriordecoderrunner.cpp:43-119): Log2LinTransitionProbs(1.0) on both HMMs,
+// initializeQueryHMMTransitions, and it hands back the linear transitions so that a test can feed the product the
+// very same numbers.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hhposteriordecoder.h"
+#include "hhviterbimatrix.h"
+
+namespace {
+HMM* make_hmm(const float* p, const float* tr_log, int L) {
+  HMM* h = new HMM(MAXSEQDIS, L + 2);
+  h->L = L;
+  for (int i = 0; i <= L; ++i) {
+    for (int a = 0; a < 20; ++a) h->p[i][a] = p[(size_t)i * 20 + a];
+    for (int a = 0; a < 7; ++a) h->tr[i][a] = tr_log[(size_t)i * 7 + a];
+  }
+  h->trans_lin = 0;
+  h->nss_dssp = -1;
+  h->nss_pred = -1;
+  h->mu = 0;
+  return h;
+}
+float zS73[NDSSP][NSSPRED][MAXCF];
+float zS33[NSSPRED][MAXCF][NSSPRED][MAXCF];
+float zS37[NSSPRED][MAXCF][NDSSP];
+}  // namespace
+
+extern "C" {
+
+// n_prev previous MAC alignments of the same template (alt_i/alt_j lists, concatenated; prev_off[n_prev+1])
+int ref_mac_realign(const float* q_p, const float* q_tr_log, int Lq, const float* t_p, const float* t_tr_log, int Lt,
+                    int local, float shift, float mact, float corr, int par_min_overlap,
+                    int vi1, int vj1, int vi2, int vj2, int v_nsteps, const int* v_i, const int* v_j,
+                    int n_prev, const int* prev_off, const int* prev_i, const int* prev_j,
+                    float* q_tr_lin, float* t_tr_lin,             // (L+1)*7 each, as the algorithms saw them
+                    unsigned char* celloff,                        // (Lq+1)*(Lt+1): mask BEFORE forward
+                    float* forward,                                // (Lq+1)*(Lt+1): p_mm after forward (scaled F_MM)
+                    float* posterior,                              // (Lq+1)*(Lt+1): p_mm after backward
+                    unsigned char* bmm,                            // (Lq+1)*(Lt+1): MAC backtrace codes after backtraceMAC
+                    double* scale, double* Pforward,               // Lq+2 ; 1
+                    int* o_scalars /* nsteps,i1,j1,i2,j2,matched_cols */, float* o_sum_of_probs,
+                    int* o_i, int* o_j, char* o_states, float* o_S, float* o_P) {
+  Log::reporting_level() = INFO;
+  HMM* q = make_hmm(q_p, q_tr_log, Lq);
+  HMM* t = make_hmm(t_p, t_tr_log, Lt);
+  q->Log2LinTransitionProbs(1.0);
+  t->Log2LinTransitionProbs(1.0);
+  // PosteriorDecoderRunner::initializeQueryHMMTransitions (src/hhposteriordecoderrunner.cpp:146-155); the runner's
+  // translation unit itself needs the database layer, so its eight assignments are restated here
+  q->tr[0][M2D] = q->tr[0][M2I] = 0.0f;
+  q->tr[0][I2M] = q->tr[0][I2I] = 0.0f;
+  q->tr[0][D2M] = q->tr[0][D2D] = 0.0f;
+  q->tr[Lq][M2M] = 1.0f;
+  q->tr[Lq][M2D] = q->tr[Lq][M2I] = 0.0f;
+  q->tr[Lq][I2M] = q->tr[Lq][I2I] = 0.0f;
+  q->tr[Lq][D2M] = 1.0f;
+  q->tr[Lq][D2D] = 0.0f;
+
+  ViterbiMatrix vm;
+  vm.AllocateBacktraceMatrix(Lq, Lt);
+  PosteriorMatrix pm;
+  pm.allocateMatrix(Lq, Lt);
+  PosteriorDecoder dec(Lt, local != 0, Lq, 0.0f, zS73, zS33, zS37);
+
+  Hit hit;
+  hit.L = Lt;
+  hit.self = 0;
+  hit.ssm1 = hit.ssm2 = 0;
+  hit.i1 = vi1;
+  hit.j1 = vj1;
+  hit.i2 = vi2;
+  hit.j2 = vj2;
+  hit.nsteps = v_nsteps;
+  hit.i = new int[v_nsteps + 2];
+  hit.j = new int[v_nsteps + 2];
+  hit.states = new char[v_nsteps + 2];
+  for (int s = 0; s <= v_nsteps; ++s) {
+    hit.i[s] = v_i[s];
+    hit.j[s] = v_j[s];
+    hit.states[s] = 0;
+  }
+  hit.score = 1.0f;
+  std::vector<std::vector<int> > pi(n_prev), pj(n_prev);
+  std::vector<PosteriorDecoder::MACBacktraceResult> excl;
+  for (int k = 0; k < n_prev; ++k) {
+    pi[k].assign(prev_i + prev_off[k], prev_i + prev_off[k + 1]);
+    pj[k].assign(prev_j + prev_off[k], prev_j + prev_off[k + 1]);
+    excl.push_back(PosteriorDecoder::MACBacktraceResult(&pi[k], &pj[k]));
+  }
+
+  // realign(), split so that the mask can be observed before the DP runs (:92-119)
+  dec.memorizeHitValues(hit);
+  dec.initializeForAlignment(*q, *t, hit, vm, 0, t->L, par_min_overlap);
+  for (size_t k = 0; k < excl.size(); ++k) dec.excludeMACAlignment(q->L, hit.L, vm, 0, excl[k]);
+  for (int i = 0; i <= Lq; ++i)
+    for (int j = 0; j <= Lt; ++j) celloff[(size_t)i * (Lt + 1) + j] = (i >= 1 && j >= 1 && vm.getCellOff(i, j, 0)) ? 1 : 0;
+  for (int i = 0; i <= Lq; ++i)
+    for (int a = 0; a < 7; ++a) q_tr_lin[(size_t)i * 7 + a] = q->tr[i][a];
+  for (int j = 0; j <= Lt; ++j)
+    for (int a = 0; a < 7; ++a) t_tr_lin[(size_t)j * 7 + a] = t->tr[j][a];
+  dec.forwardAlgorithm(*q, *t, hit, pm, vm, shift, 0);
+  *Pforward = hit.Pforward;
+  for (int i = 0; i <= Lq + 1; ++i) scale[i] = dec.scale[i];
+  for (int i = 0; i <= Lq; ++i)
+    for (int j = 0; j <= Lt; ++j) forward[(size_t)i * (Lt + 1) + j] = pm.getPosteriorValue(i, j);
+  dec.backwardAlgorithm(*q, *t, hit, pm, vm, shift, 0);
+  for (int i = 0; i <= Lq; ++i)
+    for (int j = 0; j <= Lt; ++j) posterior[(size_t)i * (Lt + 1) + j] = pm.getPosteriorValue(i, j);
+  dec.macAlgorithm(*q, *t, hit, pm, vm, mact, 0);
+  dec.backtraceMAC(*q, *t, pm, vm, 0, hit, corr);
+  for (int i = 0; i <= Lq; ++i)
+    for (int j = 0; j <= Lt; ++j) bmm[(size_t)i * (Lt + 1) + j] = (unsigned char)vm.getMatMat(i, j, 0);
+  o_scalars[0] = hit.nsteps;
+  o_scalars[1] = hit.i1;
+  o_scalars[2] = hit.j1;
+  o_scalars[3] = hit.i2;
+  o_scalars[4] = hit.j2;
+  o_scalars[5] = hit.matched_cols;
+  *o_sum_of_probs = hit.sum_of_probs;
+  for (int s = 0; s <= hit.nsteps; ++s) {
+    o_i[s] = hit.i[s];
+    o_j[s] = hit.j[s];
+    o_states[s] = hit.states[s];
+    o_S[s] = s >= 1 ? hit.S[s] : 0.0f;
+    o_P[s] = s >= 1 ? hit.P_posterior[s] : 0.0f;
+  }
+  delete q;
+  delete t;
+  return 0;
+}
+
+}  // extern "C"
