@@ -12,7 +12,7 @@ CSRC     := hh-suite_amd/csrc
 LIBDIR   := hh-suite_amd/lib
 OBJDIR   := build/obj
 LIB      := $(LIBDIR)/libhhviterbi_hip.so
-OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_prefilter.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_pack.o
+OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_prefilter.o $(OBJDIR)/hhv_mac.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_pack.o
 HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
 
 RUNNER   := $(LIBDIR)/libhhv_runner.so
@@ -32,6 +32,9 @@ $(OBJDIR)/hhv_prep.o: $(CSRC)/hhv_prep.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
 $(OBJDIR)/hhv_prefilter.o: $(CSRC)/hhv_prefilter.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OBJDIR)/hhv_mac.o: $(CSRC)/hhv_mac.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(OBJDIR)/hhv_topk.o: $(CSRC)/hhv_topk.hip $(HDRS)

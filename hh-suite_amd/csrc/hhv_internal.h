@@ -123,6 +123,40 @@ int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_bloc
 // generic kernel: a.W = ceil(Lq/32); prof_lds = striped profile built in LDS, else read from a.striped
 int launch_prefilter_generic(const PrefilterArgs& a, bool gapped, bool prof_lds, int n_blocks, size_t lds_bytes, void* stream);
 
+// MAC realignment (hhv_mac.hip): one wavefront per hit
+struct DevMacHit {
+  double Pforward;
+  float sum_of_probs;
+  int32_t i1, j1, i2, j2, nsteps, matched_cols, pad;
+};
+struct MacArgs {
+  int32_t n, Lq;
+  const float* q_p;          // [(Lq+1)][20]
+  const float* q_tr;         // [(Lq+1)][7] linear
+  const float* t_p;          // concatenated template columns, [col][20]
+  const float* t_tr;         // [col][7] linear
+  const int64_t* col_off;    // [n] first column (index 0) of hit k
+  const int32_t* Lt;         // [n]
+  const int64_t* mat_off;    // [n] offset of the (Lq+1)*(Lt+1) matrices of hit k
+  const unsigned char* celloff;
+  float* mat;                // F_MM, then posterior
+  unsigned char* bmm;        // MAC backtrace codes
+  double* scale;             // [n][Lq+2]
+  double* Pforward;          // [n]
+  DevMacHit* hits;           // [n]
+  double Cshift;
+  float mact;
+  const int64_t* path_off;   // [n] capacity Lq+Lt+2 each
+  int32_t* path_i;
+  int32_t* path_j;
+  signed char* path_state;
+  float* path_S;
+  float* path_P;
+  const float* lg2;
+  const float* diff;
+};
+int launch_mac(const MacArgs& a, bool local, int max_Lt, void* stream);
+
 // launchers implemented in hhv_kernels.hip
 int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
 int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);

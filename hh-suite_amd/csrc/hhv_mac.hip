@@ -1,0 +1,483 @@
+// hhv_mac.hip -- MAC realignment on MI355X: replaces, for a batch of hits of one query,
+//   PosteriorDecoder::forwardAlgorithm   src/hhforwardalgorithm.cpp:10-182   scaled sum-product forward, F_MM kept as float
+//   PosteriorDecoder::backwardAlgorithm  src/hhbackwardalgorithm.cpp:10-135  backward + posterior = F*B/Pforward
+//   PosteriorDecoder::macAlgorithm       src/hhmacalgorithm.cpp:18-179       maximum-accuracy DP on the posteriors
+//   PosteriorDecoder::backtraceMAC       src/hhbacktracemac.cpp:113-240      path, per-step score and posterior
+//
+// One wavefront per hit.  The reference's arithmetic is double precision with a per-row rescaling
+// (scale[i+1] = 1 / (1 + max_j F_MM(i,j))), so rows are processed one after the other; inside a row
+//   * everything that depends only on the previous row (MM, DG, MI forward; pmatch, DG, MI backward) is computed by
+//     64 lanes for 64 columns at a time, with exactly the reference's expression trees (no FMA contraction);
+//   * the two first-order recurrences ALONG the row (GD and IM) and the running total of Pforward are evaluated in the
+//     reference's sequential order by a 64-step DPP sweep: in step s every lane recomputes y = a + y(lane-1)*b from its
+//     left neighbour (wave_shr:1, lane 0 takes the carry of the previous strip); after step s lanes 0..s are final, and
+//     recomputing a final value from final inputs reproduces it, so no masking is needed.  Rounding is therefore the
+//     reference's, operation for operation - the kernels are bit-exact against it, not just within tolerance.
+// Row state (5 doubles per column, two rows) lives in LDS; F_MM / posteriors (float) and the MAC backtrace codes are
+// matrices in HBM, one per hit.
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+
+#include "hhv_internal.h"
+
+namespace hhv {
+
+namespace {
+
+enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };  // src/hhdecl.h:68
+enum { MAC_STOP = 0, MAC_MM = 2, MAC_IM = 4, MAC_MI = 6 };                              // ViterbiMatrix codes
+
+__device__ __forceinline__ double shr1_d(double y, double carry) {
+  int lo = __double2loint(y), hi = __double2hiint(y);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(carry), lo, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(carry), hi, 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float shr1_f(float y, float carry) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(y), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double lane_d(double y, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), l), __builtin_amdgcn_readlane(__double2loint(y), l));
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double w = __hiloint2double(__shfl_xor(__double2hiint(v), o, 64), __shfl_xor(__double2loint(v), o, 64));
+    v = fmax(v, w);
+  }
+  return v;
+}
+// ScalarProd20 (src/hhhit-inl.h:116-122): plain left-to-right float sum of products
+__device__ __forceinline__ float dot20(const float* __restrict__ q, const float* __restrict__ t) {
+  float r = t[0] * q[0];
+#pragma unroll
+  for (int k = 1; k < 20; ++k) r = r + t[k] * q[k];
+  return r;
+}
+__device__ __forceinline__ float fast_log2_mac(float x, const float* __restrict__ lg2, const float* __restrict__ diff) {
+  if (x <= 0) return -100000;
+  const uint32_t u = __float_as_uint(x);
+  const int aa = (int)((u & 0x7F800000u) >> 23) - 0x7f;
+  const int b = (int)((u & 0x007FE000u) >> 13);
+  const int c = (int)(u & 0x00001FFFu);
+  return ((float)aa + lg2[b]) + diff[b] * (float)c;
+}
+
+struct HitView {
+  int Lq, Lt, pitch;
+  const float* qp;
+  const float* qtr;
+  const float* tp;
+  const float* ttr;
+  const unsigned char* co;
+  float* mat;
+  unsigned char* bmm;
+  double* scale;
+};
+__device__ __forceinline__ HitView view(const MacArgs& a, int k) {
+  HitView v;
+  v.Lq = a.Lq;
+  v.Lt = a.Lt[k];
+  v.pitch = v.Lt + 1;
+  v.qp = a.q_p;
+  v.qtr = a.q_tr;
+  v.tp = a.t_p + a.col_off[k] * 20;
+  v.ttr = a.t_tr + a.col_off[k] * 7;
+  v.co = a.celloff + a.mat_off[k];
+  v.mat = a.mat + a.mat_off[k];
+  v.bmm = a.bmm + a.mat_off[k];
+  v.scale = a.scale + (int64_t)k * (a.Lq + 2);
+  return v;
+}
+
+// LDS row state: field f of row r at column j
+#define ROW(r, f, j) rows[((r)*5 + (f)) * stride + (j)]
+enum { F_MM = 0, F_GD = 1, F_IM = 2, F_DG = 3, F_MI = 4 };
+
+}  // namespace
+
+// ---- forward ------------------------------------------------------------------------------------------------------
+template <bool LOCAL>
+__global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* rows = reinterpret_cast<double*>(smem);
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const HitView h = view(a, k);
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  const double Cshift = a.Cshift;
+  for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
+  for (int e = lane; e < pitch; e += 64) h.mat[e] = 0.0f;  // row 0 of p_mm is never read
+  __syncthreads();
+  int cur = 0;
+  double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0;
+  double Pf = LOCAL ? 1.0 : 0.0;
+  if (lane == 0) h.scale[0] = h.scale[1] = h.scale[2] = 1.0;
+  double scale_i = 1.0;  // scale[i] of the row being computed
+
+  for (int i = 1; i <= Lq; ++i) {
+    const int prv = cur ^ 1;
+    if (i >= 2) {
+      if (scale_prod < DBL_MIN * 100)
+        scale_prod = 0.0;
+      else
+        scale_prod *= scale_i;
+    }
+    const float* qi = h.qp + (size_t)i * 20;
+    const float* qt1 = h.qtr + (size_t)(i - 1) * 7;  // q.tr[i-1]
+    const float* qt = h.qtr + (size_t)i * 7;         // q.tr[i]
+    const double qM2M = qt1[T_M2M], qI2M = qt1[T_I2M], qD2M = qt1[T_D2M], qM2D = qt1[T_M2D], qD2D = qt1[T_D2D];
+    const double qM2I = qt[T_M2I], qI2I = qt[T_I2I];
+    double Pmax = 0.0, carry_mm = 0.0, carry_gd = 0.0, carry_im = 0.0;
+    for (int s0 = 0; s0 < Lt; s0 += 64) {
+      const int j = 1 + s0 + lane;
+      const bool valid = j <= Lt;
+      const int jc = valid ? j : Lt;
+      const bool off = !valid || h.co[(size_t)i * pitch + jc] != 0;
+      const float pf = dot20(qi, h.tp + (size_t)jc * 20);
+      const float* tt1 = h.ttr + (size_t)(jc - 1) * 7;  // t.tr[j-1]
+      const float* tt = h.ttr + (size_t)jc * 7;         // t.tr[j]
+      double mm, dg, mi;
+      if (i == 1) {
+        mm = pf * Cshift;  // :31
+        dg = mi = 0.0;
+      } else {
+        const double pm = ROW(prv, F_MM, jc), pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
+        if (j == 1) {
+          mm = scale_prod * 1.0f * pf * Cshift;  // :71-73, fpow2(ScoreSS) = fpow2(0) = 1.0f
+        } else {
+          const double m1 = ROW(prv, F_MM, jc - 1), g1 = ROW(prv, F_GD, jc - 1), i1 = ROW(prv, F_IM, jc - 1),
+                       d1 = ROW(prv, F_DG, jc - 1), x1 = ROW(prv, F_MI, jc - 1);
+          mm = pf * Cshift * 1.0f * scale_i *
+               (pmin + m1 * qM2M * tt1[T_M2M] + g1 * qM2M * tt1[T_D2M] + i1 * qI2M * tt1[T_M2M] + d1 * qD2M * tt1[T_M2M] +
+                x1 * qM2M * tt1[T_I2M]);  // :94-103
+        }
+        dg = scale_i * (pm * qM2D + pdg * qD2D);                            // :110-112 / :79-81
+        mi = scale_i * (pm * qM2M * tt[T_M2I] + pmi * qM2M * tt[T_I2I]);    // :113-116 / :75-78
+      }
+      if (off) mm = dg = mi = 0.0;
+      if (i >= 2 && j >= 2 && !off) Pmax = fmax(Pmax, mm);
+      // the recurrences along the row (:104-109): gd = mm(j-1)*t[j-1][M2D] + gd(j-1)*t[j-1][D2D],
+      //                                           im = mm(j-1)*q[i][M2I]*t[j-1][M2M] + im(j-1)*q[i][I2I]*t[j-1][M2M]
+      const double mm_left = shr1_d(mm, carry_mm);
+      const bool chain_on = !off && (i == 1 || j >= 2);  // column 1 of rows >= 2: im = gd = 0 (:74)
+      const double a_gd = chain_on ? mm_left * tt1[T_M2D] : 0.0, b_gd = chain_on ? (double)tt1[T_D2D] : 0.0;
+      const double c_im = chain_on ? mm_left * qM2I * tt1[T_M2M] : 0.0, b_im = chain_on ? (double)tt1[T_M2M] : 0.0;
+      const double f_mm = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
+      double gd = 0.0, im = 0.0, acc = 0.0;
+      for (int s = 0; s < 64; ++s) {
+        const double gl = shr1_d(gd, carry_gd), il = shr1_d(im, carry_im);
+        gd = a_gd + gl * b_gd;
+        im = c_im + il * qI2I * b_im;
+        if (LOCAL) acc = shr1_d(acc, Pf) + f_mm;
+      }
+      if (valid) {
+        ROW(cur, F_MM, j) = mm;
+        ROW(cur, F_GD, j) = gd;
+        ROW(cur, F_IM, j) = im;
+        ROW(cur, F_DG, j) = dg;
+        ROW(cur, F_MI, j) = mi;
+        h.mat[(size_t)i * pitch + j] = (float)mm;
+      }
+      carry_mm = lane_d(mm, 63);
+      carry_gd = lane_d(gd, 63);
+      carry_im = lane_d(im, 63);
+      if (LOCAL) Pf = lane_d(acc, 63);
+    }
+    if (lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
+    double scale_next = 1.0;
+    if (i >= 2) {
+      Pmax = wave_max_d(Pmax);
+      pmin *= scale_i;
+      if (pmin < DBL_MIN * 100) pmin = 0.0;
+      scale_next = 1.0 / (Pmax + 1.0);  // :155
+      if (lane == 0) h.scale[i + 1] = scale_next;
+    }
+    __syncthreads();
+    // total forward probability (:162-182)
+    if (LOCAL) {
+      Pf *= scale_next;
+    } else if (i < Lq) {
+      Pf = (Pf + (float)ROW(cur, F_MM, Lt) * scale_next);
+    }
+    scale_i = scale_next;
+    cur = prv;
+  }
+  if (!LOCAL) {
+    // + sum_j F(Lq, j) in column order, then * scale[Lq+1]
+    const int last = cur ^ 1;
+    for (int s0 = 0; s0 < Lt; s0 += 64) {
+      const int j = 1 + s0 + lane;
+      const double f_mm = j <= Lt ? (double)(float)ROW(last, F_MM, j) : 0.0;
+      double acc = 0.0;
+      for (int s = 0; s < 64; ++s) acc = shr1_d(acc, Pf) + f_mm;
+      Pf = lane_d(acc, 63);
+    }
+    Pf *= scale_i;
+  }
+  if (lane == 0) a.Pforward[k] = Pf;
+}
+
+// ---- backward + posterior ---------------------------------------------------------------------------------------------
+template <bool LOCAL>
+__global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* rows = reinterpret_cast<double*>(smem);
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const HitView h = view(a, k);
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  const double Cshift = a.Cshift, Pf = a.Pforward[k];
+  for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
+  __syncthreads();
+  const double sL = h.scale[Lq + 1];
+  int cur = 0;  // row being computed; `prv` holds row i+1
+  // row Lq (:19-29)
+  for (int j = 1 + lane; j <= Lt; j += 64) {
+    float* pv = h.mat + (size_t)Lq * pitch + j;
+    if (h.co[(size_t)Lq * pitch + j]) {
+      *pv = 0.0f;
+      ROW(1, F_MM, j) = 0.0;
+    } else {
+      ROW(1, F_MM, j) = sL;
+      *pv = (float)(*pv * sL / Pf);
+    }
+  }
+  __syncthreads();
+  double scale_prod = sL, pmin = LOCAL ? sL : 0.0;
+  for (int i = Lq - 1; i >= 1; --i) {
+    const int prv = cur ^ 1;
+    const double sc = h.scale[i + 1];
+    scale_prod *= sc;
+    if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
+    pmin *= sc;
+    if (pmin < DBL_MIN * 100) pmin = 0.0;
+    float* row = h.mat + (size_t)i * pitch;
+    const unsigned char* corow = h.co + (size_t)i * pitch;
+    // column Lt (:58-71)
+    if (lane == 0) {
+      if (corow[Lt]) {
+        row[Lt] = 0.0f;
+        ROW(cur, F_MM, Lt) = 0.0;
+      } else {
+        ROW(cur, F_MM, Lt) = scale_prod;
+        row[Lt] = (float)(row[Lt] * scale_prod / Pf);
+      }
+      ROW(cur, F_GD, Lt) = ROW(cur, F_IM, Lt) = ROW(cur, F_DG, Lt) = ROW(cur, F_MI, Lt) = 0.0;
+    }
+    const float* qn = h.qp + (size_t)(i + 1) * 20;
+    const float* qt = h.qtr + (size_t)i * 7;
+    const double qM2M = qt[T_M2M], qM2I = qt[T_M2I], qM2D = qt[T_M2D], qI2M = qt[T_I2M], qI2I = qt[T_I2I], qD2M = qt[T_D2M],
+                 qD2D = qt[T_D2D];
+    double carry_gd = 0.0, carry_im = 0.0;  // curr[Lt].gd = curr[Lt].im = 0
+    for (int s0 = 0; s0 < Lt - 1; s0 += 64) {
+      const int j = Lt - 1 - s0 - lane;  // descending: lane 0 is the rightmost column of the strip
+      const bool valid = j >= 1;
+      const int jc = valid ? j : 1;
+      const bool off = !valid || corow[jc] != 0;
+      const float* tt = h.ttr + (size_t)jc * 7;
+      const float pf = dot20(qn, h.tp + (size_t)(jc + 1) * 20);
+      const double pmatch = ROW(prv, F_MM, jc + 1) * pf * 1.0f * Cshift * sc;  // :80-83
+      const double pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
+      const double tM2M = tt[T_M2M];
+      double dg = (+pmatch * qD2M * tM2M + pdg * qD2D * sc);                       // :103-106
+      double mi = (+pmatch * qM2M * tt[T_I2M] + pmi * qM2M * tt[T_I2I] * sc);     // :108-111
+      const double a_gd = off ? 0.0 : pmatch * qM2M * tt[T_D2M], b_gd = off ? 0.0 : (double)tt[T_D2D];  // :95-97
+      const double c_im = off ? 0.0 : pmatch * qI2M * tM2M, b_im = off ? 0.0 : tM2M;                    // :99-101
+      double gd = 0.0, im = 0.0;
+      for (int s = 0; s < 64; ++s) {
+        const double gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);
+        gd = a_gd + gr * b_gd;
+        im = c_im + ir * qI2I * b_im;
+      }
+      const double gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);  // curr[j+1].gd / .im
+      double mm = (+pmin + pmatch * qM2M * tM2M + gr * tt[T_M2D] + ir * qM2I * tM2M + pdg * qM2D * sc +
+                   pmi * qM2M * tt[T_M2I] * sc);  // :86-93
+      if (off) mm = dg = mi = 0.0;
+      if (valid) {
+        ROW(cur, F_MM, j) = mm;
+        ROW(cur, F_GD, j) = gd;
+        ROW(cur, F_IM, j) = im;
+        ROW(cur, F_DG, j) = dg;
+        ROW(cur, F_MI, j) = mi;
+        row[j] = row[j] * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
+      }
+      carry_gd = lane_d(gd, 63);
+      carry_im = lane_d(im, 63);
+    }
+    __syncthreads();
+    cur = prv;
+  }
+}
+
+// ---- maximum-accuracy DP ----------------------------------------------------------------------------------------------
+template <bool LOCAL>
+__global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* S = reinterpret_cast<float*>(smem);  // [2][Lt+2]
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const HitView h = view(a, k);
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  const float mact = a.mact;
+  const double half = 0.5 * mact;
+  for (int e = lane; e < 2 * stride; e += 64) S[e] = 0.0f;
+  for (int e = lane; e < pitch; e += 64) h.bmm[e] = MAC_STOP;
+  __syncthreads();
+  int cur = 0;
+  float best = -FLT_MAX;
+  int best_i = 0, best_j = 0;
+  for (int i = 1; i <= Lq; ++i) {
+    const int prv = cur ^ 1;
+    const float* Sp = S + prv * stride;
+    float* Sc = S + cur * stride;
+    float carry = 0.0f;  // S_curr[0]
+    for (int s0 = 0; s0 < Lt; s0 += 64) {
+      const int j = 1 + s0 + lane;
+      const bool valid = j <= Lt;
+      const int jc = valid ? j : Lt;
+      const bool off = h.co[(size_t)i * pitch + jc] != 0;
+      const float p = h.mat[(size_t)i * pitch + jc];
+      const float term1 = p - mact;
+      const float term2 = Sp[jc - 1] + p - mact;
+      const float term3 = (float)(Sp[jc] - half);
+      float mx;
+      int code;
+      if (term1 > term2) {
+        mx = term1;
+        code = MAC_STOP;
+      } else {
+        mx = term2;
+        code = MAC_MM;
+      }
+      if (term3 > mx) {
+        mx = term3;
+        code = MAC_MI;
+      }
+      float sv = 0.0f;
+      for (int s = 0; s < 64; ++s) {
+        const float t4 = (float)(shr1_f(sv, carry) - half);
+        sv = off ? -FLT_MIN : (t4 > mx ? t4 : mx);
+      }
+      const float t4 = (float)(shr1_f(sv, carry) - half);
+      if (off)
+        code = MAC_STOP;
+      else if (t4 > mx)
+        code = MAC_IM;
+      if (valid) {
+        Sc[j] = sv;
+        h.bmm[(size_t)i * pitch + j] = (unsigned char)code;
+        if (!off && sv > best && (LOCAL || i == Lq)) {
+          best = sv;
+          best_i = i;
+          best_j = j;
+        }
+      }
+      carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), 63));
+    }
+    if (lane == 0) h.bmm[(size_t)i * pitch] = 0;
+    __syncthreads();
+    if (!LOCAL && lane == 0) {
+      // global alignment: best cell of the last column (:146-151); lane 0 owns column Lt's bookkeeping
+      const float v = Sc[Lt];
+      if (v > best) {
+        best = v;
+        best_i = i;
+        best_j = Lt;
+      }
+    }
+    cur = prv;
+  }
+  // first maximum in the reference's visiting order: largest value, then smallest (i, j) -- for the global mode the
+  // visiting order is (1,Lt) .. (Lq-1,Lt), (Lq,1..Lt): rows < Lq only ever hold column Lt, so (i, j) order is the same
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64), oj = __shfl_xor(best_j, o, 64);
+    const bool take = ov > best || (ov == best && (oi < best_i || (oi == best_i && oj < best_j)));
+    if (take) {
+      best = ov;
+      best_i = oi;
+      best_j = oj;
+    }
+  }
+  if (lane == 0) {
+    a.hits[k].i2 = best_i;
+    a.hits[k].j2 = best_j;
+  }
+}
+
+// ---- MAC backtrace: one lane per hit ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= a.n) return;
+  const HitView h = view(a, k);
+  const int pitch = h.pitch;
+  int* is = a.path_i + a.path_off[k];
+  int* js = a.path_j + a.path_off[k];
+  signed char* st = a.path_state + a.path_off[k];
+  float* Ss = a.path_S + a.path_off[k];
+  float* Ps = a.path_P + a.path_off[k];
+  // :124-125: b[i][1] = b[1][j] = STOP
+  auto code_at = [&](int i, int j) -> int { return (i == 1 || j == 1) ? (int)MAC_STOP : (int)h.bmm[(size_t)i * pitch + j]; };
+  int i = a.hits[k].i2, j = a.hits[k].j2;
+  int step = 0, matched = 1, state = MAC_MM;
+  if (code_at(i, j) != MAC_MM) {
+    is[0] = i;
+    js[0] = j;
+  } else {
+    while (state != MAC_STOP) {
+      step++;
+      state = code_at(i, j);
+      st[step] = (signed char)state;
+      is[step] = i;
+      js[step] = j;
+      if (state == MAC_MM) matched++;
+      switch (state) {
+        case MAC_MM: i--; j--; break;
+        case MAC_IM: j--; break;
+        case MAC_MI: i--; break;
+        case MAC_STOP: break;
+        default: state = 0; break;
+      }
+    }
+  }
+  st[step] = MAC_MM;  // :170
+  float sum = 0.0f;
+  for (int s = 1; s <= step; ++s) {
+    if (st[s] == MAC_MM) {
+      Ss[s] = fast_log2_mac(dot20(h.qp + (size_t)is[s] * 20, h.tp + (size_t)js[s] * 20), a.lg2, a.diff);
+      Ps[s] = h.mat[(size_t)is[s] * pitch + js[s]];
+      sum += Ps[s];
+    } else {
+      Ss[s] = Ps[s] = 0.0f;
+    }
+  }
+  a.hits[k].nsteps = step;
+  a.hits[k].matched_cols = matched;
+  a.hits[k].i1 = is[step];
+  a.hits[k].j1 = js[step];
+  a.hits[k].sum_of_probs = sum;
+  a.hits[k].Pforward = a.Pforward[k];
+}
+
+#undef ROW
+
+int launch_mac(const MacArgs& a, bool local, int max_Lt, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t lds_rows = (size_t)10 * (max_Lt + 2) * sizeof(double), lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
+  if (local) {
+    (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    hipLaunchKernelGGL(hhv_mac_forward_kernel<true>, dim3(a.n), dim3(64), lds_rows, stream, a);
+    hipLaunchKernelGGL(hhv_mac_backward_kernel<true>, dim3(a.n), dim3(64), lds_rows, stream, a);
+    hipLaunchKernelGGL(hhv_mac_dp_kernel<true>, dim3(a.n), dim3(64), lds_dp, stream, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    hipLaunchKernelGGL(hhv_mac_forward_kernel<false>, dim3(a.n), dim3(64), lds_rows, stream, a);
+    hipLaunchKernelGGL(hhv_mac_backward_kernel<false>, dim3(a.n), dim3(64), lds_rows, stream, a);
+    hipLaunchKernelGGL(hhv_mac_dp_kernel<false>, dim3(a.n), dim3(64), lds_dp, stream, a);
+  }
+  hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace hhv

@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores",
+    "hhv_mac_realign", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
@@ -107,6 +108,13 @@ def load():
     L.hhv_prefilter_free_db.restype = None
     L.hhv_prefilter_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.hhv_mac_realign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_float, C.c_float, C.POINTER(C.c_void_p), C.c_void_p]
+    L.hhv_mac_path.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int32)]
+    L.hhv_mac_posterior.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.hhv_macset_free.argtypes = [C.c_void_p]
+    L.hhv_macset_free.restype = None
     L.hhv_db_write.argtypes = [C.c_char_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p,
                                C.c_void_p, C.c_void_p]
     L.hhv_db_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
@@ -302,6 +310,29 @@ class Context:
                                              out.ctypes.data))
         return out
 
+    def mac_realign(self, qp, q_tr_lin, tps, t_trs, celloffs=None, local=1, shift=-0.03, mact=0.3501):
+        """hhv_mac_realign -> MacSet (hits structured array + path()/posterior() accessors)."""
+        qp, q_tr_lin = _f32(qp), _f32(q_tr_lin)
+        tps = [_f32(a) for a in tps]
+        t_trs = [_f32(a) for a in t_trs]
+        n = len(tps)
+        Lq = qp.shape[0] - 1
+        Lt = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        pp = (C.c_void_p * n)(*[a.ctypes.data for a in tps])
+        tt = (C.c_void_p * n)(*[a.ctypes.data for a in t_trs])
+        cc = None
+        keep = None
+        if celloffs is not None:
+            keep = [None if m is None else np.ascontiguousarray(m, dtype=np.uint8) for m in celloffs]
+            for k, m in enumerate(keep):
+                assert m is None or m.shape == (Lq + 1, Lt[k] + 1)
+            cc = (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in keep])
+        hits = np.zeros(n, dtype=MAC_HIT_DTYPE)
+        h = C.c_void_p()
+        _check(self.lib.hhv_mac_realign(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, n, Lt.ctypes.data, pp, tt, cc,
+                                        int(local), shift, mact, C.byref(h), hits.ctypes.data))
+        return MacSet(self.lib, h, hits, Lq, Lt)
+
     def db_open(self, path, Ls):
         h = C.c_void_p()
         _check(self.lib.hhv_db_open(self.h, path.encode(), C.byref(h)))
@@ -433,6 +464,39 @@ def runner_alignment(qp, qtr, tps, ttrs, loc=1, egq=0.0, egt=0.0, shift=-0.03, c
     if m < 0:
         raise HhvError("hhvr_alignment failed: %d: %s" % (m, load().hhv_last_error().decode()))
     return hits[:m], i_s[:m], j_s[:m], st[:m], S[:m]
+
+
+MAC_HIT_DTYPE = np.dtype([("Pforward", "<f8"), ("sum_of_probs", "<f4"), ("i1", "<i4"), ("j1", "<i4"), ("i2", "<i4"),
+                          ("j2", "<i4"), ("nsteps", "<i4"), ("matched_cols", "<i4"), ("reserved", "<i4")])
+
+
+class MacSet:
+    """Result of hhv_mac_realign: per-hit summaries on the host, paths and posterior matrices on the device."""
+
+    def __init__(self, lib, h, hits, Lq, Lt):
+        self.lib, self.h, self.hits, self.Lq, self.Lt = lib, h, hits, Lq, Lt
+
+    def path(self, k):
+        cap = int(self.hits["nsteps"][k]) + 1
+        i_s = np.zeros(cap, np.int32)
+        j_s = np.zeros(cap, np.int32)
+        st = np.zeros(cap, np.int8)
+        S = np.zeros(cap, np.float32)
+        P = np.zeros(cap, np.float32)
+        ns = C.c_int32()
+        _check(self.lib.hhv_mac_path(self.h, k, cap, i_s.ctypes.data, j_s.ctypes.data, st.ctypes.data, S.ctypes.data,
+                                     P.ctypes.data, C.byref(ns)))
+        return i_s, j_s, st, S, P
+
+    def posterior(self, k):
+        out = np.zeros((self.Lq + 1, int(self.Lt[k]) + 1), np.float32)
+        _check(self.lib.hhv_mac_posterior(self.h, k, out.ctypes.data))
+        return out
+
+    def free(self):
+        if self.h:
+            self.lib.hhv_macset_free(self.h)
+            self.h = None
 
 
 # ---- hhv::Prefilter (host/prefilter.h): HHblits prefilter around the two GPU kernels -------------------------

@@ -184,6 +184,35 @@ int hhv_prefilter_scores(hhv_ctx* ctx, hhv_pfdb* db, const uint8_t* profile, int
                          int32_t gapped, int32_t gap_init, int32_t gap_extend, const int32_t* subset, int32_t n_subset,
                          int32_t* scores);
 
+/* ---- MAC realignment ------------------------------------------------------------------------
+ * PosteriorDecoder::realign (src/hhposteriordecoder.cpp:86-119) for a batch of n hits of one query: forward, backward,
+ * posterior, maximum-accuracy DP and MAC backtrace (src/hhforwardalgorithm.cpp, hhbackwardalgorithm.cpp,
+ * hhmacalgorithm.cpp, hhbacktracemac.cpp), one wavefront per hit, bit-exact against the reference's doubles.
+ *   q_p [(Lq+1)][20], q_tr_lin [(Lq+1)][7]: the prepared query with LINEAR transitions, i.e. after
+ *       Log2LinTransitionProbs(1.0) and initializeQueryHMMTransitions (src/hhposteriordecoderrunner.cpp:146-155)
+ *   t_p[k] [(Lt+1)][20], t_tr_lin[k] [(Lt+1)][7]: the prepared template of hit k, linear transitions, with the boundary
+ *       assignments of initializeForAlignment (src/hhposteriordecoder.cpp:159-167)
+ *   celloff[k]: (Lq+1)*(Lt+1) bytes, non-zero = cell excluded (the mask realign() builds: band around the Viterbi
+ *       path, earlier alternative alignments, -excl regions); NULL = no cell excluded
+ *   local / shift / mact: par.loc, par.shift, par.mact.  Secondary-structure scoring (ssm) is not supported here.
+ * hits[k] receives the alignment summary; paths and posteriors stay on the device in *out until fetched. */
+typedef struct hhv_mac_hit {
+  double Pforward;       /* Hit::Pforward (scaled total forward probability) */
+  float sum_of_probs;    /* Hit::sum_of_probs */
+  int32_t i1, j1, i2, j2, nsteps, matched_cols;
+  int32_t reserved;
+} hhv_mac_hit;
+typedef struct hhv_macset hhv_macset;
+int hhv_mac_realign(hhv_ctx* ctx, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                    const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff, int32_t local,
+                    float shift, float mact, hhv_macset** out, hhv_mac_hit* hits);
+/* path of hit k: entries 1..nsteps (Hit::i, ::j, ::states, ::S, ::P_posterior); cap >= nsteps + 1 */
+int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps, int8_t* states, float* S,
+                 float* P_posterior, int32_t* nsteps);
+/* dense posterior matrix of hit k, (Lq+1)*(Lt+1) floats (row 0 / column 0 unused) */
+int hhv_mac_posterior(hhv_macset* ms, int32_t k, float* posterior);
+void hhv_macset_free(hhv_macset* ms);
+
 /* Binary packed template database: the record stream plus its length table in one file, so that
  * a search mmaps/reads it straight into HBM instead of parsing and re-packing HMM text per query.
  * File = 64-byte header {magic "HHVPDB01", int32 n, int32 record_dwords (28), int64 n_records, zero pad},

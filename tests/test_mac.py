@@ -30,6 +30,36 @@ def make_pair(case, seed=0):
     return qp, qtr, tp, ttr, local, mact
 
 
+def lin_query(qtr):
+    """Log2LinTransitionProbs(1.0) (powf, src/hhhmm.cpp:2305-2313) + initializeQueryHMMTransitions
+    (src/hhposteriordecoderrunner.cpp:146-155); test helper - in the product the caller's HMM code does this."""
+    t = np.exp2(qtr.astype(np.float32)).astype(np.float32)
+    t[0, [synth.M2D, synth.M2I, synth.I2M, synth.I2I, synth.D2M, synth.D2D]] = 0.0
+    t[-1] = [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+    return t
+
+
+def lin_template(ttr):
+    """Log2LinTransitionProbs(1.0) + the boundary assignments of initializeForAlignment (src/hhposteriordecoder.cpp:159-167)."""
+    t = np.exp2(ttr.astype(np.float32)).astype(np.float32)
+    t[0] = [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    t[-1] = [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+    return t
+
+
+def oracle_mac_realign_nomask(orc, qp, q_lin, tp, t_lin, local=1, mact=0.3501):
+    """The four stages on an all-on mask (what the product does for celloff = NULL)."""
+    class V:
+        pass
+    v = V()
+    Lq, Lt = qp.shape[0] - 1, tp.shape[0] - 1
+    # a fake Viterbi hit whose band covers everything: i1 = j1 = huge, i2 = j2 = 0 -> every cell is on
+    v.nsteps, v.i2, v.j2 = 0, 0, 0
+    v.i_steps = np.array([Lq + Lt + 5], np.int32)
+    v.j_steps = np.array([Lq + Lt + 5], np.int32)
+    return oracle_mac_realign(orc, qp, q_lin, tp, t_lin, v, local=local, mact=mact)
+
+
 def same(a, b):
     assert a.nsteps == b.nsteps and (a.i1, a.j1, a.i2, a.j2, a.matched_cols) == (b.i1, b.j1, b.i2, b.j2, b.matched_cols)
     n = a.nsteps
@@ -58,3 +88,73 @@ def test_oracle_mac_matches_reference(oracle, ref, case):
         same(o, r)
         prev.append((r.i_steps[(0 if r.nsteps == 0 else 1):r.nsteps + 1].copy(), r.j_steps[(0 if r.nsteps == 0 else 1):r.nsteps + 1].copy()))
     assert r.nsteps >= 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("local", [1, 0])
+def test_gpu_mac_matches_oracle(oracle, local):
+    """All cases as ONE batch (ragged template lengths) per alignment mode, three rounds of alternative alignments."""
+    from pyhhv import capi
+    cases = [c for c in range(len(CASES)) if CASES[c][0] == 120 or True]
+    # one query per launch: group the cases by Lq
+    c = capi.Context()
+    for case in cases:
+        qp, qtr, tp, ttr, _, mact = make_pair(case)
+        par = make_params(local=local, ss_mode=0)
+        vit = oracle.align(par, qp, qtr, tp, ttr, want_path=True)
+        q_lin = lin_query(qtr)
+        t_lin = lin_template(ttr)
+        prev = []
+        for rnd in range(3):
+            o = oracle_mac_realign(oracle, qp, q_lin, tp, t_lin, vit, local=local, mact=mact, prev=prev)
+            ms = c.mac_realign(qp, q_lin, [tp], [t_lin], [o.celloff], local=local, mact=mact)
+            h = ms.hits[0]
+            assert np.float64(h["Pforward"]).tobytes() == np.float64(o.Pforward).tobytes(), (case, rnd)
+            assert ms.posterior(0)[1:, 1:].tobytes() == o.posterior[1:, 1:].tobytes(), (case, rnd)
+            got = (h["nsteps"], h["i1"], h["j1"], h["i2"], h["j2"], h["matched_cols"])
+            assert got == (o.nsteps, o.i1, o.j1, o.i2, o.j2, o.matched_cols), (case, rnd)
+            i_s, j_s, st, S, P = ms.path(0)
+            n = o.nsteps
+            lo = 0 if n == 0 else 1
+            assert np.array_equal(i_s[lo:], o.i_steps[lo:n + 1]) and np.array_equal(j_s[lo:], o.j_steps[lo:n + 1])
+            assert np.array_equal(st[1:], o.states[1:n + 1])
+            assert S[1:].tobytes() == o.S[1:n + 1].tobytes() and P[1:].tobytes() == o.P[1:n + 1].tobytes()
+            assert np.float32(h["sum_of_probs"]).tobytes() == np.float32(o.sum_of_probs).tobytes()
+            ms.free()
+            prev.append((o.i_steps[lo:n + 1].copy(), o.j_steps[lo:n + 1].copy()))
+    c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_mac_batch_of_ragged_hits(oracle):
+    """Many hits of one query in one launch (ragged Lt, some without mask) equal the same hits done one by one."""
+    from pyhhv import capi
+    Lq = 150
+    qp, qtr = synth.make_query(77, Lq)
+    q_lin = lin_query(qtr)
+    par = make_params(local=1, ss_mode=0)
+    tps, tls, masks, want = [], [], [], []
+    for k, Lt in enumerate([40, 64, 65, 128, 129, 200, 333, 1, 2, 3]):
+        tp, ttr = synth.make_homolog(500 + k, qp, L=Lt) if k % 3 else synth.make_template(500 + k, Lt)
+        t_lin = lin_template(ttr)
+        vit = oracle.align(par, qp, qtr, tp, ttr, want_path=True)
+        o = oracle_mac_realign(oracle, qp, q_lin, tp, t_lin, vit, local=1)
+        if k % 4 == 3:   # no mask at all
+            o = oracle_mac_realign_nomask(oracle, qp, q_lin, tp, t_lin)
+            masks.append(None)
+        else:
+            masks.append(o.celloff)
+        tps.append(tp)
+        tls.append(t_lin)
+        want.append(o)
+    c = capi.Context()
+    ms = c.mac_realign(qp, q_lin, tps, tls, masks, local=1)
+    for k, o in enumerate(want):
+        h = ms.hits[k]
+        assert np.float64(h["Pforward"]).tobytes() == np.float64(o.Pforward).tobytes(), k
+        assert ms.posterior(k)[1:, 1:].tobytes() == o.posterior[1:, 1:].tobytes(), k
+        assert (h["nsteps"], h["i1"], h["j1"], h["i2"], h["j2"]) == (o.nsteps, o.i1, o.j1, o.i2, o.j2), k
+        i_s, j_s, st, S, P = ms.path(k)
+        assert P[1:].tobytes() == o.P[1:o.nsteps + 1].tobytes() and np.array_equal(st[1:], o.states[1:o.nsteps + 1])
+    ms.free()
+    c.close()
