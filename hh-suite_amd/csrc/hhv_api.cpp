@@ -787,6 +787,9 @@ struct hhv_macset {
   signed char* d_path_state = nullptr;
   float* d_path_S = nullptr;
   float* d_path_P = nullptr;
+  // all five path arrays, fetched with one copy when the kernels are done
+  std::vector<char> h_paths;
+  size_t h_pi = 0, h_pj = 0, h_ps = 0, h_pS = 0, h_pP = 0;
 };
 
 void hhv_macset_free(hhv_macset* ms) {
@@ -910,7 +913,14 @@ int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t
   }
   static_assert(sizeof(DevMacHit) == sizeof(hhv_mac_hit), "hhv_mac_hit layout");
   ms->hits.resize(n);
+  ms->h_paths.resize(total - o_pi);
+  ms->h_pi = 0;
+  ms->h_pj = o_pj - o_pi;
+  ms->h_ps = o_ps - o_pi;
+  ms->h_pS = o_pS - o_pi;
+  ms->h_pP = o_pP - o_pi;
   if (rc == HHV_OK && (hipMemcpyAsync(ms->hits.data(), base + o_hits, (size_t)n * sizeof(hhv_mac_hit), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                       hipMemcpyAsync(ms->h_paths.data(), base + o_pi, total - o_pi, hipMemcpyDeviceToHost, st) != hipSuccess ||
                        hipStreamSynchronize(st) != hipSuccess))
     rc = fail(HHV_E_DEVICE, "hhv_mac_realign: kernels failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc != HHV_OK) {
@@ -928,15 +938,14 @@ int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32
   const int ns = ms->hits[k].nsteps;
   *nsteps = ns;
   if (cap < ns + 1) return fail(HHV_E_ARG, "hhv_mac_path: cap %d < nsteps + 1 = %d", cap, ns + 1);
-  HIP_TRY(hipSetDevice(ms->ctx->par.device));
   const int64_t o = ms->path_off[k];
   const size_t cnt = (size_t)ns + 1;
-  if ((i_steps && hipMemcpy(i_steps, ms->d_path_i + o, cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) ||
-      (j_steps && hipMemcpy(j_steps, ms->d_path_j + o, cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) ||
-      (states && hipMemcpy(states, ms->d_path_state + o, cnt, hipMemcpyDeviceToHost) != hipSuccess) ||
-      (S && hipMemcpy(S, ms->d_path_S + o, cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) ||
-      (P_posterior && hipMemcpy(P_posterior, ms->d_path_P + o, cnt * 4, hipMemcpyDeviceToHost) != hipSuccess))
-    return fail(HHV_E_DEVICE, "hhv_mac_path: D2H copy failed");
+  const char* hp = ms->h_paths.data();
+  if (i_steps) memcpy(i_steps, hp + ms->h_pi + (size_t)o * 4, cnt * 4);
+  if (j_steps) memcpy(j_steps, hp + ms->h_pj + (size_t)o * 4, cnt * 4);
+  if (states) memcpy(states, hp + ms->h_ps + (size_t)o, cnt);
+  if (S) memcpy(S, hp + ms->h_pS + (size_t)o * 4, cnt * 4);
+  if (P_posterior) memcpy(P_posterior, hp + ms->h_pP + (size_t)o * 4, cnt * 4);
   return HHV_OK;
 }
 

@@ -133,6 +133,21 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const bool valid = j <= Lt;
       const int jc = valid ? j : Lt;
       const bool off = !valid || h.co[(size_t)i * pitch + jc] != 0;
+      const unsigned long long on_mask = __ballot(!off);
+      if (on_mask == 0) {
+        // a strip without a single active cell: all five states are zero, the running sums are unchanged
+        if (valid) {
+          ROW(cur, F_MM, j) = 0.0;
+          ROW(cur, F_GD, j) = 0.0;
+          ROW(cur, F_IM, j) = 0.0;
+          ROW(cur, F_DG, j) = 0.0;
+          ROW(cur, F_MI, j) = 0.0;
+          h.mat[(size_t)i * pitch + j] = 0.0f;
+        }
+        carry_mm = carry_gd = carry_im = 0.0;
+        continue;
+      }
+      const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
       const float pf = dot20(qi, h.tp + (size_t)jc * 20);
       const float* tt1 = h.ttr + (size_t)(jc - 1) * 7;  // t.tr[j-1]
       const float* tt = h.ttr + (size_t)jc * 7;         // t.tr[j]
@@ -163,8 +178,11 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const double a_gd = chain_on ? mm_left * tt1[T_M2D] : 0.0, b_gd = chain_on ? (double)tt1[T_D2D] : 0.0;
       const double c_im = chain_on ? mm_left * qM2I * tt1[T_M2M] : 0.0, b_im = chain_on ? (double)tt1[T_M2M] : 0.0;
       const double f_mm = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
-      double gd = 0.0, im = 0.0, acc = 0.0;
-      for (int s = 0; s < 64; ++s) {
+      // Sweep: inactive lanes hold 0 (resp. the incoming total) whatever their neighbour says, so the lanes left of the
+      // first active one are final from the start and l1 - l0 + 1 steps finish everything up to the last active lane.
+      double gd = 0.0, im = 0.0, acc = Pf;
+      const int n_steps = l1 - l0 + 1;
+      for (int s = 0; s < n_steps; ++s) {
         const double gl = shr1_d(gd, carry_gd), il = shr1_d(im, carry_im);
         gd = a_gd + gl * b_gd;
         im = c_im + il * qI2I * b_im;
@@ -179,9 +197,9 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
         h.mat[(size_t)i * pitch + j] = (float)mm;
       }
       carry_mm = lane_d(mm, 63);
-      carry_gd = lane_d(gd, 63);
+      carry_gd = lane_d(gd, 63);   // lane 63 is either inactive (0) or l1 (final)
       carry_im = lane_d(im, 63);
-      if (LOCAL) Pf = lane_d(acc, 63);
+      if (LOCAL) Pf = lane_d(acc, l1);  // lanes right of l1 would only add zeros
     }
     if (lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
     double scale_next = 1.0;
@@ -208,7 +226,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     for (int s0 = 0; s0 < Lt; s0 += 64) {
       const int j = 1 + s0 + lane;
       const double f_mm = j <= Lt ? (double)(float)ROW(last, F_MM, j) : 0.0;
-      double acc = 0.0;
+      double acc = Pf;
       for (int s = 0; s < 64; ++s) acc = shr1_d(acc, Pf) + f_mm;
       Pf = lane_d(acc, 63);
     }
@@ -273,6 +291,20 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       const bool valid = j >= 1;
       const int jc = valid ? j : 1;
       const bool off = !valid || corow[jc] != 0;
+      const unsigned long long on_mask = __ballot(!off);
+      if (on_mask == 0) {
+        if (valid) {
+          ROW(cur, F_MM, j) = 0.0;
+          ROW(cur, F_GD, j) = 0.0;
+          ROW(cur, F_IM, j) = 0.0;
+          ROW(cur, F_DG, j) = 0.0;
+          ROW(cur, F_MI, j) = 0.0;
+          row[j] = row[j] * 0.0f;  // F * (float)(0 / Pforward)
+        }
+        carry_gd = carry_im = 0.0;
+        continue;
+      }
+      const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
       const float* tt = h.ttr + (size_t)jc * 7;
       const float pf = dot20(qn, h.tp + (size_t)(jc + 1) * 20);
       const double pmatch = ROW(prv, F_MM, jc + 1) * pf * 1.0f * Cshift * sc;  // :80-83
@@ -283,7 +315,8 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       const double a_gd = off ? 0.0 : pmatch * qM2M * tt[T_D2M], b_gd = off ? 0.0 : (double)tt[T_D2D];  // :95-97
       const double c_im = off ? 0.0 : pmatch * qI2M * tM2M, b_im = off ? 0.0 : tM2M;                    // :99-101
       double gd = 0.0, im = 0.0;
-      for (int s = 0; s < 64; ++s) {
+      const int n_steps = l1 - l0 + 1;
+      for (int s = 0; s < n_steps; ++s) {
         const double gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);
         gd = a_gd + gr * b_gd;
         im = c_im + ir * qI2I * b_im;
@@ -351,8 +384,11 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
         mx = term3;
         code = MAC_MI;
       }
-      float sv = 0.0f;
-      for (int s = 0; s < 64; ++s) {
+      // inactive cells hold -FLT_MIN whatever their neighbour says: sweep only from the first to the last active lane
+      const unsigned long long on_mask = __ballot(!off && valid);
+      const int n_steps = on_mask ? (63 - __builtin_clzll(on_mask)) - __builtin_ctzll(on_mask) + 1 : 0;
+      float sv = off ? -FLT_MIN : 0.0f;
+      for (int s = 0; s < n_steps; ++s) {
         const float t4 = (float)(shr1_f(sv, carry) - half);
         sv = off ? -FLT_MIN : (t4 > mx ? t4 : mx);
       }

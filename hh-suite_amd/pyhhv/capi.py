@@ -423,6 +423,14 @@ def load_runner():
                                            C.c_int, C.c_int,
                                            c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _runner.hhvr_linear_transitions.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    _runner.hhvr_linear_transitions.restype = None
+    _runner.hhvr_mac_celloff.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _runner.hhvr_mac_realign.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_char_p, C.c_char_p,
+                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _runner.hhvr_prefilter_db.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     _runner.hhvr_prefilter_select_first.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -574,3 +582,74 @@ def prefilter_db(ctx, seqs, offsets, lib, q_p, pav, **kw):
     if m < 0:
         raise HhvError("hhvr_prefilter_db failed: %d: %s" % (m, load().hhv_last_error().decode()))
     return ids[:m], ev[:m], p1.value
+
+
+# ---- hhv::PosteriorDecoderRunner (host/posterior_decoder.h): MAC realignment above hhv_mac_realign ----------------
+def linear_transitions(tr_log2, is_query):
+    """hhv::LinearTransitions: 2^tr (powf) + the boundary assignments of the realign stage."""
+    tr = _f32(tr_log2)
+    out = np.zeros_like(tr)
+    load_runner().hhvr_linear_transitions(tr.ctypes.data, tr.shape[0] - 1, int(bool(is_query)), out.ctypes.data)
+    return out
+
+
+def _alt_lists(prev):
+    off = np.zeros(len(prev) + 1, np.int32)
+    for k, (a, _) in enumerate(prev):
+        off[k + 1] = off[k] + len(a)
+    pi = np.concatenate([np.asarray(a, np.int32) for a, _ in prev] + [np.zeros(0, np.int32)]).astype(np.int32)
+    pj = np.concatenate([np.asarray(b, np.int32) for _, b in prev] + [np.zeros(0, np.int32)]).astype(np.int32)
+    return off, np.ascontiguousarray(pi), np.ascontiguousarray(pj)
+
+
+def mac_celloff(Lq, Lt, hit, prev=(), min_overlap=0, exclstr=None, template_exclstr=None):
+    """hhv::MacCellOff. hit = (i1, j1, i2, j2, nsteps, i_steps, j_steps); prev = [(alt_i, alt_j), ...]."""
+    i1, j1, i2, j2, ns, vi, vj = hit
+    row = np.array([0, 1, i1, j1, i2, j2, ns], np.int32)
+    vi = np.ascontiguousarray(vi, np.int32)
+    vj = np.ascontiguousarray(vj, np.int32)
+    off, pi, pj = _alt_lists(list(prev))
+    mask = np.zeros((Lq + 1, Lt + 1), np.uint8)
+    load_runner().hhvr_mac_celloff(Lq, Lt, min_overlap, exclstr.encode() if exclstr else None,
+                                   template_exclstr.encode() if template_exclstr else None, row.ctypes.data, vi.ctypes.data,
+                                   vj.ctypes.data, len(off) - 1, off.ctypes.data, pi.ctypes.data, pj.ctypes.data,
+                                   mask.ctypes.data)
+    return mask
+
+
+def runner_mac_realign(ctx, qp, q_tr_lin, tps, t_trs, hits, loc=1, shift=-0.03, mact=0.3501, min_overlap=0):
+    """hhv::PosteriorDecoderRunner::executeComputation. hits: list of (entry, irep, i1, j1, i2, j2, nsteps, i_steps, j_steps).
+    Returns (scalars[n][6] = nsteps,i1,j1,i2,j2,matched_cols; real[n][2] = Pforward,sum_of_probs; i, j, states, S, P)."""
+    lib = load_runner()
+    qp, q_tr_lin = _f32(qp), _f32(q_tr_lin)
+    tps = [_f32(a) for a in tps]
+    t_trs = [_f32(a) for a in t_trs]
+    nt, nh = len(tps), len(hits)
+    Lq = qp.shape[0] - 1
+    Lt = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+    pp = (C.c_void_p * nt)(*[a.ctypes.data for a in tps])
+    tt = (C.c_void_p * nt)(*[a.ctypes.data for a in t_trs])
+    rows = np.array([h[:7] for h in hits], dtype=np.int32).reshape(nh, 7)
+    poff = np.zeros(nh + 1, np.int64)
+    for k, h in enumerate(hits):
+        poff[k + 1] = poff[k] + h[6] + 1
+    pi = np.zeros(poff[-1], np.int32)
+    pj = np.zeros(poff[-1], np.int32)
+    for k, h in enumerate(hits):
+        pi[poff[k]:poff[k + 1]] = np.asarray(h[7], np.int32)[:h[6] + 1]
+        pj[poff[k]:poff[k + 1]] = np.asarray(h[8], np.int32)[:h[6] + 1]
+    pcap = Lq + int(Lt.max()) + 2
+    sc = np.zeros((nh, 6), np.int32)
+    re = np.zeros((nh, 2), np.float64)
+    o_i = np.zeros((nh, pcap), np.int32)
+    o_j = np.zeros((nh, pcap), np.int32)
+    o_s = np.zeros((nh, pcap), np.int8)
+    o_S = np.zeros((nh, pcap), np.float32)
+    o_P = np.zeros((nh, pcap), np.float32)
+    m = lib.hhvr_mac_realign(ctx.h, loc, shift, mact, min_overlap, None, None, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, nt,
+                             Lt.ctypes.data, pp, tt, nh, rows.ctypes.data, poff.ctypes.data, pi.ctypes.data, pj.ctypes.data,
+                             sc.ctypes.data, re.ctypes.data, pcap, o_i.ctypes.data, o_j.ctypes.data, o_s.ctypes.data,
+                             o_S.ctypes.data, o_P.ctypes.data)
+    if m < 0:
+        raise HhvError("hhvr_mac_realign failed: %d: %s" % (m, load().hhv_last_error().decode()))
+    return sc, re, o_i, o_j, o_s, o_S, o_P

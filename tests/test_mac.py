@@ -90,6 +90,64 @@ def test_oracle_mac_matches_reference(oracle, ref, case):
     assert r.nsteps >= 0
 
 
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_host_mask_and_linear_transitions_match_reference(oracle, ref, case):
+    """hhv::LinearTransitions and hhv::MacCellOff (host layer of the product) against the reference's realign()."""
+    from pyhhv import capi
+    qp, qtr, tp, ttr, local, mact = make_pair(case)
+    vit = oracle.align(make_params(local=local, ss_mode=0), qp, qtr, tp, ttr, want_path=True)
+    Lq, Lt = qp.shape[0] - 1, tp.shape[0] - 1
+    prev = []
+    for rnd in range(3):
+        r = ref_mac_realign(ref, qp, qtr, tp, ttr, vit, local=local, mact=mact, prev=prev)
+        assert capi.linear_transitions(qtr, True).tobytes() == r.q_tr_lin.tobytes()
+        assert capi.linear_transitions(ttr, False).tobytes() == r.t_tr_lin.tobytes()
+        ns = vit.nsteps
+        hit = (int(vit.i_steps[ns]), int(vit.j_steps[ns]), vit.i2, vit.j2, ns, vit.i_steps, vit.j_steps)
+        assert np.array_equal(capi.mac_celloff(Lq, Lt, hit, prev), r.celloff)
+        lo = 0 if r.nsteps == 0 else 1
+        prev.append((r.i_steps[lo:r.nsteps + 1].copy(), r.j_steps[lo:r.nsteps + 1].copy()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("local", [1, 0])
+def test_gpu_runner_matches_reference(oracle, ref, local):
+    """hhv::PosteriorDecoderRunner::executeComputation (masks + rounds on the host, DP on the GPU) against the reference's
+    realign() chain: five templates, three alternative alignments each, handed over in shuffled order."""
+    from pyhhv import capi
+    Lq = 140
+    qp, qtr = synth.make_query(4242, Lq)
+    q_lin = capi.linear_transitions(qtr, True)
+    tps, t_lins, hits, want = [], [], [], []
+    for k, Lt in enumerate([90, 150, 64, 201, 33]):
+        tp, ttr = synth.make_homolog(900 + k, qp, L=Lt)
+        vit = oracle.align(make_params(local=local, ss_mode=0), qp, qtr, tp, ttr, want_path=True)
+        ns = vit.nsteps
+        prev = []
+        for irep in (1, 2, 3):
+            r = ref_mac_realign(ref, qp, qtr, tp, ttr, vit, local=local, prev=prev)
+            lo = 0 if r.nsteps == 0 else 1
+            prev.append((r.i_steps[lo:r.nsteps + 1].copy(), r.j_steps[lo:r.nsteps + 1].copy()))
+            hits.append((k, irep, int(vit.i_steps[ns]), int(vit.j_steps[ns]), vit.i2, vit.j2, ns, vit.i_steps, vit.j_steps))
+            want.append(r)
+        tps.append(tp)
+        t_lins.append(capi.linear_transitions(ttr, False))
+    order = np.random.default_rng(3).permutation(len(hits))
+    c = capi.Context()
+    sc, re, o_i, o_j, o_s, o_S, o_P = capi.runner_mac_realign(c, qp, q_lin, tps, t_lins, [hits[h] for h in order], loc=local)
+    c.close()
+    for pos, h in enumerate(order):
+        r = want[h]
+        assert tuple(sc[pos]) == (r.nsteps, r.i1, r.j1, r.i2, r.j2, r.matched_cols), (h, tuple(sc[pos]))
+        assert np.float64(re[pos, 0]).tobytes() == np.float64(r.Pforward).tobytes()
+        assert np.float32(re[pos, 1]).tobytes() == np.float32(r.sum_of_probs).tobytes()
+        n = r.nsteps
+        lo = 0 if n == 0 else 1
+        assert np.array_equal(o_i[pos, lo:n + 1], r.i_steps[lo:n + 1]) and np.array_equal(o_j[pos, lo:n + 1], r.j_steps[lo:n + 1])
+        assert np.array_equal(o_s[pos, 1:n + 1], r.states[1:n + 1])
+        assert o_S[pos, 1:n + 1].tobytes() == r.S[1:n + 1].tobytes() and o_P[pos, 1:n + 1].tobytes() == r.P[1:n + 1].tobytes()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("local", [1, 0])
 def test_gpu_mac_matches_oracle(oracle, local):

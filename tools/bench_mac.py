@@ -1,0 +1,78 @@
+"""MAC realignment throughput: n hits of one query realigned on the GPU (hhv::PosteriorDecoderRunner)
+next to the reference's PosteriorDecoder::realign timed on one host core (oracle/_ref) on a sample of the same hits.
+usage: python tools/bench_mac.py [n_hits] [Lq] [Lt] [ref_sample]   -> one JSON line"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "hh-suite_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from pyhhv import capi, synth  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+    Lq = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    Lt = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    sample = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+    qp, qtr = synth.make_query(11, Lq)
+    tps, ttrs = [], []
+    for k in range(n):
+        tp, ttr = synth.make_homolog(100 + k, qp, L=Lt, mut=0.2 + 0.6 * (k % 7) / 7.0)
+        tps.append(tp)
+        ttrs.append(ttr)
+    c = capi.Context(local=1, shift=-0.03, corr=0.1)
+    c.set_query(qp, qtr)
+    ts = c.upload(tps, ttrs)
+    c.align(ts, backtrace=True)
+    vh = c.hits(ts)
+    hits = []
+    for k in range(n):
+        _, i_s, j_s, st, S = c.hit_path(ts, k)
+        ns = int(vh["nsteps"][k])
+        hits.append((k, 1, int(vh["i1"][k]), int(vh["j1"][k]), int(vh["i2"][k]), int(vh["j2"][k]), ns, i_s, j_s))
+    q_lin = capi.linear_transitions(qtr, True)
+    t_lins = [capi.linear_transitions(t, False) for t in ttrs]
+    capi.runner_mac_realign(c, qp, q_lin, tps[:4], t_lins[:4], hits[:4])          # warm-up
+    t0 = time.perf_counter()
+    sc, re, o_i, o_j, o_s, o_S, o_P = capi.runner_mac_realign(c, qp, q_lin, tps, t_lins, hits)
+    wall = time.perf_counter() - t0
+    kms = c.last_kernel_ms()
+    cells = float(n) * Lq * Lt
+    out = {"n_hits": n, "Lq": Lq, "Lt": Lt, "gpu_kernels_ms": round(kms, 3), "gpu_wall_ms_incl_host_masks": round(wall * 1e3, 2),
+           "gpu_hits_per_s": n / (kms * 1e-3), "gpu_cells_per_s": cells / (kms * 1e-3),
+           "mean_nsteps": float(sc[:, 0].mean()), "mean_sum_of_probs": float(re[:, 1].mean())}
+    if sample:
+        from pyoracle import Ref, ref_mac_realign
+
+        class V:
+            pass
+        ref = Ref()
+        bad = 0
+        t_ref = 0.0
+        for k in range(0, n, max(1, n // sample)):
+            v = V()
+            v.nsteps, v.i2, v.j2, v.i_steps, v.j_steps = hits[k][6], hits[k][4], hits[k][5], hits[k][7], hits[k][8]
+            t1 = time.perf_counter()
+            r = ref_mac_realign(ref, qp, qtr, tps[k], ttrs[k], v, local=1)
+            t_ref += time.perf_counter() - t1
+            ok = (tuple(sc[k]) == (r.nsteps, r.i1, r.j1, r.i2, r.j2, r.matched_cols) and
+                  np.float64(re[k, 0]).tobytes() == np.float64(r.Pforward).tobytes() and
+                  o_P[k, 1:r.nsteps + 1].tobytes() == r.P[1:r.nsteps + 1].tobytes() and
+                  np.array_equal(o_i[k, 1:r.nsteps + 1], r.i_steps[1:r.nsteps + 1]))
+            bad += int(not ok)
+            out.setdefault("checked", 0)
+            out["checked"] += 1
+        out["mismatches_vs_reference"] = bad
+        out["ref_cpu_ms_per_hit_1core"] = round(t_ref / out["checked"] * 1e3, 3)
+        out["ref_cpu_hits_per_s_1core"] = out["checked"] / t_ref
+    c.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
