@@ -71,6 +71,8 @@ struct hhv_ctx {
   std::vector<int8_t> q_pred, q_conf, q_dssp;          // [Lq+1], empty = absent
   int ss_hmm_mode = 0;                                 // HMM::NO_SS_INFORMATION
   bool ss_dirty = true;
+  void* mac_cache = nullptr;                           // one recycled device block of the MAC realignment
+  size_t mac_cache_bytes = 0;
   float* d_ss_table = nullptr;                         // ssw * table of the current mode
   int32_t* d_ss_q_off = nullptr;                       // [P*64*R]
   int ss_t_shift = 0, ss_t_mask = 0;
@@ -216,6 +218,7 @@ void hhv_destroy(hhv_ctx* c) {
   dfree(c->d_diff);
   dfree(c->d_ss_table);
   dfree(c->d_ss_q_off);
+  dfree(c->mac_cache);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -781,6 +784,8 @@ struct hhv_macset {
   std::vector<int64_t> mat_off, path_off;
   std::vector<hhv_mac_hit> hits;
   void* d_block = nullptr;  // one allocation, carved below
+  size_t block_bytes = 0;
+  unsigned char* d_celloff = nullptr;
   float* d_mat = nullptr;
   int32_t* d_path_i = nullptr;
   int32_t* d_path_j = nullptr;
@@ -795,13 +800,28 @@ struct hhv_macset {
 void hhv_macset_free(hhv_macset* ms) {
   if (!ms) return;
   if (ms->ctx) (void)hipSetDevice(ms->ctx->par.device);
-  dfree(ms->d_block);
+  if (ms->ctx && ms->d_block && ms->block_bytes > ms->ctx->mac_cache_bytes) {
+    // keep the larger block for the next batch (the next round / the next query) instead of hipFree + hipMalloc
+    dfree(ms->ctx->mac_cache);
+    ms->ctx->mac_cache = ms->d_block;
+    ms->ctx->mac_cache_bytes = ms->block_bytes;
+  } else {
+    dfree(ms->d_block);
+  }
   delete ms;
 }
 
-int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
-                    const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff, int32_t local,
-                    float shift, float mact, hhv_macset** out, hhv_mac_hit* hits) {
+struct MacMaskInput {  // what hhv_mac_realign_hits adds: masks are built on the device
+  const hhv_mac_input* in = nullptr;
+  int32_t n_qranges = 0, n_tranges = 0;
+  const int32_t* qranges = nullptr;
+  const int32_t* tranges = nullptr;
+};
+
+static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                            const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff,
+                            const MacMaskInput* mi, int32_t local, float shift, float mact, hhv_macset** out,
+                            hhv_mac_hit* hits) {
   if (!c || !q_p || !q_tr_lin || !Lt || !t_p || !t_tr_lin || !out || !hits) return fail(HHV_E_ARG, "hhv_mac_realign: null argument");
   *out = nullptr;
   if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
@@ -829,6 +849,43 @@ int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t
     col_off[k + 1] = col_off[k] + Lt[k] + 1;
   }
   const int64_t cells = ms->mat_off[n], steps = ms->path_off[n], cols = col_off[n];
+  // device-built masks: Viterbi paths and excluded cells, concatenated
+  std::vector<int64_t> vit_off(n + 1, 0), excl_off(n + 1, 0);
+  std::vector<int32_t> vit_i, vit_j, excl_i, excl_j, ends, ranges;
+  if (mi) {
+    for (int k = 0; k < n; ++k) {
+      const hhv_mac_input& h = mi->in[k];
+      if (h.nsteps < 0 || h.n_excluded < 0 || (h.nsteps > 0 && (!h.i || !h.j)) || (h.n_excluded > 0 && (!h.excluded_i || !h.excluded_j))) {
+        delete ms;
+        return fail(HHV_E_ARG, "hhv_mac_realign_hits: bad input %d", k);
+      }
+      vit_off[k + 1] = vit_off[k] + h.nsteps;
+      excl_off[k + 1] = excl_off[k] + h.n_excluded;
+    }
+    vit_i.resize((size_t)vit_off[n] + 1);
+    vit_j.resize((size_t)vit_off[n] + 1);
+    excl_i.resize((size_t)excl_off[n] + 1);
+    excl_j.resize((size_t)excl_off[n] + 1);
+    ends.resize((size_t)n * 4);
+    for (int k = 0; k < n; ++k) {
+      const hhv_mac_input& h = mi->in[k];
+      if (h.nsteps) {
+        memcpy(&vit_i[(size_t)vit_off[k]], h.i + 1, (size_t)h.nsteps * 4);  // entries 1..nsteps
+        memcpy(&vit_j[(size_t)vit_off[k]], h.j + 1, (size_t)h.nsteps * 4);
+      }
+      if (h.n_excluded) {
+        memcpy(&excl_i[(size_t)excl_off[k]], h.excluded_i, (size_t)h.n_excluded * 4);
+        memcpy(&excl_j[(size_t)excl_off[k]], h.excluded_j, (size_t)h.n_excluded * 4);
+      }
+      ends[(size_t)k * 4 + 0] = h.i1;
+      ends[(size_t)k * 4 + 1] = h.j1;
+      ends[(size_t)k * 4 + 2] = h.i2;
+      ends[(size_t)k * 4 + 3] = h.j2;
+    }
+    for (int r = 0; r < mi->n_qranges * 2; ++r) ranges.push_back(mi->qranges[r]);
+    for (int r = 0; r < mi->n_tranges * 2; ++r) ranges.push_back(mi->tranges[r]);
+  }
+  ranges.push_back(0);
   // carve one device allocation (256-byte aligned pieces)
   size_t total = 0;
   auto carve = [&](size_t bytes) {
@@ -843,18 +900,30 @@ int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t
                o_hits = carve((size_t)n * sizeof(DevMacHit)), o_poff = carve((size_t)n * 8), o_pi = carve((size_t)steps * 4),
                o_pj = carve((size_t)steps * 4), o_ps = carve((size_t)steps), o_pS = carve((size_t)steps * 4),
                o_pP = carve((size_t)steps * 4);
-  if (hipMalloc(&ms->d_block, total) != hipSuccess) {
+  const size_t path_bytes = total - o_pi;
+  const size_t o_ends = carve(ends.size() * 4 + 16), o_voff = carve((size_t)(n + 1) * 8), o_vi = carve(vit_i.size() * 4 + 4),
+               o_vj = carve(vit_j.size() * 4 + 4), o_xoff = carve((size_t)(n + 1) * 8), o_xi = carve(excl_i.size() * 4 + 4),
+               o_xj = carve(excl_j.size() * 4 + 4), o_rg = carve(ranges.size() * 4);
+  if (c->mac_cache && c->mac_cache_bytes >= total) {
+    ms->d_block = c->mac_cache;
+    ms->block_bytes = c->mac_cache_bytes;
+    c->mac_cache = nullptr;
+    c->mac_cache_bytes = 0;
+  } else if (hipMalloc(&ms->d_block, total) != hipSuccess) {
     delete ms;
     return fail(HHV_E_MEMORY, "hhv_mac_realign: cannot allocate %zu bytes on the device", total);
+  } else {
+    ms->block_bytes = total;
   }
   char* base = (char*)ms->d_block;
   // host staging of the ragged inputs
   std::vector<float> tp((size_t)cols * 20), ttr((size_t)cols * 7);
-  std::vector<unsigned char> co((size_t)cells, 0);
+  std::vector<unsigned char> co;
+  if (!mi) co.assign((size_t)cells, 0);
   for (int k = 0; k < n; ++k) {
     memcpy(&tp[(size_t)col_off[k] * 20], t_p[k], (size_t)(Lt[k] + 1) * 20 * 4);
     memcpy(&ttr[(size_t)col_off[k] * 7], t_tr_lin[k], (size_t)(Lt[k] + 1) * 7 * 4);
-    if (celloff && celloff[k]) {
+    if (!mi && celloff && celloff[k]) {
       unsigned char* dst = &co[(size_t)ms->mat_off[k]];
       const uint8_t* src = celloff[k];
       for (size_t e = 0; e < (size_t)(Lq + 1) * (Lt[k] + 1); ++e) dst[e] = src[e] ? 1 : 0;
@@ -869,7 +938,15 @@ int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t
       hipMemcpyAsync(base + o_col, col_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(base + o_Lt, Lt, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(base + o_moff, ms->mat_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(base + o_co, co.data(), co.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+      (!mi && hipMemcpyAsync(base + o_co, co.data(), co.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
+      (mi && (hipMemcpyAsync(base + o_ends, ends.data(), ends.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_voff, vit_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_vi, vit_i.data(), vit_i.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_vj, vit_j.data(), vit_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_xoff, excl_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_xi, excl_i.data(), excl_i.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_xj, excl_j.data(), excl_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_rg, ranges.data(), ranges.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess)) ||
       hipMemcpyAsync(base + o_poff, ms->path_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(HHV_E_DEVICE, "hhv_mac_realign: H2D copy failed");
   MacArgs a;
@@ -899,6 +976,7 @@ int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t
   a.lg2 = c->d_lg2;
   a.diff = c->d_diff;
   ms->d_mat = a.mat;
+  ms->d_celloff = (unsigned char*)(base + o_co);
   ms->d_path_i = a.path_i;
   ms->d_path_j = a.path_j;
   ms->d_path_state = a.path_state;
@@ -906,21 +984,36 @@ int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t
   ms->d_path_P = a.path_P;
   if (rc == HHV_OK) {
     (void)hipEventRecord(c->ev0, st);
-    const int lr = launch_mac(a, local != 0, max_Lt, st);
+    int lr = 0;
+    if (mi) {
+      MacMaskArgs m;
+      m.ends = (const int4*)(base + o_ends);
+      m.vit_off = (const int64_t*)(base + o_voff);
+      m.vit_i = (const int32_t*)(base + o_vi);
+      m.vit_j = (const int32_t*)(base + o_vj);
+      m.excl_off = (const int64_t*)(base + o_xoff);
+      m.excl_i = (const int32_t*)(base + o_xi);
+      m.excl_j = (const int32_t*)(base + o_xj);
+      m.ranges = (const int32_t*)(base + o_rg);
+      m.n_qranges = mi->n_qranges;
+      m.n_tranges = mi->n_tranges;
+      lr = launch_mac_mask(a, m, st);
+    }
+    if (lr == 0) lr = launch_mac(a, local != 0, max_Lt, st);
     (void)hipEventRecord(c->ev1, st);
     c->ev_valid = true;
     if (lr != 0) rc = fail(HHV_E_DEVICE, "MAC kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
   }
   static_assert(sizeof(DevMacHit) == sizeof(hhv_mac_hit), "hhv_mac_hit layout");
   ms->hits.resize(n);
-  ms->h_paths.resize(total - o_pi);
+  ms->h_paths.resize(path_bytes);
   ms->h_pi = 0;
   ms->h_pj = o_pj - o_pi;
   ms->h_ps = o_ps - o_pi;
   ms->h_pS = o_pS - o_pi;
   ms->h_pP = o_pP - o_pi;
   if (rc == HHV_OK && (hipMemcpyAsync(ms->hits.data(), base + o_hits, (size_t)n * sizeof(hhv_mac_hit), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                       hipMemcpyAsync(ms->h_paths.data(), base + o_pi, total - o_pi, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                       hipMemcpyAsync(ms->h_paths.data(), base + o_pi, path_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
                        hipStreamSynchronize(st) != hipSuccess))
     rc = fail(HHV_E_DEVICE, "hhv_mac_realign: kernels failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc != HHV_OK) {
@@ -929,6 +1022,34 @@ int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t
   }
   memcpy(hits, ms->hits.data(), (size_t)n * sizeof(hhv_mac_hit));
   *out = ms;
+  return HHV_OK;
+}
+
+int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                    const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff, int32_t local,
+                    float shift, float mact, hhv_macset** out, hhv_mac_hit* hits) {
+  return mac_realign_impl(c, q_p, q_tr_lin, Lq, n, Lt, t_p, t_tr_lin, celloff, nullptr, local, shift, mact, out, hits);
+}
+
+int hhv_mac_realign_hits(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                         const float* const* t_p, const float* const* t_tr_lin, const hhv_mac_input* in, int32_t n_qranges,
+                         const int32_t* qranges, int32_t n_tranges, const int32_t* tranges, int32_t local, float shift,
+                         float mact, hhv_macset** out, hhv_mac_hit* hits) {
+  if (!in || n_qranges < 0 || n_tranges < 0 || (n_qranges && !qranges) || (n_tranges && !tranges))
+    return fail(HHV_E_ARG, "hhv_mac_realign_hits: bad argument");
+  MacMaskInput mi;
+  mi.in = in;
+  mi.n_qranges = n_qranges;
+  mi.qranges = qranges;
+  mi.n_tranges = n_tranges;
+  mi.tranges = tranges;
+  return mac_realign_impl(c, q_p, q_tr_lin, Lq, n, Lt, t_p, t_tr_lin, nullptr, &mi, local, shift, mact, out, hits);
+}
+
+int hhv_mac_celloff(hhv_macset* ms, int32_t k, uint8_t* mask) {
+  if (!ms || k < 0 || k >= ms->n || !mask) return fail(HHV_E_ARG, "hhv_mac_celloff: bad argument");
+  HIP_TRY(hipSetDevice(ms->ctx->par.device));
+  HIP_TRY(hipMemcpy(mask, ms->d_celloff + ms->mat_off[k], (size_t)(ms->Lq + 1) * (ms->Lt[k] + 1), hipMemcpyDeviceToHost));
   return HHV_OK;
 }
 

@@ -155,6 +155,18 @@ struct MacArgs {
   const float* lg2;
   const float* diff;
 };
+struct MacMaskArgs {
+  const int4* ends;          // [n] i1, j1, i2, j2 of the Viterbi alignment
+  const int64_t* vit_off;    // [n+1] Viterbi path steps (entries 1..nsteps of Hit::i / ::j, concatenated)
+  const int32_t* vit_i;
+  const int32_t* vit_j;
+  const int64_t* excl_off;   // [n+1] cells of earlier MAC alignments of the same template (alt_i / alt_j)
+  const int32_t* excl_i;
+  const int32_t* excl_j;
+  const int32_t* ranges;     // n_qranges query row ranges, then n_tranges template column ranges, (lo, hi) pairs
+  int32_t n_qranges, n_tranges;
+};
+int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream);
 int launch_mac(const MacArgs& a, bool local, int max_Lt, void* stream);
 
 // launchers implemented in hhv_kernels.hip

@@ -495,6 +495,65 @@ __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
 
 #undef ROW
 
+// ---- the cell-off mask realign() builds (src/hhposteriordecoder.cpp:92-109), one workgroup per hit ------------------
+//   maskViterbiAlignment (:205-240): everything off except the rectangles above-left of (i1,j1) and below-right of
+//   (i2,j2); then +-40 rows / columns around every step of the Viterbi path on;   excludeMACAlignment (:245-262): the
+//   +-2 cross of every cell of the earlier MAC alignments off;   exclude_regions / exclude_template_regions (:121-149).
+// (Viterbi::InitializeForAlignment's minimum-overlap corners are overwritten by maskViterbiAlignment and left out.)
+__global__ void __launch_bounds__(256) hhv_mac_mask_kernel(MacArgs a, MacMaskArgs m) {
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int Lq = a.Lq, Lt = a.Lt[k], pitch = Lt + 1;
+  unsigned char* co = const_cast<unsigned char*>(a.celloff) + a.mat_off[k];
+  const int4 e = m.ends[k];  // i1, j1, i2, j2
+  const int cells = (Lq + 1) * pitch;
+  for (int c = tid; c < cells; c += 256) {
+    const int i = c / pitch, j = c - i * pitch;
+    co[c] = (i >= 1 && j >= 1) ? !((i < e.x && j < e.y) || (i > e.z && j > e.w)) : 0;
+  }
+  __syncthreads();
+  const int64_t v0 = m.vit_off[k];
+  const int ns = (int)(m.vit_off[k + 1] - v0);
+  constexpr int W = 2 * 40 + 1;  // FWD_BKW_PATHWITDH = 40 (src/hhdecl.h:37)
+  for (int w = tid; w < ns * W; w += 256) {
+    const int step = w / W, d = w - step * W - 40;
+    const int pi = m.vit_i[v0 + step], pj = m.vit_j[v0 + step];
+    if (pi + d >= 1 && pi + d <= Lq && pj >= 1 && pj <= Lt) co[(size_t)(pi + d) * pitch + pj] = 0;
+    if (pj + d >= 1 && pj + d <= Lt && pi >= 1 && pi <= Lq) co[(size_t)pi * pitch + pj + d] = 0;
+  }
+  __syncthreads();
+  const int64_t x0 = m.excl_off[k];
+  const int nx = (int)(m.excl_off[k + 1] - x0);
+  for (int w = tid; w < nx * 5; w += 256) {
+    const int c = w / 5, d = w - c * 5 - 2;
+    const int pi = m.excl_i[x0 + c], pj = m.excl_j[x0 + c];
+    if (pi + d >= 1 && pi + d <= Lq && pj >= 0 && pj <= Lt) co[(size_t)(pi + d) * pitch + pj] = 1;
+    if (pj + d >= 1 && pj + d <= Lt && pi >= 0 && pi <= Lq) co[(size_t)pi * pitch + pj + d] = 1;
+  }
+  for (int r = 0; r < m.n_qranges; ++r) {
+    const int lo = m.ranges[2 * r], hi = min(m.ranges[2 * r + 1], Lq);
+    for (int c = tid; c < (hi - lo + 1) * Lt; c += 256) {
+      const int i = lo + c / Lt, j = 1 + c % Lt;
+      if (i >= 0) co[(size_t)i * pitch + j] = 1;
+    }
+  }
+  for (int r = 0; r < m.n_tranges; ++r) {
+    const int lo = m.ranges[2 * (m.n_qranges + r)], hi = min(m.ranges[2 * (m.n_qranges + r) + 1], Lt);
+    for (int c = tid; c < (hi - lo + 1) * Lq; c += 256) {
+      const int j = lo + c / Lq, i = 1 + c % Lq;
+      if (j >= 0) co[(size_t)i * pitch + j] = 1;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c <= Lt; c += 256) co[c] = 0;  // row / column 0 are never read
+  for (int c = tid; c <= Lq; c += 256) co[(size_t)c * pitch] = 0;
+}
+
+int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
+  hipLaunchKernelGGL(hhv_mac_mask_kernel, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a, m);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 int launch_mac(const MacArgs& a, bool local, int max_Lt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const size_t lds_rows = (size_t)10 * (max_Lt + 2) * sizeof(double), lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);

@@ -5,9 +5,16 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 
 namespace hhv {
+
+// wall-clock split of the last executeComputation: masks (host), hhv_mac_realign (staging + kernels + copies), paths
+static double g_mac_ms[3] = {0, 0, 0};
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 namespace {
 enum { M2M = 0, M2I = 1, M2D = 2, I2M = 3, I2I = 4, D2M = 5, D2D = 6 };  // src/hhdecl.h:68
@@ -96,32 +103,51 @@ std::vector<MacAlignment> PosteriorDecoderRunner::executeComputation(const MacPa
     std::stable_sort(g->second.begin(), g->second.end(), [&](int a, int b) { return hits[a].irep < hits[b].irep; });
     rounds = std::max(rounds, g->second.size());
   }
+  g_mac_ms[0] = g_mac_ms[1] = g_mac_ms[2] = 0;
   for (size_t r = 0; r < rounds; ++r) {
+    const double t_start = now_ms();
     std::vector<int> batch;  // hit indices of this round
     for (std::map<int, std::vector<int> >::iterator g = groups.begin(); g != groups.end(); ++g)
       if (g->second.size() > r) batch.push_back(g->second[r]);
     const int n = (int)batch.size();
-    std::vector<std::vector<uint8_t> > masks(n);
-    std::vector<const uint8_t*> mask_ptr(n);
+    // what the device needs to build the masks realign() builds (MacCellOff above is the host statement of the same)
+    std::vector<hhv_mac_input> in(n);
+    std::vector<std::vector<int32_t> > ex_i(n), ex_j(n);
     std::vector<const float*> tp(n), ttr(n);
     std::vector<int32_t> Lt(n);
     for (int b = 0; b < n; ++b) {
       const MacInput& hit = hits[batch[b]];
       const Profile& t = templates[hit.entry];
-      std::vector<const MacAlignment*> earlier;
       const std::vector<int>& grp = groups[hit.entry];
-      for (size_t e = 0; e < r; ++e) earlier.push_back(&out[grp[e]]);
-      MacCellOff(q.L, t.L, par, hit, earlier, &masks[b]);
-      mask_ptr[b] = masks[b].data();
+      for (size_t e = 0; e < r; ++e) {
+        const MacAlignment& al = out[grp[e]];
+        for (int s = (al.nsteps == 0 ? 0 : 1); s <= al.nsteps; ++s) {
+          ex_i[b].push_back(al.i[s]);
+          ex_j[b].push_back(al.j[s]);
+        }
+      }
+      in[b].i1 = hit.i1;
+      in[b].j1 = hit.j1;
+      in[b].i2 = hit.i2;
+      in[b].j2 = hit.j2;
+      in[b].nsteps = hit.nsteps;
+      in[b].i = hit.i;
+      in[b].j = hit.j;
+      in[b].n_excluded = (int32_t)ex_i[b].size();
+      in[b].excluded_i = ex_i[b].data();
+      in[b].excluded_j = ex_j[b].data();
       tp[b] = t.p;
       ttr[b] = t.tr;
       Lt[b] = t.L;
     }
+    const std::vector<int32_t> qr = ParseRegions(par.exclstr), tr = ParseRegions(par.template_exclstr);
+    const double t_masks = now_ms();
     hhv_macset* ms = nullptr;
     std::vector<hhv_mac_hit> res(n);
-    int rc = hhv_mac_realign(ctx_, q.p, q.tr, q.L, n, Lt.data(), tp.data(), ttr.data(), mask_ptr.data(), par.loc, par.shift,
-                             par.mact, &ms, res.data());
+    int rc = hhv_mac_realign_hits(ctx_, q.p, q.tr, q.L, n, Lt.data(), tp.data(), ttr.data(), in.data(), (int32_t)qr.size() / 2,
+                                  qr.data(), (int32_t)tr.size() / 2, tr.data(), par.loc, par.shift, par.mact, &ms, res.data());
     if (rc != HHV_OK) throw Error(rc, hhv_last_error());
+    const double t_dp = now_ms();
     for (int b = 0; b < n; ++b) {
       MacAlignment& al = out[batch[b]];
       al.entry = hits[batch[b]].entry;
@@ -148,6 +174,9 @@ std::vector<MacAlignment> PosteriorDecoderRunner::executeComputation(const MacPa
       }
     }
     hhv_macset_free(ms);
+    g_mac_ms[0] += t_masks - t_start;
+    g_mac_ms[1] += t_dp - t_masks;
+    g_mac_ms[2] += now_ms() - t_dp;
   }
   return out;
 }
@@ -155,6 +184,8 @@ std::vector<MacAlignment> PosteriorDecoderRunner::executeComputation(const MacPa
 }  // namespace hhv
 
 extern "C" {
+
+void hhvr_mac_last_timing(double* ms3) { memcpy(ms3, hhv::g_mac_ms, sizeof(hhv::g_mac_ms)); }
 
 void hhvr_linear_transitions(const float* tr_log2, int32_t L, int32_t is_query, float* out) {
   hhv::LinearTransitions(tr_log2, L, is_query != 0, out);

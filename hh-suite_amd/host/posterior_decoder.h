@@ -82,6 +82,7 @@ int hhvr_mac_realign(hhv_ctx* ctx, int32_t loc, float shift, float mact, int32_t
                      const int32_t* hit_rows, const int64_t* path_off, const int32_t* path_i, const int32_t* path_j,
                      int32_t* out_scalars, double* out_real, int32_t pcap, int32_t* out_i, int32_t* out_j, int8_t* out_states,
                      float* out_S, float* out_P);
+void hhvr_mac_last_timing(double* ms3 /* host masks, hhv_mac_realign, path fetch of the last run */);
 void hhvr_linear_transitions(const float* tr_log2, int32_t L, int32_t is_query, float* out);
 int hhvr_mac_celloff(int32_t Lq, int32_t Lt, int32_t min_overlap, const char* exclstr, const char* template_exclstr,
                      const int32_t* hit_row, const int32_t* path_i, const int32_t* path_j, int32_t n_prev,

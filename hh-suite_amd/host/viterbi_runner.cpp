@@ -53,6 +53,17 @@ bool next_int(const std::string& s, size_t& pos, int& out) {
 }
 }  // namespace
 
+std::vector<int32_t> ParseRegions(const std::string& exclstr) {
+  std::vector<int32_t> pairs;
+  size_t pos = 0;
+  int a, b;
+  while (next_int(exclstr, pos, a) && next_int(exclstr, pos, b)) {
+    pairs.push_back(std::max(1, std::abs(a)));
+    pairs.push_back(std::abs(b));
+  }
+  return pairs;
+}
+
 void ExcludeRegions(std::vector<uint8_t>& mask, int Lq, int Lt, const std::string& exclstr) {
   size_t pos = 0;
   int a, b;

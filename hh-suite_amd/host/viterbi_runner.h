@@ -83,6 +83,8 @@ void ExcludeAlignment(std::vector<uint8_t>& mask, int Lq, int Lt, const int32_t*
 // integers found in the string (parsed like strint, src/util.cpp:133-151, sign ignored) switches off the query
 // rows i0..i1 (resp. template columns j0..j1) of mask[(Lq+1)*(Lt+1)]
 void ExcludeRegions(std::vector<uint8_t>& mask, int Lq, int Lt, const std::string& exclstr);
+// the (lo, hi) pairs the two functions iterate over (lo = max(1, |a|), hi = |b|; the caller clips hi to the length)
+std::vector<int32_t> ParseRegions(const std::string& exclstr);
 void ExcludeTemplateRegions(std::vector<uint8_t>& mask, int Lq, int Lt, const std::string& exclstr);
 
 class ViterbiRunner {

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores",
-    "hhv_mac_realign", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
+    "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
@@ -110,9 +110,13 @@ def load():
                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_mac_realign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_float, C.c_float, C.POINTER(C.c_void_p), C.c_void_p]
+    L.hhv_mac_realign_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_float, C.c_float, C.POINTER(C.c_void_p), C.c_void_p]
     L.hhv_mac_path.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_int32)]
     L.hhv_mac_posterior.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.hhv_mac_celloff.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_macset_free.argtypes = [C.c_void_p]
     L.hhv_macset_free.restype = None
     L.hhv_db_write.argtypes = [C.c_char_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p,
@@ -333,6 +337,34 @@ class Context:
                                         int(local), shift, mact, C.byref(h), hits.ctypes.data))
         return MacSet(self.lib, h, hits, Lq, Lt)
 
+    def mac_realign_hits(self, qp, q_tr_lin, tps, t_trs, inputs, qranges=(), tranges=(), local=1, shift=-0.03, mact=0.3501):
+        """hhv_mac_realign_hits. inputs: list of (i1, j1, i2, j2, nsteps, i_steps, j_steps, excluded_i, excluded_j)."""
+        qp, q_tr_lin = _f32(qp), _f32(q_tr_lin)
+        tps = [_f32(a) for a in tps]
+        t_trs = [_f32(a) for a in t_trs]
+        n = len(tps)
+        Lq = qp.shape[0] - 1
+        Lt = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        pp = (C.c_void_p * n)(*[a.ctypes.data for a in tps])
+        tt = (C.c_void_p * n)(*[a.ctypes.data for a in t_trs])
+        arr = (MacInputStruct * n)()
+        keep = []
+        for k, (i1, j1, i2, j2, ns, vi, vj, xi, xj) in enumerate(inputs):
+            vi, vj = np.ascontiguousarray(vi, np.int32), np.ascontiguousarray(vj, np.int32)
+            xi, xj = np.ascontiguousarray(xi, np.int32), np.ascontiguousarray(xj, np.int32)
+            keep += [vi, vj, xi, xj]
+            arr[k] = MacInputStruct(i1, j1, i2, j2, ns, len(xi), vi.ctypes.data, vj.ctypes.data,
+                                    xi.ctypes.data if len(xi) else None, xj.ctypes.data if len(xj) else None)
+        qr = np.ascontiguousarray(qranges, np.int32).reshape(-1)
+        trg = np.ascontiguousarray(tranges, np.int32).reshape(-1)
+        hits = np.zeros(n, dtype=MAC_HIT_DTYPE)
+        h = C.c_void_p()
+        _check(self.lib.hhv_mac_realign_hits(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, n, Lt.ctypes.data, pp, tt,
+                                             C.addressof(arr), len(qr) // 2, qr.ctypes.data if len(qr) else None,
+                                             len(trg) // 2, trg.ctypes.data if len(trg) else None, int(local), shift, mact,
+                                             C.byref(h), hits.ctypes.data))
+        return MacSet(self.lib, h, hits, Lq, Lt)
+
     def db_open(self, path, Ls):
         h = C.c_void_p()
         _check(self.lib.hhv_db_open(self.h, path.encode(), C.byref(h)))
@@ -474,6 +506,12 @@ def runner_alignment(qp, qtr, tps, ttrs, loc=1, egq=0.0, egt=0.0, shift=-0.03, c
     return hits[:m], i_s[:m], j_s[:m], st[:m], S[:m]
 
 
+class MacInputStruct(C.Structure):
+    _fields_ = [("i1", C.c_int32), ("j1", C.c_int32), ("i2", C.c_int32), ("j2", C.c_int32), ("nsteps", C.c_int32),
+                ("n_excluded", C.c_int32), ("i", C.c_void_p), ("j", C.c_void_p), ("excluded_i", C.c_void_p),
+                ("excluded_j", C.c_void_p)]
+
+
 MAC_HIT_DTYPE = np.dtype([("Pforward", "<f8"), ("sum_of_probs", "<f4"), ("i1", "<i4"), ("j1", "<i4"), ("i2", "<i4"),
                           ("j2", "<i4"), ("nsteps", "<i4"), ("matched_cols", "<i4"), ("reserved", "<i4")])
 
@@ -495,6 +533,11 @@ class MacSet:
         _check(self.lib.hhv_mac_path(self.h, k, cap, i_s.ctypes.data, j_s.ctypes.data, st.ctypes.data, S.ctypes.data,
                                      P.ctypes.data, C.byref(ns)))
         return i_s, j_s, st, S, P
+
+    def celloff(self, k):
+        out = np.zeros((self.Lq + 1, int(self.Lt[k]) + 1), np.uint8)
+        _check(self.lib.hhv_mac_celloff(self.h, k, out.ctypes.data))
+        return out
 
     def posterior(self, k):
         out = np.zeros((self.Lq + 1, int(self.Lt[k]) + 1), np.float32)

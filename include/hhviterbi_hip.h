@@ -206,6 +206,25 @@ typedef struct hhv_macset hhv_macset;
 int hhv_mac_realign(hhv_ctx* ctx, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
                     const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff, int32_t local,
                     float shift, float mact, hhv_macset** out, hhv_mac_hit* hits);
+/* The same with the masks built ON THE DEVICE from what realign() derives them from (src/hhposteriordecoder.cpp:92-109):
+ * the Viterbi alignment of the hit (end points, path entries 1..nsteps of Hit::i / Hit::j), the cells of the MAC
+ * alignments found earlier for the same template (Hit::alt_i / alt_j, concatenated) and the -excl / -template_excl
+ * ranges ((lo, hi) pairs, already made absolute).  No (Lq+1)*(Lt+1) byte mask crosses the bus. */
+typedef struct hhv_mac_input {
+  int32_t i1, j1, i2, j2;
+  int32_t nsteps;
+  int32_t n_excluded;
+  const int32_t* i;           /* [nsteps+1], entry 0 unused */
+  const int32_t* j;
+  const int32_t* excluded_i;  /* [n_excluded] */
+  const int32_t* excluded_j;
+} hhv_mac_input;
+int hhv_mac_realign_hits(hhv_ctx* ctx, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                         const float* const* t_p, const float* const* t_tr_lin, const hhv_mac_input* in, int32_t n_qranges,
+                         const int32_t* qranges, int32_t n_tranges, const int32_t* tranges, int32_t local, float shift,
+                         float mact, hhv_macset** out, hhv_mac_hit* hits);
+/* the mask of hit k as the kernels saw it, (Lq+1)*(Lt+1) bytes */
+int hhv_mac_celloff(hhv_macset* ms, int32_t k, uint8_t* mask);
 /* path of hit k: entries 1..nsteps (Hit::i, ::j, ::states, ::S, ::P_posterior); cap >= nsteps + 1 */
 int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps, int8_t* states, float* S,
                  float* P_posterior, int32_t* nsteps);

@@ -184,6 +184,35 @@ def test_gpu_mac_matches_oracle(oracle, local):
 
 
 @pytest.mark.gpu
+def test_gpu_device_masks_equal_host_masks(oracle):
+    """hhv_mac_realign_hits builds the masks on the device: same bytes as hhv::MacCellOff (pinned to the reference above),
+    including excluded cells of earlier alignments and -excl / -template_excl ranges."""
+    from pyhhv import capi
+    Lq = 130
+    qp, qtr = synth.make_query(31, Lq)
+    q_lin = capi.linear_transitions(qtr, True)
+    tps, t_lins, inputs, want = [], [], [], []
+    rng = np.random.default_rng(8)
+    for k, Lt in enumerate([50, 127, 128, 260, 5]):
+        tp, ttr = synth.make_homolog(300 + k, qp, L=Lt)
+        vit = oracle.align(make_params(local=1, ss_mode=0), qp, qtr, tp, ttr, want_path=True)
+        ns = vit.nsteps
+        nx = int(rng.integers(0, 40))
+        xi, xj = rng.integers(1, Lq + 1, nx).astype(np.int32), rng.integers(1, Lt + 1, nx).astype(np.int32)
+        hit = (int(vit.i_steps[ns]), int(vit.j_steps[ns]), vit.i2, vit.j2, ns, vit.i_steps, vit.j_steps)
+        want.append(capi.mac_celloff(Lq, Lt, hit, [(xi, xj)] if nx else [], exclstr="10-20,100-400", template_exclstr="3-4"))
+        inputs.append(hit + (xi, xj))
+        tps.append(tp)
+        t_lins.append(capi.linear_transitions(ttr, False))
+    c = capi.Context()
+    ms = c.mac_realign_hits(qp, q_lin, tps, t_lins, inputs, qranges=[10, 20, 100, 400], tranges=[3, 4])
+    for k in range(len(tps)):
+        assert np.array_equal(ms.celloff(k), want[k]), k
+    ms.free()
+    c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_mac_batch_of_ragged_hits(oracle):
     """Many hits of one query in one launch (ragged Lt, some without mask) equal the same hits done one by one."""
     from pyhhv import capi

@@ -42,8 +42,12 @@ def main():
     sc, re, o_i, o_j, o_s, o_S, o_P = capi.runner_mac_realign(c, qp, q_lin, tps, t_lins, hits)
     wall = time.perf_counter() - t0
     kms = c.last_kernel_ms()
+    import ctypes
+    t3 = (ctypes.c_double * 3)()
+    capi.load_runner().hhvr_mac_last_timing(t3)
     cells = float(n) * Lq * Lt
     out = {"n_hits": n, "Lq": Lq, "Lt": Lt, "gpu_kernels_ms": round(kms, 3), "gpu_wall_ms_incl_host_masks": round(wall * 1e3, 2),
+           "host_ms_masks_realign_fetch": [round(v, 2) for v in t3],
            "gpu_hits_per_s": n / (kms * 1e-3), "gpu_cells_per_s": cells / (kms * 1e-3),
            "mean_nsteps": float(sc[:, 0].mean()), "mean_sum_of_probs": float(re[:, 1].mean())}
     if sample:
