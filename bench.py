@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs1", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the short measurements of the SURVEY 8f rows (N2-N4)")
     return ap.parse_args()
 
 
@@ -282,6 +283,9 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, rec, rec_off, Ls, ctx, ts, qf, qtr, n, Lq)
 
+    if rank == 0 and world == 1 and not args.no_next_rows and not bt and args.lengths == "fixed":
+        out["next_rows"] = next_rows()
+
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -290,6 +294,33 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def next_rows():
+    """Short measurements of the callers either side of the path, each checked against the oracle / the
+    reference on a sample: prefilter kernels (N3) and MAC realignment (N4).  Not part of `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    out = {}
+    try:
+        import bench_prefilter
+        r = bench_prefilter.run(200000, 300, 50)
+        out["N3_prefilter"] = {"db_sequences": r["n_db"], "db_residues": r["residues"], "Lq": r["Lq"],
+                               "gapless_cells_per_s": r["ungapped"]["cells_per_s"], "gapless_kernel_ms": r["ungapped"]["kernel_ms"],
+                               "sw_cells_per_s": r["gapped"]["cells_per_s"], "sw_kernel_ms": r["gapped"]["kernel_ms"],
+                               "mismatches_vs_oracle": r["ungapped"]["mismatches"] + r["gapped"]["mismatches"],
+                               "checked": r["ungapped"]["checked"] + r["gapped"]["checked"]}
+    except Exception as e:  # the headline line must not depend on the side measurements
+        out["N3_prefilter"] = {"error": repr(e)}
+    try:
+        import bench_mac
+        r = bench_mac.run(500, 300, 300, 8)
+        out["N4_mac_realign"] = {"hits": r["n_hits"], "Lq": r["Lq"], "Lt": r["Lt"], "kernels_ms": r["gpu_kernels_ms"],
+                                 "end_to_end_ms": r["gpu_wall_ms_incl_host_masks"], "hits_per_s": r["gpu_hits_per_s"],
+                                 "reference_hits_per_s_1core": r.get("ref_cpu_hits_per_s_1core"),
+                                 "mismatches_vs_reference": r.get("mismatches_vs_reference"), "checked": r.get("checked")}
+    except Exception as e:
+        out["N4_mac_realign"] = {"error": repr(e)}
+    return out
 
 
 def cpu_baseline(args, rec, rec_off, Ls, ctx, ts, qf, qtr, n, Lq):

@@ -14,11 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from pyhhv import capi, synth  # noqa: E402
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-    Lq = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    Lt = int(sys.argv[3]) if len(sys.argv) > 3 else 300
-    sample = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+def run(n=500, Lq=300, Lt=300, sample=16):
     qp, qtr = synth.make_query(11, Lq)
     tps, ttrs = [], []
     for k in range(n):
@@ -75,7 +71,15 @@ def main():
         out["ref_cpu_ms_per_hit_1core"] = round(t_ref / out["checked"] * 1e3, 3)
         out["ref_cpu_hits_per_s_1core"] = out["checked"] / t_ref
     c.close()
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+    Lq = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    Lt = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    sample = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+    print(json.dumps(run(n, Lq, Lt, sample)))
 
 
 if __name__ == "__main__":

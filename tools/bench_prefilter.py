@@ -13,10 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from pyhhv import capi  # noqa: E402
 
 
-def main():
-    n_db = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-    Lq = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    check_n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+def run(n_db=1000000, Lq=300, check_n=300):
     rng = np.random.default_rng(7)
     lens = np.clip(rng.gamma(2.2, 140.0, n_db), 30, 2000).astype(np.int64)
     offs = np.zeros(n_db + 1, dtype=np.int64)
@@ -51,7 +48,14 @@ def main():
             out[name]["mismatches"] = bad
     c.prefilter_free_db(db)
     c.close()
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    n_db = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    Lq = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    check_n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    print(json.dumps(run(n_db, Lq, check_n)))
 
 
 if __name__ == "__main__":
