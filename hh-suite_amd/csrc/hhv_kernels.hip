@@ -53,6 +53,10 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int c
 template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS>
 __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   __shared__ float4 ring[RING_RECS * 7];
+  // backtrace variants: {m2d, d2d, m2i, i2i} of the lane's R query rows live in LDS (20 floats per lane: stride 20
+  // dwords is conflict-free for ds_read_b128) - the VGPRs they would occupy hold the compare results instead
+  constexpr bool QL = BT;
+  __shared__ float4 qlds[QL ? LANES * 5 : 1];
   const int lane = threadIdx.x;
   const int64_t rb = a.wave_rec[blockIdx.x];
   const int64_t re = a.wave_rec[blockIdx.x + 1];
@@ -79,6 +83,16 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 
   QRows<R> q;
   q.load(a.qpack + (size_t)lane * R * REC_DW);
+  if (QL) {
+    float* w = reinterpret_cast<float*>(qlds) + lane * 20;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      w[4 * r + 0] = q.m2d[r];
+      w[4 * r + 1] = q.d2d[r];
+      w[4 * r + 2] = q.m2i[r];
+      w[4 * r + 3] = q.i2i[r];
+    }
+  }
   LaneState<R> st;
   st.reset();
   int ss_qoff[R];
@@ -167,7 +181,10 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #pragma unroll
           for (int r = 0; r < R; ++r) ssv[r] = a.ss_table[ss_qoff[r] + tidx];
         }
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT, SS>(st, q, in, rec, j, i0, r_last, P, cell, ssv);
+        const float* ql = reinterpret_cast<const float*>(qlds) + lane * 20;
+        if (QL) asm volatile("" : "+v"(ql));  // keep the LDS reads inside the loop (they are loop invariant)
+        const uint64_t bytes =
+            lane_column<R, LOCAL, BT, CELLOFF, !BT, SS, QL>(st, q, in, rec, j, i0, r_last, P, cell, ssv, ql);
         if (BT) *bte = bytes;
       }
       if (carry_out) {

@@ -267,9 +267,12 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
 // kernel); C (rows top-down) MM += S, then DG and MI which chain through the row above.
 //   ssv      : SS only - ssv[r] = ssw * S[q_ss(i0+r)][t_ss(j)], the secondary-structure term of the ...AndSS
 //              builds (src/hhviterbialgorithm.cpp:194-213,278-280), added as ss + log2f4(..) like the reference
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS>
+//   ql       : QL only - this lane's four "second tier" query transitions per row, {m2d, d2d, m2i, i2i} x R, kept in
+//              LDS instead of VGPRs (the backtrace variants need the registers for the compare results)
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, bool QL = false>
 HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const float* rec, int j, int i0,
-                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv) {
+                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv,
+                             const float* ql = nullptr) {
   const float smin = LOCAL ? 0.0f : NEG_MAX;
   const float tM2M = rec[REC_M2M], tM2D = rec[REC_M2D], tD2M = rec[REC_D2M], tD2D = rec[REC_D2D],
               tI2M = rec[REC_I2M], tI2I = rec[REC_I2I], tM2I = rec[REC_M2I];
@@ -306,7 +309,8 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     // :307-332 (GD and IM read only the cell to the left)
     const float lMM = st.MM[r];
     const float ga = lMM + tM2D, gb = st.GD[r] + tD2D;
-    const float ia = (lMM + q.m2i[r]) + tM2M, ib = (st.IM[r] + q.i2i[r]) + tM2M;
+    const float qm2i = QL ? ql[4 * r + 2] : q.m2i[r], qi2i = QL ? ql[4 * r + 3] : q.i2i[r];
+    const float ia = (lMM + qm2i) + tM2M, ib = (st.IM[r] + qi2i) + tM2M;
     if (BT) {
       b |= (ga > gb) ? 8u : 0u;
       b |= (ia > ib) ? 16u : 0u;
@@ -330,7 +334,8 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   for (int r = 0; r < R; ++r) {
     float mm = cmax[r] + S[r];
     // :340-366
-    const float da = uMM + q.m2d[r], db = uDG + q.d2d[r];
+    const float qm2d = QL ? ql[4 * r + 0] : q.m2d[r], qd2d = QL ? ql[4 * r + 1] : q.d2d[r];
+    const float da = uMM + qm2d, db = uDG + qd2d;
     float dg = fmax2(da, db);
     const float sa = uMM + q.m2m[r], sb = uMI + q.m2m[r];
     const float ma = sa + tM2I, mb = sb + tI2I;
