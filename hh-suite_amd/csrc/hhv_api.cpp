@@ -615,6 +615,8 @@ struct hhv_pfdb {
   int32_t n = 0;
   int64_t total = 0;
   unsigned char* d_seqs = nullptr;
+  unsigned char* d_carry[2] = {nullptr, nullptr};  // slab-to-slab diagonals of the gapless kernel (long queries), lazily
+  size_t padded = 0;
   int64_t* d_off = nullptr;
   int32_t* d_order_all = nullptr;   // all sequences, longest first
   std::vector<int32_t> length;      // host copy of the lengths
@@ -656,6 +658,7 @@ int hhv_prefilter_upload_db(hhv_ctx* c, int32_t n_db, const uint8_t* seqs, const
   std::vector<int32_t> order;
   order_by_length(db->length, nullptr, n_db, db->max_len, &order);
   const size_t padded = ((size_t)total + 3) / 4 * 4 + 16;  // the kernels read whole aligned dwords
+  db->padded = padded;
   if (hipMalloc(&db->d_seqs, padded) != hipSuccess || hipMalloc(&db->d_off, (size_t)(n_db + 1) * sizeof(int64_t)) != hipSuccess ||
       hipMalloc(&db->d_order_all, (size_t)n_db * sizeof(int32_t)) != hipSuccess ||
       hipMemset(db->d_seqs + ((size_t)total / 4 * 4), 0, padded - (size_t)total / 4 * 4) != hipSuccess ||
@@ -673,6 +676,8 @@ void hhv_prefilter_free_db(hhv_pfdb* db) {
   if (!db) return;
   if (db->ctx) (void)hipSetDevice(db->ctx->par.device);
   dfree(db->d_seqs);
+  dfree(db->d_carry[0]);
+  dfree(db->d_carry[1]);
   dfree(db->d_off);
   dfree(db->d_order_all);
   delete db;
@@ -694,8 +699,11 @@ int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32
 
   // kernel choice.  Fast kernels: profile as int8 (q - offset) in LDS, state in registers.
   const int W32 = (Lq + 31) / 32;  // 32 unsigned bytes per AVX2 vector of the reference (VECSIZE_INT * 4)
-  const int Wfast = gapped ? W32 : (Lq + 63) / 64;
-  bool fast = Lq <= 512 && score_offset <= 128 && !getenv("HHV_PREFILTER_GENERIC");
+  // gapless: slabs of up to 512 query rows (W <= 8 cells per lane), any Lq; Smith-Waterman: W32 <= 20 (Lq <= 640)
+  const int n_slabs = gapped ? 1 : (Lq + 511) / 512;
+  const int slab_rows = gapped ? Lq : (Lq + n_slabs - 1) / n_slabs;
+  const int Wfast = gapped ? W32 : (slab_rows + 63) / 64;
+  bool fast = (gapped ? Lq <= 640 : true) && score_offset <= 128 && !getenv("HHV_PREFILTER_GENERIC");
   if (fast)
     for (size_t e = 0; e < (size_t)220 * Lq; ++e)
       if ((int)profile[e] - score_offset > 127) {
@@ -754,13 +762,28 @@ int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32
     a.offset = score_offset;
     a.gap_init = gap_init;
     a.gap_extend = gap_extend;
+    a.q_base = 0;
+    a.carry_in = nullptr;
+    a.carry_out = nullptr;
     const int blocks_per_cu = std::max<int>(1, std::min<int>(fast ? 2 : 8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
     const int jobs_per_block = fast ? 16 : 8;
     const int n_blocks = (int)std::max<int64_t>(
         1, std::min<int64_t>((n_jobs + jobs_per_block - 1) / jobs_per_block, (int64_t)c->num_cus * blocks_per_cu));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    const int lr = fast ? launch_prefilter_fast(a, gapped != 0, Wfast, n_blocks, c->stream)
-                        : launch_prefilter_generic(a, gapped != 0, generic_prof_lds, n_blocks, lds, c->stream);
+    int lr = 0;
+    if (fast && n_slabs > 1) {
+      for (int b = 0; b < 2 && lr == 0; ++b)
+        if (!db->d_carry[b] && hipMalloc(&db->d_carry[b], db->padded) != hipSuccess) lr = -(int)hipErrorOutOfMemory;
+      for (int sl = 0; sl < n_slabs && lr == 0; ++sl) {
+        a.q_base = sl * Wfast * 64;
+        a.carry_in = sl ? db->d_carry[(sl - 1) & 1] : nullptr;
+        a.carry_out = sl + 1 < n_slabs ? db->d_carry[sl & 1] : nullptr;
+        lr = launch_prefilter_fast(a, false, Wfast, n_blocks, c->stream);
+      }
+    } else {
+      lr = fast ? launch_prefilter_fast(a, gapped != 0, Wfast, n_blocks, c->stream)
+                : launch_prefilter_generic(a, gapped != 0, generic_prof_lds, n_blocks, lds, c->stream);
+    }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     if (lr != 0) rc = fail(HHV_E_DEVICE, "prefilter kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));

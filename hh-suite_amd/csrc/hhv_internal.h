@@ -116,8 +116,13 @@ struct PrefilterArgs {
   int32_t* scores;               // [n_jobs], indexed by slot
   int64_t n_jobs;
   int32_t Lq, W, offset, gap_init, gap_extend;
+  // gapless kernel on a query cut into slabs: first query position of this launch, S of the previous slab's last row
+  // (one byte per db residue) and where to leave this slab's last row; null / 0 for a query that fits one slab
+  int32_t q_base;
+  const unsigned char* carry_in;
+  unsigned char* carry_out;
 };
-// fast kernels: W = cells per lane (ungapped: ceil(Lq/64) <= 8, Smith-Waterman: ceil(Lq/32) <= 16), profile as int8 in LDS
+// fast kernels: W = cells per lane (ungapped: ceil(slab/64) <= 8, Smith-Waterman: ceil(Lq/32) <= 20), profile as int8 in LDS
 size_t prefilter_fast_lds(bool gapped, int W);
 int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream);
 // generic kernel: a.W = ceil(Lq/32); prof_lds = striped profile built in LDS, else read from a.striped

@@ -47,14 +47,14 @@ __device__ __forceinline__ int half_shr1_zero(int v, int k) {
 // profile -> LDS, lane-major signed bytes: word[(x * LANES + k) * WQ + q4] holds cells t = 4*q4 .. 4*q4+3 of lane k,
 // cell t = query position k*W + t; padding cells hold 0 (= the reference's padding value `offset`, minus offset)
 template <int LANES, int W>
-__device__ __forceinline__ void fill_profile_lds(uint32_t* sprof, const PrefilterArgs& a, int nthreads) {
+__device__ __forceinline__ void fill_profile_lds(uint32_t* sprof, const PrefilterArgs& a, int nthreads, int q_base = 0) {
   constexpr int WQ = (W + 3) / 4;
   for (int e = threadIdx.x; e < 220 * LANES * WQ; e += nthreads) {
     const int q4 = e % WQ, k = (e / WQ) % LANES, x = e / (WQ * LANES);
     uint32_t w = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int t = q4 * 4 + b, pos = k * W + t;
+      const int t = q4 * 4 + b, pos = q_base + k * W + t;
       const int v = (t < W && pos < a.Lq) ? (int)a.profile[(size_t)x * a.Lq + pos] - a.offset : 0;
       w |= (uint32_t)(v & 0xff) << (8 * b);
     }
@@ -64,7 +64,14 @@ __device__ __forceinline__ void fill_profile_lds(uint32_t* sprof, const Prefilte
 
 template <int WQ>
 __device__ __forceinline__ void read_cells(const uint32_t* p, uint32_t (&w)[WQ]) {
-  if (WQ == 1) {
+  if (WQ == 5) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = v.z;
+    w[3] = v.w;
+    w[4] = p[4];
+  } else if (WQ == 1) {
     w[0] = p[0];
   } else if (WQ == 2) {
     const uint2 v = *reinterpret_cast<const uint2*>(p);
@@ -98,7 +105,10 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WQ = (W + 3) / 4;
   uint32_t* sprof = reinterpret_cast<uint32_t*>(smem);
-  fill_profile_lds<64, W>(sprof, a, 1024);
+  // a query longer than 64*W positions is processed in slabs of 64*W rows (one launch per slab): the diagonals are
+  // carried from slab to slab through one byte per residue (the S value of the slab's last row), which is exact -
+  // the gapless score does not depend on how the query is cut
+  fill_profile_lds<64, W>(sprof, a, 1024, a.q_base);
   for (int e = threadIdx.x; e < 64 * WQ; e += 1024) sprof[PF_NULL * 64 * WQ + e] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -120,31 +130,49 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) 
 #pragma unroll
     for (int t = 0; t < W; ++t) S[t] = 0;
     int vmax = 0;
+    const uint32_t* cin = reinterpret_cast<const uint32_t*>(a.carry_in);
+    int c_prev = 0;  // S(last row of the previous slab, j-1); 0 in front of the sequence
     uint32_t chunk_next = words[w0 + max(min(lane, nw - 1), 0)];
+    uint32_t cchunk_next = cin ? cin[w0 + max(min(lane, nw - 1), 0)] : 0u;
     for (int c0 = 0; c0 < nw; c0 += 64) {
-      const uint32_t chunk = chunk_next;
+      const uint32_t chunk = chunk_next, cchunk = cchunk_next;
       chunk_next = words[w0 + min(c0 + 64 + lane, nw - 1)];
+      if (cin) cchunk_next = cin[w0 + min(c0 + 64 + lane, nw - 1)];
       const int n_here = min(64, nw - c0);
       for (int wl = 0; wl < n_here; ++wl) {
         uint32_t word = __builtin_amdgcn_readlane(chunk, wl);
+        uint32_t cword = cin ? (uint32_t)__builtin_amdgcn_readlane(cchunk, wl) : 0u;
         const int wi = c0 + wl;
-        if (wi == 0 || wi == nw - 1) word = mask_word(word, wi == 0 ? head : 0, wi == nw - 1 ? tail : 4);
+        if (wi == 0 || wi == nw - 1) {
+          const int lo = wi == 0 ? head : 0, hi = wi == nw - 1 ? tail : 4;
+          word = mask_word(word, lo, hi);
+          // carry bytes outside the sequence belong to its neighbours: no carry there
+          cword &= (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+        }
         uint32_t p[4][WQ];
 #pragma unroll
         for (int b = 0; b < 4; ++b) read_cells<WQ>(mine + ((word >> (8 * b)) & 0xff) * (64 * WQ), p[b]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int carry = wave_shr1_zero(S[W - 1]);
+          int carry = wave_shr1_zero(S[W - 1]);
+          if (cin) {
+            carry = lane == 0 ? c_prev : carry;
+            c_prev = (cword >> (8 * b)) & 0xff;
+          }
 #pragma unroll
           for (int t = W - 1; t >= 1; --t) S[t] = med3i(S[t - 1] + sbyte(p[b][t >> 2], t & 3), cap);
           S[0] = med3i(carry + sbyte(p[b][0], 0), cap);
 #pragma unroll
           for (int t = 0; t < W; ++t) vmax = max(vmax, S[t]);
+          if (a.carry_out) {
+            const int64_t pos = (w0 + wi) * 4 + b;
+            if (lane == 63 && pos >= beg && pos < end) a.carry_out[pos] = (unsigned char)S[W - 1];
+          }
         }
       }
     }
     for (int o = 32; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o, 64));
-    if (lane == 0) a.scores[slot] = vmax;
+    if (lane == 0) a.scores[slot] = a.q_base ? max(vmax, a.scores[slot]) : vmax;
   }
 }
 
@@ -356,7 +384,7 @@ int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_bloc
     return launch_one(hhv_pf_sw_kernel<w>, a, n_blocks, 512, lds, stream);
     HHV_PF_CASE(1) HHV_PF_CASE(2) HHV_PF_CASE(3) HHV_PF_CASE(4) HHV_PF_CASE(5) HHV_PF_CASE(6) HHV_PF_CASE(7) HHV_PF_CASE(8)
     HHV_PF_CASE(9) HHV_PF_CASE(10) HHV_PF_CASE(11) HHV_PF_CASE(12) HHV_PF_CASE(13) HHV_PF_CASE(14) HHV_PF_CASE(15)
-    HHV_PF_CASE(16)
+    HHV_PF_CASE(16) HHV_PF_CASE(17) HHV_PF_CASE(18) HHV_PF_CASE(19) HHV_PF_CASE(20)
 #undef HHV_PF_CASE
   }
   return -(int)hipErrorInvalidValue;

@@ -86,6 +86,38 @@ def test_gpu_prefilter_scores_match_oracle(oracle, seed):
     c.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lq", [513, 640, 700, 1100, 2049])
+def test_gpu_prefilter_long_queries(oracle, Lq):
+    """Queries beyond one slab: the gapless kernel runs in slabs of <= 512 rows with carried diagonals, Smith-Waterman
+    falls back to the generic kernel (striped profile in LDS up to Lq = 640, read through L2 beyond)."""
+    from pyhhv import capi
+    rng = np.random.default_rng(Lq)
+    prof = np.clip(rng.normal(30, 12, (220, Lq)), 0, 255).astype(np.uint8)
+    cons = rng.integers(0, 220, Lq)
+    prof[cons, np.arange(Lq)] = rng.integers(56, 64, Lq)
+    n = 60
+    lens = rng.integers(1, 900, n)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    seqs = rng.integers(0, 220, offs[-1]).astype(np.uint8)
+    for k in range(0, n, 2):     # every second sequence follows a stretch of the consensus that crosses slab borders
+        q0 = int(rng.integers(max(0, 512 - 200), min(Lq - 1, 512 + 50))) if Lq > 600 else int(rng.integers(0, Lq // 2))
+        L = min(int(lens[k]), Lq - q0)
+        keep = rng.random(L) < 0.85
+        seqs[offs[k]:offs[k] + L][keep] = cons[q0:q0 + L][keep]
+    o_ung, o_gap = oracle_scores(oracle, prof, Lq, seqs, offs)
+    c = capi.Context()
+    db = c.prefilter_upload_db(seqs, offs)
+    assert np.array_equal(c.prefilter_scores(db, prof, OFFSET, gapped=False), o_ung)
+    sub = np.arange(1, n, 2, dtype=np.int32)[::-1].copy()
+    assert np.array_equal(c.prefilter_scores(db, prof, OFFSET, gapped=False, subset=sub), o_ung[sub])
+    assert np.array_equal(c.prefilter_scores(db, prof, OFFSET, gapped=True, gap_init=GAP_INIT, gap_extend=GAP_EXT), o_gap)
+    assert o_ung.max() > 100
+    c.prefilter_free_db(db)
+    c.close()
+
+
 # ---- host side: flog2 / fpow2, context library, query profile, the two selection steps of prefilter_db ------------
 import os
 
