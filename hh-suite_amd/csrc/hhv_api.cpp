@@ -133,6 +133,10 @@ struct hhv_rawset {
   float* d_pb = nullptr;
   float* d_R = nullptr;
   float* d_qpav = nullptr;
+  // length classes of the prepare kernels: fused with small LDS (L <= 447), fused with large LDS (L <= 1300), split
+  int32_t* d_ids[3] = {nullptr, nullptr, nullptr};
+  int32_t n_ids[3] = {0, 0, 0};
+  int32_t max_L[3] = {0, 0, 0};
   bool prepared = false;
 };
 
@@ -490,10 +494,26 @@ int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const floa
       memcpy(w + RAW_L, &Lk, 4);
     }
   }
-  bool ok = hipMalloc(&rs->d_raw, host.size() * sizeof(float)) == hipSuccess &&
+  // length classes of the prepare kernels (hhv_prep.hip): the fused kernel keeps a template in LDS
+  std::vector<int32_t> cls_ids[3];
+  for (int k = 0; k < n; ++k) {
+    const int cls = L[k] <= 447 ? 0 : (L[k] <= 1300 ? 1 : 2);
+    cls_ids[cls].push_back(k);
+    rs->max_L[cls] = std::max(rs->max_L[cls], L[k]);
+  }
+  bool ok = true;
+  for (int cls = 0; cls < 3 && ok; ++cls) {
+    rs->n_ids[cls] = (int32_t)cls_ids[cls].size();
+    if (rs->n_ids[cls] == 0) continue;
+    ok = hipMalloc(&rs->d_ids[cls], cls_ids[cls].size() * sizeof(int32_t)) == hipSuccess &&
+         hipMemcpy(rs->d_ids[cls], cls_ids[cls].data(), cls_ids[cls].size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  // the intermediate of the split path (columns indexed like the raw stream) exists only if a template needs it
+  if (ok && rs->n_ids[2] > 0)
+    ok = hipMalloc(&rs->d_p_tmp, (size_t)off * 20 * sizeof(float)) == hipSuccess &&
+         hipMalloc(&rs->d_tr_tmp, (size_t)off * 8 * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&rs->d_raw, host.size() * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_neff_hmm, (size_t)n * sizeof(float)) == hipSuccess &&
-            hipMalloc(&rs->d_p_tmp, (size_t)off * 20 * sizeof(float)) == hipSuccess &&
-            hipMalloc(&rs->d_tr_tmp, (size_t)off * 8 * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_pav, (size_t)n * 20 * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_pb, 20 * sizeof(float)) == hipSuccess && hipMalloc(&rs->d_R, 400 * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_qpav, 20 * sizeof(float)) == hipSuccess &&
@@ -518,6 +538,7 @@ void hhv_rawset_free(hhv_rawset* rs) {
   dfree(rs->d_pb);
   dfree(rs->d_R);
   dfree(rs->d_qpav);
+  for (int cls = 0; cls < 3; ++cls) dfree(rs->d_ids[cls]);
   delete rs;
 }
 
@@ -578,7 +599,9 @@ int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par
   a.pca = par->pca;
   a.pcb = par->pcb;
   a.columnscore = par->columnscore;
-  const int rc = launch_prepare(a, rs->n, c->stream);
+  a.ids = nullptr;
+  a.lds_cols = 0;
+  const int rc = launch_prepare(a, rs->d_ids, rs->n_ids, rs->max_L, c->stream);
   if (rc != 0) {
     if (!*out) hhv_tset_free(ts);
     return fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));

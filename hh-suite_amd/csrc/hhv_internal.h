@@ -102,9 +102,12 @@ struct PrepArgs {
   int32_t pcm;
   float pca, pcb;
   int32_t columnscore;
+  const int32_t* ids;        // templates of this launch (one workgroup each)
+  int32_t lds_cols;          // fused kernel: columns the LDS buffers hold (max L of the class + 1)
 };
 
-int launch_prepare(const PrepArgs& a, int n_templates, void* stream);
+size_t prepare_fused_lds(int max_L);
+int launch_prepare(const PrepArgs& a, const int32_t* const ids[3], const int32_t n_ids[3], const int32_t max_L[3], void* stream);
 
 struct PrefilterArgs {
   const unsigned char* profile;  // plain [220][Lq]

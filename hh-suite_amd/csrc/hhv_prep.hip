@@ -8,9 +8,10 @@
 //   HMM::IncludeNullModelInHMM        src/hhhmm.cpp:2059-2144   (columnscore 0..3)
 // in the order of PrepareTemplateHMM (src/hhfunc.cpp:165-202, HHM format).
 //
-// Kernel P1: one lane per raw column (elementwise: transitions, g = R*f, p = (1-tau) f + tau g).
-// Kernel P2: one wave per template: lanes 0..19 accumulate pav[a] over the columns in the reference's order,
-//            then all lanes divide by the null model and emit the packed 28-dword records (+ header).
+// Fused kernel (templates up to 1300 columns): one workgroup per template - (1) one lane per raw column
+// (elementwise: transitions, g = R*f, p = (1-tau) f + tau g) into LDS, (2) lanes 0..19 of the first wave accumulate
+// pav[a] over the columns in the reference's order, (3) all lanes divide by the null model and emit the packed
+// 28-dword records (+ header).  Longer templates take the same three steps as two kernels with the intermediate in HBM.
 #include <hip/hip_runtime.h>
 #include <float.h>
 
@@ -49,18 +50,11 @@ __device__ __forceinline__ float fast_log2_p(float x, const float* __restrict__ 
 // reference enum order of tr[][7], src/hhdecl.h:68
 enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };
 
-__global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
-  // R[20][20] is read 400 times per column with wave-uniform indices: stage it in LDS (broadcast reads)
-  __shared__ float sR[400];
-  for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
-  __syncthreads();
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.n_cols) return;
-  const float* raw = a.raw + (size_t)c * RAW_DW;
+// One raw column -> its prepared transitions T[7] and pseudocount-mixed profile P[20] (columns >= 1).
+__device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __restrict__ raw, const float* __restrict__ sR,
+                                            float* __restrict__ P, float* __restrict__ T) {
   const int i = __builtin_bit_cast(int32_t, raw[RAW_J]) & META_JMASK;
   const int L = __builtin_bit_cast(int32_t, raw[RAW_L]);
-  float* P = a.p_tmp + (size_t)c * 20;
-  float* T = a.tr_tmp + (size_t)c * 8;
 
   // ---- AddTransitionPseudocounts (:1743-1785)
   float t[7];
@@ -120,34 +114,33 @@ __global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
-  __shared__ float s_pav[20];
-  __shared__ float s_pnul[20];
-  const int k = blockIdx.x;
-  const int lane = threadIdx.x;
-  const int64_t c0 = a.rec_off[k];
+// CalculateAminoAcidBackground + IncludeNullModelInHMM + emission of the packed stream for template k, by one wavefront
+// (`lane`); p(j, a) = Pbuf[j * PS + a], tr(j, slot) = Tbuf[j * 8 + slot] (LDS in the fused kernel, global in the split one)
+template <int PS>
+__device__ __forceinline__ void finalize_template(const PrepArgs& a, int k, int lane, const float* Pbuf, const float* Tbuf,
+                                                  float* s_pav, float* s_pnul) {
   const int L = a.L[k];
   // ---- CalculateAminoAcidBackground (:1854-1868): 20 independent sequential sums over the columns
   if (lane < 20) {
     float pav = a.pb[lane] * 100.0f / a.neff_hmm[k];
-    const float* col = a.p_tmp + (size_t)(c0 + 1) * 20 + lane;
+    const float* col = Pbuf + (size_t)PS + lane;
     int i = 1;
     // the additions are strictly sequential (fp32 order of the reference); the loads are batched ahead of them
     for (; i + 7 <= L; i += 8) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)u * 20];
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)u * PS];
 #pragma unroll
       for (int u = 0; u < 8; ++u) pav += v[u];
-      col += 8 * 20;
+      col += 8 * PS;
     }
     for (; i <= L; ++i) {
       pav += *col;
-      col += 20;
+      col += PS;
     }
     s_pav[lane] = pav;
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
     float sum = 0.0f;
     for (int q = 0; q < 20; ++q) sum += s_pav[q];
@@ -156,7 +149,7 @@ __global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
       for (int q = 0; q < 20; ++q) s_pav[q] *= fac;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   // ---- IncludeNullModelInHMM (:2069-2093)
   if (lane < 20) {
     float pn;
@@ -169,29 +162,35 @@ __global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
     s_pnul[lane] = pn;
     if (a.pav_out) a.pav_out[(size_t)k * 20 + lane] = s_pav[lane];
   }
-  __syncthreads();
-  // ---- emit the packed stream: header + L column records (layout: viterbi_lane.h)
+}
+
+// emission of the packed stream: header + L column records (layout: viterbi_lane.h); `tid` of `nthreads` (multiple of 32)
+template <int PS>
+__device__ __forceinline__ void emit_records(const PrepArgs& a, int k, int tid, int nthreads, const float* Pbuf,
+                                             const float* Tbuf, const float* s_pnul) {
+  const int64_t c0 = a.rec_off[k];
+  const int L = a.L[k];
   float* hdr = a.records + (size_t)c0 * REC_DW;
-  if (lane < REC_DW) {
+  if (tid < REC_DW) {
     float v = 0.0f;
-    if (lane == 0) v = __builtin_bit_cast(float, (int32_t)k);
-    if (lane == 1) v = __builtin_bit_cast(float, (int32_t)L);
-    if (lane == REC_META) v = __builtin_bit_cast(float, META_HDR);
-    hdr[lane] = v;
+    if (tid == 0) v = __builtin_bit_cast(float, (int32_t)k);
+    if (tid == 1) v = __builtin_bit_cast(float, (int32_t)L);
+    if (tid == REC_META) v = __builtin_bit_cast(float, META_HDR);
+    hdr[tid] = v;
   }
-  // two records per iteration: lanes 0..27 -> column j, lanes 32..59 -> column j+1
-  const int w = lane & 31;
+  // one record per 32 threads per iteration: threads 0..27 of each group of 32 write the 28 dwords of column j
+  const int w = tid & 31;
   if (w < REC_DW) {
-    for (int j = 1 + (lane >> 5); j <= L; j += 2) {
+    for (int j = 1 + (tid >> 5); j <= L; j += nthreads >> 5) {
       float v;
       if (w < 20) {
-        v = a.p_tmp[(size_t)(c0 + j) * 20 + w] / s_pnul[w];
+        v = Pbuf[(size_t)j * PS + w] / s_pnul[w];
       } else if (w < REC_META) {
         // [20..24] tr[j-1][M2M,M2D,D2M,D2D,I2M], [25..26] tr[j][I2I,M2I]
         const int src_col = (w <= REC_I2M) ? j - 1 : j;
         const int slot = (w == REC_M2M) ? T_M2M : (w == REC_M2D) ? T_M2D : (w == REC_D2M) ? T_D2M
                        : (w == REC_D2D) ? T_D2D : (w == REC_I2M) ? T_I2M : (w == REC_I2I) ? T_I2I : T_M2I;
-        v = a.tr_tmp[(size_t)(c0 + src_col) * 8 + slot];
+        v = Tbuf[(size_t)src_col * 8 + slot];
       } else {
         int32_t meta = j | (__builtin_bit_cast(int32_t, a.raw[(size_t)(c0 + j) * RAW_DW + RAW_SS]) & 0x01FF0000);
         if (j == L) meta |= META_LAST;
@@ -202,11 +201,74 @@ __global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
   }
 }
 
-int launch_prepare(const PrepArgs& a, int n_templates, void* stream) {
-  const int threads = 256;
-  const int64_t blocks = (a.n_cols + threads - 1) / threads;
-  hipLaunchKernelGGL(hhv_prep_columns_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(hhv_prep_finalize_kernel, dim3(n_templates), dim3(LANES), 0, (hipStream_t)stream, a);
+// ---- split path (templates too long for the LDS of the fused kernel): P1 over the columns of the listed templates ...
+__global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
+  // R[20][20] is read 400 times per column with wave-uniform indices: stage it in LDS (broadcast reads)
+  __shared__ float sR[400];
+  for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
+  __syncthreads();
+  const int k = a.ids[blockIdx.x];
+  const int64_t c0 = a.rec_off[k];
+  const int L = a.L[k];
+  for (int i = threadIdx.x; i <= L; i += 256)
+    prep_column(a, a.raw + (size_t)(c0 + i) * RAW_DW, sR, a.p_tmp + (size_t)(c0 + i) * 20, a.tr_tmp + (size_t)(c0 + i) * 8);
+}
+
+// ... and P2, one wavefront per template
+__global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
+  __shared__ float s_pav[20];
+  __shared__ float s_pnul[20];
+  const int k = a.ids[blockIdx.x];
+  const int64_t c0 = a.rec_off[k];
+  finalize_template<20>(a, k, threadIdx.x, a.p_tmp + (size_t)c0 * 20, a.tr_tmp + (size_t)c0 * 8, s_pav, s_pnul);
+  __syncthreads();
+  emit_records<20>(a, k, threadIdx.x, 64, a.p_tmp + (size_t)c0 * 20, a.tr_tmp + (size_t)c0 * 8, s_pnul);
+}
+
+// ---- fused path: one workgroup of 256 threads per template; the mixed profile p[L+1][20] (row stride 21 dwords:
+// conflict-free for one-dword-per-lane accesses) and the prepared transitions stay in LDS between the three steps, so
+// the only HBM traffic is the raw column (128 B) in and the packed record (112 B) out
+constexpr int PREP_PS = 21;
+__global__ void __launch_bounds__(256) hhv_prep_fused_kernel(PrepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sR = reinterpret_cast<float*>(smem);  // [400]
+  float* s_pav = sR + 400;                     // [20]
+  float* s_pnul = s_pav + 20;                  // [20]
+  float* sT = s_pnul + 24;                     // [(maxL+1)][8]
+  float* sP = sT + (size_t)(a.lds_cols) * 8;   // [(maxL+1)][21]
+  for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
+  __syncthreads();
+  const int k = a.ids[blockIdx.x];
+  const int64_t c0 = a.rec_off[k];
+  const int L = a.L[k];
+  for (int i = threadIdx.x; i <= L; i += 256)
+    prep_column(a, a.raw + (size_t)(c0 + i) * RAW_DW, sR, sP + (size_t)i * PREP_PS, sT + (size_t)i * 8);
+  __syncthreads();
+  if (threadIdx.x < 64) finalize_template<PREP_PS>(a, k, threadIdx.x, sP, sT, s_pav, s_pnul);
+  __syncthreads();
+  emit_records<PREP_PS>(a, k, threadIdx.x, 256, sP, sT, s_pnul);
+}
+
+size_t prepare_fused_lds(int max_L) { return (size_t)(400 + 20 + 24 + (size_t)(max_L + 1) * (8 + PREP_PS)) * sizeof(float); }
+
+// ids / n_ids of the three length classes (fused with a small LDS footprint, fused with a large one, split)
+int launch_prepare(const PrepArgs& a0, const int32_t* const ids[3], const int32_t n_ids[3], const int32_t max_L[3], void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int cls = 0; cls < 2; ++cls) {
+    if (n_ids[cls] == 0) continue;
+    PrepArgs a = a0;
+    a.ids = ids[cls];
+    a.lds_cols = max_L[cls] + 1;
+    const size_t lds = prepare_fused_lds(max_L[cls]);
+    (void)hipFuncSetAttribute((const void*)hhv_prep_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(hhv_prep_fused_kernel, dim3(n_ids[cls]), dim3(256), lds, stream, a);
+  }
+  if (n_ids[2]) {
+    PrepArgs a = a0;
+    a.ids = ids[2];
+    hipLaunchKernelGGL(hhv_prep_columns_kernel, dim3(n_ids[2]), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hhv_prep_finalize_kernel, dim3(n_ids[2]), dim3(LANES), 0, stream, a);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -118,3 +118,28 @@ def test_gpu_prepare_matches_oracle(oracle, columnscore, pcm):
     ts.free()
     ts2.free()
     c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_prepare_length_classes(oracle):
+    """The three code paths of hhv_prepare_templates (fused with small / large LDS footprint, split with the intermediate
+    in HBM) in one raw set: lengths on both sides of the class borders."""
+    from pyhhv import capi
+    pb, R = gonnet()
+    fq, trq, nq, nhq = raw_query_hhm()
+    q_p, q_tr, q_pav = po.oracle_prepare(oracle, 0, fq, trq, nq, nhq, pb, R)
+    lengths = [1, 447, 448, 449, 1300, 1301, 1700, 60]
+    raws = [synth.make_raw_hmm(4000 + k, L) for k, L in enumerate(lengths)]
+    c = capi.Context(local=1)
+    c.set_query(q_p[:-1], q_tr)
+    raw, Ls = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+    ts = c.prepare(raw, Ls, capi.prep_params(pb, R), q_pav)
+    pav = c.rawset_pav(raw, len(raws))
+    for k, (f, tr, neff, nh) in enumerate(raws):
+        p, tro, pv = po.oracle_prepare(oracle, 1, f, tr, neff, nh, pb, R, q_pav=q_pav)
+        want = capi.pack_profile(np.ascontiguousarray(p[:-1]), tro, index=k)
+        assert np.array_equal(c.records_of(ts, k).view(np.uint32), want.view(np.uint32)), (k, lengths[k])
+        assert np.array_equal(pav[k].view(np.uint32), pv.view(np.uint32)), k
+    c.rawset_free(raw)
+    ts.free()
+    c.close()

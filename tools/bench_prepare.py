@@ -47,8 +47,9 @@ def main():
     c.sync()
     t_align = (time.perf_counter() - t0) / reps
     cols = n * (Lt + 1)
-    # bytes moved by the two prepare kernels: raw 128 B read, 112 B temp written+read, 112 B record written per column
-    prep_bytes = cols * (128 + 2 * 112 + 112)
+    # bytes moved by the fused prepare kernel: raw column 128 B read, packed record 112 B written (the mixed profile and
+    # the prepared transitions stay in LDS)
+    prep_bytes = cols * (128 + 112)
     # spot check against the oracle
     k = 3
     p, tro, pv = po.oracle_prepare(o, 1, *base[idx[k]], pb, R, q_pav=q_pav)
