@@ -451,34 +451,21 @@ int hhv_adopt_device_stream(hhv_ctx* c, int32_t n, const int32_t* L, const void*
 }
 
 // ---- on-device PrepareTemplateHMM (N2) ---------------------------------------------------------------
-int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
-                             const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
-                             const int8_t* const* ss_conf, const int8_t* const* ss_dssp, hhv_rawset** out) {
-  if (!c || !L || !f || !tr || !neff || !neff_hmm || !out) return fail(HHV_E_ARG, "hhv_upload_raw_templates: null argument");
-  if (n < 1) return fail(HHV_E_ARG, "hhv_upload_raw_templates: n = %d", n);
-  *out = nullptr;
-  HIP_TRY(hipSetDevice(c->par.device));
-  hhv_rawset* rs = new (std::nothrow) hhv_rawset();
-  if (!rs) return fail(HHV_E_MEMORY, "out of host memory");
-  rs->ctx = c;
-  rs->n = n;
-  rs->L.assign(L, L + n);
-  rs->rec_off.resize((size_t)n + 1);
+void hhv_rawset_free(hhv_rawset* rs);
+// raw HMMs -> the 32-dword raw column block the prepare kernels read (hhv_internal.h RAW_*)
+static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, const float* const* tr, const float* const* neff,
+                           const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp,
+                           std::vector<float>* host) {
   int64_t off = 0;
   for (int k = 0; k < n; ++k) {
-    if (L[k] < 1 || L[k] > 0xFFFF || !f[k] || !tr[k] || !neff[k]) {
-      delete rs;
-      return fail(HHV_E_ARG, "raw template %d invalid", k);
-    }
-    rs->rec_off[k] = off;
+    if (L[k] < 1 || L[k] > 0xFFFF || !f[k] || !tr[k] || !neff[k]) return fail(HHV_E_ARG, "raw template %d invalid", k);
     off += (int64_t)L[k] + 1;
   }
-  rs->rec_off[n] = off;
-  rs->n_cols = off;
-  std::vector<float> host((size_t)off * RAW_DW, 0.0f);
+  host->assign((size_t)off * RAW_DW, 0.0f);
+  off = 0;
   for (int k = 0; k < n; ++k) {
     for (int i = 0; i <= L[k]; ++i) {
-      float* w = host.data() + (size_t)(rs->rec_off[k] + i) * RAW_DW;
+      float* w = host->data() + (size_t)(off + i) * RAW_DW;
       memcpy(w + RAW_F, f[k] + (size_t)i * 20, 20 * sizeof(float));
       memcpy(w + RAW_TR, tr[k] + (size_t)i * 7, 7 * sizeof(float));
       memcpy(w + RAW_NEFF, neff[k] + (size_t)i * 3, 3 * sizeof(float));
@@ -493,6 +480,35 @@ int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const floa
       const int32_t Lk = L[k];
       memcpy(w + RAW_L, &Lk, 4);
     }
+    off += (int64_t)L[k] + 1;
+  }
+  return HHV_OK;
+}
+
+// raw column block -> resident raw set (the block may come from build_raw_block or straight from a raw database file)
+static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const float* neff_hmm, const float* block,
+                             size_t block_floats, hhv_rawset** out) {
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_rawset* rs = new (std::nothrow) hhv_rawset();
+  if (!rs) return fail(HHV_E_MEMORY, "out of host memory");
+  rs->ctx = c;
+  rs->n = n;
+  rs->L.assign(L, L + n);
+  rs->rec_off.resize((size_t)n + 1);
+  int64_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1 || L[k] > 0xFFFF) {
+      delete rs;
+      return fail(HHV_E_ARG, "raw template %d: length %d", k, L[k]);
+    }
+    rs->rec_off[k] = off;
+    off += (int64_t)L[k] + 1;
+  }
+  rs->rec_off[n] = off;
+  rs->n_cols = off;
+  if ((size_t)off * RAW_DW != block_floats) {
+    delete rs;
+    return fail(HHV_E_ARG, "raw column block has %zu floats, expected %zu", block_floats, (size_t)off * RAW_DW);
   }
   // length classes of the prepare kernels (hhv_prep.hip): the fused kernel keeps a template in LDS
   std::vector<int32_t> cls_ids[3];
@@ -512,18 +528,93 @@ int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const floa
   if (ok && rs->n_ids[2] > 0)
     ok = hipMalloc(&rs->d_p_tmp, (size_t)off * 20 * sizeof(float)) == hipSuccess &&
          hipMalloc(&rs->d_tr_tmp, (size_t)off * 8 * sizeof(float)) == hipSuccess;
-  ok = ok && hipMalloc(&rs->d_raw, host.size() * sizeof(float)) == hipSuccess &&
+  ok = ok && hipMalloc(&rs->d_raw, block_floats * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_neff_hmm, (size_t)n * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_pav, (size_t)n * 20 * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_pb, 20 * sizeof(float)) == hipSuccess && hipMalloc(&rs->d_R, 400 * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_qpav, 20 * sizeof(float)) == hipSuccess &&
-            hipMemcpy(rs->d_raw, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(rs->d_raw, block, block_floats * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(rs->d_neff_hmm, neff_hmm, (size_t)n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
     hhv_rawset_free(rs);
-    return fail(HHV_E_MEMORY, "hhv_upload_raw_templates: device allocation/copy failed");
+    return fail(HHV_E_MEMORY, "raw template set: device allocation/copy failed");
   }
   *out = rs;
+  return HHV_OK;
+}
+
+int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
+                             const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
+                             const int8_t* const* ss_conf, const int8_t* const* ss_dssp, hhv_rawset** out) {
+  if (!c || !L || !f || !tr || !neff || !neff_hmm || !out) return fail(HHV_E_ARG, "hhv_upload_raw_templates: null argument");
+  if (n < 1) return fail(HHV_E_ARG, "hhv_upload_raw_templates: n = %d", n);
+  *out = nullptr;
+  std::vector<float> host;
+  const int rc = build_raw_block(n, L, f, tr, neff, ss_pred, ss_conf, ss_dssp, &host);
+  if (rc != HHV_OK) return rc;
+  return rawset_from_block(c, n, L, neff_hmm, host.data(), host.size(), out);
+}
+
+// Raw template database file (N1 for the N2 path): header, lengths, Neff_HMM, then the raw column block exactly as it
+// sits in HBM - built once from the .hhm files, loaded per search without parsing or repacking.
+namespace {
+struct RawDbHeader {
+  char magic[8];
+  int32_t n;
+  int32_t column_dwords;
+  int64_t n_cols;
+  char pad[40];
+};
+static_assert(sizeof(RawDbHeader) == 64, "raw db header");
+}  // namespace
+
+int hhv_rawdb_write(const char* path, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
+                    const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
+                    const int8_t* const* ss_conf, const int8_t* const* ss_dssp) {
+  if (!path || !L || !f || !tr || !neff || !neff_hmm || n < 1) return fail(HHV_E_ARG, "hhv_rawdb_write: bad argument");
+  std::vector<float> host;
+  const int rc = build_raw_block(n, L, f, tr, neff, ss_pred, ss_conf, ss_dssp, &host);
+  if (rc != HHV_OK) return rc;
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return fail(HHV_E_ARG, "hhv_rawdb_write: cannot open %s", path);
+  RawDbHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "HHVRAW01", 8);
+  h.n = n;
+  h.column_dwords = RAW_DW;
+  h.n_cols = (int64_t)(host.size() / RAW_DW);
+  bool ok = fwrite(&h, sizeof(h), 1, fp) == 1 && fwrite(L, sizeof(int32_t), (size_t)n, fp) == (size_t)n &&
+            fwrite(neff_hmm, sizeof(float), (size_t)n, fp) == (size_t)n &&
+            fwrite(host.data(), sizeof(float), host.size(), fp) == host.size();
+  ok = (fclose(fp) == 0) && ok;
+  return ok ? HHV_OK : fail(HHV_E_ARG, "hhv_rawdb_write: write to %s failed", path);
+}
+
+int hhv_rawdb_open(hhv_ctx* c, const char* path, hhv_rawset** out) {
+  if (!c || !path || !out) return fail(HHV_E_ARG, "hhv_rawdb_open: null argument");
+  *out = nullptr;
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return fail(HHV_E_ARG, "hhv_rawdb_open: cannot open %s", path);
+  RawDbHeader h;
+  if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "HHVRAW01", 8) != 0 || h.column_dwords != RAW_DW || h.n < 1 ||
+      h.n_cols < 2) {
+    fclose(fp);
+    return fail(HHV_E_ARG, "hhv_rawdb_open: %s is not a raw template database", path);
+  }
+  std::vector<int32_t> L((size_t)h.n);
+  std::vector<float> neff_hmm((size_t)h.n), block((size_t)h.n_cols * RAW_DW);
+  const bool ok = fread(L.data(), sizeof(int32_t), L.size(), fp) == L.size() &&
+                  fread(neff_hmm.data(), sizeof(float), neff_hmm.size(), fp) == neff_hmm.size() &&
+                  fread(block.data(), sizeof(float), block.size(), fp) == block.size();
+  fclose(fp);
+  if (!ok) return fail(HHV_E_ARG, "hhv_rawdb_open: %s is truncated", path);
+  return rawset_from_block(c, h.n, L.data(), neff_hmm.data(), block.data(), block.size(), out);
+}
+
+int32_t hhv_rawset_size(const hhv_rawset* rs) { return rs ? rs->n : 0; }
+int hhv_rawset_lengths(const hhv_rawset* rs, int32_t* L) {
+  if (!rs || !L) return fail(HHV_E_ARG, "hhv_rawset_lengths: null argument");
+  memcpy(L, rs->L.data(), (size_t)rs->n * sizeof(int32_t));
   return HHV_OK;
 }
 

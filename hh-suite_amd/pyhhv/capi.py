@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores",
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
+    "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
@@ -177,6 +178,25 @@ def db_write(path, tps, ttrs):
     return Ls
 
 
+def rawdb_write(path, fs, trs, neffs, neff_hmm):
+    """hhv_rawdb_write: raw HMMs (as HMM::Read leaves them) -> raw template database file (no device needed)."""
+    fs = [_f32(a) for a in fs]
+    trs = [_f32(a) for a in trs]
+    neffs = [_f32(a) for a in neffs]
+    n = len(fs)
+    Ls = np.array([a.shape[0] - 1 for a in trs], dtype=np.int32)
+    nh = _f32(neff_hmm)
+    ff = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in fs])
+    tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in trs])
+    nn = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in neffs])
+    L = load()
+    L.hhv_rawdb_write.argtypes = [C.c_char_p, C.c_int32, c_int_p, C.c_void_p, C.c_void_p, C.c_void_p, c_float_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+    _check(L.hhv_rawdb_write(str(path).encode(), n, Ls.ctypes.data_as(c_int_p), ff, tt, nn, nh.ctypes.data_as(c_float_p),
+                             None, None, None))
+    return Ls
+
+
 def fast_log2_tables():
     lg2 = np.zeros(1025, dtype=np.float32)
     diff = np.zeros(1025, dtype=np.float32)
@@ -270,6 +290,17 @@ class Context:
         h = C.c_void_p()
         _check(self.lib.hhv_upload_raw_templates(self.h, n, Ls.ctypes.data_as(c_int_p), ff, tt, nn,
                                                  nh.ctypes.data_as(c_float_p), None, None, None, C.byref(h)))
+        return h, Ls
+
+    def rawdb_open(self, path):
+        """hhv_rawdb_open -> (raw set handle, lengths): the raw database file straight into HBM."""
+        self.lib.hhv_rawdb_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        self.lib.hhv_rawset_size.argtypes = [C.c_void_p]
+        self.lib.hhv_rawset_lengths.argtypes = [C.c_void_p, C.c_void_p]
+        h = C.c_void_p()
+        _check(self.lib.hhv_rawdb_open(self.h, str(path).encode(), C.byref(h)))
+        Ls = np.zeros(self.lib.hhv_rawset_size(h), dtype=np.int32)
+        _check(self.lib.hhv_rawset_lengths(h, Ls.ctypes.data))
         return h, Ls
 
     def prepare(self, raw, Ls, params, q_pav, ts=None):

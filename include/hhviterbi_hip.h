@@ -163,6 +163,14 @@ int hhv_upload_raw_templates(hhv_ctx* ctx, int32_t n, const int32_t* L, const fl
                              const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
                              const int8_t* const* ss_conf, const int8_t* const* ss_dssp, hhv_rawset** out);
 void hhv_rawset_free(hhv_rawset* rs);
+/* Raw template database file (the N1 idea for the N2 path): lengths, Neff_HMM and the raw column block exactly as it
+ * sits in HBM; written once from the parsed .hhm files, opened per search without text parsing or repacking. */
+int hhv_rawdb_write(const char* path, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
+                    const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
+                    const int8_t* const* ss_conf, const int8_t* const* ss_dssp);
+int hhv_rawdb_open(hhv_ctx* ctx, const char* path, hhv_rawset** out);
+int32_t hhv_rawset_size(const hhv_rawset* rs);
+int hhv_rawset_lengths(const hhv_rawset* rs, int32_t* L);
 int hhv_prepare_templates(hhv_ctx* ctx, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out);
 /* average composition pav[n*20] of the prepared templates of the last hhv_prepare_templates (diagnostics/tests) */
 int hhv_rawset_pav(hhv_ctx* ctx, hhv_rawset* rs, float* pav);

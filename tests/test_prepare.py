@@ -143,3 +143,47 @@ def test_gpu_prepare_length_classes(oracle):
     c.rawset_free(raw)
     ts.free()
     c.close()
+
+
+def test_rawdb_file_layout(tmp_path):
+    """hhv_rawdb_write needs no device: header, lengths, Neff_HMM, 32-dword raw columns."""
+    from pyhhv import capi
+    raws = [synth.make_raw_hmm(70 + k, L) for k, L in enumerate([3, 40, 17])]
+    path = tmp_path / "db.hhvraw"
+    Ls = capi.rawdb_write(path, [r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+    blob = path.read_bytes()
+    assert blob[:8] == b"HHVRAW01"
+    n, dw, ncols = np.frombuffer(blob, np.int32, 2, 8).tolist() + [int(np.frombuffer(blob, np.int64, 1, 16)[0])]
+    assert (n, dw, ncols) == (3, 32, int((Ls + 1).sum()))
+    assert np.array_equal(np.frombuffer(blob, np.int32, 3, 64), Ls)
+    assert np.array_equal(np.frombuffer(blob, np.float32, 3, 64 + 12), np.array([r[3] for r in raws], np.float32))
+    cols = np.frombuffer(blob, np.float32, ncols * 32, 64 + 24).reshape(ncols, 32)
+    assert np.array_equal(cols[1, :20], raws[0][0][1]) and np.array_equal(cols[Ls[0] + 1 + 5, 20:27], raws[1][1][5])
+    assert len(blob) == 64 + 24 + ncols * 128
+
+
+@pytest.mark.gpu
+def test_gpu_rawdb_roundtrip(oracle, tmp_path):
+    """A raw database file opened with hhv_rawdb_open prepares to the same records as the same HMMs uploaded directly."""
+    from pyhhv import capi
+    pb, R = gonnet()
+    fq, trq, nq, nhq = raw_query_hhm()
+    q_p, q_tr, q_pav = po.oracle_prepare(oracle, 0, fq, trq, nq, nhq, pb, R)
+    raws = [synth.make_raw_hmm(600 + k, L) for k, L in enumerate([12, 300, 77, 500, 1])]
+    path = tmp_path / "db.hhvraw"
+    capi.rawdb_write(path, [r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+    c = capi.Context(local=1)
+    c.set_query(q_p[:-1], q_tr)
+    par = capi.prep_params(pb, R)
+    raw1, L1 = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+    raw2, L2 = c.rawdb_open(path)
+    assert np.array_equal(L1, L2)
+    ts1, ts2 = c.prepare(raw1, L1, par, q_pav), c.prepare(raw2, L2, par, q_pav)
+    for k in range(len(raws)):
+        assert np.array_equal(c.records_of(ts1, k).view(np.uint32), c.records_of(ts2, k).view(np.uint32)), k
+    assert np.array_equal(c.align(ts1).view(np.uint8), c.align(ts2).view(np.uint8))
+    for h in (raw1, raw2):
+        c.rawset_free(h)
+    ts1.free()
+    ts2.free()
+    c.close()
