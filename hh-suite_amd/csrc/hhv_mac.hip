@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
           ROW(cur, F_IM, j) = 0.0;
           ROW(cur, F_DG, j) = 0.0;
           ROW(cur, F_MI, j) = 0.0;
-          row[j] = row[j] * 0.0f;  // F * (float)(0 / Pforward)
+          row[j] = row[j] * (float)(0.0 / Pf);  // F * (float)(B / Pforward) with B = 0 (NaN if Pforward is 0, as in the reference)
         }
         carry_gd = carry_im = 0.0;
         continue;

@@ -562,33 +562,66 @@ int hho_ungapped_score(const unsigned char *profile, int Lq, const unsigned char
  * all with unsigned saturation; the result is the maximum H. */
 int hho_sw_score(const unsigned char *profile, int Lq, const unsigned char *seq, int Ldb, int gap_init, int gap_extend,
                  int bias, int vec_bytes) {
-  const int W = (Lq + vec_bytes - 1) / vec_bytes;
-  unsigned char *Hprev = (unsigned char *)calloc((size_t)Lq + 1, 1), *Hcur = (unsigned char *)calloc((size_t)Lq + 1, 1);
-  unsigned char *E = (unsigned char *)calloc((size_t)Lq + 1, 1);
+  /* Literal restatement of the striped loops (src/hhprefilter.cpp:70-212): V = vec_bytes vector elements, element k of
+   * segment row j is query position k*W + j.  The lazy-F loop is kept as it is written - its exit test
+   * F - (H - gap_init) == 0 prunes the F chain, which equals the full recurrence only for gap_init >= gap_extend. */
+  const int V = vec_bytes, W = (Lq + V - 1) / V;
+  unsigned char *Hs = (unsigned char *)calloc((size_t)W * V, 1), *Hl = (unsigned char *)calloc((size_t)W * V, 1);
+  unsigned char *E = (unsigned char *)calloc((size_t)W * V, 1), *F = (unsigned char *)calloc((size_t)V, 1);
+  unsigned char *H = (unsigned char *)calloc((size_t)V, 1);
   int best = 0;
-  for (int j = 0; j < Ldb; ++j) {
-    const unsigned char *q = profile + (size_t)seq[j] * Lq;
-    int fin = 0, ffull = 0;
-    for (int p = 0; p < Lq; ++p) {
-      if (p % W == 0) fin = 0;
-      const int diag = p ? Hprev[p - 1] : 0;
-      const int base = sat_sub8(sat_add8(diag, q[p]), bias);
-      const int hpre = imax2(imax2(base, E[p]), fin);
-      const int h = imax2(hpre, ffull);
-      Hcur[p] = (unsigned char)h;
-      best = imax2(best, h);
-      const int hgo = sat_sub8(hpre, gap_init);
-      E[p] = (unsigned char)imax2(sat_sub8(E[p], gap_extend), hgo);
-      fin = imax2(sat_sub8(fin, gap_extend), hgo);
-      ffull = imax2(sat_sub8(ffull, gap_extend), sat_sub8(h, gap_init));
+#define QP(x, j, k) (((k) * W + (j)) < Lq ? profile[(size_t)(x) * Lq + (k) * W + (j)] : (unsigned char)bias)
+  for (int i = 0; i < Ldb; ++i) {
+    const int x = seq[i];
+    memset(F, 0, (size_t)V);
+    /* vH = pvHStore[W-1] shifted by one element (:120-126) */
+    for (int k = V - 1; k >= 1; --k) H[k] = Hs[(size_t)(W - 1) * V + k - 1];
+    H[0] = 0;
+    unsigned char *t = Hl; /* swap the two H buffers (:129-132) */
+    Hl = Hs;
+    Hs = t;
+    for (int j = 0; j < W; ++j) {
+      for (int k = 0; k < V; ++k) {
+        int h = sat_sub8(sat_add8(H[k], QP(x, j, k)), bias);
+        unsigned char *e = &E[(size_t)j * V + k];
+        h = imax2(imax2(h, *e), F[k]);
+        best = imax2(best, h);
+        Hs[(size_t)j * V + k] = (unsigned char)h;
+        const int hg = sat_sub8(h, gap_init);
+        *e = (unsigned char)imax2(sat_sub8(*e, gap_extend), hg);
+        F[k] = (unsigned char)imax2(sat_sub8(F[k], gap_extend), hg);
+        H[k] = Hl[(size_t)j * V + k];
+      }
     }
-    unsigned char *t = Hprev;
-    Hprev = Hcur;
-    Hcur = t;
+    /* lazy-F loop (:176-203) */
+    int j = 0;
+    for (int k = 0; k < V; ++k) H[k] = Hs[k];
+    for (int k = V - 1; k >= 1; --k) F[k] = F[k - 1];
+    F[0] = 0;
+    for (;;) {
+      int any = 0;
+      for (int k = 0; k < V; ++k) any |= sat_sub8(F[k], sat_sub8(H[k], gap_init)) != 0;
+      if (!any) break;
+      for (int k = 0; k < V; ++k) {
+        const int h = imax2(H[k], F[k]);
+        best = imax2(best, h);
+        Hs[(size_t)j * V + k] = (unsigned char)h;
+        F[k] = (unsigned char)sat_sub8(F[k], gap_extend);
+      }
+      if (++j >= W) {
+        j = 0;
+        for (int k = V - 1; k >= 1; --k) F[k] = F[k - 1];
+        F[0] = 0;
+      }
+      for (int k = 0; k < V; ++k) H[k] = Hs[(size_t)j * V + k];
+    }
   }
-  free(Hprev);
-  free(Hcur);
+#undef QP
+  free(Hs);
+  free(Hl);
   free(E);
+  free(F);
+  free(H);
   return best;
 }
 

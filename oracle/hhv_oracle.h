@@ -85,10 +85,11 @@ int hho_prepare(int role, int L, const float *f, const float *tr, const float *n
 /* ---- HHblits prefilter kernels, uint8 saturating arithmetic ------------------------------
  * profile: plain [220][Lq] bytes (219 column states + ANY), seq: db column-state sequence (values 0..219).
  * hho_ungapped_score restates Prefilter::ungapped_sse_score (src/hhprefilter.cpp:214-278);
- * hho_sw_score restates Prefilter::swStripedByte (src/hhprefilter.cpp:70-212) INCLUDING its dependence on the
- * SIMD striping: E(i,j+1) is updated from the H that contains only the F contributions propagated inside a
- * stripe segment (the lazy-F correction does not touch E), so the score depends on the segment length
- * W = ceil(Lq / vec_bytes); vec_bytes = 32 for the AVX2 build the oracle is pinned to. */
+ * hho_sw_score restates Prefilter::swStripedByte (src/hhprefilter.cpp:70-212) literally - striped buffers, the same
+ * loops, the same lazy-F exit test - because its result depends on the SIMD striping: E(i,j+1) is updated from the H
+ * that contains only the F contributions propagated inside a stripe segment (the lazy-F correction does not touch E),
+ * and the lazy-F loop prunes the F chain with a test that equals the full recurrence only for gap_init >= gap_extend.
+ * vec_bytes = 32 for the AVX2 build the oracle is pinned to (W = ceil(Lq / vec_bytes)). */
 int hho_ungapped_score(const unsigned char *profile, int Lq, const unsigned char *seq, int Ldb, int score_offset);
 int hho_sw_score(const unsigned char *profile, int Lq, const unsigned char *seq, int Ldb, int gap_init, int gap_extend,
                  int bias, int vec_bytes);

@@ -118,6 +118,27 @@ def test_gpu_prefilter_long_queries(oracle, Lq):
     c.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_sw_matches_reference_for_any_gap_parameters(oracle, ref, seed):
+    """gap_init < gap_extend never happens in hhblits (gap_init = open + extend), but the striped algorithm is defined
+    for it: its lazy-F exit test then prunes the F chain, and the restatement must follow it literally."""
+    rng = np.random.default_rng(900 + seed)
+    for _ in range(40):
+        Lq = int(rng.choice([1, 31, 33, 64, 65, 100, 257]))
+        off = int(rng.choice([0, 20, 50]))
+        prof = np.clip(rng.normal(off - 4, 14, (220, Lq)), 0, 255).astype(np.uint8)
+        L = int(rng.integers(1, 40))
+        seq = rng.integers(0, 220, L).astype(np.uint8)
+        go, ge = int(rng.choice([0, 3, 5, 24, 60])), int(rng.choice([0, 1, 4, 9]))
+        offs = np.array([0, L], np.int64)
+        gap = np.zeros(1, np.int32)
+        ung = np.zeros(1, np.int32)
+        ref.lib.ref_prefilter_scores(u8(prof), Lq, u8(seq), offs.ctypes.data_as(C.POINTER(C.c_long)), 1, off, go, ge,
+                                     ung.ctypes.data_as(C.POINTER(C.c_int)), gap.ctypes.data_as(C.POINTER(C.c_int)))
+        assert oracle.lib.hho_sw_score(u8(prof), Lq, u8(seq), L, go, ge, off, 32) == gap[0], (Lq, off, L, go, ge)
+        assert oracle.lib.hho_ungapped_score(u8(prof), Lq, u8(seq), L, off) == ung[0]
+
+
 # ---- host side: flog2 / fpow2, context library, query profile, the two selection steps of prefilter_db ------------
 import os
 

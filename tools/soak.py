@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on a GPU box: the HIP kernels against the oracle (test infrastructure) on many small random
+cases per kernel family, with adversarial inputs the fixed tests do not have (exact ties, -100000 transitions, saturated
+prefilter profiles, random cell-off masks, length 1).  usage: python tools/soak.py [seconds_per_family] -> JSON line."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+for d in ("hh-suite_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, d))
+from pyhhv import capi, synth  # noqa: E402
+import pyoracle as po  # noqa: E402
+
+
+def quantize(a, rng, step):
+    """Coarse grid -> many exact ties between DP candidates."""
+    return (np.round(a / step) * step).astype(np.float32)
+
+
+def viterbi_family(orc, rng, budget):
+    t_end, cases, bad = time.time() + budget, 0, 0
+    while time.time() < t_end:
+        Lq = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 320, 321, 400]))
+        local = int(rng.integers(0, 2))
+        par = po.make_params(local=local, egq=float(rng.choice([0.0, 0.2])), egt=float(rng.choice([0.0, 0.1])),
+                             shift=float(rng.choice([-0.03, 0.0, 0.25])), ss_mode=0)
+        qp, qtr = synth.make_query(int(rng.integers(1 << 30)), Lq)
+        n = int(rng.integers(1, 12))
+        tps, ttrs, masks = [], [], []
+        for k in range(n):
+            Lt = int(rng.choice([1, 2, 3, 31, 64, 130, 257]))
+            tp, ttr = (synth.make_homolog(int(rng.integers(1 << 30)), qp, L=Lt) if rng.random() < 0.5 and Lq > 4 else
+                       synth.make_template(int(rng.integers(1 << 30)), Lt))
+            if rng.random() < 0.5:       # ties
+                ttr = quantize(ttr, rng, 0.5)
+                ttr[ttr < -1000] = -100000.0
+            if rng.random() < 0.2:       # impossible transitions in the middle
+                ttr[rng.integers(0, Lt + 1), rng.integers(0, 7)] = -100000.0
+            tps.append(tp)
+            ttrs.append(ttr)
+            masks.append((rng.random((Lq + 1, Lt + 1)) < rng.choice([0.0, 0.05, 0.5])).astype(np.uint8) if rng.random() < 0.4 else None)
+        if rng.random() < 0.5:
+            qtr = quantize(qtr, rng, 0.5)
+            qtr[qtr < -1000] = -100000.0
+        c = capi.Context(local=local, egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"], ss_mode=0)
+        c.set_query(qp, qtr)
+        ts = c.upload(tps, ttrs)
+        use_mask = any(m is not None for m in masks)
+        if use_mask:
+            for k, m in enumerate(masks):
+                c.set_celloff(ts, k, m if m is not None else np.zeros((Lq + 1, tps[k].shape[0]), np.uint8))
+        res = c.align(ts, backtrace=True, celloff=use_mask)
+        hits = c.hits(ts)
+        for k in range(n):
+            a = orc.align(par, qp, qtr, tps[k], ttrs[k], celloff=masks[k] if use_mask else None, want_path=True)
+            ok = (a.i2, a.j2) == (int(res["i2"][k]), int(res["j2"][k])) and np.float32(a.score).tobytes() == np.float32(res["score"][k]).tobytes()
+            ok = ok and np.array_equal(c.backtrace_matrix(ts, k)[1:, 1:] & 0x7F, a.bt[1:, 1:] & 0x7F)
+            ok = ok and int(hits["nsteps"][k]) == a.nsteps and np.float32(hits["score"][k]).tobytes() == np.float32(a.hit_score).tobytes()
+            cases += 1
+            bad += int(not ok)
+        ts.free()
+        c.close()
+    return {"cases": cases, "mismatches": bad}
+
+
+def prefilter_family(orc, rng, budget):
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
+    t_end, cases, bad = time.time() + budget, 0, 0
+    diag = []
+    c = capi.Context()
+    while time.time() < t_end:
+        Lq = int(rng.choice([1, 31, 32, 33, 64, 65, 255, 300, 512, 513, 641, 900]))
+        off = int(rng.choice([50, 0, 128, 20]))
+        mode = rng.integers(0, 3)
+        prof = (rng.integers(0, 256, (220, Lq)) if mode == 0 else np.clip(rng.normal(off - 4, 14, (220, Lq)), 0, 255)).astype(np.uint8)
+        if mode == 2:
+            prof[rng.integers(0, 220, Lq), np.arange(Lq)] = min(255, off + 127)   # the largest byte the fast path takes
+        n = int(rng.integers(1, 40))
+        lens = rng.integers(0, 400, n)
+        lens[rng.integers(0, n)] = 1
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum(lens)
+        seqs = rng.integers(0, 220, offs[-1]).astype(np.uint8)
+        go, ge = int(rng.choice([24, 5, 0, 40])), int(rng.choice([4, 1, 0, 9]))
+        db = c.prefilter_upload_db(seqs, offs)
+        ung = c.prefilter_scores(db, prof, off, gapped=False)
+        gap = c.prefilter_scores(db, prof, off, gapped=True, gap_init=go, gap_extend=ge)
+        for k in range(n):
+            s = np.ascontiguousarray(seqs[offs[k]:offs[k + 1]]) if lens[k] else np.zeros(1, np.uint8)
+            w_u = orc.lib.hho_ungapped_score(u8(prof), Lq, u8(s), int(lens[k]), off)
+            w_g = orc.lib.hho_sw_score(u8(prof), Lq, u8(s), int(lens[k]), go, ge, off, 32)
+            cases += 1
+            if w_u != ung[k] or w_g != gap[k]:
+                bad += 1
+                if len(diag) < 8:
+                    diag.append({"Lq": Lq, "off": off, "mode": int(mode), "len": int(lens[k]), "go": go, "ge": ge, "k": k, "n": n,
+                                 "ung": [int(w_u), int(ung[k])], "gap": [int(w_g), int(gap[k])], "pmax": int(prof.max())})
+        c.prefilter_free_db(db)
+    c.close()
+    return {"cases": cases, "mismatches": bad, "diag": diag}
+
+
+def mac_family(orc, rng, budget):
+    import test_mac as T
+    t_end, cases, bad = time.time() + budget, 0, 0
+    diag = []
+    c = capi.Context()
+    while time.time() < t_end:
+        Lq = int(rng.choice([2, 3, 40, 64, 65, 129, 200]))
+        local = int(rng.integers(0, 2))
+        mact = float(rng.choice([0.3501, 0.0, 0.9, 0.05]))
+        qp, qtr = synth.make_query(int(rng.integers(1 << 30)), Lq)
+        q_lin = T.lin_query(qtr)
+        tps, tls, masks, want = [], [], [], []
+        for k in range(int(rng.integers(1, 6))):
+            Lt = int(rng.choice([1, 2, 63, 64, 65, 128, 190]))
+            tp, ttr = (synth.make_homolog(int(rng.integers(1 << 30)), qp, L=Lt) if rng.random() < 0.6 and Lq > 4 else
+                       synth.make_template(int(rng.integers(1 << 30)), Lt))
+            t_lin = T.lin_template(ttr)
+            dens = rng.choice([0.0, 0.1, 0.6, 0.97])
+            m = (rng.random((Lq + 1, Lt + 1)) < dens).astype(np.uint8)
+            m[0, :] = 0
+            m[:, 0] = 0
+            o = po._mac_buffers(Lq, Lt)
+            L = orc.lib
+            V = C.c_void_p
+            L.hho_mac_forward.argtypes = [V, V, C.c_int, V, V, C.c_int, C.c_int, C.c_float, V, V, V, V]
+            L.hho_mac_backward.argtypes = [V, V, C.c_int, V, V, C.c_int, C.c_int, C.c_float, V, V, C.c_double, V]
+            L.hho_mac_dp.argtypes = [V, V, C.c_int, C.c_int, C.c_int, C.c_float, V, V, V]
+            L.hho_mac_backtrace.argtypes = [V, V, V, V, C.c_int, C.c_int, C.c_int, C.c_int] + [V] * 8
+            L.hho_mac_forward(qp.ctypes.data, q_lin.ctypes.data, Lq, tp.ctypes.data, t_lin.ctypes.data, Lt, local, -0.03,
+                              m.ctypes.data, o.forward.ctypes.data, o.scale.ctypes.data, C.addressof(o.Pforward))
+            o.posterior[:] = o.forward
+            L.hho_mac_backward(qp.ctypes.data, q_lin.ctypes.data, Lq, tp.ctypes.data, t_lin.ctypes.data, Lt, local, -0.03,
+                               m.ctypes.data, o.scale.ctypes.data, o.Pforward.value, o.posterior.ctypes.data)
+            i2, j2, ns, mc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            L.hho_mac_dp(o.posterior.ctypes.data, m.ctypes.data, Lq, Lt, local, mact, o.bmm.ctypes.data, C.addressof(i2), C.addressof(j2))
+            L.hho_mac_backtrace(o.bmm.ctypes.data, o.posterior.ctypes.data, qp.ctypes.data, tp.ctypes.data, Lq, Lt, i2.value,
+                                j2.value, o.i_steps.ctypes.data, o.j_steps.ctypes.data, o.states.ctypes.data, o.S.ctypes.data,
+                                o.P.ctypes.data, C.addressof(ns), C.addressof(mc), C.addressof(o.sum_of_probs))
+            o.ns, o.i2v, o.j2v, o.Pf = ns.value, i2.value, j2.value, o.Pforward.value
+            tps.append(tp)
+            tls.append(t_lin)
+            masks.append(m)
+            want.append(o)
+        ms = c.mac_realign(qp, q_lin, tps, tls, masks, local=local, mact=mact)
+        for k, o in enumerate(want):
+            h = ms.hits[k]
+            ok = np.float64(h["Pforward"]).tobytes() == np.float64(o.Pf).tobytes() or (np.isnan(o.Pf) and np.isnan(h["Pforward"]))
+            post = ms.posterior(k)
+            # a mask that leaves no path gives Pforward = 0 and NaN posteriors in the reference too: NaN == NaN here
+            ok = ok and np.array_equal(post[1:, 1:], o.posterior[1:, 1:], equal_nan=True)
+            ok = ok and (int(h["nsteps"]), int(h["i2"]), int(h["j2"])) == (o.ns, o.i2v, o.j2v)
+            if ok and o.ns:
+                i_s, j_s, st, S, P = ms.path(k)
+                ok = np.array_equal(i_s[1:], o.i_steps[1:o.ns + 1]) and np.array_equal(P[1:], o.P[1:o.ns + 1], equal_nan=True)
+            cases += 1
+            if not ok:
+                bad += 1
+                if len(diag) < 8:
+                    diag.append({"Lq": Lq, "Lt": int(tps[k].shape[0] - 1), "local": local, "mact": mact, "dens": float(masks[k].mean()),
+                                 "Pf": [o.Pf, float(h["Pforward"])], "post_eq": bool(np.array_equal(post[1:, 1:], o.posterior[1:, 1:], equal_nan=True)),
+                                 "ends": [[o.ns, o.i2v, o.j2v], [int(h["nsteps"]), int(h["i2"]), int(h["j2"])]],
+                                 "npost_diff": int((post[1:, 1:] != o.posterior[1:, 1:]).sum())})
+        ms.free()
+    c.close()
+    return {"cases": cases, "mismatches": bad, "diag": diag}
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    orc = po.Oracle()
+    fam = sys.argv[3] if len(sys.argv) > 3 else "all"
+    if fam != "all":
+        print(json.dumps({fam: {"prefilter": prefilter_family, "mac": mac_family, "viterbi": viterbi_family}[fam](orc, rng, budget)}))
+        return
+    out = {"seconds_per_family": budget,
+           "viterbi_backtrace_celloff": viterbi_family(orc, rng, budget),
+           "prefilter": prefilter_family(orc, rng, budget),
+           "mac_realign": mac_family(orc, rng, budget)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
