@@ -172,18 +172,59 @@ def mac_family(orc, rng, budget):
     return {"cases": cases, "mismatches": bad, "diag": diag}
 
 
+def prepare_family(orc, rng, budget):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "gonnet_pb_R.npz"))
+    pb, R = z["pb"], z["R"]
+    t_end, cases, bad = time.time() + budget, 0, 0
+    c = capi.Context(local=1)
+    qp, qtr = synth.make_query(3, 50)
+    c.set_query(qp, qtr)
+    while time.time() < t_end:
+        n = int(rng.integers(1, 10))
+        raws = []
+        for k in range(n):
+            L = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 447, 448, 500, 1301]))
+            f, tr, neff, nh = synth.make_raw_hmm(int(rng.integers(1 << 30)), L)
+            if rng.random() < 0.3:      # columns with a single residue / all-star transitions
+                j = int(rng.integers(1, L + 1))
+                f[j] = 2.0 ** -99.999
+                f[j, rng.integers(0, 20)] = 1.0
+                tr[j - 1] = [0.0, -99.999, -99.999, 0.0, -99.999, 0.0, -99.999]
+            if rng.random() < 0.2:
+                neff[:, 0] = 1.0        # Neff_M = 1: (nM - 1) = 0 in the transition pseudocounts
+            raws.append((f, tr, neff, nh))
+        pcm = int(rng.integers(0, 3))
+        pc = np.array([pcm, float(rng.choice([1.0, 0.4, 0.0, 1.7])), float(rng.choice([1.5, 0.5, 4.0])), 1.0], np.float32)
+        gap = np.array([rng.choice([0.15, 1.0]), rng.choice([1.0, 0.3, 2.0]), 0.6, rng.choice([0.6, 1.0]), 0.6, 0.6,
+                        rng.choice([1.0, 0.0, 2.5])], np.float32)
+        cs = int(rng.integers(0, 4))
+        q_pav = rng.dirichlet(np.ones(20) * 5).astype(np.float32)
+        raw, Ls = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+        ts = c.prepare(raw, Ls, capi.prep_params(pb, R, gap=tuple(gap), pc=tuple(pc), columnscore=cs), q_pav)
+        for k, (f, tr, neff, nh) in enumerate(raws):
+            p, tro, pv = po.oracle_prepare(orc, 1, f, tr, neff, nh, pb, R, q_pav=q_pav, gap=gap, pc=pc, columnscore=cs)
+            want = capi.pack_profile(np.ascontiguousarray(p[:-1]), tro, index=k)
+            cases += 1
+            bad += int(not np.array_equal(c.records_of(ts, k).view(np.uint32), want.view(np.uint32)))
+        c.rawset_free(raw)
+        ts.free()
+    c.close()
+    return {"cases": cases, "mismatches": bad}
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     orc = po.Oracle()
     fam = sys.argv[3] if len(sys.argv) > 3 else "all"
     if fam != "all":
-        print(json.dumps({fam: {"prefilter": prefilter_family, "mac": mac_family, "viterbi": viterbi_family}[fam](orc, rng, budget)}))
+        print(json.dumps({fam: {"prefilter": prefilter_family, "mac": mac_family, "viterbi": viterbi_family, "prepare": prepare_family}[fam](orc, rng, budget)}))
         return
     out = {"seconds_per_family": budget,
            "viterbi_backtrace_celloff": viterbi_family(orc, rng, budget),
            "prefilter": prefilter_family(orc, rng, budget),
-           "mac_realign": mac_family(orc, rng, budget)}
+           "mac_realign": mac_family(orc, rng, budget),
+           "prepare": prepare_family(orc, rng, budget)}
     print(json.dumps(out))
 
 
