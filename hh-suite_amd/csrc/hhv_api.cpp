@@ -1516,7 +1516,7 @@ int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
     for (int i = ilo; i <= ihi; ++i) {
       const int g = (i - ilo) / R, r = (i - ilo) % R;
       uint8_t* row = out + (size_t)i * (Lt + 1);
-      for (int j = 1; j <= Lt; ++j) row[j] = (uint8_t)(e[(size_t)(j - 1) * LANES + g] >> (8 * r));
+      for (int j = 1; j <= Lt; ++j) row[j] = (uint8_t)bt_decode(e[(size_t)(j - 1) * LANES + g], r, R);
     }
   }
   return HHV_OK;

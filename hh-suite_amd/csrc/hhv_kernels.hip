@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
     if (i >= 1 && j >= 1) {
       const int strip = (i - 1) / R, rr = (i - 1) - strip * R;  // strip = pass * 64 + lane
       const int pass = strip / LANES, g = strip - pass * LANES;
-      b = (uint32_t)(a.bt[(size_t)pass * a.bt_pass_stride + (size_t)(rec0 + j) * LANES + g] >> (8 * rr)) & 0xFFu;
+      b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + (size_t)(rec0 + j) * LANES + g], rr, R);
     }
     switch (state) {
       case 2:  // MM

@@ -24,9 +24,11 @@
 #include <hip/hip_runtime.h>
 #define HHV_DEV __device__ __forceinline__
 #define HHV_MEM __device__ __forceinline__
+#define HHV_HD __host__ __device__ __forceinline__
 #else
 #define HHV_DEV static inline
 #define HHV_MEM inline
+#define HHV_HD static inline
 #endif
 
 namespace hhv {
@@ -67,6 +69,39 @@ HHV_DEV float fmax2(float a, float b) {
 #else
   return a > b ? a : b;
 #endif
+}
+
+// ---- backtrace entry (8 bytes per lane per column, R <= 5 cells) -----------------------------------------------------
+// The kernel does not build the reference's backtrace byte (src/hhviterbimatrix.h:35-48) in the inner loop; it only
+// RECORDS the nine comparisons of a cell, one bit each, in evaluation order: acc = 2*acc + (a > b) is two instructions
+// (v_cmp to VCC, v_addc with VCC as carry-in) and needs no select, shift or or.  The byte is decoded where it is read
+// (trace kernel, hhv_backtrace_matrix) by bt_decode below.
+//   phase A, rows R-1 .. 0, seven bits per row: c1 > smin, c2 > m, c3 > m, c4 > m, c5 > m (m = running maximum, so the
+//            MM predecessor is the LAST candidate that won), GD: ga > gb, IM: ia > ib;  rows R-1..1 -> lo, row 0 -> hi[2R+6:2R]
+//   phase C, rows 0 .. R-1, two bits per row: DG: da > db, MI: ma > mb                 -> hi[2R-1:0]
+HHV_DEV void bt_push(uint32_t& acc, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+#else
+  acc = (acc << 1) | (a > b ? 1u : 0u);
+#endif
+}
+// entry -> the reference's byte for row r of the lane (bits 0-2 MM predecessor, 8 GD, 16 IM, 32 DG, 64 MI)
+HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R) {
+  const uint32_t lo = (uint32_t)entry, hi = (uint32_t)(entry >> 32);
+  const uint32_t f7 = r >= 1 ? (lo >> (7 * (r - 1))) & 0x7Fu : (hi >> (2 * R)) & 0x7Fu;
+  const uint32_t c2 = (hi >> (2 * (R - 1 - r))) & 3u;
+  uint32_t b = 0;
+  if (f7 & 0x40u) b = 2;  // c1 > smin            : MM
+  if (f7 & 0x20u) b = 3;  // c2 > max so far      : GD
+  if (f7 & 0x10u) b = 4;  //                        IM
+  if (f7 & 0x08u) b = 5;  //                        DG
+  if (f7 & 0x04u) b = 6;  //                        MI
+  b |= (f7 & 0x02u) ? 8u : 0u;
+  b |= (f7 & 0x01u) ? 16u : 0u;
+  b |= (c2 & 0x02u) ? 32u : 0u;
+  b |= (c2 & 0x01u) ? 64u : 0u;
+  return b;
 }
 
 // src/hhutil-inl.h:509-541, one rounding per operation
@@ -259,7 +294,7 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
 //   rec      : the 28-dword column record
 //   cellbits : CELLOFF only - byte r bit 7 set = cell (i0+r, j) excluded (same byte matrix the
 //              backtrace is written to, src/hhviterbialgorithm.cpp:373-392)
-//   returns  : BT only - byte r = backtrace byte of cell (i0+r, j) (bit layout src/hhviterbimatrix.h:35-48)
+//   returns  : BT only - the 9 compare bits of each of the R cells (layout and decoding: bt_push / bt_decode above)
 //
 // The R cells are evaluated in three phases so that every state register can be updated in place
 // (no loop-carried copies): A (rows bottom-up) everything that reads only column j-1 state - the five
@@ -277,7 +312,7 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   const float tM2M = rec[REC_M2M], tM2D = rec[REC_M2D], tD2M = rec[REC_D2M], tD2D = rec[REC_D2D],
               tI2M = rec[REC_I2M], tI2I = rec[REC_I2I], tM2I = rec[REC_M2I];
   float cmax[R];
-  uint32_t bits[R];
+  uint32_t acc_lo = 0, acc_hi = 0;  // BT: compare bits of rows R-1..1 / of row 0 and phase C (layout: bt_decode)
   // ---- phase A, rows R-1 .. 0: reads (i-1, j-1) = old state of the row above and (i, j-1) = own old state
 #pragma unroll
   for (int r = R - 1; r >= 0; --r) {
@@ -289,18 +324,18 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     const float c3 = (dIM + q.i2m[r]) + tM2M;
     const float c4 = (dDG + q.d2m[r]) + tM2M;
     const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
+    uint32_t& acc = r ? acc_lo : acc_hi;
     float mm;
-    uint32_t b = 0;
     if (BT) {
-      b = (c1 > smin) ? 2u : 0u;
+      bt_push(acc, c1, smin);
       mm = fmax2(smin, c1);
-      b = (c2 > mm) ? 3u : b;
+      bt_push(acc, c2, mm);
       mm = fmax2(mm, c2);
-      b = (c3 > mm) ? 4u : b;
+      bt_push(acc, c3, mm);
       mm = fmax2(mm, c3);
-      b = (c4 > mm) ? 5u : b;
+      bt_push(acc, c4, mm);
       mm = fmax2(mm, c4);
-      b = (c5 > mm) ? 6u : b;
+      bt_push(acc, c5, mm);
       mm = fmax2(mm, c5);
     } else {
       mm = fmax2(fmax2(fmax2(fmax2(fmax2(smin, c1), c2), c3), c4), c5);
@@ -312,10 +347,9 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     const float qm2i = QL ? ql[4 * r + 2] : q.m2i[r], qi2i = QL ? ql[4 * r + 3] : q.i2i[r];
     const float ia = (lMM + qm2i) + tM2M, ib = (st.IM[r] + qi2i) + tM2M;
     if (BT) {
-      b |= (ga > gb) ? 8u : 0u;
-      b |= (ia > ib) ? 16u : 0u;
+      bt_push(acc, ga, gb);
+      bt_push(acc, ia, ib);
     }
-    bits[r] = b;
     st.GD[r] = fmax2(ga, gb);
     st.IM[r] = fmax2(ia, ib);
   }
@@ -329,7 +363,6 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   }
   // ---- phase C, rows 0 .. R-1: (i-1, j) = new state of the row above
   float uMM = in.MM, uDG = in.DG, uMI = in.MI;
-  uint64_t bytes = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float mm = cmax[r] + S[r];
@@ -345,10 +378,8 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
       st.aMI[r] = sb;
     }
     if (BT) {
-      uint32_t b = bits[r];
-      b |= (da > db) ? 32u : 0u;
-      b |= (ma > mb) ? 64u : 0u;
-      bytes |= (uint64_t)b << (8 * r);
+      bt_push(acc_hi, da, db);
+      bt_push(acc_hi, ma, mb);
     }
     if (CELLOFF) {  // :373-392: the masked build adds -FLT_MAX or +0.0f to all five states of every cell
       const float add = ((cellbits >> (8 * r)) & 0x80u) ? NEG_MAX : 0.0f;
@@ -385,7 +416,7 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   st.dIM = in.IM;
   st.dDG = in.DG;
   st.dMI = in.MI;
-  return bytes;
+  return BT ? ((uint64_t)acc_hi << 32) | acc_lo : 0;
 }
 
 }  // namespace hhv

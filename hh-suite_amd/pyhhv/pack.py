@@ -98,15 +98,44 @@ def pack_stream(tps, ttrs, t_ss=None):
     return rec, rec_off
 
 
+def bt_decode(entry, r, R):
+    """numpy mirror of bt_decode (csrc/viterbi_lane.h): uint64 entries -> the reference's backtrace byte of row r."""
+    entry = np.asarray(entry, dtype=np.uint64)
+    lo = (entry & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (entry >> np.uint64(32)).astype(np.uint32)
+    f7 = ((lo >> np.uint32(7 * (r - 1))) if r >= 1 else (hi >> np.uint32(2 * R))) & np.uint32(0x7F)
+    c2 = (hi >> np.uint32(2 * (R - 1 - r))) & np.uint32(3)
+    b = np.zeros(entry.shape, dtype=np.uint8)
+    for bit, code in ((0x40, 2), (0x20, 3), (0x10, 4), (0x08, 5), (0x04, 6)):
+        b = np.where(f7 & np.uint32(bit), np.uint8(code), b)
+    b |= np.where(f7 & np.uint32(2), 8, 0).astype(np.uint8)
+    b |= np.where(f7 & np.uint32(1), 16, 0).astype(np.uint8)
+    b |= np.where(c2 & np.uint32(2), 32, 0).astype(np.uint8)
+    b |= np.where(c2 & np.uint32(1), 64, 0).astype(np.uint8)
+    return b
+
+
 def bt_to_matrix(bt_entries, rec_off_k, Lq, Lt, R, entry_bytes=8):
-    """Device backtrace layout -> reference layout (Lq+1, Lt+1) bytes.
-    bt_entries: flat uint8 view of the [record][lane][entry_bytes] buffer."""
+    """Device backtrace entries (9 compare bits per cell, csrc/viterbi_lane.h bt_push) -> reference layout (Lq+1, Lt+1)
+    bytes.  bt_entries: flat uint8 view of the [pass][record][lane][8] buffer."""
     P = -(-Lq // (LANES * R))
-    e = np.asarray(bt_entries, dtype=np.uint8).reshape(P, -1, LANES, entry_bytes)   # [pass][record][lane][row]
+    e = np.ascontiguousarray(np.asarray(bt_entries, dtype=np.uint8)).reshape(P, -1, LANES, entry_bytes)
+    e = e.view(np.uint64).reshape(P, -1, LANES)                                        # [pass][record][lane]
     out = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
     for i in range(1, Lq + 1):
         strip, r = (i - 1) // R, (i - 1) % R
-        out[i, 1:] = e[strip // LANES, rec_off_k + 1: rec_off_k + 1 + Lt, strip % LANES, r]
+        out[i, 1:] = bt_decode(e[strip // LANES, rec_off_k + 1: rec_off_k + 1 + Lt, strip % LANES], r, R)
+    return out
+
+
+def celloff_bits(bt_entries, rec_off_k, Lq, Lt, R, entry_bytes=8):
+    """The cell-off INPUT of the kernel: bit 7 of byte r of the entry (written by matrix_to_bt / hhv_set_celloff)."""
+    P = -(-Lq // (LANES * R))
+    e = np.asarray(bt_entries, dtype=np.uint8).reshape(P, -1, LANES, entry_bytes)
+    out = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
+    for i in range(1, Lq + 1):
+        strip, r = (i - 1) // R, (i - 1) % R
+        out[i, 1:] = e[strip // LANES, rec_off_k + 1: rec_off_k + 1 + Lt, strip % LANES, r] >> 7
     return out
 
 

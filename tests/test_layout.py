@@ -59,8 +59,7 @@ def test_bt_layout_roundtrip():
     mask[:, 0] = 0
     buf = np.zeros(((Lt + 1 + 1), 64, 8), dtype=np.uint8)
     pack.matrix_to_bt(mask, 0, R, buf)
-    back = pack.bt_to_matrix(buf, 0, Lq, Lt, R)
-    assert np.array_equal((back >> 7) & 1, mask)
+    assert np.array_equal(pack.celloff_bits(buf, 0, Lq, Lt, R), mask)
 
 
 def test_packed_db_file_matches_stream(tmp_path):
