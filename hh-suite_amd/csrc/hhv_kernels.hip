@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       if (meta < 0) {
         TemplateResult res;
         const int new_tid = __builtin_bit_cast(int32_t, rec[0]);
-        if (lane_header<R, LOCAL, !BT>(st, q, in, i0, new_tid, P, lane == g_last, res)) {
+        if (lane_header<R, LOCAL, true>(st, q, in, i0, new_tid, P, lane == g_last, res)) {
           DevResult o;
           o.score = res.score;
           o.i2 = res.i2;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         const float* ql = reinterpret_cast<const float*>(qlds) + lane * 20;
         if (QL) asm volatile("" : "+v"(ql));  // keep the LDS reads inside the loop (they are loop invariant)
         const uint64_t bytes =
-            lane_column<R, LOCAL, BT, CELLOFF, !BT, SS, QL>(st, q, in, rec, j, i0, r_last, P, cell, ssv, ql);
+            lane_column<R, LOCAL, BT, CELLOFF, true, SS, QL>(st, q, in, rec, j, i0, r_last, P, cell, ssv, ql);
         if (BT) *bte = bytes;
       }
       if (carry_out) {

@@ -76,7 +76,7 @@ static int run_pass(const float* qpack, const float* records, long M, Params P, 
         int32_t new_tid;
         memcpy(&new_tid, rec + 0, 4);
         TemplateResult res;
-        if (lane_header<R, LOCAL, !BT>(st[g], q[g], in, i0, new_tid, P, g == g_last, res)) {
+        if (lane_header<R, LOCAL, true>(st[g], q[g], in, i0, new_tid, P, g == g_last, res)) {
           if (res.tid >= 0 && res.tid < n_results) results[res.tid] = res;
           emitted++;
         }
@@ -89,9 +89,9 @@ static int run_pass(const float* qpack, const float* records, long M, Params P, 
           float ssv[R];
           const int tidx = (meta >> ss.t_shift) & ss.t_mask;
           for (int r = 0; r < R; ++r) ssv[r] = ss.table[ss.q_off[i0 - 1 + r] + tidx];
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT, true>(st[g], q[g], in, rec, j, i0, r_last, P, cell, ssv);
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, true>(st[g], q[g], in, rec, j, i0, r_last, P, cell, ssv);
         } else {
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, !BT, false>(st[g], q[g], in, rec, j, i0, r_last, P, cell, nullptr);
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, false>(st[g], q[g], in, rec, j, i0, r_last, P, cell, nullptr);
         }
         if (BT) bt[(size_t)r * 64 + g] = bytes;
       }
