@@ -62,4 +62,8 @@ clean:
 	rm -rf build $(LIBDIR) tests/emul/libwave_emul.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle emul clean
+.PHONY: example all lib oracle emul clean
+
+# plain-C++ use of the host classes (no Python): examples/search_example.cpp
+example: $(RUNNER)
+	g++ -O2 -std=c++14 -Wall -Iinclude -o build/search_example examples/search_example.cpp -L$(LIBDIR) -lhhv_runner -lhhviterbi_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'

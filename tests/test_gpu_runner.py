@@ -79,3 +79,17 @@ def test_runner_excluded_regions(oracle):
     for h, (k, irep, a) in zip(hits, want):
         assert (h["entry"], h["irep"]) == (k, irep) and same_float(h["score"], a.hit_score)
         assert (h["i2"], h["j2"], h["nsteps"]) == (a.i2, a.j2, a.nsteps)
+
+
+def test_cpp_example_runs():
+    """The host classes from plain C++ (examples/search_example.cpp): builds against the two shared objects and finds
+    the related templates, Viterbi and MAC."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", root, "example"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "build", "search_example"), "48"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    lines = out.stdout.strip().splitlines()
+    assert "realigned" in lines[0] and len(lines) >= 12
+    assert all("MAC q" in ln for ln in lines[1:])
