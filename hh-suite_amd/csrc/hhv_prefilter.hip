@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t mask_word(uint32_t word, int lo, int hi) {
 }
 
 // ---- gapless score: one wavefront per sequence ----------------------------------------------------------------
-template <int W>
+template <int W, bool SLAB>
 __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WQ = (W + 3) / 4;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) 
   // a query longer than 64*W positions is processed in slabs of 64*W rows (one launch per slab): the diagonals are
   // carried from slab to slab through one byte per residue (the S value of the slab's last row), which is exact -
   // the gapless score does not depend on how the query is cut
-  fill_profile_lds<64, W>(sprof, a, 1024, a.q_base);
+  fill_profile_lds<64, W>(sprof, a, 1024, SLAB ? a.q_base : 0);
   for (int e = threadIdx.x; e < 64 * WQ; e += 1024) sprof[PF_NULL * 64 * WQ + e] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) 
 #pragma unroll
     for (int t = 0; t < W; ++t) S[t] = 0;
     int vmax = 0;
-    const uint32_t* cin = reinterpret_cast<const uint32_t*>(a.carry_in);
+    const uint32_t* cin = SLAB ? reinterpret_cast<const uint32_t*>(a.carry_in) : nullptr;
     int c_prev = 0;  // S(last row of the previous slab, j-1); 0 in front of the sequence
     uint32_t chunk_next = words[w0 + max(min(lane, nw - 1), 0)];
     uint32_t cchunk_next = cin ? cin[w0 + max(min(lane, nw - 1), 0)] : 0u;
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) 
           S[0] = med3i(carry + sbyte(p[b][0], 0), cap);
 #pragma unroll
           for (int t = 0; t < W; ++t) vmax = max(vmax, S[t]);
-          if (a.carry_out) {
+          if (SLAB && a.carry_out) {
             const int64_t pos = (w0 + wi) * 4 + b;
             if (lane == 63 && pos >= beg && pos < end) a.carry_out[pos] = (unsigned char)S[W - 1];
           }
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) 
       }
     }
     for (int o = 32; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o, 64));
-    if (lane == 0) a.scores[slot] = a.q_base ? max(vmax, a.scores[slot]) : vmax;
+    if (lane == 0) a.scores[slot] = (SLAB && a.q_base) ? max(vmax, a.scores[slot]) : vmax;
   }
 }
 
@@ -203,18 +203,23 @@ __global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
 #pragma unroll
     for (int t = 0; t < W; ++t) H[t] = E[t] = 0;
     int vmax = 0;
-    // element k of the half keeps dword (chunk*32 + k) of the sequence, the next chunk is in flight
+    // element k of the half keeps dword (chunk*32 + k) of the sequence, the next chunk is in flight; the residues are
+    // taken a word (four of them) at a time so that the four profile reads are issued together, ahead of the arithmetic
     uint32_t chunk = 0, chunk_next = words[w0 + min(k, max(nw - 1, 0))];
-    for (int i = 0; i < len; ++i) {
-      const int bpos = head + i;  // byte position relative to word w0
-      if ((bpos & 127) == 0 || i == 0) {
+    for (int wi = 0; wi < nw; ++wi) {
+      if ((wi & 31) == 0) {
         chunk = chunk_next;
-        chunk_next = words[w0 + min((bpos >> 7) * 32 + 32 + k, max(nw - 1, 0))];
+        chunk_next = words[w0 + min(wi + 32 + k, max(nw - 1, 0))];
       }
-      const uint32_t word = (uint32_t)__shfl((int)chunk, (bpos >> 2) & 31, 32);
-      const int x = (word >> (8 * (bpos & 3))) & 0xff;
-      uint32_t p[WQ];
-      read_cells<WQ>(mine + x * (32 * WQ), p);
+      const uint32_t word = (uint32_t)__shfl((int)chunk, wi & 31, 32);
+      uint32_t pw[4][WQ];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) read_cells<WQ>(mine + ((word >> (8 * b)) & 0xff) * (32 * WQ), pw[b]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+      const int rel = wi * 4 + b - head;  // residue index inside the sequence
+      if (rel < 0 || rel >= len) continue;
+      const uint32_t* p = pw[b];
       int F = 0;
       int h = half_shr1_zero(H[W - 1], k);
 #pragma unroll
@@ -253,7 +258,8 @@ __global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
         const int Fs = half_shr1_zero(F, k);
         if (active) F = Fs;
       }
-    }
+      }  // b
+    }    // wi
     for (int o = 16; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o, 32));
     if (k == 0) a.scores[slot] = vmax;
   }
@@ -369,10 +375,12 @@ size_t prefilter_fast_lds(bool gapped, int W) { return (size_t)(gapped ? 220 * 3
 int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream) {
   const size_t lds = prefilter_fast_lds(gapped, W);
   if (!gapped) {
+    const bool slab = a.carry_in != nullptr || a.carry_out != nullptr || a.q_base != 0;
     switch (W) {
 #define HHV_PF_CASE(w) \
   case w:              \
-    return launch_one(hhv_pf_ungapped_kernel<w>, a, n_blocks, 1024, lds, stream);
+    return slab ? launch_one(hhv_pf_ungapped_kernel<w, true>, a, n_blocks, 1024, lds, stream) \
+                : launch_one(hhv_pf_ungapped_kernel<w, false>, a, n_blocks, 1024, lds, stream);
       HHV_PF_CASE(1) HHV_PF_CASE(2) HHV_PF_CASE(3) HHV_PF_CASE(4) HHV_PF_CASE(5) HHV_PF_CASE(6) HHV_PF_CASE(7) HHV_PF_CASE(8)
 #undef HHV_PF_CASE
     }
