@@ -7,12 +7,12 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: the reference build has no FMA; contraction would change low bits.
 # -fno-slp-vectorize: keeps hipcc from pairing scalar fp32 ops into v_pk_* + register shuffles.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off $(HHV_EXTRA_HIPFLAGS) -fPIC -Wall -Wno-unused-result
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off $(HHV_EXTRA_HIPFLAGS) -fPIC -fvisibility=hidden -Wall -Wno-unused-result
 CSRC     := hh-suite_amd/csrc
 LIBDIR   := hh-suite_amd/lib
 OBJDIR   := build/obj
 LIB      := $(LIBDIR)/libhhviterbi_hip.so
-OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_prefilter.o $(OBJDIR)/hhv_mac.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_pack.o
+OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_prefilter.o $(OBJDIR)/hhv_mac.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_api_db.o $(OBJDIR)/hhv_api_prep.o $(OBJDIR)/hhv_api_prefilter.o $(OBJDIR)/hhv_api_mac.o $(OBJDIR)/hhv_pack.o
 HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
 
 RUNNER   := $(LIBDIR)/libhhv_runner.so
@@ -41,6 +41,9 @@ $(OBJDIR)/hhv_topk.o: $(CSRC)/hhv_topk.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(OBJDIR)/hhv_api.o: $(CSRC)/hhv_api.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(OBJDIR)/hhv_api_%.o: $(CSRC)/hhv_api_%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 $(OBJDIR)/hhv_pack.o: $(CSRC)/hhv_pack.cpp $(HDRS)

@@ -1,0 +1,136 @@
+// hhv_api_common.h -- internals shared by the translation units of the C-ABI host layer (hhv_api*.cpp): the opaque
+// handle structs, the thread-local error message and the small device-memory helpers.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hhviterbi_hip.h"
+#include "hhv_internal.h"
+#include "hhv_pack.h"
+#include "viterbi_lane.h"
+
+namespace hhv {
+namespace api {
+
+// sets the message hhv_last_error() returns (thread local) and hands the status code back
+int fail(int code, const char* fmt, ...);
+const char* last_error();
+
+template <typename T>
+inline void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+}  // namespace api
+}  // namespace hhv
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return hhv::api::fail(e_ == hipErrorOutOfMemory ? HHV_E_MEMORY : HHV_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct hhv_ctx {
+  hhv_params par;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  int num_cus = 0;
+  // query: P passes of 64*R rows each (P = 1 up to Lq = 320)
+  int Lq = 0, R = 0, P = 0;
+  float* d_qpack = nullptr;  // [P*64*R][28]
+  float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring
+  // fast_log2 tables (src/util-inl.h:108-130)
+  float* d_lg2 = nullptr;
+  float* d_diff = nullptr;
+  // secondary structure
+  std::vector<float> S73, S33, S37;                    // host copies of the score tables
+  std::vector<int8_t> q_pred, q_conf, q_dssp;          // [Lq+1], empty = absent
+  int ss_hmm_mode = 0;                                 // HMM::NO_SS_INFORMATION
+  bool ss_dirty = true;
+  void* mac_cache = nullptr;                           // one recycled device block of the MAC realignment
+  size_t mac_cache_bytes = 0;
+  float* d_ss_table = nullptr;                         // ssw * table of the current mode
+  int32_t* d_ss_q_off = nullptr;                       // [P*64*R]
+  int ss_t_shift = 0, ss_t_mask = 0;
+};
+
+struct hhv_tset {
+  hhv_ctx* ctx = nullptr;
+  int32_t n = 0;
+  std::vector<int32_t> L;
+  std::vector<int64_t> rec_off;  // [n+1]: header record of template k; rec_off[n] = terminal header
+  int64_t n_records = 0;         // rec_off[n] + 1
+  float* d_records = nullptr;
+  bool owns_records = false;
+  int64_t* d_rec_off = nullptr;
+  int32_t* d_L = nullptr;
+  hhv::DevResult* d_results = nullptr;
+  // wave partition
+  int n_waves = 0;
+  int64_t* d_wave_rec = nullptr;
+  // backtrace bytes: [pass][record][lane] entries
+  uint64_t* d_bt = nullptr;
+  bool bt_valid = false;
+  int bt_Lq = 0, bt_R = 0, bt_P = 0;
+  // carry between the passes of a long query
+  float4* d_carry = nullptr;
+  float* d_carry_mi = nullptr;
+  // trace outputs
+  std::vector<int64_t> path_off;
+  int path_Lq = -1;
+  int64_t* d_path_off = nullptr;
+  int32_t* d_i_steps = nullptr;
+  int32_t* d_j_steps = nullptr;
+  int8_t* d_states = nullptr;
+  float* d_S = nullptr;
+  hhv::DevHit* d_hits = nullptr;
+  bool hits_valid = false;
+  // top-k scratch
+  hhv::DevHit* d_topk = nullptr;
+  int topk_cap = 0;
+  uint64_t* d_keys = nullptr;
+  uint64_t* d_sorted = nullptr;
+  void* d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  hhv::DevHit* d_raw_hits = nullptr;
+};
+
+struct hhv_rawset {
+  hhv_ctx* ctx = nullptr;
+  int32_t n = 0;
+  std::vector<int32_t> L;
+  std::vector<int64_t> rec_off;
+  int64_t n_cols = 0;
+  float* d_raw = nullptr;
+  float* d_neff_hmm = nullptr;
+  float* d_p_tmp = nullptr;
+  float* d_tr_tmp = nullptr;
+  float* d_pav = nullptr;
+  float* d_pb = nullptr;
+  float* d_R = nullptr;
+  float* d_qpav = nullptr;
+  // length classes of the prepare kernels: fused with small LDS (L <= 447), fused with large LDS (L <= 1300), split
+  int32_t* d_ids[3] = {nullptr, nullptr, nullptr};
+  int32_t n_ids[3] = {0, 0, 0};
+  int32_t max_L[3] = {0, 0, 0};
+  bool prepared = false;
+};
+
+
+namespace hhv {
+namespace api {
+// creates the host/device bookkeeping of a template set (record offsets, results) - hhv_api.cpp
+int tset_init_common(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_t* L);
+}  // namespace api
+}  // namespace hhv

@@ -1,0 +1,105 @@
+// hhv_api_db.cpp -- C ABI of the binary packed template database.
+#include "hhv_api_common.h"
+
+using namespace hhv;
+using hhv::api::dfree;
+using hhv::api::fail;
+using hhv::api::tset_init_common;
+
+extern "C" {
+
+// ---- binary packed template database (N1) -------------------------------------------------------
+namespace {
+struct DbHeader {
+  char magic[8];
+  int32_t n;
+  int32_t record_dwords;
+  int64_t n_records;
+  char pad[40];
+};
+static_assert(sizeof(DbHeader) == 64, "db header");
+}  // namespace
+
+int hhv_db_write(const char* path, int32_t n, const int32_t* L, const float* const* p, const float* const* tr,
+                 const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp) {
+  if (!path || !L || !p || !tr || n < 1) return fail(HHV_E_ARG, "hhv_db_write: bad argument");
+  int64_t nrec = 1;
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1 || L[k] > 0xFFFF || !p[k] || !tr[k]) return fail(HHV_E_ARG, "hhv_db_write: template %d invalid", k);
+    nrec += (int64_t)L[k] + 1;
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(HHV_E_ARG, "hhv_db_write: cannot open %s", path);
+  DbHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "HHVPDB01", 8);
+  h.n = n;
+  h.record_dwords = REC_DW;
+  h.n_records = nrec;
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(L, sizeof(int32_t), (size_t)n, f) == (size_t)n;
+  std::vector<float> buf;
+  for (int k = 0; k < n && ok; ++k) {
+    buf.resize(((size_t)L[k] + 1) * REC_DW);
+    pack_template(p[k], tr[k], L[k], k, buf.data(), ss_pred ? ss_pred[k] : nullptr, ss_conf ? ss_conf[k] : nullptr,
+                  ss_dssp ? ss_dssp[k] : nullptr);
+    ok = fwrite(buf.data(), sizeof(float), buf.size(), f) == buf.size();
+  }
+  if (ok) {
+    buf.assign(REC_DW, 0.0f);
+    write_header(buf.data(), -1, 0);
+    ok = fwrite(buf.data(), sizeof(float), REC_DW, f) == (size_t)REC_DW;
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? HHV_OK : fail(HHV_E_ARG, "hhv_db_write: write to %s failed", path);
+}
+
+int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
+  if (!c || !path || !out) return fail(HHV_E_ARG, "hhv_db_open: null argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(HHV_E_ARG, "hhv_db_open: cannot open %s", path);
+  DbHeader h;
+  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "HHVPDB01", 8) != 0 || h.record_dwords != REC_DW || h.n < 1) {
+    fclose(f);
+    return fail(HHV_E_ARG, "hhv_db_open: %s is not a packed template database", path);
+  }
+  std::vector<int32_t> L((size_t)h.n);
+  if (fread(L.data(), sizeof(int32_t), L.size(), f) != L.size()) {
+    fclose(f);
+    return fail(HHV_E_ARG, "hhv_db_open: truncated length table");
+  }
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_tset* ts = new (std::nothrow) hhv_tset();
+  if (!ts) {
+    fclose(f);
+    return fail(HHV_E_MEMORY, "out of host memory");
+  }
+  int rc = tset_init_common(c, ts, h.n, L.data());
+  if (rc == HHV_OK && ts->n_records != h.n_records) rc = fail(HHV_E_ARG, "hhv_db_open: record count mismatch");
+  if (rc == HHV_OK && hipMalloc(&ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
+    rc = fail(HHV_E_MEMORY, "hhv_db_open: device allocation failed");
+  if (rc == HHV_OK) {
+    ts->owns_records = true;
+    (void)hipMemset(ts->d_records + (size_t)ts->n_records * REC_DW, 0, (size_t)STREAM_PAD_RECS * REC_DW * sizeof(float));
+    const size_t slab = (64u << 20) / sizeof(float);
+    std::vector<float> buf(slab);
+    size_t left = (size_t)ts->n_records * REC_DW, off = 0;
+    while (left && rc == HHV_OK) {
+      const size_t m = std::min(left, slab);
+      if (fread(buf.data(), sizeof(float), m, f) != m) rc = fail(HHV_E_ARG, "hhv_db_open: truncated record stream");
+      else if (hipMemcpy(ts->d_records + off, buf.data(), m * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(HHV_E_DEVICE, "hhv_db_open: H2D copy failed");
+      off += m;
+      left -= m;
+    }
+  }
+  fclose(f);
+  if (rc != HHV_OK) {
+    hhv_tset_free(ts);
+    return rc;
+  }
+  *out = ts;
+  return HHV_OK;
+}
+
+}  // extern "C"

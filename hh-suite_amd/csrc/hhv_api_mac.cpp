@@ -1,0 +1,313 @@
+// hhv_api_mac.cpp -- C ABI of the MAC realignment.
+#include "hhv_api_common.h"
+
+using namespace hhv;
+using hhv::api::dfree;
+using hhv::api::fail;
+using hhv::api::tset_init_common;
+
+extern "C" {
+
+// ---- MAC realignment (N4) --------------------------------------------------------------------------------------
+struct hhv_macset {
+  hhv_ctx* ctx = nullptr;
+  int32_t n = 0, Lq = 0;
+  std::vector<int32_t> Lt;
+  std::vector<int64_t> mat_off, path_off;
+  std::vector<hhv_mac_hit> hits;
+  void* d_block = nullptr;  // one allocation, carved below
+  size_t block_bytes = 0;
+  unsigned char* d_celloff = nullptr;
+  float* d_mat = nullptr;
+  int32_t* d_path_i = nullptr;
+  int32_t* d_path_j = nullptr;
+  signed char* d_path_state = nullptr;
+  float* d_path_S = nullptr;
+  float* d_path_P = nullptr;
+  // all five path arrays, fetched with one copy when the kernels are done
+  std::vector<char> h_paths;
+  size_t h_pi = 0, h_pj = 0, h_ps = 0, h_pS = 0, h_pP = 0;
+};
+
+void hhv_macset_free(hhv_macset* ms) {
+  if (!ms) return;
+  if (ms->ctx) (void)hipSetDevice(ms->ctx->par.device);
+  if (ms->ctx && ms->d_block && ms->block_bytes > ms->ctx->mac_cache_bytes) {
+    // keep the larger block for the next batch (the next round / the next query) instead of hipFree + hipMalloc
+    dfree(ms->ctx->mac_cache);
+    ms->ctx->mac_cache = ms->d_block;
+    ms->ctx->mac_cache_bytes = ms->block_bytes;
+  } else {
+    dfree(ms->d_block);
+  }
+  delete ms;
+}
+
+struct MacMaskInput {  // what hhv_mac_realign_hits adds: masks are built on the device
+  const hhv_mac_input* in = nullptr;
+  int32_t n_qranges = 0, n_tranges = 0;
+  const int32_t* qranges = nullptr;
+  const int32_t* tranges = nullptr;
+};
+
+static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                            const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff,
+                            const MacMaskInput* mi, int32_t local, float shift, float mact, hhv_macset** out,
+                            hhv_mac_hit* hits) {
+  if (!c || !q_p || !q_tr_lin || !Lt || !t_p || !t_tr_lin || !out || !hits) return fail(HHV_E_ARG, "hhv_mac_realign: null argument");
+  *out = nullptr;
+  if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
+  int max_Lt = 0;
+  for (int k = 0; k < n; ++k) {
+    if (Lt[k] < 1 || !t_p[k] || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
+    max_Lt = std::max(max_Lt, Lt[k]);
+  }
+  if ((size_t)10 * (max_Lt + 2) * sizeof(double) > 160 * 1024)
+    return fail(HHV_E_LIMIT, "hhv_mac_realign: template length %d exceeds the LDS row state (limit 2046)", max_Lt);
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_macset* ms = new (std::nothrow) hhv_macset();
+  if (!ms) return fail(HHV_E_MEMORY, "out of host memory");
+  ms->ctx = c;
+  ms->n = n;
+  ms->Lq = Lq;
+  ms->Lt.assign(Lt, Lt + n);
+  ms->mat_off.resize(n + 1);
+  ms->path_off.resize(n + 1);
+  std::vector<int64_t> col_off(n + 1);
+  ms->mat_off[0] = ms->path_off[0] = col_off[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    ms->mat_off[k + 1] = ms->mat_off[k] + ((int64_t)(Lq + 1) * (Lt[k] + 1) + 3) / 4 * 4;
+    ms->path_off[k + 1] = ms->path_off[k] + (Lq + Lt[k] + 2 + 3) / 4 * 4;
+    col_off[k + 1] = col_off[k] + Lt[k] + 1;
+  }
+  const int64_t cells = ms->mat_off[n], steps = ms->path_off[n], cols = col_off[n];
+  // device-built masks: Viterbi paths and excluded cells, concatenated
+  std::vector<int64_t> vit_off(n + 1, 0), excl_off(n + 1, 0);
+  std::vector<int32_t> vit_i, vit_j, excl_i, excl_j, ends, ranges;
+  if (mi) {
+    for (int k = 0; k < n; ++k) {
+      const hhv_mac_input& h = mi->in[k];
+      if (h.nsteps < 0 || h.n_excluded < 0 || (h.nsteps > 0 && (!h.i || !h.j)) || (h.n_excluded > 0 && (!h.excluded_i || !h.excluded_j))) {
+        delete ms;
+        return fail(HHV_E_ARG, "hhv_mac_realign_hits: bad input %d", k);
+      }
+      vit_off[k + 1] = vit_off[k] + h.nsteps;
+      excl_off[k + 1] = excl_off[k] + h.n_excluded;
+    }
+    vit_i.resize((size_t)vit_off[n] + 1);
+    vit_j.resize((size_t)vit_off[n] + 1);
+    excl_i.resize((size_t)excl_off[n] + 1);
+    excl_j.resize((size_t)excl_off[n] + 1);
+    ends.resize((size_t)n * 4);
+    for (int k = 0; k < n; ++k) {
+      const hhv_mac_input& h = mi->in[k];
+      if (h.nsteps) {
+        memcpy(&vit_i[(size_t)vit_off[k]], h.i + 1, (size_t)h.nsteps * 4);  // entries 1..nsteps
+        memcpy(&vit_j[(size_t)vit_off[k]], h.j + 1, (size_t)h.nsteps * 4);
+      }
+      if (h.n_excluded) {
+        memcpy(&excl_i[(size_t)excl_off[k]], h.excluded_i, (size_t)h.n_excluded * 4);
+        memcpy(&excl_j[(size_t)excl_off[k]], h.excluded_j, (size_t)h.n_excluded * 4);
+      }
+      ends[(size_t)k * 4 + 0] = h.i1;
+      ends[(size_t)k * 4 + 1] = h.j1;
+      ends[(size_t)k * 4 + 2] = h.i2;
+      ends[(size_t)k * 4 + 3] = h.j2;
+    }
+    for (int r = 0; r < mi->n_qranges * 2; ++r) ranges.push_back(mi->qranges[r]);
+    for (int r = 0; r < mi->n_tranges * 2; ++r) ranges.push_back(mi->tranges[r]);
+  }
+  ranges.push_back(0);
+  // carve one device allocation (256-byte aligned pieces)
+  size_t total = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t at = total;
+    total += (bytes + 255) / 256 * 256;
+    return at;
+  };
+  const size_t o_qp = carve((size_t)(Lq + 1) * 20 * 4), o_qtr = carve((size_t)(Lq + 1) * 7 * 4), o_tp = carve((size_t)cols * 20 * 4),
+               o_ttr = carve((size_t)cols * 7 * 4), o_col = carve((size_t)n * 8), o_Lt = carve((size_t)n * 4),
+               o_moff = carve((size_t)n * 8), o_co = carve((size_t)cells), o_mat = carve((size_t)cells * 4),
+               o_bmm = carve((size_t)cells), o_scale = carve((size_t)n * (Lq + 2) * 8), o_pf = carve((size_t)n * 8),
+               o_hits = carve((size_t)n * sizeof(DevMacHit)), o_poff = carve((size_t)n * 8), o_pi = carve((size_t)steps * 4),
+               o_pj = carve((size_t)steps * 4), o_ps = carve((size_t)steps), o_pS = carve((size_t)steps * 4),
+               o_pP = carve((size_t)steps * 4);
+  const size_t path_bytes = total - o_pi;
+  const size_t o_ends = carve(ends.size() * 4 + 16), o_voff = carve((size_t)(n + 1) * 8), o_vi = carve(vit_i.size() * 4 + 4),
+               o_vj = carve(vit_j.size() * 4 + 4), o_xoff = carve((size_t)(n + 1) * 8), o_xi = carve(excl_i.size() * 4 + 4),
+               o_xj = carve(excl_j.size() * 4 + 4), o_rg = carve(ranges.size() * 4);
+  if (c->mac_cache && c->mac_cache_bytes >= total) {
+    ms->d_block = c->mac_cache;
+    ms->block_bytes = c->mac_cache_bytes;
+    c->mac_cache = nullptr;
+    c->mac_cache_bytes = 0;
+  } else if (hipMalloc(&ms->d_block, total) != hipSuccess) {
+    delete ms;
+    return fail(HHV_E_MEMORY, "hhv_mac_realign: cannot allocate %zu bytes on the device", total);
+  } else {
+    ms->block_bytes = total;
+  }
+  char* base = (char*)ms->d_block;
+  // host staging of the ragged inputs
+  std::vector<float> tp((size_t)cols * 20), ttr((size_t)cols * 7);
+  std::vector<unsigned char> co;
+  if (!mi) co.assign((size_t)cells, 0);
+  for (int k = 0; k < n; ++k) {
+    memcpy(&tp[(size_t)col_off[k] * 20], t_p[k], (size_t)(Lt[k] + 1) * 20 * 4);
+    memcpy(&ttr[(size_t)col_off[k] * 7], t_tr_lin[k], (size_t)(Lt[k] + 1) * 7 * 4);
+    if (!mi && celloff && celloff[k]) {
+      unsigned char* dst = &co[(size_t)ms->mat_off[k]];
+      const uint8_t* src = celloff[k];
+      for (size_t e = 0; e < (size_t)(Lq + 1) * (Lt[k] + 1); ++e) dst[e] = src[e] ? 1 : 0;
+    }
+  }
+  int rc = HHV_OK;
+  hipStream_t st = c->stream;
+  if (hipMemcpyAsync(base + o_qp, q_p, (size_t)(Lq + 1) * 20 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(base + o_qtr, q_tr_lin, (size_t)(Lq + 1) * 7 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(base + o_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(base + o_ttr, ttr.data(), ttr.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(base + o_col, col_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(base + o_Lt, Lt, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(base + o_moff, ms->mat_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+      (!mi && hipMemcpyAsync(base + o_co, co.data(), co.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
+      (mi && (hipMemcpyAsync(base + o_ends, ends.data(), ends.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_voff, vit_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_vi, vit_i.data(), vit_i.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_vj, vit_j.data(), vit_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_xoff, excl_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_xi, excl_i.data(), excl_i.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_xj, excl_j.data(), excl_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_rg, ranges.data(), ranges.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess)) ||
+      hipMemcpyAsync(base + o_poff, ms->path_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = fail(HHV_E_DEVICE, "hhv_mac_realign: H2D copy failed");
+  MacArgs a;
+  a.n = n;
+  a.Lq = Lq;
+  a.q_p = (const float*)(base + o_qp);
+  a.q_tr = (const float*)(base + o_qtr);
+  a.t_p = (const float*)(base + o_tp);
+  a.t_tr = (const float*)(base + o_ttr);
+  a.col_off = (const int64_t*)(base + o_col);
+  a.Lt = (const int32_t*)(base + o_Lt);
+  a.mat_off = (const int64_t*)(base + o_moff);
+  a.celloff = (const unsigned char*)(base + o_co);
+  a.mat = (float*)(base + o_mat);
+  a.bmm = (unsigned char*)(base + o_bmm);
+  a.scale = (double*)(base + o_scale);
+  a.Pforward = (double*)(base + o_pf);
+  a.hits = (DevMacHit*)(base + o_hits);
+  a.Cshift = pow(2.0, (double)shift);  // src/hhforwardalgorithm.cpp:15
+  a.mact = mact;
+  a.path_off = (const int64_t*)(base + o_poff);
+  a.path_i = (int32_t*)(base + o_pi);
+  a.path_j = (int32_t*)(base + o_pj);
+  a.path_state = (signed char*)(base + o_ps);
+  a.path_S = (float*)(base + o_pS);
+  a.path_P = (float*)(base + o_pP);
+  a.lg2 = c->d_lg2;
+  a.diff = c->d_diff;
+  ms->d_mat = a.mat;
+  ms->d_celloff = (unsigned char*)(base + o_co);
+  ms->d_path_i = a.path_i;
+  ms->d_path_j = a.path_j;
+  ms->d_path_state = a.path_state;
+  ms->d_path_S = a.path_S;
+  ms->d_path_P = a.path_P;
+  if (rc == HHV_OK) {
+    (void)hipEventRecord(c->ev0, st);
+    int lr = 0;
+    if (mi) {
+      MacMaskArgs m;
+      m.ends = (const int4*)(base + o_ends);
+      m.vit_off = (const int64_t*)(base + o_voff);
+      m.vit_i = (const int32_t*)(base + o_vi);
+      m.vit_j = (const int32_t*)(base + o_vj);
+      m.excl_off = (const int64_t*)(base + o_xoff);
+      m.excl_i = (const int32_t*)(base + o_xi);
+      m.excl_j = (const int32_t*)(base + o_xj);
+      m.ranges = (const int32_t*)(base + o_rg);
+      m.n_qranges = mi->n_qranges;
+      m.n_tranges = mi->n_tranges;
+      lr = launch_mac_mask(a, m, st);
+    }
+    if (lr == 0) lr = launch_mac(a, local != 0, max_Lt, st);
+    (void)hipEventRecord(c->ev1, st);
+    c->ev_valid = true;
+    if (lr != 0) rc = fail(HHV_E_DEVICE, "MAC kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
+  }
+  static_assert(sizeof(DevMacHit) == sizeof(hhv_mac_hit), "hhv_mac_hit layout");
+  ms->hits.resize(n);
+  ms->h_paths.resize(path_bytes);
+  ms->h_pi = 0;
+  ms->h_pj = o_pj - o_pi;
+  ms->h_ps = o_ps - o_pi;
+  ms->h_pS = o_pS - o_pi;
+  ms->h_pP = o_pP - o_pi;
+  if (rc == HHV_OK && (hipMemcpyAsync(ms->hits.data(), base + o_hits, (size_t)n * sizeof(hhv_mac_hit), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                       hipMemcpyAsync(ms->h_paths.data(), base + o_pi, path_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                       hipStreamSynchronize(st) != hipSuccess))
+    rc = fail(HHV_E_DEVICE, "hhv_mac_realign: kernels failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc != HHV_OK) {
+    hhv_macset_free(ms);
+    return rc;
+  }
+  memcpy(hits, ms->hits.data(), (size_t)n * sizeof(hhv_mac_hit));
+  *out = ms;
+  return HHV_OK;
+}
+
+int hhv_mac_realign(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                    const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff, int32_t local,
+                    float shift, float mact, hhv_macset** out, hhv_mac_hit* hits) {
+  return mac_realign_impl(c, q_p, q_tr_lin, Lq, n, Lt, t_p, t_tr_lin, celloff, nullptr, local, shift, mact, out, hits);
+}
+
+int hhv_mac_realign_hits(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n, const int32_t* Lt,
+                         const float* const* t_p, const float* const* t_tr_lin, const hhv_mac_input* in, int32_t n_qranges,
+                         const int32_t* qranges, int32_t n_tranges, const int32_t* tranges, int32_t local, float shift,
+                         float mact, hhv_macset** out, hhv_mac_hit* hits) {
+  if (!in || n_qranges < 0 || n_tranges < 0 || (n_qranges && !qranges) || (n_tranges && !tranges))
+    return fail(HHV_E_ARG, "hhv_mac_realign_hits: bad argument");
+  MacMaskInput mi;
+  mi.in = in;
+  mi.n_qranges = n_qranges;
+  mi.qranges = qranges;
+  mi.n_tranges = n_tranges;
+  mi.tranges = tranges;
+  return mac_realign_impl(c, q_p, q_tr_lin, Lq, n, Lt, t_p, t_tr_lin, nullptr, &mi, local, shift, mact, out, hits);
+}
+
+int hhv_mac_celloff(hhv_macset* ms, int32_t k, uint8_t* mask) {
+  if (!ms || k < 0 || k >= ms->n || !mask) return fail(HHV_E_ARG, "hhv_mac_celloff: bad argument");
+  HIP_TRY(hipSetDevice(ms->ctx->par.device));
+  HIP_TRY(hipMemcpy(mask, ms->d_celloff + ms->mat_off[k], (size_t)(ms->Lq + 1) * (ms->Lt[k] + 1), hipMemcpyDeviceToHost));
+  return HHV_OK;
+}
+
+int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps, int8_t* states, float* S,
+                 float* P_posterior, int32_t* nsteps) {
+  if (!ms || k < 0 || k >= ms->n || !nsteps) return fail(HHV_E_ARG, "hhv_mac_path: bad argument");
+  const int ns = ms->hits[k].nsteps;
+  *nsteps = ns;
+  if (cap < ns + 1) return fail(HHV_E_ARG, "hhv_mac_path: cap %d < nsteps + 1 = %d", cap, ns + 1);
+  const int64_t o = ms->path_off[k];
+  const size_t cnt = (size_t)ns + 1;
+  const char* hp = ms->h_paths.data();
+  if (i_steps) memcpy(i_steps, hp + ms->h_pi + (size_t)o * 4, cnt * 4);
+  if (j_steps) memcpy(j_steps, hp + ms->h_pj + (size_t)o * 4, cnt * 4);
+  if (states) memcpy(states, hp + ms->h_ps + (size_t)o, cnt);
+  if (S) memcpy(S, hp + ms->h_pS + (size_t)o * 4, cnt * 4);
+  if (P_posterior) memcpy(P_posterior, hp + ms->h_pP + (size_t)o * 4, cnt * 4);
+  return HHV_OK;
+}
+
+int hhv_mac_posterior(hhv_macset* ms, int32_t k, float* posterior) {
+  if (!ms || k < 0 || k >= ms->n || !posterior) return fail(HHV_E_ARG, "hhv_mac_posterior: bad argument");
+  HIP_TRY(hipSetDevice(ms->ctx->par.device));
+  HIP_TRY(hipMemcpy(posterior, ms->d_mat + ms->mat_off[k], (size_t)(ms->Lq + 1) * (ms->Lt[k] + 1) * 4, hipMemcpyDeviceToHost));
+  return HHV_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+// hhv_api_prep.cpp -- C ABI of the on-device PrepareTemplateHMM and the raw template database file.
+#include "hhv_api_common.h"
+
+using namespace hhv;
+using hhv::api::dfree;
+using hhv::api::fail;
+using hhv::api::tset_init_common;
+
+extern "C" {
+
+// ---- on-device PrepareTemplateHMM (N2) ---------------------------------------------------------------
+void hhv_rawset_free(hhv_rawset* rs);
+// raw HMMs -> the 32-dword raw column block the prepare kernels read (hhv_internal.h RAW_*)
+static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, const float* const* tr, const float* const* neff,
+                           const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp,
+                           std::vector<float>* host) {
+  int64_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1 || L[k] > 0xFFFF || !f[k] || !tr[k] || !neff[k]) return fail(HHV_E_ARG, "raw template %d invalid", k);
+    off += (int64_t)L[k] + 1;
+  }
+  host->assign((size_t)off * RAW_DW, 0.0f);
+  off = 0;
+  for (int k = 0; k < n; ++k) {
+    for (int i = 0; i <= L[k]; ++i) {
+      float* w = host->data() + (size_t)(off + i) * RAW_DW;
+      memcpy(w + RAW_F, f[k] + (size_t)i * 20, 20 * sizeof(float));
+      memcpy(w + RAW_TR, tr[k] + (size_t)i * 7, 7 * sizeof(float));
+      memcpy(w + RAW_NEFF, neff[k] + (size_t)i * 3, 3 * sizeof(float));
+      int32_t meta = i;
+      if (i >= 1) {
+        const int pr = ss_pred && ss_pred[k] ? (unsigned char)ss_pred[k][i] : 0, cf = ss_conf && ss_conf[k] ? ss_conf[k][i] : 0;
+        const int ds = ss_dssp && ss_dssp[k] ? (unsigned char)ss_dssp[k][i] : 0;
+        meta |= (int32_t)((unsigned char)(pr * 11 + cf) & META_PRED_MASK) << META_PRED_SHIFT;
+        meta |= (int32_t)(ds & META_DSSP_MASK) << META_DSSP_SHIFT;
+      }
+      memcpy(w + RAW_J, &meta, 4);
+      const int32_t Lk = L[k];
+      memcpy(w + RAW_L, &Lk, 4);
+    }
+    off += (int64_t)L[k] + 1;
+  }
+  return HHV_OK;
+}
+
+// raw column block -> resident raw set (the block may come from build_raw_block or straight from a raw database file)
+static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const float* neff_hmm, const float* block,
+                             size_t block_floats, hhv_rawset** out) {
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_rawset* rs = new (std::nothrow) hhv_rawset();
+  if (!rs) return fail(HHV_E_MEMORY, "out of host memory");
+  rs->ctx = c;
+  rs->n = n;
+  rs->L.assign(L, L + n);
+  rs->rec_off.resize((size_t)n + 1);
+  int64_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1 || L[k] > 0xFFFF) {
+      delete rs;
+      return fail(HHV_E_ARG, "raw template %d: length %d", k, L[k]);
+    }
+    rs->rec_off[k] = off;
+    off += (int64_t)L[k] + 1;
+  }
+  rs->rec_off[n] = off;
+  rs->n_cols = off;
+  if ((size_t)off * RAW_DW != block_floats) {
+    delete rs;
+    return fail(HHV_E_ARG, "raw column block has %zu floats, expected %zu", block_floats, (size_t)off * RAW_DW);
+  }
+  // length classes of the prepare kernels (hhv_prep.hip): the fused kernel keeps a template in LDS
+  std::vector<int32_t> cls_ids[3];
+  for (int k = 0; k < n; ++k) {
+    const int cls = L[k] <= 447 ? 0 : (L[k] <= 1300 ? 1 : 2);
+    cls_ids[cls].push_back(k);
+    rs->max_L[cls] = std::max(rs->max_L[cls], L[k]);
+  }
+  bool ok = true;
+  for (int cls = 0; cls < 3 && ok; ++cls) {
+    rs->n_ids[cls] = (int32_t)cls_ids[cls].size();
+    if (rs->n_ids[cls] == 0) continue;
+    ok = hipMalloc(&rs->d_ids[cls], cls_ids[cls].size() * sizeof(int32_t)) == hipSuccess &&
+         hipMemcpy(rs->d_ids[cls], cls_ids[cls].data(), cls_ids[cls].size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  // the intermediate of the split path (columns indexed like the raw stream) exists only if a template needs it
+  if (ok && rs->n_ids[2] > 0)
+    ok = hipMalloc(&rs->d_p_tmp, (size_t)off * 20 * sizeof(float)) == hipSuccess &&
+         hipMalloc(&rs->d_tr_tmp, (size_t)off * 8 * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&rs->d_raw, block_floats * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_neff_hmm, (size_t)n * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_pav, (size_t)n * 20 * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_pb, 20 * sizeof(float)) == hipSuccess && hipMalloc(&rs->d_R, 400 * sizeof(float)) == hipSuccess &&
+            hipMalloc(&rs->d_qpav, 20 * sizeof(float)) == hipSuccess &&
+            hipMemcpy(rs->d_raw, block, block_floats * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(rs->d_neff_hmm, neff_hmm, (size_t)n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    hhv_rawset_free(rs);
+    return fail(HHV_E_MEMORY, "raw template set: device allocation/copy failed");
+  }
+  *out = rs;
+  return HHV_OK;
+}
+
+int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
+                             const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
+                             const int8_t* const* ss_conf, const int8_t* const* ss_dssp, hhv_rawset** out) {
+  if (!c || !L || !f || !tr || !neff || !neff_hmm || !out) return fail(HHV_E_ARG, "hhv_upload_raw_templates: null argument");
+  if (n < 1) return fail(HHV_E_ARG, "hhv_upload_raw_templates: n = %d", n);
+  *out = nullptr;
+  std::vector<float> host;
+  const int rc = build_raw_block(n, L, f, tr, neff, ss_pred, ss_conf, ss_dssp, &host);
+  if (rc != HHV_OK) return rc;
+  return rawset_from_block(c, n, L, neff_hmm, host.data(), host.size(), out);
+}
+
+// Raw template database file (N1 for the N2 path): header, lengths, Neff_HMM, then the raw column block exactly as it
+// sits in HBM - built once from the .hhm files, loaded per search without parsing or repacking.
+namespace {
+struct RawDbHeader {
+  char magic[8];
+  int32_t n;
+  int32_t column_dwords;
+  int64_t n_cols;
+  char pad[40];
+};
+static_assert(sizeof(RawDbHeader) == 64, "raw db header");
+}  // namespace
+
+int hhv_rawdb_write(const char* path, int32_t n, const int32_t* L, const float* const* f, const float* const* tr,
+                    const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
+                    const int8_t* const* ss_conf, const int8_t* const* ss_dssp) {
+  if (!path || !L || !f || !tr || !neff || !neff_hmm || n < 1) return fail(HHV_E_ARG, "hhv_rawdb_write: bad argument");
+  std::vector<float> host;
+  const int rc = build_raw_block(n, L, f, tr, neff, ss_pred, ss_conf, ss_dssp, &host);
+  if (rc != HHV_OK) return rc;
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return fail(HHV_E_ARG, "hhv_rawdb_write: cannot open %s", path);
+  RawDbHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "HHVRAW01", 8);
+  h.n = n;
+  h.column_dwords = RAW_DW;
+  h.n_cols = (int64_t)(host.size() / RAW_DW);
+  bool ok = fwrite(&h, sizeof(h), 1, fp) == 1 && fwrite(L, sizeof(int32_t), (size_t)n, fp) == (size_t)n &&
+            fwrite(neff_hmm, sizeof(float), (size_t)n, fp) == (size_t)n &&
+            fwrite(host.data(), sizeof(float), host.size(), fp) == host.size();
+  ok = (fclose(fp) == 0) && ok;
+  return ok ? HHV_OK : fail(HHV_E_ARG, "hhv_rawdb_write: write to %s failed", path);
+}
+
+int hhv_rawdb_open(hhv_ctx* c, const char* path, hhv_rawset** out) {
+  if (!c || !path || !out) return fail(HHV_E_ARG, "hhv_rawdb_open: null argument");
+  *out = nullptr;
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return fail(HHV_E_ARG, "hhv_rawdb_open: cannot open %s", path);
+  RawDbHeader h;
+  if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "HHVRAW01", 8) != 0 || h.column_dwords != RAW_DW || h.n < 1 ||
+      h.n_cols < 2) {
+    fclose(fp);
+    return fail(HHV_E_ARG, "hhv_rawdb_open: %s is not a raw template database", path);
+  }
+  std::vector<int32_t> L((size_t)h.n);
+  std::vector<float> neff_hmm((size_t)h.n), block((size_t)h.n_cols * RAW_DW);
+  const bool ok = fread(L.data(), sizeof(int32_t), L.size(), fp) == L.size() &&
+                  fread(neff_hmm.data(), sizeof(float), neff_hmm.size(), fp) == neff_hmm.size() &&
+                  fread(block.data(), sizeof(float), block.size(), fp) == block.size();
+  fclose(fp);
+  if (!ok) return fail(HHV_E_ARG, "hhv_rawdb_open: %s is truncated", path);
+  return rawset_from_block(c, h.n, L.data(), neff_hmm.data(), block.data(), block.size(), out);
+}
+
+int32_t hhv_rawset_size(const hhv_rawset* rs) { return rs ? rs->n : 0; }
+int hhv_rawset_lengths(const hhv_rawset* rs, int32_t* L) {
+  if (!rs || !L) return fail(HHV_E_ARG, "hhv_rawset_lengths: null argument");
+  memcpy(L, rs->L.data(), (size_t)rs->n * sizeof(int32_t));
+  return HHV_OK;
+}
+
+void hhv_rawset_free(hhv_rawset* rs) {
+  if (!rs) return;
+  if (rs->ctx) (void)hipSetDevice(rs->ctx->par.device);
+  dfree(rs->d_raw);
+  dfree(rs->d_neff_hmm);
+  dfree(rs->d_p_tmp);
+  dfree(rs->d_tr_tmp);
+  dfree(rs->d_pav);
+  dfree(rs->d_pb);
+  dfree(rs->d_R);
+  dfree(rs->d_qpav);
+  for (int cls = 0; cls < 3; ++cls) dfree(rs->d_ids[cls]);
+  delete rs;
+}
+
+int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out) {
+  if (!c || !rs || !par || !q_pav || !out) return fail(HHV_E_ARG, "hhv_prepare_templates: null argument");
+  if (rs->ctx != c) return fail(HHV_E_ARG, "hhv_prepare_templates: raw set belongs to another context");
+  if (par->pcm < 0 || par->pcm > 2) return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm = %d (only 0, 1, 2)", par->pcm);
+  if (par->pcm == 2 && par->pcc != 1.0f)
+    return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcc = %g; only the default pcc = 1 avoids libm pow() and is built", par->pcc);
+  if (par->columnscore < 0 || par->columnscore > 3)
+    return fail(HHV_E_LIMIT, "hhv_prepare_templates: columnscore = %d (only 0..3)", par->columnscore);
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_tset* ts = *out;
+  if (!ts) {
+    ts = new (std::nothrow) hhv_tset();
+    if (!ts) return fail(HHV_E_MEMORY, "out of host memory");
+    int rc = tset_init_common(c, ts, rs->n, rs->L.data());
+    if (rc == HHV_OK && hipMalloc(&ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
+      rc = fail(HHV_E_MEMORY, "hhv_prepare_templates: device allocation failed");
+    if (rc != HHV_OK) {
+      hhv_tset_free(ts);
+      return rc;
+    }
+    ts->owns_records = true;
+    std::vector<float> tail((size_t)(1 + STREAM_PAD_RECS) * REC_DW, 0.0f);
+    write_header(tail.data(), -1, 0);
+    HIP_TRY(hipMemcpy(ts->d_records + (size_t)ts->rec_off[rs->n] * REC_DW, tail.data(), tail.size() * sizeof(float),
+                      hipMemcpyHostToDevice));
+  } else if (ts->n != rs->n || ts->n_records != rs->n_cols + 1) {
+    return fail(HHV_E_ARG, "hhv_prepare_templates: *out was not created from this raw set");
+  }
+  HIP_TRY(hipMemcpyAsync(rs->d_pb, par->pb, 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(rs->d_R, par->R, 400 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(rs->d_qpav, q_pav, 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  PrepArgs a;
+  a.raw = rs->d_raw;
+  a.n_cols = rs->n_cols;
+  a.rec_off = ts->d_rec_off;
+  a.L = ts->d_L;
+  a.neff_hmm = rs->d_neff_hmm;
+  a.pb = rs->d_pb;
+  a.R = rs->d_R;
+  a.q_pav = rs->d_qpav;
+  a.lg2 = c->d_lg2;
+  a.diff = c->d_diff;
+  a.p_tmp = rs->d_p_tmp;
+  a.tr_tmp = rs->d_tr_tmp;
+  a.records = ts->d_records;
+  a.pav_out = rs->d_pav;
+  a.gapd = par->gapd;
+  a.gape = par->gape;
+  a.gapf = par->gapf;
+  a.gapg = par->gapg;
+  a.gaph = par->gaph;
+  a.gapi = par->gapi;
+  a.gapb = par->gapb;
+  a.pcm = par->pcm;
+  a.pca = par->pca;
+  a.pcb = par->pcb;
+  a.columnscore = par->columnscore;
+  a.ids = nullptr;
+  a.lds_cols = 0;
+  const int rc = launch_prepare(a, rs->d_ids, rs->n_ids, rs->max_L, c->stream);
+  if (rc != 0) {
+    if (!*out) hhv_tset_free(ts);
+    return fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  rs->prepared = true;
+  ts->bt_valid = false;
+  ts->hits_valid = false;
+  *out = ts;
+  return HHV_OK;
+}
+
+int hhv_rawset_pav(hhv_ctx* c, hhv_rawset* rs, float* pav) {
+  if (!c || !rs || !pav) return fail(HHV_E_ARG, "hhv_rawset_pav: null argument");
+  if (!rs->prepared) return fail(HHV_E_STATE, "hhv_rawset_pav: call hhv_prepare_templates first");
+  HIP_TRY(hipSetDevice(c->par.device));
+  HIP_TRY(hipMemcpy(pav, rs->d_pav, (size_t)rs->n * 20 * sizeof(float), hipMemcpyDeviceToHost));
+  return HHV_OK;
+}
+
+int hhv_tset_records_of(hhv_ctx* c, hhv_tset* ts, int32_t k, float* out) {
+  if (!c || !ts || !out) return fail(HHV_E_ARG, "hhv_tset_records_of: null argument");
+  if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_tset_records_of: template %d of %d", k, ts->n);
+  HIP_TRY(hipSetDevice(c->par.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out, ts->d_records + (size_t)ts->rec_off[k] * REC_DW, (size_t)(ts->L[k] + 1) * REC_DW * sizeof(float),
+                    hipMemcpyDeviceToHost));
+  return HHV_OK;
+}
+
+
+}  // extern "C"

@@ -46,6 +46,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HHV_ABI_VERSION 1
 
@@ -288,6 +292,9 @@ int hhv_hit_path(hhv_ctx* ctx, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_
 #define HHV_TOPK_RAW 1u
 int hhv_topk(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, void* d_out, int32_t* n_out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
