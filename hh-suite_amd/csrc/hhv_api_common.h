@@ -113,6 +113,7 @@ struct hhv_rawset {
   std::vector<int64_t> rec_off;
   int64_t n_cols = 0;
   float* d_raw = nullptr;
+  int64_t* d_raw_off = nullptr;  // [n+1] first column of every template in d_raw
   float* d_neff_hmm = nullptr;
   float* d_p_tmp = nullptr;
   float* d_tr_tmp = nullptr;

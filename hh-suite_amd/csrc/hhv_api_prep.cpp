@@ -86,6 +86,8 @@ static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const floa
   if (ok && rs->n_ids[2] > 0)
     ok = hipMalloc(&rs->d_p_tmp, (size_t)off * 20 * sizeof(float)) == hipSuccess &&
          hipMalloc(&rs->d_tr_tmp, (size_t)off * 8 * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&rs->d_raw_off, (size_t)(n + 1) * sizeof(int64_t)) == hipSuccess &&
+       hipMemcpy(rs->d_raw_off, rs->rec_off.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMalloc(&rs->d_raw, block_floats * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_neff_hmm, (size_t)n * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_pav, (size_t)n * 20 * sizeof(float)) == hipSuccess &&
@@ -188,34 +190,78 @@ void hhv_rawset_free(hhv_rawset* rs) {
   dfree(rs->d_R);
   dfree(rs->d_qpav);
   for (int cls = 0; cls < 3; ++cls) dfree(rs->d_ids[cls]);
+  dfree(rs->d_raw_off);
   delete rs;
 }
 
-int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out) {
-  if (!c || !rs || !par || !q_pav || !out) return fail(HHV_E_ARG, "hhv_prepare_templates: null argument");
-  if (rs->ctx != c) return fail(HHV_E_ARG, "hhv_prepare_templates: raw set belongs to another context");
+static int check_prep_params(const hhv_prep_params* par) {
   if (par->pcm < 0 || par->pcm > 2) return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm = %d (only 0, 1, 2)", par->pcm);
   if (par->pcm == 2 && par->pcc != 1.0f)
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcc = %g; only the default pcc = 1 avoids libm pow() and is built", par->pcc);
   if (par->columnscore < 0 || par->columnscore > 3)
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: columnscore = %d (only 0..3)", par->columnscore);
+  return HHV_OK;
+}
+
+// allocates the record stream of a fresh template set and writes its terminal header
+static int tset_alloc_stream(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_t* L) {
+  int rc = tset_init_common(c, ts, n, L);
+  if (rc == HHV_OK && hipMalloc(&ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
+    rc = fail(HHV_E_MEMORY, "hhv_prepare_templates: device allocation failed");
+  if (rc != HHV_OK) return rc;
+  ts->owns_records = true;
+  std::vector<float> tail((size_t)(1 + STREAM_PAD_RECS) * REC_DW, 0.0f);
+  write_header(tail.data(), -1, 0);
+  HIP_TRY(hipMemcpy(ts->d_records + (size_t)ts->rec_off[n] * REC_DW, tail.data(), tail.size() * sizeof(float), hipMemcpyHostToDevice));
+  return HHV_OK;
+}
+
+static void fill_prep_args(PrepArgs* a, hhv_ctx* c, hhv_rawset* rs, hhv_tset* ts, const hhv_prep_params* par) {
+  a->raw = rs->d_raw;
+  a->n_cols = rs->n_cols;
+  a->rec_off = ts->d_rec_off;
+  a->L = ts->d_L;
+  a->neff_hmm = rs->d_neff_hmm;
+  a->pb = rs->d_pb;
+  a->R = rs->d_R;
+  a->q_pav = rs->d_qpav;
+  a->lg2 = c->d_lg2;
+  a->diff = c->d_diff;
+  a->p_tmp = rs->d_p_tmp;
+  a->tr_tmp = rs->d_tr_tmp;
+  a->records = ts->d_records;
+  a->gapd = par->gapd;
+  a->gape = par->gape;
+  a->gapf = par->gapf;
+  a->gapg = par->gapg;
+  a->gaph = par->gaph;
+  a->gapi = par->gapi;
+  a->gapb = par->gapb;
+  a->pcm = par->pcm;
+  a->pca = par->pca;
+  a->pcb = par->pcb;
+  a->columnscore = par->columnscore;
+  a->ids = nullptr;
+  a->lds_cols = 0;
+  a->src = nullptr;
+  a->raw_off = rs->d_raw_off;
+}
+
+int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out) {
+  if (!c || !rs || !par || !q_pav || !out) return fail(HHV_E_ARG, "hhv_prepare_templates: null argument");
+  if (rs->ctx != c) return fail(HHV_E_ARG, "hhv_prepare_templates: raw set belongs to another context");
+  int rc = check_prep_params(par);
+  if (rc != HHV_OK) return rc;
   HIP_TRY(hipSetDevice(c->par.device));
   hhv_tset* ts = *out;
   if (!ts) {
     ts = new (std::nothrow) hhv_tset();
     if (!ts) return fail(HHV_E_MEMORY, "out of host memory");
-    int rc = tset_init_common(c, ts, rs->n, rs->L.data());
-    if (rc == HHV_OK && hipMalloc(&ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
-      rc = fail(HHV_E_MEMORY, "hhv_prepare_templates: device allocation failed");
+    rc = tset_alloc_stream(c, ts, rs->n, rs->L.data());
     if (rc != HHV_OK) {
       hhv_tset_free(ts);
       return rc;
     }
-    ts->owns_records = true;
-    std::vector<float> tail((size_t)(1 + STREAM_PAD_RECS) * REC_DW, 0.0f);
-    write_header(tail.data(), -1, 0);
-    HIP_TRY(hipMemcpy(ts->d_records + (size_t)ts->rec_off[rs->n] * REC_DW, tail.data(), tail.size() * sizeof(float),
-                      hipMemcpyHostToDevice));
   } else if (ts->n != rs->n || ts->n_records != rs->n_cols + 1) {
     return fail(HHV_E_ARG, "hhv_prepare_templates: *out was not created from this raw set");
   }
@@ -223,34 +269,9 @@ int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par
   HIP_TRY(hipMemcpyAsync(rs->d_R, par->R, 400 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(rs->d_qpav, q_pav, 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   PrepArgs a;
-  a.raw = rs->d_raw;
-  a.n_cols = rs->n_cols;
-  a.rec_off = ts->d_rec_off;
-  a.L = ts->d_L;
-  a.neff_hmm = rs->d_neff_hmm;
-  a.pb = rs->d_pb;
-  a.R = rs->d_R;
-  a.q_pav = rs->d_qpav;
-  a.lg2 = c->d_lg2;
-  a.diff = c->d_diff;
-  a.p_tmp = rs->d_p_tmp;
-  a.tr_tmp = rs->d_tr_tmp;
-  a.records = ts->d_records;
+  fill_prep_args(&a, c, rs, ts, par);
   a.pav_out = rs->d_pav;
-  a.gapd = par->gapd;
-  a.gape = par->gape;
-  a.gapf = par->gapf;
-  a.gapg = par->gapg;
-  a.gaph = par->gaph;
-  a.gapi = par->gapi;
-  a.gapb = par->gapb;
-  a.pcm = par->pcm;
-  a.pca = par->pca;
-  a.pcb = par->pcb;
-  a.columnscore = par->columnscore;
-  a.ids = nullptr;
-  a.lds_cols = 0;
-  const int rc = launch_prepare(a, rs->d_ids, rs->n_ids, rs->max_L, c->stream);
+  rc = launch_prepare(a, rs->d_ids, rs->n_ids, rs->max_L, c->stream);
   if (rc != 0) {
     if (!*out) hhv_tset_free(ts);
     return fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
@@ -259,6 +280,69 @@ int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par
   rs->prepared = true;
   ts->bt_valid = false;
   ts->hits_valid = false;
+  *out = ts;
+  return HHV_OK;
+}
+
+int hhv_prepare_subset(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, const int32_t* ids,
+                       int32_t n_ids, hhv_tset** out) {
+  if (!c || !rs || !par || !q_pav || !ids || !out) return fail(HHV_E_ARG, "hhv_prepare_subset: null argument");
+  if (rs->ctx != c) return fail(HHV_E_ARG, "hhv_prepare_subset: raw set belongs to another context");
+  if (n_ids < 1) return fail(HHV_E_ARG, "hhv_prepare_subset: n_ids = %d", n_ids);
+  *out = nullptr;
+  int rc = check_prep_params(par);
+  if (rc != HHV_OK) return rc;
+  std::vector<int32_t> L(n_ids), cls[3];
+  int32_t max_L[3] = {0, 0, 0}, n_cls[3];
+  for (int k = 0; k < n_ids; ++k) {
+    if (ids[k] < 0 || ids[k] >= rs->n) return fail(HHV_E_ARG, "hhv_prepare_subset: ids[%d] = %d of %d", k, ids[k], rs->n);
+    L[k] = rs->L[ids[k]];
+    const int cl = L[k] <= 447 ? 0 : (L[k] <= 1300 ? 1 : 2);
+    cls[cl].push_back(k);
+    max_L[cl] = std::max(max_L[cl], L[k]);
+  }
+  HIP_TRY(hipSetDevice(c->par.device));
+  if (!cls[2].empty() && !rs->d_p_tmp) {  // the raw set had no template this long when it was uploaded?  cannot happen:
+    return fail(HHV_E_STATE, "hhv_prepare_subset: intermediate buffers missing");  // the classes depend on L only
+  }
+  hhv_tset* ts = new (std::nothrow) hhv_tset();
+  if (!ts) return fail(HHV_E_MEMORY, "out of host memory");
+  rc = tset_alloc_stream(c, ts, n_ids, L.data());
+  int32_t* d_scratch = nullptr;  // src[n_ids] followed by the three slot lists
+  if (rc == HHV_OK && hipMalloc(&d_scratch, (size_t)2 * n_ids * sizeof(int32_t)) != hipSuccess)
+    rc = fail(HHV_E_MEMORY, "hhv_prepare_subset: device allocation failed");
+  const int32_t* d_cls[3] = {nullptr, nullptr, nullptr};
+  if (rc == HHV_OK) {
+    std::vector<int32_t> lists;
+    lists.reserve(n_ids);
+    size_t at = n_ids;
+    for (int cl = 0; cl < 3; ++cl) {
+      n_cls[cl] = (int32_t)cls[cl].size();
+      d_cls[cl] = d_scratch + at;
+      at += cls[cl].size();
+      lists.insert(lists.end(), cls[cl].begin(), cls[cl].end());
+    }
+    if (hipMemcpyAsync(d_scratch, ids, (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_scratch + n_ids, lists.data(), (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(rs->d_pb, par->pb, 20 * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(rs->d_R, par->R, 400 * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(rs->d_qpav, q_pav, 20 * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      rc = fail(HHV_E_DEVICE, "hhv_prepare_subset: H2D copy failed");
+  }
+  if (rc == HHV_OK) {
+    PrepArgs a;
+    fill_prep_args(&a, c, rs, ts, par);
+    a.src = d_scratch;
+    a.pav_out = nullptr;
+    const int lr = launch_prepare(a, d_cls, n_cls, max_L, c->stream);
+    if (lr != 0) rc = fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
+  }
+  if (rc == HHV_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(HHV_E_DEVICE, "hhv_prepare_subset: kernels failed");
+  dfree(d_scratch);
+  if (rc != HHV_OK) {
+    hhv_tset_free(ts);
+    return rc;
+  }
   *out = ts;
   return HHV_OK;
 }

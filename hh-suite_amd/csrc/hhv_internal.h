@@ -86,9 +86,9 @@ constexpr int RAW_SS = 30;    // the secondary-structure bits share the dword wi
 struct PrepArgs {
   const float* raw;          // [n_cols][32]
   int64_t n_cols;            // sum(L+1)
-  const int64_t* rec_off;    // [n+1]
-  const int32_t* L;          // [n]
-  const float* neff_hmm;     // [n]
+  const int64_t* rec_off;    // [n slots + 1] output records
+  const int32_t* L;          // [n slots]
+  const float* neff_hmm;     // [n raw]
   const float* pb;           // [20]
   const float* R;            // [20][20]
   const float* q_pav;        // [20]
@@ -102,7 +102,9 @@ struct PrepArgs {
   int32_t pcm;
   float pca, pcb;
   int32_t columnscore;
-  const int32_t* ids;        // templates of this launch (one workgroup each)
+  const int32_t* ids;        // output slots of this launch (one workgroup each)
+  const int32_t* src;        // [n slots] raw template of slot k, or null = identity (the whole raw set)
+  const int64_t* raw_off;    // [n raw + 1] first column of every raw template in the raw block
   int32_t lds_cols;          // fused kernel: columns the LDS buffers hold (max L of the class + 1)
 };
 

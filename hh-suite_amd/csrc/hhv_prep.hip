@@ -114,6 +114,10 @@ __device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __re
   }
 }
 
+// slot k of the output set is raw template src(k), whose columns start at rin(k) in the raw block
+__device__ __forceinline__ int prep_src(const PrepArgs& a, int k) { return a.src ? a.src[k] : k; }
+__device__ __forceinline__ int64_t prep_rin(const PrepArgs& a, int k) { return a.raw_off[prep_src(a, k)]; }
+
 // CalculateAminoAcidBackground + IncludeNullModelInHMM + emission of the packed stream for template k, by one wavefront
 // (`lane`); p(j, a) = Pbuf[j * PS + a], tr(j, slot) = Tbuf[j * 8 + slot] (LDS in the fused kernel, global in the split one)
 template <int PS>
@@ -122,7 +126,7 @@ __device__ __forceinline__ void finalize_template(const PrepArgs& a, int k, int 
   const int L = a.L[k];
   // ---- CalculateAminoAcidBackground (:1854-1868): 20 independent sequential sums over the columns
   if (lane < 20) {
-    float pav = a.pb[lane] * 100.0f / a.neff_hmm[k];
+    float pav = a.pb[lane] * 100.0f / a.neff_hmm[prep_src(a, k)];
     const float* col = Pbuf + (size_t)PS + lane;
     int i = 1;
     // the additions are strictly sequential (fp32 order of the reference); the loads are batched ahead of them
@@ -168,7 +172,7 @@ __device__ __forceinline__ void finalize_template(const PrepArgs& a, int k, int 
 template <int PS>
 __device__ __forceinline__ void emit_records(const PrepArgs& a, int k, int tid, int nthreads, const float* Pbuf,
                                              const float* Tbuf, const float* s_pnul) {
-  const int64_t c0 = a.rec_off[k];
+  const int64_t c0 = a.rec_off[k], rin = prep_rin(a, k);
   const int L = a.L[k];
   float* hdr = a.records + (size_t)c0 * REC_DW;
   if (tid < REC_DW) {
@@ -192,7 +196,7 @@ __device__ __forceinline__ void emit_records(const PrepArgs& a, int k, int tid, 
                        : (w == REC_D2D) ? T_D2D : (w == REC_I2M) ? T_I2M : (w == REC_I2I) ? T_I2I : T_M2I;
         v = Tbuf[(size_t)src_col * 8 + slot];
       } else {
-        int32_t meta = j | (__builtin_bit_cast(int32_t, a.raw[(size_t)(c0 + j) * RAW_DW + RAW_SS]) & 0x01FF0000);
+        int32_t meta = j | (__builtin_bit_cast(int32_t, a.raw[(size_t)(rin + j) * RAW_DW + RAW_SS]) & 0x01FF0000);
         if (j == L) meta |= META_LAST;
         v = __builtin_bit_cast(float, meta);
       }
@@ -208,10 +212,10 @@ __global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
   for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
   __syncthreads();
   const int k = a.ids[blockIdx.x];
-  const int64_t c0 = a.rec_off[k];
+  const int64_t rin = prep_rin(a, k);  // the intermediate is indexed like the raw block
   const int L = a.L[k];
   for (int i = threadIdx.x; i <= L; i += 256)
-    prep_column(a, a.raw + (size_t)(c0 + i) * RAW_DW, sR, a.p_tmp + (size_t)(c0 + i) * 20, a.tr_tmp + (size_t)(c0 + i) * 8);
+    prep_column(a, a.raw + (size_t)(rin + i) * RAW_DW, sR, a.p_tmp + (size_t)(rin + i) * 20, a.tr_tmp + (size_t)(rin + i) * 8);
 }
 
 // ... and P2, one wavefront per template
@@ -219,10 +223,10 @@ __global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
   __shared__ float s_pav[20];
   __shared__ float s_pnul[20];
   const int k = a.ids[blockIdx.x];
-  const int64_t c0 = a.rec_off[k];
-  finalize_template<20>(a, k, threadIdx.x, a.p_tmp + (size_t)c0 * 20, a.tr_tmp + (size_t)c0 * 8, s_pav, s_pnul);
+  const int64_t rin = prep_rin(a, k);
+  finalize_template<20>(a, k, threadIdx.x, a.p_tmp + (size_t)rin * 20, a.tr_tmp + (size_t)rin * 8, s_pav, s_pnul);
   __syncthreads();
-  emit_records<20>(a, k, threadIdx.x, 64, a.p_tmp + (size_t)c0 * 20, a.tr_tmp + (size_t)c0 * 8, s_pnul);
+  emit_records<20>(a, k, threadIdx.x, 64, a.p_tmp + (size_t)rin * 20, a.tr_tmp + (size_t)rin * 8, s_pnul);
 }
 
 // ---- fused path: one workgroup of 256 threads per template; the mixed profile p[L+1][20] (row stride 21 dwords:
@@ -239,10 +243,10 @@ __global__ void __launch_bounds__(256) hhv_prep_fused_kernel(PrepArgs a) {
   for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
   __syncthreads();
   const int k = a.ids[blockIdx.x];
-  const int64_t c0 = a.rec_off[k];
+  const int64_t rin = prep_rin(a, k);
   const int L = a.L[k];
   for (int i = threadIdx.x; i <= L; i += 256)
-    prep_column(a, a.raw + (size_t)(c0 + i) * RAW_DW, sR, sP + (size_t)i * PREP_PS, sT + (size_t)i * 8);
+    prep_column(a, a.raw + (size_t)(rin + i) * RAW_DW, sR, sP + (size_t)i * PREP_PS, sT + (size_t)i * 8);
   __syncthreads();
   if (threadIdx.x < 64) finalize_template<PREP_PS>(a, k, threadIdx.x, sP, sT, s_pav, s_pnul);
   __syncthreads();

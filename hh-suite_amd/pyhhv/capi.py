@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores",
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
-    "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
+    "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
@@ -291,6 +291,16 @@ class Context:
         _check(self.lib.hhv_upload_raw_templates(self.h, n, Ls.ctypes.data_as(c_int_p), ff, tt, nn,
                                                  nh.ctypes.data_as(c_float_p), None, None, None, C.byref(h)))
         return h, Ls
+
+    def prepare_subset(self, raw, all_Ls, params, q_pav, ids):
+        """hhv_prepare_subset -> new TemplateSet of the raw templates ids (in that order)."""
+        q_pav = _f32(q_pav)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self.lib.hhv_prepare_subset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        _check(self.lib.hhv_prepare_subset(self.h, raw, C.byref(params), q_pav.ctypes.data, ids.ctypes.data, len(ids), C.byref(h)))
+        return TemplateSet(self, h, np.asarray(all_Ls, dtype=np.int32)[ids])
 
     def rawdb_open(self, path):
         """hhv_rawdb_open -> (raw set handle, lengths): the raw database file straight into HBM."""

@@ -176,6 +176,11 @@ int hhv_rawdb_open(hhv_ctx* ctx, const char* path, hhv_rawset** out);
 int32_t hhv_rawset_size(const hhv_rawset* rs);
 int hhv_rawset_lengths(const hhv_rawset* rs, int32_t* L);
 int hhv_prepare_templates(hhv_ctx* ctx, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out);
+/* The same for a SUBSET of the resident raw set - the templates the prefilter let through: ids[n_ids] (any order,
+ * repeats allowed) -> a NEW template set of n_ids templates in that order (template k of the set = raw template ids[k]),
+ * to be released with hhv_tset_free.  Nothing is copied between host and device but the id list. */
+int hhv_prepare_subset(hhv_ctx* ctx, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, const int32_t* ids,
+                       int32_t n_ids, hhv_tset** out);
 /* average composition pav[n*20] of the prepared templates of the last hhv_prepare_templates (diagnostics/tests) */
 int hhv_rawset_pav(hhv_ctx* ctx, hhv_rawset* rs, float* pav);
 /* the prepared packed records of template k of a set ((L[k]+1)*28 floats: header + columns), device -> host */

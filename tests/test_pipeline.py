@@ -65,10 +65,10 @@ def test_gpu_pipeline_matches_reference_chain(oracle, ref):
     assert np.array_equal(ids, want_ids) and 30 <= len(ids) < n_db
     sel = [int(k) for k in ids]
 
-    # ---- N2: prepare the survivors on the device
+    # ---- N2: the whole raw database is resident; the survivors are prepared on the device from their ids alone
     c.set_query(qp, q_tr)
-    raw, Ls = c.upload_raw([raws[k][0] for k in sel], [raws[k][1] for k in sel], [raws[k][2] for k in sel], [raws[k][3] for k in sel])
-    ts = c.prepare(raw, Ls, capi.prep_params(pb, R), q_pav)
+    raw, Ls_all = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+    ts = c.prepare_subset(raw, Ls_all, capi.prep_params(pb, R), q_pav, ids)
     ref_p, ref_tr = [], []
     for pos, k in enumerate(sel):
         f, tr, neff, nh = raws[k]

@@ -187,3 +187,35 @@ def test_gpu_rawdb_roundtrip(oracle, tmp_path):
     ts1.free()
     ts2.free()
     c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_prepare_subset(oracle):
+    """hhv_prepare_subset: any id list (order, repeats, all three length classes) of the resident raw set gives the records
+    the full preparation gives for those templates - only the template index in the header differs."""
+    from pyhhv import capi
+    pb, R = gonnet()
+    fq, trq, nq, nhq = raw_query_hhm()
+    q_p, q_tr, q_pav = po.oracle_prepare(oracle, 0, fq, trq, nq, nhq, pb, R)
+    lengths = [30, 500, 7, 1400, 447, 448, 90, 1]
+    raws = [synth.make_raw_hmm(5000 + k, L) for k, L in enumerate(lengths)]
+    c = capi.Context(local=1)
+    c.set_query(q_p[:-1], q_tr)
+    raw, Ls = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
+    par = capi.prep_params(pb, R)
+    full = c.prepare(raw, Ls, par, q_pav)
+    ids = np.array([6, 3, 3, 0, 7, 5, 1, 4], np.int32)
+    sub = c.prepare_subset(raw, Ls, par, q_pav, ids)
+    for pos, k in enumerate(ids):
+        a, b = c.records_of(sub, pos).view(np.uint32).copy(), c.records_of(full, int(k)).view(np.uint32).copy()
+        assert a[0, 0] == pos and b[0, 0] == k          # header: index inside the respective set
+        a[0, 0] = b[0, 0] = 0
+        assert np.array_equal(a, b), (pos, k)
+    ra, rb = c.align(sub), c.align(full)
+    assert np.array_equal(ra["score"].view(np.uint32), rb["score"][ids].view(np.uint32)) and np.array_equal(ra["i2"], rb["i2"][ids])
+    with pytest.raises(capi.HhvError):
+        c.prepare_subset(raw, Ls, par, q_pav, np.array([0, 8], np.int32))
+    c.rawset_free(raw)
+    full.free()
+    sub.free()
+    c.close()
