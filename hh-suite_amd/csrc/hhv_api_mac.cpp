@@ -44,6 +44,8 @@ void hhv_macset_free(hhv_macset* ms) {
 }
 
 struct MacMaskInput {  // what hhv_mac_realign_hits adds: masks are built on the device
+  const hhv_tset* ts = nullptr;         // hhv_mac_realign_tset: profiles are read from this resident set ...
+  const int32_t* template_of = nullptr; // ... hit k is template template_of[k] of it
   const hhv_mac_input* in = nullptr;
   int32_t n_qranges = 0, n_tranges = 0;
   const int32_t* qranges = nullptr;
@@ -54,12 +56,14 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
                             const float* const* t_p, const float* const* t_tr_lin, const uint8_t* const* celloff,
                             const MacMaskInput* mi, int32_t local, float shift, float mact, hhv_macset** out,
                             hhv_mac_hit* hits) {
-  if (!c || !q_p || !q_tr_lin || !Lt || !t_p || !t_tr_lin || !out || !hits) return fail(HHV_E_ARG, "hhv_mac_realign: null argument");
+  const bool from_tset = mi && mi->ts;
+  if (!c || !q_p || !q_tr_lin || !Lt || (!from_tset && !t_p) || !t_tr_lin || !out || !hits)
+    return fail(HHV_E_ARG, "hhv_mac_realign: null argument");
   *out = nullptr;
   if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
   int max_Lt = 0;
   for (int k = 0; k < n; ++k) {
-    if (Lt[k] < 1 || !t_p[k] || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
+    if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
     max_Lt = std::max(max_Lt, Lt[k]);
   }
   if ((size_t)10 * (max_Lt + 2) * sizeof(double) > 160 * 1024)
@@ -125,7 +129,8 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
     total += (bytes + 255) / 256 * 256;
     return at;
   };
-  const size_t o_qp = carve((size_t)(Lq + 1) * 20 * 4), o_qtr = carve((size_t)(Lq + 1) * 7 * 4), o_tp = carve((size_t)cols * 20 * 4),
+  const size_t o_qp = carve((size_t)(Lq + 1) * 20 * 4), o_qtr = carve((size_t)(Lq + 1) * 7 * 4),
+               o_tp = carve(from_tset ? (size_t)n * 8 : (size_t)cols * 20 * 4),
                o_ttr = carve((size_t)cols * 7 * 4), o_col = carve((size_t)n * 8), o_Lt = carve((size_t)n * 4),
                o_moff = carve((size_t)n * 8), o_co = carve((size_t)cells), o_mat = carve((size_t)cells * 4),
                o_bmm = carve((size_t)cells), o_scale = carve((size_t)n * (Lq + 2) * 8), o_pf = carve((size_t)n * 8),
@@ -149,11 +154,15 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   }
   char* base = (char*)ms->d_block;
   // host staging of the ragged inputs
-  std::vector<float> tp((size_t)cols * 20), ttr((size_t)cols * 7);
+  std::vector<float> tp(from_tset ? 0 : (size_t)cols * 20), ttr((size_t)cols * 7);
+  std::vector<int64_t> p_off(from_tset ? n : 0);  // header record of the hit's template in the resident stream
   std::vector<unsigned char> co;
   if (!mi) co.assign((size_t)cells, 0);
   for (int k = 0; k < n; ++k) {
-    memcpy(&tp[(size_t)col_off[k] * 20], t_p[k], (size_t)(Lt[k] + 1) * 20 * 4);
+    if (from_tset)
+      p_off[k] = mi->ts->rec_off[mi->template_of[k]];
+    else
+      memcpy(&tp[(size_t)col_off[k] * 20], t_p[k], (size_t)(Lt[k] + 1) * 20 * 4);
     memcpy(&ttr[(size_t)col_off[k] * 7], t_tr_lin[k], (size_t)(Lt[k] + 1) * 7 * 4);
     if (!mi && celloff && celloff[k]) {
       unsigned char* dst = &co[(size_t)ms->mat_off[k]];
@@ -165,7 +174,8 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   hipStream_t st = c->stream;
   if (hipMemcpyAsync(base + o_qp, q_p, (size_t)(Lq + 1) * 20 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(base + o_qtr, q_tr_lin, (size_t)(Lq + 1) * 7 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(base + o_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      (!from_tset && hipMemcpyAsync(base + o_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) ||
+      (from_tset && hipMemcpyAsync(base + o_tp, p_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess) ||
       hipMemcpyAsync(base + o_ttr, ttr.data(), ttr.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(base + o_col, col_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(base + o_Lt, Lt, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -186,7 +196,9 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   a.Lq = Lq;
   a.q_p = (const float*)(base + o_qp);
   a.q_tr = (const float*)(base + o_qtr);
-  a.t_p = (const float*)(base + o_tp);
+  a.t_p = from_tset ? mi->ts->d_records : (const float*)(base + o_tp);
+  a.t_p_stride = from_tset ? REC_DW : 20;
+  a.p_off = from_tset ? (const int64_t*)(base + o_tp) : nullptr;
   a.t_tr = (const float*)(base + o_ttr);
   a.col_off = (const int64_t*)(base + o_col);
   a.Lt = (const int32_t*)(base + o_Lt);
@@ -276,6 +288,29 @@ int hhv_mac_realign_hits(hhv_ctx* c, const float* q_p, const float* q_tr_lin, in
   mi.n_tranges = n_tranges;
   mi.tranges = tranges;
   return mac_realign_impl(c, q_p, q_tr_lin, Lq, n, Lt, t_p, t_tr_lin, nullptr, &mi, local, shift, mact, out, hits);
+}
+
+int hhv_mac_realign_tset(hhv_ctx* c, const float* q_p, const float* q_tr_lin, int32_t Lq, hhv_tset* ts, int32_t n,
+                         const int32_t* template_of, const float* const* t_tr_lin, const hhv_mac_input* in, int32_t n_qranges,
+                         const int32_t* qranges, int32_t n_tranges, const int32_t* tranges, int32_t local, float shift,
+                         float mact, hhv_macset** out, hhv_mac_hit* hits) {
+  if (!ts || !template_of || !in || n < 1 || n_qranges < 0 || n_tranges < 0 || (n_qranges && !qranges) || (n_tranges && !tranges))
+    return fail(HHV_E_ARG, "hhv_mac_realign_tset: bad argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_mac_realign_tset: template set belongs to another context");
+  std::vector<int32_t> Lt(n);
+  for (int k = 0; k < n; ++k) {
+    if (template_of[k] < 0 || template_of[k] >= ts->n) return fail(HHV_E_ARG, "hhv_mac_realign_tset: template_of[%d] = %d", k, template_of[k]);
+    Lt[k] = ts->L[template_of[k]];
+  }
+  MacMaskInput mi;
+  mi.ts = ts;
+  mi.template_of = template_of;
+  mi.in = in;
+  mi.n_qranges = n_qranges;
+  mi.qranges = qranges;
+  mi.n_tranges = n_tranges;
+  mi.tranges = tranges;
+  return mac_realign_impl(c, q_p, q_tr_lin, Lq, n, Lt.data(), nullptr, t_tr_lin, nullptr, &mi, local, shift, mact, out, hits);
 }
 
 int hhv_mac_celloff(hhv_macset* ms, int32_t k, uint8_t* mask) {

@@ -143,7 +143,9 @@ struct MacArgs {
   int32_t n, Lq;
   const float* q_p;          // [(Lq+1)][20]
   const float* q_tr;         // [(Lq+1)][7] linear
-  const float* t_p;          // concatenated template columns, [col][20]
+  const float* t_p;          // template columns: staged [col][20], or the record stream of a resident set ([col][28])
+  int32_t t_p_stride;        // 20 or 28
+  const int64_t* p_off;      // [n] first column of hit k in t_p when it differs from col_off (resident set), else null
   const float* t_tr;         // [col][7] linear
   const int64_t* col_off;    // [n] first column (index 0) of hit k
   const int32_t* Lt;         // [n]

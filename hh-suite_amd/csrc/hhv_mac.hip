@@ -68,6 +68,7 @@ struct HitView {
   const float* qp;
   const float* qtr;
   const float* tp;
+  int tps;  // floats between consecutive template columns (20: staged profiles, 28: records of a resident template set)
   const float* ttr;
   const unsigned char* co;
   float* mat;
@@ -81,7 +82,8 @@ __device__ __forceinline__ HitView view(const MacArgs& a, int k) {
   v.pitch = v.Lt + 1;
   v.qp = a.q_p;
   v.qtr = a.q_tr;
-  v.tp = a.t_p + a.col_off[k] * 20;
+  v.tps = a.t_p_stride;
+  v.tp = a.t_p + (a.p_off ? a.p_off[k] : a.col_off[k]) * a.t_p_stride;
   v.ttr = a.t_tr + a.col_off[k] * 7;
   v.co = a.celloff + a.mat_off[k];
   v.mat = a.mat + a.mat_off[k];
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
         continue;
       }
       const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
-      const float pf = dot20(qi, h.tp + (size_t)jc * 20);
+      const float pf = dot20(qi, h.tp + (size_t)jc * h.tps);
       const float* tt1 = h.ttr + (size_t)(jc - 1) * 7;  // t.tr[j-1]
       const float* tt = h.ttr + (size_t)jc * 7;         // t.tr[j]
       double mm, dg, mi;
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       }
       const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
       const float* tt = h.ttr + (size_t)jc * 7;
-      const float pf = dot20(qn, h.tp + (size_t)(jc + 1) * 20);
+      const float pf = dot20(qn, h.tp + (size_t)(jc + 1) * h.tps);
       const double pmatch = ROW(prv, F_MM, jc + 1) * pf * 1.0f * Cshift * sc;  // :80-83
       const double pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
       const double tM2M = tt[T_M2M];
@@ -475,10 +477,15 @@ __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
     }
   }
   st[step] = MAC_MM;  // :170
+  if (step > 0) {       // entry 0 is unused then (the reference leaves it uninitialised); keep it deterministic
+    is[0] = js[0] = 0;
+    st[0] = 0;
+  }
+  Ss[0] = Ps[0] = 0.0f;
   float sum = 0.0f;
   for (int s = 1; s <= step; ++s) {
     if (st[s] == MAC_MM) {
-      Ss[s] = fast_log2_mac(dot20(h.qp + (size_t)is[s] * 20, h.tp + (size_t)js[s] * 20), a.lg2, a.diff);
+      Ss[s] = fast_log2_mac(dot20(h.qp + (size_t)is[s] * 20, h.tp + (size_t)js[s] * h.tps), a.lg2, a.diff);
       Ps[s] = h.mat[(size_t)is[s] * pitch + js[s]];
       sum += Ps[s];
     } else {
@@ -491,6 +498,7 @@ __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
   a.hits[k].j1 = js[step];
   a.hits[k].sum_of_probs = sum;
   a.hits[k].Pforward = a.Pforward[k];
+  a.hits[k].pad = 0;
 }
 
 #undef ROW

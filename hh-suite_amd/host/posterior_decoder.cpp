@@ -144,8 +144,16 @@ std::vector<MacAlignment> PosteriorDecoderRunner::executeComputation(const MacPa
     const double t_masks = now_ms();
     hhv_macset* ms = nullptr;
     std::vector<hhv_mac_hit> res(n);
-    int rc = hhv_mac_realign_hits(ctx_, q.p, q.tr, q.L, n, Lt.data(), tp.data(), ttr.data(), in.data(), (int32_t)qr.size() / 2,
-                                  qr.data(), (int32_t)tr.size() / 2, tr.data(), par.loc, par.shift, par.mact, &ms, res.data());
+    int rc;
+    if (resident_) {
+      std::vector<int32_t> template_of(n);
+      for (int b = 0; b < n; ++b) template_of[b] = hits[batch[b]].entry;
+      rc = hhv_mac_realign_tset(ctx_, q.p, q.tr, q.L, resident_, n, template_of.data(), ttr.data(), in.data(), (int32_t)qr.size() / 2,
+                                qr.data(), (int32_t)tr.size() / 2, tr.data(), par.loc, par.shift, par.mact, &ms, res.data());
+    } else {
+      rc = hhv_mac_realign_hits(ctx_, q.p, q.tr, q.L, n, Lt.data(), tp.data(), ttr.data(), in.data(), (int32_t)qr.size() / 2,
+                                qr.data(), (int32_t)tr.size() / 2, tr.data(), par.loc, par.shift, par.mact, &ms, res.data());
+    }
     if (rc != HHV_OK) throw Error(rc, hhv_last_error());
     const double t_dp = now_ms();
     for (int b = 0; b < n; ++b) {
@@ -228,7 +236,7 @@ int hhvr_mac_celloff(int32_t Lq, int32_t Lt, int32_t min_overlap, const char* ex
   return 0;
 }
 
-int hhvr_mac_realign(hhv_ctx* ctx, int32_t loc, float shift, float mact, int32_t min_overlap, const char* exclstr,
+int hhvr_mac_realign(hhv_ctx* ctx, hhv_tset* resident, int32_t loc, float shift, float mact, int32_t min_overlap, const char* exclstr,
                      const char* template_exclstr, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n_templates,
                      const int32_t* Lt, const float* const* t_p, const float* const* t_tr_lin, int32_t n_hits,
                      const int32_t* hit_rows, const int64_t* path_off, const int32_t* path_i, const int32_t* path_j,
@@ -249,7 +257,7 @@ int hhvr_mac_realign(hhv_ctx* ctx, int32_t loc, float shift, float mact, int32_t
     std::vector<hhv::Profile> ts(n_templates);
     for (int k = 0; k < n_templates; ++k) {
       ts[k].L = Lt[k];
-      ts[k].p = t_p[k];
+      ts[k].p = t_p ? t_p[k] : nullptr;
       ts[k].tr = t_tr_lin[k];
     }
     std::vector<hhv::MacInput> hits(n_hits);
@@ -266,6 +274,7 @@ int hhvr_mac_realign(hhv_ctx* ctx, int32_t loc, float shift, float mact, int32_t
       hits[h].j = path_j + path_off[h];
     }
     hhv::PosteriorDecoderRunner runner(ctx);
+    if (resident) runner.useResidentSet(resident);
     const std::vector<hhv::MacAlignment> res = runner.executeComputation(par, q, ts, hits);
     for (int h = 0; h < n_hits; ++h) {
       const hhv::MacAlignment& al = res[h];

@@ -60,7 +60,10 @@ void MacCellOff(int Lq, int Lt, const MacParameters& par, const MacInput& hit, c
 
 class PosteriorDecoderRunner {
  public:
-  explicit PosteriorDecoderRunner(hhv_ctx* ctx) : ctx_(ctx) {}
+  explicit PosteriorDecoderRunner(hhv_ctx* ctx) : ctx_(ctx), resident_(nullptr) {}
+  // The templates are those of a resident template set (the one the Viterbi stage searched; MacInput::entry = index in
+  // it): their profiles are read on the device, Profile::p of `templates` is not used, only L and the linear tr.
+  void useResidentSet(hhv_tset* ts) { resident_ = ts; }
   // q / templates: prepared profiles with LINEAR transitions (LinearTransitions above); hits in any order.
   // Returns one MacAlignment per input hit, in input order.  Throws hhv::Error.
   std::vector<MacAlignment> executeComputation(const MacParameters& par, const Profile& q, const std::vector<Profile>& templates,
@@ -68,6 +71,7 @@ class PosteriorDecoderRunner {
 
  private:
   hhv_ctx* ctx_;
+  hhv_tset* resident_;
 };
 
 }  // namespace hhv
@@ -76,7 +80,8 @@ extern "C" {
 // plain-C shim for bindings/tests.  Hits: n_hits rows of 7 ints (entry, irep, i1, j1, i2, j2, nsteps) + concatenated paths
 // (path_off[n_hits+1], entries 1..nsteps at path_off[k]+1 ...).  Outputs: out_scalars[n_hits][6] = nsteps,i1,j1,i2,j2,
 // matched_cols; out_real[n_hits][2] = Pforward, sum_of_probs; paths into out_i/out_j/out_states/out_S/out_P with row pitch pcap.
-int hhvr_mac_realign(hhv_ctx* ctx, int32_t loc, float shift, float mact, int32_t min_overlap, const char* exclstr,
+/* resident: nullable; when given, t_p is ignored and the profiles of template set `resident` are used (entry = index in it) */
+int hhvr_mac_realign(hhv_ctx* ctx, hhv_tset* resident, int32_t loc, float shift, float mact, int32_t min_overlap, const char* exclstr,
                      const char* template_exclstr, const float* q_p, const float* q_tr_lin, int32_t Lq, int32_t n_templates,
                      const int32_t* Lt, const float* const* t_p, const float* const* t_tr_lin, int32_t n_hits,
                      const int32_t* hit_rows, const int64_t* path_off, const int32_t* path_i, const int32_t* path_j,

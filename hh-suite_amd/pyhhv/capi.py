@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores",
-    "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
+    "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
@@ -378,6 +378,34 @@ class Context:
                                         int(local), shift, mact, C.byref(h), hits.ctypes.data))
         return MacSet(self.lib, h, hits, Lq, Lt)
 
+    def mac_realign_tset(self, qp, q_tr_lin, ts, template_of, t_trs, inputs, local=1, shift=-0.03, mact=0.3501):
+        """hhv_mac_realign_tset: profiles from the resident set ts (hit k = template template_of[k]); inputs as in
+        mac_realign_hits."""
+        qp, q_tr_lin = _f32(qp), _f32(q_tr_lin)
+        t_trs = [_f32(a) for a in t_trs]
+        n = len(t_trs)
+        Lq = qp.shape[0] - 1
+        tof = np.ascontiguousarray(template_of, dtype=np.int32)
+        Lt = np.asarray(ts.L, dtype=np.int32)[tof]
+        tt = (C.c_void_p * n)(*[a.ctypes.data for a in t_trs])
+        arr = (MacInputStruct * n)()
+        keep = []
+        for k, (i1, j1, i2, j2, ns, vi, vj, xi, xj) in enumerate(inputs):
+            vi, vj = np.ascontiguousarray(vi, np.int32), np.ascontiguousarray(vj, np.int32)
+            xi, xj = np.ascontiguousarray(xi, np.int32), np.ascontiguousarray(xj, np.int32)
+            keep += [vi, vj, xi, xj]
+            arr[k] = MacInputStruct(i1, j1, i2, j2, ns, len(xi), vi.ctypes.data, vj.ctypes.data,
+                                    xi.ctypes.data if len(xi) else None, xj.ctypes.data if len(xj) else None)
+        self.lib.hhv_mac_realign_tset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                                  C.c_void_p, C.c_int32, C.c_float, C.c_float, C.POINTER(C.c_void_p), C.c_void_p]
+        hits = np.zeros(n, dtype=MAC_HIT_DTYPE)
+        h = C.c_void_p()
+        _check(self.lib.hhv_mac_realign_tset(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, ts.h, n, tof.ctypes.data, tt,
+                                             C.addressof(arr), 0, None, 0, None, int(local), shift, mact, C.byref(h),
+                                             hits.ctypes.data))
+        return MacSet(self.lib, h, hits, Lq, Lt)
+
     def mac_realign_hits(self, qp, q_tr_lin, tps, t_trs, inputs, qranges=(), tranges=(), local=1, shift=-0.03, mact=0.3501):
         """hhv_mac_realign_hits. inputs: list of (i1, j1, i2, j2, nsteps, i_steps, j_steps, excluded_i, excluded_j)."""
         qp, q_tr_lin = _f32(qp), _f32(q_tr_lin)
@@ -500,7 +528,7 @@ def load_runner():
     _runner.hhvr_linear_transitions.restype = None
     _runner.hhvr_mac_celloff.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    _runner.hhvr_mac_realign.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_char_p, C.c_char_p,
+    _runner.hhvr_mac_realign.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_char_p, C.c_char_p,
                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -701,17 +729,20 @@ def mac_celloff(Lq, Lt, hit, prev=(), min_overlap=0, exclstr=None, template_excl
     return mask
 
 
-def runner_mac_realign(ctx, qp, q_tr_lin, tps, t_trs, hits, loc=1, shift=-0.03, mact=0.3501, min_overlap=0):
+def runner_mac_realign(ctx, qp, q_tr_lin, tps, t_trs, hits, loc=1, shift=-0.03, mact=0.3501, min_overlap=0, resident=None):
     """hhv::PosteriorDecoderRunner::executeComputation. hits: list of (entry, irep, i1, j1, i2, j2, nsteps, i_steps, j_steps).
     Returns (scalars[n][6] = nsteps,i1,j1,i2,j2,matched_cols; real[n][2] = Pforward,sum_of_probs; i, j, states, S, P)."""
     lib = load_runner()
     qp, q_tr_lin = _f32(qp), _f32(q_tr_lin)
-    tps = [_f32(a) for a in tps]
     t_trs = [_f32(a) for a in t_trs]
-    nt, nh = len(tps), len(hits)
+    nt, nh = len(t_trs), len(hits)
     Lq = qp.shape[0] - 1
-    Lt = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
-    pp = (C.c_void_p * nt)(*[a.ctypes.data for a in tps])
+    Lt = np.array([a.shape[0] - 1 for a in t_trs], dtype=np.int32)
+    if resident is None:
+        tps = [_f32(a) for a in tps]
+        pp = (C.c_void_p * nt)(*[a.ctypes.data for a in tps])
+    else:
+        pp = None   # profiles are read from the resident template set; hits' entry = index in it
     tt = (C.c_void_p * nt)(*[a.ctypes.data for a in t_trs])
     rows = np.array([h[:7] for h in hits], dtype=np.int32).reshape(nh, 7)
     poff = np.zeros(nh + 1, np.int64)
@@ -730,7 +761,7 @@ def runner_mac_realign(ctx, qp, q_tr_lin, tps, t_trs, hits, loc=1, shift=-0.03, 
     o_s = np.zeros((nh, pcap), np.int8)
     o_S = np.zeros((nh, pcap), np.float32)
     o_P = np.zeros((nh, pcap), np.float32)
-    m = lib.hhvr_mac_realign(ctx.h, loc, shift, mact, min_overlap, None, None, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, nt,
+    m = lib.hhvr_mac_realign(ctx.h, resident.h if resident is not None else None, loc, shift, mact, min_overlap, None, None, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, nt,
                              Lt.ctypes.data, pp, tt, nh, rows.ctypes.data, poff.ctypes.data, pi.ctypes.data, pj.ctypes.data,
                              sc.ctypes.data, re.ctypes.data, pcap, o_i.ctypes.data, o_j.ctypes.data, o_s.ctypes.data,
                              o_S.ctypes.data, o_P.ctypes.data)

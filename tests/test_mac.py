@@ -213,6 +213,40 @@ def test_gpu_device_masks_equal_host_masks(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_mac_from_resident_template_set(oracle):
+    """hhv_mac_realign_tset reads the template profiles from the record stream the Viterbi stage searched: same results as
+    staging the profiles from the host, for hits that reference the resident set out of order and twice."""
+    from pyhhv import capi
+    Lq = 120
+    qp, qtr = synth.make_query(555, Lq)
+    q_lin = capi.linear_transitions(qtr, True)
+    tps, ttrs = zip(*[synth.make_homolog(700 + k, qp, L=L) for k, L in enumerate([60, 200, 33, 128, 90])])
+    c = capi.Context(local=1, ss_mode=0)
+    c.set_query(qp, qtr)
+    ts = c.upload(list(tps), list(ttrs))
+    c.align(ts, backtrace=True)
+    vh = c.hits(ts)
+    tof = [3, 0, 4, 0, 1]
+    inputs, t_lins = [], []
+    for t in tof:
+        ns, i_s, j_s, st, S = c.hit_path(ts, t)
+        inputs.append((int(vh["i1"][t]), int(vh["j1"][t]), int(vh["i2"][t]), int(vh["j2"][t]), ns, i_s, j_s,
+                       np.zeros(0, np.int32), np.zeros(0, np.int32)))
+        t_lins.append(capi.linear_transitions(ttrs[t], False))
+    a = c.mac_realign_tset(qp, q_lin, ts, tof, t_lins, inputs)
+    b = c.mac_realign_hits(qp, q_lin, [tps[t] for t in tof], t_lins, inputs)
+    assert a.hits.tobytes() == b.hits.tobytes()
+    for k in range(len(tof)):
+        assert a.posterior(k).tobytes() == b.posterior(k).tobytes()
+        for x, y in zip(a.path(k), b.path(k)):
+            assert np.array_equal(x, y)
+    a.free()
+    b.free()
+    ts.free()
+    c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_mac_batch_of_ragged_hits(oracle):
     """Many hits of one query in one launch (ragged Lt, some without mask) equal the same hits done one by one."""
     from pyhhv import capi

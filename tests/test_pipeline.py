@@ -88,15 +88,17 @@ def test_gpu_pipeline_matches_reference_chain(oracle, ref):
         assert np.float32(h["score"]).tobytes() == np.float32(o.hit_score).tobytes(), pos
 
     # ---- N4: MAC realignment of the 12 best hits (Hit.score order), Viterbi alignments taken from the product
+    # (profiles stay on the device: the runner reads them from the resident set; only the linear transitions of the
+    #  realigned templates - powf on the host - and the Viterbi paths go in)
     best = [int(k) for k in np.argsort(-hits["score"], kind="stable")[:12]]
     q_lin = capi.linear_transitions(q_tr, True)
-    t_lins, mac_in = [], []
-    for e, pos in enumerate(best):
+    t_lin_all = [capi.linear_transitions(t, False) for t in ref_tr]
+    mac_in = []
+    for pos in best:
         ns, i_s, j_s, st, S = c.hit_path(ts, pos)
         h = hits[pos]
-        mac_in.append((e, 1, int(h["i1"]), int(h["j1"]), int(h["i2"]), int(h["j2"]), ns, i_s, j_s))
-        t_lins.append(capi.linear_transitions(ref_tr[pos], False))
-    sc, re, o_i, o_j, o_s, o_S, o_P = capi.runner_mac_realign(c, qp, q_lin, [ref_p[pos] for pos in best], t_lins, mac_in)
+        mac_in.append((pos, 1, int(h["i1"]), int(h["j1"]), int(h["i2"]), int(h["j2"]), ns, i_s, j_s))
+    sc, re, o_i, o_j, o_s, o_S, o_P = capi.runner_mac_realign(c, qp, q_lin, None, t_lin_all, mac_in, resident=ts)
     for e, pos in enumerate(best):
         r = po.ref_mac_realign(ref, qp, q_tr, ref_p[pos], ref_tr[pos], outs[pos], local=1)
         assert tuple(sc[e]) == (r.nsteps, r.i1, r.j1, r.i2, r.j2, r.matched_cols), pos
