@@ -87,15 +87,24 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   const int64_t cells = ms->mat_off[n], steps = ms->path_off[n], cols = col_off[n];
   // device-built masks: Viterbi paths and excluded cells, concatenated
   std::vector<int64_t> vit_off(n + 1, 0), excl_off(n + 1, 0);
-  std::vector<int32_t> vit_i, vit_j, excl_i, excl_j, ends, ranges;
+  std::vector<int32_t> vit_i, vit_j, excl_i, excl_j, ends, ranges, res_template;
+  bool any_resident = false;
   if (mi) {
     for (int k = 0; k < n; ++k) {
       const hhv_mac_input& h = mi->in[k];
-      if (h.nsteps < 0 || h.n_excluded < 0 || (h.nsteps > 0 && (!h.i || !h.j)) || (h.n_excluded > 0 && (!h.excluded_i || !h.excluded_j))) {
+      const bool resident_path = from_tset && !h.i && !h.j;  // Viterbi alignment taken from the set's trace results
+      if (resident_path && !mi->ts->hits_valid) {
+        delete ms;
+        return fail(HHV_E_STATE, "hhv_mac_realign_tset: input %d has no path and the template set has no hhv_hits results", k);
+      }
+      if (h.nsteps < 0 || h.n_excluded < 0 || (!resident_path && h.nsteps > 0 && (!h.i || !h.j)) ||
+          (h.n_excluded > 0 && (!h.excluded_i || !h.excluded_j))) {
         delete ms;
         return fail(HHV_E_ARG, "hhv_mac_realign_hits: bad input %d", k);
       }
-      vit_off[k + 1] = vit_off[k] + h.nsteps;
+      res_template.push_back(resident_path ? mi->template_of[k] : -1);
+      any_resident = any_resident || resident_path;
+      vit_off[k + 1] = vit_off[k] + (resident_path ? 0 : h.nsteps);
       excl_off[k + 1] = excl_off[k] + h.n_excluded;
     }
     vit_i.resize((size_t)vit_off[n] + 1);
@@ -105,7 +114,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
     ends.resize((size_t)n * 4);
     for (int k = 0; k < n; ++k) {
       const hhv_mac_input& h = mi->in[k];
-      if (h.nsteps) {
+      if (h.nsteps && res_template[k] < 0) {
         memcpy(&vit_i[(size_t)vit_off[k]], h.i + 1, (size_t)h.nsteps * 4);  // entries 1..nsteps
         memcpy(&vit_j[(size_t)vit_off[k]], h.j + 1, (size_t)h.nsteps * 4);
       }
@@ -140,7 +149,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   const size_t path_bytes = total - o_pi;
   const size_t o_ends = carve(ends.size() * 4 + 16), o_voff = carve((size_t)(n + 1) * 8), o_vi = carve(vit_i.size() * 4 + 4),
                o_vj = carve(vit_j.size() * 4 + 4), o_xoff = carve((size_t)(n + 1) * 8), o_xi = carve(excl_i.size() * 4 + 4),
-               o_xj = carve(excl_j.size() * 4 + 4), o_rg = carve(ranges.size() * 4);
+               o_xj = carve(excl_j.size() * 4 + 4), o_rg = carve(ranges.size() * 4), o_rt = carve((size_t)n * 4 + 4);
   if (c->mac_cache && c->mac_cache_bytes >= total) {
     ms->d_block = c->mac_cache;
     ms->block_bytes = c->mac_cache_bytes;
@@ -188,7 +197,8 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
               hipMemcpyAsync(base + o_xoff, excl_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
               hipMemcpyAsync(base + o_xi, excl_i.data(), excl_i.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
               hipMemcpyAsync(base + o_xj, excl_j.data(), excl_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_rg, ranges.data(), ranges.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess)) ||
+              hipMemcpyAsync(base + o_rg, ranges.data(), ranges.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(base + o_rt, res_template.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess)) ||
       hipMemcpyAsync(base + o_poff, ms->path_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(HHV_E_DEVICE, "hhv_mac_realign: H2D copy failed");
   MacArgs a;
@@ -241,6 +251,11 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
       m.ranges = (const int32_t*)(base + o_rg);
       m.n_qranges = mi->n_qranges;
       m.n_tranges = mi->n_tranges;
+      m.res_hits = any_resident ? mi->ts->d_hits : nullptr;
+      m.res_template = (const int32_t*)(base + o_rt);
+      m.res_path_off = any_resident ? mi->ts->d_path_off : nullptr;
+      m.res_i = any_resident ? mi->ts->d_i_steps : nullptr;
+      m.res_j = any_resident ? mi->ts->d_j_steps : nullptr;
       lr = launch_mac_mask(a, m, st);
     }
     if (lr == 0) lr = launch_mac(a, local != 0, max_Lt, st);

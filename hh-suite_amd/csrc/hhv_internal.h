@@ -175,6 +175,12 @@ struct MacMaskArgs {
   const int64_t* excl_off;   // [n+1] cells of earlier MAC alignments of the same template (alt_i / alt_j)
   const int32_t* excl_i;
   const int32_t* excl_j;
+  // resident hits (hhv_mac_realign_tset with hhv_mac_input::i == NULL): Viterbi alignment from the set's trace results
+  const DevHit* res_hits;        // null = none
+  const int32_t* res_template;   // [n] template index in the resident set, or -1 = path handed over by the host
+  const int64_t* res_path_off;
+  const int32_t* res_i;
+  const int32_t* res_j;
   const int32_t* ranges;     // n_qranges query row ranges, then n_tranges template column ranges, (lo, hi) pairs
   int32_t n_qranges, n_tranges;
 };

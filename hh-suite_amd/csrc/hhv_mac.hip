@@ -512,19 +512,30 @@ __global__ void __launch_bounds__(256) hhv_mac_mask_kernel(MacArgs a, MacMaskArg
   const int k = blockIdx.x, tid = threadIdx.x;
   const int Lq = a.Lq, Lt = a.Lt[k], pitch = Lt + 1;
   unsigned char* co = const_cast<unsigned char*>(a.celloff) + a.mat_off[k];
-  const int4 e = m.ends[k];  // i1, j1, i2, j2
+  // the Viterbi alignment of the hit: handed over by the host, or - resident hits - taken from the trace results of the
+  // template set the Viterbi stage searched (hhv_hits)
+  int4 e = m.ends[k];  // i1, j1, i2, j2
+  const int32_t* vi = m.vit_i + m.vit_off[k];
+  const int32_t* vj = m.vit_j + m.vit_off[k];
+  int ns = (int)(m.vit_off[k + 1] - m.vit_off[k]);
+  if (m.res_hits && m.res_template[k] >= 0) {
+    const int t = m.res_template[k];
+    const DevHit h = m.res_hits[t];
+    e = make_int4(h.i1, h.j1, h.i2, h.j2);
+    ns = h.nsteps;
+    vi = m.res_i + m.res_path_off[t] + 1;  // entries 1..nsteps
+    vj = m.res_j + m.res_path_off[t] + 1;
+  }
   const int cells = (Lq + 1) * pitch;
   for (int c = tid; c < cells; c += 256) {
     const int i = c / pitch, j = c - i * pitch;
     co[c] = (i >= 1 && j >= 1) ? !((i < e.x && j < e.y) || (i > e.z && j > e.w)) : 0;
   }
   __syncthreads();
-  const int64_t v0 = m.vit_off[k];
-  const int ns = (int)(m.vit_off[k + 1] - v0);
   constexpr int W = 2 * 40 + 1;  // FWD_BKW_PATHWITDH = 40 (src/hhdecl.h:37)
   for (int w = tid; w < ns * W; w += 256) {
     const int step = w / W, d = w - step * W - 40;
-    const int pi = m.vit_i[v0 + step], pj = m.vit_j[v0 + step];
+    const int pi = vi[step], pj = vj[step];
     if (pi + d >= 1 && pi + d <= Lq && pj >= 1 && pj <= Lt) co[(size_t)(pi + d) * pitch + pj] = 0;
     if (pj + d >= 1 && pj + d <= Lt && pi >= 1 && pi <= Lq) co[(size_t)pi * pitch + pj + d] = 0;
   }

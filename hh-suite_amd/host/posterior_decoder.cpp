@@ -147,7 +147,7 @@ std::vector<MacAlignment> PosteriorDecoderRunner::executeComputation(const MacPa
     int rc;
     if (resident_) {
       std::vector<int32_t> template_of(n);
-      for (int b = 0; b < n; ++b) template_of[b] = hits[batch[b]].entry;
+      for (int b = 0; b < n; ++b) template_of[b] = hits[batch[b]].resident >= 0 ? hits[batch[b]].resident : hits[batch[b]].entry;
       rc = hhv_mac_realign_tset(ctx_, q.p, q.tr, q.L, resident_, n, template_of.data(), ttr.data(), in.data(), (int32_t)qr.size() / 2,
                                 qr.data(), (int32_t)tr.size() / 2, tr.data(), par.loc, par.shift, par.mact, &ms, res.data());
     } else {
@@ -262,16 +262,18 @@ int hhvr_mac_realign(hhv_ctx* ctx, hhv_tset* resident, int32_t loc, float shift,
     }
     std::vector<hhv::MacInput> hits(n_hits);
     for (int h = 0; h < n_hits; ++h) {
-      const int32_t* r = hit_rows + (size_t)h * 7;
+      const int32_t* r = hit_rows + (size_t)h * 8;
+      hits[h].resident = r[7];
       hits[h].entry = r[0];
       hits[h].irep = r[1];
       hits[h].i1 = r[2];
       hits[h].j1 = r[3];
       hits[h].i2 = r[4];
       hits[h].j2 = r[5];
-      hits[h].nsteps = r[6];
-      hits[h].i = path_i + path_off[h];
-      hits[h].j = path_j + path_off[h];
+      hits[h].nsteps = r[6] < 0 ? 0 : r[6];
+      // nsteps < 0: the Viterbi alignment of this hit is the one the resident set holds (no path handed over)
+      hits[h].i = r[6] < 0 ? nullptr : path_i + path_off[h];
+      hits[h].j = r[6] < 0 ? nullptr : path_j + path_off[h];
     }
     hhv::PosteriorDecoderRunner runner(ctx);
     if (resident) runner.useResidentSet(resident);

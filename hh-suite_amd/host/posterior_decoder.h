@@ -35,11 +35,12 @@ struct MacParameters {
 
 // what realign() reads of a Viterbi hit (src/hhposteriordecoder.cpp:205-240)
 struct MacInput {
-  int entry = -1;  // template index
+  int entry = -1;  // template index (into `templates`)
+  int resident = -1;  // with useResidentSet(): index of this template in the resident set (-1: same as entry)
   int irep = 1;    // rank of this alignment among the template's alternatives
   int i1 = 0, j1 = 0, i2 = 0, j2 = 0, nsteps = 0;
-  const int32_t* i = nullptr;  // Viterbi path, entries 1..nsteps
-  const int32_t* j = nullptr;
+  const int32_t* i = nullptr;  // Viterbi path, entries 1..nsteps; with useResidentSet(): i == j == nullptr = take end points
+  const int32_t* j = nullptr;  // and path of template `entry` from the set's own hhv_hits results
 };
 
 // the Hit fields backtraceMAC fills (src/hhbacktracemac.cpp:113-240); score / P-values are restored by realign()
@@ -77,7 +78,7 @@ class PosteriorDecoderRunner {
 }  // namespace hhv
 
 extern "C" {
-// plain-C shim for bindings/tests.  Hits: n_hits rows of 7 ints (entry, irep, i1, j1, i2, j2, nsteps) + concatenated paths
+// plain-C shim for bindings/tests.  Hits: n_hits rows of 8 ints (entry, irep, i1, j1, i2, j2, nsteps, resident) + concatenated paths
 // (path_off[n_hits+1], entries 1..nsteps at path_off[k]+1 ...).  Outputs: out_scalars[n_hits][6] = nsteps,i1,j1,i2,j2,
 // matched_cols; out_real[n_hits][2] = Pforward, sum_of_probs; paths into out_i/out_j/out_states/out_S/out_P with row pitch pcap.
 /* resident: nullable; when given, t_p is ignored and the profiles of template set `resident` are used (entry = index in it) */

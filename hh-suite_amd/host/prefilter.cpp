@@ -151,14 +151,19 @@ void Prefilter::SelectFirst(const int32_t* ungapped, const int32_t* length, int 
   std::vector<std::pair<int, int> > first(n_db);
   for (int n = 0; n < n_db; ++n)
     first[n] = std::make_pair(ungapped[n] - (int)((float)par.bit_factor * (log_qlen + flog2((float)length[n]))), n);
-  std::sort(first.begin(), first.end(), ByIntKey());
-  std::reverse(first.begin(), first.end());
-  size_t keep = first.size();
-  for (size_t k = 0; k < first.size(); ++k)
-    if ((int)k >= par.min_hits && first[k].first <= par.smax_thresh) {
-      keep = k;
-      break;
-    }
+  // The reference sorts everything (descending: std::sort + std::reverse) and cuts at the first element that is beyond
+  // min_hits AND not above smax_thresh, i.e. it keeps the min_hits best plus everything above the threshold, best first.
+  // The same set and order without sorting the whole database: nth_element for the rank boundary, sort what is kept.
+  struct Desc {
+    bool operator()(const std::pair<int, int>& l, const std::pair<int, int>& r) const { return ByIntKey()(r, l); }
+  };
+  const size_t top = std::min<size_t>((size_t)std::max(par.min_hits, 0), first.size());
+  if (top < first.size()) std::nth_element(first.begin(), first.begin() + top, first.end(), Desc());
+  size_t keep = top;
+  for (size_t k = top; k < first.size(); ++k)
+    if (first[k].first > par.smax_thresh) std::swap(first[keep++], first[k]);
+  first.resize(keep);
+  std::sort(first.begin(), first.end(), Desc());
   subset->resize(keep);
   for (size_t k = 0; k < keep; ++k) (*subset)[k] = first[k].second;
 }

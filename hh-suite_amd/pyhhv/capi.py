@@ -744,15 +744,17 @@ def runner_mac_realign(ctx, qp, q_tr_lin, tps, t_trs, hits, loc=1, shift=-0.03, 
     else:
         pp = None   # profiles are read from the resident template set; hits' entry = index in it
     tt = (C.c_void_p * nt)(*[a.ctypes.data for a in t_trs])
-    rows = np.array([h[:7] for h in hits], dtype=np.int32).reshape(nh, 7)
+    # optional 10th element of a hit: its template's index in the resident set when `entry` indexes a compact t_trs list
+    rows = np.array([list(h[:7]) + [h[9] if len(h) > 9 else -1] for h in hits], dtype=np.int32).reshape(nh, 8)
     poff = np.zeros(nh + 1, np.int64)
-    for k, h in enumerate(hits):
-        poff[k + 1] = poff[k] + h[6] + 1
+    for k, h in enumerate(hits):          # nsteps < 0: resident hit, no path handed over
+        poff[k + 1] = poff[k] + max(h[6], 0) + 1
     pi = np.zeros(poff[-1], np.int32)
     pj = np.zeros(poff[-1], np.int32)
     for k, h in enumerate(hits):
-        pi[poff[k]:poff[k + 1]] = np.asarray(h[7], np.int32)[:h[6] + 1]
-        pj[poff[k]:poff[k + 1]] = np.asarray(h[8], np.int32)[:h[6] + 1]
+        if h[6] >= 0:
+            pi[poff[k]:poff[k + 1]] = np.asarray(h[7], np.int32)[:h[6] + 1]
+            pj[poff[k]:poff[k + 1]] = np.asarray(h[8], np.int32)[:h[6] + 1]
     pcap = Lq + int(Lt.max()) + 2
     sc = np.zeros((nh, 6), np.int32)
     re = np.zeros((nh, 2), np.float64)

@@ -242,7 +242,9 @@ int hhv_mac_realign_hits(hhv_ctx* ctx, const float* q_p, const float* q_tr_lin, 
                          float mact, hhv_macset** out, hhv_mac_hit* hits);
 /* The same with the template PROFILES read from a resident template set (the one the Viterbi stage just searched: hit k is
  * template template_of[k] of ts) - only the linear transitions of the realigned templates (7 floats per column; powf is
- * the host's, see hhv::LinearTransitions) are handed over. */
+ * the host's, see hhv::LinearTransitions) are handed over.  An input with i == NULL and j == NULL takes its Viterbi
+ * alignment (end points and path) from the set's own trace results (the last hhv_hits on ts), so that nothing of the
+ * Viterbi stage has to be fetched to realign its best hits. */
 int hhv_mac_realign_tset(hhv_ctx* ctx, const float* q_p, const float* q_tr_lin, int32_t Lq, hhv_tset* ts, int32_t n,
                          const int32_t* template_of, const float* const* t_tr_lin, const hhv_mac_input* in, int32_t n_qranges,
                          const int32_t* qranges, int32_t n_tranges, const int32_t* tranges, int32_t local, float shift,
