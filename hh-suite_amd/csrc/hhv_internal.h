@@ -158,6 +158,7 @@ struct MacArgs {
   DevMacHit* hits;           // [n]
   double Cshift;
   float mact;
+  int32_t lds_cols;          // longest template of the launch (sizes the LDS sections)
   const int64_t* path_off;   // [n] capacity Lq+Lt+2 each
   int32_t* path_i;
   int32_t* path_j;

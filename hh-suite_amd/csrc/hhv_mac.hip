@@ -92,6 +92,50 @@ __device__ __forceinline__ HitView view(const MacArgs& a, int k) {
   return v;
 }
 
+// Template operands of column j: from the LDS copy made at kernel start (STAGE; one hit's template is read Lq times and a
+// lone wave per SIMD cannot hide a trip to L2 per strip), or from global memory when the template does not fit.
+template <bool STAGE>
+__device__ __forceinline__ void load_tp(const HitView& h, const float* sTp, int j, float (&t)[20]) {
+  if (STAGE) {
+    const float4* c = reinterpret_cast<const float4*>(sTp) + (size_t)j * 5;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float4 v = c[q];
+      t[4 * q + 0] = v.x;
+      t[4 * q + 1] = v.y;
+      t[4 * q + 2] = v.z;
+      t[4 * q + 3] = v.w;
+    }
+  } else {
+    const float* g = h.tp + (size_t)j * h.tps;
+#pragma unroll
+    for (int q = 0; q < 20; ++q) t[q] = g[q];
+  }
+}
+template <bool STAGE>
+__device__ __forceinline__ void load_tt(const HitView& h, const float* sTt, int j, float (&t)[7]) {
+  if (STAGE) {
+    const float4* c = reinterpret_cast<const float4*>(sTt) + (size_t)j * 2;
+    const float4 a = c[0], b = c[1];
+    t[0] = a.x;
+    t[1] = a.y;
+    t[2] = a.z;
+    t[3] = a.w;
+    t[4] = b.x;
+    t[5] = b.y;
+    t[6] = b.z;
+  } else {
+    const float* g = h.ttr + (size_t)j * 7;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) t[q] = g[q];
+  }
+}
+// copies the template of hit h into LDS: sTp [(Lt+2)][20], sTt [(Lt+2)][8]
+__device__ __forceinline__ void stage_template(const HitView& h, float* sTp, float* sTt, int lane) {
+  for (int e = lane; e < (h.Lt + 1) * 20; e += 64) sTp[e] = h.tp[(size_t)(e / 20) * h.tps + (e % 20)];
+  for (int e = lane; e < (h.Lt + 1) * 8; e += 64) sTt[e] = (e & 7) < 7 ? h.ttr[(size_t)(e >> 3) * 7 + (e & 7)] : 0.0f;
+}
+
 // LDS row state: field f of row r at column j
 #define ROW(r, f, j) rows[((r)*5 + (f)) * stride + (j)]
 enum { F_MM = 0, F_GD = 1, F_IM = 2, F_DG = 3, F_MI = 4 };
@@ -99,17 +143,22 @@ enum { F_MM = 0, F_GD = 1, F_IM = 2, F_DG = 3, F_MI = 4 };
 }  // namespace
 
 // ---- forward ------------------------------------------------------------------------------------------------------
-template <bool LOCAL>
+template <bool LOCAL, bool STAGE>
 __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = reinterpret_cast<double*>(smem);
   const int k = blockIdx.x, lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));  // layout sized for the longest template
+  float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
   const double Cshift = a.Cshift;
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
   for (int e = lane; e < pitch; e += 64) h.mat[e] = 0.0f;  // row 0 of p_mm is never read
+  if (STAGE) stage_template(h, sTp, sTt, lane);
   __syncthreads();
+  // the cell-off byte of the next strip is fetched while the current one is swept (also across the row boundary)
+  unsigned char co_next = (1 + lane <= Lt) ? h.co[(size_t)pitch + 1 + lane] : 1;
   int cur = 0;
   double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0;
   double Pf = LOCAL ? 1.0 : 0.0;
@@ -134,7 +183,12 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const int j = 1 + s0 + lane;
       const bool valid = j <= Lt;
       const int jc = valid ? j : Lt;
-      const bool off = !valid || h.co[(size_t)i * pitch + jc] != 0;
+      const bool off = !valid || co_next != 0;
+      {
+        const bool last = s0 + 64 >= Lt;
+        const int ni = last ? i + 1 : i, nj = last ? 1 + lane : j + 64;
+        co_next = (ni <= Lq && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
+      }
       const unsigned long long on_mask = __ballot(!off);
       if (on_mask == 0) {
         // a strip without a single active cell: all five states are zero, the running sums are unchanged
@@ -150,9 +204,11 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
         continue;
       }
       const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
-      const float pf = dot20(qi, h.tp + (size_t)jc * h.tps);
-      const float* tt1 = h.ttr + (size_t)(jc - 1) * 7;  // t.tr[j-1]
-      const float* tt = h.ttr + (size_t)jc * 7;         // t.tr[j]
+      float tpj[20], tt1[7], tt[7];
+      load_tp<STAGE>(h, sTp, jc, tpj);
+      load_tt<STAGE>(h, sTt, jc - 1, tt1);  // t.tr[j-1]
+      load_tt<STAGE>(h, sTt, jc, tt);       // t.tr[j]
+      const float pf = dot20(qi, tpj);
       double mm, dg, mi;
       if (i == 1) {
         mm = pf * Cshift;  // :31
@@ -238,15 +294,18 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
 }
 
 // ---- backward + posterior ---------------------------------------------------------------------------------------------
-template <bool LOCAL>
+template <bool LOCAL, bool STAGE>
 __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = reinterpret_cast<double*>(smem);
   const int k = blockIdx.x, lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));
+  float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
   const double Cshift = a.Cshift, Pf = a.Pforward[k];
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
+  if (STAGE) stage_template(h, sTp, sTt, lane);
   __syncthreads();
   const double sL = h.scale[Lq + 1];
   int cur = 0;  // row being computed; `prv` holds row i+1
@@ -263,6 +322,8 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   }
   __syncthreads();
   double scale_prod = sL, pmin = LOCAL ? sL : 0.0;
+  unsigned char co_nx = 1;  // mask byte and F_MM of the next strip, fetched while the current one is swept
+  float f_nx = 0.0f;
   for (int i = Lq - 1; i >= 1; --i) {
     const int prv = cur ^ 1;
     const double sc = h.scale[i + 1];
@@ -272,14 +333,22 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
     if (pmin < DBL_MIN * 100) pmin = 0.0;
     float* row = h.mat + (size_t)i * pitch;
     const unsigned char* corow = h.co + (size_t)i * pitch;
+    // what the first strip of this row reads from HBM (mask byte, F_MM) and, lane 0, column Lt - issued together
+    {
+      const int j0 = Lt - 1 - lane;
+      co_nx = j0 >= 1 ? corow[j0] : 1;
+      f_nx = j0 >= 1 ? row[j0] : 0.0f;
+    }
     // column Lt (:58-71)
     if (lane == 0) {
-      if (corow[Lt]) {
+      const unsigned char coL = corow[Lt];
+      const float fL = row[Lt];
+      if (coL) {
         row[Lt] = 0.0f;
         ROW(cur, F_MM, Lt) = 0.0;
       } else {
         ROW(cur, F_MM, Lt) = scale_prod;
-        row[Lt] = (float)(row[Lt] * scale_prod / Pf);
+        row[Lt] = (float)(fL * scale_prod / Pf);
       }
       ROW(cur, F_GD, Lt) = ROW(cur, F_IM, Lt) = ROW(cur, F_DG, Lt) = ROW(cur, F_MI, Lt) = 0.0;
     }
@@ -292,7 +361,13 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       const int j = Lt - 1 - s0 - lane;  // descending: lane 0 is the rightmost column of the strip
       const bool valid = j >= 1;
       const int jc = valid ? j : 1;
-      const bool off = !valid || corow[jc] != 0;
+      const bool off = !valid || co_nx != 0;
+      const float f_cur = f_nx;
+      if (s0 + 64 < Lt - 1) {
+        const int jn = j - 64;
+        co_nx = jn >= 1 ? corow[jn] : 1;
+        f_nx = jn >= 1 ? row[jn] : 0.0f;
+      }
       const unsigned long long on_mask = __ballot(!off);
       if (on_mask == 0) {
         if (valid) {
@@ -301,14 +376,16 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
           ROW(cur, F_IM, j) = 0.0;
           ROW(cur, F_DG, j) = 0.0;
           ROW(cur, F_MI, j) = 0.0;
-          row[j] = row[j] * (float)(0.0 / Pf);  // F * (float)(B / Pforward) with B = 0 (NaN if Pforward is 0, as in the reference)
+          row[j] = f_cur * (float)(0.0 / Pf);  // F * (float)(B / Pforward) with B = 0 (NaN if Pforward is 0, as in the reference)
         }
         carry_gd = carry_im = 0.0;
         continue;
       }
       const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
-      const float* tt = h.ttr + (size_t)jc * 7;
-      const float pf = dot20(qn, h.tp + (size_t)(jc + 1) * h.tps);
+      float tpn[20], tt[7];
+      load_tp<STAGE>(h, sTp, jc + 1, tpn);
+      load_tt<STAGE>(h, sTt, jc, tt);
+      const float pf = dot20(qn, tpn);
       const double pmatch = ROW(prv, F_MM, jc + 1) * pf * 1.0f * Cshift * sc;  // :80-83
       const double pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
       const double tM2M = tt[T_M2M];
@@ -333,7 +410,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
         ROW(cur, F_IM, j) = im;
         ROW(cur, F_DG, j) = dg;
         ROW(cur, F_MI, j) = mi;
-        row[j] = row[j] * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
+        row[j] = f_cur * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
       }
       carry_gd = lane_d(gd, 63);
       carry_im = lane_d(im, 63);
@@ -359,6 +436,9 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
   int cur = 0;
   float best = -FLT_MAX;
   int best_i = 0, best_j = 0;
+  // mask byte and posterior of the next strip are fetched while the current one is swept (also across rows)
+  unsigned char co_nx = h.co[(size_t)pitch + min(1 + lane, Lt)];
+  float p_nx = h.mat[(size_t)pitch + min(1 + lane, Lt)];
   for (int i = 1; i <= Lq; ++i) {
     const int prv = cur ^ 1;
     const float* Sp = S + prv * stride;
@@ -368,8 +448,14 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
       const int j = 1 + s0 + lane;
       const bool valid = j <= Lt;
       const int jc = valid ? j : Lt;
-      const bool off = h.co[(size_t)i * pitch + jc] != 0;
-      const float p = h.mat[(size_t)i * pitch + jc];
+      const bool off = co_nx != 0;
+      const float p = p_nx;
+      {
+        const bool last = s0 + 64 >= Lt;
+        const int ni = min(last ? i + 1 : i, Lq), nj = min(last ? 1 + lane : j + 64, Lt);
+        co_nx = h.co[(size_t)ni * pitch + nj];
+        p_nx = h.mat[(size_t)ni * pitch + nj];
+      }
       const float term1 = p - mact;
       const float term2 = Sp[jc - 1] + p - mact;
       const float term3 = (float)(Sp[jc] - half);
@@ -386,15 +472,25 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
         mx = term3;
         code = MAC_MI;
       }
-      // inactive cells hold -FLT_MIN whatever their neighbour says: sweep only from the first to the last active lane
+      // inactive cells hold -FLT_MIN whatever their neighbour says: sweep only from the first to the last active lane.
+      // The chain step is S = max(mx, (float)((double)S_left - 0.5*mact)).  0.5*mact is a float (halving is exact) and
+      // rounding a difference of two floats first to double and then to float equals rounding it once (53 >= 2*24+2
+      // bits), so the step is one v_sub_f32; the maximum and the cell-off override are one v_med3_f32:
+      // med3(t4, mx, +inf) = max(t4, mx), med3(t4, -FLT_MIN, -FLT_MIN) = -FLT_MIN.
       const unsigned long long on_mask = __ballot(!off && valid);
       const int n_steps = on_mask ? (63 - __builtin_clzll(on_mask)) - __builtin_ctzll(on_mask) + 1 : 0;
+      const float half_f = (float)half;
+      const float lo = off ? -FLT_MIN : mx, hi = off ? -FLT_MIN : __builtin_inff();
       float sv = off ? -FLT_MIN : 0.0f;
-      for (int s = 0; s < n_steps; ++s) {
-        const float t4 = (float)(shr1_f(sv, carry) - half);
-        sv = off ? -FLT_MIN : (t4 > mx ? t4 : mx);
+      if (__ballot(mx != mx) == 0) {
+        for (int s = 0; s < n_steps; ++s) sv = __builtin_amdgcn_fmed3f(shr1_f(sv, carry) - half_f, lo, hi);
+      } else {  // NaN posteriors (a mask that leaves no path: Pforward = 0): the literal compare/select chain
+        for (int s = 0; s < n_steps; ++s) {
+          const float t4s = shr1_f(sv, carry) - half_f;
+          sv = off ? -FLT_MIN : (t4s > mx ? t4s : mx);
+        }
       }
-      const float t4 = (float)(shr1_f(sv, carry) - half);
+      const float t4 = shr1_f(sv, carry) - half_f;
       if (off)
         code = MAC_STOP;
       else if (t4 > mx)
@@ -573,21 +669,32 @@ int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-int launch_mac(const MacArgs& a, bool local, int max_Lt, void* stream_) {
+// LDS of the forward / backward kernels: two rows of state, plus - when it fits - the template itself
+size_t mac_rows_lds(int max_Lt, bool stage) {
+  return (size_t)10 * (max_Lt + 2) * sizeof(double) + (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) : 0);
+}
+
+template <bool LOCAL, bool STAGE>
+static void launch_mac_variant(const MacArgs& a, size_t lds_rows, size_t lds_dp, hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+  (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+  hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, STAGE>), dim3(a.n), dim3(64), lds_rows, stream, a);
+  hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE>), dim3(a.n), dim3(64), lds_rows, stream, a);
+  hipLaunchKernelGGL(hhv_mac_dp_kernel<LOCAL>, dim3(a.n), dim3(64), lds_dp, stream, a);
+}
+
+int launch_mac(const MacArgs& a0, bool local, int max_Lt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const size_t lds_rows = (size_t)10 * (max_Lt + 2) * sizeof(double), lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
+  const bool stage = mac_rows_lds(max_Lt, true) <= 160 * 1024;
+  MacArgs a = a0;
+  a.lds_cols = max_Lt;
+  const size_t lds_rows = mac_rows_lds(max_Lt, stage), lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
   if (local) {
-    (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
-    (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
-    hipLaunchKernelGGL(hhv_mac_forward_kernel<true>, dim3(a.n), dim3(64), lds_rows, stream, a);
-    hipLaunchKernelGGL(hhv_mac_backward_kernel<true>, dim3(a.n), dim3(64), lds_rows, stream, a);
-    hipLaunchKernelGGL(hhv_mac_dp_kernel<true>, dim3(a.n), dim3(64), lds_dp, stream, a);
+    if (stage) launch_mac_variant<true, true>(a, lds_rows, lds_dp, stream);
+    else launch_mac_variant<true, false>(a, lds_rows, lds_dp, stream);
   } else {
-    (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
-    (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
-    hipLaunchKernelGGL(hhv_mac_forward_kernel<false>, dim3(a.n), dim3(64), lds_rows, stream, a);
-    hipLaunchKernelGGL(hhv_mac_backward_kernel<false>, dim3(a.n), dim3(64), lds_rows, stream, a);
-    hipLaunchKernelGGL(hhv_mac_dp_kernel<false>, dim3(a.n), dim3(64), lds_dp, stream, a);
+    if (stage) launch_mac_variant<false, true>(a, lds_rows, lds_dp, stream);
+    else launch_mac_variant<false, false>(a, lds_rows, lds_dp, stream);
   }
   hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
   const hipError_t e = hipGetLastError();

@@ -247,6 +247,36 @@ def test_gpu_mac_from_resident_template_set(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_mac_long_template_unstaged_path(oracle):
+    """A template too long for the LDS copy (> ~850 columns) sends the whole launch down the kernels that read the template
+    from global memory; results must not depend on the path."""
+    from pyhhv import capi
+    Lq = 90
+    qp, qtr = synth.make_query(88, Lq)
+    q_lin = lin_query(qtr)
+    par = make_params(local=1, ss_mode=0)
+    tps, tls, masks, want = [], [], [], []
+    for k, Lt in enumerate([900, 70, 1500]):
+        tp, ttr = synth.make_homolog(800 + k, qp, L=Lt)
+        t_lin = lin_template(ttr)
+        vit = oracle.align(par, qp, qtr, tp, ttr, want_path=True)
+        o = oracle_mac_realign(oracle, qp, q_lin, tp, t_lin, vit, local=1)
+        tps.append(tp)
+        tls.append(t_lin)
+        masks.append(o.celloff)
+        want.append(o)
+    c = capi.Context()
+    ms = c.mac_realign(qp, q_lin, tps, tls, masks, local=1)
+    for k, o in enumerate(want):
+        h = ms.hits[k]
+        assert np.float64(h["Pforward"]).tobytes() == np.float64(o.Pforward).tobytes(), k
+        assert ms.posterior(k)[1:, 1:].tobytes() == o.posterior[1:, 1:].tobytes(), k
+        assert (h["nsteps"], h["i1"], h["j1"], h["i2"], h["j2"]) == (o.nsteps, o.i1, o.j1, o.i2, o.j2), k
+    ms.free()
+    c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_mac_batch_of_ragged_hits(oracle):
     """Many hits of one query in one launch (ragged Lt, some without mask) equal the same hits done one by one."""
     from pyhhv import capi
