@@ -263,7 +263,7 @@ def main():
         },
     }
 
-    if rank == 0 and not args.no_configs1 and n >= 10000 and not bt and args.lengths == "fixed":
+    if rank == 0 and world == 1 and not args.no_configs1 and n >= 10000 and not bt and args.lengths == "fixed":
         # BASELINE configs[1]: the same query vs the first 10k templates of the resident stream
         ts10 = ctx.adopt_device_stream(np.full(10000, Lt, dtype=np.int32), rec.data_ptr())
         for _ in range(2):
@@ -280,7 +280,7 @@ def main():
         out["configs1_10k_templates"] = {"cells_per_s": 10000 * Lq * Lt * reps / d10, "kernel_ms": float(np.mean(ms10))}
         ts10.free()
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the contract: rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args, rec, rec_off, Ls, ctx, ts, qf, qtr, n, Lq)
 
     if rank == 0 and world == 1 and not args.no_next_rows and not bt and args.lengths == "fixed":
