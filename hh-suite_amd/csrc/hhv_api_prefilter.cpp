@@ -18,6 +18,15 @@ struct hhv_pfdb {
   size_t padded = 0;
   int64_t* d_off = nullptr;
   int32_t* d_order_all = nullptr;   // all sequences, longest first
+  // per-call scratch, kept between calls (grown on demand): profile, scores, subset ids + their order, striped profile
+  unsigned char* d_prof = nullptr;
+  size_t prof_cap = 0;
+  int32_t* d_scores = nullptr;
+  int32_t* d_subset = nullptr;
+  int32_t* d_order = nullptr;
+  size_t jobs_cap = 0, sub_cap = 0, order_cap = 0;
+  unsigned char* d_striped = nullptr;
+  size_t striped_cap = 0;
   std::vector<int32_t> length;      // host copy of the lengths
   int32_t max_len = 0;
 };
@@ -79,6 +88,11 @@ void hhv_prefilter_free_db(hhv_pfdb* db) {
   dfree(db->d_carry[1]);
   dfree(db->d_off);
   dfree(db->d_order_all);
+  dfree(db->d_prof);
+  dfree(db->d_scores);
+  dfree(db->d_subset);
+  dfree(db->d_order);
+  dfree(db->d_striped);
   delete db;
 }
 
@@ -115,13 +129,22 @@ int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32
   if (lds > 160 * 1024) return fail(HHV_E_LIMIT, "hhv_prefilter_scores: Lq = %d needs %zu bytes of LDS (limit 160 KiB)", Lq, lds);
 
   HIP_TRY(hipSetDevice(c->par.device));
-  unsigned char* d_prof = nullptr;
-  unsigned char* d_striped = nullptr;
-  int32_t* d_subset = nullptr;
-  int32_t* d_order = nullptr;
-  int32_t* d_scores = nullptr;
+  // scratch buffers live in the database handle: a search calls this twice per query
+  auto grow = [](auto*& p, size_t& cap, size_t need_bytes) -> bool {
+    if (cap >= need_bytes) return true;
+    dfree(p);
+    cap = 0;
+    if (hipMalloc(&p, need_bytes) != hipSuccess) return false;
+    cap = need_bytes;
+    return true;
+  };
   int rc = HHV_OK;
   std::vector<int32_t> order;
+  unsigned char*& d_prof = db->d_prof;
+  unsigned char*& d_striped = db->d_striped;
+  int32_t*& d_subset = db->d_subset;
+  int32_t*& d_order = db->d_order;
+  int32_t*& d_scores = db->d_scores;
   std::vector<unsigned char> striped;
   if (subset) order_by_length(db->length, subset, n_subset, db->max_len, &order);
   if (!fast && !generic_prof_lds) {
@@ -134,10 +157,10 @@ int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32
           striped[((size_t)x * W32 + j) * 32 + k] = p >= Lq ? (unsigned char)score_offset : profile[(size_t)x * Lq + p];
         }
   }
-  if (hipMalloc(&d_prof, (size_t)220 * Lq) != hipSuccess || hipMalloc(&d_scores, (size_t)n_jobs * sizeof(int32_t)) != hipSuccess ||
-      (subset && (hipMalloc(&d_subset, (size_t)n_jobs * sizeof(int32_t)) != hipSuccess ||
-                  hipMalloc(&d_order, (size_t)n_jobs * sizeof(int32_t)) != hipSuccess)) ||
-      (!striped.empty() && hipMalloc(&d_striped, striped.size()) != hipSuccess))
+  if (!grow(db->d_prof, db->prof_cap, (size_t)220 * Lq) || !grow(db->d_scores, db->jobs_cap, (size_t)n_jobs * sizeof(int32_t)) ||
+      (subset && (!grow(db->d_subset, db->sub_cap, (size_t)n_jobs * sizeof(int32_t)) ||
+                  !grow(db->d_order, db->order_cap, (size_t)n_jobs * sizeof(int32_t)))) ||
+      (!striped.empty() && !grow(db->d_striped, db->striped_cap, striped.size())))
     rc = fail(HHV_E_MEMORY, "hhv_prefilter_scores: device allocation failed");
   if (rc == HHV_OK &&
       (hipMemcpyAsync(d_prof, profile, (size_t)220 * Lq, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -152,7 +175,7 @@ int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32
     a.striped = d_striped;
     a.seqs = db->d_seqs;
     a.offsets = db->d_off;
-    a.subset = d_subset;
+    a.subset = subset ? d_subset : nullptr;  // the scratch buffer outlives the call: only valid when this call filled it
     a.order = subset ? d_order : db->d_order_all;
     a.scores = d_scores;
     a.n_jobs = n_jobs;
@@ -190,11 +213,6 @@ int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32
   if (rc == HHV_OK && (hipMemcpyAsync(scores, d_scores, (size_t)n_jobs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                        hipStreamSynchronize(c->stream) != hipSuccess))
     rc = fail(HHV_E_DEVICE, "hhv_prefilter_scores: D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
-  dfree(d_prof);
-  dfree(d_striped);
-  dfree(d_subset);
-  dfree(d_order);
-  dfree(d_scores);
   return rc;
 }
 
