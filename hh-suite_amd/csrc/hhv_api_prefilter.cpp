@@ -27,6 +27,12 @@ struct hhv_pfdb {
   size_t jobs_cap = 0, sub_cap = 0, order_cap = 0;
   unsigned char* d_striped = nullptr;
   size_t striped_cap = 0;
+  // first selection step on the device: sort keys, sorted keys, radix-sort scratch, counter
+  uint64_t* d_keys = nullptr;
+  uint64_t* d_sorted = nullptr;
+  void* d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  unsigned int* d_above = nullptr;
   std::vector<int32_t> length;      // host copy of the lengths
   int32_t max_len = 0;
 };
@@ -93,13 +99,18 @@ void hhv_prefilter_free_db(hhv_pfdb* db) {
   dfree(db->d_subset);
   dfree(db->d_order);
   dfree(db->d_striped);
+  dfree(db->d_keys);
+  dfree(db->d_sorted);
+  dfree(db->d_sort_temp);
+  dfree(db->d_above);
   delete db;
 }
 
-int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32_t Lq, int32_t score_offset,
-                         int32_t gapped, int32_t gap_init, int32_t gap_extend, const int32_t* subset, int32_t n_subset,
-                         int32_t* scores) {
-  if (!c || !db || !profile || !scores) return fail(HHV_E_ARG, "hhv_prefilter_scores: null argument");
+// runs the kernel; the scores stay in db->d_scores (and are copied to `scores` when it is not null)
+static int prefilter_scores_impl(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32_t Lq, int32_t score_offset,
+                                 int32_t gapped, int32_t gap_init, int32_t gap_extend, const int32_t* subset, int32_t n_subset,
+                                 int32_t* scores) {
+  if (!c || !db || !profile) return fail(HHV_E_ARG, "hhv_prefilter_scores: null argument");
   if (db->ctx != c) return fail(HHV_E_ARG, "hhv_prefilter_scores: database belongs to another context");
   if (Lq < 1) return fail(HHV_E_ARG, "hhv_prefilter_scores: Lq = %d", Lq);
   if (score_offset < 0 || score_offset > 255 || gap_init < 0 || gap_extend < 0)
@@ -210,10 +221,57 @@ int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32
     c->ev_valid = true;
     if (lr != 0) rc = fail(HHV_E_DEVICE, "prefilter kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
   }
-  if (rc == HHV_OK && (hipMemcpyAsync(scores, d_scores, (size_t)n_jobs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                       hipStreamSynchronize(c->stream) != hipSuccess))
+  if (rc == HHV_OK && scores &&
+      (hipMemcpyAsync(scores, d_scores, (size_t)n_jobs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+       hipStreamSynchronize(c->stream) != hipSuccess))
     rc = fail(HHV_E_DEVICE, "hhv_prefilter_scores: D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
   return rc;
+}
+
+int hhv_prefilter_scores(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32_t Lq, int32_t score_offset,
+                         int32_t gapped, int32_t gap_init, int32_t gap_extend, const int32_t* subset, int32_t n_subset,
+                         int32_t* scores) {
+  if (!scores) return fail(HHV_E_ARG, "hhv_prefilter_scores: null argument");
+  return prefilter_scores_impl(c, db, profile, Lq, score_offset, gapped, gap_init, gap_extend, subset, n_subset, scores);
+}
+
+int hhv_prefilter_first(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profile, int32_t Lq, int32_t score_offset, float log_qlen,
+                        int32_t bit_factor, int32_t smax_thresh, int32_t min_hits, int32_t* ids, int32_t cap, int32_t* n_out) {
+  if (!ids || !n_out || cap < 0) return fail(HHV_E_ARG, "hhv_prefilter_first: bad argument");
+  *n_out = 0;
+  int rc = prefilter_scores_impl(c, db, profile, Lq, score_offset, 0, 0, 0, nullptr, 0, nullptr);
+  if (rc != HHV_OK) return rc;
+  const int n = db->n;
+  if (!db->d_keys) {
+    db->sort_temp_bytes = topk_temp_bytes(n);
+    if (hipMalloc(&db->d_keys, (size_t)n * 8) != hipSuccess || hipMalloc(&db->d_sorted, (size_t)n * 8) != hipSuccess ||
+        hipMalloc(&db->d_sort_temp, db->sort_temp_bytes) != hipSuccess || hipMalloc(&db->d_above, 16) != hipSuccess)
+      return fail(HHV_E_MEMORY, "hhv_prefilter_first: device allocation failed");
+  }
+  HIP_TRY(hipMemsetAsync(db->d_above, 0, 4, c->stream));
+  int lr = pf_select_sort(db->d_scores, db->d_off, n, log_qlen, bit_factor, smax_thresh, db->d_keys, db->d_sorted, db->d_sort_temp,
+                          db->sort_temp_bytes, db->d_above, c->stream);
+  if (lr != 0) return fail(HHV_E_DEVICE, "hhv_prefilter_first: sort failed: %s", hipGetErrorString((hipError_t)(-lr)));
+  unsigned int above = 0;
+  HIP_TRY(hipMemcpyAsync(&above, db->d_above, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // the reference keeps the min_hits best plus everything above the threshold (sorted: the first max(.,.) elements)
+  const int m = (int)std::min<int64_t>(n, std::max<int64_t>(std::max(min_hits, 0), (int64_t)above));
+  *n_out = m;
+  if (m > cap) return fail(HHV_E_ARG, "hhv_prefilter_first: %d sequences pass, cap = %d", m, cap);
+  if (m == 0) return HHV_OK;
+  // ids through the (int32) subset scratch buffer
+  if (db->sub_cap < (size_t)m * 4) {
+    dfree(db->d_subset);
+    db->sub_cap = 0;
+    HIP_TRY(hipMalloc(&db->d_subset, (size_t)m * 4));
+    db->sub_cap = (size_t)m * 4;
+  }
+  lr = pf_select_ids(db->d_sorted, m, db->d_subset, c->stream);
+  if (lr != 0) return fail(HHV_E_DEVICE, "hhv_prefilter_first: gather failed");
+  HIP_TRY(hipMemcpyAsync(ids, db->d_subset, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HHV_OK;
 }
 
 

@@ -131,6 +131,11 @@ struct PrefilterArgs {
 size_t prefilter_fast_lds(bool gapped, int W);
 int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream);
 // generic kernel: a.W = ceil(Lq/32); prof_lds = striped profile built in LDS, else read from a.striped
+// first selection step of the prefilter on the device (hhv_topk.hip)
+size_t topk_temp_bytes(int n);
+int pf_select_sort(const int32_t* d_scores, const int64_t* d_offsets, int n, float log_qlen, int bit_factor, int smax_thresh,
+                   uint64_t* keys, uint64_t* sorted, void* temp, size_t temp_bytes, unsigned int* above, hipStream_t stream);
+int pf_select_ids(const uint64_t* sorted, int m, int32_t* d_ids, hipStream_t stream);
 int launch_prefilter_generic(const PrefilterArgs& a, bool gapped, bool prof_lds, int n_blocks, size_t lds_bytes, void* stream);
 
 // MAC realignment (hhv_mac.hip): one wavefront per hit

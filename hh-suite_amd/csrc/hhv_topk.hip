@@ -79,3 +79,58 @@ int topk_device(const DevHit* d_hits, int n, int k, DevHit* d_out, uint64_t* key
 }
 
 }  // namespace hhv
+
+// ---- first selection step of the prefilter on the device (Prefilter::prefilter_db, src/hhprefilter.cpp:461-505) --------
+namespace hhv {
+
+// util-inl.h:83-93: the polynomial constants are double literals there - double Horner chain, rounded to float once
+__device__ __forceinline__ float flog2_dev(float x) {
+  if (x <= 0) return -128;
+  uint32_t bits = __float_as_uint(x);
+  const float e = (float)((int)((bits & 0x7F800000u) >> 23) - 0x7f);
+  x = __uint_as_float((bits & 0x007FFFFFu) | 0x3f800000u);
+  x = (float)((double)x - 1.0);
+  x = (float)((double)x * (1.441740 + (double)x * (-0.7077702 + (double)x * (0.4123442 + (double)x * (-0.1903190 + (double)x * 0.0440047)))));
+  return x + e;
+}
+
+// key = (length-corrected score, id), both descending like the reference's sort + reverse of (score, id) pairs;
+// above[0] counts the sequences above the threshold
+__global__ void pf_select_keys_kernel(const int32_t* __restrict__ scores, const int64_t* __restrict__ offsets, int n,
+                                      float log_qlen, int bit_factor, int smax_thresh, uint64_t* __restrict__ keys,
+                                      unsigned int* __restrict__ above) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  bool hit = false;
+  if (k < n) {
+    const int len = (int)(offsets[k + 1] - offsets[k]);
+    const int corrected = scores[k] - (int)((float)bit_factor * (log_qlen + flog2_dev((float)len)));
+    keys[k] = ((uint64_t)((uint32_t)corrected ^ 0x80000000u) << 32) | (uint32_t)k;
+    hit = corrected > smax_thresh;
+  }
+  const unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(above, (unsigned int)__popcll(m));
+}
+
+__global__ void pf_select_ids_kernel(const uint64_t* __restrict__ sorted, int m, int32_t* __restrict__ ids) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < m) ids[k] = (int32_t)(sorted[k] & 0xFFFFFFFFu);
+}
+
+// keys/sorted: n uint64, temp: topk_temp_bytes(n), above: one zeroed uint.  Asynchronous on `stream`.
+int pf_select_sort(const int32_t* d_scores, const int64_t* d_offsets, int n, float log_qlen, int bit_factor, int smax_thresh,
+                   uint64_t* keys, uint64_t* sorted, void* temp, size_t temp_bytes, unsigned int* above, hipStream_t stream) {
+  const int threads = 256;
+  hipLaunchKernelGGL(pf_select_keys_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, d_scores, d_offsets, n,
+                     log_qlen, bit_factor, smax_thresh, keys, above);
+  const hipError_t e = hipcub::DeviceRadixSort::SortKeysDescending(temp, temp_bytes, keys, sorted, n, 0, 64, stream);
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+int pf_select_ids(const uint64_t* sorted, int m, int32_t* d_ids, hipStream_t stream) {
+  const int threads = 256;
+  hipLaunchKernelGGL(pf_select_ids_kernel, dim3((m + threads - 1) / threads), dim3(threads), 0, stream, sorted, m, d_ids);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace hhv

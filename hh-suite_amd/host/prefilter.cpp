@@ -211,11 +211,14 @@ int Prefilter::prefilter_db(const float* q_p, const float* q_pav, int Lq, const 
   const int n_db = (int)length_.size();
   std::vector<uint8_t> plain((size_t)220 * Lq);
   PrefilterQueryProfile(q_p, q_pav, lib_.data(), Lq, par.score_offset, par.bit_factor, plain.data());
-  // stage 1: gapless score of every sequence on the GPU
-  std::vector<int32_t> score(n_db), subset;
-  int rc = hhv_prefilter_scores(ctx_, db_, plain.data(), Lq, par.score_offset, 0, 0, 0, nullptr, 0, score.data());
+  // stage 1 entirely on the GPU: gapless score of every sequence, length correction, sort, cut (SelectFirst is the
+  // host statement of the same rule); only the surviving ids come back
+  std::vector<int32_t> subset(n_db);
+  int32_t n_sub = 0;
+  int rc = hhv_prefilter_first(ctx_, db_, plain.data(), Lq, par.score_offset, flog2((float)Lq), par.bit_factor, par.smax_thresh,
+                               par.min_hits, subset.data(), n_db, &n_sub);
   if (rc != HHV_OK) return rc;
-  SelectFirst(score.data(), length_.data(), n_db, Lq, par, &subset);
+  subset.resize(n_sub);
   if (passed_first) *passed_first = (int)subset.size();
   if (subset.empty()) return HHV_OK;
   // stage 2: Smith-Waterman of the survivors on the GPU

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
-    "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores",
+    "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
@@ -339,6 +339,18 @@ class Context:
         h = C.c_void_p()
         _check(self.lib.hhv_prefilter_upload_db(self.h, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, C.byref(h)))
         return (h, len(offsets) - 1)
+
+    def prefilter_first(self, db, profile, score_offset, log_qlen, bit_factor=4, smax_thresh=10, min_hits=100):
+        """hhv_prefilter_first: first prefilter stage entirely on the device -> surviving ids, best first."""
+        profile = np.ascontiguousarray(profile, dtype=np.uint8)
+        ids = np.zeros(db[1], dtype=np.int32)
+        n = C.c_int32()
+        self.lib.hhv_prefilter_first.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        _check(self.lib.hhv_prefilter_first(self.h, db[0], profile.ctypes.data, profile.shape[1], int(score_offset),
+                                            float(log_qlen), int(bit_factor), int(smax_thresh), int(min_hits), ids.ctypes.data,
+                                            len(ids), C.byref(n)))
+        return ids[:n.value]
 
     def prefilter_free_db(self, db):
         self.lib.hhv_prefilter_free_db(db[0])

@@ -258,6 +258,14 @@ int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32
 int hhv_mac_posterior(hhv_macset* ms, int32_t k, float* posterior);
 void hhv_macset_free(hhv_macset* ms);
 
+/* The whole first stage of Prefilter::prefilter_db on the device (src/hhprefilter.cpp:461-505): gapless scores of ALL
+ * sequences, length correction score - (int)(bit_factor * (log_qlen + flog2(len))) (log_qlen = flog2(Lq), util-inl.h:83),
+ * descending sort by (score, id), keep the min_hits best plus everything above smax_thresh.  ids[0..*n_out) = the
+ * surviving sequence ids, best first - the same set and order hhv::Prefilter::SelectFirst derives from the scores on
+ * the host; only the ids come back (4 bytes per survivor instead of 4 bytes per database sequence). */
+int hhv_prefilter_first(hhv_ctx* ctx, hhv_pfdb* db, const uint8_t* profile, int32_t Lq, int32_t score_offset, float log_qlen,
+                        int32_t bit_factor, int32_t smax_thresh, int32_t min_hits, int32_t* ids, int32_t cap, int32_t* n_out);
+
 /* Binary packed template database: the record stream plus its length table in one file, so that
  * a search mmaps/reads it straight into HBM instead of parsing and re-packing HMM text per query.
  * File = 64-byte header {magic "HHVPDB01", int32 n, int32 record_dwords (28), int64 n_records, zero pad},

@@ -265,6 +265,27 @@ def test_selection_steps_match_reference_prefilter_db(oracle, ref, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", range(len(SELECT_CASES)))
+def test_gpu_first_stage_on_device_equals_host_selection(case):
+    """hhv_prefilter_first (scores, length correction, sort and cut on the device) returns the ids hhv::Prefilter::SelectFirst
+    derives from the same scores on the host - same set, same order."""
+    from pyhhv import capi
+    kw = {k: v for k, v in SELECT_CASES[case].items() if k in ("min_hits", "smax_thresh")}
+    lib, prof, pav, qp = _fixture()
+    Lq = qp.shape[0]
+    seqs, offs, lens = make_db(prof, 5000, 300 + case)
+    c = capi.Context()
+    db = c.prefilter_upload_db(seqs, offs)
+    ung = c.prefilter_scores(db, prof, OFFSET, gapped=False)
+    want = capi.prefilter_select_first(ung, lens, Lq, **kw)
+    r = capi.load_runner()
+    got = c.prefilter_first(db, prof, OFFSET, r.hhvr_flog2(float(Lq)), 4, kw.get("smax_thresh", 10), kw.get("min_hits", 100))
+    assert np.array_equal(got, want) and len(got) >= min(kw.get("min_hits", 100), 5000)
+    c.prefilter_free_db(db)
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(SELECT_CASES)))
 def test_gpu_prefilter_db_matches_reference(ref, case):
     from pyhhv import capi
     kw = SELECT_CASES[case]

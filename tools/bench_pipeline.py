@@ -65,15 +65,17 @@ def main():
     q_lin = capi.linear_transitions(q_tr, True)
     t_lin_base = [capi.linear_transitions(po.oracle_prepare(orc, 1, *base[k], pb, R, q_pav=q_pav)[1], False) for k in range(distinct)]
 
+    flog2_Lq = capi.load_runner().hhvr_flog2(float(Lq))
+
     def search():
         t = {}
         t0 = time.perf_counter()
         c.set_query(qp, q_tr)
         prof = capi.prefilter_profile(np.ascontiguousarray(qp[:-1]), q_pav, lib)
-        ung = c.prefilter_scores(pfdb, prof, 50, gapped=False)
+        # first stage entirely on the device (scores, length correction, sort, cut): only the surviving ids come back
+        sub = c.prefilter_first(pfdb, prof, 50, flog2_Lq, 4, smax_thresh=1000, min_hits=survivors)   # forces `survivors` to pass
         t["prefilter_gapless_ms"] = (time.perf_counter() - t0) * 1e3
         t1 = time.perf_counter()
-        sub = capi.prefilter_select_first(ung, Ls_all, Lq, min_hits=survivors, smax_thresh=1000)   # forces `survivors` to pass
         sw = c.prefilter_scores(pfdb, prof, 50, gapped=True, gap_init=24, gap_extend=4, subset=sub)
         ids, ev = capi.prefilter_select_second(sw, sub, Ls_all, Lq, min_hits=survivors, maxnumdb=survivors)
         t["prefilter_sw_select_ms"] = (time.perf_counter() - t1) * 1e3
