@@ -102,4 +102,43 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
   return HHV_OK;
 }
 
+// A new template set holding templates ids[0..n) of a resident one (any order, repeats allowed), copied on the device.
+int hhv_tset_gather(hhv_ctx* c, hhv_tset* ts, const int32_t* ids, int32_t n, hhv_tset** out) {
+  if (!c || !ts || !ids || !out || n < 1) return fail(HHV_E_ARG, "hhv_tset_gather: bad argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_tset_gather: template set belongs to another context");
+  *out = nullptr;
+  std::vector<int32_t> L(n);
+  for (int k = 0; k < n; ++k) {
+    if (ids[k] < 0 || ids[k] >= ts->n) return fail(HHV_E_ARG, "hhv_tset_gather: ids[%d] = %d of %d", k, ids[k], ts->n);
+    L[k] = ts->L[ids[k]];
+  }
+  HIP_TRY(hipSetDevice(c->par.device));
+  hhv_tset* sub = new (std::nothrow) hhv_tset();
+  if (!sub) return fail(HHV_E_MEMORY, "out of host memory");
+  int rc = tset_init_common(c, sub, n, L.data());
+  int32_t* d_ids = nullptr;
+  if (rc == HHV_OK && (hipMalloc(&sub->d_records, (size_t)(sub->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess ||
+                       hipMalloc(&d_ids, (size_t)n * sizeof(int32_t)) != hipSuccess))
+    rc = fail(HHV_E_MEMORY, "hhv_tset_gather: device allocation failed");
+  if (rc == HHV_OK) {
+    sub->owns_records = true;
+    std::vector<float> tail((size_t)(1 + STREAM_PAD_RECS) * REC_DW, 0.0f);
+    write_header(tail.data(), -1, 0);
+    if (hipMemcpyAsync(sub->d_records + (size_t)sub->rec_off[n] * REC_DW, tail.data(), tail.size() * sizeof(float),
+                       hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_ids, ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      rc = fail(HHV_E_DEVICE, "hhv_tset_gather: H2D copy failed");
+  }
+  if (rc == HHV_OK && tset_gather(ts->d_records, ts->d_rec_off, d_ids, sub->d_rec_off, sub->d_L, n, sub->d_records, c->stream) != 0)
+    rc = fail(HHV_E_DEVICE, "hhv_tset_gather: kernel launch failed");
+  if (rc == HHV_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(HHV_E_DEVICE, "hhv_tset_gather: kernel failed");
+  dfree(d_ids);
+  if (rc != HHV_OK) {
+    hhv_tset_free(sub);
+    return rc;
+  }
+  *out = sub;
+  return HHV_OK;
+}
+
 }  // extern "C"

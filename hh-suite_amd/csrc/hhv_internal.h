@@ -131,6 +131,9 @@ struct PrefilterArgs {
 size_t prefilter_fast_lds(bool gapped, int W);
 int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream);
 // generic kernel: a.W = ceil(Lq/32); prof_lds = striped profile built in LDS, else read from a.striped
+// device-side subset of a resident template set (hhv_topk.hip)
+int tset_gather(const float* src, const int64_t* src_off, const int32_t* ids, const int64_t* dst_off, const int32_t* L, int n,
+                float* dst, hipStream_t stream);
 // first selection step of the prefilter on the device (hhv_topk.hip)
 size_t topk_temp_bytes(int n);
 int pf_select_sort(const int32_t* d_scores, const int64_t* d_offsets, int n, float log_qlen, int bit_factor, int smax_thresh,

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "hhv_internal.h"
+#include "viterbi_lane.h"
 
 namespace hhv {
 
@@ -129,6 +130,32 @@ int pf_select_sort(const int32_t* d_scores, const int64_t* d_offsets, int n, flo
 int pf_select_ids(const uint64_t* sorted, int m, int32_t* d_ids, hipStream_t stream) {
   const int threads = 256;
   hipLaunchKernelGGL(pf_select_ids_kernel, dim3((m + threads - 1) / threads), dim3(threads), 0, stream, sorted, m, d_ids);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace hhv
+
+// ---- device-side subset of a resident template set: copy the records of the selected templates, renumber headers -------
+namespace hhv {
+
+__global__ void __launch_bounds__(256) tset_gather_kernel(const float* __restrict__ src, const int64_t* __restrict__ src_off,
+                                                          const int32_t* __restrict__ ids, const int64_t* __restrict__ dst_off,
+                                                          const int32_t* __restrict__ L, float* __restrict__ dst) {
+  const int k = blockIdx.x;  // slot in the new set
+  const float4* s = reinterpret_cast<const float4*>(src + (size_t)src_off[ids[k]] * REC_DW);
+  float4* d = reinterpret_cast<float4*>(dst + (size_t)dst_off[k] * REC_DW);
+  const int n4 = (L[k] + 1) * (REC_DW / 4);
+  for (int e = threadIdx.x; e < n4; e += 256) {
+    float4 v = s[e];
+    if (e == 0) v.x = __int_as_float(k);  // header record: [0] = template index inside the set
+    d[e] = v;
+  }
+}
+
+int tset_gather(const float* src, const int64_t* src_off, const int32_t* ids, const int64_t* dst_off, const int32_t* L, int n,
+                float* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(tset_gather_kernel, dim3(n), dim3(256), 0, stream, src, src_off, ids, dst_off, L, dst);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

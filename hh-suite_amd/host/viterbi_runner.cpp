@@ -136,14 +136,9 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
     hhv_tset* ts = all.t;
     const int m = (int)to_align.size();
     if (alignment > 0) {
-      std::vector<int32_t> Ls(m);
-      std::vector<const float*> ps(m), trs(m);
-      for (int t = 0; t < m; ++t) {
-        Ls[t] = L[to_align[t]];
-        ps[t] = pp[to_align[t]];
-        trs[t] = tt[to_align[t]];
-      }
-      check(hhv_upload_templates(ctx.c, m, Ls.data(), ps.data(), trs.data(), &sub.t), "hhv_upload_templates");
+      // the surviving templates are copied on the device from the resident set: nothing is packed or uploaded again
+      std::vector<int32_t> ids(to_align.begin(), to_align.end());
+      check(hhv_tset_gather(ctx.c, all.t, ids.data(), m, &sub.t), "hhv_tset_gather");
       ts = sub.t;
       for (int t = 0; t < m; ++t)
         check(hhv_set_celloff(ctx.c, ts, t, masks[to_align[t]].data()), "hhv_set_celloff");

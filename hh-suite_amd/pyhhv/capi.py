@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
-    "hhv_db_write", "hhv_db_open", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
+    "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_topk",
 ]
@@ -332,6 +332,14 @@ class Context:
         out = np.zeros((int(ts.L[k]) + 1, REC_DW), dtype=np.float32)
         _check(self.lib.hhv_tset_records_of(self.h, ts.h, int(k), out.ctypes.data_as(c_float_p)))
         return out
+
+    def gather(self, ts, ids):
+        """hhv_tset_gather -> new TemplateSet with templates ids of ts (device-side copy)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self.lib.hhv_tset_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        _check(self.lib.hhv_tset_gather(self.h, ts.h, ids.ctypes.data, len(ids), C.byref(h)))
+        return TemplateSet(self, h, np.asarray(ts.L, dtype=np.int32)[ids])
 
     def prefilter_upload_db(self, seqs, offsets):
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)

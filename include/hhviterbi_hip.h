@@ -258,6 +258,11 @@ int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32
 int hhv_mac_posterior(hhv_macset* ms, int32_t k, float* posterior);
 void hhv_macset_free(hhv_macset* ms);
 
+/* A new template set made of templates ids[0..n) of a resident one (any order, repeats allowed), copied on the device:
+ * the surviving templates of an alternative-alignment round (src/hhviterbirunner.cpp:260-268) or any selection of a
+ * resident database, without touching host memory.  Template k of the new set is template ids[k] of ts. */
+int hhv_tset_gather(hhv_ctx* ctx, hhv_tset* ts, const int32_t* ids, int32_t n, hhv_tset** out);
+
 /* The whole first stage of Prefilter::prefilter_db on the device (src/hhprefilter.cpp:461-505): gapless scores of ALL
  * sequences, length correction score - (int)(bit_factor * (log_qlen + flog2(len))) (log_qlen = flog2(Lq), util-inl.h:83),
  * descending sort by (score, id), keep the min_hits best plus everything above smax_thresh.  ids[0..*n_out) = the

@@ -184,3 +184,24 @@ def test_packed_db_roundtrip(hhv, oracle, tmp_path):
     a.free()
     b.free()
     c.close()
+
+
+def test_gather_subset_on_device(hhv, oracle):
+    """hhv_tset_gather: a device-side copy of selected templates aligns exactly like the originals."""
+    par = make_params(local=1)
+    qf, qtr, tps, ttrs = workload(77, 150, 12, 5, 260)
+    c = ctx_for(hhv, par)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    full = c.align(ts, backtrace=True)
+    ids = np.array([11, 0, 5, 5, 3], np.int32)
+    sub = c.gather(ts, ids)
+    res = c.align(sub, backtrace=True)
+    assert list(res["index"]) == list(range(len(ids)))
+    assert np.array_equal(res["score"].view(np.uint32), full["score"][ids].view(np.uint32))
+    assert np.array_equal(res["i2"], full["i2"][ids]) and np.array_equal(res["j2"], full["j2"][ids])
+    for pos, k in enumerate(ids):
+        assert np.array_equal(c.backtrace_matrix(sub, pos), c.backtrace_matrix(ts, int(k)))
+    sub.free()
+    ts.free()
+    c.close()
