@@ -539,6 +539,52 @@ int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
   return HHV_OK;
 }
 
+int hhv_set_celloff_paths(hhv_ctx* c, hhv_tset* ts, int32_t n_paths, const int32_t* template_of, const int64_t* path_off,
+                          const int32_t* i_steps, const int32_t* j_steps, int32_t n_qranges, const int32_t* qranges,
+                          int32_t n_tranges, const int32_t* tranges) {
+  if (!c || !ts || n_paths < 0 || n_qranges < 0 || n_tranges < 0 || (n_paths && (!template_of || !path_off || !i_steps || !j_steps)) ||
+      (n_qranges && !qranges) || (n_tranges && !tranges))
+    return fail(HHV_E_ARG, "hhv_set_celloff_paths: bad argument");
+  if (c->Lq < 1) return fail(HHV_E_STATE, "hhv_set_celloff_paths: no query set");
+  for (int p = 0; p < n_paths; ++p)
+    if (template_of[p] < 0 || template_of[p] >= ts->n || path_off[p + 1] < path_off[p])
+      return fail(HHV_E_ARG, "hhv_set_celloff_paths: path %d invalid", p);
+  HIP_TRY(hipSetDevice(c->par.device));
+  int rc = ensure_bt(c, ts);
+  if (rc != HHV_OK) return rc;
+  const int64_t steps = n_paths ? path_off[n_paths] : 0;
+  std::vector<int32_t> ranges;
+  for (int r = 0; r < 2 * n_qranges; ++r) ranges.push_back(qranges[r]);
+  for (int r = 0; r < 2 * n_tranges; ++r) ranges.push_back(tranges[r]);
+  ranges.push_back(0);
+  // one scratch allocation: template_of | path_off | i | j | ranges
+  const size_t b_t = (size_t)n_paths * 4, b_o = (size_t)(n_paths + 1) * 8, b_s = (size_t)steps * 4, b_r = ranges.size() * 4;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  char* d = nullptr;
+  HIP_TRY(hipMalloc(&d, al(b_t) + al(b_o) + 2 * al(b_s) + al(b_r) + 256));
+  char* d_t = d;
+  char* d_o = d_t + al(b_t);
+  char* d_i = d_o + al(b_o);
+  char* d_j = d_i + al(b_s);
+  char* d_r = d_j + al(b_s);
+  bool ok = hipMemcpyAsync(d_r, ranges.data(), b_r, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+  if (n_paths)
+    ok = ok && hipMemcpyAsync(d_t, template_of, b_t, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipMemcpyAsync(d_o, path_off, b_o, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipMemcpyAsync(d_i, i_steps, b_s, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipMemcpyAsync(d_j, j_steps, b_s, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+  int lr = 0;
+  if (ok)
+    lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, ts->n_records * LANES, c->Lq, c->R, c->P, ts->n, n_paths,
+                            (const int32_t*)d_t, (const int64_t*)d_o, (const int32_t*)d_i, (const int32_t*)d_j,
+                            (const int32_t*)d_r, n_qranges, n_tranges, c->stream);
+  const bool synced = hipStreamSynchronize(c->stream) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok || lr != 0 || !synced) return fail(HHV_E_DEVICE, "hhv_set_celloff_paths: device operation failed");
+  ts->bt_valid = false;
+  return HHV_OK;
+}
+
 int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
   if (!c || !ts || !out) return fail(HHV_E_ARG, "hhv_backtrace_matrix: null argument");
   if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_backtrace_matrix: template %d of %d", k, ts->n);
@@ -622,6 +668,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   rc = launch_trace(a, c->stream);
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   ts->hits_valid = true;
+  ts->host_paths_valid = false;
   return HHV_OK;
 }
 
@@ -642,16 +689,41 @@ int hhv_hit_path(hhv_ctx* c, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_st
   if (!ts->hits_valid) return fail(HHV_E_STATE, "hhv_hit_path: call hhv_hits first");
   HIP_TRY(hipSetDevice(c->par.device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  DevHit h;
-  HIP_TRY(hipMemcpy(&h, ts->d_hits + k, sizeof(h), hipMemcpyDeviceToHost));
-  *nsteps = h.nsteps;
-  const int m = std::min(cap, h.nsteps + 1);
-  if (m <= 0) return HHV_OK;
+  const int64_t pool = ts->path_off[ts->n];
+  if (!ts->host_paths_valid && (size_t)pool * 13 <= ((size_t)768 << 20)) {
+    ts->h_i_steps.resize((size_t)pool);
+    ts->h_j_steps.resize((size_t)pool);
+    ts->h_states.resize((size_t)pool);
+    ts->h_S.resize((size_t)pool);
+    ts->h_hits.resize((size_t)ts->n);
+    HIP_TRY(hipMemcpy(ts->h_i_steps.data(), ts->d_i_steps, (size_t)pool * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ts->h_j_steps.data(), ts->d_j_steps, (size_t)pool * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ts->h_states.data(), ts->d_states, (size_t)pool * sizeof(int8_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ts->h_S.data(), ts->d_S, (size_t)pool * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ts->h_hits.data(), ts->d_hits, (size_t)ts->n * sizeof(DevHit), hipMemcpyDeviceToHost));
+    ts->host_paths_valid = true;
+  }
   const int64_t po = ts->path_off[k];
-  if (i_steps) HIP_TRY(hipMemcpy(i_steps, ts->d_i_steps + po, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (j_steps) HIP_TRY(hipMemcpy(j_steps, ts->d_j_steps + po, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (states) HIP_TRY(hipMemcpy(states, ts->d_states + po, (size_t)m * sizeof(int8_t), hipMemcpyDeviceToHost));
-  if (S) HIP_TRY(hipMemcpy(S, ts->d_S + po, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+  if (ts->host_paths_valid) {
+    const int ns = ts->h_hits[k].nsteps;
+    *nsteps = ns;
+    const int m = std::min(cap, ns + 1);
+    if (m <= 0) return HHV_OK;
+    if (i_steps) memcpy(i_steps, ts->h_i_steps.data() + po, (size_t)m * sizeof(int32_t));
+    if (j_steps) memcpy(j_steps, ts->h_j_steps.data() + po, (size_t)m * sizeof(int32_t));
+    if (states) memcpy(states, ts->h_states.data() + po, (size_t)m * sizeof(int8_t));
+    if (S) memcpy(S, ts->h_S.data() + po, (size_t)m * sizeof(float));
+  } else {  // a path pool too large to mirror on the host: copy this hit only
+    DevHit h;
+    HIP_TRY(hipMemcpy(&h, ts->d_hits + k, sizeof(h), hipMemcpyDeviceToHost));
+    *nsteps = h.nsteps;
+    const int m = std::min(cap, h.nsteps + 1);
+    if (m <= 0) return HHV_OK;
+    if (i_steps) HIP_TRY(hipMemcpy(i_steps, ts->d_i_steps + po, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (j_steps) HIP_TRY(hipMemcpy(j_steps, ts->d_j_steps + po, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (states) HIP_TRY(hipMemcpy(states, ts->d_states + po, (size_t)m * sizeof(int8_t), hipMemcpyDeviceToHost));
+    if (S) HIP_TRY(hipMemcpy(S, ts->d_S + po, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+  }
   if (i_steps) i_steps[0] = 0;
   if (j_steps) j_steps[0] = 0;
   if (states) states[0] = 0;

@@ -96,6 +96,13 @@ struct hhv_tset {
   float* d_S = nullptr;
   hhv::DevHit* d_hits = nullptr;
   bool hits_valid = false;
+  // host copy of the whole path pool, fetched with five copies on the first hhv_hit_path after a trace (asking for
+  // the paths of thousands of hits one by one would cost four small copies each)
+  std::vector<int32_t> h_i_steps, h_j_steps;
+  std::vector<int8_t> h_states;
+  std::vector<float> h_S;
+  std::vector<hhv::DevHit> h_hits;
+  bool host_paths_valid = false;
   // top-k scratch
   hhv::DevHit* d_topk = nullptr;
   int topk_cap = 0;

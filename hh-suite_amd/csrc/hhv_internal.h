@@ -131,6 +131,10 @@ struct PrefilterArgs {
 size_t prefilter_fast_lds(bool gapped, int W);
 int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream);
 // generic kernel: a.W = ceil(Lq/32); prof_lds = striped profile built in LDS, else read from a.striped
+// cell-off masks of the alternative-alignment rounds from the earlier alignments' paths (hhv_topk.hip)
+int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, int R, int P,
+                       int n_templates, int n_paths, const int32_t* template_of, const int64_t* path_off, const int32_t* pi,
+                       const int32_t* pj, const int32_t* ranges, int n_q, int n_t, hipStream_t stream);
 // device-side subset of a resident template set (hhv_topk.hip)
 int tset_gather(const float* src, const int64_t* src_off, const int32_t* ids, const int64_t* dst_off, const int32_t* L, int n,
                 float* dst, hipStream_t stream);

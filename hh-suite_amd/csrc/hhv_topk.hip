@@ -161,3 +161,71 @@ int tset_gather(const float* src, const int64_t* src_off, const int32_t* ids, co
 }
 
 }  // namespace hhv
+
+// ---- cell-off masks of the alternative-alignment rounds, built on the device ------------------------------------------
+// Viterbi::ExcludeAlignment (src/hhviterbi.cpp:61-77): for every step but the last of an earlier alignment, the cells
+// (i +- 40, j) and (i, j +- 40) are switched off.  The mask is an input of the stream kernel: bit 7 of byte r of the
+// backtrace entry [pass][record][lane] (viterbi_lane.h).
+namespace hhv {
+
+struct CellOffGeom {
+  uint64_t* bt;
+  const int64_t* rec_off;
+  const int32_t* L;
+  int64_t pass_stride;  // entries per pass
+  int Lq, R, P;
+};
+__device__ __forceinline__ void celloff_set(const CellOffGeom& g, int t, int i, int j) {
+  const int strip = (i - 1) / g.R, r = (i - 1) - strip * g.R;
+  const int pass = strip / LANES, lane = strip - pass * LANES;
+  atomicOr((unsigned long long*)(g.bt + (size_t)pass * g.pass_stride + (size_t)(g.rec_off[t] + j) * LANES + lane),
+           0x80ull << (8 * r));
+}
+
+// one workgroup per template: clear every entry, then the -excl / -template_excl ranges
+__global__ void __launch_bounds__(256) celloff_clear_kernel(CellOffGeom g, const int32_t* __restrict__ ranges, int n_q, int n_t) {
+  const int t = blockIdx.x, Lt = g.L[t];
+  for (int pass = 0; pass < g.P; ++pass) {
+    uint64_t* e = g.bt + (size_t)pass * g.pass_stride + (size_t)(g.rec_off[t] + 1) * LANES;
+    for (int k = threadIdx.x; k < Lt * LANES; k += 256) e[k] = 0;
+  }
+  __syncthreads();
+  for (int q = 0; q < n_q; ++q) {
+    const int lo = ranges[2 * q], hi = min(ranges[2 * q + 1], g.Lq);
+    for (int c = threadIdx.x; c < (hi - lo + 1) * Lt; c += 256) celloff_set(g, t, lo + c / Lt, 1 + c % Lt);
+  }
+  for (int q = 0; q < n_t; ++q) {
+    const int lo = ranges[2 * (n_q + q)], hi = min(ranges[2 * (n_q + q) + 1], Lt);
+    for (int c = threadIdx.x; c < (hi - lo + 1) * g.Lq; c += 256) celloff_set(g, t, 1 + c % g.Lq, lo + c / g.Lq);
+  }
+}
+
+// one workgroup per earlier alignment: its +-40 cross
+__global__ void __launch_bounds__(256) celloff_paths_kernel(CellOffGeom g, const int32_t* __restrict__ template_of,
+                                                            const int64_t* __restrict__ path_off,
+                                                            const int32_t* __restrict__ pi, const int32_t* __restrict__ pj) {
+  const int p = blockIdx.x, t = template_of[p], Lt = g.L[t];
+  const int64_t o = path_off[p];
+  const int ns = (int)(path_off[p + 1] - o) - 1;  // the last step is skipped, like the reference (:65)
+  constexpr int W = 2 * 40 + 1;                    // VITERBI_PATH_WIDTH = 40 (src/hhdecl.h:50)
+  for (int w = threadIdx.x; w < ns * W; w += 256) {
+    const int step = w / W, d = w - step * W - 40;
+    const int i = pi[o + step], j = pj[o + step];
+    if (i < 1 || i > g.Lq || j < 1 || j > Lt) continue;
+    if (i + d >= 1 && i + d <= g.Lq) celloff_set(g, t, i + d, j);
+    if (j + d >= 1 && j + d <= Lt) celloff_set(g, t, i, j + d);
+  }
+}
+
+int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, int R, int P,
+                       int n_templates, int n_paths, const int32_t* template_of, const int64_t* path_off, const int32_t* pi,
+                       const int32_t* pj, const int32_t* ranges, int n_q, int n_t, hipStream_t stream) {
+  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, R, P};
+  hipLaunchKernelGGL(celloff_clear_kernel, dim3(n_templates), dim3(256), 0, stream, g, ranges, n_q, n_t);
+  if (n_paths > 0)
+    hipLaunchKernelGGL(celloff_paths_kernel, dim3(n_paths), dim3(256), 0, stream, g, template_of, path_off, pi, pj);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace hhv

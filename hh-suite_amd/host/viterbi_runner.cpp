@@ -116,19 +116,19 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
   check(hhv_upload_templates(ctx.c, n, L.data(), pp.data(), tt.data(), &all.t), "hhv_upload_templates");
 
   // excludeAlignments (src/hhviterbirunner.cpp:100,262-268): accumulated mask per template
-  std::vector<std::vector<uint8_t> > masks(n);
   std::vector<int> to_align(n);
   for (int k = 0; k < n; ++k) to_align[k] = k;
-  // -excl / -template_excl regions are masked in every round, including the first (:157-164)
+  // -excl / -template_excl regions are masked in every round, including the first (:157-164); the masks are built on
+  // the device (hhv_set_celloff_paths) from the ranges and, in later rounds, the paths of the earlier alignments
   const bool regions = !par.exclstr.empty() || !par.template_exclstr.empty();
-  if (regions) {
-    for (int k = 0; k < n; ++k) {
-      masks[k].assign((size_t)(q.L + 1) * (L[k] + 1), 0);
-      if (!par.exclstr.empty()) ExcludeRegions(masks[k], q.L, L[k], par.exclstr);
-      if (!par.template_exclstr.empty()) ExcludeTemplateRegions(masks[k], q.L, L[k], par.template_exclstr);
-      check(hhv_set_celloff(ctx.c, all.t, k, masks[k].data()), "hhv_set_celloff");
-    }
-  }
+  const std::vector<int32_t> qr = ParseRegions(par.exclstr), tr = ParseRegions(par.template_exclstr);
+  if (regions)
+    check(hhv_set_celloff_paths(ctx.c, all.t, 0, nullptr, nullptr, nullptr, nullptr, (int32_t)qr.size() / 2, qr.data(),
+                                (int32_t)tr.size() / 2, tr.data()),
+          "hhv_set_celloff_paths");
+  // earlier alignments of every template (entries 1..nsteps of the path), accumulated over the rounds (:273-289)
+  std::vector<std::vector<int32_t> > prev_i(n), prev_j(n);
+  std::vector<std::vector<int64_t> > prev_off(n);
 
   for (int alignment = 0; alignment < par.altali && !to_align.empty(); ++alignment) {
     // round 0 runs on the resident set; later rounds on the (usually much smaller) surviving subset
@@ -140,8 +140,20 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
       std::vector<int32_t> ids(to_align.begin(), to_align.end());
       check(hhv_tset_gather(ctx.c, all.t, ids.data(), m, &sub.t), "hhv_tset_gather");
       ts = sub.t;
-      for (int t = 0; t < m; ++t)
-        check(hhv_set_celloff(ctx.c, ts, t, masks[to_align[t]].data()), "hhv_set_celloff");
+      std::vector<int32_t> template_of, pi, pj;
+      std::vector<int64_t> poff(1, 0);
+      for (int t = 0; t < m; ++t) {
+        const int k = to_align[t];
+        for (size_t a = 0; a + 1 < prev_off[k].size(); ++a) {
+          template_of.push_back(t);
+          pi.insert(pi.end(), prev_i[k].begin() + prev_off[k][a], prev_i[k].begin() + prev_off[k][a + 1]);
+          pj.insert(pj.end(), prev_j[k].begin() + prev_off[k][a], prev_j[k].begin() + prev_off[k][a + 1]);
+          poff.push_back((int64_t)pi.size());
+        }
+      }
+      check(hhv_set_celloff_paths(ctx.c, ts, (int32_t)template_of.size(), template_of.data(), poff.data(), pi.data(), pj.data(),
+                                  (int32_t)qr.size() / 2, qr.data(), (int32_t)tr.size() / 2, tr.data()),
+            "hhv_set_celloff_paths");
     }
     std::vector<hhv_hit> hits(m);
     check(hhv_align(ctx.c, ts, (alignment > 0 || regions) ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, nullptr),
@@ -176,8 +188,10 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
             "hhv_hit_path");
       if (h.score > par.smin) {                       // :260-268
         next.push_back(k);
-        if (masks[k].empty()) masks[k].assign((size_t)(q.L + 1) * (L[k] + 1), 0);
-        ExcludeAlignment(masks[k], q.L, L[k], hit.i.data(), hit.j.data(), hit.nsteps);
+        if (prev_off[k].empty()) prev_off[k].push_back(0);
+        prev_i[k].insert(prev_i[k].end(), hit.i.begin() + 1, hit.i.end());   // entries 1..nsteps
+        prev_j[k].insert(prev_j[k].end(), hit.j.begin() + 1, hit.j.end());
+        prev_off[k].push_back((int64_t)prev_i[k].size());
       }
       ret_hits.push_back(std::move(hit));
     }

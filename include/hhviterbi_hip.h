@@ -301,6 +301,15 @@ int hhv_last_kernel_ms(hhv_ctx* ctx, float* ms);
 /* cell-off mask of template k for the next hhv_align with HHV_ALIGN_CELLOFF: mask[(Lq+1)*(L[k]+1)],
  * non-zero = excluded.  NULL clears. */
 int hhv_set_celloff(hhv_ctx* ctx, hhv_tset* ts, int32_t k, const uint8_t* mask);
+/* The masks of a whole alternative-alignment round built on the device (exclude_alignments -> Viterbi::ExcludeAlignment,
+ * src/hhviterbirunner.cpp:152-164,273-289; src/hhviterbi.cpp:61-77): every mask of ts is cleared, then each of the n_paths
+ * earlier alignments (path p belongs to template template_of[p]; steps path_off[p] .. path_off[p+1]-1 of i_steps/j_steps,
+ * i.e. entries 1..nsteps of Hit::i / Hit::j - the last one is skipped like the reference does) switches off its +-40 cross,
+ * and the -excl / -template_excl (lo, hi) ranges are applied.  Replaces one hhv_set_celloff (a (Lq+1)*(Lt+1) byte mask
+ * built and copied by the host) per surviving template. */
+int hhv_set_celloff_paths(hhv_ctx* ctx, hhv_tset* ts, int32_t n_paths, const int32_t* template_of, const int64_t* path_off,
+                          const int32_t* i_steps, const int32_t* j_steps, int32_t n_qranges, const int32_t* qranges,
+                          int32_t n_tranges, const int32_t* tranges);
 /* raw backtrace byte matrix of template k in the reference layout: out[(Lq+1)*(L[k]+1)] */
 int hhv_backtrace_matrix(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint8_t* out);
 
