@@ -1,0 +1,187 @@
+"""The drop-in translation unit hh-suite_amd/dropin/hhviterbirunner_hip.cpp against the reference's own
+src/hhviterbirunner.cpp: both define ViterbiRunner::alignment with the signature of src/hhviterbirunner.h:50-58 and
+are driven by the same harness (oracle/ref_runner_harness.cpp) the way HHblits::run drives them - .hhm texts read by
+the reference's HMM::Read, prepared by the reference's PrepareQueryHMM / PrepareTemplateHMM, std::vector<HHEntry*> in,
+std::vector<Hit> out.  The comparison is on the Hit objects the callers consume.
+
+oracle/_ref/libhhref_dropin.so is built where /root/reference is present and travels to the GPU box prebuilt."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import hhm_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libhhref_dropin.so")
+
+
+class RRHit(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("entry", "irep", "lastrep", "L", "nsteps", "matched_cols", "i1", "j1", "i2",
+                                               "j2", "ssm1", "ssm2", "n_display")] + \
+               [(n, ctypes.c_float) for n in ("score", "score_ss", "score_aass", "Neff_HMM")] + [("name", ctypes.c_char * 64)]
+
+
+def _lib():
+    if not os.path.exists(LIB):
+        pytest.skip("oracle/_ref/libhhref_dropin.so not built (needs /root/reference at build time)")
+    return ctypes.CDLL(LIB)
+
+
+def run(which, query, templates, names, seq_len=None, loc=1, altali=4, ssm=2, early=0, prefilter=0, dbsize=20000,
+        maxres=2000, threads=1, smin=20.0, filter_thresh=0.01, egq=0.0, egt=0.0, ssw=0.11, excl="", texcl="",
+        path_cap=1400):
+    lib = _lib()
+    fn = getattr(lib, "ref_runner_run_" + which)
+    n = len(templates)
+    cap = n * max(1, altali)
+    hits = (RRHit * cap)()
+    pi = np.zeros((cap, path_cap), dtype=np.int32)
+    pj = np.zeros((cap, path_cap), dtype=np.int32)
+    ps = np.zeros((cap, path_cap), dtype=np.int8)
+    pS = np.zeros((cap, path_cap), dtype=np.float32)
+    pSS = np.zeros((cap, path_cap), dtype=np.float32)
+    texts = (ctypes.c_char_p * n)(*templates)
+    lens = (ctypes.c_size_t * n)(*[len(t) for t in templates])
+    nm = (ctypes.c_char_p * n)(*[x.encode() for x in names])
+    if seq_len is None:
+        seq_len = [int(t.split(b"LENG")[1].split()[0]) for t in templates]
+    sl = np.asarray(seq_len, dtype=np.int32)
+    oi = np.asarray([loc, altali, ssm, early, prefilter, dbsize, maxres, threads], dtype=np.int32)
+    of = np.asarray([smin, filter_thresh, egq, egt, ssw], dtype=np.float32)
+    P = ctypes.c_void_p
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, P, P, P, P, P, P, ctypes.c_char_p, ctypes.c_char_p,
+                   ctypes.c_int, P, ctypes.c_int, P, P, P, P, P]
+    m = fn(query, len(query), n, ctypes.cast(texts, P), ctypes.cast(lens, P), ctypes.cast(nm, P), sl.ctypes.data,
+           oi.ctypes.data, of.ctypes.data, excl.encode(), texcl.encode(), cap, ctypes.cast(hits, P), path_cap,
+           pi.ctypes.data, pj.ctypes.data, ps.ctypes.data, pS.ctypes.data, pSS.ctypes.data)
+    assert 0 <= m <= cap, m
+    return [hits[k] for k in range(m)], pi[:m], pj[:m], ps[:m], pS[:m], pSS[:m]
+
+
+def make_db(seed, Lq, n, lo, hi, ss_every=0, query_ss=False, homolog_every=2, same_len_every=0, ss_longest=0):
+    rng = np.random.default_rng(seed)
+    qf = hhm_text.random_columns(seed * 7 + 1, Lq)
+    query = hhm_text.hhm_text("query%d" % seed, qf, seed, ss=hhm_text.random_ss(seed, Lq) if query_ss else None)
+    texts, names = [], []
+    Ls = [int(rng.integers(lo, hi + 1)) for _ in range(n)]
+    if same_len_every:                  # equal lengths: the order std::sort leaves them in matters
+        Ls = [(lo + hi) // 2 if k % same_len_every == 0 else L for k, L in enumerate(Ls)]
+    with_ss = set(np.argsort(-np.asarray(Ls), kind="stable")[:ss_longest].tolist())   # the first SIMD batches
+    for k in range(n):
+        L = Ls[k]
+        if homolog_every and k % homolog_every == 0:
+            start = int(rng.integers(0, max(1, Lq - L + 1)))
+            f = hhm_text.mutate_columns(seed * 1000 + k, qf[start:start + L] if L <= Lq else
+                                        np.concatenate([qf, hhm_text.random_columns(seed + k, L - Lq)]), mut=0.3)
+            if k % (2 * homolog_every) == 0 and L > 60:   # a repeat: second copy of the first half -> alternative alignments
+                f[L // 2:L // 2 + L // 3] = f[:L // 3]
+        else:
+            f = hhm_text.random_columns(seed * 1000 + k, L)
+        ss = hhm_text.random_ss(seed * 31 + k, f.shape[0]) if ((ss_every and k % ss_every == 0) or k in with_ss) else None
+        names.append("t%05d" % k)
+        texts.append(hhm_text.hhm_text(names[-1], f, seed * 1000 + k, ss=ss))
+    return query, texts, names
+
+
+def compare(a, b):
+    ha, hb = a[0], b[0]
+    assert len(ha) == len(hb), (len(ha), len(hb))
+    for k, (x, y) in enumerate(zip(ha, hb)):
+        for f, _ in RRHit._fields_:
+            vx, vy = getattr(x, f), getattr(y, f)
+            assert vx == vy, (k, f, vx, vy, x.name, x.irep)
+        ns = x.nsteps
+        for arr in range(1, 6):
+            assert np.array_equal(a[arr][k][1:ns + 1], b[arr][k][1:ns + 1]), (k, arr, x.name, x.irep)
+    return len(ha)
+
+
+def test_reference_runner_on_hhm_texts():
+    """CPU only: the harness drives the reference's ViterbiRunner on synthetic .hhm texts; homologs score, repeats
+    give alternative alignments, the sort by length holds.  (Validates the test data, not the product.)"""
+    q, t, names = make_db(3, 120, 12, 60, 160)
+    hits, pi, pj, ps, pS, pSS = run("cpu", q, t, names, altali=3)
+    first = [h for h in hits if h.irep == 1]
+    assert len(first) == 12
+    assert [h.L for h in first] == sorted([h.L for h in first], reverse=True)
+    assert max(h.score for h in first) > 40 and min(h.score for h in first) < 20
+    assert any(h.irep > 1 for h in hits)
+    for k, h in enumerate(hits):
+        assert h.i2 == pi[k][1] and h.j2 == pj[k][1] and h.i1 == pi[k][h.nsteps] and h.j1 == pj[k][h.nsteps]
+
+
+def test_library_exports_both_runners():
+    lib = _lib()
+    assert lib.ref_runner_run_cpu and lib.ref_runner_run_hip
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loc,altali,threads", [(1, 4, 1), (1, 1, 3), (1, 2, 2)])
+def test_dropin_equals_reference(loc, altali, threads):
+    q, t, names = make_db(11 + altali, 150, 45, 40, 260, same_len_every=5)
+    ref = run("cpu", q, t, names, loc=loc, altali=altali, threads=1)
+    got = run("hip", q, t, names, loc=loc, altali=altali, threads=threads)
+    n = compare(ref, got)
+    assert n > 45 or altali == 1
+
+
+@pytest.mark.gpu
+def test_dropin_global_equal_lengths():
+    """global mode on templates of ONE length (no batch-composition quirk)"""
+    q, t, names = make_db(5, 100, 24, 80, 80)
+    ref = run("cpu", q, t, names, loc=0, altali=2)
+    got = run("hip", q, t, names, loc=0, altali=2)
+    compare(ref, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ssm", [2, 0, 4])
+def test_dropin_secondary_structure(ssm):
+    """query and some templates carry ss_pred/ss_conf/ss_dssp records: the ss mode is decided per SIMD batch of the
+    sorted block (src/hhviterbirunner.cpp:14-22), so templates WITH records fall into batches without SS scoring"""
+    dbs = [make_db(21, 130, 40, 50, 200, ss_every=1, query_ss=True),     # every batch scores SS
+           make_db(21, 130, 40, 50, 200, ss_every=3, query_ss=True),     # no batch does, although templates carry records
+           make_db(22, 130, 40, 50, 200, ss_longest=20, query_ss=True),  # the first two batches do, the third is mixed
+           make_db(23, 130, 24, 50, 200, ss_every=1, query_ss=False)]    # templates with records, query without
+    with_ss = []
+    for (qq, tt, nn) in dbs:
+        ref = run("cpu", qq, tt, nn, ssm=ssm, altali=2)
+        got = run("hip", qq, tt, nn, ssm=ssm, altali=2)
+        compare(ref, got)
+        with_ss.append(sum(1 for h in ref[0] if h.score_ss != 0))
+    assert with_ss[0] >= 40 and with_ss[1] == 0 and 16 <= with_ss[2] < 40 and with_ss[3] == 0, with_ss
+
+
+@pytest.mark.gpu
+def test_dropin_excluded_regions():
+    q, t, names = make_db(31, 140, 20, 60, 220)
+    ref = run("cpu", q, t, names, altali=2, excl="10-30,100-120", texcl="5-25")
+    got = run("hip", q, t, names, altali=2, excl="10-30,100-120", texcl="5-25")
+    compare(ref, got)
+
+
+@pytest.mark.gpu
+def test_dropin_early_stopping_blocks():
+    """hhblits mode: blocks of 2000 templates in round 0, stop when the block's sum of 1/(1+E) falls under the cutoff
+    (src/hhviterbirunner.cpp:109-111,178-188,213-247).  4300 unrelated short templates after 150 related ones: the
+    reference stops after the second block; the drop-in must stop at the same place and return the same hits."""
+    rng = np.random.default_rng(9)
+    Lq = 90
+    qf = hhm_text.random_columns(77, Lq)
+    q = hhm_text.hhm_text("query", qf, 1)
+    texts, names, seq_len = [], [], []
+    for k in range(4300):
+        L = int(rng.integers(30, 70))
+        f = hhm_text.mutate_columns(k, qf[:L], 0.25) if k < 150 else hhm_text.random_columns(5000 + k, L)
+        names.append("e%05d" % k)
+        texts.append(hhm_text.hhm_text(names[-1], f, k))
+        seq_len.append(L)
+    kw = dict(seq_len=seq_len, altali=2, early=1, prefilter=1, dbsize=4300, filter_thresh=0.01, maxres=400, path_cap=200)
+    ref = run("cpu", q, texts, names, **kw)
+    got = run("hip", q, texts, names, threads=4, **kw)
+    n = compare(ref, got)
+    first = sum(1 for h in ref[0] if h.irep == 1)
+    assert first in (2000, 4000), first   # stopped early, not after all 4300
