@@ -105,6 +105,15 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
   return HHV_OK;
 }
 
+int hhv_set_params(hhv_ctx* c, const hhv_params* par) {
+  if (!c || !par) return fail(HHV_E_ARG, "hhv_set_params: null argument");
+  if (par->device != c->par.device)
+    return fail(HHV_E_ARG, "hhv_set_params: the context lives on device %d, not %d", c->par.device, par->device);
+  c->par = *par;
+  c->ss_dirty = true;  // the premultiplied table carries par.ssw
+  return HHV_OK;
+}
+
 void hhv_destroy(hhv_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->par.device);
@@ -728,6 +737,22 @@ int hhv_hit_path(hhv_ctx* c, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_st
   if (j_steps) j_steps[0] = 0;
   if (states) states[0] = 0;
   if (S) S[0] = 0.0f;
+  return HHV_OK;
+}
+
+int hhv_hit_path_pool(hhv_ctx* c, hhv_tset* ts, const int64_t** path_off, const int32_t** i_steps, const int32_t** j_steps,
+                      const int8_t** states, const float** S) {
+  if (!c || !ts || !path_off || !i_steps || !j_steps || !states || !S) return fail(HHV_E_ARG, "hhv_hit_path_pool: null argument");
+  if (!ts->hits_valid) return fail(HHV_E_STATE, "hhv_hit_path_pool: call hhv_hits first");
+  int32_t ns = 0;
+  const int rc = hhv_hit_path(c, ts, 0, 0, nullptr, nullptr, nullptr, nullptr, &ns);  // mirrors the pool on first use
+  if (rc != HHV_OK) return rc;
+  if (!ts->host_paths_valid) return fail(HHV_E_LIMIT, "hhv_hit_path_pool: the path pool is too large to mirror; use hhv_hit_path");
+  *path_off = ts->path_off.data();
+  *i_steps = ts->h_i_steps.data();
+  *j_steps = ts->h_j_steps.data();
+  *states = ts->h_states.data();
+  *S = ts->h_S.data();
   return HHV_OK;
 }
 

@@ -1,6 +1,8 @@
 // hhv_api_prep.cpp -- C ABI of the on-device PrepareTemplateHMM and the raw template database file.
 #include "hhv_api_common.h"
 
+#include <thread>
+
 using namespace hhv;
 using hhv::api::dfree;
 using hhv::api::fail;
@@ -20,25 +22,36 @@ static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, c
     off += (int64_t)L[k] + 1;
   }
   host->assign((size_t)off * RAW_DW, 0.0f);
-  off = 0;
-  for (int k = 0; k < n; ++k) {
-    for (int i = 0; i <= L[k]; ++i) {
-      float* w = host->data() + (size_t)(off + i) * RAW_DW;
-      memcpy(w + RAW_F, f[k] + (size_t)i * 20, 20 * sizeof(float));
-      memcpy(w + RAW_TR, tr[k] + (size_t)i * 7, 7 * sizeof(float));
-      memcpy(w + RAW_NEFF, neff[k] + (size_t)i * 3, 3 * sizeof(float));
-      int32_t meta = i;
-      if (i >= 1) {
-        const int pr = ss_pred && ss_pred[k] ? (unsigned char)ss_pred[k][i] : 0, cf = ss_conf && ss_conf[k] ? ss_conf[k][i] : 0;
-        const int ds = ss_dssp && ss_dssp[k] ? (unsigned char)ss_dssp[k][i] : 0;
-        meta |= (int32_t)((unsigned char)(pr * 11 + cf) & META_PRED_MASK) << META_PRED_SHIFT;
-        meta |= (int32_t)(ds & META_DSSP_MASK) << META_DSSP_SHIFT;
+  std::vector<int64_t> start((size_t)n + 1, 0);
+  for (int k = 0; k < n; ++k) start[k + 1] = start[k] + (int64_t)L[k] + 1;
+  auto fill = [&](int k0, int k1) {
+    for (int k = k0; k < k1; ++k) {
+      for (int i = 0; i <= L[k]; ++i) {
+        float* w = host->data() + (size_t)(start[k] + i) * RAW_DW;
+        memcpy(w + RAW_F, f[k] + (size_t)i * 20, 20 * sizeof(float));
+        memcpy(w + RAW_TR, tr[k] + (size_t)i * 7, 7 * sizeof(float));
+        memcpy(w + RAW_NEFF, neff[k] + (size_t)i * 3, 3 * sizeof(float));
+        int32_t meta = i;
+        if (i >= 1) {
+          const int pr = ss_pred && ss_pred[k] ? (unsigned char)ss_pred[k][i] : 0, cf = ss_conf && ss_conf[k] ? ss_conf[k][i] : 0;
+          const int ds = ss_dssp && ss_dssp[k] ? (unsigned char)ss_dssp[k][i] : 0;
+          meta |= (int32_t)((unsigned char)(pr * 11 + cf) & META_PRED_MASK) << META_PRED_SHIFT;
+          meta |= (int32_t)(ds & META_DSSP_MASK) << META_DSSP_SHIFT;
+        }
+        memcpy(w + RAW_J, &meta, 4);
+        const int32_t Lk = L[k];
+        memcpy(w + RAW_L, &Lk, 4);
       }
-      memcpy(w + RAW_J, &meta, 4);
-      const int32_t Lk = L[k];
-      memcpy(w + RAW_L, &Lk, 4);
     }
-    off += (int64_t)L[k] + 1;
+  };
+  // a database upload is hundreds of megabytes of strided copies: spread the templates over a few host threads
+  const int nt = (int)std::min<int64_t>(std::min<int64_t>(16, std::max(1u, std::thread::hardware_concurrency())), off / 65536 + 1);
+  if (nt <= 1) {
+    fill(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(fill, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
+    for (auto& th : pool) th.join();
   }
   return HHV_OK;
 }

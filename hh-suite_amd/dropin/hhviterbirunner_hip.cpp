@@ -5,10 +5,9 @@
 // (HHblits::run x3, RescoreWithViterbiKeepAlignment, HHalign::run) keeps calling
 //     ViterbiRunner::alignment(par, q_simd, dbfiles, qsc, pb, S, Sim, R, ssm_mode, S73, S33, S37)
 // and receives the same std::vector<Hit> (same fields, same ownership: the path arrays are new[]'d here and freed
-// by Hit::Delete).  The host part the reference runs per template - HHEntry::getTemplateHMM + PrepareTemplateHMM
-// (src/hhviterbirunner.cpp:144-147) - is still the reference's own code, called from here under OpenMP; what
-// moves to the GPU is everything behind Viterbi::Align / Backtrace / ScoreForBacktrace (:24-31) and the
-// exclusion masks (:152-164), through the C ABI of include/hhviterbi_hip.h.  No DP arithmetic in this file.
+// by Hit::Delete).  What moves to the GPU is everything behind Viterbi::Align / Backtrace / ScoreForBacktrace
+// (src/hhviterbirunner.cpp:24-31), the exclusion masks (:152-164) and - for templates in HHM format - PrepareTemplateHMM
+// (:147), through the C ABI of include/hhviterbi_hip.h.  No DP arithmetic in this file.
 //
 // What is kept from the reference's control flow (src/hhviterbirunner.cpp:75-210):
 //   * alternative-alignment rounds 0..par.altali-1, work list of round r+1 = entries of the hits with
@@ -19,19 +18,37 @@
 //     (consensus of HMM::computeScoreSSMode over the batch, then the selection chain of :14-22)
 //   * exclusion of earlier alignments keyed by the template NAME (:262-268,273-289), -excl / -template_excl (:157-164)
 //   * Hit fields of ViterbiConsumerThread::align (:35-62)
-// Differences, by design:
-//   * a template is read and prepared ONCE; it stays resident on the device for the later rounds (the reference
-//     reads and prepares it again in every round), and the Hit of a later round copies the template information of
-//     its first-round Hit instead of calling initHitFromHMM on a freshly read HMM
+//
+// THE RESIDENT TEMPLATE CACHE.  In the reference more than half of the wall time of this function is
+// HHEntry::getTemplateHMM (text parsing) + PrepareTemplateHMM per template per query, and it does not shrink with the
+// DP.  Here a template that was read once stays on the device in RAW form (what HMM::Read leaves: frequencies,
+// log2 transitions, Neff) for the life of the process, keyed by entry name + sequence length; PrepareTemplateHMM runs
+// on the GPU per query (hhv_prepare_subset, bit-identical to the host code: tests/test_prepare.py) because its
+// result depends on the query's composition.  From the second time a template is searched - the later iterations of
+// hhblits, the next query of hhblits_omp / hhblits_mpi - nothing of it is parsed, prepared or copied by the host;
+// its Hit gets the template information (names, displayed sequences) from a prototype kept with the cache entry.
+// Templates the device preparation does not cover (HMMER formats, par.pc_hhm_nocontext_mode > 2 or pcc != 1,
+// par.columnscore > 3, a NULL line different from the caller's background) are prepared by the reference's host code
+// as before and uploaded prepared; they are not cached.  Environment: HHV_TEMPLATE_CACHE=0 disables the cache,
+// HHV_TEMPLATE_CACHE_GB (default 64) bounds it (it is emptied when full), HHV_DEVICE picks the GPU (default 0).
+// The cache and its device context are shared by all threads of the process; device work of concurrent callers
+// (hhblits_omp) is serialised by a mutex, the host-side reading of new templates is not.
+//
+// Differences from the reference, by design:
+//   * a template is read ONCE per process; the Hit of a later round / later search copies the template information of
+//     the prototype instead of calling initHitFromHMM on a freshly read HMM
 //   * hits come back in the order of the sorted block (= the reference's order with one thread; with several
 //     threads the reference's order depends on the OpenMP schedule)
 //   * global mode (par.loc = 0): every template is maximised over its OWN last column; the reference maximises over
 //     the last column of the longest template of the SIMD batch (SURVEY.md 8a, row A1 "batch-composition quirk"),
 //     so results differ for the shorter templates of mixed-length batches.  Local mode (the default) is unaffected.
-//   * the device is chosen with the environment variable HHV_DEVICE (default 0)
 // Errors follow the reference's convention at this layer: HH_LOG(ERROR) + exit(code) (src/hhsearch.h:6).
+#include <sys/time.h>
+
 #include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "hhviterbirunner.h"
@@ -43,58 +60,151 @@
 
 namespace {
 
+// HHV_DROPIN_TIMING=1 prints where alignment() spends its wall time (stderr)
+struct PhaseTimer {
+  enum { READ, UPLOAD, PREPARE, MASKS, ALIGN, PATHS, OTHER, N };
+  bool on;
+  double t_last;
+  double acc[N];
+  size_t cached, fresh, host_prepared;
+  PhaseTimer() : on(getenv("HHV_DROPIN_TIMING") != NULL), t_last(now()), cached(0), fresh(0), host_prepared(0) {
+    for (int k = 0; k < N; ++k) acc[k] = 0;
+  }
+  static double now() {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return tv.tv_sec + 1e-6 * tv.tv_usec;
+  }
+  void lap(int phase) {
+    const double t = now();
+    acc[phase] += t - t_last;
+    t_last = t;
+  }
+  ~PhaseTimer() {
+    if (on)
+      fprintf(stderr, "hhviterbirunner_hip: templates %zu cached + %zu read (+ %zu host-prepared); read %.3f s, upload %.3f s, "
+              "device prepare %.3f s, masks %.3f s, align+hits %.3f s, paths+Hit %.3f s, other %.3f s\n",
+              cached, fresh, host_prepared, acc[READ], acc[UPLOAD], acc[PREPARE], acc[MASKS], acc[ALIGN], acc[PATHS], acc[OTHER]);
+  }
+};
+
 void hip_check(int rc, const char* what) {
   if (rc == HHV_OK) return;
   HH_LOG(ERROR) << "hhviterbi_hip: " << what << " failed: " << hhv_last_error() << std::endl;
   exit(rc == HHV_E_MEMORY ? 3 : 4);
 }
 
-// a template of the search: resident on the device after its first alignment
-struct ResidentTemplate {
-  hhv_tset* set;       // the chunk it was uploaded with
-  int32_t index;       // its index inside that set
-  int L;
-  int ss_pair_mode;    // HMM::computeScoreSSMode(q, t)
-  size_t first_hit;    // index of its first-round Hit in the result vector (source of the template information)
-  std::vector<int8_t> ss_pred, ss_conf, ss_dssp;  // [L+1], empty when the template has no such record
+// secondary-structure records of a template, [L+1] each, empty when the template has none
+struct SsRecords {
+  std::vector<int8_t> pred, conf, dssp;
 };
 
-// host copy of one prepared template on its way to the device
-struct Prepared {
-  std::vector<float> p, tr;
-  std::vector<int8_t> ss_pred, ss_conf, ss_dssp;
+// host copy of one template on its way to the device: prepared (p, tr) or raw (f, tr, neff)
+struct HostTemplate {
+  bool raw;
+  int L;
+  std::vector<float> p;     // prepared: [(L+1)*20]; raw: f [(L+2)*20]
+  std::vector<float> tr;    // [(L+1)*7], enum order of src/hhdecl.h:68
+  std::vector<float> neff;  // raw only: [(L+1)*3] Neff_M, Neff_I, Neff_D
+  float neff_hmm;
+  SsRecords ss;
+  int ss_pair_mode;  // HMM::computeScoreSSMode(q, t)
+};
+
+// A template of the process-wide cache: raw columns on the device + what a Hit needs to know about the template
+struct CachedTemplate {
+  hhv_rawset* raw;
+  int32_t index;
+  int L;
+  int ss_pair_mode;
+  Hit proto;  // initHitFromHMM(q, t, nseqdis, ssm); its arrays live as long as the cache entry
+  SsRecords ss;
+  CachedTemplate() : raw(NULL), index(0), L(0), ss_pair_mode(0) {}
+};
+
+struct TemplateCache {
+  std::mutex device;  // one caller at a time on the shared context
+  hhv_ctx* ctx;
+  int device_id;
+  unsigned long owner;  // alignment() call whose query is currently installed in ctx
+  unsigned long calls;
+  int active;  // searches currently using cache entries
+  bool enabled;
+  size_t max_columns, columns;
+  std::vector<hhv_rawset*> rawsets;
+  std::unordered_map<std::string, CachedTemplate> map;
+  // what the prototypes depend on besides the template (src/hhhit.cpp:255-256,289-320)
+  int nseqdis, ssm, q_has_pred, q_has_dssp;
+  TemplateCache() : ctx(NULL), device_id(0), owner(0), calls(0), active(0), enabled(true), max_columns(0), columns(0), nseqdis(-1),
+                    ssm(-1), q_has_pred(-1), q_has_dssp(-1) {
+    const char* e = getenv("HHV_TEMPLATE_CACHE");
+    enabled = !(e && atoi(e) == 0);
+    const char* g = getenv("HHV_TEMPLATE_CACHE_GB");
+    const double gb = g ? atof(g) : 64.0;
+    max_columns = (size_t)(gb * 1e9 / 128.0);  // 32 dwords per raw column
+    const char* d = getenv("HHV_DEVICE");
+    device_id = d ? atoi(d) : 0;
+  }
+  void clear() {  // device lock held
+    for (std::unordered_map<std::string, CachedTemplate>::iterator it = map.begin(); it != map.end(); ++it) it->second.proto.Delete();
+    map.clear();
+    for (size_t k = 0; k < rawsets.size(); ++k) hhv_rawset_free(rawsets[k]);
+    rawsets.clear();
+    columns = 0;
+  }
+};
+
+TemplateCache& cache() {
+  static TemplateCache c;
+  return c;
+}
+
+std::string cache_key(HHEntry* e) {
+  char len[32];
+  snprintf(len, sizeof(len), "\n%d", e->sequence_length);
+  return std::string(e->getName()) + len;
+}
+
+// a template of THIS search: where its prepared columns are on the device
+struct ResidentTemplate {
+  hhv_tset* set;
+  int32_t index;
+  int L;
+  int ss_pair_mode;
+  size_t first_hit;     // index of its first-round Hit in the result vector (source of the template information)
+  const SsRecords* ss;  // in the cache entry or in `own_ss`
 };
 
 const int kCacheToEnum[7] = {4 /*I2I*/, 1 /*M2I*/, 0 /*M2M*/, 2 /*M2D*/, 5 /*D2M*/, 6 /*D2D*/, 3 /*I2M*/};
 
-// Lane 0 of an HMMSimd that holds ONE HMM (HMMSimd::MapHMMVector, src/hhhmmsimd.cpp:86-160) -> the prepared-profile
-// layout of the C ABI: p[(L+1)*20], tr[(L+1)*7] in the enum order of src/hhdecl.h:68.  HMM::tr and the ss arrays
-// are private to HMM; HMMSimd is its friend and publishes them, which is how the reference's kernel sees them too.
-void lane0_to_profile(const HMMSimd* s, const HMM* h, Prepared* out) {
+// Lane 0 of an HMMSimd that holds ONE HMM (HMMSimd::MapHMMVector, src/hhhmmsimd.cpp:86-160) -> the profile layout
+// of the C ABI: p[(L+1)*20], tr[(L+1)*7] in the enum order of src/hhdecl.h:68.  HMM::tr and the ss arrays are
+// private to HMM; HMMSimd is its friend and publishes them, which is how the reference's kernel sees them too.
+void lane0_to_profile(const HMMSimd* s, const HMM* h, std::vector<float>* p, std::vector<float>* tr, SsRecords* ss) {
   const int L = h->L;
-  out->p.resize((size_t)(L + 1) * 20);
-  out->tr.resize((size_t)(L + 1) * 7);
+  p->resize((size_t)(L + 1) * 20);
+  tr->resize((size_t)(L + 1) * 7);
   const float* tr_scalar = (const float*)s->tr;
   for (int i = 0; i <= L; ++i) {
-    for (int a = 0; a < 20; ++a) out->p[(size_t)i * 20 + a] = s->p[i][a * VECSIZE_FLOAT];
-    for (int c = 0; c < 7; ++c) out->tr[(size_t)i * 7 + kCacheToEnum[c]] = tr_scalar[((size_t)i * 7 + c) * VECSIZE_FLOAT];
+    for (int a = 0; a < 20; ++a) (*p)[(size_t)i * 20 + a] = s->p[i][a * VECSIZE_FLOAT];
+    for (int c = 0; c < 7; ++c) (*tr)[(size_t)i * 7 + kCacheToEnum[c]] = tr_scalar[((size_t)i * 7 + c) * VECSIZE_FLOAT];
   }
-  for (int a = 0; a < 20; ++a) out->p[a] = 0.0f;  // row 0 is never read by the DP
-  out->ss_pred.clear();
-  out->ss_conf.clear();
-  out->ss_dssp.clear();
+  for (int a = 0; a < 20; ++a) (*p)[a] = 0.0f;  // row 0 is never read by the DP
+  ss->pred.clear();
+  ss->conf.clear();
+  ss->dssp.clear();
   if (h->nss_pred >= 0) {  // pred_index = ss_pred * MAXCF + ss_conf (:133)
-    out->ss_pred.assign(L + 1, 0);
-    out->ss_conf.assign(L + 1, 0);
+    ss->pred.assign(L + 1, 0);
+    ss->conf.assign(L + 1, 0);
     for (int i = 1; i <= L; ++i) {
       const unsigned v = s->pred_index[(size_t)(i - 1) * VECSIZE_FLOAT];
-      out->ss_pred[i] = (int8_t)(v / MAXCF);
-      out->ss_conf[i] = (int8_t)(v % MAXCF);
+      ss->pred[i] = (int8_t)(v / MAXCF);
+      ss->conf[i] = (int8_t)(v % MAXCF);
     }
   }
   if (h->nss_dssp >= 0) {
-    out->ss_dssp.assign(L + 1, 0);
-    for (int i = 1; i <= L; ++i) out->ss_dssp[i] = (int8_t)s->dssp_index[(size_t)(i - 1) * VECSIZE_FLOAT];
+    ss->dssp.assign(L + 1, 0);
+    for (int i = 1; i <= L; ++i) ss->dssp[i] = (int8_t)s->dssp_index[(size_t)(i - 1) * VECSIZE_FLOAT];
   }
 }
 
@@ -121,8 +231,8 @@ std::vector<int32_t> region_pairs(char* exclstr) {
   return out;
 }
 
-// A Hit for a later round of a template whose information the first-round Hit already carries: every owned
-// array is duplicated (Hit::Delete frees them per Hit, src/hhhit.cpp:38-62)
+// A Hit of a template whose information another Hit already carries: every owned array is duplicated
+// (Hit::Delete frees them per Hit, src/hhhit.cpp:38-62)
 void copy_template_info(const Hit& src, Hit* dst) {
   *dst = src;
   dst->longname = new char[strlen(src.longname) + 1];
@@ -152,22 +262,182 @@ struct SsTables {
 };
 
 // Viterbi::ScoreSS (src/hhviterbi.h:193-211) for one aligned column pair, from the index arrays
-float score_ss_step(const SsTables& T, float ssw, int mode, const HMMSimd* q_simd, int i, const ResidentTemplate& t,
-                    int j) {
+float score_ss_step(const SsTables& T, float ssw, int mode, const HMMSimd* q_simd, int i, const SsRecords& t, int j) {
   const unsigned qp = q_simd->pred_index[(size_t)(i - 1) * VECSIZE_FLOAT];
   const unsigned qd = q_simd->dssp_index[(size_t)(i - 1) * VECSIZE_FLOAT];
   switch (mode) {
     case HMM::PRED_DSSP:
-      return ssw * T.S37[qp / MAXCF][qp % MAXCF][(int)t.ss_dssp[j]];
+      return ssw * T.S37[qp / MAXCF][qp % MAXCF][(int)t.dssp[j]];
     case HMM::DSSP_PRED:
-      return ssw * T.S73[qd][(int)t.ss_pred[j]][(int)t.ss_conf[j]];
+      return ssw * T.S73[qd][(int)t.pred[j]][(int)t.conf[j]];
     case HMM::PRED_PRED:
-      return ssw * T.S33[qp / MAXCF][qp % MAXCF][(int)t.ss_pred[j]][(int)t.ss_conf[j]];
+      return ssw * T.S33[qp / MAXCF][qp % MAXCF][(int)t.pred[j]][(int)t.conf[j]];
   }
   return 0.0;
 }
 
+// One search = one object: the caller's arguments, the query as the device wants it, and the device sections.
+struct Search {
+  Parameters& par;
+  HMMSimd* q_simd;
+  HMM* q;
+  const int ssm_mode;
+  const SsTables tables;
+  TemplateCache& tc;
+  unsigned long id;
+  int threads;
+  PhaseTimer timer;
+  std::vector<float> q_p, q_tr;
+  SsRecords q_ss;
+  std::vector<int32_t> q_ranges, t_ranges;
+  bool regions;
+  std::vector<Hit> ret_hits;
+  std::map<std::string, std::vector<size_t> > excludeAlignments;  // earlier alignments per template name (:262-268)
+
+  Search(Parameters& par, HMMSimd* q_simd, int ssm_mode, const SsTables& tables)
+      : par(par), q_simd(q_simd), q(q_simd->GetHMM(0)), ssm_mode(ssm_mode), tables(tables), tc(cache()), id(0), threads(1), regions(false) {
+    lane0_to_profile(q_simd, q, &q_p, &q_tr, &q_ss);
+    q_ranges = region_pairs(par.exclstr);
+    t_ranges = region_pairs(par.template_exclstr);
+    regions = !q_ranges.empty() || !t_ranges.empty();
+  }
+
+  // Enter a device section (tc.device is held by the caller): the shared context gets this search's parameters and
+  // query unless it still has them from the previous section.
+  void install() {
+    if (!tc.ctx) {
+      hhv_params hp;
+      memset(&hp, 0, sizeof(hp));
+      hp.device = tc.device_id;
+      hp.local = 1;
+      hip_check(hhv_create(&tc.ctx, &hp), "hhv_create");
+    }
+    if (id == 0) id = ++tc.calls;
+    if (tc.owner == id) return;
+    hhv_params hp;
+    hp.device = tc.device_id;
+    hp.local = par.loc;
+    hp.egq = par.egq;
+    hp.egt = par.egt;
+    hp.shift = par.shift;
+    hp.corr = par.corr;
+    hp.ssw = par.ssw;
+    hp.ss_mode = ssm_mode;  // the ss_mode argument of the Viterbi constructor (src/hhviterbirunner.h:32-33)
+    hip_check(hhv_set_params(tc.ctx, &hp), "hhv_set_params");
+    hip_check(hhv_set_query(tc.ctx, q_p.data(), q_tr.data(), q->L), "hhv_set_query");
+    hip_check(hhv_set_ss_tables(tc.ctx, &tables.S73[0][0][0], &tables.S33[0][0][0][0], &tables.S37[0][0][0]), "hhv_set_ss_tables");
+    hip_check(hhv_set_query_ss(tc.ctx, q_ss.pred.empty() ? NULL : q_ss.pred.data(), q_ss.conf.empty() ? NULL : q_ss.conf.data(),
+                               q_ss.dssp.empty() ? NULL : q_ss.dssp.data()),
+              "hhv_set_query_ss");
+    tc.owner = id;
+  }
+
+  // Aligns n templates of one resident set with one ss mode (device section).  ids: their indices in the set (NULL =
+  // the whole set in set order); tmpl[k] / out[k]: resident record and Hit (template information already set) of the k-th.
+  void run(hhv_tset* set, const int32_t* ids, int n, int ss_hmm_mode, const std::vector<const ResidentTemplate*>& tmpl,
+           const std::vector<Hit*>& out) {
+    hhv_ctx* ctx = tc.ctx;
+    hhv_tset* ts = set;
+    hhv_tset* sub = NULL;
+    timer.lap(PhaseTimer::OTHER);
+    if (ids) {
+      hip_check(hhv_tset_gather(ctx, set, ids, n, &sub), "hhv_tset_gather");
+      ts = sub;
+    }
+    hip_check(hhv_set_ss_mode(ctx, ss_hmm_mode), "hhv_set_ss_mode");
+    bool masked = regions;
+    if (!excludeAlignments.empty() || regions) {
+      // exclude_alignments (:273-289): every earlier alignment of a template of the same name (also inside round
+      // 0: the map is filled block by block, :173)
+      std::vector<int32_t> template_of, pi, pj;
+      std::vector<int64_t> poff(1, 0);
+      for (int k = 0; k < n && !excludeAlignments.empty(); ++k) {
+        std::map<std::string, std::vector<size_t> >::const_iterator it = excludeAlignments.find(std::string(out[k]->entry->getName()));
+        if (it == excludeAlignments.end()) continue;
+        for (size_t a = 0; a < it->second.size(); ++a) {
+          const Hit& h = ret_hits[it->second[a]];
+          template_of.push_back(k);
+          pi.insert(pi.end(), h.i + 1, h.i + h.nsteps + 1);
+          pj.insert(pj.end(), h.j + 1, h.j + h.nsteps + 1);
+          poff.push_back((int64_t)pi.size());
+          masked = true;
+        }
+      }
+      hip_check(hhv_set_celloff_paths(ctx, ts, (int32_t)template_of.size(), template_of.data(), poff.data(), pi.data(), pj.data(),
+                                      (int32_t)q_ranges.size() / 2, q_ranges.data(), (int32_t)t_ranges.size() / 2,
+                                      t_ranges.data()),
+                "hhv_set_celloff_paths");
+    }
+    std::vector<hhv_hit> hits(n);
+    timer.lap(PhaseTimer::MASKS);
+    hip_check(hhv_align(ctx, ts, masked ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, NULL), "hhv_align");
+    hip_check(hhv_hits(ctx, ts, hits.data()), "hhv_hits");
+    timer.lap(PhaseTimer::ALIGN);
+    // the path pool in one piece (host mirror of the set); the Hit objects are filled by all threads
+    const int64_t* path_off = NULL;
+    const int32_t *pool_i = NULL, *pool_j = NULL;
+    const int8_t* pool_states = NULL;
+    const float* pool_S = NULL;
+    const bool pooled = hhv_hit_path_pool(ctx, ts, &path_off, &pool_i, &pool_j, &pool_states, &pool_S) == HHV_OK;
+#pragma omp parallel for schedule(static) num_threads(threads) if (pooled && n > 256)
+    for (int k = 0; k < n; ++k) {
+      const hhv_hit& h = hits[k];
+      Hit& hit = *out[k];
+      hit.lastrep = (h.score <= par.smin) ? 1 : 0;  // :37
+      hit.realign_around_viterbi = false;
+      hit.score = h.score;
+      hit.score_ss = h.score_ss;
+      hit.score_aass = -h.score;  // BacktraceScore.score_aass, src/hhviterbi.cpp:252
+      const int cap = h.nsteps + 1;
+      hit.i = new int[cap];
+      hit.j = new int[cap];
+      hit.states = new char[cap];
+      hit.S = new float[cap];
+      hit.S_ss = new float[cap];
+      if (pooled) {
+        const int64_t po = path_off[k];
+        memcpy(hit.i, pool_i + po, (size_t)cap * sizeof(int));
+        memcpy(hit.j, pool_j + po, (size_t)cap * sizeof(int));
+        memcpy(hit.states, pool_states + po, (size_t)cap);
+        memcpy(hit.S, pool_S + po, (size_t)cap * sizeof(float));
+      } else {
+        int32_t ns = 0;
+        hip_check(hhv_hit_path(ctx, ts, k, cap, hit.i, hit.j, (int8_t*)hit.states, hit.S, &ns), "hhv_hit_path");
+      }
+      hit.i[0] = hit.j[0] = 0;
+      hit.states[0] = 0;
+      hit.S[0] = hit.S_ss[0] = 0.0f;
+      for (int step = 1; step <= h.nsteps; ++step)  // BacktraceScore.S_ss, src/hhviterbi.cpp:222-237
+        hit.S_ss[step] = (hit.states[step] == ViterbiMatrix::MM && ss_hmm_mode != HMM::NO_SS_INFORMATION)
+                             ? score_ss_step(tables, par.ssw, ss_hmm_mode, q_simd, hit.i[step], *tmpl[k]->ss, hit.j[step])
+                             : 0.0f;
+      hit.nsteps = h.nsteps;
+      hit.matched_cols = h.matched_cols;
+      hit.i1 = h.i1;
+      hit.j1 = h.j1;
+      hit.i2 = h.i2;
+      hit.j2 = h.j2;
+    }
+    if (sub) hhv_tset_free(sub);
+    timer.lap(PhaseTimer::PATHS);
+  }
+};
+
 }  // namespace
+
+// Housekeeping for the embedding program (optional): empty the resident template cache (e.g. after the database files
+// were rebuilt) and look at its size.  Safe to call between searches; a running search keeps the cache alive.
+extern "C" void hhviterbirunner_hip_cache_clear() {
+  TemplateCache& tc = cache();
+  std::lock_guard<std::mutex> lock(tc.device);
+  if (tc.active == 0) tc.clear();
+}
+extern "C" void hhviterbirunner_hip_cache_stats(size_t* templates, size_t* columns) {
+  TemplateCache& tc = cache();
+  std::lock_guard<std::mutex> lock(tc.device);
+  if (templates) *templates = tc.map.size();
+  if (columns) *columns = tc.columns;
+}
 
 std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std::vector<HHEntry*> dbfiles,
                                           const float qsc, float* pb, const float S[20][20], const float Sim[20][20],
@@ -175,133 +445,66 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                                           const float S73[NDSSP][NSSPRED][MAXCF],
                                           const float S33[NSSPRED][MAXCF][NSSPRED][MAXCF],
                                           const float S37[NSSPRED][MAXCF][NDSSP]) {
-  HMM* q = q_simd->GetHMM(0);
-  const int threads = thread_count > 0 ? thread_count : 1;
-
-  // ---- device context = the per-thread Viterbi objects of the reference (src/hhviterbirunner.h:21-34) ----
-  hhv_params hp;
-  const char* dev = getenv("HHV_DEVICE");
-  hp.device = dev ? atoi(dev) : 0;
-  hp.local = par.loc;
-  hp.egq = par.egq;
-  hp.egt = par.egt;
-  hp.shift = par.shift;
-  hp.corr = par.corr;
-  hp.ssw = par.ssw;
-  hp.ss_mode = ssm_mode;
-  hhv_ctx* ctx = NULL;
-  hip_check(hhv_create(&ctx, &hp), "hhv_create");
-  {
-    Prepared qp;
-    lane0_to_profile(q_simd, q, &qp);
-    hip_check(hhv_set_query(ctx, qp.p.data(), qp.tr.data(), q->L), "hhv_set_query");
-    hip_check(hhv_set_ss_tables(ctx, &S73[0][0][0], &S33[0][0][0][0], &S37[0][0][0]), "hhv_set_ss_tables");
-    if (!qp.ss_pred.empty() || !qp.ss_dssp.empty())
-      hip_check(hhv_set_query_ss(ctx, qp.ss_pred.empty() ? NULL : qp.ss_pred.data(),
-                                 qp.ss_conf.empty() ? NULL : qp.ss_conf.data(),
-                                 qp.ss_dssp.empty() ? NULL : qp.ss_dssp.data()),
-                "hhv_set_query_ss");
-  }
   const SsTables tables = {S73, S33, S37};
-  std::vector<int32_t> q_ranges = region_pairs(par.exclstr), t_ranges = region_pairs(par.template_exclstr);
-  const bool regions = !q_ranges.empty() || !t_ranges.empty();
+  Search search(par, q_simd, ssm_mode, tables);
+  HMM* q = search.q;
+  TemplateCache& tc = search.tc;
+  PhaseTimer& timer = search.timer;
+  std::vector<Hit>& ret_hits = search.ret_hits;
+  const int threads = thread_count > 0 ? thread_count : 1;
+  search.threads = threads;
 
-  // scratch HMMs, one per thread (the reference keeps VECSIZE_FLOAT per thread, :84-95)
-  std::vector<HMM*> t_hmm(threads);
-  std::vector<HMMSimd*> t_simd(threads);
-  for (int k = 0; k < threads; ++k) {
-    t_hmm[k] = new HMM(MAXSEQDIS, par.maxres);
-    t_simd[k] = new HMMSimd(par.maxres);
-  }
+  // Can PrepareTemplateHMM run on the device for this search?  (hhv_prepare_subset: HHM format, substitution-matrix
+  // pseudocounts pcm 0..2 with pcc = 1, null model columnscore 0..3; src/hhfunc.cpp:165-202)
+  bool device_prepare = tc.enabled && par.pc_hhm_nocontext_mode >= 0 && par.pc_hhm_nocontext_mode <= 2 &&
+                              !(par.pc_hhm_nocontext_mode == 2 && par.pc_hhm_nocontext_c != 1.0f) && par.columnscore >= 0 &&
+                              par.columnscore <= 3;
+  hhv_prep_params prep;
+  memset(&prep, 0, sizeof(prep));
+  prep.gapd = par.gapd;
+  prep.gape = par.gape;
+  prep.gapf = par.gapf;
+  prep.gapg = par.gapg;
+  prep.gaph = par.gaph;
+  prep.gapi = par.gapi;
+  prep.gapb = par.gapb;
+  prep.pcm = par.pc_hhm_nocontext_mode;
+  prep.pca = par.pc_hhm_nocontext_a;
+  prep.pcb = par.pc_hhm_nocontext_b;
+  prep.pcc = par.pc_hhm_nocontext_c;
+  prep.columnscore = par.columnscore;
+  float pb0[20];  // the background the caller hands in; HMM::Read overwrites pb with the NULL line of every file it reads
+  memcpy(pb0, pb, sizeof(pb0));
+  memcpy(prep.pb, pb0, sizeof(pb0));
+  for (int a = 0; a < 20; ++a)
+    for (int b = 0; b < 20; ++b) prep.R[a * 20 + b] = R[a][b];
 
-  std::vector<Hit> ret_hits;
-  std::vector<hhv_tset*> resident_sets;
-  std::map<HHEntry*, ResidentTemplate> resident;
-  // earlier alignments per template name: indices into ret_hits (the reference keeps borrowed pointers, :262-268)
-  std::map<std::string, std::vector<size_t> > excludeAlignments;
+  // scratch HMMs, one per thread (the reference keeps VECSIZE_FLOAT per thread, :84-95), allocated when a template
+  // has to be read
+  std::vector<HMM*> t_hmm(threads, (HMM*)NULL);
+  std::vector<HMMSimd*> t_simd(threads, (HMMSimd*)NULL);
+
+  std::vector<hhv_tset*> search_sets;              // prepared sets of this search, freed at the end
+  std::map<HHEntry*, ResidentTemplate> resident;   // an entry listed twice is the same template
+  std::vector<SsRecords*> own_ss;                  // ss records of host-prepared templates
   std::vector<HHEntry*> work(dbfiles.begin(), dbfiles.end());
 
-  // Aligns `members` (positions into `block`, all resident) with one ss mode and appends nothing: fills slot[pos].
-  struct Runner {
-    hhv_ctx* ctx;
-    Parameters& par;
-    HMMSimd* q_simd;
-    const SsTables& tables;
-    const std::vector<int32_t>&q_ranges, &t_ranges;
-    bool regions;
-    std::map<std::string, std::vector<size_t> >& excl;
-    std::vector<Hit>& ret_hits;
-
-    // set: resident chunk; ids: template indices inside it (NULL = the whole set, n templates in set order);
-    // tmpl[k]: the resident record of the k-th aligned template; out[k]: its Hit (template information already set)
-    void run(hhv_tset* set, const int32_t* ids, int n, int ss_hmm_mode,
-             const std::vector<const ResidentTemplate*>& tmpl, const std::vector<Hit*>& out) {
-      hhv_tset* ts = set;
-      hhv_tset* sub = NULL;
-      if (ids) {
-        hip_check(hhv_tset_gather(ctx, set, ids, n, &sub), "hhv_tset_gather");
-        ts = sub;
+  if (device_prepare) {  // the prototypes of the cache are valid for one (nseqdis, ssm, query ss presence) only
+    std::lock_guard<std::mutex> lock(tc.device);
+    const int qp = q->nss_pred >= 0, qd = q->nss_dssp >= 0;
+    if (tc.nseqdis != par.nseqdis || tc.ssm != par.ssm || tc.q_has_pred != qp || tc.q_has_dssp != qd) {
+      if (tc.active == 0) {
+        tc.clear();
+        tc.nseqdis = par.nseqdis;
+        tc.ssm = par.ssm;
+        tc.q_has_pred = qp;
+        tc.q_has_dssp = qd;
+      } else {
+        device_prepare = false;  // a concurrent search of another kind is using the cache: this one prepares on the host
       }
-      hip_check(hhv_set_ss_mode(ctx, ss_hmm_mode), "hhv_set_ss_mode");
-      bool masked = regions;
-      if (!excl.empty() || regions) {
-        // exclude_alignments (:273-289): every earlier alignment of a template of the same name (also inside round
-        // 0: the map is filled block by block, :173)
-        std::vector<int32_t> template_of, pi, pj;
-        std::vector<int64_t> poff(1, 0);
-        for (int k = 0; k < n; ++k) {
-          std::map<std::string, std::vector<size_t> >::const_iterator it = excl.find(std::string(out[k]->entry->getName()));
-          if (it == excl.end()) continue;
-          for (size_t a = 0; a < it->second.size(); ++a) {
-            const Hit& h = ret_hits[it->second[a]];
-            template_of.push_back(k);
-            pi.insert(pi.end(), h.i + 1, h.i + h.nsteps + 1);
-            pj.insert(pj.end(), h.j + 1, h.j + h.nsteps + 1);
-            poff.push_back((int64_t)pi.size());
-            masked = true;
-          }
-        }
-        hip_check(hhv_set_celloff_paths(ctx, ts, (int32_t)template_of.size(), template_of.data(), poff.data(), pi.data(),
-                                        pj.data(), (int32_t)q_ranges.size() / 2, q_ranges.data(),
-                                        (int32_t)t_ranges.size() / 2, t_ranges.data()),
-                  "hhv_set_celloff_paths");
-      }
-      std::vector<hhv_hit> hits(n);
-      hip_check(hhv_align(ctx, ts, masked ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, NULL), "hhv_align");
-      hip_check(hhv_hits(ctx, ts, hits.data()), "hhv_hits");
-      for (int k = 0; k < n; ++k) {
-        const hhv_hit& h = hits[k];
-        Hit& hit = *out[k];
-        hit.lastrep = (h.score <= par.smin) ? 1 : 0;  // :37
-        hit.realign_around_viterbi = false;
-        hit.score = h.score;
-        hit.score_ss = h.score_ss;
-        hit.score_aass = -h.score;  // BacktraceScore.score_aass, src/hhviterbi.cpp:252
-        const int cap = h.nsteps + 1;
-        hit.i = new int[cap];
-        hit.j = new int[cap];
-        hit.states = new char[cap];
-        hit.S = new float[cap];
-        hit.S_ss = new float[cap];
-        int32_t ns = 0;
-        hip_check(hhv_hit_path(ctx, ts, k, cap, hit.i, hit.j, (int8_t*)hit.states, hit.S, &ns), "hhv_hit_path");
-        hit.i[0] = hit.j[0] = 0;
-        hit.states[0] = 0;
-        hit.S[0] = hit.S_ss[0] = 0.0f;
-        for (int step = 1; step <= h.nsteps; ++step)  // BacktraceScore.S_ss, src/hhviterbi.cpp:222-237
-          hit.S_ss[step] = (hit.states[step] == ViterbiMatrix::MM && ss_hmm_mode != HMM::NO_SS_INFORMATION)
-                               ? score_ss_step(tables, par.ssw, ss_hmm_mode, q_simd, hit.i[step], *tmpl[k], hit.j[step])
-                               : 0.0f;
-        hit.nsteps = h.nsteps;
-        hit.matched_cols = h.matched_cols;
-        hit.i1 = h.i1;
-        hit.j1 = h.j1;
-        hit.i2 = h.i2;
-        hit.j2 = h.j2;
-      }
-      if (sub) hhv_tset_free(sub);
     }
-  } runner = {ctx, par, q_simd, tables, q_ranges, t_ranges, regions, excludeAlignments, ret_hits};
+    if (device_prepare) tc.active++;
+  }
 
   for (int alignment = 0; alignment < par.altali; alignment++) {
     HH_LOG(INFO) << "Alternative alignment: " << alignment << std::endl;
@@ -316,63 +519,197 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
       const size_t first_hit_of_block = ret_hits.size();
       ret_hits.resize(first_hit_of_block + m);
 
-      // upload in chunks that are whole SIMD batches of the reference, so that host memory stays bounded
+      // chunks that are whole SIMD batches of the reference, so that host memory stays bounded
       const unsigned int chunk_max = 16384;
       for (unsigned int c0 = 0; c0 < m; c0 += chunk_max) {
         const unsigned int cn = imin(m - c0, chunk_max);
         HHEntry** ent = &work[block_start + c0];
         Hit* hit0 = &ret_hits[first_hit_of_block + c0];
+        timer.lap(PhaseTimer::OTHER);
 
         if (alignment == 0) {
-          // ---- read + prepare on the host with the reference's code (:144-147), one template per iteration ----
-          std::vector<Prepared> prep(cn);
-          std::vector<int> pair_mode(cn);
+          // ---- which templates are already resident in raw form? ----
+          std::vector<const CachedTemplate*> cached(cn, (const CachedTemplate*)NULL);
+          std::vector<unsigned int> to_read;
+          if (device_prepare) {
+            std::lock_guard<std::mutex> lock(tc.device);
+            for (unsigned int k = 0; k < cn; ++k) {
+              std::unordered_map<std::string, CachedTemplate>::const_iterator it = tc.map.find(cache_key(ent[k]));
+              if (it != tc.map.end()) cached[k] = &it->second;  // std::unordered_map never moves its elements
+              else to_read.push_back(k);
+            }
+          } else {
+            for (unsigned int k = 0; k < cn; ++k) to_read.push_back(k);
+          }
+          timer.cached += cn - to_read.size();
+
+          // ---- read the others with the reference's code (:144), one template per iteration; no device lock ----
+          std::vector<HostTemplate> host(to_read.size());
+          const int n_read = (int)to_read.size();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-          for (unsigned int k = 0; k < cn; ++k) {
+          for (int r = 0; r < n_read; ++r) {
             int tid = 0;
 #ifdef OPENMP
             tid = omp_get_thread_num();
 #endif
+            if (!t_hmm[tid]) {
+              t_hmm[tid] = new HMM(MAXSEQDIS, par.maxres);
+              t_simd[tid] = new HMMSimd(par.maxres);
+            }
             HMM* t = t_hmm[tid];
+            const unsigned int k = to_read[r];
+            HostTemplate& h = host[r];
             int format_tmp = 0;
             char wg = 1;
             ent[k]->getTemplateHMM(par, wg, qsc, format_tmp, pb, S, Sim, t);
             t->entry = ent[k];
-            PrepareTemplateHMM(par, q, t, format_tmp, false, pb, R);
-            std::vector<HMM*> one(1, t);
-            t_simd[tid]->MapHMMVector(one);
-            lane0_to_profile(t_simd[tid], t, &prep[k]);
-            pair_mode[k] = HMM::computeScoreSSMode(q, t);
+            h.raw = device_prepare && format_tmp == 0 && memcmp(pb, pb0, sizeof(pb0)) == 0 && t->L >= 1 && t->L <= 0xFFFF;
+            h.L = t->L;
+            h.ss_pair_mode = HMM::computeScoreSSMode(q, t);
             hit0[k].initHitFromHMM(q, t, par.nseqdis, par.ssm);  // :40
-            hit0[k].entry = ent[k];
+            std::vector<HMM*> one(1, t);
+            if (h.raw) {
+              // raw columns as HMM::Read leaves them: p := f (HMM::NoAminoAcidPseudocounts), transitions untouched
+              t->NoAminoAcidPseudocounts();
+              t_simd[tid]->MapHMMVector(one);
+              std::vector<float> f;
+              lane0_to_profile(t_simd[tid], t, &f, &h.tr, &h.ss);
+              h.p.assign((size_t)(t->L + 2) * 20, 0.0f);
+              memcpy(h.p.data() + 20, f.data() + 20, (size_t)t->L * 20 * sizeof(float));
+              h.neff.resize((size_t)(t->L + 1) * 3);
+              for (int i = 0; i <= t->L; ++i) {
+                h.neff[(size_t)i * 3 + 0] = t->Neff_M[i];
+                h.neff[(size_t)i * 3 + 1] = t->Neff_I[i];
+                h.neff[(size_t)i * 3 + 2] = t->Neff_D[i];
+              }
+              h.neff_hmm = t->Neff_HMM;
+            } else {
+              PrepareTemplateHMM(par, q, t, format_tmp, false, pb, R);  // :147
+              t_simd[tid]->MapHMMVector(one);
+              lane0_to_profile(t_simd[tid], t, &h.p, &h.tr, &h.ss);
+            }
           }
-          std::vector<int32_t> L(cn);
-          std::vector<const float*> pp(cn), tt(cn);
-          std::vector<const int8_t*> sp(cn), sc(cn), sd(cn);
-          for (unsigned int k = 0; k < cn; ++k) {
-            L[k] = (int32_t)(prep[k].tr.size() / 7) - 1;
-            pp[k] = prep[k].p.data();
-            tt[k] = prep[k].tr.data();
-            sp[k] = prep[k].ss_pred.empty() ? NULL : prep[k].ss_pred.data();
-            sc[k] = prep[k].ss_conf.empty() ? NULL : prep[k].ss_conf.data();
-            sd[k] = prep[k].ss_dssp.empty() ? NULL : prep[k].ss_dssp.data();
-          }
-          hhv_tset* set = NULL;
-          hip_check(hhv_upload_templates_ss(ctx, (int32_t)cn, L.data(), pp.data(), tt.data(), sp.data(), sc.data(),
-                                            sd.data(), &set),
-                    "hhv_upload_templates_ss");
-          resident_sets.push_back(set);
-          for (unsigned int k = 0; k < cn; ++k) {
-            ResidentTemplate r;
-            r.set = set;
-            r.index = (int32_t)k;
-            r.L = L[k];
-            r.ss_pair_mode = pair_mode[k];
-            r.first_hit = first_hit_of_block + c0 + k;
-            r.ss_pred.swap(prep[k].ss_pred);
-            r.ss_conf.swap(prep[k].ss_conf);
-            r.ss_dssp.swap(prep[k].ss_dssp);
-            resident[ent[k]] = r;  // an entry listed twice is the same template
+          timer.lap(PhaseTimer::READ);
+
+          // ---- device section 1: new raw templates into the cache, host-prepared ones into a set of this search,
+          //      PrepareTemplateHMM on the device for everything raw ----
+          {
+            std::lock_guard<std::mutex> lock(tc.device);
+            search.install();
+            hhv_ctx* ctx = tc.ctx;
+            std::vector<unsigned int> raw_k, prep_k;
+            std::vector<int> raw_r, prep_r;
+            for (int r = 0; r < n_read; ++r) {
+              if (host[r].raw) {
+                raw_k.push_back(to_read[r]);
+                raw_r.push_back(r);
+              } else {
+                prep_k.push_back(to_read[r]);
+                prep_r.push_back(r);
+              }
+            }
+            timer.fresh += raw_k.size();
+            timer.host_prepared += prep_k.size();
+            if (!raw_k.empty()) {
+              size_t cols = 0;
+              const int n = (int)raw_k.size();
+              std::vector<int32_t> L(n);
+              std::vector<const float*> ff(n), tt(n), ne(n);
+              std::vector<float> nh(n);
+              std::vector<const int8_t*> sp(n), sc(n), sd(n);
+              for (int x = 0; x < n; ++x) {
+                const HostTemplate& h = host[raw_r[x]];
+                L[x] = h.L;
+                cols += (size_t)h.L + 1;
+                ff[x] = h.p.data();
+                tt[x] = h.tr.data();
+                ne[x] = h.neff.data();
+                nh[x] = h.neff_hmm;
+                sp[x] = h.ss.pred.empty() ? NULL : h.ss.pred.data();
+                sc[x] = h.ss.conf.empty() ? NULL : h.ss.conf.data();
+                sd[x] = h.ss.dssp.empty() ? NULL : h.ss.dssp.data();
+              }
+              // A full cache is emptied only when no template of it is in use by this search (nothing resident yet,
+              // nothing of this chunk found in it); otherwise it grows past the bound until the search is over.
+              if (tc.columns + cols > tc.max_columns && tc.active == 1 && resident.empty() && to_read.size() == cn) tc.clear();
+              hhv_rawset* rs = NULL;
+              hip_check(hhv_upload_raw_templates(ctx, n, L.data(), ff.data(), tt.data(), ne.data(), nh.data(), sp.data(), sc.data(),
+                                                 sd.data(), &rs),
+                        "hhv_upload_raw_templates");
+              tc.rawsets.push_back(rs);
+              tc.columns += cols;
+              for (int x = 0; x < n; ++x) {
+                HostTemplate& h = host[raw_r[x]];
+                CachedTemplate& ct = tc.map[cache_key(ent[raw_k[x]])];
+                if (ct.raw) ct.proto.Delete();  // the same key twice (two searches read it concurrently): the later upload wins
+                ct.raw = rs;
+                ct.index = x;
+                ct.L = h.L;
+                ct.ss_pair_mode = h.ss_pair_mode;
+                copy_template_info(hit0[raw_k[x]], &ct.proto);
+                ct.proto.entry = NULL;
+                ct.ss.pred.swap(h.ss.pred);
+                ct.ss.conf.swap(h.ss.conf);
+                ct.ss.dssp.swap(h.ss.dssp);
+                cached[raw_k[x]] = &ct;
+              }
+            }
+            timer.lap(PhaseTimer::UPLOAD);
+            if (!prep_k.empty()) {
+              const int n = (int)prep_k.size();
+              std::vector<int32_t> L(n);
+              std::vector<const float*> pp(n), tt(n);
+              std::vector<const int8_t*> sp(n), sc(n), sd(n);
+              for (int x = 0; x < n; ++x) {
+                HostTemplate& h = host[prep_r[x]];
+                L[x] = h.L;
+                pp[x] = h.p.data();
+                tt[x] = h.tr.data();
+                sp[x] = h.ss.pred.empty() ? NULL : h.ss.pred.data();
+                sc[x] = h.ss.conf.empty() ? NULL : h.ss.conf.data();
+                sd[x] = h.ss.dssp.empty() ? NULL : h.ss.dssp.data();
+              }
+              hhv_tset* set = NULL;
+              hip_check(hhv_upload_templates_ss(ctx, n, L.data(), pp.data(), tt.data(), sp.data(), sc.data(), sd.data(), &set),
+                        "hhv_upload_templates_ss");
+              search_sets.push_back(set);
+              for (int x = 0; x < n; ++x) {
+                HostTemplate& h = host[prep_r[x]];
+                SsRecords* ss = new SsRecords();
+                ss->pred.swap(h.ss.pred);
+                ss->conf.swap(h.ss.conf);
+                ss->dssp.swap(h.ss.dssp);
+                own_ss.push_back(ss);
+                ResidentTemplate rt = {set, (int32_t)x, h.L, h.ss_pair_mode, first_hit_of_block + c0 + prep_k[x], ss};
+                resident[ent[prep_k[x]]] = rt;
+              }
+            }
+            timer.lap(PhaseTimer::UPLOAD);
+            // PrepareTemplateHMM on the device, one launch per raw set the chunk's templates live in
+            std::map<hhv_rawset*, std::vector<unsigned int> > by_raw;
+            for (unsigned int k = 0; k < cn; ++k)
+              if (cached[k]) by_raw[cached[k]->raw].push_back(k);
+            for (std::map<hhv_rawset*, std::vector<unsigned int> >::iterator g = by_raw.begin(); g != by_raw.end(); ++g) {
+              const std::vector<unsigned int>& mem = g->second;
+              std::vector<int32_t> ids(mem.size());
+              for (size_t x = 0; x < mem.size(); ++x) ids[x] = cached[mem[x]]->index;
+              hhv_tset* set = NULL;
+              hip_check(hhv_prepare_subset(ctx, g->first, &prep, q->pav, ids.data(), (int32_t)ids.size(), &set), "hhv_prepare_subset");
+              search_sets.push_back(set);
+              for (size_t x = 0; x < mem.size(); ++x) {
+                const unsigned int k = mem[x];
+                const CachedTemplate* ct = cached[k];
+                ResidentTemplate rt = {set, (int32_t)x, ct->L, ct->ss_pair_mode, first_hit_of_block + c0 + k, &ct->ss};
+                resident[ent[k]] = rt;
+              }
+            }
+            timer.lap(PhaseTimer::PREPARE);
+            // templates not read in this search: template information from the prototype
+#pragma omp parallel for schedule(static) num_threads(threads) if (cn > 256)
+            for (unsigned int k = 0; k < cn; ++k)
+              if (cached[k] && !hit0[k].name) copy_template_info(cached[k]->proto, &hit0[k]);
+            for (unsigned int k = 0; k < cn; ++k) hit0[k].entry = ent[k];
+            timer.lap(PhaseTimer::PATHS);
           }
         } else {
           for (unsigned int k = 0; k < cn; ++k) {
@@ -391,23 +728,27 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
           for (unsigned int k = b; k < e; ++k) batch_mode[k] = mode;
         }
         std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> > groups;
-        for (unsigned int k = 0; k < cn; ++k)
-          groups[std::make_pair(resident[ent[k]].set, batch_mode[k])].push_back(k);
-        for (std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> >::iterator g = groups.begin();
-             g != groups.end(); ++g) {
-          const std::vector<unsigned int>& mem = g->second;
-          const int n = (int)mem.size();
-          std::vector<int32_t> ids(n);
-          std::vector<const ResidentTemplate*> tmpl(n);
-          std::vector<Hit*> out(n);
-          bool whole = (n == hhv_tset_size(g->first.first));
-          for (int k = 0; k < n; ++k) {
-            tmpl[k] = &resident[ent[mem[k]]];
-            ids[k] = tmpl[k]->index;
-            out[k] = &hit0[mem[k]];
-            whole = whole && ids[k] == k;
+        for (unsigned int k = 0; k < cn; ++k) groups[std::make_pair(resident[ent[k]].set, batch_mode[k])].push_back(k);
+        {
+          // device section 2: alignment, backtrace, Hit scores, paths
+          std::lock_guard<std::mutex> lock(tc.device);
+          search.install();
+          for (std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> >::iterator g = groups.begin(); g != groups.end();
+               ++g) {
+            const std::vector<unsigned int>& mem = g->second;
+            const int n = (int)mem.size();
+            std::vector<int32_t> ids(n);
+            std::vector<const ResidentTemplate*> tmpl(n);
+            std::vector<Hit*> out(n);
+            bool whole = (n == hhv_tset_size(g->first.first));
+            for (int k = 0; k < n; ++k) {
+              tmpl[k] = &resident[ent[mem[k]]];
+              ids[k] = tmpl[k]->index;
+              out[k] = &hit0[mem[k]];
+              whole = whole && ids[k] == k;
+            }
+            search.run(g->first.first, whole ? NULL : ids.data(), n, g->first.second, tmpl, out);
           }
-          runner.run(g->first.first, whole ? NULL : ids.data(), n, g->first.second, tmpl, out);
         }
       }
 
@@ -417,7 +758,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         h.irep = (alignment + 1);
         if (h.score > par.smin) {
           next_work.push_back(h.entry);
-          excludeAlignments[std::string(h.entry->getName())].push_back(first_hit_of_block + k);
+          search.excludeAlignments[std::string(h.entry->getName())].push_back(first_hit_of_block + k);
         }
       }
       HH_LOG(INFO) << (block_start + m) << " alignments done" << std::endl;
@@ -435,13 +776,21 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
     work.swap(next_work);
   }
 
-  for (size_t k = 0; k < resident_sets.size(); ++k) hhv_tset_free(resident_sets[k]);
-  hhv_destroy(ctx);
+  timer.lap(PhaseTimer::OTHER);
+  {
+    std::lock_guard<std::mutex> lock(tc.device);
+    for (size_t k = 0; k < search_sets.size(); ++k) hhv_tset_free(search_sets[k]);
+    if (device_prepare) tc.active--;
+  }
+  for (size_t k = 0; k < own_ss.size(); ++k) delete own_ss[k];
   for (int k = 0; k < threads; ++k) {
     delete t_simd[k];
     delete t_hmm[k];
   }
-  return ret_hits;
+  timer.lap(PhaseTimer::OTHER);
+  std::vector<Hit> result;
+  result.swap(ret_hits);
+  return result;
 }
 
 // src/hhviterbirunner.cpp:213-247.  Sum over the hits of the block of 1 / (1 + E-value), the E-value from the

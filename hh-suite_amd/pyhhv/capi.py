@@ -34,7 +34,7 @@ HIT_DTYPE = np.dtype([("score", np.float32), ("viterbi_score", np.float32), ("sc
 # every symbol include/hhviterbi_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
-    "hhv_create", "hhv_destroy", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
+    "hhv_create", "hhv_destroy", "hhv_set_params", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_backtrace_matrix", "hhv_hits",
-    "hhv_hit_path", "hhv_topk",
+    "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk",
 ]
 
 

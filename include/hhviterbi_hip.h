@@ -115,6 +115,10 @@ int hhv_fast_log2_tables(float* lg2, float* diff);
 
 int hhv_create(hhv_ctx** out, const hhv_params* par);
 void hhv_destroy(hhv_ctx* ctx);
+/* New search parameters for an existing context (par->device must be the context's device): what a process-wide
+ * context that outlives one ViterbiRunner::alignment call needs (hh-suite_amd/dropin/hhviterbirunner_hip.cpp keeps the
+ * raw template database of earlier searches resident in one).  The query, the resident sets and their results stay. */
+int hhv_set_params(hhv_ctx* ctx, const hhv_params* par);
 
 /* query: p[(Lq+1)*20], tr[(Lq+1)*7] */
 int hhv_set_query(hhv_ctx* ctx, const float* p, const float* tr, int32_t Lq);
@@ -320,6 +324,12 @@ int hhv_hits(hhv_ctx* ctx, hhv_tset* ts, hhv_hit* hits);
  * step 1 = alignment end); S = per-step column scores (BacktraceScore.S).  Needs hhv_hits. */
 int hhv_hit_path(hhv_ctx* ctx, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps,
                  int8_t* states, float* S, int32_t* nsteps);
+/* All paths of the last hhv_hits at once: pointers into the host mirror of the path pool, owned by the set and valid
+ * until the set is aligned again or freed.  Path of template k = entries path_off[k] + 1 .. path_off[k] + nsteps of the four
+ * arrays (entry path_off[k] is the unused index 0 of BacktraceResult).  For callers that build thousands of Hit objects:
+ * one call instead of one hhv_hit_path per hit. */
+int hhv_hit_path_pool(hhv_ctx* ctx, hhv_tset* ts, const int64_t** path_off, const int32_t** i_steps, const int32_t** j_steps,
+                      const int8_t** states, const float** S);
 /* K best hits by hit score (descending, ties by smaller index), selected on the device.
  * flags: 0 = rank by Hit.score (needs hhv_hits); HHV_TOPK_RAW = rank by the raw Viterbi score of the
  * last hhv_align (score-only searches: the records carry viterbi_score, i2, j2, index; path fields 0).

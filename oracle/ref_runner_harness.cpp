@@ -18,6 +18,8 @@
 #define RUN_NAME ref_runner_run_cpu
 #endif
 
+#include <sys/time.h>
+
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -67,13 +69,15 @@ struct rr_hit {
 };
 
 // opts_i: [0] loc [1] altali [2] ssm [3] early_stopping_filter [4] prefilter [5] dbsize [6] maxres [7] threads
+//         [8] pc_hhm_nocontext_mode (-1 = default) [9] columnscore (-1 = default)
 // opts_f: [0] smin [1] filter_thresh [2] egq [3] egt [4] ssw
 // seq_len[k]: the length the cs219 entry would announce (HHEntry::sequence_length, the sort key of :117-119)
+// alignment_seconds (nullable): wall time of the ViterbiRunner::alignment call alone.
 // Returns the number of hits (may exceed cap_hits; only cap_hits are written) or a negative error.
 int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* tmpl_hhm, const size_t* tmpl_len,
              const char* const* names, const int32_t* seq_len, const int32_t* opts_i, const float* opts_f,
              const char* exclstr, const char* template_exclstr, int cap_hits, rr_hit* hits, int path_cap, int32_t* pi,
-             int32_t* pj, int8_t* pstates, float* pS, float* pS_ss) {
+             int32_t* pj, int8_t* pstates, float* pS, float* pS_ss, double* alignment_seconds) {
   Parameters par(0, NULL);
   Log::reporting_level() = WARNING;
   par.nocontxt = 1;  // the context_data.crf blob is not part of the reference tree (.MISSING_LARGE_BLOBS)
@@ -85,6 +89,8 @@ int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* 
   par.dbsize = opts_i[5];
   par.maxres = opts_i[6];
   par.threads = opts_i[7];
+  if (opts_i[8] >= 0) par.pc_hhm_nocontext_mode = opts_i[8];
+  if (opts_i[9] >= 0) par.columnscore = opts_i[9];
   par.smin = opts_f[0];
   par.filter_thresh = opts_f[1];
   par.egq = opts_f[2];
@@ -135,7 +141,11 @@ int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* 
   }
   std::vector<HHblitsDatabase*> dbs;
   ViterbiRunner runner(vm, dbs, par.threads);
+  struct timeval t0, t1;
+  gettimeofday(&t0, NULL);
   std::vector<Hit> res = runner.alignment(par, &q_vec, entries, par.qsc_db, pb, S, Sim, R, par.ssm, S73, S33, S37);
+  gettimeofday(&t1, NULL);
+  if (alignment_seconds) *alignment_seconds = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
 
   const int m = (int)res.size();
   for (int h = 0; h < m; ++h) {

@@ -65,8 +65,10 @@ def hhm_text(name, f, seed, ss=None, neff=None):
     lines.append("HMM    " + "\t".join(SORTED) + "\t")
     lines.append("       M->M\tM->I\tM->D\tI->M\tI->I\tD->M\tD->D\tNeff\tNeff_I\tNeff_D")
     lines.append("       0\t*\t*\t0\t*\t0\t*\t*\t*\t*\t")
+    with np.errstate(divide="ignore"):
+        v = np.where(f > 0, np.rint(-1000.0 * np.log2(np.where(f > 0, f, 1.0))), 99999).astype(np.int64)[:, S2A]
     for i in range(L):
-        row = [_val(f[i][S2A[k]]) for k in range(20)]
+        row = ["*" if x >= 99999 else str(x) for x in v[i].tolist()]
         lines.append("%s %-4d %s\t%d" % (cons[i], i + 1, "\t".join(row), i + 1))
         last = i == L - 1
         if last or r.random() < 0.3:  # no observed inserts / deletes in this column

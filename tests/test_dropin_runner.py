@@ -31,7 +31,7 @@ def _lib():
 
 def run(which, query, templates, names, seq_len=None, loc=1, altali=4, ssm=2, early=0, prefilter=0, dbsize=20000,
         maxres=2000, threads=1, smin=20.0, filter_thresh=0.01, egq=0.0, egt=0.0, ssw=0.11, excl="", texcl="",
-        path_cap=1400):
+        path_cap=1400, pcm=-1, columnscore=-1):
     lib = _lib()
     fn = getattr(lib, "ref_runner_run_" + which)
     n = len(templates)
@@ -48,16 +48,18 @@ def run(which, query, templates, names, seq_len=None, loc=1, altali=4, ssm=2, ea
     if seq_len is None:
         seq_len = [int(t.split(b"LENG")[1].split()[0]) for t in templates]
     sl = np.asarray(seq_len, dtype=np.int32)
-    oi = np.asarray([loc, altali, ssm, early, prefilter, dbsize, maxres, threads], dtype=np.int32)
+    oi = np.asarray([loc, altali, ssm, early, prefilter, dbsize, maxres, threads, pcm, columnscore], dtype=np.int32)
     of = np.asarray([smin, filter_thresh, egq, egt, ssw], dtype=np.float32)
     P = ctypes.c_void_p
+    secs = ctypes.c_double(0.0)
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, P, P, P, P, P, P, ctypes.c_char_p, ctypes.c_char_p,
-                   ctypes.c_int, P, ctypes.c_int, P, P, P, P, P]
+                   ctypes.c_int, P, ctypes.c_int, P, P, P, P, P, P]
     m = fn(query, len(query), n, ctypes.cast(texts, P), ctypes.cast(lens, P), ctypes.cast(nm, P), sl.ctypes.data,
            oi.ctypes.data, of.ctypes.data, excl.encode(), texcl.encode(), cap, ctypes.cast(hits, P), path_cap,
-           pi.ctypes.data, pj.ctypes.data, ps.ctypes.data, pS.ctypes.data, pSS.ctypes.data)
+           pi.ctypes.data, pj.ctypes.data, ps.ctypes.data, pS.ctypes.data, pSS.ctypes.data, ctypes.addressof(secs))
     assert 0 <= m <= cap, m
+    run.last_alignment_seconds = secs.value
     return [hits[k] for k in range(m)], pi[:m], pj[:m], ps[:m], pS[:m], pSS[:m]
 
 
@@ -81,9 +83,20 @@ def make_db(seed, Lq, n, lo, hi, ss_every=0, query_ss=False, homolog_every=2, sa
         else:
             f = hhm_text.random_columns(seed * 1000 + k, L)
         ss = hhm_text.random_ss(seed * 31 + k, f.shape[0]) if ((ss_every and k % ss_every == 0) or k in with_ss) else None
-        names.append("t%05d" % k)
+        names.append("t%d_%05d" % (seed, k))
         texts.append(hhm_text.hhm_text(names[-1], f, seed * 1000 + k, ss=ss))
     return query, texts, names
+
+
+def cache_stats():
+    lib = _lib()
+    t, c = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    lib.hhviterbirunner_hip_cache_stats(ctypes.byref(t), ctypes.byref(c))
+    return t.value, c.value
+
+
+def cache_clear():
+    _lib().hhviterbirunner_hip_cache_clear()
 
 
 def compare(a, b):
@@ -129,6 +142,49 @@ def test_dropin_equals_reference(loc, altali, threads):
 
 
 @pytest.mark.gpu
+def test_dropin_resident_cache():
+    """The second search of the same templates takes them from the device-resident raw cache (nothing is parsed or
+    prepared on the host) - also for ANOTHER query, whose composition changes the prepared profiles - and still returns
+    the reference's hits; HHV_TEMPLATE_CACHE-less behaviour (host preparation) is covered by the ssm/pcm variants below."""
+    cache_clear()
+    q, t, names = make_db(41, 150, 60, 40, 260)
+    ref = run("cpu", q, t, names, altali=3)
+    got = run("hip", q, t, names, altali=3, threads=4)
+    compare(ref, got)
+    n_templates, n_cols = cache_stats()
+    assert n_templates == 60 and n_cols == sum(int(x.split(b"LENG")[1].split()[0]) + 1 for x in t)
+    empty = [b""] * len(t)                    # the texts are not needed any more: reading one would fail
+    got2 = run("hip", q, empty, names, altali=3, seq_len=[int(x.split(b"LENG")[1].split()[0]) for x in t])
+    compare(ref, got2)
+    q2, _, _ = make_db(42, 170, 1, 50, 50)    # another query against the resident templates
+    ref3 = run("cpu", q2, t, names, altali=2)
+    got3 = run("hip", q2, empty, names, altali=2, seq_len=[int(x.split(b"LENG")[1].split()[0]) for x in t])
+    compare(ref3, got3)
+    assert cache_stats()[0] == 60
+    cache_clear()
+    assert cache_stats() == (0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pcm,columnscore", [(3, -1), (0, 0), (1, 2), (2, 3), (-1, 4)])
+def test_dropin_preparation_variants(pcm, columnscore):
+    """pseudocount modes / null models: 0..2 / 0..3 are prepared on the device, the others by the reference's host code
+    (pcm 3, columnscore 4) - the hits must not tell the difference.  One template carries its own NULL line: the
+    reference prepares it with that background (HMM::Read overwrites pb, src/hhhmm.cpp:536-546), so it takes the host path."""
+    cache_clear()
+    q, t, names = make_db(51 + pcm + 7 * columnscore, 140, 30, 50, 220)
+    odd = t[7].split(b"NULL   ")
+    t[7] = odd[0] + b"NULL   " + odd[1].replace(b"3706\t5728", b"3500\t5900", 1)
+    assert t[7] != odd[0] + b"NULL   " + odd[1]
+    ref = run("cpu", q, t, names, altali=2, pcm=pcm, columnscore=columnscore)
+    got = run("hip", q, t, names, altali=2, pcm=pcm, columnscore=columnscore)
+    compare(ref, got)
+    device = (pcm in (-1, 0, 1, 2)) and (columnscore in (-1, 0, 1, 2, 3))
+    assert cache_stats()[0] == (29 if device else 0)
+    cache_clear()
+
+
+@pytest.mark.gpu
 def test_dropin_global_equal_lengths():
     """global mode on templates of ONE length (no batch-composition quirk)"""
     q, t, names = make_db(5, 100, 24, 80, 80)
@@ -148,6 +204,7 @@ def test_dropin_secondary_structure(ssm):
            make_db(23, 130, 24, 50, 200, ss_every=1, query_ss=False)]    # templates with records, query without
     with_ss = []
     for (qq, tt, nn) in dbs:
+        cache_clear()     # dbs[0] and dbs[1] use the same names for templates that differ in their ss records
         ref = run("cpu", qq, tt, nn, ssm=ssm, altali=2)
         got = run("hip", qq, tt, nn, ssm=ssm, altali=2)
         compare(ref, got)
