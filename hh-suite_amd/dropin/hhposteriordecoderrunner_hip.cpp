@@ -1,0 +1,299 @@
+// hhposteriordecoderrunner_hip.cpp -- DROP-IN replacement for src/hhposteriordecoderrunner.cpp of hh-suite v3.3.0.
+//
+// Same class, same constructor, same executeComputation(q, hits, par, qsc, pb, S, Sim, R) as declared by the reference's
+// own src/hhposteriordecoderrunner.h (untouched); a maintainer compiles this file instead of the reference's and links
+// libhhviterbi_hip.so.  HHblits::perform_realign (src/hhblits.cpp:973-1034) keeps calling it and finds in every Hit what
+// PosteriorDecoder::realign leaves there (src/hhposteriordecoder.cpp:86-119, src/hhbacktracemac.cpp:113-240):
+//     i, j, states, S, S_ss, P_posterior [nsteps+1], alt_i / alt_j (emptied at the end, :108-113), i1, j1, i2, j2, nsteps, matched_cols, sum_of_probs,
+//     Pforward, state = STOP, min_overlap = 0, realign_around_viterbi = true;
+//     score, score_ss, score_aass, P-values, E-value, Probab stay the Viterbi ones (memorizeHitValues / restoreHitValues).
+// Forward, backward, posterior, MAC DP and MAC backtrace run on the GPU (hhv_mac_realign_hits: one wavefront per hit,
+// the cell-off masks built on the device), bit-exact against the reference's doubles (tests/test_mac.py).
+//
+// Control flow of the reference kept here: the hits are grouped by template NAME and ordered by irep inside a group
+// (:52-66); the r-th alignment of a template excludes the cells (+-2) of the MAC alignments 1..r-1 of the same template
+// (alignment_to_exclude, :104-106); templates are independent.  The reference runs the groups in an OpenMP loop, one hit
+// after the other inside a group; here ROUND r realigns the r-th hit of every group in one launch.  The template of a
+// group is read and prepared once with the reference's own code (getTemplateHMM + PrepareTemplateHMM with linear
+// transitions, :98-99), in parallel over the groups.
+//
+// Not produced: the sparse forward / backward / posterior lists of writeProfilesToHits (hit.forward_matrix, ...;
+// src/hhbacktracemac.cpp:14-110), which only HitList::PrintMatrices (the hidden -o_matrices output) reads; they are left
+// NULL and PrintMatrices skips such hits.  Not supported (the run stops with a message instead of computing something
+// else): hits with secondary-structure scoring against DSSP states inside MAC (hit.ssm2 = 1 or 2 - query with predicted
+// SS against templates with DSSP records, or the reverse; ssm2 = 3 is a no-op in the reference, Viterbi::ScoreSS has no
+// case 3), self alignments (hit.self), templates longer than 2046 columns.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "hhposteriordecoderrunner.h"
+#include "hhviterbi_hip.h"
+
+#ifdef OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+void mac_check(int rc, const char* what) {
+  if (rc == HHV_OK) return;
+  HH_LOG(ERROR) << "hhviterbi_hip: " << what << " failed: " << hhv_last_error() << std::endl;
+  exit(rc == HHV_E_MEMORY ? 3 : 4);
+}
+
+// std::sort predicate of the reference (src/hhposteriordecoderrunner.cpp:27-31), on the pointers it is applied to
+bool irep_less(const Hit* a, const Hit* b) { return a->irep < b->irep; }
+
+std::vector<int32_t> mac_region_pairs(char* exclstr) {  // exclude_regions, src/hhposteriordecoder.cpp:121-149
+  std::vector<int32_t> out;
+  if (!exclstr) return out;
+  char* ptr = exclstr;
+  while (true) {
+    int a = abs(strint(ptr));
+    int b = abs(strint(ptr));
+    if (!ptr) break;
+    out.push_back(a < 1 ? 1 : a);
+    out.push_back(b);
+  }
+  return out;
+}
+
+struct PreparedTemplate {
+  int L;
+  std::vector<float> p, tr_lin;  // [(L+1)*20], [(L+1)*7] linear transitions with the boundary values of :159-167
+  int has_dssp;
+  std::vector<char> dssp, pred, conf;  // t.ss_dssp (sum_of_probs, src/hhbacktracemac.cpp:196-197), ss_pred / ss_conf (S_ss)
+};
+
+}  // namespace
+
+PosteriorDecoderRunner::PosteriorDecoderRunner(PosteriorMatrix** posterior_matrices, ViterbiMatrix** backtrace_matrix,
+                                               const int n_threads, const float ssw,
+                                               const float S73[NDSSP][NSSPRED][MAXCF],
+                                               const float S33[NSSPRED][MAXCF][NSSPRED][MAXCF],
+                                               const float S37[NSSPRED][MAXCF][NDSSP])
+    : S73(S73), S33(S33), S37(S37), m_posterior_matrices(posterior_matrices), m_backtrace_matrix(backtrace_matrix),
+      m_n_threads(n_threads) {}
+
+PosteriorDecoderRunner::~PosteriorDecoderRunner() {}
+
+// src/hhposteriordecoderrunner.cpp:146-155
+void PosteriorDecoderRunner::initializeQueryHMMTransitions(HMM& q) {
+  q.tr[0][M2D] = q.tr[0][M2I] = 0.0f;
+  q.tr[0][I2M] = q.tr[0][I2I] = 0.0f;
+  q.tr[0][D2M] = q.tr[0][D2D] = 0.0f;
+  q.tr[q.L][M2M] = 1.0f;
+  q.tr[q.L][M2D] = q.tr[q.L][M2I] = 0.0f;
+  q.tr[q.L][I2M] = q.tr[q.L][I2I] = 0.0f;
+  q.tr[q.L][D2M] = 1.0f;
+  q.tr[q.L][D2D] = 0.0f;
+}
+
+void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, Parameters& par, const float qsc, float* pb,
+                                                const float S[20][20], const float Sim[20][20], const float R[20][20]) {
+  HMM* q_hmm = &q;
+  q_hmm->Log2LinTransitionProbs(1.0);       // :48
+  initializeQueryHMMTransitions(*q_hmm);    // :50
+  if (hits.empty()) return;
+
+  // ---- groups: one per template name, ordered by irep (:52-66) ----
+  std::map<std::string, std::vector<Hit*> > alignments_map;
+  for (size_t i = 0; i < hits.size(); i++) {
+    Hit* h = hits[i];
+    if (h->self) {
+      HH_LOG(ERROR) << "hhviterbi_hip: MAC realignment of self alignments is not supported on the device" << std::endl;
+      exit(4);
+    }
+    if (h->ssm2 == 1 || h->ssm2 == 2) {
+      HH_LOG(ERROR) << "hhviterbi_hip: MAC realignment with secondary-structure scoring against DSSP states (hit " << h->name
+                    << ", ssm2 = " << h->ssm2 << ") is not supported on the device; run with -ssm 0" << std::endl;
+      exit(4);
+    }
+    alignments_map[h->entry->getName()].push_back(h);
+  }
+  std::vector<std::vector<Hit*> > alignment;
+  size_t rounds = 0;
+  for (std::map<std::string, std::vector<Hit*> >::iterator it = alignments_map.begin(); it != alignments_map.end(); ++it) {
+    std::sort(it->second.begin(), it->second.end(), irep_less);
+    alignment.push_back(it->second);
+    rounds = std::max(rounds, it->second.size());
+  }
+  const int n_groups = (int)alignment.size();
+
+  // ---- the template of every group, read and prepared by the reference's code (:98-99), linear transitions ----
+  const int threads = m_n_threads > 0 ? m_n_threads : 1;
+  std::vector<HMM*> t_hmm(threads, (HMM*)NULL);
+  std::vector<PreparedTemplate> tmpl(n_groups);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (int g = 0; g < n_groups; ++g) {
+    int tid = 0;
+#ifdef OPENMP
+    tid = omp_get_thread_num();
+#endif
+    if (!t_hmm[tid]) t_hmm[tid] = new HMM(MAXSEQDIS, par.maxres);
+    HMM* t = t_hmm[tid];
+    int format_tmp = 0;
+    alignment[g][0]->entry->getTemplateHMM(par, par.wg, qsc, format_tmp, pb, S, Sim, t);
+    PrepareTemplateHMM(par, q_hmm, t, format_tmp, true, pb, R);
+    PreparedTemplate& pt = tmpl[g];
+    pt.L = t->L;
+    pt.p.assign((size_t)(t->L + 1) * 20, 0.0f);
+    pt.tr_lin.resize((size_t)(t->L + 1) * 7);
+    for (int i = 0; i <= t->L; ++i) {
+      if (i >= 1) memcpy(&pt.p[(size_t)i * 20], t->p[i], 20 * sizeof(float));
+      memcpy(&pt.tr_lin[(size_t)i * 7], t->tr[i], 7 * sizeof(float));
+    }
+    // initializeForAlignment (src/hhposteriordecoder.cpp:159-167)
+    float* t0 = &pt.tr_lin[0];
+    float* tL = &pt.tr_lin[(size_t)t->L * 7];
+    t0[M2M] = 1.0f;
+    t0[M2D] = t0[M2I] = 0.0f;
+    t0[I2M] = t0[I2I] = 0.0f;
+    t0[D2M] = t0[D2D] = 0.0f;
+    tL[M2M] = 1.0f;
+    tL[M2D] = tL[M2I] = 0.0f;
+    tL[I2M] = tL[I2I] = 0.0f;
+    tL[D2M] = 1.0f;
+    tL[D2D] = 0.0f;
+    pt.has_dssp = t->nss_dssp >= 0;
+    pt.dssp.assign(t->ss_dssp, t->ss_dssp + t->L + 1);
+    pt.pred.assign(t->ss_pred, t->ss_pred + t->L + 1);
+    pt.conf.assign(t->ss_conf, t->ss_conf + t->L + 1);
+  }
+  for (int k = 0; k < threads; ++k) delete t_hmm[k];
+
+  // ---- the query as the device wants it ----
+  std::vector<float> q_p((size_t)(q.L + 1) * 20, 0.0f), q_tr((size_t)(q.L + 1) * 7);
+  for (int i = 0; i <= q.L; ++i) {
+    if (i >= 1) memcpy(&q_p[(size_t)i * 20], q.p[i], 20 * sizeof(float));
+    memcpy(&q_tr[(size_t)i * 7], q.tr[i], 7 * sizeof(float));
+  }
+  std::vector<int32_t> q_ranges = mac_region_pairs(par.exclstr), t_ranges = mac_region_pairs(par.template_exclstr);
+
+  hhv_params hp;
+  memset(&hp, 0, sizeof(hp));
+  const char* dev = getenv("HHV_DEVICE");
+  hp.device = dev ? atoi(dev) : 0;
+  hp.local = par.loc;
+  hp.shift = par.shift;
+  hp.corr = par.corr;
+  hhv_ctx* ctx = NULL;
+  mac_check(hhv_create(&ctx, &hp), "hhv_create");
+
+  // ---- round r: the r-th alignment of every template ----
+  for (size_t r = 0; r < rounds; ++r) {
+    std::vector<int> group_of;
+    for (int g = 0; g < n_groups; ++g)
+      if (alignment[g].size() > r) group_of.push_back(g);
+    const int n = (int)group_of.size();
+    std::vector<hhv_mac_input> in(n);
+    std::vector<std::vector<int32_t> > path_i(n), path_j(n), ex_i(n), ex_j(n);
+    std::vector<const float*> tp(n), ttr(n);
+    std::vector<int32_t> Lt(n);
+    for (int b = 0; b < n; ++b) {
+      const int g = group_of[b];
+      Hit* hit = alignment[g][r];
+      path_i[b].assign(hit->i, hit->i + hit->nsteps + 1);
+      path_j[b].assign(hit->j, hit->j + hit->nsteps + 1);
+      for (size_t e = 0; e < r; ++e) {  // alignment_to_exclude: alt_i / alt_j of the earlier alignments (:104-106)
+        const Hit* prev = alignment[g][e];
+        ex_i[b].insert(ex_i[b].end(), prev->alt_i->begin(), prev->alt_i->end());
+        ex_j[b].insert(ex_j[b].end(), prev->alt_j->begin(), prev->alt_j->end());
+      }
+      in[b].i1 = hit->i1;
+      in[b].j1 = hit->j1;
+      in[b].i2 = hit->i2;
+      in[b].j2 = hit->j2;
+      in[b].nsteps = hit->nsteps;
+      in[b].i = path_i[b].data();
+      in[b].j = path_j[b].data();
+      in[b].n_excluded = (int32_t)ex_i[b].size();
+      in[b].excluded_i = ex_i[b].data();
+      in[b].excluded_j = ex_j[b].data();
+      tp[b] = tmpl[g].p.data();
+      ttr[b] = tmpl[g].tr_lin.data();
+      Lt[b] = tmpl[g].L;
+    }
+    hhv_macset* ms = NULL;
+    std::vector<hhv_mac_hit> res(n);
+    mac_check(hhv_mac_realign_hits(ctx, q_p.data(), q_tr.data(), q.L, n, Lt.data(), tp.data(), ttr.data(), in.data(),
+                                   (int32_t)q_ranges.size() / 2, q_ranges.data(), (int32_t)t_ranges.size() / 2, t_ranges.data(),
+                                   par.loc, par.shift, par.mact, &ms, res.data()),
+              "hhv_mac_realign_hits");
+    for (int b = 0; b < n; ++b) {
+      const int g = group_of[b];
+      Hit& hit = *alignment[g][r];
+      const hhv_mac_hit& m = res[b];
+      // initializeForAlignment (:168-177) and initializeBacktrace (src/hhbacktracemac.cpp:273-304)
+      if (hit.alt_i) delete hit.alt_i;
+      hit.alt_i = new std::vector<int>();
+      if (hit.alt_j) delete hit.alt_j;
+      hit.alt_j = new std::vector<int>();
+      hit.realign_around_viterbi = true;
+      hit.min_overlap = 0;  // src/hhmacalgorithm.cpp:52
+      hit.Pforward = m.Pforward;
+      hit.i2 = m.i2;
+      hit.j2 = m.j2;
+      if (hit.i) delete[] hit.i;
+      if (hit.j) delete[] hit.j;
+      if (hit.states) delete[] hit.states;
+      if (hit.S) delete[] hit.S;
+      if (hit.S_ss) delete[] hit.S_ss;
+      if (hit.P_posterior) delete[] hit.P_posterior;
+      const int cap = std::max(m.i2 + m.j2 + 2, m.nsteps + 1);
+      hit.i = new int[cap];
+      hit.j = new int[cap];
+      hit.states = new char[cap];
+      hit.S = new float[m.nsteps + 1];
+      hit.S_ss = new float[m.nsteps + 1];
+      hit.P_posterior = new float[m.nsteps + 1];
+      int32_t ns = 0;
+      mac_check(hhv_mac_path(ms, b, m.nsteps + 1, hit.i, hit.j, (int8_t*)hit.states, hit.S, hit.P_posterior, &ns), "hhv_mac_path");
+      // backtraceMAC (:113-240)
+      hit.nsteps = m.nsteps;
+      hit.matched_cols = m.matched_cols;
+      hit.i1 = m.i1;
+      hit.j1 = m.j1;
+      hit.state = ViterbiMatrix::STOP;
+      if (m.nsteps == 0) {  // the backtrace did not start in a match-match state (:128-138): one cell, no steps
+        hit.i[0] = m.i2;
+        hit.j[0] = m.j2;
+        hit.alt_i->push_back(m.i2);
+        hit.alt_j->push_back(m.j2);
+        hit.states[0] = ViterbiMatrix::MM;  // hit.states[step] = MM with step = 0 (:164)
+      }
+      // S_ss[step] = Viterbi::ScoreSS(q, t, i, j, ssw, ssm1 + ssm2, ...) for match states (:188-189); with ssm2 in {0, 3}
+      // the sum is 0 or 3 (no such case in ScoreSS: 0) unless SS is scored AFTER the alignment (ssm1 = 1 or 2)
+      const int ssm = hit.ssm1 + hit.ssm2;
+      for (int step = 1; step <= m.nsteps; ++step) {
+        hit.alt_i->push_back(hit.i[step]);
+        hit.alt_j->push_back(hit.j[step]);
+        float s_ss = 0.0f;
+        if (hit.states[step] == ViterbiMatrix::MM) {
+          const int i = hit.i[step], j = hit.j[step];
+          if (ssm == HMM::PRED_DSSP) s_ss = par.ssw * S37[(int)q.ss_pred[i]][(int)q.ss_conf[i]][(int)tmpl[g].dssp[j]];
+          else if (ssm == HMM::DSSP_PRED) s_ss = par.ssw * S73[(int)q.ss_dssp[i]][(int)tmpl[g].pred[j]][(int)tmpl[g].conf[j]];
+          else if (ssm == HMM::PRED_PRED)
+            s_ss = par.ssw * S33[(int)q.ss_pred[i]][(int)q.ss_conf[i]][(int)tmpl[g].pred[j]][(int)tmpl[g].conf[j]];
+        }
+        hit.S_ss[step] = s_ss;
+      }
+      hit.sum_of_probs = m.sum_of_probs;
+      if (tmpl[g].has_dssp) {  // only columns with a resolved DSSP state count (:196-197)
+        float sum = 0.0;
+        for (int step = 1; step <= m.nsteps; ++step)
+          if (hit.states[step] == ViterbiMatrix::MM && tmpl[g].dssp[hit.j[step]] > 0) sum += hit.P_posterior[step];
+        hit.sum_of_probs = sum;
+      }
+      // score, score_ss, score_aass, Pval, Pvalt, logPval, logPvalt, Eval, logEval, Probab: untouched = restoreHitValues
+    }
+    hhv_macset_free(ms);
+  }
+  // "clear all backtrace paths" (:108-113): the vectors stay allocated, empty
+  for (size_t i = 0; i < hits.size(); i++) {
+    hits[i]->alt_i->clear();
+    hits[i]->alt_j->clear();
+  }
+  hhv_destroy(ctx);
+}

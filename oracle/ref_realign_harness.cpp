@@ -1,0 +1,187 @@
+// oracle/ref_realign_harness.cpp -- TEST INFRASTRUCTURE (never linked into the product).
+//
+// Drives the realign stage the way HHblits::perform_realign does (src/hhblits.cpp:973-1034): the Viterbi hits of a
+// search (produced here by the reference's OWN ViterbiRunner on the CPU, so that both variants start from identical
+// Hit objects) are handed to PosteriorDecoderRunner::executeComputation as std::vector<Hit*>.
+// Compiled twice into oracle/_ref/libhhref_dropin.so:
+//   - as is:           ref_realign_run_cpu -> the reference's src/hhposteriordecoderrunner.cpp + PosteriorDecoder
+//   - -DHARNESS_HIP:   ref_realign_run_hip -> hh-suite_amd/dropin/hhposteriordecoderrunner_hip.cpp (class renamed by macro)
+#ifdef HARNESS_HIP
+#define PosteriorDecoderRunner PosteriorDecoderRunnerHip
+#define RUN_NAME ref_realign_run_hip
+#else
+#define RUN_NAME ref_realign_run_cpu
+#endif
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hhdatabase.h"
+#include "hhdecl.h"
+#include "hhfunc.h"
+#include "hhhmm.h"
+#include "hhhmmsimd.h"
+#include "hhmatrices.h"
+#include "hhposteriordecoderrunner.h"
+#include "hhviterbimatrix.h"
+#include "hhviterbirunner.h"
+
+namespace {
+
+class MemEntry : public HHEntry {
+ public:
+  MemEntry(int index, const char* name, const char* text, size_t len, int sequence_length)
+      : HHEntry(sequence_length), index(index), name_(name), text_(text), len_(len) {}
+  void getTemplateHMM(Parameters& par, char use_global_weights, const float qsc, int& format, float* pb,
+                      const float S[20][20], const float Sim[20][20], HMM* t) {
+    FILE* f = fmemopen((void*)text_, len_, "r");
+    std::vector<char> nm(name_.begin(), name_.end());
+    nm.push_back('\0');
+    HHEntry::getTemplateHMM(f, nm.data(), par, use_global_weights, qsc, format, pb, S, Sim, t);
+    fclose(f);
+  }
+  char* getName() { return const_cast<char*>(name_.c_str()); }
+  int index;
+
+ private:
+  std::string name_;
+  const char* text_;
+  size_t len_;
+};
+
+}  // namespace
+
+extern "C" {
+
+struct rl_hit {
+  int32_t entry, irep, nsteps, matched_cols, i1, j1, i2, j2, n_alt, state, min_overlap, realign_around_viterbi;
+  float score, score_ss, score_aass, sum_of_probs;
+  double Pforward;
+};
+
+// opts_i: [0] loc [1] altali [2] ssm [3] maxres [4] threads [5] realign every hit with Viterbi score above smin only (0/1)
+// opts_f: [0] smin [1] mact [2] ssw
+// Returns the number of realigned hits (in the order of the Viterbi hit vector) or a negative error.
+int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* tmpl_hhm, const size_t* tmpl_len,
+             const char* const* names, const int32_t* seq_len, const int32_t* opts_i, const float* opts_f,
+             const char* exclstr, const char* template_exclstr, int cap_hits, rl_hit* hits, int path_cap, int32_t* pi,
+             int32_t* pj, int8_t* pstates, float* pS, float* pS_ss, float* pP, int32_t* alt_i, int32_t* alt_j) {
+  Parameters par(0, NULL);
+  Log::reporting_level() = WARNING;
+  par.nocontxt = 1;
+  par.loc = opts_i[0];
+  par.altali = opts_i[1];
+  par.ssm = opts_i[2];
+  par.maxres = opts_i[3];
+  par.threads = opts_i[4];
+  par.smin = opts_f[0];
+  par.mact = opts_f[1];
+  par.ssw = opts_f[2];
+  std::vector<char> ex, tex;
+  if (exclstr && *exclstr) {
+    ex.assign(exclstr, exclstr + strlen(exclstr) + 1);
+    par.exclstr = ex.data();
+  }
+  if (template_exclstr && *template_exclstr) {
+    tex.assign(template_exclstr, template_exclstr + strlen(template_exclstr) + 1);
+    par.template_exclstr = tex.data();
+  }
+  float pb[21];
+  float P[20][20], R[20][20], S[20][20], Sim[20][20];
+  SetSubstitutionMatrix(par.matrix, pb, P, R, S, Sim);
+  static float S73[NDSSP][NSSPRED][MAXCF], S33[NSSPRED][MAXCF][NSSPRED][MAXCF], S37[NSSPRED][MAXCF][NDSSP];
+  SetSecStrucSubstitutionMatrix(par.ssa, S73, S37, S33);
+
+  HMM* q = new HMM(MAXSEQDIS, par.maxres);
+  {
+    FILE* f = fmemopen((void*)query_hhm, query_len, "r");
+    char path[NAMELEN] = "";
+    if (!q->Read(f, par.maxcol, par.nseqdis, pb, path)) {
+      fclose(f);
+      return -1;
+    }
+    fclose(f);
+  }
+  char input_format = 0;
+  PrepareQueryHMM(par, input_format, q, NULL, NULL, pb, R);
+  HMMSimd q_vec(par.maxres);
+  q_vec.MapOneHMM(q);
+
+  std::vector<HHEntry*> entries;
+  int maxL = 0;
+  for (int k = 0; k < n; ++k) {
+    entries.push_back(new MemEntry(k, names[k], tmpl_hhm[k], tmpl_len[k], seq_len[k]));
+    maxL = std::max(maxL, seq_len[k]);
+  }
+  ViterbiMatrix** vm = new ViterbiMatrix*[par.threads];
+  PosteriorMatrix** pm = new PosteriorMatrix*[par.threads];
+  for (int t = 0; t < par.threads; ++t) {
+    vm[t] = new ViterbiMatrix();
+    vm[t]->AllocateBacktraceMatrix(q->L, std::min(maxL, par.maxres));
+    pm[t] = new PosteriorMatrix();
+    pm[t]->allocateMatrix(q->L, maxL + 2);  // src/hhblits.cpp:1020-1023
+  }
+  std::vector<HHblitsDatabase*> dbs;
+  ViterbiRunner viterbi(vm, dbs, 1);  // one thread: deterministic hit order
+  std::vector<Hit> vhits = viterbi.alignment(par, &q_vec, entries, par.qsc_db, pb, S, Sim, R, par.ssm, S73, S33, S37);
+
+  std::vector<Hit*> to_realign;
+  for (size_t h = 0; h < vhits.size(); ++h)
+    if (!opts_i[5] || vhits[h].score > par.smin) to_realign.push_back(&vhits[h]);
+
+  PosteriorDecoderRunner runner(pm, vm, par.threads, par.ssw, S73, S33, S37);
+  runner.executeComputation(*q, to_realign, par, par.qsc_db, pb, S, Sim, R);
+
+  const int m = (int)to_realign.size();
+  for (int h = 0; h < m && h < cap_hits; ++h) {
+    Hit& x = *to_realign[h];
+    rl_hit o;
+    memset(&o, 0, sizeof(o));
+    o.entry = static_cast<MemEntry*>(x.entry)->index;
+    o.irep = x.irep;
+    o.nsteps = x.nsteps;
+    o.matched_cols = x.matched_cols;
+    o.i1 = x.i1;
+    o.j1 = x.j1;
+    o.i2 = x.i2;
+    o.j2 = x.j2;
+    o.n_alt = x.alt_i ? (int)x.alt_i->size() : -1;
+    o.state = x.state;
+    o.min_overlap = x.min_overlap;
+    o.realign_around_viterbi = x.realign_around_viterbi;
+    o.score = x.score;
+    o.score_ss = x.score_ss;
+    o.score_aass = x.score_aass;
+    o.sum_of_probs = x.sum_of_probs;
+    o.Pforward = x.Pforward;
+    hits[h] = o;
+    const int c = std::min(path_cap, x.nsteps + 1);
+    for (int s = 1; s < c; ++s) {
+      const size_t at = (size_t)h * path_cap + s;
+      pi[at] = x.i[s];
+      pj[at] = x.j[s];
+      pstates[at] = x.states[s];
+      pS[at] = x.S[s];
+      pS_ss[at] = x.S_ss[s];
+      pP[at] = x.P_posterior[s];
+    }
+    for (int s = 0; s < o.n_alt && s < path_cap; ++s) {
+      alt_i[(size_t)h * path_cap + s] = x.alt_i->at(s);
+      alt_j[(size_t)h * path_cap + s] = x.alt_j->at(s);
+    }
+  }
+  for (size_t h = 0; h < vhits.size(); ++h) vhits[h].Delete();
+  for (int t = 0; t < par.threads; ++t) {
+    delete vm[t];
+    delete pm[t];
+  }
+  delete[] vm;
+  delete[] pm;
+  for (int k = 0; k < n; ++k) delete entries[k];
+  delete q;
+  return m;
+}
+
+}  // extern "C"

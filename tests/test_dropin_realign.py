@@ -1,0 +1,105 @@
+"""The drop-in translation unit hh-suite_amd/dropin/hhposteriordecoderrunner_hip.cpp against the reference's own
+src/hhposteriordecoderrunner.cpp (+ PosteriorDecoder): both define PosteriorDecoderRunner::executeComputation with the
+signature of src/hhposteriordecoderrunner.h and are driven by oracle/ref_realign_harness.cpp the way
+HHblits::perform_realign drives them: std::vector<Hit*> of Viterbi hits in, the same Hit objects realigned in place."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from test_dropin_runner import _lib, make_db
+
+
+class RLHit(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("entry", "irep", "nsteps", "matched_cols", "i1", "j1", "i2", "j2", "n_alt",
+                                               "state", "min_overlap", "realign_around_viterbi")] + \
+               [(n, ctypes.c_float) for n in ("score", "score_ss", "score_aass", "sum_of_probs")] + [("Pforward", ctypes.c_double)]
+
+
+def realign(which, query, templates, names, loc=1, altali=3, ssm=2, maxres=2000, threads=1, only_above_smin=1, smin=20.0,
+            mact=0.3501, ssw=0.11, excl="", texcl="", path_cap=1400):
+    lib = _lib()
+    fn = getattr(lib, "ref_realign_run_" + which)
+    n = len(templates)
+    cap = n * max(1, altali)
+    hits = (RLHit * cap)()
+    arrs = [np.zeros((cap, path_cap), dtype=dt) for dt in (np.int32, np.int32, np.int8, np.float32, np.float32, np.float32,
+                                                           np.int32, np.int32)]
+    texts = (ctypes.c_char_p * n)(*templates)
+    lens = (ctypes.c_size_t * n)(*[len(t) for t in templates])
+    nm = (ctypes.c_char_p * n)(*[x.encode() for x in names])
+    sl = np.asarray([int(t.split(b"LENG")[1].split()[0]) for t in templates], dtype=np.int32)
+    oi = np.asarray([loc, altali, ssm, maxres, threads, only_above_smin], dtype=np.int32)
+    of = np.asarray([smin, mact, ssw], dtype=np.float32)
+    P = ctypes.c_void_p
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, P, P, P, P, P, P, ctypes.c_char_p, ctypes.c_char_p,
+                   ctypes.c_int, P, ctypes.c_int] + [P] * 8
+    m = fn(query, len(query), n, ctypes.cast(texts, P), ctypes.cast(lens, P), ctypes.cast(nm, P), sl.ctypes.data,
+           oi.ctypes.data, of.ctypes.data, excl.encode(), texcl.encode(), cap, ctypes.cast(hits, P), path_cap,
+           *[a.ctypes.data for a in arrs])
+    assert 0 <= m <= cap, m
+    return [hits[k] for k in range(m)], [a[:m] for a in arrs]
+
+
+def compare(a, b):
+    ha, hb = a[0], b[0]
+    assert len(ha) == len(hb), (len(ha), len(hb))
+    for k, (x, y) in enumerate(zip(ha, hb)):
+        for f, _ in RLHit._fields_:
+            vx, vy = getattr(x, f), getattr(y, f)
+            assert vx == vy or (vx != vx and vy != vy), (k, f, vx, vy, x.entry, x.irep)
+        ns = x.nsteps
+        for arr in range(6):
+            assert np.array_equal(a[1][arr][k][1:ns + 1], b[1][arr][k][1:ns + 1], equal_nan=(arr >= 3)), (k, arr, x.entry, x.irep)
+        for arr in (6, 7):
+            assert np.array_equal(a[1][arr][k][:x.n_alt], b[1][arr][k][:x.n_alt]), (k, arr, x.entry, x.irep)
+    return len(ha)
+
+
+def test_reference_realign_on_hhm_texts():
+    """CPU only: the harness drives the reference's realign stage; MAC alignments exist and alternative alignments of one
+    template do not overlap.  (Validates the test data, not the product.)"""
+    q, t, names = make_db(61, 120, 10, 60, 160)
+    hits, arrs = realign("cpu", q, t, names)
+    assert len(hits) >= 5 and any(h.irep > 1 for h in hits)
+    for k, h in enumerate(hits):
+        assert h.nsteps >= 1 and h.n_alt == 0 and h.realign_around_viterbi == 1   # alt_i / alt_j are emptied at the end
+        assert 0.0 < h.sum_of_probs <= h.nsteps + 1e-3
+    by_entry = {}
+    for k, h in enumerate(hits):
+        cells = set(zip(arrs[0][k][1:h.nsteps + 1].tolist(), arrs[1][k][1:h.nsteps + 1].tolist()))
+        assert not (cells & by_entry.get(h.entry, set()))
+        by_entry.setdefault(h.entry, set()).update(cells)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loc,threads,only", [(1, 1, 1), (1, 4, 0), (0, 2, 1)])
+def test_dropin_realign_equals_reference(loc, threads, only):
+    L = (80, 80) if loc == 0 else (40, 260)   # global mode: one template length (no Viterbi batch quirk in the inputs)
+    q, t, names = make_db(70 + loc, 150, 36, L[0], L[1])
+    ref = realign("cpu", q, t, names, loc=loc, threads=1, only_above_smin=only)
+    got = realign("hip", q, t, names, loc=loc, threads=threads, only_above_smin=only)
+    n = compare(ref, got)
+    assert n >= 10
+
+
+@pytest.mark.gpu
+def test_dropin_realign_excluded_regions_and_mact():
+    q, t, names = make_db(75, 140, 20, 60, 220)
+    for mact in (0.3501, 0.1, 0.6):
+        ref = realign("cpu", q, t, names, mact=mact, excl="10-30", texcl="5-25")
+        got = realign("hip", q, t, names, mact=mact, excl="10-30", texcl="5-25")
+        compare(ref, got)
+
+
+@pytest.mark.gpu
+def test_dropin_realign_pred_pred_ss_is_a_noop():
+    """query and templates with predicted SS only: hit.ssm2 = 3, for which Viterbi::ScoreSS has no case (MAC scores no SS)"""
+    q, t, names = make_db(77, 130, 24, 50, 200, ss_every=1, query_ss=True)
+    t = [x.replace(b">ss_dssp", b">xx_dssp") for x in t]          # drop the DSSP records: PRED_PRED only
+    q = q.replace(b">ss_dssp", b">xx_dssp")
+    ref = realign("cpu", q, t, names, ssm=2)
+    got = realign("hip", q, t, names, ssm=2)
+    compare(ref, got)
