@@ -13,6 +13,8 @@
 #define RUN_NAME ref_realign_run_cpu
 #endif
 
+#include <sys/time.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -67,7 +69,8 @@ struct rl_hit {
 int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* tmpl_hhm, const size_t* tmpl_len,
              const char* const* names, const int32_t* seq_len, const int32_t* opts_i, const float* opts_f,
              const char* exclstr, const char* template_exclstr, int cap_hits, rl_hit* hits, int path_cap, int32_t* pi,
-             int32_t* pj, int8_t* pstates, float* pS, float* pS_ss, float* pP, int32_t* alt_i, int32_t* alt_j) {
+             int32_t* pj, int8_t* pstates, float* pS, float* pS_ss, float* pP, int32_t* alt_i, int32_t* alt_j,
+             double* realign_seconds) {
   Parameters par(0, NULL);
   Log::reporting_level() = WARNING;
   par.nocontxt = 1;
@@ -132,7 +135,11 @@ int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* 
     if (!opts_i[5] || vhits[h].score > par.smin) to_realign.push_back(&vhits[h]);
 
   PosteriorDecoderRunner runner(pm, vm, par.threads, par.ssw, S73, S33, S37);
+  struct timeval t0, t1;
+  gettimeofday(&t0, NULL);
   runner.executeComputation(*q, to_realign, par, par.qsc_db, pb, S, Sim, R);
+  gettimeofday(&t1, NULL);
+  if (realign_seconds) *realign_seconds = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
 
   const int m = (int)to_realign.size();
   for (int h = 0; h < m && h < cap_hits; ++h) {

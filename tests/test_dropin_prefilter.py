@@ -31,7 +31,7 @@ def write_ffindex(tmp, seqs, offs, dup_every=0):
     return fd, fi, names
 
 
-def prefilter_db(which, fd, fi, qp, pav, previous=(), threads=1, **kw):
+def prefilter_db(which, fd, fi, qp, pav, previous=(), threads=1, reps=1, **kw):
     from pyhhv import capi
     par = dict(capi.PREFILTER_DEFAULTS)
     par.update(kw)
@@ -41,13 +41,16 @@ def prefilter_db(which, fd, fi, qp, pav, previous=(), threads=1, **kw):
     dpar = np.asarray([par["evalue_thresh"], par["evalue_coarse_thresh"]], dtype=np.float64)
     cap = 1 << 22
     new_out, old_out = C.create_string_buffer(cap), C.create_string_buffer(cap)
-    new_len, old_len = np.zeros(1 << 16, dtype=np.int32), np.zeros(1 << 16, dtype=np.int32)
+    new_len, old_len = np.zeros(1 << 20, dtype=np.int32), np.zeros(1 << 20, dtype=np.int32)
     prev = (C.c_char_p * max(1, len(previous)))(*[p.encode() for p in previous])
     fn.restype = C.c_int
     P = C.c_void_p
-    fn.argtypes = [C.c_char_p, C.c_char_p, P, P, C.c_int, P, P, C.c_int, P, P, P, P, P, C.c_int]
+    fn.argtypes = [C.c_char_p, C.c_char_p, P, P, C.c_int, P, P, C.c_int, P, P, P, P, P, C.c_int, C.c_int, P]
+    secs = C.c_double(0.0)
     r = fn(fd.encode(), fi.encode(), qp.ctypes.data, pav.ctypes.data, qp.shape[0], ipar.ctypes.data, dpar.ctypes.data,
-           len(previous), C.cast(prev, P), C.cast(new_out, P), new_len.ctypes.data, C.cast(old_out, P), old_len.ctypes.data, cap)
+           len(previous), C.cast(prev, P), C.cast(new_out, P), new_len.ctypes.data, C.cast(old_out, P), old_len.ctypes.data, cap,
+           reps, C.addressof(secs))
+    prefilter_db.last_seconds = secs.value
     assert r >= 0, r
     n_new, n_old = r & 0xFFFFF, r >> 20
     new = list(zip(new_out.value.decode().split("\n")[:-1], new_len[:n_new].tolist()))

@@ -35,11 +35,13 @@ def realign(which, query, templates, names, loc=1, altali=3, ssm=2, maxres=2000,
     P = ctypes.c_void_p
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, P, P, P, P, P, P, ctypes.c_char_p, ctypes.c_char_p,
-                   ctypes.c_int, P, ctypes.c_int] + [P] * 8
+                   ctypes.c_int, P, ctypes.c_int] + [P] * 9
+    secs = ctypes.c_double(0.0)
     m = fn(query, len(query), n, ctypes.cast(texts, P), ctypes.cast(lens, P), ctypes.cast(nm, P), sl.ctypes.data,
            oi.ctypes.data, of.ctypes.data, excl.encode(), texcl.encode(), cap, ctypes.cast(hits, P), path_cap,
-           *[a.ctypes.data for a in arrs])
+           *([a.ctypes.data for a in arrs] + [ctypes.addressof(secs)]))
     assert 0 <= m <= cap, m
+    realign.last_seconds = secs.value
     return [hits[k] for k in range(m)], [a[:m] for a in arrs]
 
 

@@ -166,6 +166,33 @@ def test_dropin_resident_cache():
 
 
 @pytest.mark.gpu
+def test_dropin_concurrent_searches_share_the_cache():
+    """hhblits_omp: several queries search the same database from different threads of one process.  The cache and the
+    device context are shared, device sections are serialised, reading is not - every search must still return the
+    reference's hits (ctypes releases the GIL, so the four calls really overlap)."""
+    import threading
+    cache_clear()
+    _, t, names = make_db(91, 150, 120, 40, 260)
+    queries = [make_db(92 + k, 120 + 15 * k, 1, 50, 50)[0] for k in range(4)]
+    refs = [run("cpu", q, t, names, altali=2) for q in queries]
+    for rnd in range(2):                       # round 0: cold cache, all four read; round 1: warm
+        got = [None] * 4
+
+        def work(k):
+            got[k] = run("hip", queries[k], t, names, altali=2, threads=2)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        for k in range(4):
+            assert got[k] is not None
+            compare(refs[k], got[k])
+    assert cache_stats()[0] == 120
+    cache_clear()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pcm,columnscore", [(3, -1), (0, 0), (1, 2), (2, 3), (-1, 4)])
 def test_dropin_preparation_variants(pcm, columnscore):
     """pseudocount modes / null models: 0..2 / 0..3 are prepared on the device, the others by the reference's host code
