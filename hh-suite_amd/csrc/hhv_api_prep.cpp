@@ -1,6 +1,8 @@
 // hhv_api_prep.cpp -- C ABI of the on-device PrepareTemplateHMM and the raw template database file.
 #include "hhv_api_common.h"
 
+#include <chrono>
+#include <memory>
 #include <thread>
 
 using namespace hhv;
@@ -12,16 +14,30 @@ extern "C" {
 
 // ---- on-device PrepareTemplateHMM (N2) ---------------------------------------------------------------
 void hhv_rawset_free(hhv_rawset* rs);
+// a float buffer that is not value-initialised (std::vector would zero hundreds of megabytes first)
+namespace {
+struct RawBlock {
+  std::unique_ptr<float[]> p;
+  size_t n = 0;
+  void resize(size_t m) {
+    p.reset(new float[m]);
+    n = m;
+  }
+  float* data() { return p.get(); }
+  size_t size() const { return n; }
+};
+}  // namespace
+
 // raw HMMs -> the 32-dword raw column block the prepare kernels read (hhv_internal.h RAW_*)
 static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, const float* const* tr, const float* const* neff,
                            const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp,
-                           std::vector<float>* host) {
+                           RawBlock* host) {
   int64_t off = 0;
   for (int k = 0; k < n; ++k) {
     if (L[k] < 1 || L[k] > 0xFFFF || !f[k] || !tr[k] || !neff[k]) return fail(HHV_E_ARG, "raw template %d invalid", k);
     off += (int64_t)L[k] + 1;
   }
-  host->assign((size_t)off * RAW_DW, 0.0f);
+  host->resize((size_t)off * RAW_DW);  // every dword of a column block is written below: no zero fill of ~1 GB
   std::vector<int64_t> start((size_t)n + 1, 0);
   for (int k = 0; k < n; ++k) start[k + 1] = start[k] + (int64_t)L[k] + 1;
   auto fill = [&](int k0, int k1) {
@@ -122,10 +138,18 @@ int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const floa
   if (!c || !L || !f || !tr || !neff || !neff_hmm || !out) return fail(HHV_E_ARG, "hhv_upload_raw_templates: null argument");
   if (n < 1) return fail(HHV_E_ARG, "hhv_upload_raw_templates: n = %d", n);
   *out = nullptr;
-  std::vector<float> host;
+  RawBlock host;
+  const bool timing = getenv("HHV_API_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   const int rc = build_raw_block(n, L, f, tr, neff, ss_pred, ss_conf, ss_dssp, &host);
   if (rc != HHV_OK) return rc;
-  return rawset_from_block(c, n, L, neff_hmm, host.data(), host.size(), out);
+  const auto t1 = std::chrono::steady_clock::now();
+  const int rc2 = rawset_from_block(c, n, L, neff_hmm, host.data(), host.size(), out);
+  if (timing)
+    fprintf(stderr, "hhv_upload_raw_templates: %d templates, %.1f MB: pack %.1f ms, allocate + copy %.1f ms\n", n,
+            host.size() * 4e-6, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  return rc2;
 }
 
 // Raw template database file (N1 for the N2 path): header, lengths, Neff_HMM, then the raw column block exactly as it
@@ -145,7 +169,7 @@ int hhv_rawdb_write(const char* path, int32_t n, const int32_t* L, const float* 
                     const float* const* neff, const float* neff_hmm, const int8_t* const* ss_pred,
                     const int8_t* const* ss_conf, const int8_t* const* ss_dssp) {
   if (!path || !L || !f || !tr || !neff || !neff_hmm || n < 1) return fail(HHV_E_ARG, "hhv_rawdb_write: bad argument");
-  std::vector<float> host;
+  RawBlock host;
   const int rc = build_raw_block(n, L, f, tr, neff, ss_pred, ss_conf, ss_dssp, &host);
   if (rc != HHV_OK) return rc;
   FILE* fp = fopen(path, "wb");

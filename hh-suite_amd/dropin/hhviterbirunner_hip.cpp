@@ -638,12 +638,20 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                         "hhv_upload_raw_templates");
               tc.rawsets.push_back(rs);
               tc.columns += cols;
-              for (int x = 0; x < n; ++x) {
-                HostTemplate& h = host[raw_r[x]];
+              std::vector<CachedTemplate*> slot(n);
+              for (int x = 0; x < n; ++x) {  // std::unordered_map never moves its elements
                 CachedTemplate& ct = tc.map[cache_key(ent[raw_k[x]])];
                 if (ct.raw) ct.proto.Delete();  // the same key twice (two searches read it concurrently): the later upload wins
                 ct.raw = rs;
                 ct.index = x;
+                slot[x] = &ct;
+                cached[raw_k[x]] = &ct;
+              }
+#pragma omp parallel for schedule(static) num_threads(threads) if (n > 256)
+              for (int x = 0; x < n; ++x) {
+                HostTemplate& h = host[raw_r[x]];
+                CachedTemplate& ct = *slot[x];
+                if (ct.index != x) continue;  // a duplicate key inside this chunk: the last one filled the slot
                 ct.L = h.L;
                 ct.ss_pair_mode = h.ss_pair_mode;
                 copy_template_info(hit0[raw_k[x]], &ct.proto);
@@ -651,7 +659,6 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 ct.ss.pred.swap(h.ss.pred);
                 ct.ss.conf.swap(h.ss.conf);
                 ct.ss.dssp.swap(h.ss.dssp);
-                cached[raw_k[x]] = &ct;
               }
             }
             timer.lap(PhaseTimer::UPLOAD);
