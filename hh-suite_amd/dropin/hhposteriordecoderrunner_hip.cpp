@@ -23,7 +23,10 @@
 // else): hits with secondary-structure scoring against DSSP states inside MAC (hit.ssm2 = 1 or 2 - query with predicted
 // SS against templates with DSSP records, or the reverse; ssm2 = 3 is a no-op in the reference, Viterbi::ScoreSS has no
 // case 3), self alignments (hit.self), templates longer than 2046 columns.
+#include <sys/time.h>
+
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +38,12 @@
 #endif
 
 namespace {
+
+double mac_now() {
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
 
 void mac_check(int rc, const char* what) {
   if (rc == HHV_OK) return;
@@ -58,6 +67,11 @@ std::vector<int32_t> mac_region_pairs(char* exclstr) {  // exclude_regions, src/
   }
   return out;
 }
+
+// One device context per process, created at the first realignment and kept (stream, tables and the recycled device
+// block of the MAC stage survive from call to call); concurrent callers (hhblits_omp) take turns on it.
+std::mutex g_mac_device;
+hhv_ctx* g_mac_ctx = NULL;
 
 struct PreparedTemplate {
   int L;
@@ -92,6 +106,8 @@ void PosteriorDecoderRunner::initializeQueryHMMTransitions(HMM& q) {
 
 void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, Parameters& par, const float qsc, float* pb,
                                                 const float S[20][20], const float Sim[20][20], const float R[20][20]) {
+  const bool timing = getenv("HHV_DROPIN_TIMING") != NULL;  // prints where the wall time goes (stderr)
+  double t_mark = mac_now(), t_read = 0, t_create = 0, t_device = 0, t_hits = 0;
   HMM* q_hmm = &q;
   q_hmm->Log2LinTransitionProbs(1.0);       // :48
   initializeQueryHMMTransitions(*q_hmm);    // :50
@@ -162,6 +178,8 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
     pt.conf.assign(t->ss_conf, t->ss_conf + t->L + 1);
   }
   for (int k = 0; k < threads; ++k) delete t_hmm[k];
+  t_read = mac_now() - t_mark;
+  t_mark = mac_now();
 
   // ---- the query as the device wants it ----
   std::vector<float> q_p((size_t)(q.L + 1) * 20, 0.0f), q_tr((size_t)(q.L + 1) * 7);
@@ -171,15 +189,17 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   }
   std::vector<int32_t> q_ranges = mac_region_pairs(par.exclstr), t_ranges = mac_region_pairs(par.template_exclstr);
 
-  hhv_params hp;
-  memset(&hp, 0, sizeof(hp));
-  const char* dev = getenv("HHV_DEVICE");
-  hp.device = dev ? atoi(dev) : 0;
-  hp.local = par.loc;
-  hp.shift = par.shift;
-  hp.corr = par.corr;
-  hhv_ctx* ctx = NULL;
-  mac_check(hhv_create(&ctx, &hp), "hhv_create");
+  std::lock_guard<std::mutex> device_lock(g_mac_device);
+  if (!g_mac_ctx) {
+    hhv_params hp;
+    memset(&hp, 0, sizeof(hp));
+    const char* dev = getenv("HHV_DEVICE");
+    hp.device = dev ? atoi(dev) : 0;
+    hp.local = 1;
+    mac_check(hhv_create(&g_mac_ctx, &hp), "hhv_create");
+  }
+  hhv_ctx* ctx = g_mac_ctx;
+  t_create = mac_now() - t_mark;
 
   // ---- round r: the r-th alignment of every template ----
   for (size_t r = 0; r < rounds; ++r) {
@@ -217,10 +237,13 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
     }
     hhv_macset* ms = NULL;
     std::vector<hhv_mac_hit> res(n);
+    t_mark = mac_now();
     mac_check(hhv_mac_realign_hits(ctx, q_p.data(), q_tr.data(), q.L, n, Lt.data(), tp.data(), ttr.data(), in.data(),
                                    (int32_t)q_ranges.size() / 2, q_ranges.data(), (int32_t)t_ranges.size() / 2, t_ranges.data(),
                                    par.loc, par.shift, par.mact, &ms, res.data()),
               "hhv_mac_realign_hits");
+    t_device += mac_now() - t_mark;
+    t_mark = mac_now();
     for (int b = 0; b < n; ++b) {
       const int g = group_of[b];
       Hit& hit = *alignment[g][r];
@@ -289,11 +312,15 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
       // score, score_ss, score_aass, Pval, Pvalt, logPval, logPvalt, Eval, logEval, Probab: untouched = restoreHitValues
     }
     hhv_macset_free(ms);
+    t_hits += mac_now() - t_mark;
   }
+  if (timing)
+    fprintf(stderr, "hhposteriordecoderrunner_hip: %zu hits of %d templates in %zu rounds; read+prepare %.3f s, context %.3f s, "
+            "device (staging, masks, forward/backward/MAC, paths) %.3f s, Hit objects %.3f s\n", hits.size(), n_groups, rounds,
+            t_read, t_create, t_device, t_hits);
   // "clear all backtrace paths" (:108-113): the vectors stay allocated, empty
   for (size_t i = 0; i < hits.size(); i++) {
     hits[i]->alt_i->clear();
     hits[i]->alt_j->clear();
   }
-  hhv_destroy(ctx);
 }
