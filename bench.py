@@ -320,6 +320,18 @@ def next_rows():
                                  "mismatches_vs_reference": r.get("mismatches_vs_reference"), "checked": r.get("checked")}
     except Exception as e:
         out["N4_mac_realign"] = {"error": repr(e)}
+    try:
+        # the boundary itself: ViterbiRunner::alignment of the reference (its own translation unit, all host cores it asks
+        # for) against the drop-in translation unit, wall time of the call, hits compared (tools/bench_dropin.py)
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhhref_dropin.so")):
+            import bench_dropin
+            r = bench_dropin.run(4000, 32, 300, altalis=(1,))
+            a = r["altali1"]
+            out["dropin_ViterbiRunner_alignment"] = {"templates": r["n_templates"], "Lq": r["L"], "Lt": r["L"], "host_threads": r["threads"],
+                                                     "reference_s": a["reference_s"], "dropin_cold_cache_s": a["dropin_cold_cache_s"],
+                                                     "dropin_warm_cache_s": a["dropin_warm_cache_s"], "hits_identical": a["hits_identical"]}
+    except Exception as e:
+        out["dropin_ViterbiRunner_alignment"] = {"error": repr(e)}
     return out
 
 
