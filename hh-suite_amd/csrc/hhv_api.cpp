@@ -548,6 +548,26 @@ int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
   return HHV_OK;
 }
 
+int hhv_set_global_batch(hhv_ctx* c, hhv_tset* ts, const uint8_t* not_longest) {
+  if (!c || !ts) return fail(HHV_E_ARG, "hhv_set_global_batch: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_set_global_batch: template set belongs to another context");
+  if (!ts->owns_records) return fail(HHV_E_STATE, "hhv_set_global_batch: the set uses an adopted stream buffer, which is not modified");
+  HIP_TRY(hipSetDevice(c->par.device));
+  unsigned char* d_flags = nullptr;
+  if (not_longest) {
+    HIP_TRY(hipMalloc(&d_flags, (size_t)ts->n));
+    if (hipMemcpyAsync(d_flags, not_longest, (size_t)ts->n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      dfree(d_flags);
+      return fail(HHV_E_DEVICE, "hhv_set_global_batch: H2D copy failed");
+    }
+  }
+  const int lr = set_header_flags(ts->d_records, ts->d_rec_off, d_flags, ts->n, c->stream);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  dfree(d_flags);
+  if (lr != 0 || e != hipSuccess) return fail(HHV_E_DEVICE, "hhv_set_global_batch: kernel failed");
+  return HHV_OK;
+}
+
 int hhv_set_celloff_paths(hhv_ctx* c, hhv_tset* ts, int32_t n_paths, const int32_t* template_of, const int64_t* path_off,
                           const int32_t* i_steps, const int32_t* j_steps, int32_t n_qranges, const int32_t* qranges,
                           int32_t n_tranges, const int32_t* tranges) {

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         bnd.DG = c.w;
         bnd.MI = a.carry_mi[rb + r];
         if (meta < 0 && st.tid >= 0) {
-          const DevResult pr = a.results[st.tid];
+          const DevResult pr = a.results[st.tid & TID_MASK];
           bnd.fs = pr.score;
           bnd.fpos = (pr.i2 << 16) | pr.j2;
         }
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     if (active) {
       if (meta < 0) {
         TemplateResult res;
-        const int new_tid = __builtin_bit_cast(int32_t, rec[0]);
+        const int new_tid = __builtin_bit_cast(int32_t, rec[0]) | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
         if (lane_header<R, LOCAL, true>(st, q, in, i0, new_tid, P, lane == g_last, res)) {
           DevResult o;
           o.score = res.score;

@@ -162,6 +162,22 @@ int tset_gather(const float* src, const int64_t* src_off, const int32_t* ids, co
 
 }  // namespace hhv
 
+// ---- global mode: which templates are shorter than the longest of their SIMD batch in the reference ----------------------
+namespace hhv {
+__global__ void __launch_bounds__(256) header_flag_kernel(float* __restrict__ records, const int64_t* __restrict__ rec_off,
+                                                          const unsigned char* __restrict__ flags, int n) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  int32_t* meta = reinterpret_cast<int32_t*>(records + (size_t)rec_off[k] * REC_DW + REC_META);
+  *meta = META_HDR | ((flags && flags[k]) ? META_NOLASTCOL : 0);
+}
+int set_header_flags(float* records, const int64_t* rec_off, const unsigned char* flags, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(header_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, records, rec_off, flags, n);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+}  // namespace hhv
+
 // ---- cell-off masks of the alternative-alignment rounds, built on the device ------------------------------------------
 // Viterbi::ExcludeAlignment (src/hhviterbi.cpp:61-77): for every step but the last of an earlier alignment, the cells
 // (i +- 40, j) and (i, j +- 40) are switched off.  The mask is an input of the stream kernel: bit 7 of byte r of the

@@ -45,6 +45,12 @@ constexpr int REC_M2M = 20, REC_M2D = 21, REC_D2M = 22, REC_D2D = 23, REC_I2M = 
               REC_META = 27;
 constexpr int32_t META_HDR = (int32_t)0x80000000;  // header record: [0] = template index, [1] = Lt
 constexpr int32_t META_LAST = 0x40000000;          // column record of j == Lt
+// header record only: global mode, the template's own last column does not take part in the maximisation (it is not the
+// last column of its SIMD batch in the reference, src/hhviterbialgorithm.cpp:462-486 - see hhv_set_global_batch).  Carried
+// through the template in bit 30 of LaneState::tid (template indices stay below 2^30).
+constexpr int32_t META_NOLASTCOL = 0x20000000;
+constexpr int32_t TID_NOLASTCOL = 0x40000000;
+constexpr int32_t TID_MASK = 0x3FFFFFFF;
 constexpr int32_t META_JMASK = 0x0000FFFF;         // j (template lengths are limited to 65535)
 // secondary-structure indices of template column j, exactly the per-column bytes HMMSimd::MapHMMVector
 // precomputes (src/hhhmmsimd.cpp:132-135): pred_index = ss_pred*MAXCF + ss_conf (0..43), dssp_index = ss_dssp (0..7)
@@ -246,7 +252,7 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
           cs = st.bs[0];
           cj = st.bj[0];
         } else {
-          cs = st.MM[r];
+          cs = (st.tid & TID_NOLASTCOL) ? NEG_MAX : st.MM[r];  // NEG_MAX never wins the strict '>' below
           cj = st.jlast;
         }
       }
@@ -262,7 +268,7 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
       res.score = st.fs;
       res.i2 = st.fpos >> 16;
       res.j2 = st.fpos & 0xFFFF;
-      res.tid = st.tid;
+      res.tid = st.tid & TID_MASK;
       emit = true;
     }
   }

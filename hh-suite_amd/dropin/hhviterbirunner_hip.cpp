@@ -39,9 +39,8 @@
 //     the prototype instead of calling initHitFromHMM on a freshly read HMM
 //   * hits come back in the order of the sorted block (= the reference's order with one thread; with several
 //     threads the reference's order depends on the OpenMP schedule)
-//   * global mode (par.loc = 0): every template is maximised over its OWN last column; the reference maximises over
-//     the last column of the longest template of the SIMD batch (SURVEY.md 8a, row A1 "batch-composition quirk"),
-//     so results differ for the shorter templates of mixed-length batches.  Local mode (the default) is unaffected.
+//   (global mode, par.loc = 0: the reference maximises over the last column of the LONGEST template of each SIMD batch, SURVEY.md 8a
+//   row A1; the batches are rebuilt here and the shorter templates marked with hhv_set_global_batch: same results.)
 // Errors follow the reference's convention at this layer: HH_LOG(ERROR) + exit(code) (src/hhsearch.h:6).
 #include <sys/time.h>
 
@@ -335,7 +334,7 @@ struct Search {
   // Aligns n templates of one resident set with one ss mode (device section).  ids: their indices in the set (NULL =
   // the whole set in set order); tmpl[k] / out[k]: resident record and Hit (template information already set) of the k-th.
   void run(hhv_tset* set, const int32_t* ids, int n, int ss_hmm_mode, const std::vector<const ResidentTemplate*>& tmpl,
-           const std::vector<Hit*>& out) {
+           const std::vector<Hit*>& out, const std::vector<uint8_t>& not_longest) {
     hhv_ctx* ctx = tc.ctx;
     hhv_tset* ts = set;
     hhv_tset* sub = NULL;
@@ -345,6 +344,8 @@ struct Search {
       ts = sub;
     }
     hip_check(hhv_set_ss_mode(ctx, ss_hmm_mode), "hhv_set_ss_mode");
+    // global mode: the shorter templates of a SIMD batch of the reference do not see their own last column (:462-486)
+    if (!par.loc) hip_check(hhv_set_global_batch(ctx, ts, not_longest.data()), "hhv_set_global_batch");
     bool masked = regions;
     if (!excludeAlignments.empty() || regions) {
       // exclude_alignments (:273-289): every earlier alignment of a template of the same name (also inside round
@@ -727,12 +728,19 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
 
         // ---- the ss mode of every SIMD batch of the reference (:14-22), then one launch per (set, mode) ----
         std::vector<int> batch_mode(cn);
+        std::vector<uint8_t> shorter(cn, 0);  // shorter than the longest template of its batch (HMMSimd::L, src/hhhmmsimd.cpp:97)
         for (unsigned int b = 0; b < cn; b += VECSIZE_FLOAT) {
-          int consensus = 0xFF;
+          int consensus = 0xFF, Lbatch = 0;
           const unsigned int e = imin(cn, b + VECSIZE_FLOAT);
-          for (unsigned int k = b; k < e; ++k) consensus &= resident[ent[k]].ss_pair_mode;
+          for (unsigned int k = b; k < e; ++k) {
+            consensus &= resident[ent[k]].ss_pair_mode;
+            Lbatch = imax(Lbatch, resident[ent[k]].L);
+          }
           const int mode = select_ss_mode(consensus);
-          for (unsigned int k = b; k < e; ++k) batch_mode[k] = mode;
+          for (unsigned int k = b; k < e; ++k) {
+            batch_mode[k] = mode;
+            shorter[k] = resident[ent[k]].L < Lbatch;
+          }
         }
         std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> > groups;
         for (unsigned int k = 0; k < cn; ++k) groups[std::make_pair(resident[ent[k]].set, batch_mode[k])].push_back(k);
@@ -747,14 +755,16 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
             std::vector<int32_t> ids(n);
             std::vector<const ResidentTemplate*> tmpl(n);
             std::vector<Hit*> out(n);
+            std::vector<uint8_t> not_longest(n);
             bool whole = (n == hhv_tset_size(g->first.first));
             for (int k = 0; k < n; ++k) {
               tmpl[k] = &resident[ent[mem[k]]];
               ids[k] = tmpl[k]->index;
               out[k] = &hit0[mem[k]];
+              not_longest[k] = shorter[mem[k]];
               whole = whole && ids[k] == k;
             }
-            search.run(g->first.first, whole ? NULL : ids.data(), n, g->first.second, tmpl, out);
+            search.run(g->first.first, whole ? NULL : ids.data(), n, g->first.second, tmpl, out, not_longest);
           }
         }
       }

@@ -1,6 +1,8 @@
 // prefilter.cpp -- see prefilter.h.  Host-side selection logic of the HHblits prefilter around the GPU kernels.
 #include "prefilter.h"
 
+#include <chrono>
+
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -208,9 +210,16 @@ int Prefilter::prefilter_db(const float* q_p, const float* q_pav, int Lq, const 
   selected->clear();
   if (evalues) evalues->clear();
   if (!db_) return HHV_E_ARG;
+  const bool timing = getenv("HHV_API_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
   const int n_db = (int)length_.size();
   std::vector<uint8_t> plain((size_t)220 * Lq);
   PrefilterQueryProfile(q_p, q_pav, lib_.data(), Lq, par.score_offset, par.bit_factor, plain.data());
+  const double ms_profile = since(t0);
+  const auto t1 = std::chrono::steady_clock::now();
   // stage 1 entirely on the GPU: gapless score of every sequence, length correction, sort, cut (SelectFirst is the
   // host statement of the same rule); only the surviving ids come back
   std::vector<int32_t> subset(n_db);
@@ -219,6 +228,8 @@ int Prefilter::prefilter_db(const float* q_p, const float* q_pav, int Lq, const 
                                par.min_hits, subset.data(), n_db, &n_sub);
   if (rc != HHV_OK) return rc;
   subset.resize(n_sub);
+  const double ms_first = since(t1);
+  const auto t2 = std::chrono::steady_clock::now();
   if (passed_first) *passed_first = (int)subset.size();
   if (subset.empty()) return HHV_OK;
   // stage 2: Smith-Waterman of the survivors on the GPU
@@ -226,7 +237,12 @@ int Prefilter::prefilter_db(const float* q_p, const float* q_pav, int Lq, const 
   rc = hhv_prefilter_scores(ctx_, db_, plain.data(), Lq, par.score_offset, 1, par.gap_open + par.gap_extend, par.gap_extend,
                             subset.data(), (int32_t)subset.size(), sw.data());
   if (rc != HHV_OK) return rc;
+  const double ms_sw = since(t2);
+  const auto t3 = std::chrono::steady_clock::now();
   SelectSecond(sw.data(), subset.data(), (int)subset.size(), length_.data(), n_db, Lq, par, selected, evalues);
+  if (timing)
+    fprintf(stderr, "hhv::Prefilter::prefilter_db: %d sequences, Lq %d: profile %.2f ms, first stage (device) %.2f ms -> %d, "
+            "Smith-Waterman %.2f ms, selection %.2f ms -> %zu\n", n_db, Lq, ms_profile, ms_first, n_sub, ms_sw, since(t3), selected->size());
   return HHV_OK;
 }
 

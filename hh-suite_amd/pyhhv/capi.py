@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
-    "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_backtrace_matrix", "hhv_hits",
+    "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk",
 ]
 
@@ -95,6 +95,9 @@ def load():
     L.hhv_set_ss_tables.argtypes = [C.c_void_p, c_float_p, c_float_p, c_float_p]
     L.hhv_set_query_ss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_set_ss_mode.argtypes = [C.c_void_p, C.c_int32]
+    L.hhv_set_global_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hhv_set_params.argtypes = [C.c_void_p, C.POINTER(HhvParams)]
+    L.hhv_hit_path_pool.argtypes = [C.c_void_p, C.c_void_p] + [C.POINTER(C.c_void_p)] * 5
     L.hhv_adopt_device_stream.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.c_void_p, C.POINTER(C.c_void_p)]
     vpp = C.POINTER(C.c_void_p)
     L.hhv_upload_raw_templates.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
@@ -494,6 +497,15 @@ class Context:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         assert m.shape == (self.Lq + 1, int(ts.L[k]) + 1)
         _check(self.lib.hhv_set_celloff(self.h, ts.h, int(k), m.ctypes.data))
+
+    def set_global_batch(self, ts, not_longest):
+        """hhv_set_global_batch: not_longest[k] != 0 -> template k is shorter than the longest of its SIMD batch"""
+        if not_longest is None:
+            _check(self.lib.hhv_set_global_batch(self.h, ts.h, None))
+            return
+        f = np.ascontiguousarray(not_longest, dtype=np.uint8)
+        assert f.shape == (ts.n,)
+        _check(self.lib.hhv_set_global_batch(self.h, ts.h, f.ctypes.data))
 
     def backtrace_matrix(self, ts, k):
         out = np.zeros((self.Lq + 1, int(ts.L[k]) + 1), dtype=np.uint8)

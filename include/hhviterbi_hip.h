@@ -314,6 +314,13 @@ int hhv_set_celloff(hhv_ctx* ctx, hhv_tset* ts, int32_t k, const uint8_t* mask);
 int hhv_set_celloff_paths(hhv_ctx* ctx, hhv_tset* ts, int32_t n_paths, const int32_t* template_of, const int64_t* path_off,
                           const int32_t* i_steps, const int32_t* j_steps, int32_t n_qranges, const int32_t* qranges,
                           int32_t n_tranges, const int32_t* tranges);
+/* Global mode only (par.loc = 0): reproduce the reference's SIMD-batch behaviour.  Viterbi::Align maximises the global score
+ * over the last row and over the last column OF THE BATCH, i.e. of the longest of the <= VECSIZE_FLOAT templates aligned
+ * together (src/hhviterbialgorithm.cpp:462-486); for a shorter template of the batch that column is padding, so only its last
+ * ROW counts.  not_longest[k] != 0 marks template k as such a template (its own last column is then left out of the
+ * maximisation); NULL clears all marks = every template as if aligned alone (HMMSimd::MapOneHMM), the default.  The marks
+ * stay with the set until set again; sets made by hhv_tset_gather inherit those of their source. */
+int hhv_set_global_batch(hhv_ctx* ctx, hhv_tset* ts, const uint8_t* not_longest);
 /* raw backtrace byte matrix of template k in the reference layout: out[(Lq+1)*(L[k]+1)] */
 int hhv_backtrace_matrix(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint8_t* out);
 

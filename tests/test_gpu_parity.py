@@ -205,3 +205,40 @@ def test_gather_subset_on_device(hhv, oracle):
     sub.free()
     ts.free()
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lq", [37, 150, 400])
+def test_global_mode_simd_batch_last_column(oracle, Lq):
+    """hhv_set_global_batch: the reference maximises the global score over the last column of the LONGEST template of a SIMD
+    batch (src/hhviterbialgorithm.cpp:462-486); for the shorter templates of the batch only the last row counts.  Batches
+    of 8 consecutive templates of the length-sorted list, as ViterbiRunner builds them (src/hhviterbirunner.cpp:117-151);
+    the oracle emulates the batch with Lbatch (pinned to the reference, tests/test_oracle_vs_reference.py).  Multi-pass
+    queries (Lq = 400) and the backtrace included; clearing the marks restores the single-template result."""
+    from pyhhv import capi
+    par = make_params(local=0)
+    qf, qtr, tps, ttrs = workload(300 + Lq, Lq, 29, 20, 260, homolog_every=2)
+    order = sorted(range(len(tps)), key=lambda k: -(tps[k].shape[0] - 1))
+    tps, ttrs = [tps[k] for k in order], [ttrs[k] for k in order]
+    Ls = [t.shape[0] - 1 for t in tps]
+    Lb = [max(Ls[b - b % 8:b - b % 8 + 8]) for b in range(len(Ls))]
+    c = capi.Context(local=0)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    alone = c.align(ts, backtrace=True).copy()
+    c.set_global_batch(ts, np.asarray([L < b for L, b in zip(Ls, Lb)], dtype=np.uint8))
+    res = c.align(ts, backtrace=True)
+    hits = c.hits(ts)
+    changed = 0
+    for k in range(len(tps)):
+        a = oracle.align(par, qf, qtr, tps[k], ttrs[k], Lbatch=Lb[k], want_path=True)
+        assert (a.i2, a.j2) == (int(res["i2"][k]), int(res["j2"][k])), (k, Ls[k], Lb[k], a.i2, a.j2, res[k])
+        assert same_float(a.score, res["score"][k]), (k, a.score, res["score"][k])
+        assert same_float(a.hit_score, hits["score"][k]) and a.nsteps == hits["nsteps"][k], k
+        changed += (int(res["i2"][k]), int(res["j2"][k])) != (int(alone["i2"][k]), int(alone["j2"][k]))
+    assert changed > 0, "the workload must contain a template whose own last column wins when aligned alone"
+    c.set_global_batch(ts, None)
+    again = c.align(ts, backtrace=True)
+    assert np.array_equal(again, alone)
+    ts.free()
+    c.close()
