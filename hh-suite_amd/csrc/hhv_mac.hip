@@ -27,12 +27,26 @@ namespace {
 
 enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };  // src/hhdecl.h:68
 enum { MAC_STOP = 0, MAC_MM = 2, MAC_IM = 4, MAC_MI = 6 };                              // ViterbiMatrix codes
+// strips of 64 columns whose HBM operands are fetched a whole row ahead in the STAGE variants (templates up to 832 columns;
+// the template itself fits into LDS up to ~800)
+constexpr int MAC_PRE = 13;
 
 __device__ __forceinline__ double shr1_d(double y, double carry) {
   int lo = __double2loint(y), hi = __double2hiint(y);
   lo = __builtin_amdgcn_update_dpp(__double2loint(carry), lo, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
   hi = __builtin_amdgcn_update_dpp(__double2hiint(carry), hi, 0x138, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+// the same shifts with lane 0 receiving ZERO (bound_ctrl): no register has to be preloaded with the carry before every
+// DPP move, which is a third of the instructions of a sweep step.  The sweeps fold the carry into lane 0's constants
+// instead (the very operations a step would perform on it), see the kernels.
+__device__ __forceinline__ double shr1_dz(double y) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(y), 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(y), 0x138, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float shr1_fz(float y) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x138, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float shr1_f(float y, float carry) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(y), 0x138, 0xF, 0xF, false));
@@ -152,13 +166,21 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));  // layout sized for the longest template
   float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
+  // STAGE: the cell-off bytes of a row are fetched from HBM while the row BEFORE it is computed (registers), parked in LDS
+  // at the end of that row and read from there - a strip without active cells costs a few dozen cycles, and with the
+  // fetch only one strip ahead every such strip waited a full trip to L2 / HBM for the mask byte of its successor.
+  unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + (size_t)(a.lds_cols + 2) * 8);  // [2][lds_cols + 2]
+  const int co_stride = a.lds_cols + 2;
   const double Cshift = a.Cshift;
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
   for (int e = lane; e < pitch; e += 64) h.mat[e] = 0.0f;  // row 0 of p_mm is never read
-  if (STAGE) stage_template(h, sTp, sTt, lane);
+  if (STAGE) {
+    stage_template(h, sTp, sTt, lane);
+    for (int j = 1 + lane; j <= Lt; j += 64) sCo[j] = h.co[(size_t)pitch + j];  // row 1
+  }
   __syncthreads();
-  // the cell-off byte of the next strip is fetched while the current one is swept (also across the row boundary)
-  unsigned char co_next = (1 + lane <= Lt) ? h.co[(size_t)pitch + 1 + lane] : 1;
+  // !STAGE: the cell-off byte of the next strip is fetched while the current one is swept (also across the row boundary)
+  unsigned char co_next = (!STAGE && 1 + lane <= Lt) ? h.co[(size_t)pitch + 1 + lane] : 1;
   int cur = 0;
   double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0;
   double Pf = LOCAL ? 1.0 : 0.0;
@@ -179,12 +201,21 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     const double qM2M = qt1[T_M2M], qI2M = qt1[T_I2M], qD2M = qt1[T_D2M], qM2D = qt1[T_M2D], qD2D = qt1[T_D2D];
     const double qM2I = qt[T_M2I], qI2I = qt[T_I2I];
     double Pmax = 0.0, carry_mm = 0.0, carry_gd = 0.0, carry_im = 0.0;
+    unsigned char pre_co[MAC_PRE];
+    if (STAGE) {
+#pragma unroll
+      for (int u = 0; u < MAC_PRE; ++u) {
+        const int jn = 1 + u * 64 + lane;
+        pre_co[u] = (i < Lq && jn <= Lt) ? h.co[(size_t)(i + 1) * pitch + jn] : 1;
+      }
+    }
+    const unsigned char* co_row = sCo + ((i - 1) & 1) * co_stride;
     for (int s0 = 0; s0 < Lt; s0 += 64) {
       const int j = 1 + s0 + lane;
       const bool valid = j <= Lt;
       const int jc = valid ? j : Lt;
-      const bool off = !valid || co_next != 0;
-      {
+      const bool off = !valid || (STAGE ? co_row[jc] != 0 : co_next != 0);
+      if (!STAGE) {
         const bool last = s0 + 64 >= Lt;
         const int ni = last ? i + 1 : i, nj = last ? 1 + lane : j + 64;
         co_next = (ni <= Lq && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
@@ -238,13 +269,20 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const double f_mm = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
       // Sweep: inactive lanes hold 0 (resp. the incoming total) whatever their neighbour says, so the lanes left of the
       // first active one are final from the start and l1 - l0 + 1 steps finish everything up to the last active lane.
+      // Lane 0's left neighbour is the carry of the previous strip, a constant of the sweep: its step is evaluated once,
+      // with the operations of the loop body, and the loop shifts zeros into lane 0 (x + 0*b = x for the non-negative
+      // finite values here).
+      const bool first_lane = lane == 0;
+      const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
+      const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
+      const double f_mm_s = first_lane ? Pf + f_mm : f_mm;
       double gd = 0.0, im = 0.0, acc = Pf;
       const int n_steps = l1 - l0 + 1;
       for (int s = 0; s < n_steps; ++s) {
-        const double gl = shr1_d(gd, carry_gd), il = shr1_d(im, carry_im);
-        gd = a_gd + gl * b_gd;
-        im = c_im + il * qI2I * b_im;
-        if (LOCAL) acc = shr1_d(acc, Pf) + f_mm;
+        const double gl = shr1_dz(gd), il = shr1_dz(im);
+        gd = a_gd_s + gl * b_gd;
+        im = c_im_s + il * qI2I * b_im;
+        if (LOCAL) acc = shr1_dz(acc) + f_mm_s;
       }
       if (valid) {
         ROW(cur, F_MM, j) = mm;
@@ -260,6 +298,14 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       if (LOCAL) Pf = lane_d(acc, l1);  // lanes right of l1 would only add zeros
     }
     if (lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
+    if (STAGE) {
+      unsigned char* co_nextrow = sCo + (i & 1) * co_stride;
+#pragma unroll
+      for (int u = 0; u < MAC_PRE; ++u) {
+        const int jn = 1 + u * 64 + lane;
+        if (jn <= Lt) co_nextrow[jn] = pre_co[u];
+      }
+    }
     double scale_next = 1.0;
     if (i >= 2) {
       Pmax = wave_max_d(Pmax);
@@ -303,9 +349,20 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));
   float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
+  // STAGE: mask bytes and F_MM of a row are fetched while the row processed before it is computed (see the forward kernel)
+  unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + (size_t)(a.lds_cols + 2) * 8);  // [2][lds_cols + 2]
+  const int co_stride = a.lds_cols + 2;
+  float* sF = reinterpret_cast<float*>(sCo + (((size_t)2 * co_stride + 15) & ~(size_t)15));  // [2][lds_cols + 2]
   const double Cshift = a.Cshift, Pf = a.Pforward[k];
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
-  if (STAGE) stage_template(h, sTp, sTt, lane);
+  if (STAGE) {
+    stage_template(h, sTp, sTt, lane);
+    if (Lq >= 2)
+      for (int j = 1 + lane; j <= Lt; j += 64) {  // row Lq - 1, the first one of the loop below
+        sCo[((Lq - 1) & 1) * co_stride + j] = h.co[(size_t)(Lq - 1) * pitch + j];
+        sF[((Lq - 1) & 1) * co_stride + j] = h.mat[(size_t)(Lq - 1) * pitch + j];
+      }
+  }
   __syncthreads();
   const double sL = h.scale[Lq + 1];
   int cur = 0;  // row being computed; `prv` holds row i+1
@@ -333,16 +390,28 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
     if (pmin < DBL_MIN * 100) pmin = 0.0;
     float* row = h.mat + (size_t)i * pitch;
     const unsigned char* corow = h.co + (size_t)i * pitch;
-    // what the first strip of this row reads from HBM (mask byte, F_MM) and, lane 0, column Lt - issued together
-    {
+    unsigned char pre_co[MAC_PRE];
+    float pre_f[MAC_PRE];
+    const unsigned char* co_l = sCo + (i & 1) * co_stride;
+    const float* f_l = sF + (i & 1) * co_stride;
+    if (STAGE) {
+#pragma unroll
+      for (int u = 0; u < MAC_PRE; ++u) {
+        const int jn = 1 + u * 64 + lane;
+        const bool in = i >= 2 && jn <= Lt;
+        pre_co[u] = in ? h.co[(size_t)(i - 1) * pitch + jn] : 1;
+        pre_f[u] = in ? h.mat[(size_t)(i - 1) * pitch + jn] : 0.0f;
+      }
+    } else {
+      // what the first strip of this row reads from HBM (mask byte, F_MM) and, lane 0, column Lt - issued together
       const int j0 = Lt - 1 - lane;
       co_nx = j0 >= 1 ? corow[j0] : 1;
       f_nx = j0 >= 1 ? row[j0] : 0.0f;
     }
     // column Lt (:58-71)
     if (lane == 0) {
-      const unsigned char coL = corow[Lt];
-      const float fL = row[Lt];
+      const unsigned char coL = STAGE ? co_l[Lt] : corow[Lt];
+      const float fL = STAGE ? f_l[Lt] : row[Lt];
       if (coL) {
         row[Lt] = 0.0f;
         ROW(cur, F_MM, Lt) = 0.0;
@@ -361,9 +430,9 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       const int j = Lt - 1 - s0 - lane;  // descending: lane 0 is the rightmost column of the strip
       const bool valid = j >= 1;
       const int jc = valid ? j : 1;
-      const bool off = !valid || co_nx != 0;
-      const float f_cur = f_nx;
-      if (s0 + 64 < Lt - 1) {
+      const bool off = !valid || (STAGE ? co_l[jc] != 0 : co_nx != 0);
+      const float f_cur = STAGE ? (valid ? f_l[jc] : 0.0f) : f_nx;
+      if (!STAGE && s0 + 64 < Lt - 1) {
         const int jn = j - 64;
         co_nx = jn >= 1 ? corow[jn] : 1;
         f_nx = jn >= 1 ? row[jn] : 0.0f;
@@ -393,12 +462,15 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       double mi = (+pmatch * qM2M * tt[T_I2M] + pmi * qM2M * tt[T_I2I] * sc);     // :108-111
       const double a_gd = off ? 0.0 : pmatch * qM2M * tt[T_D2M], b_gd = off ? 0.0 : (double)tt[T_D2D];  // :95-97
       const double c_im = off ? 0.0 : pmatch * qI2M * tM2M, b_im = off ? 0.0 : tM2M;                    // :99-101
+      const bool first_lane = lane == 0;  // its neighbour is the carry of the previous strip: folded, see the forward kernel
+      const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
+      const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
       double gd = 0.0, im = 0.0;
       const int n_steps = l1 - l0 + 1;
       for (int s = 0; s < n_steps; ++s) {
-        const double gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);
-        gd = a_gd + gr * b_gd;
-        im = c_im + ir * qI2I * b_im;
+        const double gr = shr1_dz(gd), ir = shr1_dz(im);
+        gd = a_gd_s + gr * b_gd;
+        im = c_im_s + ir * qI2I * b_im;
       }
       const double gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);  // curr[j+1].gd / .im
       double mm = (+pmin + pmatch * qM2M * tM2M + gr * tt[T_M2D] + ir * qM2I * tM2M + pdg * qM2D * sc +
@@ -414,6 +486,18 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       }
       carry_gd = lane_d(gd, 63);
       carry_im = lane_d(im, 63);
+    }
+    if (STAGE) {
+      unsigned char* co_n = sCo + ((i - 1) & 1) * co_stride;
+      float* f_n = sF + ((i - 1) & 1) * co_stride;
+#pragma unroll
+      for (int u = 0; u < MAC_PRE; ++u) {
+        const int jn = 1 + u * 64 + lane;
+        if (jn <= Lt) {
+          co_n[jn] = pre_co[u];
+          f_n[jn] = pre_f[u];
+        }
+      }
     }
     __syncthreads();
     cur = prv;
@@ -483,7 +567,11 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
       const float lo = off ? -FLT_MIN : mx, hi = off ? -FLT_MIN : __builtin_inff();
       float sv = off ? -FLT_MIN : 0.0f;
       if (__ballot(mx != mx) == 0) {
-        for (int s = 0; s < n_steps; ++s) sv = __builtin_amdgcn_fmed3f(shr1_f(sv, carry) - half_f, lo, hi);
+        // lane 0's left neighbour is the carry, a constant of the sweep: its value is fixed up front (med3(x, v, v) = v) and
+        // the loop shifts zeros into lane 0 - the step is then v_sub_f32 with a DPP operand + v_med3_f32
+        const float v0 = __builtin_amdgcn_fmed3f(carry - half_f, lo, hi);
+        const float lo_s = lane == 0 ? v0 : lo, hi_s = lane == 0 ? v0 : hi;
+        for (int s = 0; s < n_steps; ++s) sv = __builtin_amdgcn_fmed3f(shr1_fz(sv) - half_f, lo_s, hi_s);
       } else {  // NaN posteriors (a mask that leaves no path: Pforward = 0): the literal compare/select chain
         for (int s = 0; s < n_steps; ++s) {
           const float t4s = shr1_f(sv, carry) - half_f;
@@ -671,7 +759,10 @@ int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
 
 // LDS of the forward / backward kernels: two rows of state, plus - when it fits - the template itself
 size_t mac_rows_lds(int max_Lt, bool stage) {
-  return (size_t)10 * (max_Lt + 2) * sizeof(double) + (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) : 0);
+  // staged: + the template (28 floats per column) + two rows of mask bytes + two rows of F_MM fetched a row ahead
+  return (size_t)10 * (max_Lt + 2) * sizeof(double) +
+         (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) + (((size_t)2 * (max_Lt + 2) + 15) & ~(size_t)15) +
+                      (size_t)2 * (max_Lt + 2) * sizeof(float) : 0);
 }
 
 template <bool LOCAL, bool STAGE>
@@ -685,7 +776,7 @@ static void launch_mac_variant(const MacArgs& a, size_t lds_rows, size_t lds_dp,
 
 int launch_mac(const MacArgs& a0, bool local, int max_Lt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const bool stage = mac_rows_lds(max_Lt, true) <= 160 * 1024;
+  const bool stage = mac_rows_lds(max_Lt, true) <= 160 * 1024 && max_Lt <= MAC_PRE * 64;
   MacArgs a = a0;
   a.lds_cols = max_Lt;
   const size_t lds_rows = mac_rows_lds(max_Lt, stage), lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
