@@ -228,6 +228,33 @@ def test_dropin_global_equal_lengths():
 
 
 @pytest.mark.gpu
+def test_dropin_baseline_config0_shape():
+    """BASELINE.json configs[0]: a 431-column query (the length of data/query.hhm: two passes of the stream kernel) against
+    64 synthetic templates of 200 columns, default parameters of hhsearch (local, altali 4, ssm 2, smin 20)."""
+    cache_clear()
+    q, t, names = make_db(431, 431, 64, 200, 200)
+    ref = run("cpu", q, t, names)
+    got = run("hip", q, t, names, threads=4)
+    assert compare(ref, got) >= 64
+    got2 = run("hip", q, t, names, threads=4)        # warm cache
+    compare(ref, got2)
+    cache_clear()
+
+
+@pytest.mark.gpu
+def test_dropin_long_profiles():
+    """a 700-column query (three passes) against templates of up to 1500 columns: every length class of the device
+    preparation (LDS-resident up to 447 / 1300 columns, two-kernel path beyond) behind the drop-in"""
+    cache_clear()
+    q, t, names = make_db(97, 700, 18, 300, 1500, homolog_every=3)
+    ref = run("cpu", q, t, names, altali=2, maxres=2000, path_cap=2300)
+    got = run("hip", q, t, names, altali=2, maxres=2000, path_cap=2300, threads=3)
+    compare(ref, got)
+    assert max(h.L for h in ref[0]) > 1300 and min(h.L for h in ref[0]) < 447
+    cache_clear()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("threads", [1, 3])
 def test_dropin_global_mixed_lengths(threads):
     """global mode on templates of MANY lengths: in the reference the shorter templates of a SIMD batch are maximised over
