@@ -58,6 +58,13 @@ struct hhv_ctx {
   std::vector<int8_t> q_pred, q_conf, q_dssp;          // [Lq+1], empty = absent
   int ss_hmm_mode = 0;                                 // HMM::NO_SS_INFORMATION
   bool ss_dirty = true;
+  // secondary-structure operands for the next MAC call (hhv_mac_set_ss), consumed by it
+  bool mac_ss_pending = false;
+  int mac_ss_Lq = 0;
+  std::vector<float> mac_ss_tab;
+  std::vector<uint8_t> mac_ss_qidx, mac_ss_tidx;
+  std::vector<int64_t> mac_ss_toff;
+  std::vector<int32_t> mac_ss_mode;
   void* mac_cache = nullptr;                           // one recycled device block of the MAC realignment
   size_t mac_cache_bytes = 0;
   float* d_ss_table = nullptr;                         // ssw * table of the current mode

@@ -68,6 +68,15 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   }
   if ((size_t)10 * (max_Lt + 2) * sizeof(double) > 160 * 1024)
     return fail(HHV_E_LIMIT, "hhv_mac_realign: template length %d exceeds the LDS row state (limit 2046)", max_Lt);
+  const bool with_ss = c->mac_ss_pending;
+  c->mac_ss_pending = false;  // one call only
+  if (with_ss) {
+    if ((int)c->mac_ss_mode.size() != n || c->mac_ss_Lq != Lq) return fail(HHV_E_ARG, "hhv_mac_realign: hhv_mac_set_ss was called for %zu hits, Lq %d", c->mac_ss_mode.size(), c->mac_ss_Lq);
+    bool any = false;
+    for (int k = 0; k < n; ++k) any = any || c->mac_ss_mode[k] != 0;
+    if (any && !mac_templates_are_staged(max_Lt))
+      return fail(HHV_E_LIMIT, "hhv_mac_realign: secondary-structure scoring needs templates that fit the staged kernels (longest: %d)", max_Lt);
+  }
   HIP_TRY(hipSetDevice(c->par.device));
   hhv_macset* ms = new (std::nothrow) hhv_macset();
   if (!ms) return fail(HHV_E_MEMORY, "out of host memory");
@@ -150,6 +159,9 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   const size_t o_ends = carve(ends.size() * 4 + 16), o_voff = carve((size_t)(n + 1) * 8), o_vi = carve(vit_i.size() * 4 + 4),
                o_vj = carve(vit_j.size() * 4 + 4), o_xoff = carve((size_t)(n + 1) * 8), o_xi = carve(excl_i.size() * 4 + 4),
                o_xj = carve(excl_j.size() * 4 + 4), o_rg = carve(ranges.size() * 4), o_rt = carve((size_t)n * 4 + 4);
+  const size_t o_sstab = carve(with_ss ? 704 * 4 : 0), o_ssq = carve(with_ss ? c->mac_ss_qidx.size() : 0),
+               o_sst = carve(with_ss ? c->mac_ss_tidx.size() : 0), o_ssoff = carve(with_ss ? (size_t)n * 8 : 0),
+               o_ssmode = carve(with_ss ? (size_t)n * 4 : 0);
   if (c->mac_cache && c->mac_cache_bytes >= total) {
     ms->d_block = c->mac_cache;
     ms->block_bytes = c->mac_cache_bytes;
@@ -199,7 +211,12 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
               hipMemcpyAsync(base + o_xj, excl_j.data(), excl_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
               hipMemcpyAsync(base + o_rg, ranges.data(), ranges.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
               hipMemcpyAsync(base + o_rt, res_template.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess)) ||
-      hipMemcpyAsync(base + o_poff, ms->path_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+      hipMemcpyAsync(base + o_poff, ms->path_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+      (with_ss && (hipMemcpyAsync(base + o_sstab, c->mac_ss_tab.data(), 704 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                   hipMemcpyAsync(base + o_ssq, c->mac_ss_qidx.data(), c->mac_ss_qidx.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+                   hipMemcpyAsync(base + o_sst, c->mac_ss_tidx.data(), c->mac_ss_tidx.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+                   hipMemcpyAsync(base + o_ssoff, c->mac_ss_toff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+                   hipMemcpyAsync(base + o_ssmode, c->mac_ss_mode.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess)))
     rc = fail(HHV_E_DEVICE, "hhv_mac_realign: H2D copy failed");
   MacArgs a;
   a.n = n;
@@ -229,6 +246,11 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   a.path_P = (float*)(base + o_pP);
   a.lg2 = c->d_lg2;
   a.diff = c->d_diff;
+  a.ss_tab = with_ss ? (const float*)(base + o_sstab) : nullptr;
+  a.ss_qidx = with_ss ? (const unsigned char*)(base + o_ssq) : nullptr;
+  a.ss_tidx = with_ss ? (const unsigned char*)(base + o_sst) : nullptr;
+  a.ss_toff = with_ss ? (const int64_t*)(base + o_ssoff) : nullptr;
+  a.ss_mode = with_ss ? (const int32_t*)(base + o_ssmode) : nullptr;
   ms->d_mat = a.mat;
   ms->d_celloff = (unsigned char*)(base + o_co);
   ms->d_path_i = a.path_i;
@@ -281,6 +303,37 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   }
   memcpy(hits, ms->hits.data(), (size_t)n * sizeof(hhv_mac_hit));
   *out = ms;
+  return HHV_OK;
+}
+
+int hhv_mac_set_ss(hhv_ctx* c, const float* tables, const uint8_t* q_idx, int32_t Lq, int32_t n, const int32_t* mode,
+                   const uint8_t* const* t_idx, const int32_t* Lt) {
+  if (!c || !tables || !q_idx || !mode || !t_idx || !Lt || n < 1 || Lq < 1) return fail(HHV_E_ARG, "hhv_mac_set_ss: bad argument");
+  c->mac_ss_pending = false;
+  c->mac_ss_tab.assign(tables, tables + 2 * 352);
+  c->mac_ss_qidx.assign(q_idx, q_idx + (size_t)2 * (Lq + 2));
+  c->mac_ss_Lq = Lq;
+  c->mac_ss_mode.assign(mode, mode + n);
+  c->mac_ss_toff.assign((size_t)n, 0);
+  c->mac_ss_tidx.clear();
+  for (int k = 0; k < n; ++k) {
+    if (mode[k] < 0 || mode[k] > 2 || Lt[k] < 1) return fail(HHV_E_ARG, "hhv_mac_set_ss: hit %d: mode %d, Lt %d", k, mode[k], Lt[k]);
+    if (mode[k] && !t_idx[k]) return fail(HHV_E_ARG, "hhv_mac_set_ss: hit %d has a mode but no template indices", k);
+    c->mac_ss_toff[k] = (int64_t)c->mac_ss_tidx.size();
+    const size_t m = (size_t)Lt[k] + 2;
+    if (mode[k]) {
+      const int lim = mode[k] == 1 ? 8 : 44;
+      for (size_t j = 0; j < m; ++j)
+        if (t_idx[k][j] >= lim) return fail(HHV_E_ARG, "hhv_mac_set_ss: hit %d: template index %d at column %zu", k, t_idx[k][j], j);
+      c->mac_ss_tidx.insert(c->mac_ss_tidx.end(), t_idx[k], t_idx[k] + m);
+    } else {
+      c->mac_ss_tidx.insert(c->mac_ss_tidx.end(), m, 0);
+    }
+  }
+  for (int md = 0; md < 2; ++md)
+    for (int i = 0; i < Lq + 2; ++i)
+      if (q_idx[(size_t)md * (Lq + 2) + i] >= (md == 0 ? 44 : 8)) return fail(HHV_E_ARG, "hhv_mac_set_ss: query index out of range at row %d", i);
+  c->mac_ss_pending = true;
   return HHV_OK;
 }
 

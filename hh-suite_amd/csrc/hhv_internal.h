@@ -180,6 +180,13 @@ struct MacArgs {
   float* path_P;
   const float* lg2;
   const float* diff;
+  // secondary-structure scoring inside forward / backward (hit.ssm2 = 1 PRED_DSSP or 2 DSSP_PRED), null = none:
+  // factor of cell (i, j) = ss_tab[mode-1][ss_qidx[mode-1][i] * (mode == 1 ? 8 : 44) + ss_tidx[col_off[k] + j]]
+  const float* ss_tab;            // [2][352]  fpow2(ssw * S37[q_pred][q_conf][t_dssp]), fpow2(ssw * S73[q_dssp][t_pred][t_conf])
+  const unsigned char* ss_qidx;   // [2][Lq+2]
+  const unsigned char* ss_tidx;   // [cols + n]: per hit Lt+2 entries (index Lt+1 = what the reference reads past the template)
+  const int64_t* ss_toff;         // [n] first entry of hit k in ss_tidx
+  const int32_t* ss_mode;         // [n] 0, 1, 2
 };
 struct MacMaskArgs {
   const int4* ends;          // [n] i1, j1, i2, j2 of the Viterbi alignment
@@ -200,6 +207,7 @@ struct MacMaskArgs {
 };
 int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream);
 int launch_mac(const MacArgs& a, bool local, int max_Lt, void* stream);
+bool mac_templates_are_staged(int max_Lt);  // the launch keeps the templates in LDS (needed for secondary-structure scoring)
 
 // launchers implemented in hhv_kernels.hip
 int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);

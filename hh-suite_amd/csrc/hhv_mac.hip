@@ -88,6 +88,11 @@ struct HitView {
   float* mat;
   unsigned char* bmm;
   double* scale;
+  // secondary-structure factor fpow2(ScoreSS(q, t, i, j)) (src/hhforwardalgorithm.cpp:77,100, src/hhbackwardalgorithm.cpp:82)
+  int ssm, sstw;                 // hit.ssm2 (0 = none) and the row width of its table
+  const float* sstab;            // global copy of the mode's table [44*8] or [8*44]
+  const unsigned char* ssq;      // [Lq+2] row index of query column i
+  const unsigned char* sst;      // [Lt+2] column index of template column j; [Lt+1] = the entry the reference reads for column 1
 };
 __device__ __forceinline__ HitView view(const MacArgs& a, int k) {
   HitView v;
@@ -103,6 +108,11 @@ __device__ __forceinline__ HitView view(const MacArgs& a, int k) {
   v.mat = a.mat + a.mat_off[k];
   v.bmm = a.bmm + a.mat_off[k];
   v.scale = a.scale + (int64_t)k * (a.Lq + 2);
+  v.ssm = a.ss_mode ? a.ss_mode[k] : 0;
+  v.sstw = v.ssm == 1 ? 8 : 44;
+  v.sstab = a.ss_tab ? a.ss_tab + (v.ssm == 2 ? 352 : 0) : nullptr;
+  v.ssq = a.ss_qidx ? a.ss_qidx + (v.ssm == 2 ? (a.Lq + 2) : 0) : nullptr;
+  v.sst = a.ss_tidx ? a.ss_tidx + a.ss_toff[k] : nullptr;
   return v;
 }
 
@@ -149,6 +159,11 @@ __device__ __forceinline__ void stage_template(const HitView& h, float* sTp, flo
   for (int e = lane; e < (h.Lt + 1) * 20; e += 64) sTp[e] = h.tp[(size_t)(e / 20) * h.tps + (e % 20)];
   for (int e = lane; e < (h.Lt + 1) * 8; e += 64) sTt[e] = (e & 7) < 7 ? h.ttr[(size_t)(e >> 3) * 7 + (e & 7)] : 0.0f;
 }
+// the secondary-structure table of the hit's mode in LDS (352 floats)
+__device__ __forceinline__ void stage_ss(const HitView& h, float* sSs, int lane) {
+  if (h.ssm)
+    for (int e = lane; e < 352; e += 64) sSs[e] = h.sstab[e];
+}
 
 // LDS row state: field f of row r at column j
 #define ROW(r, f, j) rows[((r)*5 + (f)) * stride + (j)]
@@ -171,11 +186,14 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   // fetch only one strip ahead every such strip waited a full trip to L2 / HBM for the mask byte of its successor.
   unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + (size_t)(a.lds_cols + 2) * 8);  // [2][lds_cols + 2]
   const int co_stride = a.lds_cols + 2;
+  float* sSs = reinterpret_cast<float*>(sCo + (((size_t)2 * co_stride + 15) & ~(size_t)15)) + (size_t)2 * co_stride;  // [352]
+  const float* sstab = STAGE ? sSs : h.sstab;
   const double Cshift = a.Cshift;
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
   for (int e = lane; e < pitch; e += 64) h.mat[e] = 0.0f;  // row 0 of p_mm is never read
   if (STAGE) {
     stage_template(h, sTp, sTt, lane);
+    stage_ss(h, sSs, lane);
     for (int j = 1 + lane; j <= Lt; j += 64) sCo[j] = h.co[(size_t)pitch + j];  // row 1
   }
   __syncthreads();
@@ -240,6 +258,9 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       load_tt<STAGE>(h, sTt, jc - 1, tt1);  // t.tr[j-1]
       load_tt<STAGE>(h, sTt, jc, tt);       // t.tr[j]
       const float pf = dot20(qi, tpj);
+      // fpow2(ScoreSS(q, t, i, j)); for column 1 the reference passes (1, j) with the stale loop variable j = t.L + 1 (:77)
+      float ssf = 1.0f;
+      if (h.ssm && i >= 2) ssf = j == 1 ? sstab[h.ssq[1] * h.sstw + h.sst[Lt + 1]] : sstab[h.ssq[i] * h.sstw + h.sst[jc]];
       double mm, dg, mi;
       if (i == 1) {
         mm = pf * Cshift;  // :31
@@ -247,11 +268,11 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       } else {
         const double pm = ROW(prv, F_MM, jc), pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
         if (j == 1) {
-          mm = scale_prod * 1.0f * pf * Cshift;  // :71-73, fpow2(ScoreSS) = fpow2(0) = 1.0f
+          mm = scale_prod * ssf * pf * Cshift;  // :71-73
         } else {
           const double m1 = ROW(prv, F_MM, jc - 1), g1 = ROW(prv, F_GD, jc - 1), i1 = ROW(prv, F_IM, jc - 1),
                        d1 = ROW(prv, F_DG, jc - 1), x1 = ROW(prv, F_MI, jc - 1);
-          mm = pf * Cshift * 1.0f * scale_i *
+          mm = pf * Cshift * ssf * scale_i *
                (pmin + m1 * qM2M * tt1[T_M2M] + g1 * qM2M * tt1[T_D2M] + i1 * qI2M * tt1[T_M2M] + d1 * qD2M * tt1[T_M2M] +
                 x1 * qM2M * tt1[T_I2M]);  // :94-103
         }
@@ -353,10 +374,13 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + (size_t)(a.lds_cols + 2) * 8);  // [2][lds_cols + 2]
   const int co_stride = a.lds_cols + 2;
   float* sF = reinterpret_cast<float*>(sCo + (((size_t)2 * co_stride + 15) & ~(size_t)15));  // [2][lds_cols + 2]
+  float* sSs = sF + (size_t)2 * co_stride;                                                    // [352]
+  const float* sstab = STAGE ? sSs : h.sstab;
   const double Cshift = a.Cshift, Pf = a.Pforward[k];
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
   if (STAGE) {
     stage_template(h, sTp, sTt, lane);
+    stage_ss(h, sSs, lane);
     if (Lq >= 2)
       for (int j = 1 + lane; j <= Lt; j += 64) {  // row Lq - 1, the first one of the loop below
         sCo[((Lq - 1) & 1) * co_stride + j] = h.co[(size_t)(Lq - 1) * pitch + j];
@@ -455,7 +479,8 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       load_tp<STAGE>(h, sTp, jc + 1, tpn);
       load_tt<STAGE>(h, sTt, jc, tt);
       const float pf = dot20(qn, tpn);
-      const double pmatch = ROW(prv, F_MM, jc + 1) * pf * 1.0f * Cshift * sc;  // :80-83
+      const float ssf = h.ssm ? sstab[h.ssq[i + 1] * h.sstw + h.sst[jc + 1]] : 1.0f;  // fpow2(ScoreSS(q, t, i+1, j+1))
+      const double pmatch = ROW(prv, F_MM, jc + 1) * pf * ssf * Cshift * sc;  // :80-83
       const double pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
       const double tM2M = tt[T_M2M];
       double dg = (+pmatch * qD2M * tM2M + pdg * qD2D * sc);                       // :103-106
@@ -759,10 +784,11 @@ int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
 
 // LDS of the forward / backward kernels: two rows of state, plus - when it fits - the template itself
 size_t mac_rows_lds(int max_Lt, bool stage) {
-  // staged: + the template (28 floats per column) + two rows of mask bytes + two rows of F_MM fetched a row ahead
+  // staged: + the template (28 floats per column) + two rows of mask bytes + two rows of F_MM fetched a row ahead + the
+  // secondary-structure table of the hit
   return (size_t)10 * (max_Lt + 2) * sizeof(double) +
          (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) + (((size_t)2 * (max_Lt + 2) + 15) & ~(size_t)15) +
-                      (size_t)2 * (max_Lt + 2) * sizeof(float) : 0);
+                      (size_t)2 * (max_Lt + 2) * sizeof(float) + 352 * sizeof(float) : 0);
 }
 
 template <bool LOCAL, bool STAGE>
@@ -774,9 +800,11 @@ static void launch_mac_variant(const MacArgs& a, size_t lds_rows, size_t lds_dp,
   hipLaunchKernelGGL(hhv_mac_dp_kernel<LOCAL>, dim3(a.n), dim3(64), lds_dp, stream, a);
 }
 
+bool mac_templates_are_staged(int max_Lt) { return mac_rows_lds(max_Lt, true) <= 160 * 1024 && max_Lt <= MAC_PRE * 64; }
+
 int launch_mac(const MacArgs& a0, bool local, int max_Lt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const bool stage = mac_rows_lds(max_Lt, true) <= 160 * 1024 && max_Lt <= MAC_PRE * 64;
+  const bool stage = mac_templates_are_staged(max_Lt);
   MacArgs a = a0;
   a.lds_cols = max_Lt;
   const size_t lds_rows = mac_rows_lds(max_Lt, stage), lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);

@@ -19,10 +19,13 @@
 //
 // Not produced: the sparse forward / backward / posterior lists of writeProfilesToHits (hit.forward_matrix, ...;
 // src/hhbacktracemac.cpp:14-110), which only HitList::PrintMatrices (the hidden -o_matrices output) reads; they are left
-// NULL and PrintMatrices skips such hits.  Not supported (the run stops with a message instead of computing something
-// else): hits with secondary-structure scoring against DSSP states inside MAC (hit.ssm2 = 1 or 2 - query with predicted
-// SS against templates with DSSP records, or the reverse; ssm2 = 3 is a no-op in the reference, Viterbi::ScoreSS has no
-// case 3), self alignments (hit.self), templates longer than 2046 columns.
+// NULL and PrintMatrices skips such hits.  Secondary-structure scoring inside forward / backward (hit.ssm2 = 1 or 2: a query
+// with predicted SS against templates with DSSP records - the HHpred case - or the reverse; ssm2 = 3 scores nothing in the
+// reference, Viterbi::ScoreSS has no case 3) runs on the device from tables of fpow2(ScoreSS) (hhv_mac_set_ss).  One cell
+// column is not reproducible: for column 1 the reference calls ScoreSS with a stale loop variable and reads the template's
+// SS state one element past its last column (src/hhforwardalgorithm.cpp:77) - zero in a fresh HMM, which is what is used
+// here.  Not supported (the run stops with a message instead of computing something else): self alignments (hit.self),
+// templates longer than 2046 columns (about 800 with secondary-structure scoring).
 #include <sys/time.h>
 
 #include <map>
@@ -121,11 +124,6 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
       HH_LOG(ERROR) << "hhviterbi_hip: MAC realignment of self alignments is not supported on the device" << std::endl;
       exit(4);
     }
-    if (h->ssm2 == 1 || h->ssm2 == 2) {
-      HH_LOG(ERROR) << "hhviterbi_hip: MAC realignment with secondary-structure scoring against DSSP states (hit " << h->name
-                    << ", ssm2 = " << h->ssm2 << ") is not supported on the device; run with -ssm 0" << std::endl;
-      exit(4);
-    }
     alignments_map[h->entry->getName()].push_back(h);
   }
   std::vector<std::vector<Hit*> > alignment;
@@ -189,6 +187,26 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   }
   std::vector<int32_t> q_ranges = mac_region_pairs(par.exclstr), t_ranges = mac_region_pairs(par.template_exclstr);
 
+  // ---- secondary-structure scoring inside forward / backward (hit.ssm2 = 1 or 2): the factors fpow2(ScoreSS) as tables ----
+  // Viterbi::ScoreSS(q, t, i, j, ssw, hit.ssm2, ...) (src/hhviterbi.h:193-211) is ssw * S37[q_pred][q_conf][t_dssp] for
+  // ssm2 = 1 (HMM::PRED_DSSP) and ssw * S73[q_dssp][t_pred][t_conf] for 2 (HMM::DSSP_PRED); 3 has no case there (factor 1).
+  bool any_ss = false;
+  for (size_t i = 0; i < hits.size(); i++) any_ss = any_ss || hits[i]->ssm2 == 1 || hits[i]->ssm2 == 2;
+  std::vector<float> ss_tables;
+  std::vector<uint8_t> ss_qidx;
+  if (any_ss) {
+    ss_tables.assign(2 * 352, 1.0f);
+    for (int qp = 0; qp < 44; ++qp)
+      for (int d = 0; d < 8; ++d) ss_tables[qp * 8 + d] = fpow2(par.ssw * S37[qp / MAXCF][qp % MAXCF][d]);
+    for (int qd = 0; qd < 8; ++qd)
+      for (int tp = 0; tp < 44; ++tp) ss_tables[352 + qd * 44 + tp] = fpow2(par.ssw * S73[qd][tp / MAXCF][tp % MAXCF]);
+    ss_qidx.assign((size_t)2 * (q.L + 2), 0);
+    for (int i = 1; i <= q.L; ++i) {
+      if (q.nss_pred >= 0) ss_qidx[i] = (uint8_t)(q.ss_pred[i] * MAXCF + q.ss_conf[i]);
+      if (q.nss_dssp >= 0) ss_qidx[(size_t)(q.L + 2) + i] = (uint8_t)q.ss_dssp[i];
+    }
+  }
+
   std::lock_guard<std::mutex> device_lock(g_mac_device);
   if (!g_mac_ctx) {
     hhv_params hp;
@@ -234,6 +252,27 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
       tp[b] = tmpl[g].p.data();
       ttr[b] = tmpl[g].tr_lin.data();
       Lt[b] = tmpl[g].L;
+    }
+    if (any_ss) {
+      std::vector<int32_t> mode(n, 0);
+      std::vector<std::vector<uint8_t> > tidx(n);
+      std::vector<const uint8_t*> tidx_p(n, (const uint8_t*)NULL);
+      bool round_has_ss = false;
+      for (int b = 0; b < n; ++b) {
+        const Hit* hit = alignment[group_of[b]][r];
+        const PreparedTemplate& pt = tmpl[group_of[b]];
+        if (hit->ssm2 != 1 && hit->ssm2 != 2) continue;
+        mode[b] = hit->ssm2;
+        round_has_ss = true;
+        // entry L+1 stays 0: the reference reads the element past the template's records there (the stale loop variable of
+        // src/hhforwardalgorithm.cpp:77), which is zero in a freshly allocated HMM
+        tidx[b].assign((size_t)pt.L + 2, 0);
+        for (int j = 1; j <= pt.L; ++j)
+          tidx[b][j] = hit->ssm2 == 1 ? (uint8_t)pt.dssp[j] : (uint8_t)(pt.pred[j] * MAXCF + pt.conf[j]);
+        tidx_p[b] = tidx[b].data();
+      }
+      if (round_has_ss)
+        mac_check(hhv_mac_set_ss(ctx, ss_tables.data(), ss_qidx.data(), q.L, n, mode.data(), tidx_p.data(), Lt.data()), "hhv_mac_set_ss");
     }
     hhv_macset* ms = NULL;
     std::vector<hhv_mac_hit> res(n);

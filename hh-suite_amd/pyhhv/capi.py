@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
-    "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
+    "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_hits",
@@ -96,6 +96,7 @@ def load():
     L.hhv_set_query_ss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_set_ss_mode.argtypes = [C.c_void_p, C.c_int32]
     L.hhv_set_global_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hhv_mac_set_ss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_set_params.argtypes = [C.c_void_p, C.POINTER(HhvParams)]
     L.hhv_hit_path_pool.argtypes = [C.c_void_p, C.c_void_p] + [C.POINTER(C.c_void_p)] * 5
     L.hhv_adopt_device_stream.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.c_void_p, C.POINTER(C.c_void_p)]

@@ -215,7 +215,7 @@ int hhv_prefilter_scores(hhv_ctx* ctx, hhv_pfdb* db, const uint8_t* profile, int
  *       assignments of initializeForAlignment (src/hhposteriordecoder.cpp:159-167)
  *   celloff[k]: (Lq+1)*(Lt+1) bytes, non-zero = cell excluded (the mask realign() builds: band around the Viterbi
  *       path, earlier alternative alignments, -excl regions); NULL = no cell excluded
- *   local / shift / mact: par.loc, par.shift, par.mact.  Secondary-structure scoring (ssm) is not supported here.
+ *   local / shift / mact: par.loc, par.shift, par.mact.  Secondary-structure scoring: hhv_mac_set_ss before the call.
  * hits[k] receives the alignment summary; paths and posteriors stay on the device in *out until fetched. */
 typedef struct hhv_mac_hit {
   double Pforward;       /* Hit::Pforward (scaled total forward probability) */
@@ -253,6 +253,19 @@ int hhv_mac_realign_tset(hhv_ctx* ctx, const float* q_p, const float* q_tr_lin, 
                          const int32_t* template_of, const float* const* t_tr_lin, const hhv_mac_input* in, int32_t n_qranges,
                          const int32_t* qranges, int32_t n_tranges, const int32_t* tranges, int32_t local, float shift,
                          float mact, hhv_macset** out, hhv_mac_hit* hits);
+/* Secondary-structure scoring inside the NEXT hhv_mac_realign* call of this context: PosteriorDecoder multiplies the match
+ * probability of every cell by fpow2(Viterbi::ScoreSS(q, t, i, j, ssw, hit.ssm2, ...)) (src/hhforwardalgorithm.cpp:77,100,
+ * src/hhbackwardalgorithm.cpp:82).
+ *   tables  [2][352] floats, the factors themselves: [0] = fpow2(ssw * S37[q_pred][q_conf][t_dssp]) as [44][8] (hit mode 1,
+ *           HMM::PRED_DSSP), [1] = fpow2(ssw * S73[q_dssp][t_pred][t_conf]) as [8][44] (mode 2, HMM::DSSP_PRED)
+ *   q_idx   [2][Lq+2] row index of every query column for the two modes (ss_pred*11 + ss_conf; ss_dssp)
+ *   mode[k] hit.ssm2 of hit k: 0 = none, 1, 2 (ssm2 = 3 scores nothing in the reference: pass 0)
+ *   t_idx[k] [Lt[k]+2] column index of the template for the hit's mode (ss_dssp; ss_pred*11 + ss_conf); entry Lt+1 is the
+ *           element PAST the template, which the reference reads for the cells of column 1 (the stale loop variable of
+ *           src/hhforwardalgorithm.cpp:77).  NULL for mode 0.
+ * The setting is consumed by one call.  Hits with a mode need templates that fit the LDS-staged kernels (<= ~800 columns). */
+int hhv_mac_set_ss(hhv_ctx* ctx, const float* tables, const uint8_t* q_idx, int32_t Lq, int32_t n, const int32_t* mode,
+                   const uint8_t* const* t_idx, const int32_t* Lt);
 /* the mask of hit k as the kernels saw it, (Lq+1)*(Lt+1) bytes */
 int hhv_mac_celloff(hhv_macset* ms, int32_t k, uint8_t* mask);
 /* path of hit k: entries 1..nsteps (Hit::i, ::j, ::states, ::S, ::P_posterior); cap >= nsteps + 1 */

@@ -13,6 +13,7 @@
 #define RUN_NAME ref_realign_run_cpu
 #endif
 
+#include <malloc.h>
 #include <sys/time.h>
 
 #include <cstdio>
@@ -71,6 +72,10 @@ int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* 
              const char* exclstr, const char* template_exclstr, int cap_hits, rl_hit* hits, int path_cap, int32_t* pi,
              int32_t* pj, int8_t* pstates, float* pS, float* pS_ss, float* pP, int32_t* alt_i, int32_t* alt_j,
              double* realign_seconds) {
+  // Fresh heap memory reads as zero from here on: the reference's forward pass reads the template's secondary-structure state
+  // one element past its last column (src/hhforwardalgorithm.cpp:77, stale loop variable), i.e. uninitialised memory of a
+  // scratch HMM; with M_PERTURB = 255 malloc fills new blocks with ~255 = 0 and the comparison is deterministic.
+  mallopt(M_PERTURB, 255);
   Parameters par(0, NULL);
   Log::reporting_level() = WARNING;
   par.nocontxt = 1;

@@ -99,9 +99,31 @@ def test_dropin_realign_excluded_regions_and_mact():
 @pytest.mark.gpu
 def test_dropin_realign_pred_pred_ss_is_a_noop():
     """query and templates with predicted SS only: hit.ssm2 = 3, for which Viterbi::ScoreSS has no case (MAC scores no SS)"""
-    q, t, names = make_db(77, 130, 24, 50, 200, ss_every=1, query_ss=True)
-    t = [x.replace(b">ss_dssp", b">xx_dssp") for x in t]          # drop the DSSP records: PRED_PRED only
-    q = q.replace(b">ss_dssp", b">xx_dssp")
+    q, t, names = make_db(77, 130, 24, 50, 200, ss_every=1, query_ss=("pred", "conf"), ss_keys=("pred", "conf"))
     ref = realign("cpu", q, t, names, ssm=2)
     got = realign("hip", q, t, names, ssm=2)
     compare(ref, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which_ss", ["pred_dssp", "dssp_pred"])
+def test_dropin_realign_secondary_structure_in_mac(which_ss):
+    """hit.ssm2 = 1 (query with predicted SS, templates with DSSP states: the HHpred situation) and 2 (the reverse): forward and
+    backward multiply every match probability by fpow2(ScoreSS) (src/hhforwardalgorithm.cpp:100, hhbackwardalgorithm.cpp:82).
+    Templates without the needed records in the same search get ssm2 = 0 or 3 and are realigned without the factor.
+    All templates have ONE length: for the cells of column 1 the reference reads the template's SS state one element past its
+    last column (stale loop variable, src/hhforwardalgorithm.cpp:77) out of a scratch HMM that is reused from template to
+    template - with ragged lengths that element is whatever a longer template left there earlier in the same thread, which no
+    implementation can reproduce; with one length it is never written and reads as zero (the harness zero-fills fresh heap
+    memory), which is also what the drop-in assumes."""
+    if which_ss == "pred_dssp":      # query: pred only; templates: all records, every fourth one none
+        q, t, names = make_db(81, 130, 30, 150, 150, ss_every=1, query_ss=("pred", "conf"))
+        _, t_plain, _ = make_db(81, 130, 30, 150, 150)
+        t = [x if k % 4 else t_plain[k] for k, x in enumerate(t)]
+    else:                            # query: dssp only; templates: pred only
+        q, t, names = make_db(81, 130, 30, 150, 150, ss_every=1, query_ss=("dssp",), ss_keys=("pred", "conf"))
+    ref = realign("cpu", q, t, names, ssm=2)
+    got = realign("hip", q, t, names, ssm=2, threads=3)
+    assert compare(ref, got) >= 10
+    plain = realign("cpu", q, t, names, ssm=0)          # the factor matters: without it the posteriors differ
+    assert any(not np.array_equal(a, b) for a, b in zip(ref[1][5], plain[1][5]))

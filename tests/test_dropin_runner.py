@@ -63,10 +63,16 @@ def run(which, query, templates, names, seq_len=None, loc=1, altali=4, ssm=2, ea
     return [hits[k] for k in range(m)], pi[:m], pj[:m], ps[:m], pS[:m], pSS[:m]
 
 
-def make_db(seed, Lq, n, lo, hi, ss_every=0, query_ss=False, homolog_every=2, same_len_every=0, ss_longest=0):
+def _ss(seed, L, keys):
+    """random secondary-structure records; keys: True = all three, or a tuple out of ("dssp", "pred", "conf")"""
+    d = hhm_text.random_ss(seed, L)
+    return d if keys is True else {k: v for k, v in d.items() if k in keys}
+
+
+def make_db(seed, Lq, n, lo, hi, ss_every=0, query_ss=False, homolog_every=2, same_len_every=0, ss_longest=0, ss_keys=True):
     rng = np.random.default_rng(seed)
     qf = hhm_text.random_columns(seed * 7 + 1, Lq)
-    query = hhm_text.hhm_text("query%d" % seed, qf, seed, ss=hhm_text.random_ss(seed, Lq) if query_ss else None)
+    query = hhm_text.hhm_text("query%d" % seed, qf, seed, ss=_ss(seed, Lq, query_ss) if query_ss else None)
     texts, names = [], []
     Ls = [int(rng.integers(lo, hi + 1)) for _ in range(n)]
     if same_len_every:                  # equal lengths: the order std::sort leaves them in matters
@@ -82,7 +88,7 @@ def make_db(seed, Lq, n, lo, hi, ss_every=0, query_ss=False, homolog_every=2, sa
                 f[L // 2:L // 2 + L // 3] = f[:L // 3]
         else:
             f = hhm_text.random_columns(seed * 1000 + k, L)
-        ss = hhm_text.random_ss(seed * 31 + k, f.shape[0]) if ((ss_every and k % ss_every == 0) or k in with_ss) else None
+        ss = _ss(seed * 31 + k, f.shape[0], ss_keys) if ((ss_every and k % ss_every == 0) or k in with_ss) else None
         names.append("t%d_%05d" % (seed, k))
         texts.append(hhm_text.hhm_text(names[-1], f, seed * 1000 + k, ss=ss))
     return query, texts, names
