@@ -1,0 +1,110 @@
+"""The reference's own applications with the three replaced translation units: oracle/Makefile compiles hhsearch and hhblits
+(src/hhblits_app.cpp and everything behind it) directly with g++ twice - `*_cpu` from the reference's translation units only,
+`*_hip` with src/hhviterbirunner.cpp, src/hhposteriordecoderrunner.cpp and src/hhprefilter.cpp replaced by
+hh-suite_amd/dropin/*_hip.cpp (no renaming, linked with libhhviterbi_hip.so) - and this test runs both command lines on the
+same ffindex database and compares the result files (.hhr hit list + alignments, score file, alignment table).
+BASELINE.json configs[0] is the first case: hhsearch, a 431-column query, 64 synthetic templates of 200 columns."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import hhm_text
+from test_dropin_runner import make_db
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref")
+
+
+def have(name):
+    return os.path.exists(os.path.join(BIN, name))
+
+
+def write_ffindex(path_base, entries):
+    """entries: list of (name, bytes); data = payload + NUL, index sorted by name (lib/ffindex/src/ffindex.h)"""
+    data, index, at = bytearray(), [], 0
+    for name, payload in entries:
+        blob = payload + b"\0"
+        data += blob
+        index.append((name, at, len(blob)))
+        at += len(blob)
+    open(path_base + ".ffdata", "wb").write(bytes(data))
+    open(path_base + ".ffindex", "w").write("".join("%s\t%d\t%d\n" % e for e in sorted(index)))
+
+
+def build_db(tmp, query, templates, names, seed):
+    """<tmp>/db_hhm.ff{data,index} with the .hhm texts and <tmp>/db_cs219.ff{data,index} with one random column-state
+    sequence per template under the same name (the prefilter only has to be deterministic here, not sensitive)."""
+    rng = np.random.default_rng(seed)
+    base = os.path.join(tmp, "db")
+    write_ffindex(base + "_hhm", [(n, t) for n, t in zip(names, templates)])
+    cs = []
+    for n, t in zip(names, templates):
+        L = int(t.split(b"LENG")[1].split()[0])
+        cs.append((n, bytes(rng.integers(0, 219, L).astype(np.uint8))))
+    write_ffindex(base + "_cs219", cs)
+    qpath = os.path.join(tmp, "query.hhm")
+    open(qpath, "wb").write(query)
+    return base, qpath
+
+
+def run_app(binary, args, out_prefix):
+    cmd = [os.path.join(BIN, binary)] + args + ["-o", out_prefix + ".hhr", "-scores", out_prefix + ".scores", "-atab",
+                                                out_prefix + ".atab", "-v", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, (cmd, r.stdout.decode()[-2000:])
+    out = {}
+    for ext in ("hhr", "scores", "atab"):
+        lines = open(out_prefix + "." + ext).read().splitlines()
+        out[ext] = [l for l in lines if not l.startswith(("Date", "Command", "FILE", "COMM"))]   # time stamp, command line
+    return out
+
+
+def compare_outputs(a, b):
+    for ext in a:
+        assert len(a[ext]) == len(b[ext]), (ext, len(a[ext]), len(b[ext]))
+        for k, (x, y) in enumerate(zip(a[ext], b[ext])):
+            assert x == y, (ext, k, x, y)
+    assert len(a["hhr"]) > 20
+
+
+@pytest.mark.skipif(not have("hhsearch_cpu"), reason="oracle/_ref/hhsearch_cpu not built (needs /root/reference at build time)")
+def test_reference_hhsearch_runs_on_the_synthetic_database(tmp_path):
+    """CPU only: the reference's hhsearch, compiled by oracle/Makefile, on a database written by this test"""
+    q, t, names = make_db(500, 120, 16, 60, 160)
+    base, qpath = build_db(str(tmp_path), q, t, names, 1)
+    out = run_app("hhsearch_cpu", ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "2"], str(tmp_path / "cpu"))
+    hits = [l for l in out["hhr"] if l.startswith("No ")]
+    assert len(hits) >= 8
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("case", ["configs0", "ragged_global", "ss"])
+def test_hhsearch_with_replaced_units_writes_the_same_files(tmp_path, case):
+    extra = []
+    if case == "configs0":          # BASELINE.json configs[0]
+        q, t, names = make_db(431, 431, 64, 200, 200)
+    elif case == "ragged_global":
+        q, t, names = make_db(501, 150, 60, 40, 260, same_len_every=5)
+        extra = ["-glob"]
+    else:                           # query with predicted SS, templates with DSSP + predicted SS (one length, see test_dropin_realign)
+        q, t, names = make_db(502, 130, 40, 150, 150, ss_every=1, query_ss=("pred", "conf"))
+    base, qpath = build_db(str(tmp_path), q, t, names, 2)
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "1"] + extra
+    cpu = run_app("hhsearch_cpu", args, str(tmp_path / "cpu"))
+    hip = run_app("hhsearch_hip", args, str(tmp_path / "hip"))
+    compare_outputs(cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhblits_hip"), reason="oracle/_ref/hhblits_hip not built (needs /root/reference at build time)")
+def test_hhblits_with_replaced_units_writes_the_same_files(tmp_path):
+    """one hhblits iteration: prefilter (replaced) -> Viterbi (replaced) -> MAC realignment (replaced) -> result files"""
+    q, t, names = make_db(503, 140, 300, 50, 220, homolog_every=3)
+    base, qpath = build_db(str(tmp_path), q, t, names, 3)
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-n", "1", "-cpu", "1"]
+    cpu = run_app("hhblits_cpu", args, str(tmp_path / "cpu"))
+    hip = run_app("hhblits_hip", args, str(tmp_path / "hip"))
+    compare_outputs(cpu, hip)
