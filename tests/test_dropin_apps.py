@@ -108,3 +108,41 @@ def test_hhblits_with_replaced_units_writes_the_same_files(tmp_path):
     cpu = run_app("hhblits_cpu", args, str(tmp_path / "cpu"))
     hip = run_app("hhblits_hip", args, str(tmp_path / "hip"))
     compare_outputs(cpu, hip)
+
+
+def read_ffindex(base):
+    data = open(base + ".ffdata", "rb").read()
+    out = {}
+    for line in open(base + ".ffindex"):
+        name, off, ln = line.split("\t")
+        text = data[int(off):int(off) + int(ln)].rstrip(b"\0").decode()
+        out[name] = [l for l in text.splitlines() if not l.startswith(("Date", "Command", "FILE", "COMM"))]
+    return out
+
+
+def run_omp_app(binary, args, out_prefix):
+    cmd = [os.path.join(BIN, binary)] + args + ["-o", out_prefix + "_hhr", "-scores", out_prefix + "_scores", "-v", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, (cmd, r.stdout.decode()[-2000:])
+    return {"hhr": read_ffindex(out_prefix + "_hhr"), "scores": read_ffindex(out_prefix + "_scores")}
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhsearch_omp_hip"), reason="oracle/_ref/hhsearch_omp_hip not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("app,extra", [("hhsearch_omp", []), ("hhblits_omp", ["-n", "1"])])
+def test_omp_applications_with_replaced_units(tmp_path, app, extra):
+    """hhsearch_omp / hhblits_omp (src/hhblits_omp.cpp): six queries of an ffindex searched by three concurrent threads of ONE
+    process - the situation the resident template cache is made for (the later queries find the templates on the device) and
+    the one in which its device sections are contended."""
+    _, t, names = make_db(510, 150, 150, 50, 220, homolog_every=3)
+    queries = [make_db(520 + k, 110 + 12 * k, 1, 50, 50)[0] for k in range(6)]
+    base, _ = build_db(str(tmp_path), queries[0], t, names, 4)
+    qbase = os.path.join(str(tmp_path), "queries")
+    write_ffindex(qbase, [("q%02d" % k, q.rstrip(b"\n")) for k, q in enumerate(queries)])
+    args = ["-i", qbase, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "3"] + extra
+    cpu = run_omp_app(app + "_cpu", args, str(tmp_path / "cpu"))
+    hip = run_omp_app(app + "_hip", args, str(tmp_path / "hip"))
+    for kind in cpu:
+        assert sorted(cpu[kind]) == sorted(hip[kind]) and len(cpu[kind]) == 6
+        for name in cpu[kind]:
+            assert cpu[kind][name] == hip[kind][name], (kind, name)
