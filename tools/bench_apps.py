@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""tools/bench_apps.py [n_templates] [threads] [n_queries] -- wall time of the reference's own command-line programs, built by
+oracle/Makefile from the reference's sources (`*_cpu`) and with the three translation units of hh-suite_amd/dropin/ swapped in
+(`*_hip`), on one synthetic ffindex database (templates and queries of 300 columns):
+  hhsearch      -i query.hhm   -d db -cpu <threads>          one query, the threads work on its templates
+  hhsearch_omp  -i queries     -d db -cpu <min(threads, nq)> n_queries queries, one thread each (src/hhblits_omp.cpp)
+Whole-process wall time (start-up, database open, query read, search, realignment, output files); outputs compared.
+Run on the GPU box."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import hhm_text
+from test_dropin_apps import BIN, build_db, compare_outputs, read_ffindex, run_app, write_ffindex
+
+
+def timed(fn, *a):
+    t0 = time.time()
+    r = fn(*a)
+    return time.time() - t0, r
+
+
+def run_omp(binary, args, prefix):
+    cmd = [os.path.join(BIN, binary)] + args + ["-o", prefix + "_hhr", "-v", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=3000)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return read_ffindex(prefix + "_hhr")
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    nq = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    L = 300
+    rng = np.random.default_rng(5)
+    qfs = [hhm_text.random_columns(900 + k, L) for k in range(nq)]
+    queries = [hhm_text.hhm_text("query%02d" % k, qfs[k], 900 + k) for k in range(nq)]
+    uniq = min(n, 400)
+    base_txt = []
+    for k in range(uniq):
+        f = hhm_text.mutate_columns(k, qfs[k % nq], 0.4) if k % 20 == 0 else hhm_text.random_columns(2000 + k, L)
+        base_txt.append(hhm_text.hhm_text("@NAME@", f, k))
+    names = ["a%06d" % k for k in range(n)]
+    texts = [base_txt[k % uniq].replace(b"@NAME@", names[k].encode()) for k in range(n)]
+    out = {"n_templates": n, "L": L, "threads": threads, "n_queries": nq}
+    with tempfile.TemporaryDirectory() as tmp:
+        base, qpath = build_db(tmp, queries[0], texts, names, 9)
+        common = ["-d", base, "-nocontxt", "-premerge", "0"]
+        args = ["-i", qpath, "-cpu", str(threads)] + common
+        t_cpu, o_cpu = timed(run_app, "hhsearch_cpu", args, os.path.join(tmp, "c1"))
+        t_hip, o_hip = timed(run_app, "hhsearch_hip", args, os.path.join(tmp, "h1"))
+        # with several threads the reference adds equal-score hits in thread order: compare the sorted hit lines
+        same = sorted(o_cpu["scores"]) == sorted(o_hip["scores"])
+        out["hhsearch_one_query"] = {"reference_s": round(t_cpu, 2), "replaced_units_s": round(t_hip, 2), "same_scores_file": same}
+        qbase = os.path.join(tmp, "queries")
+        write_ffindex(qbase, [("q%02d" % k, q.rstrip(b"\n")) for k, q in enumerate(queries)])
+        args = ["-i", qbase, "-cpu", str(min(threads, nq))] + common
+        t_cpu, o_cpu = timed(run_omp, "hhsearch_omp_cpu", args, os.path.join(tmp, "c2"))
+        t_hip, o_hip = timed(run_omp, "hhsearch_omp_hip", args, os.path.join(tmp, "h2"))
+        same = all(o_cpu[k] == o_hip[k] for k in o_cpu) and sorted(o_cpu) == sorted(o_hip)
+        out["hhsearch_omp_%d_queries" % nq] = {"reference_s": round(t_cpu, 2), "replaced_units_s": round(t_hip, 2),
+                                                "same_hhr_files": same}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
