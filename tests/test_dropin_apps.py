@@ -56,6 +56,8 @@ def run_app(binary, args, out_prefix):
     assert r.returncode == 0, (cmd, r.stdout.decode()[-2000:])
     out = {}
     for ext in ("hhr", "scores", "atab"):
+        if not os.path.exists(out_prefix + "." + ext):
+            continue            # hhalign writes no score file
         lines = open(out_prefix + "." + ext).read().splitlines()
         out[ext] = [l for l in lines if not l.startswith(("Date", "Command", "FILE", "COMM"))]   # time stamp, command line
     return out
@@ -107,6 +109,23 @@ def test_hhblits_with_replaced_units_writes_the_same_files(tmp_path):
     args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-n", "1", "-cpu", "1"]
     cpu = run_app("hhblits_cpu", args, str(tmp_path / "cpu"))
     hip = run_app("hhblits_hip", args, str(tmp_path / "hip"))
+    compare_outputs(cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhalign_hip"), reason="oracle/_ref/hhalign_hip not built (needs /root/reference at build time)")
+def test_hhalign_with_replaced_units_writes_the_same_files(tmp_path):
+    """hhalign -i query -t template ...: HHalign::run hands HHFileEntry objects (files on disk) to the same ViterbiRunner"""
+    q, t, names = make_db(530, 140, 5, 100, 180, homolog_every=1)
+    qp = str(tmp_path / "q.hhm")
+    open(qp, "wb").write(q)
+    args = ["-i", qp, "-nocontxt"]
+    for k, x in enumerate(t):
+        p = str(tmp_path / ("t%d.hhm" % k))
+        open(p, "wb").write(x)
+        args += ["-t", p]
+    cpu = run_app("hhalign_cpu", args, str(tmp_path / "cpu"))
+    hip = run_app("hhalign_hip", args, str(tmp_path / "hip"))
     compare_outputs(cpu, hip)
 
 
