@@ -650,10 +650,14 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
   }
 }
 
-// ---- MAC backtrace: one lane per hit ----------------------------------------------------------------------------------
+// ---- MAC backtrace: one wavefront per hit --------------------------------------------------------------------------------
+// The walk itself is a pointer chase (src/hhbacktracemac.cpp:126-160) and every step used to cost one dependent trip to
+// L2 / HBM for a single code byte.  Now the wave fetches the 8 x 8 block of codes above-left of the current cell with one
+// load (lane l holds cell (i - l/8, j - l%8)) and walks inside it with v_readlane until it leaves the block: eight or more
+// steps per memory latency.  The per-step column scores and posteriors are then computed by all lanes, 64 steps at a time;
+// only the sum of the posteriors keeps the reference's sequential order (:196-197).
 __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= a.n) return;
+  const int k = blockIdx.x, lane = threadIdx.x;
   const HitView h = view(a, k);
   const int pitch = h.pitch;
   int* is = a.path_i + a.path_off[k];
@@ -661,20 +665,34 @@ __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
   signed char* st = a.path_state + a.path_off[k];
   float* Ss = a.path_S + a.path_off[k];
   float* Ps = a.path_P + a.path_off[k];
-  // :124-125: b[i][1] = b[1][j] = STOP
-  auto code_at = [&](int i, int j) -> int { return (i == 1 || j == 1) ? (int)MAC_STOP : (int)h.bmm[(size_t)i * pitch + j]; };
-  int i = a.hits[k].i2, j = a.hits[k].j2;
-  int step = 0, matched = 1, state = MAC_MM;
-  if (code_at(i, j) != MAC_MM) {
-    is[0] = i;
-    js[0] = j;
+  int i = __builtin_amdgcn_readfirstlane(a.hits[k].i2), j = __builtin_amdgcn_readfirstlane(a.hits[k].j2);
+  // the block of codes whose bottom-right corner is (bi, bj); :124-125: b[i][1] = b[1][j] = STOP
+  int bi = i, bj = j, codes;
+  auto load_block = [&]() {
+    const int ti = bi - (lane >> 3), tj = bj - (lane & 7);
+    codes = (ti < 1 || tj < 1 || ti == 1 || tj == 1) ? (int)MAC_STOP : (int)h.bmm[(size_t)ti * pitch + tj];
+  };
+  load_block();
+  int step = 0, state = MAC_MM, matched = 1;
+  if (__builtin_amdgcn_readlane(codes, 0) != MAC_MM) {
+    if (lane == 0) {
+      is[0] = i;
+      js[0] = j;
+    }
   } else {
     while (state != MAC_STOP) {
+      if (bi - i > 7 || bj - j > 7) {
+        bi = i;
+        bj = j;
+        load_block();
+      }
       step++;
-      state = code_at(i, j);
-      st[step] = (signed char)state;
-      is[step] = i;
-      js[step] = j;
+      state = __builtin_amdgcn_readlane(codes, (bi - i) * 8 + (bj - j));
+      if (lane == 0) {
+        st[step] = (signed char)state;
+        is[step] = i;
+        js[step] = j;
+      }
       if (state == MAC_MM) matched++;
       switch (state) {
         case MAC_MM: i--; j--; break;
@@ -685,29 +703,46 @@ __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
       }
     }
   }
-  st[step] = MAC_MM;  // :170
-  if (step > 0) {       // entry 0 is unused then (the reference leaves it uninitialised); keep it deterministic
-    is[0] = js[0] = 0;
-    st[0] = 0;
-  }
-  Ss[0] = Ps[0] = 0.0f;
-  float sum = 0.0f;
-  for (int s = 1; s <= step; ++s) {
-    if (st[s] == MAC_MM) {
-      Ss[s] = fast_log2_mac(dot20(h.qp + (size_t)is[s] * 20, h.tp + (size_t)js[s] * h.tps), a.lg2, a.diff);
-      Ps[s] = h.mat[(size_t)is[s] * pitch + js[s]];
-      sum += Ps[s];
-    } else {
-      Ss[s] = Ps[s] = 0.0f;
+  if (lane == 0) {
+    st[step] = MAC_MM;  // :170
+    if (step > 0) {       // entry 0 is unused then (the reference leaves it uninitialised); keep it deterministic
+      is[0] = js[0] = 0;
+      st[0] = 0;
     }
+    Ss[0] = Ps[0] = 0.0f;
   }
-  a.hits[k].nsteps = step;
-  a.hits[k].matched_cols = matched;
-  a.hits[k].i1 = is[step];
-  a.hits[k].j1 = js[step];
-  a.hits[k].sum_of_probs = sum;
-  a.hits[k].Pforward = a.Pforward[k];
-  a.hits[k].pad = 0;
+  __threadfence();  // the path written by lane 0 is read by all lanes below
+  // per-step scores (:183-203), 64 steps at a time
+  float sum = 0.0f;
+  const int i1 = step > 0 ? is[step] : is[0], j1 = step > 0 ? js[step] : js[0];
+  for (int s0 = 1; s0 <= step; s0 += 64) {
+    const int sidx = s0 + lane;
+    const bool in = sidx <= step;
+    const bool mm = in && st[sidx] == MAC_MM;
+    float S = 0.0f, P = 0.0f;
+    if (mm) {
+      const int si = is[sidx], sj = js[sidx];
+      S = fast_log2_mac(dot20(h.qp + (size_t)si * 20, h.tp + (size_t)sj * h.tps), a.lg2, a.diff);
+      P = h.mat[(size_t)si * pitch + sj];
+    }
+    if (in) {
+      Ss[sidx] = S;
+      Ps[sidx] = P;
+    }
+    const unsigned long long mm_mask = __ballot(mm);
+    const int cnt = min(64, step - s0 + 1);
+    for (int l = 0; l < cnt; ++l)  // the reference's sequential float sum over the match states, in step order
+      if ((mm_mask >> l) & 1ull) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P), l));
+  }
+  if (lane == 0) {
+    a.hits[k].nsteps = step;
+    a.hits[k].matched_cols = matched;
+    a.hits[k].i1 = i1;
+    a.hits[k].j1 = j1;
+    a.hits[k].sum_of_probs = sum;
+    a.hits[k].Pforward = a.Pforward[k];
+    a.hits[k].pad = 0;
+  }
 }
 
 #undef ROW
@@ -815,7 +850,7 @@ int launch_mac(const MacArgs& a0, bool local, int max_Lt, void* stream_) {
     if (stage) launch_mac_variant<false, true>(a, lds_rows, lds_dp, stream);
     else launch_mac_variant<false, false>(a, lds_rows, lds_dp, stream);
   }
-  hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3(a.n), dim3(64), 0, stream, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
