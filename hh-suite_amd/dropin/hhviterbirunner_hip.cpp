@@ -486,7 +486,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
   std::vector<HMMSimd*> t_simd(threads, (HMMSimd*)NULL);
 
   std::vector<hhv_tset*> search_sets;              // prepared sets of this search, freed at the end
-  std::map<HHEntry*, ResidentTemplate> resident;   // an entry listed twice is the same template
+  std::unordered_map<HHEntry*, ResidentTemplate> resident;   // an entry listed twice is the same template
   std::vector<SsRecords*> own_ss;                  // ss records of host-prepared templates
   std::vector<HHEntry*> work(dbfiles.begin(), dbfiles.end());
 
@@ -727,23 +727,25 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         }
 
         // ---- the ss mode of every SIMD batch of the reference (:14-22), then one launch per (set, mode) ----
+        std::vector<const ResidentTemplate*> rt(cn);  // one table lookup per template and round
+        for (unsigned int k = 0; k < cn; ++k) rt[k] = &resident[ent[k]];
         std::vector<int> batch_mode(cn);
         std::vector<uint8_t> shorter(cn, 0);  // shorter than the longest template of its batch (HMMSimd::L, src/hhhmmsimd.cpp:97)
         for (unsigned int b = 0; b < cn; b += VECSIZE_FLOAT) {
           int consensus = 0xFF, Lbatch = 0;
           const unsigned int e = imin(cn, b + VECSIZE_FLOAT);
           for (unsigned int k = b; k < e; ++k) {
-            consensus &= resident[ent[k]].ss_pair_mode;
-            Lbatch = imax(Lbatch, resident[ent[k]].L);
+            consensus &= rt[k]->ss_pair_mode;
+            Lbatch = imax(Lbatch, rt[k]->L);
           }
           const int mode = select_ss_mode(consensus);
           for (unsigned int k = b; k < e; ++k) {
             batch_mode[k] = mode;
-            shorter[k] = resident[ent[k]].L < Lbatch;
+            shorter[k] = rt[k]->L < Lbatch;
           }
         }
         std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> > groups;
-        for (unsigned int k = 0; k < cn; ++k) groups[std::make_pair(resident[ent[k]].set, batch_mode[k])].push_back(k);
+        for (unsigned int k = 0; k < cn; ++k) groups[std::make_pair(rt[k]->set, batch_mode[k])].push_back(k);
         {
           // device section 2: alignment, backtrace, Hit scores, paths
           std::lock_guard<std::mutex> lock(tc.device);
@@ -758,7 +760,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
             std::vector<uint8_t> not_longest(n);
             bool whole = (n == hhv_tset_size(g->first.first));
             for (int k = 0; k < n; ++k) {
-              tmpl[k] = &resident[ent[mem[k]]];
+              tmpl[k] = rt[mem[k]];
               ids[k] = tmpl[k]->index;
               out[k] = &hit0[mem[k]];
               not_longest[k] = shorter[mem[k]];
