@@ -83,24 +83,24 @@ Prefilter::~Prefilter() {
   delete cs_lib;
 }
 
-// src/hhprefilter.cpp:280-294
+namespace {
+// (length, name) of one index entry, the pair HHblitsDatabase::getEntriesFromNames expects
+std::pair<int, std::string> length_and_name(const ffindex_entry_t* e) { return std::make_pair((int)e->length, std::string(e->name)); }
+}  // namespace
+
+// no prefiltering (hhsearch): every entry of the database, in index order (src/hhprefilter.cpp:280-294)
 void Prefilter::init_no_prefiltering(FFindexDatabase* query_database, std::vector<std::pair<int, std::string> >& prefiltered_entries) {
-  ffindex_index_t* db_index = query_database->db_index;
-  for (size_t n = 0; n < db_index->n_entries; n++) {
-    ffindex_entry_t* entry = ffindex_get_entry_by_index(db_index, n);
-    prefiltered_entries.push_back(std::pair<int, std::string>(entry->length, std::string(entry->name)));
-  }
+  ffindex_index_t* index = query_database->db_index;
+  prefiltered_entries.reserve(prefiltered_entries.size() + index->n_entries);
+  for (size_t k = 0; k < index->n_entries; ++k) prefiltered_entries.push_back(length_and_name(ffindex_get_entry_by_index(index, k)));
   HH_LOG(INFO) << "Searching " << prefiltered_entries.size() << " database HHMs without prefiltering" << std::endl;
 }
 
-// src/hhprefilter.cpp:296-310
+// the entries named by the caller, in the caller's order (src/hhprefilter.cpp:296-310)
 void Prefilter::init_selected(FFindexDatabase* cs219_database, std::vector<std::string> templates,
                               std::vector<std::pair<int, std::string> >& prefiltered_entries) {
-  ffindex_index_t* db_index = cs219_database->db_index;
-  for (size_t n = 0; n < templates.size(); n++) {
-    ffindex_entry_t* entry = ffindex_get_entry_by_name(db_index, const_cast<char*>(templates[n].c_str()));
-    prefiltered_entries.push_back(std::pair<int, std::string>(entry->length, std::string(entry->name)));
-  }
+  for (std::vector<std::string>::iterator name = templates.begin(); name != templates.end(); ++name)
+    prefiltered_entries.push_back(length_and_name(ffindex_get_entry_by_name(cs219_database->db_index, const_cast<char*>(name->c_str()))));
 }
 
 // src/hhprefilter.cpp:315-338 + the upload: the column-state sequences go to the device once and stay there
@@ -141,13 +141,15 @@ void Prefilter::init_prefilter(FFindexDatabase* cs219_database) {
   HH_LOG(INFO) << "Searching " << num_dbs << " column state sequences." << std::endl;
 }
 
-// src/hhprefilter.cpp:340-353
+// The old text format of cs219 databases starts every entry with '>': refused like the reference does
+// (src/hhprefilter.cpp:340-353, including its way of counting: the limit of the scan shrinks with every hit)
 void Prefilter::checkCSFormat(size_t nr_checks) {
-  for (size_t n = 0; n < std::min(nr_checks, num_dbs); n++)
-    if (first[n][0] == '>') nr_checks--;
-  if (nr_checks == 0) {
-    HH_LOG(ERROR) << "In " << __FILE__ << ":" << __LINE__ << ": " << __func__ << ":" << std::endl;
-    HH_LOG(ERROR) << "\tYour cs database is in an old format that is no longer supported (see the user manual)." << std::endl;
+  size_t remaining = nr_checks;
+  for (size_t n = 0; n < std::min(remaining, num_dbs); n++)
+    if (first[n][0] == '>') remaining--;
+  if (remaining == 0) {
+    HH_LOG(ERROR) << "hhprefilter: the column-state database is in the old text format, which is no longer supported "
+                     "(see the user manual)" << std::endl;
     exit(1);
   }
 }
