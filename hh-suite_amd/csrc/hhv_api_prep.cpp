@@ -402,5 +402,12 @@ int hhv_tset_records_of(hhv_ctx* c, hhv_tset* ts, int32_t k, float* out) {
   return HHV_OK;
 }
 
+int hhv_tset_download(hhv_ctx* c, hhv_tset* ts, float* out) {
+  if (!c || !ts || !out) return fail(HHV_E_ARG, "hhv_tset_download: null argument");
+  HIP_TRY(hipSetDevice(c->par.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out, ts->d_records, (size_t)ts->n_records * REC_DW * sizeof(float), hipMemcpyDeviceToHost));
+  return HHV_OK;
+}
 
 }  // extern "C"

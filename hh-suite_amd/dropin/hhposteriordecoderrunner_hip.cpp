@@ -35,6 +35,7 @@
 
 #include "hhposteriordecoderrunner.h"
 #include "hhviterbi_hip.h"
+#include "hhv_template_cache.h"
 
 #ifdef OPENMP
 #include <omp.h>
@@ -71,10 +72,8 @@ std::vector<int32_t> mac_region_pairs(char* exclstr) {  // exclude_regions, src/
   return out;
 }
 
-// One device context per process, created at the first realignment and kept (stream, tables and the recycled device
-// block of the MAC stage survive from call to call); concurrent callers (hhblits_omp) take turns on it.
-std::mutex g_mac_device;
-hhv_ctx* g_mac_ctx = NULL;
+// The device context is the process-wide one of the resident template cache (hhv_template_cache.h): stream, tables and the
+// recycled device block of the MAC stage survive from call to call; concurrent callers (hhblits_omp) take turns on it.
 
 struct PreparedTemplate {
   int L;
@@ -135,12 +134,35 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   }
   const int n_groups = (int)alignment.size();
 
-  // ---- the template of every group, read and prepared by the reference's code (:98-99), linear transitions ----
+  // ---- the template of every group ----
+  // Templates the Viterbi stage left in the resident cache (raw columns on the device) are prepared there for this query and
+  // fetched back prepared - nothing is parsed; the others are read and prepared by the reference's code (:98-99).  Either way
+  // the transitions become linear on the host: 2^x is the host's powf (HMM::Log2LinTransitionProbs, src/hhhmm.cpp:2305-2313).
+  hhv_dropin::TemplateCache& tc = hhv_dropin::cache();
   const int threads = m_n_threads > 0 ? m_n_threads : 1;
-  std::vector<HMM*> t_hmm(threads, (HMM*)NULL);
   std::vector<PreparedTemplate> tmpl(n_groups);
+  std::vector<const hhv_dropin::CachedTemplate*> cached(n_groups, (const hhv_dropin::CachedTemplate*)NULL);
+  bool use_cache = tc.enabled && hhv_dropin::device_prepare_covers(par);
+  {
+    std::lock_guard<std::mutex> lock(tc.device);
+    use_cache = use_cache && !tc.map.empty() && tc.nseqdis == par.nseqdis && tc.ssm == par.ssm;
+    if (use_cache) {
+      tc.active++;  // keeps the entries alive until the end of this call
+      for (int g = 0; g < n_groups; ++g) {
+        std::unordered_map<std::string, hhv_dropin::CachedTemplate>::const_iterator it =
+            tc.map.find(hhv_dropin::cache_key(alignment[g][0]->entry));
+        if (it != tc.map.end()) cached[g] = &it->second;
+      }
+    }
+  }
+  std::vector<int> to_read;
+  for (int g = 0; g < n_groups; ++g)
+    if (!cached[g]) to_read.push_back(g);
+  std::vector<HMM*> t_hmm(threads, (HMM*)NULL);
+  const int n_read = (int)to_read.size();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-  for (int g = 0; g < n_groups; ++g) {
+  for (int r = 0; r < n_read; ++r) {
+    const int g = to_read[r];
     int tid = 0;
 #ifdef OPENMP
     tid = omp_get_thread_num();
@@ -158,9 +180,86 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
       if (i >= 1) memcpy(&pt.p[(size_t)i * 20], t->p[i], 20 * sizeof(float));
       memcpy(&pt.tr_lin[(size_t)i * 7], t->tr[i], 7 * sizeof(float));
     }
-    // initializeForAlignment (src/hhposteriordecoder.cpp:159-167)
+    pt.has_dssp = t->nss_dssp >= 0;
+    pt.dssp.assign(t->ss_dssp, t->ss_dssp + t->L + 1);
+    pt.pred.assign(t->ss_pred, t->ss_pred + t->L + 1);
+    pt.conf.assign(t->ss_conf, t->ss_conf + t->L + 1);
+  }
+  for (int k = 0; k < threads; ++k) delete t_hmm[k];
+  t_read = mac_now() - t_mark;
+  t_mark = mac_now();
+
+  std::lock_guard<std::mutex> device_lock(tc.device);
+  if (!tc.ctx) {
+    hhv_params hp;
+    memset(&hp, 0, sizeof(hp));
+    hp.device = tc.device_id;
+    hp.local = 1;
+    mac_check(hhv_create(&tc.ctx, &hp), "hhv_create");
+  }
+  hhv_ctx* ctx = tc.ctx;
+  if (n_read < n_groups) {
+    // PrepareTemplateHMM on the device (hhv_prepare_subset), one launch per raw set, and the prepared records back in one copy
+    const hhv_prep_params prep = hhv_dropin::prepare_params(par, pb, R);
+    std::map<hhv_rawset*, std::vector<int> > by_raw;
+    for (int g = 0; g < n_groups; ++g)
+      if (cached[g]) by_raw[cached[g]->raw].push_back(g);
+    for (std::map<hhv_rawset*, std::vector<int> >::iterator b = by_raw.begin(); b != by_raw.end(); ++b) {
+      const std::vector<int>& mem = b->second;
+      std::vector<int32_t> ids(mem.size());
+      for (size_t x = 0; x < mem.size(); ++x) ids[x] = cached[mem[x]]->index;
+      hhv_tset* set = NULL;
+      mac_check(hhv_prepare_subset(ctx, b->first, &prep, q.pav, ids.data(), (int32_t)ids.size(), &set), "hhv_prepare_subset");
+      std::vector<float> rec((size_t)hhv_tset_records(set) * 28);
+      mac_check(hhv_tset_download(ctx, set, rec.data()), "hhv_tset_download");
+      hhv_tset_free(set);
+      size_t at = 0;  // header record of the template
+      for (size_t x = 0; x < mem.size(); ++x) {
+        const hhv_dropin::CachedTemplate& ct = *cached[mem[x]];
+        PreparedTemplate& pt = tmpl[mem[x]];
+        const int L = ct.L;
+        pt.L = L;
+        pt.p.assign((size_t)(L + 1) * 20, 0.0f);
+        pt.tr_lin.assign((size_t)(L + 1) * 7, 0.0f);
+        // column record j (layout: DESIGN.md section 2): [0..19] p[j], [20..24] tr[j-1][M2M, M2D, D2M, D2D, I2M], [25..26] tr[j][I2I, M2I]
+        for (int j = 1; j <= L; ++j) {
+          const float* w = &rec[(at + j) * 28];
+          memcpy(&pt.p[(size_t)j * 20], w, 20 * sizeof(float));
+          float* prev = &pt.tr_lin[(size_t)(j - 1) * 7];
+          prev[M2M] = w[20];
+          prev[M2D] = w[21];
+          prev[D2M] = w[22];
+          prev[D2D] = w[23];
+          prev[I2M] = w[24];
+          float* cur = &pt.tr_lin[(size_t)j * 7];
+          cur[I2I] = w[25];
+          cur[M2I] = w[26];
+        }
+        at += (size_t)L + 1;
+        pt.has_dssp = !ct.ss.dssp.empty();
+        pt.dssp.assign(L + 1, 0);
+        pt.pred.assign(L + 1, 0);
+        pt.conf.assign(L + 1, 0);
+        for (int j = 1; j <= L; ++j) {
+          if (!ct.ss.dssp.empty()) pt.dssp[j] = (char)ct.ss.dssp[j];
+          if (!ct.ss.pred.empty()) pt.pred[j] = (char)ct.ss.pred[j];
+          if (!ct.ss.conf.empty()) pt.conf[j] = (char)ct.ss.conf[j];
+        }
+      }
+    }
+    // HMM::Log2LinTransitionProbs(1.0) of the rows that keep their value (rows 0 and L are assigned below)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (int g = 0; g < n_groups; ++g) {
+      if (!cached[g]) continue;
+      PreparedTemplate& pt = tmpl[g];
+      for (size_t e = 7; e < (size_t)pt.L * 7; ++e) pt.tr_lin[e] = powf(2.0f, 1.0f * pt.tr_lin[e]);
+    }
+  }
+  // initializeForAlignment (src/hhposteriordecoder.cpp:159-167)
+  for (int g = 0; g < n_groups; ++g) {
+    PreparedTemplate& pt = tmpl[g];
     float* t0 = &pt.tr_lin[0];
-    float* tL = &pt.tr_lin[(size_t)t->L * 7];
+    float* tL = &pt.tr_lin[(size_t)pt.L * 7];
     t0[M2M] = 1.0f;
     t0[M2D] = t0[M2I] = 0.0f;
     t0[I2M] = t0[I2I] = 0.0f;
@@ -170,14 +269,8 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
     tL[I2M] = tL[I2I] = 0.0f;
     tL[D2M] = 1.0f;
     tL[D2D] = 0.0f;
-    pt.has_dssp = t->nss_dssp >= 0;
-    pt.dssp.assign(t->ss_dssp, t->ss_dssp + t->L + 1);
-    pt.pred.assign(t->ss_pred, t->ss_pred + t->L + 1);
-    pt.conf.assign(t->ss_conf, t->ss_conf + t->L + 1);
   }
-  for (int k = 0; k < threads; ++k) delete t_hmm[k];
-  t_read = mac_now() - t_mark;
-  t_mark = mac_now();
+  t_create = mac_now() - t_mark;
 
   // ---- the query as the device wants it ----
   std::vector<float> q_p((size_t)(q.L + 1) * 20, 0.0f), q_tr((size_t)(q.L + 1) * 7);
@@ -207,17 +300,6 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
     }
   }
 
-  std::lock_guard<std::mutex> device_lock(g_mac_device);
-  if (!g_mac_ctx) {
-    hhv_params hp;
-    memset(&hp, 0, sizeof(hp));
-    const char* dev = getenv("HHV_DEVICE");
-    hp.device = dev ? atoi(dev) : 0;
-    hp.local = 1;
-    mac_check(hhv_create(&g_mac_ctx, &hp), "hhv_create");
-  }
-  hhv_ctx* ctx = g_mac_ctx;
-  t_create = mac_now() - t_mark;
 
   // ---- round r: the r-th alignment of every template ----
   for (size_t r = 0; r < rounds; ++r) {
@@ -354,12 +436,13 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
     t_hits += mac_now() - t_mark;
   }
   if (timing)
-    fprintf(stderr, "hhposteriordecoderrunner_hip: %zu hits of %d templates in %zu rounds; read+prepare %.3f s, context %.3f s, "
-            "device (staging, masks, forward/backward/MAC, paths) %.3f s, Hit objects %.3f s\n", hits.size(), n_groups, rounds,
+    fprintf(stderr, "hhposteriordecoderrunner_hip: %zu hits of %d templates (%d read) in %zu rounds; read+prepare %.3f s, device prepare %.3f s, "
+            "device (staging, masks, forward/backward/MAC, paths) %.3f s, Hit objects %.3f s\n", hits.size(), n_groups, n_read, rounds,
             t_read, t_create, t_device, t_hits);
   // "clear all backtrace paths" (:108-113): the vectors stay allocated, empty
   for (size_t i = 0; i < hits.size(); i++) {
     hits[i]->alt_i->clear();
     hits[i]->alt_j->clear();
   }
+  if (use_cache) tc.active--;  // (the device lock is still held)
 }

@@ -52,12 +52,19 @@
 
 #include "hhviterbirunner.h"
 #include "hhviterbi_hip.h"
+#include "hhv_template_cache.h"
 
 #ifdef OPENMP
 #include <omp.h>
 #endif
 
 namespace {
+
+using hhv_dropin::SsRecords;
+using hhv_dropin::CachedTemplate;
+using hhv_dropin::TemplateCache;
+using hhv_dropin::cache;
+using hhv_dropin::cache_key;
 
 // HHV_DROPIN_TIMING=1 prints where alignment() spends its wall time (stderr)
 struct PhaseTimer {
@@ -93,11 +100,6 @@ void hip_check(int rc, const char* what) {
   exit(rc == HHV_E_MEMORY ? 3 : 4);
 }
 
-// secondary-structure records of a template, [L+1] each, empty when the template has none
-struct SsRecords {
-  std::vector<int8_t> pred, conf, dssp;
-};
-
 // host copy of one template on its way to the device: prepared (p, tr) or raw (f, tr, neff)
 struct HostTemplate {
   bool raw;
@@ -109,60 +111,6 @@ struct HostTemplate {
   SsRecords ss;
   int ss_pair_mode;  // HMM::computeScoreSSMode(q, t)
 };
-
-// A template of the process-wide cache: raw columns on the device + what a Hit needs to know about the template
-struct CachedTemplate {
-  hhv_rawset* raw;
-  int32_t index;
-  int L;
-  int ss_pair_mode;
-  Hit proto;  // initHitFromHMM(q, t, nseqdis, ssm); its arrays live as long as the cache entry
-  SsRecords ss;
-  CachedTemplate() : raw(NULL), index(0), L(0), ss_pair_mode(0) {}
-};
-
-struct TemplateCache {
-  std::mutex device;  // one caller at a time on the shared context
-  hhv_ctx* ctx;
-  int device_id;
-  unsigned long owner;  // alignment() call whose query is currently installed in ctx
-  unsigned long calls;
-  int active;  // searches currently using cache entries
-  bool enabled;
-  size_t max_columns, columns;
-  std::vector<hhv_rawset*> rawsets;
-  std::unordered_map<std::string, CachedTemplate> map;
-  // what the prototypes depend on besides the template (src/hhhit.cpp:255-256,289-320)
-  int nseqdis, ssm, q_has_pred, q_has_dssp;
-  TemplateCache() : ctx(NULL), device_id(0), owner(0), calls(0), active(0), enabled(true), max_columns(0), columns(0), nseqdis(-1),
-                    ssm(-1), q_has_pred(-1), q_has_dssp(-1) {
-    const char* e = getenv("HHV_TEMPLATE_CACHE");
-    enabled = !(e && atoi(e) == 0);
-    const char* g = getenv("HHV_TEMPLATE_CACHE_GB");
-    const double gb = g ? atof(g) : 64.0;
-    max_columns = (size_t)(gb * 1e9 / 128.0);  // 32 dwords per raw column
-    const char* d = getenv("HHV_DEVICE");
-    device_id = d ? atoi(d) : 0;
-  }
-  void clear() {  // device lock held
-    for (std::unordered_map<std::string, CachedTemplate>::iterator it = map.begin(); it != map.end(); ++it) it->second.proto.Delete();
-    map.clear();
-    for (size_t k = 0; k < rawsets.size(); ++k) hhv_rawset_free(rawsets[k]);
-    rawsets.clear();
-    columns = 0;
-  }
-};
-
-TemplateCache& cache() {
-  static TemplateCache c;
-  return c;
-}
-
-std::string cache_key(HHEntry* e) {
-  char len[32];
-  snprintf(len, sizeof(len), "\n%d", e->sequence_length);
-  return std::string(e->getName()) + len;
-}
 
 // a template of THIS search: where its prepared columns are on the device
 struct ResidentTemplate {
@@ -455,30 +403,10 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
   const int threads = thread_count > 0 ? thread_count : 1;
   search.threads = threads;
 
-  // Can PrepareTemplateHMM run on the device for this search?  (hhv_prepare_subset: HHM format, substitution-matrix
-  // pseudocounts pcm 0..2 with pcc = 1, null model columnscore 0..3; src/hhfunc.cpp:165-202)
-  bool device_prepare = tc.enabled && par.pc_hhm_nocontext_mode >= 0 && par.pc_hhm_nocontext_mode <= 2 &&
-                              !(par.pc_hhm_nocontext_mode == 2 && par.pc_hhm_nocontext_c != 1.0f) && par.columnscore >= 0 &&
-                              par.columnscore <= 3;
-  hhv_prep_params prep;
-  memset(&prep, 0, sizeof(prep));
-  prep.gapd = par.gapd;
-  prep.gape = par.gape;
-  prep.gapf = par.gapf;
-  prep.gapg = par.gapg;
-  prep.gaph = par.gaph;
-  prep.gapi = par.gapi;
-  prep.gapb = par.gapb;
-  prep.pcm = par.pc_hhm_nocontext_mode;
-  prep.pca = par.pc_hhm_nocontext_a;
-  prep.pcb = par.pc_hhm_nocontext_b;
-  prep.pcc = par.pc_hhm_nocontext_c;
-  prep.columnscore = par.columnscore;
+  bool device_prepare = tc.enabled && hhv_dropin::device_prepare_covers(par);
   float pb0[20];  // the background the caller hands in; HMM::Read overwrites pb with the NULL line of every file it reads
   memcpy(pb0, pb, sizeof(pb0));
-  memcpy(prep.pb, pb0, sizeof(pb0));
-  for (int a = 0; a < 20; ++a)
-    for (int b = 0; b < 20; ++b) prep.R[a * 20 + b] = R[a][b];
+  hhv_prep_params prep = hhv_dropin::prepare_params(par, pb0, R);
 
   // scratch HMMs, one per thread (the reference keeps VECSIZE_FLOAT per thread, :84-95), allocated when a template
   // has to be read

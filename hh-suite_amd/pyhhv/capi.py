@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
     "hhv_create", "hhv_destroy", "hhv_set_params", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
-    "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of",
+    "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of", "hhv_tset_download",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
@@ -108,6 +108,7 @@ def load():
     L.hhv_prepare_templates.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(HhvPrepParams), c_float_p, C.POINTER(C.c_void_p)]
     L.hhv_rawset_pav.argtypes = [C.c_void_p, C.c_void_p, c_float_p]
     L.hhv_tset_records_of.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, c_float_p]
+    L.hhv_tset_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_prefilter_upload_db.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     L.hhv_prefilter_free_db.argtypes = [C.c_void_p]
     L.hhv_prefilter_free_db.restype = None

@@ -189,6 +189,9 @@ int hhv_prepare_subset(hhv_ctx* ctx, hhv_rawset* rs, const hhv_prep_params* par,
 int hhv_rawset_pav(hhv_ctx* ctx, hhv_rawset* rs, float* pav);
 /* the prepared packed records of template k of a set ((L[k]+1)*28 floats: header + columns), device -> host */
 int hhv_tset_records_of(hhv_ctx* ctx, hhv_tset* ts, int32_t k, float* out);
+/* the whole record stream of a set in one copy: hhv_tset_records(ts) * 28 floats (template k starts at record
+ * sum_{m<k} (L[m] + 1); the last record is the terminal header) */
+int hhv_tset_download(hhv_ctx* ctx, hhv_tset* ts, float* out);
 
 /* ---- HHblits prefilter kernels ---------------------------------------------------------
  * Prefilter::ungapped_sse_score / Prefilter::swStripedByte (src/hhprefilter.cpp:214-278, 70-212) of one query

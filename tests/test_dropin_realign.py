@@ -88,6 +88,28 @@ def test_dropin_realign_equals_reference(loc, threads, only):
 
 
 @pytest.mark.gpu
+def test_dropin_realign_takes_templates_from_the_resident_cache():
+    """After a Viterbi search by the drop-in ViterbiRunner the templates are resident on the device in raw form; the realign
+    stage prepares them there for its query and fetches them back prepared instead of parsing them again (the texts handed to
+    the second run are empty: reading one would fail).  Mixed case: half of the templates are not in the cache."""
+    from test_dropin_runner import cache_clear, cache_stats, run
+    cache_clear()
+    q, t, names = make_db(79, 150, 40, 40, 260)
+    ref = realign("cpu", q, t, names, altali=3)
+    run("hip", q, t[::2], names[::2], altali=1)                 # every second template becomes resident
+    assert cache_stats()[0] == 20
+    got = realign("hip", q, t, names, altali=3, threads=3)
+    compare(ref, got)
+    run("hip", q, t, names, altali=1)                           # now all of them
+    assert cache_stats()[0] == 40
+    q2, _, _ = make_db(80, 170, 1, 50, 50)                      # another query: the device preparation depends on it
+    ref2 = realign("cpu", q2, t, names, altali=2)
+    got2 = realign("hip", q2, t, names, altali=2)
+    compare(ref2, got2)
+    cache_clear()
+
+
+@pytest.mark.gpu
 def test_dropin_realign_excluded_regions_and_mact():
     q, t, names = make_db(75, 140, 20, 60, 220)
     for mact in (0.3501, 0.1, 0.6):
