@@ -14,8 +14,9 @@
 // (:52-66); the r-th alignment of a template excludes the cells (+-2) of the MAC alignments 1..r-1 of the same template
 // (alignment_to_exclude, :104-106); templates are independent.  The reference runs the groups in an OpenMP loop, one hit
 // after the other inside a group; here ROUND r realigns the r-th hit of every group in one launch.  The template of a
-// group is read and prepared once with the reference's own code (getTemplateHMM + PrepareTemplateHMM with linear
-// transitions, :98-99), in parallel over the groups.
+// group comes from the resident template cache of the Viterbi stage when it is there (prepared on the device for this
+// query and fetched back in one copy - no parsing); otherwise it is read and prepared once with the reference's own code
+// (getTemplateHMM + PrepareTemplateHMM with linear transitions, :98-99), in parallel over the groups.
 //
 // Not produced: the sparse forward / backward / posterior lists of writeProfilesToHits (hit.forward_matrix, ...;
 // src/hhbacktracemac.cpp:14-110), which only HitList::PrintMatrices (the hidden -o_matrices output) reads; they are left
