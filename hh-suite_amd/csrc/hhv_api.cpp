@@ -105,6 +105,15 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
   return HHV_OK;
 }
 
+int hhv_set_fast_log2_tables(hhv_ctx* c, const float* lg2, const float* diff) {
+  if (!c || !lg2 || !diff) return fail(HHV_E_ARG, "hhv_set_fast_log2_tables: null argument");
+  HIP_TRY(hipSetDevice(c->par.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(c->d_lg2, lg2, 1025 * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_diff, diff, 1025 * sizeof(float), hipMemcpyHostToDevice));
+  return HHV_OK;
+}
+
 int hhv_set_params(hhv_ctx* c, const hhv_params* par) {
   if (!c || !par) return fail(HHV_E_ARG, "hhv_set_params: null argument");
   if (par->device != c->par.device)

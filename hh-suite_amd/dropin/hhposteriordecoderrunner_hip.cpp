@@ -14,8 +14,9 @@
 // (:52-66); the r-th alignment of a template excludes the cells (+-2) of the MAC alignments 1..r-1 of the same template
 // (alignment_to_exclude, :104-106); templates are independent.  The reference runs the groups in an OpenMP loop, one hit
 // after the other inside a group; here ROUND r realigns the r-th hit of every group in one launch.  The template of a
-// group comes from the resident template cache of the Viterbi stage when it is there (prepared on the device for this
-// query and fetched back in one copy - no parsing); otherwise it is read and prepared once with the reference's own code
+// group comes from the resident template cache of the Viterbi stage when it is there and was read with the same sequence
+// weighting (par.wg = 1: prepared on the device for this query and fetched back in one copy - no parsing); otherwise it is
+// read and prepared once with the reference's own code
 // (getTemplateHMM + PrepareTemplateHMM with linear transitions, :98-99), in parallel over the groups.
 //
 // Not produced: the sparse forward / backward / posterior lists of writeProfilesToHits (hit.forward_matrix, ...;
@@ -143,7 +144,10 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   const int threads = m_n_threads > 0 ? m_n_threads : 1;
   std::vector<PreparedTemplate> tmpl(n_groups);
   std::vector<const hhv_dropin::CachedTemplate*> cached(n_groups, (const hhv_dropin::CachedTemplate*)NULL);
-  bool use_cache = tc.enabled && hhv_dropin::device_prepare_covers(par);
+  // The cache holds what ViterbiRunner read with use_global_weights = 1 (src/hhviterbirunner.cpp:143); this stage reads with
+  // par.wg (:98), and for templates built from alignments the sequence weighting changes the HMM - so the cache stands in
+  // for the reader only when par.wg asks for the same weighting (-wg).
+  bool use_cache = tc.enabled && par.wg == 1 && hhv_dropin::device_prepare_covers(par);
   {
     std::lock_guard<std::mutex> lock(tc.device);
     use_cache = use_cache && !tc.map.empty() && tc.nseqdis == par.nseqdis && tc.ssm == par.ssm;
@@ -191,13 +195,7 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   t_mark = mac_now();
 
   std::lock_guard<std::mutex> device_lock(tc.device);
-  if (!tc.ctx) {
-    hhv_params hp;
-    memset(&hp, 0, sizeof(hp));
-    hp.device = tc.device_id;
-    hp.local = 1;
-    mac_check(hhv_create(&tc.ctx, &hp), "hhv_create");
-  }
+  mac_check(hhv_dropin::ensure_context(tc), "hhv_create");
   hhv_ctx* ctx = tc.ctx;
   if (n_read < n_groups) {
     // PrepareTemplateHMM on the device (hhv_prepare_subset), one launch per raw set, and the prepared records back in one copy

@@ -40,7 +40,8 @@ namespace {
 struct DeviceSide {
   hhv_ctx* ctx;
   DevicePrefilter* pf;
-  DeviceSide() : ctx(NULL), pf(NULL) {}
+  std::mutex* busy;  // hhblits_omp: several threads share one Prefilter object; its device context serves one at a time
+  DeviceSide() : ctx(NULL), pf(NULL), busy(NULL) {}
 };
 std::mutex g_side_mutex;
 std::map<const Prefilter*, DeviceSide> g_side;
@@ -73,6 +74,7 @@ Prefilter::~Prefilter() {
     if (it != g_side.end()) {
       delete it->second.pf;
       hhv_destroy(it->second.ctx);
+      delete it->second.busy;
       g_side.erase(it);
     }
   }
@@ -132,6 +134,7 @@ void Prefilter::init_prefilter(FFindexDatabase* cs219_database) {
   hp.device = dev ? atoi(dev) : 0;
   hp.local = 1;
   pf_check(hhv_create(&side.ctx, &hp), "hhv_create");
+  side.busy = new std::mutex();
   side.pf = new DevicePrefilter(side.ctx, (int32_t)num_dbs, seqs.data(), offsets.data(), lib.data());
   if (!side.pf->ok()) pf_check(HHV_E_DEVICE, "hhv_prefilter_upload_db");
   {
@@ -180,7 +183,10 @@ void Prefilter::prefilter_db(HMM* q_tmp, Hash<Hit>* previous_hits, const int thr
   for (int i = 0; i < LQ; ++i) memcpy(&qp[(size_t)i * 20], q_tmp->p[i], 20 * sizeof(float));
   std::vector<int32_t> ids;
   int passed_first = 0;
-  pf_check(side.pf->prefilter_db(qp.data(), q_tmp->pav, LQ, pp, &ids, NULL, &passed_first), "prefilter_db");
+  {
+    std::lock_guard<std::mutex> one_at_a_time(*side.busy);
+    pf_check(side.pf->prefilter_db(qp.data(), q_tmp->pav, LQ, pp, &ids, NULL, &passed_first), "prefilter_db");
+  }
   HH_LOG(INFO) << "HMMs passed 1st prefilter (gapless profile-profile alignment)  : " << passed_first << std::endl;
 
   // :555-590: names, each database entry once, split by "searched in a previous round"

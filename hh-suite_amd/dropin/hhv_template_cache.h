@@ -17,6 +17,7 @@
 #include "hhdatabase.h"
 #include "hhdecl.h"
 #include "hhhit.h"
+#include "util.h"
 #include "hhviterbi_hip.h"
 
 namespace hhv_dropin {
@@ -80,6 +81,37 @@ inline std::string cache_key(HHEntry* e) {
   return std::string(e->getName()) + len;
 }
 
+
+// The fast_log2 tables THIS PROCESS has (src/util-inl.h:108-130).  They live in function-local statics initialised by the first
+// caller, with an initialiser that is compiled per translation unit (double log / logf), so the flavour depends on what ran
+// first - an .hhm query or an alignment query, for instance.  lg2[b] is read back through the function itself (x = 1 + b/1024
+// has exponent 0 and no low mantissa bits: fast_log2(x) = 0 + lg2[b] + diff[b] * 0); lg2[1024] is 1 in either flavour; diff is
+// recomputed from lg2 with the initialiser's own expression.
+inline void process_fast_log2_tables(float* lg2, float* diff) {
+  for (int b = 0; b < 1024; ++b) {
+    const uint32_t bits = 0x3F800000u | ((uint32_t)b << 13);
+    float x;
+    memcpy(&x, &bits, sizeof(x));
+    lg2[b] = fast_log2(x);
+  }
+  lg2[1024] = 1.0f;
+  for (int i = 1; i <= 1024; ++i) diff[i - 1] = (lg2[i] - lg2[i - 1]) * 1.2352E-4;
+  diff[1024] = 0.0f;
+}
+
+// the shared device context (device lock held): created on first use, with the process's own fast_log2 tables
+inline int ensure_context(TemplateCache& tc) {
+  if (tc.ctx) return HHV_OK;
+  hhv_params hp;
+  memset(&hp, 0, sizeof(hp));
+  hp.device = tc.device_id;
+  hp.local = 1;
+  int rc = hhv_create(&tc.ctx, &hp);
+  if (rc != HHV_OK) return rc;
+  float lg2[1025], diff[1025];
+  process_fast_log2_tables(lg2, diff);
+  return hhv_set_fast_log2_tables(tc.ctx, lg2, diff);
+}
 
 // Can PrepareTemplateHMM run on the device for this search?  (hhv_prepare_subset: HHM format, substitution-matrix
 // pseudocounts pcm 0..2 with pcc = 1, null model columnscore 0..3; src/hhfunc.cpp:165-202)

@@ -252,13 +252,7 @@ struct Search {
   // Enter a device section (tc.device is held by the caller): the shared context gets this search's parameters and
   // query unless it still has them from the previous section.
   void install() {
-    if (!tc.ctx) {
-      hhv_params hp;
-      memset(&hp, 0, sizeof(hp));
-      hp.device = tc.device_id;
-      hp.local = 1;
-      hip_check(hhv_create(&tc.ctx, &hp), "hhv_create");
-    }
+    hip_check(hhv_dropin::ensure_context(tc), "hhv_create");
     if (id == 0) id = ++tc.calls;
     if (tc.owner == id) return;
     hhv_params hp;

@@ -34,7 +34,7 @@ HIT_DTYPE = np.dtype([("score", np.float32), ("viterbi_score", np.float32), ("sc
 # every symbol include/hhviterbi_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
-    "hhv_create", "hhv_destroy", "hhv_set_params", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
+    "hhv_create", "hhv_destroy", "hhv_set_params", "hhv_set_fast_log2_tables", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of", "hhv_tset_download",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
@@ -98,6 +98,7 @@ def load():
     L.hhv_set_global_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_mac_set_ss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_set_params.argtypes = [C.c_void_p, C.POINTER(HhvParams)]
+    L.hhv_set_fast_log2_tables.argtypes = [C.c_void_p, c_float_p, c_float_p]
     L.hhv_hit_path_pool.argtypes = [C.c_void_p, C.c_void_p] + [C.POINTER(C.c_void_p)] * 5
     L.hhv_adopt_device_stream.argtypes = [C.c_void_p, C.c_int32, c_int_p, C.c_void_p, C.POINTER(C.c_void_p)]
     vpp = C.POINTER(C.c_void_p)

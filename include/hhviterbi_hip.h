@@ -114,6 +114,13 @@ int hhv_pack_profile(const float* p, const float* tr, int32_t L, int32_t index, 
 int hhv_fast_log2_tables(float* lg2, float* diff);
 
 int hhv_create(hhv_ctx** out, const hhv_params* par);
+/* Replace the context's fast_log2 tables (lg2[1025], diff[1025]; default: hhv_fast_log2_tables).  The reference keeps these
+ * tables in function-local statics that the FIRST caller in the process initialises, and the initialiser is compiled per
+ * translation unit (double log in one, logf in another): which of the two flavours a run sees depends on what ran first
+ * (an .hhm query: HMM::AddTransitionPseudocounts; an alignment query: the alignment code).  A caller that lives in the same
+ * process as the reference's code (the drop-in translation units) reads the tables the process actually has and hands them
+ * over, so that per-column scores - and with them Hit.score - match to the last bit in every kind of run. */
+int hhv_set_fast_log2_tables(hhv_ctx* ctx, const float* lg2, const float* diff);
 void hhv_destroy(hhv_ctx* ctx);
 /* New search parameters for an existing context (par->device must be the context's device): what a process-wide
  * context that outlives one ViterbiRunner::alignment call needs (hh-suite_amd/dropin/hhviterbirunner_hip.cpp keeps the

@@ -65,6 +65,7 @@ struct rl_hit {
 };
 
 // opts_i: [0] loc [1] altali [2] ssm [3] maxres [4] threads [5] realign every hit with Viterbi score above smin only (0/1)
+//         [6] wg (par.wg: global sequence weights when templates are built from alignments)
 // opts_f: [0] smin [1] mact [2] ssw
 // Returns the number of realigned hits (in the order of the Viterbi hit vector) or a negative error.
 int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* tmpl_hhm, const size_t* tmpl_len,
@@ -84,6 +85,7 @@ int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* 
   par.ssm = opts_i[2];
   par.maxres = opts_i[3];
   par.threads = opts_i[4];
+  par.wg = opts_i[6];
   par.smin = opts_f[0];
   par.mact = opts_f[1];
   par.ssw = opts_f[2];

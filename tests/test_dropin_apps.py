@@ -66,8 +66,8 @@ def run_app(binary, args, out_prefix):
 def compare_outputs(a, b):
     for ext in a:
         assert len(a[ext]) == len(b[ext]), (ext, len(a[ext]), len(b[ext]))
-        for k, (x, y) in enumerate(zip(a[ext], b[ext])):
-            assert x == y, (ext, k, x, y)
+        diff = [(k, x, y) for k, (x, y) in enumerate(zip(a[ext], b[ext])) if x != y]
+        assert not diff, (ext, len(diff), diff[:4])
     assert len(a["hhr"]) > 20
 
 
@@ -165,3 +165,80 @@ def test_omp_applications_with_replaced_units(tmp_path, app, extra):
         assert sorted(cpu[kind]) == sorted(hip[kind]) and len(cpu[kind]) == 6
         for name in cpu[kind]:
             assert cpu[kind][name] == hip[kind][name], (kind, name)
+
+
+# ---- alignment (a3m) databases: the templates are built from multiple sequence alignments at search time ----------------
+AA = "ARNDCQEGHILKMFPSTWYV"
+
+
+def random_family(rng, L, n_seq, base=None, mut=0.25):
+    """an a3m family: first sequence = (mutated) base, the others mutated copies with a few deletions ('-') and insertions
+    (lower case), i.e. what HHblits databases hold (src/hhalignment.cpp Alignment::Read)"""
+    if base is None:
+        base = "".join(rng.choice(list(AA), L))
+    seqs = []
+    for s in range(n_seq):
+        out = []
+        for ch in base:
+            r = rng.random()
+            if s > 0 and r < 0.03:
+                out.append("-")
+            elif s > 0 and r < mut:
+                out.append(str(rng.choice(list(AA))))
+            else:
+                out.append(ch)
+            if s > 0 and rng.random() < 0.02:
+                out.append(str(rng.choice(list(AA))).lower())
+        seqs.append("".join(out))
+    return base, seqs
+
+
+def a3m_text(name, seqs):
+    return "".join(">%s_%d\n%s\n" % (name, k, s) for k, s in enumerate(seqs)).encode()
+
+
+def build_a3m_db(tmp, seed, n, Lq):
+    rng = np.random.default_rng(seed)
+    qbase, qseqs = random_family(rng, Lq, 6)
+    names, entries, cs = [], [], []
+    for k in range(n):
+        L = int(rng.integers(60, 220))
+        if k % 3 == 0:            # related to a window of the query family
+            start = int(rng.integers(0, max(1, Lq - L)))
+            base = "".join(ch if rng.random() > 0.3 else str(rng.choice(list(AA))) for ch in qbase[start:start + L])
+            _, seqs = random_family(rng, len(base), int(rng.integers(3, 7)), base=base)
+        else:
+            _, seqs = random_family(rng, L, int(rng.integers(3, 7)))
+        name = "fam%04d" % k
+        names.append(name)
+        entries.append((name, a3m_text(name, seqs)))
+        cs.append((name, bytes(rng.integers(0, 219, len(seqs[0])).astype(np.uint8))))
+    base = os.path.join(tmp, "db")
+    write_ffindex(base + "_a3m", entries)
+    write_ffindex(base + "_cs219", cs)
+    qpath = os.path.join(tmp, "query.a3m")
+    open(qpath, "wb").write(a3m_text("query", qseqs))
+    return base, qpath
+
+
+@pytest.mark.skipif(not have("hhblits_cpu"), reason="oracle/_ref/hhblits_cpu not built (needs /root/reference at build time)")
+def test_reference_hhblits_runs_on_an_a3m_database(tmp_path):
+    """CPU only: the reference's hhblits, two iterations, query and templates given as alignments"""
+    base, qpath = build_a3m_db(str(tmp_path), 7, 120, 150)
+    out = run_app("hhblits_cpu", ["-i", qpath, "-d", base, "-nocontxt", "-n", "2", "-cpu", "2"], str(tmp_path / "cpu"))
+    assert len([l for l in out["hhr"] if l.startswith("No ")]) >= 10
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhblits_hip"), reason="oracle/_ref/hhblits_hip not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("n_iter", [1, 2])
+def test_hhblits_on_an_a3m_database_with_replaced_units(tmp_path, n_iter):
+    """The usual HHblits database type: templates are multiple sequence alignments, turned into HMMs at search time
+    (HHEntry::getTemplateHMM -> Alignment::FrequenciesAndTransitions, src/hhdatabase.cpp:300-336).  With two iterations the hits
+    of the first one are merged into the query, the second prefilter splits the survivors into new and previously searched
+    templates and the old ones are rescored (RescoreWithViterbiKeepAlignment): every caller of the replaced units runs."""
+    base, qpath = build_a3m_db(str(tmp_path), 8, 300, 160)
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-n", str(n_iter), "-cpu", "1"]
+    cpu = run_app("hhblits_cpu", args, str(tmp_path / "cpu"))
+    hip = run_app("hhblits_hip", args, str(tmp_path / "hip"))
+    compare_outputs(cpu, hip)

@@ -18,7 +18,7 @@ class RLHit(ctypes.Structure):
 
 
 def realign(which, query, templates, names, loc=1, altali=3, ssm=2, maxres=2000, threads=1, only_above_smin=1, smin=20.0,
-            mact=0.3501, ssw=0.11, excl="", texcl="", path_cap=1400):
+            mact=0.3501, ssw=0.11, excl="", texcl="", path_cap=1400, wg=0):
     lib = _lib()
     fn = getattr(lib, "ref_realign_run_" + which)
     n = len(templates)
@@ -29,8 +29,11 @@ def realign(which, query, templates, names, loc=1, altali=3, ssm=2, maxres=2000,
     texts = (ctypes.c_char_p * n)(*templates)
     lens = (ctypes.c_size_t * n)(*[len(t) for t in templates])
     nm = (ctypes.c_char_p * n)(*[x.encode() for x in names])
-    sl = np.asarray([int(t.split(b"LENG")[1].split()[0]) for t in templates], dtype=np.int32)
-    oi = np.asarray([loc, altali, ssm, maxres, threads, only_above_smin], dtype=np.int32)
+    if globals().get("_seq_len_override") is not None:
+        sl = np.asarray(globals()["_seq_len_override"], dtype=np.int32)
+    else:
+        sl = np.asarray([int(t.split(b"LENG")[1].split()[0]) if t else 1 for t in templates], dtype=np.int32)
+    oi = np.asarray([loc, altali, ssm, maxres, threads, only_above_smin, wg], dtype=np.int32)
     of = np.asarray([smin, mact, ssw], dtype=np.float32)
     P = ctypes.c_void_p
     fn.restype = ctypes.c_int
@@ -95,18 +98,52 @@ def test_dropin_realign_takes_templates_from_the_resident_cache():
     from test_dropin_runner import cache_clear, cache_stats, run
     cache_clear()
     q, t, names = make_db(79, 150, 40, 40, 260)
-    ref = realign("cpu", q, t, names, altali=3)
+    ref = realign("cpu", q, t, names, altali=3, wg=1)
     run("hip", q, t[::2], names[::2], altali=1)                 # every second template becomes resident
     assert cache_stats()[0] == 20
-    got = realign("hip", q, t, names, altali=3, threads=3)
+    got = realign("hip", q, t, names, altali=3, threads=3, wg=1)
     compare(ref, got)
     run("hip", q, t, names, altali=1)                           # now all of them
     assert cache_stats()[0] == 40
     q2, _, _ = make_db(80, 170, 1, 50, 50)                      # another query: the device preparation depends on it
-    ref2 = realign("cpu", q2, t, names, altali=2)
-    got2 = realign("hip", q2, t, names, altali=2)
+    ref2 = realign("cpu", q2, t, names, altali=2, wg=1)
+    got2 = realign("hip", q2, t, names, altali=2, wg=1)
     compare(ref2, got2)
     cache_clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wg", [0, 1])
+def test_dropin_realign_templates_from_alignments(wg):
+    """Templates given as multiple sequence alignments (the usual HHblits database): ViterbiRunner builds their HMMs with global
+    sequence weights (src/hhviterbirunner.cpp:143), the realign stage with par.wg (src/hhposteriordecoderrunner.cpp:98) - two
+    different HMMs unless -wg is given, so the resident cache of the Viterbi stage may stand in only then."""
+    from test_dropin_apps import a3m_text, random_family
+    from test_dropin_runner import cache_clear, run
+    cache_clear()
+    rng = np.random.default_rng(12)
+    q, _, _ = make_db(83, 150, 1, 50, 50)
+    texts, names = [], []
+    for k in range(24):
+        _, seqs = random_family(rng, int(rng.integers(60, 200)), int(rng.integers(3, 7)))
+        names.append("ali%04d" % k)
+        texts.append(a3m_text(names[-1], seqs))
+    lens = [len(x.split(b"\n")[1]) for x in texts]      # first sequence has no gaps: its length = number of match columns
+    ref = realign_a3m("cpu", q, texts, names, lens, wg)
+    run("hip", q, texts, names, seq_len=lens, altali=1, smin=-100.0)        # fills the cache (weights: global)
+    got = realign_a3m("hip", q, texts, names, lens, wg)
+    compare(ref, got)
+    cache_clear()
+
+
+def realign_a3m(which, q, texts, names, lens, wg):
+    """realign() for texts without a LENG line: the sequence lengths are handed over explicitly"""
+    saved = realign.__globals__["_seq_len_override"] if "_seq_len_override" in realign.__globals__ else None
+    realign.__globals__["_seq_len_override"] = lens
+    try:
+        return realign(which, q, texts, names, altali=2, smin=-100.0, only_above_smin=0, wg=wg)
+    finally:
+        realign.__globals__["_seq_len_override"] = saved
 
 
 @pytest.mark.gpu
