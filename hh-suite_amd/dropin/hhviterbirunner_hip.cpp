@@ -664,6 +664,9 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
           for (unsigned int k = b; k < e; ++k) {
             batch_mode[k] = mode;
             shorter[k] = rt[k]->L < Lbatch;
+            if (getenv("HHV_DROPIN_DEBUG") && strstr(ent[k]->getName(), getenv("HHV_DROPIN_DEBUG")))
+              fprintf(stderr, "hhviterbirunner_hip debug: %s round %d position %u of %u: L %d, sequence_length %d, batch L %d\n",
+                      ent[k]->getName(), alignment, c0 + k, m, rt[k]->L, ent[k]->sequence_length, Lbatch);
           }
         }
         std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> > groups;
