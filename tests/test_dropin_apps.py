@@ -279,3 +279,25 @@ def test_command_line_options_reach_the_replaced_units(tmp_path, app):
             compare_outputs(cpu, hip, polluted_ok=app == "hhblits")
         except AssertionError as e:
             raise AssertionError("options %s: %s" % (opts, str(e)[:1500]))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhblits_omp_hip"), reason="oracle/_ref/hhblits_omp_hip not built (needs /root/reference at build time)")
+def test_hhblits_omp_on_an_alignment_database(tmp_path):
+    """six alignment queries, three threads, one process, templates built from alignments: the resident cache is filled by
+    whichever query reads a template first and serves the others"""
+    base, _ = build_a3m_db(str(tmp_path), 31, 200, 150)
+    rng = np.random.default_rng(32)
+    entries = []
+    for k in range(6):
+        _, seqs = random_family(rng, int(rng.integers(100, 180)), 5)
+        entries.append(("qa%02d" % k, a3m_text("qa%02d" % k, seqs).rstrip(b"\n")))
+    qbase = os.path.join(str(tmp_path), "queries")
+    write_ffindex(qbase, entries)
+    args = ["-i", qbase, "-d", base, "-nocontxt", "-n", "1", "-cpu", "3"]
+    cpu = run_omp_app("hhblits_omp_cpu", args, str(tmp_path / "cpu"))
+    hip = run_omp_app("hhblits_omp_hip", args, str(tmp_path / "hip"))
+    for kind in cpu:
+        assert sorted(cpu[kind]) == sorted(hip[kind]) and len(cpu[kind]) == 6
+        for name in cpu[kind]:
+            assert cpu[kind][name] == hip[kind][name], (kind, name)
