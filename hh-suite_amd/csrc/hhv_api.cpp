@@ -133,6 +133,7 @@ void hhv_destroy(hhv_ctx* c) {
   dfree(c->d_ss_table);
   dfree(c->d_ss_q_off);
   dfree(c->mac_cache);
+  if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -61,21 +61,22 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
     return fail(HHV_E_ARG, "hhv_mac_realign: null argument");
   *out = nullptr;
   if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
-  int max_Lt = 0;
+  MacClasses cls = {{0, 0, 0}, {0, 0, 0}};  // the launch is split by template length (hhv_internal.h)
   for (int k = 0; k < n; ++k) {
     if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
-    max_Lt = std::max(max_Lt, Lt[k]);
+    const int cl = mac_length_class(Lt[k]);
+    cls.n[cl]++;
+    cls.max_Lt[cl] = std::max(cls.max_Lt[cl], Lt[k]);
   }
-  if ((size_t)10 * (max_Lt + 2) * sizeof(double) > 160 * 1024)
-    return fail(HHV_E_LIMIT, "hhv_mac_realign: template length %d exceeds the LDS row state (limit 2046)", max_Lt);
+  std::vector<int32_t> sel((size_t)n);
+  {
+    int at[3] = {0, cls.n[0], cls.n[0] + cls.n[1]};
+    for (int k = 0; k < n; ++k) sel[(size_t)at[mac_length_class(Lt[k])]++] = k;
+  }
   const bool with_ss = c->mac_ss_pending;
   c->mac_ss_pending = false;  // one call only
   if (with_ss) {
     if ((int)c->mac_ss_mode.size() != n || c->mac_ss_Lq != Lq) return fail(HHV_E_ARG, "hhv_mac_realign: hhv_mac_set_ss was called for %zu hits, Lq %d", c->mac_ss_mode.size(), c->mac_ss_Lq);
-    bool any = false;
-    for (int k = 0; k < n; ++k) any = any || c->mac_ss_mode[k] != 0;
-    if (any && !mac_templates_are_staged(max_Lt))
-      return fail(HHV_E_LIMIT, "hhv_mac_realign: secondary-structure scoring needs templates that fit the staged kernels (longest: %d)", max_Lt);
   }
   HIP_TRY(hipSetDevice(c->par.device));
   hhv_macset* ms = new (std::nothrow) hhv_macset();
@@ -140,7 +141,9 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
     for (int r = 0; r < mi->n_tranges * 2; ++r) ranges.push_back(mi->tranges[r]);
   }
   ranges.push_back(0);
-  // carve one device allocation (256-byte aligned pieces)
+  // One device allocation, carved into 256-byte aligned pieces.  Everything the host hands over comes first and
+  // contiguously: it is assembled in a pinned staging buffer of the context with the same layout and goes to the device
+  // in ONE copy (two dozen pageable copies of a few bytes to a few megabytes each used to cost as much as the kernels).
   size_t total = 0;
   auto carve = [&](size_t bytes) {
     const size_t at = total;
@@ -150,18 +153,22 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   const size_t o_qp = carve((size_t)(Lq + 1) * 20 * 4), o_qtr = carve((size_t)(Lq + 1) * 7 * 4),
                o_tp = carve(from_tset ? (size_t)n * 8 : (size_t)cols * 20 * 4),
                o_ttr = carve((size_t)cols * 7 * 4), o_col = carve((size_t)n * 8), o_Lt = carve((size_t)n * 4),
-               o_moff = carve((size_t)n * 8), o_co = carve((size_t)cells), o_mat = carve((size_t)cells * 4),
-               o_bmm = carve((size_t)cells), o_scale = carve((size_t)n * (Lq + 2) * 8), o_pf = carve((size_t)n * 8),
-               o_hits = carve((size_t)n * sizeof(DevMacHit)), o_poff = carve((size_t)n * 8), o_pi = carve((size_t)steps * 4),
-               o_pj = carve((size_t)steps * 4), o_ps = carve((size_t)steps), o_pS = carve((size_t)steps * 4),
-               o_pP = carve((size_t)steps * 4);
-  const size_t path_bytes = total - o_pi;
+               o_moff = carve((size_t)n * 8), o_poff = carve((size_t)n * 8);
   const size_t o_ends = carve(ends.size() * 4 + 16), o_voff = carve((size_t)(n + 1) * 8), o_vi = carve(vit_i.size() * 4 + 4),
                o_vj = carve(vit_j.size() * 4 + 4), o_xoff = carve((size_t)(n + 1) * 8), o_xi = carve(excl_i.size() * 4 + 4),
                o_xj = carve(excl_j.size() * 4 + 4), o_rg = carve(ranges.size() * 4), o_rt = carve((size_t)n * 4 + 4);
   const size_t o_sstab = carve(with_ss ? 704 * 4 : 0), o_ssq = carve(with_ss ? c->mac_ss_qidx.size() : 0),
                o_sst = carve(with_ss ? c->mac_ss_tidx.size() : 0), o_ssoff = carve(with_ss ? (size_t)n * 8 : 0),
                o_ssmode = carve(with_ss ? (size_t)n * 4 : 0);
+  const size_t o_sel = carve((size_t)n * 4);
+  const size_t o_co = carve((size_t)cells);  // explicit masks (hhv_mac_realign) are input too; device-built ones are not
+  const size_t input_bytes = mi ? o_co : total;
+  const size_t o_mat = carve((size_t)cells * 4), o_bmm = carve((size_t)cells), o_scale = carve((size_t)n * (Lq + 2) * 8),
+               o_pf = carve((size_t)n * 8), o_hits = carve((size_t)n * sizeof(DevMacHit)), o_pi = carve((size_t)steps * 4),
+               o_pj = carve((size_t)steps * 4), o_ps = carve((size_t)steps), o_pS = carve((size_t)steps * 4),
+               o_pP = carve((size_t)steps * 4);
+  const size_t path_bytes = total - o_pi;
+  const size_t o_rows = carve((size_t)cls.n[2] * 10 * (cls.max_Lt[2] + 2) * 8);  // row state of the templates beyond LDS
   if (c->mac_cache && c->mac_cache_bytes >= total) {
     ms->d_block = c->mac_cache;
     ms->block_bytes = c->mac_cache_bytes;
@@ -173,50 +180,68 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   } else {
     ms->block_bytes = total;
   }
-  char* base = (char*)ms->d_block;
-  // host staging of the ragged inputs
-  std::vector<float> tp(from_tset ? 0 : (size_t)cols * 20), ttr((size_t)cols * 7);
-  std::vector<int64_t> p_off(from_tset ? n : 0);  // header record of the hit's template in the resident stream
-  std::vector<unsigned char> co;
-  if (!mi) co.assign((size_t)cells, 0);
-  for (int k = 0; k < n; ++k) {
-    if (from_tset)
-      p_off[k] = mi->ts->rec_off[mi->template_of[k]];
-    else
-      memcpy(&tp[(size_t)col_off[k] * 20], t_p[k], (size_t)(Lt[k] + 1) * 20 * 4);
-    memcpy(&ttr[(size_t)col_off[k] * 7], t_tr_lin[k], (size_t)(Lt[k] + 1) * 7 * 4);
-    if (!mi && celloff && celloff[k]) {
-      unsigned char* dst = &co[(size_t)ms->mat_off[k]];
-      const uint8_t* src = celloff[k];
-      for (size_t e = 0; e < (size_t)(Lq + 1) * (Lt[k] + 1); ++e) dst[e] = src[e] ? 1 : 0;
+  if (c->mac_pinned_bytes < input_bytes) {
+    if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
+    c->mac_pinned = nullptr;
+    c->mac_pinned_bytes = 0;
+    const size_t want = input_bytes + input_bytes / 4;
+    if (hipHostMalloc(&c->mac_pinned, want, hipHostMallocDefault) != hipSuccess) {
+      hhv_macset_free(ms);
+      return fail(HHV_E_MEMORY, "hhv_mac_realign: cannot allocate %zu bytes of pinned host memory", want);
     }
+    c->mac_pinned_bytes = want;
+  }
+  char* base = (char*)ms->d_block;
+  char* stage = (char*)c->mac_pinned;
+  auto put = [&](size_t at, const void* src, size_t bytes) {
+    if (bytes) memcpy(stage + at, src, bytes);
+  };
+  put(o_qp, q_p, (size_t)(Lq + 1) * 20 * 4);
+  put(o_qtr, q_tr_lin, (size_t)(Lq + 1) * 7 * 4);
+  for (int k = 0; k < n; ++k) {  // the ragged template operands, packed
+    if (from_tset) {
+      const int64_t p_off = mi->ts->rec_off[mi->template_of[k]];  // header record of the hit's template in the resident stream
+      put(o_tp + (size_t)k * 8, &p_off, 8);
+    } else {
+      put(o_tp + (size_t)col_off[k] * 20 * 4, t_p[k], (size_t)(Lt[k] + 1) * 20 * 4);
+    }
+    put(o_ttr + (size_t)col_off[k] * 7 * 4, t_tr_lin[k], (size_t)(Lt[k] + 1) * 7 * 4);
+    if (!mi) {
+      unsigned char* dst = (unsigned char*)stage + o_co + (size_t)ms->mat_off[k];
+      if (celloff && celloff[k]) {
+        const uint8_t* src = celloff[k];
+        for (size_t e = 0; e < (size_t)(Lq + 1) * (Lt[k] + 1); ++e) dst[e] = src[e] ? 1 : 0;
+      } else {
+        memset(dst, 0, (size_t)(ms->mat_off[k + 1] - ms->mat_off[k]));
+      }
+    }
+  }
+  put(o_col, col_off.data(), (size_t)n * 8);
+  put(o_Lt, Lt, (size_t)n * 4);
+  put(o_moff, ms->mat_off.data(), (size_t)n * 8);
+  put(o_poff, ms->path_off.data(), (size_t)n * 8);
+  put(o_sel, sel.data(), (size_t)n * 4);
+  if (mi) {
+    put(o_ends, ends.data(), ends.size() * 4);
+    put(o_voff, vit_off.data(), (size_t)(n + 1) * 8);
+    put(o_vi, vit_i.data(), vit_i.size() * 4);
+    put(o_vj, vit_j.data(), vit_j.size() * 4);
+    put(o_xoff, excl_off.data(), (size_t)(n + 1) * 8);
+    put(o_xi, excl_i.data(), excl_i.size() * 4);
+    put(o_xj, excl_j.data(), excl_j.size() * 4);
+    put(o_rg, ranges.data(), ranges.size() * 4);
+    put(o_rt, res_template.data(), (size_t)n * 4);
+  }
+  if (with_ss) {
+    put(o_sstab, c->mac_ss_tab.data(), 704 * 4);
+    put(o_ssq, c->mac_ss_qidx.data(), c->mac_ss_qidx.size());
+    put(o_sst, c->mac_ss_tidx.data(), c->mac_ss_tidx.size());
+    put(o_ssoff, c->mac_ss_toff.data(), (size_t)n * 8);
+    put(o_ssmode, c->mac_ss_mode.data(), (size_t)n * 4);
   }
   int rc = HHV_OK;
   hipStream_t st = c->stream;
-  if (hipMemcpyAsync(base + o_qp, q_p, (size_t)(Lq + 1) * 20 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(base + o_qtr, q_tr_lin, (size_t)(Lq + 1) * 7 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      (!from_tset && hipMemcpyAsync(base + o_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) ||
-      (from_tset && hipMemcpyAsync(base + o_tp, p_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess) ||
-      hipMemcpyAsync(base + o_ttr, ttr.data(), ttr.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(base + o_col, col_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(base + o_Lt, Lt, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(base + o_moff, ms->mat_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-      (!mi && hipMemcpyAsync(base + o_co, co.data(), co.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
-      (mi && (hipMemcpyAsync(base + o_ends, ends.data(), ends.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_voff, vit_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_vi, vit_i.data(), vit_i.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_vj, vit_j.data(), vit_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_xoff, excl_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_xi, excl_i.data(), excl_i.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_xj, excl_j.data(), excl_j.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_rg, ranges.data(), ranges.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-              hipMemcpyAsync(base + o_rt, res_template.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess)) ||
-      hipMemcpyAsync(base + o_poff, ms->path_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-      (with_ss && (hipMemcpyAsync(base + o_sstab, c->mac_ss_tab.data(), 704 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-                   hipMemcpyAsync(base + o_ssq, c->mac_ss_qidx.data(), c->mac_ss_qidx.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
-                   hipMemcpyAsync(base + o_sst, c->mac_ss_tidx.data(), c->mac_ss_tidx.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
-                   hipMemcpyAsync(base + o_ssoff, c->mac_ss_toff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-                   hipMemcpyAsync(base + o_ssmode, c->mac_ss_mode.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess)))
+  if (hipMemcpyAsync(base, stage, input_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(HHV_E_DEVICE, "hhv_mac_realign: H2D copy failed");
   MacArgs a;
   a.n = n;
@@ -244,6 +269,8 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   a.path_state = (signed char*)(base + o_ps);
   a.path_S = (float*)(base + o_pS);
   a.path_P = (float*)(base + o_pP);
+  a.sel = (const int32_t*)(base + o_sel);
+  a.row_scratch = (double*)(base + o_rows);
   a.lg2 = c->d_lg2;
   a.diff = c->d_diff;
   a.ss_tab = with_ss ? (const float*)(base + o_sstab) : nullptr;
@@ -280,7 +307,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
       m.res_j = any_resident ? mi->ts->d_j_steps : nullptr;
       lr = launch_mac_mask(a, m, st);
     }
-    if (lr == 0) lr = launch_mac(a, local != 0, max_Lt, st);
+    if (lr == 0) lr = launch_mac(a, local != 0, cls, st);
     (void)hipEventRecord(c->ev1, st);
     c->ev_valid = true;
     if (lr != 0) rc = fail(HHV_E_DEVICE, "MAC kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));

@@ -172,6 +172,9 @@ struct MacArgs {
   double Cshift;
   float mact;
   int32_t lds_cols;          // longest template of the launch (sizes the LDS sections)
+  // forward / backward / DP run one launch per LENGTH CLASS of the batch (MacClasses): block b works on hit sel[b]
+  const int32_t* sel;        // [n] hit numbers, grouped by class
+  double* row_scratch;       // row state of the class whose templates do not fit into LDS: [block][10][lds_cols + 2]
   const int64_t* path_off;   // [n] capacity Lq+Lt+2 each
   int32_t* path_i;
   int32_t* path_j;
@@ -206,8 +209,18 @@ struct MacMaskArgs {
   int32_t n_qranges, n_tranges;
 };
 int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream);
-int launch_mac(const MacArgs& a, bool local, int max_Lt, void* stream);
-bool mac_templates_are_staged(int max_Lt);  // the launch keeps the templates in LDS (needed for secondary-structure scoring)
+// Length classes of a batch of hits.  A lone wave per hit keeps its row state (and, if it fits, the template) in LDS, and the
+// LDS footprint of a launch is that of its longest template; one long template must not take the occupancy of the other
+// hits nor set their limits, so the hits are launched class by class:
+//   0  template + row state + prefetch rows in LDS (up to ~800 columns)
+//   1  row state in LDS, template operands from global memory (up to 2046 columns)
+//   2  row state in global memory too (any length)
+struct MacClasses {
+  int n[3];       // hits per class; MacArgs::sel lists class 0 first, then 1, then 2
+  int max_Lt[3];  // longest template per class
+};
+int mac_length_class(int Lt);
+int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream);
 
 // launchers implemented in hhv_kernels.hip
 int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);

@@ -172,11 +172,13 @@ enum { F_MM = 0, F_GD = 1, F_IM = 2, F_DG = 3, F_MI = 4 };
 }  // namespace
 
 // ---- forward ------------------------------------------------------------------------------------------------------
-template <bool LOCAL, bool STAGE>
+// GROWS: the row state lives in global memory (a.row_scratch) instead of LDS - templates of any length.  The accesses are
+// the same; rows written before a __syncthreads() are read after it, by the same (only) wavefront of the workgroup.
+template <bool LOCAL, bool STAGE, bool GROWS>
 __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* rows = reinterpret_cast<double*>(smem);
-  const int k = blockIdx.x, lane = threadIdx.x;
+  double* rows = GROWS ? a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2) : reinterpret_cast<double*>(smem);
+  const int k = a.sel[blockIdx.x], lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));  // layout sized for the longest template
@@ -361,11 +363,11 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
 }
 
 // ---- backward + posterior ---------------------------------------------------------------------------------------------
-template <bool LOCAL, bool STAGE>
+template <bool LOCAL, bool STAGE, bool GROWS>
 __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* rows = reinterpret_cast<double*>(smem);
-  const int k = blockIdx.x, lane = threadIdx.x;
+  double* rows = GROWS ? a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2) : reinterpret_cast<double*>(smem);
+  const int k = a.sel[blockIdx.x], lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));
@@ -530,11 +532,12 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
 }
 
 // ---- maximum-accuracy DP ----------------------------------------------------------------------------------------------
-template <bool LOCAL>
+template <bool LOCAL, bool GROWS>
 __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* S = reinterpret_cast<float*>(smem);  // [2][Lt+2]
-  const int k = blockIdx.x, lane = threadIdx.x;
+  float* S = GROWS ? reinterpret_cast<float*>(a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2))
+                   : reinterpret_cast<float*>(smem);  // [2][Lt+2]
+  const int k = a.sel[blockIdx.x], lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   const float mact = a.mact;
@@ -825,32 +828,47 @@ size_t mac_rows_lds(int max_Lt, bool stage) {
          (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) + (((size_t)2 * (max_Lt + 2) + 15) & ~(size_t)15) +
                       (size_t)2 * (max_Lt + 2) * sizeof(float) + 352 * sizeof(float) : 0);
 }
+constexpr size_t MAC_LDS_LIMIT = 160 * 1024;
 
-template <bool LOCAL, bool STAGE>
-static void launch_mac_variant(const MacArgs& a, size_t lds_rows, size_t lds_dp, hipStream_t stream) {
-  (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
-  (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
-  hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, STAGE>), dim3(a.n), dim3(64), lds_rows, stream, a);
-  hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE>), dim3(a.n), dim3(64), lds_rows, stream, a);
-  hipLaunchKernelGGL(hhv_mac_dp_kernel<LOCAL>, dim3(a.n), dim3(64), lds_dp, stream, a);
+template <bool LOCAL, bool STAGE, bool GROWS>
+static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<LOCAL, STAGE, GROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>), dim3(n), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE, GROWS>), dim3(n), dim3(64), lds, stream, a);
+}
+template <bool LOCAL>
+static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream) {
+  if (cls == 0) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
+  else if (cls == 1) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream);
+  else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
+  const size_t lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
+  if (lds_dp <= MAC_LDS_LIMIT) {
+    (void)hipFuncSetAttribute((const void*)hhv_mac_dp_kernel<LOCAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp);
+    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, false>), dim3(n), dim3(64), lds_dp, stream, a);
+  } else {
+    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, true>), dim3(n), dim3(64), 0, stream, a);  // (class 2 only: row_scratch is there)
+  }
 }
 
-bool mac_templates_are_staged(int max_Lt) { return mac_rows_lds(max_Lt, true) <= 160 * 1024 && max_Lt <= MAC_PRE * 64; }
+int mac_length_class(int Lt) {
+  if (mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64) return 0;
+  return mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT ? 1 : 2;
+}
 
-int launch_mac(const MacArgs& a0, bool local, int max_Lt, void* stream_) {
+int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const bool stage = mac_templates_are_staged(max_Lt);
-  MacArgs a = a0;
-  a.lds_cols = max_Lt;
-  const size_t lds_rows = mac_rows_lds(max_Lt, stage), lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
-  if (local) {
-    if (stage) launch_mac_variant<true, true>(a, lds_rows, lds_dp, stream);
-    else launch_mac_variant<true, false>(a, lds_rows, lds_dp, stream);
-  } else {
-    if (stage) launch_mac_variant<false, true>(a, lds_rows, lds_dp, stream);
-    else launch_mac_variant<false, false>(a, lds_rows, lds_dp, stream);
+  int first = 0;
+  for (int c = 0; c < 3; ++c) {
+    if (cls.n[c] == 0) continue;
+    MacArgs a = a0;
+    a.sel = a0.sel + first;
+    a.lds_cols = cls.max_Lt[c];
+    if (local) launch_mac_class<true>(a, c, cls.n[c], cls.max_Lt[c], stream);
+    else launch_mac_class<false>(a, c, cls.n[c], cls.max_Lt[c], stream);
+    first += cls.n[c];
   }
-  hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3(a.n), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3(a0.n), dim3(64), 0, stream, a0);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

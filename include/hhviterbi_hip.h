@@ -273,7 +273,7 @@ int hhv_mac_realign_tset(hhv_ctx* ctx, const float* q_p, const float* q_tr_lin, 
  *   t_idx[k] [Lt[k]+2] column index of the template for the hit's mode (ss_dssp; ss_pred*11 + ss_conf); entry Lt+1 is the
  *           element PAST the template, which the reference reads for the cells of column 1 (the stale loop variable of
  *           src/hhforwardalgorithm.cpp:77).  NULL for mode 0.
- * The setting is consumed by one call.  Hits with a mode need templates that fit the LDS-staged kernels (<= ~800 columns). */
+ * The setting is consumed by one call.  Templates of any length. */
 int hhv_mac_set_ss(hhv_ctx* ctx, const float* tables, const uint8_t* q_idx, int32_t Lq, int32_t n, const int32_t* mode,
                    const uint8_t* const* t_idx, const int32_t* Lt);
 /* the mask of hit k as the kernels saw it, (Lq+1)*(Lt+1) bytes */

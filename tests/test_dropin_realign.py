@@ -186,3 +186,32 @@ def test_dropin_realign_secondary_structure_in_mac(which_ss):
     assert compare(ref, got) >= 10
     plain = realign("cpu", q, t, names, ssm=0)          # the factor matters: without it the posteriors differ
     assert any(not np.array_equal(a, b) for a, b in zip(ref[1][5], plain[1][5]))
+
+
+@pytest.mark.gpu
+def test_dropin_realign_templates_of_any_length():
+    """templates from 300 to 2600 columns in one search: the three length classes of the MAC launch (LDS-staged, LDS row state,
+    row state in global memory) side by side, alternative alignments included"""
+    q, t, names = make_db(91, 90, 12, 300, 2600)
+    lens = sorted(int(x.split(b"LENG")[1].split()[0]) for x in t)
+    assert lens[0] <= 800 and lens[-1] > 2046 and any(800 < L <= 2046 for L in lens)
+    kw = dict(maxres=2700, path_cap=2800)
+    ref = realign("cpu", q, t, names, **kw)
+    got = realign("hip", q, t, names, threads=2, **kw)
+    assert compare(ref, got) >= 4
+    hit_lens = {int(t[h.entry].split(b"LENG")[1].split()[0]) for h in ref[0]}
+    assert min(hit_lens) <= 800 and max(hit_lens) > 2046 and any(800 < L <= 2046 for L in hit_lens)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [1000, 2100])
+def test_dropin_realign_secondary_structure_in_mac_long_templates(L):
+    """the HHpred situation (hit.ssm2 = 1) with templates beyond the LDS-staged kernels: 1000 columns (row state in LDS) and
+    2100 (row state in global memory).  One length per search, see test_dropin_realign_secondary_structure_in_mac."""
+    q, t, names = make_db(93 + L, 70, 6, L, L, ss_every=1, query_ss=("pred", "conf"))
+    kw = dict(maxres=L + 100, path_cap=L + 200, ssm=2)
+    ref = realign("cpu", q, t, names, **kw)
+    got = realign("hip", q, t, names, **kw)
+    assert compare(ref, got) >= 2
+    plain = realign("cpu", q, t, names, **dict(kw, ssm=0))
+    assert any(not np.array_equal(a, b) for a, b in zip(ref[1][5], plain[1][5]))

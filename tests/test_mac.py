@@ -247,16 +247,18 @@ def test_gpu_mac_from_resident_template_set(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_mac_long_template_unstaged_path(oracle):
-    """A template too long for the LDS copy (> ~850 columns) sends the whole launch down the kernels that read the template
-    from global memory; results must not depend on the path."""
+@pytest.mark.parametrize("lengths", [[900, 70, 1500], [2100, 64, 810, 2047, 2046, 3000, 300]])
+def test_gpu_mac_length_classes(oracle, lengths):
+    """The hits of a call are launched by length class: template and row state in LDS (up to ~800 columns), row state in LDS
+    and the template read from global memory (up to 2046), row state in global memory too (any length).  Results must not
+    depend on the class, and one long template must not change what the others get."""
     from pyhhv import capi
-    Lq = 90
+    Lq = 90 if max(lengths) < 2000 else 48
     qp, qtr = synth.make_query(88, Lq)
     q_lin = lin_query(qtr)
     par = make_params(local=1, ss_mode=0)
     tps, tls, masks, want = [], [], [], []
-    for k, Lt in enumerate([900, 70, 1500]):
+    for k, Lt in enumerate(lengths):
         tp, ttr = synth.make_homolog(800 + k, qp, L=Lt)
         t_lin = lin_template(ttr)
         vit = oracle.align(par, qp, qtr, tp, ttr, want_path=True)
