@@ -27,6 +27,8 @@ struct hhv_pfdb {
   size_t jobs_cap = 0, sub_cap = 0, order_cap = 0;
   unsigned char* d_striped = nullptr;
   size_t striped_cap = 0;
+  unsigned char* d_state = nullptr;  // H/E columns of the generic kernel for queries beyond LDS
+  size_t state_cap = 0;
   // first selection step on the device: sort keys, sorted keys, radix-sort scratch, counter
   uint64_t* d_keys = nullptr;
   uint64_t* d_sorted = nullptr;
@@ -99,6 +101,7 @@ void hhv_prefilter_free_db(hhv_pfdb* db) {
   dfree(db->d_subset);
   dfree(db->d_order);
   dfree(db->d_striped);
+  dfree(db->d_state);
   dfree(db->d_keys);
   dfree(db->d_sorted);
   dfree(db->d_sort_temp);
@@ -136,8 +139,9 @@ static int prefilter_scores_impl(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profil
       }
   const size_t state_lds = (size_t)8 * 3 * W32 * 32, prof_lds = (size_t)220 * W32 * 32;
   const bool generic_prof_lds = prof_lds + state_lds <= 160 * 1024;
-  const size_t lds = fast ? prefilter_fast_lds(gapped != 0, Wfast) : state_lds + (generic_prof_lds ? prof_lds : 0);
-  if (lds > 160 * 1024) return fail(HHV_E_LIMIT, "hhv_prefilter_scores: Lq = %d needs %zu bytes of LDS (limit 160 KiB)", Lq, lds);
+  // the generic kernel keeps the H/E columns of its eight sequence slots in LDS up to Lq = 6816, beyond that in global memory
+  const bool state_global = !fast && state_lds > 160 * 1024;
+  const size_t lds = fast ? prefilter_fast_lds(gapped != 0, Wfast) : state_global ? 0 : state_lds + (generic_prof_lds ? prof_lds : 0);
 
   HIP_TRY(hipSetDevice(c->par.device));
   // scratch buffers live in the database handle: a search calls this twice per query
@@ -171,7 +175,8 @@ static int prefilter_scores_impl(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profil
   if (!grow(db->d_prof, db->prof_cap, (size_t)220 * Lq) || !grow(db->d_scores, db->jobs_cap, (size_t)n_jobs * sizeof(int32_t)) ||
       (subset && (!grow(db->d_subset, db->sub_cap, (size_t)n_jobs * sizeof(int32_t)) ||
                   !grow(db->d_order, db->order_cap, (size_t)n_jobs * sizeof(int32_t)))) ||
-      (!striped.empty() && !grow(db->d_striped, db->striped_cap, striped.size())))
+      (!striped.empty() && !grow(db->d_striped, db->striped_cap, striped.size())) ||
+      (state_global && !grow(db->d_state, db->state_cap, (size_t)c->num_cus * 8 * state_lds)))
     rc = fail(HHV_E_MEMORY, "hhv_prefilter_scores: device allocation failed");
   if (rc == HHV_OK &&
       (hipMemcpyAsync(d_prof, profile, (size_t)220 * Lq, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -198,6 +203,7 @@ static int prefilter_scores_impl(hhv_ctx* c, hhv_pfdb* db, const uint8_t* profil
     a.q_base = 0;
     a.carry_in = nullptr;
     a.carry_out = nullptr;
+    a.state_scratch = state_global ? db->d_state : nullptr;  // sized for num_cus * 8 blocks
     const int blocks_per_cu = std::max<int>(1, std::min<int>(fast ? 2 : 8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
     const int jobs_per_block = fast ? 16 : 8;
     const int n_blocks = (int)std::max<int64_t>(

@@ -126,6 +126,7 @@ struct PrefilterArgs {
   int32_t q_base;
   const unsigned char* carry_in;
   unsigned char* carry_out;
+  unsigned char* state_scratch;  // generic kernel: H/E columns of queries beyond LDS, [block][8][3][W][32]; null = LDS
 };
 // fast kernels: W = cells per lane (ungapped: ceil(slab/64) <= 8, Smith-Waterman: ceil(Lq/32) <= 20), profile as int8 in LDS
 size_t prefilter_fast_lds(bool gapped, int W);

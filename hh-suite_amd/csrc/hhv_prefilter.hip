@@ -266,14 +266,17 @@ __global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
 }
 
 // ---- generic kernel: H/E columns in LDS, profile striped like the reference in LDS or global --------------------
-template <bool GAPPED, bool PROF_LDS>
+// STATE_GLOBAL: queries whose H/E columns (3 * 32 * W bytes per sequence slot) exceed LDS keep them in a.state_scratch; a
+// thread only ever reads the bytes it wrote itself (stripe element k), so nothing but the address changes.
+template <bool GAPPED, bool PROF_LDS, bool STATE_GLOBAL>
 __global__ void __launch_bounds__(256) hhv_pf_generic_kernel(PrefilterArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = a.W;
   const int k = threadIdx.x & 31;     // stripe element
   const int half = threadIdx.x >> 5;  // 0..7: sequence slot inside the block
   unsigned char* sprof = smem;        // [220][W][32] when PROF_LDS
-  unsigned char* state = smem + (PROF_LDS ? (size_t)220 * W * 32 : 0) + (size_t)half * 3 * W * 32;
+  unsigned char* state = STATE_GLOBAL ? a.state_scratch + ((size_t)blockIdx.x * 8 + half) * 3 * W * 32
+                                      : smem + (PROF_LDS ? (size_t)220 * W * 32 : 0) + (size_t)half * 3 * W * 32;
   if (PROF_LDS) {
     // stripe the plain [220][Lq] profile exactly like Prefilter::stripe_query_profile (:386-425)
     for (int e = threadIdx.x; e < 220 * W * 32; e += 256) {
@@ -399,11 +402,14 @@ int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_bloc
 }
 
 int launch_prefilter_generic(const PrefilterArgs& a, bool gapped, bool prof_lds, int n_blocks, size_t lds, void* stream) {
+  if (a.state_scratch)
+    return gapped ? launch_one(hhv_pf_generic_kernel<true, false, true>, a, n_blocks, 256, 0, stream)
+                  : launch_one(hhv_pf_generic_kernel<false, false, true>, a, n_blocks, 256, 0, stream);
   if (gapped)
-    return prof_lds ? launch_one(hhv_pf_generic_kernel<true, true>, a, n_blocks, 256, lds, stream)
-                    : launch_one(hhv_pf_generic_kernel<true, false>, a, n_blocks, 256, lds, stream);
-  return prof_lds ? launch_one(hhv_pf_generic_kernel<false, true>, a, n_blocks, 256, lds, stream)
-                  : launch_one(hhv_pf_generic_kernel<false, false>, a, n_blocks, 256, lds, stream);
+    return prof_lds ? launch_one(hhv_pf_generic_kernel<true, true, false>, a, n_blocks, 256, lds, stream)
+                    : launch_one(hhv_pf_generic_kernel<true, false, false>, a, n_blocks, 256, lds, stream);
+  return prof_lds ? launch_one(hhv_pf_generic_kernel<false, true, false>, a, n_blocks, 256, lds, stream)
+                  : launch_one(hhv_pf_generic_kernel<false, false, false>, a, n_blocks, 256, lds, stream);
 }
 
 }  // namespace hhv

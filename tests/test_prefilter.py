@@ -87,11 +87,14 @@ def test_gpu_prefilter_scores_match_oracle(oracle, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("Lq", [513, 640, 700, 1100, 2049])
-def test_gpu_prefilter_long_queries(oracle, Lq):
+@pytest.mark.parametrize("Lq", [513, 640, 700, 1100, 2049, 6816, 6817, 9001])
+def test_gpu_prefilter_long_queries(oracle, Lq, monkeypatch):
     """Queries beyond one slab: the gapless kernel runs in slabs of <= 512 rows with carried diagonals, Smith-Waterman
-    falls back to the generic kernel (striped profile in LDS up to Lq = 640, read through L2 beyond)."""
+    falls back to the generic kernel (striped profile in LDS up to Lq = 640, read through L2 beyond; its H/E columns in LDS
+    up to Lq = 6816, in global memory beyond - no query length is refused)."""
     from pyhhv import capi
+    if Lq > 6000:
+        monkeypatch.setenv("HHV_PREFILTER_GENERIC", "1")    # the gapless scores through the generic kernel as well
     rng = np.random.default_rng(Lq)
     prof = np.clip(rng.normal(30, 12, (220, Lq)), 0, 255).astype(np.uint8)
     cons = rng.integers(0, 220, Lq)
