@@ -119,6 +119,8 @@ def mac_family(orc, rng, budget):
         tps, tls, masks, want = [], [], [], []
         for k in range(int(rng.integers(1, 6))):
             Lt = int(rng.choice([1, 2, 63, 64, 65, 128, 190]))
+            if rng.random() < 0.15:     # the other two length classes of the launch (LDS row state only; rows in global memory)
+                Lt = int(rng.choice([790, 805, 1000, 2046, 2047, 2300]))
             tp, ttr = (synth.make_homolog(int(rng.integers(1 << 30)), qp, L=Lt) if rng.random() < 0.6 and Lq > 4 else
                        synth.make_template(int(rng.integers(1 << 30)), Lt))
             t_lin = T.lin_template(ttr)
