@@ -133,6 +133,11 @@ void hhv_destroy(hhv_ctx* c) {
   dfree(c->d_ss_table);
   dfree(c->d_ss_q_off);
   dfree(c->mac_cache);
+  for (int k = 0; k < MAC_CLASSES; ++k) {
+    if (c->mac_side.s[k]) (void)hipStreamDestroy((hipStream_t)c->mac_side.s[k]);
+    if (c->mac_side.join[k]) (void)hipEventDestroy((hipEvent_t)c->mac_side.join[k]);
+  }
+  if (c->mac_side.fork) (void)hipEventDestroy((hipEvent_t)c->mac_side.fork);
   if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);

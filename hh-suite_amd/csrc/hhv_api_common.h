@@ -65,6 +65,8 @@ struct hhv_ctx {
   std::vector<uint8_t> mac_ss_qidx, mac_ss_tidx;
   std::vector<int64_t> mac_ss_toff;
   std::vector<int32_t> mac_ss_mode;
+  hhv::MacStreams mac_side = {};                          // side streams of the MAC length classes (created at the first use)
+  bool mac_side_ready = false;
   void* mac_pinned = nullptr;                          // pinned staging buffer of the MAC inputs
   size_t mac_pinned_bytes = 0;
   void* mac_cache = nullptr;                           // one recycled device block of the MAC realignment

@@ -61,7 +61,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
     return fail(HHV_E_ARG, "hhv_mac_realign: null argument");
   *out = nullptr;
   if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
-  MacClasses cls = {{0, 0, 0}, {0, 0, 0}};  // the launch is split by template length (hhv_internal.h)
+  MacClasses cls = {};  // the launch is split by template length (hhv_internal.h)
   for (int k = 0; k < n; ++k) {
     if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
     const int cl = mac_length_class(Lt[k]);
@@ -70,7 +70,8 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   }
   std::vector<int32_t> sel((size_t)n);
   {
-    int at[3] = {0, cls.n[0], cls.n[0] + cls.n[1]};
+    int at[MAC_CLASSES] = {};
+    for (int cl = 1; cl < MAC_CLASSES; ++cl) at[cl] = at[cl - 1] + cls.n[cl - 1];
     for (int k = 0; k < n; ++k) sel[(size_t)at[mac_length_class(Lt[k])]++] = k;
   }
   const bool with_ss = c->mac_ss_pending;
@@ -168,7 +169,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
                o_pj = carve((size_t)steps * 4), o_ps = carve((size_t)steps), o_pS = carve((size_t)steps * 4),
                o_pP = carve((size_t)steps * 4);
   const size_t path_bytes = total - o_pi;
-  const size_t o_rows = carve((size_t)cls.n[2] * 10 * (cls.max_Lt[2] + 2) * 8);  // row state of the templates beyond LDS
+  const size_t o_rows = carve((size_t)cls.n[MAC_CLASSES - 1] * 10 * (cls.max_Lt[MAC_CLASSES - 1] + 2) * 8);  // row state of the templates beyond LDS
   if (c->mac_cache && c->mac_cache_bytes >= total) {
     ms->d_block = c->mac_cache;
     ms->block_bytes = c->mac_cache_bytes;
@@ -307,7 +308,16 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
       m.res_j = any_resident ? mi->ts->d_j_steps : nullptr;
       lr = launch_mac_mask(a, m, st);
     }
-    if (lr == 0) lr = launch_mac(a, local != 0, cls, st);
+    if (!c->mac_side_ready) {  // side streams of the length classes; without them the classes simply run one after the other
+      c->mac_side_ready = true;
+      bool ok = hipEventCreateWithFlags((hipEvent_t*)&c->mac_side.fork, hipEventDisableTiming) == hipSuccess;
+      for (int k = 1; k < MAC_CLASSES && ok; ++k)
+        ok = hipStreamCreateWithFlags((hipStream_t*)&c->mac_side.s[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags((hipEvent_t*)&c->mac_side.join[k], hipEventDisableTiming) == hipSuccess;
+      if (!ok)
+        for (int k = 0; k < MAC_CLASSES; ++k) c->mac_side.s[k] = nullptr;
+    }
+    if (lr == 0) lr = launch_mac(a, local != 0, cls, st, c->mac_side.fork ? &c->mac_side : nullptr);
     (void)hipEventRecord(c->ev1, st);
     c->ev_valid = true;
     if (lr != 0) rc = fail(HHV_E_DEVICE, "MAC kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));

@@ -212,16 +212,23 @@ struct MacMaskArgs {
 int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream);
 // Length classes of a batch of hits.  A lone wave per hit keeps its row state (and, if it fits, the template) in LDS, and the
 // LDS footprint of a launch is that of its longest template; one long template must not take the occupancy of the other
-// hits nor set their limits, so the hits are launched class by class:
-//   0  template + row state + prefetch rows in LDS (up to ~800 columns)
-//   1  row state in LDS, template operands from global memory (up to 2046 columns)
-//   2  row state in global memory too (any length)
+// hits nor set their limits, so the hits are launched class by class, every class on a stream of its own (they overlap):
+//   0..3  template + row state + prefetch rows in LDS: up to 128 / 256 / 384 / ~800 columns (5 / 3 / 2 / 1 workgroups per CU)
+//   4, 5  row state in LDS, template operands from global memory: up to 1022 / 2046 columns
+//   6     row state in global memory too (any length)
+constexpr int MAC_CLASSES = 7;
 struct MacClasses {
-  int n[3];       // hits per class; MacArgs::sel lists class 0 first, then 1, then 2
-  int max_Lt[3];  // longest template per class
+  int n[MAC_CLASSES];       // hits per class; MacArgs::sel lists class 0 first, then 1, ...
+  int max_Lt[MAC_CLASSES];  // longest template per class
+};
+// side streams of the class launches: s[c] for class c (null = the caller's stream), fork / join events
+struct MacStreams {
+  void* s[MAC_CLASSES];
+  void* fork;
+  void* join[MAC_CLASSES];
 };
 int mac_length_class(int Lt);
-int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream);
+int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream, const MacStreams* side);
 
 // launchers implemented in hhv_kernels.hip
 int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);

@@ -839,35 +839,54 @@ static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t str
 }
 template <bool LOCAL>
 static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream) {
-  if (cls == 0) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
-  else if (cls == 1) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream);
+  if (cls <= 3) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
+  else if (cls <= 5) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream);
   else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
   const size_t lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
   if (lds_dp <= MAC_LDS_LIMIT) {
     (void)hipFuncSetAttribute((const void*)hhv_mac_dp_kernel<LOCAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp);
     hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, false>), dim3(n), dim3(64), lds_dp, stream, a);
   } else {
-    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, true>), dim3(n), dim3(64), 0, stream, a);  // (class 2 only: row_scratch is there)
+    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, true>), dim3(n), dim3(64), 0, stream, a);  // (class 6 only: row_scratch is there)
   }
 }
 
 int mac_length_class(int Lt) {
-  if (mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64) return 0;
-  return mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT ? 1 : 2;
+  if (mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64) return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : 3;
+  if (mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT) return Lt <= 1022 ? 4 : 5;
+  return 6;
 }
 
-int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* stream_) {
+// One launch sequence (forward, backward, DP) per non-empty class.  The first non-empty class runs on the caller's stream,
+// the others on side streams that wait for what the caller's stream has queued so far (inputs, masks) and are joined
+// before the backtrace of all hits.
+int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* stream_, const MacStreams* side) {
   hipStream_t stream = (hipStream_t)stream_;
-  int first = 0;
-  for (int c = 0; c < 3; ++c) {
+  int first = 0, non_empty = 0;
+  for (int c = 0; c < MAC_CLASSES; ++c) non_empty += cls.n[c] > 0;
+  const bool fork = side && non_empty > 1;
+  if (fork) (void)hipEventRecord((hipEvent_t)side->fork, stream);  // everything queued so far: inputs, masks
+  bool main_used = false;
+  bool joined[MAC_CLASSES] = {};
+  for (int c = 0; c < MAC_CLASSES; ++c) {
     if (cls.n[c] == 0) continue;
+    hipStream_t st = stream;
+    if (main_used && fork && side->s[c]) {
+      st = (hipStream_t)side->s[c];
+      (void)hipStreamWaitEvent(st, (hipEvent_t)side->fork, 0);
+      joined[c] = true;
+    }
+    main_used = true;
     MacArgs a = a0;
     a.sel = a0.sel + first;
     a.lds_cols = cls.max_Lt[c];
-    if (local) launch_mac_class<true>(a, c, cls.n[c], cls.max_Lt[c], stream);
-    else launch_mac_class<false>(a, c, cls.n[c], cls.max_Lt[c], stream);
+    if (local) launch_mac_class<true>(a, c, cls.n[c], cls.max_Lt[c], st);
+    else launch_mac_class<false>(a, c, cls.n[c], cls.max_Lt[c], st);
+    if (joined[c]) (void)hipEventRecord((hipEvent_t)side->join[c], st);
     first += cls.n[c];
   }
+  for (int c = 0; c < MAC_CLASSES; ++c)
+    if (joined[c]) (void)hipStreamWaitEvent(stream, (hipEvent_t)side->join[c], 0);
   hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3(a0.n), dim3(64), 0, stream, a0);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

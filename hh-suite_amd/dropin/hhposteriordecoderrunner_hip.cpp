@@ -26,8 +26,8 @@
 // reference, Viterbi::ScoreSS has no case 3) runs on the device from tables of fpow2(ScoreSS) (hhv_mac_set_ss).  One cell
 // column is not reproducible: for column 1 the reference calls ScoreSS with a stale loop variable and reads the template's
 // SS state one element past its last column (src/hhforwardalgorithm.cpp:77) - zero in a fresh HMM, which is what is used
-// here.  Templates of any length: the hits of a round are launched by length class (template and row state in LDS up to
-// about 800 columns, row state in LDS up to 2046, row state in global memory beyond).  Not supported (the run stops with a
+// here.  Templates of any length: the hits of a round are launched by length class on overlapping streams (template and row
+// state in LDS up to about 800 columns, row state in LDS up to 2046, row state in global memory beyond).  Not supported (the run stops with a
 // message instead of computing something else): self alignments (hit.self; nothing in v3.3.0 sets it, src/hhhit.cpp:13).
 #include <sys/time.h>
 

@@ -1,6 +1,7 @@
 """MAC realignment throughput: n hits of one query realigned on the GPU (hhv::PosteriorDecoderRunner)
 next to the reference's PosteriorDecoder::realign timed on one host core (oracle/_ref) on a sample of the same hits.
-usage: python tools/bench_mac.py [n_hits] [Lq] [Lt] [ref_sample]   -> one JSON line"""
+usage: python tools/bench_mac.py [n_hits] [Lq] [Lt] [ref_sample]   -> one JSON line
+Lt = 0: template lengths of a real search, log-normal around 250 columns, 40 .. 1800 (all length classes of the launch)"""
 import json
 import os
 import sys
@@ -17,8 +18,11 @@ from pyhhv import capi, synth  # noqa: E402
 def run(n=500, Lq=300, Lt=300, sample=16):
     qp, qtr = synth.make_query(11, Lq)
     tps, ttrs = [], []
+    lens = [Lt] * n
+    if Lt <= 0:
+        lens = np.clip(np.random.default_rng(3).lognormal(np.log(250.0), 0.7, n), 40, 1800).astype(int).tolist()
     for k in range(n):
-        tp, ttr = synth.make_homolog(100 + k, qp, L=Lt, mut=0.2 + 0.6 * (k % 7) / 7.0)
+        tp, ttr = synth.make_homolog(100 + k, qp, L=lens[k], mut=0.2 + 0.6 * (k % 7) / 7.0)
         tps.append(tp)
         ttrs.append(ttr)
     c = capi.Context(local=1, shift=-0.03, corr=0.1)
@@ -41,8 +45,8 @@ def run(n=500, Lq=300, Lt=300, sample=16):
     import ctypes
     t3 = (ctypes.c_double * 3)()
     capi.load_runner().hhvr_mac_last_timing(t3)
-    cells = float(n) * Lq * Lt
-    out = {"n_hits": n, "Lq": Lq, "Lt": Lt, "gpu_kernels_ms": round(kms, 3), "gpu_wall_ms_incl_host_masks": round(wall * 1e3, 2),
+    cells = float(Lq) * float(sum(lens))
+    out = {"n_hits": n, "Lq": Lq, "Lt": Lt if Lt > 0 else "lognormal(250, 0.7) in 40..1800, max %d" % max(lens), "gpu_kernels_ms": round(kms, 3), "gpu_wall_ms_incl_host_masks": round(wall * 1e3, 2),
            "host_ms_masks_realign_fetch": [round(v, 2) for v in t3],
            "gpu_hits_per_s": n / (kms * 1e-3), "gpu_cells_per_s": cells / (kms * 1e-3),
            "mean_nsteps": float(sc[:, 0].mean()), "mean_sum_of_probs": float(re[:, 1].mean())}
