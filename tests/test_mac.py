@@ -247,7 +247,7 @@ def test_gpu_mac_from_resident_template_set(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lengths", [[900, 70, 1500], [2100, 64, 810, 2047, 2046, 3000, 300]])
+@pytest.mark.parametrize("lengths", [[900, 70, 1500], [2100, 64, 810, 2047, 2046, 3000, 300, 500, 790, 200]])
 def test_gpu_mac_length_classes(oracle, lengths):
     """The hits of a call are launched by length class: template and row state in LDS (up to ~800 columns), row state in LDS
     and the template read from global memory (up to 2046), row state in global memory too (any length).  Results must not
