@@ -14,9 +14,9 @@
 // (:52-66); the r-th alignment of a template excludes the cells (+-2) of the MAC alignments 1..r-1 of the same template
 // (alignment_to_exclude, :104-106); templates are independent.  The reference runs the groups in an OpenMP loop, one hit
 // after the other inside a group; here ROUND r realigns the r-th hit of every group in one launch.  The template of a
-// group comes from the resident template cache of the Viterbi stage when it is there and was read with the same sequence
-// weighting (par.wg = 1: prepared on the device for this query and fetched back in one copy - no parsing); otherwise it is
-// read and prepared once with the reference's own code
+// group comes from the resident template cache of the Viterbi stage when it is there and its reading did not depend on the
+// sequence weighting (an .hhm text, or par.wg = 1: prepared on the device for this query and fetched back in one copy - no
+// parsing); otherwise it is read and prepared once with the reference's own code
 // (getTemplateHMM + PrepareTemplateHMM with linear transitions, :98-99), in parallel over the groups.
 //
 // Not produced: the sparse forward / backward / posterior lists of writeProfilesToHits (hit.forward_matrix, ...;
@@ -147,8 +147,8 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   std::vector<const hhv_dropin::CachedTemplate*> cached(n_groups, (const hhv_dropin::CachedTemplate*)NULL);
   // The cache holds what ViterbiRunner read with use_global_weights = 1 (src/hhviterbirunner.cpp:143); this stage reads with
   // par.wg (:98), and for templates built from alignments the sequence weighting changes the HMM - so the cache stands in
-  // for the reader only when par.wg asks for the same weighting (-wg).
-  bool use_cache = tc.enabled && par.wg == 1 && hhv_dropin::device_prepare_covers(par);
+  // for the reader when par.wg asks for the same weighting (-wg), or for entries that are .hhm texts (weights_free).
+  bool use_cache = tc.enabled && hhv_dropin::device_prepare_covers(par);
   {
     std::lock_guard<std::mutex> lock(tc.device);
     use_cache = use_cache && !tc.map.empty() && tc.nseqdis == par.nseqdis && tc.ssm == par.ssm;
@@ -157,7 +157,7 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
       for (int g = 0; g < n_groups; ++g) {
         std::unordered_map<std::string, hhv_dropin::CachedTemplate>::const_iterator it =
             tc.map.find(hhv_dropin::cache_key(alignment[g][0]->entry));
-        if (it != tc.map.end()) cached[g] = &it->second;
+        if (it != tc.map.end() && (par.wg == 1 || it->second.weights_free)) cached[g] = &it->second;
       }
     }
   }

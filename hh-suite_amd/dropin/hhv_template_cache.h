@@ -33,9 +33,12 @@ struct CachedTemplate {
   int32_t index;
   int L;
   int ss_pair_mode;
+  // The entry is an .hhm TEXT of a database (not an alignment): reading it does not depend on the sequence-weighting
+  // argument of getTemplateHMM, so the realign stage (which reads with par.wg, the Viterbi stage with 1) may use it too.
+  bool weights_free;
   Hit proto;  // initHitFromHMM(q, t, nseqdis, ssm); its arrays live as long as the cache entry
   SsRecords ss;
-  CachedTemplate() : raw(NULL), index(0), L(0), ss_pair_mode(0) {}
+  CachedTemplate() : raw(NULL), index(0), L(0), ss_pair_mode(0), weights_free(false) {}
 };
 
 struct TemplateCache {

@@ -103,6 +103,7 @@ void hip_check(int rc, const char* what) {
 // host copy of one template on its way to the device: prepared (p, tr) or raw (f, tr, neff)
 struct HostTemplate {
   bool raw;
+  bool hh_text;  // an .hhm text of a database's hhm ffindex (see CachedTemplate::weights_free)
   int L;
   std::vector<float> p;     // prepared: [(L+1)*20]; raw: f [(L+2)*20]
   std::vector<float> tr;    // [(L+1)*7], enum order of src/hhdecl.h:68
@@ -111,6 +112,31 @@ struct HostTemplate {
   SsRecords ss;
   int ss_pair_mode;  // HMM::computeScoreSSMode(q, t)
 };
+
+// Is the entry of this name an HHM text in every database that has it?  HHblitsDatabase::getEntriesFromNames takes a name
+// from hhm_database when it is there (src/hhdatabase.cpp:198-206) and HHEntry::getTemplateHMM recognises the format by
+// the first non-blank line (:414-432, "HH..."); alignments (a3m / ca3m entries, or an alignment stored in the hhm index) are
+// read through Alignment::FrequenciesAndTransitions, which depends on the weighting argument.
+bool entry_is_hh_text(const std::vector<HHblitsDatabase*>& dbs, char* name) {
+  bool found = false;
+  for (size_t d = 0; d < dbs.size(); ++d) {
+    HHblitsDatabase* db = dbs[d];
+    if (!db) continue;
+    ffindex_entry_t* e = db->hhm_database ? ffindex_get_entry_by_name(db->hhm_database->db_index, name) : NULL;
+    if (e) {
+      const char* text = ffindex_get_data_by_entry(db->hhm_database->db_data, e);
+      size_t at = 0;
+      while (text && at < e->length && (text[at] == ' ' || text[at] == '\t' || text[at] == '\n' || text[at] == '\r')) ++at;
+      if (!text || at + 2 > e->length || text[at] != 'H' || text[at + 1] != 'H') return false;
+      found = true;
+      continue;
+    }
+    if ((db->a3m_database && ffindex_get_entry_by_name(db->a3m_database->db_index, name)) ||
+        (db->use_compressed && db->ca3m_database && ffindex_get_entry_by_name(db->ca3m_database->db_index, name)))
+      return false;
+  }
+  return found;
+}
 
 // a template of THIS search: where its prepared columns are on the device
 struct ResidentTemplate {
@@ -488,6 +514,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
             t->entry = ent[k];
             h.raw = device_prepare && format_tmp == 0 && memcmp(pb, pb0, sizeof(pb0)) == 0 && t->L >= 1 && t->L <= 0xFFFF;
             h.L = t->L;
+            h.hh_text = h.raw && entry_is_hh_text(databases, ent[k]->getName());
             h.ss_pair_mode = HMM::computeScoreSSMode(q, t);
             hit0[k].initHitFromHMM(q, t, par.nseqdis, par.ssm);  // :40
             std::vector<HMM*> one(1, t);
@@ -576,6 +603,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 CachedTemplate& ct = *slot[x];
                 if (ct.index != x) continue;  // a duplicate key inside this chunk: the last one filled the slot
                 ct.L = h.L;
+                ct.weights_free = h.hh_text;
                 ct.ss_pair_mode = h.ss_pair_mode;
                 copy_template_info(hit0[raw_k[x]], &ct.proto);
                 ct.proto.entry = NULL;

@@ -115,6 +115,21 @@ def test_hhsearch_with_replaced_units_writes_the_same_files(tmp_path, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
+def test_realign_stage_takes_hhm_texts_from_the_resident_cache(tmp_path):
+    """default options (no -wg): the realign stage reads with par.wg = 0, the Viterbi stage with 1 - which makes no difference
+    for .hhm texts, so nothing is parsed a second time (the files written are compared by the tests above)"""
+    q, t, names = make_db(431, 431, 64, 200, 200)
+    base, qpath = build_db(str(tmp_path), q, t, names, 2)
+    cmd = [os.path.join(BIN, "hhsearch_hip"), "-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "2", "-o",
+           str(tmp_path / "x.hhr"), "-v", "1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=dict(os.environ, HHV_DROPIN_TIMING="1"))
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("hhposteriordecoderrunner_hip:")]
+    assert lines and all("(0 read)" in l for l in lines), lines
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not have("hhblits_hip"), reason="oracle/_ref/hhblits_hip not built (needs /root/reference at build time)")
 def test_hhblits_with_replaced_units_writes_the_same_files(tmp_path):
     """one hhblits iteration: prefilter (replaced) -> Viterbi (replaced) -> MAC realignment (replaced) -> result files"""
