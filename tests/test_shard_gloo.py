@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: world_size-2 gloo.  Each rank "aligns" its shard with the oracle (standing
+"""Multi-rank path on CPU: world_size-2 and -3 gloo.  Each rank "aligns" its shard with the oracle (standing
 in for its GPU), builds the K-record buffer exactly like hhv_topk lays it out, and the exchange +
 merge of pyhhv.shard must give every rank the global top-K a single process computes."""
 import os
@@ -65,13 +65,14 @@ def worker(rank, world, port, n, K, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_topk_merge(tmp_path):
-    n, K, world = 40, 7, 2
+@pytest.mark.parametrize("world,K", [(2, 7), (3, 20)])    # (3, 20): a shard holds fewer templates than K - padded records
+def test_multi_rank_topk_merge(tmp_path, world, K):
+    n = 40
     port = free_port()
     mp.spawn(worker, args=(world, port, n, K, str(tmp_path)), nprocs=world, join=True)
     m0 = np.load(tmp_path / "merged_0.npy")
-    m1 = np.load(tmp_path / "merged_1.npy")
-    assert np.array_equal(m0, m1), "ranks disagree on the merged hit list"
+    for r in range(1, world):
+        assert np.array_equal(m0, np.load(tmp_path / ("merged_%d.npy" % r))), "ranks disagree on the merged hit list"
     o = Oracle()
     par = make_params(local=1)
     qf, qtr, tps, ttrs = make_db(n)
