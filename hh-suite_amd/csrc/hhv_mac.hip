@@ -13,8 +13,10 @@
 //     left neighbour (wave_shr:1, lane 0 takes the carry of the previous strip); after step s lanes 0..s are final, and
 //     recomputing a final value from final inputs reproduces it, so no masking is needed.  Rounding is therefore the
 //     reference's, operation for operation - the kernels are bit-exact against it, not just within tolerance.
-// Row state (5 doubles per column, two rows) lives in LDS; F_MM / posteriors (float) and the MAC backtrace codes are
-// matrices in HBM, one per hit.
+// Row state (5 doubles per column, two rows) lives in LDS - in global memory for templates beyond 2046 columns (GROWS);
+// F_MM / posteriors (float) and the MAC backtrace codes are matrices in HBM, one per hit.  The hits of a call are launched
+// by template-length class (launch_mac below), every class with the LDS footprint of its own longest template and on a
+// stream of its own.
 #include <hip/hip_runtime.h>
 
 #include <float.h>
