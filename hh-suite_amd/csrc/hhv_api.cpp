@@ -71,6 +71,41 @@ int hhv_fast_log2_tables(float* lg2, float* diff) {
   return HHV_OK;
 }
 
+int hhv_device_count(int32_t* n) {
+  if (!n) return fail(HHV_E_ARG, "hhv_device_count: null");
+  int ndev = 0;
+  const hipError_t e = hipGetDeviceCount(&ndev);
+  *n = e == hipSuccess ? ndev : 0;
+  if (e != hipSuccess || ndev <= 0)
+    return fail(HHV_E_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  return HHV_OK;
+}
+
+int hhv_shard_plan(int32_t n, const int32_t* L, int32_t n_shards, int32_t* shard_of) {
+  if (n < 0 || n_shards < 1 || (n && (!L || !shard_of))) return fail(HHV_E_ARG, "hhv_shard_plan: bad argument");
+  if (n == 0) return HHV_OK;
+  std::vector<int32_t> order((size_t)n);
+  for (int k = 0; k < n; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return L[a] > L[b]; });
+  if (L[order[0]] == L[order[n - 1]]) {  // equal lengths: contiguous blocks (order == identity)
+    for (int r = 0; r < n_shards; ++r)
+      for (int64_t k = (int64_t)n * r / n_shards; k < (int64_t)n * (r + 1) / n_shards; ++k) shard_of[order[k]] = r;
+    return HHV_OK;
+  }
+  const int bsz = std::max(1, std::min(64, n / (4 * n_shards)));  // 64-template bins, smaller for tiny databases
+  std::vector<int64_t> load((size_t)n_shards, 0);
+  for (int a = 0; a < n; a += bsz) {
+    int r = 0;
+    for (int t = 1; t < n_shards; ++t)
+      if (load[t] < load[r]) r = t;
+    for (int k = a; k < std::min(n, a + bsz); ++k) {
+      shard_of[order[k]] = r;
+      load[r] += (int64_t)L[order[k]] + 1;
+    }
+  }
+  return HHV_OK;
+}
+
 int hhv_create(hhv_ctx** out, const hhv_params* par) {
   if (!out || !par) return fail(HHV_E_ARG, "hhv_create: null argument");
   *out = nullptr;

@@ -45,18 +45,131 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ src, int c
   }
 }
 
+// ---- LDS operand source of a column step -----------------------------------------------------------------------------
+// The ring is filled by LDS-DMA (global_load_lds).  hipcc cannot tell which ds_read may alias a DMA in flight, so in
+// front of EVERY ds_read it can see it waits vmcnt(0) - which in the backtrace variants is the previous step's
+// global_store of the compare bits (stores count on vmcnt): a full store round trip per step.  The loop therefore reads
+// LDS only through inline asm, which hipcc does not count, and places the waits itself:
+//   head()          ds_read_b128 of record dwords 20..27 (7 transitions + meta) [+ QL: the phase-A query transitions]
+//                   and lgkmcnt(0) in ONE statement: everything it returns has landed.
+//   begin_column()  issues the five reads of the profile values; they land under phase A.  Outputs of an asm load count
+//                   as written at the end of the statement, so the values are only touched through before_B(), whose
+//                   wait statement names every destination "+v" (no consumer can be scheduled above it).
+//   before_B()      lgkmcnt(0) for the profile, then [QL] issues the phase-C query transitions, waited in before_C().
+// Every read that is issued is waited for on the same control path, so no destination register is ever dead with a read
+// still in flight.  The DMA itself is ordered by the explicit vmcnt(0) at each chunk boundary (below).
+// tools/audit_asm.py checks in the generated .s that nothing touches a destination between its load and its wait.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int R, bool QL_>
+struct LdsColumn {
+  static constexpr bool QL = QL_;
+  static constexpr int NA = (R + 1) / 2;      // float4 reads covering the A block {m2i, i2i} x R (floats 0 .. 2R-1)
+  static constexpr int C0 = (2 * R) / 4;      // first float4 of the C block {m2d, d2d} x R (floats 2R .. 4R-1)
+  static constexpr int NC = R - C0;
+  v4f v0, v1, v2, v3, v4, v5, v6;
+  v4f qa0, qa1, qa2, qc0, qc1, qc2;
+  uint32_t rec_addr, ql_addr;  // LDS byte addresses: this lane's record in the ring / its 20 floats of query transitions
+
+  __device__ __forceinline__ void head() {
+    if (!QL) {
+      asm volatile("ds_read_b128 %0, %2 offset:96\n\tds_read_b128 %1, %2 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v6), "=&v"(v5) : "v"(rec_addr) : "memory");
+    } else if (NA == 1) {
+      asm volatile("ds_read_b128 %0, %3 offset:96\n\tds_read_b128 %1, %3 offset:80\n\tds_read_b128 %2, %4\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(v6), "=&v"(v5), "=&v"(qa0) : "v"(rec_addr), "v"(ql_addr) : "memory");
+    } else if (NA == 2) {
+      asm volatile("ds_read_b128 %0, %4 offset:96\n\tds_read_b128 %1, %4 offset:80\n\tds_read_b128 %2, %5\n\t"
+                   "ds_read_b128 %3, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v6), "=&v"(v5), "=&v"(qa0), "=&v"(qa1) : "v"(rec_addr), "v"(ql_addr) : "memory");
+    } else {
+      asm volatile("ds_read_b128 %0, %5 offset:96\n\tds_read_b128 %1, %5 offset:80\n\tds_read_b128 %2, %6\n\t"
+                   "ds_read_b128 %3, %6 offset:16\n\tds_read_b128 %4, %6 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v6), "=&v"(v5), "=&v"(qa0), "=&v"(qa1), "=&v"(qa2) : "v"(rec_addr), "v"(ql_addr) : "memory");
+    }
+  }
+  __device__ __forceinline__ int32_t meta() const {
+    const float w = v6.w;  // (bit_cast applied to the element expression itself reads element 0 with this clang)
+    return __builtin_bit_cast(int32_t, w);
+  }
+  // header record: dword 0 = template index (read and waited for in one statement)
+  __device__ __forceinline__ int32_t header_tid() const {
+    int32_t t;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t) : "v"(rec_addr));
+    return t;
+  }
+  __device__ __forceinline__ void begin_column() {
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+                 "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4) : "v"(rec_addr));
+  }
+  __device__ __forceinline__ float tr(int k) const {
+    switch (k) {
+      case 0: return v5.x;
+      case 1: return v5.y;
+      case 2: return v5.z;
+      case 3: return v5.w;
+      case 4: return v6.x;
+      case 5: return v6.y;
+      default: return v6.z;
+    }
+  }
+  __device__ __forceinline__ void before_B() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4));
+    if (QL) {
+      // float4 C0 .. R-1 of the lane's 20 floats (for odd R the first one straddles the A block and is read again)
+      if (NC == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(qc0) : "v"(ql_addr), "i"(16 * C0));
+      if (NC == 2)
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=&v"(qc0), "=&v"(qc1) : "v"(ql_addr), "i"(16 * C0), "i"(16 * C0 + 16));
+      if (NC == 3)
+        asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6"
+                     : "=&v"(qc0), "=&v"(qc1), "=&v"(qc2) : "v"(ql_addr), "i"(16 * C0), "i"(16 * C0 + 16), "i"(16 * C0 + 32));
+    }
+  }
+  __device__ __forceinline__ void get_p(float* tp) const {
+    tp[0] = v0.x, tp[1] = v0.y, tp[2] = v0.z, tp[3] = v0.w;
+    tp[4] = v1.x, tp[5] = v1.y, tp[6] = v1.z, tp[7] = v1.w;
+    tp[8] = v2.x, tp[9] = v2.y, tp[10] = v2.z, tp[11] = v2.w;
+    tp[12] = v3.x, tp[13] = v3.y, tp[14] = v3.z, tp[15] = v3.w;
+    tp[16] = v4.x, tp[17] = v4.y, tp[18] = v4.z, tp[19] = v4.w;
+  }
+  __device__ __forceinline__ void before_C() {
+    if (QL) {
+      if (NC == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qc0));
+      if (NC == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qc0), "+v"(qc1));
+      if (NC == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qc0), "+v"(qc1), "+v"(qc2));
+    }
+  }
+  static __device__ __forceinline__ float pick(const v4f& a, const v4f& b, const v4f& c, int f) {
+    const v4f& v = f < 4 ? a : (f < 8 ? b : c);
+    switch (f & 3) {
+      case 0: return v.x;
+      case 1: return v.y;
+      case 2: return v.z;
+      default: return v.w;
+    }
+  }
+  // lane layout in LDS: floats [0, 2R) = {m2i, i2i} of rows 0..R-1, floats [2R, 4R) = {m2d, d2d}
+  __device__ __forceinline__ float qa(int r, int w) const { return pick(qa0, qa1, qa2, 2 * r + w); }
+  __device__ __forceinline__ float qc(int r, int w) const { return pick(qc0, qc1, qc2, 2 * R + 2 * r + w - 4 * C0); }
+};
+
 // Occupancy: VALU issue needs >= 2 waves per SIMD to reach its rate on gfx950 (a lone wave issues one
 // VOP2 every ~6.3 clk, two waves one every ~2.5 clk: tools/valu_ubench).  Up to R = 5 rows per lane the
-// kernel is held to <= 256 VGPRs (2 waves/SIMD; the backtrace variants spill a few dwords to scratch).
+// kernel is held to <= 256 VGPRs (2 waves/SIMD, no scratch in any variant).
 // MULTI = the query needs more than one pass of 64*R rows (the carry hand-over code is compiled out otherwise).
 // SS = secondary-structure term added to the emission score (the reference's ...AndSS builds).
 template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS>
 __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
-  __shared__ float4 ring[RING_RECS * 7];
-  // backtrace variants: {m2d, d2d, m2i, i2i} of the lane's R query rows live in LDS (20 floats per lane: stride 20
-  // dwords is conflict-free for ds_read_b128) - the VGPRs they would occupy hold the compare results instead
+  // backtrace variants: {m2i, i2i} and {m2d, d2d} of the lane's R query rows live in LDS (20 floats per lane; the
+  // 20-dword stride is conflict-free for ds_read_b128) - the VGPRs they would occupy hold the compare results instead.
+  // ONE __shared__ object: [QL block][ring].
   constexpr bool QL = BT;
-  __shared__ float4 qlds[QL ? LANES * 5 : 1];
+  constexpr int QL_F4 = QL ? LANES * 5 : 0;
+  __shared__ float4 smem[QL_F4 + RING_RECS * 7];
+  float4* const ring = smem + QL_F4;
   const int lane = threadIdx.x;
   const int64_t rb = a.wave_rec[blockIdx.x];
   const int64_t re = a.wave_rec[blockIdx.x + 1];
@@ -83,14 +196,18 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 
   QRows<R> q;
   q.load(a.qpack + (size_t)lane * R * REC_DW);
+  LdsColumn<R, QL> col;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const uint32_t ring_addr = smem_addr + QL_F4 * 16;
+  col.ql_addr = smem_addr + lane * 80;
   if (QL) {
-    float* w = reinterpret_cast<float*>(qlds) + lane * 20;
+    float* w = reinterpret_cast<float*>(smem) + lane * 20;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      w[4 * r + 0] = q.m2d[r];
-      w[4 * r + 1] = q.d2d[r];
-      w[4 * r + 2] = q.m2i[r];
-      w[4 * r + 3] = q.i2i[r];
+      w[2 * r + 0] = q.m2i[r];
+      w[2 * r + 1] = q.i2i[r];
+      w[2 * R + 2 * r + 0] = q.m2d[r];
+      w[2 * R + 2 * r + 1] = q.d2d[r];
     }
   }
   LaneState<R> st;
@@ -101,13 +218,15 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     for (int r = 0; r < R; ++r) ss_qoff[r] = a.ss_q_off[i0 - 1 + r];
   }
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // chunks 0 and 1 have landed, the lane's own ds_writes above are done (LDS executes a wave's operations in order)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   for (int s = 0; s < M + LANES - 1; ++s) {
     if ((s & (CHUNK_RECS - 1)) == 0 && s > 0) {
       // chunk c = s/32 was issued 32 steps ago: make sure it has landed, then refill the slot that
       // held chunk c-3 (its last reader, lane 63, finished at step 32(c-2)+62 < 32c) with chunk c+1.
       // The live window [s-63, s] spans chunks c-2..c, so the ring holds 4 chunks = 128 records.
+      // (The same wait retires the backtrace stores of the last 32 steps - the only place they are waited for.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int c = s / CHUNK_RECS;
       if (c + 1 < nchunks) load_chunk(src, c + 1, ring, lane);
@@ -115,19 +234,9 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     const int r = s - lane;
     const bool active = (r >= 0) && (r < M);
 
-    float rec[REC_DW];
-    {
-      const float4* p = ring + ((s - lane) & (RING_RECS - 1)) * 7;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const float4 v = p[k];
-        rec[4 * k + 0] = v.x;
-        rec[4 * k + 1] = v.y;
-        rec[4 * k + 2] = v.z;
-        rec[4 * k + 3] = v.w;
-      }
-    }
-    const int32_t meta = __builtin_bit_cast(int32_t, rec[REC_META]);
+    col.rec_addr = ring_addr + (uint32_t)((s - lane) & (RING_RECS - 1)) * (REC_DW * 4);
+    col.head();
+    const int32_t meta = col.meta();
 
     // hand-off from lane g-1 (full EXEC here); lane 0 takes the DP boundary row 0, or - in later passes of
     // a long query - the bottom row the previous pass left for this record (and its running best)
@@ -159,7 +268,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     if (active) {
       if (meta < 0) {
         TemplateResult res;
-        const int new_tid = __builtin_bit_cast(int32_t, rec[0]) | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
+        const int new_tid = col.header_tid() | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
         if (lane_header<R, LOCAL, true>(st, q, in, i0, new_tid, P, lane == g_last, res)) {
           DevResult o;
           o.score = res.score;
@@ -181,10 +290,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #pragma unroll
           for (int r = 0; r < R; ++r) ssv[r] = a.ss_table[ss_qoff[r] + tidx];
         }
-        const float* ql = reinterpret_cast<const float*>(qlds) + lane * 20;
-        if (QL) asm volatile("" : "+v"(ql));  // keep the LDS reads inside the loop (they are loop invariant)
-        const uint64_t bytes =
-            lane_column<R, LOCAL, BT, CELLOFF, true, SS, QL>(st, q, in, rec, j, i0, r_last, P, cell, ssv, ql);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS>(st, q, in, col, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
       if (carry_out) {

@@ -296,8 +296,29 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
   return emit;
 }
 
+// Operand source of a column step: where the template record and (QL sources) the lane's "second tier" query
+// transitions come from.  ArraySrc reads plain arrays (host emulation, tests); the kernel's LdsColumn
+// (hhv_kernels.hip) reads the LDS ring with inline-asm ds_read_b128 and puts the waits where the values are used.
+//   tr(k)        k = 0..6: the record's M2M, M2D, D2M, D2D, I2M, I2I, M2I      (needed first, phase A)
+//   get_p(tp)    the 20 profile values, valid from phase B on (a source may still be waiting for them before)
+//   qa(r, w)     QL only: w = 0 m2i, 1 i2i of row r (phase A);   qc(r, w): w = 0 m2d, 1 d2d (phase C)
+//   begin_column / before_B / before_C   issue and wait points of an asynchronous source
+struct ArraySrc {
+  static constexpr bool QL = false;
+  const float* rec;
+  HHV_MEM void begin_column() {}
+  HHV_MEM float tr(int k) const { return rec[REC_M2M + k]; }
+  HHV_MEM void before_B() {}
+  HHV_MEM void get_p(float* tp) const {
+    for (int a = 0; a < 20; ++a) tp[a] = rec[a];
+  }
+  HHV_MEM void before_C() {}
+  HHV_MEM float qa(int, int) const { return 0.0f; }
+  HHV_MEM float qc(int, int) const { return 0.0f; }
+};
+
 // One template column j for the R rows of this lane.
-//   rec      : the 28-dword column record
+//   src      : the 28-dword column record (and, for QL sources, four of the lane's query transitions per row)
 //   cellbits : CELLOFF only - byte r bit 7 set = cell (i0+r, j) excluded (same byte matrix the
 //              backtrace is written to, src/hhviterbialgorithm.cpp:373-392)
 //   returns  : BT only - the 9 compare bits of each of the R cells (layout and decoding: bt_push / bt_decode above)
@@ -308,15 +329,14 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
 // kernel); C (rows top-down) MM += S, then DG and MI which chain through the row above.
 //   ssv      : SS only - ssv[r] = ssw * S[q_ss(i0+r)][t_ss(j)], the secondary-structure term of the ...AndSS
 //              builds (src/hhviterbialgorithm.cpp:194-213,278-280), added as ss + log2f4(..) like the reference
-//   ql       : QL only - this lane's four "second tier" query transitions per row, {m2d, d2d, m2i, i2i} x R, kept in
-//              LDS instead of VGPRs (the backtrace variants need the registers for the compare results)
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, bool QL = false>
-HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const float* rec, int j, int i0,
-                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv,
-                             const float* ql = nullptr) {
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, class Src>
+HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, Src& src, int j, int i0,
+                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv) {
+  constexpr bool QL = Src::QL;
   const float smin = LOCAL ? 0.0f : NEG_MAX;
-  const float tM2M = rec[REC_M2M], tM2D = rec[REC_M2D], tD2M = rec[REC_D2M], tD2D = rec[REC_D2D],
-              tI2M = rec[REC_I2M], tI2I = rec[REC_I2I], tM2I = rec[REC_M2I];
+  src.begin_column();
+  const float tM2M = src.tr(0), tM2D = src.tr(1), tD2M = src.tr(2), tD2D = src.tr(3), tI2M = src.tr(4), tI2I = src.tr(5),
+              tM2I = src.tr(6);
   float cmax[R];
   uint32_t acc_lo = 0, acc_hi = 0;  // BT: compare bits of rows R-1..1 / of row 0 and phase C (layout: bt_decode)
   // ---- phase A, rows R-1 .. 0: reads (i-1, j-1) = old state of the row above and (i, j-1) = own old state
@@ -350,7 +370,7 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     // :307-332 (GD and IM read only the cell to the left)
     const float lMM = st.MM[r];
     const float ga = lMM + tM2D, gb = st.GD[r] + tD2D;
-    const float qm2i = QL ? ql[4 * r + 2] : q.m2i[r], qi2i = QL ? ql[4 * r + 3] : q.i2i[r];
+    const float qm2i = QL ? src.qa(r, 0) : q.m2i[r], qi2i = QL ? src.qa(r, 1) : q.i2i[r];
     const float ia = (lMM + qm2i) + tM2M, ib = (st.IM[r] + qi2i) + tM2M;
     if (BT) {
       bt_push(acc, ga, gb);
@@ -360,20 +380,24 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     st.IM[r] = fmax2(ia, ib);
   }
   // ---- phase B: :277-283
+  src.before_B();
+  float tp[20];
+  src.get_p(tp);
   float S[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float v = log2f4(dot20(q.p[r], rec));
+    float v = log2f4(dot20(q.p[r], tp));
     if (SS) v = ssv[r] + v;
     S[r] = v + P.shift;
   }
   // ---- phase C, rows 0 .. R-1: (i-1, j) = new state of the row above
+  src.before_C();
   float uMM = in.MM, uDG = in.DG, uMI = in.MI;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float mm = cmax[r] + S[r];
     // :340-366
-    const float qm2d = QL ? ql[4 * r + 0] : q.m2d[r], qd2d = QL ? ql[4 * r + 1] : q.d2d[r];
+    const float qm2d = QL ? src.qc(r, 0) : q.m2d[r], qd2d = QL ? src.qc(r, 1) : q.d2d[r];
     const float da = uMM + qm2d, db = uDG + qd2d;
     float dg = fmax2(da, db);
     const float sa = uMM + q.m2m[r], sb = uMI + q.m2m[r];

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_hits",
-    "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk",
+    "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan",
 ]
 
 
@@ -83,6 +83,8 @@ def load():
     L.hhv_record_bytes.restype = C.c_int32
     L.hhv_pack_profile.argtypes = [c_float_p, c_float_p, C.c_int32, C.c_int32, c_float_p]
     L.hhv_fast_log2_tables.argtypes = [c_float_p, c_float_p]
+    L.hhv_device_count.argtypes = [c_int_p]
+    L.hhv_shard_plan.argtypes = [C.c_int32, c_int_p, C.c_int32, c_int_p]
     L.hhv_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(HhvParams)]
     L.hhv_destroy.argtypes = [C.c_void_p]
     L.hhv_destroy.restype = None
@@ -151,6 +153,21 @@ def load():
     L.hhv_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, c_int_p]
     _lib = L
     return L
+
+
+def device_count():
+    """hhv_device_count: usable HIP devices (0 when there is none; no exception)."""
+    n = C.c_int32(0)
+    load().hhv_device_count(C.byref(n))
+    return n.value
+
+
+def shard_plan(lengths, n_shards):
+    """hhv_shard_plan: shard of every template (the partition pyhhv.shard.shard_templates computes in Python)."""
+    L = np.ascontiguousarray(lengths, dtype=np.int32)
+    out = np.zeros(L.shape[0], dtype=np.int32)
+    _check(load().hhv_shard_plan(L.shape[0], L.ctypes.data_as(c_int_p), int(n_shards), out.ctypes.data_as(c_int_p)))
+    return out
 
 
 def _check(rc):
@@ -530,6 +547,20 @@ class Context:
         _check(self.lib.hhv_hit_path(self.h, ts.h, int(k), cap, i_steps.ctypes.data, j_steps.ctypes.data,
                                      states.ctypes.data, S.ctypes.data, C.byref(ns)))
         return ns.value, i_steps, j_steps, states, S
+
+    def hit_path_pool(self, ts):
+        """hhv_hit_path_pool: (path_off[n+1], i_steps, j_steps, states, S) of all templates as numpy copies of the
+        library's host mirror (entry path_off[k] + s = step s of template k, s = 1..nsteps)."""
+        ptrs = [C.c_void_p() for _ in range(5)]
+        _check(self.lib.hhv_hit_path_pool(self.h, ts.h, *[C.byref(p) for p in ptrs]))
+        n = ts.n
+        off = np.ctypeslib.as_array(C.cast(ptrs[0], C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+        tot = int(off[n])
+        i_steps = np.ctypeslib.as_array(C.cast(ptrs[1], C.POINTER(C.c_int32)), shape=(tot,)).copy()
+        j_steps = np.ctypeslib.as_array(C.cast(ptrs[2], C.POINTER(C.c_int32)), shape=(tot,)).copy()
+        states = np.ctypeslib.as_array(C.cast(ptrs[3], C.POINTER(C.c_int8)), shape=(tot,)).copy()
+        S = np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_float)), shape=(tot,)).copy()
+        return off, i_steps, j_steps, states, S
 
     def topk(self, ts, k, d_out=None, fetch=True, raw=False):
         out = np.zeros(k, dtype=HIT_DTYPE) if fetch else None

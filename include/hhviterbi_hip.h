@@ -113,6 +113,18 @@ int32_t hhv_record_bytes(void);
 int hhv_pack_profile(const float* p, const float* tr, int32_t L, int32_t index, float* out);
 int hhv_fast_log2_tables(float* lg2, float* diff);
 
+/* Number of usable HIP devices (0 and HHV_E_DEVICE when there is none). */
+int hhv_device_count(int32_t* n);
+
+/* Template-database sharding over the GPUs of one node: the unit of independence is the SIMD batch
+ * loop of ViterbiRunner::alignment (src/hhviterbirunner.cpp:122, the OpenMP loop over batches), so whole templates are
+ * distributed and no DP data crosses GPUs.  Templates are ordered by length descending (like :117-119), cut into bins
+ * of 64 and the bins go to the currently least loaded shard (LPT on stream records = sum of L+1); equal lengths give
+ * contiguous n/n_shards blocks.  shard_of[k] receives the shard of template k (0 .. n_shards-1).  Pure host function:
+ * every rank of a multi-process job and the in-process multi-device runner (hhv::ShardedViterbiRunner) compute the same
+ * plan from the same lengths. */
+int hhv_shard_plan(int32_t n, const int32_t* L, int32_t n_shards, int32_t* shard_of);
+
 int hhv_create(hhv_ctx** out, const hhv_params* par);
 /* Replace the context's fast_log2 tables (lg2[1025], diff[1025]; default: hhv_fast_log2_tables).  The reference keeps these
  * tables in function-local statics that the FIRST caller in the process initialises, and the initialiser is compiled per

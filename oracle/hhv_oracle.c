@@ -942,3 +942,45 @@ double hho_bench_align(const hho_params *par, const float *qp, const float *qtr,
   clock_gettime(CLOCK_MONOTONIC, &t1);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* N templates with backtrace: hho_align + hho_backtrace + hho_score_for_backtrace per template (single-length batches),
+ * OpenMP over templates; the per-template outputs and the two path checksums of ref_bench_hits (oracle/ref_harness.cpp). */
+double hho_bench_hits(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
+                      const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2, int *i1,
+                      int *j1, int *nsteps, int *matched_cols, float *hit_score, unsigned long long *path_hash,
+                      unsigned long long *s_hash) {
+  struct timespec t0, t1;
+  if (threads < 1) threads = 1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (int k = 0; k < N; k++) {
+    const int Lt = L[k], cap = Lq + Lt + 4;
+    unsigned char *bt = (unsigned char *)calloc((size_t)(Lq + 1) * (Lt + 1), 1);
+    int *is = (int *)calloc(cap, sizeof(int)), *js = (int *)calloc(cap, sizeof(int));
+    signed char *st = (signed char *)calloc(cap, 1);
+    float *S = (float *)calloc(cap, sizeof(float));
+    float sss = 0;
+    hho_align(par, qp, qtr, Lq, p[k], tr[k], Lt, Lt, NULL, NULL, &score[k], &i2[k], &j2[k], bt);
+    hho_backtrace(bt, Lt + 1, i2[k], j2[k], is, js, st, cap, &nsteps[k], &matched_cols[k]);
+    hho_score_for_backtrace(par, qp, p[k], NULL, is, js, st, nsteps[k], score[k], S, &hit_score[k], &sss);
+    i1[k] = is[nsteps[k]];
+    j1[k] = js[nsteps[k]];
+    unsigned long long h = 0, hs = 0;
+    for (int s = 1; s <= nsteps[k]; s++) {
+      const unsigned long long w = 2ull * (unsigned long long)s + 1ull;
+      unsigned int bits;
+      h += (((unsigned long long)is[s] * 1000003ull + (unsigned long long)js[s]) * 31ull + (unsigned long long)(unsigned char)st[s]) * w;
+      memcpy(&bits, &S[s], 4);
+      hs += (unsigned long long)bits * w;
+    }
+    path_hash[k] = h;
+    s_hash[k] = hs;
+    free(bt);
+    free(is);
+    free(js);
+    free(st);
+    free(S);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

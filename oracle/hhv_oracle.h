@@ -121,6 +121,12 @@ int hho_mac_backtrace(unsigned char *bmm, const float *post, const float *qp, co
 double hho_bench_align(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
                        const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2);
 
+/* The same with backtrace + Hit score per template and two path checksums (see oracle/ref_harness.cpp ref_bench_hits). */
+double hho_bench_hits(const hho_params *par, const float *qp, const float *qtr, int Lq, int N, const int *L,
+                      const float *const *p, const float *const *tr, int threads, float *score, int *i2, int *j2, int *i1,
+                      int *j1, int *nsteps, int *matched_cols, float *hit_score, unsigned long long *path_hash,
+                      unsigned long long *s_hash);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,46 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _hits_buffers(N):
+    return {"score": np.zeros(N, dtype=np.float32), "i2": np.zeros(N, dtype=np.int32), "j2": np.zeros(N, dtype=np.int32),
+            "i1": np.zeros(N, dtype=np.int32), "j1": np.zeros(N, dtype=np.int32), "nsteps": np.zeros(N, dtype=np.int32),
+            "matched_cols": np.zeros(N, dtype=np.int32), "hit_score": np.zeros(N, dtype=np.float32),
+            "path_hash": np.zeros(N, dtype=np.uint64), "s_hash": np.zeros(N, dtype=np.uint64)}
+
+
+def _hits_args(o):
+    u64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_ulonglong))
+    return [_fp(o["score"]), _ip(o["i2"]), _ip(o["j2"]), _ip(o["i1"]), _ip(o["j1"]), _ip(o["nsteps"]),
+            _ip(o["matched_cols"]), _fp(o["hit_score"]), u64(o["path_hash"]), u64(o["s_hash"])]
+
+
+def path_hashes(path_off, i_steps, j_steps, states, S, nsteps):
+    """The two checksums of ref_bench_hits / hho_bench_hits computed from a path pool (arrays concatenated per template at
+    path_off[k], 1-based steps): returns (path_hash, s_hash) as uint64 arrays."""
+    n = len(nsteps)
+    ph = np.zeros(n, dtype=np.uint64)
+    sh = np.zeros(n, dtype=np.uint64)
+    nsteps = np.asarray(nsteps, dtype=np.int64)
+    total = int(nsteps.sum())
+    if total == 0:
+        return ph, sh
+    starts = np.asarray(path_off[:n], dtype=np.int64) + 1
+    seg = np.repeat(np.arange(n), nsteps)
+    first = np.cumsum(nsteps) - nsteps
+    step = np.arange(total, dtype=np.int64) - np.repeat(first, nsteps) + 1
+    idx = np.repeat(starts, nsteps) + step - 1
+    w = (2 * step + 1).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        a = (np.asarray(i_steps)[idx].astype(np.uint64) * np.uint64(1000003) + np.asarray(j_steps)[idx].astype(np.uint64)) * np.uint64(31) \
+            + (np.asarray(states)[idx].astype(np.uint8)).astype(np.uint64)
+        a = a * w
+        b = np.asarray(S, dtype=np.float32)[idx].view(np.uint32).astype(np.uint64) * w
+        nz = nsteps > 0
+        ph[nz] = np.add.reduceat(a, first[nz])
+        sh[nz] = np.add.reduceat(b, first[nz])
+    return ph, sh
+
+
 class HhoParams(C.Structure):
     _fields_ = [("local", C.c_int), ("egq", C.c_float), ("egt", C.c_float), ("shift", C.c_float),
                 ("corr", C.c_float), ("ssw", C.c_float), ("ss_mode", C.c_int)]
@@ -191,6 +231,24 @@ class Oracle:
         return sec, score, i2, j2
 
 
+    def bench_hits(self, par, qp, qtr, tps, ttrs, threads=1, replicate=True):
+        """Align + Backtrace + ScoreForBacktrace for every template (single-length batches).  Returns a dict of arrays:
+        sec, score, i2, j2, i1, j1, nsteps, matched_cols, hit_score, path_hash, s_hash (see oracle/ref_harness.cpp)."""
+        qp, qtr = _f32(qp), _f32(qtr)
+        tps = [_f32(a) for a in tps]
+        ttrs = [_f32(a) for a in ttrs]
+        N = len(tps)
+        L = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        pp = (c_float_p * N)(*[_fp(a) for a in tps])
+        tt = (c_float_p * N)(*[_fp(a) for a in ttrs])
+        o = _hits_buffers(N)
+        P = HhoParams(**par)
+        self.lib.hho_bench_hits.restype = C.c_double
+        o["sec"] = self.lib.hho_bench_hits(C.byref(P), _fp(qp), _fp(qtr), qp.shape[0] - 1, N, _ip(L), pp, tt, int(threads),
+                                           *_hits_args(o))
+        return o
+
+
 class Ref:
     """The reference itself (Viterbi::Align & co) behind oracle/ref_harness.cpp."""
 
@@ -335,6 +393,25 @@ class Ref:
                                        _fp(qp), _fp(qtr), qp.shape[0] - 1, N, _ip(L), pp, tt, int(threads),
                                        _fp(score), _ip(i2), _ip(j2), C.byref(mapsec))
         return sec, mapsec.value, score, i2, j2
+
+
+    def bench_hits(self, par, qp, qtr, tps, ttrs, threads=1, replicate=False):
+        """The reference's batch loop with Backtrace + ScoreForBacktrace (ref_bench_hits, oracle/ref_harness.cpp)."""
+        qp, qtr = _f32(qp), _f32(qtr)
+        tps = [_f32(a) for a in tps]
+        ttrs = [_f32(a) for a in ttrs]
+        N = len(tps)
+        L = np.array([a.shape[0] - 1 for a in tps], dtype=np.int32)
+        maxres = max(qp.shape[0] - 1, int(L.max())) + 2
+        pp = (c_float_p * N)(*[_fp(a) for a in tps])
+        tt = (c_float_p * N)(*[_fp(a) for a in ttrs])
+        o = _hits_buffers(N)
+        self.lib.ref_bench_hits.restype = C.c_double
+        o["sec"] = self.lib.ref_bench_hits(C.c_int(maxres), C.c_int(par["local"]), C.c_float(par["egq"]), C.c_float(par["egt"]),
+                                           C.c_float(par["corr"]), C.c_float(par["shift"]), _fp(qp), _fp(qtr),
+                                           C.c_int(qp.shape[0] - 1), C.c_int(N), _ip(L), pp, tt, C.c_int(int(threads)),
+                                           C.c_int(int(bool(replicate))), *_hits_args(o))
+        return o
 
 
 DEFAULT_GAP = np.array([0.15, 1.0, 0.6, 0.6, 0.6, 0.6, 1.0], dtype=np.float32)   # gapd gape gapf gapg gaph gapi gapb

@@ -386,4 +386,86 @@ double ref_bench_align(int maxres, int local, float egq, float egt, float corr, 
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// The reference's batch loop with backtrace: Align + Backtrace + ScoreForBacktrace for every lane of every batch
+// (src/hhviterbirunner.cpp:12-71), OpenMP over batches like ViterbiRunner::alignment (:122).  replicate != 0 aligns every
+// template alone (MapOneHMM = single-length batch, the parity definition for global mode over ragged lengths).
+// Per template: ViterbiResult, alignment start, nsteps, matched_cols, Hit score and two checksums over the path
+//   path_hash = sum_s ((i_s * 1000003 + j_s) * 31 + state_s) * (2 s + 1)   (mod 2^64, s = 1..nsteps)
+//   s_hash    = sum_s bits(S_s) * (2 s + 1)
+// which the GPU test recomputes from the engine's path pool.  Returns wall seconds.
+double ref_bench_hits(int maxres, int local, float egq, float egt, float corr, float shift, const float* qp,
+                      const float* qtr, int Lq, int N, const int* L, const float* const* p, const float* const* tr,
+                      int threads, int replicate, float* score, int* i2, int* j2, int* i1, int* j1, int* nsteps,
+                      int* matched_cols, float* hit_score, unsigned long long* path_hash, unsigned long long* s_hash) {
+  const int V = replicate ? 1 : VECSIZE_FLOAT;
+  if (threads < 1) threads = 1;
+  std::vector<RefCtx*> ctx(threads);
+  int Lmax = 0;
+  for (int k = 0; k < N; k++) Lmax = std::max(Lmax, L[k]);
+  for (int t = 0; t < threads; t++) {
+    ctx[t] = (RefCtx*)ref_create(maxres, local, egq, egt, corr, shift, 0, 0.0f, NULL, NULL, NULL);
+    ref_set_query(ctx[t], qp, qtr, Lq, NULL, NULL, NULL);
+    ctx[t]->mat->AllocateBacktraceMatrix(Lq, Lmax);
+  }
+  const int nb = (N + V - 1) / V;
+  auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (int b = 0; b < nb; b++) {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    RefCtx* c = ctx[tid];
+    const int n = std::min(V, N - b * V);
+    std::vector<HMM*> v;
+    for (int e = 0; e < n; e++) {
+      const int k = b * V + e;
+      shell_fill(c->t[e], p[k], tr[k], L[k], NULL, NULL, NULL);
+      v.push_back(c->t[e]->hmm);
+    }
+    int lanes = n;
+    if (replicate) {
+      c->ts->MapOneHMM(c->t[0]->hmm);
+      lanes = VECSIZE_FLOAT;
+    } else {
+      c->ts->MapHMMVector(v);
+    }
+    c->mat->setCellOff(false);
+    Viterbi::ViterbiResult* r = c->vit->Align(c->qs, c->ts, c->mat, lanes, 0);
+    for (int e = 0; e < n; e++) {
+      const int k = b * V + e;
+      score[k] = r->score[e];
+      i2[k] = r->i[e];
+      j2[k] = r->j[e];
+      Viterbi::BacktraceResult bt = Viterbi::Backtrace(c->mat, e, r->i, r->j);
+      Viterbi::BacktraceScore bs = c->vit->ScoreForBacktrace(c->qs, c->ts, e, &bt, r->score, 0);
+      nsteps[k] = bt.count;
+      matched_cols[k] = bt.matched_cols;
+      hit_score[k] = bs.score;
+      i1[k] = bt.i_steps[bt.count];
+      j1[k] = bt.j_steps[bt.count];
+      unsigned long long h = 0, hs = 0;
+      for (int s = 1; s <= bt.count; s++) {
+        const unsigned long long w = 2ull * (unsigned long long)s + 1ull;
+        h += (((unsigned long long)bt.i_steps[s] * 1000003ull + (unsigned long long)bt.j_steps[s]) * 31ull +
+              (unsigned long long)(unsigned char)bt.states[s]) * w;
+        unsigned int bits;
+        memcpy(&bits, &bs.S[s], 4);
+        hs += (unsigned long long)bits * w;
+      }
+      path_hash[k] = h;
+      s_hash[k] = hs;
+      delete[] bt.i_steps;
+      delete[] bt.j_steps;
+      delete[] bt.states;
+      delete[] bs.S;
+      delete[] bs.S_ss;
+    }
+    delete r;
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  for (int t = 0; t < threads; t++) ref_destroy(ctx[t]);
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
 }  // extern "C"

@@ -85,13 +85,15 @@ static int run_pass(const float* qpack, const float* records, long M, Params P, 
         uint64_t cell = 0;
         if (CELLOFF) cell = bt[(size_t)r * 64 + g];
         uint64_t bytes;
+        ArraySrc src;
+        src.rec = rec;
         if (ss.table) {
           float ssv[R];
           const int tidx = (meta >> ss.t_shift) & ss.t_mask;
           for (int r = 0; r < R; ++r) ssv[r] = ss.table[ss.q_off[i0 - 1 + r] + tidx];
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, true>(st[g], q[g], in, rec, j, i0, r_last, P, cell, ssv);
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, true>(st[g], q[g], in, src, j, i0, r_last, P, cell, ssv);
         } else {
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, false>(st[g], q[g], in, rec, j, i0, r_last, P, cell, nullptr);
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, false>(st[g], q[g], in, src, j, i0, r_last, P, cell, nullptr);
         }
         if (BT) bt[(size_t)r * 64 + g] = bytes;
       }

@@ -1,0 +1,15 @@
+"""The stream kernel reads LDS through inline asm that hipcc does not count: audit the generated
+ISA of every instantiation (tools/audit_asm.py) - nothing touches a destination register while its read is in flight,
+no compiler-generated LDS read or vmcnt wait in the loop of the plain variants, no scratch.  CPU-only: hipcc
+cross-compiles gfx950 without a GPU."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stream_kernel_isa_audit():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    assert "audited 120" in out.stdout, out.stdout

@@ -127,3 +127,28 @@ def test_secondary_structure_variant(oracle, ref):
             assert bits(a.score) == bits(b.score) and (a.i2, a.j2) == (b.i2, b.j2), mode
             assert np.array_equal(a.bt[1:, 1:], b.bt[1:, 1:])
             assert bits(a.hit_score) == bits(b.hit_score) and bits(a.score_ss) == bits(b.score_ss)
+
+
+def test_bench_hits_oracle_equals_reference(oracle, ref):
+    """The batch loops with backtrace used by the configs[2] / configs[4] parity tests and by bench.py: restatement ==
+    reference for every output incl. the path checksums, batched (equal lengths) and replicated (ragged lengths)."""
+    from pyhhv import synth
+    from pyoracle import path_hashes
+    qf, qtr = synth.make_query(5, 90)
+    for local, ragged in ((0, False), (1, True), (0, True)):
+        par = make_params(local=local)
+        tps, ttrs = [], []
+        for k in range(37):
+            L = 70 + (k * 7) % 50 if ragged else 80
+            p, tr = synth.make_homolog(900 + k, qf, L=L) if k % 2 else synth.make_template(900 + k, L)
+            tps.append(p)
+            ttrs.append(tr)
+        a = ref.bench_hits(par, qf, qtr, tps, ttrs, threads=3, replicate=ragged)
+        b = oracle.bench_hits(par, qf, qtr, tps, ttrs, threads=3)
+        for k in a:
+            if k != "sec":
+                assert np.array_equal(a[k], b[k]), (local, ragged, k)
+        # the numpy restatement of the checksums (what the GPU tests apply to the engine's path pool)
+        o = oracle.align(par, qf, qtr, tps[3], ttrs[3], want_path=True)
+        ph, sh = path_hashes([0], o.i_steps, o.j_steps, o.states, o.S, [o.nsteps])
+        assert ph[0] == a["path_hash"][3] and sh[0] == a["s_hash"][3]

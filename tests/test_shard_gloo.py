@@ -102,3 +102,15 @@ def test_merge_tie_break():
                         [-1] * 10], dtype=torch.int32)
     m = shard.merge_records(torch, rec, 3)
     assert list(m[:, shard.COL_INDEX]) == [4, 3, 9]
+
+
+def test_c_abi_shard_plan_equals_python_partition():
+    """hhv_shard_plan (the partition the C++ hosts use) == pyhhv.shard.shard_templates, ragged and equal lengths."""
+    from pyhhv import capi
+    for Ls in (synth.zipf_lengths(9, 3000), np.full(1000, 300, dtype=np.int32), synth.zipf_lengths(2, 37), np.array([5], dtype=np.int32)):
+        for world in (1, 2, 3, 8):
+            plan = capi.shard_plan(Ls, world)
+            parts = shard.shard_templates(Ls, world)
+            for r, ids in enumerate(parts):
+                assert np.all(plan[ids] == r)
+            assert sum(len(p) for p in parts) == len(Ls)

@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 KERNEL = "hhv_stream_kernel"
@@ -58,8 +58,29 @@ if "WRITE_SIZE" in pm:
     wr = pm["WRITE_SIZE"] * 1024.0
     summary["hbm_write_bytes_per_launch"] = wr
     lines.append("HBM write bytes/launch (WRITE_SIZE KiB x 1024, uncalibrated)         = %.0f" % wr)
+# WRITE_SIZE calibration (tools/write_calib.hip: 15 052 800 000 bytes stored per launch, 8 or 16 bytes per lane)
+CAL_BYTES = 2048 * 14700 * 64 * 8
+cal = {}
+for r in rows("pmc_wcal/**/*counter_collection.csv"):
+    if r.get("Counter_Name") == "WRITE_SIZE":
+        cal.setdefault("store16" if "store16" in r.get("Kernel_Name", "") else "store8", []).append(float(r["Counter_Value"]))
+if cal:
+    lines.append("")
+    lines.append("== WRITE_SIZE calibration (known %d bytes per launch, pattern of the backtrace stores)" % CAL_BYTES)
+    summary["write_size_calibration"] = {}
+    for k, v in sorted(cal.items()):
+        ratio = (sum(v) / len(v)) * 1024.0 / CAL_BYTES
+        summary["write_size_calibration"][k] = {"counter_KiB": sum(v) / len(v), "true_bytes": CAL_BYTES, "counter_over_true": ratio}
+        lines.append("%-8s WRITE_SIZE x 1024 / true bytes = %.3f" % (k, ratio))
+    f8 = summary["write_size_calibration"].get("store8", {}).get("counter_over_true")
+    if f8 and "WRITE_SIZE" in pm:
+        summary["hbm_write_bytes_per_launch_calibrated"] = pm["WRITE_SIZE"] * 1024.0 / f8
+        lines.append("HBM write bytes/launch calibrated with the 8-B-per-lane factor            = %.0f" % summary["hbm_write_bytes_per_launch_calibrated"])
+if "SQ_INSTS_VALU" in pm:
+    summary["valu_wave_instr_per_launch"] = pm["SQ_INSTS_VALU"]
 if "hbm_read_bytes_per_launch_corrected" in summary:
-    summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch_corrected"] + summary.get("hbm_write_bytes_per_launch", 0.0)
+    summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch_corrected"] + summary.get(
+        "hbm_write_bytes_per_launch_calibrated", summary.get("hbm_write_bytes_per_launch", 0.0))
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 with open(os.path.join(root, "profiles", tag + "_summary.txt"), "w") as f:
     f.write("\n".join(lines) + "\n")

@@ -76,6 +76,44 @@ __global__ void __launch_bounds__(256) kmisc(float* out, int iters, float seed) 
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
+// round-2 additions: what makes an instruction "half rate"?  (a) IEEE mode (v_max_f32 must quiet sNaNs), (b) the 8-byte
+// encodings (VOP3 / 32-bit literal), (c) cheap integer VOP2 forms that could replace v_bfe / v_cvt / v_and_or in log2f4.
+#define REP8X(A) A A A A A A A A
+#define CH8(OP, TAIL)                                                                                                     \
+  OP " %0, %0" TAIL "\n" OP " %1, %1" TAIL "\n" OP " %2, %2" TAIL "\n" OP " %3, %3" TAIL "\n" OP " %4, %4" TAIL "\n" OP   \
+     " %5, %5" TAIL "\n" OP " %6, %6" TAIL "\n" OP " %7, %7" TAIL "\n"
+template <int KIND>
+__global__ void __launch_bounds__(256) kx(float* out, int iters, float seed) {
+  float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+  float b = seed * 0.5f + threadIdx.x * 1e-9f;
+  if (KIND == 0 || KIND == 7) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0");  // IEEE off
+  for (int it = 0; it < iters; ++it) {
+#define OUTS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)
+    if (KIND == 0) asm volatile(REP8X(CH8("v_max_f32", ", %8")) OUTS);                     // v_max_f32, IEEE mode off
+    if (KIND == 1) asm volatile(REP8X(CH8("v_add_f32_e64", ", %8")) OUTS);                 // VOP3-encoded add
+    if (KIND == 2) asm volatile(REP8X("v_add_f32 %0, 0x3fc00001, %0\n v_add_f32 %1, 0x3fc00001, %1\n v_add_f32 %2, 0x3fc00001, %2\n"
+                                      "v_add_f32 %3, 0x3fc00001, %3\n v_add_f32 %4, 0x3fc00001, %4\n v_add_f32 %5, 0x3fc00001, %5\n"
+                                      "v_add_f32 %6, 0x3fc00001, %6\n v_add_f32 %7, 0x3fc00001, %7\n") OUTS);  // VOP2 + 32-bit literal
+    if (KIND == 3) asm volatile(REP8X(CH8("v_and_b32", ", %8")) OUTS);
+    if (KIND == 4) asm volatile(REP8X(CH8("v_lshrrev_b32", ", %8")) OUTS);                 // note: dst = src1 >> src0
+    if (KIND == 5) asm volatile(REP8X(CH8("v_or_b32", ", %8")) OUTS);
+    if (KIND == 6) asm volatile(REP8X("v_cmp_gt_f32_e32 vcc, %0, %8\n v_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n"
+                                      "v_cmp_gt_f32_e32 vcc, %2, %8\n v_addc_co_u32_e32 %3, vcc, %3, %3, vcc\n"
+                                      "v_cmp_gt_f32_e32 vcc, %4, %8\n v_addc_co_u32_e32 %5, vcc, %5, %5, vcc\n"
+                                      "v_cmp_gt_f32_e32 vcc, %6, %8\n v_addc_co_u32_e32 %7, vcc, %7, %7, vcc\n") OUTS : "vcc");
+    if (KIND == 7) asm volatile(REP8X("v_max3_f32 %0, %0, %8, %1\n v_max3_f32 %1, %1, %8, %2\n v_max3_f32 %2, %2, %8, %3\n"
+                                      "v_max3_f32 %3, %3, %8, %4\n v_max3_f32 %4, %4, %8, %5\n v_max3_f32 %5, %5, %8, %6\n"
+                                      "v_max3_f32 %6, %6, %8, %7\n v_max3_f32 %7, %7, %8, %0\n") OUTS);  // IEEE off
+    if (KIND == 8) asm volatile(REP8X(CH8("v_sub_f32", ", %8")) OUTS);
+    if (KIND == 9) asm volatile(REP8X(CH8("v_fmac_f32", ", %8")) OUTS);                    // VOP2 FMA: dst += src0 * src1
+    if (KIND == 10) asm volatile(REP8X(CH8("v_min_f32", ", %8")) OUTS);
+    if (KIND == 11) asm volatile(REP8X(CH8("v_max_u32", ", %8")) OUTS);                    // integer max
+    if (KIND == 12) asm volatile(REP8X(CH8("v_max_i32", ", %8")) OUTS);
+#undef OUTS
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 template <typename F>
 static void run(const char* name, F launch, int width) {
   hipDeviceProp_t prop;
@@ -125,5 +163,19 @@ int main() {
   run("v_and_or_b32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<8>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
   run("v_fma_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<9>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
   run("v_max3_f32", [](int b, float* o, int it) { hipLaunchKernelGGL(kmisc<4>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1);
+#define RUNX(NAME, K) run(NAME, [](int b, float* o, int it) { hipLaunchKernelGGL(kx<K>, dim3(b), dim3(256), 0, 0, o, it, 1.0f); }, 1)
+  RUNX("v_max_f32 IEEE=0", 0);
+  RUNX("v_max3_f32 IEEE=0", 7);
+  RUNX("v_min_f32", 10);
+  RUNX("v_max_u32", 11);
+  RUNX("v_max_i32", 12);
+  RUNX("v_add_f32_e64", 1);
+  RUNX("v_add_f32 literal", 2);
+  RUNX("v_sub_f32", 8);
+  RUNX("v_fmac_f32 (VOP2)", 9);
+  RUNX("v_and_b32", 3);
+  RUNX("v_lshrrev_b32", 4);
+  RUNX("v_or_b32", 5);
+  RUNX("v_cmp_e32+v_addc", 6);
   return 0;
 }
