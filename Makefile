@@ -23,7 +23,7 @@ lib: $(LIB) $(RUNNER)
 
 # C++ host layer above the C ABI (mirror of the reference's ViterbiRunner); plain g++, links only the C ABI
 $(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/prefilter.h hh-suite_amd/host/posterior_decoder.cpp hh-suite_amd/host/posterior_decoder.h include/hhviterbi_hip.h $(LIB)
-	g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared -Wall -Iinclude -o $@ hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/posterior_decoder.cpp -L$(LIBDIR) -lhhviterbi_hip -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared -Wall -Iinclude -o $@ hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/posterior_decoder.cpp -L$(LIBDIR) -lhhviterbi_hip -lpthread -Wl,-rpath,'$$ORIGIN'
 
 $(OBJDIR)/hhv_kernels.o: $(CSRC)/hhv_kernels.hip $(HDRS)
 	@mkdir -p $(OBJDIR)

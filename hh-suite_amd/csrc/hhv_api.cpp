@@ -184,25 +184,13 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   if (!c || !p || !tr) return fail(HHV_E_ARG, "hhv_set_query: null argument");
   if (Lq < 1) return fail(HHV_E_ARG, "hhv_set_query: Lq = %d", Lq);
   if (Lq > 0x7FFF) return fail(HHV_E_LIMIT, "hhv_set_query: Lq = %d exceeds 32767", Lq);
-  // strips of 64*R rows (R <= 5 keeps the kernel at 2 waves/SIMD).  Cost of a pass per stream record ~ a fixed
-  // per-step overhead (LDS read, DPP hand-off, loop) of ~0.7 cell-equivalents plus R cells: pick the (R, P)
-  // minimising P * (0.7 + R), ties -> fewer passes.
-  int R = 1, P = 0;
-  {
-    double best = -1.0;
-    for (int r = 1; r <= MAX_R; ++r) {
-      const int p = (Lq + LANES * r - 1) / (LANES * r);
-      const double cost = p * (0.7 + r);
-      if (best < 0 || cost < best - 1e-9 || (cost < best + 1e-9 && p < P)) {
-        best = cost;
-        R = r;
-        P = p;
-      }
-    }
-  }
+  // strips of 64*R rows, R <= 5 (keeps the kernel at 2 waves/SIMD): the fewest passes that cover Lq, rows spread evenly
+  const StripPlan plan = StripPlan::make(Lq);
   HIP_TRY(hipSetDevice(c->par.device));
-  std::vector<float> qpack((size_t)P * LANES * R * REC_DW, 0.0f);
+  std::vector<float> qpack((size_t)plan.rows() * REC_DW, 0.0f);
   pack_columns(p, tr, Lq, qpack.data());
+  c->Lq = 0;  // no query until the new one is in place (a failure below must not leave the old geometry with freed buffers)
+  c->ss_dirty = true;
   dfree(c->d_qpack);
   dfree(c->d_qp);
   HIP_TRY(hipMalloc(&c->d_qpack, qpack.size() * sizeof(float)));
@@ -211,8 +199,7 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   HIP_TRY(hipMemcpyAsync(c->d_qp, p, (size_t)(Lq + 1) * 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->Lq = Lq;
-  c->R = R;
-  c->P = P;
+  c->plan = plan;
   c->q_pred.clear();
   c->q_conf.clear();
   c->q_dssp.clear();
@@ -262,12 +249,16 @@ static int ensure_ss(hhv_ctx* c) {
   if (!c->ss_dirty) return HHV_OK;
   dfree(c->d_ss_table);
   dfree(c->d_ss_q_off);
-  c->ss_dirty = false;
-  if (c->ss_hmm_mode == 0 || c->Lq < 1) return HHV_OK;
+  // ss_dirty is cleared only once the operands are on the device: after a failure the next call tries again instead of
+  // launching the SS kernels with null tables
+  if (c->ss_hmm_mode == 0 || c->Lq < 1) {
+    c->ss_dirty = false;
+    return HHV_OK;
+  }
   const std::vector<float>& T = c->ss_hmm_mode == 4 ? c->S33 : (c->ss_hmm_mode == 2 ? c->S73 : c->S37);
   std::vector<float> tab(T.size());
   for (size_t k = 0; k < T.size(); ++k) tab[k] = c->par.ssw * T[k];
-  const size_t rows = (size_t)c->P * LANES * c->R;
+  const size_t rows = (size_t)c->plan.rows();
   std::vector<int32_t> off(rows, 0);
   for (int i = 1; i <= c->Lq; ++i) {
     const int pred = c->q_pred.empty() ? 0 : (unsigned char)c->q_pred[i], conf = c->q_conf.empty() ? 0 : c->q_conf[i];
@@ -286,6 +277,7 @@ static int ensure_ss(hhv_ctx* c) {
   HIP_TRY(hipMalloc(&c->d_ss_q_off, off.size() * sizeof(int32_t)));
   HIP_TRY(hipMemcpy(c->d_ss_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_ss_q_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->ss_dirty = false;
   return HHV_OK;
 }
 
@@ -462,15 +454,15 @@ static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_waves) {
 }
 
 static int ensure_bt(hhv_ctx* c, hhv_tset* ts) {
-  if (ts->d_bt && ts->bt_R == c->R && ts->bt_P == c->P) return HHV_OK;
+  if (ts->d_bt && ts->bt_plan == c->plan) return HHV_OK;
   dfree(ts->d_bt);
-  const size_t bytes = (size_t)c->P * ts->n_records * LANES * sizeof(uint64_t);
+  const size_t bytes = (size_t)c->plan.P * ts->n_records * LANES * sizeof(uint64_t);
   if (hipMalloc(&ts->d_bt, bytes) != hipSuccess)
     return fail(HHV_E_MEMORY, "backtrace buffer of %zu bytes does not fit on the device", bytes);
   HIP_TRY(hipMemsetAsync(ts->d_bt, 0, bytes, c->stream));
-  ts->bt_R = c->R;
-  ts->bt_P = c->P;
+  ts->bt_plan = c->plan;
   ts->bt_valid = false;
+  ts->bt_dirty = false;
   return HHV_OK;
 }
 
@@ -486,9 +478,16 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   if (rc != HHV_OK) return rc;
   // src/hhviterbi.cpp:175: the ...AndSS kernels run only for ssm == SCORE_ALIGNMENT and a non-zero ss_hmm_mode
   const bool ss = c->par.ss_mode == 2 && c->ss_hmm_mode != 0;
-  int blocks_per_cu = 0, vgprs = 0;
-  rc = stream_kernel_occupancy(c->R, local, bt, celloff, c->P > 1, ss, &blocks_per_cu, &vgprs);
-  if (rc != 0 || blocks_per_cu < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
+  // one wave partition for all passes: the smallest residency among the kernels of the plan (R_hi and R_hi - 1)
+  const StripPlan& plan = c->plan;
+  const bool multi = plan.P > 1;
+  int blocks_per_cu = 0;
+  for (int R = plan.R(plan.P - 1); R <= plan.R_hi; ++R) {
+    int nb = 0, vgprs = 0;
+    rc = stream_kernel_occupancy(R, local, bt, celloff, multi, ss, &nb, &vgprs);
+    if (rc != 0 || nb < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
+    blocks_per_cu = blocks_per_cu ? std::min(blocks_per_cu, nb) : nb;
+  }
   const int n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu, ts->n));
   rc = ensure_partition(c, ts, n_waves);
   if (rc != HHV_OK) return rc;
@@ -513,7 +512,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.ss_q_off = ss ? c->d_ss_q_off : nullptr;
   a.ss_t_shift = c->ss_t_shift;
   a.ss_t_mask = c->ss_t_mask;
-  if (c->P > 1) {
+  if (multi) {
     if (!ts->d_carry) {
       HIP_TRY(hipMalloc(&ts->d_carry, (size_t)ts->n_records * sizeof(float4)));
       HIP_TRY(hipMalloc(&ts->d_carry_mi, (size_t)ts->n_records * sizeof(float)));
@@ -522,12 +521,13 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.carry_mi = ts->d_carry_mi;
   }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  for (int pass = 0; pass < c->P; ++pass) {
-    a.qpack = c->d_qpack + (size_t)pass * LANES * c->R * REC_DW;
-    a.row_base = pass * LANES * c->R;
+  for (int pass = 0; pass < plan.P; ++pass) {
+    a.row_base = plan.base(pass);
+    a.bt_plane = pass;
+    a.qpack = c->d_qpack + (size_t)a.row_base * REC_DW;
     a.pass_first = pass == 0;
-    a.pass_last = pass == c->P - 1;
-    rc = launch_stream(c->R, local, bt, celloff, c->P > 1, ss, a, n_waves, c->stream);
+    a.pass_last = pass == plan.P - 1;
+    rc = launch_stream(plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -537,6 +537,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   }
   if (bt) {
     ts->bt_valid = true;
+    ts->bt_dirty = true;
     ts->bt_Lq = c->Lq;
   }
   ts->hits_valid = false;
@@ -571,18 +572,26 @@ int hhv_align(hhv_ctx* c, hhv_tset* ts, uint32_t flags, hhv_result* out) {
 
 int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
   if (!c || !ts) return fail(HHV_E_ARG, "hhv_set_celloff: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_set_celloff: template set belongs to another context");
   if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_set_celloff: template %d of %d", k, ts->n);
   if (c->Lq < 1) return fail(HHV_E_STATE, "hhv_set_celloff: no query set");
   HIP_TRY(hipSetDevice(c->par.device));
   int rc = ensure_bt(c, ts);
   if (rc != HHV_OK) return rc;
-  const int Lt = ts->L[k], Lq = c->Lq, R = c->R;
+  if (ts->bt_dirty) {
+    // an earlier backtrace / cell-off launch left compare bits in every entry; as masks they are garbage for the
+    // templates that do not get a fresh mask now: start from "no cell excluded" for the whole set
+    HIP_TRY(hipMemsetAsync(ts->d_bt, 0, (size_t)ts->bt_plan.P * ts->n_records * LANES * sizeof(uint64_t), c->stream));
+    ts->bt_dirty = false;
+  }
+  const int Lt = ts->L[k], Lq = c->Lq;
   // per pass: entries of columns 1..Lt: [Lt][64] x 8 bytes; only bit 7 of each byte is an input of the kernel
   std::vector<uint64_t> e((size_t)Lt * LANES);
-  for (int pass = 0; pass < c->P; ++pass) {
+  for (int pass = 0; pass < c->plan.P; ++pass) {
     std::fill(e.begin(), e.end(), 0);
     if (mask) {
-      const int ilo = pass * LANES * R + 1, ihi = std::min(Lq, (pass + 1) * LANES * R);
+      const int R = c->plan.R(pass);
+      const int ilo = c->plan.base(pass) + 1, ihi = std::min(Lq, c->plan.base(pass + 1));
       for (int i = ilo; i <= ihi; ++i) {
         const int g = (i - ilo) / R, r = (i - ilo) % R;
         const uint8_t* row = mask + (size_t)i * (Lt + 1);
@@ -624,7 +633,12 @@ int hhv_set_celloff_paths(hhv_ctx* c, hhv_tset* ts, int32_t n_paths, const int32
   if (!c || !ts || n_paths < 0 || n_qranges < 0 || n_tranges < 0 || (n_paths && (!template_of || !path_off || !i_steps || !j_steps)) ||
       (n_qranges && !qranges) || (n_tranges && !tranges))
     return fail(HHV_E_ARG, "hhv_set_celloff_paths: bad argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_set_celloff_paths: template set belongs to another context");
   if (c->Lq < 1) return fail(HHV_E_STATE, "hhv_set_celloff_paths: no query set");
+  for (int r = 0; r < n_qranges + n_tranges; ++r) {
+    const int32_t* rg = r < n_qranges ? qranges + 2 * r : tranges + 2 * (r - n_qranges);
+    if (rg[0] < 1) return fail(HHV_E_ARG, "hhv_set_celloff_paths: range %d starts at %d (rows and columns are 1-based)", r, rg[0]);
+  }
   for (int p = 0; p < n_paths; ++p)
     if (template_of[p] < 0 || template_of[p] >= ts->n || path_off[p + 1] < path_off[p])
       return fail(HHV_E_ARG, "hhv_set_celloff_paths: path %d invalid", p);
@@ -654,13 +668,14 @@ int hhv_set_celloff_paths(hhv_ctx* c, hhv_tset* ts, int32_t n_paths, const int32
          hipMemcpyAsync(d_j, j_steps, b_s, hipMemcpyHostToDevice, c->stream) == hipSuccess;
   int lr = 0;
   if (ok)
-    lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, ts->n_records * LANES, c->Lq, c->R, c->P, ts->n, n_paths,
+    lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, ts->n_records * LANES, c->Lq, c->plan, ts->n, n_paths,
                             (const int32_t*)d_t, (const int64_t*)d_o, (const int32_t*)d_i, (const int32_t*)d_j,
                             (const int32_t*)d_r, n_qranges, n_tranges, c->stream);
   const bool synced = hipStreamSynchronize(c->stream) == hipSuccess;
   (void)hipFree(d);
   if (!ok || lr != 0 || !synced) return fail(HHV_E_DEVICE, "hhv_set_celloff_paths: device operation failed");
   ts->bt_valid = false;
+  ts->bt_dirty = false;  // the clear kernel rewrote every entry of every template
   return HHV_OK;
 }
 
@@ -669,14 +684,15 @@ int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
   if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_backtrace_matrix: template %d of %d", k, ts->n);
   if (!ts->bt_valid || !ts->d_bt) return fail(HHV_E_STATE, "hhv_backtrace_matrix: no backtrace computed");
   HIP_TRY(hipSetDevice(c->par.device));
-  const int Lt = ts->L[k], Lq = ts->bt_Lq, R = ts->bt_R;
+  const int Lt = ts->L[k], Lq = ts->bt_Lq;
   std::vector<uint64_t> e((size_t)Lt * LANES);
   HIP_TRY(hipStreamSynchronize(c->stream));
   memset(out, 0, (size_t)(Lq + 1) * (Lt + 1));
-  for (int pass = 0; pass < ts->bt_P; ++pass) {
+  for (int pass = 0; pass < ts->bt_plan.P; ++pass) {
+    const int R = ts->bt_plan.R(pass);
     HIP_TRY(hipMemcpy(e.data(), ts->d_bt + (size_t)pass * ts->n_records * LANES + (size_t)(ts->rec_off[k] + 1) * LANES,
                       e.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    const int ilo = pass * LANES * R + 1, ihi = std::min(Lq, (pass + 1) * LANES * R);
+    const int ilo = ts->bt_plan.base(pass) + 1, ihi = std::min(Lq, ts->bt_plan.base(pass + 1));
     for (int i = ilo; i <= ihi; ++i) {
       const int g = (i - ilo) / R, r = (i - ilo) % R;
       uint8_t* row = out + (size_t)i * (Lt + 1);
@@ -735,7 +751,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.corr = c->par.corr;
   a.ss_mode = c->par.ss_mode;
   a.Lq = c->Lq;
-  a.R = ts->bt_R;
+  a.plan = ts->bt_plan;
   a.n = ts->n;
   a.bt_pass_stride = ts->n_records * LANES;
   rc = ensure_ss(c);
@@ -753,6 +769,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
 
 int hhv_hits(hhv_ctx* c, hhv_tset* ts, hhv_hit* hits) {
   if (!c || !ts) return fail(HHV_E_ARG, "hhv_hits: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_hits: template set belongs to another context");
   HIP_TRY(hipSetDevice(c->par.device));
   int rc = run_trace(c, ts);
   if (rc != HHV_OK) return rc;

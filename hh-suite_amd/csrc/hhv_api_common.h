@@ -46,9 +46,10 @@ struct hhv_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
   int num_cus = 0;
-  // query: P passes of 64*R rows each (P = 1 up to Lq = 320)
-  int Lq = 0, R = 0, P = 0;
-  float* d_qpack = nullptr;  // [P*64*R][28]
+  // query: plan.P passes of 64 * plan.R(p) rows (one pass up to Lq = 320)
+  int Lq = 0;
+  hhv::StripPlan plan;
+  float* d_qpack = nullptr;  // [plan.rows()][28]
   float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring
   // fast_log2 tables (src/util-inl.h:108-130)
   float* d_lg2 = nullptr;
@@ -72,7 +73,7 @@ struct hhv_ctx {
   void* mac_cache = nullptr;                           // one recycled device block of the MAC realignment
   size_t mac_cache_bytes = 0;
   float* d_ss_table = nullptr;                         // ssw * table of the current mode
-  int32_t* d_ss_q_off = nullptr;                       // [P*64*R]
+  int32_t* d_ss_q_off = nullptr;                       // [plan.rows()]
   int ss_t_shift = 0, ss_t_mask = 0;
 };
 
@@ -93,7 +94,11 @@ struct hhv_tset {
   // backtrace bytes: [pass][record][lane] entries
   uint64_t* d_bt = nullptr;
   bool bt_valid = false;
-  int bt_Lq = 0, bt_R = 0, bt_P = 0;
+  // the backtrace / cell-off variants overwrite the mask bytes with compare bits: once such a launch has run, every entry
+  // of the buffer is stale as a MASK until it is cleared (hhv_set_celloff clears the whole buffer when this is set)
+  bool bt_dirty = false;
+  int bt_Lq = 0;
+  hhv::StripPlan bt_plan;
   // carry between the passes of a long query
   float4* d_carry = nullptr;
   float* d_carry_mi = nullptr;

@@ -13,6 +13,46 @@ constexpr int RING_RECS = CHUNK_RECS * RING_CHUNKS;
 constexpr int STREAM_PAD_RECS = 256;  // slack after the terminal header (chunk over-read)
 constexpr int BT_ENTRY_BYTES = 8;  // one backtrace entry = the R (<= 8) bytes of one lane at one column
 
+// Strip plan of a query: the Lq rows are cut into P passes of 64 * R_p rows.  With U = ceil(Lq / 64)
+// row units, P = ceil(U / MAX_R) is the smallest number of passes and the units are spread as evenly as possible: the
+// first P_hi passes take R_hi rows per lane, the others R_hi - 1 (Lq = 431: 4 + 3 rows per lane = 448 rows instead of
+// 2 x 4 = 512; Lq = 2000: 4 x 5 + 3 x 4).  Every pass is its own launch (R is a template parameter of the kernel).
+struct StripPlan {
+  int32_t P = 0, P_hi = 0, R_hi = 0;
+  __host__ __device__ int R(int p) const { return p < P_hi ? R_hi : R_hi - 1; }
+  __host__ __device__ int base(int p) const {  // rows before pass p
+    return p <= P_hi ? p * LANES * R_hi : P_hi * LANES * R_hi + (p - P_hi) * LANES * (R_hi - 1);
+  }
+  __host__ __device__ int rows() const { return base(P); }
+  // 1-based query row i -> backtrace plane (pass), lane, row of the lane, rows per lane of that pass
+  __host__ __device__ void locate(int i, int& pass, int& lane, int& r, int& Rp) const {
+    int k = i - 1;
+    const int hi_rows = P_hi * LANES * R_hi;
+    if (k < hi_rows) {
+      Rp = R_hi;
+      pass = k / (LANES * R_hi);
+      k -= pass * LANES * R_hi;
+    } else {
+      Rp = R_hi - 1;
+      k -= hi_rows;
+      const int q = k / (LANES * Rp);
+      pass = P_hi + q;
+      k -= q * LANES * Rp;
+    }
+    lane = k / Rp;
+    r = k - lane * Rp;
+  }
+  __host__ __device__ bool operator==(const StripPlan& o) const { return P == o.P && P_hi == o.P_hi && R_hi == o.R_hi; }
+  static StripPlan make(int Lq) {
+    StripPlan s;
+    const int U = (Lq + LANES - 1) / LANES;
+    s.P = (U + MAX_R - 1) / MAX_R;
+    s.R_hi = (U + s.P - 1) / s.P;
+    s.P_hi = U - s.P * (s.R_hi - 1);
+    return s;
+  }
+};
+
 struct DevResult {  // matches hhv_result
   float score;
   int32_t i2, j2;
@@ -37,8 +77,9 @@ struct StreamArgs {
   uint64_t* bt;              // [n_records][64] backtrace entries (BT / CELLOFF variants)
   float egq, egt, shift;
   int32_t Lq;
-  // multi-pass strips (Lq > 64*R): pass p handles query rows row_base+1 .. row_base+64*R
-  int32_t row_base;          // p * 64 * R
+  // multi-pass strips (StripPlan): pass p handles query rows row_base+1 .. row_base+64*R_p
+  int32_t row_base;          // StripPlan::base(p)
+  int32_t bt_plane;          // p: the plane of the backtrace buffer this pass reads masks from / writes to
   int32_t pass_first;        // lane 0 takes the DP boundary row 0 (else: the carry of the previous pass)
   int32_t pass_last;         // the lane owning row Lq emits the result (else: lane 63 writes the carry)
   float4* carry;             // [n_records] bottom-row state {MM,GD,IM,DG} of the previous / for the next pass ...
@@ -67,8 +108,9 @@ struct TraceArgs {
   const int64_t* path_off;   // [n+1]
   float corr;
   int32_t ss_mode;
-  int32_t Lq, R, n;
-  int64_t bt_pass_stride;    // backtrace entries per pass (rows are split in passes of 64*R)
+  int32_t Lq, n;
+  StripPlan plan;            // which plane / lane / byte of the backtrace buffer holds query row i
+  int64_t bt_pass_stride;    // backtrace entries per pass
   const float* ss_table;     // null: no secondary-structure information (score_ss = 0)
   const int32_t* ss_q_off;
   int32_t ss_t_shift, ss_t_mask;
@@ -133,7 +175,7 @@ size_t prefilter_fast_lds(bool gapped, int W);
 int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_blocks, void* stream);
 // generic kernel: a.W = ceil(Lq/32); prof_lds = striped profile built in LDS, else read from a.striped
 // cell-off masks of the alternative-alignment rounds from the earlier alignments' paths (hhv_topk.hip)
-int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, int R, int P,
+int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan,
                        int n_templates, int n_paths, const int32_t* template_of, const int64_t* path_off, const int32_t* pi,
                        const int32_t* pj, const int32_t* ranges, int n_q, int n_t, hipStream_t stream);
 // device-side subset of a resident template set (hhv_topk.hip)

@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         uint64_t cell = 0;
         uint64_t* bte = nullptr;
         if (BT || CELLOFF)
-          bte = a.bt + ((MULTI ? (size_t)(a.row_base / (LANES * R)) * a.bt_pass_stride : 0) + (size_t)(rb + r) * LANES + lane);
+          bte = a.bt + ((MULTI ? (size_t)a.bt_plane * a.bt_pass_stride : 0) + (size_t)(rb + r) * LANES + lane);
         if (CELLOFF) cell = *bte;
         float ssv[R];
         if (SS) {
@@ -330,7 +330,6 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   if (k >= a.n) return;
   const DevResult res = a.results[k];
   const int64_t rec0 = a.rec_off[k];
-  const int R = a.R;
   const int64_t po = a.path_off[k];
   int32_t* i_steps = a.i_steps + po;
   int32_t* j_steps = a.j_steps + po;
@@ -346,9 +345,9 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
     j_steps[step] = j;
     uint32_t b = 0;
     if (i >= 1 && j >= 1) {
-      const int strip = (i - 1) / R, rr = (i - 1) - strip * R;  // strip = pass * 64 + lane
-      const int pass = strip / LANES, g = strip - pass * LANES;
-      b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + (size_t)(rec0 + j) * LANES + g], rr, R);
+      int pass, g, rr, Rp;
+      a.plan.locate(i, pass, g, rr, Rp);
+      b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + (size_t)(rec0 + j) * LANES + g], rr, Rp);
     }
     switch (state) {
       case 2:  // MM

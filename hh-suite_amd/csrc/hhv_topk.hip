@@ -189,11 +189,12 @@ struct CellOffGeom {
   const int64_t* rec_off;
   const int32_t* L;
   int64_t pass_stride;  // entries per pass
-  int Lq, R, P;
+  int Lq;
+  StripPlan plan;
 };
 __device__ __forceinline__ void celloff_set(const CellOffGeom& g, int t, int i, int j) {
-  const int strip = (i - 1) / g.R, r = (i - 1) - strip * g.R;
-  const int pass = strip / LANES, lane = strip - pass * LANES;
+  int pass, lane, r, Rp;
+  g.plan.locate(i, pass, lane, r, Rp);
   atomicOr((unsigned long long*)(g.bt + (size_t)pass * g.pass_stride + (size_t)(g.rec_off[t] + j) * LANES + lane),
            0x80ull << (8 * r));
 }
@@ -201,7 +202,7 @@ __device__ __forceinline__ void celloff_set(const CellOffGeom& g, int t, int i, 
 // one workgroup per template: clear every entry, then the -excl / -template_excl ranges
 __global__ void __launch_bounds__(256) celloff_clear_kernel(CellOffGeom g, const int32_t* __restrict__ ranges, int n_q, int n_t) {
   const int t = blockIdx.x, Lt = g.L[t];
-  for (int pass = 0; pass < g.P; ++pass) {
+  for (int pass = 0; pass < g.plan.P; ++pass) {
     uint64_t* e = g.bt + (size_t)pass * g.pass_stride + (size_t)(g.rec_off[t] + 1) * LANES;
     for (int k = threadIdx.x; k < Lt * LANES; k += 256) e[k] = 0;
   }
@@ -233,10 +234,10 @@ __global__ void __launch_bounds__(256) celloff_paths_kernel(CellOffGeom g, const
   }
 }
 
-int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, int R, int P,
+int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan,
                        int n_templates, int n_paths, const int32_t* template_of, const int64_t* path_off, const int32_t* pi,
                        const int32_t* pj, const int32_t* ranges, int n_q, int n_t, hipStream_t stream) {
-  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, R, P};
+  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, plan};
   hipLaunchKernelGGL(celloff_clear_kernel, dim3(n_templates), dim3(256), 0, stream, g, ranges, n_q, n_t);
   if (n_paths > 0)
     hipLaunchKernelGGL(celloff_paths_kernel, dim3(n_paths), dim3(256), 0, stream, g, template_of, path_off, pi, pj);

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 namespace hhv {
 
@@ -200,6 +201,80 @@ std::vector<Hit> ViterbiRunner::alignment(const Parameters& par, const Profile& 
   return ret_hits;
 }
 
+ShardedViterbiRunner::ShardedViterbiRunner(const std::vector<int>& devices) : devices_(devices) {
+  if (devices_.empty()) {
+    int32_t n = 0;
+    check(hhv_device_count(&n), "hhv_device_count");
+    for (int d = 0; d < n; ++d) devices_.push_back(d);
+  }
+}
+
+std::vector<Hit> ShardedViterbiRunner::alignment(const Parameters& par, const Profile& q,
+                                                 const std::vector<Profile>& templates) {
+  const int n = (int)templates.size(), S = (int)devices_.size();
+  shard_sizes_.assign(S, 0);
+  if (n == 0) return std::vector<Hit>();
+  if (S == 1) {
+    shard_sizes_[0] = n;
+    return ViterbiRunner(devices_[0]).alignment(par, q, templates);
+  }
+  std::vector<int32_t> L(n), shard_of(n);
+  for (int k = 0; k < n; ++k) L[k] = templates[k].L;
+  check(hhv_shard_plan(n, L.data(), S, shard_of.data()), "hhv_shard_plan");
+  // the templates of a shard keep their input order, so that a shard's own hit order is the global one restricted to it
+  std::vector<std::vector<Profile> > part(S);
+  std::vector<std::vector<int> > global_id(S);
+  for (int k = 0; k < n; ++k) {
+    part[shard_of[k]].push_back(templates[k]);
+    global_id[shard_of[k]].push_back(k);
+  }
+  std::vector<std::vector<Hit> > hits(S);
+  std::vector<int> status(S, HHV_OK);
+  std::vector<std::string> message(S);
+  std::vector<std::thread> workers;
+  for (int s = 0; s < S; ++s) {
+    shard_sizes_[s] = (int)part[s].size();
+    workers.push_back(std::thread([&, s]() {   // one host thread per context, as the C ABI asks
+      try {
+        if (!part[s].empty()) hits[s] = ViterbiRunner(devices_[s]).alignment(par, q, part[s]);
+      } catch (const Error& e) {
+        status[s] = e.status;
+        message[s] = e.what();
+      } catch (const std::exception& e) {
+        status[s] = HHV_E_MEMORY;
+        message[s] = e.what();
+      }
+    }));
+  }
+  for (size_t w = 0; w < workers.size(); ++w) workers[w].join();
+  for (int s = 0; s < S; ++s)
+    if (status[s] != HHV_OK) throw Error(status[s], "shard " + std::to_string(s) + ": " + message[s]);
+  // merge in hit order: a single runner returns round 1 of every template in template order, then round 2, ...
+  size_t total = 0;
+  for (int s = 0; s < S; ++s) {
+    for (size_t h = 0; h < hits[s].size(); ++h) hits[s][h].entry = global_id[s][hits[s][h].entry];
+    total += hits[s].size();
+  }
+  std::vector<Hit> merged;
+  merged.reserve(total);
+  std::vector<size_t> at(S, 0);
+  while (merged.size() < total) {  // S-way merge of lists that are each sorted by (irep, entry)
+    int best = -1;
+    for (int s = 0; s < S; ++s) {
+      if (at[s] >= hits[s].size()) continue;
+      const Hit& a = hits[s][at[s]];
+      if (best < 0) {
+        best = s;
+        continue;
+      }
+      const Hit& b = hits[best][at[best]];
+      if (a.irep < b.irep || (a.irep == b.irep && a.entry < b.entry)) best = s;
+    }
+    merged.push_back(std::move(hits[best][at[best]++]));
+  }
+  return merged;
+}
+
 }  // namespace hhv
 
 // ---- C shim so that the parity tests (ctypes) can drive the C++ class ------------------------------
@@ -240,8 +315,19 @@ int hhvr_alignment(int device, int loc, float egq, float egt, float shift, float
       ts[k].p = p[k];
       ts[k].tr = tr[k];
     }
-    hhv::ViterbiRunner runner(device);
-    std::vector<hhv::Hit> hits = runner.alignment(par, q, ts);
+    // device >= 0: one GPU; device < 0: -device logical shards, shard s on device s % (number of GPUs) - the sharded runner
+    std::vector<hhv::Hit> hits;
+    if (device >= 0) {
+      hhv::ViterbiRunner runner(device);
+      hits = runner.alignment(par, q, ts);
+    } else {
+      int32_t ndev = 0;
+      if (hhv_device_count(&ndev) != HHV_OK) return HHV_E_DEVICE;
+      std::vector<int> devs;
+      for (int s = 0; s < -device; ++s) devs.push_back(s % ndev);
+      hhv::ShardedViterbiRunner runner(devs);
+      hits = runner.alignment(par, q, ts);
+    }
     const int m = (int)hits.size();
     for (int h = 0; h < m && h < cap_hits; ++h) {
       const hhv::Hit& x = hits[h];

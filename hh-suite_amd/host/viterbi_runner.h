@@ -97,4 +97,26 @@ class ViterbiRunner {
   int device_;
 };
 
+// The same search with the template database sharded over several GPUs of one node.  The reference's unit
+// of independence is the batch loop of ViterbiRunner::alignment (src/hhviterbirunner.cpp:122: `#pragma omp parallel for`
+// over SIMD batches, every batch aligned on its own; the results are merged serially afterwards, :173): that is where
+// the shard boundary goes.  Whole templates are distributed (hhv_shard_plan: length-sorted bins of 64, longest
+// processing time first), every shard runs ALL alternative-alignment rounds of its templates on its own device with its
+// own hhv_ctx (rounds >= 2 only touch the templates and paths of the same shard: no exchange), one host thread per
+// shard, and the hit lists are merged in the order a single ViterbiRunner returns them (round, then template order).
+//   devices: one entry per shard; a device may be listed more than once (logical shards on one GPU - what the tests use
+//            on a one-GPU box).  Empty = one shard per device of the node (hhv_device_count).
+class ShardedViterbiRunner {
+ public:
+  explicit ShardedViterbiRunner(const std::vector<int>& devices = std::vector<int>());
+  std::vector<Hit> alignment(const Parameters& par, const Profile& q, const std::vector<Profile>& templates);
+  const std::vector<int>& devices() const { return devices_; }
+  // templates per shard of the last call (for reporting / tests)
+  const std::vector<int>& shard_sizes() const { return shard_sizes_; }
+
+ private:
+  std::vector<int> devices_;
+  std::vector<int> shard_sizes_;
+};
+
 }  // namespace hhv

@@ -109,6 +109,60 @@ def test_celloff_second_round(hhv, oracle):
         c.close()
 
 
+def test_celloff_for_a_subset_after_a_backtrace_run(hhv, oracle):
+    """hhv_set_celloff for SOME templates after a backtrace launch: the mask bytes share the buffer with the compare bits
+    the launch left behind, so the templates without a fresh mask must read as "no cell excluded", not as stale bits."""
+    for local, Lq in ((1, 150), (0, 431)):
+        par = make_params(local=local)
+        qf, qtr, tps, ttrs = workload(90 + local, Lq, 6, 80, 170, homolog_every=1)
+        c = ctx_for(hhv, par)
+        c.set_query(qf, qtr)
+        ts = c.upload(tps, ttrs)
+        plain = c.align(ts, backtrace=True)
+        c.hits(ts)
+        masked = {}
+        for e in (0, 3):
+            ns, i_s, j_s, st, S = c.hit_path(ts, e)
+            masked[e] = oracle.exclude_alignment(Lq, tps[e].shape[0] - 1, i_s, j_s, ns)
+        for e, m in masked.items():
+            c.set_celloff(ts, e, m)
+        res = c.align(ts, celloff=True)
+        for e in range(6):
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], celloff=masked.get(e), want_path=True)
+            assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and same_float(a.score, res["score"][e]), (local, e)
+            assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:])
+            if e not in masked:
+                assert res[e] == plain[e]
+        # and again: the second masked launch left compare bits too; "NULL clears" for one template, the rest unmasked
+        c.set_celloff(ts, 3, None)
+        res = c.align(ts, celloff=True)
+        assert np.array_equal(res.view(np.uint8), plain.view(np.uint8))
+        ts.free()
+        c.close()
+
+
+def test_strip_plan_rows_per_pass(hhv, oracle):
+    """Queries whose passes have different rows per lane (Lq 431: 4 + 3, 385: 4 + 3, 700: 4 + 4 + 3, 1000: 4 x 4,
+    1217: 4 x 5): scores, backtrace bytes of every pass and paths against the oracle."""
+    for Lq in (385, 431, 700, 1217):
+        par = make_params(local=Lq % 2)
+        qf, qtr, tps, ttrs = workload(300 + Lq, Lq, 4, 60, 200, homolog_every=1)
+        c = ctx_for(hhv, par)
+        c.set_query(qf, qtr)
+        ts = c.upload(tps, ttrs)
+        res = c.align(ts, backtrace=True)
+        hits = c.hits(ts)
+        for e in range(4):
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True)
+            assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and same_float(a.score, res["score"][e]), (Lq, e)
+            assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:]), (Lq, e)
+            ns, i_s, j_s, st, S = c.hit_path(ts, e)
+            assert ns == a.nsteps and np.array_equal(i_s[1:ns + 1], a.i_steps[1:ns + 1]) and np.array_equal(j_s[1:ns + 1], a.j_steps[1:ns + 1])
+            assert same_float(hits["score"][e], a.hit_score)
+        ts.free()
+        c.close()
+
+
 def test_many_templates_partitioning(hhv, oracle):
     """More templates than resident waves, ragged lengths: exercises the wave partition, chunk refills
     (streams much longer than the 192-record LDS ring) and the header/finalize plumbing."""

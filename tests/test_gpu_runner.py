@@ -81,6 +81,24 @@ def test_runner_excluded_regions(oracle):
         assert (h["i2"], h["j2"], h["nsteps"]) == (a.i2, a.j2, a.nsteps)
 
 
+@pytest.mark.parametrize("local,shards", [(1, 2), (0, 3), (1, 8)])
+def test_sharded_runner_equals_single_runner(local, shards):
+    """hhv::ShardedViterbiRunner (template database sharded by hhv_shard_plan, one hhv_ctx and one host thread per shard,
+    logical shards on this one GPU) returns exactly what one ViterbiRunner returns: same hits in the same order, all
+    alternative-alignment rounds, paths included."""
+    from pyhhv import capi
+    Lq = 160
+    qf, qtr, tps, ttrs = workload(80 + shards, Lq, 150, 30, 260, homolog_every=3)
+    one = capi.runner_alignment(qf, qtr, tps, ttrs, loc=local, altali=3, smin=20.0, device=0)
+    many = capi.runner_alignment(qf, qtr, tps, ttrs, loc=local, altali=3, smin=20.0, device=-shards)
+    assert len(one[0]) > len(tps), "workload must trigger alternative alignments"
+    assert np.array_equal(one[0], many[0])
+    for a, b in zip(one[1:], many[1:]):
+        assert np.array_equal(a, b)
+    plan = capi.shard_plan([t.shape[0] - 1 for t in tps], shards)
+    assert len(set(plan.tolist())) == shards
+
+
 def test_cpp_example_runs():
     """The host classes from plain C++ (examples/search_example.cpp): builds against the two shared objects and finds
     the related templates, Viterbi and MAC."""
