@@ -185,7 +185,9 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   if (Lq < 1) return fail(HHV_E_ARG, "hhv_set_query: Lq = %d", Lq);
   if (Lq > 0x7FFF) return fail(HHV_E_LIMIT, "hhv_set_query: Lq = %d exceeds 32767", Lq);
   // strips of 64*R rows, R <= 5 (keeps the kernel at 2 waves/SIMD): the fewest passes that cover Lq, rows spread evenly
-  const StripPlan plan = StripPlan::make(Lq);
+  // (HHV_ARRAY_LANES = 64 / 32 keeps short queries on wider arrays: for measurements)
+  const char* al = getenv("HHV_ARRAY_LANES");
+  const StripPlan plan = StripPlan::make(Lq, al ? atoi(al) : 16);
   HIP_TRY(hipSetDevice(c->par.device));
   std::vector<float> qpack((size_t)plan.rows() * REC_DW, 0.0f);
   pack_columns(p, tr, Lq, qpack.data());
@@ -434,29 +436,31 @@ int64_t hhv_tset_cells(const hhv_tset* ts, int32_t Lq) {
 
 // Contiguous template ranges with ~equal record counts, one per wave.  All waves are resident at
 // once (n_waves = CUs x blocks/CU the variant's VGPR/LDS budget admits), so there is no tail.
-static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_waves) {
-  if (ts->n_waves == n_waves && ts->d_wave_rec) return HHV_OK;
+static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_ranges, int n_slots) {
+  // n_ranges non-empty ranges, padded with empty ones to n_slots (a wave of a short-query launch takes 64 / W ranges)
+  if (ts->n_waves == n_ranges && ts->n_range_slots == n_slots && ts->d_wave_rec) return HHV_OK;
   dfree(ts->d_wave_rec);
-  std::vector<int64_t> wr((size_t)n_waves + 1);
+  std::vector<int64_t> wr((size_t)n_slots + 1);
   const int64_t total = ts->rec_off[ts->n];
   int k = 0;
-  for (int w = 0; w < n_waves; ++w) {
-    const int64_t target = (int64_t)(((__int128)total * w) / n_waves);
+  for (int w = 0; w < n_ranges; ++w) {
+    const int64_t target = (int64_t)(((__int128)total * w) / n_ranges);
     while (k < ts->n && ts->rec_off[k] < target) ++k;
     wr[w] = ts->rec_off[k];
   }
-  wr[n_waves] = total;
+  for (int w = n_ranges; w <= n_slots; ++w) wr[w] = total;
   HIP_TRY(hipMalloc(&ts->d_wave_rec, wr.size() * sizeof(int64_t)));
   HIP_TRY(hipMemcpyAsync(ts->d_wave_rec, wr.data(), wr.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  ts->n_waves = n_waves;
+  ts->n_waves = n_ranges;
+  ts->n_range_slots = n_slots;
   return HHV_OK;
 }
 
 static int ensure_bt(hhv_ctx* c, hhv_tset* ts) {
   if (ts->d_bt && ts->bt_plan == c->plan) return HHV_OK;
   dfree(ts->d_bt);
-  const size_t bytes = (size_t)c->plan.P * ts->n_records * LANES * sizeof(uint64_t);
+  const size_t bytes = (size_t)c->plan.P * bt_plane_entries(ts->n_records, c->plan.W) * sizeof(uint64_t);
   if (hipMalloc(&ts->d_bt, bytes) != hipSuccess)
     return fail(HHV_E_MEMORY, "backtrace buffer of %zu bytes does not fit on the device", bytes);
   HIP_TRY(hipMemsetAsync(ts->d_bt, 0, bytes, c->stream));
@@ -481,15 +485,17 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   // one wave partition for all passes: the smallest residency among the kernels of the plan (R_hi and R_hi - 1)
   const StripPlan& plan = c->plan;
   const bool multi = plan.P > 1;
+  const int arrays = LANES / plan.W;  // systolic arrays per wave (short queries: 2 or 4), one stream range each
   int blocks_per_cu = 0;
   for (int R = plan.R(plan.P - 1); R <= plan.R_hi; ++R) {
     int nb = 0, vgprs = 0;
-    rc = stream_kernel_occupancy(R, local, bt, celloff, multi, ss, &nb, &vgprs);
+    rc = stream_kernel_occupancy(plan.W, R, local, bt, celloff, multi, ss, &nb, &vgprs);
     if (rc != 0 || nb < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
     blocks_per_cu = blocks_per_cu ? std::min(blocks_per_cu, nb) : nb;
   }
-  const int n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu, ts->n));
-  rc = ensure_partition(c, ts, n_waves);
+  const int n_ranges = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu * arrays, ts->n));
+  const int n_waves = (n_ranges + arrays - 1) / arrays;
+  rc = ensure_partition(c, ts, n_ranges, n_waves * arrays);
   if (rc != HHV_OK) return rc;
   if (bt) {
     rc = ensure_bt(c, ts);
@@ -507,7 +513,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.Lq = c->Lq;
   a.carry = nullptr;
   a.carry_mi = nullptr;
-  a.bt_pass_stride = ts->n_records * LANES;
+  a.bt_pass_stride = (int64_t)bt_plane_entries(ts->n_records, plan.W);
   a.ss_table = ss ? c->d_ss_table : nullptr;
   a.ss_q_off = ss ? c->d_ss_q_off : nullptr;
   a.ss_t_shift = c->ss_t_shift;
@@ -527,7 +533,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.qpack = c->d_qpack + (size_t)a.row_base * REC_DW;
     a.pass_first = pass == 0;
     a.pass_last = pass == plan.P - 1;
-    rc = launch_stream(plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
+    rc = launch_stream(plan.W, plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -581,28 +587,26 @@ int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
   if (ts->bt_dirty) {
     // an earlier backtrace / cell-off launch left compare bits in every entry; as masks they are garbage for the
     // templates that do not get a fresh mask now: start from "no cell excluded" for the whole set
-    HIP_TRY(hipMemsetAsync(ts->d_bt, 0, (size_t)ts->bt_plan.P * ts->n_records * LANES * sizeof(uint64_t), c->stream));
+    HIP_TRY(hipMemsetAsync(ts->d_bt, 0, (size_t)ts->bt_plan.P * bt_plane_entries(ts->n_records, ts->bt_plan.W) * sizeof(uint64_t), c->stream));
     ts->bt_dirty = false;
   }
+  // the mask bytes go to the device once; a kernel turns them into the entries of template k (bit 7 of byte r of the
+  // entry of (column j, lane): the only input bit of the kernel in this buffer)
   const int Lt = ts->L[k], Lq = c->Lq;
-  // per pass: entries of columns 1..Lt: [Lt][64] x 8 bytes; only bit 7 of each byte is an input of the kernel
-  std::vector<uint64_t> e((size_t)Lt * LANES);
-  for (int pass = 0; pass < c->plan.P; ++pass) {
-    std::fill(e.begin(), e.end(), 0);
-    if (mask) {
-      const int R = c->plan.R(pass);
-      const int ilo = c->plan.base(pass) + 1, ihi = std::min(Lq, c->plan.base(pass + 1));
-      for (int i = ilo; i <= ihi; ++i) {
-        const int g = (i - ilo) / R, r = (i - ilo) % R;
-        const uint8_t* row = mask + (size_t)i * (Lt + 1);
-        for (int j = 1; j <= Lt; ++j)
-          if (row[j]) e[(size_t)(j - 1) * LANES + g] |= (uint64_t)0x80 << (8 * r);
-      }
+  unsigned char* d_mask = nullptr;
+  if (mask) {
+    const size_t bytes = (size_t)(Lq + 1) * (Lt + 1);
+    HIP_TRY(hipMalloc(&d_mask, bytes));
+    if (hipMemcpyAsync(d_mask, mask, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      dfree(d_mask);
+      return fail(HHV_E_DEVICE, "hhv_set_celloff: H2D copy failed");
     }
-    HIP_TRY(hipMemcpyAsync(ts->d_bt + (size_t)pass * ts->n_records * LANES + (size_t)(ts->rec_off[k] + 1) * LANES,
-                           e.data(), e.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  const int lr = celloff_from_mask(ts->d_bt, ts->d_rec_off, ts->d_L, (int64_t)bt_plane_entries(ts->n_records, c->plan.W), Lq,
+                                   c->plan, k, d_mask, Lt, c->stream);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  dfree(d_mask);
+  if (lr != 0 || e != hipSuccess) return fail(HHV_E_DEVICE, "hhv_set_celloff: device operation failed");
   ts->bt_valid = false;
   return HHV_OK;
 }
@@ -668,7 +672,7 @@ int hhv_set_celloff_paths(hhv_ctx* c, hhv_tset* ts, int32_t n_paths, const int32
          hipMemcpyAsync(d_j, j_steps, b_s, hipMemcpyHostToDevice, c->stream) == hipSuccess;
   int lr = 0;
   if (ok)
-    lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, ts->n_records * LANES, c->Lq, c->plan, ts->n, n_paths,
+    lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, (int64_t)bt_plane_entries(ts->n_records, c->plan.W), c->Lq, c->plan, ts->n, n_paths,
                             (const int32_t*)d_t, (const int64_t*)d_o, (const int32_t*)d_i, (const int32_t*)d_j,
                             (const int32_t*)d_r, n_qranges, n_tranges, c->stream);
   const bool synced = hipStreamSynchronize(c->stream) == hipSuccess;
@@ -685,20 +689,15 @@ int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
   if (!ts->bt_valid || !ts->d_bt) return fail(HHV_E_STATE, "hhv_backtrace_matrix: no backtrace computed");
   HIP_TRY(hipSetDevice(c->par.device));
   const int Lt = ts->L[k], Lq = ts->bt_Lq;
-  std::vector<uint64_t> e((size_t)Lt * LANES);
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  memset(out, 0, (size_t)(Lq + 1) * (Lt + 1));
-  for (int pass = 0; pass < ts->bt_plan.P; ++pass) {
-    const int R = ts->bt_plan.R(pass);
-    HIP_TRY(hipMemcpy(e.data(), ts->d_bt + (size_t)pass * ts->n_records * LANES + (size_t)(ts->rec_off[k] + 1) * LANES,
-                      e.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    const int ilo = ts->bt_plan.base(pass) + 1, ihi = std::min(Lq, ts->bt_plan.base(pass + 1));
-    for (int i = ilo; i <= ihi; ++i) {
-      const int g = (i - ilo) / R, r = (i - ilo) % R;
-      uint8_t* row = out + (size_t)i * (Lt + 1);
-      for (int j = 1; j <= Lt; ++j) row[j] = (uint8_t)bt_decode(e[(size_t)(j - 1) * LANES + g], r, R);
-    }
-  }
+  const size_t bytes = (size_t)(Lq + 1) * (Lt + 1);
+  unsigned char* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, bytes));
+  const int lr = bt_matrix(ts->d_bt, ts->d_rec_off, (int64_t)bt_plane_entries(ts->n_records, ts->bt_plan.W), Lq, ts->bt_plan, k, Lt,
+                           d_out, c->stream);
+  hipError_t e = lr == 0 ? hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream) : hipErrorUnknown;
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  dfree(d_out);
+  if (e != hipSuccess) return fail(HHV_E_DEVICE, "hhv_backtrace_matrix: device operation failed");
   return HHV_OK;
 }
 
@@ -753,7 +752,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.Lq = c->Lq;
   a.plan = ts->bt_plan;
   a.n = ts->n;
-  a.bt_pass_stride = ts->n_records * LANES;
+  a.bt_pass_stride = (int64_t)bt_plane_entries(ts->n_records, ts->bt_plan.W);
   rc = ensure_ss(c);
   if (rc != HHV_OK) return rc;
   a.ss_table = c->ss_hmm_mode ? c->d_ss_table : nullptr;

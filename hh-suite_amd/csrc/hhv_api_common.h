@@ -89,7 +89,7 @@ struct hhv_tset {
   int32_t* d_L = nullptr;
   hhv::DevResult* d_results = nullptr;
   // wave partition
-  int n_waves = 0;
+  int n_waves = 0, n_range_slots = 0;  // non-empty stream ranges / ranges incl. the empty padding
   int64_t* d_wave_rec = nullptr;
   // backtrace bytes: [pass][record][lane] entries
   uint64_t* d_bt = nullptr;

@@ -13,45 +13,64 @@ constexpr int RING_RECS = CHUNK_RECS * RING_CHUNKS;
 constexpr int STREAM_PAD_RECS = 256;  // slack after the terminal header (chunk over-read)
 constexpr int BT_ENTRY_BYTES = 8;  // one backtrace entry = the R (<= 8) bytes of one lane at one column
 
-// Strip plan of a query: the Lq rows are cut into P passes of 64 * R_p rows.  With U = ceil(Lq / 64)
-// row units, P = ceil(U / MAX_R) is the smallest number of passes and the units are spread as evenly as possible: the
-// first P_hi passes take R_hi rows per lane, the others R_hi - 1 (Lq = 431: 4 + 3 rows per lane = 448 rows instead of
-// 2 x 4 = 512; Lq = 2000: 4 x 5 + 3 x 4).  Every pass is its own launch (R is a template parameter of the kernel).
+// Strip plan of a query.
+// Long queries: the Lq rows are cut into P passes of 64 * R_p rows.  With U = ceil(Lq / 64) row units, P = ceil(U / MAX_R)
+// is the smallest number of passes and the units are spread as evenly as possible: the first P_hi passes take R_hi rows
+// per lane, the others R_hi - 1 (Lq = 431: 4 + 3 rows per lane = 448 rows instead of 2 x 4 = 512; Lq = 2000: 4 x 5 + 3 x 4).
+// Every pass is its own launch (R is a template parameter of the kernel).
+// Short queries: a 64-lane array would leave most rows of the strip empty (Lq = 80: R = 2, 128 rows) and pay the per-step
+// overhead for few cells, so the wavefront is split into 64 / W independent systolic arrays of W = 32 (Lq <= 160) or
+// 16 (Lq <= 80) lanes, each walking its own range of the template stream with R = ceil(Lq / W) rows per lane.
 struct StripPlan {
   int32_t P = 0, P_hi = 0, R_hi = 0;
+  int32_t W = LANES;  // lanes per systolic array (64, 32 or 16; < 64 only with P == 1)
   __host__ __device__ int R(int p) const { return p < P_hi ? R_hi : R_hi - 1; }
   __host__ __device__ int base(int p) const {  // rows before pass p
-    return p <= P_hi ? p * LANES * R_hi : P_hi * LANES * R_hi + (p - P_hi) * LANES * (R_hi - 1);
+    return p <= P_hi ? p * W * R_hi : P_hi * W * R_hi + (p - P_hi) * W * (R_hi - 1);
   }
   __host__ __device__ int rows() const { return base(P); }
-  // 1-based query row i -> backtrace plane (pass), lane, row of the lane, rows per lane of that pass
+  // 1-based query row i -> backtrace plane (pass), lane of the array, row of the lane, rows per lane of that pass
   __host__ __device__ void locate(int i, int& pass, int& lane, int& r, int& Rp) const {
     int k = i - 1;
-    const int hi_rows = P_hi * LANES * R_hi;
+    const int hi_rows = P_hi * W * R_hi;
     if (k < hi_rows) {
       Rp = R_hi;
-      pass = k / (LANES * R_hi);
-      k -= pass * LANES * R_hi;
+      pass = k / (W * R_hi);
+      k -= pass * W * R_hi;
     } else {
       Rp = R_hi - 1;
       k -= hi_rows;
-      const int q = k / (LANES * Rp);
+      const int q = k / (W * Rp);
       pass = P_hi + q;
-      k -= q * LANES * Rp;
+      k -= q * W * Rp;
     }
     lane = k / Rp;
     r = k - lane * Rp;
   }
-  __host__ __device__ bool operator==(const StripPlan& o) const { return P == o.P && P_hi == o.P_hi && R_hi == o.R_hi; }
-  static StripPlan make(int Lq) {
+  __host__ __device__ bool operator==(const StripPlan& o) const {
+    return P == o.P && P_hi == o.P_hi && R_hi == o.R_hi && W == o.W;
+  }
+  // max_array_lanes: 64 disables the short-query arrays (HHV_ARRAY_LANES, for measurements)
+  static StripPlan make(int Lq, int max_split = 16) {
     StripPlan s;
-    const int U = (Lq + LANES - 1) / LANES;
+    s.W = LANES;
+    if (Lq <= 16 * MAX_R && max_split <= 16) s.W = 16;
+    else if (Lq <= 32 * MAX_R && max_split <= 32) s.W = 32;
+    const int U = (Lq + s.W - 1) / s.W;
     s.P = (U + MAX_R - 1) / MAX_R;
     s.R_hi = (U + s.P - 1) / s.P;
     s.P_hi = U - s.P * (s.R_hi - 1);
     return s;
   }
 };
+
+// Backtrace / cell-off buffer: one plane per pass, one 8-byte entry per (stream record, lane).
+// The entry of (record rec, lane g) sits at row rec + g, column g: at step s lane g works on record s - g, so the W
+// entries a systolic array stores in one step share the row (first record + s) - ONE contiguous W * 8 byte store per
+// array and step, whatever the wave partition is (a record-major layout would scatter the 8-byte pieces of a step over
+// W different rows: 4 x write amplification at the HBM, measured with WRITE_SIZE in profiles/r1bt_summary.txt).
+__host__ __device__ inline size_t bt_entry(int64_t rec, int g, int W) { return (size_t)(rec + g) * (size_t)W + (size_t)g; }
+__host__ __device__ inline size_t bt_plane_entries(int64_t n_records, int W) { return (size_t)(n_records + W) * (size_t)W; }
 
 struct DevResult {  // matches hhv_result
   float score;
@@ -71,10 +90,10 @@ struct DevHit {  // matches hhv_hit
 
 struct StreamArgs {
   const float* records;      // [n_records + pad][28]
-  const int64_t* wave_rec;   // [n_waves + 1] first record of each wave's template range
+  const int64_t* wave_rec;   // [n_waves * (64 / W) + 1] first record of each array's template range
   const float* qpack;        // [64*R][28]
   DevResult* results;        // [n_templates]
-  uint64_t* bt;              // [n_records][64] backtrace entries (BT / CELLOFF variants)
+  uint64_t* bt;              // backtrace / cell-off entries, bt_entry() layout (BT / CELLOFF variants)
   float egq, egt, shift;
   int32_t Lq;
   // multi-pass strips (StripPlan): pass p handles query rows row_base+1 .. row_base+64*R_p
@@ -84,7 +103,7 @@ struct StreamArgs {
   int32_t pass_last;         // the lane owning row Lq emits the result (else: lane 63 writes the carry)
   float4* carry;             // [n_records] bottom-row state {MM,GD,IM,DG} of the previous / for the next pass ...
   float* carry_mi;           // ... and MI
-  int64_t bt_pass_stride;    // backtrace entries per pass = n_records * 64
+  int64_t bt_pass_stride;    // entries per plane = bt_plane_entries(n_records, W)
   // secondary-structure term (SS variants): ss(i,j) = ss_table[ss_q_off[i-1] + ((meta_j >> ss_t_shift) & ss_t_mask)]
   const float* ss_table;     // ssw * S33 / S73 / S37, premultiplied on the host (same fp32 product as the reference)
   const int32_t* ss_q_off;   // [P*64*R] table row offset of query row i at index i-1
@@ -273,8 +292,18 @@ int mac_length_class(int Lt);
 int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream, const MacStreams* side);
 
 // launchers implemented in hhv_kernels.hip
-int launch_stream(int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
-int stream_kernel_occupancy(int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);
+// W = lanes per systolic array (64, 32, 16): W < 64 variants exist for single-pass queries only (multi = false)
+int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
+int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);
+// per-W instantiation units (hhv_kernels.hip: 64, hhv_kernels_w32.hip, hhv_kernels_w16.hip)
+void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss);
+void* stream_kernel_w32(int R, bool local, bool bt, bool celloff, bool ss);
+void* stream_kernel_w16(int R, bool local, bool bt, bool celloff, bool ss);
+// one template's mask bytes -> cell-off entries; entries -> the reference's backtrace byte matrix (hhv_topk.hip)
+int celloff_from_mask(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan, int t,
+                      const unsigned char* d_mask /* (Lq+1) x (Lt+1) bytes, null = clear */, int Lt, hipStream_t stream);
+int bt_matrix(const uint64_t* bt, const int64_t* rec_off, int64_t pass_stride, int Lq, StripPlan plan, int t, int Lt,
+              unsigned char* d_out /* (Lq+1) x (Lt+1) */, hipStream_t stream);
 int launch_trace(const TraceArgs& a, void* stream);
 
 }  // namespace hhv

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <string>
 
 #include "hhv_internal.h"
@@ -195,16 +196,16 @@ struct CellOffGeom {
 __device__ __forceinline__ void celloff_set(const CellOffGeom& g, int t, int i, int j) {
   int pass, lane, r, Rp;
   g.plan.locate(i, pass, lane, r, Rp);
-  atomicOr((unsigned long long*)(g.bt + (size_t)pass * g.pass_stride + (size_t)(g.rec_off[t] + j) * LANES + lane),
+  atomicOr((unsigned long long*)(g.bt + (size_t)pass * g.pass_stride + bt_entry(g.rec_off[t] + j, lane, g.plan.W)),
            0x80ull << (8 * r));
 }
 
 // one workgroup per template: clear every entry, then the -excl / -template_excl ranges
 __global__ void __launch_bounds__(256) celloff_clear_kernel(CellOffGeom g, const int32_t* __restrict__ ranges, int n_q, int n_t) {
-  const int t = blockIdx.x, Lt = g.L[t];
+  const int t = blockIdx.x, Lt = g.L[t], W = g.plan.W;
   for (int pass = 0; pass < g.plan.P; ++pass) {
-    uint64_t* e = g.bt + (size_t)pass * g.pass_stride + (size_t)(g.rec_off[t] + 1) * LANES;
-    for (int k = threadIdx.x; k < Lt * LANES; k += 256) e[k] = 0;
+    uint64_t* e = g.bt + (size_t)pass * g.pass_stride;
+    for (int k = threadIdx.x; k < Lt * W; k += 256) e[bt_entry(g.rec_off[t] + 1 + k / W, k % W, W)] = 0;
   }
   __syncthreads();
   for (int q = 0; q < n_q; ++q) {
@@ -214,6 +215,40 @@ __global__ void __launch_bounds__(256) celloff_clear_kernel(CellOffGeom g, const
   for (int q = 0; q < n_t; ++q) {
     const int lo = ranges[2 * (n_q + q)], hi = min(ranges[2 * (n_q + q) + 1], Lt);
     for (int c = threadIdx.x; c < (hi - lo + 1) * g.Lq; c += 256) celloff_set(g, t, 1 + c % g.Lq, lo + c / g.Lq);
+  }
+}
+
+// hhv_set_celloff: the caller's byte mask of ONE template -> its entries (every entry of the template is rewritten)
+__global__ void __launch_bounds__(256) celloff_mask_kernel(CellOffGeom g, int t, int Lt, const unsigned char* __restrict__ mask) {
+  const int W = g.plan.W;
+  for (int pass = 0; pass < g.plan.P; ++pass) {
+    const int R = g.plan.R(pass), ilo = g.plan.base(pass) + 1;
+    uint64_t* e = g.bt + (size_t)pass * g.pass_stride;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < Lt * W; k += gridDim.x * 256) {
+      const int j = 1 + k / W, lane = k % W;
+      uint64_t v = 0;
+      if (mask)
+        for (int r = 0; r < R; ++r) {
+          const int i = ilo + lane * R + r;
+          if (i <= g.Lq && mask[(size_t)i * (Lt + 1) + j]) v |= 0x80ull << (8 * r);
+        }
+      e[bt_entry(g.rec_off[t] + j, lane, W)] = v;
+    }
+  }
+}
+
+// hhv_backtrace_matrix: the entries of one template decoded into the reference's byte matrix [(Lq+1)][(Lt+1)]
+__global__ void __launch_bounds__(256) bt_matrix_kernel(CellOffGeom g, int t, int Lt, unsigned char* __restrict__ out) {
+  const int64_t cells = (int64_t)(g.Lq + 1) * (Lt + 1);
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cells; c += (int64_t)gridDim.x * 256) {
+    const int i = (int)(c / (Lt + 1)), j = (int)(c % (Lt + 1));
+    unsigned char b = 0;
+    if (i >= 1 && j >= 1) {
+      int pass, lane, r, Rp;
+      g.plan.locate(i, pass, lane, r, Rp);
+      b = (unsigned char)bt_decode(g.bt[(size_t)pass * g.pass_stride + bt_entry(g.rec_off[t] + j, lane, g.plan.W)], r, Rp);
+    }
+    out[c] = b;
   }
 }
 
@@ -241,6 +276,25 @@ int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, i
   hipLaunchKernelGGL(celloff_clear_kernel, dim3(n_templates), dim3(256), 0, stream, g, ranges, n_q, n_t);
   if (n_paths > 0)
     hipLaunchKernelGGL(celloff_paths_kernel, dim3(n_paths), dim3(256), 0, stream, g, template_of, path_off, pi, pj);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+int celloff_from_mask(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan, int t,
+                      const unsigned char* d_mask, int Lt, hipStream_t stream) {
+  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, plan};
+  const int blocks = std::max(1, std::min(256, (Lt * plan.W + 255) / 256));
+  hipLaunchKernelGGL(celloff_mask_kernel, dim3(blocks), dim3(256), 0, stream, g, t, Lt, d_mask);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+int bt_matrix(const uint64_t* bt, const int64_t* rec_off, int64_t pass_stride, int Lq, StripPlan plan, int t, int Lt,
+              unsigned char* d_out, hipStream_t stream) {
+  CellOffGeom g{const_cast<uint64_t*>(bt), rec_off, nullptr, pass_stride, Lq, plan};
+  const int64_t cells = (int64_t)(Lq + 1) * (Lt + 1);
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (cells + 255) / 256));
+  hipLaunchKernelGGL(bt_matrix_kernel, dim3(blocks), dim3(256), 0, stream, g, t, Lt, d_out);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

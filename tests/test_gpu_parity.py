@@ -163,6 +163,58 @@ def test_strip_plan_rows_per_pass(hhv, oracle):
         c.close()
 
 
+@pytest.mark.parametrize("Lq", [1, 7, 16, 17, 33, 64, 80, 81, 97, 128, 160, 161])
+def test_short_query_arrays(hhv, oracle, Lq):
+    """Short queries run as 4 (Lq <= 80) or 2 (Lq <= 160) independent systolic arrays per wavefront, every array on its own
+    stream range: more templates than arrays so that every array of every wave works, ragged lengths (templates shorter
+    than an array, streams longer than the ring), with backtrace, Hit scores and paths; a masked second round for some."""
+    rng = np.random.default_rng(Lq)
+    par = make_params(local=Lq % 2, egq=0.0 if Lq % 3 else 0.2, egt=0.0 if Lq % 3 else 0.1)
+    n = 700
+    from pyhhv import synth
+    qf, qtr = synth.make_query(3000 + Lq, Lq)
+    base = []
+    for k in range(48):
+        L = int(rng.integers(1, 200)) if k % 6 else int(rng.integers(1, 12))
+        base.append(synth.make_homolog(9100 + k, qf, L=L) if k % 3 == 0 else synth.make_template(9100 + k, L))
+    idx = rng.integers(0, 48, n)
+    tps = [base[i][0] for i in idx]
+    ttrs = [base[i][1] for i in idx]
+    c = ctx_for(hhv, par)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    plain = c.align(ts)
+    res = c.align(ts, backtrace=True)
+    assert np.array_equal(plain.view(np.uint8), res.view(np.uint8))
+    hits = c.hits(ts)
+    ref = [oracle.align(par, qf, qtr, base[i][0], base[i][1], want_path=True) for i in range(48)]
+    for e in range(n):
+        a = ref[idx[e]]
+        assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and same_float(a.score, res["score"][e]), (Lq, e)
+        assert hits["nsteps"][e] == a.nsteps and same_float(hits["score"][e], a.hit_score), (Lq, e)
+    for e in (0, 1, n // 2, n - 1):
+        a = ref[idx[e]]
+        assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:]), (Lq, e)
+        ns, i_s, j_s, st, S = c.hit_path(ts, e)
+        assert np.array_equal(i_s[1:ns + 1], a.i_steps[1:ns + 1]) and np.array_equal(S[1:ns + 1], a.S[1:ns + 1])
+    # cell-off round for three templates, the others unmasked
+    masked = {}
+    for e in (2, n // 3, n - 2):
+        a = ref[idx[e]]
+        masked[e] = oracle.exclude_alignment(Lq, tps[e].shape[0] - 1, a.i_steps, a.j_steps, a.nsteps)
+        c.set_celloff(ts, e, masked[e])
+    res2 = c.align(ts, celloff=True)
+    for e in range(n):
+        if e in masked:
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], celloff=masked[e], want_path=True)
+            assert (a.i2, a.j2) == (res2["i2"][e], res2["j2"][e]) and same_float(a.score, res2["score"][e]), (Lq, e)
+            assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:])
+        else:
+            assert res2[e] == res[e]
+    ts.free()
+    c.close()
+
+
 def test_many_templates_partitioning(hhv, oracle):
     """More templates than resident waves, ragged lengths: exercises the wave partition, chunk refills
     (streams much longer than the 192-record LDS ring) and the header/finalize plumbing."""

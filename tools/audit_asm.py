@@ -32,14 +32,28 @@ def regs_of(text):
     return out
 
 
+UNITS = ("hhv_kernels.hip", "hhv_kernels_w32.hip", "hhv_kernels_w16.hip")
+
+
 def compile_s(workdir):
-    src = os.path.join(ROOT, "hh-suite_amd", "csrc", "hhv_kernels.hip")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-           "-fvisibility=hidden", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(ROOT, "hh-suite_amd", "csrc"), "--cuda-device-only", "-S", src, "-o",
-           os.path.join(workdir, "hhv_kernels.s")]
-    subprocess.check_call(cmd, cwd=workdir)
-    return os.path.join(workdir, "hhv_kernels.s")
+    """the instantiation units of hhv_stream_kernel (64, 32 and 16 lanes per systolic array) -> one concatenated .s"""
+    procs = []
+    for u in UNITS:
+        src = os.path.join(ROOT, "hh-suite_amd", "csrc", u)
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+               "-fvisibility=hidden", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(ROOT, "hh-suite_amd", "csrc"), "--cuda-device-only", "-S", src, "-o",
+               os.path.join(workdir, u + ".s")]
+        procs.append(subprocess.Popen(cmd, cwd=workdir, stderr=subprocess.DEVNULL))
+    for p in procs:
+        if p.wait() != 0:
+            raise SystemExit("hipcc failed")
+    out = os.path.join(workdir, "hhv_kernels_all.s")
+    with open(out, "w") as f:
+        for u in UNITS:
+            f.write(open(os.path.join(workdir, u + ".s")).read())
+            f.write("\n")
+    return out
 
 
 def functions(lines):
