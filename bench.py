@@ -529,7 +529,10 @@ def next_rows():
         import bench_mac
         r = bench_mac.run(500, 300, 300, 8)
         out["N4_mac_realign"] = {"hits": r["n_hits"], "Lq": r["Lq"], "Lt": r["Lt"], "kernels_ms": r["gpu_kernels_ms"],
-                                 "end_to_end_ms": r["gpu_wall_ms_incl_host_masks"], "hits_per_s": r["gpu_hits_per_s"],
+                                 "end_to_end_ms_host_staged_profiles": r["gpu_wall_ms_incl_host_masks"],
+                                 "end_to_end_ms_resident_set": r["resident_set"]["runner_ms"],
+                                 "resident_identical_to_staged": r["resident_set"]["identical_to_staged"],
+                                 "hits_per_s": r["gpu_hits_per_s"],
                                  "reference_hits_per_s_1core": r.get("ref_cpu_hits_per_s_1core"),
                                  "mismatches_vs_reference": r.get("mismatches_vs_reference"), "checked": r.get("checked")}
     except Exception as e:

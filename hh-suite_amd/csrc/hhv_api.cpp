@@ -174,6 +174,7 @@ void hhv_destroy(hhv_ctx* c) {
   }
   if (c->mac_side.fork) (void)hipEventDestroy((hipEvent_t)c->mac_side.fork);
   if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
+  if (c->mac_pinned_out) (void)hipHostFree(c->mac_pinned_out);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -70,6 +70,8 @@ struct hhv_ctx {
   bool mac_side_ready = false;
   void* mac_pinned = nullptr;                          // pinned staging buffer of the MAC inputs
   size_t mac_pinned_bytes = 0;
+  void* mac_pinned_out = nullptr;                      // pinned buffer of the MAC paths coming back (recycled through hhv_macset_free)
+  size_t mac_pinned_out_bytes = 0;
   void* mac_cache = nullptr;                           // one recycled device block of the MAC realignment
   size_t mac_cache_bytes = 0;
   float* d_ss_table = nullptr;                         // ssw * table of the current mode

@@ -28,10 +28,20 @@ struct SsRecords {
 };
 
 // A template of the process-wide cache: raw columns on the device + what a Hit needs to know about the template
+// Which database entry a cached template came from: the ffindex data block it lives in and its place there.  Entry name and
+// sequence length alone do not identify a template when a process opens several databases (or a rebuilt one).
+struct EntryIdentity {
+  const void* data;  // FFindexDatabase::db_data of the hhm / a3m / ca3m index that holds the entry (NULL: a file entry)
+  uint64_t offset, length;
+  EntryIdentity() : data(NULL), offset(0), length(0) {}
+  bool operator==(const EntryIdentity& o) const { return data == o.data && offset == o.offset && length == o.length; }
+};
+
 struct CachedTemplate {
   hhv_rawset* raw;
   int32_t index;
   int L;
+  EntryIdentity id;
   int ss_pair_mode;
   // The entry is an .hhm TEXT of a database (not an alignment): reading it does not depend on the sequence-weighting
   // argument of getTemplateHMM, so the realign stage (which reads with par.wg, the Viterbi stage with 1) may use it too.
@@ -54,8 +64,11 @@ struct TemplateCache {
   std::unordered_map<std::string, CachedTemplate> map;
   // what the prototypes depend on besides the template (src/hhhit.cpp:255-256,289-320)
   int nseqdis, ssm, q_has_pred, q_has_dssp;
+  // ... and what reading a template from an ALIGNMENT depends on (HHEntry::getTemplateHMM, src/hhdatabase.cpp:299-460): a
+  // change empties the cache like a change of nseqdis does
+  uint64_t read_param_hash;
   TemplateCache() : ctx(NULL), device_id(0), owner(0), calls(0), active(0), enabled(true), max_columns(0), columns(0), nseqdis(-1),
-                    ssm(-1), q_has_pred(-1), q_has_dssp(-1) {
+                    ssm(-1), q_has_pred(-1), q_has_dssp(-1), read_param_hash(0) {
     const char* e = getenv("HHV_TEMPLATE_CACHE");
     enabled = !(e && atoi(e) == 0);
     const char* g = getenv("HHV_TEMPLATE_CACHE_GB");
@@ -76,6 +89,19 @@ struct TemplateCache {
 inline TemplateCache& cache() {
   static TemplateCache c;
   return c;
+}
+
+// FNV-1a over the parameters that shape a template read from an a3m / ca3m alignment or with a different size limit
+inline uint64_t read_parameters_hash(const Parameters& par, float qsc) {
+  uint64_t h = 1469598103934665603ull;
+  const int iv[] = {par.M_template, par.Mgaps, par.max_seqid_db, par.coverage_db, par.qid_db, par.Ndiff_db, par.maxres, par.maxcol,
+                    par.maxseq, (int)par.mark, (int)par.cons, (int)par.showcons};
+  const float fv[] = {qsc, par.qsc_db};
+  const unsigned char* b = (const unsigned char*)iv;
+  for (size_t k = 0; k < sizeof(iv); ++k) h = (h ^ b[k]) * 1099511628211ull;
+  b = (const unsigned char*)fv;
+  for (size_t k = 0; k < sizeof(fv); ++k) h = (h ^ b[k]) * 1099511628211ull;
+  return h;
 }
 
 inline std::string cache_key(HHEntry* e) {

@@ -44,6 +44,7 @@
 // Errors follow the reference's convention at this layer: HH_LOG(ERROR) + exit(code) (src/hhsearch.h:6).
 #include <sys/time.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -53,6 +54,7 @@
 #include "hhviterbirunner.h"
 #include "hhviterbi_hip.h"
 #include "hhv_template_cache.h"
+#include "hhv_sidecar.h"
 
 #ifdef OPENMP
 #include <omp.h>
@@ -72,8 +74,8 @@ struct PhaseTimer {
   bool on;
   double t_last;
   double acc[N];
-  size_t cached, fresh, host_prepared;
-  PhaseTimer() : on(getenv("HHV_DROPIN_TIMING") != NULL), t_last(now()), cached(0), fresh(0), host_prepared(0) {
+  size_t cached, fresh, host_prepared, sidecar;
+  PhaseTimer() : on(getenv("HHV_DROPIN_TIMING") != NULL), t_last(now()), cached(0), fresh(0), host_prepared(0), sidecar(0) {
     for (int k = 0; k < N; ++k) acc[k] = 0;
   }
   static double now() {
@@ -88,9 +90,9 @@ struct PhaseTimer {
   }
   ~PhaseTimer() {
     if (on)
-      fprintf(stderr, "hhviterbirunner_hip: templates %zu cached + %zu read (+ %zu host-prepared); read %.3f s, upload %.3f s, "
+      fprintf(stderr, "hhviterbirunner_hip: templates %zu cached + %zu read, %zu of them from the sidecar (+ %zu host-prepared); read %.3f s, upload %.3f s, "
               "device prepare %.3f s, masks %.3f s, align+hits %.3f s, paths+Hit %.3f s, other %.3f s\n",
-              cached, fresh, host_prepared, acc[READ], acc[UPLOAD], acc[PREPARE], acc[MASKS], acc[ALIGN], acc[PATHS], acc[OTHER]);
+              cached, fresh, sidecar, host_prepared, acc[READ], acc[UPLOAD], acc[PREPARE], acc[MASKS], acc[ALIGN], acc[PATHS], acc[OTHER]);
   }
 };
 
@@ -136,6 +138,89 @@ bool entry_is_hh_text(const std::vector<HHblitsDatabase*>& dbs, char* name) {
       return false;
   }
   return found;
+}
+
+// The hhm ffindex database that holds this entry as an HHM text (and no database holds it as anything else): the
+// entries whose parse result the sidecar may stand in for.  *fe = its ffindex entry (offset / length = the validity key).
+FFindexDatabase* hh_text_database(const std::vector<HHblitsDatabase*>& dbs, char* name, ffindex_entry_t** fe) {
+  if (!entry_is_hh_text(dbs, name)) return NULL;
+  for (size_t d = 0; d < dbs.size(); ++d) {
+    HHblitsDatabase* db = dbs[d];
+    if (!db || !db->hhm_database) continue;
+    ffindex_entry_t* e = ffindex_get_entry_by_name(db->hhm_database->db_index, name);
+    if (e) {
+      *fe = e;
+      return db->hhm_database;
+    }
+  }
+  return NULL;
+}
+
+// the database entry behind a name, in the order HHblitsDatabase::getEntriesFromNames looks (src/hhdatabase.cpp:198-215)
+hhv_dropin::EntryIdentity identify_entry(const std::vector<HHblitsDatabase*>& dbs, char* name) {
+  hhv_dropin::EntryIdentity id;
+  for (size_t d = 0; d < dbs.size(); ++d) {
+    HHblitsDatabase* db = dbs[d];
+    if (!db) continue;
+    FFindexDatabase* candidates[3] = {db->hhm_database, db->use_compressed ? db->ca3m_database : NULL, db->a3m_database};
+    for (int c = 0; c < 3; ++c) {
+      if (!candidates[c]) continue;
+      ffindex_entry_t* e = ffindex_get_entry_by_name(candidates[c]->db_index, name);
+      if (e) {
+        id.data = candidates[c]->db_data;
+        id.offset = (uint64_t)e->offset;
+        id.length = (uint64_t)e->length;
+        return id;
+      }
+    }
+  }
+  return id;
+}
+
+// one Sidecar object per hhm data file of the process
+hhv_dropin::Sidecar* sidecar_of(FFindexDatabase* fdb) {
+  static std::mutex mu;
+  static std::map<std::string, hhv_dropin::Sidecar*> open_files;
+  std::lock_guard<std::mutex> lock(mu);
+  const std::string path = hhv_dropin::sidecar_path(fdb->data_filename);
+  std::map<std::string, hhv_dropin::Sidecar*>::iterator it = open_files.find(path);
+  if (it != open_files.end()) return it->second;
+  hhv_dropin::Sidecar* sc = new hhv_dropin::Sidecar(path);
+  open_files[path] = sc;
+  return sc;
+}
+
+// what Hit::initHitFromHMM and HMM::computeScoreSSMode read from a template HMM, from a sidecar record into the
+// thread's scratch HMM (the sequences of its previous template are released the way HMM::Read does, src/hhhmm.cpp:212-226)
+void hmm_header_from_sidecar(const hhv_dropin::SidecarRecord& r, HMM* t) {
+  // (dont_delete_seqs, private, is false for these scratch objects: nothing in v3.3.0 sets it, src/hhhit.cpp:205)
+  for (int k = 0; k < t->n_seqs; k++) delete[] t->sname[k];
+  for (int k = 0; k < t->n_seqs; k++) delete[] t->seq[k];
+  t->L = r.L;
+  t->Neff_HMM = r.neff_hmm;
+  t->n_seqs = r.n_seqs;
+  t->n_display = r.n_display;
+  t->N_in = t->N_filtered = 0;
+  t->ncons = r.ncons;
+  t->nfirst = r.nfirst;
+  t->nss_dssp = r.nss_dssp;
+  t->nsa_dssp = r.nsa_dssp;
+  t->nss_pred = r.nss_pred;
+  t->nss_conf = r.nss_conf;
+  t->lamda = t->mu = 0.0;
+  strmcpy(t->name, r.name.c_str(), NAMELEN - 1);
+  strmcpy(t->longname, r.longname.c_str(), DESCLEN - 1);
+  strmcpy(t->fam, r.fam.c_str(), NAMELEN - 1);
+  strmcpy(t->sfam, r.sfam.c_str(), NAMELEN - 1);
+  strmcpy(t->fold, r.fold.c_str(), NAMELEN - 1);
+  strmcpy(t->cl, r.cl.c_str(), NAMELEN - 1);
+  strmcpy(t->file, r.file.c_str(), NAMELEN - 1);
+  for (int k = 0; k < r.n_seqs; ++k) {
+    t->sname[k] = new char[r.sname[k].size() + 1];
+    strcpy(t->sname[k], r.sname[k].c_str());
+    t->seq[k] = new char[r.seq[k].size() + 1];
+    strcpy(t->seq[k], r.seq[k].c_str());
+  }
 }
 
 // a template of THIS search: where its prepared columns are on the device
@@ -424,6 +509,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
   search.threads = threads;
 
   bool device_prepare = tc.enabled && hhv_dropin::device_prepare_covers(par);
+  const bool use_sidecar = device_prepare && hhv_dropin::sidecar_enabled();
   float pb0[20];  // the background the caller hands in; HMM::Read overwrites pb with the NULL line of every file it reads
   memcpy(pb0, pb, sizeof(pb0));
   hhv_prep_params prep = hhv_dropin::prepare_params(par, pb0, R);
@@ -432,6 +518,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
   // has to be read
   std::vector<HMM*> t_hmm(threads, (HMM*)NULL);
   std::vector<HMMSimd*> t_simd(threads, (HMMSimd*)NULL);
+  std::vector<HMM*> t_hdr(threads, (HMM*)NULL);  // header-only HMMs of the templates that come from the sidecar
 
   std::vector<hhv_tset*> search_sets;              // prepared sets of this search, freed at the end
   std::unordered_map<HHEntry*, ResidentTemplate> resident;   // an entry listed twice is the same template
@@ -441,13 +528,15 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
   if (device_prepare) {  // the prototypes of the cache are valid for one (nseqdis, ssm, query ss presence) only
     std::lock_guard<std::mutex> lock(tc.device);
     const int qp = q->nss_pred >= 0, qd = q->nss_dssp >= 0;
-    if (tc.nseqdis != par.nseqdis || tc.ssm != par.ssm || tc.q_has_pred != qp || tc.q_has_dssp != qd) {
+    const uint64_t rph = hhv_dropin::read_parameters_hash(par, qsc);
+    if (tc.nseqdis != par.nseqdis || tc.ssm != par.ssm || tc.q_has_pred != qp || tc.q_has_dssp != qd || tc.read_param_hash != rph) {
       if (tc.active == 0) {
         tc.clear();
         tc.nseqdis = par.nseqdis;
         tc.ssm = par.ssm;
         tc.q_has_pred = qp;
         tc.q_has_dssp = qd;
+        tc.read_param_hash = rph;
       } else {
         device_prepare = false;  // a concurrent search of another kind is using the cache: this one prepares on the host
       }
@@ -484,7 +573,9 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
             std::lock_guard<std::mutex> lock(tc.device);
             for (unsigned int k = 0; k < cn; ++k) {
               std::unordered_map<std::string, CachedTemplate>::const_iterator it = tc.map.find(cache_key(ent[k]));
-              if (it != tc.map.end()) cached[k] = &it->second;  // std::unordered_map never moves its elements
+              // same name and length but another database entry (two databases, a rebuilt one): read it again, the new
+              // upload takes the slot
+              if (it != tc.map.end() && it->second.id == identify_entry(databases, ent[k]->getName())) cached[k] = &it->second;  // std::unordered_map never moves its elements
               else to_read.push_back(k);
             }
           } else {
@@ -495,21 +586,52 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
           // ---- read the others with the reference's code (:144), one template per iteration; no device lock ----
           std::vector<HostTemplate> host(to_read.size());
           const int n_read = (int)to_read.size();
+          std::vector<char> from_sidecar(to_read.size(), 0);
+          std::vector<hhv_dropin::Sidecar*> touched(to_read.size(), (hhv_dropin::Sidecar*)NULL);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
           for (int r = 0; r < n_read; ++r) {
             int tid = 0;
 #ifdef OPENMP
             tid = omp_get_thread_num();
 #endif
+            const unsigned int k = to_read[r];
+            HostTemplate& h = host[r];
+            int format_tmp = 0;
+            char wg = 1;
+            // the binary sidecar of the database first (hhv_sidecar.h): an HHM text that was parsed once - by any process -
+            // is not parsed again
+            ffindex_entry_t* fe = NULL;
+            FFindexDatabase* fdb = use_sidecar ? hh_text_database(databases, ent[k]->getName(), &fe) : NULL;
+            hhv_dropin::Sidecar* sc = fdb ? sidecar_of(fdb) : NULL;
+            hhv_dropin::SidecarRecord rec;
+            const uint64_t text_hash = sc ? hhv_dropin::sidecar_text_hash(ffindex_get_data_by_entry(fdb->db_data, fe), fe->length) : 0;
+            if (sc && sc->find(ent[k]->getName(), text_hash, (uint64_t)fe->length, par.nseqdis, pb0, &rec) &&
+                rec.L + 2 <= par.maxres && rec.n_seqs <= MAXSEQDIS) {
+              // a header-only HMM: the full-size scratch HMM (par.maxres rows, ~80 000 allocations) is only built by a
+              // thread that really has to parse
+              if (!t_hdr[tid]) t_hdr[tid] = new HMM(MAXSEQDIS, 2);
+              HMM* t = t_hdr[tid];
+              hmm_header_from_sidecar(rec, t);
+              t->entry = ent[k];
+              h.raw = h.hh_text = true;
+              h.L = rec.L;
+              h.ss_pair_mode = HMM::computeScoreSSMode(q, t);
+              hit0[k].initHitFromHMM(q, t, par.nseqdis, par.ssm);  // :40
+              h.p.swap(rec.f);
+              h.tr.swap(rec.tr);
+              h.neff.swap(rec.neff);
+              h.neff_hmm = rec.neff_hmm;
+              h.ss.pred.swap(rec.pred);
+              h.ss.conf.swap(rec.conf);
+              h.ss.dssp.swap(rec.dssp);
+              from_sidecar[r] = 1;
+              continue;
+            }
             if (!t_hmm[tid]) {
               t_hmm[tid] = new HMM(MAXSEQDIS, par.maxres);
               t_simd[tid] = new HMMSimd(par.maxres);
             }
             HMM* t = t_hmm[tid];
-            const unsigned int k = to_read[r];
-            HostTemplate& h = host[r];
-            int format_tmp = 0;
-            char wg = 1;
             ent[k]->getTemplateHMM(par, wg, qsc, format_tmp, pb, S, Sim, t);
             t->entry = ent[k];
             h.raw = device_prepare && format_tmp == 0 && memcmp(pb, pb0, sizeof(pb0)) == 0 && t->L >= 1 && t->L <= 0xFFFF;
@@ -533,11 +655,57 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 h.neff[(size_t)i * 3 + 2] = t->Neff_D[i];
               }
               h.neff_hmm = t->Neff_HMM;
+              if (sc && h.hh_text) {  // parsed here for the first time: leave it in the sidecar for the next process
+                rec.ff_hash = text_hash;
+                rec.ff_length = (uint64_t)fe->length;
+                rec.nseqdis = par.nseqdis;
+                memcpy(rec.null_pb, pb0, sizeof(rec.null_pb));
+                rec.L = t->L;
+                rec.n_seqs = t->n_seqs;
+                rec.n_display = t->n_display;
+                rec.ncons = t->ncons;
+                rec.nfirst = t->nfirst;
+                rec.nss_dssp = t->nss_dssp;
+                rec.nsa_dssp = t->nsa_dssp;
+                rec.nss_pred = t->nss_pred;
+                rec.nss_conf = t->nss_conf;
+                rec.neff_hmm = t->Neff_HMM;
+                rec.entry_name = ent[k]->getName();
+                rec.name = t->name;
+                rec.longname = t->longname;
+                rec.fam = t->fam;
+                rec.sfam = t->sfam;
+                rec.fold = t->fold;
+                rec.cl = t->cl;
+                rec.file = t->file;
+                rec.sname.resize(t->n_seqs);
+                rec.seq.resize(t->n_seqs);
+                for (int x = 0; x < t->n_seqs; ++x) {
+                  rec.sname[x] = t->sname[x];
+                  rec.seq[x] = t->seq[x];
+                }
+                rec.f = h.p;
+                rec.tr = h.tr;
+                rec.neff = h.neff;
+                rec.pred = h.ss.pred;
+                rec.conf = h.ss.conf;
+                rec.dssp = h.ss.dssp;
+                sc->add(rec);
+                touched[r] = sc;
+              }
             } else {
               PrepareTemplateHMM(par, q, t, format_tmp, false, pb, R);  // :147
               t_simd[tid]->MapHMMVector(one);
               lane0_to_profile(t_simd[tid], t, &h.p, &h.tr, &h.ss);
             }
+          }
+          {  // what was parsed for the first time goes to the sidecar files: one append per file and search
+            std::vector<hhv_dropin::Sidecar*> files;
+            for (int r = 0; r < n_read; ++r) {
+              timer.sidecar += from_sidecar[r];
+              if (touched[r] && std::find(files.begin(), files.end(), touched[r]) == files.end()) files.push_back(touched[r]);
+            }
+            for (size_t x = 0; x < files.size(); ++x) files[x]->flush();
           }
           timer.lap(PhaseTimer::READ);
 
@@ -594,6 +762,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 if (ct.raw) ct.proto.Delete();  // the same key twice (two searches read it concurrently): the later upload wins
                 ct.raw = rs;
                 ct.index = x;
+                ct.id = identify_entry(databases, ent[raw_k[x]]->getName());
                 slot[x] = &ct;
                 cached[raw_k[x]] = &ct;
               }
@@ -758,6 +927,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
   for (int k = 0; k < threads; ++k) {
     delete t_simd[k];
     delete t_hmm[k];
+    delete t_hdr[k];
   }
   timer.lap(PhaseTimer::OTHER);
   std::vector<Hit> result;

@@ -316,3 +316,55 @@ def test_hhblits_omp_on_an_alignment_database(tmp_path):
         assert sorted(cpu[kind]) == sorted(hip[kind]) and len(cpu[kind]) == 6
         for name in cpu[kind]:
             assert cpu[kind][name] == hip[kind][name], (kind, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("case", ["plain", "ss"])
+def test_sidecar_replaces_the_text_parse_in_the_next_process(tmp_path, case):
+    """SURVEY.md 8f N1 in the product path: the first hhsearch over a database leaves <db>_hhm.ffdata.hhvside behind
+    (hh-suite_amd/dropin/hhv_sidecar.h); the next PROCESS takes every template from it - no HMM::Read - and writes the same
+    result files as the reference.  A sidecar whose entries do not match the database any more is ignored."""
+    if case == "plain":
+        q, t, names = make_db(610, 200, 80, 60, 260)
+    else:
+        q, t, names = make_db(611, 130, 40, 150, 150, ss_every=1, query_ss=("pred", "conf"))
+    base, qpath = build_db(str(tmp_path), q, t, names, 4)
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "2"]
+    side = base + "_hhm.ffdata.hhvside"
+    cpu = run_app("hhsearch_cpu", args, str(tmp_path / "cpu"))
+
+    def run_hip(tag, env_extra=None):
+        env = dict(os.environ, HHV_DROPIN_TIMING="1")
+        env.update(env_extra or {})
+        cmd = [os.path.join(BIN, "hhsearch_hip")] + args + ["-o", str(tmp_path / (tag + ".hhr")), "-scores",
+                                                             str(tmp_path / (tag + ".scores")), "-atab", str(tmp_path / (tag + ".atab")), "-v", "1"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        out = {}
+        for ext in ("hhr", "scores", "atab"):
+            lines = open(str(tmp_path / (tag + "." + ext))).read().splitlines()
+            out[ext] = [l for l in lines if not l.startswith(("Date", "Command", "FILE", "COMM"))]
+        timing = [l for l in r.stderr.decode().splitlines() if l.startswith("hhviterbirunner_hip: templates")]
+        return out, timing[0]
+
+    off, line = run_hip("off", {"HHV_SIDECAR": "0"})
+    assert not os.path.exists(side) and " 0 of them from the sidecar" in line
+    compare_outputs(cpu, off)
+    cold, line = run_hip("cold")
+    assert os.path.exists(side) and os.path.getsize(side) > 1000 and " 0 of them from the sidecar" in line
+    compare_outputs(cpu, cold)
+    size_after_first = os.path.getsize(side)
+    warm, line = run_hip("warm")
+    n = len(names)
+    assert "%d read, %d of them from the sidecar" % (n, n) in line, line
+    compare_outputs(cpu, warm)
+    assert os.path.getsize(side) == size_after_first, "nothing new to append"
+    # the database is rebuilt with one template changed: its record is stale (the entry moved or changed length), every
+    # other record whose entry kept offset and length stays valid
+    t2 = list(t)
+    t2[0], t2[1] = t[1].replace(names[1].encode(), names[0].encode()), t[0].replace(names[0].encode(), names[1].encode())
+    build_db(str(tmp_path), q, t2, names, 4)
+    cpu2 = run_app("hhsearch_cpu", args, str(tmp_path / "cpu2"))
+    again, line = run_hip("again")
+    compare_outputs(cpu2, again)

@@ -55,10 +55,19 @@ def main():
         common = ["-d", base, "-nocontxt", "-premerge", "0"]
         args = ["-i", qpath, "-cpu", str(threads)] + common
         t_cpu, o_cpu = timed(run_app, "hhsearch_cpu", args, os.path.join(tmp, "c1"))
+        # one cold process each: without the binary sidecar (every template parsed from the .hhm text), the first run that
+        # writes it, and a run that finds it (hh-suite_amd/dropin/hhv_sidecar.h)
+        os.environ["HHV_SIDECAR"] = "0"
         t_hip, o_hip = timed(run_app, "hhsearch_hip", args, os.path.join(tmp, "h1"))
+        os.environ["HHV_SIDECAR"] = "1"
+        t_w, o_w = timed(run_app, "hhsearch_hip", args, os.path.join(tmp, "h1w"))
+        t_s, o_s = timed(run_app, "hhsearch_hip", args, os.path.join(tmp, "h1s"))
         # with several threads the reference adds equal-score hits in thread order: compare the sorted hit lines
-        same = sorted(o_cpu["scores"]) == sorted(o_hip["scores"])
-        out["hhsearch_one_query"] = {"reference_s": round(t_cpu, 2), "replaced_units_s": round(t_hip, 2), "same_scores_file": same}
+        same = sorted(o_cpu["scores"]) == sorted(o_hip["scores"]) == sorted(o_w["scores"]) == sorted(o_s["scores"])
+        out["hhsearch_one_query"] = {"reference_s": round(t_cpu, 2), "replaced_units_s": round(t_hip, 2),
+                                     "replaced_units_writing_sidecar_s": round(t_w, 2), "replaced_units_with_sidecar_s": round(t_s, 2),
+                                     "sidecar_bytes": os.path.getsize(base + "_hhm.ffdata.hhvside"), "same_scores_file": same}
+        os.environ["HHV_SIDECAR"] = "0"
         qbase = os.path.join(tmp, "queries")
         write_ffindex(qbase, [("q%02d" % k, q.rstrip(b"\n")) for k, q in enumerate(queries)])
         args = ["-i", qbase, "-cpu", str(min(threads, nq))] + common

@@ -45,9 +45,23 @@ def run(n=500, Lq=300, Lt=300, sample=16):
     import ctypes
     t3 = (ctypes.c_double * 3)()
     capi.load_runner().hhvr_mac_last_timing(t3)
+    # the same hits with the profiles AND the Viterbi alignments taken from the resident template set the Viterbi stage just
+    # searched (hhv_mac_realign_tset, inputs without a path): only the linear transitions cross PCIe
+    res_hits = [(k, 1, h[2], h[3], h[4], h[5], -1, None, None) for k, h in enumerate(hits)]
+    capi.runner_mac_realign(c, qp, q_lin, None, t_lins[:4], res_hits[:4], resident=ts)
+    t0 = time.perf_counter()
+    r_sc, r_re, r_i, r_j, r_s, r_S, r_P = capi.runner_mac_realign(c, qp, q_lin, None, t_lins, res_hits, resident=ts)
+    wall_res = time.perf_counter() - t0
+    kms_res = c.last_kernel_ms()
+    t3r = (ctypes.c_double * 3)()
+    capi.load_runner().hhvr_mac_last_timing(t3r)
+    same = bool(np.array_equal(sc, r_sc) and re.tobytes() == r_re.tobytes() and np.array_equal(o_i, r_i) and o_P.tobytes() == r_P.tobytes())
     cells = float(Lq) * float(sum(lens))
     out = {"n_hits": n, "Lq": Lq, "Lt": Lt if Lt > 0 else "lognormal(250, 0.7) in 40..1800, max %d" % max(lens), "gpu_kernels_ms": round(kms, 3), "gpu_wall_ms_incl_host_masks": round(wall * 1e3, 2),
            "host_ms_masks_realign_fetch": [round(v, 2) for v in t3],
+           "resident_set": {"gpu_kernels_ms": round(kms_res, 3), "gpu_wall_ms": round(wall_res * 1e3, 2),
+                            "runner_ms_inputs_realign_fetch": [round(v, 2) for v in t3r], "runner_ms": round(sum(t3r), 2),
+                            "identical_to_staged": same},
            "gpu_hits_per_s": n / (kms * 1e-3), "gpu_cells_per_s": cells / (kms * 1e-3),
            "mean_nsteps": float(sc[:, 0].mean()), "mean_sum_of_probs": float(re[:, 1].mean())}
     if sample:
