@@ -102,6 +102,14 @@ struct LdsColumn {
                    : "=&v"(v6), "=&v"(v5), "=&v"(qa0), "=&v"(qa1), "=&v"(qa2) : "v"(rec_addr), "v"(ql_addr) : "memory");
     }
   }
+  // software-pipelined head (score-only variants): the head of step s+1 is requested at the top of step s and waited for
+  // at its end, so its LDS round trip lies under the step's arithmetic instead of in front of it
+  static __device__ __forceinline__ void head_issue(uint32_t addr, v4f& n6, v4f& n5) {
+    asm volatile("ds_read_b128 %0, %2 offset:96\n\tds_read_b128 %1, %2 offset:80" : "=&v"(n6), "=&v"(n5) : "v"(addr) : "memory");
+  }
+  static __device__ __forceinline__ void head_wait(v4f& n6, v4f& n5) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n6), "+v"(n5));
+  }
   __device__ __forceinline__ int32_t meta() const {
     const float w = v6.w;  // (bit_cast applied to the element expression itself reads element 0 with this clang)
     return __builtin_bit_cast(int32_t, w);
@@ -258,26 +266,45 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // chunks 0 and 1 have landed, the lane's own ds_writes above are done (LDS executes a wave's operations in order)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
+  // PF: the plain score-only variants fetch the head of the NEXT step while the current one is computed (8 more VGPRs;
+  // the backtrace / SS variants have none to spare).  The ring bookkeeping then runs one step early: chunk c must have
+  // landed before step C c - 1 requests the first record of it.
+  constexpr bool PF = !BT && !CELLOFF && !SS && !MULTI && W == LANES;
+  constexpr int LEAD = PF ? 1 : 0;
+  auto record_addr = [&](int step) -> uint32_t {
+    const int rr = step - g;
+    if (W == LANES) return ring_addr + (uint32_t)(rr & (RING_RECS - 1)) * (REC_DW * 4);
+    // slot (r / C) & 3 of the ring, record r % C of this array's section of the slot
+    const uint32_t t = (uint32_t)rr & (4 * C - 1);
+    return ring_addr + (t / C) * (CHUNK_RECS * REC_DW * 4) + (t & (C - 1)) * (REC_DW * 4);
+  };
+  v4f n6, n5;
+  if (PF) {
+    LdsColumn<R, QL>::head_issue(record_addr(0), n6, n5);
+    LdsColumn<R, QL>::head_wait(n6, n5);
+  }
+
   for (int s = 0; s < Mmax + W - 1; ++s) {
-    if ((s & (C - 1)) == 0 && s > 0) {
-      // chunk c = s/C was issued C steps ago: make sure it has landed, then refill the slot that held chunk c-3 (its
-      // last reader, lane W-1, finished at step C(c-2)+2(W-1) < C c) with chunk c+1.  The live window [s-W+1, s] spans
+    if (((s + LEAD) & (C - 1)) == 0 && s + LEAD > 0) {
+      // chunk c = (s + LEAD)/C was issued C steps ago: make sure it has landed, then refill the slot that held chunk c-3
+      // (its last reader, lane W-1, finished at step C(c-2)+2(W-1) < C c - LEAD) with chunk c+1.  The live window [s-W+1, s] spans
       // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
       // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int c = s / C;
+      const int c = (s + LEAD) / C;
       if (c + 1 < nchunks_max) load_chunk<W>(records, rb_a, nch_a, c + 1, ring, lane);
     }
     const int r = s - g;
-    const bool active = (r >= 0) && (r < M);
+    const bool active = (uint32_t)r < (uint32_t)M;  // 0 <= r < M in one compare
 
-    if (W == LANES) {
-      col.rec_addr = ring_addr + (uint32_t)(r & (RING_RECS - 1)) * (REC_DW * 4);
-    } else {  // slot (r / C) & 3 of the ring, record r % C of this array's section of the slot
-      const uint32_t t = (uint32_t)r & (4 * C - 1);
-      col.rec_addr = ring_addr + (t / C) * (CHUNK_RECS * REC_DW * 4) + (t & (C - 1)) * (REC_DW * 4);
+    col.rec_addr = record_addr(s);
+    if (PF) {
+      col.v6 = n6;  // landed: waited for at the end of the previous step
+      col.v5 = n5;
+      LdsColumn<R, QL>::head_issue(record_addr(s + 1), n6, n5);
+    } else {
+      col.head();
     }
-    col.head();
     const int32_t meta = col.meta();
 
     // hand-off from lane g-1 (full EXEC here); lane 0 of an array takes the DP boundary row 0, or - in later passes of
@@ -305,8 +332,14 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     in.IM = dpp_shr1<W>(bnd.IM, st.IM[R - 1], head_lane);
     in.DG = dpp_shr1<W>(bnd.DG, st.DG[R - 1], head_lane);
     in.MI = dpp_shr1<W>(bnd.MI, st.MI[R - 1], head_lane);
-    in.fs = dpp_shr1<W>(bnd.fs, st.fs, head_lane);
-    in.fpos = dpp_shr1<W>(bnd.fpos, st.fpos, head_lane);
+    // the finalized best only matters to a lane that stands on a header record: the two moves are skipped (wave-uniform
+    // branch, full EXEC inside) in the ~4 of 5 steps in which no lane does
+    in.fs = NEG_MAX;
+    in.fpos = 0;
+    if (MULTI || __builtin_amdgcn_ballot_w64(meta < 0) != 0) {  // (the multi-pass variants measured slower with the branch)
+      in.fs = dpp_shr1<W>(bnd.fs, st.fs, head_lane);
+      in.fpos = dpp_shr1<W>(bnd.fpos, st.fpos, head_lane);
+    }
 
     if (active) {
       if (meta < 0) {
@@ -344,6 +377,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         }
       }
     }
+    if (PF) LdsColumn<R, QL>::head_wait(n6, n5);  // full EXEC again: the head of step s+1 is in n6 / n5 from here on
   }
 }
 

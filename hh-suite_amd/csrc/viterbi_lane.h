@@ -113,7 +113,15 @@ HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R) {
 // src/hhutil-inl.h:509-541, one rounding per operation
 HHV_DEV float log2f4(float x) {
   const uint32_t i = f2bits(x);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // e = float(biased exponent - 127) without v_bfe / v_cvt (half-rate issue on gfx950, profiles/r2_valu_ubench.txt): the
+  // exponent field is dropped into the mantissa of 2^23 - bits 0x4B000000 | E are the float 8388608 + E exactly - and
+  // 8388608 + 127 is subtracted; every step is exact, so e is the same float the int -> float conversion gives
+  // (and, shift, or, sub: four full-rate VOP2 operations).
+  const float e = bits2f(((i & 0x7F800000u) >> 23) | 0x4B000000u) - 8388735.0f;
+#else
   const float e = (float)((int32_t)((i & 0x7F800000u) >> 23) - 127);
+#endif
   const float m = bits2f((i & 0x007FFFFFu) | 0x3F800000u);
   float p = -0.107254423828329604454f * m;
   p = p + 0.688243882994381274313f;

@@ -9,6 +9,15 @@ for p in (os.path.join(ROOT, "hh-suite_amd"), os.path.join(ROOT, "oracle"), ROOT
         sys.path.insert(0, p)
 
 
+# torch first: the PyTorch-ROCm wheel carries its own HIP runtime; if libhhviterbi_hip.so (linked against /opt/rocm) brings
+# up HIP before torch is imported, the process ends up with two runtimes and torch reports "No HIP GPUs are available".
+# Imported here, torch's runtime is the one both use (bench.py imports torch first for the same reason).
+try:
+    import torch  # noqa: F401
+except Exception:  # a box without torch can still run the C-ABI tests
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
