@@ -1,6 +1,8 @@
 // hhv_api_db.cpp -- C ABI of the binary packed template database.
 #include "hhv_api_common.h"
 
+#include <sys/stat.h>
+
 using namespace hhv;
 using hhv::api::dfree;
 using hhv::api::fail;
@@ -63,6 +65,14 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
     fclose(f);
     return fail(HHV_E_ARG, "hhv_db_open: %s is not a packed template database", path);
   }
+  // the header is checked against the file size before anything is allocated from it
+  struct stat st;
+  if (fstat(fileno(f), &st) != 0 || h.n_records < (int64_t)h.n * 2 + 1 ||
+      (int64_t)st.st_size != (int64_t)sizeof(DbHeader) + (int64_t)h.n * 4 + h.n_records * REC_DW * 4) {
+    fclose(f);
+    return fail(HHV_E_ARG, "hhv_db_open: %s: header (%d templates, %lld records) does not match the file size", path, h.n,
+                (long long)h.n_records);
+  }
   std::vector<int32_t> L((size_t)h.n);
   if (fread(L.data(), sizeof(int32_t), L.size(), f) != L.size()) {
     fclose(f);
@@ -81,13 +91,37 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
   if (rc == HHV_OK) {
     ts->owns_records = true;
     (void)hipMemset(ts->d_records + (size_t)ts->n_records * REC_DW, 0, (size_t)STREAM_PAD_RECS * REC_DW * sizeof(float));
-    const size_t slab = (64u << 20) / sizeof(float);
+    const size_t slab = (64u << 20) / sizeof(float) / REC_DW * REC_DW;  // whole records per slab
     std::vector<float> buf(slab);
     size_t left = (size_t)ts->n_records * REC_DW, off = 0;
+    // The kernel takes the template index and the template boundaries from the records themselves (it writes
+    // results[index] and resets at meta < 0), so a stale or damaged file must not reach the device: every record's meta
+    // word is checked against the length table while the slabs go by.
+    int64_t rec = 0;   // stream record index
+    int32_t tmpl = 0;  // template the record belongs to
+    int64_t next_hdr = 0;
     while (left && rc == HHV_OK) {
       const size_t m = std::min(left, slab);
       if (fread(buf.data(), sizeof(float), m, f) != m) rc = fail(HHV_E_ARG, "hhv_db_open: truncated record stream");
-      else if (hipMemcpy(ts->d_records + off, buf.data(), m * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      for (size_t r0 = 0; r0 < m && rc == HHV_OK; r0 += REC_DW, ++rec) {
+        int32_t meta, w0, w1;
+        memcpy(&meta, &buf[r0 + REC_META], 4);
+        memcpy(&w0, &buf[r0], 4);
+        memcpy(&w1, &buf[r0 + 1], 4);
+        if (rec == next_hdr) {  // header of template `tmpl` (or the terminal header)
+          const bool last = tmpl == h.n;
+          if (meta >= 0 || (last ? w0 != -1 : (w0 != tmpl || w1 != L[tmpl])))
+            rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not the header of template %d", path, (long long)rec, tmpl);
+          if (!last) next_hdr = rec + L[tmpl] + 1;
+          ++tmpl;
+        } else {
+          const int32_t j = (int32_t)(rec - (next_hdr - L[tmpl - 1] - 1));
+          if (meta < 0 || (meta & META_JMASK) != j || (((meta & META_LAST) != 0) != (j == L[tmpl - 1])))
+            rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not column %d of template %d", path, (long long)rec, j, tmpl - 1);
+        }
+      }
+      if (rc != HHV_OK) break;
+      if (hipMemcpy(ts->d_records + off, buf.data(), m * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(HHV_E_DEVICE, "hhv_db_open: H2D copy failed");
       off += m;
       left -= m;

@@ -87,3 +87,48 @@ def test_limits_are_reported_not_fatal(tmp_path):
         c.rawdb_open(bad)
     assert len(c.align(c.upload(tps, ttrs))) == 3             # still alive
     c.close()
+
+
+def test_packed_db_file_is_validated_on_open(tmp_path):
+    """hhv_db_open: a file whose records do not match its length table (stale, damaged, truncated) is refused on the host -
+    the kernel would take template indices and boundaries from those records."""
+    import numpy as np
+    from pyhhv import capi, synth
+    tps, ttrs = zip(*[synth.make_template(700 + k, 20 + 7 * k) for k in range(6)])
+    path = str(tmp_path / "db.hhvpdb")
+    capi.db_write(path, list(tps), list(ttrs))
+    Ls = [t.shape[0] - 1 for t in tps]
+    c = capi.Context(local=1)
+    qf, qtr = synth.make_query(3, 50)
+    c.set_query(qf, qtr)
+    ts = c.db_open(path, Ls)
+    good = c.align(ts)
+    ts.free()
+    raw = bytearray(open(path, "rb").read())
+    head = 64 + 4 * len(Ls)
+    rec = 112
+
+    def refused(data, what):
+        bad = str(tmp_path / "bad.hhvpdb")
+        open(bad, "wb").write(bytes(data))
+        with pytest.raises(capi.HhvError) as e:
+            c.db_open(bad, Ls)
+        assert what in str(e.value), str(e.value)
+
+    d = bytearray(raw)
+    d[head:head + 4] = np.int32(3).tobytes()                      # header of template 0 claims index 3
+    refused(d, "not the header of template 0")
+    d = bytearray(raw)
+    d[head + rec * 5 + 108:head + rec * 5 + 112] = np.int32(9).tobytes()   # column 5 claims j = 9
+    refused(d, "not column 5 of template 0")
+    d = bytearray(raw)
+    d[head + rec * (Ls[0] + 1) + 108:head + rec * (Ls[0] + 1) + 112] = np.int32(1).tobytes()   # header of template 1 turned into a column
+    refused(d, "not the header of template 1")
+    refused(raw[:-rec], "does not match the file size")
+    d = bytearray(raw)
+    d[8:12] = np.int32(1 << 30).tobytes()                          # absurd template count
+    refused(d, "does not match the file size")
+    ts = c.db_open(path, Ls)                                       # the intact file still opens and gives the same results
+    assert np.array_equal(c.align(ts).view(np.uint8), good.view(np.uint8))
+    ts.free()
+    c.close()

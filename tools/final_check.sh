@@ -1,9 +1,13 @@
+#!/bin/bash
+# what the driver runs at round end, on one box: GPU suite, default bench line, smoke; plus the side benches quoted in DESIGN.md
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-mkdir -p $OUT/prof_next
-timeout 400 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > $OUT/gpu_suite.log; cat $OUT/gpu_suite.log
-timeout 200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json
+mkdir -p $OUT
+cd $ROOT
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > $OUT/gpu_suite.log; cat $OUT/gpu_suite.log
+timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 4500 $OUT/bench_default.json
 timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-(cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_next/mac -o stats -- python $ROOT/tools/bench_mac.py 500 300 300 0 > $OUT/prof_next/mac.txt 2>&1)
-tail -1 $OUT/prof_next/mac.txt | cut -c1-400
-head -8 $OUT/prof_next/mac/stats_kernel_stats.csv
+for cfg in "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 150 --templates 100000" "--lq 150 --templates 100000 --backtrace 1" "--lq 80 --templates 100000" "--lq 300 --templates 100000 --local 1" "--lq 300 --templates 100000 --backtrace 1"; do
+  echo -n "== $cfg : "
+  timeout 200 python bench.py $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.3e cells/s, %.2f ms/step, kernel %.2f ms' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))"
+done
