@@ -157,7 +157,8 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
       for (int g = 0; g < n_groups; ++g) {
         std::unordered_map<std::string, hhv_dropin::CachedTemplate>::const_iterator it =
             tc.map.find(hhv_dropin::cache_key(alignment[g][0]->entry));
-        if (it != tc.map.end() && (par.wg == 1 || it->second.weights_free)) cached[g] = &it->second;
+        // (templates a multi-device search parked on another device are read again here, like uncached ones)
+        if (it != tc.map.end() && it->second.dev == 0 && (par.wg == 1 || it->second.weights_free)) cached[g] = &it->second;
       }
     }
   }
@@ -197,7 +198,7 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
 
   std::lock_guard<std::mutex> device_lock(tc.device);
   mac_check(hhv_dropin::ensure_context(tc), "hhv_create");
-  hhv_ctx* ctx = tc.ctx;
+  hhv_ctx* ctx = tc.slots[0].ctx;  // the realign stage works on the primary device
   if (n_read < n_groups) {
     // PrepareTemplateHMM on the device (hhv_prepare_subset), one launch per raw set, and the prepared records back in one copy
     const hhv_prep_params prep = hhv_dropin::prepare_params(par, pb, R);

@@ -39,6 +39,7 @@ struct EntryIdentity {
 
 struct CachedTemplate {
   hhv_rawset* raw;
+  int dev;  // slot of TemplateCache::slots whose device holds `raw`
   int32_t index;
   int L;
   EntryIdentity id;
@@ -48,40 +49,74 @@ struct CachedTemplate {
   bool weights_free;
   Hit proto;  // initHitFromHMM(q, t, nseqdis, ssm); its arrays live as long as the cache entry
   SsRecords ss;
-  CachedTemplate() : raw(NULL), index(0), L(0), ss_pair_mode(0), weights_free(false) {}
+  CachedTemplate() : raw(NULL), dev(0), index(0), L(0), ss_pair_mode(0), weights_free(false) {}
 };
 
-struct TemplateCache {
-  std::mutex device;  // one caller at a time on the shared context
+// One GPU (or one logical shard of a GPU) of the process: its context, whose query it currently holds, its raw sets.
+struct DeviceSlot {
   hhv_ctx* ctx;
   int device_id;
   unsigned long owner;  // alignment() call whose query is currently installed in ctx
+  std::vector<hhv_rawset*> rawsets;
+  size_t columns;
+  DeviceSlot() : ctx(NULL), device_id(0), owner(0), columns(0) {}
+};
+
+// HHV_DEVICES = "0,1,2,3" / "0-7" / "0,0" (two logical shards on device 0): the devices a search spreads its templates over
+// (template-database sharding, SURVEY.md 8e: whole templates, the SIMD batches of the reference are still formed on the whole
+// sorted block first, so the results do not depend on the number of devices).  Default: the one device of HHV_DEVICE (0).
+inline std::vector<int> configured_devices() {
+  std::vector<int> out;
+  const char* e = getenv("HHV_DEVICES");
+  if (e && *e) {
+    const char* p = e;
+    while (*p) {
+      while (*p && (*p < '0' || *p > '9')) ++p;
+      if (!*p) break;
+      int a = (int)strtol(p, (char**)&p, 10), b = a;
+      if (*p == '-') b = (int)strtol(p + 1, (char**)&p, 10);
+      for (int d = a; d <= b && out.size() < 64; ++d) out.push_back(d);
+    }
+  }
+  if (out.empty()) {
+    const char* d = getenv("HHV_DEVICE");
+    out.push_back(d ? atoi(d) : 0);
+  }
+  return out;
+}
+
+struct TemplateCache {
+  std::mutex device;  // one caller at a time on the shared contexts (a search holds it for its device sections)
+  std::vector<DeviceSlot> slots;  // slot 0 is the primary device (the realign stage works there)
   unsigned long calls;
   int active;  // searches currently using cache entries
   bool enabled;
   size_t max_columns, columns;
-  std::vector<hhv_rawset*> rawsets;
   std::unordered_map<std::string, CachedTemplate> map;
   // what the prototypes depend on besides the template (src/hhhit.cpp:255-256,289-320)
   int nseqdis, ssm, q_has_pred, q_has_dssp;
   // ... and what reading a template from an ALIGNMENT depends on (HHEntry::getTemplateHMM, src/hhdatabase.cpp:299-460): a
   // change empties the cache like a change of nseqdis does
   uint64_t read_param_hash;
-  TemplateCache() : ctx(NULL), device_id(0), owner(0), calls(0), active(0), enabled(true), max_columns(0), columns(0), nseqdis(-1),
-                    ssm(-1), q_has_pred(-1), q_has_dssp(-1), read_param_hash(0) {
+  TemplateCache() : calls(0), active(0), enabled(true), max_columns(0), columns(0), nseqdis(-1), ssm(-1), q_has_pred(-1),
+                    q_has_dssp(-1), read_param_hash(0) {
     const char* e = getenv("HHV_TEMPLATE_CACHE");
     enabled = !(e && atoi(e) == 0);
     const char* g = getenv("HHV_TEMPLATE_CACHE_GB");
     const double gb = g ? atof(g) : 64.0;
     max_columns = (size_t)(gb * 1e9 / 128.0);  // 32 dwords per raw column
-    const char* d = getenv("HHV_DEVICE");
-    device_id = d ? atoi(d) : 0;
+    const std::vector<int> devs = configured_devices();
+    slots.resize(devs.size());
+    for (size_t k = 0; k < devs.size(); ++k) slots[k].device_id = devs[k];
   }
   void clear() {  // device lock held
     for (std::unordered_map<std::string, CachedTemplate>::iterator it = map.begin(); it != map.end(); ++it) it->second.proto.Delete();
     map.clear();
-    for (size_t k = 0; k < rawsets.size(); ++k) hhv_rawset_free(rawsets[k]);
-    rawsets.clear();
+    for (size_t d = 0; d < slots.size(); ++d) {
+      for (size_t k = 0; k < slots[d].rawsets.size(); ++k) hhv_rawset_free(slots[d].rawsets[k]);
+      slots[d].rawsets.clear();
+      slots[d].columns = 0;
+    }
     columns = 0;
   }
 };
@@ -128,18 +163,25 @@ inline void process_fast_log2_tables(float* lg2, float* diff) {
   diff[1024] = 0.0f;
 }
 
-// the shared device context (device lock held): created on first use, with the process's own fast_log2 tables
+// the shared device contexts (device lock held): created on first use, with the process's own fast_log2 tables
 inline int ensure_context(TemplateCache& tc) {
-  if (tc.ctx) return HHV_OK;
-  hhv_params hp;
-  memset(&hp, 0, sizeof(hp));
-  hp.device = tc.device_id;
-  hp.local = 1;
-  int rc = hhv_create(&tc.ctx, &hp);
-  if (rc != HHV_OK) return rc;
   float lg2[1025], diff[1025];
-  process_fast_log2_tables(lg2, diff);
-  return hhv_set_fast_log2_tables(tc.ctx, lg2, diff);
+  bool tables = false;
+  for (size_t d = 0; d < tc.slots.size(); ++d) {
+    DeviceSlot& sl = tc.slots[d];
+    if (sl.ctx) continue;
+    hhv_params hp;
+    memset(&hp, 0, sizeof(hp));
+    hp.device = sl.device_id;
+    hp.local = 1;
+    int rc = hhv_create(&sl.ctx, &hp);
+    if (rc != HHV_OK) return rc;
+    if (!tables) process_fast_log2_tables(lg2, diff);
+    tables = true;
+    rc = hhv_set_fast_log2_tables(sl.ctx, lg2, diff);
+    if (rc != HHV_OK) return rc;
+  }
+  return HHV_OK;
 }
 
 // Can PrepareTemplateHMM run on the device for this search?  (hhv_prepare_subset: HHM format, substitution-matrix

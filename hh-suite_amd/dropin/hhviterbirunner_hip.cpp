@@ -48,6 +48,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -226,6 +227,7 @@ void hmm_header_from_sidecar(const hhv_dropin::SidecarRecord& r, HMM* t) {
 // a template of THIS search: where its prepared columns are on the device
 struct ResidentTemplate {
   hhv_tset* set;
+  int dev;  // device slot the set lives on
   int32_t index;
   int L;
   int ss_pair_mode;
@@ -360,38 +362,43 @@ struct Search {
     regions = !q_ranges.empty() || !t_ranges.empty();
   }
 
-  // Enter a device section (tc.device is held by the caller): the shared context gets this search's parameters and
+  // Enter a device section (tc.device is held by the caller): every device's context gets this search's parameters and
   // query unless it still has them from the previous section.
   void install() {
     hip_check(hhv_dropin::ensure_context(tc), "hhv_create");
     if (id == 0) id = ++tc.calls;
-    if (tc.owner == id) return;
-    hhv_params hp;
-    hp.device = tc.device_id;
-    hp.local = par.loc;
-    hp.egq = par.egq;
-    hp.egt = par.egt;
-    hp.shift = par.shift;
-    hp.corr = par.corr;
-    hp.ssw = par.ssw;
-    hp.ss_mode = ssm_mode;  // the ss_mode argument of the Viterbi constructor (src/hhviterbirunner.h:32-33)
-    hip_check(hhv_set_params(tc.ctx, &hp), "hhv_set_params");
-    hip_check(hhv_set_query(tc.ctx, q_p.data(), q_tr.data(), q->L), "hhv_set_query");
-    hip_check(hhv_set_ss_tables(tc.ctx, &tables.S73[0][0][0], &tables.S33[0][0][0][0], &tables.S37[0][0][0]), "hhv_set_ss_tables");
-    hip_check(hhv_set_query_ss(tc.ctx, q_ss.pred.empty() ? NULL : q_ss.pred.data(), q_ss.conf.empty() ? NULL : q_ss.conf.data(),
-                               q_ss.dssp.empty() ? NULL : q_ss.dssp.data()),
-              "hhv_set_query_ss");
-    tc.owner = id;
+    for (size_t d = 0; d < tc.slots.size(); ++d) {
+      hhv_dropin::DeviceSlot& sl = tc.slots[d];
+      if (sl.owner == id) continue;
+      hhv_params hp;
+      hp.device = sl.device_id;
+      hp.local = par.loc;
+      hp.egq = par.egq;
+      hp.egt = par.egt;
+      hp.shift = par.shift;
+      hp.corr = par.corr;
+      hp.ssw = par.ssw;
+      hp.ss_mode = ssm_mode;  // the ss_mode argument of the Viterbi constructor (src/hhviterbirunner.h:32-33)
+      hip_check(hhv_set_params(sl.ctx, &hp), "hhv_set_params");
+      hip_check(hhv_set_query(sl.ctx, q_p.data(), q_tr.data(), q->L), "hhv_set_query");
+      hip_check(hhv_set_ss_tables(sl.ctx, &tables.S73[0][0][0], &tables.S33[0][0][0][0], &tables.S37[0][0][0]), "hhv_set_ss_tables");
+      hip_check(hhv_set_query_ss(sl.ctx, q_ss.pred.empty() ? NULL : q_ss.pred.data(), q_ss.conf.empty() ? NULL : q_ss.conf.data(),
+                                 q_ss.dssp.empty() ? NULL : q_ss.dssp.data()),
+                "hhv_set_query_ss");
+      sl.owner = id;
+    }
   }
 
   // Aligns n templates of one resident set with one ss mode (device section).  ids: their indices in the set (NULL =
   // the whole set in set order); tmpl[k] / out[k]: resident record and Hit (template information already set) of the k-th.
-  void run(hhv_tset* set, const int32_t* ids, int n, int ss_hmm_mode, const std::vector<const ResidentTemplate*>& tmpl,
-           const std::vector<Hit*>& out, const std::vector<uint8_t>& not_longest) {
-    hhv_ctx* ctx = tc.ctx;
+  // dev: the device slot the set lives on; timed: this call runs on the search's own thread (the phase timer is not shared
+  // between the per-device threads of a multi-device search)
+  void run(int dev, bool timed, hhv_tset* set, const int32_t* ids, int n, int ss_hmm_mode,
+           const std::vector<const ResidentTemplate*>& tmpl, const std::vector<Hit*>& out, const std::vector<uint8_t>& not_longest) {
+    hhv_ctx* ctx = tc.slots[dev].ctx;
     hhv_tset* ts = set;
     hhv_tset* sub = NULL;
-    timer.lap(PhaseTimer::OTHER);
+    if (timed) timer.lap(PhaseTimer::OTHER);
     if (ids) {
       hip_check(hhv_tset_gather(ctx, set, ids, n, &sub), "hhv_tset_gather");
       ts = sub;
@@ -423,10 +430,10 @@ struct Search {
                 "hhv_set_celloff_paths");
     }
     std::vector<hhv_hit> hits(n);
-    timer.lap(PhaseTimer::MASKS);
+    if (timed) timer.lap(PhaseTimer::MASKS);
     hip_check(hhv_align(ctx, ts, masked ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, NULL), "hhv_align");
     hip_check(hhv_hits(ctx, ts, hits.data()), "hhv_hits");
-    timer.lap(PhaseTimer::ALIGN);
+    if (timed) timer.lap(PhaseTimer::ALIGN);
     // the path pool in one piece (host mirror of the set); the Hit objects are filled by all threads
     const int64_t* path_off = NULL;
     const int32_t *pool_i = NULL, *pool_j = NULL;
@@ -473,7 +480,7 @@ struct Search {
       hit.j2 = h.j2;
     }
     if (sub) hhv_tset_free(sub);
-    timer.lap(PhaseTimer::PATHS);
+    if (timed) timer.lap(PhaseTimer::PATHS);
   }
 };
 
@@ -714,7 +721,8 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
           {
             std::lock_guard<std::mutex> lock(tc.device);
             search.install();
-            hhv_ctx* ctx = tc.ctx;
+            const int n_slots = (int)tc.slots.size();
+            hhv_ctx* ctx = tc.slots[0].ctx;  // host-prepared templates (the rare path) go to the primary device
             std::vector<unsigned int> raw_k, prep_k;
             std::vector<int> raw_r, prep_r;
             for (int r = 0; r < n_read; ++r) {
@@ -732,45 +740,70 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
               size_t cols = 0;
               const int n = (int)raw_k.size();
               std::vector<int32_t> L(n);
-              std::vector<const float*> ff(n), tt(n), ne(n);
-              std::vector<float> nh(n);
-              std::vector<const int8_t*> sp(n), sc(n), sd(n);
               for (int x = 0; x < n; ++x) {
-                const HostTemplate& h = host[raw_r[x]];
-                L[x] = h.L;
-                cols += (size_t)h.L + 1;
-                ff[x] = h.p.data();
-                tt[x] = h.tr.data();
-                ne[x] = h.neff.data();
-                nh[x] = h.neff_hmm;
-                sp[x] = h.ss.pred.empty() ? NULL : h.ss.pred.data();
-                sc[x] = h.ss.conf.empty() ? NULL : h.ss.conf.data();
-                sd[x] = h.ss.dssp.empty() ? NULL : h.ss.dssp.data();
+                L[x] = host[raw_r[x]].L;
+                cols += (size_t)L[x] + 1;
               }
               // A full cache is emptied only when no template of it is in use by this search (nothing resident yet,
               // nothing of this chunk found in it); otherwise it grows past the bound until the search is over.
               if (tc.columns + cols > tc.max_columns && tc.active == 1 && resident.empty() && to_read.size() == cn) tc.clear();
-              hhv_rawset* rs = NULL;
-              hip_check(hhv_upload_raw_templates(ctx, n, L.data(), ff.data(), tt.data(), ne.data(), nh.data(), sp.data(), sc.data(),
-                                                 sd.data(), &rs),
-                        "hhv_upload_raw_templates");
-              tc.rawsets.push_back(rs);
+              // the new templates are spread over the devices (hhv_shard_plan: length-sorted bins, longest processing time
+              // first); a template stays on the device that first received it for as long as it is cached
+              std::vector<int32_t> shard_of(n, 0);
+              if (n_slots > 1) hip_check(hhv_shard_plan(n, L.data(), n_slots, shard_of.data()), "hhv_shard_plan");
+              std::vector<std::vector<int> > members(n_slots);
+              for (int x = 0; x < n; ++x) members[shard_of[x]].push_back(x);
+              std::vector<hhv_rawset*> new_set(n_slots, (hhv_rawset*)NULL);
+              std::vector<std::thread> uploads;
+              for (int d = 0; d < n_slots; ++d) {
+                if (members[d].empty()) continue;
+                uploads.push_back(std::thread([&, d]() {  // one host thread per context
+                  const std::vector<int>& mem = members[d];
+                  const int m = (int)mem.size();
+                  std::vector<int32_t> Ld(m);
+                  std::vector<const float*> ff(m), tt(m), ne(m);
+                  std::vector<float> nh(m);
+                  std::vector<const int8_t*> sp(m), sc(m), sd(m);
+                  for (int y = 0; y < m; ++y) {
+                    const HostTemplate& h = host[raw_r[mem[y]]];
+                    Ld[y] = h.L;
+                    ff[y] = h.p.data();
+                    tt[y] = h.tr.data();
+                    ne[y] = h.neff.data();
+                    nh[y] = h.neff_hmm;
+                    sp[y] = h.ss.pred.empty() ? NULL : h.ss.pred.data();
+                    sc[y] = h.ss.conf.empty() ? NULL : h.ss.conf.data();
+                    sd[y] = h.ss.dssp.empty() ? NULL : h.ss.dssp.data();
+                  }
+                  hip_check(hhv_upload_raw_templates(tc.slots[d].ctx, m, Ld.data(), ff.data(), tt.data(), ne.data(), nh.data(), sp.data(),
+                                                     sc.data(), sd.data(), &new_set[d]),
+                            "hhv_upload_raw_templates");
+                }));
+              }
+              for (size_t u = 0; u < uploads.size(); ++u) uploads[u].join();
               tc.columns += cols;
               std::vector<CachedTemplate*> slot(n);
-              for (int x = 0; x < n; ++x) {  // std::unordered_map never moves its elements
-                CachedTemplate& ct = tc.map[cache_key(ent[raw_k[x]])];
-                if (ct.raw) ct.proto.Delete();  // the same key twice (two searches read it concurrently): the later upload wins
-                ct.raw = rs;
-                ct.index = x;
-                ct.id = identify_entry(databases, ent[raw_k[x]]->getName());
-                slot[x] = &ct;
-                cached[raw_k[x]] = &ct;
+              for (int d = 0; d < n_slots; ++d) {
+                if (members[d].empty()) continue;
+                tc.slots[d].rawsets.push_back(new_set[d]);
+                for (size_t y = 0; y < members[d].size(); ++y) {  // std::unordered_map never moves its elements
+                  const int x = members[d][y];
+                  tc.slots[d].columns += (size_t)L[x] + 1;
+                  CachedTemplate& ct = tc.map[cache_key(ent[raw_k[x]])];
+                  if (ct.raw) ct.proto.Delete();  // the same key twice (two searches read it concurrently): the later upload wins
+                  ct.raw = new_set[d];
+                  ct.dev = d;
+                  ct.index = (int32_t)y;
+                  ct.id = identify_entry(databases, ent[raw_k[x]]->getName());
+                  slot[x] = &ct;
+                  cached[raw_k[x]] = &ct;
+                }
               }
 #pragma omp parallel for schedule(static) num_threads(threads) if (n > 256)
               for (int x = 0; x < n; ++x) {
                 HostTemplate& h = host[raw_r[x]];
                 CachedTemplate& ct = *slot[x];
-                if (ct.index != x) continue;  // a duplicate key inside this chunk: the last one filled the slot
+                if (cached[raw_k[x]] != &ct) continue;  // (kept for symmetry; every slot is distinct unless a key repeats)
                 ct.L = h.L;
                 ct.weights_free = h.hh_text;
                 ct.ss_pair_mode = h.ss_pair_mode;
@@ -807,26 +840,47 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 ss->conf.swap(h.ss.conf);
                 ss->dssp.swap(h.ss.dssp);
                 own_ss.push_back(ss);
-                ResidentTemplate rt = {set, (int32_t)x, h.L, h.ss_pair_mode, first_hit_of_block + c0 + prep_k[x], ss};
+                ResidentTemplate rt = {set, 0, (int32_t)x, h.L, h.ss_pair_mode, first_hit_of_block + c0 + prep_k[x], ss};
                 resident[ent[prep_k[x]]] = rt;
               }
             }
             timer.lap(PhaseTimer::UPLOAD);
-            // PrepareTemplateHMM on the device, one launch per raw set the chunk's templates live in
+            // PrepareTemplateHMM on the device, one launch per raw set the chunk's templates live in; the devices work side
+            // by side (one host thread each)
             std::map<hhv_rawset*, std::vector<unsigned int> > by_raw;
             for (unsigned int k = 0; k < cn; ++k)
               if (cached[k]) by_raw[cached[k]->raw].push_back(k);
+            std::vector<std::vector<hhv_rawset*> > raw_of_slot(n_slots);
+            for (std::map<hhv_rawset*, std::vector<unsigned int> >::iterator g = by_raw.begin(); g != by_raw.end(); ++g)
+              raw_of_slot[cached[g->second[0]]->dev].push_back(g->first);
+            std::map<hhv_rawset*, hhv_tset*> prepared;
+            for (std::map<hhv_rawset*, std::vector<unsigned int> >::iterator g = by_raw.begin(); g != by_raw.end(); ++g) prepared[g->first] = NULL;
+            auto prepare_slot = [&](int d) {
+              for (size_t w = 0; w < raw_of_slot[d].size(); ++w) {
+                hhv_rawset* rs = raw_of_slot[d][w];
+                const std::vector<unsigned int>& mem = by_raw[rs];
+                std::vector<int32_t> ids(mem.size());
+                for (size_t x = 0; x < mem.size(); ++x) ids[x] = cached[mem[x]]->index;
+                hip_check(hhv_prepare_subset(tc.slots[d].ctx, rs, &prep, q->pav, ids.data(), (int32_t)ids.size(), &prepared[rs]),
+                          "hhv_prepare_subset");
+              }
+            };
+            if (n_slots == 1) {
+              prepare_slot(0);
+            } else {
+              std::vector<std::thread> workers;
+              for (int d = 0; d < n_slots; ++d)
+                if (!raw_of_slot[d].empty()) workers.push_back(std::thread(prepare_slot, d));
+              for (size_t w = 0; w < workers.size(); ++w) workers[w].join();
+            }
             for (std::map<hhv_rawset*, std::vector<unsigned int> >::iterator g = by_raw.begin(); g != by_raw.end(); ++g) {
               const std::vector<unsigned int>& mem = g->second;
-              std::vector<int32_t> ids(mem.size());
-              for (size_t x = 0; x < mem.size(); ++x) ids[x] = cached[mem[x]]->index;
-              hhv_tset* set = NULL;
-              hip_check(hhv_prepare_subset(ctx, g->first, &prep, q->pav, ids.data(), (int32_t)ids.size(), &set), "hhv_prepare_subset");
+              hhv_tset* set = prepared[g->first];
               search_sets.push_back(set);
               for (size_t x = 0; x < mem.size(); ++x) {
                 const unsigned int k = mem[x];
                 const CachedTemplate* ct = cached[k];
-                ResidentTemplate rt = {set, (int32_t)x, ct->L, ct->ss_pair_mode, first_hit_of_block + c0 + k, &ct->ss};
+                ResidentTemplate rt = {set, ct->dev, (int32_t)x, ct->L, ct->ss_pair_mode, first_hit_of_block + c0 + k, &ct->ss};
                 resident[ent[k]] = rt;
               }
             }
@@ -869,26 +923,42 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> > groups;
         for (unsigned int k = 0; k < cn; ++k) groups[std::make_pair(rt[k]->set, batch_mode[k])].push_back(k);
         {
-          // device section 2: alignment, backtrace, Hit scores, paths
+          // device section 2: alignment, backtrace, Hit scores, paths - the groups of one device one after the other, the
+          // devices side by side (one host thread per context)
           std::lock_guard<std::mutex> lock(tc.device);
           search.install();
-          for (std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> >::iterator g = groups.begin(); g != groups.end();
-               ++g) {
-            const std::vector<unsigned int>& mem = g->second;
-            const int n = (int)mem.size();
-            std::vector<int32_t> ids(n);
-            std::vector<const ResidentTemplate*> tmpl(n);
-            std::vector<Hit*> out(n);
-            std::vector<uint8_t> not_longest(n);
-            bool whole = (n == hhv_tset_size(g->first.first));
-            for (int k = 0; k < n; ++k) {
-              tmpl[k] = rt[mem[k]];
-              ids[k] = tmpl[k]->index;
-              out[k] = &hit0[mem[k]];
-              not_longest[k] = shorter[mem[k]];
-              whole = whole && ids[k] == k;
+          const int n_slots = (int)tc.slots.size();
+          typedef std::map<std::pair<hhv_tset*, int>, std::vector<unsigned int> >::iterator GroupIt;
+          std::vector<std::vector<GroupIt> > groups_of_slot(n_slots);
+          for (GroupIt g = groups.begin(); g != groups.end(); ++g) groups_of_slot[rt[g->second[0]]->dev].push_back(g);
+          auto run_slot = [&](int d, bool timed) {
+            for (size_t w = 0; w < groups_of_slot[d].size(); ++w) {
+              GroupIt g = groups_of_slot[d][w];
+              const std::vector<unsigned int>& mem = g->second;
+              const int n = (int)mem.size();
+              std::vector<int32_t> ids(n);
+              std::vector<const ResidentTemplate*> tmpl(n);
+              std::vector<Hit*> out(n);
+              std::vector<uint8_t> not_longest(n);
+              bool whole = (n == hhv_tset_size(g->first.first));
+              for (int k = 0; k < n; ++k) {
+                tmpl[k] = rt[mem[k]];
+                ids[k] = tmpl[k]->index;
+                out[k] = &hit0[mem[k]];
+                not_longest[k] = shorter[mem[k]];
+                whole = whole && ids[k] == k;
+              }
+              search.run(d, timed, g->first.first, whole ? NULL : ids.data(), n, g->first.second, tmpl, out, not_longest);
             }
-            search.run(g->first.first, whole ? NULL : ids.data(), n, g->first.second, tmpl, out, not_longest);
+          };
+          if (n_slots == 1) {
+            run_slot(0, true);
+          } else {
+            std::vector<std::thread> workers;
+            for (int d = 0; d < n_slots; ++d)
+              if (!groups_of_slot[d].empty()) workers.push_back(std::thread(run_slot, d, false));
+            for (size_t w = 0; w < workers.size(); ++w) workers[w].join();
+            timer.lap(PhaseTimer::ALIGN);
           }
         }
       }

@@ -49,10 +49,11 @@ def build_db(tmp, query, templates, names, seed):
     return base, qpath
 
 
-def run_app(binary, args, out_prefix):
+def run_app(binary, args, out_prefix, env=None):
     cmd = [os.path.join(BIN, binary)] + args + ["-o", out_prefix + ".hhr", "-scores", out_prefix + ".scores", "-atab",
                                                 out_prefix + ".atab", "-v", "1"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, (cmd, r.stdout.decode()[-2000:])
     out = {}
     for ext in ("hhr", "scores", "atab"):
@@ -368,3 +369,30 @@ def test_sidecar_replaces_the_text_parse_in_the_next_process(tmp_path, case):
     cpu2 = run_app("hhsearch_cpu", args, str(tmp_path / "cpu2"))
     again, line = run_hip("again")
     compare_outputs(cpu2, again)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhblits_hip"), reason="oracle/_ref/hhblits_hip not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("case", ["hhsearch_ragged_global", "hhsearch_ss_alt", "hhblits_one_iteration"])
+def test_template_database_sharded_over_devices(tmp_path, case):
+    """HHV_DEVICES: the Viterbi translation unit spreads the templates of a search over several device contexts
+    (hhv_shard_plan, one host thread per context; here three logical shards on the one GPU of the box) - the SIMD batches of
+    the reference are still formed on the whole sorted block, so the result files must be the reference's, as with one device.
+    The hhblits case sends the hits through the realign stage, which finds part of its templates on a non-primary device."""
+    extra, app = [], "hhsearch"
+    if case == "hhsearch_ragged_global":
+        q, t, names = make_db(701, 150, 90, 40, 260, same_len_every=5)
+        extra = ["-glob"]
+    elif case == "hhsearch_ss_alt":
+        q, t, names = make_db(702, 130, 60, 150, 150, ss_every=2, query_ss=("pred", "conf"))
+        extra = ["-alt", "3"]
+    else:
+        q, t, names = make_db(703, 180, 120, 60, 240)
+        app, extra = "hhblits", ["-n", "1"]
+    base, qpath = build_db(str(tmp_path), q, t, names, 6)
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "1"] + extra   # one thread: the reference's hit order is then defined
+    cpu = run_app(app + "_cpu", args, str(tmp_path / "cpu"))
+    one = run_app(app + "_hip", args, str(tmp_path / "one"), env={"HHV_SIDECAR": "0"})
+    three = run_app(app + "_hip", args, str(tmp_path / "three"), env={"HHV_SIDECAR": "0", "HHV_DEVICES": "0,0,0", "HHV_DROPIN_TIMING": "1"})
+    compare_outputs(cpu, one)
+    compare_outputs(cpu, three)
