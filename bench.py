@@ -233,7 +233,10 @@ def main():
     cells_per_rank = ts.cells()
     K = args.topk
     topk_buf = torch.zeros((K, shard.REC_I32), dtype=torch.int32, device=device)   # K hhv_hit records (40 B each)
-    gids = torch.arange(n_local, dtype=torch.int64, device=device) + pieces[0] * n   # global template ids of this shard
+    ctx.set_global_ids(ts, np.arange(n_local, dtype=np.int64) + pieces[0] * n)   # hhv_topk reports global template ids
+    gloo = world > 1 and dist.get_backend() == "gloo"   # debug path only (HHV_BENCH_BACKEND, ranks sharing a device)
+    gathered = torch.zeros((world * K, shard.REC_I32), dtype=torch.int32, device="cpu" if gloo else device)
+    merged_buf = torch.zeros((K, shard.REC_I32), dtype=torch.int32, device=device)
     bt = bool(args.backtrace)
 
     kernel_ms = []
@@ -244,9 +247,15 @@ def main():
             ctx.hits(ts, fetch=False)
         ctx.topk(ts, K, d_out=topk_buf.data_ptr(), fetch=False, raw=not bt)
         kernel_ms.append(ctx.last_kernel_ms())
-        # hit-list exchange: ONE all_gather of K records per rank over RCCL, identical merge everywhere
-        recs = shard.to_global_ids(torch, topk_buf, gids)
-        return shard.exchange_and_merge(torch, dist if world > 1 else None, recs, K)
+        # hit-list exchange: ONE all_gather of K records per rank over RCCL, then the same device merge on every rank
+        # (hhv_merge_hits; with one rank it merges the rank's own list, so that a step is the same job at every N)
+        src = topk_buf
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, topk_buf.cpu() if gloo else topk_buf)
+            src = gathered.to(device) if gloo else gathered
+            torch.cuda.current_stream().synchronize()   # the gathered records are visible to the library's stream
+        _, nm = ctx.merge_hits(src.data_ptr(), world * K, K, d_out=merged_buf.data_ptr(), fetch=False)
+        return merged_buf[:nm]
 
     def barrier():
         if world > 1:
@@ -517,7 +526,7 @@ def next_rows():
     out = {}
     try:
         import bench_prefilter
-        r = bench_prefilter.run(200000, 300, 50)
+        r = bench_prefilter.run(200000, 300, 1000)
         out["N3_prefilter"] = {"db_sequences": r["n_db"], "db_residues": r["residues"], "Lq": r["Lq"],
                                "gapless_cells_per_s": r["ungapped"]["cells_per_s"], "gapless_kernel_ms": r["ungapped"]["kernel_ms"],
                                "sw_cells_per_s": r["gapped"]["cells_per_s"], "sw_kernel_ms": r["gapped"]["kernel_ms"],
@@ -527,7 +536,7 @@ def next_rows():
         out["N3_prefilter"] = {"error": repr(e)}
     try:
         import bench_mac
-        r = bench_mac.run(500, 300, 300, 8)
+        r = bench_mac.run(500, 300, 300, 100)
         out["N4_mac_realign"] = {"hits": r["n_hits"], "Lq": r["Lq"], "Lt": r["Lt"], "kernels_ms": r["gpu_kernels_ms"],
                                  "end_to_end_ms_host_staged_profiles": r["gpu_wall_ms_incl_host_masks"],
                                  "end_to_end_ms_resident_set": r["resident_set"]["runner_ms"],

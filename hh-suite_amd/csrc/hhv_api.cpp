@@ -35,8 +35,9 @@ const char* last_error() { return g_err.c_str(); }
 namespace hhv {
 size_t topk_temp_bytes(int n);
 void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t stream);
-int topk_device(const DevHit* d_hits, int n, int k, DevHit* d_out, uint64_t* keys, uint64_t* sorted, void* temp,
-                size_t temp_bytes, hipStream_t stream, std::string* err);
+int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit* d_out, uint64_t* keys, uint64_t* sorted,
+                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err);
+int merge_hits_device(const DevHit* d_in, int m, int k, DevHit* d_out, int* d_n, hipStream_t stream, std::string* err);
 }
 
 extern "C" {
@@ -168,6 +169,7 @@ void hhv_destroy(hhv_ctx* c) {
   dfree(c->d_ss_table);
   dfree(c->d_ss_q_off);
   dfree(c->mac_cache);
+  dfree(c->d_merge);
   for (int k = 0; k < MAC_CLASSES; ++k) {
     if (c->mac_side.s[k]) (void)hipStreamDestroy((hipStream_t)c->mac_side.s[k]);
     if (c->mac_side.join[k]) (void)hipEventDestroy((hipEvent_t)c->mac_side.join[k]);
@@ -423,6 +425,7 @@ void hhv_tset_free(hhv_tset* ts) {
   dfree(ts->d_sorted);
   dfree(ts->d_sort_temp);
   dfree(ts->d_raw_hits);
+  dfree(ts->d_gids);
   delete ts;
 }
 
@@ -869,13 +872,54 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
   }
   DevHit* dst = d_out ? (DevHit*)d_out : ts->d_topk;
   std::string err;
-  if (topk_device(src, ts->n, kk, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
+  if (topk_device(src, ts->n, kk, ts->d_gids, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
                   &err) != 0)
     return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
   if (kk < k) HIP_TRY(hipMemsetAsync(dst + kk, 0xFF, (size_t)(k - kk) * sizeof(DevHit), c->stream));
   if (out) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (n_out) *n_out = kk;
+  return HHV_OK;
+}
+
+int hhv_tset_set_global_ids(hhv_ctx* c, hhv_tset* ts, const int32_t* ids) {
+  if (!c || !ts) return fail(HHV_E_ARG, "hhv_tset_set_global_ids: null argument");
+  HIP_TRY(hipSetDevice(c->par.device));
+  if (!ids) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(ts->d_gids);
+    ts->d_gids = nullptr;
+    return HHV_OK;
+  }
+  for (int k = 0; k < ts->n; ++k)
+    if (ids[k] < 0) return fail(HHV_E_ARG, "hhv_tset_set_global_ids: ids[%d] = %d (must be >= 0)", k, ids[k]);
+  if (!ts->d_gids) HIP_TRY(hipMalloc(&ts->d_gids, (size_t)std::max(ts->n, 1) * sizeof(int32_t)));
+  HIP_TRY(hipMemcpyAsync(ts->d_gids, ids, (size_t)ts->n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HHV_OK;
+}
+
+int hhv_merge_hits(hhv_ctx* c, const void* d_in, int32_t m, int32_t k, hhv_hit* out, void* d_out, int32_t* n_out) {
+  if (!c || !d_in) return fail(HHV_E_ARG, "hhv_merge_hits: null argument");
+  if (m < 1 || k < 1) return fail(HHV_E_ARG, "hhv_merge_hits: m = %d, k = %d", m, k);
+  HIP_TRY(hipSetDevice(c->par.device));
+  if (c->merge_cap < k) {
+    dfree(c->d_merge);
+    c->d_merge = nullptr;
+    c->merge_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_merge, (size_t)k * sizeof(DevHit) + sizeof(int)));
+    c->merge_cap = k;
+  }
+  int* d_n = reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_merge) + (size_t)c->merge_cap * sizeof(DevHit));
+  DevHit* dst = d_out ? (DevHit*)d_out : (DevHit*)c->d_merge;
+  std::string err;
+  if (merge_hits_device((const DevHit*)d_in, m, k, dst, d_n, c->stream, &err) != 0)
+    return fail(HHV_E_DEVICE, "hhv_merge_hits: %s", err.c_str());
+  int nv = 0;
+  if (out) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&nv, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_out) *n_out = nv;
   return HHV_OK;
 }
 

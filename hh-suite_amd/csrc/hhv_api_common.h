@@ -77,6 +77,8 @@ struct hhv_ctx {
   float* d_ss_table = nullptr;                         // ssw * table of the current mode
   int32_t* d_ss_q_off = nullptr;                       // [plan.rows()]
   int ss_t_shift = 0, ss_t_mask = 0;
+  void* d_merge = nullptr;                             // hhv_merge_hits: merge_cap records + one int
+  int merge_cap = 0;
 };
 
 struct hhv_tset {
@@ -129,6 +131,7 @@ struct hhv_tset {
   void* d_sort_temp = nullptr;
   size_t sort_temp_bytes = 0;
   hhv::DevHit* d_raw_hits = nullptr;
+  int32_t* d_gids = nullptr;  // hhv_tset_set_global_ids: global template id of every entry (sharded databases)
 };
 
 struct hhv_rawset {

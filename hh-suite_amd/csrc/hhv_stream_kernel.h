@@ -74,9 +74,13 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ records, c
 // tools/audit_asm.py checks in the generated .s that nothing touches a destination between its load and its wait.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int R, bool QL_>
+template <int R, bool QL_, bool SPLIT_ = false>
 struct LdsColumn {
   static constexpr bool QL = QL_;
+  // SPLIT_A (backtrace variants with the pipelined head): the phase-A query transitions are requested at the top of the
+  // step without a wait; lane_column evaluates the MM candidates of all rows first (they do not need them) and calls
+  // before_A2() in front of the GD / IM updates.
+  static constexpr bool SPLIT_A = SPLIT_;
   static constexpr int NA = (R + 1) / 2;      // float4 reads covering the A block {m2i, i2i} x R (floats 0 .. 2R-1)
   static constexpr int C0 = (2 * R) / 4;      // first float4 of the C block {m2d, d2d} x R (floats 2R .. 4R-1)
   static constexpr int NC = R - C0;
@@ -101,6 +105,23 @@ struct LdsColumn {
                    "ds_read_b128 %3, %6 offset:16\n\tds_read_b128 %4, %6 offset:32\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(v6), "=&v"(v5), "=&v"(qa0), "=&v"(qa1), "=&v"(qa2) : "v"(rec_addr), "v"(ql_addr) : "memory");
     }
+  }
+  // SPLIT_A: the phase-A query transitions, issued without a wait (full EXEC, top of the step)
+  __device__ __forceinline__ void qa_issue() {
+    if (NA == 1) asm volatile("ds_read_b128 %0, %1" : "=&v"(qa0) : "v"(ql_addr) : "memory");
+    if (NA == 2)
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(qa0), "=&v"(qa1) : "v"(ql_addr) : "memory");
+    if (NA == 3)
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
+                   : "=&v"(qa0), "=&v"(qa1), "=&v"(qa2) : "v"(ql_addr) : "memory");
+  }
+  // LDS returns a wave's reads in order: behind qa_issue() the step has requested the next head (2 reads) and the profile
+  // (5 reads, begin_column), so "at most 7 outstanding" means the query transitions have landed
+  __device__ __forceinline__ void before_A2() {
+    if (!SPLIT_A) return;
+    if (NA == 1) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(qa0));
+    if (NA == 2) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(qa0), "+v"(qa1));
+    if (NA == 3) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(qa0), "+v"(qa1), "+v"(qa2));
   }
   // software-pipelined head (score-only variants): the head of step s+1 is requested at the top of step s and waited for
   // at its end, so its LDS round trip lies under the step's arithmetic instead of in front of it
@@ -241,7 +262,13 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 
   QRows<R> q;
   q.load(a.qpack + (size_t)g * R * REC_DW);
-  LdsColumn<R, QL> col;
+  // PF: the head of the NEXT step (7 transitions + meta) is fetched while the current one is computed (8 more VGPRs).
+  // The ring bookkeeping then runs one step early: chunk c must have landed before step C c - 1 requests its first record.
+  // All 64-lane variants except the cell-off / secondary-structure ones (no VGPRs to spare there); in the backtrace
+  // variants the phase-A query-transition reads are deferred as well (SPLIT_A).  Measured in one session each
+  // (tools/gpu_ab.sh): score-only -2 %, multi-pass -0.8 %, backtrace -0.5 %.
+  constexpr bool PF = !CELLOFF && !SS && W == LANES;
+  LdsColumn<R, QL, (PF && QL)> col;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t ring_addr = smem_addr + QL_F4 * 16 + arr * (C * REC_DW * 4);
   col.ql_addr = smem_addr + lane * 80;
@@ -266,10 +293,6 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // chunks 0 and 1 have landed, the lane's own ds_writes above are done (LDS executes a wave's operations in order)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-  // PF: the plain score-only variants fetch the head of the NEXT step while the current one is computed (8 more VGPRs;
-  // the backtrace / SS variants have none to spare).  The ring bookkeeping then runs one step early: chunk c must have
-  // landed before step C c - 1 requests the first record of it.
-  constexpr bool PF = !BT && !CELLOFF && !SS && !MULTI && W == LANES;
   constexpr int LEAD = PF ? 1 : 0;
   auto record_addr = [&](int step) -> uint32_t {
     const int rr = step - g;
@@ -280,20 +303,36 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   };
   v4f n6, n5;
   if (PF) {
-    LdsColumn<R, QL>::head_issue(record_addr(0), n6, n5);
-    LdsColumn<R, QL>::head_wait(n6, n5);
+    decltype(col)::head_issue(record_addr(0), n6, n5);
+    decltype(col)::head_wait(n6, n5);
   }
 
-  for (int s = 0; s < Mmax + W - 1; ++s) {
-    if (((s + LEAD) & (C - 1)) == 0 && s + LEAD > 0) {
-      // chunk c = (s + LEAD)/C was issued C steps ago: make sure it has landed, then refill the slot that held chunk c-3
-      // (its last reader, lane W-1, finished at step C(c-2)+2(W-1) < C c - LEAD) with chunk c+1.  The live window [s-W+1, s] spans
+  // Later passes of a long query: lane 0 takes the bottom row the previous pass left for its record (a.carry).  The row of
+  // step s + 1 is requested during step s - a global round trip per step in front of the hand-off would stall the wave
+  // (and with two waves per SIMD, most of the SIMD) for its whole latency.
+  float4 ncar = make_float4(0.f, 0.f, 0.f, 0.f);
+  float nmi = 0.f;
+  if (MULTI && !first) {
+    if (lane == 0 && M > 0) {
+      ncar = a.carry[rb];
+      nmi = a.carry_mi[rb];
+    }
+  }
+
+  // Two nested loops: the outer one walks the ring chunks (one refill each), the inner one the C steps of a chunk, so
+  // that the refill test is not part of a step.
+  const int s_end = Mmax + W - 1;
+  for (int c = 0; c * C - LEAD < s_end; ++c) {
+    if (c > 0) {
+      // chunk c was issued C steps ago: make sure it has landed, then refill the slot that held chunk c-3 (its last
+      // reader, lane W-1, finished at step C(c-2)+2(W-1) < C c - LEAD) with chunk c+1.  The live window [s-W+1, s] spans
       // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
       // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int c = (s + LEAD) / C;
       if (c + 1 < nchunks_max) load_chunk<W>(records, rb_a, nch_a, c + 1, ring, lane);
     }
+    const int s_lo = c > 0 ? c * C - LEAD : 0, s_hi = min((c + 1) * C - LEAD, s_end);
+  for (int s = s_lo; s < s_hi; ++s) {
     const int r = s - g;
     const bool active = (uint32_t)r < (uint32_t)M;  // 0 <= r < M in one compare
 
@@ -301,7 +340,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     if (PF) {
       col.v6 = n6;  // landed: waited for at the end of the previous step
       col.v5 = n5;
-      LdsColumn<R, QL>::head_issue(record_addr(s + 1), n6, n5);
+      if (QL) col.qa_issue();
+      decltype(col)::head_issue(record_addr(s + 1), n6, n5);
     } else {
       col.head();
     }
@@ -312,16 +352,19 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     Incoming bnd = boundary_incoming(meta, P);
     if (!first) {
       if (lane == 0 && active) {
-        const float4 c = a.carry[rb + r];
-        bnd.MM = c.x;
-        bnd.GD = c.y;
-        bnd.IM = c.z;
-        bnd.DG = c.w;
-        bnd.MI = a.carry_mi[rb + r];
+        bnd.MM = ncar.x;
+        bnd.GD = ncar.y;
+        bnd.IM = ncar.z;
+        bnd.DG = ncar.w;
+        bnd.MI = nmi;
         if (meta < 0 && st.tid >= 0) {
           const DevResult pr = a.results[st.tid & TID_MASK];
           bnd.fs = pr.score;
           bnd.fpos = (pr.i2 << 16) | pr.j2;
+        }
+        if (r + 1 < M) {  // lane 0: r = s
+          ncar = a.carry[rb + r + 1];
+          nmi = a.carry_mi[rb + r + 1];
         }
       }
     }
@@ -377,7 +420,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         }
       }
     }
-    if (PF) LdsColumn<R, QL>::head_wait(n6, n5);  // full EXEC again: the head of step s+1 is in n6 / n5 from here on
+    if (PF) decltype(col)::head_wait(n6, n5);  // full EXEC again: the head of step s+1 is in n6 / n5 from here on
+  }
   }
 }
 

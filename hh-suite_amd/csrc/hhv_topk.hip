@@ -22,12 +22,152 @@ __global__ void topk_keys_kernel(const DevHit* __restrict__ hits, int n, uint64_
   keys[k] = ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)k);
 }
 
+// gids: the shard's global template ids (hhv_tset_set_global_ids), or null = the index inside the set
 __global__ void topk_gather_kernel(const DevHit* __restrict__ hits, const uint64_t* __restrict__ sorted, int k,
-                                   DevHit* __restrict__ out) {
+                                   const int32_t* __restrict__ gids, DevHit* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k) return;
   const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(sorted[t] & 0xFFFFFFFFu);
-  out[t] = hits[idx];
+  DevHit h = hits[idx];
+  if (gids) h.index = gids[h.index];
+  out[t] = h;
+}
+
+// ---- merge of the hit lists of several shards (the other half of SURVEY.md 8e) ---------------------------------------
+// in: m records, the concatenation of every shard's hhv_topk output (global ids in `index`, padding records index < 0).
+// out: the k best, score descending, ties by the smaller global id - the order the reference's caller gives the hit list
+// (src/hhhit.h:116-126) after ViterbiRunner::alignment appended the batches serially (src/hhviterbirunner.cpp:173).
+// One workgroup: m <= MERGE_MAX keys are sorted in LDS by a bitonic network (m = ranks x K, a few thousand).
+constexpr int MERGE_MAX = 4096;
+
+__device__ __forceinline__ uint64_t merge_key(const DevHit& h) {
+  if (h.index < 0) return 0;  // padding sorts last
+  uint32_t u = __builtin_bit_cast(uint32_t, h.score);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)h.index);  // valid records: low word >= 0x80000000
+}
+
+__global__ void __launch_bounds__(1024) merge_hits_kernel(const DevHit* __restrict__ in, int m, int k, DevHit* __restrict__ out,
+                                                          int* __restrict__ n_out) {
+  __shared__ uint64_t key[MERGE_MAX];
+  __shared__ uint16_t pos[MERGE_MAX];
+  __shared__ int n_valid;
+  int P = 2;
+  while (P < m) P <<= 1;
+  if (threadIdx.x == 0) n_valid = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    const uint64_t kk = i < m ? merge_key(in[i]) : 0;
+    key[i] = kk;
+    pos[i] = (uint16_t)i;
+    mine += kk != 0;
+  }
+  if (mine) atomicAdd(&n_valid, mine);
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < P / 2; i += blockDim.x) {
+        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;  // final order: descending
+        const uint64_t a = key[lo], b = key[hi];
+        if ((a < b) == desc) {
+          key[lo] = b;
+          key[hi] = a;
+          const uint16_t t = pos[lo];
+          pos[lo] = pos[hi];
+          pos[hi] = t;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nv = min(n_valid, k);
+  for (int t = threadIdx.x; t < k; t += blockDim.x) {
+    DevHit h;
+    if (t < nv) {
+      h = in[pos[t]];
+    } else {
+      h.score = h.viterbi_score = h.score_ss = __builtin_bit_cast(float, 0xFFFFFFFFu);
+      h.index = h.i1 = h.j1 = h.i2 = h.j2 = h.nsteps = h.matched_cols = -1;
+    }
+    out[t] = h;
+  }
+  if (threadIdx.x == 0) *n_out = nv;
+}
+
+// general case (m > MERGE_MAX): keys to global memory, hipCUB pair sort
+__global__ void merge_keys_kernel(const DevHit* __restrict__ in, int m, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                  int* __restrict__ n_valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < m) {
+    const uint64_t kk = merge_key(in[i]);
+    keys[i] = kk;
+    vals[i] = (uint32_t)i;
+    ok = kk != 0;
+  }
+  const unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
+}
+__global__ void merge_gather_kernel(const DevHit* __restrict__ in, const uint32_t* __restrict__ order, int k, int* __restrict__ n_valid,
+                                    DevHit* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k) return;
+  const int nv = min(*n_valid, k);
+  DevHit h;
+  if (t < nv) {
+    h = in[order[t]];
+  } else {
+    h.score = h.viterbi_score = h.score_ss = __builtin_bit_cast(float, 0xFFFFFFFFu);
+    h.index = h.i1 = h.j1 = h.i2 = h.j2 = h.nsteps = h.matched_cols = -1;
+  }
+  out[t] = h;
+}
+
+__global__ void merge_fix_count_kernel(int* n_valid, int k) { *n_valid = min(*n_valid, k); }
+
+// d_n: one device int (receives min(k, valid records)).  Asynchronous on `stream`.
+int merge_hits_device(const DevHit* d_in, int m, int k, DevHit* d_out, int* d_n, hipStream_t stream, std::string* err) {
+  if (m <= MERGE_MAX) {
+    hipLaunchKernelGGL(merge_hits_kernel, dim3(1), dim3(1024), 0, stream, d_in, m, k, d_out, d_n);
+  } else {
+    uint64_t *keys = nullptr, *keys2 = nullptr;
+    uint32_t *vals = nullptr, *vals2 = nullptr;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, keys, keys2, vals, vals2, m, 0, 64, stream);
+    hipError_t e = hipMalloc(&keys, (size_t)m * 8);
+    if (e == hipSuccess) e = hipMalloc(&keys2, (size_t)m * 8);
+    if (e == hipSuccess) e = hipMalloc(&vals, (size_t)m * 4);
+    if (e == hipSuccess) e = hipMalloc(&vals2, (size_t)m * 4);
+    if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1);
+    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(int), stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(merge_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, d_in, m, keys, vals, d_n);
+      e = hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, keys, keys2, vals, vals2, m, 0, 64, stream);
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(merge_gather_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, d_in, vals2, k, d_n, d_out);
+      hipLaunchKernelGGL(merge_fix_count_kernel, dim3(1), dim3(1), 0, stream, d_n, k);
+      e = hipStreamSynchronize(stream);
+    }
+    (void)hipFree(keys);
+    (void)hipFree(keys2);
+    (void)hipFree(vals);
+    (void)hipFree(vals2);
+    (void)hipFree(temp);
+    if (e != hipSuccess) {
+      if (err) *err = std::string("merge (general path): ") + hipGetErrorString(e);
+      return -1;
+    }
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    if (err) *err = std::string("merge: ") + hipGetErrorString(e);
+    return -1;
+  }
+  return 0;
 }
 
 __global__ void results_to_hits_kernel(const DevResult* __restrict__ res, int n, DevHit* __restrict__ hits) {
@@ -61,8 +201,8 @@ void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t 
 }
 
 // keys/sorted: n uint64 each, temp: topk_temp_bytes(n).  Asynchronous on `stream`.
-int topk_device(const DevHit* d_hits, int n, int k, DevHit* d_out, uint64_t* keys, uint64_t* sorted, void* temp,
-                size_t temp_bytes, hipStream_t stream, std::string* err) {
+int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit* d_out, uint64_t* keys, uint64_t* sorted,
+                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err) {
   const int threads = 256;
   hipLaunchKernelGGL(topk_keys_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, d_hits, n, keys);
   hipError_t e = hipcub::DeviceRadixSort::SortKeysDescending(temp, temp_bytes, keys, sorted, n, 0, 64, stream);
@@ -71,7 +211,7 @@ int topk_device(const DevHit* d_hits, int n, int k, DevHit* d_out, uint64_t* key
     return -1;
   }
   hipLaunchKernelGGL(topk_gather_kernel, dim3((k + threads - 1) / threads), dim3(threads), 0, stream, d_hits, sorted, k,
-                     d_out);
+                     gids, d_out);
   e = hipGetLastError();
   if (e != hipSuccess) {
     if (err) *err = std::string("gather: ") + hipGetErrorString(e);

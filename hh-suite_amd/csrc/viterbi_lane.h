@@ -82,8 +82,9 @@ HHV_DEV float fmax2(float a, float b) {
 // RECORDS the nine comparisons of a cell, one bit each, in evaluation order: acc = 2*acc + (a > b) is two instructions
 // (v_cmp to VCC, v_addc with VCC as carry-in) and needs no select, shift or or.  The byte is decoded where it is read
 // (trace kernel, hhv_backtrace_matrix) by bt_decode below.
-//   phase A, rows R-1 .. 0, seven bits per row: c1 > smin, c2 > m, c3 > m, c4 > m, c5 > m (m = running maximum, so the
-//            MM predecessor is the LAST candidate that won), GD: ga > gb, IM: ia > ib;  rows R-1..1 -> lo, row 0 -> hi[2R+6:2R]
+//   phase A1, rows R-1 .. 0, five bits per row: c1 > smin, c2 > m, c3 > m, c4 > m, c5 > m (m = running maximum, so the
+//            MM predecessor is the LAST candidate that won);  rows R-1..1 -> lo[7(R-1)-1 : 2(R-1)], row 0 -> hi[2R+6 : 2R+2]
+//   phase A2, rows R-1 .. 0, two bits per row: GD: ga > gb, IM: ia > ib;  rows R-1..1 -> lo[2(R-1)-1 : 0], row 0 -> hi[2R+1 : 2R]
 //   phase C, rows 0 .. R-1, two bits per row: DG: da > db, MI: ma > mb                 -> hi[2R-1:0]
 HHV_DEV void bt_push(uint32_t& acc, float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -95,7 +96,8 @@ HHV_DEV void bt_push(uint32_t& acc, float a, float b) {
 // entry -> the reference's byte for row r of the lane (bits 0-2 MM predecessor, 8 GD, 16 IM, 32 DG, 64 MI)
 HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R) {
   const uint32_t lo = (uint32_t)entry, hi = (uint32_t)(entry >> 32);
-  const uint32_t f7 = r >= 1 ? (lo >> (7 * (r - 1))) & 0x7Fu : (hi >> (2 * R)) & 0x7Fu;
+  const uint32_t f7 = r >= 1 ? (((lo >> (2 * (R - 1) + 5 * (r - 1))) & 0x1Fu) << 2) | ((lo >> (2 * (r - 1))) & 3u)
+                             : (hi >> (2 * R)) & 0x7Fu;
   const uint32_t c2 = (hi >> (2 * (R - 1 - r))) & 3u;
   uint32_t b = 0;
   if (f7 & 0x40u) b = 2;  // c1 > smin            : MM
@@ -310,12 +312,13 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
 //   tr(k)        k = 0..6: the record's M2M, M2D, D2M, D2D, I2M, I2I, M2I      (needed first, phase A)
 //   get_p(tp)    the 20 profile values, valid from phase B on (a source may still be waiting for them before)
 //   qa(r, w)     QL only: w = 0 m2i, 1 i2i of row r (phase A);   qc(r, w): w = 0 m2d, 1 d2d (phase C)
-//   begin_column / before_B / before_C   issue and wait points of an asynchronous source
+//   begin_column / before_A2 / before_B / before_C   issue and wait points of an asynchronous source
 struct ArraySrc {
   static constexpr bool QL = false;
   const float* rec;
   HHV_MEM void begin_column() {}
   HHV_MEM float tr(int k) const { return rec[REC_M2M + k]; }
+  HHV_MEM void before_A2() {}
   HHV_MEM void before_B() {}
   HHV_MEM void get_p(float* tp) const {
     for (int a = 0; a < 20; ++a) tp[a] = rec[a];
@@ -348,21 +351,23 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   float cmax[R];
   uint32_t acc_lo = 0, acc_hi = 0;  // BT: compare bits of rows R-1..1 / of row 0 and phase C (layout: bt_decode)
   // ---- phase A, rows R-1 .. 0: reads (i-1, j-1) = old state of the row above and (i, j-1) = own old state
+  if (BT) {
+    // backtrace variants, two sweeps: A1 = the MM candidates of all rows (they read only registers and the record head),
+    // A2 = the GD / IM updates, which overwrite what A1 read and need the query's {m2i, i2i} - with a QL source those
+    // come from LDS and have had the whole of A1 to arrive (src.before_A2()).
 #pragma unroll
-  for (int r = R - 1; r >= 0; --r) {
-    const float dMM = r ? st.MM[r - 1] : st.dMM, dGD = r ? st.GD[r - 1] : st.dGD, dIM = r ? st.IM[r - 1] : st.dIM,
-                dDG = r ? st.DG[r - 1] : st.dDG, dMI = r ? st.MI[r - 1] : st.dMI;
-    // :241-273
-    const float c1 = (SHARE ? st.aMM[r] : (dMM + q.m2m[r])) + tM2M;
-    const float c2 = (dGD + q.m2m[r]) + tD2M;
-    const float c3 = (dIM + q.i2m[r]) + tM2M;
-    const float c4 = (dDG + q.d2m[r]) + tM2M;
-    const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
-    uint32_t& acc = r ? acc_lo : acc_hi;
-    float mm;
-    if (BT) {
+    for (int r = R - 1; r >= 0; --r) {
+      const float dMM = r ? st.MM[r - 1] : st.dMM, dGD = r ? st.GD[r - 1] : st.dGD, dIM = r ? st.IM[r - 1] : st.dIM,
+                  dDG = r ? st.DG[r - 1] : st.dDG, dMI = r ? st.MI[r - 1] : st.dMI;
+      // :241-273
+      const float c1 = (SHARE ? st.aMM[r] : (dMM + q.m2m[r])) + tM2M;
+      const float c2 = (dGD + q.m2m[r]) + tD2M;
+      const float c3 = (dIM + q.i2m[r]) + tM2M;
+      const float c4 = (dDG + q.d2m[r]) + tM2M;
+      const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
+      uint32_t& acc = r ? acc_lo : acc_hi;
       bt_push(acc, c1, smin);
-      mm = fmax2(smin, c1);
+      float mm = fmax2(smin, c1);
       bt_push(acc, c2, mm);
       mm = fmax2(mm, c2);
       bt_push(acc, c3, mm);
@@ -371,21 +376,41 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
       mm = fmax2(mm, c4);
       bt_push(acc, c5, mm);
       mm = fmax2(mm, c5);
-    } else {
-      mm = fmax2(fmax2(fmax2(fmax2(fmax2(smin, c1), c2), c3), c4), c5);
+      cmax[r] = mm;
     }
-    cmax[r] = mm;
-    // :307-332 (GD and IM read only the cell to the left)
-    const float lMM = st.MM[r];
-    const float ga = lMM + tM2D, gb = st.GD[r] + tD2D;
-    const float qm2i = QL ? src.qa(r, 0) : q.m2i[r], qi2i = QL ? src.qa(r, 1) : q.i2i[r];
-    const float ia = (lMM + qm2i) + tM2M, ib = (st.IM[r] + qi2i) + tM2M;
-    if (BT) {
+    src.before_A2();
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+      // :307-332 (GD and IM read only the cell to the left)
+      const float lMM = st.MM[r];
+      const float ga = lMM + tM2D, gb = st.GD[r] + tD2D;
+      const float qm2i = QL ? src.qa(r, 0) : q.m2i[r], qi2i = QL ? src.qa(r, 1) : q.i2i[r];
+      const float ia = (lMM + qm2i) + tM2M, ib = (st.IM[r] + qi2i) + tM2M;
+      uint32_t& acc = r ? acc_lo : acc_hi;
       bt_push(acc, ga, gb);
       bt_push(acc, ia, ib);
+      st.GD[r] = fmax2(ga, gb);
+      st.IM[r] = fmax2(ia, ib);
     }
-    st.GD[r] = fmax2(ga, gb);
-    st.IM[r] = fmax2(ia, ib);
+  } else {
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+      const float dMM = r ? st.MM[r - 1] : st.dMM, dGD = r ? st.GD[r - 1] : st.dGD, dIM = r ? st.IM[r - 1] : st.dIM,
+                  dDG = r ? st.DG[r - 1] : st.dDG, dMI = r ? st.MI[r - 1] : st.dMI;
+      // :241-273.  Score only: c1, c3 and c4 add the same tM2M.  x -> fl(x + t) is monotonic (round to nearest), hence
+      // max(fl(x1+t), fl(x3+t), fl(x4+t)) == fl(max(x1, x3, x4) + t) bit for bit: one addition instead of three.
+      // (The backtrace variants cannot do this: their compare bits must see the rounded sums, which can tie where the x do not.)
+      const float x1 = SHARE ? st.aMM[r] : (dMM + q.m2m[r]), x3 = dIM + q.i2m[r], x4 = dDG + q.d2m[r];
+      const float c2 = (dGD + q.m2m[r]) + tD2M;
+      const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
+      cmax[r] = fmax2(smin, fmax2(fmax2(fmax2(fmax2(x1, x3), x4) + tM2M, c2), c5));
+      // :307-332 (GD and IM read only the cell to the left); IM with the same monotonicity argument
+      const float lMM = st.MM[r];
+      const float ga = lMM + tM2D, gb = st.GD[r] + tD2D;
+      const float qm2i = QL ? src.qa(r, 0) : q.m2i[r], qi2i = QL ? src.qa(r, 1) : q.i2i[r];
+      st.IM[r] = fmax2(lMM + qm2i, st.IM[r] + qi2i) + tM2M;
+      st.GD[r] = fmax2(ga, gb);
+    }
   }
   // ---- phase B: :277-283
   src.before_B();

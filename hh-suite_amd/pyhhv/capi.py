@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_hits",
     "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan",
+    "hhv_tset_set_global_ids", "hhv_merge_hits",
 ]
 
 
@@ -151,6 +152,8 @@ def load():
     L.hhv_hit_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, c_int_p]
     L.hhv_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, c_int_p]
+    L.hhv_tset_set_global_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hhv_merge_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_int_p]
     _lib = L
     return L
 
@@ -567,6 +570,24 @@ class Context:
         n = C.c_int32()
         _check(self.lib.hhv_topk(self.h, ts.h, int(k), 1 if raw else 0, out.ctypes.data if fetch else None,
                                  C.c_void_p(d_out) if d_out else None, C.byref(n)))
+        return (out[:n.value] if fetch else None), n.value
+
+    def set_global_ids(self, ts, ids):
+        """ids: global template id of every entry of the shard (None = back to set indices); hhv_topk then reports them"""
+        if ids is None:
+            _check(self.lib.hhv_tset_set_global_ids(self.h, ts.h, None))
+            return
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.shape[0] != ts.n:
+            raise HhvError("set_global_ids: %d ids for %d templates" % (ids.shape[0], ts.n))
+        _check(self.lib.hhv_tset_set_global_ids(self.h, ts.h, ids.ctypes.data_as(C.c_void_p)))
+
+    def merge_hits(self, d_in, m, k, d_out=None, fetch=True):
+        """d_in: device pointer to m hhv_hit records (gathered top-K lists, global ids) -> the k best, merged on the device"""
+        out = np.zeros(k, dtype=HIT_DTYPE) if fetch else None
+        n = C.c_int32()
+        _check(self.lib.hhv_merge_hits(self.h, C.c_void_p(d_in), int(m), int(k), out.ctypes.data if fetch else None,
+                                       C.c_void_p(d_out) if d_out else None, C.byref(n)))
         return (out[:n.value] if fetch else None), n.value
 
 

@@ -103,7 +103,10 @@ def bt_decode(entry, r, R):
     entry = np.asarray(entry, dtype=np.uint64)
     lo = (entry & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     hi = (entry >> np.uint64(32)).astype(np.uint32)
-    f7 = ((lo >> np.uint32(7 * (r - 1))) if r >= 1 else (hi >> np.uint32(2 * R))) & np.uint32(0x7F)
+    if r >= 1:
+        f7 = (((lo >> np.uint32(2 * (R - 1) + 5 * (r - 1))) & np.uint32(0x1F)) << np.uint32(2)) | ((lo >> np.uint32(2 * (r - 1))) & np.uint32(3))
+    else:
+        f7 = (hi >> np.uint32(2 * R)) & np.uint32(0x7F)
     c2 = (hi >> np.uint32(2 * (R - 1 - r))) & np.uint32(3)
     b = np.zeros(entry.shape, dtype=np.uint8)
     for bit, code in ((0x40, 2), (0x20, 3), (0x10, 4), (0x08, 5), (0x04, 6)):

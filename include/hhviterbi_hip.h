@@ -24,6 +24,9 @@
  *                              ss_hmm_mode argument of Viterbi::Align (src/hhviterbi.cpp:163-177)
  *   hhv_topk                   (new) device-side selection of the K best hits by Hit.score, the
  *                              per-GPU half of the sharded top-K merge
+ *   hhv_tset_set_global_ids / hhv_merge_hits
+ *                              (new) the other half: global template ids in the selected records and the merge of the
+ *                              gathered lists into one hit list ordered like the reference's (src/hhhit.h:116-126)
  *
  * Conventions
  *   - plain C: pointers and sizes only, no C++/torch types.  Host pointers unless a parameter is
@@ -379,6 +382,16 @@ int hhv_hit_path_pool(hhv_ctx* ctx, hhv_tset* ts, const int64_t** path_off, cons
  * multi-GPU caller hands to its all-gather; entries beyond *n_out are filled with 0xFF bytes. */
 #define HHV_TOPK_RAW 1u
 int hhv_topk(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, void* d_out, int32_t* n_out);
+/* Sharded databases (one hhv_ctx / hhv_tset per GPU, hhv_shard_plan): ids[k] >= 0 = the GLOBAL template id of entry k
+ * of this shard (host array, ts->n entries, copied).  From then on hhv_topk reports ids[index] in hhv_hit.index, so that
+ * its output can go straight into the exchange; NULL switches back to the index inside the set. */
+int hhv_tset_set_global_ids(hhv_ctx* ctx, hhv_tset* ts, const int32_t* ids);
+/* The merge half of the sharded top-K: d_in = DEVICE pointer to m hhv_hit records, the concatenation of every shard's
+ * hhv_topk output after the all-gather (records with index < 0 are padding).  Returns the k best by score (descending,
+ * ties by the smaller global id - the order the reference's caller gives the hit list, src/hhhit.h:116-126, after
+ * ViterbiRunner::alignment appended the batches one after the other, src/hhviterbirunner.cpp:173); identical on every
+ * rank.  out: host, k entries (nullable); d_out: DEVICE, k entries (nullable); entries beyond *n_out are 0xFF bytes. */
+int hhv_merge_hits(hhv_ctx* ctx, const void* d_in, int32_t m, int32_t k, hhv_hit* out, void* d_out, int32_t* n_out);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -1,0 +1,95 @@
+"""The merge half of the sharded top-K on the device (hhv_tset_set_global_ids, hhv_merge_hits) against the torch/numpy
+statement of the same order (pyhhv/shard.py::merge_records: score descending, ties by the smaller global id, padding last)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(rng, m, n_pad, ties=True):
+    from pyhhv import capi
+    rec = np.zeros(m, dtype=capi.HIT_DTYPE)
+    score = rng.normal(40.0, 25.0, m).astype(np.float32)
+    if ties:
+        score[rng.integers(0, m, m // 3)] = np.float32(17.25)      # many equal scores: the id decides
+        score[rng.integers(0, m, m // 10)] = np.float32(-3.5)
+    rec["score"] = score
+    rec["viterbi_score"] = score + 1
+    rec["index"] = rng.permutation(4 * m)[:m].astype(np.int32)     # distinct global ids
+    rec["i2"] = rng.integers(1, 300, m)
+    rec["j2"] = rng.integers(1, 300, m)
+    pad = rng.choice(m, n_pad, replace=False)
+    raw = rec.view(np.uint8).reshape(m, -1)
+    raw[pad] = 0xFF                                                 # what hhv_topk writes beyond its n_out
+    return rec
+
+
+def _expected(rec, k):
+    ok = rec["index"] >= 0
+    v = rec[ok]
+    order = np.lexsort((v["index"], -v["score"].astype(np.float64)))
+    return v[order[:k]]
+
+
+@pytest.mark.parametrize("m,k,n_pad", [(500, 500, 0), (500, 500, 37), (4000, 500, 400), (4096, 1000, 0), (10000, 500, 1200),
+                                      (1, 5, 0), (3, 2, 3), (6000, 6000, 100)])
+def test_merge_hits_equals_reference_order(m, k, n_pad):
+    import torch
+    from pyhhv import capi
+    rng = np.random.default_rng(m * 31 + k)
+    rec = _records(rng, m, n_pad)
+    d = torch.from_numpy(rec.view(np.int32).reshape(m, -1).copy()).cuda()
+    c = capi.Context()
+    out, n = c.merge_hits(d.data_ptr(), m, k)
+    exp = _expected(rec, k)
+    assert n == len(exp)
+    assert out.tobytes() == exp.tobytes()
+    # device output buffer: the same records, 0xFF padding behind them
+    dbuf = torch.zeros((k, 10), dtype=torch.int32, device="cuda")
+    _, n2 = c.merge_hits(d.data_ptr(), m, k, d_out=dbuf.data_ptr(), fetch=False)
+    h = dbuf.cpu().numpy()
+    assert n2 == n and h[:n].tobytes() == exp.tobytes()
+    assert (h[n:].view(np.uint8) == 0xFF).all()
+    c.close()
+
+
+def test_merge_equals_torch_merge_records():
+    """the CPU/gloo tests use shard.merge_records; both statements of the order must agree"""
+    import torch
+    from pyhhv import capi, shard
+    rng = np.random.default_rng(5)
+    rec = _records(rng, 3000, 211)
+    t = torch.from_numpy(rec.view(np.int32).reshape(3000, -1).copy())
+    ref = shard.merge_records(torch, t, 500).numpy()
+    c = capi.Context()
+    out, n = c.merge_hits(t.cuda().data_ptr(), 3000, 500)
+    assert n == 500 and out.view(np.int32).reshape(n, -1).tobytes() == ref.tobytes()
+    c.close()
+
+
+def test_topk_reports_global_ids():
+    import torch  # noqa: F401
+    from pyhhv import capi, synth
+    rng = np.random.default_rng(11)
+    q, qtr = synth.make_query(901, 120)
+    tps, ttrs = [], []
+    for k in range(300):
+        p, tr = synth.make_template(5000 + k, int(rng.integers(40, 200)))
+        tps.append(p)
+        ttrs.append(tr)
+    c = capi.Context(local=1)
+    c.set_query(q, qtr)
+    ts = c.upload(tps, ttrs)
+    c.align(ts)
+    base, _ = c.topk(ts, 50, raw=True)
+    gids = (np.arange(300, dtype=np.int32) * 7 + 1000)[::-1].copy()
+    c.set_global_ids(ts, gids)
+    glob, _ = c.topk(ts, 50, raw=True)
+    assert np.array_equal(glob["index"], gids[base["index"]])
+    assert np.array_equal(glob["score"], base["score"])
+    c.set_global_ids(ts, None)
+    again, _ = c.topk(ts, 50, raw=True)
+    assert again.tobytes() == base.tobytes()
+    with pytest.raises(capi.HhvError):
+        c.set_global_ids(ts, -np.ones(300, dtype=np.int32))
+    c.close()

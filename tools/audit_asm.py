@@ -75,7 +75,7 @@ def audit_function(name, body):
     problems = []
     m = re.search(r"hhv_stream_kernelILi\dELb\dELb\dELb(\d)ELb(\d)ELb(\d)E", name)
     loads_in_loop = m is None or "1" in m.groups()
-    pending = set()      # destination registers of issued, not yet waited-for asm reads
+    pending = []         # destination registers of issued, not yet waited-for asm reads, one set per read in issue order
     in_asm = False
     asm_lines = []
     in_loop = False
@@ -89,16 +89,14 @@ def audit_function(name, body):
             continue
         if line.startswith(";;#ASMEND"):
             in_asm = False
-            text = "\n".join(asm_lines)
-            has_read = "ds_read" in text
-            has_wait = "lgkmcnt(0)" in text
-            if has_wait:
-                pending.clear()
-            elif has_read:
-                for a in asm_lines:
-                    if a.startswith("ds_read"):
-                        dst = a.split(",")[0]
-                        pending |= regs_of(dst)
+            # LDS returns a wave's reads in order: lgkmcnt(N) leaves at most the N youngest in flight
+            for a in asm_lines:
+                if a.startswith("ds_read"):
+                    pending.append(regs_of(a.split(",")[0]))
+                w = re.search(r"lgkmcnt\((\d+)\)", a)
+                if w:
+                    n_left = int(w.group(1))
+                    pending = pending[len(pending) - n_left:] if n_left else []
             continue
         if in_asm:
             asm_lines.append(line)
@@ -107,7 +105,7 @@ def audit_function(name, body):
             continue
         code = line.split(";")[0]
         if pending:
-            hit = regs_of(code) & pending
+            hit = regs_of(code) & set().union(*pending)
             if hit:
                 problems.append("%s: line %d touches v%s while its read is in flight: %s" % (name, ln, sorted(hit), code.strip()))
         if in_loop:
@@ -117,7 +115,7 @@ def audit_function(name, body):
             if op == "s_waitcnt" and "vmcnt" in code and not loads_in_loop:
                 problems.append("%s: compiler-generated '%s' in the loop (line %d)" % (name, code.strip(), ln))
     if pending:
-        problems.append("%s: reads still in flight at the end of the function: v%s" % (name, sorted(pending)))
+        problems.append("%s: reads still in flight at the end of the function: v%s" % (name, sorted(set().union(*pending))))
     return problems
 
 

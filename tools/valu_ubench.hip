@@ -109,6 +109,27 @@ __global__ void __launch_bounds__(256) kx(float* out, int iters, float seed) {
     if (KIND == 10) asm volatile(REP8X(CH8("v_min_f32", ", %8")) OUTS);
     if (KIND == 11) asm volatile(REP8X(CH8("v_max_u32", ", %8")) OUTS);                    // integer max
     if (KIND == 12) asm volatile(REP8X(CH8("v_max_i32", ", %8")) OUTS);
+    // compare-bit accumulation without v_cmp: sign of (b - a) shifted into the accumulator by one v_alignbit_b32
+    if (KIND == 13) asm volatile(REP8X("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %8, 31\n v_alignbit_b32 %2, %2, %8, 31\n"
+                                       "v_alignbit_b32 %3, %3, %8, 31\n v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %8, 31\n"
+                                       "v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %8, 31\n") OUTS);
+    if (KIND == 14) asm volatile(REP8X("v_sub_f32 %0, %8, %1\n v_alignbit_b32 %1, %1, %0, 31\n"
+                                       "v_sub_f32 %2, %8, %3\n v_alignbit_b32 %3, %3, %2, 31\n"
+                                       "v_sub_f32 %4, %8, %5\n v_alignbit_b32 %5, %5, %4, 31\n"
+                                       "v_sub_f32 %6, %8, %7\n v_alignbit_b32 %7, %7, %6, 31\n") OUTS);
+    if (KIND == 15) asm volatile(REP8X(CH8("v_lshl_or_b32", ", 1, %8")) OUTS);
+    if (KIND == 16) asm volatile(REP8X(CH8("v_lshl_add_u32", ", 1, %8")) OUTS);
+    if (KIND == 17) asm volatile(REP8X(CH8("v_ashrrev_i32", ", %8")) OUTS);
+    if (KIND == 18) asm volatile(REP8X(CH8("v_add_u32", ", %8")) OUTS);
+    if (KIND == 19) asm volatile(REP8X(CH8("v_xor_b32", ", %8")) OUTS);
+    if (KIND == 20) asm volatile(REP8X(CH8("v_bfi_b32", ", %8, %8")) OUTS);
+    if (KIND == 21) asm volatile(REP8X(CH8("v_perm_b32", ", %8, %8")) OUTS);
+    if (KIND == 22) asm volatile(REP8X(CH8("v_min3_f32", ", %8, %8")) OUTS);
+    if (KIND == 23) asm volatile(REP8X(CH8("v_med3_f32", ", %8, %8")) OUTS);
+    if (KIND == 24) asm volatile(REP8X(CH8("v_mul_legacy_f32", ", %8")) OUTS);
+    if (KIND == 25) asm volatile(REP8X(CH8("v_subrev_f32", ", %8")) OUTS);
+    if (KIND == 26) asm volatile(REP8X(CH8("v_lshlrev_b32", ", %8")) OUTS);
+    if (KIND == 27) asm volatile(REP8X(CH8("v_add3_u32", ", %8, %8")) OUTS);
 #undef OUTS
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -144,6 +165,33 @@ static void run(const char* name, F launch, int width) {
   hipFree(out);
 }
 
+// (a > b) against the sign bit of (b - a): equal for every pair of non-NaN floats if -inf - -inf gives a NaN with a clear sign bit
+__global__ void ksign(const float* v, int n, unsigned* bad, unsigned* nanbits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * n) return;
+  const float a = v[i / n], b = v[i % n];
+  float d;
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(a));
+  const unsigned s = __builtin_bit_cast(unsigned, d) >> 31;
+  if (s != (a > b ? 1u : 0u)) atomicAdd(bad, 1u);
+  if (d != d) atomicOr(nanbits, __builtin_bit_cast(unsigned, d) | 1u);
+}
+
+static void sign_check() {
+  const float vals[] = {0.0f, -0.0f, 1.0f, -1.0f, 1.0000001f, 3.4028235e38f, -3.4028235e38f, __builtin_inff(), -__builtin_inff(), 1e-45f,
+                        -1e-45f, 1.17549435e-38f, -1.17549435e-38f, 1.17549421e-38f, 123.456f, 123.45601f, -77.25f, -77.250008f, 2e-39f, 3e-39f};
+  const int n = sizeof(vals) / sizeof(vals[0]);
+  float* dv;
+  unsigned *dbad, h[2] = {0, 0};
+  hipMalloc(&dv, sizeof(vals));
+  hipMalloc(&dbad, 8);
+  hipMemcpy(dv, vals, sizeof(vals), hipMemcpyHostToDevice);
+  hipMemcpy(dbad, h, 8, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(ksign, dim3((n * n + 255) / 256), dim3(256), 0, 0, dv, n, dbad, dbad + 1);
+  hipMemcpy(h, dbad, 8, hipMemcpyDeviceToHost);
+  printf("sign(b - a) == (a > b): %d pairs of %d special values, %u mismatches; NaN results OR-ed bits %08x\n", n * n, n, h[0], h[1]);
+}
+
 int main() {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
@@ -177,5 +225,21 @@ int main() {
   RUNX("v_lshrrev_b32", 4);
   RUNX("v_or_b32", 5);
   RUNX("v_cmp_e32+v_addc", 6);
+  RUNX("v_alignbit_b32", 13);
+  RUNX("v_sub_f32+v_alignbit", 14);
+  RUNX("v_lshl_or_b32", 15);
+  RUNX("v_lshl_add_u32", 16);
+  RUNX("v_ashrrev_i32", 17);
+  RUNX("v_add_u32", 18);
+  RUNX("v_xor_b32", 19);
+  RUNX("v_bfi_b32", 20);
+  RUNX("v_perm_b32", 21);
+  RUNX("v_min3_f32", 22);
+  RUNX("v_med3_f32", 23);
+  RUNX("v_mul_legacy_f32", 24);
+  RUNX("v_subrev_f32", 25);
+  RUNX("v_lshlrev_b32", 26);
+  RUNX("v_add3_u32", 27);
+  sign_check();
   return 0;
 }
