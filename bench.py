@@ -390,6 +390,15 @@ def main():
     if single and not args.no_next_rows and plain:
         out["next_rows"] = next_rows()
 
+    if single and os.environ.get("HHV_DEBUG_CLK"):
+        # measurement builds (-DHHV_EXP_TIMING, tools/gpu_round2i.sh) export the shader-clock totals of wave 0
+        import ctypes
+        lib = capi.load()
+        if hasattr(lib, "hhv_debug_clk"):
+            ctx.align(ts)
+            buf = (ctypes.c_ulonglong * 8)()
+            lib.hhv_debug_clk(buf)
+            out["debug_clk"] = [int(x) for x in buf]
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -497,6 +497,10 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     if (rc != 0 || nb < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
     blocks_per_cu = blocks_per_cu ? std::min(blocks_per_cu, nb) : nb;
   }
+  if (const char* e = getenv("HHV_BLOCKS_PER_CU")) {  // measurement aid: fewer resident waves per CU than the kernel admits
+    const int v = atoi(e);
+    if (v >= 1) blocks_per_cu = std::min(blocks_per_cu, v);
+  }
   const int n_ranges = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu * arrays, ts->n));
   const int n_waves = (n_ranges + arrays - 1) / arrays;
   rc = ensure_partition(c, ts, n_ranges, n_waves * arrays);

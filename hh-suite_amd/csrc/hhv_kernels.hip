@@ -18,6 +18,12 @@
 #include "hhv_stream_kernel.h"
 #include "viterbi_lane.h"
 
+#if defined(HHV_EXP_TIMING)
+extern "C" __attribute__((visibility("default"))) int hhv_debug_clk(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hhv::hhv_dbg_clk), 8 * sizeof(unsigned long long));
+}
+#endif
+
 namespace hhv {
 
 // ---------------------------------------------------------------------------------------------
@@ -41,7 +47,59 @@ __device__ __forceinline__ float dot20_scalar_dev(const float* __restrict__ q, c
   return r;
 }
 
+// one step of Viterbi::Backtrace (src/hhviterbi.cpp:96-146); b = the reference's backtrace byte of cell (i, j)
+__device__ __forceinline__ void trace_step(int& state, int& i, int& j, int& matched, uint32_t b) {
+  switch (state) {
+    case 2:  // MM
+      matched++;
+      if (i <= 1 || j <= 1) state = 0;
+      else {
+        state = b & 7;
+        i--;
+        j--;
+      }
+      break;
+    case 3:  // GD
+      if (j <= 1) state = 0;
+      else {
+        if (b & 8) state = 2;
+        j--;
+      }
+      break;
+    case 4:  // IM
+      if (j <= 1) state = 0;
+      else {
+        if (b & 16) state = 2;
+        j--;
+      }
+      break;
+    case 5:  // DG
+      if (i <= 1) state = 0;
+      else {
+        if (b & 32) state = 2;
+        i--;
+      }
+      break;
+    case 6:  // MI
+      if (i <= 1) state = 0;
+      else {
+        if (b & 64) state = 2;
+        i--;
+      }
+      break;
+    default:  // :139-144
+      state = 0;
+      break;
+  }
+}
+
 // Kernel 2a: Viterbi::Backtrace (src/hhviterbi.cpp:83-160) - a serial pointer chase, one lane per template.
+// Every step reads one 8-byte entry that depends on the step before - an HBM round trip per step if done naively
+// (the entries of a launch are written once, gigabytes ago).  Single-pass plans therefore read a WINDOW per round trip:
+// from cell (i, j) with entry (row, g) a path can only move to rows row, row - 1, row - 2 and to lane g or g - 1
+// (bt_entry: row = record + lane; a step lowers i and / or j by one), so the ten entries {row .. row - 4} x {g - 1, g} -
+// five independent 16-byte reads - cover the next two steps at least, four on a diagonal; the walk continues out of
+// registers until it leaves the window.
 __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.n) return;
@@ -55,58 +113,54 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   int step = 0, matched = 0;
   int i = res.i2, j = res.j2;
   int state = 2;  // MM
-  while (state != 0) {
-    step++;
-    states[step] = (int8_t)state;
-    i_steps[step] = i;
-    j_steps[step] = j;
-    uint32_t b = 0;
-    if (i >= 1 && j >= 1) {
-      int pass, g, rr, Rp;
-      a.plan.locate(i, pass, g, rr, Rp);
-      b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + bt_entry(rec0 + j, g, a.plan.W)], rr, Rp);
+  if (a.plan.P == 1) {
+    const int R = a.plan.R_hi, W = a.plan.W;
+    constexpr int WIN = 5;
+    while (state != 0) {
+      const int g0 = i >= 1 ? (i - 1) / R : 0;
+      const int c0 = max(g0 - 1, 0);       // first of the two columns of the window (c0 + 1 <= W - 1)
+      const int64_t row0 = rec0 + j + g0;  // row of the entry of (i, j)
+      uint64_t w[WIN][2];
+#pragma unroll
+      for (int d = 0; d < WIN; ++d) {
+        const uint64_t* e = a.bt + (size_t)max<int64_t>(row0 - d, 0) * (size_t)W + (size_t)c0;
+        w[d][0] = e[0];
+        w[d][1] = e[1];
+      }
+#pragma unroll
+      for (int sub = 0; sub < WIN + 1; ++sub) {
+        if (state == 0) break;
+        uint32_t b = 0;
+        if (i >= 1 && j >= 1) {
+          const int g = (i - 1) / R, rr = (i - 1) - g * R;
+          const int d = (int)(row0 - (rec0 + j + g));  // rows behind the anchor, >= 0
+          const int c = g - c0;                        // 0 or 1 inside the window
+          if (d >= WIN || c < 0) break;                // left the window: next round trip (at least one step was made)
+          uint64_t entry = c ? w[0][1] : w[0][0];
+#pragma unroll
+          for (int t = 1; t < WIN; ++t) entry = (d == t) ? (c ? w[t][1] : w[t][0]) : entry;
+          b = bt_decode(entry, rr, R);
+        }
+        step++;
+        states[step] = (int8_t)state;
+        i_steps[step] = i;
+        j_steps[step] = j;
+        trace_step(state, i, j, matched, b);
+      }
     }
-    switch (state) {
-      case 2:  // MM
-        matched++;
-        if (i <= 1 || j <= 1) state = 0;
-        else {
-          state = b & 7;
-          i--;
-          j--;
-        }
-        break;
-      case 3:  // GD
-        if (j <= 1) state = 0;
-        else {
-          if (b & 8) state = 2;
-          j--;
-        }
-        break;
-      case 4:  // IM
-        if (j <= 1) state = 0;
-        else {
-          if (b & 16) state = 2;
-          j--;
-        }
-        break;
-      case 5:  // DG
-        if (i <= 1) state = 0;
-        else {
-          if (b & 32) state = 2;
-          i--;
-        }
-        break;
-      case 6:  // MI
-        if (i <= 1) state = 0;
-        else {
-          if (b & 64) state = 2;
-          i--;
-        }
-        break;
-      default:  // :139-144
-        state = 0;
-        break;
+  } else {
+    while (state != 0) {
+      step++;
+      states[step] = (int8_t)state;
+      i_steps[step] = i;
+      j_steps[step] = j;
+      uint32_t b = 0;
+      if (i >= 1 && j >= 1) {
+        int pass, g, rr, Rp;
+        a.plan.locate(i, pass, g, rr, Rp);
+        b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + bt_entry(rec0 + j, g, a.plan.W)], rr, Rp);
+      }
+      trace_step(state, i, j, matched, b);
     }
   }
   states[step] = 2;  // :147

@@ -9,6 +9,15 @@
 
 namespace hhv {
 
+#if defined(HHV_EXP_TIMING)
+// measurement build only: shader-clock totals of the three sections of a step, summed over the steps of wave 0 of block 0
+// [0] steps, [1] top of the step + phase A, [2] phase B, [3] phase C + the end of the step
+static __device__ unsigned long long hhv_dbg_clk[8];
+// the stamp is one asm statement together with "+v" ties to values produced before / consumed after it, so that hipcc
+// cannot move the arithmetic of the neighbouring phases across it
+#define HHV_STAMP(t_, ...) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), __VA_ARGS__)
+#endif
+
 // lane n <- lane n-1 of the same systolic array; the first lane of an array keeps `old`
 //   W = 64: v_mov_b32_dpp wave_shr:1 (lane 0 keeps old)
 //   W = 16: v_mov_b32_dpp row_shr:1  (a DPP row IS 16 lanes: lanes 0, 16, 32, 48 keep old)
@@ -86,6 +95,9 @@ struct LdsColumn {
   static constexpr int NC = R - C0;
   v4f v0, v1, v2, v3, v4, v5, v6;
   v4f qa0, qa1, qa2, qc0, qc1, qc2;
+#if defined(HHV_EXP_TIMING)
+  unsigned long long tA, tB;
+#endif
   uint32_t rec_addr, ql_addr;  // LDS byte addresses: this lane's record in the ring / its 20 floats of query transitions
 
   __device__ __forceinline__ void head() {
@@ -159,6 +171,9 @@ struct LdsColumn {
   }
   __device__ __forceinline__ void before_B() {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4));
+#if defined(HHV_EXP_TIMING)
+    HHV_STAMP(tA, "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4));
+#endif
     if (QL) {
       // float4 C0 .. R-1 of the lane's 20 floats (for odd R the first one straddles the A block and is read again)
       if (NC == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(qc0) : "v"(ql_addr), "i"(16 * C0));
@@ -177,6 +192,9 @@ struct LdsColumn {
     tp[12] = v3.x, tp[13] = v3.y, tp[14] = v3.z, tp[15] = v3.w;
     tp[16] = v4.x, tp[17] = v4.y, tp[18] = v4.z, tp[19] = v4.w;
   }
+#if defined(HHV_EXP_TIMING)
+  __device__ __forceinline__ void stamp_B(float& a, float& b) { HHV_STAMP(tB, "+v"(a), "+v"(b)); }
+#endif
   __device__ __forceinline__ void before_C() {
     if (QL) {
       if (NC == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qc0));
@@ -301,10 +319,12 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     const uint32_t t = (uint32_t)rr & (4 * C - 1);
     return ring_addr + (t / C) * (CHUNK_RECS * REC_DW * 4) + (t & (C - 1)) * (REC_DW * 4);
   };
-  v4f n6, n5;
+  // PF: two operand sources used in turn - the step that computes with `cur` fetches the head of the next step into
+  // `nxt` (no copy between the steps: the step loop is unrolled by two).
+  decltype(col) col2 = col;
   if (PF) {
-    decltype(col)::head_issue(record_addr(0), n6, n5);
-    decltype(col)::head_wait(n6, n5);
+    decltype(col)::head_issue(record_addr(0), col.v6, col.v5);
+    decltype(col)::head_wait(col.v6, col.v5);
   }
 
   // Later passes of a long query: lane 0 takes the bottom row the previous pass left for its record (a.carry).  The row of
@@ -318,76 +338,99 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       nmi = a.carry_mi[rb];
     }
   }
+  // Hand-off registers that live across the steps (single-pass variants).  The DPP move leaves the first lane of an array
+  // untouched, so that lane keeps the DP boundary (-FLT_MAX, position 0) without being re-initialised every step; GD / IM /
+  // DG are handed over straight into st.dGD / dIM / dDG (see DiagSums).
+  float hMI = NEG_MAX, hfs = NEG_MAX;
+  int hfpos = 0;
+#if defined(HHV_EXP_TIMING)
+  unsigned long long dbg0 = 0, dbg1 = 0, dbg2 = 0, dbg3 = 0;
+#endif
+  const bool head_lane = g == 0;
 
-  // Two nested loops: the outer one walks the ring chunks (one refill each), the inner one the C steps of a chunk, so
-  // that the refill test is not part of a step.
-  const int s_end = Mmax + W - 1;
-  for (int c = 0; c * C - LEAD < s_end; ++c) {
-    if (c > 0) {
-      // chunk c was issued C steps ago: make sure it has landed, then refill the slot that held chunk c-3 (its last
-      // reader, lane W-1, finished at step C(c-2)+2(W-1) < C c - LEAD) with chunk c+1.  The live window [s-W+1, s] spans
-      // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
-      // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (c + 1 < nchunks_max) load_chunk<W>(records, rb_a, nch_a, c + 1, ring, lane);
-    }
-    const int s_lo = c > 0 ? c * C - LEAD : 0, s_hi = min((c + 1) * C - LEAD, s_end);
-  for (int s = s_lo; s < s_hi; ++s) {
+  auto step = [&](const int s, decltype(col)& cur, decltype(col)& nxt) __attribute__((always_inline)) {
     const int r = s - g;
     const bool active = (uint32_t)r < (uint32_t)M;  // 0 <= r < M in one compare
+#if defined(HHV_EXP_TIMING)
+    unsigned long long t0;
+    HHV_STAMP(t0, "+v"(cur.v6), "+v"(cur.v5));
+    cur.tA = t0;
+    cur.tB = t0;
+#endif
 
-    col.rec_addr = record_addr(s);
+    cur.rec_addr = record_addr(s);
     if (PF) {
-      col.v6 = n6;  // landed: waited for at the end of the previous step
-      col.v5 = n5;
-      if (QL) col.qa_issue();
-      decltype(col)::head_issue(record_addr(s + 1), n6, n5);
+      if (QL) cur.qa_issue();
+      decltype(col)::head_issue(record_addr(s + 1), nxt.v6, nxt.v5);
     } else {
-      col.head();
+      cur.head();
     }
-    const int32_t meta = col.meta();
+    const int32_t meta = cur.meta();
 
     // hand-off from lane g-1 (full EXEC here); lane 0 of an array takes the DP boundary row 0, or - in later passes of
     // a long query - the bottom row the previous pass left for this record (and its running best)
-    Incoming bnd = boundary_incoming(meta, P);
-    if (!first) {
-      if (lane == 0 && active) {
-        bnd.MM = ncar.x;
-        bnd.GD = ncar.y;
-        bnd.IM = ncar.z;
-        bnd.DG = ncar.w;
-        bnd.MI = nmi;
-        if (meta < 0 && st.tid >= 0) {
-          const DevResult pr = a.results[st.tid & TID_MASK];
-          bnd.fs = pr.score;
-          bnd.fpos = (pr.i2 << 16) | pr.j2;
+    DiagSums ds = lane_diag(st, q);  // reads the hand-off of the previous step: before the moves below
+    Incoming in = boundary_incoming(meta, P);
+    if (MULTI) {
+      // multi-pass variants: plain hand-off registers (measured 5 % slower with the in-place scheme below).  In later
+      // passes lane 0 takes the bottom row the previous pass left for this record, and its running best.
+      if (!first) {
+        if (lane == 0 && active) {
+          in.MM = ncar.x;
+          in.GD = ncar.y;
+          in.IM = ncar.z;
+          in.DG = ncar.w;
+          in.MI = nmi;
+          if (meta < 0 && st.tid >= 0) {
+            const DevResult pr = a.results[st.tid & TID_MASK];
+            in.fs = pr.score;
+            in.fpos = (pr.i2 << 16) | pr.j2;
+          }
         }
-        if (r + 1 < M) {  // lane 0: r = s
+      }
+      in.MM = dpp_shr1<W>(in.MM, st.MM[R - 1], head_lane);
+      in.GD = dpp_shr1<W>(in.GD, st.GD[R - 1], head_lane);
+      in.IM = dpp_shr1<W>(in.IM, st.IM[R - 1], head_lane);
+      in.DG = dpp_shr1<W>(in.DG, st.DG[R - 1], head_lane);
+      in.MI = dpp_shr1<W>(in.MI, st.MI[R - 1], head_lane);
+      in.fs = dpp_shr1<W>(in.fs, st.fs, head_lane);
+      in.fpos = dpp_shr1<W>(in.fpos, st.fpos, head_lane);
+      // the carry row of the next step is requested only now, behind the moves that consumed this step's row: the load
+      // lands in the same registers and is not waited for before the next step (requested inside the block above, hipcc
+      // loads into temporaries, copies and waits for the round trip on the spot)
+      if (!first) {
+        if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
           ncar = a.carry[rb + r + 1];
           nmi = a.carry_mi[rb + r + 1];
         }
       }
-    }
-    const bool head_lane = g == 0;
-    Incoming in;
-    in.MM = dpp_shr1<W>(bnd.MM, st.MM[R - 1], head_lane);
-    in.GD = dpp_shr1<W>(bnd.GD, st.GD[R - 1], head_lane);
-    in.IM = dpp_shr1<W>(bnd.IM, st.IM[R - 1], head_lane);
-    in.DG = dpp_shr1<W>(bnd.DG, st.DG[R - 1], head_lane);
-    in.MI = dpp_shr1<W>(bnd.MI, st.MI[R - 1], head_lane);
-    // the finalized best only matters to a lane that stands on a header record: the two moves are skipped (wave-uniform
-    // branch, full EXEC inside) in the ~4 of 5 steps in which no lane does
-    in.fs = NEG_MAX;
-    in.fpos = 0;
-    if (MULTI || __builtin_amdgcn_ballot_w64(meta < 0) != 0) {  // (the multi-pass variants measured slower with the branch)
-      in.fs = dpp_shr1<W>(bnd.fs, st.fs, head_lane);
-      in.fpos = dpp_shr1<W>(bnd.fpos, st.fpos, head_lane);
+    } else {
+      // single pass: the first lane of an array is never written by the moves and keeps the DP boundary (-FLT_MAX, position
+      // 0) for the whole kernel, so nothing is re-initialised per step; GD / IM / DG go straight into st.dGD / dIM / dDG
+      asm volatile("" : "+v"(ds.t2), "+v"(ds.x3), "+v"(ds.x4));  // (hipcc would sink the three adds below the moves and copy)
+      in.MM = dpp_shr1<W>(in.MM, st.MM[R - 1], head_lane);
+      st.dGD = dpp_shr1<W>(st.dGD, st.GD[R - 1], head_lane);
+      st.dIM = dpp_shr1<W>(st.dIM, st.IM[R - 1], head_lane);
+      st.dDG = dpp_shr1<W>(st.dDG, st.DG[R - 1], head_lane);
+      hMI = dpp_shr1<W>(hMI, st.MI[R - 1], head_lane);
+      in.GD = st.dGD;
+      in.IM = st.dIM;
+      in.DG = st.dDG;
+      in.MI = hMI;
+      // the finalized best only matters to a lane that stands on a header record: the two moves are skipped (wave-uniform
+      // branch, full EXEC inside) in the ~4 of 5 steps in which no lane does
+      if (__builtin_amdgcn_ballot_w64(meta < 0) != 0) {
+        hfs = dpp_shr1<W>(hfs, st.fs, head_lane);
+        hfpos = dpp_shr1<W>(hfpos, st.fpos, head_lane);
+      }
+      in.fs = hfs;
+      in.fpos = hfpos;
     }
 
     if (active) {
       if (meta < 0) {
         TemplateResult res;
-        const int new_tid = col.header_tid() | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
+        const int new_tid = cur.header_tid() | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
         if (lane_header<R, LOCAL, true>(st, q, in, i0, new_tid, P, g == g_last, res)) {
           DevResult o;
           o.score = res.score;
@@ -410,7 +453,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #pragma unroll
           for (int r = 0; r < R; ++r) ssv[r] = a.ss_table[ss_qoff[r] + tidx];
         }
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS>(st, q, in, col, j, i0, r_last, P, cell, ssv);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS>(st, q, in, ds, cur, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
       if (carry_out) {
@@ -420,9 +463,63 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         }
       }
     }
-    if (PF) decltype(col)::head_wait(n6, n5);  // full EXEC again: the head of step s+1 is in n6 / n5 from here on
+    if (PF) decltype(col)::head_wait(nxt.v6, nxt.v5);  // full EXEC again: the head of step s+1 is in nxt.v6 / v5 from here on
+#if defined(HHV_EXP_TIMING)
+    {
+      unsigned long long tE;
+      HHV_STAMP(tE, "+v"(nxt.v6), "+v"(nxt.v5));
+      dbg0 += 1;
+      dbg1 += cur.tA - t0;
+      dbg2 += cur.tB - cur.tA;
+      dbg3 += tE - cur.tB;
+    }
+#endif
+  };
+
+  // Two nested loops: the outer one walks the ring chunks (one refill each), the inner one the C steps of a chunk, so
+  // that the refill test is not part of a step.
+  const int s_end = Mmax + W - 1;
+  for (int c = 0; c * C - LEAD < s_end; ++c) {
+    if (c > 0) {
+      // chunk c was issued C steps ago: make sure it has landed, then refill the slot that held chunk c-3 (its last
+      // reader, lane W-1, finished at step C(c-2)+2(W-1) < C c - LEAD) with chunk c+1.  The live window [s-W+1, s] spans
+      // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
+      // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (c + 1 < nchunks_max) load_chunk<W>(records, rb_a, nch_a, c + 1, ring, lane);
+    }
+    const int s_lo = c > 0 ? c * C - LEAD : 0, s_hi = min((c + 1) * C - LEAD, s_end);
+    if (PF && !MULTI) {
+      // unrolled by two: the heads alternate between col and col2, no copy between the steps
+      int s = s_lo;
+      for (; s + 1 < s_hi; s += 2) {
+        step(s, col, col2);
+        step(s + 1, col2, col);
+      }
+      if (s < s_hi) {  // odd number of steps (the first chunk, the last one): once per chunk
+        step(s, col, col2);
+        col.v6 = col2.v6;
+        col.v5 = col2.v5;
+      }
+    } else if (PF) {
+      // multi-pass variants (measured 1 % slower unrolled): one step per iteration, the prefetched head is copied
+      for (int s = s_lo; s < s_hi; ++s) {
+        step(s, col, col2);
+        col.v6 = col2.v6;
+        col.v5 = col2.v5;
+      }
+    } else {
+      for (int s = s_lo; s < s_hi; ++s) step(s, col, col);
+    }
   }
+#if defined(HHV_EXP_TIMING)
+  if (blockIdx.x == 0 && lane == 0) {
+    hhv_dbg_clk[0] = dbg0;
+    hhv_dbg_clk[1] = dbg1;
+    hhv_dbg_clk[2] = dbg2;
+    hhv_dbg_clk[3] = dbg3;
   }
+#endif
 }
 
 // ---- kernel selection (instantiates the variants of one W in the including unit) --------------------------------------

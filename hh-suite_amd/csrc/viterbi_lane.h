@@ -188,6 +188,14 @@ struct Incoming {
   int fpos;                  // (i2 << 16) | j2
 };
 
+// Row-0 sums that read the diagonal (i0-1, j-1), i.e. what lane g-1 handed over ONE step ago (st.dGD / dIM / dDG).  They
+// are taken at the top of a step, before this step's hand-off: the kernel then lets the DPP move write the new hand-off
+// values straight into st.dGD / dIM / dDG (no second register set, no copy at the end of the step; the first lane of an
+// array is never written by the move and keeps its boundary value -FLT_MAX for the whole kernel).
+struct DiagSums {
+  float t2, x3, x4;  // dGD + q.m2m[0], dIM + q.i2m[0], dDG + q.d2m[0]   (src/hhviterbialgorithm.cpp:241-273, first add)
+};
+
 template <int R>
 struct LaneState {
   float MM[R], GD[R], IM[R], DG[R], MI[R];  // own rows, column j-1 (the previous step)
@@ -216,6 +224,15 @@ struct LaneState {
     jlast = 0;
   }
 };
+
+template <int R>
+HHV_DEV DiagSums lane_diag(const LaneState<R>& st, const QRows<R>& q) {
+  DiagSums d;
+  d.t2 = st.dGD + q.m2m[0];
+  d.x3 = st.dIM + q.i2m[0];
+  d.x4 = st.dDG + q.d2m[0];
+  return d;
+}
 
 // boundary row 0 as seen by lane 0 (src/hhviterbialgorithm.cpp:144-153,161): MM(0,j) = -j*egt, the rest
 // -FLT_MAX.  On a header step the value becomes the diagonal of cell (1,1), which the reference
@@ -341,8 +358,8 @@ struct ArraySrc {
 //   ssv      : SS only - ssv[r] = ssw * S[q_ss(i0+r)][t_ss(j)], the secondary-structure term of the ...AndSS
 //              builds (src/hhviterbialgorithm.cpp:194-213,278-280), added as ss + log2f4(..) like the reference
 template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, class Src>
-HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, Src& src, int j, int i0,
-                             int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv) {
+HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const DiagSums& ds, Src& src, int j,
+                             int i0, int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv) {
   constexpr bool QL = Src::QL;
   const float smin = LOCAL ? 0.0f : NEG_MAX;
   src.begin_column();
@@ -357,13 +374,12 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     // come from LDS and have had the whole of A1 to arrive (src.before_A2()).
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
-      const float dMM = r ? st.MM[r - 1] : st.dMM, dGD = r ? st.GD[r - 1] : st.dGD, dIM = r ? st.IM[r - 1] : st.dIM,
-                  dDG = r ? st.DG[r - 1] : st.dDG, dMI = r ? st.MI[r - 1] : st.dMI;
-      // :241-273
+      const float dMM = r ? st.MM[r - 1] : st.dMM, dMI = r ? st.MI[r - 1] : st.dMI;
+      // :241-273 (row 0: the first add of c2 / c3 / c4 was taken before the hand-off, lane_diag)
       const float c1 = (SHARE ? st.aMM[r] : (dMM + q.m2m[r])) + tM2M;
-      const float c2 = (dGD + q.m2m[r]) + tD2M;
-      const float c3 = (dIM + q.i2m[r]) + tM2M;
-      const float c4 = (dDG + q.d2m[r]) + tM2M;
+      const float c2 = (r ? st.GD[r - 1] + q.m2m[r] : ds.t2) + tD2M;
+      const float c3 = (r ? st.IM[r - 1] + q.i2m[r] : ds.x3) + tM2M;
+      const float c4 = (r ? st.DG[r - 1] + q.d2m[r] : ds.x4) + tM2M;
       const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
       uint32_t& acc = r ? acc_lo : acc_hi;
       bt_push(acc, c1, smin);
@@ -395,13 +411,13 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   } else {
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
-      const float dMM = r ? st.MM[r - 1] : st.dMM, dGD = r ? st.GD[r - 1] : st.dGD, dIM = r ? st.IM[r - 1] : st.dIM,
-                  dDG = r ? st.DG[r - 1] : st.dDG, dMI = r ? st.MI[r - 1] : st.dMI;
+      const float dMM = r ? st.MM[r - 1] : st.dMM, dMI = r ? st.MI[r - 1] : st.dMI;
       // :241-273.  Score only: c1, c3 and c4 add the same tM2M.  x -> fl(x + t) is monotonic (round to nearest), hence
       // max(fl(x1+t), fl(x3+t), fl(x4+t)) == fl(max(x1, x3, x4) + t) bit for bit: one addition instead of three.
       // (The backtrace variants cannot do this: their compare bits must see the rounded sums, which can tie where the x do not.)
-      const float x1 = SHARE ? st.aMM[r] : (dMM + q.m2m[r]), x3 = dIM + q.i2m[r], x4 = dDG + q.d2m[r];
-      const float c2 = (dGD + q.m2m[r]) + tD2M;
+      const float x1 = SHARE ? st.aMM[r] : (dMM + q.m2m[r]), x3 = r ? st.IM[r - 1] + q.i2m[r] : ds.x3,
+                  x4 = r ? st.DG[r - 1] + q.d2m[r] : ds.x4;
+      const float c2 = (r ? st.GD[r - 1] + q.m2m[r] : ds.t2) + tD2M;
       const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
       cmax[r] = fmax2(smin, fmax2(fmax2(fmax2(fmax2(x1, x3), x4) + tM2M, c2), c5));
       // :307-332 (GD and IM read only the cell to the left); IM with the same monotonicity argument
@@ -424,6 +440,9 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     S[r] = v + P.shift;
   }
   // ---- phase C, rows 0 .. R-1: (i-1, j) = new state of the row above
+#if defined(HHV_EXP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  src.stamp_B(S[0], S[R - 1]);
+#endif
   src.before_C();
   float uMM = in.MM, uDG = in.DG, uMI = in.MI;
 #pragma unroll

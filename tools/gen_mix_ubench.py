@@ -81,15 +81,35 @@ PATTERNS = [
     ("(A*31 Y)*8 ds_write_b128", ("A" * 31 + "Y") * 8),
     ("(A*31 R)*8 ds_read+wait", ("A" * 31 + "R") * 8),
     ("(A*31 G)*8 store8", ("A" * 31 + "G") * 8),
+    # dependent chains: the same pattern over fewer independent accumulators (1 = every instruction waits for the one before)
+    ("A*256 1 chain", "A" * 256, 1),
+    ("A*256 2 chains", "A" * 256, 2),
+    ("A*256 4 chains", "A" * 256, 4),
+    ("U*256 1 chain", "U" * 256, 1),
+    ("M*256 1 chain", "M" * 256, 1),
+    ("M*256 2 chains", "M" * 256, 2),
+    ("(MAAA)*64 1 chain", "MAAA" * 64, 1),
+    ("(MAAA)*64 2 chains", "MAAA" * 64, 2),
+    ("(MAAA)*64 4 chains", "MAAA" * 64, 4),
+    ("(F)*128 add->max 1 chain", "F" * 128, 1),
+    ("(F)*128 add->max 2 chains", "F" * 128, 2),
+    ("(F)*128 add->max 5 chains", "F" * 128, 5),
+    ("(X)*256 max3 2 chains", "X" * 256, 2),
+    ("(A*15 i A*15 W)*8 ds_read", ("A" * 15 + "i" + "A" * 15 + "W") * 8),
+    ("(A*63 i A*63 W)*2 ds_read", ("A" * 63 + "i" + "A" * 63 + "W") * 2),
+    ("(A*100 D*7 A*340 T) step-like", "A" * 100 + "D" * 7 + "A" * 340 + "T"),
+    ("(A*100 D*7 V A*340 T) step-like", "A" * 100 + "D" * 7 + "V" + "A" * 340 + "T"),
+    ("(A*440 T) step-like", "A" * 440 + "T"),
 ]
 
 
-def emit(pat):
+def emit(pat, nacc=16):
+    """nacc = number of independent accumulators the pattern cycles through (1 = one dependent chain)"""
     out = []
     k = 0
     for ch in pat:
-        r = "%%%d" % (k % 16)
-        r2 = "%%%d" % ((k + 1) % 16)
+        r = "%%%d" % (k % nacc)
+        r2 = "%%%d" % ((k + 1) % nacc)
         if ch == "A":
             out.append("v_add_f32 %s, %s, %%16" % (r, r))
         elif ch == "U":
@@ -172,6 +192,12 @@ def emit(pat):
         elif ch == "G":
             out.append("global_store_dwordx2 %18, v[100:101], off")
             continue
+        elif ch == "i":  # ds_read_b128 issued, waited for by a later W
+            out.append("ds_read_b128 v[100:103], %17")
+            continue
+        elif ch == "F":  # dependent v_add -> v_max pair on one register (phase A / C chains)
+            out.append("v_add_f32 %s, %s, %%16" % (r, r))
+            out.append("v_max_f32 %s, %s, %%16" % (r, r))
         elif ch == "C":
             out.append("v_cmp_gt_f32_e32 vcc, %s, %%16" % r)
             out.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (r2, r2, r2))
@@ -186,8 +212,9 @@ def emit(pat):
 
 def main():
     src = ['// generated by tools/gen_mix_ubench.py - do not edit', '#include <hip/hip_runtime.h>', '#include <stdio.h>', '']
-    for idx, (name, pat) in enumerate(PATTERNS):
-        ins = emit(pat)
+    for idx, item in enumerate(PATTERNS):
+        name, pat = item[0], item[1]
+        ins = emit(pat, *item[2:])
         body = "\\n".join(ins) + "\\n"
         src.append('__global__ void __launch_bounds__(256) k%d(float* out, int iters, float bb) {' % idx)
         src.append('  __shared__ float lds[1024]; lds[threadIdx.x] = bb; __syncthreads();')
@@ -204,8 +231,9 @@ def main():
         src.append('')
     src.append('struct Case { const char* name; void (*fn)(float*, int, float); int n_inst; };')
     src.append('static Case cases[] = {')
-    for idx, (name, pat) in enumerate(PATTERNS):
-        n = len([x for x in emit(pat) if not x.endswith(':')])
+    for idx, item in enumerate(PATTERNS):
+        name, pat = item[0], item[1]
+        n = len([x for x in emit(pat, *item[2:]) if not x.endswith(':')])
         src.append('  {"%s", k%d, %d},' % (name, idx, (4 if n <= 32 else 1) * n))
     src.append('};')
     src.append(r'''

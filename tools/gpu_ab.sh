@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 LIBS=${HHV_AB_LIBS:-"base hip"}
 CFGS=${HHV_AB_CFGS:-"--lq 300 --templates 100000"}
-for rep in 1 2 3; do
+for rep in $(seq 1 ${HHV_AB_REPS:-3}); do
   IFS='|' read -ra CF <<< "$CFGS"
   for cfg in "${CF[@]}"; do
     for l in $LIBS; do
