@@ -36,6 +36,9 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 
                                           # 2 flops on the same issue rate; the reference arithmetic has no FMA
                                           # (separate mul and add are part of the parity contract), so 78.6 T is the bound.
 VALU_PEAK_FMA_TFLOPS = 157.3
+# measured: two waves per SIMD of a 64-thread / 248-VGPR kernel retire one v_add_f32 wave-instruction per 2.25 clk (nominal
+# 2.4 GHz) per SIMD - tools/gen_shape_ubench.py, profiles/r2_shape_ubench.txt
+MEASURED_ISSUE_CEILING = 256 * 4 * 64 / 2.25 * 2.4e9
 PROFILE_JSON = "r2_summary.json"
 REC_BYTES = 112
 OPS_PER_CELL = 92          # SURVEY.md 8d / BASELINE.md 5: fp32 operations per DP cell of the reference
@@ -357,6 +360,11 @@ def main():
             "achieved_lane_ops_per_s": lane_ops / (k_ms * 1e-3),
             "frac_of_issue_peak": lane_ops / (k_ms * 1e-3) / VALU_PEAK_LANEOPS,
             "source": "profiles/%s (SQ_INSTS_VALU per launch) / kernel_ms of this run" % PROFILE_JSON,
+            # what a SIMD of this chip actually issues: a plain v_add_f32 stream in a kernel of this shape (64-thread
+            # workgroups, 248 VGPRs, two waves per SIMD) retires one wave-instruction per 2.23-2.29 clk of the nominal 2.4 GHz
+            # (a lone wave one per 4.5), profiles/r2_shape_ubench.txt - the ceiling the kernel's 2 waves per SIMD can reach
+            "measured_issue_ceiling_lane_ops_per_s": MEASURED_ISSUE_CEILING,
+            "frac_of_measured_issue_ceiling": lane_ops / (k_ms * 1e-3) / MEASURED_ISSUE_CEILING,
         }
 
     single = rank == 0 and world == 1 and args.virtual_shards == 1
