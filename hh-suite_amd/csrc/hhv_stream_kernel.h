@@ -266,6 +266,11 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   P.egt = a.egt;
   P.shift = a.shift;
   P.Lq = a.Lq;
+  // log2f4's constants as SGPR operands instead of 32-bit literals (viterbi_lane.h: Log2Consts); the asm keeps hipcc from
+  // folding them back into the instructions
+  asm volatile("s_mov_b32 %0, 0xbddba835\n\ts_mov_b32 %1, 0x3f3030c0\n\ts_mov_b32 %2, 0xbfe0d411\n\ts_mov_b32 %3, 0x402786ee\n\t"
+               "s_mov_b32 %4, 0x4b00007f\n\ts_mov_b32 %5, 0x4b000000\n\ts_mov_b32 %6, 0x007fffff"
+               : "=s"(P.lg.c4), "=s"(P.lg.c3), "=s"(P.lg.c2), "=s"(P.lg.c1), "=s"(P.lg.ebias), "=s"(P.lg.expor), "=s"(P.lg.mant));
   const int i0 = a.row_base + g * R + 1;
   // the lane that emits results: owner of row Lq in the last pass, the array's last lane otherwise
   const int g_last = (!MULTI || a.pass_last) ? (a.Lq - a.row_base - 1) / R : W - 1;
@@ -312,9 +317,13 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   constexpr int LEAD = PF ? 1 : 0;
+  // the ring arithmetic's constants as SGPR operands as well (three more literal-carrying instructions per step otherwise)
+  uint32_t k_ring_mask, k_rec_bytes, k_jmask;
+  asm volatile("s_mov_b32 %0, %3\n\ts_mov_b32 %1, %4\n\ts_mov_b32 %2, %5"
+               : "=s"(k_ring_mask), "=s"(k_rec_bytes), "=s"(k_jmask) : "i"(RING_RECS - 1), "i"(REC_DW * 4), "i"(META_JMASK));
   auto record_addr = [&](int step) -> uint32_t {
     const int rr = step - g;
-    if (W == LANES) return ring_addr + (uint32_t)(rr & (RING_RECS - 1)) * (REC_DW * 4);
+    if (W == LANES) return ring_addr + ((uint32_t)rr & k_ring_mask) * k_rec_bytes;
     // slot (r / C) & 3 of the ring, record r % C of this array's section of the slot
     const uint32_t t = (uint32_t)rr & (4 * C - 1);
     return ring_addr + (t / C) * (CHUNK_RECS * REC_DW * 4) + (t & (C - 1)) * (REC_DW * 4);
@@ -370,7 +379,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     // hand-off from lane g-1 (full EXEC here); lane 0 of an array takes the DP boundary row 0, or - in later passes of
     // a long query - the bottom row the previous pass left for this record (and its running best)
     DiagSums ds = lane_diag(st, q);  // reads the hand-off of the previous step: before the moves below
-    Incoming in = boundary_incoming(meta, P);
+    const int jcol = meta & (int)k_jmask;  // column index of a column record
+    Incoming in = boundary_incoming(meta, jcol, P);
     if (MULTI) {
       // multi-pass variants: plain hand-off registers (measured 5 % slower with the in-place scheme below).  In later
       // passes lane 0 takes the bottom row the previous pass left for this record, and its running best.
@@ -440,7 +450,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
           a.results[res.tid] = o;
         }
       } else {
-        const int j = meta & META_JMASK;
+        const int j = jcol;
         uint64_t cell = 0;
         uint64_t* bte = nullptr;
         // entry of (record rb + r, lane g): row rb + r + g = rb + s, the same row for all lanes of the array (bt_entry)

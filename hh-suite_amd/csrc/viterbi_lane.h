@@ -25,10 +25,12 @@
 #define HHV_DEV __device__ __forceinline__
 #define HHV_MEM __device__ __forceinline__
 #define HHV_HD __host__ __device__ __forceinline__
+#define HHV_HDMEM __host__ __device__ __forceinline__
 #else
 #define HHV_DEV static inline
 #define HHV_MEM inline
 #define HHV_HD static inline
+#define HHV_HDMEM inline
 #endif
 
 namespace hhv {
@@ -112,28 +114,50 @@ HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R) {
   return b;
 }
 
+// The constants of log2f4.  On the device the kernel pins them in SGPRs (hhv_stream_kernel.h: Log2Consts::pinned()): as
+// 32-bit literals they make 8-byte instructions, and a literal-carrying VOP2 costs a wave ~0.3 clk more than one with an SGPR
+// operand (tools/gen_replay_ubench.py: the emission phase replayed with and without its literals, 4.81 vs 4.53 clk per
+// instruction; 30 such instructions per step).  Same values either way.
+struct Log2Consts {
+  float c4, c3, c2, c1;  // -0.10725..., 0.68824..., -1.75647..., 2.61761...  (src/hhutil-inl.h:530-535)
+  float ebias;           // 8388608 + 127
+  uint32_t expor;        // bits of 8388608.0f
+  uint32_t mant;         // mantissa mask
+  HHV_HDMEM static Log2Consts literal() {
+    Log2Consts k;
+    k.c4 = -0.107254423828329604454f;
+    k.c3 = 0.688243882994381274313f;
+    k.c2 = -1.75647175389045657003f;
+    k.c1 = 2.61761038894603480148f;
+    k.ebias = 8388735.0f;
+    k.expor = 0x4B000000u;
+    k.mant = 0x007FFFFFu;
+    return k;
+  }
+};
+
 // src/hhutil-inl.h:509-541, one rounding per operation
-HHV_DEV float log2f4(float x) {
+HHV_DEV float log2f4(float x, const Log2Consts& K) {
   const uint32_t i = f2bits(x);
 #if defined(__HIP_DEVICE_COMPILE__)
-  // e = float(biased exponent - 127) without v_bfe / v_cvt (half-rate issue on gfx950, profiles/r2_valu_ubench.txt): the
+  // e = float(biased exponent - 127) without v_cvt (half-rate issue on gfx950, profiles/r2_valu_ubench.txt): the
   // exponent field is dropped into the mantissa of 2^23 - bits 0x4B000000 | E are the float 8388608 + E exactly - and
-  // 8388608 + 127 is subtracted; every step is exact, so e is the same float the int -> float conversion gives
-  // (and, shift, or, sub: four full-rate VOP2 operations).
-  const float e = bits2f(((i & 0x7F800000u) >> 23) | 0x4B000000u) - 8388735.0f;
+  // 8388608 + 127 is subtracted; every step is exact, so e is the same float the int -> float conversion gives.
+  const float e = bits2f(((i & 0x7F800000u) >> 23) | K.expor) - K.ebias;
 #else
   const float e = (float)((int32_t)((i & 0x7F800000u) >> 23) - 127);
 #endif
-  const float m = bits2f((i & 0x007FFFFFu) | 0x3F800000u);
-  float p = -0.107254423828329604454f * m;
-  p = p + 0.688243882994381274313f;
+  const float m = bits2f((i & K.mant) | 0x3F800000u);
+  float p = K.c4 * m;
+  p = p + K.c3;
   p = p * m;
-  p = p + -1.75647175389045657003f;
+  p = p + K.c2;
   p = p * m;
-  p = p + 2.61761038894603480148f;
+  p = p + K.c1;
   p = p * (m - 1.0f);
   return p + e;
 }
+HHV_DEV float log2f4(float x) { return log2f4(x, Log2Consts::literal()); }
 
 // src/hhviterbi.h:126-161: four partial accumulators, (r0+r1)+(r2+r3)
 HHV_DEV float dot20(const float* q, const float* t) {
@@ -156,6 +180,7 @@ HHV_DEV float dot20(const float* q, const float* t) {
 struct Params {
   float egq, egt, shift;
   int Lq;
+  Log2Consts lg = Log2Consts::literal();
 };
 
 // query rows owned by one lane (row i = i0 + r)
@@ -237,15 +262,16 @@ HHV_DEV DiagSums lane_diag(const LaneState<R>& st, const QRows<R>& q) {
 // boundary row 0 as seen by lane 0 (src/hhviterbialgorithm.cpp:144-153,161): MM(0,j) = -j*egt, the rest
 // -FLT_MAX.  On a header step the value becomes the diagonal of cell (1,1), which the reference
 // initialises as -(i-1)*egq = -0*egq (:161).
-HHV_DEV Incoming boundary_incoming(int32_t meta, const Params& P) {
+HHV_DEV Incoming boundary_incoming(int32_t meta, int j /* meta & META_JMASK */, const Params& P) {
   Incoming in;
   if (meta < 0) in.MM = (float)(-0) * P.egq;
-  else in.MM = (float)(-(meta & META_JMASK)) * P.egt;
+  else in.MM = (float)(-j) * P.egt;
   in.GD = in.IM = in.DG = in.MI = NEG_MAX;
   in.fs = NEG_MAX;
   in.fpos = 0;
   return in;
 }
+HHV_DEV Incoming boundary_incoming(int32_t meta, const Params& P) { return boundary_incoming(meta, meta & META_JMASK, P); }
 
 struct TemplateResult {
   float score;
@@ -435,7 +461,7 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   float S[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float v = log2f4(dot20(q.p[r], tp));
+    float v = log2f4(dot20(q.p[r], tp), P.lg);
     if (SS) v = ssv[r] + v;
     S[r] = v + P.shift;
   }
