@@ -18,8 +18,26 @@ static __device__ unsigned long long hhv_dbg_clk[8];
 #define HHV_STAMP(t_, ...) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), __VA_ARGS__)
 #endif
 
+// Hand-off lane n <- lane n-1: pulled through the LDS crossbar (ds_bpermute_b32: no LDS memory, returns on lgkmcnt like a
+// read) at the top of the step and delivered LATE - MM / DG / MI of the row above are first needed in phase C, GD / IM / DG as
+// next step's diagonal - so the round trip (300+ clk under this kernel's LDS load) lies under phases A and B.  Rounds 1-2a
+// used v_mov_b32_dpp wave_shr:1 / row_shr:1: with two waves per SIMD those moves cost ~10 % of the kernel (the launch with
+// plain v_mov in their place - wrong results, timing only - 16.27 -> 14.67 ms, profiles/r2_ab_session2.txt ab9; replaying
+// one step of the kernel's own ISA, tools/gen_step_replay_ubench.py, a DPP move holds up the other wave of the SIMD).
+__device__ __forceinline__ void pull5(uint32_t addr, float& d0, float& d1, float& d2, float& d3, float& d4, float s0, float s1,
+                                      float s2, float s3, float s4) {
+  asm volatile("ds_bpermute_b32 %0, %5, %6\n\tds_bpermute_b32 %1, %5, %7\n\tds_bpermute_b32 %2, %5, %8\n\t"
+               "ds_bpermute_b32 %3, %5, %9\n\tds_bpermute_b32 %4, %5, %10"
+               : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4)
+               : "v"(addr), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4));
+}
+__device__ __forceinline__ void pull2(uint32_t addr, float& d0, int& d1, float s0, int s1) {
+  asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4" : "=&v"(d0), "=&v"(d1) : "v"(addr), "v"(s0), "v"(s1));
+}
+
+// Short-query arrays (W = 32 / 16 lanes, variants that read the record head at the top of the step): the DPP moves stay - the
+// pulls, waited for with the head, measured 1.5 / 4 % slower there (profiles/r2_ab_session2.txt ab11).
 // lane n <- lane n-1 of the same systolic array; the first lane of an array keeps `old`
-//   W = 64: v_mov_b32_dpp wave_shr:1 (lane 0 keeps old)
 //   W = 16: v_mov_b32_dpp row_shr:1  (a DPP row IS 16 lanes: lanes 0, 16, 32, 48 keep old)
 //   W = 32: wave_shr:1, then lane 32 is put back to `old` (one v_cndmask with a loop-invariant lane mask)
 template <int W>
@@ -95,6 +113,28 @@ struct LdsColumn {
   static constexpr int NC = R - C0;
   v4f v0, v1, v2, v3, v4, v5, v6;
   v4f qa0, qa1, qa2, qc0, qc1, qc2;
+  // hand-off values pulled from lane - 1, in flight from the top of the step to the first lgkmcnt(0) behind it (GD / IM / DG
+  // are pulled straight into st.dGD / dIM / dDG: their old values were consumed by lane_diag at the top of the step)
+  float hMM, hMI, hfs;
+  int hfpos;
+  bool head_lane;  // first lane of an array: keeps the boundary instead of what it pulled
+  // called behind a wait that covers the pulls (before_B / before_C in a column, header_tid on a header)
+  template <class State>
+  __device__ __forceinline__ Incoming resolve(const Incoming& bnd, State& st) {
+    asm volatile("" : "+v"(hMM), "+v"(hMI), "+v"(st.dGD), "+v"(st.dIM), "+v"(st.dDG));
+    Incoming r = bnd;
+    r.MM = head_lane ? bnd.MM : hMM;
+    r.GD = head_lane ? bnd.GD : st.dGD;
+    r.IM = head_lane ? bnd.IM : st.dIM;
+    r.DG = head_lane ? bnd.DG : st.dDG;
+    r.MI = head_lane ? bnd.MI : hMI;
+    return r;
+  }
+  __device__ __forceinline__ void resolve_best(const Incoming& bnd, Incoming& r) {
+    asm volatile("" : "+v"(hfs), "+v"(hfpos));
+    r.fs = head_lane ? bnd.fs : hfs;
+    r.fpos = head_lane ? bnd.fpos : hfpos;
+  }
 #if defined(HHV_EXP_TIMING)
   unsigned long long tA, tB;
 #endif
@@ -290,11 +330,15 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // All 64-lane variants except the cell-off / secondary-structure ones (no VGPRs to spare there); in the backtrace
   // variants the phase-A query-transition reads are deferred as well (SPLIT_A).  Measured in one session each
   // (tools/gpu_ab.sh): score-only -2 %, multi-pass -0.8 %, backtrace -0.5 %.
-  constexpr bool PF = !CELLOFF && !SS && W == LANES;
+  // (not the local five-row single-pass variants: 256 VGPRs do not hold the prefetched head next to the per-row best)
+  constexpr bool PF = !CELLOFF && !SS && W == LANES && !(LOCAL && R == 5 && !MULTI);
   LdsColumn<R, QL, (PF && QL)> col;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t ring_addr = smem_addr + QL_F4 * 16 + arr * (C * REC_DW * 4);
   col.ql_addr = smem_addr + lane * 80;
+  col.head_lane = W == LANES && g == 0;  // (the DPP moves of the short-query arrays deliver the boundary themselves)
+  col.hMM = col.hMI = col.hfs = NEG_MAX;
+  col.hfpos = 0;
   if (QL) {
     float* w = reinterpret_cast<float*>(smem) + lane * 20;
 #pragma unroll
@@ -347,15 +391,11 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       nmi = a.carry_mi[rb];
     }
   }
-  // Hand-off registers that live across the steps (single-pass variants).  The DPP move leaves the first lane of an array
-  // untouched, so that lane keeps the DP boundary (-FLT_MAX, position 0) without being re-initialised every step; GD / IM /
-  // DG are handed over straight into st.dGD / dIM / dDG (see DiagSums).
-  float hMI = NEG_MAX, hfs = NEG_MAX;
-  int hfpos = 0;
 #if defined(HHV_EXP_TIMING)
   unsigned long long dbg0 = 0, dbg1 = 0, dbg2 = 0, dbg3 = 0;
 #endif
-  const bool head_lane = g == 0;
+  // every lane pulls from the lane below it (the first lane of an array pulls whatever and keeps the boundary instead)
+  const uint32_t pull_addr = (uint32_t)((lane + LANES - 1) & (LANES - 1)) * 4u;
 
   auto step = [&](const int s, decltype(col)& cur, decltype(col)& nxt) __attribute__((always_inline)) {
     const int r = s - g;
@@ -368,80 +408,84 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #endif
 
     cur.rec_addr = record_addr(s);
-    if (PF) {
+
+    // hand-off from lane g-1 (full EXEC here).  The row-0 sums that read LAST step's hand-off first; then the pulls: MM and MI
+    // into the operand source, GD / IM / DG straight into st.dGD / dIM / dDG - nothing touches the five registers until
+    // LdsColumn::resolve(), behind a wait (the pulls are issued in front of this step's other reads: lgkmcnt counts stay valid)
+    DiagSums ds = lane_diag(st, q);
+    asm volatile("" : "+v"(ds.t2), "+v"(ds.x3), "+v"(ds.x4));  // (hipcc would sink the three adds below the pulls and copy)
+    int32_t meta;
+    if (W < LANES) {
+      // short-query arrays: DPP moves.  A move never writes the first lane of an array, which therefore keeps the boundary
+      // (-FLT_MAX, position 0) it was initialised with for the whole kernel: only MM of row 0, which changes per column,
+      // goes through the `old` operand
+      cur.head();
+      meta = cur.meta();
+      const Incoming b0 = boundary_incoming(meta, meta & (int)k_jmask, P);
+      const bool first_lane = g == 0;
+      cur.hMM = dpp_shr1<W>(b0.MM, st.MM[R - 1], first_lane);
+      st.dGD = dpp_shr1<W>(st.dGD, st.GD[R - 1], first_lane);
+      st.dIM = dpp_shr1<W>(st.dIM, st.IM[R - 1], first_lane);
+      st.dDG = dpp_shr1<W>(st.dDG, st.DG[R - 1], first_lane);
+      cur.hMI = dpp_shr1<W>(cur.hMI, st.MI[R - 1], first_lane);
+      if (__builtin_amdgcn_ballot_w64(meta < 0) != 0) {
+        cur.hfs = dpp_shr1<W>(cur.hfs, st.fs, first_lane);
+        cur.hfpos = dpp_shr1<W>(cur.hfpos, st.fpos, first_lane);
+      }
+    } else if (PF) {
+      pull5(pull_addr, cur.hMM, st.dGD, st.dIM, st.dDG, cur.hMI, st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1], st.MI[R - 1]);
+      meta = cur.meta();  // (the head of this step landed at the end of the previous one)
+      // the finalized best only matters to a lane that stands on a header record: two more pulls in the ~1 of 5 steps in
+      // which some lane does (wave-uniform branch, full EXEC inside)
+      const bool any_header = MULTI || __builtin_amdgcn_ballot_w64(meta < 0) != 0;
+      if (any_header) pull2(pull_addr, cur.hfs, cur.hfpos, st.fs, st.fpos);
       if (QL) cur.qa_issue();
       decltype(col)::head_issue(record_addr(s + 1), nxt.v6, nxt.v5);
+      // hfs / hfpos are only read by lanes on a header, but the pull writes them for the whole wave whenever it lands: the
+      // column code must not get their registers before that.  Waited for on the spot (the pulls are the oldest operations in
+      // flight: the reads issued behind them may stay outstanding) - an LDS round trip in the steps that have a header
+      if (any_header) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cur.hfs), "+v"(cur.hfpos) : "n"(2 + (QL ? decltype(col)::NA : 0)));
     } else {
+      // 64-lane variants that read the head at the top of the step: all seven pulls in front of it, its wait covers them
+      pull5(pull_addr, cur.hMM, st.dGD, st.dIM, st.dDG, cur.hMI, st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1], st.MI[R - 1]);
+      pull2(pull_addr, cur.hfs, cur.hfpos, st.fs, st.fpos);
       cur.head();
+      asm volatile("" : "+v"(cur.hfs), "+v"(cur.hfpos));
+      meta = cur.meta();
     }
-    const int32_t meta = cur.meta();
-
-    // hand-off from lane g-1 (full EXEC here); lane 0 of an array takes the DP boundary row 0, or - in later passes of
-    // a long query - the bottom row the previous pass left for this record (and its running best)
-    DiagSums ds = lane_diag(st, q);  // reads the hand-off of the previous step: before the moves below
+    // what the first lane of an array takes instead: the DP boundary row 0, or - in later passes of a long query - the
+    // bottom row the previous pass left for this record (and its running best)
     const int jcol = meta & (int)k_jmask;  // column index of a column record
     Incoming in = boundary_incoming(meta, jcol, P);
-    if (MULTI) {
-      // multi-pass variants: plain hand-off registers (measured 5 % slower with the in-place scheme below).  In later
-      // passes lane 0 takes the bottom row the previous pass left for this record, and its running best.
-      if (!first) {
-        if (lane == 0 && active) {
-          in.MM = ncar.x;
-          in.GD = ncar.y;
-          in.IM = ncar.z;
-          in.DG = ncar.w;
-          in.MI = nmi;
-          if (meta < 0 && st.tid >= 0) {
-            const DevResult pr = a.results[st.tid & TID_MASK];
-            in.fs = pr.score;
-            in.fpos = (pr.i2 << 16) | pr.j2;
-          }
+    if (MULTI && !first) {
+      if (lane == 0 && active) {
+        in.MM = ncar.x;
+        in.GD = ncar.y;
+        in.IM = ncar.z;
+        in.DG = ncar.w;
+        in.MI = nmi;
+        if (meta < 0 && st.tid >= 0) {
+          const DevResult pr = a.results[st.tid & TID_MASK];
+          in.fs = pr.score;
+          in.fpos = (pr.i2 << 16) | pr.j2;
         }
       }
-      in.MM = dpp_shr1<W>(in.MM, st.MM[R - 1], head_lane);
-      in.GD = dpp_shr1<W>(in.GD, st.GD[R - 1], head_lane);
-      in.IM = dpp_shr1<W>(in.IM, st.IM[R - 1], head_lane);
-      in.DG = dpp_shr1<W>(in.DG, st.DG[R - 1], head_lane);
-      in.MI = dpp_shr1<W>(in.MI, st.MI[R - 1], head_lane);
-      in.fs = dpp_shr1<W>(in.fs, st.fs, head_lane);
-      in.fpos = dpp_shr1<W>(in.fpos, st.fpos, head_lane);
-      // the carry row of the next step is requested only now, behind the moves that consumed this step's row: the load
+      // the carry row of the next step is requested only now, behind the copies that consumed this step's row: the load
       // lands in the same registers and is not waited for before the next step (requested inside the block above, hipcc
       // loads into temporaries, copies and waits for the round trip on the spot)
-      if (!first) {
-        if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
-          ncar = a.carry[rb + r + 1];
-          nmi = a.carry_mi[rb + r + 1];
-        }
+      if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
+        ncar = a.carry[rb + r + 1];
+        nmi = a.carry_mi[rb + r + 1];
       }
-    } else {
-      // single pass: the first lane of an array is never written by the moves and keeps the DP boundary (-FLT_MAX, position
-      // 0) for the whole kernel, so nothing is re-initialised per step; GD / IM / DG go straight into st.dGD / dIM / dDG
-      asm volatile("" : "+v"(ds.t2), "+v"(ds.x3), "+v"(ds.x4));  // (hipcc would sink the three adds below the moves and copy)
-      in.MM = dpp_shr1<W>(in.MM, st.MM[R - 1], head_lane);
-      st.dGD = dpp_shr1<W>(st.dGD, st.GD[R - 1], head_lane);
-      st.dIM = dpp_shr1<W>(st.dIM, st.IM[R - 1], head_lane);
-      st.dDG = dpp_shr1<W>(st.dDG, st.DG[R - 1], head_lane);
-      hMI = dpp_shr1<W>(hMI, st.MI[R - 1], head_lane);
-      in.GD = st.dGD;
-      in.IM = st.dIM;
-      in.DG = st.dDG;
-      in.MI = hMI;
-      // the finalized best only matters to a lane that stands on a header record: the two moves are skipped (wave-uniform
-      // branch, full EXEC inside) in the ~4 of 5 steps in which no lane does
-      if (__builtin_amdgcn_ballot_w64(meta < 0) != 0) {
-        hfs = dpp_shr1<W>(hfs, st.fs, head_lane);
-        hfpos = dpp_shr1<W>(hfpos, st.fpos, head_lane);
-      }
-      in.fs = hfs;
-      in.fpos = hfpos;
     }
 
     if (active) {
       if (meta < 0) {
         TemplateResult res;
-        const int new_tid = cur.header_tid() | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
-        if (lane_header<R, LOCAL, true>(st, q, in, i0, new_tid, P, g == g_last, res)) {
+        const int new_tid = cur.header_tid() | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);  // waits: the pulls have landed
+        Incoming inh = cur.resolve(in, st);
+        cur.resolve_best(in, inh);
+        if (lane_header<R, LOCAL, true>(st, q, inh, i0, new_tid, P, g == g_last, res)) {
           DevResult o;
           o.score = res.score;
           o.i2 = res.i2;
@@ -463,7 +507,10 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #pragma unroll
           for (int r = 0; r < R; ++r) ssv[r] = a.ss_table[ss_qoff[r] + tidx];
         }
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS>(st, q, in, ds, cur, j, i0, r_last, P, cell, ssv);
+        // single pass: the boundary value of the first lane is formed inside the column's block, so that it need not be held
+        // through phases A and B (it is read in phase C)
+        const Incoming inc = MULTI ? in : boundary_incoming(meta, jcol, P);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
       if (carry_out) {

@@ -369,6 +369,9 @@ struct ArraySrc {
   HHV_MEM void before_C() {}
   HHV_MEM float qa(int, int) const { return 0.0f; }
   HHV_MEM float qc(int, int) const { return 0.0f; }
+  // the hand-off of the step as phase C and the end of the column see it (a source may deliver it late: LdsColumn)
+  template <class State>
+  HHV_MEM Incoming resolve(const Incoming& in, State&) const { return in; }
 };
 
 // One template column j for the R rows of this lane.
@@ -470,7 +473,8 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   src.stamp_B(S[0], S[R - 1]);
 #endif
   src.before_C();
-  float uMM = in.MM, uDG = in.DG, uMI = in.MI;
+  const Incoming up = src.resolve(in, st);  // MM / DG / MI of row i0-1 in this column; GD / IM / DG for the next column's diagonal
+  float uMM = up.MM, uDG = up.DG, uMI = up.MI;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float mm = cmax[r] + S[r];
@@ -519,11 +523,11 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     st.bj[0] = up ? j : st.bj[0];
   }
   st.jlast = j;
-  st.dMM = in.MM;
-  st.dGD = in.GD;
-  st.dIM = in.IM;
-  st.dDG = in.DG;
-  st.dMI = in.MI;
+  st.dMM = up.MM;
+  st.dGD = up.GD;
+  st.dIM = up.IM;
+  st.dDG = up.DG;
+  st.dMI = up.MI;
   return BT ? ((uint64_t)acc_hi << 32) | acc_lo : 0;
 }
 

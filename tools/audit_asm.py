@@ -91,7 +91,7 @@ def audit_function(name, body):
             in_asm = False
             # LDS returns a wave's reads in order: lgkmcnt(N) leaves at most the N youngest in flight
             for a in asm_lines:
-                if a.startswith("ds_read"):
+                if a.startswith("ds_read") or a.startswith("ds_bpermute"):
                     pending.append(regs_of(a.split(",")[0]))
                 w = re.search(r"lgkmcnt\((\d+)\)", a)
                 if w:

@@ -11,12 +11,22 @@ os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # matrix: the same v_add stream under different kernel shapes: workgroup size x VGPR allocation
 src=open('tools/shape_ubench.hip','w')
 src.write('#include <hip/hip_runtime.h>\n#include <stdio.h>\n')
-seq="\\n".join("v_add_f32_e32 v%d, v%d, v1"%(10+k%16,10+k%16) for k in range(256))+"\\n"
+def stream(kind, nv=32):
+    out=[]
+    for k in range(256):
+        r=10+k%16
+        if kind=="mixhi": r=nv-20+k%16   # the same mix on the highest registers of the allocation
+        if kind in ("mix","mixhi") and k%5==0: out.append("v_max_f32_e32 v%d, v%d, v1"%(r,r))     # every fifth instruction is a "slow class" one
+        else: out.append("v_add_f32_e32 v%d, v%d, v1"%(r,r))
+    return "\\n".join(out)+"\\n"
 cases=[]
-for wg in (64,256):
-    for nv in (32,96,128,168,200,248,256):
-        if wg==256 and nv>128: continue  # 4 waves per WG must fit... (occupancy decides) keep small
-        name='k_wg%d_v%d'%(wg,nv)
+for kind in ("add","mix","mixhi"):
+  for wg in (64,128,256):
+    for nv in (32,128,248):
+        seq=stream(kind,nv)
+        if kind=="mixhi" and nv==32: continue
+        if wg*nv//64 > 512*4//2 and False: continue
+        name='k_%s_wg%d_v%d'%(kind,wg,nv)
         clob=",".join('"v%d"'%k for k in range(0,nv))
         src.write('''__global__ void __launch_bounds__(%d) %s(float* out, int iters) {
   for (int it = 0; it < iters; ++it) { asm volatile("%s" ::: %s); }
