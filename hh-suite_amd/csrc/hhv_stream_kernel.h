@@ -101,8 +101,9 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ records, c
 // tools/audit_asm.py checks in the generated .s that nothing touches a destination between its load and its wait.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int R, bool QL_, bool SPLIT_ = false>
+template <int R, bool QL_, bool SPLIT_ = false, bool LATE_ = true>
 struct LdsColumn {
+  static constexpr bool LATE = LATE_;  // the hand-off values are pulled through LDS and in flight until a wait (64-lane variants)
   static constexpr bool QL = QL_;
   // SPLIT_A (backtrace variants with the pipelined head): the phase-A query transitions are requested at the top of the
   // step without a wait; lane_column evaluates the MM candidates of all rows first (they do not need them) and calls
@@ -121,7 +122,7 @@ struct LdsColumn {
   // called behind a wait that covers the pulls (before_B / before_C in a column, header_tid on a header)
   template <class State>
   __device__ __forceinline__ Incoming resolve(const Incoming& bnd, State& st) {
-    asm volatile("" : "+v"(hMM), "+v"(hMI), "+v"(st.dGD), "+v"(st.dIM), "+v"(st.dDG));
+    if (LATE) asm volatile("" : "+v"(hMM), "+v"(hMI), "+v"(st.dGD), "+v"(st.dIM), "+v"(st.dDG));
     Incoming r = bnd;
     r.MM = head_lane ? bnd.MM : hMM;
     r.GD = head_lane ? bnd.GD : st.dGD;
@@ -131,7 +132,7 @@ struct LdsColumn {
     return r;
   }
   __device__ __forceinline__ void resolve_best(const Incoming& bnd, Incoming& r) {
-    asm volatile("" : "+v"(hfs), "+v"(hfpos));
+    if (LATE) asm volatile("" : "+v"(hfs), "+v"(hfpos));
     r.fs = head_lane ? bnd.fs : hfs;
     r.fpos = head_lane ? bnd.fpos : hfpos;
   }
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // (tools/gpu_ab.sh): score-only -2 %, multi-pass -0.8 %, backtrace -0.5 %.
   // (not the local five-row single-pass variants: 256 VGPRs do not hold the prefetched head next to the per-row best)
   constexpr bool PF = !CELLOFF && !SS && W == LANES && !(LOCAL && R == 5 && !MULTI);
-  LdsColumn<R, QL, (PF && QL)> col;
+  LdsColumn<R, QL, (PF && QL), (W == LANES)> col;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t ring_addr = smem_addr + QL_F4 * 16 + arr * (C * REC_DW * 4);
   col.ql_addr = smem_addr + lane * 80;
@@ -412,8 +413,11 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     // hand-off from lane g-1 (full EXEC here).  The row-0 sums that read LAST step's hand-off first; then the pulls: MM and MI
     // into the operand source, GD / IM / DG straight into st.dGD / dIM / dDG - nothing touches the five registers until
     // LdsColumn::resolve(), behind a wait (the pulls are issued in front of this step's other reads: lgkmcnt counts stay valid)
-    DiagSums ds = lane_diag(st, q);
-    asm volatile("" : "+v"(ds.t2), "+v"(ds.x3), "+v"(ds.x4));  // (hipcc would sink the three adds below the pulls and copy)
+    DiagSums ds;
+    if (W == LANES) {
+      ds = lane_diag(st, q);
+      asm volatile("" : "+v"(ds.t2), "+v"(ds.x3), "+v"(ds.x4));  // (hipcc would sink the three adds below the pulls and copy)
+    }
     int32_t meta;
     if (W < LANES) {
       // short-query arrays: DPP moves.  A move never writes the first lane of an array, which therefore keeps the boundary
@@ -421,6 +425,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       // goes through the `old` operand
       cur.head();
       meta = cur.meta();
+      ds = lane_diag(st, q);
+      asm volatile("" : "+v"(ds.t2), "+v"(ds.x3), "+v"(ds.x4));
       const Incoming b0 = boundary_incoming(meta, meta & (int)k_jmask, P);
       const bool first_lane = g == 0;
       cur.hMM = dpp_shr1<W>(b0.MM, st.MM[R - 1], first_lane);
