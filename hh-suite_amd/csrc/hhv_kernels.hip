@@ -6,7 +6,7 @@
 //           this unit) or two / four arrays for short queries (hhv_kernels_w32.hip / _w16.hip), see viterbi_lane.h.  The wave's template stream is staged through a 14 KiB LDS ring with
 //           global_load_lds_dwordx4 (HBM -> LDS without touching VGPRs), lanes read their record
 //           with 7 conflict-free ds_read_b128 (28-dword stride = 16 distinct 4-bank slots), the
-//           lane-to-lane hand-off is 5 v_mov_b32_dpp wave_shr:1 per step (+ 2 in steps with a header).
+//           lane-to-lane hand-off is 5 ds_bpermute_b32 per step (+ 2 in steps with a header), delivered late (hhv_stream_kernel.h).
 // Kernel 2a hhv_trace_kernel   Viterbi::Backtrace (src/hhviterbi.cpp:83-160), one lane per template
 //           (serial pointer chase, O(Lq+Lt) dependent byte loads).
 // Kernel 2b hhv_rescore_kernel Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), one wave per template.

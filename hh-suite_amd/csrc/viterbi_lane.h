@@ -6,7 +6,8 @@
 // at step s lane g processes stream record r = s - g.  A record is either a template header
 // (column 0: finalize the previous template, initialise the DP boundary) or one template column j.
 // The only cross-lane traffic per step is the bottom-row state of lane g-1 (5 floats; the running best only in
-// steps with a header), fetched with a DPP wave_shr:1; everything else is lane local.
+// steps with a header), pulled through the LDS crossbar (64-lane arrays) or moved with DPP (short-query arrays);
+// everything else is lane local.
 //
 // The arithmetic restates, operation for operation and in the same association, the reference's
 //   Viterbi::AlignWithOutCellOff / AlignWithCellOff  src/hhviterbialgorithm.cpp:144-494
