@@ -132,7 +132,6 @@ struct LdsColumn {
     return r;
   }
   __device__ __forceinline__ void resolve_best(const Incoming& bnd, Incoming& r) {
-    if (LATE) asm volatile("" : "+v"(hfs), "+v"(hfpos));
     r.fs = head_lane ? bnd.fs : hfs;
     r.fpos = head_lane ? bnd.fpos : hfpos;
   }
@@ -193,6 +192,18 @@ struct LdsColumn {
     int32_t t;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t) : "v"(rec_addr));
     return t;
+  }
+  // 64-lane variants: the finalized best of the template travels lane to lane through LDS memory (8 bytes per lane: a lane
+  // writes its slot at the end of its header step, its neighbour reads it one step later, in the same round trip as the
+  // template index) - no cross-lane operation and no wait outside the header path
+  __device__ __forceinline__ int32_t header_tid_best(uint32_t prev_slot) {
+    int32_t t;
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %4 offset:4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t), "=&v"(hfs), "=&v"(hfpos) : "v"(rec_addr), "v"(prev_slot));
+    return t;
+  }
+  static __device__ __forceinline__ void publish_best(uint32_t own_slot, float fs, int fpos) {
+    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4" ::"v"(own_slot), "v"(fs), "v"(fpos) : "memory");
   }
   __device__ __forceinline__ void begin_column() {
     asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
@@ -276,7 +287,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // ONE __shared__ object: [QL block][ring].
   constexpr bool QL = BT;
   constexpr int QL_F4 = QL ? LANES * 5 : 0;
-  __shared__ float4 smem[QL_F4 + RING_RECS * 7];
+  constexpr int BEST_F4 = W == LANES ? LANES / 2 : 0;  // 8 bytes per lane: the finalized best on its way to the next lane
+  __shared__ float4 smem[QL_F4 + RING_RECS * 7 + BEST_F4];
   float4* const ring = smem + QL_F4;
   const int lane = threadIdx.x;
   const int g = lane & (W - 1);  // lane of the array
@@ -336,6 +348,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   LdsColumn<R, QL, (PF && QL), (W == LANES)> col;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t ring_addr = smem_addr + QL_F4 * 16 + arr * (C * REC_DW * 4);
+  const uint32_t best_base = smem_addr + (QL_F4 + RING_RECS * 7) * 16;
   col.ql_addr = smem_addr + lane * 80;
   col.head_lane = W == LANES && g == 0;  // (the DPP moves of the short-query arrays deliver the boundary themselves)
   col.hMM = col.hMI = col.hfs = NEG_MAX;
@@ -441,22 +454,12 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     } else if (PF) {
       pull5(pull_addr, cur.hMM, st.dGD, st.dIM, st.dDG, cur.hMI, st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1], st.MI[R - 1]);
       meta = cur.meta();  // (the head of this step landed at the end of the previous one)
-      // the finalized best only matters to a lane that stands on a header record: two more pulls in the ~1 of 5 steps in
-      // which some lane does (wave-uniform branch, full EXEC inside)
-      const bool any_header = MULTI || __builtin_amdgcn_ballot_w64(meta < 0) != 0;
-      if (any_header) pull2(pull_addr, cur.hfs, cur.hfpos, st.fs, st.fpos);
       if (QL) cur.qa_issue();
       decltype(col)::head_issue(record_addr(s + 1), nxt.v6, nxt.v5);
-      // hfs / hfpos are only read by lanes on a header, but the pull writes them for the whole wave whenever it lands: the
-      // column code must not get their registers before that.  Waited for on the spot (the pulls are the oldest operations in
-      // flight: the reads issued behind them may stay outstanding) - an LDS round trip in the steps that have a header
-      if (any_header) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cur.hfs), "+v"(cur.hfpos) : "n"(2 + (QL ? decltype(col)::NA : 0)));
     } else {
-      // 64-lane variants that read the head at the top of the step: all seven pulls in front of it, its wait covers them
+      // 64-lane variants that read the head at the top of the step: the pulls in front of it, its wait covers them
       pull5(pull_addr, cur.hMM, st.dGD, st.dIM, st.dDG, cur.hMI, st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1], st.MI[R - 1]);
-      pull2(pull_addr, cur.hfs, cur.hfpos, st.fs, st.fpos);
       cur.head();
-      asm volatile("" : "+v"(cur.hfs), "+v"(cur.hfpos));
       meta = cur.meta();
     }
     // what the first lane of an array takes instead: the DP boundary row 0, or - in later passes of a long query - the
@@ -488,10 +491,14 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     if (active) {
       if (meta < 0) {
         TemplateResult res;
-        const int new_tid = cur.header_tid() | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);  // waits: the pulls have landed
+        // (the wait inside covers the pulls of this step as well)
+        const int tid0 = W == LANES ? cur.header_tid_best(best_base + pull_addr * 2) : cur.header_tid();
+        const int new_tid = tid0 | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
         Incoming inh = cur.resolve(in, st);
         cur.resolve_best(in, inh);
-        if (lane_header<R, LOCAL, true>(st, q, inh, i0, new_tid, P, g == g_last, res)) {
+        const bool emit = lane_header<R, LOCAL, true>(st, q, inh, i0, new_tid, P, g == g_last, res);
+        if (W == LANES) decltype(col)::publish_best(best_base + (uint32_t)lane * 8u, st.fs, st.fpos);
+        if (emit) {
           DevResult o;
           o.score = res.score;
           o.i2 = res.i2;
