@@ -20,7 +20,9 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                        "-I" + os.path.join(ROOT, "hh-suite_amd", "csrc"), "--cuda-device-only", "-S",
                        os.path.join(ROOT, "hh-suite_amd", "csrc", "hhv_kernels.hip"), "-o", asm], stderr=subprocess.DEVNULL)
 text = open(asm).read().split('\n')
-name = "_ZN3hhv17hhv_stream_kernelILi5ELb0ELb0ELb0ELb0ELb0ELi64EEEvNS_10StreamArgsE:"
+# usage: gen_step_replay_ubench.py [bt]   (default: the score-only kernel; bt: the backtrace variant, VALU-only variants)
+BT = len(sys.argv) > 1 and sys.argv[1] == "bt"
+name = "_ZN3hhv17hhv_stream_kernelILi5ELb0ELb%dELb0ELb0ELb0ELi64EEEvNS_10StreamArgsE:" % (1 if BT else 0)
 b0 = next(i for i, l in enumerate(text) if l.startswith(name))
 b1 = next(i for i in range(b0, len(text)) if text[i].startswith(".Lfunc_end"))
 L = text[b0:b1]
@@ -72,7 +74,8 @@ def clean(lines, variant):
     return out
 
 
-variants = ["full", "full_nodpp", "nobranch", "nobranch_nodpp", "nolds", "noexec", "valuonly", "v_nodpp"]
+variants = (["valuonly", "v_nocmp", "v_noaddc", "v_max2add", "v_vop3toadd", "v_noslow"] if BT else
+            ["nobranch", "nobranch_nodpp", "valuonly", "v_nodpp", "v_noslow"])
 
 
 def transform(ins, v):
@@ -85,7 +88,10 @@ def transform(ins, v):
         op = t.split()[0]
         args = [a.strip() for a in t[len(op):].split(",")]
         slow_all = v in ("v_noslow", "v_noslow_nosgpr", "v_keepdpp")
-        if op.startswith("v_max3") and (slow_all or v == "v_vop3toadd"):
+        if op.startswith("v_addc") and (slow_all or v in ("v_nocmp", "v_noaddc")):
+            vs = [a for a in args if re.match(r"v\d+$", a)]
+            t = "v_add_u32_e32 %s, %s, %s" % (vs[0], vs[1], vs[2])
+        elif op.startswith("v_max3") and (slow_all or v == "v_vop3toadd"):
             t = "v_add_f32_e32 %s, %s, %s" % (args[0], args[1], args[2])
         elif op.startswith("v_max_f32") and (slow_all or v == "v_max2add"):
             t = "v_add_f32_e32 %s, %s, %s" % (args[0], args[1], args[2])
@@ -146,7 +152,7 @@ for v in variants:
     src.append('  if (iters < 0) out[threadIdx.x] = lds[threadIdx.x];')
     src.append('  const int delay = 1 + (int)((blockIdx.x * 2654435761u >> 20) % 197u);  // 0 ... ~3000 clk of start offset per wave')
     src.append('  asm volatile("s_mov_b32 s101, %%1\\nDLY%%=:\\ns_nop 7\\ns_nop 7\\ns_sub_u32 s101, s101, 1\\ns_cmp_lg_u32 s101, 0\\ns_cbranch_scc1 DLY%%=\\n%sLOOP%%=:\\ns_mov_b64 exec, -1\\n%ss_sub_u32 s100, s100, 1\\ns_cmp_lg_u32 s100, 0\\ns_cbranch_scc1 LOOP%%=\\ns_endpgm\\n" :: "s"(iters), "s"(delay) : %s);'
-               % (setup, code, ",".join(['"v%d"' % k for k in range(0, 248)] + ['"vcc"', '"memory"'])))
+               % (setup, code, ",".join(['"v%d"' % k for k in range(0, 252)] + ['"vcc"', '"memory"'])))
     src.append('}')
     cases.append((v, n, nv))
 src.append('struct C{const char* n; void(*f)(float*,int); int ni; int nv;}; static C cs[]={' +
