@@ -31,10 +31,6 @@ __device__ __forceinline__ void pull5(uint32_t addr, float& d0, float& d1, float
                : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4)
                : "v"(addr), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4));
 }
-__device__ __forceinline__ void pull2(uint32_t addr, float& d0, int& d1, float s0, int s1) {
-  asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4" : "=&v"(d0), "=&v"(d1) : "v"(addr), "v"(s0), "v"(s1));
-}
-
 // Short-query arrays (W = 32 / 16 lanes, variants that read the record head at the top of the step): the DPP moves stay - the
 // pulls, waited for with the head, measured 1.5 / 4 % slower there (profiles/r2_ab_session2.txt ab11).
 // lane n <- lane n-1 of the same systolic array; the first lane of an array keeps `old`
