@@ -124,7 +124,8 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
   c->par = *par;
   c->num_cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming) != hipSuccess) {
     hhv_destroy(c);
     return fail(HHV_E_DEVICE, "hhv_create: stream/event creation failed");
   }
@@ -177,6 +178,8 @@ void hhv_destroy(hhv_ctx* c) {
   if (c->mac_side.fork) (void)hipEventDestroy((hipEvent_t)c->mac_side.fork);
   if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
   if (c->mac_pinned_out) (void)hipHostFree(c->mac_pinned_out);
+  if (c->q_stage) (void)hipHostFree(c->q_stage);
+  if (c->ev_q) (void)hipEventDestroy(c->ev_q);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -192,17 +195,48 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   const char* al = getenv("HHV_ARRAY_LANES");
   const StripPlan plan = StripPlan::make(Lq, al ? atoi(al) : 16);
   HIP_TRY(hipSetDevice(c->par.device));
-  std::vector<float> qpack((size_t)plan.rows() * REC_DW, 0.0f);
-  pack_columns(p, tr, Lq, qpack.data());
+  // The packed rows and the AoS profile go through ONE pinned staging block and two asynchronous copies on the context's
+  // stream; device buffers and staging are kept between queries (grown when a longer query arrives).  A search loop that
+  // sets a query per step therefore neither frees device memory (hipFree waits for the whole device) nor waits for the
+  // stream: the only wait is for the PREVIOUS query's copies to have left the staging block (an event, long signalled).
+  const size_t n_qpack = (size_t)plan.rows() * REC_DW, n_qp = (size_t)(Lq + 1) * 20;
+  const size_t stage_bytes = (n_qpack + n_qp) * sizeof(float);
   c->Lq = 0;  // no query until the new one is in place (a failure below must not leave the old geometry with freed buffers)
   c->ss_dirty = true;
-  dfree(c->d_qpack);
-  dfree(c->d_qp);
-  HIP_TRY(hipMalloc(&c->d_qpack, qpack.size() * sizeof(float)));
-  HIP_TRY(hipMalloc(&c->d_qp, (size_t)(Lq + 1) * 20 * sizeof(float)));
-  HIP_TRY(hipMemcpyAsync(c->d_qpack, qpack.data(), qpack.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->d_qp, p, (size_t)(Lq + 1) * 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->q_stage_busy) {
+    HIP_TRY(hipEventSynchronize(c->ev_q));
+    c->q_stage_busy = false;
+  }
+  if (c->q_stage_bytes < stage_bytes) {
+    if (c->q_stage) (void)hipHostFree(c->q_stage);
+    c->q_stage = nullptr;
+    c->q_stage_bytes = 0;
+    HIP_TRY(hipHostMalloc(&c->q_stage, stage_bytes, hipHostMallocDefault));
+    c->q_stage_bytes = stage_bytes;
+  }
+  if (c->qpack_cap < n_qpack) {
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (a launch that still reads the old rows)
+    dfree(c->d_qpack);
+    c->qpack_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_qpack, n_qpack * sizeof(float)));
+    c->qpack_cap = n_qpack;
+  }
+  if (c->qp_cap < n_qp) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->d_qp);
+    c->qp_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_qp, n_qp * sizeof(float)));
+    c->qp_cap = n_qp;
+  }
+  float* const h_qpack = (float*)c->q_stage;
+  float* const h_qp = h_qpack + n_qpack;
+  memset(h_qpack, 0, n_qpack * sizeof(float));
+  pack_columns(p, tr, Lq, h_qpack);
+  memcpy(h_qp, p, n_qp * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(c->d_qpack, h_qpack, n_qpack * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_qp, h_qp, n_qp * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_q, c->stream));
+  c->q_stage_busy = true;
   c->Lq = Lq;
   c->plan = plan;
   c->q_pred.clear();
@@ -508,6 +542,13 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   if (bt) {
     rc = ensure_bt(c, ts);
     if (rc != HHV_OK) return rc;
+    if (celloff && ts->bt_dirty) {
+      // The buffer still holds the compare bits of an earlier backtrace / cell-off launch and no mask has been set since
+      // (hhv_set_celloff / hhv_set_celloff_paths clear it): read as masks they would switch off arbitrary cells.  The
+      // reference's matrix has no cell switched off in that situation (src/hhviterbi.cpp:188), so neither has this launch.
+      HIP_TRY(hipMemsetAsync(ts->d_bt, 0, (size_t)ts->bt_plan.P * bt_plane_entries(ts->n_records, ts->bt_plan.W) * sizeof(uint64_t), c->stream));
+      ts->bt_dirty = false;
+    }
   }
   StreamArgs a;
   a.records = ts->d_records;
@@ -780,8 +821,10 @@ int hhv_hits(hhv_ctx* c, hhv_tset* ts, hhv_hit* hits) {
   HIP_TRY(hipSetDevice(c->par.device));
   int rc = run_trace(c, ts);
   if (rc != HHV_OK) return rc;
-  if (hits) HIP_TRY(hipMemcpyAsync(hits, ts->d_hits, (size_t)ts->n * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (hits) {  // (hits == NULL: trace and rescoring are only enqueued on the context's stream, like hhv_align_async)
+    HIP_TRY(hipMemcpyAsync(hits, ts->d_hits, (size_t)ts->n * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   return HHV_OK;
 }
 
@@ -880,14 +923,17 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
                   &err) != 0)
     return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
   if (kk < k) HIP_TRY(hipMemsetAsync(dst + kk, 0xFF, (size_t)(k - kk) * sizeof(DevHit), c->stream));
-  if (out) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (n_out) *n_out = kk;
+  if (out) {
+    HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  if (n_out) *n_out = kk;  // (known without the device: nothing to wait for when the records stay on the device)
   return HHV_OK;
 }
 
 int hhv_tset_set_global_ids(hhv_ctx* c, hhv_tset* ts, const int32_t* ids) {
   if (!c || !ts) return fail(HHV_E_ARG, "hhv_tset_set_global_ids: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_tset_set_global_ids: template set belongs to another context");
   HIP_TRY(hipSetDevice(c->par.device));
   if (!ids) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -919,6 +965,7 @@ int hhv_merge_hits(hhv_ctx* c, const void* d_in, int32_t m, int32_t k, hhv_hit* 
   std::string err;
   if (merge_hits_device((const DevHit*)d_in, m, k, dst, d_n, c->stream, &err) != 0)
     return fail(HHV_E_DEVICE, "hhv_merge_hits: %s", err.c_str());
+  if (!out && !n_out) return HHV_OK;  // records and count stay on the device: asynchronous on the context's stream
   int nv = 0;
   if (out) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(&nv, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));

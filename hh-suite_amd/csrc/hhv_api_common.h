@@ -51,6 +51,11 @@ struct hhv_ctx {
   hhv::StripPlan plan;
   float* d_qpack = nullptr;  // [plan.rows()][28]
   float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring
+  size_t qpack_cap = 0, qp_cap = 0;  // floats allocated behind d_qpack / d_qp (kept between queries)
+  void* q_stage = nullptr;           // pinned staging block of hhv_set_query
+  size_t q_stage_bytes = 0;
+  hipEvent_t ev_q = nullptr;         // the last query's copies have left the staging block
+  bool q_stage_busy = false;
   // fast_log2 tables (src/util-inl.h:108-130)
   float* d_lg2 = nullptr;
   float* d_diff = nullptr;

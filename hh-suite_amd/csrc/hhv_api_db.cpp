@@ -78,7 +78,10 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
     fclose(f);
     return fail(HHV_E_ARG, "hhv_db_open: truncated length table");
   }
-  HIP_TRY(hipSetDevice(c->par.device));
+  if (const hipError_t e = hipSetDevice(c->par.device); e != hipSuccess) {
+    fclose(f);
+    return fail(HHV_E_DEVICE, "hhv_db_open: hipSetDevice(%d): %s", c->par.device, hipGetErrorString(e));
+  }
   hhv_tset* ts = new (std::nothrow) hhv_tset();
   if (!ts) {
     fclose(f);

@@ -18,6 +18,7 @@
 #ifndef HHV_SIDECAR_H_
 #define HHV_SIDECAR_H_
 
+#include <errno.h>
 #include <fcntl.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -97,14 +98,20 @@ class Sidecar {
     }
     size_t written = 0;
     if (flock(fd, LOCK_EX) == 0) {
-      struct stat st;
-      if (fstat(fd, &st) == 0 && st.st_size == 0) {
-        const char head[16] = {'H', 'H', 'V', 'S', 'I', 'D', 'E', '1', 1, 0, 0, 0, 0, 0, 0, 0};
-        if (write(fd, head, sizeof(head)) != (ssize_t)sizeof(head)) usable_ = false;
+      // Under the lock: find the end of the last VALID record.  A file of another format version starts over; a torn tail (a
+      // writer killed in the middle of its write, a full disk) is cut off - appended behind it, every later record would be
+      // unreachable for load(), which stops at the first invalid one, and the file would grow with every search.
+      off_t end = valid_end(fd);
+      if (end < (off_t)kHeadBytes) {
+        if (ftruncate(fd, 0) != 0 || !write_all(fd, file_head(), kHeadBytes)) usable_ = false;
+        end = kHeadBytes;
+      } else {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && st.st_size > end && ftruncate(fd, end) != 0) usable_ = false;
       }
       if (usable_) {
-        const ssize_t w = write(fd, pending_.data(), pending_.size());
-        written = w > 0 ? (size_t)w : 0;
+        if (write_all(fd, pending_.data(), pending_.size())) written = pending_.size();
+        else if (ftruncate(fd, end) != 0) usable_ = false;   // a short write: leave no torn record behind
       }
       flock(fd, LOCK_UN);
     }
@@ -115,6 +122,39 @@ class Sidecar {
   size_t size() const { return index_.size(); }
 
  private:
+  // format version 2: records of version 1 could hold templates truncated by a small -maxres
+  enum { kHeadBytes = 16 };
+  static const char* file_head() {
+    static const char h[kHeadBytes] = {'H', 'H', 'V', 'S', 'I', 'D', 'E', '2', 2, 0, 0, 0, 0, 0, 0, 0};
+    return h;
+  }
+
+  static bool write_all(int fd, const char* p, size_t n) {
+    while (n) {
+      const ssize_t w = write(fd, p, n);
+      if (w < 0 && errno == EINTR) continue;
+      if (w <= 0) return false;
+      p += w;
+      n -= (size_t)w;
+    }
+    return true;
+  }
+  // offset behind the last valid record (record headers only); 0 = no valid file header
+  static off_t valid_end(int fd) {
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < (off_t)kHeadBytes) return 0;
+    char head[kHeadBytes];
+    if (pread(fd, head, kHeadBytes, 0) != (ssize_t)kHeadBytes || memcmp(head, file_head(), 8) != 0) return 0;
+    off_t at = kHeadBytes;
+    while (at + 12 <= st.st_size) {
+      uint32_t h[3];
+      if (pread(fd, h, 12, at) != 12) break;
+      if (h[0] != kRecMagic || h[1] < 12 || at + (off_t)h[1] > st.st_size || 12 + (size_t)h[2] > h[1]) break;
+      at += h[1];
+    }
+    return at;
+  }
+
   std::string path_;
   void* map_;
   size_t map_bytes_;
@@ -295,14 +335,14 @@ class Sidecar {
     void* m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return;
-    if (memcmp(m, "HHVSIDE1", 8) != 0) {
+    if (memcmp(m, file_head(), 8) != 0) {  // another format version: ignored here, started over by the next flush()
       munmap(m, (size_t)st.st_size);
       return;
     }
     map_ = m;
     map_bytes_ = (size_t)st.st_size;
     // index scan: record header + entry name only
-    size_t at = 16;
+    size_t at = kHeadBytes;
     const char* base = (const char*)map_;
     while (at + 12 <= map_bytes_) {
       uint32_t magic, total, nlen;

@@ -141,10 +141,28 @@ bool entry_is_hh_text(const std::vector<HHblitsDatabase*>& dbs, char* name) {
   return found;
 }
 
+// An HHEntry does not say which database it came from (HHDatabaseEntry::ffdatabase / entry are private,
+// src/hhdatabase.h:98-101), so everything below finds "the" entry behind a name by looking the name up.  That is only an
+// identity while ONE of the searched databases holds the name: with the same name in two -d databases the lookup would
+// hand an entry of the second database the text, sidecar record and resident columns of the first.  Such
+// names take the reference's own path every time: read through the entry itself, prepared on the host, not cached.
+bool name_in_several_databases(const std::vector<HHblitsDatabase*>& dbs, char* name) {
+  int holders = 0;
+  for (size_t d = 0; d < dbs.size(); ++d) {
+    HHblitsDatabase* db = dbs[d];
+    if (!db) continue;
+    if ((db->hhm_database && ffindex_get_entry_by_name(db->hhm_database->db_index, name)) ||
+        (db->a3m_database && ffindex_get_entry_by_name(db->a3m_database->db_index, name)) ||
+        (db->use_compressed && db->ca3m_database && ffindex_get_entry_by_name(db->ca3m_database->db_index, name)))
+      ++holders;
+  }
+  return holders > 1;
+}
+
 // The hhm ffindex database that holds this entry as an HHM text (and no database holds it as anything else): the
 // entries whose parse result the sidecar may stand in for.  *fe = its ffindex entry (offset / length = the validity key).
 FFindexDatabase* hh_text_database(const std::vector<HHblitsDatabase*>& dbs, char* name, ffindex_entry_t** fe) {
-  if (!entry_is_hh_text(dbs, name)) return NULL;
+  if (name_in_several_databases(dbs, name) || !entry_is_hh_text(dbs, name)) return NULL;
   for (size_t d = 0; d < dbs.size(); ++d) {
     HHblitsDatabase* db = dbs[d];
     if (!db || !db->hhm_database) continue;
@@ -158,8 +176,10 @@ FFindexDatabase* hh_text_database(const std::vector<HHblitsDatabase*>& dbs, char
 }
 
 // the database entry behind a name, in the order HHblitsDatabase::getEntriesFromNames looks (src/hhdatabase.cpp:198-215)
+// (an empty identity - data == NULL - for a name that several databases hold: never equal to a cached one, see valid())
 hhv_dropin::EntryIdentity identify_entry(const std::vector<HHblitsDatabase*>& dbs, char* name) {
   hhv_dropin::EntryIdentity id;
+  if (name_in_several_databases(dbs, name)) return id;
   for (size_t d = 0; d < dbs.size(); ++d) {
     HHblitsDatabase* db = dbs[d];
     if (!db) continue;
@@ -582,7 +602,8 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
               std::unordered_map<std::string, CachedTemplate>::const_iterator it = tc.map.find(cache_key(ent[k]));
               // same name and length but another database entry (two databases, a rebuilt one): read it again, the new
               // upload takes the slot
-              if (it != tc.map.end() && it->second.id == identify_entry(databases, ent[k]->getName())) cached[k] = &it->second;  // std::unordered_map never moves its elements
+              const hhv_dropin::EntryIdentity id = identify_entry(databases, ent[k]->getName());
+              if (it != tc.map.end() && id.data != NULL && it->second.id == id) cached[k] = &it->second;  // std::unordered_map never moves its elements
               else to_read.push_back(k);
             }
           } else {
@@ -641,7 +662,8 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
             HMM* t = t_hmm[tid];
             ent[k]->getTemplateHMM(par, wg, qsc, format_tmp, pb, S, Sim, t);
             t->entry = ent[k];
-            h.raw = device_prepare && format_tmp == 0 && memcmp(pb, pb0, sizeof(pb0)) == 0 && t->L >= 1 && t->L <= 0xFFFF;
+            h.raw = device_prepare && format_tmp == 0 && memcmp(pb, pb0, sizeof(pb0)) == 0 && t->L >= 1 && t->L <= 0xFFFF &&
+                    !name_in_several_databases(databases, ent[k]->getName());
             h.L = t->L;
             h.hh_text = h.raw && entry_is_hh_text(databases, ent[k]->getName());
             h.ss_pair_mode = HMM::computeScoreSSMode(q, t);
@@ -662,7 +684,12 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 h.neff[(size_t)i * 3 + 2] = t->Neff_D[i];
               }
               h.neff_hmm = t->Neff_HMM;
-              if (sc && h.hh_text) {  // parsed here for the first time: leave it in the sidecar for the next process
+              // parsed here for the first time: leave it in the sidecar for the next process - unless this parse may have been
+              // cut short by the limits of THIS run (HMM::Read stops at maxres - 2 columns and at maxcol - 1 characters per
+              // sequence, src/hhhmm.cpp:395-468,601,669): a record is valid for every later run, whatever its -maxres
+              bool whole = t->L < par.maxres - 2;
+              for (int x = 0; whole && x < t->n_seqs; ++x) whole = t->seq[x] == NULL || (int)strlen(t->seq[x]) < par.maxcol - 2;
+              if (sc && h.hh_text && whole) {
                 rec.ff_hash = text_hash;
                 rec.ff_length = (uint64_t)fe->length;
                 rec.nseqdis = par.nseqdis;
@@ -783,6 +810,10 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
               for (size_t u = 0; u < uploads.size(); ++u) uploads[u].join();
               tc.columns += cols;
               std::vector<CachedTemplate*> slot(n);
+              // the same key twice in one chunk (an entry listed twice): both x share ONE CachedTemplate; the later upload
+              // owns it and only that x fills it below (two fills would race on ct.proto under the parallel loop)
+              std::vector<char> fills(n, 0);
+              std::unordered_map<CachedTemplate*, int> owner;
               for (int d = 0; d < n_slots; ++d) {
                 if (members[d].empty()) continue;
                 tc.slots[d].rawsets.push_back(new_set[d]);
@@ -797,13 +828,17 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                   ct.id = identify_entry(databases, ent[raw_k[x]]->getName());
                   slot[x] = &ct;
                   cached[raw_k[x]] = &ct;
+                  std::unordered_map<CachedTemplate*, int>::iterator ow = owner.find(&ct);
+                  if (ow != owner.end()) fills[ow->second] = 0;
+                  owner[&ct] = x;
+                  fills[x] = 1;
                 }
               }
 #pragma omp parallel for schedule(static) num_threads(threads) if (n > 256)
               for (int x = 0; x < n; ++x) {
                 HostTemplate& h = host[raw_r[x]];
                 CachedTemplate& ct = *slot[x];
-                if (cached[raw_k[x]] != &ct) continue;  // (kept for symmetry; every slot is distinct unless a key repeats)
+                if (!fills[x]) continue;
                 ct.L = h.L;
                 ct.weights_free = h.hh_text;
                 ct.ss_pair_mode = h.ss_pair_mode;

@@ -192,6 +192,23 @@ def pack_profile(p, tr, index=-1):
     return out
 
 
+def _row_pointers(block):
+    """(n, ...) C-contiguous float32 block -> ctypes float*[n] with element k pointing at block[k] (no per-row Python object)."""
+    assert block.dtype == np.float32 and block.flags.c_contiguous
+    n = block.shape[0]
+    addr = (block.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(block.strides[0])).astype(np.uint64)
+    arr = (c_float_p * n).from_buffer_copy(addr.tobytes())
+    return arr
+
+
+def db_write_blocks(path, P, T):
+    """hhv_db_write for equal-length templates held in two blocks: P (n, L+1, 20), T (n, L+1, 7)."""
+    n, L = P.shape[0], P.shape[1] - 1
+    Ls = np.full(n, L, dtype=np.int32)
+    _check(load().hhv_db_write(str(path).encode(), n, Ls.ctypes.data_as(c_int_p), _row_pointers(P), _row_pointers(T), None, None, None))
+    return Ls
+
+
 def db_write(path, tps, ttrs):
     """hhv_db_write: pack host profiles into a binary template database file (no device needed)."""
     tps = [_f32(a) for a in tps]
@@ -287,6 +304,14 @@ class Context:
                 arrs.append((C.c_void_p * n)(*[(k[col].ctypes.data if k[col] is not None else None) for k in keep]))
             _check(self.lib.hhv_upload_templates_ss(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, arrs[0], arrs[1],
                                                     arrs[2], C.byref(h)))
+        return TemplateSet(self, h, Ls)
+
+    def upload_blocks(self, P, T):
+        """hhv_upload_templates for equal-length templates held in two blocks: P (n, L+1, 20), T (n, L+1, 7) float32."""
+        n, L = P.shape[0], P.shape[1] - 1
+        Ls = np.full(n, L, dtype=np.int32)
+        h = C.c_void_p()
+        _check(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), _row_pointers(P), _row_pointers(T), C.byref(h)))
         return TemplateSet(self, h, Ls)
 
     def set_ss_tables(self, S73, S33, S37):
@@ -582,13 +607,15 @@ class Context:
             raise HhvError("set_global_ids: %d ids for %d templates" % (ids.shape[0], ts.n))
         _check(self.lib.hhv_tset_set_global_ids(self.h, ts.h, ids.ctypes.data_as(C.c_void_p)))
 
-    def merge_hits(self, d_in, m, k, d_out=None, fetch=True):
-        """d_in: device pointer to m hhv_hit records (gathered top-K lists, global ids) -> the k best, merged on the device"""
+    def merge_hits(self, d_in, m, k, d_out=None, fetch=True, count=True):
+        """d_in: device pointer to m hhv_hit records (gathered top-K lists, global ids) -> the k best, merged on the device.
+        fetch=False, count=False: the merge is only enqueued on the context's stream (no host wait); returns (None, None)"""
         out = np.zeros(k, dtype=HIT_DTYPE) if fetch else None
         n = C.c_int32()
+        want_n = fetch or count
         _check(self.lib.hhv_merge_hits(self.h, C.c_void_p(d_in), int(m), int(k), out.ctypes.data if fetch else None,
-                                       C.c_void_p(d_out) if d_out else None, C.byref(n)))
-        return (out[:n.value] if fetch else None), n.value
+                                       C.c_void_p(d_out) if d_out else None, C.byref(n) if want_n else None))
+        return (out[:n.value] if fetch else None), (n.value if want_n else None)
 
 
 # ---- C++ runner (hh-suite_amd/host/viterbi_runner.cpp) through its C shim --------------------------

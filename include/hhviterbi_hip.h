@@ -142,7 +142,9 @@ void hhv_destroy(hhv_ctx* ctx);
  * raw template database of earlier searches resident in one).  The query, the resident sets and their results stay. */
 int hhv_set_params(hhv_ctx* ctx, const hhv_params* par);
 
-/* query: p[(Lq+1)*20], tr[(Lq+1)*7] */
+/* query: p[(Lq+1)*20], tr[(Lq+1)*7] (copied before the call returns: the caller may reuse its arrays at once).
+ * The rows travel through a pinned staging block with asynchronous copies on the context's stream; device buffers and
+ * staging are kept between queries, so a loop that sets one query per search does not wait for the device. */
 int hhv_set_query(hhv_ctx* ctx, const float* p, const float* tr, int32_t Lq);
 
 /* secondary structure (all optional; without them the engine runs the reference's no-SS kernels).
@@ -363,7 +365,8 @@ int hhv_set_global_batch(hhv_ctx* ctx, hhv_tset* ts, const uint8_t* not_longest)
 int hhv_backtrace_matrix(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint8_t* out);
 
 /* Viterbi::Backtrace + Viterbi::ScoreForBacktrace for all templates, on the device (needs a
- * preceding hhv_align with HHV_ALIGN_BACKTRACE).  hits (host, n entries, nullable). */
+ * preceding hhv_align with HHV_ALIGN_BACKTRACE).  hits (host, n entries, nullable; NULL = the kernels are only
+ * enqueued on the context's stream, the records stay on the device for hhv_topk / hhv_hit_path). */
 int hhv_hits(hhv_ctx* ctx, hhv_tset* ts, hhv_hit* hits);
 /* path of template k: arrays of cap entries, 1-based like BacktraceResult (index 0 unused,
  * step 1 = alignment end); S = per-step column scores (BacktraceScore.S).  Needs hhv_hits. */
@@ -379,7 +382,9 @@ int hhv_hit_path_pool(hhv_ctx* ctx, hhv_tset* ts, const int64_t** path_off, cons
  * flags: 0 = rank by Hit.score (needs hhv_hits); HHV_TOPK_RAW = rank by the raw Viterbi score of the
  * last hhv_align (score-only searches: the records carry viterbi_score, i2, j2, index; path fields 0).
  * out: host, k entries (nullable); d_out: DEVICE pointer to k hhv_hit records (nullable) - the buffer a
- * multi-GPU caller hands to its all-gather; entries beyond *n_out are filled with 0xFF bytes. */
+ * multi-GPU caller hands to its all-gather; entries beyond *n_out are filled with 0xFF bytes.
+ * With out == NULL the call only enqueues work on the context's stream (hhv_stream) and does not wait for it: a caller
+ * that consumes d_out on another stream orders the two with an event (bench.py: hhv_topk -> all_gather -> hhv_merge_hits). */
 #define HHV_TOPK_RAW 1u
 int hhv_topk(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, void* d_out, int32_t* n_out);
 /* Sharded databases (one hhv_ctx / hhv_tset per GPU, hhv_shard_plan): ids[k] >= 0 = the GLOBAL template id of entry k
@@ -390,7 +395,8 @@ int hhv_tset_set_global_ids(hhv_ctx* ctx, hhv_tset* ts, const int32_t* ids);
  * hhv_topk output after the all-gather (records with index < 0 are padding).  Returns the k best by score (descending,
  * ties by the smaller global id - the order the reference's caller gives the hit list, src/hhhit.h:116-126, after
  * ViterbiRunner::alignment appended the batches one after the other, src/hhviterbirunner.cpp:173); identical on every
- * rank.  out: host, k entries (nullable); d_out: DEVICE, k entries (nullable); entries beyond *n_out are 0xFF bytes. */
+ * rank.  out: host, k entries (nullable); d_out: DEVICE, k entries (nullable); entries beyond *n_out are 0xFF bytes.
+ * With out == NULL and n_out == NULL the merge is only enqueued on the context's stream (no host wait). */
 int hhv_merge_hits(hhv_ctx* ctx, const void* d_in, int32_t m, int32_t k, hhv_hit* out, void* d_out, int32_t* n_out);
 
 #if defined(__GNUC__)

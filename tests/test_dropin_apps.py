@@ -372,6 +372,86 @@ def test_sidecar_replaces_the_text_parse_in_the_next_process(tmp_path, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
+def test_sidecar_never_keeps_a_template_truncated_by_maxres(tmp_path):
+    """ADVICE r2: HMM::Read cuts a template at -maxres - 2 columns (src/hhhmm.cpp:601,669).  A run with a small -maxres must
+    not leave the cut template in the sidecar, where a later run with the default -maxres would take it for the whole one."""
+    q, t, names = make_db(620, 120, 24, 60, 200)
+    base, qpath = build_db(str(tmp_path), q, t, names, 4)
+    side = base + "_hhm.ffdata.hhvside"
+    common = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "2"]
+    small = common + ["-maxres", "130"]                       # templates longer than 128 columns are cut
+    lens = [int(x.split(b"LENG")[1].split()[0]) for x in t]
+    assert any(L > 128 for L in lens) and any(L < 128 for L in lens)
+    cpu_small = run_app("hhsearch_cpu", small, str(tmp_path / "cpu_small"))
+    hip_small = run_app("hhsearch_hip", small, str(tmp_path / "hip_small"))
+    compare_outputs(cpu_small, hip_small)
+    assert os.path.exists(side)
+    cpu_full = run_app("hhsearch_cpu", common, str(tmp_path / "cpu_full"))
+    hip_full = run_app("hhsearch_hip", common, str(tmp_path / "hip_full"), env={"HHV_DROPIN_TIMING": "1"})
+    compare_outputs(cpu_full, hip_full)                        # (with a cut record in the sidecar the long templates would differ)
+    hip_again = run_app("hhsearch_hip", common, str(tmp_path / "hip_again"))
+    compare_outputs(cpu_full, hip_again)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
+def test_sidecar_survives_a_torn_tail_and_an_old_format(tmp_path):
+    """a writer killed in the middle of its append leaves a torn record; the next writer must cut it off instead of
+    appending behind it (load() stops at the first invalid record: everything behind it would be unreachable and re-appended
+    by every later search).  A file of another format version is started over."""
+    q, t, names = make_db(621, 100, 16, 50, 120)
+    base, qpath = build_db(str(tmp_path), q, t, names, 4)
+    side = base + "_hhm.ffdata.hhvside"
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "2"]
+    cpu = run_app("hhsearch_cpu", args, str(tmp_path / "cpu"))
+    open(side, "wb").write(b"HHVSIDE1" + bytes(8) + b"x" * 5000)          # an old-format file
+    a = run_app("hhsearch_hip", args, str(tmp_path / "a"))
+    compare_outputs(cpu, a)
+    whole = os.path.getsize(side)
+    assert open(side, "rb").read(8) == b"HHVSIDE2" and whole > 16
+    with open(side, "ab") as f:                                             # a torn record behind the valid ones
+        f.write(b"REC1" + (100000).to_bytes(4, "little") + b"garbage")
+    b = run_app("hhsearch_hip", args, str(tmp_path / "b"))                  # reads the valid records, appends nothing
+    compare_outputs(cpu, b)
+    # change one template: the next run has something to append and must cut the torn tail first
+    t2 = list(t)
+    t2[0] = t[0].replace(b"NEFF  ", b"NEFF   ", 1) if b"NEFF  " in t[0] else t[0] + b"\n"
+    build_db(str(tmp_path), q, t2, names, 4)
+    cpu2 = run_app("hhsearch_cpu", args, str(tmp_path / "cpu2"))
+    c = run_app("hhsearch_hip", args, str(tmp_path / "c"))
+    compare_outputs(cpu2, c)
+    data = open(side, "rb").read()
+    assert b"garbage" not in data and len(data) > 16
+    d = run_app("hhsearch_hip", args, str(tmp_path / "d"), env={"HHV_DROPIN_TIMING": "1"})
+    compare_outputs(cpu2, d)
+    assert os.path.getsize(side) == len(data), "every record is reachable: nothing appended again"
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
+def test_same_name_in_two_databases(tmp_path):
+    """two -d databases that both hold a template name (same length, different columns).  A lookup by name cannot
+    tell the two entries apart, so such names bypass sidecar and resident cache; cold and warm runs equal the reference."""
+    q, t, names = make_db(630, 110, 12, 90, 90)
+    qb, tb, namesb = make_db(631, 110, 12, 90, 90)
+    d1, d2 = tmp_path / "one", tmp_path / "two"
+    d1.mkdir()
+    d2.mkdir()
+    base1, qpath = build_db(str(d1), q, t, names, 4)
+    # the second database: other columns under the first database's names for half of its entries
+    tb = [x.replace(nb.encode(), n.encode()) if k % 2 == 0 else x for k, (x, nb, n) in enumerate(zip(tb, namesb, names))]
+    names2 = [n if k % 2 == 0 else nb for k, (nb, n) in enumerate(zip(namesb, names))]
+    base2, _ = build_db(str(d2), qb, tb, names2, 5)
+    args = ["-i", qpath, "-d", base1, "-d", base2, "-nocontxt", "-premerge", "0", "-cpu", "2"]
+    cpu = run_app("hhsearch_cpu", args, str(tmp_path / "cpu"))
+    cold = run_app("hhsearch_hip", args, str(tmp_path / "cold"))
+    compare_outputs(cpu, cold)
+    warm = run_app("hhsearch_hip", args, str(tmp_path / "warm"))
+    compare_outputs(cpu, warm)
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not have("hhblits_hip"), reason="oracle/_ref/hhblits_hip not built (needs /root/reference at build time)")
 @pytest.mark.parametrize("case", ["hhsearch_ragged_global", "hhsearch_ss_alt", "hhblits_one_iteration"])
 def test_template_database_sharded_over_devices(tmp_path, case):

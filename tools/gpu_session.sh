@@ -1,0 +1,44 @@
+#!/bin/bash
+# The GPU-box sessions of a round, one stage per gpurun call:  gpurun -- 'bash tools/gpu_session.sh <stage> [args]'
+# (what each stage produced is logged in tools/SESSIONS.md; outputs land in gpurun_out/ and the ones that are evidence are
+# copied to profiles/ by hand).  Stages:
+#   check [soak_s]   the driver's round-end sequence (GPU suite, default bench line, smoke) + the multi-rank bench variants
+#                    + the randomised soak on HEAD (default 100 s per family)
+#   ab <libdir>...   A/B of library builds on the fixed set of bench configurations (tools/gpu_ab.sh)
+#   profile          rocprofv3 kernel trace + PMC passes of the headline command and its backtrace twin (tools/profile.sh)
+#   next             the same for the prefilter / MAC kernels (tools/profile_next.sh)
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd $ROOT
+stage=$1; shift
+short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload"
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.3e cells/s, %.2f ms/step, kernel %.2f ms (min %.2f)' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['kernel_ms_min']))"; }
+case $stage in
+check)
+  soak_s=${1:-100}
+  timeout 1700 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > $OUT/gpu_suite.log; cat $OUT/gpu_suite.log
+  timeout 500 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 6000 $OUT/bench_default.json; tail -3 $OUT/bench_default.err
+  timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+  echo "== one rank through RCCL (--force-dist), headline size"
+  timeout 300 python bench.py --force-dist --steps 20 --warmup 5 $short > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err; line < $OUT/bench_force_dist.json; tail -2 $OUT/bench_force_dist.err
+  echo "== configs[4] as one of 8 shards would see it: --lengths zipf --local 1, 125k templates"
+  timeout 300 python bench.py --lengths zipf --local 1 --templates 125000 --steps 10 --warmup 3 $short > $OUT/bench_zipf.json 2> $OUT/bench_zipf.err; line < $OUT/bench_zipf.json
+  for cfg in "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 150 --templates 100000" "--lq 150 --templates 100000 --backtrace 1" "--lq 80 --templates 100000" "--lq 300 --templates 100000 --local 1" "--lq 300 --templates 100000 --backtrace 1"; do
+    echo -n "== $cfg : "
+    timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+  done
+  echo "== soak, $soak_s s per family"
+  timeout $((soak_s * 5 + 120)) python tools/soak.py $soak_s > $OUT/soak.json 2> $OUT/soak.err; cat $OUT/soak.json; tail -2 $OUT/soak.err
+  ;;
+ab)
+  bash tools/gpu_ab.sh "$@"
+  ;;
+profile)
+  bash tools/profile.sh "$@"
+  ;;
+next)
+  bash tools/profile_next.sh "$@"
+  ;;
+*) echo "unknown stage $stage"; exit 2;;
+esac

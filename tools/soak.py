@@ -47,20 +47,35 @@ def viterbi_family(orc, rng, budget):
         if rng.random() < 0.5:
             qtr = quantize(qtr, rng, 0.5)
             qtr[qtr < -1000] = -100000.0
+        # a third of the cases: thousands of copies of the pool in random order, so that every resident wavefront walks several
+        # templates - most of them 1-3 columns long - back to back (headers in consecutive steps: the finalized-best hand-off of
+        # the 64-lane arrays, the column-0 reset behind a last column); the pool alone is one template per wavefront
+        many = rng.random() < 0.35
+        idx = rng.integers(0, n, int(rng.integers(2500, 6000))) if many else np.arange(n)
+        if many and rng.random() < 0.7:
+            short = [k for k in range(n) if tps[k].shape[0] - 1 <= 3]
+            if short:
+                idx = np.where(rng.random(idx.shape[0]) < 0.6, rng.choice(short, idx.shape[0]), idx)
         c = capi.Context(local=local, egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"], ss_mode=0)
         c.set_query(qp, qtr)
-        ts = c.upload(tps, ttrs)
+        ts = c.upload([tps[k] for k in idx], [ttrs[k] for k in idx])
         use_mask = any(m is not None for m in masks)
         if use_mask:
-            for k, m in enumerate(masks):
-                c.set_celloff(ts, k, m if m is not None else np.zeros((Lq + 1, tps[k].shape[0]), np.uint8))
+            for e, k in enumerate(idx):
+                if many and e >= 64 and masks[k] is None:
+                    continue   # (a set that never saw a compare-bit launch starts with all cells on)
+                m = masks[k]
+                c.set_celloff(ts, e, m if m is not None else np.zeros((Lq + 1, tps[k].shape[0]), np.uint8))
         res = c.align(ts, backtrace=True, celloff=use_mask)
         hits = c.hits(ts)
-        for k in range(n):
-            a = orc.align(par, qp, qtr, tps[k], ttrs[k], celloff=masks[k] if use_mask else None, want_path=True)
-            ok = (a.i2, a.j2) == (int(res["i2"][k]), int(res["j2"][k])) and np.float32(a.score).tobytes() == np.float32(res["score"][k]).tobytes()
-            ok = ok and np.array_equal(c.backtrace_matrix(ts, k)[1:, 1:] & 0x7F, a.bt[1:, 1:] & 0x7F)
-            ok = ok and int(hits["nsteps"][k]) == a.nsteps and np.float32(hits["score"][k]).tobytes() == np.float32(a.hit_score).tobytes()
+        want = [orc.align(par, qp, qtr, tps[k], ttrs[k], celloff=masks[k] if use_mask else None, want_path=True) for k in range(n)]
+        bt_sample = set(range(len(idx))) if not many else set(int(e) for e in rng.integers(0, len(idx), 12))
+        for e, k in enumerate(idx):
+            a = want[k]
+            ok = (a.i2, a.j2) == (int(res["i2"][e]), int(res["j2"][e])) and np.float32(a.score).tobytes() == np.float32(res["score"][e]).tobytes()
+            if e in bt_sample:
+                ok = ok and np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:] & 0x7F, a.bt[1:, 1:] & 0x7F)
+            ok = ok and int(hits["nsteps"][e]) == a.nsteps and np.float32(hits["score"][e]).tobytes() == np.float32(a.hit_score).tobytes()
             cases += 1
             bad += int(not ok)
         ts.free()
