@@ -49,8 +49,8 @@ int32_t hhv_record_bytes(void) { return REC_DW * (int32_t)sizeof(float); }
 
 int hhv_pack_profile(const float* p, const float* tr, int32_t L, int32_t index, float* out) {
   if (!p || !tr || !out || L < 1) return fail(HHV_E_ARG, "hhv_pack_profile: bad argument");
-  if (index >= 0) pack_template(p, tr, L, index, out);
-  else pack_columns(p, tr, L, out);
+  const bool ok = index >= 0 ? pack_template(p, tr, L, index, out) : pack_columns(p, tr, L, out);
+  if (!ok) return fail(HHV_E_ARG, "hhv_pack_profile: negative profile value (profile values are probabilities / odds)");
   return HHV_OK;
 }
 
@@ -231,7 +231,8 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   float* const h_qpack = (float*)c->q_stage;
   float* const h_qp = h_qpack + n_qpack;
   memset(h_qpack, 0, n_qpack * sizeof(float));
-  pack_columns(p, tr, Lq, h_qpack);
+  if (!pack_columns(p, tr, Lq, h_qpack))
+    return fail(HHV_E_ARG, "hhv_set_query: negative profile value (profile values are probabilities)");
   memcpy(h_qp, p, n_qp * sizeof(float));
   HIP_TRY(hipMemcpyAsync(c->d_qpack, h_qpack, n_qpack * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_qp, h_qp, n_qp * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -396,8 +397,11 @@ int hhv_upload_templates_ss(hhv_ctx* c, int32_t n, const int32_t* L, const float
           return fail(HHV_E_ARG, "template %d column %d: secondary-structure code out of range", t, j);
         }
       }
-      pack_template(p[t], tr[t], L[t], t, stage.data() + o, ss_pred ? ss_pred[t] : nullptr,
-                    ss_conf ? ss_conf[t] : nullptr, ss_dssp ? ss_dssp[t] : nullptr);
+      if (!pack_template(p[t], tr[t], L[t], t, stage.data() + o, ss_pred ? ss_pred[t] : nullptr,
+                         ss_conf ? ss_conf[t] : nullptr, ss_dssp ? ss_dssp[t] : nullptr)) {
+        hhv_tset_free(ts);
+        return fail(HHV_E_ARG, "hhv_upload_templates: template %d has a negative profile value (p = f / null model >= 0)", t);
+      }
       o += ((size_t)L[t] + 1) * REC_DW;
     }
     if (hipMemcpy(ts->d_records + (size_t)ts->rec_off[k0] * REC_DW, stage.data(), stage.size() * sizeof(float),
@@ -594,6 +598,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     ts->bt_valid = true;
     ts->bt_dirty = true;
     ts->bt_Lq = c->Lq;
+    ts->bt_mm = bt_mm_mode(plan.W, plan.R_hi, local, celloff, ss);  // (multi-pass plans are 64-lane plans: one encoding for all passes)
   }
   ts->hits_valid = false;
   return HHV_OK;
@@ -741,7 +746,7 @@ int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
   const size_t bytes = (size_t)(Lq + 1) * (Lt + 1);
   unsigned char* d_out = nullptr;
   HIP_TRY(hipMalloc(&d_out, bytes));
-  const int lr = bt_matrix(ts->d_bt, ts->d_rec_off, (int64_t)bt_plane_entries(ts->n_records, ts->bt_plan.W), Lq, ts->bt_plan, k, Lt,
+  const int lr = bt_matrix(ts->d_bt, ts->d_rec_off, (int64_t)bt_plane_entries(ts->n_records, ts->bt_plan.W), Lq, ts->bt_plan, ts->bt_mm, k, Lt,
                            d_out, c->stream);
   hipError_t e = lr == 0 ? hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream) : hipErrorUnknown;
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -802,6 +807,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.plan = ts->bt_plan;
   a.n = ts->n;
   a.bt_pass_stride = (int64_t)bt_plane_entries(ts->n_records, ts->bt_plan.W);
+  a.bt_mm = ts->bt_mm;
   rc = ensure_ss(c);
   if (rc != HHV_OK) return rc;
   a.ss_table = c->ss_hmm_mode ? c->d_ss_table : nullptr;

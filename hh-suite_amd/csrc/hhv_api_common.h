@@ -107,6 +107,7 @@ struct hhv_tset {
   // of the buffer is stale as a MASK until it is cleared (hhv_set_celloff clears the whole buffer when this is set)
   bool bt_dirty = false;
   int bt_Lq = 0;
+  int bt_mm = 0;  // encoding of the MM predecessor the last backtrace launch wrote (viterbi_lane.h bt_mm_mode)
   hhv::StripPlan bt_plan;
   // carry between the passes of a long query
   float4* d_carry = nullptr;

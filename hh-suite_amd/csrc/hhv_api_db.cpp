@@ -40,11 +40,20 @@ int hhv_db_write(const char* path, int32_t n, const int32_t* L, const float* con
   h.n_records = nrec;
   bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(L, sizeof(int32_t), (size_t)n, f) == (size_t)n;
   std::vector<float> buf;
+  int negative = -1;
   for (int k = 0; k < n && ok; ++k) {
     buf.resize(((size_t)L[k] + 1) * REC_DW);
-    pack_template(p[k], tr[k], L[k], k, buf.data(), ss_pred ? ss_pred[k] : nullptr, ss_conf ? ss_conf[k] : nullptr,
-                  ss_dssp ? ss_dssp[k] : nullptr);
+    if (!pack_template(p[k], tr[k], L[k], k, buf.data(), ss_pred ? ss_pred[k] : nullptr, ss_conf ? ss_conf[k] : nullptr,
+                       ss_dssp ? ss_dssp[k] : nullptr)) {
+      negative = k;
+      break;
+    }
     ok = fwrite(buf.data(), sizeof(float), buf.size(), f) == buf.size();
+  }
+  if (negative >= 0) {
+    fclose(f);
+    remove(path);
+    return fail(HHV_E_ARG, "hhv_db_write: template %d has a negative profile value", negative);
   }
   if (ok) {
     buf.assign(REC_DW, 0.0f);

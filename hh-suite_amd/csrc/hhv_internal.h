@@ -130,6 +130,7 @@ struct TraceArgs {
   int32_t Lq, n;
   StripPlan plan;            // which plane / lane / byte of the backtrace buffer holds query row i
   int64_t bt_pass_stride;    // backtrace entries per pass
+  int32_t bt_mm;             // encoding of the MM predecessor in the entries (viterbi_lane.h bt_mm_mode of the launch that wrote them)
   const float* ss_table;     // null: no secondary-structure information (score_ss = 0)
   const int32_t* ss_q_off;
   int32_t ss_t_shift, ss_t_mask;
@@ -302,7 +303,7 @@ void* stream_kernel_w16(int R, bool local, bool bt, bool celloff, bool ss);
 // one template's mask bytes -> cell-off entries; entries -> the reference's backtrace byte matrix (hhv_topk.hip)
 int celloff_from_mask(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan, int t,
                       const unsigned char* d_mask /* (Lq+1) x (Lt+1) bytes, null = clear */, int Lt, hipStream_t stream);
-int bt_matrix(const uint64_t* bt, const int64_t* rec_off, int64_t pass_stride, int Lq, StripPlan plan, int t, int Lt,
+int bt_matrix(const uint64_t* bt, const int64_t* rec_off, int64_t pass_stride, int Lq, StripPlan plan, int bt_mm, int t, int Lt,
               unsigned char* d_out /* (Lq+1) x (Lt+1) */, hipStream_t stream);
 int launch_trace(const TraceArgs& a, void* stream);
 

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
           uint64_t entry = c ? w[0][1] : w[0][0];
 #pragma unroll
           for (int t = 1; t < WIN; ++t) entry = (d == t) ? (c ? w[t][1] : w[t][0]) : entry;
-          b = bt_decode(entry, rr, R);
+          b = bt_decode(entry, rr, R, a.bt_mm);
         }
         step++;
         states[step] = (int8_t)state;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
       if (i >= 1 && j >= 1) {
         int pass, g, rr, Rp;
         a.plan.locate(i, pass, g, rr, Rp);
-        b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + bt_entry(rec0 + j, g, a.plan.W)], rr, Rp);
+        b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + bt_entry(rec0 + j, g, a.plan.W)], rr, Rp, a.bt_mm);
       }
       trace_step(state, i, j, matched, b);
     }

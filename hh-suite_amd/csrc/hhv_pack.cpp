@@ -15,10 +15,19 @@ namespace hhv {
 // reference enum order of tr[][7], src/hhdecl.h:68
 enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };
 
-void pack_columns(const float* p, const float* tr, int L, float* out) {
+bool pack_columns(const float* p, const float* tr, int L, float* out) {
+  bool negative = false;
   for (int k = 1; k <= L; ++k) {
     float* w = out + (size_t)(k - 1) * REC_DW;
-    memcpy(w, p + (size_t)k * 20, 20 * sizeof(float));
+    const float* src = p + (size_t)k * 20;
+    // Profile values are probabilities / odds.  The kernel's log2f4 takes the exponent of a column product with a plain shift
+    // (viterbi_lane.h), which is the reference's masked field only for a sign bit of 0: negative values are reported to the
+    // caller, and -0.0f is stored as +0.0f (x + 0: every product, sum and log2f4 of the reference comes out the same).
+    for (int a = 0; a < 20; ++a) {
+      const float v = src[a];
+      negative |= v < 0.0f;
+      w[a] = v + 0.0f;
+    }
     const float* a = tr + (size_t)(k - 1) * 7;
     const float* b = tr + (size_t)k * 7;
     w[REC_M2M] = a[T_M2M];
@@ -30,6 +39,7 @@ void pack_columns(const float* p, const float* tr, int L, float* out) {
     w[REC_M2I] = b[T_M2I];
     w[REC_META] = 0.0f;
   }
+  return !negative;
 }
 
 static inline void put_i32(float* dst, int32_t v) { memcpy(dst, &v, 4); }
@@ -41,10 +51,10 @@ void write_header(float* rec, int32_t index, int32_t L) {
   put_i32(rec + REC_META, META_HDR);
 }
 
-void pack_template(const float* p, const float* tr, int L, int32_t index, float* out, const int8_t* ss_pred,
+bool pack_template(const float* p, const float* tr, int L, int32_t index, float* out, const int8_t* ss_pred,
                    const int8_t* ss_conf, const int8_t* ss_dssp) {
   write_header(out, index, L);
-  pack_columns(p, tr, L, out + REC_DW);
+  const bool ok = pack_columns(p, tr, L, out + REC_DW);
   for (int j = 1; j <= L; ++j) {
     int32_t meta = j;
     if (j == L) meta |= META_LAST;
@@ -55,6 +65,7 @@ void pack_template(const float* p, const float* tr, int L, int32_t index, float*
     meta |= (int32_t)(dssp & META_DSSP_MASK) << META_DSSP_SHIFT;
     put_i32(out + (size_t)j * REC_DW + REC_META, meta);
   }
+  return ok;
 }
 
 }  // namespace hhv

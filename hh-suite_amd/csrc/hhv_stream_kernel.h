@@ -315,10 +315,10 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   P.egt = a.egt;
   P.shift = a.shift;
   P.Lq = a.Lq;
-  // log2f4's constants as SGPR operands instead of 32-bit literals (viterbi_lane.h: Log2Consts); the asm keeps hipcc from
-  // folding them back into the instructions
+  // log2f4's constants as SGPR operands instead of 32-bit literals (viterbi_lane.h: Log2Consts; expor is the v_alignbit
+  // operand 0x4B000000 >> 9); the asm keeps hipcc from folding them back into the instructions
   asm volatile("s_mov_b32 %0, 0xbddba835\n\ts_mov_b32 %1, 0x3f3030c0\n\ts_mov_b32 %2, 0xbfe0d411\n\ts_mov_b32 %3, 0x402786ee\n\t"
-               "s_mov_b32 %4, 0x4b00007f\n\ts_mov_b32 %5, 0x4b000000\n\ts_mov_b32 %6, 0x007fffff"
+               "s_mov_b32 %4, 0x4b00007f\n\ts_mov_b32 %5, 0x00258000\n\ts_mov_b32 %6, 0x007fffff"
                : "=s"(P.lg.c4), "=s"(P.lg.c3), "=s"(P.lg.c2), "=s"(P.lg.c1), "=s"(P.lg.ebias), "=s"(P.lg.expor), "=s"(P.lg.mant));
   const int i0 = a.row_base + g * R + 1;
   // the lane that emits results: owner of row Lq in the last pass, the array's last lane otherwise
@@ -386,7 +386,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // `nxt` (no copy between the steps: the step loop is unrolled by two).
   decltype(col) col2 = col;
   if (PF) {
-    decltype(col)::head_issue(record_addr(0), col.v6, col.v5);
+    col.rec_addr = record_addr(0);
+    decltype(col)::head_issue(col.rec_addr, col.v6, col.v5);
     decltype(col)::head_wait(col.v6, col.v5);
   }
 
@@ -417,7 +418,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     cur.tB = t0;
 #endif
 
-    cur.rec_addr = record_addr(s);
+    // (PF: the address of this step's record was formed one step ago, for the head prefetch, and kept in the operand source)
+    if (!PF) cur.rec_addr = record_addr(s);
 
     // hand-off from lane g-1 (full EXEC here).  The row-0 sums that read LAST step's hand-off first; then the pulls: MM and MI
     // into the operand source, GD / IM / DG straight into st.dGD / dIM / dDG - nothing touches the five registers until
@@ -451,7 +453,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       pull5(pull_addr, cur.hMM, st.dGD, st.dIM, st.dDG, cur.hMI, st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1], st.MI[R - 1]);
       meta = cur.meta();  // (the head of this step landed at the end of the previous one)
       if (QL) cur.qa_issue();
-      decltype(col)::head_issue(record_addr(s + 1), nxt.v6, nxt.v5);
+      nxt.rec_addr = record_addr(s + 1);
+      decltype(col)::head_issue(nxt.rec_addr, nxt.v6, nxt.v5);
     } else {
       // 64-lane variants that read the head at the top of the step: the pulls in front of it, its wait covers them
       pull5(pull_addr, cur.hMM, st.dGD, st.dIM, st.dDG, cur.hMI, st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1], st.MI[R - 1]);
@@ -519,7 +522,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         // single pass: the boundary value of the first lane is formed inside the column's block, so that it need not be held
         // through phases A and B (it is read in phase C)
         const Incoming inc = MULTI ? in : boundary_incoming(meta, jcol, P);
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
       if (carry_out) {
@@ -566,6 +569,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         step(s, col, col2);
         col.v6 = col2.v6;
         col.v5 = col2.v5;
+        col.rec_addr = col2.rec_addr;
       }
     } else if (PF) {
       // multi-pass variants (measured 1 % slower unrolled): one step per iteration, the prefetched head is copied
@@ -573,6 +577,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         step(s, col, col2);
         col.v6 = col2.v6;
         col.v5 = col2.v5;
+        col.rec_addr = col2.rec_addr;
       }
     } else {
       for (int s = s_lo; s < s_hi; ++s) step(s, col, col);

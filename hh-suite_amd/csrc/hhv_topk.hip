@@ -332,6 +332,7 @@ struct CellOffGeom {
   int64_t pass_stride;  // entries per pass
   int Lq;
   StripPlan plan;
+  int bt_mm;  // bt_matrix_kernel only: encoding of the MM predecessor in the entries
 };
 __device__ __forceinline__ void celloff_set(const CellOffGeom& g, int t, int i, int j) {
   int pass, lane, r, Rp;
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(256) bt_matrix_kernel(CellOffGeom g, int t, in
     if (i >= 1 && j >= 1) {
       int pass, lane, r, Rp;
       g.plan.locate(i, pass, lane, r, Rp);
-      b = (unsigned char)bt_decode(g.bt[(size_t)pass * g.pass_stride + bt_entry(g.rec_off[t] + j, lane, g.plan.W)], r, Rp);
+      b = (unsigned char)bt_decode(g.bt[(size_t)pass * g.pass_stride + bt_entry(g.rec_off[t] + j, lane, g.plan.W)], r, Rp, g.bt_mm);
     }
     out[c] = b;
   }
@@ -412,7 +413,7 @@ __global__ void __launch_bounds__(256) celloff_paths_kernel(CellOffGeom g, const
 int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan,
                        int n_templates, int n_paths, const int32_t* template_of, const int64_t* path_off, const int32_t* pi,
                        const int32_t* pj, const int32_t* ranges, int n_q, int n_t, hipStream_t stream) {
-  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, plan};
+  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, plan, 0};
   hipLaunchKernelGGL(celloff_clear_kernel, dim3(n_templates), dim3(256), 0, stream, g, ranges, n_q, n_t);
   if (n_paths > 0)
     hipLaunchKernelGGL(celloff_paths_kernel, dim3(n_paths), dim3(256), 0, stream, g, template_of, path_off, pi, pj);
@@ -422,16 +423,16 @@ int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, i
 
 int celloff_from_mask(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan, int t,
                       const unsigned char* d_mask, int Lt, hipStream_t stream) {
-  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, plan};
+  CellOffGeom g{bt, rec_off, L, pass_stride, Lq, plan, 0};
   const int blocks = std::max(1, std::min(256, (Lt * plan.W + 255) / 256));
   hipLaunchKernelGGL(celloff_mask_kernel, dim3(blocks), dim3(256), 0, stream, g, t, Lt, d_mask);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-int bt_matrix(const uint64_t* bt, const int64_t* rec_off, int64_t pass_stride, int Lq, StripPlan plan, int t, int Lt,
+int bt_matrix(const uint64_t* bt, const int64_t* rec_off, int64_t pass_stride, int Lq, StripPlan plan, int bt_mm, int t, int Lt,
               unsigned char* d_out, hipStream_t stream) {
-  CellOffGeom g{const_cast<uint64_t*>(bt), rec_off, nullptr, pass_stride, Lq, plan};
+  CellOffGeom g{const_cast<uint64_t*>(bt), rec_off, nullptr, pass_stride, Lq, plan, bt_mm};
   const int64_t cells = (int64_t)(Lq + 1) * (Lt + 1);
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (cells + 255) / 256));
   hipLaunchKernelGGL(bt_matrix_kernel, dim3(blocks), dim3(256), 0, stream, g, t, Lt, d_out);

@@ -82,13 +82,47 @@ HHV_DEV float fmax2(float a, float b) {
 
 // ---- backtrace entry (8 bytes per lane per column, R <= 5 cells) -----------------------------------------------------
 // The kernel does not build the reference's backtrace byte (src/hhviterbimatrix.h:35-48) in the inner loop; it only
-// RECORDS the nine comparisons of a cell, one bit each, in evaluation order: acc = 2*acc + (a > b) is two instructions
-// (v_cmp to VCC, v_addc with VCC as carry-in) and needs no select, shift or or.  The byte is decoded where it is read
+// RECORDS nine comparisons of a cell, one bit each, at fixed positions of the entry.  The byte is decoded where it is read
 // (trace kernel, hhv_backtrace_matrix) by bt_decode below.
-//   phase A1, rows R-1 .. 0, five bits per row: c1 > smin, c2 > m, c3 > m, c4 > m, c5 > m (m = running maximum, so the
-//            MM predecessor is the LAST candidate that won);  rows R-1..1 -> lo[7(R-1)-1 : 2(R-1)], row 0 -> hi[2R+6 : 2R+2]
+//   phase A1, rows R-1 .. 0, five bits per row (the MM predecessor, see below);
+//            rows R-1..1 -> lo[7(R-1)-1 : 2(R-1)], row 0 -> hi[2R+6 : 2R+2]
 //   phase A2, rows R-1 .. 0, two bits per row: GD: ga > gb, IM: ia > ib;  rows R-1..1 -> lo[2(R-1)-1 : 0], row 0 -> hi[2R+1 : 2R]
 //   phase C, rows 0 .. R-1, two bits per row: DG: da > db, MI: ma > mb                 -> hi[2R-1:0]
+// The MM predecessor.  The reference keeps a running maximum over smin, c1 .. c5 and the code of the LAST candidate that was
+// strictly greater (src/hhviterbialgorithm.cpp:241-273, MAX2 with the byte codes :17-20) - which is the FIRST candidate that
+// reaches the final maximum m.  Two encodings of that:
+//   BT_MM_FIRST_EQUAL  e0 = (m > smin), e_k = (c_k == m) for k = 1..4: m comes from two v_max3 + one v_max (the five
+//                      maxima of the running form are three instructions), the flags from v_cmp + v_addc pairs
+//   BT_MM_RUNNING      c1 > smin, c2 > m1, .. c5 > m4 with the v_cmpx form of bt_max below
+// and two forms of a pairwise maximum with its bit (GD, IM, DG, MI, and the running MM form):
+//   BT_PAIR_ADDC       v_max + v_cmp (VCC) + v_addc (VCC as carry-in: acc = 2 acc + bit)
+//   BT_PAIR_CMPX       v_cmpx narrows EXEC to the lanes with a > m, a masked v_mov takes a there, a masked v_or sets the bit,
+//                      EXEC comes back from an SGPR pair: one VOPC + two plain VOP2 instead of three VOPC / carry instructions
+// Which is faster depends on the kernel around it (profiles/r3_ab.txt, one session each): the 64-lane arrays run FIRST_EQUAL
+// + ADDC (-3 %: 20.4 -> 19.7 ms per 100 k templates; the v_cmpx forms gain nothing there), the short-query arrays RUNNING +
+// CMPX (Lq 150: 12.0 -> 11.0 ms, -8 %; FIRST_EQUAL + CMPX 11.2, FIRST_EQUAL + ADDC 11.7).  The macros are the A/B switches.
+enum { BT_MM_RUNNING = 1, BT_MM_FIRST_EQUAL = 3, BT_PAIR_ADDC = 0, BT_PAIR_CMPX = 1 };
+#ifndef HHV_BT_MM64
+#define HHV_BT_MM64 BT_MM_FIRST_EQUAL
+#endif
+#ifndef HHV_BT_PAIR64
+#define HHV_BT_PAIR64 BT_PAIR_ADDC
+#endif
+#ifndef HHV_BT_MMS
+#define HHV_BT_MMS BT_MM_RUNNING
+#endif
+#ifndef HHV_BT_PAIRS
+#define HHV_BT_PAIRS BT_PAIR_CMPX
+#endif
+// The encoding a kernel variant writes; the host records it with the backtrace buffer (hhv_tset::bt_mm) and hands it to the
+// kernels that decode.  (The local five-row cell-off + secondary-structure variant of the short-query arrays has no register
+// left for the running form's maximum: it flags.)
+HHV_HD constexpr int bt_mm_mode(int W, int R, bool local, bool celloff, bool ss) {
+  return W == 64 ? HHV_BT_MM64 : (R == 5 && local && celloff && ss) ? (int)BT_MM_FIRST_EQUAL : HHV_BT_MMS;
+}
+HHV_HD constexpr int bt_pair_mode(int W) { return W == 64 ? HHV_BT_PAIR64 : HHV_BT_PAIRS; }
+
+// acc = 2 acc + (a > b) / + (a == b)
 HHV_DEV void bt_push(uint32_t& acc, float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
@@ -96,18 +130,50 @@ HHV_DEV void bt_push(uint32_t& acc, float a, float b) {
   acc = (acc << 1) | (a > b ? 1u : 0u);
 #endif
 }
+HHV_DEV void bt_push_eq(uint32_t& acc, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_cmp_eq_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+#else
+  acc = (acc << 1) | (a == b ? 1u : 0u);
+#endif
+}
+// if (a > m) { m = a; acc |= bit; }   (bit: a compile-time constant after unrolling; exec_save: EXEC of the caller's block)
+HHV_DEV void bt_max(uint32_t& acc, float& m, float a, uint32_t bit, uint64_t exec_save) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_cmpx_gt_f32_e32 vcc, %2, %0\n\tv_mov_b32_e32 %0, %2\n\tv_or_b32_e32 %1, %3, %1\n\ts_mov_b64 exec, %4"
+               : "+v"(m), "+v"(acc) : "v"(a), "i"(bit), "s"(exec_save) : "vcc");
+#else
+  (void)exec_save;
+  if (a > m) {
+    m = a;
+    acc |= bit;
+  }
+#endif
+}
+HHV_DEV uint64_t bt_exec() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_read_exec();
+#else
+  return 0;
+#endif
+}
 // entry -> the reference's byte for row r of the lane (bits 0-2 MM predecessor, 8 GD, 16 IM, 32 DG, 64 MI)
-HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R) {
+HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R, int mm_mode) {
   const uint32_t lo = (uint32_t)entry, hi = (uint32_t)(entry >> 32);
   const uint32_t f7 = r >= 1 ? (((lo >> (2 * (R - 1) + 5 * (r - 1))) & 0x1Fu) << 2) | ((lo >> (2 * (r - 1))) & 3u)
                              : (hi >> (2 * R)) & 0x7Fu;
   const uint32_t c2 = (hi >> (2 * (R - 1 - r))) & 3u;
   uint32_t b = 0;
-  if (f7 & 0x40u) b = 2;  // c1 > smin            : MM
-  if (f7 & 0x20u) b = 3;  // c2 > max so far      : GD
-  if (f7 & 0x10u) b = 4;  //                        IM
-  if (f7 & 0x08u) b = 5;  //                        DG
-  if (f7 & 0x04u) b = 6;  //                        MI
+  if (mm_mode == BT_MM_FIRST_EQUAL) {
+    // e0 = (m > smin); the first of c1..c4 that equals m, c5 if none does: codes 2 (MM), 3 (GD), 4 (IM), 5 (DG), 6 (MI)
+    if (f7 & 0x40u) b = (f7 & 0x20u) ? 2 : (f7 & 0x10u) ? 3 : (f7 & 0x08u) ? 4 : (f7 & 0x04u) ? 5 : 6;
+  } else {
+    if (f7 & 0x40u) b = 2;  // c1 > smin            : MM
+    if (f7 & 0x20u) b = 3;  // c2 > max so far      : GD
+    if (f7 & 0x10u) b = 4;  //                        IM
+    if (f7 & 0x08u) b = 5;  //                        DG
+    if (f7 & 0x04u) b = 6;  //                        MI
+  }
   b |= (f7 & 0x02u) ? 8u : 0u;
   b |= (f7 & 0x01u) ? 16u : 0u;
   b |= (c2 & 0x02u) ? 32u : 0u;
@@ -122,7 +188,7 @@ HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R) {
 struct Log2Consts {
   float c4, c3, c2, c1;  // -0.10725..., 0.68824..., -1.75647..., 2.61761...  (src/hhutil-inl.h:530-535)
   float ebias;           // 8388608 + 127
-  uint32_t expor;        // bits of 8388608.0f
+  uint32_t expor;        // bits of 8388608.0f >> 9 (the high operand of v_alignbit_b32 .., 23)
   uint32_t mant;         // mantissa mask
   HHV_HDMEM static Log2Consts literal() {
     Log2Consts k;
@@ -131,7 +197,7 @@ struct Log2Consts {
     k.c2 = -1.75647175389045657003f;
     k.c1 = 2.61761038894603480148f;
     k.ebias = 8388735.0f;
-    k.expor = 0x4B000000u;
+    k.expor = 0x4B000000u >> 9;
     k.mant = 0x007FFFFFu;
     return k;
   }
@@ -141,10 +207,13 @@ struct Log2Consts {
 HHV_DEV float log2f4(float x, const Log2Consts& K) {
   const uint32_t i = f2bits(x);
 #if defined(__HIP_DEVICE_COMPILE__)
-  // e = float(biased exponent - 127) without v_cvt (half-rate issue on gfx950, profiles/r2_valu_ubench.txt): the
-  // exponent field is dropped into the mantissa of 2^23 - bits 0x4B000000 | E are the float 8388608 + E exactly - and
-  // 8388608 + 127 is subtracted; every step is exact, so e is the same float the int -> float conversion gives.
-  const float e = bits2f(((i & 0x7F800000u) >> 23) | K.expor) - K.ebias;
+  // e = float(biased exponent - 127) without v_cvt and without a field extract: ONE v_alignbit_b32 drops the exponent field
+  // into the mantissa of 2^23 - alignbit(K, bits, 23) = (bits >> 23) | (K << 9) with K = 0x4B000000 >> 9, i.e. the float
+  // 8388608 + E exactly - and 8388608 + 127 is subtracted; every step is exact, so e is the float the reference's
+  // int -> float conversion gives.  (bits >> 23 is the exponent field because x >= 0: x is a sum of products of profile
+  // values, which are probabilities / odds - hhv_upload_templates and hhv_set_query refuse negative ones.  Round 2 masked the
+  // field with v_bfe_u32 + v_or_b32: one VALU instruction more per cell, 1 % of the kernel.)
+  const float e = bits2f(__builtin_amdgcn_alignbit(K.expor, i, 23)) - K.ebias;
 #else
   const float e = (float)((int32_t)((i & 0x7F800000u) >> 23) - 127);
 #endif
@@ -387,7 +456,8 @@ struct ArraySrc {
 // kernel); C (rows top-down) MM += S, then DG and MI which chain through the row above.
 //   ssv      : SS only - ssv[r] = ssw * S[q_ss(i0+r)][t_ss(j)], the secondary-structure term of the ...AndSS
 //              builds (src/hhviterbialgorithm.cpp:194-213,278-280), added as ss + log2f4(..) like the reference
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, class Src>
+//   BTM / BTP : BT only - encoding of the MM predecessor and form of the pairwise maxima (bt_mm_mode / bt_pair_mode of the array width)
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, int BTM, int BTP, class Src>
 HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const DiagSums& ds, Src& src, int j,
                              int i0, int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv) {
   constexpr bool QL = Src::QL;
@@ -402,6 +472,7 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     // backtrace variants, two sweeps: A1 = the MM candidates of all rows (they read only registers and the record head),
     // A2 = the GD / IM updates, which overwrite what A1 read and need the query's {m2i, i2i} - with a QL source those
     // come from LDS and have had the whole of A1 to arrive (src.before_A2()).
+    const uint64_t ex = bt_exec();
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
       const float dMM = r ? st.MM[r - 1] : st.dMM, dMI = r ? st.MI[r - 1] : st.dMI;
@@ -412,31 +483,55 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
       const float c4 = (r ? st.DG[r - 1] + q.d2m[r] : ds.x4) + tM2M;
       const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
       uint32_t& acc = r ? acc_lo : acc_hi;
-      bt_push(acc, c1, smin);
-      float mm = fmax2(smin, c1);
-      bt_push(acc, c2, mm);
-      mm = fmax2(mm, c2);
-      bt_push(acc, c3, mm);
-      mm = fmax2(mm, c3);
-      bt_push(acc, c4, mm);
-      mm = fmax2(mm, c4);
-      bt_push(acc, c5, mm);
-      mm = fmax2(mm, c5);
-      cmax[r] = mm;
+      if (BTM == BT_MM_FIRST_EQUAL) {
+        const float mm = fmax2(fmax2(fmax2(fmax2(fmax2(smin, c1), c2), c3), c4), c5);  // v_max3, v_max3, v_max
+        bt_push(acc, mm, smin);
+        bt_push_eq(acc, c1, mm);
+        bt_push_eq(acc, c2, mm);
+        bt_push_eq(acc, c3, mm);
+        bt_push_eq(acc, c4, mm);
+        cmax[r] = mm;
+      } else {
+        // (the same five positions through fixed masks; the accumulators of this mode are only ever or-ed into)
+        const int top = r ? 7 * (R - 1) - 1 - 5 * (R - 1 - r) : 6 + 2 * R;  // position of the row's first bit
+        float mm = smin;
+        bt_max(acc, mm, c1, 1u << (top - 0), ex);
+        bt_max(acc, mm, c2, 1u << (top - 1), ex);
+        bt_max(acc, mm, c3, 1u << (top - 2), ex);
+        bt_max(acc, mm, c4, 1u << (top - 3), ex);
+        bt_max(acc, mm, c5, 1u << (top - 4), ex);
+        cmax[r] = mm;
+      }
+    }
+    static_assert(!BT || BTM == BT_MM_FIRST_EQUAL || BTP == BT_PAIR_CMPX, "the running form sets its bits in place");
+    if (BTM == BT_MM_FIRST_EQUAL && BTP == BT_PAIR_CMPX) {
+      // the flags were shifted in, the pairwise bits are set in place: make room for them
+      acc_lo <<= 2 * (R - 1);
+      acc_hi <<= 2 + 2 * R;
     }
     src.before_A2();
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
       // :307-332 (GD and IM read only the cell to the left)
       const float lMM = st.MM[r];
-      const float ga = lMM + tM2D, gb = st.GD[r] + tD2D;
+      const float ga = lMM + tM2D;
+      float gb = st.GD[r] + tD2D;
       const float qm2i = QL ? src.qa(r, 0) : q.m2i[r], qi2i = QL ? src.qa(r, 1) : q.i2i[r];
-      const float ia = (lMM + qm2i) + tM2M, ib = (st.IM[r] + qi2i) + tM2M;
+      const float ia = (lMM + qm2i) + tM2M;
+      float ib = (st.IM[r] + qi2i) + tM2M;
       uint32_t& acc = r ? acc_lo : acc_hi;
-      bt_push(acc, ga, gb);
-      bt_push(acc, ia, ib);
-      st.GD[r] = fmax2(ga, gb);
-      st.IM[r] = fmax2(ia, ib);
+      if (BTP == BT_PAIR_CMPX) {
+        const int top = r ? 2 * (R - 1) - 1 - 2 * (R - 1 - r) : 1 + 2 * R;
+        bt_max(acc, gb, ga, 1u << top, ex);
+        bt_max(acc, ib, ia, 1u << (top - 1), ex);
+        st.GD[r] = gb;
+        st.IM[r] = ib;
+      } else {
+        bt_push(acc, ga, gb);
+        bt_push(acc, ia, ib);
+        st.GD[r] = fmax2(ga, gb);
+        st.IM[r] = fmax2(ia, ib);
+      }
     }
   } else {
 #pragma unroll
@@ -482,15 +577,20 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
     // :340-366
     const float qm2d = QL ? src.qc(r, 0) : q.m2d[r], qd2d = QL ? src.qc(r, 1) : q.d2d[r];
     const float da = uMM + qm2d, db = uDG + qd2d;
-    float dg = fmax2(da, db);
+    const bool cmpx = BT && BTP == BT_PAIR_CMPX;
+    float dg = cmpx ? db : fmax2(da, db);
     const float sa = uMM + q.m2m[r], sb = uMI + q.m2m[r];
     const float ma = sa + tM2I, mb = sb + tI2I;
-    float mi = fmax2(ma, mb);
+    float mi = cmpx ? mb : fmax2(ma, mb);
     if (SHARE) {
       st.aMM[r] = sa;
       st.aMI[r] = sb;
     }
-    if (BT) {
+    if (cmpx) {
+      const uint64_t exc = bt_exec();
+      bt_max(acc_hi, dg, da, 1u << (2 * (R - 1 - r) + 1), exc);
+      bt_max(acc_hi, mi, ma, 1u << (2 * (R - 1 - r)), exc);
+    } else if (BT) {
       bt_push(acc_hi, da, db);
       bt_push(acc_hi, ma, mb);
     }

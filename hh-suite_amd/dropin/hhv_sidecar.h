@@ -90,7 +90,7 @@ class Sidecar {
       pending_.clear();
       return 0;
     }
-    const int fd = open(path_.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+    const int fd = open(path_.c_str(), O_RDWR | O_CREAT | O_APPEND, 0644);  // (read: the tail check below)
     if (fd < 0) {  // read-only database directory: the sidecar is an optimisation, not a requirement
       usable_ = false;
       pending_.clear();

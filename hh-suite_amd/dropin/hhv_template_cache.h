@@ -33,8 +33,11 @@ struct SsRecords {
 struct EntryIdentity {
   const void* data;  // FFindexDatabase::db_data of the hhm / a3m / ca3m index that holds the entry (NULL: a file entry)
   uint64_t offset, length;
-  EntryIdentity() : data(NULL), offset(0), length(0) {}
-  bool operator==(const EntryIdentity& o) const { return data == o.data && offset == o.offset && length == o.length; }
+  bool ambiguous;    // several of the searched databases hold the name: a lookup by name cannot tell which entry this is
+  EntryIdentity() : data(NULL), offset(0), length(0), ambiguous(false) {}
+  bool operator==(const EntryIdentity& o) const {
+    return !ambiguous && !o.ambiguous && data == o.data && offset == o.offset && length == o.length;
+  }
 };
 
 struct CachedTemplate {

@@ -176,10 +176,13 @@ FFindexDatabase* hh_text_database(const std::vector<HHblitsDatabase*>& dbs, char
 }
 
 // the database entry behind a name, in the order HHblitsDatabase::getEntriesFromNames looks (src/hhdatabase.cpp:198-215)
-// (an empty identity - data == NULL - for a name that several databases hold: never equal to a cached one, see valid())
+// (a name that several databases hold gets an `ambiguous` identity, which equals nothing - not even itself)
 hhv_dropin::EntryIdentity identify_entry(const std::vector<HHblitsDatabase*>& dbs, char* name) {
   hhv_dropin::EntryIdentity id;
-  if (name_in_several_databases(dbs, name)) return id;
+  if (name_in_several_databases(dbs, name)) {
+    id.ambiguous = true;
+    return id;
+  }
   for (size_t d = 0; d < dbs.size(); ++d) {
     HHblitsDatabase* db = dbs[d];
     if (!db) continue;
@@ -603,7 +606,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
               // same name and length but another database entry (two databases, a rebuilt one): read it again, the new
               // upload takes the slot
               const hhv_dropin::EntryIdentity id = identify_entry(databases, ent[k]->getName());
-              if (it != tc.map.end() && id.data != NULL && it->second.id == id) cached[k] = &it->second;  // std::unordered_map never moves its elements
+              if (it != tc.map.end() && it->second.id == id) cached[k] = &it->second;  // std::unordered_map never moves its elements
               else to_read.push_back(k);
             }
           } else {

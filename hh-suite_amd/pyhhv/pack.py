@@ -98,8 +98,12 @@ def pack_stream(tps, ttrs, t_ss=None):
     return rec, rec_off
 
 
-def bt_decode(entry, r, R):
-    """numpy mirror of bt_decode (csrc/viterbi_lane.h): uint64 entries -> the reference's backtrace byte of row r."""
+BT_MM_RUNNING, BT_MM_FIRST_EQUAL = 1, 3
+
+
+def bt_decode(entry, r, R, mm_mode=BT_MM_FIRST_EQUAL):
+    """numpy mirror of bt_decode (csrc/viterbi_lane.h): uint64 entries -> the reference's backtrace byte of row r.
+    mm_mode: encoding of the MM predecessor (FIRST_EQUAL: e0 = (m > smin), e_k = (c_k == m); RUNNING: c_k > running max)."""
     entry = np.asarray(entry, dtype=np.uint64)
     lo = (entry & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     hi = (entry >> np.uint64(32)).astype(np.uint32)
@@ -109,8 +113,14 @@ def bt_decode(entry, r, R):
         f7 = (hi >> np.uint32(2 * R)) & np.uint32(0x7F)
     c2 = (hi >> np.uint32(2 * (R - 1 - r))) & np.uint32(3)
     b = np.zeros(entry.shape, dtype=np.uint8)
-    for bit, code in ((0x40, 2), (0x20, 3), (0x10, 4), (0x08, 5), (0x04, 6)):
-        b = np.where(f7 & np.uint32(bit), np.uint8(code), b)
+    if mm_mode == BT_MM_FIRST_EQUAL:
+        b = np.full(entry.shape, 6, dtype=np.uint8)
+        for bit, code in ((0x04, 5), (0x08, 4), (0x10, 3), (0x20, 2)):      # the FIRST candidate equal to the maximum wins
+            b = np.where(f7 & np.uint32(bit), np.uint8(code), b)
+        b = np.where(f7 & np.uint32(0x40), b, np.uint8(0))
+    else:
+        for bit, code in ((0x40, 2), (0x20, 3), (0x10, 4), (0x08, 5), (0x04, 6)):
+            b = np.where(f7 & np.uint32(bit), np.uint8(code), b)
     b |= np.where(f7 & np.uint32(2), 8, 0).astype(np.uint8)
     b |= np.where(f7 & np.uint32(1), 16, 0).astype(np.uint8)
     b |= np.where(c2 & np.uint32(2), 32, 0).astype(np.uint8)

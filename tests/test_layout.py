@@ -1,6 +1,7 @@
 """Packed record layout: product packer (C, hh-suite_amd/csrc/hhv_pack.cpp) == numpy mirror, and
 the fast_log2 tables the product uploads == the oracle's (which are pinned to the reference)."""
 import numpy as np
+import pytest
 
 from pyhhv import capi, pack, synth
 
@@ -76,3 +77,28 @@ def test_packed_db_file_matches_stream(tmp_path):
     body = np.frombuffer(raw[64 + 4 * n:], dtype=np.int32).reshape(nrec, 28)
     rec, off = pack.pack_stream(list(tps), list(ttrs))
     assert np.array_equal(body, rec.view(np.int32))
+
+
+def test_packer_refuses_negative_profile_values_and_stores_plus_zero():
+    """The kernel's log2f4 shifts the exponent of a column product out without masking the sign (one v_alignbit_b32,
+    viterbi_lane.h): profile values must be >= 0.  The packer - every host path into the engine goes through it - reports
+    negative values and turns -0.0f into +0.0f (x + 0.0: products, sums and log2f4 of the reference come out the same)."""
+    from pyhhv import capi, synth
+    p, tr = synth.make_template(77, 9)
+    rec = capi.pack_profile(p, tr, index=3)
+    assert rec.shape == (10, 28)
+    bad = p.copy()
+    bad[4, 7] = -1e-30
+    with pytest.raises(capi.HhvError, match="negative profile value"):
+        capi.pack_profile(bad, tr, index=3)
+    with pytest.raises(capi.HhvError, match="negative profile value"):
+        capi.pack_profile(bad, tr)
+    z = p.copy()
+    z[2, :] = -0.0
+    z[5, 3] = -0.0
+    rec = capi.pack_profile(z, tr, index=0)
+    assert not np.any(np.signbit(rec[1:, :20])) and np.all(rec[2, :20] == 0.0)
+    keep = np.ones_like(z, dtype=bool)
+    keep[2, :] = False
+    keep[5, 3] = False
+    assert np.array_equal(rec[1:, :20][keep[1:]], p[1:][keep[1:]])

@@ -25,7 +25,7 @@ def rows(pattern):
 summary = {"tag": tag, "kernel": KERNEL}
 lines = []
 stats = rows("stats/**/*kernel_stats.csv")
-lines.append("== rocprofv3 --kernel-trace --stats (python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-configs1)")
+lines.append("== rocprofv3 --kernel-trace --stats (python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs1 ...)")
 lines.append("%-70s %8s %14s %14s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in sorted(stats, key=lambda r: -float(r.get("TotalDurationNs", 0)))[:12]:
     name = r["Name"]
@@ -35,6 +35,26 @@ for r in sorted(stats, key=lambda r: -float(r.get("TotalDurationNs", 0)))[:12]:
     if KERNEL in name:
         summary["stats"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                             "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
+
+# per-dispatch durations from the kernel trace of the same pass: min and median next to the mean (the first launches of a
+# process run slower; the driver's bench takes 20 steps after 5 warm-up steps)
+dur = sorted((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) for r in rows("stats/**/*kernel_trace.csv")
+             if KERNEL in r.get("Kernel_Name", ""))
+if dur:
+    med = dur[len(dur) // 2] if len(dur) % 2 else 0.5 * (dur[len(dur) // 2 - 1] + dur[len(dur) // 2])
+    summary["stats"].update({"median_ns": med, "min_ns_trace": dur[0], "launches_in_trace": len(dur)})
+    lines.append("%s: %d launches, min %.0f ns, median %.0f ns, mean %.0f ns" % (KERNEL, len(dur), dur[0], med, sum(dur) / len(dur)))
+    try:   # the bench line of the profiled run itself: its HIP-event kernel time must agree with the trace
+        for l in open(os.path.join(src, "stats_bench.txt")):
+            if l.startswith("{"):
+                b = json.loads(l)
+                summary["bench_line_of_profiled_run"] = {"ms_per_step": b["ms_per_step"], "kernel_ms_mean": b["roofline"]["kernel_ms"],
+                                                         "kernel_ms_min": b["roofline"].get("kernel_ms_min"),
+                                                         "kernel_ms_median": b["roofline"].get("kernel_ms_median"), "value": b["value"]}
+                lines.append("bench line of the same run: %.3f ms per step, kernel (HIP events) mean %.3f / median %.3f / min %.3f ms"
+                             % (b["ms_per_step"], b["roofline"]["kernel_ms"], b["roofline"].get("kernel_ms_median", 0), b["roofline"].get("kernel_ms_min", 0)))
+    except Exception:
+        pass
 
 pmc = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
