@@ -17,9 +17,14 @@ HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
 
 RUNNER   := $(LIBDIR)/libhhv_runner.so
 
-all: lib oracle emul
+all: lib lib_fma oracle emul
 
 lib: $(LIB) $(RUNNER)
+
+# OPT-IN build, never the default: the emission score with fused multiply-adds (viterbi_lane.h HHV_EMISSION_FMA) - a second
+# library next to the bit-exact one; nothing links it, a caller chooses it by name (bench.py `fast_mode`, tests/test_gpu_fast_mode.py)
+lib_fma:
+	$(MAKE) $(LIBDIR)/libhhviterbi_hip_fma.so LIB=$(LIBDIR)/libhhviterbi_hip_fma.so OBJDIR=build/obj_fma HHV_EXTRA_HIPFLAGS="$(HHV_EXTRA_HIPFLAGS) -DHHV_EMISSION_FMA"
 
 # C++ host layer above the C ABI (mirror of the reference's ViterbiRunner); plain g++, links only the C ABI
 $(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/prefilter.h hh-suite_amd/host/posterior_decoder.cpp hh-suite_amd/host/posterior_decoder.h include/hhviterbi_hip.h $(LIB)
@@ -68,7 +73,7 @@ clean:
 	rm -rf build $(LIBDIR) tests/emul/libwave_emul.so
 	$(MAKE) -C oracle clean
 
-.PHONY: example all lib oracle emul clean
+.PHONY: example all lib lib_fma oracle emul clean
 
 # plain-C++ use of the host classes (no Python): examples/search_example.cpp
 example: $(RUNNER)

@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--no-configs2", action="store_true")
     ap.add_argument("--no-configs4", action="store_true")
     ap.add_argument("--no-upload", action="store_true", help="skip the template_upload entry (pack + H2D, packed-file open)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the fast_mode entry (the opt-in fused-emission build)")
     ap.add_argument("--virtual-shards", type=int, default=1,
                     help="single rank only: hold ALL shards of the V-shard database (V x --templates, same global plan, same "
                          "global ids) - the single-process reference of a V-rank run")
@@ -419,6 +420,9 @@ def main():
     if single and not args.no_upload and plain:
         out["template_upload"] = template_upload(capi, ctx, rec, rec_off, Ls, qf, qtr, Lt)
 
+    if single and not args.no_fast_mode and plain:
+        out["fast_mode"] = fast_mode(args, capi, ctx, ts, rec, Ls, qf, qtr, dev_index, K)
+
     if single and not args.no_next_rows and plain:
         out["next_rows"] = next_rows()
 
@@ -439,6 +443,54 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def fast_mode(args, capi, ctx, ts, rec, Ls, qf, qtr, dev_index, K):
+    """OPT-IN, never `value`: the same resident set through libhhviterbi_hip_fma.so (make lib_fma; emission score with fused
+    multiply-adds, viterbi_lane.h HHV_EMISSION_FMA) - what it gains and what it changes against the bit-exact default build
+    on ALL templates of the set: end points, scores, top-K, and with backtrace the alignments and Hit scores."""
+    out = {"library": "libhhviterbi_hip_fma.so", "what": "emission with v_fmac_f32 (16 of the 20 products accumulate fused, log2f4's "
+           "polynomial fused): one rounding per term instead of two; opt-in build, the default library has no FMA"}
+    try:
+        cf = capi.Context(local=args.local, device=dev_index, lib_path=capi.FMA_LIB_PATH)
+        cf.set_query(qf, qtr)
+        tf = cf.adopt_device_stream(Ls, rec.data_ptr())
+        for _ in range(2):
+            cf.align_async(tf)
+            cf.topk(tf, K, fetch=False, raw=True)
+        cf.sync()
+        reps, ms = 10, []
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            cf.set_query(qf, qtr)
+            cf.align_async(tf)
+            cf.topk(tf, K, fetch=False, raw=True)
+            ms.append(cf.last_kernel_ms())
+        cf.sync()
+        sec = (time.perf_counter() - t1) / reps
+        out["score_only"] = {"cells_per_s": tf.cells() / sec, "ms_per_step": sec * 1e3, "dp_kernel_ms": float(np.mean(ms))}
+        f, d = cf.align(tf), ctx.align(ts)
+        top_f, _ = cf.topk(tf, K, raw=True)
+        top_d, _ = ctx.topk(ts, K, raw=True)
+        out["vs_default_build"] = {
+            "templates": int(ts.n), "endpoint_mismatches": int(np.sum((f["i2"] != d["i2"]) | (f["j2"] != d["j2"]))),
+            "scores_changed": int(np.sum(f["score"] != d["score"])),
+            "max_abs_score_diff": float(np.max(np.abs(f["score"].astype(np.float64) - d["score"].astype(np.float64)))),
+            "topk_same_templates_same_order": bool(np.array_equal(top_f["index"], top_d["index"]))}
+        secb, kmsb = time_bt_steps(cf, tf, K, reps=3, warm=1)
+        out["backtrace_hits"] = {"cells_per_s": tf.cells() / secb, "ms_per_step": secb * 1e3, "dp_kernel_ms": kmsb}
+        hf = cf.hits(tf)
+        ctx.align_async(ts, backtrace=True)
+        hd = ctx.hits(ts)
+        out["vs_default_build"].update({
+            "alignment_mismatches_i1_j1_nsteps_matched_cols": int(np.sum((hf["i1"] != hd["i1"]) | (hf["j1"] != hd["j1"]) |
+                                                                         (hf["nsteps"] != hd["nsteps"]) | (hf["matched_cols"] != hd["matched_cols"]))),
+            "max_abs_hit_score_diff": float(np.max(np.abs(hf["score"].astype(np.float64) - hd["score"].astype(np.float64))))})
+        tf.free()
+        cf.close()
+    except Exception as e:  # the headline line must not depend on the side measurements
+        out["error"] = repr(e)
+    return out
 
 
 def template_upload(capi, ctx, rec, rec_off, Ls, qf, qtr, Lt):
@@ -631,15 +683,37 @@ def next_rows():
     except Exception as e:
         out["N4_mac_realign"] = {"error": repr(e)}
     try:
+        # VALU-issue roofline of these kernels from the committed counters (profiles/r3_next_rows_summary.json, tools/profile_next.sh):
+        # executed VALU lane-instructions per cell x the rate measured here (prefilter), issue fraction of the profiled launch (MAC)
+        with open(os.path.join(ROOT, "profiles", "r3_next_rows_summary.json")) as f:
+            k = json.load(f)["kernels"]
+        rv = {}
+        for name, key, rate in (("gapless", "hhv_pf_ungapped_kernel", out.get("N3_prefilter", {}).get("gapless_cells_per_s")),
+                                ("smith_waterman", "hhv_pf_sw_kernel", out.get("N3_prefilter", {}).get("sw_cells_per_s"))):
+            e = next((v for n, v in k.items() if key in n and v.get("valu_lane_instr_per_cell")), None)
+            if e and rate:
+                rv[name] = {"valu_lane_instr_per_cell": e["valu_lane_instr_per_cell"],
+                            "frac_of_valu_issue_peak": rate * e["valu_lane_instr_per_cell"] / VALU_PEAK_LANEOPS,
+                            "frac_in_profiled_launch": e["frac_of_valu_issue_peak"]}
+        for n, v in k.items():
+            if "mac_" in n:
+                rv[n.split("<")[0]] = {"frac_in_profiled_launch": v["frac_of_valu_issue_peak"], "avg_ms_profiled": v["avg_ms"]}
+        out["roofline_valu"] = {"bound": "valu_issue", "peak_T_lane_ops_per_s": VALU_PEAK_LANEOPS / 1e12, "kernels": rv,
+                                "source": "profiles/r3_next_rows_summary.json (SQ_INSTS_VALU per launch) x the rates of this run"}
+    except Exception as e:
+        out["roofline_valu"] = {"error": repr(e)}
+    try:
         # the boundary itself: ViterbiRunner::alignment of the reference (its own translation unit, all host cores it asks
         # for) against the drop-in translation unit, wall time of the call, hits compared (tools/bench_dropin.py)
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhhref_dropin.so")):
             import bench_dropin
-            r = bench_dropin.run(4000, 32, 300, altalis=(1,))
+            r = bench_dropin.run(4000, min(32, usable_cores()[0]), 300, altalis=(1,))   # (threads the box really grants: 32 on a 16-CPU quota was noise)
             a = r["altali1"]
             out["dropin_ViterbiRunner_alignment"] = {"templates": r["n_templates"], "Lq": r["L"], "Lt": r["L"], "host_threads": r["threads"],
                                                      "reference_s": a["reference_s"], "dropin_cold_cache_s": a["dropin_cold_cache_s"],
-                                                     "dropin_warm_cache_s": a["dropin_warm_cache_s"], "hits_identical": a["hits_identical"]}
+                                                     "dropin_warm_cache_s": a["dropin_warm_cache_s"], "hits_identical": a["hits_identical"],
+                                                     "note": "cold = every template's HHM text parsed by the host's HMM::Read, as in the reference (the DP is ~1 ms of "
+                                                             "it); warm = templates resident on the device (second search of the process)"}
     except Exception as e:
         out["dropin_ViterbiRunner_alignment"] = {"error": repr(e)}
     return out

@@ -234,9 +234,13 @@ __global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
         F = max(sat_sub(F, ge), t);
         h = old;
       }
-      // lazy-F loop (:176-203); a half leaves it for good as soon as none of its 32 elements needs a correction
+      // lazy-F loop (:176-203); a half leaves it for good as soon as none of its 32 elements needs a correction.
+      // The loop's first test - does any element need a correction at segment row 0 - fails for most residues, for both halves:
+      // it is taken out of the loop as ONE wave-uniform test, so that the common case jumps over the whole (unrolled,
+      // predicated) loop body with a single scalar branch instead of walking its W guarded blocks.
       F = half_shr1_zero(F, k);
       bool active = true;
+      if (__ballot(sat_sub(F, sat_sub(H[0], go)) != 0) != 0)
       for (;;) {
         bool done = false;
 #pragma unroll

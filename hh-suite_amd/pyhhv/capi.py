@@ -70,15 +70,22 @@ class HhvError(RuntimeError):
 
 
 _lib = None
+_libs = {}
+FMA_LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libhhviterbi_hip_fma.so")   # the opt-in fused-emission build
 
 
-def load():
+def load(path=None):
+    """the product library (HHV_LIB or hh-suite_amd/lib/libhhviterbi_hip.so); path = another build of it (the opt-in
+    libhhviterbi_hip_fma.so), loaded next to the default one"""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise HhvError("libhhviterbi_hip.so not built (%s): run `make lib` / __graft_entry__.build()" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    if path is not None and path in _libs:
+        return _libs[path]
+    lib_path = LIB_PATH if path is None else path
+    if not os.path.exists(lib_path):
+        raise HhvError("%s not built (%s): run `make lib` / __graft_entry__.build()" % (os.path.basename(lib_path), lib_path))
+    L = C.CDLL(lib_path)
     L.hhv_abi_version.restype = C.c_int
     L.hhv_last_error.restype = C.c_char_p
     L.hhv_record_bytes.restype = C.c_int32
@@ -154,7 +161,10 @@ def load():
     L.hhv_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, c_int_p]
     L.hhv_tset_set_global_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hhv_merge_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_int_p]
-    _lib = L
+    if path is None:
+        _lib = L
+    else:
+        _libs[path] = L
     return L
 
 
@@ -254,21 +264,21 @@ class TemplateSet:
 
     def free(self):
         if self.h:
-            load().hhv_tset_free(self.h)
+            self.ctx.lib.hhv_tset_free(self.h)
             self.h = None
 
     def cells(self):
-        return int(load().hhv_tset_cells(self.h, self.ctx.Lq))
+        return int(self.ctx.lib.hhv_tset_cells(self.h, self.ctx.Lq))
 
     def records(self):
-        return int(load().hhv_tset_records(self.h))
+        return int(self.ctx.lib.hhv_tset_records(self.h))
 
 
 class Context:
     """One hhv_ctx = the per-thread Viterbi object of the reference (src/hhviterbirunner.h:21-34)."""
 
-    def __init__(self, local=0, egq=0.0, egt=0.0, shift=-0.03, corr=0.1, ssw=0.11, ss_mode=2, device=0):
-        self.lib = load()
+    def __init__(self, local=0, egq=0.0, egt=0.0, shift=-0.03, corr=0.1, ssw=0.11, ss_mode=2, device=0, lib_path=None):
+        self.lib = load(lib_path)
         self.par = HhvParams(int(device), int(local), float(egq), float(egt), float(shift), float(corr), float(ssw),
                              int(ss_mode))
         h = C.c_void_p()

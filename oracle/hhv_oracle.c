@@ -40,11 +40,19 @@ static inline float u2f(uint32_t u) {
 /* x86 MAXPS(a,b): a > b ? a : b (returns b when equal or unordered) */
 static inline float mx(float a, float b) { return a > b ? a : b; }
 
+static int g_emission_mode = 0; /* hho_set_emission_mode below */
+
 /* src/hhutil-inl.h:509-541 */
 float hho_log2f4(float x) {
   const uint32_t i = f2u(x);
   const float e = (float)((int32_t)((i & 0x7F800000u) >> 23) - 127);
   const float m = u2f((i & 0x007FFFFFu) | 0x3F800000u);
+  if (g_emission_mode == 2) { /* the engine's opt-in fused build (viterbi_lane.h HHV_EMISSION_FMA), restated */
+    float f = fmaf(-0.107254423828329604454f, m, 0.688243882994381274313f);
+    f = fmaf(f, m, -1.75647175389045657003f);
+    f = fmaf(f, m, 2.61761038894603480148f);
+    return fmaf(f, m - 1.0f, e);
+  }
   /* POLY3(m, c0, c1, c2, c3): ((c3*m + c2)*m + c1)*m + c0, each step mul then add */
   float p = -0.107254423828329604454f * m;
   p = p + 0.688243882994381274313f;
@@ -91,12 +99,12 @@ float hho_fast_log2(float x) {
   return ((float)a + lg2_tab[b]) + diff_tab[b] * (float)c;
 }
 
-/* STUDY SWITCH, never used by a parity test: what would the emission score look like if the 20-term product ran on the
- * matrix pipe?  v_mfma_f32_32x32x2_f32 accumulates exactly like a chain of fmaf over k (MI355X_MICROARCH.md, matrix cores),
- * i.e. ONE rounding per term instead of the reference's separate multiply and add in four partial sums.  Mode 1 makes
- * hho_align use that chain for the DP's emission scores (tools/mfma_emission_study.py measures what it does to scores,
- * end points and paths); mode 0 (default) is the reference's arithmetic. */
-static int g_emission_mode = 0;
+/* SWITCH, never touched by a parity test of the default engine.  Mode 0 (default) is the reference's arithmetic.
+ * Mode 1 (study, tools/mfma_emission_study.py): the 20-term product as ONE fmaf chain over k - what v_mfma_f32_32x32x2_f32
+ * would compute (MI355X_MICROARCH.md, matrix cores).
+ * Mode 2: the arithmetic of the engine's OPT-IN fused build (libhhviterbi_hip_fma.so, viterbi_lane.h HHV_EMISSION_FMA): the
+ * reference's four partial sums, each accumulating step a fused multiply-add, and log2f4's polynomial fused - so that the
+ * opt-in build has an exact checker of its own (tests/test_gpu_fast_mode.py) next to the tolerance comparison with mode 0. */
 void hho_set_emission_mode(int mode) { g_emission_mode = mode; }
 static float dot20_fma_chain(const float *q, const float *t) {
   float acc = 0.0f;
@@ -111,6 +119,17 @@ float hho_dot20_vec(const float *q, const float *t) {
   float r1 = t[1] * q[1];
   float r2 = t[2] * q[2];
   float r3 = t[3] * q[3];
+  if (g_emission_mode == 2) {
+    for (int k = 4; k < 20; k += 4) {
+      r0 = fmaf(t[k + 0], q[k + 0], r0);
+      r1 = fmaf(t[k + 1], q[k + 1], r1);
+      r2 = fmaf(t[k + 2], q[k + 2], r2);
+      r3 = fmaf(t[k + 3], q[k + 3], r3);
+    }
+    r0 = r0 + r1;
+    r2 = r2 + r3;
+    return r0 + r2;
+  }
   for (int k = 4; k < 20; k += 4) {
     r0 = t[k + 0] * q[k + 0] + r0;
     r1 = t[k + 1] * q[k + 1] + r1;

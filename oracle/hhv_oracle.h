@@ -44,8 +44,9 @@ typedef struct {
 float hho_log2f4(float x);
 float hho_fast_log2(float x);
 float hho_dot20_vec(const float *q, const float *t); /* Viterbi::ScalarProd20Vec order */
-/* study switch (tools/mfma_emission_study.py): 1 = emission dot product as an fmaf chain, what an f32 MFMA would compute;
- * 0 (default) = the reference's arithmetic.  Process-wide; no parity test touches it. */
+/* switch: 0 (default) = the reference's arithmetic; 1 = study (tools/mfma_emission_study.py): emission dot product as one fmaf
+ * chain, what an f32 MFMA would compute; 2 = the arithmetic of the engine's opt-in fused build (libhhviterbi_hip_fma.so).
+ * Process-wide; no parity test of the default engine touches it. */
 void hho_set_emission_mode(int mode);
 float hho_dot20_scalar(const float *q, const float *t); /* ScalarProd20 order (plain C branch) */
 

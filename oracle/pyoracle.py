@@ -144,6 +144,11 @@ class Oracle:
                                       c_int_p]
 
     # -- unit probes
+    def set_emission_mode(self, mode):
+        """0 = the reference's arithmetic (default); 2 = the engine's opt-in fused build (hho_set_emission_mode).  Process-wide:
+        callers put it back to 0."""
+        self.lib.hho_set_emission_mode(int(mode))
+
     def log2f4(self, x):
         return self.lib.hho_log2f4(C.c_float(x))
 

@@ -114,7 +114,7 @@ def run_bench(extra, env_extra=None, timeout=900):
     env.pop("LOCAL_RANK", None)
     env.update(env_extra or {})
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs1",
-           "--no-configs2", "--no-configs4", "--no-next-rows", "--no-upload"] + extra
+           "--no-configs2", "--no-configs4", "--no-next-rows", "--no-upload", "--no-fast-mode"] + extra
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -1,0 +1,68 @@
+"""The OPT-IN fused-emission build (libhhviterbi_hip_fma.so, `make lib_fma`; viterbi_lane.h HHV_EMISSION_FMA) - never the
+default, never what parity or bench.py's `value` are judged on.
+
+It computes the emission score with fused multiply-adds (one rounding per term instead of two), 24 % fewer VALU
+instructions per DP step.  Two checks (-m gpu):
+  * bit for bit against the oracle's restatement of exactly that arithmetic (hho_set_emission_mode(2)): the build is as
+    deterministic and as testable as the default one - score bits, end points, every backtrace byte, paths, Hit scores;
+  * against the reference's arithmetic (mode 0): end points, paths and top-K order unchanged, Viterbi scores within
+    2e-4 (BASELINE.json's tolerance is 1e-4; the measured maximum is reported by bench.py `fast_mode`)."""
+import numpy as np
+import pytest
+
+from common import workload
+from pyoracle import make_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hhv():
+    from pyhhv import capi
+    capi.load()
+    capi.load(capi.FMA_LIB_PATH)
+    return capi
+
+
+@pytest.mark.parametrize("case", [(300, 0), (300, 1), (431, 0), (150, 1), (64, 0)])
+def test_fused_build_equals_its_own_oracle_and_stays_near_the_reference(hhv, oracle, case):
+    Lq, local = case
+    par = make_params(local=local)
+    qf, qtr, tps, ttrs = workload(900 + Lq + local, Lq, 40, 20, 330)
+    c = hhv.Context(local=local, lib_path=hhv.FMA_LIB_PATH)
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    plain = c.align(ts)
+    res = c.align(ts, backtrace=True)
+    assert np.array_equal(plain.view(np.uint8), res.view(np.uint8))
+    hits = c.hits(ts)
+    exact = c0 = None
+    try:
+        oracle.set_emission_mode(2)
+        exact = [oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True) for e in range(len(tps))]
+    finally:
+        oracle.set_emission_mode(0)
+    ref = [oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True) for e in range(len(tps))]
+    worst = 0.0
+    for e, (a, r) in enumerate(zip(exact, ref)):
+        # the build's own arithmetic: everything bit for bit
+        assert (a.i2, a.j2) == (res["i2"][e], res["j2"][e]) and np.float32(a.score) == res["score"][e], (case, e)
+        assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:]), (case, e)
+        assert hits["nsteps"][e] == a.nsteps and np.float32(a.hit_score) == hits["score"][e], (case, e)
+        # the reference's arithmetic: same alignment, score within the tolerance band
+        assert (r.i2, r.j2, r.nsteps) == (a.i2, a.j2, a.nsteps), (case, e)
+        assert np.array_equal(r.i_steps[1:r.nsteps + 1], a.i_steps[1:a.nsteps + 1])
+        assert np.array_equal(r.states[1:r.nsteps + 1], a.states[1:a.nsteps + 1])
+        worst = max(worst, abs(float(r.score) - float(a.score)))
+    assert worst <= 2e-4, worst
+    # the default library in the same process is untouched by the second one
+    d = hhv.Context(local=local)
+    d.set_query(qf, qtr)
+    td = d.upload(tps, ttrs)
+    rd = d.align(td)
+    for e, r in enumerate(ref):
+        assert (r.i2, r.j2) == (rd["i2"][e], rd["j2"][e]) and np.float32(r.score) == rd["score"][e]
+    td.free()
+    d.close()
+    ts.free()
+    c.close()

@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 stage=$1; shift
-short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload"
+short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload --no-fast-mode"
 line() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); print('%.3e cells/s, %.2f ms/step, kernel %.2f ms (min %.2f)' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['kernel_ms_min']))"; }
 case $stage in
 check)
@@ -29,7 +29,7 @@ check)
     timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
   done
   echo "== soak, $soak_s s per family"
-  timeout $((soak_s * 5 + 120)) python tools/soak.py $soak_s > $OUT/soak.json 2> $OUT/soak.err; cat $OUT/soak.json; tail -2 $OUT/soak.err
+  timeout $((soak_s * 6 + 120)) python tools/soak.py $soak_s > $OUT/soak.json 2> $OUT/soak.err; cat $OUT/soak.json; tail -2 $OUT/soak.err
   ;;
 ab)
   bash tools/gpu_ab.sh "$@"

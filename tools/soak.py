@@ -83,6 +83,59 @@ def viterbi_family(orc, rng, budget):
     return {"cases": cases, "mismatches": bad}
 
 
+def fast_family(orc, rng, budget):
+    """The opt-in fused-emission build (libhhviterbi_hip_fma.so): bit for bit against the oracle's restatement of its arithmetic
+    (emission mode 2), and against the reference's arithmetic (mode 0): how many end points / alignments change, largest score
+    difference.  Adversarial inputs as in viterbi_family (ties, dead transitions, tiny templates), no masks."""
+    t_end, cases, bad, idx_changed, worst, worst_hit = time.time() + budget, 0, 0, 0, 0.0, 0.0
+    while time.time() < t_end:
+        Lq = int(rng.choice([5, 63, 64, 65, 100, 300, 320, 321, 400]))
+        local = int(rng.integers(0, 2))
+        par = po.make_params(local=local, egq=float(rng.choice([0.0, 0.2])), egt=float(rng.choice([0.0, 0.1])),
+                             shift=float(rng.choice([-0.03, 0.0])), ss_mode=0)
+        qp, qtr = synth.make_query(int(rng.integers(1 << 30)), Lq)
+        n = int(rng.integers(4, 24))
+        tps, ttrs = [], []
+        for k in range(n):
+            Lt = int(rng.choice([1, 3, 31, 64, 130, 257, 300]))
+            tp, ttr = (synth.make_homolog(int(rng.integers(1 << 30)), qp, L=Lt) if rng.random() < 0.6 and Lq > 4 else
+                       synth.make_template(int(rng.integers(1 << 30)), Lt))
+            if rng.random() < 0.3:
+                ttr = quantize(ttr, rng, 0.5)
+                ttr[ttr < -1000] = -100000.0
+            tps.append(tp)
+            ttrs.append(ttr)
+        c = capi.Context(local=local, egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"], ss_mode=0,
+                         lib_path=capi.FMA_LIB_PATH)
+        c.set_query(qp, qtr)
+        ts = c.upload(tps, ttrs)
+        res = c.align(ts, backtrace=True)
+        hits = c.hits(ts)
+        try:
+            orc.set_emission_mode(2)
+            own = [orc.align(par, qp, qtr, tps[k], ttrs[k], want_path=True) for k in range(n)]
+        finally:
+            orc.set_emission_mode(0)
+        ref = [orc.align(par, qp, qtr, tps[k], ttrs[k], want_path=True) for k in range(n)]
+        for k in range(n):
+            a, r = own[k], ref[k]
+            ok = (a.i2, a.j2) == (int(res["i2"][k]), int(res["j2"][k])) and np.float32(a.score).tobytes() == np.float32(res["score"][k]).tobytes()
+            ok = ok and int(hits["nsteps"][k]) == a.nsteps and np.float32(hits["score"][k]).tobytes() == np.float32(a.hit_score).tobytes()
+            cases += 1
+            bad += int(not ok)
+            same = (a.i2, a.j2, a.nsteps) == (r.i2, r.j2, r.nsteps) and np.array_equal(a.i_steps[1:a.nsteps + 1], r.i_steps[1:r.nsteps + 1]) \
+                and np.array_equal(a.states[1:a.nsteps + 1], r.states[1:r.nsteps + 1])
+            idx_changed += int(not same)
+            if np.isfinite(a.score) and np.isfinite(r.score):
+                worst = max(worst, abs(float(a.score) - float(r.score)))
+            if same:
+                worst_hit = max(worst_hit, abs(float(a.hit_score) - float(r.hit_score)))
+        ts.free()
+        c.close()
+    return {"cases": cases, "mismatches_vs_own_oracle": bad, "alignments_changed_vs_reference_arithmetic": idx_changed,
+            "max_abs_viterbi_score_diff": worst, "max_abs_hit_score_diff_same_alignment": worst_hit}
+
+
 def prefilter_family(orc, rng, budget):
     u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
     t_end, cases, bad = time.time() + budget, 0, 0
@@ -235,13 +288,16 @@ def main():
     orc = po.Oracle()
     fam = sys.argv[3] if len(sys.argv) > 3 else "all"
     if fam != "all":
-        print(json.dumps({fam: {"prefilter": prefilter_family, "mac": mac_family, "viterbi": viterbi_family, "prepare": prepare_family}[fam](orc, rng, budget)}))
+        print(json.dumps({fam: {"prefilter": prefilter_family, "mac": mac_family, "viterbi": viterbi_family, "prepare": prepare_family,
+                                "fast": fast_family}[fam](orc, rng, budget)}))
         return
     out = {"seconds_per_family": budget,
            "viterbi_backtrace_celloff": viterbi_family(orc, rng, budget),
            "prefilter": prefilter_family(orc, rng, budget),
            "mac_realign": mac_family(orc, rng, budget),
            "prepare": prepare_family(orc, rng, budget)}
+    if os.path.exists(capi.FMA_LIB_PATH):
+        out["fast_mode_opt_in_build"] = fast_family(orc, rng, budget)
     print(json.dumps(out))
 
 
