@@ -73,9 +73,25 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   *out = nullptr;
   if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
   MacClasses cls = {};  // the launch is split by template length (hhv_internal.h)
+  // first by length alone; a staged class (template in LDS) with more hits than are resident at once gives its hits to the
+  // lean classes (template operands from global memory, three times the residency) - see mac_staged_capacity
+  bool stage_ok[MAC_CLASSES];
+  {
+    MacClasses first = {};
+    for (int k = 0; k < n; ++k) {
+      if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
+      const int cl = mac_length_class(Lt[k]);
+      first.n[cl]++;
+      first.max_Lt[cl] = std::max(first.max_Lt[cl], Lt[k]);
+    }
+    for (int cl = 0; cl < MAC_CLASSES; ++cl)
+      stage_ok[cl] = cl > 3 || first.n[cl] <= mac_staged_capacity(first.max_Lt[cl], c->num_cus);
+  }
+  std::vector<int8_t> cls_of((size_t)n);
   for (int k = 0; k < n; ++k) {
-    if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
-    const int cl = mac_length_class(Lt[k]);
+    int cl = mac_length_class(Lt[k]);
+    if (!stage_ok[cl]) cl = mac_length_class(Lt[k], false);
+    cls_of[k] = (int8_t)cl;
     cls.n[cl]++;
     cls.max_Lt[cl] = std::max(cls.max_Lt[cl], Lt[k]);
   }
@@ -83,7 +99,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   {
     int at[MAC_CLASSES] = {};
     for (int cl = 1; cl < MAC_CLASSES; ++cl) at[cl] = at[cl - 1] + cls.n[cl - 1];
-    for (int k = 0; k < n; ++k) sel[(size_t)at[mac_length_class(Lt[k])]++] = k;
+    for (int k = 0; k < n; ++k) sel[(size_t)at[cls_of[k]]++] = k;
   }
   const bool with_ss = c->mac_ss_pending;
   c->mac_ss_pending = false;  // one call only

@@ -237,6 +237,10 @@ static int check_prep_params(const hhv_prep_params* par) {
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcc = %g; only the default pcc = 1 avoids libm pow() and is built", par->pcc);
   if (par->columnscore < 0 || par->columnscore > 3)
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: columnscore = %d (only 0..3)", par->columnscore);
+  // p = (1 - tau) f + tau g with tau <= pca (src/hhhmm.cpp:1874-1964): an admixture weight above 1 makes profile values
+  // negative, which the DP kernel's log2f4 does not take (viterbi_lane.h; the packer refuses them on the host paths too)
+  if (par->pcm != 0 && !(par->pca >= 0.0f && par->pca <= 1.0f))
+    return fail(HHV_E_LIMIT, "hhv_prepare_templates: pca = %g; the pseudocount admixture must lie in [0, 1] (profile values stay >= 0)", par->pca);
   return HHV_OK;
 }
 

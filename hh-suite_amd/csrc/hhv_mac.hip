@@ -18,6 +18,8 @@
 // by template-length class (launch_mac below), every class with the LDS footprint of its own longest template and on a
 // stream of its own.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdlib.h>
 
 #include <float.h>
 
@@ -853,8 +855,19 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
   }
 }
 
-int mac_length_class(int Lt) {
-  if (mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64) return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : 3;
+// hits of a staged class that are resident at once: the LDS footprint of the class's longest template decides how many
+// single-wave workgroups a CU holds.  A class with more hits than that runs in rounds; with the template operands read from
+// global memory instead (classes 4, 5: 80 B of LDS per column instead of 202) three times as many hits are resident, which more
+// than pays for the slower operand path: 2 000 hits of 300 columns 15.6 -> 10.6 ms of kernels, 500 hits 4.64 -> 5.00 ms
+// (tools/bench_mac.py, HHV_MAC_NO_STAGE; profiles/r3_next_rows_summary.txt).
+int mac_staged_capacity(int max_Lt, int num_cus) {
+  const size_t lds = mac_rows_lds(max_Lt, true);
+  return num_cus * (int)std::max<size_t>(1, MAC_LDS_LIMIT / std::max<size_t>(lds, 1));
+}
+int mac_length_class(int Lt, bool stage_allowed) {
+  static const bool no_stage = getenv("HHV_MAC_NO_STAGE") != nullptr;  // measurement aid: template operands from global memory for every length
+  if (stage_allowed && !no_stage && mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64)
+    return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : 3;
   if (mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT) return Lt <= 1022 ? 4 : 5;
   return 6;
 }

@@ -137,6 +137,9 @@ HHV_DEV void bt_push_eq(uint32_t& acc, float a, float b) {
   acc = (acc << 1) | (a == b ? 1u : 0u);
 #endif
 }
+// (Compares into SGPR pairs of their own - v_cmp_e64 - with the v_addc_e64 that consume them issued as a block behind, so that
+// no instruction waits for VCC: built and measured, 19.3 -> 26.4 ms per 100 k templates; a VALU write to an SGPR pair is far more
+// expensive than the VCC round trip it avoids.  profiles/r3_ab.txt, ab-r3-4.)
 // if (a > m) { m = a; acc |= bit; }   (bit: a compile-time constant after unrolling; exec_save: EXEC of the caller's block)
 HHV_DEV void bt_max(uint32_t& acc, float& m, float a, uint32_t bit, uint64_t exec_save) {
 #if defined(__HIP_DEVICE_COMPILE__)

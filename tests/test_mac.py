@@ -279,6 +279,35 @@ def test_gpu_mac_length_classes(oracle, lengths):
 
 
 @pytest.mark.gpu
+def test_gpu_mac_more_hits_than_resident_workgroups(oracle):
+    """A staged length class (template in LDS) with more hits than its workgroups are resident at once hands its hits to the
+    lean classes (template operands from global memory, hhv_api_mac.cpp / mac_staged_capacity): 1 400 hits of 20-40 columns
+    (the class holds 5 x 256) together with a few long ones that stay staged; results must not depend on the class taken."""
+    from pyhhv import capi
+    Lq = 36
+    qp, qtr = synth.make_query(91, Lq)
+    q_lin = lin_query(qtr)
+    par = make_params(local=1, ss_mode=0)
+    base = []
+    for k, Lt in enumerate([20, 24, 31, 33, 40, 28, 300, 200]):
+        tp, ttr = synth.make_homolog(1700 + k, qp, L=Lt)
+        t_lin = lin_template(ttr)
+        vit = oracle.align(par, qp, qtr, tp, ttr, want_path=True)
+        base.append((tp, t_lin, oracle_mac_realign(oracle, qp, q_lin, tp, t_lin, vit, local=1)))
+    idx = [k % 6 for k in range(1400)] + [6, 7, 6]
+    c = capi.Context()
+    ms = c.mac_realign(qp, q_lin, [base[i][0] for i in idx], [base[i][1] for i in idx], [base[i][2].celloff for i in idx], local=1)
+    for e, i in enumerate(idx):
+        o, h = base[i][2], ms.hits[e]
+        assert np.float64(h["Pforward"]).tobytes() == np.float64(o.Pforward).tobytes(), e
+        assert (h["nsteps"], h["i1"], h["j1"], h["i2"], h["j2"]) == (o.nsteps, o.i1, o.j1, o.i2, o.j2), e
+    for e in (0, 5, 700, 1399, 1400, 1402):
+        assert ms.posterior(e)[1:, 1:].tobytes() == base[idx[e]][2].posterior[1:, 1:].tobytes(), e
+    ms.free()
+    c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_mac_batch_of_ragged_hits(oracle):
     """Many hits of one query in one launch (ragged Lt, some without mask) equal the same hits done one by one."""
     from pyhhv import capi

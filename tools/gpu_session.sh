@@ -34,11 +34,15 @@ check)
 ab)
   bash tools/gpu_ab.sh "$@"
   ;;
-profile)
-  bash tools/profile.sh "$@"
+profile)   # profile <tag> [bench args]: raw passes, summary into gpurun_out/profiles_out, raw directories removed (size limit)
+  bash tools/profile.sh "$@" > $OUT/profile_$1.log 2>&1
+  HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_profile.py $1 | tail -40
+  rm -rf $OUT/prof_$1
   ;;
 next)
-  bash tools/profile_next.sh "$@"
+  bash tools/profile_next.sh > $OUT/profile_next.log 2>&1
+  HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
+  rm -rf $OUT/prof_next
   ;;
 *) echo "unknown stage $stage"; exit 2;;
 esac

@@ -264,7 +264,7 @@ def prepare_family(orc, rng, budget):
                 neff[:, 0] = 1.0        # Neff_M = 1: (nM - 1) = 0 in the transition pseudocounts
             raws.append((f, tr, neff, nh))
         pcm = int(rng.integers(0, 3))
-        pc = np.array([pcm, float(rng.choice([1.0, 0.4, 0.0, 1.7])), float(rng.choice([1.5, 0.5, 4.0])), 1.0], np.float32)
+        pc = np.array([pcm, float(rng.choice([1.0, 0.4, 0.0, 0.85])), float(rng.choice([1.5, 0.5, 4.0])), 1.0], np.float32)
         gap = np.array([rng.choice([0.15, 1.0]), rng.choice([1.0, 0.3, 2.0]), 0.6, rng.choice([0.6, 1.0]), 0.6, 0.6,
                         rng.choice([1.0, 0.0, 2.5])], np.float32)
         cs = int(rng.integers(0, 4))

@@ -15,7 +15,7 @@ import sys
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_next")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("HHV_PROFILE_OUT", os.path.join(ROOT, "profiles"))   # on the GPU box: gpurun_out/profiles_out
 PEAK = 256 * 4 * 32 * 2.4e9
 
 
@@ -55,6 +55,7 @@ def short(name):
 
 
 def main():
+    os.makedirs(DST, exist_ok=True)
     pf, mac, mac2k = (last_json(os.path.join(SRC, n + ".txt")) for n in ("prefilter", "mac", "mac2k"))
     summary = {"tag": TAG, "valu_issue_peak_lane_ops_per_s": PEAK, "bench_prefilter": pf, "bench_mac_500": mac, "bench_mac_2000": mac2k, "kernels": {}}
     txt = ["profiles/%s_next_rows_summary.txt -- rocprofv3 evidence for the widened rows (SURVEY.md 8f N3, N4), 1x MI355X" % TAG,

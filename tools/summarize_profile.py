@@ -101,9 +101,15 @@ if "SQ_INSTS_VALU" in pm:
 if "hbm_read_bytes_per_launch_corrected" in summary:
     summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch_corrected"] + summary.get(
         "hbm_write_bytes_per_launch_calibrated", summary.get("hbm_write_bytes_per_launch", 0.0))
-os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
-with open(os.path.join(root, "profiles", tag + "_summary.txt"), "w") as f:
+# on the GPU box the summary goes to gpurun_out/profiles_out (HHV_PROFILE_OUT): only gpurun_out/ travels back, and the raw
+# profile directories (tens of MB per pass) would push it over the 64 MiB that are copied
+dst = os.environ.get("HHV_PROFILE_OUT", os.path.join(root, "profiles"))
+os.makedirs(dst, exist_ok=True)
+with open(os.path.join(dst, tag + "_summary.txt"), "w") as f:
     f.write("\n".join(lines) + "\n")
-with open(os.path.join(root, "profiles", tag + "_summary.json"), "w") as f:
+with open(os.path.join(dst, tag + "_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
+import shutil
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv"))
 print("\n".join(lines))
