@@ -601,8 +601,25 @@ def configs2(args, torch, ctx, ts, rec, rec_off, Ls, qf, qtr, Lq, Lt, K):
     ts10.free()
     try:
         sec, kms = time_bt_steps(ctx, ts, K, reps=3, warm=1)
-        out["%dk" % (ts.n // 1000)] = {"cells_per_s": ts.cells() / sec, "ms_per_step": sec * 1e3, "dp_kernel_ms": kms,
-                                        "backtrace_bytes_written_per_launch": int(ts.records()) * 512}
+        e = {"cells_per_s": ts.cells() / sec, "ms_per_step": sec * 1e3, "dp_kernel_ms": kms,
+             "backtrace_bytes_written_per_launch": int(ts.records()) * 512}
+        if ts.n == 100000 and Lq == 300 and Lt == 300:
+            try:   # the backtrace kernel's executed VALU instructions and HBM traffic from its own committed counters
+                with open(os.path.join(ROOT, "profiles", "r3bt_summary.json")) as f:
+                    prof = json.load(f)
+                lane_ops = prof["valu_wave_instr_per_launch"] * 64.0
+                e["roofline_valu"] = {"valu_wave_instr_per_launch": prof["valu_wave_instr_per_launch"],
+                                      "valu_lane_instr_per_cell": lane_ops / ts.cells(),
+                                      "frac_of_issue_peak": lane_ops / (kms * 1e-3) / VALU_PEAK_LANEOPS,
+                                      "frac_reference_flops": ts.cells() / (kms * 1e-3) * OPS_PER_CELL / VALU_PEAK_LANEOPS,
+                                      "source": "profiles/r3bt_summary.json (SQ_INSTS_VALU per launch) / dp_kernel_ms of this run"}
+                e["roofline_hbm"] = {"traffic_bytes_per_launch": prof["traffic_bytes_per_launch"],
+                                     "algorithmic_bytes_per_launch": int(ts.records()) * REC_BYTES + ts.n * 16 + int(ts.cells()),
+                                     "achieved_GBs": prof["traffic_bytes_per_launch"] / (kms * 1e-3) / 1e9,
+                                     "frac_of_hbm_peak": prof["traffic_bytes_per_launch"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            except Exception:
+                pass
+        out["%dk" % (ts.n // 1000)] = e
     except Exception as e:
         out["%dk" % (ts.n // 1000)] = {"error": repr(e)}
     return out
