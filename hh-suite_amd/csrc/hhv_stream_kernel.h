@@ -278,10 +278,10 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   constexpr int A = LANES / W;   // arrays per wave
   constexpr int C = W / 2;       // records per ring chunk and array (the live window of W records spans <= 3 chunks)
   static_assert(RING_CHUNKS == 4 && CHUNK_RECS == 32 && A * C == CHUNK_RECS, "ring geometry");
-  // backtrace variants: {m2i, i2i} and {m2d, d2d} of the lane's R query rows live in LDS (20 floats per lane; the
+  // five-row backtrace variants: {m2i, i2i} and {m2d, d2d} of the lane's R query rows live in LDS (20 floats per lane; the
   // 20-dword stride is conflict-free for ds_read_b128) - the VGPRs they would occupy hold the compare results instead.
   // ONE __shared__ object: [QL block][ring].
-  constexpr bool QL = BT;
+  constexpr bool QL = BT && R == 5;  // (up to four rows per lane the registers hold the query's gap transitions as well)
   constexpr int QL_F4 = QL ? LANES * 5 : 0;
   constexpr int BEST_F4 = W == LANES ? LANES / 2 : 0;  // 8 bytes per lane: the finalized best on its way to the next lane
   __shared__ float4 smem[QL_F4 + RING_RECS * 7 + BEST_F4];
