@@ -132,3 +132,44 @@ def test_packed_db_file_is_validated_on_open(tmp_path):
     assert np.array_equal(c.align(ts).view(np.uint8), good.view(np.uint8))
     ts.free()
     c.close()
+
+
+def test_advice_r2_celloff_without_mask_after_backtrace_and_foreign_set_ids():
+    """(1) hhv_align(HHV_ALIGN_CELLOFF) on a set whose buffer still holds the compare bits of a backtrace launch and got
+    no mask since must not read those bits as masks: no cell is switched off (like the reference's cleared matrix), so the run
+    equals a plain backtrace run; (2) hhv_tset_set_global_ids checks that the set belongs to the context; (3) negative profile
+    values are refused on upload, by hhv_set_query and - a pseudocount admixture above 1 - by the device preparation."""
+    from pyhhv import capi
+    c = capi.Context(local=1)
+    qp, qtr = synth.make_query(2, 70)
+    tps, ttrs = zip(*[synth.make_homolog(30 + k, qp, L=40 + 3 * k) for k in range(12)])
+    c.set_query(qp, qtr)
+    ts = c.upload(list(tps), list(ttrs))
+    plain = c.align(ts, backtrace=True)
+    bt0 = [c.backtrace_matrix(ts, k) for k in range(12)]
+    masked = c.align(ts, celloff=True)                      # no hhv_set_celloff in between
+    assert np.array_equal(plain.view(np.uint8), masked.view(np.uint8))
+    for k in range(12):
+        assert np.array_equal(c.backtrace_matrix(ts, k) & 0x7F, bt0[k] & 0x7F)
+    c2 = capi.Context(local=1)
+    with pytest.raises(capi.HhvError, match="another context"):
+        c2.set_global_ids(ts, np.arange(12))
+    c2.close()
+    bad = tps[0].copy()
+    bad[3, 5] = -0.25
+    with pytest.raises(capi.HhvError, match="negative profile value"):
+        c.upload([bad], [ttrs[0]])
+    badq = qp.copy()
+    badq[7, 0] = -1e-3
+    with pytest.raises(capi.HhvError, match="negative profile value"):
+        c.set_query(badq, qtr)
+    c.set_query(qp, qtr)
+    assert np.array_equal(c.align(ts).view(np.uint8), plain.view(np.uint8))     # the context survived
+    z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "gonnet_pb_R.npz"))
+    f, tr, neff, nh = synth.make_raw_hmm(5, 30)
+    raw, Ls = c.upload_raw([f], [tr], [neff], [nh])
+    with pytest.raises(capi.HhvError, match="pca"):
+        c.prepare(raw, Ls, capi.prep_params(z["pb"], z["R"], pc=(2, 1.7, 1.5, 1.0)), z["pb"].astype(np.float32))
+    c.rawset_free(raw)
+    ts.free()
+    c.close()
