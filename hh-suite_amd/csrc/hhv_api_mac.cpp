@@ -74,26 +74,31 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
   MacClasses cls = {};  // the launch is split by template length (hhv_internal.h)
   // first by length alone; a staged class (template in LDS) with more hits than are resident at once gives its hits to the
-  // lean classes (template operands from global memory, three times the residency) - see mac_staged_capacity
-  bool stage_ok[MAC_CLASSES];
-  {
-    MacClasses first = {};
-    for (int k = 0; k < n; ++k) {
-      if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
-      const int cl = mac_length_class(Lt[k]);
-      first.n[cl]++;
-      first.max_Lt[cl] = std::max(first.max_Lt[cl], Lt[k]);
-    }
-    for (int cl = 0; cl < MAC_CLASSES; ++cl)
-      stage_ok[cl] = cl > 3 || first.n[cl] <= mac_staged_capacity(first.max_Lt[cl], c->num_cus);
-  }
+  // lean classes (template operands from global memory, three times the residency), and a lean class that is over-subscribed
+  // in turn to the class without LDS - see mac_staged_capacity
   std::vector<int8_t> cls_of((size_t)n);
   for (int k = 0; k < n; ++k) {
-    int cl = mac_length_class(Lt[k]);
-    if (!stage_ok[cl]) cl = mac_length_class(Lt[k], false);
-    cls_of[k] = (int8_t)cl;
-    cls.n[cl]++;
-    cls.max_Lt[cl] = std::max(cls.max_Lt[cl], Lt[k]);
+    if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
+    cls_of[k] = (int8_t)mac_length_class(Lt[k]);
+  }
+  for (int level = 0; level < 2; ++level) {  // level 0: staged -> lean, level 1: lean -> no LDS
+    MacClasses cnt = {};
+    for (int k = 0; k < n; ++k) {
+      cnt.n[cls_of[k]]++;
+      cnt.max_Lt[cls_of[k]] = std::max(cnt.max_Lt[cls_of[k]], Lt[k]);
+    }
+    for (int k = 0; k < n; ++k) {
+      const int cl = cls_of[k];
+      const bool staged = cl <= 3, lean = cl == 4 || cl == 5;
+      if (level == 0 && staged && cnt.n[cl] > mac_staged_capacity(cnt.max_Lt[cl], c->num_cus, true))
+        cls_of[k] = (int8_t)mac_length_class(Lt[k], false);
+      if (level == 1 && lean && cnt.n[cl] > mac_staged_capacity(cnt.max_Lt[cl], c->num_cus, false))
+        cls_of[k] = (int8_t)mac_length_class(Lt[k], false, false);
+    }
+  }
+  for (int k = 0; k < n; ++k) {
+    cls.n[cls_of[k]]++;
+    cls.max_Lt[cls_of[k]] = std::max(cls.max_Lt[cls_of[k]], Lt[k]);
   }
   std::vector<int32_t> sel((size_t)n);
   {

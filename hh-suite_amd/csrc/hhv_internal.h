@@ -289,8 +289,8 @@ struct MacStreams {
   void* fork;
   void* join[MAC_CLASSES];
 };
-int mac_length_class(int Lt, bool stage_allowed = true);
-int mac_staged_capacity(int max_Lt, int num_cus);  // hits of a staged class resident at once
+int mac_length_class(int Lt, bool stage_allowed = true, bool lds_allowed = true);
+int mac_staged_capacity(int max_Lt, int num_cus, bool stage = true);  // hits of a staged (stage) / lean (!stage) class resident at once
 int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream, const MacStreams* side);
 
 // launchers implemented in hhv_kernels.hip

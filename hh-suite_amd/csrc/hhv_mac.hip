@@ -860,15 +860,19 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
 // global memory instead (classes 4, 5: 80 B of LDS per column instead of 202) three times as many hits are resident, which more
 // than pays for the slower operand path: 2 000 hits of 300 columns 15.6 -> 10.6 ms of kernels, 500 hits 4.64 -> 5.00 ms
 // (tools/bench_mac.py, HHV_MAC_NO_STAGE; profiles/r3_next_rows_summary.txt).
-int mac_staged_capacity(int max_Lt, int num_cus) {
-  const size_t lds = mac_rows_lds(max_Lt, true);
+// The same one level further: a lean class (row state in LDS) with more hits than ITS residency runs with the row state in
+// global memory as well (class 6: no LDS, as many workgroups as the registers admit): 2 000 hits 10.6 -> 9.35 ms, 500 hits
+// 4.68 (staged) / 5.01 (lean) / 4.90 (no LDS) - the sweeps' dependent chains, not the operand path, set the pace.
+int mac_staged_capacity(int max_Lt, int num_cus, bool stage) {
+  const size_t lds = mac_rows_lds(max_Lt, stage);
   return num_cus * (int)std::max<size_t>(1, MAC_LDS_LIMIT / std::max<size_t>(lds, 1));
 }
-int mac_length_class(int Lt, bool stage_allowed) {
+int mac_length_class(int Lt, bool stage_allowed, bool lds_allowed) {
   static const bool no_stage = getenv("HHV_MAC_NO_STAGE") != nullptr;  // measurement aid: template operands from global memory for every length
   if (stage_allowed && !no_stage && mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64)
     return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : 3;
-  if (mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT) return Lt <= 1022 ? 4 : 5;
+  static const bool no_lds = getenv("HHV_MAC_NO_LDS") != nullptr;  // measurement aid: row state in global memory for every length
+  if (lds_allowed && !no_lds && mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT) return Lt <= 1022 ? 4 : 5;
   return 6;
 }
 

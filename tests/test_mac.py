@@ -304,6 +304,23 @@ def test_gpu_mac_more_hits_than_resident_workgroups(oracle):
     for e in (0, 5, 700, 1399, 1400, 1402):
         assert ms.posterior(e)[1:, 1:].tobytes() == base[idx[e]][2].posterior[1:, 1:].tobytes(), e
     ms.free()
+    # one level further: a lean class (row state in LDS: two workgroups per CU at 1 000 columns) with more hits than that gives
+    # them to the class without LDS
+    long_ = []
+    for k, Lt in enumerate([1000, 990]):
+        tp, ttr = synth.make_homolog(1800 + k, qp, L=Lt)
+        t_lin = lin_template(ttr)
+        vit = oracle.align(par, qp, qtr, tp, ttr, want_path=True)
+        long_.append((tp, t_lin, oracle_mac_realign(oracle, qp, q_lin, tp, t_lin, vit, local=1)))
+    idx = [k % 2 for k in range(620)]
+    ms = c.mac_realign(qp, q_lin, [long_[i][0] for i in idx], [long_[i][1] for i in idx], [long_[i][2].celloff for i in idx], local=1)
+    for e, i in enumerate(idx):
+        o, h = long_[i][2], ms.hits[e]
+        assert np.float64(h["Pforward"]).tobytes() == np.float64(o.Pforward).tobytes(), e
+        assert (h["nsteps"], h["i1"], h["j1"], h["i2"], h["j2"]) == (o.nsteps, o.i1, o.j1, o.i2, o.j2), e
+    for e in (0, 1, 619):
+        assert ms.posterior(e)[1:, 1:].tobytes() == long_[idx[e]][2].posterior[1:, 1:].tobytes(), e
+    ms.free()
     c.close()
 
 
