@@ -26,6 +26,12 @@ lib: $(LIB) $(RUNNER)
 lib_fma:
 	$(MAKE) $(LIBDIR)/libhhviterbi_hip_fma.so LIB=$(LIBDIR)/libhhviterbi_hip_fma.so OBJDIR=build/obj_fma HHV_EXTRA_HIPFLAGS="$(HHV_EXTRA_HIPFLAGS) -DHHV_EMISSION_FMA"
 
+# measurement builds next to the product library (tools/README.md), e.g.
+#   make lib_variant NAME=nq FLAGS=-DHHV_NO_QUEUE        a fixed stream range per wave in every variant (A/B of the work queue)
+#   make lib_variant NAME=wt FLAGS=-DHHV_EXP_WAVETIME    per-workgroup entry / exit times (tools/wave_times.py)
+lib_variant:
+	$(MAKE) $(LIBDIR)/libhhviterbi_$(NAME).so LIB=$(LIBDIR)/libhhviterbi_$(NAME).so OBJDIR=build/obj_$(NAME) HHV_EXTRA_HIPFLAGS="$(HHV_EXTRA_HIPFLAGS) $(FLAGS)"
+
 # C++ host layer above the C ABI (mirror of the reference's ViterbiRunner); plain g++, links only the C ABI
 $(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/prefilter.h hh-suite_amd/host/posterior_decoder.cpp hh-suite_amd/host/posterior_decoder.h include/hhviterbi_hip.h $(LIB)
 	g++ -O2 -std=c++14 -ffp-contract=off -fPIC -shared -Wall -Iinclude -o $@ hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/posterior_decoder.cpp -L$(LIBDIR) -lhhviterbi_hip -lpthread -Wl,-rpath,'$$ORIGIN'
@@ -73,7 +79,7 @@ clean:
 	rm -rf build $(LIBDIR) tests/emul/libwave_emul.so
 	$(MAKE) -C oracle clean
 
-.PHONY: example all lib lib_fma oracle emul clean
+.PHONY: example all lib lib_fma lib_variant oracle emul clean
 
 # plain-C++ use of the host classes (no Python): examples/search_example.cpp
 example: $(RUNNER)

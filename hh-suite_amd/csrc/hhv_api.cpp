@@ -164,6 +164,7 @@ void hhv_destroy(hhv_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->par.device);
   dfree(c->d_qpack);
+  dfree(c->d_queue);
   dfree(c->d_qp);
   dfree(c->d_lg2);
   dfree(c->d_diff);
@@ -449,6 +450,7 @@ void hhv_tset_free(hhv_tset* ts) {
   dfree(ts->d_L);
   dfree(ts->d_results);
   dfree(ts->d_wave_rec);
+  dfree(ts->d_seg);
   dfree(ts->d_bt);
   dfree(ts->d_carry);
   dfree(ts->d_carry_mi);
@@ -476,10 +478,14 @@ int64_t hhv_tset_cells(const hhv_tset* ts, int32_t Lq) {
   return s;
 }
 
-// Contiguous template ranges with ~equal record counts, one per wave.  All waves are resident at
-// once (n_waves = CUs x blocks/CU the variant's VGPR/LDS budget admits), so there is no tail.
+// Fixed ranges (multi-pass and short-query launches; the single-pass 64-lane launches draw segments from a queue instead,
+// ensure_segments): contiguous template ranges with ~equal record counts, cut at the first template boundary behind
+// w x total / n.  All waves are resident at once (n_waves = CUs x blocks/CU the variant's VGPR/LDS budget admits).
+// (The contiguous partition with the smallest maximum - bisection + greedy fill, largest range 1.4 % instead of 7.6 % over the
+// mean on a 50..1000-column database - measured 1.3 % SLOWER: profiles/r3_ab.txt ab-r3-10.  The waves do not run at one speed,
+// so the largest range is not what ends the launch; what fixes that is the queue.)
 static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_ranges, int n_slots) {
-  // n_ranges non-empty ranges, padded with empty ones to n_slots (a wave of a short-query launch takes 64 / W ranges)
+  // n_ranges ranges, padded with empty ones to n_slots (a wave of a short-query launch takes 64 / W ranges)
   if (ts->n_waves == n_ranges && ts->n_range_slots == n_slots && ts->d_wave_rec) return HHV_OK;
   dfree(ts->d_wave_rec);
   std::vector<int64_t> wr((size_t)n_slots + 1);
@@ -496,6 +502,44 @@ static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_ranges, int n_slots)
   HIP_TRY(hipStreamSynchronize(c->stream));
   ts->n_waves = n_ranges;
   ts->n_range_slots = n_slots;
+  return HHV_OK;
+}
+
+// Segment table of the stream kernel's work queue: whole templates in stream order, a segment closed as soon as it holds
+// >= 128 records (a ring chunk of 32 records may hold one junction only, and a draw costs a round trip); a short remainder
+// joins the segment in front of it.  Drawn longest first, so that what is left for the end of the launch are the short
+// ones (a 1000-column template drawn last would add its whole length to the launch).  Depends on the stream only.
+static int ensure_segments(hhv_ctx* c, hhv_tset* ts) {
+  if (!c->d_queue) HIP_TRY(hipMalloc(&c->d_queue, sizeof(uint32_t)));
+  if (ts->d_seg) return HHV_OK;
+  constexpr int64_t kMinRecords = 128;
+  std::vector<int64_t> first;
+  first.reserve((size_t)ts->n + 1);
+  int64_t start = 0;
+  for (int k = 0; k < ts->n; ++k) {
+    if (ts->rec_off[k + 1] - start >= kMinRecords) {
+      first.push_back(start);
+      start = ts->rec_off[k + 1];
+    }
+  }
+  const int64_t total = ts->rec_off[ts->n];
+  if (first.empty() && total > 0) first.push_back(0);  // (a remainder of < 128 records belongs to the last segment)
+  const int n_seg = (int)first.size();
+  first.push_back(total);
+  std::vector<int32_t> order((size_t)n_seg);
+  for (int k = 0; k < n_seg; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first[x + 1] - first[x] > first[y + 1] - first[y]; });
+  std::vector<int64_t> seg((size_t)2 * (n_seg + 1));
+  for (int k = 0; k < n_seg; ++k) {
+    seg[2 * (size_t)k] = first[order[k]];
+    seg[2 * (size_t)k + 1] = first[order[k] + 1];
+  }
+  seg[2 * (size_t)n_seg] = total;  // the terminal header
+  seg[2 * (size_t)n_seg + 1] = total + 1;
+  ts->n_seg = n_seg;
+  HIP_TRY(hipMalloc(&ts->d_seg, seg.size() * sizeof(int64_t)));
+  HIP_TRY(hipMemcpyAsync(ts->d_seg, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return HHV_OK;
 }
 
@@ -540,9 +584,21 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     if (v >= 1) blocks_per_cu = std::min(blocks_per_cu, v);
   }
   const int n_ranges = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu * arrays, ts->n));
-  const int n_waves = (n_ranges + arrays - 1) / arrays;
+  int n_waves = (n_ranges + arrays - 1) / arrays;
   rc = ensure_partition(c, ts, n_ranges, n_waves * arrays);
   if (rc != HHV_OK) return rc;
+  // single pass, 64 lanes: the waves draw stream segments from a queue instead (hhv_stream_kernel.h DQ)
+#if defined(HHV_NO_QUEUE)  // measurement build (matches hhv_stream_kernel.h): a fixed range per wave in every variant
+  const bool queue = false;
+#else
+  const bool queue = plan.W == LANES && !multi;
+#endif
+  if (queue) {
+    rc = ensure_segments(c, ts);
+    if (rc != HHV_OK) return rc;
+    n_waves = std::max(1, std::min(c->num_cus * blocks_per_cu, ts->n_seg));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves, 1, c->stream));  // wave w starts with segment w
+  }
   if (bt) {
     rc = ensure_bt(c, ts);
     if (rc != HHV_OK) return rc;
@@ -571,6 +627,9 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.ss_q_off = ss ? c->d_ss_q_off : nullptr;
   a.ss_t_shift = c->ss_t_shift;
   a.ss_t_mask = c->ss_t_mask;
+  a.seg_first = queue ? ts->d_seg : nullptr;
+  a.n_seg = queue ? ts->n_seg : 0;
+  a.queue = c->d_queue;
   if (multi) {
     if (!ts->d_carry) {
       HIP_TRY(hipMalloc(&ts->d_carry, (size_t)ts->n_records * sizeof(float4)));

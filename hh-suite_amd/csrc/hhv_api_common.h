@@ -50,6 +50,7 @@ struct hhv_ctx {
   int Lq = 0;
   hhv::StripPlan plan;
   float* d_qpack = nullptr;  // [plan.rows()][28]
+  uint32_t* d_queue = nullptr;  // ticket counter of the stream kernel's work queue (set in front of each launch)
   float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring
   size_t qpack_cap = 0, qp_cap = 0;  // floats allocated behind d_qpack / d_qp (kept between queries)
   void* q_stage = nullptr;           // pinned staging block of hhv_set_query
@@ -100,6 +101,8 @@ struct hhv_tset {
   // wave partition
   int n_waves = 0, n_range_slots = 0;  // non-empty stream ranges / ranges incl. the empty padding
   int64_t* d_wave_rec = nullptr;
+  int64_t* d_seg = nullptr;      // [n_seg + 1][2] segment table of the work queue (hhv_stream_kernel.h DQ), built at the first launch
+  int n_seg = 0;
   // backtrace bytes: [pass][record][lane] entries
   uint64_t* d_bt = nullptr;
   bool bt_valid = false;

@@ -24,6 +24,12 @@ extern "C" __attribute__((visibility("default"))) int hhv_debug_clk(unsigned lon
 }
 #endif
 
+#if defined(HHV_EXP_WAVETIME)
+extern "C" __attribute__((visibility("default"))) int hhv_debug_wave(unsigned long long* out, int n_waves) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hhv::hhv_dbg_wave), (size_t)n_waves * 4 * sizeof(unsigned long long));
+}
+#endif
+
 namespace hhv {
 
 // ---------------------------------------------------------------------------------------------

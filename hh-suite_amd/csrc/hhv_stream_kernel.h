@@ -18,6 +18,12 @@ static __device__ unsigned long long hhv_dbg_clk[8];
 #define HHV_STAMP(t_, ...) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), __VA_ARGS__)
 #endif
 
+#if defined(HHV_EXP_WAVETIME)
+// measurement build only (tools/wave_times.py): per workgroup the constant-rate 100 MHz clock at entry and exit, its range's
+// record count and the hardware ids (HW_ID: simd / cu / sh / se, XCC_ID) - who finishes when, and where it ran
+static __device__ unsigned long long hhv_dbg_wave[4 * 16384];
+#endif
+
 // Hand-off lane n <- lane n-1: pulled through the LDS crossbar (ds_bpermute_b32: no LDS memory, returns on lgkmcnt like a
 // read) at the top of the step and delivered LATE - MM / DG / MI of the row above are first needed in phase C, GD / IM / DG as
 // next step's diagonal - so the round trip (300+ clk under this kernel's LDS load) lies under phases A and B.  Rounds 1-2a
@@ -48,6 +54,111 @@ __device__ __forceinline__ float dpp_shr1(float old, float src, bool first_of_ar
   return __builtin_bit_cast(float, dpp_shr1<W>(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), first_of_array));
 }
 
+// ---- work queue of the single-pass 64-lane variants (see the kernel: DQ) ------------------------------------
+// A wave's stream is the concatenation of the segments it draws; positions count its records from 0.  All state is wave
+// uniform and kept in SGPRs (every update goes through readfirstlane: these variants have no VGPR to spare).  A segment is
+// drawn when the ring refill reaches the end of the current one - a round trip of an atomic and a scalar load per segment
+// (>= 128 steps), during which the other wave of the SIMD has the issue slots to itself.
+struct WorkQueue {
+  int delta_lo, delta_hi;  // record = position + delta for positions < J
+  int J;                   // end (position) of the current segment
+  // the junction passed last, for the lanes' own record indices (backtrace entries): positions < Jlast have dprev, positions
+  // >= Jlast delta_lo (mod 2^32: record indices are < 2^32).  One junction of history is enough: the refill runs at most 96
+  // positions ahead of the first lane and segments have >= 128 records, so when it passes a junction the one before it is
+  // behind the last lane (position s - 63).
+  int Jlast, dprev;
+  int tail;                // the refill has passed the terminal header: the rest is the stream's padding
+  int end;                 // records of the wave's stream incl. the terminal header, M_OPEN until the queue is empty
+  static constexpr int M_OPEN = 0x3FFFFFFF;
+
+  static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ __forceinline__ int64_t delta() const { return (int64_t)(((uint64_t)(uint32_t)delta_hi << 32) | (uint32_t)delta_lo); }
+  __device__ __forceinline__ void set_delta(int64_t v) {
+    delta_lo = uni((int)(uint32_t)v);
+    delta_hi = uni((int)(uint32_t)((uint64_t)v >> 32));
+  }
+  // One ticket for the wave: EXEC is narrowed to lane 0 inside the statement (uniform control flow around it), and the
+  // statement waits for the value itself - no register is in flight outside it.
+  static __device__ __forceinline__ int draw(const uint32_t* queue) {
+    uint64_t save;
+    uint32_t zero = 0, one = 1, ticket;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(ticket), "=&s"(save) : "v"(zero), "v"(one), "s"(queue) : "memory");
+    return __builtin_amdgcn_readfirstlane((int)ticket);
+  }
+  // segment id = records [seg[2 id], seg[2 id + 1]) by one scalar load (the table is never written by a kernel)
+  static __device__ __forceinline__ void segment(const int64_t* seg_first, int id, int64_t& first, int64_t& end) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i w;
+    const uint32_t off = (uint32_t)id * 16u;
+    asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(seg_first), "s"(off) : "memory");
+    first = (int64_t)(((uint64_t)(uint32_t)w.y << 32) | (uint32_t)w.x);
+    end = (int64_t)(((uint64_t)(uint32_t)w.w << 32) | (uint32_t)w.z);
+  }
+  // first segment of the wave: its own number (the ticket counter starts at the number of waves - 2048 draws of the same
+  // counter at the start of a launch would queue up behind each other); false: more waves than segments
+  __device__ __forceinline__ bool start(const int64_t* seg_first, int n_seg, int wave) {
+    const int id = wave;
+    if (id >= n_seg) return false;
+    int64_t f0, f1;
+    segment(seg_first, id, f0, f1);
+    set_delta(f0);
+    J = uni((int)(f1 - f0));
+    Jlast = 0;
+    dprev = 0;
+    tail = 0;
+    end = M_OPEN;
+    return true;
+  }
+  // Refill of chunk cc = positions [32 cc, 32 cc + 32).  When the chunk reaches the end of the current segment the next one is
+  // drawn (queue empty: the terminal header, which ends the stream: `end`); one junction at most lies inside a chunk (segments
+  // have >= 128 records; behind the terminal header the stream's padding is read, like behind the end of a fixed range).
+  __device__ __forceinline__ void refill(const float4* __restrict__ records, const int64_t* seg_first, int n_seg,
+                                         const uint32_t* queue, int cc, float4* ring, int lane) {
+    constexpr int SLOT_F4 = CHUNK_RECS * 7;
+    float4* const l = ring + (cc & (RING_CHUNKS - 1)) * SLOT_F4;
+    const int P0 = cc * CHUNK_RECS;
+    const bool cross = !tail && P0 + CHUNK_RECS > J;
+    int64_t next = 0;
+    int nlen = 1;
+    if (cross) {
+      const int id = draw(queue);
+      int64_t f1;
+      segment(seg_first, min(id, n_seg), next, f1);  // (entry n_seg = the terminal header)
+      if (id < n_seg) {
+        nlen = (int)(f1 - next);
+      } else {
+        end = uni(J + 1);
+        tail = 1;
+      }
+    }
+    const int64_t base = ((int64_t)P0 + delta()) * 7;
+    const int64_t jump = cross ? ((next - J) - delta()) * 7 : 0;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // (keeps hipcc from carrying the per-lane parts of the addresses through the step loop)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x = k * LANES + ln;
+      int64_t off = base + x;
+      if (cross && P0 + ((x * 9363) >> 16) >= J) off += jump;  // x / 7 for x < 224
+      if (k < 3 || ln < 32)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(records + off),
+                                         (__attribute__((address_space(3))) void*)(l + k * LANES), 16, 0, 0);
+    }
+    if (cross) {
+      dprev = delta_lo;
+      Jlast = J;
+      set_delta(next - J);
+      J = uni(J + nlen);
+    }
+  }
+  // record index (mod 2^32) of position p, for p inside the lanes' window
+  __device__ __forceinline__ uint32_t record_of(int p) const {
+    return (uint32_t)p + (uint32_t)delta_lo + (p < Jlast ? (uint32_t)dprev - (uint32_t)delta_lo : 0u);
+  }
+};
+
 // Ring refill.  Per refill every array of the wave gets its next chunk of C = W / 2 records; the 64 / W chunks together
 // are always 32 records = 224 float4 = 3.5 wave-wide 16-byte-per-lane loads straight into LDS (one ring slot = the chunks
 // of all arrays back to back).  W = 64: one stream, lane l of load k fetches float4 64 k + l of the chunk.  W < 64: float4
@@ -59,6 +170,7 @@ __device__ __forceinline__ void load_chunk(const float4* __restrict__ records, c
                                            const int (&nchunks)[LANES / W], int chunk, float4* ring, int lane) {
   constexpr int A = LANES / W, C = W / 2, CF4 = C * 7, SLOT_F4 = CHUNK_RECS * 7;  // 224 float4 per slot
   float4* l = ring + (chunk & (RING_CHUNKS - 1)) * SLOT_F4;
+  if (A == 1) asm volatile("" : "+v"(lane));  // (64-lane variants: no VGPR pair for a per-lane address carried through the step loop)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int x = k * LANES + lane;
@@ -289,19 +401,46 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   const int lane = threadIdx.x;
   const int g = lane & (W - 1);  // lane of the array
   const int arr = lane / W;
+#if defined(HHV_EXP_WAVETIME)
+  const unsigned long long wt_start = wall_clock64();
+#endif
+  // DQ: the single-pass 64-lane variants take their work from a queue of stream SEGMENTS (whole templates, >= 128 records
+  // each, a.seg_first) instead of one fixed range per wave: a wave's stream is the concatenation of the segments it draws
+  // (one atomic ticket each).  The position -> record mapping is needed by the ring refill and, in the backtrace / cell-off
+  // variants, for the entry address (WorkQueue::record_of); the header of the next segment's first template finalizes the
+  // previous template like any other header.  Why: waves run at different speeds (tools/wave_times.py: the two waves of a
+  // SIMD finish 0.8 ms apart, XCDs differ by 3 %) and a fixed equal split ends with the slowest one - 4.6 % of the headline
+  // launch, 15 % with mixed lengths (a fixed split cannot cut inside a 1000-column template either).
+#if defined(HHV_NO_QUEUE)  // measurement build: a fixed range per wave in every variant
+  constexpr bool DQV = false;
+#else
+  constexpr bool DQV = W == LANES && !MULTI;
+#endif
+  constexpr bool dq = DQV;
+  WorkQueue wq = {};
   // stream ranges: rb / M per lane (uniform within an array), and per array as wave-uniform values for the refill
   int64_t rb_a[A];
   int M_a[A], nch_a[A];
   int Mmax = 0;
+  if (DQV && dq) {
+    if (!wq.start(a.seg_first, a.n_seg, (int)blockIdx.x)) return;
+    rb_a[0] = wq.delta();
+    M_a[0] = nch_a[0] = Mmax = WorkQueue::M_OPEN;
+  } else {
 #pragma unroll
-  for (int j = 0; j < A; ++j) {
-    const int64_t b0 = a.wave_rec[blockIdx.x * A + j], e0 = a.wave_rec[blockIdx.x * A + j + 1];
-    rb_a[j] = b0;
-    M_a[j] = e0 > b0 ? (int)(e0 - b0) + 1 : 0;  // the range's records plus the next header (finalizes the last template)
-    nch_a[j] = (M_a[j] + C - 1) / C;
-    Mmax = max(Mmax, M_a[j]);
+    for (int j = 0; j < A; ++j) {
+      const int64_t b0 = a.wave_rec[blockIdx.x * A + j], e0 = a.wave_rec[blockIdx.x * A + j + 1];
+      rb_a[j] = b0;
+      M_a[j] = e0 > b0 ? (int)(e0 - b0) + 1 : 0;  // the range's records plus the next header (finalizes the last template)
+      if (A == 1) {  // wave uniform, but loaded through the vector path: into SGPRs
+        rb_a[j] = (int64_t)(((uint64_t)(uint32_t)WorkQueue::uni((int)(uint32_t)((uint64_t)b0 >> 32)) << 32) | (uint32_t)WorkQueue::uni((int)(uint32_t)b0));
+        M_a[j] = WorkQueue::uni(M_a[j]);
+      }
+      nch_a[j] = (M_a[j] + C - 1) / C;
+      Mmax = max(Mmax, M_a[j]);
+    }
+    if (Mmax == 0) return;
   }
-  if (Mmax == 0) return;
   int64_t rb = rb_a[0];
   int M = M_a[0];
 #pragma unroll
@@ -328,9 +467,16 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   const bool carry_out = MULTI && a.pass_last == 0;
 
   const float4* const records = (const float4*)a.records;
-  const int nchunks_max = (Mmax + C - 1) / C;
-  load_chunk<W>(records, rb_a, nch_a, 0, ring, lane);
-  load_chunk<W>(records, rb_a, nch_a, 1, ring, lane);  // the stream is padded: over-reading past M is harmless
+  int nchunks_max = (Mmax + C - 1) / C;
+  if (DQV && dq) {
+    wq.refill(records, a.seg_first, a.n_seg, a.queue, 0, ring, lane);
+    wq.refill(records, a.seg_first, a.n_seg, a.queue, 1, ring, lane);
+    M = Mmax = wq.end;  // (a stream of less than two chunks is at its end already)
+    nchunks_max = (Mmax + C - 1) / C;
+  } else {
+    load_chunk<W>(records, rb_a, nch_a, 0, ring, lane);
+    load_chunk<W>(records, rb_a, nch_a, 1, ring, lane);  // the stream is padded: over-reading past M is harmless
+  }
 
   QRows<R> q;
   q.load(a.qpack + (size_t)g * R * REC_DW);
@@ -510,8 +656,11 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         uint64_t cell = 0;
         uint64_t* bte = nullptr;
         // entry of (record rb + r, lane g): row rb + r + g = rb + s, the same row for all lanes of the array (bt_entry)
-        if (BT || CELLOFF)
-          bte = a.bt + ((MULTI ? (size_t)a.bt_plane * a.bt_pass_stride : 0) + (size_t)(rb + s) * W + g);
+        if (BT || CELLOFF) {
+          // (work queue: the lane's record sits wherever its segment lies; (record + g) is the row, uniform between junctions)
+          const size_t row = DQV ? (size_t)(uint32_t)(wq.record_of(r) + (uint32_t)g) : (size_t)(rb + s);
+          bte = a.bt + ((MULTI ? (size_t)a.bt_plane * a.bt_pass_stride : 0) + row * W + g);
+        }
         if (CELLOFF) cell = *bte;
         float ssv[R];
         if (SS) {
@@ -547,7 +696,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 
   // Two nested loops: the outer one walks the ring chunks (one refill each), the inner one the C steps of a chunk, so
   // that the refill test is not part of a step.
-  const int s_end = Mmax + W - 1;
+  int s_end = Mmax + W - 1;
   for (int c = 0; c * C - LEAD < s_end; ++c) {
     if (c > 0) {
       // chunk c was issued C steps ago: make sure it has landed, then refill the slot that held chunk c-3 (its last
@@ -555,7 +704,17 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
       // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (c + 1 < nchunks_max) load_chunk<W>(records, rb_a, nch_a, c + 1, ring, lane);
+      if (DQV && dq) {
+        if (c + 1 < nchunks_max) wq.refill(records, a.seg_first, a.n_seg, a.queue, c + 1, ring, lane);
+        if (wq.end != M) {  // the queue is empty: the stream ends behind the current segment's terminal header
+          M = wq.end;
+          s_end = M + W - 1;
+          nchunks_max = (M + C - 1) / C;
+          if (c * C - LEAD >= s_end) break;
+        }
+      } else {
+        if (c + 1 < nchunks_max) load_chunk<W>(records, rb_a, nch_a, c + 1, ring, lane);
+      }
     }
     const int s_lo = c > 0 ? c * C - LEAD : 0, s_hi = min((c + 1) * C - LEAD, s_end);
     if (PF && !MULTI) {
@@ -583,6 +742,14 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       for (int s = s_lo; s < s_hi; ++s) step(s, col, col);
     }
   }
+#if defined(HHV_EXP_WAVETIME)
+  if (lane == 0 && blockIdx.x < 16384) {
+    hhv_dbg_wave[4 * blockIdx.x + 0] = wt_start;
+    hhv_dbg_wave[4 * blockIdx.x + 1] = wall_clock64();
+    hhv_dbg_wave[4 * blockIdx.x + 2] = (unsigned long long)(DQV && dq ? M : Mmax);
+    hhv_dbg_wave[4 * blockIdx.x + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
 #if defined(HHV_EXP_TIMING)
   if (blockIdx.x == 0 && lane == 0) {
     hhv_dbg_clk[0] = dbg0;

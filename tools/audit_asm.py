@@ -9,7 +9,9 @@ This script compiles hhv_kernels.hip with --save-temps (or takes an existing .s)
      outside asm blocks reads or writes one of the destination registers;
   2. the kernel's main loop contains no compiler-generated ds_read / flat_load, and - in the variants without global
      loads in the loop (no CELLOFF, MULTI, SS) - no compiler-generated s_waitcnt vmcnt;
-  3. no scratch (private segment) is used.
+  3. no scratch (private segment) is used;
+  4. the work queue's ticket (global_atomic_add in an asm block, hhv_stream_kernel.h WorkQueue::draw) is not touched outside
+     asm blocks between its draw and the asm vmcnt(0) that precedes its use.
 Exit status 0 = clean.  Used by tests/test_asm_audit.py (CPU-only: hipcc cross-compiles without a GPU).
 """
 import os
@@ -76,6 +78,7 @@ def audit_function(name, body):
     m = re.search(r"hhv_stream_kernelILi\dELb\dELb\dELb(\d)ELb(\d)ELb(\d)E", name)
     loads_in_loop = m is None or "1" in m.groups()
     pending = []         # destination registers of issued, not yet waited-for asm reads, one set per read in issue order
+    ticket = []          # destination of the work queue's atomic, not yet waited for
     in_asm = False
     asm_lines = []
     in_loop = False
@@ -93,6 +96,11 @@ def audit_function(name, body):
             for a in asm_lines:
                 if a.startswith("ds_read") or a.startswith("ds_bpermute"):
                     pending.append(regs_of(a.split(",")[0]))
+                # the work queue's ticket (WorkQueue::draw): in flight on vmcnt until an asm vmcnt(0)
+                if a.startswith("global_atomic_add"):
+                    ticket.append(regs_of(a.split(",")[0]))
+                if re.search(r"vmcnt\(0\)", a):
+                    ticket = []
                 w = re.search(r"lgkmcnt\((\d+)\)", a)
                 if w:
                     n_left = int(w.group(1))
@@ -108,6 +116,10 @@ def audit_function(name, body):
             hit = regs_of(code) & set().union(*pending)
             if hit:
                 problems.append("%s: line %d touches v%s while its read is in flight: %s" % (name, ln, sorted(hit), code.strip()))
+        if ticket:
+            hit = regs_of(code) & set().union(*ticket)
+            if hit:
+                problems.append("%s: line %d touches v%s while the queue ticket is in flight: %s" % (name, ln, sorted(hit), code.strip()))
         if in_loop:
             op = code.split()[0]
             if op.startswith("ds_read") or op.startswith("flat_load"):
