@@ -587,17 +587,16 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   int n_waves = (n_ranges + arrays - 1) / arrays;
   rc = ensure_partition(c, ts, n_ranges, n_waves * arrays);
   if (rc != HHV_OK) return rc;
-  // single pass, 64 lanes: the waves draw stream segments from a queue instead (hhv_stream_kernel.h DQ)
+  // 64-lane arrays: the waves draw stream segments from a queue instead (hhv_stream_kernel.h DQ)
 #if defined(HHV_NO_QUEUE)  // measurement build (matches hhv_stream_kernel.h): a fixed range per wave in every variant
   const bool queue = false;
 #else
-  const bool queue = plan.W == LANES && !multi;
+  const bool queue = plan.W == LANES;
 #endif
   if (queue) {
     rc = ensure_segments(c, ts);
     if (rc != HHV_OK) return rc;
     n_waves = std::max(1, std::min(c->num_cus * blocks_per_cu, ts->n_seg));
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves, 1, c->stream));  // wave w starts with segment w
   }
   if (bt) {
     rc = ensure_bt(c, ts);
@@ -645,6 +644,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.qpack = c->d_qpack + (size_t)a.row_base * REC_DW;
     a.pass_first = pass == 0;
     a.pass_last = pass == plan.P - 1;
+    if (queue) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves, 1, c->stream));  // wave w starts with segment w
     rc = launch_stream(plan.W, plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   }

@@ -54,7 +54,7 @@ __device__ __forceinline__ float dpp_shr1(float old, float src, bool first_of_ar
   return __builtin_bit_cast(float, dpp_shr1<W>(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), first_of_array));
 }
 
-// ---- work queue of the single-pass 64-lane variants (see the kernel: DQ) ------------------------------------
+// ---- work queue of the 64-lane variants (see the kernel: DQ) ------------------------------------
 // A wave's stream is the concatenation of the segments it draws; positions count its records from 0.  All state is wave
 // uniform and kept in SGPRs (every update goes through readfirstlane: these variants have no VGPR to spare).  A segment is
 // drawn when the ring refill reaches the end of the current one - a round trip of an atomic and a scalar load per segment
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #if defined(HHV_EXP_WAVETIME)
   const unsigned long long wt_start = wall_clock64();
 #endif
-  // DQ: the single-pass 64-lane variants take their work from a queue of stream SEGMENTS (whole templates, >= 128 records
+  // DQ: the 64-lane variants take their work from a queue of stream SEGMENTS (whole templates, >= 128 records
   // each, a.seg_first) instead of one fixed range per wave: a wave's stream is the concatenation of the segments it draws
   // (one atomic ticket each).  The position -> record mapping is needed by the ring refill and, in the backtrace / cell-off
   // variants, for the entry address (WorkQueue::record_of); the header of the next segment's first template finalizes the
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #if defined(HHV_NO_QUEUE)  // measurement build: a fixed range per wave in every variant
   constexpr bool DQV = false;
 #else
-  constexpr bool DQV = W == LANES && !MULTI;
+  constexpr bool DQV = W == LANES;
 #endif
   constexpr bool dq = DQV;
   WorkQueue wq = {};
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   float nmi = 0.f;
   if (MULTI && !first) {
     if (lane == 0 && M > 0) {
-      ncar = a.carry[rb];
+      ncar = a.carry[rb];  // (work queue: rb = the first record of the wave's first segment)
       nmi = a.carry_mi[rb];
     }
   }
@@ -628,8 +628,9 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       // lands in the same registers and is not waited for before the next step (requested inside the block above, hipcc
       // loads into temporaries, copies and waits for the round trip on the spot)
       if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
-        ncar = a.carry[rb + r + 1];
-        nmi = a.carry_mi[rb + r + 1];
+        const size_t rn = DQV ? (size_t)wq.record_of(r + 1) : (size_t)(rb + r + 1);
+        ncar = a.carry[rn];
+        nmi = a.carry_mi[rn];
       }
     }
 
@@ -676,8 +677,9 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       }
       if (carry_out) {
         if (lane == LANES - 1) {
-          a.carry[rb + r] = make_float4(st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1]);
-          a.carry_mi[rb + r] = st.MI[R - 1];
+          const size_t rc = DQV ? (size_t)wq.record_of(r) : (size_t)(rb + r);
+          a.carry[rc] = make_float4(st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1]);
+          a.carry_mi[rc] = st.MI[R - 1];
         }
       }
     }
