@@ -478,7 +478,7 @@ int64_t hhv_tset_cells(const hhv_tset* ts, int32_t Lq) {
   return s;
 }
 
-// Fixed ranges (multi-pass and short-query launches; the single-pass 64-lane launches draw segments from a queue instead,
+// Fixed ranges (the -DHHV_NO_QUEUE measurement build only; the product's arrays draw segments from a queue instead,
 // ensure_segments): contiguous template ranges with ~equal record counts, cut at the first template boundary behind
 // w x total / n.  All waves are resident at once (n_waves = CUs x blocks/CU the variant's VGPR/LDS budget admits).
 // (The contiguous partition with the smallest maximum - bisection + greedy fill, largest range 1.4 % instead of 7.6 % over the
@@ -587,16 +587,16 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   int n_waves = (n_ranges + arrays - 1) / arrays;
   rc = ensure_partition(c, ts, n_ranges, n_waves * arrays);
   if (rc != HHV_OK) return rc;
-  // 64-lane arrays: the waves draw stream segments from a queue instead (hhv_stream_kernel.h DQ)
+  // the systolic arrays draw stream segments from a queue (hhv_stream_kernel.h DQ); the fixed ranges above serve the -DHHV_NO_QUEUE build
 #if defined(HHV_NO_QUEUE)  // measurement build (matches hhv_stream_kernel.h): a fixed range per wave in every variant
   const bool queue = false;
 #else
-  const bool queue = plan.W == LANES;
+  const bool queue = true;
 #endif
   if (queue) {
     rc = ensure_segments(c, ts);
     if (rc != HHV_OK) return rc;
-    n_waves = std::max(1, std::min(c->num_cus * blocks_per_cu, ts->n_seg));
+    n_waves = (std::max(1, std::min(c->num_cus * blocks_per_cu * arrays, ts->n_seg)) + arrays - 1) / arrays;
   }
   if (bt) {
     rc = ensure_bt(c, ts);
@@ -644,7 +644,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.qpack = c->d_qpack + (size_t)a.row_base * REC_DW;
     a.pass_first = pass == 0;
     a.pass_last = pass == plan.P - 1;
-    if (queue) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves, 1, c->stream));  // wave w starts with segment w
+    if (queue) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves * arrays, 1, c->stream));  // array k starts with segment k
     rc = launch_stream(plan.W, plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   }

@@ -108,7 +108,7 @@ struct StreamArgs {
   const float* ss_table;     // ssw * S33 / S73 / S37, premultiplied on the host (same fp32 product as the reference)
   const int32_t* ss_q_off;   // [P*64*R] table row offset of query row i at index i-1
   int32_t ss_t_shift, ss_t_mask;
-  // work queue of the score-only single-pass 64-lane variants (hhv_stream_kernel.h DQ); seg_first = nullptr: fixed ranges
+  // work queue of the 64-lane variants (hhv_stream_kernel.h DQ); unused by the short-query arrays (fixed ranges, wave_rec)
   const int64_t* seg_first;  // [n_seg + 1][2] records [first, end) of segment k in the order they are drawn: whole templates,
                              // >= 128 records, longest first; entry n_seg = the terminal header
   int32_t n_seg;

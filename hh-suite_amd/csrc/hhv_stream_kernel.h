@@ -96,30 +96,36 @@ struct WorkQueue {
     first = (int64_t)(((uint64_t)(uint32_t)w.y << 32) | (uint32_t)w.x);
     end = (int64_t)(((uint64_t)(uint32_t)w.w << 32) | (uint32_t)w.z);
   }
-  // first segment of the wave: its own number (the ticket counter starts at the number of waves - 2048 draws of the same
-  // counter at the start of a launch would queue up behind each other); false: more waves than segments
-  __device__ __forceinline__ bool start(const int64_t* seg_first, int n_seg, int wave) {
-    const int id = wave;
-    if (id >= n_seg) return false;
+  // first segment of an array: its own number (the ticket counter starts at the number of arrays - thousands of draws of the
+  // same counter at the start of a launch would queue up behind each other); false: more arrays than segments, nothing to do
+  __device__ __forceinline__ bool start(const int64_t* seg_first, int n_seg, int id) {
+    Jlast = 0;
+    dprev = 0;
+    if (id >= n_seg) {
+      delta_lo = delta_hi = J = 0;
+      tail = 1;
+      end = 0;
+      return false;
+    }
     int64_t f0, f1;
     segment(seg_first, id, f0, f1);
     set_delta(f0);
     J = uni((int)(f1 - f0));
-    Jlast = 0;
-    dprev = 0;
     tail = 0;
     end = M_OPEN;
     return true;
   }
-  // Refill of chunk cc = positions [32 cc, 32 cc + 32).  When the chunk reaches the end of the current segment the next one is
-  // drawn (queue empty: the terminal header, which ends the stream: `end`); one junction at most lies inside a chunk (segments
-  // have >= 128 records; behind the terminal header the stream's padding is read, like behind the end of a fixed range).
+  // Refill of chunk cc = positions [C cc, C cc + C) of one systolic array (C = W / 2 records = 7 C float4, loaded by
+  // ceil(7 C / 64) wave-wide 16-byte-per-lane loads straight into the array's part of the ring slot, `dst`).  When the chunk
+  // reaches the end of the current segment the next one is drawn (queue empty: the terminal header, which ends the stream:
+  // `end`); one junction at most lies inside a chunk (segments have >= 128 records; behind the terminal header the stream's
+  // padding is read).  Everything that depends on the array is wave uniform here: no per-lane selects.
+  template <int W>
   __device__ __forceinline__ void refill(const float4* __restrict__ records, const int64_t* seg_first, int n_seg,
-                                         const uint32_t* queue, int cc, float4* ring, int lane) {
-    constexpr int SLOT_F4 = CHUNK_RECS * 7;
-    float4* const l = ring + (cc & (RING_CHUNKS - 1)) * SLOT_F4;
-    const int P0 = cc * CHUNK_RECS;
-    const bool cross = !tail && P0 + CHUNK_RECS > J;
+                                         const uint32_t* queue, int cc, float4* dst, int lane) {
+    constexpr int C = W / 2, CF4 = C * 7, H = (CF4 + LANES - 1) / LANES;
+    const int P0 = cc * C;
+    const bool cross = !tail && P0 + C > J;
     int64_t next = 0;
     int nlen = 1;
     if (cross) {
@@ -138,13 +144,13 @@ struct WorkQueue {
     int ln = lane;
     asm volatile("" : "+v"(ln));  // (keeps hipcc from carrying the per-lane parts of the addresses through the step loop)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int x = k * LANES + ln;
+    for (int h = 0; h < H; ++h) {
+      const int x = h * LANES + ln;
       int64_t off = base + x;
       if (cross && P0 + ((x * 9363) >> 16) >= J) off += jump;  // x / 7 for x < 224
-      if (k < 3 || ln < 32)
+      if ((h + 1) * LANES <= CF4 || x < CF4)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(records + off),
-                                         (__attribute__((address_space(3))) void*)(l + k * LANES), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(dst + h * LANES), 16, 0, 0);
     }
     if (cross) {
       dprev = delta_lo;
@@ -411,21 +417,26 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // previous template like any other header.  Why: waves run at different speeds (tools/wave_times.py: the two waves of a
   // SIMD finish 0.8 ms apart, XCDs differ by 3 %) and a fixed equal split ends with the slowest one - 4.6 % of the headline
   // launch, 15 % with mixed lengths (a fixed split cannot cut inside a 1000-column template either).
-#if defined(HHV_NO_QUEUE)  // measurement build: a fixed range per wave in every variant
+#if defined(HHV_NO_QUEUE)  // measurement build: a fixed range per array in every variant
   constexpr bool DQV = false;
 #else
-  constexpr bool DQV = W == LANES;
+  constexpr bool DQV = true;
 #endif
-  constexpr bool dq = DQV;
-  WorkQueue wq = {};
+  WorkQueue wq[A] = {};
   // stream ranges: rb / M per lane (uniform within an array), and per array as wave-uniform values for the refill
   int64_t rb_a[A];
   int M_a[A], nch_a[A];
   int Mmax = 0;
-  if (DQV && dq) {
-    if (!wq.start(a.seg_first, a.n_seg, (int)blockIdx.x)) return;
-    rb_a[0] = wq.delta();
-    M_a[0] = nch_a[0] = Mmax = WorkQueue::M_OPEN;
+  if (DQV) {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      any |= wq[j].start(a.seg_first, a.n_seg, (int)blockIdx.x * A + j);
+      rb_a[j] = wq[j].delta();
+      M_a[j] = nch_a[j] = wq[j].end;
+      Mmax = max(Mmax, M_a[j]);
+    }
+    if (!any) return;
   } else {
 #pragma unroll
     for (int j = 0; j < A; ++j) {
@@ -448,6 +459,39 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     rb = (arr == j) ? rb_a[j] : rb;
     M = (arr == j) ? M_a[j] : M;
   }
+  // work queue: the refill of chunk cc for every array that still has records there; then the arrays' stream ends as the
+  // lanes see them (M per lane, Mmax for the loop) and - backtrace / cell-off variants of the short-query arrays - the lane's
+  // copy of its array's position -> record mapping (the 64-lane variants read the SGPRs)
+  uint32_t lq_delta = 0, lq_prev = 0;
+  int lq_J = 0;
+  auto dq_refill = [&](const int cc) __attribute__((always_inline)) {
+    constexpr int SLOT_F4 = CHUNK_RECS * 7;
+    float4* const slot = ring + (cc & (RING_CHUNKS - 1)) * SLOT_F4;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      if (cc * C < wq[j].end) wq[j].template refill<W>((const float4*)a.records, a.seg_first, a.n_seg, a.queue, cc, slot + j * (C * 7), lane);
+    }
+    M = wq[0].end;
+    Mmax = wq[0].end;
+#pragma unroll
+    for (int j = 1; j < A; ++j) {
+      M = (arr == j) ? wq[j].end : M;
+      Mmax = max(Mmax, wq[j].end);
+    }
+    if (A > 1 && (BT || CELLOFF)) {
+      lq_delta = (uint32_t)wq[0].delta_lo, lq_prev = (uint32_t)wq[0].dprev, lq_J = wq[0].Jlast;
+#pragma unroll
+      for (int j = 1; j < A; ++j) {
+        lq_delta = (arr == j) ? (uint32_t)wq[j].delta_lo : lq_delta;
+        lq_prev = (arr == j) ? (uint32_t)wq[j].dprev : lq_prev;
+        lq_J = (arr == j) ? wq[j].Jlast : lq_J;
+      }
+    }
+  };
+  auto record_of = [&](const int p) __attribute__((always_inline)) -> uint32_t {
+    if (A == 1) return wq[0].record_of(p);
+    return (uint32_t)p + lq_delta + (p < lq_J ? lq_prev - lq_delta : 0u);
+  };
 
   Params P;
   P.egq = a.egq;
@@ -468,10 +512,9 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 
   const float4* const records = (const float4*)a.records;
   int nchunks_max = (Mmax + C - 1) / C;
-  if (DQV && dq) {
-    wq.refill(records, a.seg_first, a.n_seg, a.queue, 0, ring, lane);
-    wq.refill(records, a.seg_first, a.n_seg, a.queue, 1, ring, lane);
-    M = Mmax = wq.end;  // (a stream of less than two chunks is at its end already)
+  if (DQV) {
+    dq_refill(0);
+    dq_refill(1);  // (a stream of less than two chunks is at its end already: M, Mmax)
     nchunks_max = (Mmax + C - 1) / C;
   } else {
     load_chunk<W>(records, rb_a, nch_a, 0, ring, lane);
@@ -628,7 +671,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       // lands in the same registers and is not waited for before the next step (requested inside the block above, hipcc
       // loads into temporaries, copies and waits for the round trip on the spot)
       if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
-        const size_t rn = DQV ? (size_t)wq.record_of(r + 1) : (size_t)(rb + r + 1);
+        const size_t rn = DQV ? (size_t)record_of(r + 1) : (size_t)(rb + r + 1);
         ncar = a.carry[rn];
         nmi = a.carry_mi[rn];
       }
@@ -659,7 +702,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         // entry of (record rb + r, lane g): row rb + r + g = rb + s, the same row for all lanes of the array (bt_entry)
         if (BT || CELLOFF) {
           // (work queue: the lane's record sits wherever its segment lies; (record + g) is the row, uniform between junctions)
-          const size_t row = DQV ? (size_t)(uint32_t)(wq.record_of(r) + (uint32_t)g) : (size_t)(rb + s);
+          const size_t row = DQV ? (size_t)(uint32_t)(record_of(r) + (uint32_t)g) : (size_t)(rb + s);
           bte = a.bt + ((MULTI ? (size_t)a.bt_plane * a.bt_pass_stride : 0) + row * W + g);
         }
         if (CELLOFF) cell = *bte;
@@ -677,7 +720,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       }
       if (carry_out) {
         if (lane == LANES - 1) {
-          const size_t rc = DQV ? (size_t)wq.record_of(r) : (size_t)(rb + r);
+          const size_t rc = DQV ? (size_t)record_of(r) : (size_t)(rb + r);
           a.carry[rc] = make_float4(st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1]);
           a.carry_mi[rc] = st.MI[R - 1];
         }
@@ -706,12 +749,12 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
       // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (DQV && dq) {
-        if (c + 1 < nchunks_max) wq.refill(records, a.seg_first, a.n_seg, a.queue, c + 1, ring, lane);
-        if (wq.end != M) {  // the queue is empty: the stream ends behind the current segment's terminal header
-          M = wq.end;
-          s_end = M + W - 1;
-          nchunks_max = (M + C - 1) / C;
+      if (DQV) {
+        const int m_before = Mmax;
+        if (c + 1 < nchunks_max) dq_refill(c + 1);
+        if (Mmax != m_before) {  // the queue is empty: the last array's stream ends behind its current segment's terminal header
+          s_end = Mmax + W - 1;
+          nchunks_max = (Mmax + C - 1) / C;
           if (c * C - LEAD >= s_end) break;
         }
       } else {
@@ -748,7 +791,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   if (lane == 0 && blockIdx.x < 16384) {
     hhv_dbg_wave[4 * blockIdx.x + 0] = wt_start;
     hhv_dbg_wave[4 * blockIdx.x + 1] = wall_clock64();
-    hhv_dbg_wave[4 * blockIdx.x + 2] = (unsigned long long)(DQV && dq ? M : Mmax);
+    hhv_dbg_wave[4 * blockIdx.x + 2] = (unsigned long long)Mmax;
     hhv_dbg_wave[4 * blockIdx.x + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   }
 #endif

@@ -1,11 +1,12 @@
-"""The stream kernel's work queue (-m gpu): single-pass 64-lane launches draw stream SEGMENTS (whole templates, >= 128 records,
-longest first) instead of walking one fixed range per wave (hhv_stream_kernel.h WorkQueue, hhv_api.cpp ensure_segments).
+"""The stream kernel's work queue (-m gpu): every systolic array (one per wave, or two / four for short queries) draws stream
+SEGMENTS (whole templates, >= 128 records, longest first) instead of walking one fixed range (hhv_stream_kernel.h WorkQueue, hhv_api.cpp ensure_segments).
 
 What can go wrong there and nowhere else: a ring chunk that holds a junction between two segments (records of two places of
 the stream in one 32-record chunk), the header of a segment's first template finalizing the last template of ANOTHER segment,
 the terminal header behind the last segment a wave drew, the backtrace entry address of a lane whose record lies behind a
 junction while its neighbour's lies in front of it, segments of exactly 128 records (a junction every fourth chunk), a stream
-shorter than one chunk, a remainder of < 128 records joining the segment in front of it, fewer segments than waves.
+shorter than one chunk, a remainder of < 128 records joining the segment in front of it, fewer segments than arrays (a wave
+whose second array has nothing to do).
 Every case: score-only, backtrace (bytes of a sample, Hit scores and step counts of all) and a masked round, local and
 global, against the oracle - the reference's definition of the path is per template, so which wave aligned it must not show."""
 import numpy as np
@@ -56,11 +57,11 @@ def base_templates(qf, Lq, lengths, seed):
 
 @pytest.mark.parametrize("local", [0, 1])
 @pytest.mark.parametrize("name", list(PATTERNS))
-@pytest.mark.parametrize("Lq", [300, 161])
+@pytest.mark.parametrize("Lq", [300, 161, 150, 70])   # five / three rows per lane on 64 lanes; two 32-lane arrays; four 16-lane arrays
 def test_queue_junctions(hhv, oracle, Lq, name, local):
     from pyhhv import synth
     if Lq == 161 and name not in ("mixed", "L127"):
-        pytest.skip("the small cases run at the headline query length")
+        pytest.skip("the small cases run at the headline query length and on the short-query arrays")
     cycle, n = PATTERNS[name]
     rng = np.random.default_rng(len(name) * 100 + Lq + local)
     par = make_params(local=local)
