@@ -82,6 +82,51 @@ int hhv_device_count(int32_t* n) {
   return HHV_OK;
 }
 
+// Segment table of the stream kernel's work queue (hhv_stream_kernel.h DQ): whole templates in stream order, a segment closed
+// as soon as it holds >= HHV_SEGMENT_MIN_RECORDS records (a ring chunk of <= 32 records may hold one junction only, and a
+// draw costs a round trip); a short remainder joins the segment in front of it.  Listed longest first (stable), so that what
+// is left for the end of a launch are the short ones - a 1000-column template drawn last would add its whole length to the
+// launch.  seg = (first record, end record) per segment in draw order + the terminal entry (total, total + 1).
+static int plan_segments(const int64_t* rec_off, int n, std::vector<int64_t>& seg) {
+  std::vector<int64_t> first;
+  first.reserve((size_t)n + 1);
+  int64_t start = 0;
+  for (int k = 0; k < n; ++k) {
+    if (rec_off[k + 1] - start >= HHV_SEGMENT_MIN_RECORDS) {
+      first.push_back(start);
+      start = rec_off[k + 1];
+    }
+  }
+  const int64_t total = n > 0 ? rec_off[n] : 0;
+  if (first.empty() && total > 0) first.push_back(0);  // (a remainder of < 128 records belongs to the last segment)
+  const int n_seg = (int)first.size();
+  first.push_back(total);
+  std::vector<int32_t> order((size_t)n_seg);
+  for (int k = 0; k < n_seg; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first[x + 1] - first[x] > first[y + 1] - first[y]; });
+  seg.assign((size_t)2 * (n_seg + 1), 0);
+  for (int k = 0; k < n_seg; ++k) {
+    seg[2 * (size_t)k] = first[order[k]];
+    seg[2 * (size_t)k + 1] = first[order[k] + 1];
+  }
+  seg[2 * (size_t)n_seg] = total;  // the terminal header
+  seg[2 * (size_t)n_seg + 1] = total + 1;
+  return n_seg;
+}
+
+int hhv_segment_plan(int32_t n, const int32_t* L, int64_t* seg_out, int32_t* n_seg) {
+  if (n < 0 || !n_seg || !seg_out || (n && !L)) return fail(HHV_E_ARG, "hhv_segment_plan: bad argument");
+  std::vector<int64_t> rec_off((size_t)n + 1, 0);
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1) return fail(HHV_E_ARG, "hhv_segment_plan: template %d has %d columns", k, L[k]);
+    rec_off[k + 1] = rec_off[k] + L[k] + 1;
+  }
+  std::vector<int64_t> seg;
+  *n_seg = plan_segments(rec_off.data(), n, seg);
+  std::copy(seg.begin(), seg.end(), seg_out);
+  return HHV_OK;
+}
+
 int hhv_shard_plan(int32_t n, const int32_t* L, int32_t n_shards, int32_t* shard_of) {
   if (n < 0 || n_shards < 1 || (n && (!L || !shard_of))) return fail(HHV_E_ARG, "hhv_shard_plan: bad argument");
   if (n == 0) return HHV_OK;
@@ -505,38 +550,12 @@ static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_ranges, int n_slots)
   return HHV_OK;
 }
 
-// Segment table of the stream kernel's work queue: whole templates in stream order, a segment closed as soon as it holds
-// >= 128 records (a ring chunk of 32 records may hold one junction only, and a draw costs a round trip); a short remainder
-// joins the segment in front of it.  Drawn longest first, so that what is left for the end of the launch are the short
-// ones (a 1000-column template drawn last would add its whole length to the launch).  Depends on the stream only.
+// the segment table on the device (plan_segments above; depends on the stream only) and the context's ticket counter
 static int ensure_segments(hhv_ctx* c, hhv_tset* ts) {
   if (!c->d_queue) HIP_TRY(hipMalloc(&c->d_queue, sizeof(uint32_t)));
   if (ts->d_seg) return HHV_OK;
-  constexpr int64_t kMinRecords = 128;
-  std::vector<int64_t> first;
-  first.reserve((size_t)ts->n + 1);
-  int64_t start = 0;
-  for (int k = 0; k < ts->n; ++k) {
-    if (ts->rec_off[k + 1] - start >= kMinRecords) {
-      first.push_back(start);
-      start = ts->rec_off[k + 1];
-    }
-  }
-  const int64_t total = ts->rec_off[ts->n];
-  if (first.empty() && total > 0) first.push_back(0);  // (a remainder of < 128 records belongs to the last segment)
-  const int n_seg = (int)first.size();
-  first.push_back(total);
-  std::vector<int32_t> order((size_t)n_seg);
-  for (int k = 0; k < n_seg; ++k) order[k] = k;
-  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first[x + 1] - first[x] > first[y + 1] - first[y]; });
-  std::vector<int64_t> seg((size_t)2 * (n_seg + 1));
-  for (int k = 0; k < n_seg; ++k) {
-    seg[2 * (size_t)k] = first[order[k]];
-    seg[2 * (size_t)k + 1] = first[order[k] + 1];
-  }
-  seg[2 * (size_t)n_seg] = total;  // the terminal header
-  seg[2 * (size_t)n_seg + 1] = total + 1;
-  ts->n_seg = n_seg;
+  std::vector<int64_t> seg;
+  ts->n_seg = plan_segments(ts->rec_off.data(), ts->n, seg);
   HIP_TRY(hipMalloc(&ts->d_seg, seg.size() * sizeof(int64_t)));
   HIP_TRY(hipMemcpyAsync(ts->d_seg, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_hits",
-    "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan",
+    "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan", "hhv_segment_plan",
     "hhv_tset_set_global_ids", "hhv_merge_hits",
 ]
 
@@ -93,6 +93,7 @@ def load(path=None):
     L.hhv_fast_log2_tables.argtypes = [c_float_p, c_float_p]
     L.hhv_device_count.argtypes = [c_int_p]
     L.hhv_shard_plan.argtypes = [C.c_int32, c_int_p, C.c_int32, c_int_p]
+    L.hhv_segment_plan.argtypes = [C.c_int32, c_int_p, C.POINTER(C.c_int64), c_int_p]
     L.hhv_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(HhvParams)]
     L.hhv_destroy.argtypes = [C.c_void_p]
     L.hhv_destroy.restype = None
@@ -181,6 +182,16 @@ def shard_plan(lengths, n_shards):
     out = np.zeros(L.shape[0], dtype=np.int32)
     _check(load().hhv_shard_plan(L.shape[0], L.ctypes.data_as(c_int_p), int(n_shards), out.ctypes.data_as(c_int_p)))
     return out
+
+
+def segment_plan(lengths):
+    """hhv_segment_plan: the DP kernel's work queue for a template stream of these lengths -> (n_seg, [(first, end)] in draw
+    order incl. the terminal entry).  Pure host function."""
+    L = np.ascontiguousarray(lengths, dtype=np.int32)
+    seg = np.zeros(2 * (L.shape[0] + 1), dtype=np.int64)
+    n_seg = C.c_int32(0)
+    _check(load().hhv_segment_plan(L.shape[0], L.ctypes.data_as(c_int_p), seg.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n_seg)))
+    return n_seg.value, seg[: 2 * (n_seg.value + 1)].reshape(-1, 2)
 
 
 def _check(rc):

@@ -128,6 +128,17 @@ int hhv_device_count(int32_t* n);
  * plan from the same lengths. */
 int hhv_shard_plan(int32_t n, const int32_t* L, int32_t n_shards, int32_t* shard_of);
 
+/* The work queue of the DP kernel (replaces the static batch list of src/hhviterbirunner.cpp:117-122 - the
+ * reference hands its sorted SIMD batches to OpenMP threads with schedule(dynamic), this is the device's form of it).  The
+ * template stream (per template a header record + L columns) is cut into segments of whole templates in stream order, each
+ * closed as soon as it holds >= HHV_SEGMENT_MIN_RECORDS records (a shorter remainder joins the last one); the systolic arrays
+ * of the device draw them longest first (stable).  Which array aligns a template does not enter any result.  Pure host
+ * function - what hhv_align uses internally, exposed so that the plan can be inspected and tested without a device.
+ * seg: [2 * (n + 1)] (first record, end record) per segment in draw order, then the terminal entry (total, total + 1);
+ * *n_seg = number of segments (<= n). */
+#define HHV_SEGMENT_MIN_RECORDS 128
+int hhv_segment_plan(int32_t n, const int32_t* L, int64_t* seg, int32_t* n_seg);
+
 int hhv_create(hhv_ctx** out, const hhv_params* par);
 /* Replace the context's fast_log2 tables (lg2[1025], diff[1025]; default: hhv_fast_log2_tables).  The reference keeps these
  * tables in function-local statics that the FIRST caller in the process initialises, and the initialiser is compiled per

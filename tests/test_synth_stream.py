@@ -107,3 +107,37 @@ def test_bench_defaults_are_baseline_configs():
         sys.argv = old
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "100000 if args.gpus == 1 else 125000" in src      # 8 x 125 000 = configs[3]'s 1 M templates
+
+
+def test_segment_plan_of_the_work_queue():
+    """hhv_segment_plan (host logic of the DP kernel's work queue, hhv_api.cpp plan_segments): whole templates, every record
+    exactly once, >= 128 records per segment unless the whole stream is shorter, drawn longest first (stable), terminal entry."""
+    from pyhhv import capi, synth
+    rng = np.random.default_rng(5)
+    cases = [np.full(1000, 300), np.full(500, 127), np.full(7, 20), np.array([20]), np.array([60, 30]), np.array([200, 200, 30]),
+             synth.zipf_lengths(0x21F, 20000), rng.integers(1, 40, 3000), np.array([1000, 1, 1, 1]), np.zeros(0, dtype=np.int32)]
+    for L in cases:
+        L = np.asarray(L, dtype=np.int32)
+        n = L.shape[0]
+        n_seg, seg = capi.segment_plan(L)
+        off = np.concatenate([[0], np.cumsum(L.astype(np.int64) + 1)])
+        total = int(off[-1])
+        assert seg.shape == (n_seg + 1, 2) and tuple(seg[n_seg]) == (total, total + 1)
+        if n == 0:
+            assert n_seg == 0
+            continue
+        body = seg[:n_seg]
+        length = body[:, 1] - body[:, 0]
+        assert np.all(length[:-1] >= length[1:])                                  # longest first ...
+        same = length[:-1] == length[1:]
+        assert np.all(body[:-1, 0][same] < body[1:, 0][same])                     # ... stable: equal lengths in stream order
+        by_pos = body[np.argsort(body[:, 0])]
+        assert by_pos[0, 0] == 0 and by_pos[-1, 1] == total and np.array_equal(by_pos[1:, 0], by_pos[:-1, 1])   # a partition
+        assert np.all(np.isin(by_pos[:, 0], off))                                  # cut at template boundaries only
+        assert n_seg == 1 or np.all(length >= 128)
+        assert n_seg <= n
+        # closed as soon as it holds 128 records: without its last template a segment is shorter (the last one excepted)
+        ends = np.searchsorted(off, by_pos[:-1, 1])
+        assert np.all(off[ends - 1] - by_pos[:-1, 0] < 128)
+    assert capi.load().hhv_segment_plan(2, np.array([5, 0], dtype=np.int32).ctypes.data_as(capi.c_int_p), seg.ctypes.data_as(capi.C.POINTER(capi.C.c_int64)),
+                                        capi.C.byref(capi.C.c_int32(0))) != 0
