@@ -511,7 +511,7 @@ def template_upload(capi, ctx, rec, rec_off, Ls, qf, qtr, Lt):
         ctx.sync()
         sec = time.perf_counter() - t0
         out["hhv_upload_templates"] = {"templates": n, "seconds": sec, "stream_bytes": stream_bytes,
-                                       "GB_per_s": stream_bytes / sec / 1e9, "what": "host pack (1 thread) + H2D in 64 MiB slabs"}
+                                       "GB_per_s": stream_bytes / sec / 1e9, "what": "host pack (up to 8 threads) into two pinned 64 MiB slabs, H2D of one slab under the packing of the next"}
         want = ctx.align(tsu)
         tsu.free()
         with tempfile.TemporaryDirectory() as d:
