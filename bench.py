@@ -527,7 +527,7 @@ def template_upload(capi, ctx, rec, rec_off, Ls, qf, qtr, Lt):
             got = ctx.align(tsd)
             tsd.free()
         out["hhv_db_open"] = {"templates": n, "seconds": sec, "GB_per_s": stream_bytes / sec / 1e9, "hhv_db_write_seconds": wsec,
-                              "what": "packed file (page cache warm) -> validated -> H2D; no parsing, no packing",
+                              "what": "packed file (page cache warm) -> read and validated by up to 8 threads into pinned slabs -> H2D; no parsing, no packing",
                               "results_equal_uploaded_set": bool(np.array_equal(got.view(np.uint8), want.view(np.uint8)))}
     except Exception as e:  # the headline line must not depend on the side measurements
         out["error"] = repr(e)

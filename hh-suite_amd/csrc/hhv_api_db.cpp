@@ -2,6 +2,10 @@
 #include "hhv_api_common.h"
 
 #include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <thread>
 
 using namespace hhv;
 using hhv::api::dfree;
@@ -103,40 +107,103 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
   if (rc == HHV_OK) {
     ts->owns_records = true;
     (void)hipMemset(ts->d_records + (size_t)ts->n_records * REC_DW, 0, (size_t)STREAM_PAD_RECS * REC_DW * sizeof(float));
-    const size_t slab = (64u << 20) / sizeof(float) / REC_DW * REC_DW;  // whole records per slab
-    std::vector<float> buf(slab);
-    size_t left = (size_t)ts->n_records * REC_DW, off = 0;
     // The kernel takes the template index and the template boundaries from the records themselves (it writes
     // results[index] and resets at meta < 0), so a stale or damaged file must not reach the device: every record's meta
-    // word is checked against the length table while the slabs go by.
-    int64_t rec = 0;   // stream record index
-    int32_t tmpl = 0;  // template the record belongs to
-    int64_t next_hdr = 0;
-    while (left && rc == HHV_OK) {
-      const size_t m = std::min(left, slab);
-      if (fread(buf.data(), sizeof(float), m, f) != m) rc = fail(HHV_E_ARG, "hhv_db_open: truncated record stream");
-      for (size_t r0 = 0; r0 < m && rc == HHV_OK; r0 += REC_DW, ++rec) {
-        int32_t meta, w0, w1;
-        memcpy(&meta, &buf[r0 + REC_META], 4);
-        memcpy(&w0, &buf[r0], 4);
-        memcpy(&w1, &buf[r0 + 1], 4);
-        if (rec == next_hdr) {  // header of template `tmpl` (or the terminal header)
-          const bool last = tmpl == h.n;
-          if (meta >= 0 || (last ? w0 != -1 : (w0 != tmpl || w1 != L[tmpl])))
-            rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not the header of template %d", path, (long long)rec, tmpl);
-          if (!last) next_hdr = rec + L[tmpl] + 1;
-          ++tmpl;
-        } else {
-          const int32_t j = (int32_t)(rec - (next_hdr - L[tmpl - 1] - 1));
-          if (meta < 0 || (meta & META_JMASK) != j || (((meta & META_LAST) != 0) != (j == L[tmpl - 1])))
-            rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not column %d of template %d", path, (long long)rec, j, tmpl - 1);
+    // word is checked against the length table while the slabs go by.  Slabs of 64 MiB, two pinned buffers used in turn: a
+    // few host threads read (pread, page cache -> pinned memory) and check their share of a slab while the copy of the slab
+    // before it is in flight.
+    const int64_t slab_recs = (int64_t)((64u << 20) / (REC_DW * sizeof(float)));
+    const int64_t data0 = (int64_t)sizeof(DbHeader) + (int64_t)h.n * 4;
+    const int fd = fileno(f);
+    float* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2 && rc == HHV_OK; ++b) {
+      if (hipHostMalloc(&stage[b], (size_t)slab_recs * REC_DW * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess)
+        rc = fail(HHV_E_MEMORY, "hhv_db_open: pinned staging failed");
+    }
+    int n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("HHV_PACK_THREADS")) n_threads = std::max(1, std::min(64, atoi(e)));
+    struct Bad {
+      int64_t rec = -1;  // first bad record of a thread's share (-1: none); kind 0 = short read, 1 = header, 2 = column
+      int kind = 0, tmpl = 0, j = 0;
+    };
+    const std::vector<int64_t>& ro = ts->rec_off;  // [n + 1]: header record of template k; ro[n] = the terminal header
+    int slab = 0;
+    for (int64_t r0 = 0; r0 < ts->n_records && rc == HHV_OK; r0 += slab_recs, ++slab) {
+      const int64_t r1 = std::min<int64_t>(ts->n_records, r0 + slab_recs);
+      const int b = slab & 1;
+      if (slab >= 2 && hipEventSynchronize(done[b]) != hipSuccess) {
+        rc = fail(HHV_E_DEVICE, "hhv_db_open: H2D copy failed");
+        break;
+      }
+      float* const buf = stage[b];
+      const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (r1 - r0) / 4096));
+      std::vector<Bad> bad((size_t)nt);
+      auto share = [&](int w) {
+        const int64_t a0 = r0 + (r1 - r0) * w / nt, a1 = r0 + (r1 - r0) * (w + 1) / nt;
+        Bad& bd = bad[(size_t)w];
+        size_t want = (size_t)(a1 - a0) * REC_DW * sizeof(float), got = 0;
+        char* dst = reinterpret_cast<char*>(buf + (size_t)(a0 - r0) * REC_DW);
+        while (got < want) {
+          const ssize_t m = pread(fd, dst + got, want - got, (off_t)(data0 + a0 * REC_DW * (int64_t)sizeof(float) + (int64_t)got));
+          if (m <= 0) {
+            bd.rec = a0;
+            bd.kind = 0;
+            return;
+          }
+          got += (size_t)m;
         }
+        // template of record a0: the last header at or before it (the terminal header counts as template n)
+        int32_t tmpl = (int32_t)(std::upper_bound(ro.begin(), ro.end(), a0) - ro.begin()) - 1;
+        for (int64_t rec = a0; rec < a1; ++rec) {
+          const float* r = buf + (size_t)(rec - r0) * REC_DW;
+          int32_t meta, w0, w1;
+          memcpy(&meta, r + REC_META, 4);
+          memcpy(&w0, r, 4);
+          memcpy(&w1, r + 1, 4);
+          if (tmpl < h.n && rec == ro[(size_t)tmpl + 1]) ++tmpl;
+          if (rec == ro[(size_t)tmpl]) {  // header of template `tmpl` (or the terminal header)
+            const bool last = tmpl == h.n;
+            if (meta >= 0 || (last ? w0 != -1 : (w0 != tmpl || w1 != L[(size_t)tmpl]))) {
+              bd.rec = rec, bd.kind = 1, bd.tmpl = tmpl;
+              return;
+            }
+          } else {
+            const int32_t j = (int32_t)(rec - ro[(size_t)tmpl]);
+            if (meta < 0 || (meta & META_JMASK) != j || (((meta & META_LAST) != 0) != (j == L[(size_t)tmpl]))) {
+              bd.rec = rec, bd.kind = 2, bd.tmpl = tmpl, bd.j = j;
+              return;
+            }
+          }
+        }
+      };
+      if (nt == 1) {
+        share(0);
+      } else {
+        std::vector<std::thread> pool;
+        for (int w = 0; w < nt; ++w) pool.emplace_back(share, w);
+        for (auto& th : pool) th.join();
+      }
+      for (const Bad& bd : bad) {  // shares are in record order: the first one that failed holds the first bad record
+        if (bd.rec < 0) continue;
+        if (bd.kind == 0) rc = fail(HHV_E_ARG, "hhv_db_open: truncated record stream");
+        else if (bd.kind == 1)
+          rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not the header of template %d", path, (long long)bd.rec, bd.tmpl);
+        else
+          rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not column %d of template %d", path, (long long)bd.rec, bd.j, bd.tmpl);
+        break;
       }
       if (rc != HHV_OK) break;
-      if (hipMemcpy(ts->d_records + off, buf.data(), m * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      if (hipMemcpyAsync(ts->d_records + (size_t)r0 * REC_DW, buf, (size_t)(r1 - r0) * REC_DW * sizeof(float), hipMemcpyHostToDevice,
+                         c->stream) != hipSuccess ||
+          hipEventRecord(done[b], c->stream) != hipSuccess)
         rc = fail(HHV_E_DEVICE, "hhv_db_open: H2D copy failed");
-      off += m;
-      left -= m;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == HHV_OK) rc = fail(HHV_E_DEVICE, "hhv_db_open: H2D copy failed");
+    for (int b = 0; b < 2; ++b) {
+      if (done[b]) (void)hipEventDestroy(done[b]);
+      if (stage[b]) (void)hipHostFree(stage[b]);
     }
   }
   fclose(f);
