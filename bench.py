@@ -36,8 +36,10 @@ import os
 # the CPUs this process may run on, read before an OpenMP runtime exists: with OMP_PROC_BIND set, libgomp binds the initial
 # thread to its first place when it is loaded (torch brings one), and sched_getaffinity would report that one core
 try:
-    AFFINITY_CPUS = len(os.sched_getaffinity(0))
+    AFFINITY_SET = os.sched_getaffinity(0)
+    AFFINITY_CPUS = len(AFFINITY_SET)
 except AttributeError:
+    AFFINITY_SET = None
     AFFINITY_CPUS = os.cpu_count() or 1
 # the cpu_baseline leg times OpenMP code (oracle/_ref): pin its threads to cores, one per core, before any OpenMP runtime
 # is loaded - unpinned threads of a dynamic schedule migrate and the number is not reproducible
@@ -499,6 +501,15 @@ def template_upload(capi, ctx, rec, rec_off, Ls, qf, qtr, Lt):
     written once with hhv_db_write and loaded with hhv_db_open (validated read + H2D, no packing)."""
     import tempfile
     out = {}
+    # the library's packing threads inherit the CPU mask of the thread that calls it - here the initial thread, which libgomp
+    # has bound to one core for the cpu_baseline leg (OMP_PROC_BIND above): give it the process's own mask back for this entry
+    bound = None
+    if AFFINITY_SET is not None:
+        try:
+            bound = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, AFFINITY_SET)
+        except OSError:
+            bound = None
     try:
         n = int(Ls.shape[0])
         from pyhhv import synth_stream
@@ -531,6 +542,11 @@ def template_upload(capi, ctx, rec, rec_off, Ls, qf, qtr, Lt):
                               "results_equal_uploaded_set": bool(np.array_equal(got.view(np.uint8), want.view(np.uint8)))}
     except Exception as e:  # the headline line must not depend on the side measurements
         out["error"] = repr(e)
+    if bound is not None:
+        try:
+            os.sched_setaffinity(0, bound)
+        except OSError:
+            pass
     return out
 
 
