@@ -492,8 +492,13 @@ int hhv_upload_templates_ss(hhv_ctx* c, int32_t n, const int32_t* L, const float
       pack_range(k0, k);
     } else {
       std::vector<std::thread> pool;
-      for (int w = 0; w < nt; ++w)
-        pool.emplace_back(pack_range, k0 + (int)((int64_t)(k - k0) * w / nt), k0 + (int)((int64_t)(k - k0) * (w + 1) / nt));
+      int started = 0;
+      try {
+        for (; started < nt; ++started)
+          pool.emplace_back(pack_range, k0 + (int)((int64_t)(k - k0) * started / nt), k0 + (int)((int64_t)(k - k0) * (started + 1) / nt));
+      } catch (...) {  // no more threads to be had: the calling thread packs the shares that found none
+      }
+      for (int w = started; w < nt; ++w) pack_range(k0 + (int)((int64_t)(k - k0) * w / nt), k0 + (int)((int64_t)(k - k0) * (w + 1) / nt));
       for (auto& th : pool) th.join();
     }
     if (bad_ss.load() >= 0 || bad_neg.load() >= 0) {

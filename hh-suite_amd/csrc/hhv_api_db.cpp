@@ -182,7 +182,12 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
         share(0);
       } else {
         std::vector<std::thread> pool;
-        for (int w = 0; w < nt; ++w) pool.emplace_back(share, w);
+        int started = 0;
+        try {
+          for (; started < nt; ++started) pool.emplace_back(share, started);
+        } catch (...) {  // no more threads to be had: the calling thread does the shares that found none
+        }
+        for (int w = started; w < nt; ++w) share(w);
         for (auto& th : pool) th.join();
       }
       for (const Bad& bd : bad) {  // shares are in record order: the first one that failed holds the first bad record
