@@ -80,8 +80,8 @@ def main():
     qf, qtr = synth.make_query(0x51000000, Lq)
     res = []
     for name in which:
-        if name == "fixed":
-            n, local = 100000, 0
+        if name.startswith("fixed"):
+            n, local = (int(name[5:]) if len(name) > 5 else 100000), 0      # fixed / fixed10000 ...
             Ls = np.full(n, 300, dtype=np.int32)
             ids = np.arange(n)
         else:
