@@ -401,8 +401,8 @@ def main():
             ctx.align_async(ts10)
         ctx.sync()
         t1 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):       # five searches back to back, nothing waited for in between
+        reps = 20                   # (a launch that follows an idle device runs ~0.2 ms longer, tools/SESSIONS.md call 43:
+        for _ in range(reps):       #  twenty searches back to back, nothing waited for in between, like the headline loop)
             ctx.set_query(qf, qtr)
             ctx.align_async(ts10)
         ctx.sync()
@@ -550,7 +550,7 @@ def template_upload(capi, ctx, rec, rec_off, Ls, qf, qtr, Lt):
     return out
 
 
-def time_bt_steps(ctx, ts, K, reps=5, warm=2):
+def time_bt_steps(ctx, ts, K, reps=8, warm=2):
     """Whole step with backtrace: DP kernel with compare bits, trace + rescoring kernels, device top-K by Hit.score."""
     ms = []
     for _ in range(warm):
@@ -599,7 +599,7 @@ def configs2(args, torch, ctx, ts, rec, rec_off, Ls, qf, qtr, Lq, Lt, K):
     out = {}
     n10 = 10000
     ts10 = ctx.adopt_device_stream(np.full(n10, Lt, dtype=np.int32), rec.data_ptr())
-    sec, kms = time_bt_steps(ctx, ts10, K)
+    sec, kms = time_bt_steps(ctx, ts10, K, reps=20)
     out["10k"] = {"cells_per_s": n10 * Lq * Lt / sec, "ms_per_step": sec * 1e3, "dp_kernel_ms": kms}
     try:
         cores = usable_cores()[0]
