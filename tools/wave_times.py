@@ -2,10 +2,13 @@
 """tools/wave_times.py -- who finishes when: per-workgroup entry / exit times of hhv_stream_kernel (measurement build
 `-DHHV_EXP_WAVETIME`, HHV_LIB must point at it; hh-suite_amd/csrc/hhv_stream_kernel.h hhv_dbg_wave).
 
-All workgroups of a launch are resident at once and every one walks its own contiguous range of the template stream, so
-the launch lasts as long as its slowest workgroup.  This prints, per workload: the spread of the range sizes, of the
-durations and of the time per record, by XCD / by position on the chip, and how the exit times relate to the range sizes.
-    HHV_LIB=.../libhhviterbi_wt.so python tools/wave_times.py [fixed|zipf|zipf_local ...]
+All workgroups of a launch are resident at once, so the launch lasts as long as its slowest workgroup.  With one fixed range
+of the template stream per workgroup (rounds 1-3, today's -DHHV_NO_QUEUE build) this showed exits 11.3 .. 14.2 ms in the
+headline launch - what led to the work queue (NOTES_r3.md 7); with the queue it shows how close together the workgroups end.
+Per workload: the spread of the record counts, of the durations and of the time per record, by XCD, per SIMD pair, and how the
+exit times relate to the record counts.
+    make lib_variant NAME=wt FLAGS=-DHHV_EXP_WAVETIME       (add -DHHV_NO_QUEUE for the fixed ranges)
+    HHV_LIB=.../libhhviterbi_wt.so python tools/wave_times.py [fixed|fixed10000|zipf_local|zipf_sorted_global ...]
 """
 import ctypes as C
 import json
