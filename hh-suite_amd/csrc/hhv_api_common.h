@@ -163,6 +163,10 @@ struct hhv_rawset {
   int32_t n_ids[3] = {0, 0, 0};
   int32_t max_L[3] = {0, 0, 0};
   bool prepared = false;
+  // pcm 2 with pcc != 1 (src/hhhmm.cpp:1903-1909): tau per raw column, evaluated on the host with libm's powf - the device has
+  // no bit-exact powf - for the (pca, pcb, pcc) it was last asked for
+  float* d_tau = nullptr;
+  float tau_pca = 0, tau_pcb = 0, tau_pcc = 0;
 };
 
 

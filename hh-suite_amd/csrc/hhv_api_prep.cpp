@@ -228,13 +228,12 @@ void hhv_rawset_free(hhv_rawset* rs) {
   dfree(rs->d_qpav);
   for (int cls = 0; cls < 3; ++cls) dfree(rs->d_ids[cls]);
   dfree(rs->d_raw_off);
+  dfree(rs->d_tau);
   delete rs;
 }
 
 static int check_prep_params(const hhv_prep_params* par) {
   if (par->pcm < 0 || par->pcm > 2) return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm = %d (only 0, 1, 2)", par->pcm);
-  if (par->pcm == 2 && par->pcc != 1.0f)
-    return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcc = %g; only the default pcc = 1 avoids libm pow() and is built", par->pcc);
   if (par->columnscore < 0 || par->columnscore > 3)
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: columnscore = %d (only 0..3)", par->columnscore);
   // p = (1 - tau) f + tau g with tau <= pca (src/hhhmm.cpp:1874-1964): an admixture weight above 1 makes profile values
@@ -254,6 +253,43 @@ static int tset_alloc_stream(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_t*
   std::vector<float> tail((size_t)(1 + STREAM_PAD_RECS) * REC_DW, 0.0f);
   write_header(tail.data(), -1, 0);
   HIP_TRY(hipMemcpy(ts->d_records + (size_t)ts->rec_off[n] * REC_DW, tail.data(), tail.size() * sizeof(float), hipMemcpyHostToDevice));
+  return HHV_OK;
+}
+
+// pcm 2 with pcc != 1: tau[i] = fmin(1, pca / (1 + pow(Neff_M[i] / pcb, pcc))) (src/hhhmm.cpp:1903-1909; float arguments: the
+// float overload of pow, i.e. powf).  The device has no bit-exact powf, so the host evaluates it once per raw set and
+// (pca, pcb, pcc): Neff_M of every raw column comes back in one strided copy, a few threads call libm, the table goes up.
+// This is parameter preparation like the fast_log2 tables, not a fallback of the kernels: the columns are prepared on the device.
+static int ensure_tau(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par) {
+  if (par->pcm != 2 || par->pcc == 1.0f) return HHV_OK;
+  if (rs->d_tau && rs->tau_pca == par->pca && rs->tau_pcb == par->pcb && rs->tau_pcc == par->pcc) return HHV_OK;
+  const size_t n = (size_t)rs->n_cols;
+  std::vector<float> v(n);
+  if (!rs->d_tau) HIP_TRY(hipMalloc(&rs->d_tau, n * sizeof(float)));
+  rs->tau_pcc = 1.0f;  // (the table is being rewritten: not valid for any pcc != 1 until it is complete)
+  if (const int lr = launch_gather_neff(rs->d_raw, rs->n_cols, rs->d_tau, c->stream); lr != 0)
+    return fail(HHV_E_DEVICE, "hhv_prepare_templates: kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
+  HIP_TRY(hipMemcpyAsync(v.data(), rs->d_tau, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const float pca = par->pca, pcb = par->pcb, pcc = par->pcc;
+  auto eval = [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; ++i) v[i] = (float)fmin(1.0, (double)pca / (1. + (double)powf(v[i] / pcb, pcc)));
+  };
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>(8, n / 65536));
+  if (nt == 1) {
+    eval(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    int started = 0;
+    try {
+      for (; started < nt; ++started) pool.emplace_back(eval, n * started / nt, n * (started + 1) / nt);
+    } catch (...) {
+    }
+    for (int w = started; w < nt; ++w) eval(n * w / nt, n * (w + 1) / nt);
+    for (auto& th : pool) th.join();
+  }
+  HIP_TRY(hipMemcpy(rs->d_tau, v.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  rs->tau_pca = pca, rs->tau_pcb = pcb, rs->tau_pcc = pcc;
   return HHV_OK;
 }
 
@@ -281,6 +317,7 @@ static void fill_prep_args(PrepArgs* a, hhv_ctx* c, hhv_rawset* rs, hhv_tset* ts
   a->pcm = par->pcm;
   a->pca = par->pca;
   a->pcb = par->pcb;
+  a->tau = (par->pcm == 2 && par->pcc != 1.0f) ? rs->d_tau : nullptr;
   a->columnscore = par->columnscore;
   a->ids = nullptr;
   a->lds_cols = 0;
@@ -294,6 +331,8 @@ int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par
   int rc = check_prep_params(par);
   if (rc != HHV_OK) return rc;
   HIP_TRY(hipSetDevice(c->par.device));
+  rc = ensure_tau(c, rs, par);
+  if (rc != HHV_OK) return rc;
   hhv_tset* ts = *out;
   if (!ts) {
     ts = new (std::nothrow) hhv_tset();
@@ -343,6 +382,8 @@ int hhv_prepare_subset(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, c
     max_L[cl] = std::max(max_L[cl], L[k]);
   }
   HIP_TRY(hipSetDevice(c->par.device));
+  rc = ensure_tau(c, rs, par);
+  if (rc != HHV_OK) return rc;
   if (!cls[2].empty() && !rs->d_p_tmp) {  // the raw set had no template this long when it was uploaded?  cannot happen:
     return fail(HHV_E_STATE, "hhv_prepare_subset: intermediate buffers missing");  // the classes depend on L only
   }

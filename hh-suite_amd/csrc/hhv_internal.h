@@ -168,6 +168,7 @@ struct PrepArgs {
   float gapd, gape, gapf, gapg, gaph, gapi, gapb;
   int32_t pcm;
   float pca, pcb;
+  const float* tau;          // pcm 2 with pcc != 1: tau of every raw column (the host evaluated libm's powf, hhv_api_prep.cpp); else null
   int32_t columnscore;
   const int32_t* ids;        // output slots of this launch (one workgroup each)
   const int32_t* src;        // [n slots] raw template of slot k, or null = identity (the whole raw set)
@@ -177,6 +178,7 @@ struct PrepArgs {
 
 size_t prepare_fused_lds(int max_L);
 int launch_prepare(const PrepArgs& a, const int32_t* const ids[3], const int32_t n_ids[3], const int32_t max_L[3], void* stream);
+int launch_gather_neff(const float* raw, int64_t n_cols, float* out, void* stream);  // out[i] = Neff_M of raw column i
 
 struct PrefilterArgs {
   const unsigned char* profile;  // plain [220][Lq]

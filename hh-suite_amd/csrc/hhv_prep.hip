@@ -3,7 +3,7 @@
 // the host.  Restates, operation for operation (fp32/fp64 mix included), the reference's
 //   HMM::AddTransitionPseudocounts    src/hhhmm.cpp:1722-1806   (fpow2 src/util-inl.h:190-215, fast_log2 :108-130)
 //   HMM::PreparePseudocounts          src/hhhmm.cpp:1811-1815   (ScalarProd20, plain branch, src/hhhit-inl.h:125-131)
-//   HMM::AddAminoAcidPseudocounts     src/hhhmm.cpp:1874-1964   (pcm 0, 1, 2 with pcc == 1)
+//   HMM::AddAminoAcidPseudocounts     src/hhhmm.cpp:1874-1964   (pcm 0, 1, 2; with pcc != 1 tau comes from the host)
 //   HMM::CalculateAminoAcidBackground src/hhhmm.cpp:1854-1868   (NormalizeTo1 src/util-inl.h:277-291)
 //   HMM::IncludeNullModelInHMM        src/hhhmm.cpp:2059-2144   (columnscore 0..3)
 // in the order of PrepareTemplateHMM (src/hhfunc.cpp:165-202, HHM format).
@@ -99,7 +99,8 @@ __device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __re
     for (int b = 0; b < 20; ++b) f[b] = raw[RAW_F + b];
     float tau = 0.0f;
     if (a.pcm == 1) tau = a.pca;
-    if (a.pcm == 2) tau = (float)fmin(1.0, (double)a.pca / (1. + (double)(raw[RAW_NEFF + 0] / a.pcb)));
+    if (a.pcm == 2)  // :1898-1909; pcc != 1 needs libm's powf: the host has evaluated tau for every raw column
+      tau = a.tau ? a.tau[(raw - a.raw) / RAW_DW] : (float)fmin(1.0, (double)a.pca / (1. + (double)(raw[RAW_NEFF + 0] / a.pcb)));
     for (int aa = 0; aa < 20; ++aa) {
       if (a.pcm == 0) {
         P[aa] = f[aa];
@@ -254,6 +255,18 @@ __global__ void __launch_bounds__(256) hhv_prep_fused_kernel(PrepArgs a) {
 }
 
 size_t prepare_fused_lds(int max_L) { return (size_t)(400 + 20 + 24 + (size_t)(max_L + 1) * (8 + PREP_PS)) * sizeof(float); }
+
+// Neff_M of every raw column, compacted (for the host's tau table when pcc != 1, hhv_api_prep.cpp ensure_tau)
+__global__ void __launch_bounds__(256) hhv_gather_neff_kernel(const float* __restrict__ raw, int64_t n_cols, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cols; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = raw[i * RAW_DW + RAW_NEFF];
+}
+int launch_gather_neff(const float* raw, int64_t n_cols, float* out, void* stream) {
+  const int blocks = (int)std::min<int64_t>(4096, (n_cols + 255) / 256);
+  hipLaunchKernelGGL(hhv_gather_neff_kernel, dim3(std::max(1, blocks)), dim3(256), 0, (hipStream_t)stream, raw, n_cols, out);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
 
 // ids / n_ids of the three length classes (fused with a small LDS footprint, fused with a large one, split)
 int launch_prepare(const PrepArgs& a0, const int32_t* const ids[3], const int32_t n_ids[3], const int32_t max_L[3], void* stream_) {

@@ -188,10 +188,10 @@ inline int ensure_context(TemplateCache& tc) {
 }
 
 // Can PrepareTemplateHMM run on the device for this search?  (hhv_prepare_subset: HHM format, substitution-matrix
-// pseudocounts pcm 0..2 with pcc = 1, null model columnscore 0..3; src/hhfunc.cpp:165-202)
+// pseudocounts pcm 0..2, null model columnscore 0..3; src/hhfunc.cpp:165-202)
 inline bool device_prepare_covers(const Parameters& par) {
   return par.pc_hhm_nocontext_mode >= 0 && par.pc_hhm_nocontext_mode <= 2 &&
-         !(par.pc_hhm_nocontext_mode == 2 && par.pc_hhm_nocontext_c != 1.0f) && par.columnscore >= 0 && par.columnscore <= 3 &&
+         par.columnscore >= 0 && par.columnscore <= 3 &&
          (par.pc_hhm_nocontext_mode == 0 || (par.pc_hhm_nocontext_a >= 0.0f && par.pc_hhm_nocontext_a <= 1.0f));
 }
 

@@ -27,7 +27,7 @@
 // result depends on the query's composition.  From the second time a template is searched - the later iterations of
 // hhblits, the next query of hhblits_omp / hhblits_mpi - nothing of it is parsed, prepared or copied by the host;
 // its Hit gets the template information (names, displayed sequences) from a prototype kept with the cache entry.
-// Templates the device preparation does not cover (HMMER formats, par.pc_hhm_nocontext_mode > 2 or pcc != 1,
+// Templates the device preparation does not cover (HMMER formats, par.pc_hhm_nocontext_mode > 2,
 // par.columnscore > 3, a NULL line different from the caller's background) are prepared by the reference's host code
 // as before and uploaded prepared; they are not cached.  Environment: HHV_TEMPLATE_CACHE=0 disables the cache,
 // HHV_TEMPLATE_CACHE_GB (default 64) bounds it (it is emptied when full), HHV_DEVICE picks the GPU (default 0).

@@ -197,7 +197,7 @@ typedef struct hhv_rawset hhv_rawset;
 typedef struct {
   float gapd, gape, gapf, gapg, gaph, gapi, gapb; /* par.gap*        defaults 0.15 1 .6 .6 .6 .6 1 (src/hhdecl.cpp:74-80) */
   int32_t pcm;                                    /* par.pc_hhm_nocontext_mode  (0, 1, 2)            (src/hhdecl.cpp:64) */
-  float pca, pcb, pcc;                            /* par.pc_hhm_nocontext_a/b/c 1.0 1.5 1.0; pcc must be 1 on the device */
+  float pca, pcb, pcc;                            /* par.pc_hhm_nocontext_a/b/c 1.0 1.5 1.0 (pcc != 1: the host evaluates powf per column once) */
   int32_t columnscore;                            /* par.columnscore 0..3, default 1                 (src/hhdecl.cpp:98) */
   float pb[20];                                   /* background frequencies  (SetSubstitutionMatrix, src/hhmatrices.cpp:53-58) */
   float R[400];                                   /* R[a][b] = P(a|b)        (src/hhmatrices.cpp:66-69) */

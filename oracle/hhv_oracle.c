@@ -519,7 +519,9 @@ int hho_prepare(int role, int L, const float *f, const float *tr, const float *n
     if (pcm == 1) tau = pca;
     if (pcm == 2) {
       if (pcc == 1.0f) tau = (float)fmin(1.0, (double)pca / (1. + (double)(neff[i * 3] / pcb)));
-      else tau = (float)fmin(1.0, (double)pca / (1. + pow((double)(neff[i * 3] / pcb), (double)pcc)));
+      /* :1905: pow(Neff_M[i] / pcb, pcc) with float arguments in C++ is the float overload (= powf); its result joins a
+         double expression */
+      else tau = (float)fmin(1.0, (double)pca / (1. + (double)powf(neff[i * 3] / pcb, pcc)));
     }
     for (int a = 0; a < 20; ++a) {
       if (pcm == 0) {

@@ -47,12 +47,14 @@ def test_fpow2_bitexact(oracle, ref):
         assert np.float32(a).tobytes() == np.float32(b).tobytes(), x
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(20))
 def test_prepare_restatement_bitexact_synthetic(oracle, ref, seed):
     pb, R = gonnet()
     L = 5 + seed * 17
     f, tr, neff, nh = synth.make_raw_hmm(100 + seed, L)
-    pc = np.array([[2, 1.0, 1.5, 1.0], [0, 1, 1.5, 1], [1, 0.4, 1.5, 1.0], [2, 0.9, 2.0, 1.0]][seed % 4], np.float32)
+    # (seeds 12..19: pcc != 1 - src/hhhmm.cpp:1903-1909, where pow(float, float) is the float overload: powf)
+    pc = np.array(([[2, 1.0, 1.5, 1.0], [0, 1, 1.5, 1], [1, 0.4, 1.5, 1.0], [2, 0.9, 2.0, 1.0]] if seed < 12 else
+                   [[2, 1.0, 1.5, 0.8], [2, 0.9, 2.0, 1.3], [2, 1.0, 1.5, 2.0], [2, 0.7, 1.0, 0.5]])[seed % 4], np.float32)
     gap = po.DEFAULT_GAP.copy()
     if seed % 5 == 0:
         gap[0], gap[1] = 0.3, 0.8
@@ -81,15 +83,16 @@ def test_prepare_restatement_bitexact_real_hhm(oracle, ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("columnscore,pcm", [(1, 2), (0, 2), (2, 1), (3, 0)])
-def test_gpu_prepare_matches_oracle(oracle, columnscore, pcm):
+@pytest.mark.parametrize("columnscore,pcm,pcc", [(1, 2, 1.0), (0, 2, 1.0), (2, 1, 1.0), (3, 0, 1.0), (1, 2, 0.8), (0, 2, 1.7)])
+def test_gpu_prepare_matches_oracle(oracle, columnscore, pcm, pcc):
+    """(pcc != 1: tau of every raw column comes from the host's powf, hhv_api_prep.cpp ensure_tau - same bits as the reference)"""
     from pyhhv import capi
     pb, R = gonnet()
     rng = np.random.default_rng(columnscore * 10 + pcm)
     fq, trq, nq, nhq = raw_query_hhm()
     q_p, q_tr, q_pav = po.oracle_prepare(oracle, 0, fq, trq, nq, nhq, pb, R)
     raws = [synth.make_raw_hmm(300 + k, int(rng.integers(1, 200))) for k in range(20)] + [(fq, trq, nq, nhq)]
-    pc = (pcm, 0.7 if pcm == 1 else 1.0, 1.5, 1.0)
+    pc = (pcm, 0.7 if pcm == 1 else 1.0, 1.5, pcc)
     c = capi.Context(local=1)
     c.set_query(q_p[:-1], q_tr)
     raw, Ls = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
