@@ -379,7 +379,8 @@ int hhv::api::tset_init_common(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_
   ts->rec_off.resize((size_t)n + 1);
   int64_t off = 0;
   for (int k = 0; k < n; ++k) {
-    if (L[k] < 1 || L[k] > 0xFFFF) return fail(HHV_E_ARG, "template %d: L = %d out of range [1, 65535]", k, L[k]);
+    if (L[k] < 1) return fail(HHV_E_ARG, "template %d: L = %d out of range [1, 65535]", k, L[k]);
+    if (L[k] > 0xFFFF) return fail(HHV_E_LIMIT, "template %d: L = %d exceeds 65535", k, L[k]);
     ts->rec_off[k] = off;
     off += (int64_t)L[k] + 1;
   }
@@ -1027,6 +1028,32 @@ int hhv_hit_path(hhv_ctx* c, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_st
   if (j_steps) j_steps[0] = 0;
   if (states) states[0] = 0;
   if (S) S[0] = 0.0f;
+  return HHV_OK;
+}
+
+// SURVEY.md 8(b)'s hhv_backtrace: Viterbi::Backtrace for ONE template as the reference's caller sees it (BacktraceResult:
+// i_steps / j_steps / states, count, matched_cols).  The walk itself runs for all templates of the set at once on the device
+// (run_trace, started here if hhv_hits has not been called since the last backtrace launch); this entry hands out one result.
+int hhv_backtrace(hhv_ctx* c, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps, int8_t* states,
+                  int32_t* nsteps, int32_t* matched_cols) {
+  if (!c || !ts || !nsteps) return fail(HHV_E_ARG, "hhv_backtrace: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_backtrace: template set belongs to another context");
+  if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_backtrace: template %d of %d", k, ts->n);
+  if (!ts->hits_valid) {
+    const int rc = hhv_hits(c, ts, nullptr);
+    if (rc != HHV_OK) return rc;
+  }
+  const int rc = hhv_hit_path(c, ts, k, cap, i_steps, j_steps, states, nullptr, nsteps);
+  if (rc != HHV_OK) return rc;
+  if (matched_cols) {
+    if (ts->host_paths_valid) {
+      *matched_cols = ts->h_hits[k].matched_cols;
+    } else {
+      DevHit h;
+      HIP_TRY(hipMemcpy(&h, ts->d_hits + k, sizeof(h), hipMemcpyDeviceToHost));
+      *matched_cols = h.matched_cols;
+    }
+  }
   return HHV_OK;
 }
 

@@ -1,8 +1,12 @@
 // hhv_topk.hip -- device-side selection of the K best hits (the per-GPU half of the sharded top-K
 // merge).  Key = Hit.score descending, ties broken by the smaller template index, the
 // order ViterbiRunner's caller establishes when it sorts the hit list (src/hhhit.h:116-126 compares
-// score_aass = -score).  A full 64-bit radix sort of (orderable score, ~index) via hipCUB is used:
-// n <= a few 10^5 per GPU, this stage is microseconds next to the DP.
+// score_aass = -score).  The K best of n are SELECTED, not sorted out of a full sort: every workgroup
+// radix-selects the K largest 64-bit keys (orderable score, ~index) of its chunk of 16 384 keys held in
+// registers, the survivors (chunks x K) go through the same step again until at most 4096 are left, and
+// one workgroup sorts those in LDS and gathers the K records - two launches for 100 k templates and
+// K = 500, work proportional to n once.  (hipCUB's full radix sort remains for K > 1024 and for the
+// prefilter's selection, which needs the whole order.)
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -14,12 +18,145 @@
 
 namespace hhv {
 
+__device__ __forceinline__ uint64_t topk_key(float score, uint32_t idx) {
+  uint32_t u = __builtin_bit_cast(uint32_t, score);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
+  return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - idx);
+}
+
+// ---- radix select -------------------------------------------------------------------------------------------------------
+// One workgroup = one chunk of <= SEL_CHUNK keys, 16 per thread in registers; key 0 = no key (padding of a lower level).
+// Eight passes over the eight bytes of the key from the top: a 256-bin histogram in LDS of the keys that still share the
+// prefix found so far, a suffix scan, the byte of the K-th largest key; after the last pass the prefix IS that key (keys
+// are unique: the index is part of them) and every key >= it is written out - exactly K of them.
+constexpr int SEL_THREADS = 1024, SEL_PER_THREAD = 16, SEL_CHUNK = SEL_THREADS * SEL_PER_THREAD;
+constexpr int SEL_KMAX = 1024;   // a level keeps K of 16 384: the selection shrinks its input 16 x or more
+constexpr int SORT_MAX = 4096;   // keys the final workgroup sorts in LDS
+
+template <bool FROM_HITS>
+__global__ void __launch_bounds__(SEL_THREADS) topk_select_kernel(const DevHit* __restrict__ hits, const uint64_t* __restrict__ in_keys,
+                                                                  int n, int k, uint64_t* __restrict__ out_keys) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_digit, sh_krem, sh_valid, sh_out;
+  const int base = blockIdx.x * SEL_CHUNK;
+  uint64_t key[SEL_PER_THREAD];
+  int mine = 0;
+#pragma unroll
+  for (int e = 0; e < SEL_PER_THREAD; ++e) {
+    const int i = base + e * SEL_THREADS + (int)threadIdx.x;  // coalesced
+    uint64_t kk = 0;
+    if (i < n) kk = FROM_HITS ? topk_key(hits[i].score, (uint32_t)i) : in_keys[i];
+    key[e] = kk;
+    mine += kk != 0;
+  }
+  if (threadIdx.x == 0) sh_valid = 0, sh_out = 0;
+  __syncthreads();
+  {
+    // (one atomic per wave)
+    int v = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh_valid, (uint32_t)v);
+  }
+  __syncthreads();
+  const int valid = (int)sh_valid;
+  uint64_t* out = out_keys + (size_t)blockIdx.x * k;
+  uint64_t T = 1;  // fewer than k keys: all of them (every key >= 1)
+  if (valid > k) {
+    uint64_t prefix = 0;
+    uint32_t krem = (uint32_t)k;
+    for (int p = 0; p < 8; ++p) {
+      const int shift = 56 - 8 * p;
+      if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < SEL_PER_THREAD; ++e) {
+        // still a candidate for the K-th key: a real key whose bytes above this one equal the prefix
+        bool act = key[e] != 0 && (p == 0 || (key[e] >> (shift + 8)) == (prefix >> (shift + 8)));
+        const uint32_t d = (uint32_t)(key[e] >> shift) & 255u;
+        // the top bytes of the keys (sign, exponent) are nearly the same for all of them: two rounds of wave-aggregated
+        // adds (all lanes that share the leader's byte add once) before the plain atomics
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+          const unsigned long long am = __ballot(act);
+          if (am == 0) break;
+          const uint32_t lead = (uint32_t)__shfl((int)d, __ffsll((long long)am) - 1);
+          const unsigned long long same = __ballot(act && d == lead);
+          if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&hist[lead], (uint32_t)__popcll(same));
+          act = act && d != lead;
+        }
+        if (act) atomicAdd(&hist[d], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        // suffix[t] = number of candidates whose byte is >= t; the byte of the krem-th largest is the one with
+        // suffix[t] >= krem > suffix[t + 1]
+        uint32_t above = 0;
+        for (int x = (int)threadIdx.x + 1; x < 256; ++x) above += hist[x];
+        const uint32_t here = above + hist[threadIdx.x];
+        if (here >= krem && above < krem) {
+          sh_digit = threadIdx.x;
+          sh_krem = krem - above;
+        }
+      }
+      __syncthreads();
+      prefix |= (uint64_t)sh_digit << shift;
+      krem = sh_krem;
+      __syncthreads();
+    }
+    T = prefix;
+  }
+#pragma unroll
+  for (int e = 0; e < SEL_PER_THREAD; ++e) {
+    const bool take = key[e] >= T && key[e] != 0;
+    const unsigned long long m = __ballot(take);
+    if (m) {
+      uint32_t slot0 = 0;
+      const int leader = __ffsll((long long)m) - 1;
+      if ((int)(threadIdx.x & 63) == leader) slot0 = atomicAdd(&sh_out, (uint32_t)__popcll(m));
+      slot0 = (uint32_t)__shfl((int)slot0, leader);
+      if (take) out[slot0 + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = key[e];
+    }
+  }
+  __syncthreads();
+  for (int t = (int)sh_out + (int)threadIdx.x; t < k; t += SEL_THREADS) out[t] = 0;  // padding of a chunk with fewer than k keys
+}
+
+// the last level: m <= SORT_MAX keys (or hits) sorted descending in LDS by a bitonic network, the k best gathered
+template <bool FROM_HITS>
+__global__ void __launch_bounds__(1024) topk_final_kernel(const DevHit* __restrict__ hits, const uint64_t* __restrict__ in_keys, int m,
+                                                          int k, const int32_t* __restrict__ gids, DevHit* __restrict__ out) {
+  __shared__ uint64_t key[SORT_MAX];
+  int P = 2;
+  while (P < m) P <<= 1;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) key[i] = i < m ? (FROM_HITS ? topk_key(hits[i].score, (uint32_t)i) : in_keys[i]) : 0;
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < P / 2; i += blockDim.x) {
+        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;  // final order: descending
+        const uint64_t a = key[lo], b = key[hi];
+        if ((a < b) == desc) {
+          key[lo] = b;
+          key[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < k; t += blockDim.x) {
+    const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(key[t] & 0xFFFFFFFFu);
+    DevHit h = hits[idx];
+    if (gids) h.index = gids[h.index];
+    out[t] = h;
+  }
+}
+
 __global__ void topk_keys_kernel(const DevHit* __restrict__ hits, int n, uint64_t* __restrict__ keys) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  uint32_t u = __builtin_bit_cast(uint32_t, hits[k].score);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
-  keys[k] = ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)k);
+  keys[k] = topk_key(hits[k].score, (uint32_t)k);
 }
 
 // gids: the shard's global template ids (hhv_tset_set_global_ids), or null = the index inside the set
@@ -200,21 +337,43 @@ void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t 
                      d_hits);
 }
 
-// keys/sorted: n uint64 each, temp: topk_temp_bytes(n).  Asynchronous on `stream`.
+// keys/sorted: n uint64 each, temp: topk_temp_bytes(n) (used by the full-sort path only).  Asynchronous on `stream`; k <= n.
 int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit* d_out, uint64_t* keys, uint64_t* sorted,
                 void* temp, size_t temp_bytes, hipStream_t stream, std::string* err) {
   const int threads = 256;
-  hipLaunchKernelGGL(topk_keys_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, d_hits, n, keys);
-  hipError_t e = hipcub::DeviceRadixSort::SortKeysDescending(temp, temp_bytes, keys, sorted, n, 0, 64, stream);
-  if (e != hipSuccess) {
-    if (err) *err = std::string("radix sort: ") + hipGetErrorString(e);
-    return -1;
+  hipError_t e = hipSuccess;
+  if (n <= SORT_MAX) {
+    hipLaunchKernelGGL(topk_final_kernel<true>, dim3(1), dim3(1024), 0, stream, d_hits, (const uint64_t*)nullptr, n, k, gids, d_out);
+  } else if (k <= SEL_KMAX) {
+    // levels of selection: n keys -> chunks x k -> ... -> at most SORT_MAX, the buffers used in turn
+    int m = n;
+    uint64_t* buf[2] = {keys, sorted};
+    int cur = 0;
+    const uint64_t* src = nullptr;
+    while (m > SORT_MAX) {
+      const int chunks = (m + SEL_CHUNK - 1) / SEL_CHUNK;
+      if (src == nullptr)
+        hipLaunchKernelGGL(topk_select_kernel<true>, dim3(chunks), dim3(SEL_THREADS), 0, stream, d_hits, (const uint64_t*)nullptr, m, k, buf[cur]);
+      else
+        hipLaunchKernelGGL(topk_select_kernel<false>, dim3(chunks), dim3(SEL_THREADS), 0, stream, (const DevHit*)nullptr, src, m, k, buf[cur]);
+      src = buf[cur];
+      cur ^= 1;
+      m = chunks * k;
+    }
+    hipLaunchKernelGGL(topk_final_kernel<false>, dim3(1), dim3(1024), 0, stream, d_hits, src, m, k, gids, d_out);
+  } else {
+    hipLaunchKernelGGL(topk_keys_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, d_hits, n, keys);
+    e = hipcub::DeviceRadixSort::SortKeysDescending(temp, temp_bytes, keys, sorted, n, 0, 64, stream);
+    if (e != hipSuccess) {
+      if (err) *err = std::string("radix sort: ") + hipGetErrorString(e);
+      return -1;
+    }
+    hipLaunchKernelGGL(topk_gather_kernel, dim3((k + threads - 1) / threads), dim3(threads), 0, stream, d_hits, sorted, k,
+                       gids, d_out);
   }
-  hipLaunchKernelGGL(topk_gather_kernel, dim3((k + threads - 1) / threads), dim3(threads), 0, stream, d_hits, sorted, k,
-                     gids, d_out);
   e = hipGetLastError();
   if (e != hipSuccess) {
-    if (err) *err = std::string("gather: ") + hipGetErrorString(e);
+    if (err) *err = std::string("top-K selection: ") + hipGetErrorString(e);
     return -1;
   }
   return 0;

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
-    "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_hits",
+    "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
     "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan", "hhv_segment_plan",
     "hhv_tset_set_global_ids", "hhv_merge_hits",
 ]
@@ -155,8 +155,12 @@ def load(path=None):
     L.hhv_stream.restype = C.c_void_p
     L.hhv_last_kernel_ms.argtypes = [C.c_void_p, c_float_p]
     L.hhv_set_celloff.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.hhv_set_celloff_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_backtrace_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hhv_backtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.hhv_hit_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, c_int_p]
     L.hhv_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, c_int_p]
@@ -567,6 +571,22 @@ class Context:
         assert m.shape == (self.Lq + 1, int(ts.L[k]) + 1)
         _check(self.lib.hhv_set_celloff(self.h, ts.h, int(k), m.ctypes.data))
 
+    def set_celloff_paths(self, ts, paths, qranges=(), tranges=()):
+        """hhv_set_celloff_paths: paths = [(template, nsteps, i_steps, j_steps)] with 1-based step arrays as hit_path returns
+        them (entries 1..nsteps are handed over); qranges / tranges = [(lo, hi)] of -excl / -template_excl"""
+        template_of = np.array([p[0] for p in paths], dtype=np.int32)
+        off = np.zeros(len(paths) + 1, dtype=np.int64)
+        for k, p in enumerate(paths):
+            off[k + 1] = off[k] + int(p[1])
+        pi = np.concatenate([np.asarray(p[2], dtype=np.int32)[1:int(p[1]) + 1] for p in paths]) if paths else np.zeros(0, np.int32)
+        pj = np.concatenate([np.asarray(p[3], dtype=np.int32)[1:int(p[1]) + 1] for p in paths]) if paths else np.zeros(0, np.int32)
+        pi, pj = np.ascontiguousarray(pi), np.ascontiguousarray(pj)
+        qr = np.ascontiguousarray(np.asarray(qranges, dtype=np.int32).reshape(-1))
+        tr = np.ascontiguousarray(np.asarray(tranges, dtype=np.int32).reshape(-1))
+        _check(self.lib.hhv_set_celloff_paths(self.h, ts.h, len(paths), template_of.ctypes.data, off.ctypes.data,
+                                              pi.ctypes.data, pj.ctypes.data, len(qr) // 2, qr.ctypes.data if len(qr) else None,
+                                              len(tr) // 2, tr.ctypes.data if len(tr) else None))
+
     def set_global_batch(self, ts, not_longest):
         """hhv_set_global_batch: not_longest[k] != 0 -> template k is shorter than the longest of its SIMD batch"""
         if not_longest is None:
@@ -585,6 +605,17 @@ class Context:
         out = np.zeros(ts.n, dtype=HIT_DTYPE) if fetch else None
         _check(self.lib.hhv_hits(self.h, ts.h, out.ctypes.data if fetch else None))
         return out
+
+    def backtrace(self, ts, k):
+        """hhv_backtrace: (nsteps, matched_cols, i_steps, j_steps, states) of template k - Viterbi::Backtrace's BacktraceResult"""
+        cap = self.Lq + int(ts.L[k]) + 2
+        i_steps = np.zeros(cap, dtype=np.int32)
+        j_steps = np.zeros(cap, dtype=np.int32)
+        states = np.zeros(cap, dtype=np.int8)
+        ns, mc = C.c_int32(), C.c_int32()
+        _check(self.lib.hhv_backtrace(self.h, ts.h, int(k), cap, i_steps.ctypes.data_as(C.c_void_p), j_steps.ctypes.data_as(C.c_void_p),
+                                      states.ctypes.data_as(C.c_void_p), C.byref(ns), C.byref(mc)))
+        return ns.value, mc.value, i_steps, j_steps, states
 
     def hit_path(self, ts, k):
         cap = self.Lq + int(ts.L[k]) + 2

@@ -14,9 +14,10 @@
  *                                                                      src/hhviterbi.cpp:163-191, src/hhviterbi.h:21-32
  *   hhv_set_celloff            ViterbiMatrix::setCellOff(i,j,elem,true) / Viterbi::ExcludeAlignment
  *                                                                      src/hhviterbimatrix-inl.h:28-35, src/hhviterbi.cpp:61-77
- *   hhv_backtrace              Viterbi::Backtrace(matrix, elem, i[], j[]) -> BacktraceResult
+ *   hhv_backtrace              Viterbi::Backtrace(matrix, elem, i[], j[]) -> BacktraceResult of one template
  *                                                                      src/hhviterbi.cpp:83-160, src/hhviterbi.h:34-40
- *   hhv_hits / hhv_hit_path    Viterbi::ScoreForBacktrace(...) -> BacktraceScore and the Hit fields filled in
+ *   hhv_hits / hhv_hit_path    the same walk for ALL templates of a set on the device, followed by
+ *                              Viterbi::ScoreForBacktrace(...) -> BacktraceScore and the Hit fields filled in
  *                              ViterbiConsumerThread::align            src/hhviterbi.cpp:195-281, src/hhviterbirunner.cpp:35-62
  *   hhv_set_ss_tables / hhv_set_query_ss / hhv_upload_templates_ss / hhv_set_ss_mode
  *                              the secondary-structure inputs of Viterbi::Align...AndSS: S73/S33/S37 of the
@@ -379,6 +380,13 @@ int hhv_backtrace_matrix(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint8_t* out);
  * preceding hhv_align with HHV_ALIGN_BACKTRACE).  hits (host, n entries, nullable; NULL = the kernels are only
  * enqueued on the context's stream, the records stay on the device for hhv_topk / hhv_hit_path). */
 int hhv_hits(hhv_ctx* ctx, hhv_tset* ts, hhv_hit* hits);
+/* Viterbi::Backtrace(matrix, elem, i2, j2) -> BacktraceResult (src/hhviterbi.cpp:83-160, src/hhviterbi.h:34-40) of template k:
+ * i_steps / j_steps / states of cap entries (nullable), 1-based, step 1 = alignment END, states[nsteps] = MM like the
+ * reference; *nsteps = BacktraceResult.count, *matched_cols (nullable) = BacktraceResult.matched_cols.  Needs a preceding
+ * hhv_align with HHV_ALIGN_BACKTRACE.  The device walks the paths of all templates of the set in one launch (the first call
+ * after an alignment starts it, like hhv_hits); per-step scores and Hit fields: hhv_hits / hhv_hit_path. */
+int hhv_backtrace(hhv_ctx* ctx, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps, int8_t* states,
+                  int32_t* nsteps, int32_t* matched_cols);
 /* path of template k: arrays of cap entries, 1-based like BacktraceResult (index 0 unused,
  * step 1 = alignment end); S = per-step column scores (BacktraceScore.S).  Needs hhv_hits. */
 int hhv_hit_path(hhv_ctx* ctx, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_steps, int32_t* j_steps,

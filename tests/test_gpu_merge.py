@@ -93,3 +93,33 @@ def test_topk_reports_global_ids():
     with pytest.raises(capi.HhvError):
         c.set_global_ids(ts, -np.ones(300, dtype=np.int32))
     c.close()
+
+
+@pytest.mark.parametrize("n,ks", [(4096, (1, 500)), (4097, (1, 7, 500, 1024)), (20000, (500, 1024, 1025, 3000)),
+                                  (70000, (1, 64, 500)), (300000, (500, 1024))])
+def test_topk_selection_equals_a_full_sort(n, ks):
+    """hhv_topk selects (chunks of 16 384 keys radix-selected in registers, levels until 4096 keys are left, one bitonic
+    sort) instead of sorting everything: every path - final sort only (n <= 4096), one level, two levels (300 000 x 1024),
+    the full-sort path for K > 1024 - against numpy's order: score descending, ties by the smaller index
+    (src/hhhit.h:116-126).  The set holds only 40 distinct templates, so almost every score is shared by thousands of
+    templates and the K-th key is decided by the index bytes."""
+    from pyhhv import capi, synth
+    q, qtr = synth.make_query(902, 6)
+    base = [synth.make_template(6100 + k, 3 + k % 5) for k in range(40)]
+    rng = np.random.default_rng(n)
+    pick = rng.integers(0, 40, size=n)
+    tps, ttrs = [base[p][0] for p in pick], [base[p][1] for p in pick]
+    c = capi.Context(local=1)
+    c.set_query(q, qtr)
+    ts = c.upload(tps, ttrs)
+    res = c.align(ts)
+    score = np.asarray(res["score"], dtype=np.float32)
+    order = np.lexsort((np.arange(n), -score.astype(np.float64)))
+    for k in ks:
+        top, nv = c.topk(ts, k, raw=True)
+        assert nv == k
+        assert np.array_equal(top["index"], order[:k]), (n, k)
+        assert np.array_equal(top["score"], score[order[:k]])
+    # fewer templates than K: all of them, the rest padding
+    ts.free()
+    c.close()

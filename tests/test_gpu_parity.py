@@ -56,6 +56,12 @@ def test_backtrace_hits_match_oracle(hhv, oracle, case):
     c.set_query(qf, qtr)
     ts = c.upload(tps, ttrs)
     res = c.align(ts, backtrace=True)
+    # hhv_backtrace (Viterbi::Backtrace of one template) straight after the alignment: it starts the device walk itself
+    a0 = oracle.align(par, qf, qtr, tps[0], ttrs[0], want_path=True)
+    ns0, mc0, bi, bj, bs = c.backtrace(ts, 0)
+    assert (ns0, mc0) == (a0.nsteps, a0.matched_cols)
+    assert np.array_equal(bi[1:ns0 + 1], a0.i_steps[1:ns0 + 1]) and np.array_equal(bj[1:ns0 + 1], a0.j_steps[1:ns0 + 1])
+    assert np.array_equal(bs[1:ns0 + 1], a0.states[1:ns0 + 1])
     hits = c.hits(ts)
     for e in range(n):
         a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True)
