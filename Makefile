@@ -79,8 +79,14 @@ clean:
 	rm -rf build $(LIBDIR) tests/emul/libwave_emul.so
 	$(MAKE) -C oracle clean
 
-.PHONY: example all lib lib_fma lib_variant oracle emul clean
+.PHONY: example example_rccl all lib lib_fma lib_variant oracle emul clean
 
 # plain-C++ use of the host classes (no Python): examples/search_example.cpp
 example: $(RUNNER)
 	g++ -O2 -std=c++14 -Wall -Iinclude -o build/search_example examples/search_example.cpp -L$(LIBDIR) -lhhv_runner -lhhviterbi_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
+# the sharded search as a native multi-process program: one rank per GPU, librccl directly (examples/sharded_search_rccl.cpp)
+example_rccl: build/sharded_search_rccl
+build/sharded_search_rccl: examples/sharded_search_rccl.cpp include/hhviterbi_hip.h $(LIB)
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wall -Iinclude -o build/sharded_search_rccl examples/sharded_search_rccl.cpp -L$(LIBDIR) -lhhviterbi_hip -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib

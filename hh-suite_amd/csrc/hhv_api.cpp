@@ -433,7 +433,11 @@ int hhv_upload_templates_ss(hhv_ctx* c, int32_t n, const int32_t* L, const float
   const size_t slab_recs = (64u << 20) / (REC_DW * sizeof(float));
   size_t max_template = 0;
   for (int t = 0; t < n; ++t) max_template = std::max(max_template, (size_t)L[t] + 1);
-  const size_t stage_floats = std::max(slab_recs, max_template) * REC_DW;
+  // (the staging follows the upload - a handful of templates does not pin 2 x 64 MiB; an upload that fits one slab
+  // gets one buffer)
+  const size_t upload_recs = (size_t)ts->n_records;
+  const size_t stage_floats = std::max(std::min(slab_recs, upload_recs), max_template) * REC_DW;
+  const int n_stage = upload_recs > slab_recs ? 2 : 1;
   float* stage[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
   auto release = [&]() {
@@ -442,7 +446,7 @@ int hhv_upload_templates_ss(hhv_ctx* c, int32_t n, const int32_t* L, const float
       if (stage[b]) (void)hipHostFree(stage[b]);
     }
   };
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < n_stage; ++b) {
     if (hipHostMalloc(&stage[b], stage_floats * sizeof(float), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) {
       release();

@@ -157,7 +157,7 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
         // template of record a0: the last header at or before it (the terminal header counts as template n)
         int32_t tmpl = (int32_t)(std::upper_bound(ro.begin(), ro.end(), a0) - ro.begin()) - 1;
         for (int64_t rec = a0; rec < a1; ++rec) {
-          const float* r = buf + (size_t)(rec - r0) * REC_DW;
+          float* r = buf + (size_t)(rec - r0) * REC_DW;
           int32_t meta, w0, w1;
           memcpy(&meta, r + REC_META, 4);
           memcpy(&w0, r, 4);
@@ -174,6 +174,21 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
             if (meta < 0 || (meta & META_JMASK) != j || (((meta & META_LAST) != 0) != (j == L[(size_t)tmpl]))) {
               bd.rec = rec, bd.kind = 2, bd.tmpl = tmpl, bd.j = j;
               return;
+            }
+            // the kernel takes the exponent of a column product with a plain shift (viterbi_lane.h log2f4): a profile word
+            // with the sign bit set - a file written by another tool or an older build - would give a wrong score silently.
+            // -0 becomes +0 (same value in every product), anything negative is refused like the packer refuses it
+            for (int a = 0; a < 20; ++a) {
+              uint32_t u;
+              memcpy(&u, r + a, 4);
+              if (u & 0x80000000u) {
+                if (u == 0x80000000u) {
+                  r[a] = 0.0f;
+                } else {
+                  bd.rec = rec, bd.kind = 3, bd.tmpl = tmpl, bd.j = j;
+                  return;
+                }
+              }
             }
           }
         }
@@ -195,6 +210,8 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
         if (bd.kind == 0) rc = fail(HHV_E_ARG, "hhv_db_open: truncated record stream");
         else if (bd.kind == 1)
           rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not the header of template %d", path, (long long)bd.rec, bd.tmpl);
+        else if (bd.kind == 3)
+          rc = fail(HHV_E_ARG, "hhv_db_open: %s: column %d of template %d has a negative profile value (p = f / null model >= 0)", path, bd.j, bd.tmpl);
         else
           rc = fail(HHV_E_ARG, "hhv_db_open: %s: record %lld is not column %d of template %d", path, (long long)bd.rec, bd.j, bd.tmpl);
         break;

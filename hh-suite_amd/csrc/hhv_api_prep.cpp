@@ -73,9 +73,49 @@ static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, c
 }
 
 // raw column block -> resident raw set (the block may come from build_raw_block or straight from a raw database file)
-static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const float* neff_hmm, const float* block,
+static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const float* neff_hmm, float* block,
                              size_t block_floats, hhv_rawset** out) {
   HIP_TRY(hipSetDevice(c->par.device));
+  // Column frequencies are >= 0: what the prepare kernels make of them goes to the DP kernel, whose log2f4 takes the exponent
+  // of a column product with a plain shift (viterbi_lane.h).  A block from a file of another tool or build is checked like the
+  // packer checks host profiles: -0 becomes +0, a negative value is refused.
+  {
+    const size_t cols = block_floats / RAW_DW;
+    const int nt = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), cols / 65536 + 1);
+    std::vector<int64_t> bad((size_t)nt, -1);
+    auto scan = [&](int w) {
+      for (size_t col = cols * w / nt; col < cols * (w + 1) / nt; ++col) {
+        float* fw = block + col * RAW_DW + RAW_F;
+        int32_t meta;
+        memcpy(&meta, block + col * RAW_DW + RAW_J, 4);
+        if ((meta & META_JMASK) == 0) continue;  // row 0 of a template is not a column (nothing reads its frequencies)
+        for (int a = 0; a < 20; ++a) {
+          uint32_t u;
+          memcpy(&u, fw + a, 4);
+          if (!(u & 0x80000000u)) continue;
+          if (u == 0x80000000u) {
+            fw[a] = 0.0f;
+          } else if (bad[(size_t)w] < 0) {
+            bad[(size_t)w] = (int64_t)col;
+          }
+        }
+      }
+    };
+    if (nt <= 1) {
+      scan(0);
+    } else {
+      std::vector<std::thread> pool;
+      int started = 0;
+      try {
+        for (; started < nt; ++started) pool.emplace_back(scan, started);
+      } catch (...) {
+      }
+      for (int w = started; w < nt; ++w) scan(w);
+      for (auto& th : pool) th.join();
+    }
+    for (int64_t b : bad)
+      if (b >= 0) return fail(HHV_E_ARG, "raw template set: raw column %lld has a negative frequency (f >= 0)", (long long)b);
+  }
   hhv_rawset* rs = new (std::nothrow) hhv_rawset();
   if (!rs) return fail(HHV_E_MEMORY, "out of host memory");
   rs->ctx = c;
@@ -238,8 +278,11 @@ static int check_prep_params(const hhv_prep_params* par) {
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: columnscore = %d (only 0..3)", par->columnscore);
   // p = (1 - tau) f + tau g with tau <= pca (src/hhhmm.cpp:1874-1964): an admixture weight above 1 makes profile values
   // negative, which the DP kernel's log2f4 does not take (viterbi_lane.h; the packer refuses them on the host paths too)
-  if (par->pcm != 0 && !(par->pca >= 0.0f && par->pca <= 1.0f))
-    return fail(HHV_E_LIMIT, "hhv_prepare_templates: pca = %g; the pseudocount admixture must lie in [0, 1] (profile values stay >= 0)", par->pca);
+  // (pcm 2 clamps tau with fmin(1.0, ..), :1900/:1906: there pca > 1 is legal and only pca >= 0, pcb > 0 are needed - ADVICE r3)
+  if (par->pcm == 1 && !(par->pca >= 0.0f && par->pca <= 1.0f))
+    return fail(HHV_E_LIMIT, "hhv_prepare_templates: pca = %g; the constant pseudocount admixture (pcm 1) must lie in [0, 1] (profile values stay >= 0)", par->pca);
+  if (par->pcm == 2 && !(par->pca >= 0.0f && par->pcb > 0.0f))
+    return fail(HHV_E_LIMIT, "hhv_prepare_templates: pca = %g, pcb = %g; pcm 2 needs pca >= 0 and pcb > 0 (profile values stay >= 0)", par->pca, par->pcb);
   return HHV_OK;
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/hhviterbi_hip.h"  // HHV_SEGMENT_MIN_RECORDS: the planner's constant the ring geometry below depends on
 #include "hhv_internal.h"
 #include "viterbi_lane.h"
 
@@ -560,6 +561,11 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   constexpr int LEAD = PF ? 1 : 0;
+  //  WorkQueue::record_of keeps ONE junction of history: when the refill (at most 2 C + LEAD positions ahead of the
+  // first lane) passes a junction, the one before it must be behind the array's last lane (W - 1 positions back), and a ring
+  // chunk may hold one junction only.  The planner's constant, the prefetch lead and the ring geometry are tied together here.
+  static_assert(HHV_SEGMENT_MIN_RECORDS >= 2 * C + W - 2 + LEAD, "segments too short for one junction of history");
+  static_assert(HHV_SEGMENT_MIN_RECORDS >= CHUNK_RECS, "a ring chunk would hold two junctions");
   // the ring arithmetic's constants as SGPR operands as well (three more literal-carrying instructions per step otherwise)
   uint32_t k_ring_mask, k_rec_bytes, k_jmask;
   asm volatile("s_mov_b32 %0, %3\n\ts_mov_b32 %1, %4\n\ts_mov_b32 %2, %5"

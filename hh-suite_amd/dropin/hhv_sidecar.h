@@ -54,7 +54,7 @@ class Sidecar {
  public:
   static const uint32_t kRecMagic = 0x31434552u;  // "REC1"
 
-  explicit Sidecar(const std::string& path) : path_(path), map_(NULL), map_bytes_(0), usable_(true) { load(); }
+  explicit Sidecar(const std::string& path) : path_(path), map_(NULL), map_bytes_(0), usable_(true), checked_end_(0) { load(); }
   ~Sidecar() {
     if (map_) munmap(map_, map_bytes_);
   }
@@ -101,7 +101,9 @@ class Sidecar {
       // Under the lock: find the end of the last VALID record.  A file of another format version starts over; a torn tail (a
       // writer killed in the middle of its write, a full disk) is cut off - appended behind it, every later record would be
       // unreachable for load(), which stops at the first invalid one, and the file would grow with every search.
-      off_t end = valid_end(fd);
+      // (the walk starts where load() or the previous flush() ended - records are only ever appended whole under this
+      // lock, so what was valid stays valid; a large sidecar is not re-walked header by header on every search)
+      off_t end = valid_end(fd, checked_end_);
       if (end < (off_t)kHeadBytes) {
         if (ftruncate(fd, 0) != 0 || !write_all(fd, file_head(), kHeadBytes)) usable_ = false;
         end = kHeadBytes;
@@ -112,6 +114,7 @@ class Sidecar {
       if (usable_) {
         if (write_all(fd, pending_.data(), pending_.size())) written = pending_.size();
         else if (ftruncate(fd, end) != 0) usable_ = false;   // a short write: leave no torn record behind
+        checked_end_ = end + (off_t)written;
       }
       flock(fd, LOCK_UN);
     }
@@ -139,13 +142,14 @@ class Sidecar {
     }
     return true;
   }
-  // offset behind the last valid record (record headers only); 0 = no valid file header
-  static off_t valid_end(int fd) {
+  // offset behind the last valid record (record headers only); 0 = no valid file header.  `from` = an offset known to be
+  // the end of a valid record of THIS file (0 = none); a file that is shorter than that was started over: walked from its head
+  static off_t valid_end(int fd, off_t from) {
     struct stat st;
     if (fstat(fd, &st) != 0 || st.st_size < (off_t)kHeadBytes) return 0;
     char head[kHeadBytes];
     if (pread(fd, head, kHeadBytes, 0) != (ssize_t)kHeadBytes || memcmp(head, file_head(), 8) != 0) return 0;
-    off_t at = kHeadBytes;
+    off_t at = (from >= (off_t)kHeadBytes && from <= st.st_size) ? from : (off_t)kHeadBytes;
     while (at + 12 <= st.st_size) {
       uint32_t h[3];
       if (pread(fd, h, 12, at) != 12) break;
@@ -159,6 +163,7 @@ class Sidecar {
   void* map_;
   size_t map_bytes_;
   bool usable_;
+  off_t checked_end_;  // end of the last record known to be valid (load(), flush())
   std::mutex mu_;
   std::unordered_map<std::string, size_t> index_;  // entry name -> offset of its newest record
   std::string pending_;
@@ -353,6 +358,7 @@ class Sidecar {
       index_[std::string(base + at + 12, nlen)] = at;
       at += total;
     }
+    checked_end_ = (off_t)at;
   }
 };
 

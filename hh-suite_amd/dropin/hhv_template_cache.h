@@ -192,7 +192,8 @@ inline int ensure_context(TemplateCache& tc) {
 inline bool device_prepare_covers(const Parameters& par) {
   return par.pc_hhm_nocontext_mode >= 0 && par.pc_hhm_nocontext_mode <= 2 &&
          par.columnscore >= 0 && par.columnscore <= 3 &&
-         (par.pc_hhm_nocontext_mode == 0 || (par.pc_hhm_nocontext_a >= 0.0f && par.pc_hhm_nocontext_a <= 1.0f));
+         (par.pc_hhm_nocontext_mode != 1 || (par.pc_hhm_nocontext_a >= 0.0f && par.pc_hhm_nocontext_a <= 1.0f)) &&
+         (par.pc_hhm_nocontext_mode != 2 || (par.pc_hhm_nocontext_a >= 0.0f && par.pc_hhm_nocontext_b > 0.0f));
 }
 
 // the arguments of PrepareTemplateHMM that do not depend on the template

@@ -168,8 +168,15 @@ def test_advice_r2_celloff_without_mask_after_backtrace_and_foreign_set_ids():
     z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "gonnet_pb_R.npz"))
     f, tr, neff, nh = synth.make_raw_hmm(5, 30)
     raw, Ls = c.upload_raw([f], [tr], [neff], [nh])
+    # a constant admixture above 1 makes profile values negative: refused; with pcm 2 the reference clamps tau with
+    # fmin(1.0, ..) (src/hhhmm.cpp:1900), so pca > 1 is legal there and prepares (bit-exact values: tests/test_prepare.py)
     with pytest.raises(capi.HhvError, match="pca"):
-        c.prepare(raw, Ls, capi.prep_params(z["pb"], z["R"], pc=(2, 1.7, 1.5, 1.0)), z["pb"].astype(np.float32))
+        c.prepare(raw, Ls, capi.prep_params(z["pb"], z["R"], pc=(1, 1.7, 1.5, 1.0)), z["pb"].astype(np.float32))
+    with pytest.raises(capi.HhvError, match="pcb"):
+        c.prepare(raw, Ls, capi.prep_params(z["pb"], z["R"], pc=(2, 1.0, -1.5, 1.0)), z["pb"].astype(np.float32))
+    ts2 = c.prepare(raw, Ls, capi.prep_params(z["pb"], z["R"], pc=(2, 1.7, 1.5, 1.0)), z["pb"].astype(np.float32))
+    assert len(c.align(ts2)) == 1
+    ts2.free()
     c.rawset_free(raw)
     ts.free()
     c.close()
