@@ -708,8 +708,8 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.qpack = c->d_qpack;
   a.results = d_out ? (DevResult*)d_out : ts->d_results;
   a.bt = ts->d_bt;
-  a.egq = c->par.egq;
-  a.egt = c->par.egt;
+  a.negq = 0.0f - c->par.egq;  // (+0 for a zero penalty: viterbi_lane.h Params)
+  a.negt = 0.0f - c->par.egt;
   a.shift = c->par.shift;
   a.Lq = c->Lq;
   a.carry = nullptr;
@@ -919,7 +919,9 @@ static int ensure_paths(hhv_ctx* c, hhv_tset* ts) {
   int64_t off = 0;
   for (int k = 0; k < ts->n; ++k) {
     ts->path_off[k] = off;
-    off += (int64_t)c->Lq + ts->L[k] + 2;  // BacktraceResult arrays: i2 + j2 + 2 entries (src/hhviterbi.cpp:90-93)
+    // BacktraceResult arrays: i2 + j2 + 2 entries (src/hhviterbi.cpp:90-93); pools start on multiples of four entries (the
+    // trace kernel writes its state bytes in words of four)
+    off += ((int64_t)c->Lq + ts->L[k] + 2 + 3) & ~(int64_t)3;
   }
   ts->path_off[ts->n] = off;
   HIP_TRY(hipMalloc(&ts->d_path_off, ts->path_off.size() * sizeof(int64_t)));

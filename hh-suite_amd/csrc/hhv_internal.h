@@ -94,7 +94,7 @@ struct StreamArgs {
   const float* qpack;        // [64*R][28]
   DevResult* results;        // [n_templates]
   uint64_t* bt;              // backtrace / cell-off entries, bt_entry() layout (BT / CELLOFF variants)
-  float egq, egt, shift;
+  float negq, negt, shift;  // 0 - par.egq, 0 - par.egt (viterbi_lane.h Params), par.shift
   int32_t Lq;
   // multi-pass strips (StripPlan): pass p handles query rows row_base+1 .. row_base+64*R_p
   int32_t row_base;          // StripPlan::base(p)

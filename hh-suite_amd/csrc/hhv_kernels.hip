@@ -9,7 +9,8 @@
 //           lane-to-lane hand-off is 5 ds_bpermute_b32 per step (+ 2 in steps with a header), delivered late (hhv_stream_kernel.h).
 // Kernel 2a hhv_trace_kernel   Viterbi::Backtrace (src/hhviterbi.cpp:83-160), one lane per template
 //           (serial pointer chase, O(Lq+Lt) dependent byte loads).
-// Kernel 2b hhv_rescore_kernel Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), one wave per template.
+// Kernel 2b hhv_rescore_kernel Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), per-step scores: one wave per template;
+// Kernel 2c hhv_scorr_kernel   its correlation sums and the Hit score: one lane per template.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (fp contraction would change results).
 #include <hip/hip_runtime.h>
@@ -106,19 +107,37 @@ __device__ __forceinline__ void trace_step(int& state, int& i, int& j, int& matc
 // (bt_entry: row = record + lane; a step lowers i and / or j by one), so the ten entries {row .. row - 4} x {g - 1, g} -
 // five independent 16-byte reads - cover the next two steps at least, four on a diagonal; the walk continues out of
 // registers until it leaves the window.
+// What the walk WRITES is one byte per step, the state (round 4): the kernel is bound by memory transactions - 64 lanes on
+// 64 different paths, every access its own 64-byte sector - and i_steps / j_steps (two scattered 4-byte stores per step and
+// lane) follow from the states and the end point: every recorded step but the last lowers i (MM, DG, MI) and / or j (MM, GD,
+// IM) by one.  hhv_rescore_kernel, which needs (i, j) of every step anyway, rebuilds them with two ballots per 64 steps and
+// writes them as contiguous 256-byte rows.  The state bytes leave in words of four (pools start on multiples of four).
 __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.n) return;
   const DevResult res = a.results[k];
   const int64_t rec0 = a.rec_off[k];
   const int64_t po = a.path_off[k];
-  int32_t* i_steps = a.i_steps + po;
-  int32_t* j_steps = a.j_steps + po;
-  int8_t* states = a.states + po;
+  uint32_t* state_words = reinterpret_cast<uint32_t*>(a.states + po);  // (po % 4 == 0: ensure_paths)
 
   int step = 0, matched = 0;
   int i = res.i2, j = res.j2;
+  int last_i = i, last_j = j;
   int state = 2;  // MM
+  uint32_t sbuf = 0;  // states of steps 4 w .. 4 w + 3, byte (step & 3) each; byte 0 of word 0 = the unused index 0
+  // one step of the walk: the state recorded for it is known after the step (the LAST step is recorded as MM, :147)
+  auto walk = [&](uint32_t b) __attribute__((always_inline)) {
+    const int st_here = state;
+    last_i = i;
+    last_j = j;
+    trace_step(state, i, j, matched, b);
+    step++;
+    sbuf |= (uint32_t)(state == 0 ? 2 : st_here) << (8 * (step & 3));
+    if ((step & 3) == 3) {
+      state_words[step >> 2] = sbuf;
+      sbuf = 0;
+    }
+  };
   if (a.plan.P == 1) {
     const int R = a.plan.R_hi, W = a.plan.W;
     constexpr int WIN = 5;
@@ -147,36 +166,28 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
           for (int t = 1; t < WIN; ++t) entry = (d == t) ? (c ? w[t][1] : w[t][0]) : entry;
           b = bt_decode(entry, rr, R, a.bt_mm);
         }
-        step++;
-        states[step] = (int8_t)state;
-        i_steps[step] = i;
-        j_steps[step] = j;
-        trace_step(state, i, j, matched, b);
+        walk(b);
       }
     }
   } else {
     while (state != 0) {
-      step++;
-      states[step] = (int8_t)state;
-      i_steps[step] = i;
-      j_steps[step] = j;
       uint32_t b = 0;
       if (i >= 1 && j >= 1) {
         int pass, g, rr, Rp;
         a.plan.locate(i, pass, g, rr, Rp);
         b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + bt_entry(rec0 + j, g, a.plan.W)], rr, Rp, a.bt_mm);
       }
-      trace_step(state, i, j, matched, b);
+      walk(b);
     }
   }
-  states[step] = 2;  // :147
+  if ((step & 3) != 3) state_words[step >> 2] = sbuf;  // the last, partial word (its upper bytes lie inside the template's own pool)
   DevHit h;
-  h.score = res.score;  // completed by hhv_rescore_kernel
+  h.score = res.score;  // completed by hhv_scorr_kernel
   h.viterbi_score = res.score;
   h.score_ss = 0.0f;
   h.index = k;
-  h.i1 = i_steps[step];
-  h.j1 = j_steps[step];
+  h.i1 = last_i;
+  h.j1 = last_j;
   h.i2 = res.i2;
   h.j2 = res.j2;
   h.nsteps = step;
@@ -184,63 +195,116 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   a.hits[k] = h;
 }
 
-// Kernel 2b: Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), one wavefront per template: the per-step
-// column scores S are independent (lanes stride over the steps); the four correlation sums are then
-// accumulated by one lane in exactly the reference's order (:241-249), reading S from LDS.
-constexpr int RESCORE_LDS_FLOATS = 4096;
+// Kernel 2b: Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), first half - one wavefront per template: (i, j) of
+// every step rebuilt from the state bytes (see hhv_trace_kernel) and written out, and the per-step column scores
+// S[step] = fast_log2(ScalarProd20(q.p[i], t.p[j])) of the MM steps (:225-235), lanes striding over the steps.  The template
+// columns are read with 16-byte loads straight from the record stream: this kernel reads the database a second time and
+// runs at the speed that read allows.
 __global__ void __launch_bounds__(64) hhv_rescore_kernel(TraceArgs a) {
-  __shared__ float sS[RESCORE_LDS_FLOATS];
   const int k = blockIdx.x;
   const int lane = threadIdx.x;
   const int64_t rec0 = a.rec_off[k];
   const int64_t po = a.path_off[k];
-  const int32_t* i_steps = a.i_steps + po;
-  const int32_t* j_steps = a.j_steps + po;
+  int32_t* i_steps = a.i_steps + po;
+  int32_t* j_steps = a.j_steps + po;
   const int8_t* states = a.states + po;
   float* S = a.S + po;
-  const int nsteps = a.hits[k].nsteps;
-  const bool in_lds = nsteps + 1 <= RESCORE_LDS_FLOATS;
-  for (int s = 1 + lane; s <= nsteps; s += LANES) {
-    float v = 0.0f;
-    if (states[s] == 2) {
-      const float* qp = a.qp + (size_t)i_steps[s] * 20;
-      const float* tp = a.records + (size_t)(rec0 + j_steps[s]) * REC_DW;
-      v = fast_log2_dev(dot20_scalar_dev(qp, tp), a.lg2, a.diff);
-    }
-    S[s] = v;
-    if (in_lds) sS[s] = v;
-  }
-  __syncthreads();
-  if (lane == 0) {
-    float score = a.hits[k].viterbi_score;
-    // :225-238: score_ss = sum over MM steps of ScoreSS(q,t,i,j) in step order; subtracted when ssm == 2
-    float score_ss = 0.0f;
-    if (a.ss_table) {
-      for (int s = 1; s <= nsteps; ++s) {
-        if (states[s] == 2 && i_steps[s] >= 1 && j_steps[s] >= 1) {
-          const int32_t meta = __builtin_bit_cast(int32_t, a.records[(size_t)(rec0 + j_steps[s]) * REC_DW + REC_META]);
-          score_ss += a.ss_table[a.ss_q_off[i_steps[s] - 1] + ((meta >> a.ss_t_shift) & a.ss_t_mask)];
+  const DevHit h = a.hits[k];
+  const int nsteps = h.nsteps;
+  int ci = h.i2, cj = h.j2;  // (i, j) of the first step of the chunk
+  for (int s0 = 1; s0 <= nsteps; s0 += LANES) {
+    const int s = s0 + lane;
+    const int st = s <= nsteps ? (int)states[s] : 0;
+    // step s + 1 starts at (i, j) of step s lowered by the move of state st (src/hhviterbi.cpp:96-146); the state recorded
+    // for the last step (always MM, :147) is not followed by a move - no step reads it
+    const bool di = st == 2 || st == 5 || st == 6, dj = st == 2 || st == 3 || st == 4;
+    const unsigned long long mi = __ballot(di), mj = __ballot(dj);
+    const int i = ci - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+    const int j = cj - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mj >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mj, 0u));
+    ci -= (int)__popcll(mi);
+    cj -= (int)__popcll(mj);
+    if (s <= nsteps) {
+      i_steps[s] = i;
+      j_steps[s] = j;
+      float v = 0.0f;
+      if (st == 2) {
+        const float4* qp = reinterpret_cast<const float4*>(a.qp + (size_t)i * 20);
+        const float4* tp = reinterpret_cast<const float4*>(a.records + (size_t)(rec0 + j) * REC_DW);
+        float q[20], t[20];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+          const float4 qa = qp[x], ta = tp[x];
+          q[4 * x + 0] = qa.x, q[4 * x + 1] = qa.y, q[4 * x + 2] = qa.z, q[4 * x + 3] = qa.w;
+          t[4 * x + 0] = ta.x, t[4 * x + 1] = ta.y, t[4 * x + 2] = ta.z, t[4 * x + 3] = ta.w;
         }
+        v = fast_log2_dev(dot20_scalar_dev(q, t), a.lg2, a.diff);
+      }
+      S[s] = v;
+    }
+  }
+}
+
+// Kernel 2c: the second half of ScoreForBacktrace - one LANE per template: score = Viterbi score [- score_ss] + corr * Scorr
+// with Scorr = sum over d = 1..4 of sum over steps of S[step] * S[step - d], ONE float accumulator through the four loops
+// in the reference's order (:241-249) - 4 x nsteps dependent additions per template, which one lane of a wave per template
+// used to walk alone (half of the old rescoring kernel's time).  Here 64 templates share a wave; their S rows come through
+// an LDS tile (64 coalesced loads of 256 bytes per 64 steps, transposed on the way out), once per d.
+constexpr int SCORR_PITCH = LANES + 1;
+__global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
+  __shared__ float tile[LANES * SCORR_PITCH];
+  __shared__ int64_t s_po[LANES];
+  __shared__ int s_ns[LANES];
+  const int lane = threadIdx.x;
+  const int k = blockIdx.x * LANES + lane;
+  const bool valid = k < a.n;
+  const int ns = valid ? a.hits[k].nsteps : 0;
+  const int64_t po = valid ? a.path_off[k] : 0;
+  s_po[lane] = po;
+  s_ns[lane] = ns;
+  int max_ns = ns;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) max_ns = max(max_ns, __shfl_xor(max_ns, o));
+  const int n_here = min(LANES, a.n - (int)blockIdx.x * LANES);
+  __syncthreads();
+  float Scorr = 0;
+  for (int d = 1; d <= 4; ++d) {
+    float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;  // S[s - 1] .. S[s - 4]
+    for (int t0 = 1; t0 <= max_ns; t0 += LANES) {
+      for (int t = 0; t < n_here; ++t) {
+        const int s = t0 + lane;
+        tile[t * SCORR_PITCH + lane] = s <= s_ns[t] ? a.S[s_po[t] + s] : 0.0f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int u = 0; u < LANES; ++u) {
+        const int s = t0 + u;
+        const float cur = tile[lane * SCORR_PITCH + u];
+        const float prev = d == 1 ? p1 : d == 2 ? p2 : d == 3 ? p3 : p4;
+        const float term = cur * prev;
+        Scorr = (s > d && s <= ns) ? Scorr + term : Scorr;
+        p4 = p3, p3 = p2, p2 = p1, p1 = cur;
+      }
+      __syncthreads();
+    }
+  }
+  if (!valid) return;
+  float score = a.hits[k].viterbi_score;
+  // :225-238: score_ss = sum over MM steps of ScoreSS(q,t,i,j) in step order; subtracted when ssm == 2
+  float score_ss = 0.0f;
+  if (a.ss_table) {
+    const int64_t rec0 = a.rec_off[k];
+    for (int s = 1; s <= ns; ++s) {
+      const int i = a.i_steps[po + s], j = a.j_steps[po + s];
+      if (a.states[po + s] == 2 && i >= 1 && j >= 1) {
+        const int32_t meta = __builtin_bit_cast(int32_t, a.records[(size_t)(rec0 + j) * REC_DW + REC_META]);
+        score_ss += a.ss_table[a.ss_q_off[i - 1] + ((meta >> a.ss_t_shift) & a.ss_t_mask)];
       }
     }
-    if (a.ss_mode == 2) score -= score_ss;
-    a.hits[k].score_ss = score_ss;
-    float Scorr = 0;
-    if (in_lds) {
-      for (int s = 2; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 1];
-      for (int s = 3; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 2];
-      for (int s = 4; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 3];
-      for (int s = 5; s <= nsteps; ++s) Scorr += sS[s] * sS[s - 4];
-    } else {
-      __threadfence_block();
-      for (int s = 2; s <= nsteps; ++s) Scorr += S[s] * S[s - 1];
-      for (int s = 3; s <= nsteps; ++s) Scorr += S[s] * S[s - 2];
-      for (int s = 4; s <= nsteps; ++s) Scorr += S[s] * S[s - 3];
-      for (int s = 5; s <= nsteps; ++s) Scorr += S[s] * S[s - 4];
-    }
-    score += a.corr * Scorr;
-    a.hits[k].score = score;
   }
+  if (a.ss_mode == 2) score -= score_ss;
+  score += a.corr * Scorr;
+  a.hits[k].score_ss = score_ss;
+  a.hits[k].score = score;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -287,6 +351,7 @@ int launch_trace(const TraceArgs& a, void* stream) {
   // 64 templates per wave for the chase (latency bound: many small blocks spread over all CUs)
   hipLaunchKernelGGL(hhv_trace_kernel, dim3((a.n + LANES - 1) / LANES), dim3(LANES), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(hhv_rescore_kernel, dim3(a.n), dim3(LANES), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(hhv_scorr_kernel, dim3((a.n + LANES - 1) / LANES), dim3(LANES), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

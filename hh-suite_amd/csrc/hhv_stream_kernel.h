@@ -495,8 +495,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   };
 
   Params P;
-  P.egq = a.egq;
-  P.egt = a.egt;
+  P.negq = a.negq;
+  P.negt = a.negt;
   P.shift = a.shift;
   P.Lq = a.Lq;
   // log2f4's constants as SGPR operands instead of 32-bit literals (viterbi_lane.h: Log2Consts; expor is the v_alignbit
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         // single pass: the boundary value of the first lane is formed inside the column's block, so that it need not be held
         // through phases A and B (it is read in phase C)
         const Incoming inc = MULTI ? in : boundary_incoming(meta, jcol, P);
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
       if (carry_out) {

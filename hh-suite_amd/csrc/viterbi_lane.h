@@ -101,7 +101,17 @@ HHV_DEV float fmax2(float a, float b) {
 // Which is faster depends on the kernel around it (profiles/r3_ab.txt, one session each): the 64-lane arrays run FIRST_EQUAL
 // + ADDC (-3 %: 20.4 -> 19.7 ms per 100 k templates; the v_cmpx forms gain nothing there), the short-query arrays RUNNING +
 // CMPX (Lq 150: 12.0 -> 11.0 ms, -8 %; FIRST_EQUAL + CMPX 11.2, FIRST_EQUAL + ADDC 11.7).  The macros are the A/B switches.
-enum { BT_MM_RUNNING = 1, BT_MM_FIRST_EQUAL = 3, BT_PAIR_ADDC = 0, BT_PAIR_CMPX = 1 };
+//   BT_MM_FIRST_EQUAL_NEG / BT_PAIR_SIGN (round 4, 64-lane variants without cell-off)  the same nine facts taken from the SIGN
+//                      of a difference, shifted in by v_alignbit_b32 (acc = {acc, d} >> 31): a > b is the sign bit of b - a,
+//                      and c_k == m (c_k <= m) is the INVERTED sign bit of c_k - m, stored inverted (bt_decode flips the four
+//                      bits).  No VOPC, no VCC, no carry chain.  Exact because no value compared here is ever -0 (b - a = -0
+//                      for a = +0, b = -0 would claim a > b): the DP boundaries are formed as j * (0 - egt), i.e. +0 where the
+//                      reference has -0 (equal values, and x + t is -0 only for x = t = -0: by induction no state is), and
+//                      two -inf operands (a NaN difference) need two masked cells: the cell-off variants keep v_cmp.
+enum { BT_MM_RUNNING = 1, BT_MM_FIRST_EQUAL = 3, BT_MM_FIRST_EQUAL_NEG = 5, BT_PAIR_ADDC = 0, BT_PAIR_CMPX = 1, BT_PAIR_SIGN = 2 };
+#ifndef HHV_BT_SIGN
+#define HHV_BT_SIGN 1
+#endif
 #ifndef HHV_BT_MM64
 #define HHV_BT_MM64 BT_MM_FIRST_EQUAL
 #endif
@@ -117,10 +127,12 @@ enum { BT_MM_RUNNING = 1, BT_MM_FIRST_EQUAL = 3, BT_PAIR_ADDC = 0, BT_PAIR_CMPX 
 // The encoding a kernel variant writes; the host records it with the backtrace buffer (hhv_tset::bt_mm) and hands it to the
 // kernels that decode.  (The local five-row cell-off + secondary-structure variant of the short-query arrays has no register
 // left for the running form's maximum: it flags.)
+HHV_HD constexpr bool bt_sign_mode(int W, bool celloff) { return HHV_BT_SIGN && W == 64 && !celloff && HHV_BT_MM64 == BT_MM_FIRST_EQUAL; }
 HHV_HD constexpr int bt_mm_mode(int W, int R, bool local, bool celloff, bool ss) {
-  return W == 64 ? HHV_BT_MM64 : (R == 5 && local && celloff && ss) ? (int)BT_MM_FIRST_EQUAL : HHV_BT_MMS;
+  return bt_sign_mode(W, celloff) ? (int)BT_MM_FIRST_EQUAL_NEG
+         : W == 64 ? HHV_BT_MM64 : (R == 5 && local && celloff && ss) ? (int)BT_MM_FIRST_EQUAL : HHV_BT_MMS;
 }
-HHV_HD constexpr int bt_pair_mode(int W) { return W == 64 ? HHV_BT_PAIR64 : HHV_BT_PAIRS; }
+HHV_HD constexpr int bt_pair_mode(int W, bool celloff) { return bt_sign_mode(W, celloff) ? (int)BT_PAIR_SIGN : W == 64 ? HHV_BT_PAIR64 : HHV_BT_PAIRS; }
 
 // acc = 2 acc + (a > b) / + (a == b)
 HHV_DEV void bt_push(uint32_t& acc, float a, float b) {
@@ -135,6 +147,15 @@ HHV_DEV void bt_push_eq(uint32_t& acc, float a, float b) {
   asm("v_cmp_eq_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
 #else
   acc = (acc << 1) | (a == b ? 1u : 0u);
+#endif
+}
+// acc = 2 acc + signbit(x - y): for x, y that are never -0 (and not both -inf) this is acc = 2 acc + (y > x)
+HHV_DEV void bt_push_sign(uint32_t& acc, float x, float y) {
+  const float d = x - y;
+#if defined(__HIP_DEVICE_COMPILE__)
+  acc = __builtin_amdgcn_alignbit(acc, f2bits(d), 31);
+#else
+  acc = (acc << 1) | (f2bits(d) >> 31);
 #endif
 }
 // (Compares into SGPR pairs of their own - v_cmp_e64 - with the v_addc_e64 that consume them issued as a block behind, so that
@@ -167,7 +188,11 @@ HHV_HD uint32_t bt_decode(uint64_t entry, int r, int R, int mm_mode) {
                              : (hi >> (2 * R)) & 0x7Fu;
   const uint32_t c2 = (hi >> (2 * (R - 1 - r))) & 3u;
   uint32_t b = 0;
-  if (mm_mode == BT_MM_FIRST_EQUAL) {
+  if (mm_mode == BT_MM_FIRST_EQUAL_NEG) {
+    // e0 = (m > smin) as is; bits 5..2 hold c_k < m, i.e. NOT (c_k == m)
+    const uint32_t g7 = f7 ^ 0x3Cu;
+    if (g7 & 0x40u) b = (g7 & 0x20u) ? 2 : (g7 & 0x10u) ? 3 : (g7 & 0x08u) ? 4 : (g7 & 0x04u) ? 5 : 6;
+  } else if (mm_mode == BT_MM_FIRST_EQUAL) {
     // e0 = (m > smin); the first of c1..c4 that equals m, c5 if none does: codes 2 (MM), 3 (GD), 4 (IM), 5 (DG), 6 (MI)
     if (f7 & 0x40u) b = (f7 & 0x20u) ? 2 : (f7 & 0x10u) ? 3 : (f7 & 0x08u) ? 4 : (f7 & 0x04u) ? 5 : 6;
   } else {
@@ -274,9 +299,17 @@ HHV_DEV float dot20(const float* q, const float* t) {
 }
 
 struct Params {
-  float egq, egt, shift;
+  float negq, negt, shift;  // 0 - egq, 0 - egt (formed once by the caller: Params::set_gaps), par.shift
   int Lq;
   Log2Consts lg = Log2Consts::literal();
+  // The DP boundaries -j * egt and -i * egq (src/hhviterbialgorithm.cpp:144-153,161-173) are formed as j * negt and i * negq
+  // with negt = 0 - egt: the same value bit for bit - except that a zero penalty gives +0 where the reference's int -> float
+  // -> multiply gives -0 (equal as values; no comparison or sum of the recurrence can tell them apart).  With that, NO state
+  // of the DP is ever -0 (x + t is -0 only for x = t = -0), which the sign-bit form of the backtrace flags relies on.
+  HHV_HDMEM void set_gaps(float egq, float egt) {
+    negq = 0.0f - egq;
+    negt = 0.0f - egt;
+  }
 };
 
 // query rows owned by one lane (row i = i0 + r)
@@ -360,8 +393,8 @@ HHV_DEV DiagSums lane_diag(const LaneState<R>& st, const QRows<R>& q) {
 // initialises as -(i-1)*egq = -0*egq (:161).
 HHV_DEV Incoming boundary_incoming(int32_t meta, int j /* meta & META_JMASK */, const Params& P) {
   Incoming in;
-  if (meta < 0) in.MM = (float)(-0) * P.egq;
-  else in.MM = (float)(-j) * P.egt;
+  if (meta < 0) in.MM = (float)(0) * P.negq;
+  else in.MM = (float)(j) * P.negt;
   in.GD = in.IM = in.DG = in.MI = NEG_MAX;
   in.fs = NEG_MAX;
   in.fpos = 0;
@@ -425,7 +458,7 @@ HHV_DEV bool lane_header(LaneState<R>& st, const QRows<R>& q, const Incoming& in
   st.jlast = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    st.MM[r] = (float)(-(i0 + r)) * P.egq;
+    st.MM[r] = (float)(i0 + r) * P.negq;
     st.GD[r] = st.IM[r] = st.DG[r] = st.MI[r] = NEG_MAX;
     st.bs[r] = NEG_MAX;
     st.bj[r] = 0;
@@ -509,7 +542,15 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
       const float c4 = (r ? st.DG[r - 1] + q.d2m[r] : ds.x4) + tM2M;
       const float c5 = (SHARE ? st.aMI[r] : (dMI + q.m2m[r])) + tI2M;
       uint32_t& acc = r ? acc_lo : acc_hi;
-      if (BTM == BT_MM_FIRST_EQUAL) {
+      if (BTM == BT_MM_FIRST_EQUAL_NEG) {
+        const float mm = fmax2(fmax2(fmax2(fmax2(fmax2(smin, c1), c2), c3), c4), c5);  // v_max3, v_max3, v_max
+        bt_push_sign(acc, smin, mm);  // m > smin
+        bt_push_sign(acc, c1, mm);    // c_k < m (the equality flag, inverted)
+        bt_push_sign(acc, c2, mm);
+        bt_push_sign(acc, c3, mm);
+        bt_push_sign(acc, c4, mm);
+        cmax[r] = mm;
+      } else if (BTM == BT_MM_FIRST_EQUAL) {
         const float mm = fmax2(fmax2(fmax2(fmax2(fmax2(smin, c1), c2), c3), c4), c5);  // v_max3, v_max3, v_max
         bt_push(acc, mm, smin);
         bt_push_eq(acc, c1, mm);
@@ -529,7 +570,8 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
         cmax[r] = mm;
       }
     }
-    static_assert(!BT || BTM == BT_MM_FIRST_EQUAL || BTP == BT_PAIR_CMPX, "the running form sets its bits in place");
+    static_assert(!BT || BTM == BT_MM_FIRST_EQUAL || BTM == BT_MM_FIRST_EQUAL_NEG || BTP == BT_PAIR_CMPX, "the running form sets its bits in place");
+    static_assert((BTM == BT_MM_FIRST_EQUAL_NEG) == (BTP == BT_PAIR_SIGN) || !BT, "the sign forms come together");
     if (BTM == BT_MM_FIRST_EQUAL && BTP == BT_PAIR_CMPX) {
       // the flags were shifted in, the pairwise bits are set in place: make room for them
       acc_lo <<= 2 * (R - 1);
@@ -552,6 +594,11 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
         bt_max(acc, ib, ia, 1u << (top - 1), ex);
         st.GD[r] = gb;
         st.IM[r] = ib;
+      } else if (BTP == BT_PAIR_SIGN) {
+        bt_push_sign(acc, gb, ga);  // ga > gb
+        bt_push_sign(acc, ib, ia);
+        st.GD[r] = fmax2(ga, gb);
+        st.IM[r] = fmax2(ia, ib);
       } else {
         bt_push(acc, ga, gb);
         bt_push(acc, ia, ib);
@@ -616,6 +663,9 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
       const uint64_t exc = bt_exec();
       bt_max(acc_hi, dg, da, 1u << (2 * (R - 1 - r) + 1), exc);
       bt_max(acc_hi, mi, ma, 1u << (2 * (R - 1 - r)), exc);
+    } else if (BT && BTP == BT_PAIR_SIGN) {
+      bt_push_sign(acc_hi, db, da);  // da > db
+      bt_push_sign(acc_hi, mb, ma);
     } else if (BT) {
       bt_push(acc_hi, da, db);
       bt_push(acc_hi, ma, mb);

@@ -159,8 +159,9 @@ def load(path=None):
                                         C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_backtrace_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    L.hhv_backtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    if hasattr(L, "hhv_backtrace"):  # (an A/B partner built from an older tree, tools/gpu_ab.sh, may lack the newest entries)
+        L.hhv_backtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.hhv_hit_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, c_int_p]
     L.hhv_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, c_int_p]

@@ -98,12 +98,13 @@ def pack_stream(tps, ttrs, t_ss=None):
     return rec, rec_off
 
 
-BT_MM_RUNNING, BT_MM_FIRST_EQUAL = 1, 3
+BT_MM_RUNNING, BT_MM_FIRST_EQUAL, BT_MM_FIRST_EQUAL_NEG = 1, 3, 5
 
 
 def bt_decode(entry, r, R, mm_mode=BT_MM_FIRST_EQUAL):
     """numpy mirror of bt_decode (csrc/viterbi_lane.h): uint64 entries -> the reference's backtrace byte of row r.
-    mm_mode: encoding of the MM predecessor (FIRST_EQUAL: e0 = (m > smin), e_k = (c_k == m); RUNNING: c_k > running max)."""
+    mm_mode: encoding of the MM predecessor (FIRST_EQUAL: e0 = (m > smin), e_k = (c_k == m); FIRST_EQUAL_NEG: the four
+    equality bits stored inverted (sign of c_k - m); RUNNING: c_k > running max)."""
     entry = np.asarray(entry, dtype=np.uint64)
     lo = (entry & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     hi = (entry >> np.uint64(32)).astype(np.uint32)
@@ -113,6 +114,9 @@ def bt_decode(entry, r, R, mm_mode=BT_MM_FIRST_EQUAL):
         f7 = (hi >> np.uint32(2 * R)) & np.uint32(0x7F)
     c2 = (hi >> np.uint32(2 * (R - 1 - r))) & np.uint32(3)
     b = np.zeros(entry.shape, dtype=np.uint8)
+    if mm_mode == BT_MM_FIRST_EQUAL_NEG:
+        f7 = f7 ^ np.uint32(0x3C)
+        mm_mode = BT_MM_FIRST_EQUAL
     if mm_mode == BT_MM_FIRST_EQUAL:
         b = np.full(entry.shape, 6, dtype=np.uint8)
         for bit, code in ((0x04, 5), (0x08, 4), (0x10, 3), (0x20, 2)):      # the FIRST candidate equal to the maximum wins
@@ -128,7 +132,7 @@ def bt_decode(entry, r, R, mm_mode=BT_MM_FIRST_EQUAL):
     return b
 
 
-def bt_to_matrix(bt_entries, rec_off_k, Lq, Lt, R, entry_bytes=8):
+def bt_to_matrix(bt_entries, rec_off_k, Lq, Lt, R, entry_bytes=8, mm_mode=BT_MM_FIRST_EQUAL):
     """Device backtrace entries (9 compare bits per cell, csrc/viterbi_lane.h bt_push) -> reference layout (Lq+1, Lt+1)
     bytes.  bt_entries: flat uint8 view of the [pass][record][lane][8] buffer."""
     P = -(-Lq // (LANES * R))
@@ -137,7 +141,7 @@ def bt_to_matrix(bt_entries, rec_off_k, Lq, Lt, R, entry_bytes=8):
     out = np.zeros((Lq + 1, Lt + 1), dtype=np.uint8)
     for i in range(1, Lq + 1):
         strip, r = (i - 1) // R, (i - 1) % R
-        out[i, 1:] = bt_decode(e[strip // LANES, rec_off_k + 1: rec_off_k + 1 + Lt, strip % LANES], r, R)
+        out[i, 1:] = bt_decode(e[strip // LANES, rec_off_k + 1: rec_off_k + 1 + Lt, strip % LANES], r, R, mm_mode)
     return out
 
 

@@ -92,9 +92,9 @@ static int run_pass(const float* qpack, const float* records, long M, Params P, 
           float ssv[R];
           const int tidx = (meta >> ss.t_shift) & ss.t_mask;
           for (int r = 0; r < R; ++r) ssv[r] = ss.table[ss.q_off[i0 - 1 + r] + tidx];
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, true, bt_mm_mode(64, R, LOCAL, CELLOFF, true), bt_pair_mode(64)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, ssv);
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, true, bt_mm_mode(64, R, LOCAL, CELLOFF, true), bt_pair_mode(64, CELLOFF)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, ssv);
         } else {
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, false, bt_mm_mode(64, R, LOCAL, CELLOFF, false), bt_pair_mode(64)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, nullptr);
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, false, bt_mm_mode(64, R, LOCAL, CELLOFF, false), bt_pair_mode(64, CELLOFF)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, nullptr);
         }
         if (BT) bt[(size_t)r * 64 + g] = bytes;
       }
@@ -136,14 +136,16 @@ static int dispatch(int local, int want_bt, int celloff, const float* qpack, con
                : run_wave<R, false, false, false>(qpack, records, M, P, results, n_results, bt, passes, ss);
 }
 
+// encoding of the MM predecessor the emulated variant writes (viterbi_lane.h bt_mm_mode): the tests decode with it
+extern "C" int hhv_emul_bt_mm_mode(int R, int local, int celloff, int ss) { return bt_mm_mode(64, R, local != 0, celloff != 0, ss != 0); }
+
 extern "C" int hhv_emul_wave(int R, int local, int want_bt, int celloff, const float* qpack, const float* records,
                              long M, float egq, float egt, float shift, int Lq, TemplateResult* results,
                              int n_results, uint64_t* bt, int passes, const float* ss_table, const int32_t* ss_q_off,
                              int ss_t_shift, int ss_t_mask) {
   SSArgs ss = {ss_table, ss_q_off, ss_t_shift, ss_t_mask};
   Params P;
-  P.egq = egq;
-  P.egt = egt;
+  P.set_gaps(egq, egt);
   P.shift = shift;
   P.Lq = Lq;
   switch (R) {

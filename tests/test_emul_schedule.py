@@ -58,6 +58,7 @@ def run(emul, par, qf, qtr, tps, ttrs, want_bt, bt_in=None, ss=None, t_ss=None):
     em = emul.hhv_emul_wave(R, par["local"], int(want_bt), int(bt_in is not None), qpack.ctypes.data, rec.ctypes.data,
                             M, par["egq"], par["egt"], par["shift"], Lq, res, n, bt.ctypes.data, P, *ssargs)
     assert em == n
+    run.mm_mode = emul.hhv_emul_bt_mm_mode(R, par["local"], int(bt_in is not None), int(ss is not None))  # how to decode bt
     return res, bt, off, R
 
 
@@ -74,7 +75,7 @@ def test_schedule_matches_oracle(emul, oracle, case):
             a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_bt=True)
             assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2), (case, e)
             if want_bt:
-                m = pack.bt_to_matrix(bt.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R)
+                m = pack.bt_to_matrix(bt.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R, mm_mode=run.mm_mode)
                 assert np.array_equal(m[1:, 1:], a.bt[1:, 1:])
 
 
@@ -97,7 +98,7 @@ def test_schedule_celloff(emul, oracle):
         for e in range(3):
             a = oracle.align(par, qf, qtr, tps[e], ttrs[e], celloff=masks[e], want_bt=True)
             assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2)
-            m = pack.bt_to_matrix(bt2.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R)
+            m = pack.bt_to_matrix(bt2.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R, mm_mode=run.mm_mode)
             assert np.array_equal(m[1:, 1:], a.bt[1:, 1:])
 
 
@@ -120,5 +121,37 @@ def test_schedule_secondary_structure(emul, oracle):
             for e in range(3):
                 a = oracle.align(par, qf, qtr, tps[e], ttrs[e], ss=ss, t_ss=t_ss[e], want_bt=True)
                 assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2), (Lq, mode, e)
-                m = pack.bt_to_matrix(bt.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R)
+                m = pack.bt_to_matrix(bt.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R, mm_mode=run.mm_mode)
                 assert np.array_equal(m[1:, 1:], a.bt[1:, 1:])
+
+
+@pytest.mark.parametrize("local", [0, 1])
+def test_sign_bit_flags_with_exact_ties_and_negative_zero(emul, oracle, local):
+    """The 64-lane backtrace variants take their compare bits from the SIGN of a difference (viterbi_lane.h BT_PAIR_SIGN):
+    exact as long as no DP state is -0.  Transition scores on a 0.5 grid (exact ties between candidates, sums that cancel
+    to +0), transitions that ARE -0.0f, zero end-gap penalties (the reference's boundary -j * egt is -0 there) and profile
+    columns repeated so that whole cells tie: every backtrace byte must still be the reference's."""
+    from pyhhv import synth
+    par = make_params(local=local, egq=0.0, egt=0.0)
+    for Lq in (37, 300):
+        qf, qtr = synth.make_query(7700 + Lq, Lq)
+        qtr = (np.round(qtr / 0.5) * 0.5).astype(np.float32)
+        qtr[qtr == 0] = np.float32(-0.0)
+        qf[5:9] = qf[4]
+        tps, ttrs = [], []
+        for e in range(4):
+            Lt = [33, 120, 64, 7][e]
+            p, tr = synth.make_homolog(7800 + e, qf, L=Lt) if e % 2 == 0 else synth.make_template(7800 + e, Lt)
+            tr = (np.round(tr / 0.5) * 0.5).astype(np.float32)
+            tr[tr == 0] = np.float32(-0.0)
+            if Lt > 12:
+                p[8:12] = p[7]
+            tps.append(p)
+            ttrs.append(tr)
+        res, bt, off, R = run(emul, par, qf, qtr, tps, ttrs, 1)
+        assert run.mm_mode == pack.BT_MM_FIRST_EQUAL_NEG
+        for e in range(4):
+            a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_bt=True)
+            assert same_float(a.score, res[e].score) and (a.i2, a.j2) == (res[e].i2, res[e].j2), (Lq, e)
+            m = pack.bt_to_matrix(bt.view(np.uint8), int(off[e]), Lq, tps[e].shape[0] - 1, R, mm_mode=run.mm_mode)
+            assert np.array_equal(m[1:, 1:], a.bt[1:, 1:]), (Lq, e)

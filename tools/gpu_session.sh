@@ -44,5 +44,21 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4a)   # round 4, first kernel session: the whole GPU suite on the new tests / top-K / trace chain, the NaN probe, A/B base - nosign - hip
+  timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > $OUT/gpu_suite.log; cat $OUT/gpu_suite.log
+  ./build/nan_probe
+  HHV_AB_LIBS="base nosign hip" HHV_AB_REPS=2 HHV_AB_CFGS="--lq 300 --templates 100000 --backtrace 1|--lq 300 --templates 10000 --backtrace 1|--lq 300 --templates 100000" bash tools/gpu_ab.sh
+  echo "== kernel trace of one backtrace search over 100 k templates"
+  cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_bt -- python $ROOT/bench.py --lq 300 --templates 100000 --backtrace 1 --steps 5 --warmup 2 $short > /dev/null 2>&1
+  python - <<'PY'
+import csv, glob
+for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    for r in rows:
+        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"]:
+            print("%-60s calls %5s  avg %10.1f us  total %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3))
+PY
+  ;;
 *) echo "unknown stage $stage"; exit 2;;
 esac
