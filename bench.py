@@ -223,7 +223,7 @@ def main():
     mine = [rank] if args.virtual_shards == 1 else list(range(n_shards))
     gids = np.concatenate([shard_ids[r] for r in mine])
 
-    qf, qtr = synth.make_query(0x51000000, Lq)
+    qf, qtr = synth_stream.query_np(Lq, synth.PB)   # the stream seeded with 0x51000000
     rec, rec_off, Ls = synth_stream.gen_stream(torch, device, gids, Lglobal[gids], synth.PB)
     n_local = int(Ls.shape[0])
     torch.cuda.synchronize()
@@ -305,6 +305,10 @@ def main():
     if bt:
         algo_bytes += cells_per_rank  # 1 backtrace byte per cell
     achieved_gbs = algo_bytes / (k_ms * 1e-3) / 1e9
+    # SURVEY.md 8(d)'s own figure: 27 floats per column incl. column 0 read, 12 bytes (score, i2, j2) written per template, the
+    # query once; + 1 byte per cell written with backtrace.  (The engine's record has 28 dwords - the 28th is the meta word - and
+    # its result 16 bytes: `algorithmic_bytes_per_launch` above; the two differ by 3.7 %.)
+    algo_bytes_8d = int(rec_off[-1]) * 108 + n_local * 12 + 108 * (Lq + 1) + (cells_per_rank if bt else 0)
     kernel_cells_s = cells_per_rank / (k_ms * 1e-3)
 
     # HBM traffic and VALU instruction count of the dominant kernel from the committed rocprofv3 PMC profile
@@ -352,6 +356,8 @@ def main():
             "step": "hhv_set_query (H2D) + hhv_align_async + hhv_topk%s + hhv_merge_hits; templates resident in HBM"
                     % (" + all_gather" if use_dist else ""),
             "prng": "splitmix64 -> xoshiro256**, seed 0x5EED0000 + global template id (query 0x51000000), u = (x >> 40) * 2^-24",
+            "columns": "SURVEY.md 8(d): f = 0.7 g + 0.3 pb, g = normalised Gamma(0.5) draws (erfinv(2u - 1)^2), p = f / pb; M2I, M2D = "
+                       "0.6 log2 U[0.01, 0.05], M2M = log2(1 - pI - pD), I2M = D2M = log2 0.6, I2I = D2D = 0.6 log2 0.4 (pyhhv/synth_stream.py)",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -359,6 +365,8 @@ def main():
             "traffic_source": "profiles/%s (rocprofv3 PMC, bytes per launch)" % profile_json if traffic else None,
             "kernel": "hhv_stream_kernel", "kernel_ms": k_ms, "kernel_ms_min": float(np.min(kernel_ms)),
             "kernel_ms_median": float(np.median(kernel_ms)), "algorithmic_bytes_per_launch": algo_bytes,
+            "algorithmic_bytes_8d": algo_bytes_8d, "achieved_8d": algo_bytes_8d / (k_ms * 1e-3) / 1e9,
+            "frac_8d": algo_bytes_8d / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "the path is VALU-issue bound, not HBM bound (SURVEY.md 8d): see roofline_valu",
         },
         "roofline_valu": {
@@ -412,6 +420,9 @@ def main():
 
     if single and not args.no_cpu_baseline:   # the contract: rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args, rec, rec_off, Ls, ctx, ts, qf, qtr, n, Lq)
+    elif world > 1:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_note"] = "timed at N = 1 only (rank 0 of a one-GPU run): see the --gpus 1 line"
 
     if single and not args.no_configs2 and n >= 10000 and plain:
         out["configs2_backtrace_top500"] = configs2(args, torch, ctx, ts, rec, rec_off, Ls, qf, qtr, Lq, Lt, K)
@@ -749,6 +760,14 @@ def next_rows():
                                                              "it); warm = templates resident on the device (second search of the process)"}
     except Exception as e:
         out["dropin_ViterbiRunner_alignment"] = {"error": repr(e)}
+    try:
+        # cold PROCESSES of the reference's hhsearch and of the same program with the replaced translation units: the
+        # number the sidecar (N1 inside the product's cold path) exists for is `dropin_cold_with_sidecar_process_s`
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hhsearch_hip")):
+            import bench_apps
+            out["dropin_cold_process"] = bench_apps.sidecar_processes(4000, min(16, usable_cores()[0]), 300)
+    except Exception as e:
+        out["dropin_cold_process"] = {"error": repr(e)}
     return out
 
 

@@ -272,8 +272,11 @@ void hhv_rawset_free(hhv_rawset* rs) {
   delete rs;
 }
 
+// pcm 3 recomputes the admixture constant from pcb (src/hhhmm.cpp:1914: a double expression stored in the float pca)
+static float prep_pca3(float pcb) { return (float)(0.793 + 0.048 * ((double)pcb - 10.0)); }
+
 static int check_prep_params(const hhv_prep_params* par) {
-  if (par->pcm < 0 || par->pcm > 2) return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm = %d (only 0, 1, 2)", par->pcm);
+  if (par->pcm < 0 || par->pcm > 3) return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm = %d (only 0 .. 3)", par->pcm);
   if (par->columnscore < 0 || par->columnscore > 3)
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: columnscore = %d (only 0..3)", par->columnscore);
   // p = (1 - tau) f + tau g with tau <= pca (src/hhhmm.cpp:1874-1964): an admixture weight above 1 makes profile values
@@ -281,6 +284,16 @@ static int check_prep_params(const hhv_prep_params* par) {
   // (pcm 2 clamps tau with fmin(1.0, ..), :1900/:1906: there pca > 1 is legal and only pca >= 0, pcb > 0 are needed - ADVICE r3)
   if (par->pcm == 1 && !(par->pca >= 0.0f && par->pca <= 1.0f))
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: pca = %g; the constant pseudocount admixture (pcm 1) must lie in [0, 1] (profile values stay >= 0)", par->pca);
+  if (par->pcm == 3) {
+    // :1911-1919: tau = fmax(0, pca3 h(x)), pca3 = 0.793 + 0.048 (pcb - 10), h(x) = 1 - x + pcc x (1 - x), x = Neff_M / pcb >= 0.
+    // tau stays in [0, 1] for every column iff pcb > 0, pca3 >= 0 and pca3 * max h <= 1 (max h = 1 for pcc <= 1, else
+    // 1 + (pcc - 1)^2 / (4 pcc))
+    const float pca3 = prep_pca3(par->pcb);
+    const double hmax = par->pcc > 1.0f ? 1.0 + (double)(par->pcc - 1.0f) * (par->pcc - 1.0f) / (4.0 * par->pcc) : 1.0;
+    if (!(par->pcb > 0.0f && pca3 >= 0.0f && par->pcc >= 0.0f && (double)pca3 * hmax <= 0.999))
+      return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm 3 with pcb = %g, pcc = %g can leave [0, 1] with its admixture (profile values stay >= 0)",
+                  par->pcb, par->pcc);
+  }
   if (par->pcm == 2 && !(par->pca >= 0.0f && par->pcb > 0.0f))
     return fail(HHV_E_LIMIT, "hhv_prepare_templates: pca = %g, pcb = %g; pcm 2 needs pca >= 0 and pcb > 0 (profile values stay >= 0)", par->pca, par->pcb);
   return HHV_OK;
@@ -358,8 +371,9 @@ static void fill_prep_args(PrepArgs* a, hhv_ctx* c, hhv_rawset* rs, hhv_tset* ts
   a->gapi = par->gapi;
   a->gapb = par->gapb;
   a->pcm = par->pcm;
-  a->pca = par->pca;
+  a->pca = par->pcm == 3 ? prep_pca3(par->pcb) : par->pca;
   a->pcb = par->pcb;
+  a->pcc = par->pcc;
   a->tau = (par->pcm == 2 && par->pcc != 1.0f) ? rs->d_tau : nullptr;
   a->columnscore = par->columnscore;
   a->ids = nullptr;

@@ -167,7 +167,7 @@ struct PrepArgs {
   float* pav_out;            // [n][20] or null
   float gapd, gape, gapf, gapg, gaph, gapi, gapb;
   int32_t pcm;
-  float pca, pcb;
+  float pca, pcb, pcc;       // (pcm 3: pca holds the reference's recomputed pca = 0.793 + 0.048 (pcb - 10), hhv_api_prep.cpp)
   const float* tau;          // pcm 2 with pcc != 1: tau of every raw column (the host evaluated libm's powf, hhv_api_prep.cpp); else null
   int32_t columnscore;
   const int32_t* ids;        // output slots of this launch (one workgroup each)

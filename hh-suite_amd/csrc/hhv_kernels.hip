@@ -270,9 +270,15 @@ __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
   for (int d = 1; d <= 4; ++d) {
     float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;  // S[s - 1] .. S[s - 4]
     for (int t0 = 1; t0 <= max_ns; t0 += LANES) {
-      for (int t = 0; t < n_here; ++t) {
+      {
+        // the tile: row t = steps t0 .. t0 + 63 of template t, one coalesced 256-byte load each - all of them issued before the
+        // first one is used (one trip to memory per tile, not one per template)
         const int s = t0 + lane;
-        tile[t * SCORR_PITCH + lane] = s <= s_ns[t] ? a.S[s_po[t] + s] : 0.0f;
+        float v[LANES];
+#pragma unroll
+        for (int t = 0; t < LANES; ++t) v[t] = (t < n_here && s <= s_ns[t]) ? a.S[s_po[t] + s] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < LANES; ++t) tile[t * SCORR_PITCH + lane] = v[t];
       }
       __syncthreads();
 #pragma unroll 8

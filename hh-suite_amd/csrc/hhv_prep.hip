@@ -3,7 +3,7 @@
 // the host.  Restates, operation for operation (fp32/fp64 mix included), the reference's
 //   HMM::AddTransitionPseudocounts    src/hhhmm.cpp:1722-1806   (fpow2 src/util-inl.h:190-215, fast_log2 :108-130)
 //   HMM::PreparePseudocounts          src/hhhmm.cpp:1811-1815   (ScalarProd20, plain branch, src/hhhit-inl.h:125-131)
-//   HMM::AddAminoAcidPseudocounts     src/hhhmm.cpp:1874-1964   (pcm 0, 1, 2; with pcc != 1 tau comes from the host)
+//   HMM::AddAminoAcidPseudocounts     src/hhhmm.cpp:1874-1964   (pcm 0 - 3; pcm 2 with pcc != 1: tau comes from the host)
 //   HMM::CalculateAminoAcidBackground src/hhhmm.cpp:1854-1868   (NormalizeTo1 src/util-inl.h:277-291)
 //   HMM::IncludeNullModelInHMM        src/hhhmm.cpp:2059-2144   (columnscore 0..3)
 // in the order of PrepareTemplateHMM (src/hhfunc.cpp:165-202, HHM format).
@@ -101,6 +101,10 @@ __device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __re
     if (a.pcm == 1) tau = a.pca;
     if (a.pcm == 2)  // :1898-1909; pcc != 1 needs libm's powf: the host has evaluated tau for every raw column
       tau = a.tau ? a.tau[(raw - a.raw) / RAW_DW] : (float)fmin(1.0, (double)a.pca / (1. + (double)(raw[RAW_NEFF + 0] / a.pcb)));
+    if (a.pcm == 3) {  // :1911-1919, constant-diversity pseudocounts: float arithmetic, the maximum with the double 0.0
+      const float x = raw[RAW_NEFF + 0] / a.pcb;
+      tau = (float)fmax(0.0, (double)(a.pca * ((1.0f - x) + (a.pcc * x) * (1.0f - x))));
+    }
     for (int aa = 0; aa < 20; ++aa) {
       if (a.pcm == 0) {
         P[aa] = f[aa];

@@ -393,7 +393,7 @@ HHV_DEV DiagSums lane_diag(const LaneState<R>& st, const QRows<R>& q) {
 // initialises as -(i-1)*egq = -0*egq (:161).
 HHV_DEV Incoming boundary_incoming(int32_t meta, int j /* meta & META_JMASK */, const Params& P) {
   Incoming in;
-  if (meta < 0) in.MM = (float)(0) * P.negq;
+  if (meta < 0) in.MM = 0.0f;  // -(0) * egq: +0 (0 * negq would be -0 for a positive penalty)
   else in.MM = (float)(j) * P.negt;
   in.GD = in.IM = in.DG = in.MI = NEG_MAX;
   in.fs = NEG_MAX;

@@ -9,7 +9,8 @@ shard it was assigned to or its place in the stream.  A database sharded over N 
 same database as the one a single rank holds (bench.py --virtual-shards, tests/test_gpu_configs.py).
 
 Draw order of a template: column j = 1..L, per column 28 uniforms - 20 for the profile column, 8 for the transitions
-(6 used).  The streams are walked in lock step: one torch tensor element per template, one step per draw, 18 small integer
+(2 used: pI and pD; SURVEY.md 8(d) fixes the other transitions).  The query (`query_np`) is one more such stream, seeded with
+0x51000000 itself.  The streams are walked in lock step: one torch tensor element per template, one step per draw, 18 small integer
 kernels per draw; the templates are visited in descending length order so that the active set is a prefix.
 
 xoshiro256** / splitmix64: Blackman & Vigna, public domain reference implementations (restated here on int64 tensors
@@ -67,6 +68,41 @@ def uniforms_np(gids, ndraws):
     return out
 
 
+QUERY_SEED = 0x51000000
+
+
+def query_np(Lq, pb):
+    """The query SURVEY.md 8(d) prescribes: stream seeded with 0x51000000, the same draws per column as a template; p = column
+    probabilities (no null model: HMM::p of a query), tr in the enum order of src/hhdecl.h:68; rows 0 and Lq as
+    AddTransitionPseudocounts leaves them.  Returns (p[(Lq+1), 20], tr[(Lq+1), 7]) float32."""
+    from scipy.special import erfinv
+    s = splitmix64_states(np.array([QUERY_SEED], dtype=np.uint64))
+    u = np.zeros((Lq + 1, DRAWS_PER_COLUMN), dtype=np.float64)
+    for i in range(1, Lq + 1):
+        for d in range(DRAWS_PER_COLUMN):
+            u[i, d] = float(xoshiro_next_np(s)[0] >> np.uint64(40)) * 2.0 ** -24
+    g = erfinv(2.0 * u[:, :20] - 1.0 + 2.0 ** -24) ** 2
+    g[0] = 1.0
+    g = g / g.sum(axis=1, keepdims=True)
+    pbd = np.asarray(pb, dtype=np.float64)
+    f = 0.7 * g + 0.3 * pbd[None, :]
+    f = f / f.sum(axis=1, keepdims=True)
+    f[0] = 0.0
+    pI, pD = 0.01 + 0.04 * u[:, 20], 0.01 + 0.04 * u[:, 21]
+    tr = np.zeros((Lq + 1, 7), dtype=np.float64)   # M2M, M2I, M2D, I2M, I2I, D2M, D2D
+    tr[:, 0] = np.log2(1.0 - pI - pD)
+    tr[:, 1] = 0.6 * np.log2(pI)
+    tr[:, 2] = 0.6 * np.log2(pD)
+    tr[:, 3] = tr[:, 5] = np.log2(0.6)
+    tr[:, 4] = tr[:, 6] = 0.6 * np.log2(0.4)
+    for i in (0, Lq):
+        tr[i, 0] = 0.0
+        tr[i, 1] = tr[i, 2] = -100000.0
+    tr[Lq, 5] = 0.0
+    tr[Lq, 6] = -100000.0
+    return f.astype(np.float32), tr.astype(np.float32)
+
+
 class _Xoshiro:
     """xoshiro256** on int64 torch tensors, one stream per element (two's-complement arithmetic wraps like uint64)."""
 
@@ -121,8 +157,9 @@ def uniforms_torch(torch, device, gids, ndraws):
 def gen_stream(torch, device, gids, Ls, pb):
     """Packed record stream of the templates `gids` (global ids, any order) with lengths `Ls`, in that order:
     per template a header (index = position in this set) + L column records; + terminal header + pad.
-    Column values: same distribution family as pyhhv/synth.py (peaky columns mixed with the background, divided by the
-    null model; transitions like AddTransitionPseudocounts leaves them), drawn from the template's own stream.
+    Column values and transitions exactly as SURVEY.md 8(d) prescribes for BASELINE's configs 2-4 (normalised Gamma(0.5)
+    draws mixed with the background, divided by the null model; M2I / M2D from U[0.01, 0.05], the other transitions
+    constants; rows 0 and L as AddTransitionPseudocounts leaves them), drawn from the template's own stream.
     Returns (records tensor [(nrec + 1 + 256), 28] float32, rec_off int64 numpy [n+1], Ls int32 numpy)."""
     gids = np.asarray(gids, dtype=np.int64)
     Ls = np.asarray(Ls, dtype=np.int64)
@@ -152,29 +189,44 @@ def gen_stream(torch, device, gids, Ls, pb):
         rec[off_o[:cnt] + j] = col[:cnt].to(torch.float32) * (2.0 ** -24)
     del col, tmp, g
 
-    # --- uniforms -> record fields, in slabs
+    # --- uniforms -> record fields, in slabs ("Configs 2-4"):
+    #   column:      f = 0.7 g + 0.3 pb with g = 20 Gamma(0.5) draws, normalised; p = f / pnul, pnul = pb.
+    #                Gamma(1/2) = Z^2 / 2 with Z standard normal, and Z = sqrt(2) erfinv(2 u - 1): g = erfinv(x)^2 with
+    #                x = 2 u - 1 + 2^-24 (u = k 2^-24: x is the midpoint of the k-th of 2^24 cells of (-1, 1), never +-1)
+    #   transitions: per column pI, pD ~ U[0.01, 0.05]: M2I = 0.6 log2 pI, M2D = 0.6 log2 pD, M2M = log2(1 - pI - pD);
+    #                I2M = D2M = log2 0.6, I2I = D2D = 0.6 log2 0.4.  Record j carries tr[j-1][M2M, M2D, D2M, D2D, I2M] and
+    #                tr[j][I2I, M2I]: the M2M / M2D fields come from the draws of the record before it.
     pbt = torch.tensor(np.asarray(pb, dtype=np.float32), dtype=torch.float32, device=device)
+    c_x2m = float(np.log2(np.float32(0.6)))                    # I2M, D2M
+    c_x2x = float(np.float32(0.6) * np.log2(np.float32(0.4)))  # I2I, D2D
+    pI_all = (0.01 + 0.04 * rec[:nrec, 20]).clone()
+    pD_all = (0.01 + 0.04 * rec[:nrec, 21]).clone()
     chunk = 1 << 21
     for a in range(0, nrec, chunk):
         b = min(nrec, a + chunk)
-        u = rec[a:b, 0:20].clone()
-        t = rec[a:b, 20:28].clone()
-        gg = u.pow(6.0) + 1e-9
+        x = rec[a:b, 0:20].double() * 2.0 - 1.0 + 2.0 ** -24
+        gg = torch.special.erfinv(x).square_().float()
+        del x
         gg = gg / gg.sum(dim=1, keepdim=True)
         f = 0.7 * gg + 0.3 * pbt
         f = f / f.sum(dim=1, keepdim=True)
         rec[a:b, 0:20] = f / pbt
-        # record j: tr[j-1][M2M,M2D,D2M,D2D,I2M], tr[j][I2I,M2I]
-        pI, pD, pII, pDD = 0.01 + 0.04 * t[:, 0], 0.01 + 0.04 * t[:, 1], 0.25 + 0.3 * t[:, 2], 0.25 + 0.3 * t[:, 3]
-        rec[a:b, 20] = torch.log2(1.0 - pI - pD)
-        rec[a:b, 21] = torch.log2(pD) * 0.6
-        rec[a:b, 22] = torch.log2(1.0 - pDD)
-        rec[a:b, 23] = torch.log2(pDD) * 0.6
-        rec[a:b, 24] = torch.log2(1.0 - pII)
-        rec[a:b, 25] = torch.log2(0.25 + 0.3 * t[:, 4]) * 0.6
-        rec[a:b, 26] = torch.log2(0.01 + 0.04 * t[:, 5]) * 0.6
+        # (record a - 1 is the record before record a: a template's header for its column 1, overwritten below)
+        a1 = max(a - 1, 0)
+        pI_prev, pD_prev = pI_all[a1:b - 1], pD_all[a1:b - 1]
+        if a == 0:
+            pI_prev = torch.cat([pI_all[:1], pI_prev])
+            pD_prev = torch.cat([pD_all[:1], pD_prev])
+        rec[a:b, 20] = torch.log2(1.0 - pI_prev - pD_prev)
+        rec[a:b, 21] = torch.log2(pD_prev) * 0.6
+        rec[a:b, 22] = c_x2m
+        rec[a:b, 23] = c_x2x
+        rec[a:b, 24] = c_x2m
+        rec[a:b, 25] = c_x2x
+        rec[a:b, 26] = torch.log2(pI_all[a:b]) * 0.6
         rec[a:b, 27] = 0.0
-        del u, t, gg, f
+        del gg, f
+    del pI_all, pD_all
 
     # --- per-record template index and column index; headers; the two boundary columns
     off_t = torch.from_numpy(rec_off).to(device)

@@ -511,7 +511,7 @@ int hho_prepare(int role, int L, const float *f, const float *tr, const float *n
   /* ---- PreparePseudocounts (:1811-1815) + AddAminoAcidPseudocounts (:1874-1964) */
   const int pcm = (int)pc[0];
   const float pca = pc[1], pcb = pc[2], pcc = pc[3];
-  if (pcm < 0 || pcm > 2) return -1;
+  if (pcm < 0 || pcm > 3) return -1;
   memset(p, 0, sizeof(float) * 20 * (size_t)(L + 2));
   for (int i = 1; i <= L; ++i) {
     const float *fi = f + (size_t)i * 20;
@@ -522,6 +522,13 @@ int hho_prepare(int role, int L, const float *f, const float *tr, const float *n
       /* :1905: pow(Neff_M[i] / pcb, pcc) with float arguments in C++ is the float overload (= powf); its result joins a
          double expression */
       else tau = (float)fmin(1.0, (double)pca / (1. + (double)powf(neff[i * 3] / pcb, pcc)));
+    }
+    if (pcm == 3) {
+      /* :1911-1919 constant-diversity pseudocounts: x and the product are float expressions, pca is recomputed from pcb (a
+         double expression stored in the float parameter), fmax(0.0, ..) is the double overload */
+      const float x = neff[i * 3] / pcb;
+      const float pca3 = (float)(0.793 + 0.048 * ((double)pcb - 10.0));
+      tau = (float)fmax(0.0, (double)(pca3 * ((1.0f - x) + (pcc * x) * (1.0f - x))));
     }
     for (int a = 0; a < 20; ++a) {
       if (pcm == 0) {

@@ -34,6 +34,55 @@ def run_omp(binary, args, prefix):
     return read_ffindex(prefix + "_hhr")
 
 
+def sidecar_processes(n=4000, threads=16, L=300):
+    """One cold PROCESS each of the reference's hhsearch and of the same program with the replaced translation units: without
+    the binary sidecar of the hhm database (every template parsed from its text by HMM::Read, like the reference), the run that
+    writes the sidecar, and a cold process that finds it (what N1 is for).  Whole-process wall time and the drop-in's own
+    account of ViterbiRunner::alignment (HHV_DROPIN_TIMING)."""
+    import re
+    qf = hhm_text.random_columns(900, L)
+    query = hhm_text.hhm_text("query00", qf, 900)
+    uniq = min(n, 400)
+    base_txt = []
+    for k in range(uniq):
+        f = hhm_text.mutate_columns(k, qf, 0.4) if k % 20 == 0 else hhm_text.random_columns(2000 + k, L)
+        base_txt.append(hhm_text.hhm_text("@NAME@", f, k))
+    names = ["a%06d" % k for k in range(n)]
+    texts = [base_txt[k % uniq].replace(b"@NAME@", names[k].encode()) for k in range(n)]
+    out = {"templates": n, "L": L, "host_threads": threads}
+
+    def one(binary, tag, sidecar):
+        cmd = [os.path.join(BIN, binary), "-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", str(threads), "-o",
+               os.path.join(tmp, tag + ".hhr"), "-scores", os.path.join(tmp, tag + ".scores"), "-v", "0"]
+        env = dict(os.environ, HHV_DROPIN_TIMING="1", HHV_SIDECAR=sidecar)
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, env=env, timeout=600)
+        dt = time.time() - t0
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        phases = None
+        for line in r.stderr.decode().splitlines():
+            m = re.search(r"read ([\d.]+) s, upload ([\d.]+) s, device prepare ([\d.]+) s, masks ([\d.]+) s, align\+hits ([\d.]+) s, paths\+Hit ([\d.]+) s, other ([\d.]+) s", line)
+            if m and "hhviterbirunner_hip" in line:
+                v = [float(x) for x in m.groups()]
+                phases = {"alignment_call_s": round(sum(v), 4), "read_s": v[0], "align_and_hits_s": v[4]}
+                break
+        scores = sorted(l for l in open(os.path.join(tmp, tag + ".scores")).read().splitlines() if not l.startswith(("Date", "Command", "FILE", "COMM")))
+        return round(dt, 3), phases, scores
+
+    with tempfile.TemporaryDirectory() as tmp:
+        base, qpath = build_db(tmp, query, texts, names, 9)
+        t_ref, _, s_ref = one("hhsearch_cpu", "ref", "0")
+        t_cold, ph_cold, s_cold = one("hhsearch_hip", "cold", "0")
+        t_w, ph_w, s_w = one("hhsearch_hip", "write", "1")
+        t_s, ph_s, s_s = one("hhsearch_hip", "side", "1")
+        out.update({"reference_process_s": t_ref, "dropin_cold_process_s": t_cold, "dropin_cold_writing_sidecar_process_s": t_w,
+                    "dropin_cold_with_sidecar_process_s": t_s,
+                    "dropin_cold_alignment": ph_cold, "dropin_cold_with_sidecar_alignment": ph_s,
+                    "sidecar_bytes": os.path.getsize(base + "_hhm.ffdata.hhvside"),
+                    "same_scores_file": s_ref == s_cold == s_w == s_s})
+    return out
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 32
