@@ -251,46 +251,57 @@ __global__ void __launch_bounds__(64) hhv_rescore_kernel(TraceArgs a) {
 // an LDS tile (64 coalesced loads of 256 bytes per 64 steps, transposed on the way out), once per d.
 constexpr int SCORR_PITCH = LANES + 1;
 __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
-  __shared__ float tile[LANES * SCORR_PITCH];
-  __shared__ int64_t s_po[LANES];
-  __shared__ int s_ns[LANES];
+  __shared__ float tile[2][LANES * SCORR_PITCH];
   const int lane = threadIdx.x;
   const int k = blockIdx.x * LANES + lane;
   const bool valid = k < a.n;
   const int ns = valid ? a.hits[k].nsteps : 0;
   const int64_t po = valid ? a.path_off[k] : 0;
-  s_po[lane] = po;
-  s_ns[lane] = ns;
   int max_ns = ns;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) max_ns = max(max_ns, __shfl_xor(max_ns, o));
-  const int n_here = min(LANES, a.n - (int)blockIdx.x * LANES);
-  __syncthreads();
+  const int po_lo = (int)(uint32_t)po, po_hi = (int)(uint32_t)((uint64_t)po >> 32);
+  const int n_tiles = (max_ns + LANES - 1) / LANES;
+  // a tile: row t = steps t0 .. t0 + 63 of template t, ONE coalesced 256-byte load per template; the 64 loads are independent
+  // and unconditional (index clamped into the template's own pool, the value masked afterwards; the template's pool offset
+  // and length come out of the lanes' registers as scalars), so that all of them are in flight together.  The loads of the
+  // next tile are issued before the sums over the current one and land under them.
+  float v[LANES];
+  auto fetch = [&](const int tile_no) __attribute__((always_inline)) {
+    const int s = 1 + (tile_no % n_tiles) * LANES + lane;
+#pragma unroll
+    for (int t = 0; t < LANES; ++t) {
+      const int ns_t = __builtin_amdgcn_readlane(ns, t);
+      const int64_t po_t = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(po_hi, t) << 32) | (uint32_t)__builtin_amdgcn_readlane(po_lo, t));
+      const float x = a.S[po_t + min(s, ns_t)];
+      v[t] = s <= ns_t ? x : 0.0f;
+    }
+  };
   float Scorr = 0;
-  for (int d = 1; d <= 4; ++d) {
-    float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;  // S[s - 1] .. S[s - 4]
-    for (int t0 = 1; t0 <= max_ns; t0 += LANES) {
-      {
-        // the tile: row t = steps t0 .. t0 + 63 of template t, one coalesced 256-byte load each - all of them issued before the
-        // first one is used (one trip to memory per tile, not one per template)
-        const int s = t0 + lane;
-        float v[LANES];
+  const int total = 4 * n_tiles;  // tile sequence: d = 1 tiles 0 .. n_tiles-1, d = 2 the same tiles again, ...
+  if (total > 0) fetch(0);
+  for (int seq = 0; seq < total; ++seq) {
+    float* const buf = tile[seq & 1];
 #pragma unroll
-        for (int t = 0; t < LANES; ++t) v[t] = (t < n_here && s <= s_ns[t]) ? a.S[s_po[t] + s] : 0.0f;
-#pragma unroll
-        for (int t = 0; t < LANES; ++t) tile[t * SCORR_PITCH + lane] = v[t];
-      }
-      __syncthreads();
+    for (int t = 0; t < LANES; ++t) buf[t * SCORR_PITCH + lane] = v[t];
+    __syncthreads();  // (one wave: orders the LDS writes of all lanes before the reads below)
+    if (seq + 1 < total) fetch(seq + 1);
+    const int d = 1 + seq / n_tiles, t0 = 1 + (seq % n_tiles) * LANES;
+    // S[s - d] of the first steps of a tile: the last values of the tile before it (zero in front of a pass)
+    static_assert(LANES >= 4, "lag window");
+    float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+    if (seq % n_tiles != 0) {
+      const float* prev = tile[(seq & 1) ^ 1] + lane * SCORR_PITCH;
+      p1 = prev[LANES - 1], p2 = prev[LANES - 2], p3 = prev[LANES - 3], p4 = prev[LANES - 4];
+    }
 #pragma unroll 8
-      for (int u = 0; u < LANES; ++u) {
-        const int s = t0 + u;
-        const float cur = tile[lane * SCORR_PITCH + u];
-        const float prev = d == 1 ? p1 : d == 2 ? p2 : d == 3 ? p3 : p4;
-        const float term = cur * prev;
-        Scorr = (s > d && s <= ns) ? Scorr + term : Scorr;
-        p4 = p3, p3 = p2, p2 = p1, p1 = cur;
-      }
-      __syncthreads();
+    for (int u = 0; u < LANES; ++u) {
+      const int s = t0 + u;
+      const float cur = buf[lane * SCORR_PITCH + u];
+      const float prev = d == 1 ? p1 : d == 2 ? p2 : d == 3 ? p3 : p4;
+      const float term = cur * prev;
+      Scorr = (s > d && s <= ns) ? Scorr + term : Scorr;
+      p4 = p3, p3 = p2, p2 = p1, p1 = cur;
     }
   }
   if (!valid) return;

@@ -52,12 +52,12 @@ def test_limits_are_reported_not_fatal(tmp_path):
     c = capi.Context(local=1)
     qp, qtr, tps, ttrs = small_set(c)
     c.set_query(qp, qtr)
-    # prepare: amino-acid pseudocount mode the device code does not restate
+    # prepare: a pseudocount setting whose admixture leaves [0, 1] (pcm 3 takes its constant from pcb: 0.793 + 0.048 (40 - 10) > 1)
     z = np.load(__file__.replace("test_gpu_errors.py", "golden/gonnet_pb_R.npz"))
     raws = [synth.make_raw_hmm(5, 30)]
     raw, Ls = c.upload_raw([r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws], [r[3] for r in raws])
-    par = capi.prep_params(z["pb"], z["R"], pc=(3, 1.0, 1.5, 1.0))
-    with pytest.raises(capi.HhvError, match="pcm"):
+    par = capi.prep_params(z["pb"], z["R"], pc=(3, 1.0, 40.0, 1.0))
+    with pytest.raises(capi.HhvError, match="pcm 3"):
         c.prepare(raw, Ls, par, synth.PB)
     c.rawset_free(raw)
     # MAC realignment: a template beyond the LDS row state is no limit any more (row state in global memory)

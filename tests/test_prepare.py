@@ -47,14 +47,16 @@ def test_fpow2_bitexact(oracle, ref):
         assert np.float32(a).tobytes() == np.float32(b).tobytes(), x
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(24))
 def test_prepare_restatement_bitexact_synthetic(oracle, ref, seed):
     pb, R = gonnet()
     L = 5 + seed * 17
     f, tr, neff, nh = synth.make_raw_hmm(100 + seed, L)
     # (seeds 12..19: pcc != 1 - src/hhhmm.cpp:1903-1909, where pow(float, float) is the float overload: powf)
+    # (seeds 20..23: pcm 3, the constant-diversity pseudocounts of :1911-1919 - pca is recomputed from pcb there)
     pc = np.array(([[2, 1.0, 1.5, 1.0], [0, 1, 1.5, 1], [1, 0.4, 1.5, 1.0], [2, 0.9, 2.0, 1.0]] if seed < 12 else
-                   [[2, 1.0, 1.5, 0.8], [2, 0.9, 2.0, 1.3], [2, 1.0, 1.5, 2.0], [2, 0.7, 1.0, 0.5]])[seed % 4], np.float32)
+                   [[2, 1.0, 1.5, 0.8], [2, 0.9, 2.0, 1.3], [2, 1.0, 1.5, 2.0], [2, 0.7, 1.0, 0.5]] if seed < 20 else
+                   [[3, 1.0, 1.5, 1.0], [3, 0.3, 4.0, 0.5], [3, 1.0, 12.0, 1.6], [3, 1.0, 2.5, 0.0]])[seed % 4], np.float32)
     gap = po.DEFAULT_GAP.copy()
     if seed % 5 == 0:
         gap[0], gap[1] = 0.3, 0.8
@@ -83,7 +85,8 @@ def test_prepare_restatement_bitexact_real_hhm(oracle, ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("columnscore,pcm,pcc", [(1, 2, 1.0), (0, 2, 1.0), (2, 1, 1.0), (3, 0, 1.0), (1, 2, 0.8), (0, 2, 1.7)])
+@pytest.mark.parametrize("columnscore,pcm,pcc", [(1, 2, 1.0), (0, 2, 1.0), (2, 1, 1.0), (3, 0, 1.0), (1, 2, 0.8), (0, 2, 1.7),
+                                                 (1, 3, 1.0), (2, 3, 1.6)])
 def test_gpu_prepare_matches_oracle(oracle, columnscore, pcm, pcc):
     """(pcc != 1: tau of every raw column comes from the host's powf, hhv_api_prep.cpp ensure_tau - same bits as the reference)"""
     from pyhhv import capi
