@@ -245,6 +245,7 @@ def main():
     ev_gathered = torch.cuda.Event()
 
     kernel_ms = []
+    ag_events = []   # (start, end) of every timed step's all-gather on torch's stream (read after the timed region)
 
     def step(record_ms=True):
         ctx.set_query(qf, qtr)   # H2D of the query is part of a search
@@ -264,7 +265,13 @@ def main():
             cur = torch.cuda.current_stream()
             ev_topk.record(lib_stream)
             cur.wait_event(ev_topk)           # the collective starts when this rank's K records are written
+            if record_ms:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
             dist.all_gather_into_tensor(gathered, topk_buf)
+            if record_ms:
+                e1.record(cur)
+                ag_events.append((e0, e1))
             ev_gathered.record(cur)
             lib_stream.wait_event(ev_gathered)   # the merge starts when the gathered records have arrived
             src = gathered
@@ -287,6 +294,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     merged = merged_buf[merged_buf[:, shard.COL_INDEX] >= 0]
+    # what every rank saw, for an attributable scaling curve: its DP kernel, its all-gather (from the moment its own K records
+    # were ready to the arrival of everybody's: includes the wait for the slowest rank) and its wall time of the timed region
+    ag_ms = [a.elapsed_time(b) for a, b in ag_events]
+    mine = [float(np.mean(kernel_ms)), float(np.min(kernel_ms)), float(np.mean(ag_ms)) if ag_ms else 0.0,
+            float(np.min(ag_ms)) if ag_ms else 0.0, dt / args.steps * 1e3, float(n_local), float(cells_per_rank)]
+    per_rank = [mine]
+    if world > 1:
+        allr = torch.zeros((world, len(mine)), dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_gather_into_tensor(allr, torch.tensor([mine], dtype=torch.float64, device=allr.device))
+        per_rank = allr.cpu().tolist()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -378,6 +395,11 @@ def main():
             "frac_of_fma_peak": kernel_cells_s * OPS_PER_CELL / (VALU_PEAK_FMA_TFLOPS * 1e12),
         },
     }
+    if use_dist:
+        out["per_rank"] = [{"rank": r, "dp_kernel_ms": v[0], "dp_kernel_ms_min": v[1], "all_gather_ms": v[2], "all_gather_ms_min": v[3],
+                            "ms_per_step": v[4], "templates": int(v[5]), "cells": int(v[6])} for r, v in enumerate(per_rank)]
+        out["per_rank_note"] = ("all_gather_ms runs from the moment the rank's own K records are ready to the arrival of every rank's: "
+                                "it contains the wait for the slowest rank; dp_kernel_ms is hhv_stream_kernel alone (HIP events on the library's stream)")
     if n_shards > 1:
         out["config"]["shards"] = {"stream_records_per_shard": [int(x) for x in shard_records],
                                    "templates_per_shard": [int(len(g)) for g in shard_ids],

@@ -928,7 +928,7 @@ static int ensure_paths(hhv_ctx* c, hhv_tset* ts) {
   HIP_TRY(hipMalloc(&ts->d_i_steps, (size_t)off * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&ts->d_j_steps, (size_t)off * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&ts->d_states, (size_t)off * sizeof(int8_t)));
-  HIP_TRY(hipMalloc(&ts->d_S, (size_t)off * sizeof(float)));
+  HIP_TRY(hipMalloc(&ts->d_S, ((size_t)off + 64) * sizeof(float)));  // (+ 64: hhv_scorr_kernel reads whole 64-step tiles)
   HIP_TRY(hipMalloc(&ts->d_hits, (size_t)ts->n * sizeof(DevHit)));
   HIP_TRY(hipMemcpy(ts->d_path_off, ts->path_off.data(), ts->path_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   ts->path_Lq = c->Lq;

@@ -247,11 +247,29 @@ __global__ void __launch_bounds__(64) hhv_rescore_kernel(TraceArgs a) {
 // Kernel 2c: the second half of ScoreForBacktrace - one LANE per template: score = Viterbi score [- score_ss] + corr * Scorr
 // with Scorr = sum over d = 1..4 of sum over steps of S[step] * S[step - d], ONE float accumulator through the four loops
 // in the reference's order (:241-249) - 4 x nsteps dependent additions per template, which one lane of a wave per template
-// used to walk alone (half of the old rescoring kernel's time).  Here 64 templates share a wave; their S rows come through
-// an LDS tile (64 coalesced loads of 256 bytes per 64 steps, transposed on the way out), once per d.
-constexpr int SCORR_PITCH = LANES + 1;
+// used to walk alone (half of the old rescoring kernel's time).  Here 64 templates share a wave.  A lane reads ITS OWN
+// template's S row, 64 steps (256 contiguous bytes, sixteen 16-byte loads) at a time, into registers - the values land in the
+// lane that sums them, nothing is transposed; the tile after the current one is in flight while the current one is summed.
+// (A first version moved 64 x 64 tiles through LDS with one coalesced load per template: 64 scalar address computations per
+// tile made it issue bound - 0.2 ms per 100 k templates; profiles/r4_ab.txt.)
+constexpr int SCORR_TILE = 64;
+struct ScorrState {
+  float acc, p1, p2, p3, p4;  // the accumulator; S[s - 1] .. S[s - 4]
+};
+// one tile of the loop over steps for lag D: steps s0 .. s0 + 63, of which [lo, lim] (tile-relative) take part
+template <int D>
+__device__ __forceinline__ void scorr_tile(ScorrState& z, const float4 (&t)[SCORR_TILE / 4], int lo, int lim) {
+#pragma unroll
+  for (int u = 0; u < SCORR_TILE; ++u) {
+    const float4 q = t[u >> 2];
+    const float cur = (u & 3) == 0 ? q.x : (u & 3) == 1 ? q.y : (u & 3) == 2 ? q.z : q.w;
+    const float prev = D == 1 ? z.p1 : D == 2 ? z.p2 : D == 3 ? z.p3 : z.p4;
+    const float term = cur * prev;
+    z.acc = (u >= lo && u <= lim) ? z.acc + term : z.acc;
+    z.p4 = z.p3, z.p3 = z.p2, z.p2 = z.p1, z.p1 = cur;
+  }
+}
 __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
-  __shared__ float tile[2][LANES * SCORR_PITCH];
   const int lane = threadIdx.x;
   const int k = blockIdx.x * LANES + lane;
   const bool valid = k < a.n;
@@ -260,50 +278,39 @@ __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
   int max_ns = ns;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) max_ns = max(max_ns, __shfl_xor(max_ns, o));
-  const int po_lo = (int)(uint32_t)po, po_hi = (int)(uint32_t)((uint64_t)po >> 32);
-  const int n_tiles = (max_ns + LANES - 1) / LANES;
-  // a tile: row t = steps t0 .. t0 + 63 of template t, ONE coalesced 256-byte load per template; the 64 loads are independent
-  // and unconditional (index clamped into the template's own pool, the value masked afterwards; the template's pool offset
-  // and length come out of the lanes' registers as scalars), so that all of them are in flight together.  The loads of the
-  // next tile are issued before the sums over the current one and land under them.
-  float v[LANES];
-  auto fetch = [&](const int tile_no) __attribute__((always_inline)) {
-    const int s = 1 + (tile_no % n_tiles) * LANES + lane;
+  const int n_tiles = max_ns / SCORR_TILE + 1;  // tile x = steps 64 x .. 64 x + 63 (step 0 is the unused entry of the pool)
+  // a lane never reads beyond the tile that holds its own last step (the pool is followed by the next template's, the last
+  // pool by 64 entries of slack: ensure_paths); what lies behind its last step is masked out of the sums
+  const float4* const row = reinterpret_cast<const float4*>(a.S + po);  // (pools start on multiples of four entries)
+  const int last_tile = ns / SCORR_TILE;
+  float4 v[2][SCORR_TILE / 4];
+  auto fetch = [&](const int seq, float4 (&dst)[SCORR_TILE / 4]) __attribute__((always_inline)) {
+    const float4* p = row + (size_t)min(seq % n_tiles, last_tile) * (SCORR_TILE / 4);
 #pragma unroll
-    for (int t = 0; t < LANES; ++t) {
-      const int ns_t = __builtin_amdgcn_readlane(ns, t);
-      const int64_t po_t = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(po_hi, t) << 32) | (uint32_t)__builtin_amdgcn_readlane(po_lo, t));
-      const float x = a.S[po_t + min(s, ns_t)];
-      v[t] = s <= ns_t ? x : 0.0f;
+    for (int x = 0; x < SCORR_TILE / 4; ++x) dst[x] = p[x];
+  };
+  ScorrState z = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int total = 4 * n_tiles;  // tile sequence: d = 1 tiles 0 .. n_tiles-1, d = 2 the same tiles again, ...
+  auto sum_tile = [&](const int seq, const float4 (&t)[SCORR_TILE / 4]) __attribute__((always_inline)) {
+    const int d = 1 + seq / n_tiles, tile_no = seq % n_tiles;
+    const int lo = tile_no == 0 ? d + 1 : 0;             // the loop of lag d starts at step d + 1 (:241-249)
+    const int lim = ns - tile_no * SCORR_TILE;           // last step of this lane, tile-relative
+    switch (d) {
+      case 1: scorr_tile<1>(z, t, lo, lim); break;
+      case 2: scorr_tile<2>(z, t, lo, lim); break;
+      case 3: scorr_tile<3>(z, t, lo, lim); break;
+      default: scorr_tile<4>(z, t, lo, lim); break;
     }
   };
-  float Scorr = 0;
-  const int total = 4 * n_tiles;  // tile sequence: d = 1 tiles 0 .. n_tiles-1, d = 2 the same tiles again, ...
-  if (total > 0) fetch(0);
-  for (int seq = 0; seq < total; ++seq) {
-    float* const buf = tile[seq & 1];
-#pragma unroll
-    for (int t = 0; t < LANES; ++t) buf[t * SCORR_PITCH + lane] = v[t];
-    __syncthreads();  // (one wave: orders the LDS writes of all lanes before the reads below)
-    if (seq + 1 < total) fetch(seq + 1);
-    const int d = 1 + seq / n_tiles, t0 = 1 + (seq % n_tiles) * LANES;
-    // S[s - d] of the first steps of a tile: the last values of the tile before it (zero in front of a pass)
-    static_assert(LANES >= 4, "lag window");
-    float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
-    if (seq % n_tiles != 0) {
-      const float* prev = tile[(seq & 1) ^ 1] + lane * SCORR_PITCH;
-      p1 = prev[LANES - 1], p2 = prev[LANES - 2], p3 = prev[LANES - 3], p4 = prev[LANES - 4];
-    }
-#pragma unroll 8
-    for (int u = 0; u < LANES; ++u) {
-      const int s = t0 + u;
-      const float cur = buf[lane * SCORR_PITCH + u];
-      const float prev = d == 1 ? p1 : d == 2 ? p2 : d == 3 ? p3 : p4;
-      const float term = cur * prev;
-      Scorr = (s > d && s <= ns) ? Scorr + term : Scorr;
-      p4 = p3, p3 = p2, p2 = p1, p1 = cur;
-    }
+  fetch(0, v[0]);
+  for (int seq = 0; seq < total; seq += 2) {
+    if (seq + 1 < total) fetch(seq + 1, v[1]);
+    sum_tile(seq, v[0]);
+    if (seq + 1 >= total) break;
+    if (seq + 2 < total) fetch(seq + 2, v[0]);
+    sum_tile(seq + 1, v[1]);
   }
+  const float Scorr = z.acc;
   if (!valid) return;
   float score = a.hits[k].viterbi_score;
   // :225-238: score_ss = sum over MM steps of ScoreSS(q,t,i,j) in step order; subtracted when ssm == 2

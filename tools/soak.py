@@ -83,6 +83,71 @@ def viterbi_family(orc, rng, budget):
     return {"cases": cases, "mismatches": bad}
 
 
+def long_family(orc, rng, budget):
+    """Lengths beyond the 2100 columns the fixed tests and viterbi_family stop at, up to the reference's maxres (20 001, src/hhdecl.cpp:11)
+    and the library's own limits in one dimension: many passes (carry rows, the running best across passes), 16-bit column indices,
+    path pools of tens of thousands of steps; ties, -0.0f and dead transitions, a masked second round on the first template."""
+    t_end, cases, bad = time.time() + budget, 0, 0
+    while time.time() < t_end:
+        Lq = int(rng.choice([2101, 3000, 4097, 7777, 12000, 20001, 321, 640]))
+        lt_pool = [2101, 2500, 5000, 9000, 20001, 40000, 65535] if Lq <= 4097 else [77, 1500, 2101, 6000, 20001]
+        local = int(rng.integers(0, 2))
+        par = po.make_params(local=local, egq=float(rng.choice([0.0, 0.2])), egt=float(rng.choice([0.0, 0.1])), ss_mode=0)
+        qp, qtr = synth.make_query(int(rng.integers(1 << 30)), Lq)
+        if rng.random() < 0.5:
+            qtr = quantize(qtr, rng, 0.5)
+            qtr[qtr < -1000] = -100000.0
+            qtr[qtr == 0] = np.float32(-0.0)
+        n = int(rng.integers(1, 4))
+        tps, ttrs = [], []
+        for k in range(n):
+            Lt = int(rng.choice(lt_pool))
+            if Lq * Lt > 4.2e8:
+                Lt = 2101
+            tp, ttr = (synth.make_homolog(int(rng.integers(1 << 30)), qp, L=Lt) if rng.random() < 0.6 else
+                       synth.make_template(int(rng.integers(1 << 30)), Lt))
+            if rng.random() < 0.5:
+                ttr = quantize(ttr, rng, 0.5)
+                ttr[ttr < -1000] = -100000.0
+                ttr[ttr == 0] = np.float32(-0.0)
+            if rng.random() < 0.3:
+                ttr[rng.integers(0, Lt + 1), rng.integers(0, 7)] = -100000.0
+            tps.append(tp)
+            ttrs.append(ttr)
+        c = capi.Context(local=local, egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"], ss_mode=0)
+        c.set_query(qp, qtr)
+        ts = c.upload(tps, ttrs)
+        so = c.align(ts)
+        res = c.align(ts, backtrace=True)
+        hits = c.hits(ts)
+        want = [orc.align(par, qp, qtr, tps[k], ttrs[k], want_path=True) for k in range(n)]
+        for k in range(n):
+            a = want[k]
+            ok = (a.i2, a.j2) == (int(res["i2"][k]), int(res["j2"][k])) == (int(so["i2"][k]), int(so["j2"][k]))
+            ok = ok and np.float32(a.score).tobytes() == np.float32(res["score"][k]).tobytes() == np.float32(so["score"][k]).tobytes()
+            ok = ok and int(hits["nsteps"][k]) == a.nsteps and np.float32(hits["score"][k]).tobytes() == np.float32(a.hit_score).tobytes()
+            if ok:
+                ns, i_s, j_s, st, S = c.hit_path(ts, k)
+                ok = (np.array_equal(i_s[1:ns + 1], a.i_steps[1:ns + 1]) and np.array_equal(j_s[1:ns + 1], a.j_steps[1:ns + 1])
+                      and np.array_equal(st[1:ns + 1], a.states[1:ns + 1]) and np.array_equal(S[1:ns + 1], a.S[1:ns + 1]))
+            cases += 1
+            bad += int(not ok)
+        # second round on template 0: its first path masked (src/hhviterbirunner.cpp:152-164)
+        a = want[0]
+        m = orc.exclude_alignment(Lq, tps[0].shape[0] - 1, a.i_steps, a.j_steps, a.nsteps)
+        c.set_celloff(ts, 0, m)
+        res2 = c.align(ts, celloff=True)
+        hits2 = c.hits(ts)
+        b = orc.align(par, qp, qtr, tps[0], ttrs[0], celloff=m, want_path=True)
+        ok = ((b.i2, b.j2) == (int(res2["i2"][0]), int(res2["j2"][0])) and np.float32(b.score).tobytes() == np.float32(res2["score"][0]).tobytes()
+              and int(hits2["nsteps"][0]) == b.nsteps and np.float32(hits2["score"][0]).tobytes() == np.float32(b.hit_score).tobytes())
+        cases += 1
+        bad += int(not ok)
+        ts.free()
+        c.close()
+    return {"cases": cases, "mismatches": bad}
+
+
 def fast_family(orc, rng, budget):
     """The opt-in fused-emission build (libhhviterbi_hip_fma.so): bit for bit against the oracle's restatement of its arithmetic
     (emission mode 2), and against the reference's arithmetic (mode 0): how many end points / alignments change, largest score
@@ -263,8 +328,9 @@ def prepare_family(orc, rng, budget):
             if rng.random() < 0.2:
                 neff[:, 0] = 1.0        # Neff_M = 1: (nM - 1) = 0 in the transition pseudocounts
             raws.append((f, tr, neff, nh))
-        pcm = int(rng.integers(0, 3))
-        pc = np.array([pcm, float(rng.choice([1.0, 0.4, 0.0, 0.85])), float(rng.choice([1.5, 0.5, 4.0])), 1.0], np.float32)
+        pcm = int(rng.integers(0, 4))   # (pcm 3 takes its admixture constant from pcb: 0.793 + 0.048 (pcb - 10) is in [0, 1] for these)
+        pc = np.array([pcm, float(rng.choice([1.0, 0.4, 0.0, 0.85, 1.7 if pcm == 2 else 1.0])), float(rng.choice([1.5, 0.5, 4.0])),
+                       float(rng.choice([1.0, 1.0, 0.7, 1.6]))], np.float32)
         gap = np.array([rng.choice([0.15, 1.0]), rng.choice([1.0, 0.3, 2.0]), 0.6, rng.choice([0.6, 1.0]), 0.6, 0.6,
                         rng.choice([1.0, 0.0, 2.5])], np.float32)
         cs = int(rng.integers(0, 4))
@@ -289,10 +355,11 @@ def main():
     fam = sys.argv[3] if len(sys.argv) > 3 else "all"
     if fam != "all":
         print(json.dumps({fam: {"prefilter": prefilter_family, "mac": mac_family, "viterbi": viterbi_family, "prepare": prepare_family,
-                                "fast": fast_family}[fam](orc, rng, budget)}))
+                                "fast": fast_family, "long": long_family}[fam](orc, rng, budget)}))
         return
     out = {"seconds_per_family": budget,
            "viterbi_backtrace_celloff": viterbi_family(orc, rng, budget),
+           "viterbi_long_profiles": long_family(orc, rng, budget),
            "prefilter": prefilter_family(orc, rng, budget),
            "mac_realign": mac_family(orc, rng, budget),
            "prepare": prepare_family(orc, rng, budget)}
