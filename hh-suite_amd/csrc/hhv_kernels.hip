@@ -141,16 +141,48 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   if (a.plan.P == 1) {
     const int R = a.plan.R_hi, W = a.plan.W;
     constexpr int WIN = 5;
+    // Small sets (a.speculate): a few hundred wavefronts cannot hide the trip to HBM of every window, the walk is a chain of
+    // (load, walk) rounds - so the window the walk will need NEXT if it stays on the diagonal (the paths of real searches do
+    // for ~96 % of their steps) is requested together with the current one and has arrived when the walk gets there; a walk
+    // that leaves the diagonal pays an ordinary round.  Large sets are bound by memory transactions, not latency: there the
+    // extra requests of the missed guesses would cost more than the hits save.
+    uint64_t w[WIN][2], wn[WIN][2];
+    int spec_i = -1, spec_j = -1;  // cell the prefetched window `wn` is anchored at
+    auto load_window = [&](int ci, int cj, uint64_t (&dst)[WIN][2]) __attribute__((always_inline)) {
+      const int g0 = ci >= 1 ? (ci - 1) / R : 0;
+      const int c0 = max(g0 - 1, 0);
+      const int64_t row0 = rec0 + cj + g0;
+#pragma unroll
+      for (int d = 0; d < WIN; ++d) {
+        const uint64_t* e = a.bt + (size_t)max<int64_t>(row0 - d, 0) * (size_t)W + (size_t)c0;
+        dst[d][0] = e[0];
+        dst[d][1] = e[1];
+      }
+    };
     while (state != 0) {
       const int g0 = i >= 1 ? (i - 1) / R : 0;
       const int c0 = max(g0 - 1, 0);       // first of the two columns of the window (c0 + 1 <= W - 1)
       const int64_t row0 = rec0 + j + g0;  // row of the entry of (i, j)
-      uint64_t w[WIN][2];
+      if (a.speculate && i == spec_i && j == spec_j) {
 #pragma unroll
-      for (int d = 0; d < WIN; ++d) {
-        const uint64_t* e = a.bt + (size_t)max<int64_t>(row0 - d, 0) * (size_t)W + (size_t)c0;
-        w[d][0] = e[0];
-        w[d][1] = e[1];
+        for (int d = 0; d < WIN; ++d) w[d][0] = wn[d][0], w[d][1] = wn[d][1];
+      } else {
+        load_window(i, j, w);
+      }
+      if (a.speculate) {
+        // where a purely diagonal walk leaves this window: every step lowers the row by one, by two when it crosses into
+        // the lane above (same test as the walk below)
+        int pi = i, pj = j;
+#pragma unroll
+        for (int sub = 0; sub < WIN + 1; ++sub) {
+          if (pi < 1 || pj < 1) break;
+          const int g = (pi - 1) / R;
+          if ((int)(row0 - (rec0 + pj + g)) >= WIN || g - c0 < 0) break;
+          --pi, --pj;
+        }
+        spec_i = pi, spec_j = pj;
+        if (pi >= 1 && pj >= 1 && (pi != i || pj != j)) load_window(pi, pj, wn);
+        else spec_i = -1;
       }
 #pragma unroll
       for (int sub = 0; sub < WIN + 1; ++sub) {

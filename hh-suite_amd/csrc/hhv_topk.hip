@@ -37,7 +37,7 @@ template <bool FROM_HITS>
 __global__ void __launch_bounds__(SEL_THREADS) topk_select_kernel(const DevHit* __restrict__ hits, const uint64_t* __restrict__ in_keys,
                                                                   int n, int k, uint64_t* __restrict__ out_keys) {
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t sh_digit, sh_krem, sh_valid, sh_out;
+  __shared__ uint32_t sh_digit, sh_krem, sh_valid, sh_out, sh_all;
   const int base = blockIdx.x * SEL_CHUNK;
   uint64_t key[SEL_PER_THREAD];
   int mine = 0;
@@ -88,21 +88,37 @@ __global__ void __launch_bounds__(SEL_THREADS) topk_select_kernel(const DevHit* 
         if (act) atomicAdd(&hist[d], 1u);
       }
       __syncthreads();
-      if (threadIdx.x < 256) {
-        // suffix[t] = number of candidates whose byte is >= t; the byte of the krem-th largest is the one with
-        // suffix[t] >= krem > suffix[t + 1]
-        uint32_t above = 0;
-        for (int x = (int)threadIdx.x + 1; x < 256; ++x) above += hist[x];
-        const uint32_t here = above + hist[threadIdx.x];
-        if (here >= krem && above < krem) {
-          sh_digit = threadIdx.x;
-          sh_krem = krem - above;
+      if (threadIdx.x < 64) {
+        // suffix scan by the first wave: lane l holds bins 4 l .. 4 l + 3; `above` = candidates in the bins above bin b.  The
+        // byte of the krem-th largest key is the bin with above < krem <= above + hist[b].
+        const uint32_t h0 = hist[4 * threadIdx.x], h1 = hist[4 * threadIdx.x + 1], h2 = hist[4 * threadIdx.x + 2], h3 = hist[4 * threadIdx.x + 3];
+        const uint32_t own = h0 + h1 + h2 + h3;
+        uint32_t incl = own;  // sum over lanes >= this one
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_down((int)incl, o);
+          if ((int)threadIdx.x + o < 64) incl += up;
+        }
+        const uint32_t above_lane = incl - own;  // candidates in the bins of higher lanes
+        const uint32_t a3 = above_lane, a2 = a3 + h3, a1 = a2 + h2, a0 = a1 + h1;
+        int b = -1;
+        uint32_t ab = 0, hb = 0;
+        if (a3 < krem && krem <= a3 + h3) b = 3, ab = a3, hb = h3;
+        else if (a2 < krem && krem <= a2 + h2) b = 2, ab = a2, hb = h2;
+        else if (a1 < krem && krem <= a1 + h1) b = 1, ab = a1, hb = h1;
+        else if (a0 < krem && krem <= a0 + h0) b = 0, ab = a0, hb = h0;
+        if (b >= 0) {
+          sh_digit = 4 * threadIdx.x + b;
+          sh_krem = krem - ab;
+          sh_all = (krem - ab) == hb;  // every key of this bin is taken: the bytes below do not matter any more
         }
       }
       __syncthreads();
       prefix |= (uint64_t)sh_digit << shift;
       krem = sh_krem;
+      const bool all_of_bin = sh_all != 0;
       __syncthreads();
+      if (all_of_bin) break;  // T = the smallest key with this prefix: exactly k keys are >= it
     }
     T = prefix;
   }
