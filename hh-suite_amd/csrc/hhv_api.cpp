@@ -968,12 +968,6 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.ss_q_off = c->ss_hmm_mode ? c->d_ss_q_off : nullptr;
   a.ss_t_shift = c->ss_t_shift;
   a.ss_t_mask = c->ss_t_mask;
-  {
-    // below ~32 k templates the walk is a chain of round trips (one wavefront per 64 templates, fewer wavefronts than SIMDs:
-    // nothing hides the latency): speculate on the diagonal; above, memory transactions bound the kernel (hhv_kernels.hip)
-    static const char* env = getenv("HHV_TRACE_SPECULATE");
-    a.speculate = env ? atoi(env) : (ts->n <= 32768 ? 1 : 0);
-  }
   rc = launch_trace(a, c->stream);
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   ts->hits_valid = true;

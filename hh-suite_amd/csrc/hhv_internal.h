@@ -139,7 +139,6 @@ struct TraceArgs {
   const float* ss_table;     // null: no secondary-structure information (score_ss = 0)
   const int32_t* ss_q_off;
   int32_t ss_t_shift, ss_t_mask;
-  int32_t speculate;         // trace kernel: prefetch the window a diagonal walk needs next (small sets: latency bound)
 };
 
 // raw (unprepared) template column, 32 dwords: the fields of the reference's HMM after HMM::Read

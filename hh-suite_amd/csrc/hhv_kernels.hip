@@ -107,11 +107,18 @@ __device__ __forceinline__ void trace_step(int& state, int& i, int& j, int& matc
 // (bt_entry: row = record + lane; a step lowers i and / or j by one), so the ten entries {row .. row - 4} x {g - 1, g} -
 // five independent 16-byte reads - cover the next two steps at least, four on a diagonal; the walk continues out of
 // registers until it leaves the window.
-// What the walk WRITES is one byte per step, the state (round 4): the kernel is bound by memory transactions - 64 lanes on
-// 64 different paths, every access its own 64-byte sector - and i_steps / j_steps (two scattered 4-byte stores per step and
-// lane) follow from the states and the end point: every recorded step but the last lowers i (MM, DG, MI) and / or j (MM, GD,
-// IM) by one.  hhv_rescore_kernel, which needs (i, j) of every step anyway, rebuilds them with two ballots per 64 steps and
-// writes them as contiguous 256-byte rows.  The state bytes leave in words of four (pools start on multiples of four).
+// What the walk WRITES is one byte per step, the state (round 4): with large sets the kernel is bound by memory
+// transactions - 64 lanes on 64 different paths, every access its own 64-byte sector - and i_steps / j_steps (two scattered
+// 4-byte stores per step and lane) follow from the states and the end point: every recorded step but the last lowers i
+// (MM, DG, MI) and / or j (MM, GD, IM) by one.  hhv_rescore_kernel, which needs (i, j) of every step anyway, rebuilds them
+// with two ballots per 64 steps and writes them as contiguous 256-byte rows.  The state bytes leave in words of four (pools
+// start on multiples of four).
+// With small sets (fewer wavefronts than SIMDs) the walk's own instructions are the time: RC / MMC = rows per lane and
+// encoding of the MM predecessor as compile-time constants for the single-pass plans (the row -> lane division and the
+// decoder's shifts fold), 0 = run-time values (multi-pass plans).  (Requesting the window a diagonal walk needs next together
+// with the current one - the paths of the benchmark are 96 % diagonal - made the kernel slower at 10 k templates as well as
+// at 100 k, 253 -> 305 us and 608 -> 640 us: the loads were not what a round waits for.  profiles/r4_ab.txt.)
+template <int RC, int MMC>
 __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.n) return;
@@ -138,51 +145,20 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
       sbuf = 0;
     }
   };
-  if (a.plan.P == 1) {
-    const int R = a.plan.R_hi, W = a.plan.W;
+  if (RC > 0) {
+    constexpr int R = RC > 0 ? RC : 1;
+    const int W = a.plan.W;
     constexpr int WIN = 5;
-    // Small sets (a.speculate): a few hundred wavefronts cannot hide the trip to HBM of every window, the walk is a chain of
-    // (load, walk) rounds - so the window the walk will need NEXT if it stays on the diagonal (the paths of real searches do
-    // for ~96 % of their steps) is requested together with the current one and has arrived when the walk gets there; a walk
-    // that leaves the diagonal pays an ordinary round.  Large sets are bound by memory transactions, not latency: there the
-    // extra requests of the missed guesses would cost more than the hits save.
-    uint64_t w[WIN][2], wn[WIN][2];
-    int spec_i = -1, spec_j = -1;  // cell the prefetched window `wn` is anchored at
-    auto load_window = [&](int ci, int cj, uint64_t (&dst)[WIN][2]) __attribute__((always_inline)) {
-      const int g0 = ci >= 1 ? (ci - 1) / R : 0;
-      const int c0 = max(g0 - 1, 0);
-      const int64_t row0 = rec0 + cj + g0;
-#pragma unroll
-      for (int d = 0; d < WIN; ++d) {
-        const uint64_t* e = a.bt + (size_t)max<int64_t>(row0 - d, 0) * (size_t)W + (size_t)c0;
-        dst[d][0] = e[0];
-        dst[d][1] = e[1];
-      }
-    };
     while (state != 0) {
       const int g0 = i >= 1 ? (i - 1) / R : 0;
       const int c0 = max(g0 - 1, 0);       // first of the two columns of the window (c0 + 1 <= W - 1)
       const int64_t row0 = rec0 + j + g0;  // row of the entry of (i, j)
-      if (a.speculate && i == spec_i && j == spec_j) {
+      uint64_t w[WIN][2];
 #pragma unroll
-        for (int d = 0; d < WIN; ++d) w[d][0] = wn[d][0], w[d][1] = wn[d][1];
-      } else {
-        load_window(i, j, w);
-      }
-      if (a.speculate) {
-        // where a purely diagonal walk leaves this window: every step lowers the row by one, by two when it crosses into
-        // the lane above (same test as the walk below)
-        int pi = i, pj = j;
-#pragma unroll
-        for (int sub = 0; sub < WIN + 1; ++sub) {
-          if (pi < 1 || pj < 1) break;
-          const int g = (pi - 1) / R;
-          if ((int)(row0 - (rec0 + pj + g)) >= WIN || g - c0 < 0) break;
-          --pi, --pj;
-        }
-        spec_i = pi, spec_j = pj;
-        if (pi >= 1 && pj >= 1 && (pi != i || pj != j)) load_window(pi, pj, wn);
-        else spec_i = -1;
+      for (int d = 0; d < WIN; ++d) {
+        const uint64_t* e = a.bt + (size_t)max<int64_t>(row0 - d, 0) * (size_t)W + (size_t)c0;
+        w[d][0] = e[0];
+        w[d][1] = e[1];
       }
 #pragma unroll
       for (int sub = 0; sub < WIN + 1; ++sub) {
@@ -196,7 +172,7 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
           uint64_t entry = c ? w[0][1] : w[0][0];
 #pragma unroll
           for (int t = 1; t < WIN; ++t) entry = (d == t) ? (c ? w[t][1] : w[t][0]) : entry;
-          b = bt_decode(entry, rr, R, a.bt_mm);
+          b = bt_decode(entry, rr, R, MMC);
         }
         walk(b);
       }
@@ -405,7 +381,21 @@ int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, boo
 
 int launch_trace(const TraceArgs& a, void* stream) {
   // 64 templates per wave for the chase (latency bound: many small blocks spread over all CUs)
-  hipLaunchKernelGGL(hhv_trace_kernel, dim3((a.n + LANES - 1) / LANES), dim3(LANES), 0, (hipStream_t)stream, a);
+  {
+    const dim3 grid((a.n + LANES - 1) / LANES), block(LANES);
+    hipStream_t st = (hipStream_t)stream;
+    const int R = a.plan.P == 1 ? a.plan.R_hi : 0;
+#define HHV_TRACE_CASE(r, m)                                                       \
+  if (R == r && a.bt_mm == m) {                                                    \
+    hipLaunchKernelGGL((hhv_trace_kernel<r, m>), grid, block, 0, st, a);           \
+  } else
+#define HHV_TRACE_ROWS(r) HHV_TRACE_CASE(r, BT_MM_RUNNING) HHV_TRACE_CASE(r, BT_MM_FIRST_EQUAL) HHV_TRACE_CASE(r, BT_MM_FIRST_EQUAL_NEG)
+    HHV_TRACE_ROWS(1) HHV_TRACE_ROWS(2) HHV_TRACE_ROWS(3) HHV_TRACE_ROWS(4) HHV_TRACE_ROWS(5) {
+      hipLaunchKernelGGL((hhv_trace_kernel<0, 0>), grid, block, 0, st, a);
+    }
+#undef HHV_TRACE_ROWS
+#undef HHV_TRACE_CASE
+  }
   hipLaunchKernelGGL(hhv_rescore_kernel, dim3(a.n), dim3(LANES), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(hhv_scorr_kernel, dim3((a.n + LANES - 1) / LANES), dim3(LANES), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
