@@ -65,7 +65,7 @@ VALU_PEAK_FMA_TFLOPS = 157.3
 # measured: two waves per SIMD of a 64-thread / 248-VGPR kernel retire one v_add_f32 wave-instruction per 2.25 clk (nominal
 # 2.4 GHz) per SIMD - tools/gen_shape_ubench.py, profiles/r2_shape_ubench.txt
 MEASURED_ISSUE_CEILING = 256 * 4 * 64 / 2.25 * 2.4e9
-PROFILE_JSONS = ("r3_summary.json", "r2_summary.json")   # newest committed PMC profile of the headline command first
+PROFILE_JSONS = ("r4_summary.json", "r3_summary.json", "r2_summary.json")   # newest committed PMC profile of the headline command first
 REC_BYTES = 112
 OPS_PER_CELL = 92          # SURVEY.md 8d / BASELINE.md 5: fp32 operations per DP cell of the reference
 ZIPF_SEED = 0x21F          # the ONE seed of configs[4]'s global length vector
@@ -654,14 +654,15 @@ def configs2(args, torch, ctx, ts, rec, rec_off, Ls, qf, qtr, Lq, Lt, K):
              "backtrace_bytes_written_per_launch": int(ts.records()) * 512}
         if ts.n == 100000 and Lq == 300 and Lt == 300:
             try:   # the backtrace kernel's executed VALU instructions and HBM traffic from its own committed counters
-                with open(os.path.join(ROOT, "profiles", "r3bt_summary.json")) as f:
+                bt_json = "r4bt_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r4bt_summary.json")) else "r3bt_summary.json"
+                with open(os.path.join(ROOT, "profiles", bt_json)) as f:
                     prof = json.load(f)
                 lane_ops = prof["valu_wave_instr_per_launch"] * 64.0
                 e["roofline_valu"] = {"valu_wave_instr_per_launch": prof["valu_wave_instr_per_launch"],
                                       "valu_lane_instr_per_cell": lane_ops / ts.cells(),
                                       "frac_of_issue_peak": lane_ops / (kms * 1e-3) / VALU_PEAK_LANEOPS,
                                       "frac_reference_flops": ts.cells() / (kms * 1e-3) * OPS_PER_CELL / VALU_PEAK_LANEOPS,
-                                      "source": "profiles/r3bt_summary.json (SQ_INSTS_VALU per launch) / dp_kernel_ms of this run"}
+                                      "source": "profiles/%s (SQ_INSTS_VALU per launch) / dp_kernel_ms of this run" % bt_json}
                 e["roofline_hbm"] = {"traffic_bytes_per_launch": prof["traffic_bytes_per_launch"],
                                      "algorithmic_bytes_per_launch": int(ts.records()) * REC_BYTES + ts.n * 16 + int(ts.cells()),
                                      "achieved_GBs": prof["traffic_bytes_per_launch"] / (kms * 1e-3) / 1e9,

@@ -591,8 +591,29 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // (and with two waves per SIMD, most of the SIMD) for its whole latency.
   float4 ncar = make_float4(0.f, 0.f, 0.f, 0.f);
   float nmi = 0.f;
+  // CB (round 4): the carry rows come in BLOCKS instead - once per ring chunk lanes 0 .. C-1 load the rows of the C positions
+  // lane 0 will stand on during the chunk AFTER the next refill (one coalesced load, a whole chunk of steps ahead, retired by
+  // the chunk boundary's own vmcnt(0)); in a step lane 0 takes its row out of the lane that holds it (five v_readlane with a
+  // wave-uniform index).  No global load and no address arithmetic in the step, nothing a step has to wait for.
+#ifndef HHV_CARRY_BLOCK
+#define HHV_CARRY_BLOCK 1
+#endif
+  constexpr bool CB = MULTI && HHV_CARRY_BLOCK != 0;
+  float cb_cur[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, cb_nxt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  int cb_base = -LEAD;  // position held by lane 0 of cb_cur
+  auto carry_block_load = [&](const int blk) __attribute__((always_inline)) {
+    const int p = blk * C - LEAD + lane;  // block blk = the positions of chunk-loop iteration blk
+    if (lane < C && p >= 0 && p < M) {
+      const size_t rn = DQV ? (size_t)record_of(p) : (size_t)(rb + p);
+      const float4 v = a.carry[rn];
+      cb_nxt[0] = v.x, cb_nxt[1] = v.y, cb_nxt[2] = v.z, cb_nxt[3] = v.w;
+      cb_nxt[4] = a.carry_mi[rn];
+    }
+  };
   if (MULTI && !first) {
-    if (lane == 0 && M > 0) {
+    if (CB) {
+      carry_block_load(0);
+    } else if (lane == 0 && M > 0) {
       ncar = a.carry[rb];  // (work queue: rb = the first record of the wave's first segment)
       nmi = a.carry_mi[rb];
     }
@@ -661,12 +682,21 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     const int jcol = meta & (int)k_jmask;  // column index of a column record
     Incoming in = boundary_incoming(meta, jcol, P);
     if (MULTI && !first) {
+      float c0 = ncar.x, c1 = ncar.y, c2 = ncar.z, c3 = ncar.w, c4 = nmi;
+      if (CB) {
+        const int idx = s - cb_base;  // wave uniform, 0 .. C-1
+        c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[0]), idx));
+        c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[1]), idx));
+        c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[2]), idx));
+        c3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[3]), idx));
+        c4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[4]), idx));
+      }
       if (lane == 0 && active) {
-        in.MM = ncar.x;
-        in.GD = ncar.y;
-        in.IM = ncar.z;
-        in.DG = ncar.w;
-        in.MI = nmi;
+        in.MM = c0;
+        in.GD = c1;
+        in.IM = c2;
+        in.DG = c3;
+        in.MI = c4;
         if (meta < 0 && st.tid >= 0) {
           const DevResult pr = a.results[st.tid & TID_MASK];
           in.fs = pr.score;
@@ -676,7 +706,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       // the carry row of the next step is requested only now, behind the copies that consumed this step's row: the load
       // lands in the same registers and is not waited for before the next step (requested inside the block above, hipcc
       // loads into temporaries, copies and waits for the round trip on the spot)
-      if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
+      if (!CB && lane == 0 && active && r + 1 < M) {  // lane 0: r = s
         const size_t rn = DQV ? (size_t)record_of(r + 1) : (size_t)(rb + r + 1);
         ncar = a.carry[rn];
         nmi = a.carry_mi[rn];
@@ -768,6 +798,13 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
       }
     }
     const int s_lo = c > 0 ? c * C - LEAD : 0, s_hi = min((c + 1) * C - LEAD, s_end);
+    if (CB && !first) {
+      // the block requested a chunk ago has landed (the wait above; at c = 0 the compiler's own); request the next one
+#pragma unroll
+      for (int x = 0; x < 5; ++x) cb_cur[x] = cb_nxt[x];
+      cb_base = c * C - LEAD;
+      carry_block_load(c + 1);
+    }
     if (PF && !MULTI) {
       // unrolled by two: the heads alternate between col and col2, no copy between the steps
       int s = s_lo;

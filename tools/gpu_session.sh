@@ -44,6 +44,26 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4e)   # trace kernel specialised on (R, encoding): parity + kernel trace; then the round's profiles (r4, r4bt)
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_configs.py tests/test_gpu_queue.py tests/test_gpu_ss.py tests/test_gpu_lengths.py -q -m gpu 2>&1 | tail -5
+  for n in 100000 10000; do
+    echo "== backtrace searches over $n templates"
+    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bt && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bt -o stats -- python $ROOT/bench.py --lq 300 --templates $n --backtrace 1 --steps 5 --warmup 2 $short > /tmp/prof_bt.log 2>&1)
+    python - <<'PY'
+import csv, glob
+for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"]:
+            print("%-60s calls %5s  avg %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+  done
+  for tag in r4 r4bt; do
+    extra=""; [ $tag = r4bt ] && extra="--backtrace 1"
+    bash tools/profile.sh $tag "$extra" > $OUT/profile_$tag.log 2>&1
+    HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_profile.py $tag | tail -34
+    rm -rf $OUT/prof_$tag
+  done
+  ;;
 r4d)   # trace speculation on / off at 10 k and 100 k, scorr in registers, top-K select with early exit: parity + kernel trace
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_merge.py tests/test_gpu_configs.py tests/test_gpu_queue.py tests/test_gpu_ss.py tests/test_gpu_runner.py tests/test_gpu_fullsize.py -q -m gpu 2>&1 | tail -8
   for spec in 0 1; do for n in 100000 10000; do
