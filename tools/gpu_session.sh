@@ -44,6 +44,10 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4f)   # carry rows of the multi-pass variants in blocks (lanes 0..31 load a chunk of rows ahead, lane 0 takes its row by v_readlane): parity + A/B
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_lengths.py tests/test_gpu_queue.py -q -m gpu 2>&1 | tail -5
+  HHV_AB_LIBS="nocb hip" HHV_AB_REPS=2 HHV_AB_CFGS="--lq 431 --templates 50000|--lq 431 --templates 50000 --backtrace 1|--lq 700 --templates 30000|--lq 1000 --lt 500 --templates 20000|--lq 2000 --lt 300 --templates 10000 --local 1" bash tools/gpu_ab.sh
+  ;;
 r4e)   # trace kernel specialised on (R, encoding): parity + kernel trace; then the round's profiles (r4, r4bt)
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_configs.py tests/test_gpu_queue.py tests/test_gpu_ss.py tests/test_gpu_lengths.py -q -m gpu 2>&1 | tail -5
   for n in 100000 10000; do
