@@ -598,8 +598,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 #ifndef HHV_CARRY_BLOCK
 #define HHV_CARRY_BLOCK 1
 #endif
-  // (not the local five-row score-only variants: 256 VGPRs do not hold two blocks next to the per-row best)
-  constexpr bool CB = MULTI && HHV_CARRY_BLOCK != 0 && !(R == 5 && LOCAL && !BT);
+  constexpr bool CB = MULTI && HHV_CARRY_BLOCK != 0;
   float cb_cur[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, cb_nxt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   int cb_base = -LEAD;  // position held by lane 0 of cb_cur
   auto carry_block_load = [&](const int blk) __attribute__((always_inline)) {
