@@ -526,11 +526,11 @@ __global__ void __launch_bounds__(256) celloff_clear_kernel(CellOffGeom g, const
   __syncthreads();
   for (int q = 0; q < n_q; ++q) {
     const int lo = ranges[2 * q], hi = min(ranges[2 * q + 1], g.Lq);
-    for (int c = threadIdx.x; c < (hi - lo + 1) * Lt; c += 256) celloff_set(g, t, lo + c / Lt, 1 + c % Lt);
+    for (int64_t c = threadIdx.x; c < (int64_t)(hi - lo + 1) * Lt; c += 256) celloff_set(g, t, lo + (int)(c / Lt), 1 + (int)(c % Lt));
   }
   for (int q = 0; q < n_t; ++q) {
     const int lo = ranges[2 * (n_q + q)], hi = min(ranges[2 * (n_q + q) + 1], Lt);
-    for (int c = threadIdx.x; c < (hi - lo + 1) * g.Lq; c += 256) celloff_set(g, t, 1 + c % g.Lq, lo + c / g.Lq);
+    for (int64_t c = threadIdx.x; c < (int64_t)(hi - lo + 1) * g.Lq; c += 256) celloff_set(g, t, 1 + (int)(c % g.Lq), lo + (int)(c / g.Lq));
   }
 }
 

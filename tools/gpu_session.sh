@@ -29,7 +29,10 @@ check)
     timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
   done
   echo "== soak, $soak_s s per family"
-  timeout $((soak_s * 6 + 120)) python tools/soak.py $soak_s > $OUT/soak.json 2> $OUT/soak.err; cat $OUT/soak.json; tail -2 $OUT/soak.err
+  timeout $((soak_s * 7 + 180)) python tools/soak.py $soak_s > $OUT/soak.json 2> $OUT/soak.err; cat $OUT/soak.json; tail -2 $OUT/soak.err
+  echo "== the native multi-rank program, one rank through RCCL (examples/sharded_search_rccl.cpp)"
+  timeout 300 ./build/sharded_search_rccl --world 1 --templates 20000 --steps 5 --check 2>&1 | tail -4
+  timeout 300 ./build/sharded_search_rccl --world 1 --templates 20000 --steps 5 --backtrace 2>&1 | tail -3
   ;;
 ab)
   bash tools/gpu_ab.sh "$@"
