@@ -390,22 +390,37 @@ struct LdsColumn {
 // SS = secondary-structure term added to the emission score (the reference's ...AndSS builds).
 // W = lanes per systolic array: 64, or - short queries, single pass - 32 / 16: the wave is 2 / 4 independent arrays, array
 //     a = lane / W walking the stream range wave_rec[blockIdx * (64 / W) + a]; every array has its own ring section.
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W>
-__global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
+// LDS of one wavefront: [QL block][ring][best slots]
+template <int R, bool BT, int W>
+struct StreamSmem {
+  // five-row backtrace variants: {m2i, i2i} and {m2d, d2d} of the lane's R query rows live in LDS (20 floats per lane; the
+  // 20-dword stride is conflict-free for ds_read_b128) - the VGPRs they would occupy hold the compare results instead.
+  static constexpr bool QL = BT && R == 5;  // (up to four rows per lane the registers hold the query's gap transitions as well)
+  static constexpr int QL_F4 = QL ? LANES * 5 : 0;
+  static constexpr int BEST_F4 = W == LANES ? LANES / 2 : 0;  // 8 bytes per lane: the finalized best on its way to the next lane
+  static constexpr int F4 = QL_F4 + RING_RECS * 7 + BEST_F4;
+};
+
+// The body of the kernel for ONE wavefront; `array0` = number of its first systolic array (the workgroup number for the
+// one-wave kernel).  Its LDS (StreamSmem<R, BT, W>::F4 float4) is a static object of the instantiation: constant addresses, and
+// the two bodies of a pair kernel get two disjoint objects.
+// PM (pair mode): 0 = the wavefront is a workgroup of its own; 1 / 2 = first / second wavefront of a two-wave workgroup that
+// aligns a query of two strips in ONE launch (hhv_pair_kernel below).
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, int PM>
+__device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0) {
+  __shared__ float4 smem[StreamSmem<R, BT, W>::F4];
+  const int lane = PM == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LANES - 1));
   static_assert(W == 64 || W == 32 || W == 16, "lanes per array");
   static_assert(!MULTI || W == LANES, "short-query arrays are single pass");
   constexpr int A = LANES / W;   // arrays per wave
   constexpr int C = W / 2;       // records per ring chunk and array (the live window of W records spans <= 3 chunks)
   static_assert(RING_CHUNKS == 4 && CHUNK_RECS == 32 && A * C == CHUNK_RECS, "ring geometry");
-  // five-row backtrace variants: {m2i, i2i} and {m2d, d2d} of the lane's R query rows live in LDS (20 floats per lane; the
-  // 20-dword stride is conflict-free for ds_read_b128) - the VGPRs they would occupy hold the compare results instead.
-  // ONE __shared__ object: [QL block][ring].
-  constexpr bool QL = BT && R == 5;  // (up to four rows per lane the registers hold the query's gap transitions as well)
-  constexpr int QL_F4 = QL ? LANES * 5 : 0;
-  constexpr int BEST_F4 = W == LANES ? LANES / 2 : 0;  // 8 bytes per lane: the finalized best on its way to the next lane
-  __shared__ float4 smem[QL_F4 + RING_RECS * 7 + BEST_F4];
+  // SHARE: (MM(i-1,j-1) + q.M2M) and (MI(i-1,j-1) + q.M2M) are computed once and carried (viterbi_lane.h LaneState::aMM / aMI:
+  // two additions per row and step less for ten registers) - everywhere but in the one variant that has no register for them
+  constexpr bool SHARE = !(LOCAL && R == 5 && !BT && MULTI && SS);
+  constexpr bool QL = StreamSmem<R, BT, W>::QL;
+  constexpr int QL_F4 = StreamSmem<R, BT, W>::QL_F4;
   float4* const ring = smem + QL_F4;
-  const int lane = threadIdx.x;
   const int g = lane & (W - 1);  // lane of the array
   const int arr = lane / W;
 #if defined(HHV_EXP_WAVETIME)
@@ -432,7 +447,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     bool any = false;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      any |= wq[j].start(a.seg_first, a.n_seg, (int)blockIdx.x * A + j);
+      any |= wq[j].start(a.seg_first, a.n_seg, array0 * A + j);
       rb_a[j] = wq[j].delta();
       M_a[j] = nch_a[j] = wq[j].end;
       Mmax = max(Mmax, M_a[j]);
@@ -441,7 +456,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   } else {
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      const int64_t b0 = a.wave_rec[blockIdx.x * A + j], e0 = a.wave_rec[blockIdx.x * A + j + 1];
+      const int64_t b0 = a.wave_rec[array0 * A + j], e0 = a.wave_rec[array0 * A + j + 1];
       rb_a[j] = b0;
       M_a[j] = e0 > b0 ? (int)(e0 - b0) + 1 : 0;  // the range's records plus the next header (finalizes the last template)
       if (A == 1) {  // wave uniform, but loaded through the vector path: into SGPRs
@@ -530,7 +545,8 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   // variants the phase-A query-transition reads are deferred as well (SPLIT_A).  Measured in one session each
   // (tools/gpu_ab.sh): score-only -2 %, multi-pass -0.8 %, backtrace -0.5 %.
   // (not the local five-row single-pass variants: 256 VGPRs do not hold the prefetched head next to the per-row best)
-  constexpr bool PF = !CELLOFF && !SS && W == LANES && !(LOCAL && R == 5 && !MULTI);
+  // (nor the local five-row score-only multi-pass ones: with the body as a function of its own they spilled three registers)
+  constexpr bool PF = !CELLOFF && !SS && W == LANES && !(LOCAL && R == 5 && !MULTI) && !(LOCAL && R == 5 && !BT && MULTI);
   LdsColumn<R, QL, (PF && QL), (W == LANES)> col;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t ring_addr = smem_addr + QL_F4 * 16 + arr * (C * REC_DW * 4);
@@ -721,7 +737,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         const int new_tid = tid0 | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
         Incoming inh = cur.resolve(in, st);
         cur.resolve_best(in, inh);
-        const bool emit = lane_header<R, LOCAL, true>(st, q, inh, i0, new_tid, P, g == g_last, res);
+        const bool emit = lane_header<R, LOCAL, SHARE>(st, q, inh, i0, new_tid, P, g == g_last, res);
         if (W == LANES) decltype(col)::publish_best(best_base + (uint32_t)lane * 8u, st.fs, st.fpos);
         if (emit) {
           DevResult o;
@@ -751,7 +767,7 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
         // single pass: the boundary value of the first lane is formed inside the column's block, so that it need not be held
         // through phases A and B (it is read in phase C)
         const Incoming inc = MULTI ? in : boundary_incoming(meta, jcol, P);
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, true, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
+        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, SHARE, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
       if (carry_out) {
@@ -831,21 +847,26 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
     }
   }
 #if defined(HHV_EXP_WAVETIME)
-  if (lane == 0 && blockIdx.x < 16384) {
-    hhv_dbg_wave[4 * blockIdx.x + 0] = wt_start;
-    hhv_dbg_wave[4 * blockIdx.x + 1] = wall_clock64();
-    hhv_dbg_wave[4 * blockIdx.x + 2] = (unsigned long long)Mmax;
-    hhv_dbg_wave[4 * blockIdx.x + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  if (lane == 0 && array0 < 16384) {
+    hhv_dbg_wave[4 * array0 + 0] = wt_start;
+    hhv_dbg_wave[4 * array0 + 1] = wall_clock64();
+    hhv_dbg_wave[4 * array0 + 2] = (unsigned long long)Mmax;
+    hhv_dbg_wave[4 * array0 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   }
 #endif
 #if defined(HHV_EXP_TIMING)
-  if (blockIdx.x == 0 && lane == 0) {
+  if (array0 == 0 && lane == 0) {
     hhv_dbg_clk[0] = dbg0;
     hhv_dbg_clk[1] = dbg1;
     hhv_dbg_clk[2] = dbg2;
     hhv_dbg_clk[3] = dbg3;
   }
 #endif
+}
+
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W>
+__global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
+  stream_body<R, LOCAL, BT, CELLOFF, MULTI, SS, W, 0>(a, (int)blockIdx.x);
 }
 
 // ---- kernel selection (instantiates the variants of one W in the including unit) --------------------------------------

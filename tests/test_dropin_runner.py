@@ -208,8 +208,8 @@ def test_dropin_concurrent_searches_share_the_cache():
 @pytest.mark.gpu
 @pytest.mark.parametrize("pcm,columnscore", [(3, -1), (0, 0), (1, 2), (2, 3), (-1, 4)])
 def test_dropin_preparation_variants(pcm, columnscore):
-    """pseudocount modes / null models: 0..2 / 0..3 are prepared on the device, the others by the reference's host code
-    (pcm 3, columnscore 4) - the hits must not tell the difference.  One template carries its own NULL line: the
+    """pseudocount modes / null models: 0..3 / 0..3 are prepared on the device, the others by the reference's host code
+    (columnscore 4) - the hits must not tell the difference.  One template carries its own NULL line: the
     reference prepares it with that background (HMM::Read overwrites pb, src/hhhmm.cpp:536-546), so it takes the host path."""
     cache_clear()
     q, t, names = make_db(51 + pcm + 7 * columnscore, 140, 30, 50, 220)
@@ -219,7 +219,7 @@ def test_dropin_preparation_variants(pcm, columnscore):
     ref = run("cpu", q, t, names, altali=2, pcm=pcm, columnscore=columnscore)
     got = run("hip", q, t, names, altali=2, pcm=pcm, columnscore=columnscore)
     compare(ref, got)
-    device = (pcm in (-1, 0, 1, 2)) and (columnscore in (-1, 0, 1, 2, 3))
+    device = (pcm in (-1, 0, 1, 2, 3)) and (columnscore in (-1, 0, 1, 2, 3))   # (pcm 3: on the device since round 4)
     assert cache_stats()[0] == (29 if device else 0)
     cache_clear()
 

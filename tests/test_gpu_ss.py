@@ -10,7 +10,7 @@ from pyoracle import SSInfo, make_params
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("Lq,local", [(80, 1), (300, 0), (330, 1)])
+@pytest.mark.parametrize("Lq,local", [(80, 1), (300, 0), (330, 1), (600, 1), (640, 0)])   # (600 / 640: two passes of five rows per lane)
 def test_ss_modes_match_oracle(oracle, Lq, local):
     from pyhhv import capi
     rng = np.random.default_rng(5 + Lq)
