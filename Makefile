@@ -12,7 +12,7 @@ CSRC     := hh-suite_amd/csrc
 LIBDIR   := hh-suite_amd/lib
 OBJDIR   := build/obj
 LIB      := $(LIBDIR)/libhhviterbi_hip.so
-OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_kernels_w32.o $(OBJDIR)/hhv_kernels_w16.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_prefilter.o $(OBJDIR)/hhv_mac.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_api_db.o $(OBJDIR)/hhv_api_prep.o $(OBJDIR)/hhv_api_prefilter.o $(OBJDIR)/hhv_api_mac.o $(OBJDIR)/hhv_pack.o
+OBJS     := $(OBJDIR)/hhv_kernels.o $(OBJDIR)/hhv_kernels_w32.o $(OBJDIR)/hhv_kernels_w16.o $(OBJDIR)/hhv_kernels_pair.o $(OBJDIR)/hhv_prep.o $(OBJDIR)/hhv_prefilter.o $(OBJDIR)/hhv_mac.o $(OBJDIR)/hhv_topk.o $(OBJDIR)/hhv_api.o $(OBJDIR)/hhv_api_db.o $(OBJDIR)/hhv_api_prep.o $(OBJDIR)/hhv_api_prefilter.o $(OBJDIR)/hhv_api_mac.o $(OBJDIR)/hhv_pack.o
 HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
 
 RUNNER   := $(LIBDIR)/libhhv_runner.so
@@ -40,6 +40,9 @@ $(OBJDIR)/hhv_kernels.o: $(CSRC)/hhv_kernels.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
 $(OBJDIR)/hhv_kernels_w%.o: $(CSRC)/hhv_kernels_w%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
+$(OBJDIR)/hhv_kernels_pair.o: $(CSRC)/hhv_kernels_pair.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
 $(OBJDIR)/hhv_prep.o: $(CSRC)/hhv_prep.hip $(HDRS)

@@ -730,8 +730,28 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.carry = ts->d_carry;
     a.carry_mi = ts->d_carry_mi;
   }
+  // Two strips (321 .. 640 query rows): ONE launch of two-wave workgroups, the first strip's bottom row handed to the second
+  // through LDS (hhv_stream_kernel.h PairLds) instead of two launches with the row in HBM.  Not for masked rounds, the ...AndSS
+  // builds and five-row backtrace strips (LDS-parked query rows); HHV_PAIR=0 keeps the two launches (measurement aid).
+  int pair_wgs = 0;
+  {
+    const char* env = getenv("HHV_PAIR");  // (read per call: the tests switch it inside one process)
+    if (queue && plan.P == 2 && plan.W == LANES && !celloff && !ss && !(env && atoi(env) == 0))
+      pair_wgs = pair_kernel_occupancy(plan.R(0), plan.R(1), local, bt);
+  }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  for (int pass = 0; pass < plan.P; ++pass) {
+  if (pair_wgs > 0) {
+    const int n_wg = std::max(1, std::min(c->num_cus * pair_wgs, ts->n_seg));
+    a.row_base = 0;
+    a.bt_plane = 0;
+    a.qpack = c->d_qpack;
+    a.pass_first = 1;
+    a.pass_last = 0;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // workgroup k starts with segment k
+    rc = launch_pair(plan.R(0), plan.R(1), local, bt, a, n_wg, c->stream);
+    if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  }
+  for (int pass = 0; pass < plan.P && pair_wgs == 0; ++pass) {
     a.row_base = plan.base(pass);
     a.bt_plane = pass;
     a.qpack = c->d_qpack + (size_t)a.row_base * REC_DW;

@@ -1,0 +1,44 @@
+// hhv_kernels_pair.hip -- instantiation unit of hhv_pair_kernel: queries of two strips (321 .. 640 rows) aligned in ONE launch
+// by workgroups of two wavefronts, a 128-lane systolic array (hhv_stream_kernel.h: PairLds, hhv_pair_kernel).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (like hhv_kernels.hip).
+#include "hhv_stream_kernel.h"
+
+namespace hhv {
+
+template <bool LOCAL, bool BT>
+static void* pair_kernel_ptr(int R0, int R1) {
+  if (R0 == 3 && R1 == 3) return (void*)hhv_pair_kernel<3, 3, LOCAL, BT>;
+  if (R0 == 4 && R1 == 3) return (void*)hhv_pair_kernel<4, 3, LOCAL, BT>;
+  if (R0 == 4 && R1 == 4) return (void*)hhv_pair_kernel<4, 4, LOCAL, BT>;
+  if (!BT) {  // (five rows per lane with backtrace park query rows in LDS: those plans stay two launches)
+    if (R0 == 5 && R1 == 4) return (void*)hhv_pair_kernel<5, 4, LOCAL, false>;
+    if (R0 == 5 && R1 == 5) return (void*)hhv_pair_kernel<5, 5, LOCAL, false>;
+  }
+  return nullptr;
+}
+static void* pair_kernel_pick(int R0, int R1, bool local, bool bt) {
+  if (bt) return local ? pair_kernel_ptr<true, true>(R0, R1) : pair_kernel_ptr<false, true>(R0, R1);
+  return local ? pair_kernel_ptr<true, false>(R0, R1) : pair_kernel_ptr<false, false>(R0, R1);
+}
+
+void* pair_kernel(int R0, int R1, bool local, bool bt) { return pair_kernel_pick(R0, R1, local, bt); }
+
+int launch_pair(int R0, int R1, bool local, bool bt, const StreamArgs& a, int n_workgroups, void* stream) {
+  void* fn = pair_kernel(R0, R1, local, bt);
+  if (!fn) return -1;
+  StreamArgs args = a;
+  void* kargs[] = {&args};
+  const hipError_t e = hipLaunchKernel(fn, dim3(n_workgroups), dim3(2 * LANES), kargs, 0, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// workgroups (of two wavefronts) a CU holds; 0 = no pair kernel for these strips
+int pair_kernel_occupancy(int R0, int R1, bool local, bool bt) {
+  void* fn = pair_kernel(R0, R1, local, bt);
+  if (!fn) return 0;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 2 * LANES, 0) != hipSuccess) return 0;
+  return nb;
+}
+
+}  // namespace hhv

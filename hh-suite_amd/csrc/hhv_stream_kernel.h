@@ -55,6 +55,47 @@ __device__ __forceinline__ float dpp_shr1(float old, float src, bool first_of_ar
   return __builtin_bit_cast(float, dpp_shr1<W>(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), first_of_array));
 }
 
+// ---- two-wave workgroups (hhv_pair_kernel): a query of two strips aligned in ONE launch ---------------------------------------
+// The two strips of a query of 321 .. 640 rows used to be two launches, the bottom row of the first strip travelling to the
+// second through HBM (20 bytes per stream record, a load per step in front of the hand-off: 6-10 % of those kernels, NOTES_r3 6,
+// NOTES_r4 6).  Here the strips are the two wavefronts of ONE workgroup - a 128-lane systolic array: both walk the same
+// sequence of stream segments (the first wave draws them from the queue and publishes the ids, the second follows), and
+// the first wave's last lane hands its bottom row (and, at headers, the finalized best) to the second wave's first lane
+// through a FIFO in LDS, slot = stream position mod PAIR_FIFO.  Flow control once per ring chunk, through two progress
+// counters: the second wave runs 3 .. 9 chunks behind the first.
+constexpr int PAIR_FIFO = 256;
+struct PairLds {
+  float4 carry[PAIR_FIFO][2];  // {MM, GD, IM, DG}, {MI, fs, fpos, -}
+  int seg_id[16];              // segment ids in the order the first wave drew them
+  int seg_count;               // ... how many so far
+  int w0_done;                 // positions the first wave has written (INT_MAX when it is through)
+  int w1_done;                 // positions the second wave has consumed
+  int pad;
+};
+__device__ __forceinline__ PairLds* pair_lds() {
+  __shared__ PairLds p;
+  return &p;
+}
+// The control words are read and written through inline asm (a read and its wait in ONE statement): hipcc would put a
+// vmcnt(0) in front of every LDS access it can see (the ring's LDS-DMA), and the audit (tools/audit_asm.py) allows no
+// compiler-generated LDS read in the loops.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ int lds_peek(uint32_t addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void lds_poke(uint32_t addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// spin until the word at `addr` is >= need (bounded: a logic error must not hang the device)
+__device__ __forceinline__ void pair_wait(uint32_t addr, int need) {
+  for (int guard = 0; guard < (1 << 17); ++guard) {
+    if (lds_peek(addr) >= need) return;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
 // ---- work queue of the 64-lane variants (see the kernel: DQ) ------------------------------------
 // A wave's stream is the concatenation of the segments it draws; positions count its records from 0.  All state is wave
 // uniform and kept in SGPRs (every update goes through readfirstlane: these variants have no VGPR to spare).  A segment is
@@ -102,6 +143,7 @@ struct WorkQueue {
   __device__ __forceinline__ bool start(const int64_t* seg_first, int n_seg, int id) {
     Jlast = 0;
     dprev = 0;
+    draws = 0;
     if (id >= n_seg) {
       delta_lo = delta_hi = J = 0;
       tail = 1;
@@ -121,16 +163,29 @@ struct WorkQueue {
   // reaches the end of the current segment the next one is drawn (queue empty: the terminal header, which ends the stream:
   // `end`); one junction at most lies inside a chunk (segments have >= 128 records; behind the terminal header the stream's
   // padding is read).  Everything that depends on the array is wave uniform here: no per-lane selects.
-  template <int W>
+  // PM (pair mode, see PairLds): 1 = publish every id drawn, 2 = take the ids the first wave published instead of drawing
+  int draws = 0;
+  template <int W, int PM = 0>
   __device__ __forceinline__ void refill(const float4* __restrict__ records, const int64_t* seg_first, int n_seg,
-                                         const uint32_t* queue, int cc, float4* dst, int lane) {
+                                         const uint32_t* queue, int cc, float4* dst, int lane, PairLds* pair = nullptr) {
     constexpr int C = W / 2, CF4 = C * 7, H = (CF4 + LANES - 1) / LANES;
     const int P0 = cc * C;
     const bool cross = !tail && P0 + C > J;
     int64_t next = 0;
     int nlen = 1;
     if (cross) {
-      const int id = draw(queue);
+      int id;
+      if (PM == 2) {
+        pair_wait(lds_addr_of(&pair->seg_count), draws + 1);
+        id = lds_peek(lds_addr_of(&pair->seg_id[draws & 15]));
+      } else {
+        id = draw(queue);
+        if (PM == 1) {  // (LDS executes a wave's operations in order: the id is written before the count)
+          lds_poke(lds_addr_of(&pair->seg_id[draws & 15]), id);
+          lds_poke(lds_addr_of(&pair->seg_count), draws + 1);
+        }
+      }
+      draws = uni(draws + 1);
       int64_t f1;
       segment(seg_first, min(id, n_seg), next, f1);  // (entry n_seg = the terminal header)
       if (id < n_seg) {
@@ -410,6 +465,9 @@ template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, 
 __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0) {
   __shared__ float4 smem[StreamSmem<R, BT, W>::F4];
   const int lane = PM == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LANES - 1));
+  static_assert(PM == 0 || (MULTI && W == LANES && !CELLOFF && !SS && !(BT && R == 5)), "pair variants: two strips, 64 lanes, no cell-off / SS, no LDS-parked query rows");
+  PairLds* const pair = PM ? pair_lds() : nullptr;
+  const uint32_t pair_carry_addr = PM ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&pair->carry[0][0] : 0u;
   static_assert(W == 64 || W == 32 || W == 16, "lanes per array");
   static_assert(!MULTI || W == LANES, "short-query arrays are single pass");
   constexpr int A = LANES / W;   // arrays per wave
@@ -485,7 +543,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     float4* const slot = ring + (cc & (RING_CHUNKS - 1)) * SLOT_F4;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      if (cc * C < wq[j].end) wq[j].template refill<W>((const float4*)a.records, a.seg_first, a.n_seg, a.queue, cc, slot + j * (C * 7), lane);
+      if (cc * C < wq[j].end) wq[j].template refill<W, PM>((const float4*)a.records, a.seg_first, a.n_seg, a.queue, cc, slot + j * (C * 7), lane, pair);
     }
     M = wq[0].end;
     Mmax = wq[0].end;
@@ -739,7 +797,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         cur.resolve_best(in, inh);
         const bool emit = lane_header<R, LOCAL, SHARE>(st, q, inh, i0, new_tid, P, g == g_last, res);
         if (W == LANES) decltype(col)::publish_best(best_base + (uint32_t)lane * 8u, st.fs, st.fpos);
-        if (emit) {
+        if (emit && PM != 1) {  // (first wave of a pair: the best travels on through the FIFO)
           DevResult o;
           o.score = res.score;
           o.i2 = res.i2;
@@ -770,7 +828,14 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, SHARE, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
-      if (carry_out) {
+      if (PM == 1) {
+        if (lane == LANES - 1) {
+          const uint32_t addr = pair_carry_addr + ((uint32_t)r & (uint32_t)(PAIR_FIFO - 1)) * 32u;
+          const v4f o0 = {st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1]};
+          const v4f o1 = {st.MI[R - 1], st.fs, __builtin_bit_cast(float, st.fpos), 0.0f};
+          asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16" ::"v"(addr), "v"(o0), "v"(o1) : "memory");
+        }
+      } else if (carry_out) {
         if (lane == LANES - 1) {
           const size_t rc = DQV ? (size_t)record_of(r) : (size_t)(rb + r);
           a.carry[rc] = make_float4(st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1]);
@@ -801,6 +866,18 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
       // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (PM == 1) {
+        // positions below c C - LEAD - (W - 1) are in the FIFO (their ds_writes are complete: LDS executes a wave's operations
+        // in order and the steps' waits have passed them); the coming chunk writes positions up to pmax, which must not lap the
+        // second wave
+        if (c * C - LEAD - (W - 1) > 0) lds_poke(lds_addr_of(&pair->w0_done), c * C - LEAD - (W - 1));
+        const int pmax = (c + 1) * C - LEAD - W;
+        if (pmax - (PAIR_FIFO - 1) > 0) pair_wait(lds_addr_of(&pair->w1_done), pmax - (PAIR_FIFO - 1));
+      }
+      if (PM == 2) {
+        lds_poke(lds_addr_of(&pair->w1_done), c * C - LEAD);
+        pair_wait(lds_addr_of(&pair->w0_done), (c + 1) * C - LEAD + 1);
+      }
       if (DQV) {
         const int m_before = Mmax;
         if (c + 1 < nchunks_max) dq_refill(c + 1);
@@ -846,6 +923,8 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       for (int s = s_lo; s < s_hi; ++s) step(s, col, col);
     }
   }
+  if (PM == 1) lds_poke(lds_addr_of(&pair->w0_done), 0x7FFFFFFF);  // through: the second wave never waits again
+  if (PM == 2) lds_poke(lds_addr_of(&pair->w1_done), 0x7FFFFFFF);
 #if defined(HHV_EXP_WAVETIME)
   if (lane == 0 && array0 < 16384) {
     hhv_dbg_wave[4 * array0 + 0] = wt_start;
@@ -869,6 +948,36 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
   stream_body<R, LOCAL, BT, CELLOFF, MULTI, SS, W, 0>(a, (int)blockIdx.x);
 }
 
+// Two strips of R0 and R1 rows per lane as the two wavefronts of one workgroup (PairLds above).  Which wave index takes which
+// strip alternates with the workgroup number: the strips differ in work (R0 >= R1), and the waves of the workgroups that share a
+// SIMD should not all be the heavy ones.
+template <int R0, int R1, bool LOCAL, bool BT>
+__global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
+  PairLds* const p = pair_lds();
+  if (threadIdx.x == 0) {
+    p->seg_count = 0;
+    p->w0_done = 0;
+    p->w1_done = 0;
+  }
+  __syncthreads();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (((wv ^ (int)blockIdx.x) & 1) == 0) {
+    StreamArgs a0 = a;
+    a0.row_base = 0;
+    a0.bt_plane = 0;
+    a0.pass_first = 1;
+    a0.pass_last = 0;
+    stream_body<R0, LOCAL, BT, false, true, false, LANES, 1>(a0, (int)blockIdx.x);
+  } else {
+    StreamArgs a1 = a;
+    a1.row_base = LANES * R0;
+    a1.qpack = a.qpack + (size_t)(LANES * R0) * REC_DW;
+    a1.bt_plane = 1;
+    a1.pass_first = 0;
+    a1.pass_last = 1;
+    stream_body<R1, LOCAL, BT, false, true, false, LANES, 2>(a1, (int)blockIdx.x);
+  }
+}
 // ---- kernel selection (instantiates the variants of one W in the including unit) --------------------------------------
 template <int W, int R, bool LOCAL, bool BT, bool CELLOFF>
 static void* stream_kernel_ptr(bool multi, bool ss) {

@@ -34,7 +34,7 @@ def regs_of(text):
     return out
 
 
-UNITS = ("hhv_kernels.hip", "hhv_kernels_w32.hip", "hhv_kernels_w16.hip")
+UNITS = ("hhv_kernels.hip", "hhv_kernels_w32.hip", "hhv_kernels_w16.hip", "hhv_kernels_pair.hip")
 
 
 def compile_s(workdir):
@@ -63,7 +63,7 @@ def functions(lines):
     i = 0
     n = len(lines)
     while i < n:
-        m = re.match(r"^(_ZN3hhv17hhv_stream_kernel\w+):", lines[i])
+        m = re.match(r"^(_ZN3hhv1[75]hhv_(?:stream|pair)_kernel\w+):", lines[i])
         if m:
             j = i
             while j < n and not lines[j].strip().startswith("s_endpgm"):
@@ -76,7 +76,7 @@ def functions(lines):
 def audit_function(name, body):
     problems = []
     m = re.search(r"hhv_stream_kernelILi\dELb\dELb\dELb(\d)ELb(\d)ELb(\d)E", name)
-    loads_in_loop = m is None or "1" in m.groups()
+    loads_in_loop = m is None or "1" in m.groups()   # (pair kernels: m is None - their waits are placed by hand too, but they are MULTI bodies)
     pending = []         # destination registers of issued, not yet waited-for asm reads, one set per read in issue order
     ticket = []          # destination of the work queue's atomic, not yet waited for
     in_asm = False

@@ -47,6 +47,13 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4g)   # two-strip queries as ONE launch of two-wave workgroups (hhv_pair_kernel): parity, then HHV_PAIR=0 / 1 on the bench configurations
+  timeout 900 python -m pytest tests/test_gpu_pair.py -q -m gpu -x 2>&1 | tail -12
+  for rep in 1 2; do for cfg in "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000" "--lq 640 --templates 40000" "--lq 350 --templates 50000 --backtrace 1" "--lq 431 --templates 100000 --lengths zipf --local 1"; do for pv in 0 1; do
+    echo -n "HHV_PAIR=$pv $cfg : "
+    HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+  done; done; done
+  ;;
 r4f)   # carry rows of the multi-pass variants in blocks (lanes 0..31 load a chunk of rows ahead, lane 0 takes its row by v_readlane): parity + A/B
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_lengths.py tests/test_gpu_queue.py -q -m gpu 2>&1 | tail -5
   HHV_AB_LIBS="nocb hip" HHV_AB_REPS=2 HHV_AB_CFGS="--lq 431 --templates 50000|--lq 431 --templates 50000 --backtrace 1|--lq 700 --templates 30000|--lq 1000 --lt 500 --templates 20000|--lq 2000 --lt 300 --templates 10000 --local 1" bash tools/gpu_ab.sh
