@@ -90,6 +90,9 @@ __device__ __forceinline__ void lds_poke(uint32_t addr, int v) {
 }
 // spin until the word at `addr` is >= need (bounded: a logic error must not hang the device)
 __device__ __forceinline__ void pair_wait(uint32_t addr, int need) {
+#if defined(HHV_EXP_PAIR_NOSYNC)  // measurement build, WRONG results: nobody waits for anybody
+  return;
+#endif
   for (int guard = 0; guard < (1 << 17); ++guard) {
     if (lds_peek(addr) >= need) return;
     __builtin_amdgcn_s_sleep(4);
@@ -474,8 +477,8 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
   constexpr int C = W / 2;       // records per ring chunk and array (the live window of W records spans <= 3 chunks)
   static_assert(RING_CHUNKS == 4 && CHUNK_RECS == 32 && A * C == CHUNK_RECS, "ring geometry");
   // SHARE: (MM(i-1,j-1) + q.M2M) and (MI(i-1,j-1) + q.M2M) are computed once and carried (viterbi_lane.h LaneState::aMM / aMI:
-  // two additions per row and step less for ten registers) - everywhere but in the one variant that has no register for them
-  constexpr bool SHARE = !(LOCAL && R == 5 && !BT && MULTI && SS);
+  // two additions per row and step less for ten registers)
+  constexpr bool SHARE = true;
   constexpr bool QL = StreamSmem<R, BT, W>::QL;
   constexpr int QL_F4 = StreamSmem<R, BT, W>::QL_F4;
   float4* const ring = smem + QL_F4;
@@ -581,8 +584,15 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
   // the lane that emits results: owner of row Lq in the last pass, the array's last lane otherwise
   const int g_last = (!MULTI || a.pass_last) ? (a.Lq - a.row_base - 1) / R : W - 1;
   const int r_last = (a.Lq - a.row_base - 1) % R;
-  const bool first = !MULTI || a.pass_first != 0;
-  const bool carry_out = MULTI && a.pass_last == 0;
+#if defined(HHV_EXP_MULTI_NOCARRY)  // measurement build, WRONG results: the multi-pass bodies without their carry traffic
+  const bool first = true;
+  const bool carry_out = false;
+#else
+  // (the waves of a pair know their role at compile time: no code of the other role - its global loads made hipcc put a
+  // vmcnt(0) into every step of BOTH roles, profiles/r4_ab.txt ab-r4-5)
+  const bool first = PM == 1 ? true : PM == 2 ? false : (!MULTI || a.pass_first != 0);
+  const bool carry_out = PM ? false : (MULTI && a.pass_last == 0);
+#endif
 
   const float4* const records = (const float4*)a.records;
   int nchunks_max = (Mmax + C - 1) / C;
@@ -603,8 +613,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
   // variants the phase-A query-transition reads are deferred as well (SPLIT_A).  Measured in one session each
   // (tools/gpu_ab.sh): score-only -2 %, multi-pass -0.8 %, backtrace -0.5 %.
   // (not the local five-row single-pass variants: 256 VGPRs do not hold the prefetched head next to the per-row best)
-  // (nor the local five-row score-only multi-pass ones: with the body as a function of its own they spilled three registers)
-  constexpr bool PF = !CELLOFF && !SS && W == LANES && !(LOCAL && R == 5 && !MULTI) && !(LOCAL && R == 5 && !BT && MULTI);
+  constexpr bool PF = !CELLOFF && !SS && W == LANES && !(LOCAL && R == 5 && !MULTI);
   LdsColumn<R, QL, (PF && QL), (W == LANES)> col;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t ring_addr = smem_addr + QL_F4 * 16 + arr * (C * REC_DW * 4);
@@ -665,29 +674,29 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
   // (and with two waves per SIMD, most of the SIMD) for its whole latency.
   float4 ncar = make_float4(0.f, 0.f, 0.f, 0.f);
   float nmi = 0.f;
-  // CB (round 4): the carry rows come in BLOCKS instead - once per ring chunk lanes 0 .. C-1 load the rows of the C positions
-  // lane 0 will stand on during the chunk AFTER the next refill (one coalesced load, a whole chunk of steps ahead, retired by
-  // the chunk boundary's own vmcnt(0)); in a step lane 0 takes its row out of the lane that holds it (five v_readlane with a
-  // wave-uniform index).  No global load and no address arithmetic in the step, nothing a step has to wait for.
-#ifndef HHV_CARRY_BLOCK
-#define HHV_CARRY_BLOCK 1
+  // (Round 4 tried the rows in BLOCKS instead: once per ring chunk lanes 0 .. 31 load the rows of the next chunk's positions -
+  // one coalesced load a whole chunk ahead, retired by the chunk boundary's own vmcnt(0) - and lane 0 takes its row out of the
+  // lane that holds it with five v_readlane per step: no global load, no address arithmetic, no wait in the step - and 2-4 %
+  // SLOWER on every multi-pass query (Lq 431: 12.17 -> 12.65 ms; profiles/r4_ab.txt ab-r4-3): a VALU write to an SGPR costs
+  // more than the load it replaces, like the v_cmp_e64 of round 3.)
+  // PM == 2: the row comes out of the pair's FIFO instead (slot = position mod PAIR_FIFO): requested one step ahead like the
+  // global row, by an inline-asm read that is waited for by the step's own lgkmcnt(0) waits (every lane reads the slot:
+  // a broadcast; lane 0 uses it).  pc0 = {MM, GD, IM, DG}, pc1 = {MI, fs, fpos, -} of the NEXT step's position.
+  v4f pc0 = {0.f, 0.f, 0.f, 0.f}, pc1 = {0.f, 0.f, 0.f, 0.f};
+  auto pair_carry_issue = [&](const int pos) __attribute__((always_inline)) {
+#if defined(HHV_EXP_PAIR_NOFIFO)  // measurement build, WRONG results: no carry traffic through LDS
+    return;
 #endif
-  constexpr bool CB = MULTI && HHV_CARRY_BLOCK != 0;
-  float cb_cur[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, cb_nxt[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  int cb_base = -LEAD;  // position held by lane 0 of cb_cur
-  auto carry_block_load = [&](const int blk) __attribute__((always_inline)) {
-    const int p = blk * C - LEAD + lane;  // block blk = the positions of chunk-loop iteration blk
-    if (lane < C && p >= 0 && p < M) {
-      const size_t rn = DQV ? (size_t)record_of(p) : (size_t)(rb + p);
-      const float4 v = a.carry[rn];
-      cb_nxt[0] = v.x, cb_nxt[1] = v.y, cb_nxt[2] = v.z, cb_nxt[3] = v.w;
-      cb_nxt[4] = a.carry_mi[rn];
-    }
+    const uint32_t addr = pair_carry_addr + ((uint32_t)pos & (uint32_t)(PAIR_FIFO - 1)) * 32u;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(pc0), "=&v"(pc1) : "v"(addr) : "memory");
   };
-  if (MULTI && !first) {
-    if (CB) {
-      carry_block_load(0);
-    } else if (lane == 0 && M > 0) {
+  if (PM == 2) {
+    pair_wait(lds_addr_of(&pair->w0_done), C + 1);  // the first chunk's positions (and the one read ahead) have been written
+    pair_carry_issue(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc0), "+v"(pc1));
+  }
+  if (MULTI && !first && PM != 2) {
+    if (lane == 0 && M > 0) {
       ncar = a.carry[rb];  // (work queue: rb = the first record of the wave's first segment)
       nmi = a.carry_mi[rb];
     }
@@ -755,22 +764,28 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     // bottom row the previous pass left for this record (and its running best)
     const int jcol = meta & (int)k_jmask;  // column index of a column record
     Incoming in = boundary_incoming(meta, jcol, P);
-    if (MULTI && !first) {
-      float c0 = ncar.x, c1 = ncar.y, c2 = ncar.z, c3 = ncar.w, c4 = nmi;
-      if (CB) {
-        const int idx = s - cb_base;  // wave uniform, 0 .. C-1
-        c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[0]), idx));
-        c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[1]), idx));
-        c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[2]), idx));
-        c3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[3]), idx));
-        c4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb_cur[4]), idx));
-      }
+    if (PM == 2) {
+      // (pc0 / pc1 were requested a step ago and have landed: the end of every step waits lgkmcnt(0))
       if (lane == 0 && active) {
-        in.MM = c0;
-        in.GD = c1;
-        in.IM = c2;
-        in.DG = c3;
-        in.MI = c4;
+        in.MM = pc0.x;
+        in.GD = pc0.y;
+        in.IM = pc0.z;
+        in.DG = pc0.w;
+        in.MI = pc1.x;
+        if (meta < 0 && st.tid >= 0) {
+          in.fs = pc1.y;
+          const float fp = pc1.z;
+          in.fpos = __builtin_bit_cast(int, fp);
+        }
+      }
+      pair_carry_issue(s + 1);
+    } else if (MULTI && !first) {
+      if (lane == 0 && active) {
+        in.MM = ncar.x;
+        in.GD = ncar.y;
+        in.IM = ncar.z;
+        in.DG = ncar.w;
+        in.MI = nmi;
         if (meta < 0 && st.tid >= 0) {
           const DevResult pr = a.results[st.tid & TID_MASK];
           in.fs = pr.score;
@@ -780,7 +795,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       // the carry row of the next step is requested only now, behind the copies that consumed this step's row: the load
       // lands in the same registers and is not waited for before the next step (requested inside the block above, hipcc
       // loads into temporaries, copies and waits for the round trip on the spot)
-      if (!CB && lane == 0 && active && r + 1 < M) {  // lane 0: r = s
+      if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
         const size_t rn = DQV ? (size_t)record_of(r + 1) : (size_t)(rb + r + 1);
         ncar = a.carry[rn];
         nmi = a.carry_mi[rn];
@@ -829,12 +844,14 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         if (BT) *bte = bytes;
       }
       if (PM == 1) {
+#if !defined(HHV_EXP_PAIR_NOFIFO)
         if (lane == LANES - 1) {
           const uint32_t addr = pair_carry_addr + ((uint32_t)r & (uint32_t)(PAIR_FIFO - 1)) * 32u;
           const v4f o0 = {st.MM[R - 1], st.GD[R - 1], st.IM[R - 1], st.DG[R - 1]};
           const v4f o1 = {st.MI[R - 1], st.fs, __builtin_bit_cast(float, st.fpos), 0.0f};
           asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16" ::"v"(addr), "v"(o0), "v"(o1) : "memory");
         }
+#endif
       } else if (carry_out) {
         if (lane == LANES - 1) {
           const size_t rc = DQV ? (size_t)record_of(r) : (size_t)(rb + r);
@@ -844,6 +861,9 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       }
     }
     if (PF) decltype(col)::head_wait(nxt.v6, nxt.v5);  // full EXEC again: the head of step s+1 is in nxt.v6 / v5 from here on
+    // (pair: the FIFO slot requested at the top of this step has landed too - LDS returns a wave's reads in order; the tie
+    // keeps its eight registers the slot's until here, whatever the step uses of them)
+    if (PM == 2) asm volatile("" : "+v"(pc0), "+v"(pc1));
 #if defined(HHV_EXP_TIMING)
     {
       unsigned long long tE;
@@ -891,13 +911,6 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       }
     }
     const int s_lo = c > 0 ? c * C - LEAD : 0, s_hi = min((c + 1) * C - LEAD, s_end);
-    if (CB && !first) {
-      // the block requested a chunk ago has landed (the wait above; at c = 0 the compiler's own); request the next one
-#pragma unroll
-      for (int x = 0; x < 5; ++x) cb_cur[x] = cb_nxt[x];
-      cb_base = c * C - LEAD;
-      carry_block_load(c + 1);
-    }
     if (PF && !MULTI) {
       // unrolled by two: the heads alternate between col and col2, no copy between the steps
       int s = s_lo;

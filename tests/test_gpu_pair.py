@@ -45,6 +45,10 @@ def test_pair_equals_oracle_and_two_launches(oracle, Lq, local):
         return so, res, hits, mats
 
     (so1, res1, hits1, mats1), (so0, res0, hits0, mats0) = both_ways(run)
+    for e in range(n):  # (first against the oracle, template by template: a failure names the template and the path)
+        a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_bt=False)
+        for tag, r in (("two launches", so0), ("pair", so1), ("two launches bt", res0), ("pair bt", res1)):
+            assert (a.i2, a.j2) == (r["i2"][e], r["j2"][e]) and same_float(a.score, r["score"][e]), (tag, Lq, e, tps[e].shape[0] - 1, a.score, r["score"][e], (a.i2, a.j2), (r["i2"][e], r["j2"][e]))
     assert so1.tobytes() == so0.tobytes() and res1.tobytes() == res0.tobytes() and hits1.tobytes() == hits0.tobytes()
     for a, b in zip(mats1, mats0):
         assert np.array_equal(a, b)

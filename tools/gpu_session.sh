@@ -47,6 +47,35 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4j)   # timing-only builds (WRONG results): pair kernels without waits (pns), without waits and FIFO traffic (pnf), multi-pass bodies without carry traffic (mnc)
+  for cfg in "--lq 512 --templates 50000" "--lq 431 --templates 50000"; do
+    for lib in hip pns pnf mnc; do for pv in 1 0; do
+      [ $pv = 0 ] && [ $lib != mnc ] && [ $lib != hip ] && continue
+      echo -n "$lib HHV_PAIR=$pv $cfg : "
+      HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_$lib.so HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+    done; done
+  done
+  ;;
+r4i)   # where the multi-pass penalty sits: per-launch durations of the two passes (kernel trace), single pass at the same set size
+  for cfg in "--lq 256 --templates 50000" "--lq 320 --templates 50000"; do echo -n "$cfg : "; timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line; done
+  for pv in 0 1; do for lq in 512 640; do
+    echo "== HHV_PAIR=$pv --lq $lq --templates 50000: every dispatch of the stream / pair kernels (us)"
+    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_kt && HHV_PAIR=$pv timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_kt -o kt -- python $ROOT/bench.py --lq $lq --templates 50000 --steps 4 --warmup 1 $short > /tmp/prof_kt.log 2>&1)
+    python - <<'PY'
+import csv, glob
+for f in glob.glob("/tmp/prof_kt/**/*kernel_trace.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if "hhv_stream_kernel" in r["Kernel_Name"] or "hhv_pair_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    print("  ".join("%s:%.0f" % (r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "")[:18], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows[-8:]))
+PY
+  done; done
+  ;;
+r4h)   # what a step costs at R rows per lane, single pass against multi pass (is the multi-pass penalty VALU or latency?)
+  for cfg in "--lq 320 --templates 100000" "--lq 256 --templates 100000" "--lq 192 --templates 100000" "--lq 640 --templates 50000" "--lq 512 --templates 50000" "--lq 384 --templates 50000"; do for pv in 0 1; do
+    echo -n "HHV_PAIR=$pv $cfg : "
+    HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+  done; done
+  ;;
 r4g)   # two-strip queries as ONE launch of two-wave workgroups (hhv_pair_kernel): parity, then HHV_PAIR=0 / 1 on the bench configurations
   timeout 900 python -m pytest tests/test_gpu_pair.py -q -m gpu -x 2>&1 | tail -12
   for rep in 1 2; do for cfg in "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000" "--lq 640 --templates 40000" "--lq 350 --templates 50000 --backtrace 1" "--lq 431 --templates 100000 --lengths zipf --local 1"; do for pv in 0 1; do
