@@ -714,6 +714,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.Lq = c->Lq;
   a.carry = nullptr;
   a.carry_mi = nullptr;
+  a.pair_swap = 0;
   a.bt_pass_stride = (int64_t)bt_plane_entries(ts->n_records, plan.W);
   a.ss_table = ss ? c->d_ss_table : nullptr;
   a.ss_q_off = ss ? c->d_ss_q_off : nullptr;
@@ -747,6 +748,10 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.qpack = c->d_qpack;
     a.pass_first = 1;
     a.pass_last = 0;
+    {
+      const char* sw = getenv("HHV_PAIR_SWAP");  // measurement aid: which workgroups swap the strips of their two waves
+      a.pair_swap = sw ? atoi(sw) : 0;
+    }
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // workgroup k starts with segment k
     rc = launch_pair(plan.R(0), plan.R(1), local, bt, a, n_wg, c->stream);
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));

@@ -100,6 +100,7 @@ struct StreamArgs {
   int32_t row_base;          // StripPlan::base(p)
   int32_t bt_plane;          // p: the plane of the backtrace buffer this pass reads masks from / writes to
   int32_t pass_first;        // lane 0 takes the DP boundary row 0 (else: the carry of the previous pass)
+  int32_t pair_swap;         // pair kernels: workgroups whose number has bit pair_swap set run the strips on swapped wave indices (-1: none)
   int32_t pass_last;         // the lane owning row Lq emits the result (else: lane 63 writes the carry)
   float4* carry;             // [n_records] bottom-row state {MM,GD,IM,DG} of the previous / for the next pass ...
   float* carry_mi;           // ... and MI

@@ -974,7 +974,8 @@ __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
   }
   __syncthreads();
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (((wv ^ (int)blockIdx.x) & 1) == 0) {
+  const int swap = a.pair_swap >= 0 ? ((int)blockIdx.x >> a.pair_swap) & 1 : 0;
+  if ((wv ^ swap) == 0) {
     StreamArgs a0 = a;
     a0.row_base = 0;
     a0.bt_plane = 0;

@@ -151,7 +151,7 @@ def main():
     for m in re.finditer(r"\.vgpr_spill_count:\s*(\d+)", text):
         if int(m.group(1)) != 0:
             problems.append("a kernel spills %s VGPRs" % m.group(1))
-    print("audited %d hhv_stream_kernel instantiations, %d problems" % (count, len(problems)))
+    print("audited %d hhv_stream_kernel / hhv_pair_kernel instantiations, %d problems" % (count, len(problems)))
     for p in problems[:50]:
         print("  " + p)
     return 1 if problems or count == 0 else 0
