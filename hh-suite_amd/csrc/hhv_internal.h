@@ -306,7 +306,7 @@ int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream
 int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
 int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);
 // per-W instantiation units (hhv_kernels.hip: 64, hhv_kernels_w32.hip, hhv_kernels_w16.hip)
-void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss);
+void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip);
 // two-strip queries as one launch of two-wave workgroups (hhv_kernels_pair.hip)
 int launch_pair(int R0, int R1, bool local, bool bt, const StreamArgs& a, int n_workgroups, void* stream);
 int pair_kernel_occupancy(int R0, int R1, bool local, bool bt);

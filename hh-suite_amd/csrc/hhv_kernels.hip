@@ -342,12 +342,12 @@ __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 
-void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss) {
-  return stream_kernel_pick<LANES>(R, local, bt, celloff, multi, ss);
+void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip) {
+  return stream_kernel_pick<LANES>(R, local, bt, celloff, multi, ss, first_strip);
 }
 
-static void* pick(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss) {
-  if (W == LANES) return stream_kernel_w64(R, local, bt, celloff, multi, ss);
+static void* pick(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip = false) {
+  if (W == LANES) return stream_kernel_w64(R, local, bt, celloff, multi, ss, first_strip);
   if (multi) return nullptr;
   if (W == 32) return stream_kernel_w32(R, local, bt, celloff, ss);
   if (W == 16) return stream_kernel_w16(R, local, bt, celloff, ss);
@@ -356,7 +356,8 @@ static void* pick(int W, int R, bool local, bool bt, bool celloff, bool multi, b
 
 int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves,
                   void* stream) {
-  void* fn = pick(W, R, local, bt, celloff, multi, ss);
+  // (the first strip of a multi-strip plan has a kernel of its own: no code of the later strips in its steps)
+  void* fn = pick(W, R, local, bt, celloff, multi, ss, multi && a.pass_first != 0);
   if (!fn) return -1;
   StreamArgs args = a;
   void* kargs[] = {&args};

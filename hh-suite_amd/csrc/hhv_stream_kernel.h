@@ -463,14 +463,18 @@ struct StreamSmem {
 // one-wave kernel).  Its LDS (StreamSmem<R, BT, W>::F4 float4) is a static object of the instantiation: constant addresses, and
 // the two bodies of a pair kernel get two disjoint objects.
 // PM (pair mode): 0 = the wavefront is a workgroup of its own; 1 / 2 = first / second wavefront of a two-wave workgroup that
-// aligns a query of two strips in ONE launch (hhv_pair_kernel below).
+// aligns a query of two strips in ONE launch (hhv_pair_kernel below); 3 = a workgroup of its own that runs the FIRST strip of a
+// one-launch-per-strip plan - known at compile time, so that its steps contain no code of the later strips (whose carry loads make
+// hipcc wait vmcnt(0) in every step of a body that contains them, whichever role it plays at run time).
 template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, int PM>
 __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0) {
   __shared__ float4 smem[StreamSmem<R, BT, W>::F4];
   const int lane = PM == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LANES - 1));
-  static_assert(PM == 0 || (MULTI && W == LANES && !CELLOFF && !SS && !(BT && R == 5)), "pair variants: two strips, 64 lanes, no cell-off / SS, no LDS-parked query rows");
-  PairLds* const pair = PM ? pair_lds() : nullptr;
-  const uint32_t pair_carry_addr = PM ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&pair->carry[0][0] : 0u;
+  constexpr bool PAIRED = PM == 1 || PM == 2;
+  static_assert(!PAIRED || (MULTI && W == LANES && !CELLOFF && !SS && !(BT && R == 5)), "pair variants: two strips, 64 lanes, no cell-off / SS, no LDS-parked query rows");
+  static_assert(PM != 3 || MULTI, "first strip of a multi-strip plan");
+  PairLds* const pair = PAIRED ? pair_lds() : nullptr;
+  const uint32_t pair_carry_addr = PAIRED ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&pair->carry[0][0] : 0u;
   static_assert(W == 64 || W == 32 || W == 16, "lanes per array");
   static_assert(!MULTI || W == LANES, "short-query arrays are single pass");
   constexpr int A = LANES / W;   // arrays per wave
@@ -590,8 +594,8 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
 #else
   // (the waves of a pair know their role at compile time: no code of the other role - its global loads made hipcc put a
   // vmcnt(0) into every step of BOTH roles, profiles/r4_ab.txt ab-r4-5)
-  const bool first = PM == 1 ? true : PM == 2 ? false : (!MULTI || a.pass_first != 0);
-  const bool carry_out = PM ? false : (MULTI && a.pass_last == 0);
+  const bool first = (PM == 1 || PM == 3) ? true : PM == 2 ? false : (!MULTI || a.pass_first != 0);
+  const bool carry_out = PAIRED ? false : (MULTI && a.pass_last == 0);
 #endif
 
   const float4* const records = (const float4*)a.records;
@@ -792,11 +796,14 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
           in.fpos = (pr.i2 << 16) | pr.j2;
         }
       }
-      // the carry row of the next step is requested only now, behind the copies that consumed this step's row: the load
-      // lands in the same registers and is not waited for before the next step (requested inside the block above, hipcc
-      // loads into temporaries, copies and waits for the round trip on the spot)
-      if (lane == 0 && active && r + 1 < M) {  // lane 0: r = s
-        const size_t rn = DQV ? (size_t)record_of(r + 1) : (size_t)(rb + r + 1);
+      // The carry row of the next step is requested now, behind the copies that consumed this step's row - by EVERY lane, for
+      // its own next position (clamped into the stream: 64 neighbouring rows, one coalesced load; lane 0's is the one that is
+      // used).  Round 4: requested by lane 0 alone, under a divergent branch, the loaded registers met their old values in a
+      // phi behind the branch and hipcc waited vmcnt(0) right there - a memory round trip in every step, +24-26 % per step
+      // (profiles/r4_ab.txt ab-r4-4).  Without the branch the first use is the top of the next step.
+      {
+        const int pn = min(max(r + 1, 0), M - 1);
+        const size_t rn = DQV ? (size_t)record_of(pn) : (size_t)(rb + pn);
         ncar = a.carry[rn];
         nmi = a.carry_mi[rn];
       }
@@ -956,9 +963,10 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
 #endif
 }
 
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W>
+// FIRSTP: the launch of the FIRST strip of a multi-strip query (MULTI only)
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, bool FIRSTP = false>
 __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
-  stream_body<R, LOCAL, BT, CELLOFF, MULTI, SS, W, 0>(a, (int)blockIdx.x);
+  stream_body<R, LOCAL, BT, CELLOFF, MULTI, SS, W, (FIRSTP ? 3 : 0)>(a, (int)blockIdx.x);
 }
 
 // Two strips of R0 and R1 rows per lane as the two wavefronts of one workgroup (PairLds above).  Which wave index takes which
@@ -994,7 +1002,10 @@ __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
 }
 // ---- kernel selection (instantiates the variants of one W in the including unit) --------------------------------------
 template <int W, int R, bool LOCAL, bool BT, bool CELLOFF>
-static void* stream_kernel_ptr(bool multi, bool ss) {
+static void* stream_kernel_ptr(bool multi, bool ss, bool first_strip) {
+  if (W == LANES && multi && first_strip)
+    return ss ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), true, W, (W == LANES)>
+              : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), false, W, (W == LANES)>;
   if (W == LANES && multi)
     return ss ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), true, W>
               : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), false, W>;
@@ -1002,21 +1013,21 @@ static void* stream_kernel_ptr(bool multi, bool ss) {
             : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, false, false, W>;
 }
 template <int W, int R>
-static void* stream_kernel_variant(bool local, bool bt, bool celloff, bool multi, bool ss) {
+static void* stream_kernel_variant(bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip) {
   if (celloff)
-    return local ? stream_kernel_ptr<W, R, true, true, true>(multi, ss) : stream_kernel_ptr<W, R, false, true, true>(multi, ss);
+    return local ? stream_kernel_ptr<W, R, true, true, true>(multi, ss, first_strip) : stream_kernel_ptr<W, R, false, true, true>(multi, ss, first_strip);
   if (bt)
-    return local ? stream_kernel_ptr<W, R, true, true, false>(multi, ss) : stream_kernel_ptr<W, R, false, true, false>(multi, ss);
-  return local ? stream_kernel_ptr<W, R, true, false, false>(multi, ss) : stream_kernel_ptr<W, R, false, false, false>(multi, ss);
+    return local ? stream_kernel_ptr<W, R, true, true, false>(multi, ss, first_strip) : stream_kernel_ptr<W, R, false, true, false>(multi, ss, first_strip);
+  return local ? stream_kernel_ptr<W, R, true, false, false>(multi, ss, first_strip) : stream_kernel_ptr<W, R, false, false, false>(multi, ss, first_strip);
 }
 template <int W>
-static void* stream_kernel_pick(int R, bool local, bool bt, bool celloff, bool multi, bool ss) {
+static void* stream_kernel_pick(int R, bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip = false) {
   switch (R) {
-    case 1: return stream_kernel_variant<W, 1>(local, bt, celloff, multi, ss);
-    case 2: return stream_kernel_variant<W, 2>(local, bt, celloff, multi, ss);
-    case 3: return stream_kernel_variant<W, 3>(local, bt, celloff, multi, ss);
-    case 4: return stream_kernel_variant<W, 4>(local, bt, celloff, multi, ss);
-    case 5: return stream_kernel_variant<W, 5>(local, bt, celloff, multi, ss);
+    case 1: return stream_kernel_variant<W, 1>(local, bt, celloff, multi, ss, first_strip);
+    case 2: return stream_kernel_variant<W, 2>(local, bt, celloff, multi, ss, first_strip);
+    case 3: return stream_kernel_variant<W, 3>(local, bt, celloff, multi, ss, first_strip);
+    case 4: return stream_kernel_variant<W, 4>(local, bt, celloff, multi, ss, first_strip);
+    case 5: return stream_kernel_variant<W, 5>(local, bt, celloff, multi, ss, first_strip);
   }
   return nullptr;
 }
