@@ -801,6 +801,8 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       // used).  Round 4: requested by lane 0 alone, under a divergent branch, the loaded registers met their old values in a
       // phi behind the branch and hipcc waited vmcnt(0) right there - a memory round trip in every step, +24-26 % per step
       // (profiles/r4_ab.txt ab-r4-4).  Without the branch the first use is the top of the next step.
+      // (Letting the other lanes look AHEAD instead - positions s + 2 .. s + 16, so that lane 0's row is in the cache when its turn
+      // comes - changed nothing: the trip to HBM was not what was left.  profiles/r4_ab.txt ab-r4-7.)
       {
         const int pn = min(max(r + 1, 0), M - 1);
         const size_t rn = DQV ? (size_t)record_of(pn) : (size_t)(rb + pn);
