@@ -733,12 +733,16 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   }
   // Two strips (321 .. 640 query rows): ONE launch of two-wave workgroups, the first strip's bottom row handed to the second
   // through LDS (hhv_stream_kernel.h PairLds) instead of two launches with the row in HBM.  Not for masked rounds, the ...AndSS
-  // builds and five-row backtrace strips (LDS-parked query rows); HHV_PAIR=0 keeps the two launches (measurement aid).
+  // builds and five-row backtrace strips (LDS-parked query rows).  Score-only strips of UNEQUAL height (4 + 3, 5 + 4 rows per
+  // lane) stay two launches: the lock step of a heavy and a light wave costs the pair more than the HBM carry costs the
+  // launches since the first strip has kernels of its own (Lq 431: 12.13 vs 11.77 ms, profiles/r4_ab.txt ab-r4-7); with
+  // backtrace the pair is ahead either way (15.05 vs 15.73).  HHV_PAIR=0 / 1: never / whenever eligible (tests, measurements).
   int pair_wgs = 0;
   {
     const char* env = getenv("HHV_PAIR");  // (read per call: the tests switch it inside one process)
-    if (queue && plan.P == 2 && plan.W == LANES && !celloff && !ss && !(env && atoi(env) == 0))
-      pair_wgs = pair_kernel_occupancy(plan.R(0), plan.R(1), local, bt);
+    const bool eligible = queue && plan.P == 2 && plan.W == LANES && !celloff && !ss;
+    const bool wanted = env ? atoi(env) != 0 : (bt || plan.R(0) == plan.R(1));
+    if (eligible && wanted) pair_wgs = pair_kernel_occupancy(plan.R(0), plan.R(1), local, bt);
   }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   if (pair_wgs > 0) {
