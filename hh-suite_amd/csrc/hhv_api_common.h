@@ -67,6 +67,7 @@ struct hhv_ctx {
   bool ss_dirty = true;
   // secondary-structure operands for the next MAC call (hhv_mac_set_ss), consumed by it
   bool mac_ss_pending = false;
+  bool mac_lists = false;  // hhv_mac_set_lists: the following hhv_mac_realign* calls keep the forward / backward list planes
   int mac_ss_Lq = 0;
   std::vector<float> mac_ss_tab;
   std::vector<uint8_t> mac_ss_qidx, mac_ss_tidx;

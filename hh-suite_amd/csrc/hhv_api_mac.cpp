@@ -1,6 +1,8 @@
 // hhv_api_mac.cpp -- C ABI of the MAC realignment.
 #include "hhv_api_common.h"
 
+#include <cmath>
+
 using namespace hhv;
 using hhv::api::dfree;
 using hhv::api::fail;
@@ -19,6 +21,8 @@ struct hhv_macset {
   size_t block_bytes = 0;
   unsigned char* d_celloff = nullptr;
   float* d_mat = nullptr;
+  float* d_fwd_list = nullptr;  // hhv_mac_set_lists: dense planes of the forward / backward list values (else null)
+  float* d_bwd_list = nullptr;
   int32_t* d_path_i = nullptr;
   int32_t* d_path_j = nullptr;
   signed char* d_path_state = nullptr;
@@ -202,6 +206,8 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
                o_pP = carve((size_t)steps * 4);
   const size_t path_bytes = total - o_pi;
   const size_t o_rows = carve((size_t)cls.n[MAC_CLASSES - 1] * 10 * (cls.max_Lt[MAC_CLASSES - 1] + 2) * 8);  // row state of the templates beyond LDS
+  const bool lists = c->mac_lists;
+  const size_t o_fwl = carve(lists ? (size_t)cells * 4 : 0), o_bwl = carve(lists ? (size_t)cells * 4 : 0);
   if (c->mac_cache && c->mac_cache_bytes >= total) {
     ms->d_block = c->mac_cache;
     ms->block_bytes = c->mac_cache_bytes;
@@ -311,6 +317,13 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   a.ss_tidx = with_ss ? (const unsigned char*)(base + o_sst) : nullptr;
   a.ss_toff = with_ss ? (const int64_t*)(base + o_ssoff) : nullptr;
   a.ss_mode = with_ss ? (const int32_t*)(base + o_ssmode) : nullptr;
+  a.fwd_list = lists ? (float*)(base + o_fwl) : nullptr;
+  a.bwd_list = lists ? (float*)(base + o_bwl) : nullptr;
+  ms->d_fwd_list = a.fwd_list;
+  ms->d_bwd_list = a.bwd_list;
+  // (the kernels write the cells the reference visits: rows 1 .. Lq [- 1], active cells; everything else reads as "no entry")
+  if (lists && rc == HHV_OK && hipMemsetAsync(base + o_fwl, 0, (o_bwl - o_fwl) + (size_t)cells * 4, st) != hipSuccess)
+    rc = fail(HHV_E_DEVICE, "hhv_mac_realign: memset failed");
   ms->d_mat = a.mat;
   ms->d_celloff = (unsigned char*)(base + o_co);
   ms->d_path_i = a.path_i;
@@ -485,6 +498,62 @@ int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32
   if (S) memcpy(S, hp + ms->h_pS + (size_t)o * 4, cnt * 4);
   if (P_posterior) memcpy(P_posterior, hp + ms->h_pP + (size_t)o * 4, cnt * 4);
   return HHV_OK;
+}
+
+int hhv_mac_set_lists(hhv_ctx* c, int32_t on) {
+  if (!c) return HHV_E_ARG;
+  c->mac_lists = on != 0;
+  return HHV_OK;
+}
+
+// The reference's three sparse lists of a realigned hit (PosteriorDecoder::writeProfilesToHits, src/hhbacktracemac.cpp:14-110),
+// in its order (sorted by i, then j - what std::sort with compareIndices leaves; the posterior list is built in that order).
+int64_t hhv_mac_list(hhv_macset* ms, int32_t k, int32_t which, int64_t cap, int32_t* li, int32_t* lj, float* lv) {
+  if (!ms || k < 0 || k >= ms->n || which < 0 || which > 2 || cap < 0 || (cap > 0 && (!li || !lj || !lv)))
+    return fail(HHV_E_ARG, "hhv_mac_list: bad argument");
+  if (which < 2 && !ms->d_fwd_list)
+    return fail(HHV_E_STATE, "hhv_mac_list: the set was computed without hhv_mac_set_lists(ctx, 1)");
+  HIP_TRY(hipSetDevice(ms->ctx->par.device));
+  const int Lq = ms->Lq, Lt = ms->Lt[k], pitch = Lt + 1;
+  const size_t cells = (size_t)(Lq + 1) * pitch;
+  std::vector<float> v(cells);
+  const float* src = which == 0 ? ms->d_fwd_list : which == 1 ? ms->d_bwd_list : ms->d_mat;
+  if (hipMemcpy(v.data(), src + ms->mat_off[k], cells * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(HHV_E_DEVICE, "hhv_mac_list: D2H copy failed");
+  std::vector<unsigned char> co;
+  if (which == 2) {
+    co.resize(cells);
+    if (hipMemcpy(co.data(), ms->d_celloff + ms->mat_off[k], cells, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(HHV_E_DEVICE, "hhv_mac_list: D2H copy failed");
+    // backtraceMAC has switched off the cells within two rows / columns of every path step by the time the reference builds
+    // the list (src/hhbacktracemac.cpp:149-154)
+    const int ns = ms->hits[k].nsteps;
+    const int32_t* pi = (const int32_t*)(ms->h_paths + ms->h_pi) + ms->path_off[k];
+    const int32_t* pj = (const int32_t*)(ms->h_paths + ms->h_pj) + ms->path_off[k];
+    for (int s = 1; s <= ns; ++s) {
+      const int i = pi[s], j = pj[s];
+      for (int ii = std::max(i - 2, 1); ii <= std::min(i + 2, Lq); ++ii) co[(size_t)ii * pitch + j] = 1;
+      for (int jj = std::max(j - 2, 1); jj <= std::min(j + 2, Lt); ++jj) co[(size_t)i * pitch + jj] = 1;
+    }
+  }
+  int64_t count = 0;
+  for (int i = 1; i <= Lq; ++i)
+    for (int j = 1; j <= Lt; ++j) {
+      const float x = v[(size_t)i * pitch + j];
+      bool entry;
+      if (which == 2)  // posterior >= POSTERIOR_PROBABILITY_THRESHOLD (src/hhdecl.h:49), cell on, finite (:82-108)
+        entry = x >= 0.01f && !co[(size_t)i * pitch + j] && !std::isinf(x) && !std::isnan(x);
+      else  // the planes hold the value wherever the reference pushed an entry (a value > 1e-4, possibly inf), 0 elsewhere
+        entry = x != 0.0f;
+      if (!entry) continue;
+      if (count < cap) {
+        li[count] = i;
+        lj[count] = j;
+        lv[count] = x;
+      }
+      ++count;
+    }
+  return count;
 }
 
 int hhv_mac_posterior(hhv_macset* ms, int32_t k, float* posterior) {

@@ -261,6 +261,10 @@ struct MacArgs {
   const unsigned char* ss_tidx;   // [cols + n]: per hit Lt+2 entries (index Lt+1 = what the reference reads past the template)
   const int64_t* ss_toff;         // [n] first entry of hit k in ss_tidx
   const int32_t* ss_mode;         // [n] 0, 1, 2
+  // -o_matrices (hhv_mac_set_lists): dense planes laid out like mat, the value of the reference's sparse forward / backward
+  // list entry where it has one, 0 elsewhere; null = not wanted
+  float* fwd_list;
+  float* bwd_list;
 };
 struct MacMaskArgs {
   const int4* ends;          // [n] i1, j1, i2, j2 of the Viterbi alignment

@@ -34,6 +34,8 @@ enum { MAC_STOP = 0, MAC_MM = 2, MAC_IM = 4, MAC_MI = 6 };                      
 // strips of 64 columns whose HBM operands are fetched a whole row ahead in the STAGE variants (templates up to 832 columns;
 // the template itself fits into LDS up to ~800)
 constexpr int MAC_PRE = 13;
+// PosteriorDecoder::m_back_forward_matrix_threshold (src/hhposteriordecoder.cpp:62): a float
+constexpr float MAC_LIST_THRESHOLD = 0.0001f;
 
 __device__ __forceinline__ double shr1_d(double y, double carry) {
   int lo = __double2loint(y), hi = __double2hiint(y);
@@ -366,8 +368,42 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   if (lane == 0) a.Pforward[k] = Pf;
 }
 
+// ---- forward list (-o_matrices) ---------------------------------------------------------------------------------------
+// src/hhforwardalgorithm.cpp:184-219, run between forward and backward (backward turns F_MM into the posterior in place):
+// ffprob = F_MM(i, j) / Pforward * scale_rate(i) in double; where the reference pushes an entry (ffprob > 1e-4) the dense plane
+// a.fwd_list takes (float)ffprob, elsewhere 0.  One workgroup per hit; every thread carries the row constants itself.
+__global__ void __launch_bounds__(256) hhv_mac_fwdlist_kernel(MacArgs a) {
+  const int k = a.sel[blockIdx.x];
+  const HitView h = view(a, k);
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch;
+  float* out = a.fwd_list + a.mat_off[k];
+  const double Pf = a.Pforward[k];
+  double scale_prod = 1.0;  // as the forward loop leaves it (:17, :66-69)
+  for (int i = 2; i <= Lq; ++i) {
+    if (scale_prod < DBL_MIN * 100)
+      scale_prod = 0.0;
+    else
+      scale_prod *= h.scale[i];
+  }
+  const double top = scale_prod * h.scale[Lq + 1];
+  double scale_prod_curr = 1.0;
+  for (int i = 1; i <= Lq; ++i) {
+    if (scale_prod_curr < DBL_MIN * 100)
+      scale_prod_curr = 0.0;
+    else
+      scale_prod_curr *= h.scale[i];
+    const double scale_rate = scale_prod_curr == 0.0 ? 0.0 : top / scale_prod_curr;
+    for (int j = 1 + (int)threadIdx.x; j <= Lt; j += 256) {
+      const double ff = ((double)h.mat[(size_t)i * pitch + j] / Pf) * scale_rate;
+      out[(size_t)i * pitch + j] = ff > (double)MAC_LIST_THRESHOLD ? (float)ff : 0.0f;
+    }
+  }
+}
+
 // ---- backward + posterior ---------------------------------------------------------------------------------------------
-template <bool LOCAL, bool STAGE, bool GROWS>
+// LISTS: the values of the reference's sparse backward list (-o_matrices; src/hhbackwardalgorithm.cpp:112-122) go into the
+// dense plane a.bwd_list: the value where the reference would push an entry, 0 elsewhere (an entry's value is > 1e-4).
+template <bool LOCAL, bool STAGE, bool GROWS, bool LISTS>
 __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = GROWS ? a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2) : reinterpret_cast<double*>(smem);
@@ -409,6 +445,14 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   }
   __syncthreads();
   double scale_prod = sL, pmin = LOCAL ? sL : 0.0;
+  double final_scale_prod = sL;  // :31-36
+  if (LISTS) {
+    for (int i = Lq - 1; i >= 1; --i) {
+      final_scale_prod *= h.scale[i + 1];
+      if (final_scale_prod < DBL_MIN * 100) final_scale_prod = 0.0;
+    }
+  }
+  float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
   unsigned char co_nx = 1;  // mask byte and F_MM of the next strip, fetched while the current one is swept
   float f_nx = 0.0f;
   for (int i = Lq - 1; i >= 1; --i) {
@@ -514,6 +558,14 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
         ROW(cur, F_DG, j) = dg;
         ROW(cur, F_MI, j) = mi;
         row[j] = f_cur * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
+      }
+      if (LISTS && valid && !off) {
+        // :112-122: float = ProbFwd(q.p[i], t.p[j]) * Cshift * B_MM / Pforward * final_scale_prod / scale_prod, left to right
+        float tpj[20];
+        load_tp<STAGE>(h, sTp, jc, tpj);
+        const float sub = dot20(h.qp + (size_t)i * 20, tpj);
+        const float v = (float)((double)sub * Cshift * mm / Pf * final_scale_prod / scale_prod);
+        if (v > MAC_LIST_THRESHOLD) blist[(size_t)i * pitch + j] = v;
       }
       carry_gd = lane_d(gd, 63);
       carry_im = lane_d(im, 63);
@@ -837,9 +889,15 @@ constexpr size_t MAC_LDS_LIMIT = 160 * 1024;
 template <bool LOCAL, bool STAGE, bool GROWS>
 static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t stream) {
   (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<LOCAL, STAGE, GROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>), dim3(n), dim3(64), lds, stream, a);
-  hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE, GROWS>), dim3(n), dim3(64), lds, stream, a);
+  if (a.fwd_list) {  // the -o_matrices lists were asked for (hhv_mac_set_lists)
+    hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
+    (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<LOCAL, STAGE, GROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE, GROWS, true>), dim3(n), dim3(64), lds, stream, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<LOCAL, STAGE, GROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE, GROWS, false>), dim3(n), dim3(64), lds, stream, a);
+  }
 }
 template <bool LOCAL>
 static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream) {

@@ -19,9 +19,11 @@
 // parsing); otherwise it is read and prepared once with the reference's own code
 // (getTemplateHMM + PrepareTemplateHMM with linear transitions, :98-99), in parallel over the groups.
 //
-// Not produced: the sparse forward / backward / posterior lists of writeProfilesToHits (hit.forward_matrix, ...;
-// src/hhbacktracemac.cpp:14-110), which only HitList::PrintMatrices (the hidden -o_matrices output) reads; they are left
-// NULL and PrintMatrices skips such hits.  Secondary-structure scoring inside forward / backward (hit.ssm2 = 1 or 2: a query
+// The sparse forward / backward / posterior lists and the two profiles of writeProfilesToHits (hit.forward_matrix, ...;
+// src/hhbacktracemac.cpp:14-110) are read by HitList::PrintMatrices only (the hidden -o_matrices output): they are produced
+// when that output is asked for (par.matrices_output_file; HHV_MAC_LISTS=1 forces them) - entry for entry the reference's
+// (hhv_mac_list) - and left NULL otherwise (the reference computes them for every hit of every search; PrintMatrices skips
+// hits without them).  Secondary-structure scoring inside forward / backward (hit.ssm2 = 1 or 2: a query
 // with predicted SS against templates with DSSP records - the HHpred case - or the reverse; ssm2 = 3 scores nothing in the
 // reference, Viterbi::ScoreSS has no case 3) runs on the device from tables of fpow2(ScoreSS) (hhv_mac_set_ss).  One cell
 // column is not reproducible: for column 1 the reference calls ScoreSS with a stale loop variable and reads the template's
@@ -73,6 +75,47 @@ std::vector<int32_t> mac_region_pairs(char* exclstr) {  // exclude_regions, src/
     out.push_back(b);
   }
   return out;
+}
+
+// writeProfilesToHits (src/hhbacktracemac.cpp:14-110): the three lists as arrays of float[3] = {i, j, value} owned by the Hit
+// (freed by Hit::Delete like the reference's), the profiles = the sums of a list's values per query row, in list order
+void mac_lists_to_hit(hhv_macset* ms, int b, int Lq, Hit& hit) {
+  if (hit.forward_profile) delete[] hit.forward_profile;
+  hit.forward_profile = new float[Lq + 1];
+  if (hit.backward_profile) delete[] hit.backward_profile;
+  hit.backward_profile = new float[Lq + 1];
+  for (int i = 0; i <= Lq; i++) hit.backward_profile[i] = hit.forward_profile[i] = 0;
+  float*** const mat[3] = {&hit.backward_matrix, &hit.forward_matrix, &hit.posterior_matrix};
+  size_t* const cnt[3] = {&hit.backward_entries, &hit.forward_entries, &hit.posterior_entries};
+  float* const prof[3] = {hit.backward_profile, hit.forward_profile, NULL};
+  const int which[3] = {1, 0, 2};  // (the reference fills backward first)
+  std::vector<int32_t> li, lj;
+  std::vector<float> lv;
+  for (int w = 0; w < 3; ++w) {
+    if (*mat[w]) {
+      for (size_t e = 0; e < *cnt[w]; e++) delete[] (*mat[w])[e];
+      delete[] *mat[w];
+    }
+    int64_t n = hhv_mac_list(ms, b, which[w], 0, NULL, NULL, NULL);
+    if (n < 0) mac_check((int)n, "hhv_mac_list");
+    li.resize((size_t)n);
+    lj.resize((size_t)n);
+    lv.resize((size_t)n);
+    if (n > 0) {
+      const int64_t m = hhv_mac_list(ms, b, which[w], n, li.data(), lj.data(), lv.data());
+      if (m != n) mac_check(m < 0 ? (int)m : HHV_E_STATE, "hhv_mac_list");
+    }
+    *cnt[w] = (size_t)n;
+    *mat[w] = new float*[(size_t)n];
+    for (int64_t e = 0; e < n; ++e) {
+      float* t = new float[3];
+      t[0] = li[(size_t)e];
+      t[1] = lj[(size_t)e];
+      t[2] = lv[(size_t)e];
+      (*mat[w])[e] = t;
+      if (prof[w]) prof[w][li[(size_t)e]] += lv[(size_t)e];
+    }
+  }
 }
 
 // The device context is the process-wide one of the resident template cache (hhv_template_cache.h): stream, tables and the
@@ -302,6 +345,8 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   }
 
 
+  static const bool force_lists = getenv("HHV_MAC_LISTS") && atoi(getenv("HHV_MAC_LISTS")) != 0;
+  const bool want_lists = force_lists || par.matrices_output_file[0] != 0;
   // ---- round r: the r-th alignment of every template ----
   for (size_t r = 0; r < rounds; ++r) {
     std::vector<int> group_of;
@@ -360,6 +405,7 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
     hhv_macset* ms = NULL;
     std::vector<hhv_mac_hit> res(n);
     t_mark = mac_now();
+    mac_check(hhv_mac_set_lists(ctx, want_lists ? 1 : 0), "hhv_mac_set_lists");
     mac_check(hhv_mac_realign_hits(ctx, q_p.data(), q_tr.data(), q.L, n, Lt.data(), tp.data(), ttr.data(), in.data(),
                                    (int32_t)q_ranges.size() / 2, q_ranges.data(), (int32_t)t_ranges.size() / 2, t_ranges.data(),
                                    par.loc, par.shift, par.mact, &ms, res.data()),
@@ -432,6 +478,7 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
         hit.sum_of_probs = sum;
       }
       // score, score_ss, score_aass, Pval, Pvalt, logPval, logPvalt, Eval, logEval, Probab: untouched = restoreHitValues
+      if (want_lists) mac_lists_to_hit(ms, b, q.L, hit);  // writeProfilesToHits (:117)
     }
     hhv_macset_free(ms);
     t_hits += mac_now() - t_mark;

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of", "hhv_tset_download",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
-    "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_macset_free",
+    "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_mac_set_lists", "hhv_mac_list", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
     "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
@@ -135,6 +135,9 @@ def load(path=None):
                                C.POINTER(C.c_int32)]
     L.hhv_mac_posterior.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.hhv_mac_celloff.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.hhv_mac_set_lists.argtypes = [C.c_void_p, C.c_int32]
+    L.hhv_mac_list.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hhv_mac_list.restype = C.c_int64
     L.hhv_macset_free.argtypes = [C.c_void_p]
     L.hhv_macset_free.restype = None
     L.hhv_db_write.argtypes = [C.c_char_p, C.c_int32, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.c_void_p,
@@ -451,6 +454,10 @@ class Context:
                                              sub.ctypes.data if sub is not None else None, 0 if sub is None else len(sub),
                                              out.ctypes.data))
         return out
+
+    def mac_set_lists(self, on):
+        """hhv_mac_set_lists: keep the -o_matrices forward / backward lists of the following mac_realign* calls"""
+        _check(self.lib.hhv_mac_set_lists(self.h, int(on)))
 
     def mac_realign(self, qp, q_tr_lin, tps, t_trs, celloffs=None, local=1, shift=-0.03, mact=0.3501):
         """hhv_mac_realign -> MacSet (hits structured array + path()/posterior() accessors)."""
@@ -779,6 +786,17 @@ class MacSet:
         out = np.zeros((self.Lq + 1, int(self.Lt[k]) + 1), np.float32)
         _check(self.lib.hhv_mac_posterior(self.h, k, out.ctypes.data))
         return out
+
+    def list(self, k, which):
+        """hhv_mac_list: the reference's sparse forward (0) / backward (1) / posterior (2) list of hit k -> (i, j, value)"""
+        n = self.lib.hhv_mac_list(self.h, k, which, 0, None, None, None)
+        if n < 0:
+            _check(int(n))
+        li, lj, lv = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        if n:
+            m = self.lib.hhv_mac_list(self.h, k, which, n, li.ctypes.data, lj.ctypes.data, lv.ctypes.data)
+            assert m == n, (m, n)
+        return li, lj, lv
 
     def free(self):
         if self.h:

@@ -312,6 +312,17 @@ int hhv_mac_path(hhv_macset* ms, int32_t k, int32_t cap, int32_t* i_steps, int32
                  float* P_posterior, int32_t* nsteps);
 /* dense posterior matrix of hit k, (Lq+1)*(Lt+1) floats (row 0 / column 0 unused) */
 int hhv_mac_posterior(hhv_macset* ms, int32_t k, float* posterior);
+/* The sparse lists the reference attaches to a realigned hit for its -o_matrices output (PosteriorDecoder::
+ * writeProfilesToHits, src/hhbacktracemac.cpp:14-110; entries pushed by src/hhforwardalgorithm.cpp:184-219 and
+ * src/hhbackwardalgorithm.cpp:112-122): which = 0 forward (Hit::forward_matrix), 1 backward (Hit::backward_matrix),
+ * 2 posterior (Hit::posterior_matrix: posterior >= 0.01, finite, cell on - the mask of the DP plus the cells within two rows /
+ * columns of a step of the MAC path, which backtraceMAC switches off before the list is built).  Entries (i, j, value) in the reference's order
+ * (i ascending, then j).  Returns the number of entries of the list (also when cap is smaller: call again with room), or
+ * a negative error.  Lists 0 and 1 exist only for sets computed after hhv_mac_set_lists(ctx, 1) - the setting holds until it is
+ * changed and costs two more matrices per hit on the device; Hit::forward_profile[i] / backward_profile[i] are the sums of a
+ * list's values of row i in list order. */
+int hhv_mac_set_lists(hhv_ctx* ctx, int32_t on);
+int64_t hhv_mac_list(hhv_macset* ms, int32_t k, int32_t which, int64_t cap, int32_t* i, int32_t* j, float* value);
 void hhv_macset_free(hhv_macset* ms);
 
 /* A new template set made of templates ids[0..n) of a resident one (any order, repeats allowed), copied on the device:

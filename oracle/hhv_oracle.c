@@ -807,8 +807,57 @@ int hho_mac_forward(const float *qp, const float *qtr, int Lq, const float *tp, 
   return 0;
 }
 
+/* PosteriorDecoder::m_back_forward_matrix_threshold (src/hhposteriordecoder.cpp:62): a float */
+static const float mac_list_threshold = 0.0001f;
+
+/* "save forward profile" (src/hhforwardalgorithm.cpp:184-219), on forward's outputs and before backward overwrites fwd: the
+ * dense plane `list` ((Lq+1)*(Lt+1)) takes (float)ffprob where the reference pushes an entry (ffprob > 1e-4), 0 elsewhere.
+ * Entries read row by row, column by column are the reference's sorted list (src/hhbacktracemac.cpp:68-80). */
+int hho_mac_forward_list(const float *fwd, int Lq, int Lt, const double *scale, double Pforward, float *list) {
+  const int pitch = Lt + 1;
+  double scale_prod = 1.0; /* as forward's row loop leaves it (:17, :66-69) */
+  for (int i = 2; i <= Lq; ++i) {
+    if (scale_prod < DBL_MIN * 100)
+      scale_prod = 0.0;
+    else
+      scale_prod *= scale[i];
+  }
+  memset(list, 0, sizeof(float) * (size_t)(Lq + 1) * pitch);
+  double scale_rate, scale_prod_curr = 1.0, ffprob;
+  for (int i = 1; i <= Lq; ++i) {
+    if (scale_prod_curr < DBL_MIN * 100)
+      scale_prod_curr = 0.0;
+    else
+      scale_prod_curr *= scale[i];
+    for (int j = 1; j <= Lt; ++j) {
+      if (scale_prod_curr == 0.0)
+        scale_rate = 0.0;
+      else
+        scale_rate = (scale_prod * scale[Lq + 1]) / scale_prod_curr;
+      ffprob = (fwd[(size_t)i * pitch + j] / Pforward) * scale_rate;
+      if (ffprob > mac_list_threshold) list[(size_t)i * pitch + j] = (float)ffprob;
+    }
+  }
+  return 0;
+}
+
+static int mac_backward_impl(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                             float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post,
+                             float *blist);
 int hho_mac_backward(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
                      float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post) {
+  return mac_backward_impl(qp, qtr, Lq, tp, ttr, Lt, local, shift, celloff, scale, Pforward, post, NULL);
+}
+/* the same, and the backward list (src/hhbackwardalgorithm.cpp:112-122) as a dense plane like hho_mac_forward_list's */
+int hho_mac_backward_list(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                          float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post,
+                          float *blist) {
+  memset(blist, 0, sizeof(float) * (size_t)(Lq + 1) * (Lt + 1));
+  return mac_backward_impl(qp, qtr, Lq, tp, ttr, Lt, local, shift, celloff, scale, Pforward, post, blist);
+}
+static int mac_backward_impl(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                             float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post,
+                             float *blist) {
   const int pitch = Lt + 1;
   mac_col *curr = (mac_col *)calloc((size_t)Lt + 3, sizeof(mac_col)), *prev = (mac_col *)calloc((size_t)Lt + 3, sizeof(mac_col));
   if (!curr || !prev) return -1;
@@ -824,6 +873,11 @@ int hho_mac_backward(const float *qp, const float *qtr, int Lq, const float *tp,
       *pv = (float)(*pv * scale[Lq + 1] / Pforward);
     }
     prev[j].mi = prev[j].dg = 0.0;
+  }
+  double final_scale_prod = scale[Lq + 1]; /* :31-36 */
+  for (int i = Lq - 1; i >= 1; i--) {
+    final_scale_prod *= scale[i + 1];
+    if (final_scale_prod < DBL_MIN * 100) final_scale_prod = 0.0;
   }
   double pmin = local ? scale[Lq + 1] : 0.0;
   for (int i = Lq - 1; i >= 1; --i) {
@@ -851,6 +905,11 @@ int hho_mac_backward(const float *qp, const float *qtr, int Lq, const float *tp,
       curr[j].im = (+pmatch * QT(i, T_I2M) * TT(j, T_M2M) + curr[j + 1].im * QT(i, T_I2I) * TT(j, T_M2M));
       curr[j].dg = (+pmatch * QT(i, T_D2M) * TT(j, T_M2M) + prev[j].dg * QT(i, T_D2D) * scale[i + 1]);
       curr[j].mi = (+pmatch * QT(i, T_M2M) * TT(j, T_I2M) + prev[j].mi * QT(i, T_M2M) * TT(j, T_I2I) * scale[i + 1]);
+      if (blist) { /* :112-122 */
+        float substitutionScore = PF(i, j);
+        float actual_backward_single = substitutionScore * Cshift * curr[j].mm / Pforward * final_scale_prod / scale_prod;
+        if (actual_backward_single > mac_list_threshold) blist[(size_t)i * pitch + j] = actual_backward_single;
+      }
     }
     /* multiplyPosteriorValue takes a float: F (float) * (float)(B / Pforward) (:122-124, hhposteriormatrix.h:43) */
     for (int j = 1; j <= Lt - 1; ++j) row[j] *= (float)(curr[j].mm / Pforward);

@@ -114,6 +114,14 @@ int hho_mac_forward(const float *qp, const float *qtr, int Lq, const float *tp, 
                     float shift, const unsigned char *celloff, float *fwd, double *scale, double *Pforward);
 int hho_mac_backward(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
                      float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post);
+/* The sparse lists of the reference's -o_matrices output as dense planes ((Lq+1)*(Lt+1) floats: the entry's value where the
+ * reference pushes one, 0 elsewhere; row-major order = the reference's sorted lists, src/hhbacktracemac.cpp:52-80):
+ *   hho_mac_forward_list   src/hhforwardalgorithm.cpp:184-219, on forward's fwd / scale / Pforward (before backward)
+ *   hho_mac_backward_list  hho_mac_backward + src/hhbackwardalgorithm.cpp:31-36,112-122 */
+int hho_mac_forward_list(const float *fwd, int Lq, int Lt, const double *scale, double Pforward, float *list);
+int hho_mac_backward_list(const float *qp, const float *qtr, int Lq, const float *tp, const float *ttr, int Lt, int local,
+                          float shift, const unsigned char *celloff, const double *scale, double Pforward, float *post,
+                          float *blist);
 int hho_mac_dp(const float *post, const unsigned char *celloff, int Lq, int Lt, int local, float mact, unsigned char *bmm,
                int *i2, int *j2);
 int hho_mac_backtrace(unsigned char *bmm, const float *post, const float *qp, const float *tp, int Lq, int Lt, int i2, int j2,

@@ -564,7 +564,52 @@ def ref_mac_realign(ref, qp, qtr, tp, ttr, vit, local=1, shift=-0.03, mact=0.350
            C.addressof(o.Pforward), o.scalars.ctypes.data, C.addressof(o.sum_of_probs), o.i_steps.ctypes.data,
            o.j_steps.ctypes.data, o.states.ctypes.data, o.S.ctypes.data, o.P.ctypes.data)
     assert rc == 0
+    # what writeProfilesToHits attached to the hit: lists[w] = (i, j, value) of forward / backward / posterior, profiles[w]
+    ll = ref.lib.ref_mac_last_list
+    ll.restype = C.c_long
+    ll.argtypes = [C.c_int, C.c_long, C.c_void_p]
+    o.lists = []
+    for w in range(3):
+        n = ll(w, 0, None)
+        t = np.zeros((n, 3), np.float32)
+        assert ll(w, n, t.ctypes.data) == n
+        o.lists.append((t[:, 0].astype(np.int32), t[:, 1].astype(np.int32), t[:, 2].copy()))
+    o.profiles = []
+    for w in range(2):
+        pr = np.zeros(Lq + 1, np.float32)
+        assert ref.lib.ref_mac_last_profile(w, C.c_void_p(pr.ctypes.data)) == Lq + 1
+        o.profiles.append(pr)
     return _mac_finish(o)
+
+
+def mac_plane_to_list(plane):
+    """dense list plane (value where the reference has an entry, 0 elsewhere) -> (i, j, value) in the reference's order"""
+    i, j = np.nonzero(plane[1:, 1:] != 0)
+    return (i + 1).astype(np.int32), (j + 1).astype(np.int32), plane[i + 1, j + 1].astype(np.float32)
+
+
+def mac_posterior_list(posterior, celloff, i_steps, j_steps, nsteps):
+    """Hit::posterior_matrix (src/hhbacktracemac.cpp:82-108): posterior >= 0.01, finite, cell on - by then backtraceMAC has
+    switched off the cells within two rows / columns of every path step (:149-154)"""
+    p = posterior[1:, 1:]
+    co = celloff.copy()
+    Lq, Lt = co.shape[0] - 1, co.shape[1] - 1
+    for s in range(1, nsteps + 1):
+        i, j = int(i_steps[s]), int(j_steps[s])
+        co[max(i - 2, 1):min(i + 2, Lq) + 1, j] = 1
+        co[i, max(j - 2, 1):min(j + 2, Lt) + 1] = 1
+    with np.errstate(invalid="ignore"):
+        keep = (p >= np.float32(0.01)) & (co[1:, 1:] == 0) & np.isfinite(p)
+    i, j = np.nonzero(keep)
+    return (i + 1).astype(np.int32), (j + 1).astype(np.int32), p[i, j].astype(np.float32)
+
+
+def mac_list_profile(lst, Lq):
+    """Hit::forward_profile / backward_profile: float sums of a list's values per row, in list order (src/hhbacktracemac.cpp:64,79)"""
+    out = np.zeros(Lq + 1, np.float32)
+    for i, v in zip(lst[0], lst[2]):
+        out[i] = np.float32(out[i] + v)
+    return out
 
 
 def oracle_mac_realign(orc, qp, q_tr_lin, tp, t_tr_lin, vit, local=1, shift=-0.03, mact=0.3501, min_overlap=0, prev=()):
@@ -590,8 +635,15 @@ def oracle_mac_realign(orc, qp, q_tr_lin, tp, t_tr_lin, vit, local=1, shift=-0.0
                              shift, o.celloff.ctypes.data, o.forward.ctypes.data, o.scale.ctypes.data,
                              C.addressof(o.Pforward)) == 0
     o.posterior[:] = o.forward
-    assert L.hho_mac_backward(qp.ctypes.data, q_tr_lin.ctypes.data, Lq, tp.ctypes.data, t_tr_lin.ctypes.data, Lt, int(local),
-                              shift, o.celloff.ctypes.data, o.scale.ctypes.data, o.Pforward.value, o.posterior.ctypes.data) == 0
+    # the -o_matrices lists as dense planes (value where the reference pushes an entry, 0 elsewhere)
+    o.fwd_list = np.zeros((Lq + 1, Lt + 1), np.float32)
+    o.bwd_list = np.zeros((Lq + 1, Lt + 1), np.float32)
+    L.hho_mac_forward_list.argtypes = [V, C.c_int, C.c_int, V, C.c_double, V]
+    L.hho_mac_backward_list.argtypes = [V, V, C.c_int, V, V, C.c_int, C.c_int, C.c_float, V, V, C.c_double, V, V]
+    assert L.hho_mac_forward_list(o.forward.ctypes.data, Lq, Lt, o.scale.ctypes.data, o.Pforward.value, o.fwd_list.ctypes.data) == 0
+    assert L.hho_mac_backward_list(qp.ctypes.data, q_tr_lin.ctypes.data, Lq, tp.ctypes.data, t_tr_lin.ctypes.data, Lt, int(local),
+                                   shift, o.celloff.ctypes.data, o.scale.ctypes.data, o.Pforward.value, o.posterior.ctypes.data,
+                                   o.bwd_list.ctypes.data) == 0
     i2, j2 = C.c_int(), C.c_int()
     assert L.hho_mac_dp(o.posterior.ctypes.data, o.celloff.ctypes.data, Lq, Lt, int(local), mact, o.bmm.ctypes.data,
                         C.addressof(i2), C.addressof(j2)) == 0

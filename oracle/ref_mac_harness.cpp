@@ -5,6 +5,7 @@
 //     backwardAlgorithm  src/hhbackwardalgorithm.cpp:10-135
 //     macAlgorithm       src/hhmacalgorithm.cpp:18-179
 //     backtraceMAC       src/hhbacktracemac.cpp:113-272
+//     writeProfilesToHits  src/hhbacktracemac.cpp:14-110 (the sparse lists of the -o_matrices output)
 // run on two prepared HMMs given as tensors (the same p / log2-tr arrays the Viterbi harness takes) and a
 // Viterbi hit (end points + path).  The harness does what PosteriorDecoderRunner::executeComputation does around
 // realign (src/hhposteriordecoderrunner.cpp:43-119): Log2LinTransitionProbs(1.0) on both HMMs,
@@ -34,6 +35,9 @@ HMM* make_hmm(const float* p, const float* tr_log, int L) {
 float zS73[NDSSP][NSSPRED][MAXCF];
 float zS33[NSSPRED][MAXCF][NSSPRED][MAXCF];
 float zS37[NSSPRED][MAXCF][NDSSP];
+// what writeProfilesToHits (src/hhbacktracemac.cpp:14-110) attached to the hit of the last ref_mac_realign call:
+// lists 0 forward, 1 backward, 2 posterior as (i, j, value), and the two profiles
+std::vector<float> g_list[3], g_profile[2];
 }  // namespace
 
 extern "C" {
@@ -121,6 +125,17 @@ int ref_mac_realign(const float* q_p, const float* q_tr_log, int Lq, const float
   dec.backtraceMAC(*q, *t, pm, vm, 0, hit, corr);
   for (int i = 0; i <= Lq; ++i)
     for (int j = 0; j <= Lt; ++j) bmm[(size_t)i * (Lt + 1) + j] = (unsigned char)vm.getMatMat(i, j, 0);
+  dec.writeProfilesToHits(*q, *t, pm, vm, hit);  // (realign() calls it last, :117)
+  {
+    float** const m[3] = {hit.forward_matrix, hit.backward_matrix, hit.posterior_matrix};
+    const size_t n[3] = {hit.forward_entries, hit.backward_entries, hit.posterior_entries};
+    for (int w = 0; w < 3; ++w) {
+      g_list[w].clear();
+      for (size_t e = 0; e < n[w]; ++e) g_list[w].insert(g_list[w].end(), m[w][e], m[w][e] + 3);
+    }
+    g_profile[0].assign(hit.forward_profile, hit.forward_profile + Lq + 1);
+    g_profile[1].assign(hit.backward_profile, hit.backward_profile + Lq + 1);
+  }
   o_scalars[0] = hit.nsteps;
   o_scalars[1] = hit.i1;
   o_scalars[2] = hit.j1;
@@ -138,6 +153,21 @@ int ref_mac_realign(const float* q_p, const float* q_tr_log, int Lq, const float
   delete q;
   delete t;
   return 0;
+}
+
+// list `which` (0 forward, 1 backward, 2 posterior) of the last ref_mac_realign call: returns the number of entries and
+// copies up to cap of them as float triples (i, j, value) - the layout of Hit::forward_matrix[e][0..2]
+long ref_mac_last_list(int which, long cap, float* triples) {
+  const std::vector<float>& l = g_list[which];
+  const long n = (long)(l.size() / 3);
+  for (long e = 0; e < n && e < cap; ++e)
+    for (int c = 0; c < 3; ++c) triples[e * 3 + c] = l[(size_t)e * 3 + c];
+  return n;
+}
+// Hit::forward_profile (0) / backward_profile (1) of the last call, Lq + 1 floats
+int ref_mac_last_profile(int which, float* out) {
+  for (size_t i = 0; i < g_profile[which].size(); ++i) out[i] = g_profile[which][i];
+  return (int)g_profile[which].size();
 }
 
 }  // extern "C"

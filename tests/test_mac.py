@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from pyhhv import synth
-from pyoracle import make_params, oracle_mac_realign, ref_mac_realign
+from pyoracle import (mac_list_profile, mac_plane_to_list, mac_posterior_list, make_params, oracle_mac_realign,
+                      ref_mac_realign)
 
 CASES = [
     # (Lq, Lt, local, homolog?, mact)
@@ -70,6 +71,20 @@ def same(a, b):
     assert np.float32(a.sum_of_probs).tobytes() == np.float32(b.sum_of_probs).tobytes()
 
 
+def lists_of(o):
+    """the three lists of an oracle result (dense planes -> entries in the reference's order)"""
+    return [mac_plane_to_list(o.fwd_list), mac_plane_to_list(o.bwd_list), mac_posterior_list(o.posterior, o.celloff, o.i_steps, o.j_steps, o.nsteps)]
+
+
+def same_lists(got, r, Lq):
+    """got: three (i, j, value) lists; r: a reference result with .lists / .profiles"""
+    for w in range(3):
+        assert np.array_equal(got[w][0], r.lists[w][0]) and np.array_equal(got[w][1], r.lists[w][1]), (w, len(got[w][0]), len(r.lists[w][0]))
+        assert got[w][2].tobytes() == r.lists[w][2].tobytes(), w
+    for w in range(2):
+        assert mac_list_profile(got[w], Lq).tobytes() == r.profiles[w].tobytes(), w
+
+
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_oracle_mac_matches_reference(oracle, ref, case):
     qp, qtr, tp, ttr, local, mact = make_pair(case)
@@ -86,6 +101,8 @@ def test_oracle_mac_matches_reference(oracle, ref, case):
         assert o.posterior[1:, 1:].tobytes() == r.posterior[1:, 1:].tobytes()
         assert np.array_equal(o.bmm[1:, 1:], r.bmm[1:, 1:])
         same(o, r)
+        # the -o_matrices lists (writeProfilesToHits): forward, backward, posterior entries and the two profiles
+        same_lists(lists_of(o), r, o.forward.shape[0] - 1)
         prev.append((r.i_steps[(0 if r.nsteps == 0 else 1):r.nsteps + 1].copy(), r.j_steps[(0 if r.nsteps == 0 else 1):r.nsteps + 1].copy()))
     assert r.nsteps >= 0
 
@@ -156,6 +173,7 @@ def test_gpu_mac_matches_oracle(oracle, local):
     cases = [c for c in range(len(CASES)) if CASES[c][0] == 120 or True]
     # one query per launch: group the cases by Lq
     c = capi.Context()
+    c.mac_set_lists(1)
     for case in cases:
         qp, qtr, tp, ttr, _, mact = make_pair(case)
         par = make_params(local=local, ss_mode=0)
@@ -178,8 +196,49 @@ def test_gpu_mac_matches_oracle(oracle, local):
             assert np.array_equal(st[1:], o.states[1:n + 1])
             assert S[1:].tobytes() == o.S[1:n + 1].tobytes() and P[1:].tobytes() == o.P[1:n + 1].tobytes()
             assert np.float32(h["sum_of_probs"]).tobytes() == np.float32(o.sum_of_probs).tobytes()
+            want = lists_of(o)
+            for w in range(3):
+                li, lj, lv = ms.list(0, w)
+                assert np.array_equal(li, want[w][0]) and np.array_equal(lj, want[w][1]), (case, rnd, w, len(li), len(want[w][0]))
+                assert lv.tobytes() == want[w][2].tobytes(), (case, rnd, w)
+            assert len(want[0][0]) > 0 and len(want[1][0]) > 0
             ms.free()
             prev.append((o.i_steps[lo:n + 1].copy(), o.j_steps[lo:n + 1].copy()))
+    c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_mac_lists_match_reference_in_a_batch(oracle, ref):
+    """hhv_mac_set_lists + hhv_mac_list on a ragged batch (all length classes that fit a small test: staged, lean) against the
+    lists the reference's writeProfilesToHits attaches to the hit; without hhv_mac_set_lists the forward / backward lists are
+    refused and the posterior list still works."""
+    from pyhhv import capi
+    Lq = 150
+    qp, qtr = synth.make_query(777, Lq)
+    q_lin = capi.linear_transitions(qtr, True)
+    tps, t_lins, cos, want = [], [], [], []
+    for k, Lt in enumerate([40, 129, 300, 64, 1100]):
+        tp, ttr = synth.make_homolog(40 + k, qp, L=Lt)
+        vit = oracle.align(make_params(local=1, ss_mode=0), qp, qtr, tp, ttr, want_path=True)
+        r = ref_mac_realign(ref, qp, qtr, tp, ttr, vit, local=1)
+        tps.append(tp)
+        t_lins.append(r.t_tr_lin)
+        cos.append(r.celloff)
+        want.append(r)
+    c = capi.Context()
+    c.mac_set_lists(1)
+    ms = c.mac_realign(qp, q_lin, tps, t_lins, cos, local=1)
+    for k, r in enumerate(want):
+        got = [ms.list(k, w) for w in range(3)]
+        same_lists(got, r, Lq)
+    ms.free()
+    c.mac_set_lists(0)
+    ms = c.mac_realign(qp, q_lin, tps, t_lins, cos, local=1)
+    with pytest.raises(capi.HhvError):
+        ms.list(0, 0)
+    got = ms.list(1, 2)
+    assert np.array_equal(got[0], want[1].lists[2][0]) and got[2].tobytes() == want[1].lists[2][2].tobytes()
+    ms.free()
     c.close()
 
 
