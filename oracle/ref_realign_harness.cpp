@@ -58,14 +58,28 @@ class MemEntry : public HHEntry {
 
 extern "C" {
 
+static uint32_t fnv(uint32_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t k = 0; k < n; ++k) h = (h ^ b[k]) * 16777619u;
+  return h;
+}
+static int32_t fnv_triples(float** m, size_t n) {
+  uint32_t h = 2166136261u;
+  for (size_t e = 0; e < n; ++e) h = fnv(h, m[e], 12);
+  return (int32_t)h;
+}
+
 struct rl_hit {
   int32_t entry, irep, nsteps, matched_cols, i1, j1, i2, j2, n_alt, state, min_overlap, realign_around_viterbi;
+  // opts_i[7]: the lists writeProfilesToHits attaches (-o_matrices): entries and FNV-1a of the float triples, of the profiles
+  int32_t n_fwd, n_bwd, n_post, h_fwd, h_bwd, h_post, h_fprof, h_bprof;
   float score, score_ss, score_aass, sum_of_probs;
   double Pforward;
 };
 
 // opts_i: [0] loc [1] altali [2] ssm [3] maxres [4] threads [5] realign every hit with Viterbi score above smin only (0/1)
 //         [6] wg (par.wg: global sequence weights when templates are built from alignments)
+//         [7] 1 = par.matrices_output_file set (the -o_matrices lists are wanted) and reported in rl_hit
 // opts_f: [0] smin [1] mact [2] ssw
 // Returns the number of realigned hits (in the order of the Viterbi hit vector) or a negative error.
 int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* tmpl_hhm, const size_t* tmpl_len,
@@ -86,6 +100,7 @@ int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* 
   par.maxres = opts_i[3];
   par.threads = opts_i[4];
   par.wg = opts_i[6];
+  if (opts_i[7]) strcpy(par.matrices_output_file, "stdout");  // (nothing is printed: the harness never calls writeMatricesFile)
   par.smin = opts_f[0];
   par.mact = opts_f[1];
   par.ssw = opts_f[2];
@@ -170,6 +185,16 @@ int RUN_NAME(const char* query_hhm, size_t query_len, int n, const char* const* 
     o.score_aass = x.score_aass;
     o.sum_of_probs = x.sum_of_probs;
     o.Pforward = x.Pforward;
+    if (opts_i[7]) {
+      o.n_fwd = x.forward_matrix ? (int32_t)x.forward_entries : -1;
+      o.n_bwd = x.backward_matrix ? (int32_t)x.backward_entries : -1;
+      o.n_post = x.posterior_matrix ? (int32_t)x.posterior_entries : -1;
+      o.h_fwd = x.forward_matrix ? fnv_triples(x.forward_matrix, x.forward_entries) : 0;
+      o.h_bwd = x.backward_matrix ? fnv_triples(x.backward_matrix, x.backward_entries) : 0;
+      o.h_post = x.posterior_matrix ? fnv_triples(x.posterior_matrix, x.posterior_entries) : 0;
+      o.h_fprof = x.forward_profile ? (int32_t)fnv(2166136261u, x.forward_profile, (size_t)(q->L + 1) * 4) : 0;
+      o.h_bprof = x.backward_profile ? (int32_t)fnv(2166136261u, x.backward_profile, (size_t)(q->L + 1) * 4) : 0;
+    }
     hits[h] = o;
     const int c = std::min(path_cap, x.nsteps + 1);
     for (int s = 1; s < c; ++s) {

@@ -143,6 +143,23 @@ def test_hhblits_with_replaced_units_writes_the_same_files(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not have("hhblits_hip"), reason="oracle/_ref/hhblits_hip not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("extra", [[], ["-filter_matrices"]])
+def test_hhblits_omat_with_replaced_units_writes_the_same_matrices_file(tmp_path, extra):
+    """hhblits -omat <file> (HHblits::writeMatricesFile -> HitList::PrintMatrices, src/hhhitlist.cpp:533-800): the binary file of
+    the forward / backward profiles and the sparse posterior lists of the accepted hits, built from what the realign stage
+    attached to the Hit objects (writeProfilesToHits) - byte for byte the reference's."""
+    q, t, names = make_db(503, 140, 300, 50, 220, homolog_every=3)
+    base, qpath = build_db(str(tmp_path), q, t, names, 3)
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-n", "1", "-cpu", "1"] + extra
+    cpu = run_app("hhblits_cpu", args + ["-omat", str(tmp_path / "cpu.mat")], str(tmp_path / "cpu"))
+    hip = run_app("hhblits_hip", args + ["-omat", str(tmp_path / "hip.mat")], str(tmp_path / "hip"))
+    compare_outputs(cpu, hip)
+    a, b = open(tmp_path / "cpu.mat", "rb").read(), open(tmp_path / "hip.mat", "rb").read()
+    assert len(a) > 10000 and a == b
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not have("hhalign_hip"), reason="oracle/_ref/hhalign_hip not built (needs /root/reference at build time)")
 def test_hhalign_with_replaced_units_writes_the_same_files(tmp_path):
     """hhalign -i query -t template ...: HHalign::run hands HHFileEntry objects (files on disk) to the same ViterbiRunner"""

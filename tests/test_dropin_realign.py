@@ -13,12 +13,13 @@ from test_dropin_runner import _lib, make_db
 
 class RLHit(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("entry", "irep", "nsteps", "matched_cols", "i1", "j1", "i2", "j2", "n_alt",
-                                               "state", "min_overlap", "realign_around_viterbi")] + \
+                                               "state", "min_overlap", "realign_around_viterbi",
+                                               "n_fwd", "n_bwd", "n_post", "h_fwd", "h_bwd", "h_post", "h_fprof", "h_bprof")] + \
                [(n, ctypes.c_float) for n in ("score", "score_ss", "score_aass", "sum_of_probs")] + [("Pforward", ctypes.c_double)]
 
 
 def realign(which, query, templates, names, loc=1, altali=3, ssm=2, maxres=2000, threads=1, only_above_smin=1, smin=20.0,
-            mact=0.3501, ssw=0.11, excl="", texcl="", path_cap=1400, wg=0):
+            mact=0.3501, ssw=0.11, excl="", texcl="", path_cap=1400, wg=0, lists=0):
     lib = _lib()
     fn = getattr(lib, "ref_realign_run_" + which)
     n = len(templates)
@@ -33,7 +34,7 @@ def realign(which, query, templates, names, loc=1, altali=3, ssm=2, maxres=2000,
         sl = np.asarray(globals()["_seq_len_override"], dtype=np.int32)
     else:
         sl = np.asarray([int(t.split(b"LENG")[1].split()[0]) if t else 1 for t in templates], dtype=np.int32)
-    oi = np.asarray([loc, altali, ssm, maxres, threads, only_above_smin, wg], dtype=np.int32)
+    oi = np.asarray([loc, altali, ssm, maxres, threads, only_above_smin, wg, lists], dtype=np.int32)
     of = np.asarray([smin, mact, ssw], dtype=np.float32)
     P = ctypes.c_void_p
     fn.restype = ctypes.c_int
@@ -215,3 +216,36 @@ def test_dropin_realign_secondary_structure_in_mac_long_templates(L):
     assert compare(ref, got) >= 2
     plain = realign("cpu", q, t, names, **dict(kw, ssm=0))
     assert any(not np.array_equal(a, b) for a, b in zip(ref[1][5], plain[1][5]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loc", [1, 0])
+def test_dropin_realign_matrices_lists(loc):
+    """-o_matrices: with par.matrices_output_file set the drop-in attaches the sparse forward / backward / posterior lists and
+    the two profiles of writeProfilesToHits (src/hhbacktracemac.cpp:14-110) to every realigned hit - entry for entry the
+    reference's (counts, checksums of the float triples and of the profiles), alternative alignments included; without the
+    option it attaches none."""
+    L = (80, 80) if loc == 0 else (40, 260)
+    q, t, names = make_db(70 + loc, 150, 36, L[0], L[1])
+    ref = realign("cpu", q, t, names, loc=loc, threads=1, lists=1)
+    got = realign("hip", q, t, names, loc=loc, threads=3, lists=1)
+    assert compare(ref, got) >= 10
+    assert all(h.n_fwd > 0 and h.n_bwd > 0 and h.n_post >= 0 for h in ref[0]) and any(h.n_post > 0 for h in ref[0])
+    assert loc == 0 or any(h.irep > 1 for h in ref[0])
+    none = realign("hip", q, t, names, loc=loc, threads=3, lists=0)
+    assert all(h.n_fwd == 0 and h.h_fwd == 0 and h.h_fprof == 0 for h in none[0])
+
+
+@pytest.mark.gpu
+def test_dropin_realign_matrices_lists_with_ss_and_long_templates():
+    """the lists with secondary-structure scoring inside forward / backward (the backward list's substitution score has no SS
+    factor, src/hhbackwardalgorithm.cpp:113) and for templates of every MAC length class"""
+    q, t, names = make_db(81, 130, 30, 150, 150, ss_every=1, query_ss=("pred", "conf"))
+    ref = realign("cpu", q, t, names, ssm=2, lists=1)
+    got = realign("hip", q, t, names, ssm=2, threads=2, lists=1)
+    assert compare(ref, got) >= 10
+    q, t, names = make_db(91, 90, 12, 300, 2600)
+    kw = dict(maxres=2700, path_cap=2800, lists=1)
+    ref = realign("cpu", q, t, names, **kw)
+    got = realign("hip", q, t, names, threads=2, **kw)
+    assert compare(ref, got) >= 4

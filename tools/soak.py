@@ -250,6 +250,7 @@ def mac_family(orc, rng, budget):
         qp, qtr = synth.make_query(int(rng.integers(1 << 30)), Lq)
         q_lin = T.lin_query(qtr)
         tps, tls, masks, want = [], [], [], []
+        lists = bool(rng.integers(0, 2))   # every other batch with the -o_matrices lists (hhv_mac_set_lists)
         for k in range(int(rng.integers(1, 6))):
             Lt = int(rng.choice([1, 2, 63, 64, 65, 128, 190]))
             if rng.random() < 0.15:     # the other two length classes of the launch (LDS row state only; rows in global memory)
@@ -271,8 +272,13 @@ def mac_family(orc, rng, budget):
             L.hho_mac_forward(qp.ctypes.data, q_lin.ctypes.data, Lq, tp.ctypes.data, t_lin.ctypes.data, Lt, local, -0.03,
                               m.ctypes.data, o.forward.ctypes.data, o.scale.ctypes.data, C.addressof(o.Pforward))
             o.posterior[:] = o.forward
-            L.hho_mac_backward(qp.ctypes.data, q_lin.ctypes.data, Lq, tp.ctypes.data, t_lin.ctypes.data, Lt, local, -0.03,
-                               m.ctypes.data, o.scale.ctypes.data, o.Pforward.value, o.posterior.ctypes.data)
+            o.fwd_list = np.zeros((Lq + 1, Lt + 1), np.float32)
+            o.bwd_list = np.zeros((Lq + 1, Lt + 1), np.float32)
+            L.hho_mac_forward_list.argtypes = [V, C.c_int, C.c_int, V, C.c_double, V]
+            L.hho_mac_backward_list.argtypes = [V, V, C.c_int, V, V, C.c_int, C.c_int, C.c_float, V, V, C.c_double, V, V]
+            L.hho_mac_forward_list(o.forward.ctypes.data, Lq, Lt, o.scale.ctypes.data, o.Pforward.value, o.fwd_list.ctypes.data)
+            L.hho_mac_backward_list(qp.ctypes.data, q_lin.ctypes.data, Lq, tp.ctypes.data, t_lin.ctypes.data, Lt, local, -0.03,
+                                    m.ctypes.data, o.scale.ctypes.data, o.Pforward.value, o.posterior.ctypes.data, o.bwd_list.ctypes.data)
             i2, j2, ns, mc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
             L.hho_mac_dp(o.posterior.ctypes.data, m.ctypes.data, Lq, Lt, local, mact, o.bmm.ctypes.data, C.addressof(i2), C.addressof(j2))
             L.hho_mac_backtrace(o.bmm.ctypes.data, o.posterior.ctypes.data, qp.ctypes.data, tp.ctypes.data, Lq, Lt, i2.value,
@@ -283,6 +289,7 @@ def mac_family(orc, rng, budget):
             tls.append(t_lin)
             masks.append(m)
             want.append(o)
+        c.mac_set_lists(lists)
         ms = c.mac_realign(qp, q_lin, tps, tls, masks, local=local, mact=mact)
         for k, o in enumerate(want):
             h = ms.hits[k]
@@ -294,11 +301,19 @@ def mac_family(orc, rng, budget):
             if ok and o.ns:
                 i_s, j_s, st, S, P = ms.path(k)
                 ok = np.array_equal(i_s[1:], o.i_steps[1:o.ns + 1]) and np.array_equal(P[1:], o.P[1:o.ns + 1], equal_nan=True)
+            lists_ok = True
+            if lists:
+                wl = [po.mac_plane_to_list(o.fwd_list), po.mac_plane_to_list(o.bwd_list),
+                      po.mac_posterior_list(o.posterior, masks[k], o.i_steps, o.j_steps, o.ns)]
+                for w in range(3):
+                    g = ms.list(k, w)
+                    lists_ok = lists_ok and np.array_equal(g[0], wl[w][0]) and np.array_equal(g[1], wl[w][1]) and g[2].tobytes() == wl[w][2].tobytes()
+                ok = ok and lists_ok
             cases += 1
             if not ok:
                 bad += 1
                 if len(diag) < 8:
-                    diag.append({"Lq": Lq, "Lt": int(tps[k].shape[0] - 1), "local": local, "mact": mact, "dens": float(masks[k].mean()),
+                    diag.append({"Lq": Lq, "Lt": int(tps[k].shape[0] - 1), "local": local, "lists_ok": lists_ok, "mact": mact, "dens": float(masks[k].mean()),
                                  "Pf": [o.Pf, float(h["Pforward"])], "post_eq": bool(np.array_equal(post[1:, 1:], o.posterior[1:, 1:], equal_nan=True)),
                                  "ends": [[o.ns, o.i2v, o.j2v], [int(h["nsteps"]), int(h["i2"]), int(h["j2"])]],
                                  "npost_diff": int((post[1:, 1:] != o.posterior[1:, 1:]).sum())})
