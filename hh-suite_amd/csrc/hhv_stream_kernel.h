@@ -870,6 +870,11 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       }
     }
     if (PF) decltype(col)::head_wait(nxt.v6, nxt.v5);  // full EXEC again: the head of step s+1 is in nxt.v6 / v5 from here on
+    // Multi-strip bodies, unrolled: hipcc lays the column / header blocks (which hold the waits for this step's pulls) out of
+    // line, hoists the next step's row-0 sums above the wait above, and re-uses the register of the pulled MI for the carry-out
+    // address.  All of that is behind a wait on every path that has an active lane - but the five pull targets are tied to
+    // this point anyway, so that the order is in the code (and tools/audit_asm.py, which reads the ISA top to bottom, can see it).
+    if (PF && MULTI && W == LANES && R < 5) asm volatile("" : "+v"(st.dGD), "+v"(st.dIM), "+v"(st.dDG), "+v"(cur.hMM), "+v"(cur.hMI));
     // (pair: the FIFO slot requested at the top of this step has landed too - LDS returns a wave's reads in order; the tie
     // keeps its eight registers the slot's until here, whatever the step uses of them)
     if (PM == 2) asm volatile("" : "+v"(pc0), "+v"(pc1));
@@ -920,8 +925,11 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       }
     }
     const int s_lo = c > 0 ? c * C - LEAD : 0, s_hi = min((c + 1) * C - LEAD, s_end);
-    if (PF && !MULTI) {
-      // unrolled by two: the heads alternate between col and col2, no copy between the steps
+    if (PF && (!MULTI || R < 5)) {
+      // unrolled by two: the heads alternate between col and col2, no copy between the steps.  (Round 3 had measured the
+      // multi-strip variants 1 % slower unrolled - with hipcc's vmcnt(0) behind the carry loads in every step; without it the
+      // five copies per step count: Lq 512 -2.4 %, Lq 431 -2.3 %, Lq 1000 -1.6 %, with backtrace -0.5 .. -1 %, ab-r4-8.
+      // Five-row strips of multi-strip queries have no registers for the second set of heads: they spill, and keep the copies.)
       int s = s_lo;
       for (; s + 1 < s_hi; s += 2) {
         step(s, col, col2);
@@ -934,7 +942,6 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         col.rec_addr = col2.rec_addr;
       }
     } else if (PF) {
-      // multi-pass variants (measured 1 % slower unrolled): one step per iteration, the prefetched head is copied
       for (int s = s_lo; s < s_hi; ++s) {
         step(s, col, col2);
         col.v6 = col2.v6;

@@ -47,6 +47,15 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4p)   # multi-strip step loops unrolled by two like the single-strip ones (-DHHV_EXP_MULTI_UNROLL, lib "mu"): A/B, then parity on mu
+  for cfg in "--lq 512 --templates 50000" "--lq 640 --templates 50000" "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 512 --templates 50000 --backtrace 1"; do
+    for lib in hip mu hip mu; do
+      echo -n "$lib $cfg : "
+      HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_$lib.so timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+    done
+  done
+  HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_mu.so timeout 600 python -m pytest tests/test_gpu_pair.py tests/test_gpu_parity.py tests/test_gpu_lengths.py -q -m gpu -x 2>&1 | tail -4
+  ;;
 r4j)   # timing-only builds (WRONG results): pair kernels without waits (pns), without waits and FIFO traffic (pnf), multi-pass bodies without carry traffic (mnc)
   for cfg in "--lq 512 --templates 50000" "--lq 431 --templates 50000"; do
     for lib in hip pns pnf mnc; do for pv in 1 0; do
