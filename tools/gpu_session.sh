@@ -47,6 +47,12 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4q)   # the multi-strip configurations on the default build
+  for cfg in "--lq 512 --templates 50000" "--lq 640 --templates 50000" "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 2000 --lt 500 --templates 10000"; do
+    echo -n "$cfg : "
+    timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+  done
+  ;;
 r4p)   # multi-strip step loops unrolled by two like the single-strip ones (-DHHV_EXP_MULTI_UNROLL, lib "mu"): A/B, then parity on mu
   for cfg in "--lq 512 --templates 50000" "--lq 640 --templates 50000" "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 512 --templates 50000 --backtrace 1"; do
     for lib in hip mu hip mu; do
