@@ -45,7 +45,7 @@ def compile_s(workdir):
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-fvisibility=hidden", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(ROOT, "hh-suite_amd", "csrc"), "--cuda-device-only", "-S", src, "-o",
-               os.path.join(workdir, u + ".s")]
+               os.path.join(workdir, u + ".s")] + os.environ.get("HHV_AUDIT_FLAGS", "").split()   # (measurement builds: -D...)
         procs.append(subprocess.Popen(cmd, cwd=workdir, stderr=subprocess.DEVNULL))
     for p in procs:
         if p.wait() != 0:
