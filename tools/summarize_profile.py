@@ -11,7 +11,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-KERNEL = "hhv_stream_kernel"
+KERNEL = os.environ.get("HHV_PROFILE_KERNEL", "hhv_stream_kernel")   # (hhv_pair_kernel for the two-strip launches)
 
 
 def rows(pattern):
