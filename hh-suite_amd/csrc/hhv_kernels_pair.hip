@@ -1,6 +1,8 @@
 // hhv_kernels_pair.hip -- instantiation unit of hhv_pair_kernel: queries of two strips (321 .. 640 rows) aligned in ONE launch
 // by workgroups of two wavefronts, a 128-lane systolic array (hhv_stream_kernel.h: PairLds, hhv_pair_kernel).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (like hhv_kernels.hip).
+#include <atomic>
+
 #include "hhv_stream_kernel.h"
 
 namespace hhv {
@@ -36,8 +38,15 @@ int launch_pair(int R0, int R1, bool local, bool bt, const StreamArgs& a, int n_
 int pair_kernel_occupancy(int R0, int R1, bool local, bool bt) {
   void* fn = pair_kernel(R0, R1, local, bt);
   if (!fn) return 0;
-  int nb = 0;
+  // asked once per kernel (every search of a two-strip query comes through here; the devices of a process are of one kind).
+  // Concurrent first calls store the same value.
+  static std::atomic<int> cache[6][6][2][2];
+  std::atomic<int>& slot = cache[R0][R1][local ? 1 : 0][bt ? 1 : 0];
+  int nb = slot.load(std::memory_order_relaxed) - 1;  // (0 = not asked yet)
+  if (nb >= 0) return nb;
+  nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 2 * LANES, 0) != hipSuccess) return 0;
+  slot.store(nb + 1, std::memory_order_relaxed);
   return nb;
 }
 
