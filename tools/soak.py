@@ -25,7 +25,7 @@ def quantize(a, rng, step):
 def viterbi_family(orc, rng, budget):
     t_end, cases, bad = time.time() + budget, 0, 0
     while time.time() < t_end:
-        Lq = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 320, 321, 400]))
+        Lq = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 320, 321, 400, 512, 600]))   # (321 ..: two strips = the pair kernels)
         local = int(rng.integers(0, 2))
         par = po.make_params(local=local, egq=float(rng.choice([0.0, 0.2])), egt=float(rng.choice([0.0, 0.1])),
                              shift=float(rng.choice([-0.03, 0.0, 0.25])), ss_mode=0)
@@ -66,16 +66,19 @@ def viterbi_family(orc, rng, budget):
                     continue   # (a set that never saw a compare-bit launch starts with all cells on)
                 m = masks[k]
                 c.set_celloff(ts, e, m if m is not None else np.zeros((Lq + 1, tps[k].shape[0]), np.uint8))
-        res = c.align(ts, backtrace=True, celloff=use_mask)
-        hits = c.hits(ts)
+        # one case in five score-only (other kernels; two equal strips run as a pair only then): end points and scores
+        with_bt = use_mask or rng.random() < 0.8
+        res = c.align(ts, backtrace=with_bt, celloff=use_mask)
+        hits = c.hits(ts) if with_bt else None
         want = [orc.align(par, qp, qtr, tps[k], ttrs[k], celloff=masks[k] if use_mask else None, want_path=True) for k in range(n)]
         bt_sample = set(range(len(idx))) if not many else set(int(e) for e in rng.integers(0, len(idx), 12))
         for e, k in enumerate(idx):
             a = want[k]
             ok = (a.i2, a.j2) == (int(res["i2"][e]), int(res["j2"][e])) and np.float32(a.score).tobytes() == np.float32(res["score"][e]).tobytes()
-            if e in bt_sample:
+            if with_bt and e in bt_sample:
                 ok = ok and np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:] & 0x7F, a.bt[1:, 1:] & 0x7F)
-            ok = ok and int(hits["nsteps"][e]) == a.nsteps and np.float32(hits["score"][e]).tobytes() == np.float32(a.hit_score).tobytes()
+            if with_bt:
+                ok = ok and int(hits["nsteps"][e]) == a.nsteps and np.float32(hits["score"][e]).tobytes() == np.float32(a.hit_score).tobytes()
             cases += 1
             bad += int(not ok)
         ts.free()
