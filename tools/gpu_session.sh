@@ -47,6 +47,14 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4r)   # hipcc scheduling strategy max-ilp (lib "ilp") against the default build
+  for cfg in "" "--backtrace 1" "--local 1" "--lq 150 --templates 100000" "--lq 512 --templates 50000" "--lengths zipf --local 1 --templates 125000"; do
+    for lib in hip ilp hip ilp; do
+      echo -n "$lib $cfg : "
+      HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_$lib.so timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+    done
+  done
+  ;;
 r4q)   # the multi-strip configurations on the default build
   for cfg in "--lq 512 --templates 50000" "--lq 640 --templates 50000" "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 2000 --lt 500 --templates 10000"; do
     echo -n "$cfg : "
