@@ -49,7 +49,7 @@ next)
   ;;
 r4r)   # hipcc scheduling strategy max-ilp (lib "ilp") against the default build
   for cfg in "" "--backtrace 1" "--local 1" "--lq 150 --templates 100000" "--lq 512 --templates 50000" "--lengths zipf --local 1 --templates 125000"; do
-    for lib in hip ilp hip ilp; do
+    for lib in hip ${VARIANT:-ilp} hip ${VARIANT:-ilp}; do
       echo -n "$lib $cfg : "
       HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_$lib.so timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
     done
