@@ -736,38 +736,41 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   // builds and five-row backtrace strips (LDS-parked query rows).  Score-only strips of UNEQUAL height (4 + 3, 5 + 4 rows per
   // lane) stay two launches: the lock step of a heavy and a light wave costs the pair more than the HBM carry costs the
   // launches since the first strip has kernels of its own (Lq 431: 12.13 vs 11.77 ms, profiles/r4_ab.txt ab-r4-7); with
-  // backtrace the pair is ahead either way (15.05 vs 15.73).  HHV_PAIR=0 / 1: never / whenever eligible (tests, measurements).
-  int pair_wgs = 0;
+  // backtrace the pair is ahead either way (15.05 vs 15.73).
+  // More than two strips: a CHAIN of launches - neighbouring strips two by two as pair launches (HBM carries only between the
+  // links: half the launches, half the rows through HBM), a strip without a partner or without a pair kernel as a launch of its
+  // own.  HHV_PAIR=0 / 1: never / whenever a pair kernel exists (tests, measurements).
+  const char* pair_env = getenv("HHV_PAIR");  // (read per call: the tests switch it inside one process)
+  const bool pairs_possible = queue && plan.P >= 2 && plan.W == LANES && !celloff && !ss && !(pair_env && atoi(pair_env) == 0);
+  const bool pairs_forced = pair_env && atoi(pair_env) != 0;
   {
-    const char* env = getenv("HHV_PAIR");  // (read per call: the tests switch it inside one process)
-    const bool eligible = queue && plan.P == 2 && plan.W == LANES && !celloff && !ss;
-    const bool wanted = env ? atoi(env) != 0 : (bt || plan.R(0) == plan.R(1));
-    if (eligible && wanted) pair_wgs = pair_kernel_occupancy(plan.R(0), plan.R(1), local, bt);
+    const char* sw = getenv("HHV_PAIR_SWAP");  // measurement aid: which workgroups swap the strips of their two waves
+    a.pair_swap = sw ? atoi(sw) : 0;
   }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  if (pair_wgs > 0) {
-    const int n_wg = std::max(1, std::min(c->num_cus * pair_wgs, ts->n_seg));
-    a.row_base = 0;
-    a.bt_plane = 0;
-    a.qpack = c->d_qpack;
-    a.pass_first = 1;
-    a.pass_last = 0;
-    {
-      const char* sw = getenv("HHV_PAIR_SWAP");  // measurement aid: which workgroups swap the strips of their two waves
-      a.pair_swap = sw ? atoi(sw) : 0;
-    }
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // workgroup k starts with segment k
-    rc = launch_pair(plan.R(0), plan.R(1), local, bt, a, n_wg, c->stream);
-    if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
-  }
-  for (int pass = 0; pass < plan.P && pair_wgs == 0; ++pass) {
+  for (int pass = 0; pass < plan.P;) {
     a.row_base = plan.base(pass);
     a.bt_plane = pass;
     a.qpack = c->d_qpack + (size_t)a.row_base * REC_DW;
     a.pass_first = pass == 0;
-    a.pass_last = pass == plan.P - 1;
-    if (queue) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves * arrays, 1, c->stream));  // array k starts with segment k
-    rc = launch_stream(plan.W, plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
+    int pair_wgs = 0, chain = 0;
+    if (pairs_possible && pass + 1 < plan.P) {
+      chain = (pass > 0 ? 1 : 0) | (pass + 2 < plan.P ? 2 : 0);
+      const bool wanted = pairs_forced || plan.P > 2 || bt || plan.R(0) == plan.R(1);
+      if (wanted) pair_wgs = pair_kernel_occupancy(plan.R(pass), plan.R(pass + 1), local, bt, chain);
+    }
+    if (pair_wgs > 0) {
+      const int n_wg = std::max(1, std::min(c->num_cus * pair_wgs, ts->n_seg));
+      a.pass_last = 0;  // (the kernel gives its two waves their own)
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // workgroup k starts with segment k
+      rc = launch_pair(plan.R(pass), plan.R(pass + 1), local, bt, chain, a, n_wg, c->stream);
+      pass += 2;
+    } else {
+      a.pass_last = pass == plan.P - 1;
+      if (queue) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves * arrays, 1, c->stream));  // array k starts with segment k
+      rc = launch_stream(plan.W, plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
+      pass += 1;
+    }
     if (rc != 0) return fail(HHV_E_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));

@@ -7,26 +7,37 @@
 
 namespace hhv {
 
-template <bool LOCAL, bool BT>
+template <bool LOCAL, bool BT, int CHAIN>
 static void* pair_kernel_ptr(int R0, int R1) {
-  if (R0 == 3 && R1 == 3) return (void*)hhv_pair_kernel<3, 3, LOCAL, BT>;
-  if (R0 == 4 && R1 == 3) return (void*)hhv_pair_kernel<4, 3, LOCAL, BT>;
-  if (R0 == 4 && R1 == 4) return (void*)hhv_pair_kernel<4, 4, LOCAL, BT>;
-  if (!BT) {  // (five rows per lane with backtrace park query rows in LDS: those plans stay two launches)
-    if (R0 == 5 && R1 == 4) return (void*)hhv_pair_kernel<5, 4, LOCAL, false>;
-    if (R0 == 5 && R1 == 5) return (void*)hhv_pair_kernel<5, 5, LOCAL, false>;
+  if (R0 == 3 && R1 == 3) return (void*)hhv_pair_kernel<3, 3, LOCAL, BT, CHAIN>;
+  if (R0 == 4 && R1 == 3) return (void*)hhv_pair_kernel<4, 3, LOCAL, BT, CHAIN>;
+  if (R0 == 4 && R1 == 4) return (void*)hhv_pair_kernel<4, 4, LOCAL, BT, CHAIN>;
+  // (five rows per lane with backtrace park query rows in LDS: those strips stay launches of their own; so do the five-row
+  // strips of local-mode chains - a link's extra carry path does not fit into the 256 registers next to the per-row best)
+  if (!BT && !(LOCAL && CHAIN != 0)) {
+    if (R0 == 5 && R1 == 4) return (void*)hhv_pair_kernel<5, 4, LOCAL, false, (LOCAL ? 0 : CHAIN)>;
+    if (R0 == 5 && R1 == 5) return (void*)hhv_pair_kernel<5, 5, LOCAL, false, (LOCAL ? 0 : CHAIN)>;
   }
   return nullptr;
 }
+template <int CHAIN>
 static void* pair_kernel_pick(int R0, int R1, bool local, bool bt) {
-  if (bt) return local ? pair_kernel_ptr<true, true>(R0, R1) : pair_kernel_ptr<false, true>(R0, R1);
-  return local ? pair_kernel_ptr<true, false>(R0, R1) : pair_kernel_ptr<false, false>(R0, R1);
+  if (bt) return local ? pair_kernel_ptr<true, true, CHAIN>(R0, R1) : pair_kernel_ptr<false, true, CHAIN>(R0, R1);
+  return local ? pair_kernel_ptr<true, false, CHAIN>(R0, R1) : pair_kernel_ptr<false, false, CHAIN>(R0, R1);
 }
 
-void* pair_kernel(int R0, int R1, bool local, bool bt) { return pair_kernel_pick(R0, R1, local, bt); }
+// chain: bit 0 = not the first link of a chain of launches, bit 1 = not the last (hhv_pair_kernel)
+void* pair_kernel(int R0, int R1, bool local, bool bt, int chain) {
+  switch (chain & 3) {
+    case 0: return pair_kernel_pick<0>(R0, R1, local, bt);
+    case 1: return pair_kernel_pick<1>(R0, R1, local, bt);
+    case 2: return pair_kernel_pick<2>(R0, R1, local, bt);
+    default: return pair_kernel_pick<3>(R0, R1, local, bt);
+  }
+}
 
-int launch_pair(int R0, int R1, bool local, bool bt, const StreamArgs& a, int n_workgroups, void* stream) {
-  void* fn = pair_kernel(R0, R1, local, bt);
+int launch_pair(int R0, int R1, bool local, bool bt, int chain, const StreamArgs& a, int n_workgroups, void* stream) {
+  void* fn = pair_kernel(R0, R1, local, bt, chain);
   if (!fn) return -1;
   StreamArgs args = a;
   void* kargs[] = {&args};
@@ -35,13 +46,13 @@ int launch_pair(int R0, int R1, bool local, bool bt, const StreamArgs& a, int n_
 }
 
 // workgroups (of two wavefronts) a CU holds; 0 = no pair kernel for these strips
-int pair_kernel_occupancy(int R0, int R1, bool local, bool bt) {
-  void* fn = pair_kernel(R0, R1, local, bt);
+int pair_kernel_occupancy(int R0, int R1, bool local, bool bt, int chain) {
+  void* fn = pair_kernel(R0, R1, local, bt, chain);
   if (!fn) return 0;
-  // asked once per kernel (every search of a two-strip query comes through here; the devices of a process are of one kind).
+  // asked once per kernel (every search of a multi-strip query comes through here; the devices of a process are of one kind).
   // Concurrent first calls store the same value.
-  static std::atomic<int> cache[6][6][2][2];
-  std::atomic<int>& slot = cache[R0][R1][local ? 1 : 0][bt ? 1 : 0];
+  static std::atomic<int> cache[6][6][2][2][4];
+  std::atomic<int>& slot = cache[R0][R1][local ? 1 : 0][bt ? 1 : 0][chain & 3];
   int nb = slot.load(std::memory_order_relaxed) - 1;  // (0 = not asked yet)
   if (nb >= 0) return nb;
   nb = 0;

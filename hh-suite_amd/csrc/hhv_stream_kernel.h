@@ -470,7 +470,12 @@ template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, 
 __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0) {
   __shared__ float4 smem[StreamSmem<R, BT, W>::F4];
   const int lane = PM == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LANES - 1));
-  constexpr bool PAIRED = PM == 1 || PM == 2;
+  // PW0 / PW1: first / second wavefront of a pair.  PM 4 / 5 are the waves of a pair that is one link of a longer chain of
+  // strips (queries of more than two strips run as a sequence of pair launches, round 4): 4 = first wave of a LATER pair - its
+  // strip takes the bottom row of the strip above it from HBM like any later strip, and hands its own on through the FIFO;
+  // 5 = second wave of a pair that is NOT the last - FIFO in, its own bottom row out to HBM for the next launch.
+  constexpr bool PW0 = PM == 1 || PM == 4, PW1 = PM == 2 || PM == 5;
+  constexpr bool PAIRED = PW0 || PW1;
   static_assert(!PAIRED || (MULTI && W == LANES && !CELLOFF && !SS && !(BT && R == 5)), "pair variants: two strips, 64 lanes, no cell-off / SS, no LDS-parked query rows");
   static_assert(PM != 3 || MULTI, "first strip of a multi-strip plan");
   PairLds* const pair = PAIRED ? pair_lds() : nullptr;
@@ -550,7 +555,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     float4* const slot = ring + (cc & (RING_CHUNKS - 1)) * SLOT_F4;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      if (cc * C < wq[j].end) wq[j].template refill<W, PM>((const float4*)a.records, a.seg_first, a.n_seg, a.queue, cc, slot + j * (C * 7), lane, pair);
+      if (cc * C < wq[j].end) wq[j].template refill<W, (PW0 ? 1 : PW1 ? 2 : 0)>((const float4*)a.records, a.seg_first, a.n_seg, a.queue, cc, slot + j * (C * 7), lane, pair);
     }
     M = wq[0].end;
     Mmax = wq[0].end;
@@ -594,8 +599,8 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
 #else
   // (the waves of a pair know their role at compile time: no code of the other role - its global loads made hipcc put a
   // vmcnt(0) into every step of BOTH roles, profiles/r4_ab.txt ab-r4-5)
-  const bool first = (PM == 1 || PM == 3) ? true : PM == 2 ? false : (!MULTI || a.pass_first != 0);
-  const bool carry_out = PAIRED ? false : (MULTI && a.pass_last == 0);
+  const bool first = (PM == 1 || PM == 3) ? true : (PM == 2 || PM == 4 || PM == 5) ? false : (!MULTI || a.pass_first != 0);
+  const bool carry_out = PM == 5 ? true : PAIRED ? false : (MULTI && a.pass_last == 0);
 #endif
 
   const float4* const records = (const float4*)a.records;
@@ -694,12 +699,12 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     const uint32_t addr = pair_carry_addr + ((uint32_t)pos & (uint32_t)(PAIR_FIFO - 1)) * 32u;
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(pc0), "=&v"(pc1) : "v"(addr) : "memory");
   };
-  if (PM == 2) {
+  if (PW1) {
     pair_wait(lds_addr_of(&pair->w0_done), C + 1);  // the first chunk's positions (and the one read ahead) have been written
     pair_carry_issue(0);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc0), "+v"(pc1));
   }
-  if (MULTI && !first && PM != 2) {
+  if (MULTI && !first && !PW1) {
     if (lane == 0 && M > 0) {
       ncar = a.carry[rb];  // (work queue: rb = the first record of the wave's first segment)
       nmi = a.carry_mi[rb];
@@ -768,7 +773,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     // bottom row the previous pass left for this record (and its running best)
     const int jcol = meta & (int)k_jmask;  // column index of a column record
     Incoming in = boundary_incoming(meta, jcol, P);
-    if (PM == 2) {
+    if (PW1) {
       // (pc0 / pc1 were requested a step ago and have landed: the end of every step waits lgkmcnt(0))
       if (lane == 0 && active) {
         in.MM = pc0.x;
@@ -821,7 +826,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         cur.resolve_best(in, inh);
         const bool emit = lane_header<R, LOCAL, SHARE>(st, q, inh, i0, new_tid, P, g == g_last, res);
         if (W == LANES) decltype(col)::publish_best(best_base + (uint32_t)lane * 8u, st.fs, st.fpos);
-        if (emit && PM != 1) {  // (first wave of a pair: the best travels on through the FIFO)
+        if (emit && !PW0) {  // (first wave of a pair: the best travels on through the FIFO)
           DevResult o;
           o.score = res.score;
           o.i2 = res.i2;
@@ -852,7 +857,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, SHARE, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
         if (BT) *bte = bytes;
       }
-      if (PM == 1) {
+      if (PW0) {
 #if !defined(HHV_EXP_PAIR_NOFIFO)
         if (lane == LANES - 1) {
           const uint32_t addr = pair_carry_addr + ((uint32_t)r & (uint32_t)(PAIR_FIFO - 1)) * 32u;
@@ -877,7 +882,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     if (PF && MULTI && W == LANES && R < 5) asm volatile("" : "+v"(st.dGD), "+v"(st.dIM), "+v"(st.dDG), "+v"(cur.hMM), "+v"(cur.hMI));
     // (pair: the FIFO slot requested at the top of this step has landed too - LDS returns a wave's reads in order; the tie
     // keeps its eight registers the slot's until here, whatever the step uses of them)
-    if (PM == 2) asm volatile("" : "+v"(pc0), "+v"(pc1));
+    if (PW1) asm volatile("" : "+v"(pc0), "+v"(pc1));
 #if defined(HHV_EXP_TIMING)
     {
       unsigned long long tE;
@@ -900,7 +905,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       // chunks c-2..c, so the ring holds 4 chunks = 2W records per array.
       // (The same wait retires the backtrace stores of the last C steps - the only place they are waited for.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (PM == 1) {
+      if (PW0) {
         // positions below c C - LEAD - (W - 1) are in the FIFO (their ds_writes are complete: LDS executes a wave's operations
         // in order and the steps' waits have passed them); the coming chunk writes positions up to pmax, which must not lap the
         // second wave
@@ -908,7 +913,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         const int pmax = (c + 1) * C - LEAD - W;
         if (pmax - (PAIR_FIFO - 1) > 0) pair_wait(lds_addr_of(&pair->w1_done), pmax - (PAIR_FIFO - 1));
       }
-      if (PM == 2) {
+      if (PW1) {
         lds_poke(lds_addr_of(&pair->w1_done), c * C - LEAD);
         pair_wait(lds_addr_of(&pair->w0_done), (c + 1) * C - LEAD + 1);
       }
@@ -952,8 +957,8 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       for (int s = s_lo; s < s_hi; ++s) step(s, col, col);
     }
   }
-  if (PM == 1) lds_poke(lds_addr_of(&pair->w0_done), 0x7FFFFFFF);  // through: the second wave never waits again
-  if (PM == 2) lds_poke(lds_addr_of(&pair->w1_done), 0x7FFFFFFF);
+  if (PW0) lds_poke(lds_addr_of(&pair->w0_done), 0x7FFFFFFF);  // through: the second wave never waits again
+  if (PW1) lds_poke(lds_addr_of(&pair->w1_done), 0x7FFFFFFF);
 #if defined(HHV_EXP_WAVETIME)
   if (lane == 0 && array0 < 16384) {
     hhv_dbg_wave[4 * array0 + 0] = wt_start;
@@ -981,7 +986,11 @@ __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
 // Two strips of R0 and R1 rows per lane as the two wavefronts of one workgroup (PairLds above).  Which wave index takes which
 // strip alternates with the workgroup number: the strips differ in work (R0 >= R1), and the waves of the workgroups that share a
 // SIMD should not all be the heavy ones.
-template <int R0, int R1, bool LOCAL, bool BT>
+// CHAIN: queries of more than two strips are a sequence of such launches (and of single-strip launches where no pair kernel
+// exists); bit 0 = this pair is not the first link (its first strip takes its carry row from HBM: a.carry, a.results),
+// bit 1 = not the last (its second strip leaves its bottom row and running best there).  a.row_base / a.qpack / a.bt_plane are
+// those of the pair's first strip.
+template <int R0, int R1, bool LOCAL, bool BT, int CHAIN = 0>
 __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
   PairLds* const p = pair_lds();
   if (threadIdx.x == 0) {
@@ -994,19 +1003,17 @@ __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
   const int swap = a.pair_swap >= 0 ? ((int)blockIdx.x >> a.pair_swap) & 1 : 0;
   if ((wv ^ swap) == 0) {
     StreamArgs a0 = a;
-    a0.row_base = 0;
-    a0.bt_plane = 0;
-    a0.pass_first = 1;
+    a0.pass_first = (CHAIN & 1) ? 0 : 1;
     a0.pass_last = 0;
-    stream_body<R0, LOCAL, BT, false, true, false, LANES, 1>(a0, (int)blockIdx.x);
+    stream_body<R0, LOCAL, BT, false, true, false, LANES, ((CHAIN & 1) ? 4 : 1)>(a0, (int)blockIdx.x);
   } else {
     StreamArgs a1 = a;
-    a1.row_base = LANES * R0;
+    a1.row_base = a.row_base + LANES * R0;
     a1.qpack = a.qpack + (size_t)(LANES * R0) * REC_DW;
-    a1.bt_plane = 1;
+    a1.bt_plane = a.bt_plane + 1;
     a1.pass_first = 0;
-    a1.pass_last = 1;
-    stream_body<R1, LOCAL, BT, false, true, false, LANES, 2>(a1, (int)blockIdx.x);
+    a1.pass_last = (CHAIN & 2) ? 0 : 1;
+    stream_body<R1, LOCAL, BT, false, true, false, LANES, ((CHAIN & 2) ? 5 : 2)>(a1, (int)blockIdx.x);
   }
 }
 // ---- kernel selection (instantiates the variants of one W in the including unit) --------------------------------------

@@ -26,7 +26,9 @@ def both_ways(fn):
     return out
 
 
-@pytest.mark.parametrize("Lq", [321, 384, 431, 448, 449, 512, 513, 576, 600, 640])
+# 321 .. 640: one pair launch; beyond: chains of launches (three strips = pair + strip, four = two pairs, five = two pairs +
+# strip, seven = three pairs + strip; five-row strips of local mode and of backtrace plans stay launches of their own)
+@pytest.mark.parametrize("Lq", [321, 384, 431, 448, 449, 512, 513, 576, 600, 640, 641, 700, 768, 960, 1000, 1280, 1300, 1600, 2000])
 @pytest.mark.parametrize("local", [0, 1])
 def test_pair_equals_oracle_and_two_launches(oracle, Lq, local):
     from pyhhv import capi
@@ -64,7 +66,7 @@ def test_pair_equals_oracle_and_two_launches(oracle, Lq, local):
     c.close()
 
 
-@pytest.mark.parametrize("Lq,local", [(431, 0), (431, 1), (512, 1), (640, 0)])
+@pytest.mark.parametrize("Lq,local", [(431, 0), (431, 1), (512, 1), (640, 0), (700, 1), (1000, 0), (1000, 1), (1300, 0)])
 def test_pair_on_large_sets_equals_two_launches(Lq, local):
     """every resident workgroup walks tens of segments: junctions, the segment FIFO, the carry FIFO's wrap-around and both
     flow-control waits; tiny templates back to back (headers in consecutive steps: the best travels through the FIFO too)"""

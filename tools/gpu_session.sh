@@ -47,6 +47,15 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
+r4s)   # chains of pair launches for queries of more than two strips: parity, then HHV_PAIR=0 (one launch per strip) against the default
+  timeout 500 python -m pytest tests/test_gpu_pair.py tests/test_gpu_lengths.py tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -6
+  for cfg in "--lq 700 --templates 30000" "--lq 1000 --lt 500 --templates 20000" "--lq 1280 --lt 500 --templates 16000" "--lq 2000 --lt 500 --templates 10000" "--lq 1000 --lt 500 --templates 20000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000 --local 1"; do
+    for pv in 0 x 0 x; do
+      echo -n "HHV_PAIR=$pv $cfg : "
+      if [ $pv = x ]; then timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line; else HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line; fi
+    done
+  done
+  ;;
 r4r)   # hipcc scheduling strategy max-ilp (lib "ilp") against the default build
   for cfg in "" "--backtrace 1" "--local 1" "--lq 150 --templates 100000" "--lq 512 --templates 50000" "--lengths zipf --local 1 --templates 125000"; do
     for lib in hip ${VARIANT:-ilp} hip ${VARIANT:-ilp}; do
