@@ -25,7 +25,7 @@ def quantize(a, rng, step):
 def viterbi_family(orc, rng, budget):
     t_end, cases, bad = time.time() + budget, 0, 0
     while time.time() < t_end:
-        Lq = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 320, 321, 400, 512, 600]))   # (321 ..: two strips = the pair kernels)
+        Lq = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 320, 321, 400, 512, 600, 700, 1000]))   # (321 ..: pair kernels, 641 ..: chains of them)
         local = int(rng.integers(0, 2))
         par = po.make_params(local=local, egq=float(rng.choice([0.0, 0.2])), egt=float(rng.choice([0.0, 0.1])),
                              shift=float(rng.choice([-0.03, 0.0, 0.25])), ss_mode=0)
