@@ -1,5 +1,6 @@
-// hhv_kernels_pair.hip -- instantiation unit of hhv_pair_kernel: queries of two strips (321 .. 640 rows) aligned in ONE launch
-// by workgroups of two wavefronts, a 128-lane systolic array (hhv_stream_kernel.h: PairLds, hhv_pair_kernel).
+// hhv_kernels_pair.hip -- instantiation unit of hhv_pair_kernel: two neighbouring strips of a query aligned in ONE launch by
+// workgroups of two wavefronts, a 128-lane systolic array (hhv_stream_kernel.h: PairLds, hhv_pair_kernel) - the whole query
+// (321 .. 640 rows), or one link of the chain of launches of a longer one.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (like hhv_kernels.hip).
 #include <atomic>
 
