@@ -17,7 +17,7 @@ HDRS     := $(wildcard $(CSRC)/*.h) include/hhviterbi_hip.h
 
 RUNNER   := $(LIBDIR)/libhhv_runner.so
 
-all: lib lib_fma oracle emul
+all: lib lib_fma lib_pto oracle emul
 
 lib: $(LIB) $(RUNNER)
 
@@ -31,6 +31,17 @@ lib_fma:
 #   make lib_variant NAME=wt FLAGS=-DHHV_EXP_WAVETIME    per-workgroup entry / exit times (tools/wave_times.py)
 lib_variant:
 	$(MAKE) $(LIBDIR)/libhhviterbi_$(NAME).so LIB=$(LIBDIR)/libhhviterbi_$(NAME).so OBJDIR=build/obj_$(NAME) HHV_EXTRA_HIPFLAGS="$(HHV_EXTRA_HIPFLAGS) $(FLAGS)"
+
+# TEST build (tests/test_gpu_errors.py): the product objects with ONE unit replaced - the pair kernels compiled with
+# -DHHV_EXP_PAIR_TIMEOUT (the first wave of a two-wave workgroup never reports progress, short spin bound), so that the second
+# wave's bounded wait runs out: the launch must end with HHV_E_DEVICE, not with a result
+lib_pto: $(LIBDIR)/libhhviterbi_hip_pto.so
+build/obj_pto/hhv_kernels_pair.o: $(CSRC)/hhv_kernels_pair.hip $(HDRS)
+	@mkdir -p build/obj_pto
+	$(HIPCC) $(HIPFLAGS) -DHHV_EXP_PAIR_TIMEOUT -fno-slp-vectorize -c $< -o $@
+$(LIBDIR)/libhhviterbi_hip_pto.so: $(OBJS) build/obj_pto/hhv_kernels_pair.o
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter-out $(OBJDIR)/hhv_kernels_pair.o,$(OBJS)) build/obj_pto/hhv_kernels_pair.o
 
 # C++ host layer above the C ABI (mirror of the reference's ViterbiRunner); plain g++, links only the C ABI
 $(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/prefilter.h hh-suite_amd/host/posterior_decoder.cpp hh-suite_amd/host/posterior_decoder.h include/hhviterbi_hip.h $(LIB)
@@ -82,7 +93,7 @@ clean:
 	rm -rf build $(LIBDIR) tests/emul/libwave_emul.so
 	$(MAKE) -C oracle clean
 
-.PHONY: example example_rccl all lib lib_fma lib_variant oracle emul clean
+.PHONY: example example_rccl all lib lib_fma lib_pto lib_variant oracle emul clean
 
 # plain-C++ use of the host classes (no Python): examples/search_example.cpp
 example: $(RUNNER)

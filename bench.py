@@ -94,6 +94,8 @@ def parse():
     ap.add_argument("--no-configs4", action="store_true")
     ap.add_argument("--no-upload", action="store_true", help="skip the template_upload entry (pack + H2D, packed-file open)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the fast_mode entry (the opt-in fused-emission build)")
+    ap.add_argument("--no-rows", action="store_true", help="skip ss_modes / multi_strip / masked_round (tools/bench_rows.py: SURVEY 8a rows A5, A4 and "
+                    "the multi-strip queries the headline configuration does not exercise)")
     ap.add_argument("--virtual-shards", type=int, default=1,
                     help="single rank only: hold ALL shards of the V-shard database (V x --templates, same global plan, same "
                          "global ids) - the single-process reference of a V-rank run")
@@ -361,6 +363,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "generator_version": 2,   # 2 = SURVEY 8(d) to the letter since round 4 (Gamma(0.5) columns, the prescribed query stream); rounds 1-3 = 1
         "templates_per_s": n_global * args.steps / dt,
         "config": {
             "workload": "Lq%d_vs_%dx_Lt%s_%s_%s" % (Lq, n_global, Lt if args.lengths == "fixed" else "zipf50-1000",
@@ -457,6 +460,13 @@ def main():
 
     if single and not args.no_fast_mode and plain:
         out["fast_mode"] = fast_mode(args, capi, ctx, ts, rec, Ls, qf, qtr, dev_index, K)
+
+    if single and not args.no_rows and plain and n >= 50000:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_rows
+        out["ss_modes"] = bench_rows.ss_modes(torch, capi, dev_index, rec, rec_off, Ls, qf, qtr, K, local=args.local)
+        out["multi_strip"] = bench_rows.multi_strip(torch, capi, dev_index, rec, rec_off, Ls, K, local=args.local)
+        out["masked_round"] = bench_rows.masked_round(torch, capi, dev_index, rec, rec_off, Ls, qf, qtr, K, local=args.local)
 
     if single and not args.no_next_rows and plain:
         out["next_rows"] = next_rows()

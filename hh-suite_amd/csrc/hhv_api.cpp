@@ -11,6 +11,7 @@
 using namespace hhv;
 using hhv::api::dfree;
 using hhv::api::fail;
+using hhv::api::sync_check;
 using hhv::api::tset_init_common;
 
 static_assert(sizeof(hhv_result) == sizeof(DevResult), "hhv_result layout");
@@ -32,6 +33,21 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 const char* last_error() { return g_err.c_str(); }
+
+int sync_check(hhv_ctx* c, const char* who) {
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(HHV_E_DEVICE, "%s: %s", who, hipGetErrorString(e));
+  if (c->h_err) {
+    const uint32_t w = *(volatile uint32_t*)c->h_err;
+    if (w) {
+      *(volatile uint32_t*)c->h_err = 0;
+      return fail(HHV_E_DEVICE, "%s: device-side failure 0x%x:%s%s - the results of the launches since the last check are invalid", who, w,
+                  (w & DEV_ERR_PAIR_TIMEOUT) ? " a wave of a two-wave workgroup waited in vain for its partner (pair kernel flow control)" : "",
+                  (w & DEV_ERR_TRACE_STATE) ? " illegal state in the backtrace walk (src/hhviterbi.cpp:139-144)" : "");
+    }
+  }
+  return HHV_OK;
+}
 }  // namespace api
 }  // namespace hhv
 
@@ -177,6 +193,16 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
     hhv_destroy(c);
     return fail(HHV_E_DEVICE, "hhv_create: stream/event creation failed");
   }
+  if (hipHostMalloc((void**)&c->h_err, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0) != hipSuccess) {
+    hhv_destroy(c);
+    return fail(HHV_E_DEVICE, "hhv_create: error word allocation failed");
+  }
+  *c->h_err = 0;
+  // launch-policy defaults from the environment, read once per context (hhv_set_launch_policy overrides them)
+  if (const char* e = getenv("HHV_PAIR")) c->pair_mode = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("HHV_PAIR_SWAP")) c->pair_swap = std::max(-1, std::min(31, atoi(e)));
+  if (const char* e = getenv("HHV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(0, atoi(e));
   std::vector<float> lg2(1025), diff(1025);
   hhv_fast_log2_tables(lg2.data(), diff.data());
   if (hipMalloc(&c->d_lg2, 1025 * sizeof(float)) != hipSuccess ||
@@ -208,6 +234,17 @@ int hhv_set_params(hhv_ctx* c, const hhv_params* par) {
   return HHV_OK;
 }
 
+int hhv_set_launch_policy(hhv_ctx* c, int32_t pair_mode, int32_t pair_swap, int32_t blocks_per_cu) {
+  if (!c) return fail(HHV_E_ARG, "hhv_set_launch_policy: null argument");
+  if (pair_mode < -1 || pair_mode > 1) return fail(HHV_E_ARG, "hhv_set_launch_policy: pair_mode %d is not one of -1 (library's choice), 0 (one launch per strip), 1 (pairs wherever possible)", pair_mode);
+  if (pair_swap < -1 || pair_swap > 31) return fail(HHV_E_ARG, "hhv_set_launch_policy: pair_swap %d outside [-1, 31]", pair_swap);
+  if (blocks_per_cu < 0) return fail(HHV_E_ARG, "hhv_set_launch_policy: blocks_per_cu %d", blocks_per_cu);
+  c->pair_mode = pair_mode;
+  c->pair_swap = pair_swap;
+  c->blocks_per_cu = blocks_per_cu;
+  return HHV_OK;
+}
+
 void hhv_destroy(hhv_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->par.device);
@@ -228,6 +265,7 @@ void hhv_destroy(hhv_ctx* c) {
   if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
   if (c->mac_pinned_out) (void)hipHostFree(c->mac_pinned_out);
   if (c->q_stage) (void)hipHostFree(c->q_stage);
+  if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->ev_q) (void)hipEventDestroy(c->ev_q);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -672,10 +710,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     if (rc != 0 || nb < 1) return fail(HHV_E_DEVICE, "occupancy query failed (%d)", rc);
     blocks_per_cu = blocks_per_cu ? std::min(blocks_per_cu, nb) : nb;
   }
-  if (const char* e = getenv("HHV_BLOCKS_PER_CU")) {  // measurement aid: fewer resident waves per CU than the kernel admits
-    const int v = atoi(e);
-    if (v >= 1) blocks_per_cu = std::min(blocks_per_cu, v);
-  }
+  if (c->blocks_per_cu >= 1) blocks_per_cu = std::min(blocks_per_cu, c->blocks_per_cu);  // measurement aid (hhv_set_launch_policy)
   const int n_ranges = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu * arrays, ts->n));
   int n_waves = (n_ranges + arrays - 1) / arrays;
   rc = ensure_partition(c, ts, n_ranges, n_waves * arrays);
@@ -739,14 +774,11 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   // backtrace the pair is ahead either way (15.05 vs 15.73).
   // More than two strips: a CHAIN of launches - neighbouring strips two by two as pair launches (HBM carries only between the
   // links: half the launches, half the rows through HBM), a strip without a partner or without a pair kernel as a launch of its
-  // own.  HHV_PAIR=0 / 1: never / whenever a pair kernel exists (tests, measurements).
-  const char* pair_env = getenv("HHV_PAIR");  // (read per call: the tests switch it inside one process)
-  const bool pairs_possible = queue && plan.P >= 2 && plan.W == LANES && !celloff && !ss && !(pair_env && atoi(pair_env) == 0);
-  const bool pairs_forced = pair_env && atoi(pair_env) != 0;
-  {
-    const char* sw = getenv("HHV_PAIR_SWAP");  // measurement aid: which workgroups swap the strips of their two waves
-    a.pair_swap = sw ? atoi(sw) : 0;
-  }
+  // own.  hhv_set_launch_policy pair_mode 0 / 1: never / whenever a pair kernel exists (tests, measurements).
+  const bool pairs_possible = queue && plan.P >= 2 && plan.W == LANES && !celloff && !ss && c->pair_mode != 0;
+  const bool pairs_forced = c->pair_mode == 1;
+  a.pair_swap = c->pair_swap;
+  a.err = c->d_err;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int pass = 0; pass < plan.P;) {
     a.row_base = plan.base(pass);
@@ -790,8 +822,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
 
 int hhv_sync(hhv_ctx* c) {
   if (!c) return fail(HHV_E_ARG, "hhv_sync: null");
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return HHV_OK;
+  return sync_check(c, "hhv_sync");
 }
 
 void* hhv_stream(hhv_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -810,8 +841,7 @@ int hhv_align(hhv_ctx* c, hhv_tset* ts, uint32_t flags, hhv_result* out) {
   if (out) {
     HIP_TRY(hipMemcpyAsync(out, ts->d_results, (size_t)ts->n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
   }
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return HHV_OK;
+  return sync_check(c, "hhv_align");
 }
 
 int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
@@ -933,10 +963,10 @@ int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
   const int lr = bt_matrix(ts->d_bt, ts->d_rec_off, (int64_t)bt_plane_entries(ts->n_records, ts->bt_plan.W), Lq, ts->bt_plan, ts->bt_mm, k, Lt,
                            d_out, c->stream);
   hipError_t e = lr == 0 ? hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream) : hipErrorUnknown;
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  const int sc = e == hipSuccess ? sync_check(c, "hhv_backtrace_matrix") : HHV_OK;
   dfree(d_out);
   if (e != hipSuccess) return fail(HHV_E_DEVICE, "hhv_backtrace_matrix: device operation failed");
-  return HHV_OK;
+  return sc;
 }
 
 static int ensure_paths(hhv_ctx* c, hhv_tset* ts) {
@@ -1000,6 +1030,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.ss_q_off = c->ss_hmm_mode ? c->d_ss_q_off : nullptr;
   a.ss_t_shift = c->ss_t_shift;
   a.ss_t_mask = c->ss_t_mask;
+  a.err = c->d_err;
   rc = launch_trace(a, c->stream);
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   ts->hits_valid = true;
@@ -1015,7 +1046,7 @@ int hhv_hits(hhv_ctx* c, hhv_tset* ts, hhv_hit* hits) {
   if (rc != HHV_OK) return rc;
   if (hits) {  // (hits == NULL: trace and rescoring are only enqueued on the context's stream, like hhv_align_async)
     HIP_TRY(hipMemcpyAsync(hits, ts->d_hits, (size_t)ts->n * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    return sync_check(c, "hhv_hits");
   }
   return HHV_OK;
 }
@@ -1026,7 +1057,10 @@ int hhv_hit_path(hhv_ctx* c, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_st
   if (k < 0 || k >= ts->n) return fail(HHV_E_ARG, "hhv_hit_path: template %d of %d", k, ts->n);
   if (!ts->hits_valid) return fail(HHV_E_STATE, "hhv_hit_path: call hhv_hits first");
   HIP_TRY(hipSetDevice(c->par.device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  {
+    const int src_ = sync_check(c, "hhv_hit_path");
+    if (src_ != HHV_OK) return src_;
+  }
   const int64_t pool = ts->path_off[ts->n];
   if (!ts->host_paths_valid && (size_t)pool * 13 <= ((size_t)768 << 20)) {
     ts->h_i_steps.resize((size_t)pool);
@@ -1143,7 +1177,10 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
   if (kk < k) HIP_TRY(hipMemsetAsync(dst + kk, 0xFF, (size_t)(k - kk) * sizeof(DevHit), c->stream));
   if (out) {
     HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+      const int src_ = sync_check(c, "hhv_topk");
+      if (src_ != HHV_OK) return src_;
+    }
   }
   if (n_out) *n_out = kk;  // (known without the device: nothing to wait for when the records stay on the device)
   return HHV_OK;
@@ -1187,7 +1224,10 @@ int hhv_merge_hits(hhv_ctx* c, const void* d_in, int32_t m, int32_t k, hhv_hit* 
   int nv = 0;
   if (out) HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(&nv, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  {
+    const int src_ = sync_check(c, "hhv_merge_hits");
+    if (src_ != HHV_OK) return src_;
+  }
   if (n_out) *n_out = nv;
   return HHV_OK;
 }

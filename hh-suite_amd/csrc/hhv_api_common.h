@@ -24,6 +24,11 @@ namespace api {
 int fail(int code, const char* fmt, ...);
 const char* last_error();
 
+// hipStreamSynchronize on the context's stream, then the device error word: a kernel that met a failure (a pair wave that
+// waited in vain for its partner, an illegal backtrace state) has set a bit there - HHV_E_DEVICE with text, the word is
+// cleared.  Every entry point that hands device results to the host comes through here.
+int sync_check(struct ::hhv_ctx* c, const char* who);
+
 template <typename T>
 inline void dfree(T*& p) {
   if (p) (void)hipFree(p);
@@ -86,6 +91,14 @@ struct hhv_ctx {
   int ss_t_shift = 0, ss_t_mask = 0;
   void* d_merge = nullptr;                             // hhv_merge_hits: merge_cap records + one int
   int merge_cap = 0;
+  // device error word (hhv_internal.h DEV_ERR_*): one host-mapped dword the kernels store to when they meet a failure;
+  // read by every call that has just waited for the stream (hhv::api::sync_check)
+  uint32_t* h_err = nullptr;
+  uint32_t* d_err = nullptr;                           // the device's address of *h_err
+  // launch policy (hhv_set_launch_policy; the defaults may come from the environment, read ONCE in hhv_create: ADVICE r4)
+  int pair_mode = -1;                                  // -1 the library chooses, 0 one launch per strip, 1 a pair launch wherever a pair kernel exists
+  int pair_swap = 0;                                   // pair kernels: workgroups with this bit of their number set swap the strips of their waves; -1 none
+  int blocks_per_cu = 0;                               // > 0: at most this many resident workgroups per CU (measurements)
 };
 
 struct hhv_tset {

@@ -114,7 +114,13 @@ struct StreamArgs {
                              // >= 128 records, longest first; entry n_seg = the terminal header
   int32_t n_seg;
   uint32_t* queue;           // ticket counter, = the number of waves at launch (wave w starts with segment w)
+  uint32_t* err;             // the context's device error word (host-mapped): DEV_ERR_* bits, set by system-scope atomics
 };
+
+// Device-side failures (the reference stops loudly on an illegal state, src/hhviterbi.cpp:139-144): a kernel that meets one
+// sets a bit in the context's error word; every call that waits for the stream reports it as HHV_E_DEVICE (hhv_api.cpp).
+constexpr uint32_t DEV_ERR_PAIR_TIMEOUT = 1u;   // a wave of a two-wave workgroup waited in vain for its partner (hhv_stream_kernel.h pair_wait)
+constexpr uint32_t DEV_ERR_TRACE_STATE = 2u;    // hhv_trace_kernel met a state that is not one of STOP, MM, GD, IM, DG, MI
 
 struct TraceArgs {
   const float* records;
@@ -140,6 +146,7 @@ struct TraceArgs {
   const float* ss_table;     // null: no secondary-structure information (score_ss = 0)
   const int32_t* ss_q_off;
   int32_t ss_t_shift, ss_t_mask;
+  uint32_t* err;             // the context's device error word (StreamArgs::err)
 };
 
 // raw (unprepared) template column, 32 dwords: the fields of the reference's HMM after HMM::Read

@@ -55,7 +55,7 @@ __device__ __forceinline__ float dot20_scalar_dev(const float* __restrict__ q, c
 }
 
 // one step of Viterbi::Backtrace (src/hhviterbi.cpp:96-146); b = the reference's backtrace byte of cell (i, j)
-__device__ __forceinline__ void trace_step(int& state, int& i, int& j, int& matched, uint32_t b) {
+__device__ __forceinline__ void trace_step(int& state, int& i, int& j, int& matched, uint32_t b, uint32_t* err) {
   switch (state) {
     case 2:  // MM
       matched++;
@@ -94,7 +94,8 @@ __device__ __forceinline__ void trace_step(int& state, int& i, int& j, int& matc
         i--;
       }
       break;
-    default:  // :139-144
+    default:  // :139-144: the reference reports "unallowed state value" and ends the path; here the context's error word
+      if (err) *(volatile uint32_t*)err = DEV_ERR_TRACE_STATE;
       state = 0;
       break;
   }
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
     const int st_here = state;
     last_i = i;
     last_j = j;
-    trace_step(state, i, j, matched, b);
+    trace_step(state, i, j, matched, b, a.err);
     step++;
     sbuf |= (uint32_t)(state == 0 ? 2 : st_here) << (8 * (step & 3));
     if ((step & 3) == 3) {

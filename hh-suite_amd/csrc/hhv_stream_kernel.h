@@ -88,15 +88,28 @@ __device__ __forceinline__ int lds_peek(uint32_t addr) {
 __device__ __forceinline__ void lds_poke(uint32_t addr, int v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-// spin until the word at `addr` is >= need (bounded: a logic error must not hang the device)
-__device__ __forceinline__ void pair_wait(uint32_t addr, int need) {
+// spin until the word at `addr` is >= need.  Bounded: a logic error (or a partner wave that is held up for tens of
+// milliseconds) must not hang the device - but it must not pass for a result either: when the bound is hit the wave sets
+// DEV_ERR_PAIR_TIMEOUT in the context's error word (host-mapped memory, a plain store: any non-zero word is a failure) and
+// every call that waits for the stream answers HHV_E_DEVICE (hhv_api.cpp sync_check).  `dead` (wave
+// uniform, kept by the caller) makes the later waits of a wave that has given up return at once: its results are garbage
+// anyway, and a launch of thousands of chunks must not spend the bound thousands of times.
+#if defined(HHV_EXP_PAIR_TIMEOUT)  // test build (tests/test_gpu_errors.py): the first wave never reports progress, short bound
+constexpr int PAIR_WAIT_SPINS = 1 << 8;
+#else
+constexpr int PAIR_WAIT_SPINS = 1 << 17;
+#endif
+__device__ __forceinline__ void pair_wait(uint32_t addr, int need, uint32_t* err, int& dead) {
 #if defined(HHV_EXP_PAIR_NOSYNC)  // measurement build, WRONG results: nobody waits for anybody
   return;
 #endif
-  for (int guard = 0; guard < (1 << 17); ++guard) {
+  if (dead) return;
+  for (int guard = 0; guard < PAIR_WAIT_SPINS; ++guard) {
     if (lds_peek(addr) >= need) return;
     __builtin_amdgcn_s_sleep(4);
   }
+  dead = 1;
+  if (err) *(volatile uint32_t*)err = DEV_ERR_PAIR_TIMEOUT;
 }
 
 // ---- work queue of the 64-lane variants (see the kernel: DQ) ------------------------------------
@@ -168,9 +181,11 @@ struct WorkQueue {
   // padding is read).  Everything that depends on the array is wave uniform here: no per-lane selects.
   // PM (pair mode, see PairLds): 1 = publish every id drawn, 2 = take the ids the first wave published instead of drawing
   int draws = 0;
+  int dead = 0;  // pair kernels: this wave has given up waiting for its partner (pair_wait)
   template <int W, int PM = 0>
   __device__ __forceinline__ void refill(const float4* __restrict__ records, const int64_t* seg_first, int n_seg,
-                                         const uint32_t* queue, int cc, float4* dst, int lane, PairLds* pair = nullptr) {
+                                         const uint32_t* queue, int cc, float4* dst, int lane, PairLds* pair = nullptr,
+                                         uint32_t* err = nullptr) {
     constexpr int C = W / 2, CF4 = C * 7, H = (CF4 + LANES - 1) / LANES;
     const int P0 = cc * C;
     const bool cross = !tail && P0 + C > J;
@@ -179,8 +194,9 @@ struct WorkQueue {
     if (cross) {
       int id;
       if (PM == 2) {
-        pair_wait(lds_addr_of(&pair->seg_count), draws + 1);
+        pair_wait(lds_addr_of(&pair->seg_count), draws + 1, err, dead);
         id = lds_peek(lds_addr_of(&pair->seg_id[draws & 15]));
+        if (dead) id = n_seg;  // (given up: the id may never have been written - the stream ends here)
       } else {
         id = draw(queue);
         if (PM == 1) {  // (LDS executes a wave's operations in order: the id is written before the count)
@@ -555,7 +571,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     float4* const slot = ring + (cc & (RING_CHUNKS - 1)) * SLOT_F4;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      if (cc * C < wq[j].end) wq[j].template refill<W, (PW0 ? 1 : PW1 ? 2 : 0)>((const float4*)a.records, a.seg_first, a.n_seg, a.queue, cc, slot + j * (C * 7), lane, pair);
+      if (cc * C < wq[j].end) wq[j].template refill<W, (PW0 ? 1 : PW1 ? 2 : 0)>((const float4*)a.records, a.seg_first, a.n_seg, a.queue, cc, slot + j * (C * 7), lane, pair, a.err);
     }
     M = wq[0].end;
     Mmax = wq[0].end;
@@ -700,7 +716,7 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(pc0), "=&v"(pc1) : "v"(addr) : "memory");
   };
   if (PW1) {
-    pair_wait(lds_addr_of(&pair->w0_done), C + 1);  // the first chunk's positions (and the one read ahead) have been written
+    pair_wait(lds_addr_of(&pair->w0_done), C + 1, a.err, wq[0].dead);  // the first chunk's positions (and the one read ahead) have been written
     pair_carry_issue(0);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc0), "+v"(pc1));
   }
@@ -909,13 +925,15 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
         // positions below c C - LEAD - (W - 1) are in the FIFO (their ds_writes are complete: LDS executes a wave's operations
         // in order and the steps' waits have passed them); the coming chunk writes positions up to pmax, which must not lap the
         // second wave
+        #if !defined(HHV_EXP_PAIR_TIMEOUT)
         if (c * C - LEAD - (W - 1) > 0) lds_poke(lds_addr_of(&pair->w0_done), c * C - LEAD - (W - 1));
+#endif
         const int pmax = (c + 1) * C - LEAD - W;
-        if (pmax - (PAIR_FIFO - 1) > 0) pair_wait(lds_addr_of(&pair->w1_done), pmax - (PAIR_FIFO - 1));
+        if (pmax - (PAIR_FIFO - 1) > 0) pair_wait(lds_addr_of(&pair->w1_done), pmax - (PAIR_FIFO - 1), a.err, wq[0].dead);
       }
       if (PW1) {
         lds_poke(lds_addr_of(&pair->w1_done), c * C - LEAD);
-        pair_wait(lds_addr_of(&pair->w0_done), (c + 1) * C - LEAD + 1);
+        pair_wait(lds_addr_of(&pair->w0_done), (c + 1) * C - LEAD + 1, a.err, wq[0].dead);
       }
       if (DQV) {
         const int m_before = Mmax;
@@ -957,7 +975,9 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       for (int s = s_lo; s < s_hi; ++s) step(s, col, col);
     }
   }
+#if !defined(HHV_EXP_PAIR_TIMEOUT)
   if (PW0) lds_poke(lds_addr_of(&pair->w0_done), 0x7FFFFFFF);  // through: the second wave never waits again
+#endif
   if (PW1) lds_poke(lds_addr_of(&pair->w1_done), 0x7FFFFFFF);
 #if defined(HHV_EXP_WAVETIME)
   if (lane == 0 && array0 < 16384) {

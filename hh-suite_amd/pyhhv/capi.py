@@ -34,7 +34,7 @@ HIT_DTYPE = np.dtype([("score", np.float32), ("viterbi_score", np.float32), ("sc
 # every symbol include/hhviterbi_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
-    "hhv_create", "hhv_destroy", "hhv_set_params", "hhv_set_fast_log2_tables", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
+    "hhv_create", "hhv_destroy", "hhv_set_params", "hhv_set_launch_policy", "hhv_set_fast_log2_tables", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
     "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of", "hhv_tset_download",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
@@ -301,7 +301,7 @@ class Context:
         self.par = HhvParams(int(device), int(local), float(egq), float(egt), float(shift), float(corr), float(ssw),
                              int(ss_mode))
         h = C.c_void_p()
-        _check(self.lib.hhv_create(C.byref(h), C.byref(self.par)))
+        self._chk(self.lib.hhv_create(C.byref(h), C.byref(self.par)))
         self.h = h
         self.Lq = 0
 
@@ -310,10 +310,19 @@ class Context:
             self.lib.hhv_destroy(self.h)
             self.h = None
 
+    def _chk(self, rc):
+        """status check against the library THIS context lives in (a second build loaded by path keeps its own error text)"""
+        if rc != 0:
+            raise HhvError("hhv error %d: %s" % (rc, self.lib.hhv_last_error().decode()))
+
+    def set_launch_policy(self, pair_mode=-1, pair_swap=0, blocks_per_cu=0):
+        """hhv_set_launch_policy: pair_mode -1 library's choice / 0 one launch per strip / 1 pair launches wherever possible"""
+        self._chk(self.lib.hhv_set_launch_policy(self.h, int(pair_mode), int(pair_swap), int(blocks_per_cu)))
+
     def set_query(self, p, tr):
         p, tr = _f32(p), _f32(tr)
         self.Lq = p.shape[0] - 1
-        _check(self.lib.hhv_set_query(self.h, p.ctypes.data_as(c_float_p), tr.ctypes.data_as(c_float_p), self.Lq))
+        self._chk(self.lib.hhv_set_query(self.h, p.ctypes.data_as(c_float_p), tr.ctypes.data_as(c_float_p), self.Lq))
 
     def upload(self, tps, ttrs, t_ss=None):
         """t_ss: optional list of (ss_pred, ss_conf, ss_dssp) int8 arrays per template (entries may be None)."""
@@ -325,13 +334,13 @@ class Context:
         tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in ttrs])
         h = C.c_void_p()
         if t_ss is None:
-            _check(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, C.byref(h)))
+            self._chk(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, C.byref(h)))
         else:
             keep = [[None if x is None else np.ascontiguousarray(x, dtype=np.int8) for x in t] for t in t_ss]
             arrs = []
             for col in range(3):
                 arrs.append((C.c_void_p * n)(*[(k[col].ctypes.data if k[col] is not None else None) for k in keep]))
-            _check(self.lib.hhv_upload_templates_ss(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, arrs[0], arrs[1],
+            self._chk(self.lib.hhv_upload_templates_ss(self.h, n, Ls.ctypes.data_as(c_int_p), pp, tt, arrs[0], arrs[1],
                                                     arrs[2], C.byref(h)))
         return TemplateSet(self, h, Ls)
 
@@ -340,21 +349,21 @@ class Context:
         n, L = P.shape[0], P.shape[1] - 1
         Ls = np.full(n, L, dtype=np.int32)
         h = C.c_void_p()
-        _check(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), _row_pointers(P), _row_pointers(T), C.byref(h)))
+        self._chk(self.lib.hhv_upload_templates(self.h, n, Ls.ctypes.data_as(c_int_p), _row_pointers(P), _row_pointers(T), C.byref(h)))
         return TemplateSet(self, h, Ls)
 
     def set_ss_tables(self, S73, S33, S37):
         S73, S33, S37 = _f32(S73).reshape(-1), _f32(S33).reshape(-1), _f32(S37).reshape(-1)
         assert S73.size == 352 and S33.size == 1936 and S37.size == 352
-        _check(self.lib.hhv_set_ss_tables(self.h, S73.ctypes.data_as(c_float_p), S33.ctypes.data_as(c_float_p),
+        self._chk(self.lib.hhv_set_ss_tables(self.h, S73.ctypes.data_as(c_float_p), S33.ctypes.data_as(c_float_p),
                                           S37.ctypes.data_as(c_float_p)))
 
     def set_query_ss(self, ss_pred=None, ss_conf=None, ss_dssp=None):
         a = [None if x is None else np.ascontiguousarray(x, dtype=np.int8) for x in (ss_pred, ss_conf, ss_dssp)]
-        _check(self.lib.hhv_set_query_ss(self.h, *[(x.ctypes.data if x is not None else None) for x in a]))
+        self._chk(self.lib.hhv_set_query_ss(self.h, *[(x.ctypes.data if x is not None else None) for x in a]))
 
     def set_ss_mode(self, mode):
-        _check(self.lib.hhv_set_ss_mode(self.h, int(mode)))
+        self._chk(self.lib.hhv_set_ss_mode(self.h, int(mode)))
 
     def upload_raw(self, fs, trs, neffs, neff_hmm):
         """hhv_upload_raw_templates: raw HMMs (f[(L+2),20], tr[(L+1),7], neff[(L+1),3], Neff_HMM) -> raw set handle."""
@@ -368,7 +377,7 @@ class Context:
         tt = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in trs])
         nn = (c_float_p * n)(*[a.ctypes.data_as(c_float_p) for a in neffs])
         h = C.c_void_p()
-        _check(self.lib.hhv_upload_raw_templates(self.h, n, Ls.ctypes.data_as(c_int_p), ff, tt, nn,
+        self._chk(self.lib.hhv_upload_raw_templates(self.h, n, Ls.ctypes.data_as(c_int_p), ff, tt, nn,
                                                  nh.ctypes.data_as(c_float_p), None, None, None, C.byref(h)))
         return h, Ls
 
@@ -379,7 +388,7 @@ class Context:
         self.lib.hhv_prepare_subset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.POINTER(C.c_void_p)]
         h = C.c_void_p()
-        _check(self.lib.hhv_prepare_subset(self.h, raw, C.byref(params), q_pav.ctypes.data, ids.ctypes.data, len(ids), C.byref(h)))
+        self._chk(self.lib.hhv_prepare_subset(self.h, raw, C.byref(params), q_pav.ctypes.data, ids.ctypes.data, len(ids), C.byref(h)))
         return TemplateSet(self, h, np.asarray(all_Ls, dtype=np.int32)[ids])
 
     def rawdb_open(self, path):
@@ -388,21 +397,21 @@ class Context:
         self.lib.hhv_rawset_size.argtypes = [C.c_void_p]
         self.lib.hhv_rawset_lengths.argtypes = [C.c_void_p, C.c_void_p]
         h = C.c_void_p()
-        _check(self.lib.hhv_rawdb_open(self.h, str(path).encode(), C.byref(h)))
+        self._chk(self.lib.hhv_rawdb_open(self.h, str(path).encode(), C.byref(h)))
         Ls = np.zeros(self.lib.hhv_rawset_size(h), dtype=np.int32)
-        _check(self.lib.hhv_rawset_lengths(h, Ls.ctypes.data))
+        self._chk(self.lib.hhv_rawset_lengths(h, Ls.ctypes.data))
         return h, Ls
 
     def prepare(self, raw, Ls, params, q_pav, ts=None):
         """hhv_prepare_templates -> TemplateSet (created on the first call, refilled afterwards)."""
         q_pav = _f32(q_pav)
         h = C.c_void_p(ts.h.value) if ts is not None else C.c_void_p()
-        _check(self.lib.hhv_prepare_templates(self.h, raw, C.byref(params), q_pav.ctypes.data_as(c_float_p), C.byref(h)))
+        self._chk(self.lib.hhv_prepare_templates(self.h, raw, C.byref(params), q_pav.ctypes.data_as(c_float_p), C.byref(h)))
         return ts if ts is not None else TemplateSet(self, h, Ls)
 
     def rawset_pav(self, raw, n):
         pav = np.zeros((n, 20), dtype=np.float32)
-        _check(self.lib.hhv_rawset_pav(self.h, raw, pav.ctypes.data_as(c_float_p)))
+        self._chk(self.lib.hhv_rawset_pav(self.h, raw, pav.ctypes.data_as(c_float_p)))
         return pav
 
     def rawset_free(self, raw):
@@ -410,7 +419,7 @@ class Context:
 
     def records_of(self, ts, k):
         out = np.zeros((int(ts.L[k]) + 1, REC_DW), dtype=np.float32)
-        _check(self.lib.hhv_tset_records_of(self.h, ts.h, int(k), out.ctypes.data_as(c_float_p)))
+        self._chk(self.lib.hhv_tset_records_of(self.h, ts.h, int(k), out.ctypes.data_as(c_float_p)))
         return out
 
     def gather(self, ts, ids):
@@ -418,14 +427,14 @@ class Context:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         self.lib.hhv_tset_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         h = C.c_void_p()
-        _check(self.lib.hhv_tset_gather(self.h, ts.h, ids.ctypes.data, len(ids), C.byref(h)))
+        self._chk(self.lib.hhv_tset_gather(self.h, ts.h, ids.ctypes.data, len(ids), C.byref(h)))
         return TemplateSet(self, h, np.asarray(ts.L, dtype=np.int32)[ids])
 
     def prefilter_upload_db(self, seqs, offsets):
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         h = C.c_void_p()
-        _check(self.lib.hhv_prefilter_upload_db(self.h, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, C.byref(h)))
+        self._chk(self.lib.hhv_prefilter_upload_db(self.h, len(offsets) - 1, seqs.ctypes.data, offsets.ctypes.data, C.byref(h)))
         return (h, len(offsets) - 1)
 
     def prefilter_first(self, db, profile, score_offset, log_qlen, bit_factor=4, smax_thresh=10, min_hits=100):
@@ -435,7 +444,7 @@ class Context:
         n = C.c_int32()
         self.lib.hhv_prefilter_first.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
-        _check(self.lib.hhv_prefilter_first(self.h, db[0], profile.ctypes.data, profile.shape[1], int(score_offset),
+        self._chk(self.lib.hhv_prefilter_first(self.h, db[0], profile.ctypes.data, profile.shape[1], int(score_offset),
                                             float(log_qlen), int(bit_factor), int(smax_thresh), int(min_hits), ids.ctypes.data,
                                             len(ids), C.byref(n)))
         return ids[:n.value]
@@ -449,7 +458,7 @@ class Context:
         n = db[1] if subset is None else len(subset)
         out = np.zeros(n, dtype=np.int32)
         sub = None if subset is None else np.ascontiguousarray(subset, dtype=np.int32)
-        _check(self.lib.hhv_prefilter_scores(self.h, db[0], profile.ctypes.data, profile.shape[1], int(score_offset),
+        self._chk(self.lib.hhv_prefilter_scores(self.h, db[0], profile.ctypes.data, profile.shape[1], int(score_offset),
                                              int(bool(gapped)), int(gap_init), int(gap_extend),
                                              sub.ctypes.data if sub is not None else None, 0 if sub is None else len(sub),
                                              out.ctypes.data))
@@ -457,7 +466,7 @@ class Context:
 
     def mac_set_lists(self, on):
         """hhv_mac_set_lists: keep the -o_matrices forward / backward lists of the following mac_realign* calls"""
-        _check(self.lib.hhv_mac_set_lists(self.h, int(on)))
+        self._chk(self.lib.hhv_mac_set_lists(self.h, int(on)))
 
     def mac_realign(self, qp, q_tr_lin, tps, t_trs, celloffs=None, local=1, shift=-0.03, mact=0.3501):
         """hhv_mac_realign -> MacSet (hits structured array + path()/posterior() accessors)."""
@@ -478,7 +487,7 @@ class Context:
             cc = (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in keep])
         hits = np.zeros(n, dtype=MAC_HIT_DTYPE)
         h = C.c_void_p()
-        _check(self.lib.hhv_mac_realign(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, n, Lt.ctypes.data, pp, tt, cc,
+        self._chk(self.lib.hhv_mac_realign(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, n, Lt.ctypes.data, pp, tt, cc,
                                         int(local), shift, mact, C.byref(h), hits.ctypes.data))
         return MacSet(self.lib, h, hits, Lq, Lt)
 
@@ -505,7 +514,7 @@ class Context:
                                                   C.c_void_p, C.c_int32, C.c_float, C.c_float, C.POINTER(C.c_void_p), C.c_void_p]
         hits = np.zeros(n, dtype=MAC_HIT_DTYPE)
         h = C.c_void_p()
-        _check(self.lib.hhv_mac_realign_tset(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, ts.h, n, tof.ctypes.data, tt,
+        self._chk(self.lib.hhv_mac_realign_tset(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, ts.h, n, tof.ctypes.data, tt,
                                              C.addressof(arr), 0, None, 0, None, int(local), shift, mact, C.byref(h),
                                              hits.ctypes.data))
         return MacSet(self.lib, h, hits, Lq, Lt)
@@ -532,7 +541,7 @@ class Context:
         trg = np.ascontiguousarray(tranges, np.int32).reshape(-1)
         hits = np.zeros(n, dtype=MAC_HIT_DTYPE)
         h = C.c_void_p()
-        _check(self.lib.hhv_mac_realign_hits(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, n, Lt.ctypes.data, pp, tt,
+        self._chk(self.lib.hhv_mac_realign_hits(self.h, qp.ctypes.data, q_tr_lin.ctypes.data, Lq, n, Lt.ctypes.data, pp, tt,
                                              C.addressof(arr), len(qr) // 2, qr.ctypes.data if len(qr) else None,
                                              len(trg) // 2, trg.ctypes.data if len(trg) else None, int(local), shift, mact,
                                              C.byref(h), hits.ctypes.data))
@@ -540,44 +549,44 @@ class Context:
 
     def db_open(self, path, Ls):
         h = C.c_void_p()
-        _check(self.lib.hhv_db_open(self.h, path.encode(), C.byref(h)))
+        self._chk(self.lib.hhv_db_open(self.h, path.encode(), C.byref(h)))
         return TemplateSet(self, h, Ls)
 
     def adopt_device_stream(self, Ls, device_ptr):
         Ls = np.ascontiguousarray(Ls, dtype=np.int32)
         h = C.c_void_p()
-        _check(self.lib.hhv_adopt_device_stream(self.h, len(Ls), Ls.ctypes.data_as(c_int_p), C.c_void_p(device_ptr),
+        self._chk(self.lib.hhv_adopt_device_stream(self.h, len(Ls), Ls.ctypes.data_as(c_int_p), C.c_void_p(device_ptr),
                                                 C.byref(h)))
         return TemplateSet(self, h, Ls)
 
     def align(self, ts, backtrace=False, celloff=False):
         flags = (HHV_ALIGN_BACKTRACE if backtrace else 0) | (HHV_ALIGN_CELLOFF if celloff else 0)
         out = np.zeros(ts.n, dtype=RESULT_DTYPE)
-        _check(self.lib.hhv_align(self.h, ts.h, flags, out.ctypes.data))
+        self._chk(self.lib.hhv_align(self.h, ts.h, flags, out.ctypes.data))
         return out
 
     def align_async(self, ts, backtrace=False, celloff=False, d_out=None):
         flags = (HHV_ALIGN_BACKTRACE if backtrace else 0) | (HHV_ALIGN_CELLOFF if celloff else 0)
-        _check(self.lib.hhv_align_async(self.h, ts.h, flags, C.c_void_p(d_out) if d_out else None))
+        self._chk(self.lib.hhv_align_async(self.h, ts.h, flags, C.c_void_p(d_out) if d_out else None))
 
     def sync(self):
-        _check(self.lib.hhv_sync(self.h))
+        self._chk(self.lib.hhv_sync(self.h))
 
     def stream(self):
         return self.lib.hhv_stream(self.h)
 
     def last_kernel_ms(self):
         ms = C.c_float()
-        _check(self.lib.hhv_last_kernel_ms(self.h, C.byref(ms)))
+        self._chk(self.lib.hhv_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
     def set_celloff(self, ts, k, mask):
         if mask is None:
-            _check(self.lib.hhv_set_celloff(self.h, ts.h, int(k), None))
+            self._chk(self.lib.hhv_set_celloff(self.h, ts.h, int(k), None))
             return
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         assert m.shape == (self.Lq + 1, int(ts.L[k]) + 1)
-        _check(self.lib.hhv_set_celloff(self.h, ts.h, int(k), m.ctypes.data))
+        self._chk(self.lib.hhv_set_celloff(self.h, ts.h, int(k), m.ctypes.data))
 
     def set_celloff_paths(self, ts, paths, qranges=(), tranges=()):
         """hhv_set_celloff_paths: paths = [(template, nsteps, i_steps, j_steps)] with 1-based step arrays as hit_path returns
@@ -591,27 +600,27 @@ class Context:
         pi, pj = np.ascontiguousarray(pi), np.ascontiguousarray(pj)
         qr = np.ascontiguousarray(np.asarray(qranges, dtype=np.int32).reshape(-1))
         tr = np.ascontiguousarray(np.asarray(tranges, dtype=np.int32).reshape(-1))
-        _check(self.lib.hhv_set_celloff_paths(self.h, ts.h, len(paths), template_of.ctypes.data, off.ctypes.data,
+        self._chk(self.lib.hhv_set_celloff_paths(self.h, ts.h, len(paths), template_of.ctypes.data, off.ctypes.data,
                                               pi.ctypes.data, pj.ctypes.data, len(qr) // 2, qr.ctypes.data if len(qr) else None,
                                               len(tr) // 2, tr.ctypes.data if len(tr) else None))
 
     def set_global_batch(self, ts, not_longest):
         """hhv_set_global_batch: not_longest[k] != 0 -> template k is shorter than the longest of its SIMD batch"""
         if not_longest is None:
-            _check(self.lib.hhv_set_global_batch(self.h, ts.h, None))
+            self._chk(self.lib.hhv_set_global_batch(self.h, ts.h, None))
             return
         f = np.ascontiguousarray(not_longest, dtype=np.uint8)
         assert f.shape == (ts.n,)
-        _check(self.lib.hhv_set_global_batch(self.h, ts.h, f.ctypes.data))
+        self._chk(self.lib.hhv_set_global_batch(self.h, ts.h, f.ctypes.data))
 
     def backtrace_matrix(self, ts, k):
         out = np.zeros((self.Lq + 1, int(ts.L[k]) + 1), dtype=np.uint8)
-        _check(self.lib.hhv_backtrace_matrix(self.h, ts.h, int(k), out.ctypes.data))
+        self._chk(self.lib.hhv_backtrace_matrix(self.h, ts.h, int(k), out.ctypes.data))
         return out
 
     def hits(self, ts, fetch=True):
         out = np.zeros(ts.n, dtype=HIT_DTYPE) if fetch else None
-        _check(self.lib.hhv_hits(self.h, ts.h, out.ctypes.data if fetch else None))
+        self._chk(self.lib.hhv_hits(self.h, ts.h, out.ctypes.data if fetch else None))
         return out
 
     def backtrace(self, ts, k):
@@ -621,7 +630,7 @@ class Context:
         j_steps = np.zeros(cap, dtype=np.int32)
         states = np.zeros(cap, dtype=np.int8)
         ns, mc = C.c_int32(), C.c_int32()
-        _check(self.lib.hhv_backtrace(self.h, ts.h, int(k), cap, i_steps.ctypes.data_as(C.c_void_p), j_steps.ctypes.data_as(C.c_void_p),
+        self._chk(self.lib.hhv_backtrace(self.h, ts.h, int(k), cap, i_steps.ctypes.data_as(C.c_void_p), j_steps.ctypes.data_as(C.c_void_p),
                                       states.ctypes.data_as(C.c_void_p), C.byref(ns), C.byref(mc)))
         return ns.value, mc.value, i_steps, j_steps, states
 
@@ -632,7 +641,7 @@ class Context:
         states = np.zeros(cap, dtype=np.int8)
         S = np.zeros(cap, dtype=np.float32)
         ns = C.c_int32()
-        _check(self.lib.hhv_hit_path(self.h, ts.h, int(k), cap, i_steps.ctypes.data, j_steps.ctypes.data,
+        self._chk(self.lib.hhv_hit_path(self.h, ts.h, int(k), cap, i_steps.ctypes.data, j_steps.ctypes.data,
                                      states.ctypes.data, S.ctypes.data, C.byref(ns)))
         return ns.value, i_steps, j_steps, states, S
 
@@ -640,7 +649,7 @@ class Context:
         """hhv_hit_path_pool: (path_off[n+1], i_steps, j_steps, states, S) of all templates as numpy copies of the
         library's host mirror (entry path_off[k] + s = step s of template k, s = 1..nsteps)."""
         ptrs = [C.c_void_p() for _ in range(5)]
-        _check(self.lib.hhv_hit_path_pool(self.h, ts.h, *[C.byref(p) for p in ptrs]))
+        self._chk(self.lib.hhv_hit_path_pool(self.h, ts.h, *[C.byref(p) for p in ptrs]))
         n = ts.n
         off = np.ctypeslib.as_array(C.cast(ptrs[0], C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
         tot = int(off[n])
@@ -653,19 +662,19 @@ class Context:
     def topk(self, ts, k, d_out=None, fetch=True, raw=False):
         out = np.zeros(k, dtype=HIT_DTYPE) if fetch else None
         n = C.c_int32()
-        _check(self.lib.hhv_topk(self.h, ts.h, int(k), 1 if raw else 0, out.ctypes.data if fetch else None,
+        self._chk(self.lib.hhv_topk(self.h, ts.h, int(k), 1 if raw else 0, out.ctypes.data if fetch else None,
                                  C.c_void_p(d_out) if d_out else None, C.byref(n)))
         return (out[:n.value] if fetch else None), n.value
 
     def set_global_ids(self, ts, ids):
         """ids: global template id of every entry of the shard (None = back to set indices); hhv_topk then reports them"""
         if ids is None:
-            _check(self.lib.hhv_tset_set_global_ids(self.h, ts.h, None))
+            self._chk(self.lib.hhv_tset_set_global_ids(self.h, ts.h, None))
             return
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         if ids.shape[0] != ts.n:
             raise HhvError("set_global_ids: %d ids for %d templates" % (ids.shape[0], ts.n))
-        _check(self.lib.hhv_tset_set_global_ids(self.h, ts.h, ids.ctypes.data_as(C.c_void_p)))
+        self._chk(self.lib.hhv_tset_set_global_ids(self.h, ts.h, ids.ctypes.data_as(C.c_void_p)))
 
     def merge_hits(self, d_in, m, k, d_out=None, fetch=True, count=True):
         """d_in: device pointer to m hhv_hit records (gathered top-K lists, global ids) -> the k best, merged on the device.
@@ -673,7 +682,7 @@ class Context:
         out = np.zeros(k, dtype=HIT_DTYPE) if fetch else None
         n = C.c_int32()
         want_n = fetch or count
-        _check(self.lib.hhv_merge_hits(self.h, C.c_void_p(d_in), int(m), int(k), out.ctypes.data if fetch else None,
+        self._chk(self.lib.hhv_merge_hits(self.h, C.c_void_p(d_in), int(m), int(k), out.ctypes.data if fetch else None,
                                        C.c_void_p(d_out) if d_out else None, C.byref(n) if want_n else None))
         return (out[:n.value] if fetch else None), (n.value if want_n else None)
 
@@ -765,6 +774,10 @@ class MacSet:
     def __init__(self, lib, h, hits, Lq, Lt):
         self.lib, self.h, self.hits, self.Lq, self.Lt = lib, h, hits, Lq, Lt
 
+    def _chk(self, rc):
+        if rc != 0:
+            raise HhvError("hhv error %d: %s" % (rc, self.lib.hhv_last_error().decode()))
+
     def path(self, k):
         cap = int(self.hits["nsteps"][k]) + 1
         i_s = np.zeros(cap, np.int32)
@@ -773,18 +786,18 @@ class MacSet:
         S = np.zeros(cap, np.float32)
         P = np.zeros(cap, np.float32)
         ns = C.c_int32()
-        _check(self.lib.hhv_mac_path(self.h, k, cap, i_s.ctypes.data, j_s.ctypes.data, st.ctypes.data, S.ctypes.data,
+        self._chk(self.lib.hhv_mac_path(self.h, k, cap, i_s.ctypes.data, j_s.ctypes.data, st.ctypes.data, S.ctypes.data,
                                      P.ctypes.data, C.byref(ns)))
         return i_s, j_s, st, S, P
 
     def celloff(self, k):
         out = np.zeros((self.Lq + 1, int(self.Lt[k]) + 1), np.uint8)
-        _check(self.lib.hhv_mac_celloff(self.h, k, out.ctypes.data))
+        self._chk(self.lib.hhv_mac_celloff(self.h, k, out.ctypes.data))
         return out
 
     def posterior(self, k):
         out = np.zeros((self.Lq + 1, int(self.Lt[k]) + 1), np.float32)
-        _check(self.lib.hhv_mac_posterior(self.h, k, out.ctypes.data))
+        self._chk(self.lib.hhv_mac_posterior(self.h, k, out.ctypes.data))
         return out
 
     def list(self, k, which):

@@ -153,6 +153,16 @@ void hhv_destroy(hhv_ctx* ctx);
  * context that outlives one ViterbiRunner::alignment call needs (hh-suite_amd/dropin/hhviterbirunner_hip.cpp keeps the
  * raw template database of earlier searches resident in one).  The query, the resident sets and their results stay. */
 int hhv_set_params(hhv_ctx* ctx, const hhv_params* par);
+/* How the library launches the DP of a context - nothing a result depends on; for tests and measurements (the reference has
+ * no counterpart: its batches are OpenMP iterations, src/hhviterbirunner.cpp:122).
+ *   pair_mode      queries of two and more strips: -1 the library chooses (default), 0 one launch per strip, 1 two-wave
+ *                  workgroups (pair / chain launches) wherever a pair kernel exists
+ *   pair_swap      pair kernels: workgroups whose number has this bit set run the strips on swapped wave indices (default 0;
+ *                  -1 none; at most 31)
+ *   blocks_per_cu  > 0: at most this many resident workgroups per CU; 0 = what the kernel admits
+ * The defaults of a new context can be preset through the environment, read once in hhv_create: HHV_PAIR (0 / 1),
+ * HHV_PAIR_SWAP, HHV_BLOCKS_PER_CU. */
+int hhv_set_launch_policy(hhv_ctx* ctx, int32_t pair_mode, int32_t pair_swap, int32_t blocks_per_cu);
 
 /* query: p[(Lq+1)*20], tr[(Lq+1)*7] (copied before the call returns: the caller may reuse its arrays at once).
  * The rows travel through a pinned staging block with asynchronous copies on the context's stream; device buffers and

@@ -180,3 +180,39 @@ def test_advice_r2_celloff_without_mask_after_backtrace_and_foreign_set_ids():
     c.rawset_free(raw)
     ts.free()
     c.close()
+
+
+def test_pair_flow_control_timeout_is_an_error_not_a_result():
+    """VERDICT r4 #3 / ADVICE r4: a wave of a two-wave workgroup whose bounded wait for its partner runs out must not pass for
+    a result.  libhhviterbi_hip_pto.so (make lib_pto) = the product objects with the pair kernels compiled with
+    -DHHV_EXP_PAIR_TIMEOUT: the first wave never reports progress, the second wave's wait times out after a short bound,
+    sets DEV_ERR_PAIR_TIMEOUT in the context's error word and ends its stream.  Every call that waits for the stream then
+    answers HHV_E_DEVICE with text; the word is cleared and the context keeps working (a query of one strip afterwards is right)."""
+    import os
+    from pyhhv import capi
+    from pyoracle import Oracle, make_params
+    path = os.path.join(os.path.dirname(capi.LIB_PATH), "libhhviterbi_hip_pto.so")
+    if not os.path.exists(path):
+        pytest.skip("libhhviterbi_hip_pto.so not built (make lib_pto)")
+    c = capi.Context(local=0, lib_path=path)
+    qp, qtr = synth.make_query(3, 512)   # two strips of four rows per lane: one pair launch
+    tps, ttrs = zip(*[synth.make_template(50 + k, 150 + k) for k in range(200)])
+    tps, ttrs = list(tps), list(ttrs)
+    ts = c.upload(tps, ttrs)
+    c.set_query(qp, qtr)
+    c.set_launch_policy(pair_mode=1)
+    with pytest.raises(capi.HhvError, match="waited in vain"):
+        c.align(ts)
+    c.align_async(ts)
+    with pytest.raises(capi.HhvError, match="device-side failure"):
+        c.sync()
+    c.sync()                                       # the word was cleared by the report
+    c.set_launch_policy(pair_mode=0)               # one launch per strip: no pair kernel, right results from the same context
+    res = c.align(ts)
+    o = Oracle()
+    par = make_params(local=0)
+    for e in (0, 77, 199):
+        a = o.align(par, qp, qtr, tps[e], ttrs[e], want_bt=False)
+        assert (a.i2, a.j2) == (int(res["i2"][e]), int(res["j2"][e])) and np.float32(a.score) == res["score"][e]
+    ts.free()
+    c.close()

@@ -1,10 +1,8 @@
 """Queries of two strips (321 .. 640 rows) in ONE launch of two-wave workgroups (hhv_stream_kernel.h PairLds, hhv_pair_kernel):
 the first strip's bottom row reaches the second through an LDS FIFO, the second wave follows the first wave's segment draws.
-Against the oracle on samples, and bit for bit against the two-launch path (HHV_PAIR=0) on sets large enough that every
+Against the oracle on samples, and bit for bit against the two-launch path (hhv_set_launch_policy pair_mode 0) on sets large enough that every
 resident workgroup walks many segments (thousands of templates, 1-3-column templates back to back, streams shorter than the
 pipeline's lag, more workgroups than segments)."""
-import os
-
 import numpy as np
 import pytest
 
@@ -14,15 +12,15 @@ from pyoracle import make_params
 pytestmark = pytest.mark.gpu
 
 
-def both_ways(fn):
-    """fn() with the pair kernels and with two launches"""
+def both_ways(c, fn):
+    """fn() with the pair kernels and with one launch per strip (hhv_set_launch_policy of context c)"""
     out = []
-    for v in ("1", "0"):
-        os.environ["HHV_PAIR"] = v
+    for v in (1, 0):
+        c.set_launch_policy(pair_mode=v)
         try:
             out.append(fn())
         finally:
-            os.environ.pop("HHV_PAIR", None)
+            c.set_launch_policy(pair_mode=-1)
     return out
 
 
@@ -46,7 +44,7 @@ def test_pair_equals_oracle_and_two_launches(oracle, Lq, local):
         mats = [c.backtrace_matrix(ts, e) for e in (0, 5, 11)]
         return so, res, hits, mats
 
-    (so1, res1, hits1, mats1), (so0, res0, hits0, mats0) = both_ways(run)
+    (so1, res1, hits1, mats1), (so0, res0, hits0, mats0) = both_ways(c, run)
     for e in range(n):  # (first against the oracle, template by template: a failure names the template and the path)
         a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_bt=False)
         for tag, r in (("two launches", so0), ("pair", so1), ("two launches bt", res0), ("pair bt", res1)):
@@ -90,7 +88,7 @@ def test_pair_on_large_sets_equals_two_launches(Lq, local):
             hits = c.hits(ts).copy()
             return so, res, hits
 
-        (so1, res1, hits1), (so0, res0, hits0) = both_ways(run)
+        (so1, res1, hits1), (so0, res0, hits0) = both_ways(c, run)
         assert so1.tobytes() == so0.tobytes(), (Lq, n)
         assert res1.tobytes() == res0.tobytes(), (Lq, n)
         assert hits1.tobytes() == hits0.tobytes(), (Lq, n)

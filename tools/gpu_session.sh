@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 stage=$1; shift
-short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload --no-fast-mode"
+short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload --no-fast-mode --no-rows"
 line() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); print('%.3e cells/s, %.2f ms/step, kernel %.2f ms (min %.2f)' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['kernel_ms_min']))"; }
 case $stage in
 check)
@@ -47,156 +47,44 @@ next)
   HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_next.py ${1:-r3} | tail -30
   rm -rf $OUT/prof_next
   ;;
-r4s)   # chains of pair launches for queries of more than two strips: parity, then HHV_PAIR=0 (one launch per strip) against the default
-  timeout 500 python -m pytest tests/test_gpu_pair.py tests/test_gpu_lengths.py tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -6
-  for cfg in "--lq 700 --templates 30000" "--lq 1000 --lt 500 --templates 20000" "--lq 1280 --lt 500 --templates 16000" "--lq 2000 --lt 500 --templates 10000" "--lq 1000 --lt 500 --templates 20000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000 --local 1"; do
-    for pv in 0 x 0 x; do
-      echo -n "HHV_PAIR=$pv $cfg : "
-      if [ $pv = x ]; then timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line; else HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line; fi
-    done
-  done
-  ;;
-r4r)   # hipcc scheduling strategy max-ilp (lib "ilp") against the default build
-  for cfg in "" "--backtrace 1" "--local 1" "--lq 150 --templates 100000" "--lq 512 --templates 50000" "--lengths zipf --local 1 --templates 125000"; do
-    for lib in hip ${VARIANT:-ilp} hip ${VARIANT:-ilp}; do
-      echo -n "$lib $cfg : "
-      HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_$lib.so timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
-    done
-  done
-  ;;
-r4q)   # the multi-strip configurations on the default build
-  for cfg in "--lq 512 --templates 50000" "--lq 640 --templates 50000" "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 2000 --lt 500 --templates 10000"; do
-    echo -n "$cfg : "
-    timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
-  done
-  ;;
-r4p)   # multi-strip step loops unrolled by two like the single-strip ones (-DHHV_EXP_MULTI_UNROLL, lib "mu"): A/B, then parity on mu
-  for cfg in "--lq 512 --templates 50000" "--lq 640 --templates 50000" "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 1000 --lt 500 --templates 20000" "--lq 512 --templates 50000 --backtrace 1"; do
-    for lib in hip mu hip mu; do
-      echo -n "$lib $cfg : "
-      HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_$lib.so timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
-    done
-  done
-  HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_mu.so timeout 600 python -m pytest tests/test_gpu_pair.py tests/test_gpu_parity.py tests/test_gpu_lengths.py -q -m gpu -x 2>&1 | tail -4
-  ;;
-r4j)   # timing-only builds (WRONG results): pair kernels without waits (pns), without waits and FIFO traffic (pnf), multi-pass bodies without carry traffic (mnc)
-  for cfg in "--lq 512 --templates 50000" "--lq 431 --templates 50000"; do
-    for lib in hip pns pnf mnc; do for pv in 1 0; do
-      [ $pv = 0 ] && [ $lib != mnc ] && [ $lib != hip ] && continue
-      echo -n "$lib HHV_PAIR=$pv $cfg : "
-      HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_$lib.so HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
-    done; done
-  done
-  ;;
-r4i)   # where the multi-pass penalty sits: per-launch durations of the two passes (kernel trace), single pass at the same set size
-  for cfg in "--lq 256 --templates 50000" "--lq 320 --templates 50000"; do echo -n "$cfg : "; timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line; done
-  for pv in 0 1; do for lq in 512 640; do
-    echo "== HHV_PAIR=$pv --lq $lq --templates 50000: every dispatch of the stream / pair kernels (us)"
-    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_kt && HHV_PAIR=$pv timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_kt -o kt -- python $ROOT/bench.py --lq $lq --templates 50000 --steps 4 --warmup 1 $short > /tmp/prof_kt.log 2>&1)
-    python - <<'PY'
-import csv, glob
-for f in glob.glob("/tmp/prof_kt/**/*kernel_trace.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "hhv_stream_kernel" in r["Kernel_Name"] or "hhv_pair_kernel" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    print("  ".join("%s:%.0f" % (r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "")[:18], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows[-8:]))
+rows)   # rows [libname]: the side entries of bench.py (tools/bench_rows.py: ss_modes, multi_strip, masked_round) on the resident headline set
+  HHV_LIB=$ROOT/hh-suite_amd/lib/libhhviterbi_${1:-hip}.so timeout 900 python - > $OUT/rows_${1:-hip}.json 2> $OUT/rows_${1:-hip}.err <<'PY'
+import json, os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+sys.path.insert(0, os.path.join(ROOT, "hh-suite_amd")); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+from pyhhv import capi, synth, synth_stream
+import bench_rows
+dev = torch.device("cuda", 0)
+n, Lq, Lt, K = 100000, 300, 300, 500
+qf, qtr = synth_stream.query_np(Lq, synth.PB)
+rec, rec_off, Ls = synth_stream.gen_stream(torch, dev, np.arange(n), np.full(n, Lt), synth.PB)
+torch.cuda.synchronize()
+out = {"ss_modes": bench_rows.ss_modes(torch, capi, 0, rec, rec_off, Ls, qf, qtr, K),
+       "multi_strip": bench_rows.multi_strip(torch, capi, 0, rec, rec_off, Ls, K),
+       "masked_round": bench_rows.masked_round(torch, capi, 0, rec, rec_off, Ls, qf, qtr, K)}
+print(json.dumps(out))
 PY
-  done; done
-  ;;
-r4h)   # what a step costs at R rows per lane, single pass against multi pass (is the multi-pass penalty VALU or latency?)
-  for cfg in "--lq 320 --templates 100000" "--lq 256 --templates 100000" "--lq 192 --templates 100000" "--lq 640 --templates 50000" "--lq 512 --templates 50000" "--lq 384 --templates 50000"; do for pv in 0 1; do
-    echo -n "HHV_PAIR=$pv $cfg : "
-    HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
-  done; done
-  ;;
-r4g)   # two-strip queries as ONE launch of two-wave workgroups (hhv_pair_kernel): parity, then HHV_PAIR=0 / 1 on the bench configurations
-  timeout 900 python -m pytest tests/test_gpu_pair.py -q -m gpu -x 2>&1 | tail -12
-  for rep in 1 2; do for cfg in "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000" "--lq 640 --templates 40000" "--lq 350 --templates 50000 --backtrace 1" "--lq 431 --templates 100000 --lengths zipf --local 1"; do for pv in 0 1; do
-    echo -n "HHV_PAIR=$pv $cfg : "
-    HHV_PAIR=$pv timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
-  done; done; done
-  ;;
-r4f)   # carry rows of the multi-pass variants in blocks (lanes 0..31 load a chunk of rows ahead, lane 0 takes its row by v_readlane): parity + A/B
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_lengths.py tests/test_gpu_queue.py -q -m gpu 2>&1 | tail -5
-  HHV_AB_LIBS="nocb hip" HHV_AB_REPS=2 HHV_AB_CFGS="--lq 431 --templates 50000|--lq 431 --templates 50000 --backtrace 1|--lq 700 --templates 30000|--lq 1000 --lt 500 --templates 20000|--lq 2000 --lt 300 --templates 10000 --local 1" bash tools/gpu_ab.sh
-  ;;
-r4e)   # trace kernel specialised on (R, encoding): parity + kernel trace; then the round's profiles (r4, r4bt)
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_configs.py tests/test_gpu_queue.py tests/test_gpu_ss.py tests/test_gpu_lengths.py -q -m gpu 2>&1 | tail -5
-  for n in 100000 10000; do
-    echo "== backtrace searches over $n templates"
-    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bt && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bt -o stats -- python $ROOT/bench.py --lq 300 --templates $n --backtrace 1 --steps 5 --warmup 2 $short > /tmp/prof_bt.log 2>&1)
-    python - <<'PY'
-import csv, glob
-for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"]:
-            print("%-60s calls %5s  avg %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+  tail -3 $OUT/rows_${1:-hip}.err
+  python - <<PY
+import json
+d = json.load(open("$OUT/rows_${1:-hip}.json"))
+def walk(p, v):
+    if isinstance(v, dict):
+        if "cells_per_s" in v:
+            print("%-70s %.3e cells/s  step %.2f ms  DP %.2f ms" % (p, v["cells_per_s"], v["ms_per_step"], v["dp_kernel_ms"]))
+        for k, x in v.items():
+            if k == "gpu_matches_cpu_on_sample" or k == "error" or k == "results_identical":
+                print("%-70s %s" % (p + "." + k, x))
+            elif isinstance(x, dict):
+                walk(p + "." + k, x)
+walk("", d)
+print("masked_round", {k: v for k, v in d["masked_round"].items() if not isinstance(v, dict)})
 PY
-  done
-  for tag in r4 r4bt; do
-    extra=""; [ $tag = r4bt ] && extra="--backtrace 1"
-    bash tools/profile.sh $tag "$extra" > $OUT/profile_$tag.log 2>&1
-    HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_profile.py $tag | tail -34
-    rm -rf $OUT/prof_$tag
-  done
   ;;
-r4d)   # trace speculation on / off at 10 k and 100 k, scorr in registers, top-K select with early exit: parity + kernel trace
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_merge.py tests/test_gpu_configs.py tests/test_gpu_queue.py tests/test_gpu_ss.py tests/test_gpu_runner.py tests/test_gpu_fullsize.py -q -m gpu 2>&1 | tail -8
-  for spec in 0 1; do for n in 100000 10000; do
-    echo "== HHV_TRACE_SPECULATE=$spec, backtrace searches over $n templates"
-    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bt && HHV_TRACE_SPECULATE=$spec timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bt -o stats -- python $ROOT/bench.py --lq 300 --templates $n --backtrace 1 --steps 5 --warmup 2 $short > /tmp/prof_bt.log 2>&1)
-    python - <<'PY'
-import csv, glob
-for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"]:
-            print("%-60s calls %5s  avg %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
-PY
-  done; done
-  ;;
-r4c)   # scorr kernel with pipelined tile loads, pcm 3 on the device, the default bench line with the 8(d) generator
-  timeout 600 python -m pytest tests/test_prepare.py tests/test_gpu_errors.py tests/test_gpu_parity.py tests/test_gpu_configs.py -q -m gpu 2>&1 | tail -8
-  timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 7000 $OUT/bench_default.json; tail -3 $OUT/bench_default.err
-  for n in 100000 10000; do
-    echo "== kernel trace of backtrace searches over $n templates"
-    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bt && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bt -o stats -- python $ROOT/bench.py --lq 300 --templates $n --backtrace 1 --steps 5 --warmup 2 $short > /tmp/prof_bt.log 2>&1; grep -c . /tmp/prof_bt.log > /dev/null)
-    python - <<'PY'
-import csv, glob
-for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"]:
-            print("%-60s calls %5s  avg %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
-PY
-  done
-  ;;
-r4b)   # the tests behind the one that stopped r4a + the kernel trace of the backtrace step
-  timeout 1200 python -m pytest tests/test_gpu_lengths.py tests/test_gpu_merge.py tests/test_gpu_parity.py tests/test_gpu_queue.py tests/test_gpu_rccl_example.py tests/test_gpu_runner.py tests/test_gpu_ss.py tests/test_layout.py tests/test_mac.py tests/test_pipeline.py tests/test_prefilter.py tests/test_prepare.py tests/test_real_profile.py tests/test_gpu_errors.py -q -m gpu 2>&1 | tail -25
-  for n in 100000 10000; do
-    echo "== kernel trace of backtrace searches over $n templates"
-    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bt && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bt -o stats -- python $ROOT/bench.py --lq 300 --templates $n --backtrace 1 --steps 5 --warmup 2 $short > /tmp/prof_bt.log 2>&1; tail -2 /tmp/prof_bt.log)
-    python - <<'PY'
-import csv, glob
-for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"]:
-            print("%-60s calls %5s  avg %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
-PY
-  done
-  ;;
-r4a)   # round 4, first kernel session: the whole GPU suite on the new tests / top-K / trace chain, the NaN probe, A/B base - nosign - hip
-  timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > $OUT/gpu_suite.log; cat $OUT/gpu_suite.log
-  ./build/nan_probe
-  HHV_AB_LIBS="base nosign hip" HHV_AB_REPS=2 HHV_AB_CFGS="--lq 300 --templates 100000 --backtrace 1|--lq 300 --templates 10000 --backtrace 1|--lq 300 --templates 100000" bash tools/gpu_ab.sh
-  echo "== kernel trace of one backtrace search over 100 k templates"
-  cd /tmp && export TMPDIR=/tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bt -o stats -- python $ROOT/bench.py --lq 300 --templates 100000 --backtrace 1 --steps 5 --warmup 2 $short > /dev/null 2>&1
-  python - <<'PY'
-import csv, glob
-for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
-    rows = list(csv.DictReader(open(f)))
-    for r in rows:
-        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"]:
-            print("%-60s calls %5s  avg %10.1f us  total %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3))
-PY
+r5a)   # round 5, first session: the device error word and the launch policy (tests), then the baseline of the new bench rows on HEAD~ kernels
+  timeout 600 python -m pytest tests/test_gpu_errors.py tests/test_gpu_pair.py -q -m gpu -x 2>&1 | tail -5
+  bash tools/gpu_session.sh rows hip
   ;;
 *) echo "unknown stage $stage"; exit 2;;
 esac
