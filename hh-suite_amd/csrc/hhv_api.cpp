@@ -265,6 +265,8 @@ void hhv_destroy(hhv_ctx* c) {
   if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
   if (c->mac_pinned_out) (void)hipHostFree(c->mac_pinned_out);
   if (c->q_stage) (void)hipHostFree(c->q_stage);
+  if (c->ss_stage) (void)hipHostFree(c->ss_stage);
+  if (c->ev_ss) (void)hipEventDestroy(c->ev_ss);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->ev_q) (void)hipEventDestroy(c->ev_q);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -374,19 +376,44 @@ int hhv_set_ss_mode(hhv_ctx* c, int32_t mode) {
 //   PRED_DSSP: S37[q_pred][q_conf][t_dssp]          row (q_pred*11+q_conf)*8,   column dssp_index   (:203-204)
 static int ensure_ss(hhv_ctx* c) {
   if (!c->ss_dirty) return HHV_OK;
-  dfree(c->d_ss_table);
-  dfree(c->d_ss_q_off);
-  // ss_dirty is cleared only once the operands are on the device: after a failure the next call tries again instead of
-  // launching the SS kernels with null tables
+  // ss_dirty is cleared only once the operands are on their way to the device: after a failure the next call tries again
+  // instead of launching the SS kernels with stale tables
   if (c->ss_hmm_mode == 0 || c->Lq < 1) {
     c->ss_dirty = false;
     return HHV_OK;
   }
+  // A search loop sets a query - and with it the query's secondary structure - per search: like hhv_set_query this neither
+  // frees device memory nor waits for the stream.  Table and offsets go through one pinned staging block with asynchronous
+  // copies on the context's stream; the device buffers are kept (the table has a fixed capacity, the offsets grow with Lq).
   const std::vector<float>& T = c->ss_hmm_mode == 4 ? c->S33 : (c->ss_hmm_mode == 2 ? c->S73 : c->S37);
-  std::vector<float> tab(T.size());
-  for (size_t k = 0; k < T.size(); ++k) tab[k] = c->par.ssw * T[k];
   const size_t rows = (size_t)c->plan.rows();
-  std::vector<int32_t> off(rows, 0);
+  constexpr size_t TAB_MAX = 4 * 11 * 4 * 11;
+  if (T.size() > TAB_MAX) return fail(HHV_E_ARG, "secondary-structure table of %zu entries", T.size());
+  const size_t stage_bytes = TAB_MAX * sizeof(float) + rows * sizeof(int32_t);
+  if (c->ss_stage_busy) {
+    HIP_TRY(hipEventSynchronize(c->ev_ss));
+    c->ss_stage_busy = false;
+  }
+  if (c->ss_stage_bytes < stage_bytes) {
+    if (c->ss_stage) (void)hipHostFree(c->ss_stage);
+    c->ss_stage = nullptr;
+    c->ss_stage_bytes = 0;
+    HIP_TRY(hipHostMalloc(&c->ss_stage, stage_bytes, hipHostMallocDefault));
+    c->ss_stage_bytes = stage_bytes;
+  }
+  if (!c->ev_ss) HIP_TRY(hipEventCreateWithFlags(&c->ev_ss, hipEventDisableTiming));
+  if (!c->d_ss_table) HIP_TRY(hipMalloc(&c->d_ss_table, TAB_MAX * sizeof(float)));
+  if (c->ss_q_cap < rows) {
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (a launch that still reads the old offsets)
+    dfree(c->d_ss_q_off);
+    c->ss_q_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_ss_q_off, rows * sizeof(int32_t)));
+    c->ss_q_cap = rows;
+  }
+  float* const tab = (float*)c->ss_stage;
+  int32_t* const off = (int32_t*)(tab + TAB_MAX);
+  for (size_t k = 0; k < T.size(); ++k) tab[k] = c->par.ssw * T[k];
+  memset(off, 0, rows * sizeof(int32_t));
   for (int i = 1; i <= c->Lq; ++i) {
     const int pred = c->q_pred.empty() ? 0 : (unsigned char)c->q_pred[i], conf = c->q_conf.empty() ? 0 : c->q_conf[i];
     const int dssp = c->q_dssp.empty() ? 0 : (unsigned char)c->q_dssp[i];
@@ -400,10 +427,11 @@ static int ensure_ss(hhv_ctx* c) {
   }
   c->ss_t_shift = c->ss_hmm_mode == 1 ? META_DSSP_SHIFT : META_PRED_SHIFT;
   c->ss_t_mask = c->ss_hmm_mode == 1 ? META_DSSP_MASK : META_PRED_MASK;
-  HIP_TRY(hipMalloc(&c->d_ss_table, tab.size() * sizeof(float)));
-  HIP_TRY(hipMalloc(&c->d_ss_q_off, off.size() * sizeof(int32_t)));
-  HIP_TRY(hipMemcpy(c->d_ss_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->d_ss_q_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->ss_tab_n = (int)T.size();
+  HIP_TRY(hipMemcpyAsync(c->d_ss_table, tab, T.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_ss_q_off, off, rows * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_ss, c->stream));
+  c->ss_stage_busy = true;
   c->ss_dirty = false;
   return HHV_OK;
 }
@@ -616,6 +644,7 @@ void hhv_tset_free(hhv_tset* ts) {
   dfree(ts->d_j_steps);
   dfree(ts->d_states);
   dfree(ts->d_S);
+  dfree(ts->d_Sss);
   dfree(ts->d_hits);
   dfree(ts->d_topk);
   dfree(ts->d_keys);
@@ -712,7 +741,8 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   }
   if (c->blocks_per_cu >= 1) blocks_per_cu = std::min(blocks_per_cu, c->blocks_per_cu);  // measurement aid (hhv_set_launch_policy)
   const int n_ranges = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * blocks_per_cu * arrays, ts->n));
-  int n_waves = (n_ranges + arrays - 1) / arrays;
+  const int wpw = stream_kernel_waves(plan.W, ss);  // whole workgroups: hhv_ss_kernel has eight wavefronts (an array beyond the last range / segment returns at once)
+  int n_waves = ((n_ranges + arrays - 1) / arrays + wpw - 1) / wpw * wpw;
   rc = ensure_partition(c, ts, n_ranges, n_waves * arrays);
   if (rc != HHV_OK) return rc;
   // the systolic arrays draw stream segments from a queue (hhv_stream_kernel.h DQ); the fixed ranges above serve the -DHHV_NO_QUEUE build
@@ -726,6 +756,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     if (rc != HHV_OK) return rc;
     n_waves = (std::max(1, std::min(c->num_cus * blocks_per_cu * arrays, ts->n_seg)) + arrays - 1) / arrays;
   }
+  n_waves = (n_waves + wpw - 1) / wpw * wpw;
   if (bt) {
     rc = ensure_bt(c, ts);
     if (rc != HHV_OK) return rc;
@@ -755,6 +786,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.ss_q_off = ss ? c->d_ss_q_off : nullptr;
   a.ss_t_shift = c->ss_t_shift;
   a.ss_t_mask = c->ss_t_mask;
+  a.ss_tab_n = c->ss_tab_n;
   a.seg_first = queue ? ts->d_seg : nullptr;
   a.n_seg = queue ? ts->n_seg : 0;
   a.queue = c->d_queue;
@@ -976,6 +1008,7 @@ static int ensure_paths(hhv_ctx* c, hhv_tset* ts) {
   dfree(ts->d_j_steps);
   dfree(ts->d_states);
   dfree(ts->d_S);
+  dfree(ts->d_Sss);
   dfree(ts->d_hits);
   ts->path_off.resize((size_t)ts->n + 1);
   int64_t off = 0;
@@ -1030,6 +1063,11 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.ss_q_off = c->ss_hmm_mode ? c->d_ss_q_off : nullptr;
   a.ss_t_shift = c->ss_t_shift;
   a.ss_t_mask = c->ss_t_mask;
+  a.Sss = nullptr;
+  if (c->ss_hmm_mode) {  // the per-step secondary-structure scores: a second pool like S, allocated with the first search that has them
+    if (!ts->d_Sss) HIP_TRY(hipMalloc(&ts->d_Sss, ((size_t)ts->path_off[ts->n] + 64) * sizeof(float)));
+    a.Sss = ts->d_Sss;
+  }
   a.err = c->d_err;
   rc = launch_trace(a, c->stream);
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));

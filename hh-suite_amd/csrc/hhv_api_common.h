@@ -86,8 +86,14 @@ struct hhv_ctx {
   size_t mac_pinned_out_bytes = 0;
   void* mac_cache = nullptr;                           // one recycled device block of the MAC realignment
   size_t mac_cache_bytes = 0;
-  float* d_ss_table = nullptr;                         // ssw * table of the current mode
-  int32_t* d_ss_q_off = nullptr;                       // [plan.rows()]
+  float* d_ss_table = nullptr;                         // ssw * table of the current mode (SS_TABLE_MAX floats, allocated once)
+  int32_t* d_ss_q_off = nullptr;                       // [plan.rows()], kept between queries (ss_q_cap entries)
+  size_t ss_q_cap = 0;
+  void* ss_stage = nullptr;                            // pinned staging block of ensure_ss: table + offsets travel with asynchronous copies
+  size_t ss_stage_bytes = 0;
+  hipEvent_t ev_ss = nullptr;                          // the last staging block has left the host
+  bool ss_stage_busy = false;
+  int ss_tab_n = 0;                                    // floats of the current table
   int ss_t_shift = 0, ss_t_mask = 0;
   void* d_merge = nullptr;                             // hhv_merge_hits: merge_cap records + one int
   int merge_cap = 0;
@@ -137,6 +143,7 @@ struct hhv_tset {
   int32_t* d_j_steps = nullptr;
   int8_t* d_states = nullptr;
   float* d_S = nullptr;
+  float* d_Sss = nullptr;  // per-step secondary-structure scores (searches with secondary-structure information only)
   hhv::DevHit* d_hits = nullptr;
   bool hits_valid = false;
   // host copy of the whole path pool, fetched with five copies on the first hhv_hit_path after a trace (asking for

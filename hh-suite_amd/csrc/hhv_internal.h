@@ -109,6 +109,7 @@ struct StreamArgs {
   const float* ss_table;     // ssw * S33 / S73 / S37, premultiplied on the host (same fp32 product as the reference)
   const int32_t* ss_q_off;   // [P*64*R] table row offset of query row i at index i-1
   int32_t ss_t_shift, ss_t_mask;
+  int32_t ss_tab_n;          // floats of the table (1936 / 352): what hhv_ss_kernel copies into LDS
   // work queue of the 64-lane variants (hhv_stream_kernel.h DQ); unused by the short-query arrays (fixed ranges, wave_rec)
   const int64_t* seg_first;  // [n_seg + 1][2] records [first, end) of segment k in the order they are drawn: whole templates,
                              // >= 128 records, longest first; entry n_seg = the terminal header
@@ -136,6 +137,7 @@ struct TraceArgs {
   int32_t* j_steps;
   int8_t* states;
   float* S;
+  float* Sss;                // per-step secondary-structure scores (same pools as S), null without secondary-structure information
   const int64_t* path_off;   // [n+1]
   float corr;
   int32_t ss_mode;
@@ -316,6 +318,7 @@ int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream
 // W = lanes per systolic array (64, 32, 16): W < 64 variants exist for single-pass queries only (multi = false)
 int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
 int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);
+int stream_kernel_waves(int W, bool ss);  // wavefronts per workgroup of the kernel launch_stream starts (8 for hhv_ss_kernel)
 // per-W instantiation units (hhv_kernels.hip: 64, hhv_kernels_w32.hip, hhv_kernels_w16.hip)
 void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip);
 // two-strip queries as one launch of two-wave workgroups (hhv_kernels_pair.hip)

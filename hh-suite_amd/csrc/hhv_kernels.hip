@@ -249,6 +249,16 @@ __global__ void __launch_bounds__(64) hhv_rescore_kernel(TraceArgs a) {
         v = fast_log2_dev(dot20_scalar_dev(q, t), a.lg2, a.diff);
       }
       S[s] = v;
+      if (a.Sss) {
+        // S_ss[step] = ScoreSS(q, t, i, j) for the match steps, 0 elsewhere (:225-235); the column index sits in the meta word of
+        // the record the profile came from; summed in step order by hhv_scorr_kernel
+        float vs = 0.0f;
+        if (st == 2 && i >= 1 && j >= 1) {
+          const int32_t meta = __builtin_bit_cast(int32_t, a.records[(size_t)(rec0 + j) * REC_DW + REC_META]);
+          vs = a.ss_table[a.ss_q_off[i - 1] + ((meta >> a.ss_t_shift) & a.ss_t_mask)];
+        }
+        a.Sss[po + s] = vs;
+      }
     }
   }
 }
@@ -291,15 +301,19 @@ __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
   // a lane never reads beyond the tile that holds its own last step (the pool is followed by the next template's, the last
   // pool by 64 entries of slack: ensure_paths); what lies behind its last step is masked out of the sums
   const float4* const row = reinterpret_cast<const float4*>(a.S + po);  // (pools start on multiples of four entries)
+  // secondary structure: one more pass over the tiles, of the S_ss row hhv_rescore_kernel wrote - score_ss = the sum of its
+  // entries in step order (:225-235: the reference adds the match steps' values as it meets them; the zeros in between change nothing)
+  const float4* const row_ss = a.Sss ? reinterpret_cast<const float4*>(a.Sss + po) : row;
   const int last_tile = ns / SCORR_TILE;
   float4 v[2][SCORR_TILE / 4];
   auto fetch = [&](const int seq, float4 (&dst)[SCORR_TILE / 4]) __attribute__((always_inline)) {
-    const float4* p = row + (size_t)min(seq % n_tiles, last_tile) * (SCORR_TILE / 4);
+    const float4* p = (seq >= 4 * n_tiles ? row_ss : row) + (size_t)min(seq % n_tiles, last_tile) * (SCORR_TILE / 4);
 #pragma unroll
     for (int x = 0; x < SCORR_TILE / 4; ++x) dst[x] = p[x];
   };
   ScorrState z = {0.f, 0.f, 0.f, 0.f, 0.f};
-  const int total = 4 * n_tiles;  // tile sequence: d = 1 tiles 0 .. n_tiles-1, d = 2 the same tiles again, ...
+  float score_ss = 0.0f;
+  const int total = (a.Sss ? 5 : 4) * n_tiles;  // tile sequence: d = 1 tiles 0 .. n_tiles-1, d = 2 the same tiles again, ... [, the S_ss tiles]
   auto sum_tile = [&](const int seq, const float4 (&t)[SCORR_TILE / 4]) __attribute__((always_inline)) {
     const int d = 1 + seq / n_tiles, tile_no = seq % n_tiles;
     const int lo = tile_no == 0 ? d + 1 : 0;             // the loop of lag d starts at step d + 1 (:241-249)
@@ -308,7 +322,16 @@ __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
       case 1: scorr_tile<1>(z, t, lo, lim); break;
       case 2: scorr_tile<2>(z, t, lo, lim); break;
       case 3: scorr_tile<3>(z, t, lo, lim); break;
-      default: scorr_tile<4>(z, t, lo, lim); break;
+      case 4: scorr_tile<4>(z, t, lo, lim); break;
+      default: {  // S_ss: steps 1 .. ns
+        const int lo1 = tile_no == 0 ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < SCORR_TILE; ++u) {
+          const float4 q = t[u >> 2];
+          const float cur = (u & 3) == 0 ? q.x : (u & 3) == 1 ? q.y : (u & 3) == 2 ? q.z : q.w;
+          score_ss = (u >= lo1 && u <= lim) ? score_ss + cur : score_ss;
+        }
+      }
     }
   };
   fetch(0, v[0]);
@@ -322,18 +345,7 @@ __global__ void __launch_bounds__(64) hhv_scorr_kernel(TraceArgs a) {
   const float Scorr = z.acc;
   if (!valid) return;
   float score = a.hits[k].viterbi_score;
-  // :225-238: score_ss = sum over MM steps of ScoreSS(q,t,i,j) in step order; subtracted when ssm == 2
-  float score_ss = 0.0f;
-  if (a.ss_table) {
-    const int64_t rec0 = a.rec_off[k];
-    for (int s = 1; s <= ns; ++s) {
-      const int i = a.i_steps[po + s], j = a.j_steps[po + s];
-      if (a.states[po + s] == 2 && i >= 1 && j >= 1) {
-        const int32_t meta = __builtin_bit_cast(int32_t, a.records[(size_t)(rec0 + j) * REC_DW + REC_META]);
-        score_ss += a.ss_table[a.ss_q_off[i - 1] + ((meta >> a.ss_t_shift) & a.ss_t_mask)];
-      }
-    }
-  }
+  // :225-238: score_ss = sum over MM steps of ScoreSS(q,t,i,j) in step order (summed above); subtracted when ssm == 2
   if (a.ss_mode == 2) score -= score_ss;
   score += a.corr * Scorr;
   a.hits[k].score_ss = score_ss;
@@ -362,21 +374,28 @@ int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, b
   if (!fn) return -1;
   StreamArgs args = a;
   void* kargs[] = {&args};
-  hipError_t e = hipLaunchKernel(fn, dim3(n_waves), dim3(LANES), kargs, 0, (hipStream_t)stream);
+  // (the 64-lane secondary-structure variants are workgroups of SS_WAVES wavefronts sharing one LDS table: hhv_ss_kernel)
+  const bool wide = ss && W == LANES;
+  hipError_t e = hipLaunchKernel(fn, dim3(wide ? (n_waves + SS_WAVES - 1) / SS_WAVES : n_waves), dim3(wide ? SS_WAVES * LANES : LANES), kargs, 0,
+                                 (hipStream_t)stream);
   return e == hipSuccess ? 0 : -(int)e;
 }
+
+// wavefronts per workgroup of the kernel launch_stream starts: the caller rounds its wave count up to a multiple
+int stream_kernel_waves(int W, bool ss) { return ss && W == LANES ? SS_WAVES : 1; }
 
 int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu,
                             int* vgprs) {
   void* fn = pick(W, R, local, bt, celloff, multi, ss);
   if (!fn) return -1;
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, LANES, 0);
+  const int wpw = stream_kernel_waves(W, ss);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, wpw * LANES, 0);
   if (e != hipSuccess) return -(int)e;
   hipFuncAttributes fa;
   e = hipFuncGetAttributes(&fa, fn);
   if (e != hipSuccess) return -(int)e;
-  if (blocks_per_cu) *blocks_per_cu = nb;
+  if (blocks_per_cu) *blocks_per_cu = nb * wpw;  // resident WAVEFRONTS (= one-wave workgroups for every kernel but hhv_ss_kernel)
   if (vgprs) *vgprs = fa.numRegs;
   return 0;
 }

@@ -8,6 +8,11 @@
 #include "hhv_internal.h"
 #include "viterbi_lane.h"
 
+// which secondary-structure variants fetch the head of the next step early (PF below): all that have the registers for it
+#ifndef HHV_SS_PF
+#define HHV_SS_PF(R, LOCAL, BT, MULTI) (!((R) == 5 && (LOCAL)))  // (local mode, five rows: the per-row best leaves no room)
+#endif
+
 namespace hhv {
 
 #if defined(HHV_EXP_TIMING)
@@ -382,17 +387,22 @@ struct LdsColumn {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t) : "v"(rec_addr));
     return t;
   }
-  // 64-lane variants: the finalized best of the template travels lane to lane through LDS memory (8 bytes per lane: a lane
-  // writes its slot at the end of its header step, its neighbour reads it one step later, in the same round trip as the
-  // template index) - no cross-lane operation and no wait outside the header path
-  __device__ __forceinline__ int32_t header_tid_best(uint32_t prev_slot) {
-    int32_t t;
-    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %4 offset:4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(t), "=&v"(hfs), "=&v"(hfpos) : "v"(rec_addr), "v"(prev_slot));
-    return t;
+  // 64-lane variants: the finalized best of the template travels lane to lane through LDS memory - through the HEADER RECORD
+  // itself (round 5; until then 8 bytes per lane behind the ring): dwords 2 and 3 of a header record are unused by the stream
+  // format, every lane works on the record one step after its neighbour, so a lane leaves (fs, fpos) there at the end of its
+  // header step and the next lane finds them next to the template index - ONE ds_read_b128 {index, L, fs, fpos} instead of three
+  // reads, no cross-lane operation, no wait outside the header path, and no LDS of its own (which is what lets eight
+  // wavefronts with LDS-parked query rows share a CU with the secondary-structure table: hhv_ss_kernel below).
+  __device__ __forceinline__ int32_t header_tid_best() {
+    v4f h;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(h) : "v"(rec_addr));
+    const float t = h.x, p = h.w;
+    hfs = h.z;
+    hfpos = __builtin_bit_cast(int32_t, p);
+    return __builtin_bit_cast(int32_t, t);
   }
-  static __device__ __forceinline__ void publish_best(uint32_t own_slot, float fs, int fpos) {
-    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4" ::"v"(own_slot), "v"(fs), "v"(fpos) : "memory");
+  __device__ __forceinline__ void publish_best(float fs, int fpos) const {
+    asm volatile("ds_write_b32 %0, %1 offset:8\n\tds_write_b32 %0, %2 offset:12" ::"v"(rec_addr), "v"(fs), "v"(fpos) : "memory");
   }
   __device__ __forceinline__ void begin_column() {
     asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
@@ -457,6 +467,33 @@ struct LdsColumn {
   __device__ __forceinline__ float qc(int r, int w) const { return pick(qc0, qc1, qc2, 2 * R + 2 * r + w - 4 * C0); }
 };
 
+// Secondary-structure term of the 64-lane ...AndSS variants (hhv_ss_kernel; src/hhviterbialgorithm.cpp:194-213,278-280): the
+// premultiplied table ssw * S33 / S73 / S37 lives in the workgroup's LDS; row[r] = LDS byte address of the table row of the
+// lane's query row r, set once; per column the R values at row[r] + 4 * (column index of the record) are requested right behind
+// the wait for the profile (they land under the emission arithmetic, like the phase-C query transitions of the QL sources) and
+// waited for in front of phase C - reads and wait through inline asm like every other LDS access of the loop (a compiler-visible
+// gather - round 4: global loads - drags a vmcnt(0) / lgkmcnt(0) of hipcc's choosing into every step).
+template <int R>
+struct SsLds {
+  static constexpr bool ASYNC = true;
+  uint32_t row[R];
+  uint32_t col4;  // 4 x the column index (pred_index / dssp_index) of this step's record
+  float v[R];
+  __device__ __forceinline__ void issue() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t ad = row[r] + col4;
+      asm volatile("ds_read_b32 %0, %1" : "=&v"(v[r]) : "v"(ad));
+    }
+  }
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(v[r]));  // (no consumer above the wait)
+  }
+  __device__ __forceinline__ float get(int r) const { return v[r]; }
+};
+
 // Occupancy: VALU issue needs >= 2 waves per SIMD to reach its rate on gfx950 (a lone wave issues one
 // VOP2 every ~6.3 clk, two waves one every ~2.5 clk: tools/valu_ubench).  Up to R = 5 rows per lane the
 // kernel is held to <= 256 VGPRs (2 waves/SIMD, no scratch in any variant).
@@ -464,28 +501,27 @@ struct LdsColumn {
 // SS = secondary-structure term added to the emission score (the reference's ...AndSS builds).
 // W = lanes per systolic array: 64, or - short queries, single pass - 32 / 16: the wave is 2 / 4 independent arrays, array
 //     a = lane / W walking the stream range wave_rec[blockIdx * (64 / W) + a]; every array has its own ring section.
-// LDS of one wavefront: [QL block][ring][best slots]
+// LDS of one wavefront: [QL block][ring]
 template <int R, bool BT, int W>
 struct StreamSmem {
   // five-row backtrace variants: {m2i, i2i} and {m2d, d2d} of the lane's R query rows live in LDS (20 floats per lane; the
   // 20-dword stride is conflict-free for ds_read_b128) - the VGPRs they would occupy hold the compare results instead.
   static constexpr bool QL = BT && R == 5;  // (up to four rows per lane the registers hold the query's gap transitions as well)
   static constexpr int QL_F4 = QL ? LANES * 5 : 0;
-  static constexpr int BEST_F4 = W == LANES ? LANES / 2 : 0;  // 8 bytes per lane: the finalized best on its way to the next lane
-  static constexpr int F4 = QL_F4 + RING_RECS * 7 + BEST_F4;
+  static constexpr int F4 = QL_F4 + RING_RECS * 7;
 };
 
 // The body of the kernel for ONE wavefront; `array0` = number of its first systolic array (the workgroup number for the
-// one-wave kernel).  Its LDS (StreamSmem<R, BT, W>::F4 float4) is a static object of the instantiation: constant addresses, and
-// the two bodies of a pair kernel get two disjoint objects.
+// one-wave kernel).  `smem` = its LDS (StreamSmem<R, BT, W>::F4 float4), owned by the kernel that calls it: the one-wave kernel
+// has one, the two bodies of a pair kernel two disjoint ones, hhv_ss_kernel one per wavefront of its workgroup.
+// `ss_tab` (64-lane SS variants): LDS byte address of the workgroup's copy of the premultiplied secondary-structure table.
 // PM (pair mode): 0 = the wavefront is a workgroup of its own; 1 / 2 = first / second wavefront of a two-wave workgroup that
 // aligns a query of two strips in ONE launch (hhv_pair_kernel below); 3 = a workgroup of its own that runs the FIRST strip of a
 // one-launch-per-strip plan - known at compile time, so that its steps contain no code of the later strips (whose carry loads make
 // hipcc wait vmcnt(0) in every step of a body that contains them, whichever role it plays at run time).
 template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, int PM>
-__device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0) {
-  __shared__ float4 smem[StreamSmem<R, BT, W>::F4];
-  const int lane = PM == 0 ? (int)threadIdx.x : (int)(threadIdx.x & (LANES - 1));
+__device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0, float4* const smem, const uint32_t ss_tab = 0) {
+  const int lane = (int)(threadIdx.x & (LANES - 1));  // (the wavefront's lane: workgroups have one, two (pairs) or eight (hhv_ss_kernel) wavefronts)
   // PW0 / PW1: first / second wavefront of a pair.  PM 4 / 5 are the waves of a pair that is one link of a longer chain of
   // strips (queries of more than two strips run as a sequence of pair launches, round 4): 4 = first wave of a LATER pair - its
   // strip takes the bottom row of the strip above it from HBM like any later strip, and hands its own on through the FIFO;
@@ -634,15 +670,18 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
   q.load(a.qpack + (size_t)g * R * REC_DW);
   // PF: the head of the NEXT step (7 transitions + meta) is fetched while the current one is computed (8 more VGPRs).
   // The ring bookkeeping then runs one step early: chunk c must have landed before step C c - 1 requests its first record.
-  // All 64-lane variants except the cell-off / secondary-structure ones (no VGPRs to spare there); in the backtrace
+  // All 64-lane variants except the cell-off ones (no VGPRs to spare there; the secondary-structure variants joined in round 5,
+  // when their table values stopped being compiler-scheduled global loads); in the backtrace
   // variants the phase-A query-transition reads are deferred as well (SPLIT_A).  Measured in one session each
   // (tools/gpu_ab.sh): score-only -2 %, multi-pass -0.8 %, backtrace -0.5 %.
   // (not the local five-row single-pass variants: 256 VGPRs do not hold the prefetched head next to the per-row best)
-  constexpr bool PF = !CELLOFF && !SS && W == LANES && !(LOCAL && R == 5 && !MULTI);
+  // SSL: the secondary-structure values come out of the workgroup's LDS table (SsLds; 64-lane arrays = hhv_ss_kernel); the
+  // short-query arrays gather them from global memory as before
+  constexpr bool SSL = SS && W == LANES;
+  constexpr bool PF = !CELLOFF && (!SS || (SSL && HHV_SS_PF(R, LOCAL, BT, MULTI))) && W == LANES && !(LOCAL && R == 5 && !MULTI);
   LdsColumn<R, QL, (PF && QL), (W == LANES)> col;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t ring_addr = smem_addr + QL_F4 * 16 + arr * (C * REC_DW * 4);
-  const uint32_t best_base = smem_addr + (QL_F4 + RING_RECS * 7) * 16;
   col.ql_addr = smem_addr + lane * 80;
   col.head_lane = W == LANES && g == 0;  // (the DPP moves of the short-query arrays deliver the boundary themselves)
   col.hMM = col.hMI = col.hfs = NEG_MAX;
@@ -659,11 +698,18 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
   }
   LaneState<R> st;
   st.reset();
-  int ss_qoff[R];
-  if (SS) {
+  int ss_qoff[SSL ? 1 : R];
+  SsLds<R> ssl;
+  if (SS && !SSL) {
 #pragma unroll
     for (int r = 0; r < R; ++r) ss_qoff[r] = a.ss_q_off[i0 - 1 + r];
   }
+  if (SSL) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) ssl.row[r] = ss_tab + 4u * (uint32_t)a.ss_q_off[i0 - 1 + r];
+  }
+  // (the column index of a record as a byte offset into a table row: (meta >> (shift - 2)) & (mask << 2), both wave uniform)
+  const int ss_sh4 = a.ss_t_shift - 2, ss_mask4 = a.ss_t_mask << 2;
 
   // chunks 0 and 1 have landed, the lane's own ds_writes above are done (LDS executes a wave's operations in order)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -836,12 +882,12 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
       if (meta < 0) {
         TemplateResult res;
         // (the wait inside covers the pulls of this step as well)
-        const int tid0 = W == LANES ? cur.header_tid_best(best_base + pull_addr * 2) : cur.header_tid();
+        const int tid0 = W == LANES ? cur.header_tid_best() : cur.header_tid();
         const int new_tid = tid0 | ((meta & META_NOLASTCOL) ? TID_NOLASTCOL : 0);
         Incoming inh = cur.resolve(in, st);
         cur.resolve_best(in, inh);
         const bool emit = lane_header<R, LOCAL, SHARE>(st, q, inh, i0, new_tid, P, g == g_last, res);
-        if (W == LANES) decltype(col)::publish_best(best_base + (uint32_t)lane * 8u, st.fs, st.fpos);
+        if (W == LANES) cur.publish_best(st.fs, st.fpos);
         if (emit && !PW0) {  // (first wave of a pair: the best travels on through the FIFO)
           DevResult o;
           o.score = res.score;
@@ -861,16 +907,20 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
           bte = a.bt + ((MULTI ? (size_t)a.bt_plane * a.bt_pass_stride : 0) + row * W + g);
         }
         if (CELLOFF) cell = *bte;
-        float ssv[R];
-        if (SS) {
+        float ssv[SSL ? 1 : R];
+        if (SS && !SSL) {
           const int tidx = (meta >> a.ss_t_shift) & a.ss_t_mask;
 #pragma unroll
           for (int r = 0; r < R; ++r) ssv[r] = a.ss_table[ss_qoff[r] + tidx];
         }
+        if (SSL) ssl.col4 = (uint32_t)((meta >> ss_sh4) & ss_mask4);
+        PtrSs ssp{ssv};
         // single pass: the boundary value of the first lane is formed inside the column's block, so that it need not be held
         // through phases A and B (it is read in phase C)
         const Incoming inc = MULTI ? in : boundary_incoming(meta, jcol, P);
-        const uint64_t bytes = lane_column<R, LOCAL, BT, CELLOFF, SHARE, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssv);
+        uint64_t bytes;
+        if (SSL) bytes = lane_column<R, LOCAL, BT, CELLOFF, SHARE, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssl);
+        else bytes = lane_column<R, LOCAL, BT, CELLOFF, SHARE, SS, bt_mm_mode(W, R, LOCAL, CELLOFF, SS), bt_pair_mode(W, CELLOFF)>(st, q, inc, ds, cur, j, i0, r_last, P, cell, ssp);
         if (BT) *bte = bytes;
       }
       if (PW0) {
@@ -1000,7 +1050,32 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
 // FIRSTP: the launch of the FIRST strip of a multi-strip query (MULTI only)
 template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, bool FIRSTP = false>
 __global__ void __launch_bounds__(LANES, 2) hhv_stream_kernel(StreamArgs a) {
-  stream_body<R, LOCAL, BT, CELLOFF, MULTI, SS, W, (FIRSTP ? 3 : 0)>(a, (int)blockIdx.x);
+  static_assert(!(SS && W == LANES), "the 64-lane secondary-structure variants run as hhv_ss_kernel");
+  __shared__ float4 smem[StreamSmem<R, BT, W>::F4];
+  stream_body<R, LOCAL, BT, CELLOFF, MULTI, SS, W, (FIRSTP ? 3 : 0)>(a, (int)blockIdx.x, smem);
+}
+
+// The ...AndSS variants of the 64-lane arrays (par.ssm = 2 is the reference's default, src/hhdecl.cpp:82): ONE
+// workgroup of SS_WAVES = 8 independent wavefronts per CU - each a systolic array of its own with its own ring, drawing its own
+// segments from the queue - sharing one LDS copy of the premultiplied score table (ssw * S33: 44 x 44 floats = 7.6 KB; eight
+// one-wave workgroups with a copy each would not fit: 8 x (14 + 7.6) KB > 160 KB).  Eight bodies, one table: 8 x 14 KB (19 KB with
+// LDS-parked query rows) + 7.6 KB <= 160 KB, 2 waves per SIMD as everywhere.
+constexpr int SS_WAVES = 8;
+constexpr int SS_TAB_FLOATS = 4 * 11 * 4 * 11;  // the largest of the three tables (S33)
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool FIRSTP = false>
+__global__ void __launch_bounds__(SS_WAVES * LANES, 2) hhv_ss_kernel(StreamArgs a) {
+  constexpr int F4 = StreamSmem<R, BT, LANES>::F4;
+  __shared__ float4 smem[SS_WAVES * F4];
+  __shared__ float tab[SS_TAB_FLOATS];
+  static_assert(SS_TAB_FLOATS <= 4 * SS_WAVES * LANES, "table copy: four entries per thread");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // (no loop: tools/audit_asm.py reads everything behind the first loop header as the step loop)
+    const int e = (int)threadIdx.x + k * SS_WAVES * LANES;
+    if (e < a.ss_tab_n) tab[e] = a.ss_table[e];
+  }
+  __syncthreads();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  stream_body<R, LOCAL, BT, CELLOFF, MULTI, true, LANES, (FIRSTP ? 3 : 0)>(a, (int)blockIdx.x * SS_WAVES + wv, smem + wv * F4, lds_addr_of(tab));
 }
 
 // Two strips of R0 and R1 rows per lane as the two wavefronts of one workgroup (PairLds above).  Which wave index takes which
@@ -1025,7 +1100,8 @@ __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
     StreamArgs a0 = a;
     a0.pass_first = (CHAIN & 1) ? 0 : 1;
     a0.pass_last = 0;
-    stream_body<R0, LOCAL, BT, false, true, false, LANES, ((CHAIN & 1) ? 4 : 1)>(a0, (int)blockIdx.x);
+    __shared__ float4 smem0[StreamSmem<R0, BT, LANES>::F4];
+    stream_body<R0, LOCAL, BT, false, true, false, LANES, ((CHAIN & 1) ? 4 : 1)>(a0, (int)blockIdx.x, smem0);
   } else {
     StreamArgs a1 = a;
     a1.row_base = a.row_base + LANES * R0;
@@ -1033,20 +1109,32 @@ __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
     a1.bt_plane = a.bt_plane + 1;
     a1.pass_first = 0;
     a1.pass_last = (CHAIN & 2) ? 0 : 1;
-    stream_body<R1, LOCAL, BT, false, true, false, LANES, ((CHAIN & 2) ? 5 : 2)>(a1, (int)blockIdx.x);
+    __shared__ float4 smem1[StreamSmem<R1, BT, LANES>::F4];
+    stream_body<R1, LOCAL, BT, false, true, false, LANES, ((CHAIN & 2) ? 5 : 2)>(a1, (int)blockIdx.x, smem1);
   }
 }
 // ---- kernel selection (instantiates the variants of one W in the including unit) --------------------------------------
+// (ss with 64-lane arrays: workgroups of SS_WAVES wavefronts, hhv_ss_kernel - the launcher asks stream_kernel_waves())
+template <int W, int R, bool LOCAL, bool BT, bool CELLOFF, bool SS>
+struct StreamKernelOf {
+  template <bool MULTI, bool FIRSTP>
+  static void* get() { return (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, MULTI, SS, W, FIRSTP>; }
+};
+template <int R, bool LOCAL, bool BT, bool CELLOFF>
+struct StreamKernelOf<LANES, R, LOCAL, BT, CELLOFF, true> {
+  template <bool MULTI, bool FIRSTP>
+  static void* get() { return (void*)hhv_ss_kernel<R, LOCAL, BT, CELLOFF, MULTI, FIRSTP>; }
+};
 template <int W, int R, bool LOCAL, bool BT, bool CELLOFF>
 static void* stream_kernel_ptr(bool multi, bool ss, bool first_strip) {
   if (W == LANES && multi && first_strip)
-    return ss ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), true, W, (W == LANES)>
-              : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), false, W, (W == LANES)>;
+    return ss ? StreamKernelOf<W, R, LOCAL, BT, CELLOFF, true>::template get<(W == LANES), (W == LANES)>()
+              : StreamKernelOf<W, R, LOCAL, BT, CELLOFF, false>::template get<(W == LANES), (W == LANES)>();
   if (W == LANES && multi)
-    return ss ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), true, W>
-              : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, (W == LANES), false, W>;
-  return ss ? (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, false, true, W>
-            : (void*)hhv_stream_kernel<R, LOCAL, BT, CELLOFF, false, false, W>;
+    return ss ? StreamKernelOf<W, R, LOCAL, BT, CELLOFF, true>::template get<(W == LANES), false>()
+              : StreamKernelOf<W, R, LOCAL, BT, CELLOFF, false>::template get<(W == LANES), false>();
+  return ss ? StreamKernelOf<W, R, LOCAL, BT, CELLOFF, true>::template get<false, false>()
+            : StreamKernelOf<W, R, LOCAL, BT, CELLOFF, false>::template get<false, false>();
 }
 template <int W, int R>
 static void* stream_kernel_variant(bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip) {

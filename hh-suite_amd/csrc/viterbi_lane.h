@@ -503,6 +503,17 @@ struct ArraySrc {
   HHV_MEM Incoming resolve(const Incoming& in, State&) const { return in; }
 };
 
+// Source of the secondary-structure values of a column (SS variants): PtrSs = R values the caller has gathered already (host
+// emulation, short-query arrays); an ASYNC source (hhv_stream_kernel.h SsLds) is asked for them behind the profile's wait and
+// delivers in front of phase C.
+struct PtrSs {
+  static constexpr bool ASYNC = false;
+  const float* v;
+  HHV_MEM void issue() {}
+  HHV_MEM void wait() {}
+  HHV_MEM float get(int r) const { return v[r]; }
+};
+
 // One template column j for the R rows of this lane.
 //   src      : the 28-dword column record (and, for QL sources, four of the lane's query transitions per row)
 //   cellbits : CELLOFF only - byte r bit 7 set = cell (i0+r, j) excluded (same byte matrix the
@@ -513,12 +524,12 @@ struct ArraySrc {
 // (no loop-carried copies): A (rows bottom-up) everything that reads only column j-1 state - the five
 // MM candidates, GD and IM; B the R emission scores (independent dot products = the ILP of the
 // kernel); C (rows top-down) MM += S, then DG and MI which chain through the row above.
-//   ssv      : SS only - ssv[r] = ssw * S[q_ss(i0+r)][t_ss(j)], the secondary-structure term of the ...AndSS
+//   ssx      : SS only - ssx.get(r) = ssw * S[q_ss(i0+r)][t_ss(j)], the secondary-structure term of the ...AndSS
 //              builds (src/hhviterbialgorithm.cpp:194-213,278-280), added as ss + log2f4(..) like the reference
 //   BTM / BTP : BT only - encoding of the MM predecessor and form of the pairwise maxima (bt_mm_mode / bt_pair_mode of the array width)
-template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, int BTM, int BTP, class Src>
+template <int R, bool LOCAL, bool BT, bool CELLOFF, bool SHARE, bool SS, int BTM, int BTP, class Src, class Ssx>
 HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming& in, const DiagSums& ds, Src& src, int j,
-                             int i0, int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, const float* ssv) {
+                             int i0, int r_last /* (Lq-1) % R */, const Params& P, uint64_t cellbits, Ssx& ssx) {
   constexpr bool QL = Src::QL;
   const float smin = LOCAL ? 0.0f : NEG_MAX;
   src.begin_column();
@@ -631,17 +642,24 @@ HHV_DEV uint64_t lane_column(LaneState<R>& st, const QRows<R>& q, const Incoming
   float tp[20];
   src.get_p(tp);
   float S[R];
+  constexpr bool SSA = SS && Ssx::ASYNC;  // the table values arrive in front of phase C: the two additions behind log2f4 wait for them
+  if (SSA) ssx.issue();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float v = log2f4(dot20(q.p[r], tp), P.lg);
-    if (SS) v = ssv[r] + v;
-    S[r] = v + P.shift;
+    if (SS && !SSA) v = ssx.get(r) + v;
+    S[r] = SSA ? v : v + P.shift;
   }
   // ---- phase C, rows 0 .. R-1: (i-1, j) = new state of the row above
 #if defined(HHV_EXP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
   src.stamp_B(S[0], S[R - 1]);
 #endif
   src.before_C();
+  if (SSA) {
+    ssx.wait();
+#pragma unroll
+    for (int r = 0; r < R; ++r) S[r] = (ssx.get(r) + S[r]) + P.shift;  // (ss + log2f4(..)) + shift, :278-283
+  }
   const Incoming up = src.resolve(in, st);  // MM / DG / MI of row i0-1 in this column; GD / IM / DG for the next column's diagonal
   float uMM = up.MM, uDG = up.DG, uMI = up.MI;
 #pragma unroll

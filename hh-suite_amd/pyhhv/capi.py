@@ -588,21 +588,30 @@ class Context:
         assert m.shape == (self.Lq + 1, int(ts.L[k]) + 1)
         self._chk(self.lib.hhv_set_celloff(self.h, ts.h, int(k), m.ctypes.data))
 
-    def set_celloff_paths(self, ts, paths, qranges=(), tranges=()):
-        """hhv_set_celloff_paths: paths = [(template, nsteps, i_steps, j_steps)] with 1-based step arrays as hit_path returns
-        them (entries 1..nsteps are handed over); qranges / tranges = [(lo, hi)] of -excl / -template_excl"""
+    @staticmethod
+    def pack_celloff_paths(paths):
+        """paths = [(template, nsteps, i_steps, j_steps)] with 1-based step arrays as hit_path returns them (entries 1..nsteps
+        are handed over) -> the arrays hhv_set_celloff_paths takes: (template_of, path_off, i, j)"""
         template_of = np.array([p[0] for p in paths], dtype=np.int32)
         off = np.zeros(len(paths) + 1, dtype=np.int64)
         for k, p in enumerate(paths):
             off[k + 1] = off[k] + int(p[1])
         pi = np.concatenate([np.asarray(p[2], dtype=np.int32)[1:int(p[1]) + 1] for p in paths]) if paths else np.zeros(0, np.int32)
         pj = np.concatenate([np.asarray(p[3], dtype=np.int32)[1:int(p[1]) + 1] for p in paths]) if paths else np.zeros(0, np.int32)
-        pi, pj = np.ascontiguousarray(pi), np.ascontiguousarray(pj)
+        return template_of, off, np.ascontiguousarray(pi), np.ascontiguousarray(pj)
+
+    def set_celloff_paths_packed(self, ts, packed, qranges=(), tranges=()):
+        template_of, off, pi, pj = packed
         qr = np.ascontiguousarray(np.asarray(qranges, dtype=np.int32).reshape(-1))
         tr = np.ascontiguousarray(np.asarray(tranges, dtype=np.int32).reshape(-1))
-        self._chk(self.lib.hhv_set_celloff_paths(self.h, ts.h, len(paths), template_of.ctypes.data, off.ctypes.data,
-                                              pi.ctypes.data, pj.ctypes.data, len(qr) // 2, qr.ctypes.data if len(qr) else None,
-                                              len(tr) // 2, tr.ctypes.data if len(tr) else None))
+        self._chk(self.lib.hhv_set_celloff_paths(self.h, ts.h, len(template_of), template_of.ctypes.data, off.ctypes.data,
+                                                 pi.ctypes.data, pj.ctypes.data, len(qr) // 2, qr.ctypes.data if len(qr) else None,
+                                                 len(tr) // 2, tr.ctypes.data if len(tr) else None))
+
+    def set_celloff_paths(self, ts, paths, qranges=(), tranges=()):
+        """hhv_set_celloff_paths: paths = [(template, nsteps, i_steps, j_steps)] with 1-based step arrays as hit_path returns
+        them (entries 1..nsteps are handed over); qranges / tranges = [(lo, hi)] of -excl / -template_excl"""
+        self.set_celloff_paths_packed(ts, self.pack_celloff_paths(paths), qranges, tranges)
 
     def set_global_batch(self, ts, not_longest):
         """hhv_set_global_batch: not_longest[k] != 0 -> template k is shorter than the longest of its SIMD batch"""

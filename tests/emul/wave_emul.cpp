@@ -92,9 +92,11 @@ static int run_pass(const float* qpack, const float* records, long M, Params P, 
           float ssv[R];
           const int tidx = (meta >> ss.t_shift) & ss.t_mask;
           for (int r = 0; r < R; ++r) ssv[r] = ss.table[ss.q_off[i0 - 1 + r] + tidx];
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, true, bt_mm_mode(64, R, LOCAL, CELLOFF, true), bt_pair_mode(64, CELLOFF)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, ssv);
+          PtrSs ssx{ssv};
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, true, bt_mm_mode(64, R, LOCAL, CELLOFF, true), bt_pair_mode(64, CELLOFF)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, ssx);
         } else {
-          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, false, bt_mm_mode(64, R, LOCAL, CELLOFF, false), bt_pair_mode(64, CELLOFF)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, nullptr);
+          PtrSs noss{nullptr};
+          bytes = lane_column<R, LOCAL, BT, CELLOFF, true, false, bt_mm_mode(64, R, LOCAL, CELLOFF, false), bt_pair_mode(64, CELLOFF)>(st[g], q[g], in, ds, src, j, i0, r_last, P, cell, noss);
         }
         if (BT) bt[(size_t)r * 64 + g] = bytes;
       }

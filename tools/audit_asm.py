@@ -63,7 +63,7 @@ def functions(lines):
     i = 0
     n = len(lines)
     while i < n:
-        m = re.match(r"^(_ZN3hhv1[75]hhv_(?:stream|pair)_kernel\w+):", lines[i])
+        m = re.match(r"^(_ZN3hhv1[753]hhv_(?:stream|pair|ss)_kernel\w+):", lines[i])
         if m:
             j = i
             while j < n and not lines[j].strip().startswith("s_endpgm"):
@@ -76,6 +76,10 @@ def functions(lines):
 def audit_function(name, body):
     problems = []
     m = re.search(r"hhv_stream_kernelILi\dELb\dELb\dELb(\d)ELb(\d)ELb(\d)E", name)
+    if m and m.group(3) == "1" and "ELi64E" in name:
+        return ["%s: a 64-lane secondary-structure variant of hhv_stream_kernel (they run as hhv_ss_kernel)" % name]
+    if m is None:   # hhv_ss_kernel<R, LOCAL, BT, CELLOFF, MULTI, FIRSTP>: the table values come out of LDS through inline asm - only the
+        m = re.search(r"hhv_ss_kernelILi\dELb\dELb\dELb(\d)ELb(\d)E", name)   # cell-off masks and the carry rows are global loads
     loads_in_loop = m is None or "1" in m.groups()   # (pair kernels: m is None - their waits are placed by hand too, but they are MULTI bodies)
     pending = []         # destination registers of issued, not yet waited-for asm reads, one set per read in issue order
     ticket = []          # destination of the work queue's atomic, not yet waited for
@@ -151,7 +155,7 @@ def main():
     for m in re.finditer(r"\.vgpr_spill_count:\s*(\d+)", text):
         if int(m.group(1)) != 0:
             problems.append("a kernel spills %s VGPRs" % m.group(1))
-    print("audited %d hhv_stream_kernel / hhv_pair_kernel instantiations, %d problems" % (count, len(problems)))
+    print("audited %d hhv_stream_kernel / hhv_pair_kernel / hhv_ss_kernel instantiations, %d problems" % (count, len(problems)))
     for p in problems[:50]:
         print("  " + p)
     return 1 if problems or count == 0 else 0

@@ -65,13 +65,16 @@ def template_ss_of(meta_host, L):
     return (pi // 11).astype(np.int8), (pi % 11).astype(np.int8), ds.astype(np.int8)
 
 
-def _time_steps(ctx, ts, qf, qtr, K, bt, reps, warm=2):
+def _time_steps(ctx, ts, qf, qtr, K, bt, reps, warm=2, q_ss=None):
+    """a step = a search: the query (and its secondary structure: hhv_set_query forgets the previous query's) goes to the device"""
     ms = []
     for it in range(warm + reps):
         if it == warm:
             ctx.sync()
             t0 = time.perf_counter()
         ctx.set_query(qf, qtr)
+        if q_ss is not None:
+            ctx.set_query_ss(*q_ss)
         ctx.align_async(ts, backtrace=bt)
         if bt:
             ctx.hits(ts, fetch=False)
@@ -97,6 +100,8 @@ def _check_ss(ctx, ts, rec, rec_off, Ls, qf, qtr, q_ss, tables, mode, local, m):
     metas = host.view(np.int32)[:, 27]
     t_sss = [template_ss_of(metas[int(rec_off[k]): int(rec_off[k + 1])], int(Ls[k])) for k in range(m)]
     ss = pyoracle.SSInfo(mode, q_ss[0], q_ss[1], q_ss[2], S73, S33, S37)
+    ctx.set_query(qf, qtr)
+    ctx.set_query_ss(*q_ss)
     res = ctx.align(ts, backtrace=True)
     hits = ctx.hits(ts)
     bad = 0
@@ -152,7 +157,8 @@ def ss_modes(torch, capi, dev_index, rec, rec_off, Ls, qf, qtr, K, local=0, reps
         out["no_ss_same_stream"] = {"score_only": _time_steps(c, ts, qf, qtr, K, False, reps), "backtrace_hits": _time_steps(c, ts, qf, qtr, K, True, max(3, reps // 2))}
         for mode, name in ((4, "PRED_PRED"), (2, "DSSP_PRED")):
             c.set_ss_mode(mode)
-            e = {"score_only": _time_steps(c, ts, qf, qtr, K, False, reps), "backtrace_hits": _time_steps(c, ts, qf, qtr, K, True, max(3, reps // 2))}
+            e = {"score_only": _time_steps(c, ts, qf, qtr, K, False, reps, q_ss=q_ss),
+                 "backtrace_hits": _time_steps(c, ts, qf, qtr, K, True, max(3, reps // 2), q_ss=q_ss)}
             try:
                 e["gpu_matches_cpu_on_sample"] = _check_ss(c, ts, rs, rec_off, Ls, qf, qtr, q_ss, tables, mode, local, min(check, n))
             except Exception as ex:
@@ -168,8 +174,8 @@ def ss_modes(torch, capi, dev_index, rec, rec_off, Ls, qf, qtr, K, local=0, reps
             ts2 = c.adopt_device_stream(Ls[:n2], rs.data_ptr())
             for mode, name in ((0, "no_ss"), (4, "PRED_PRED")):
                 c.set_ss_mode(mode)
-                out["Lq%d_%dk_%s" % (lq2, n2 // 1000, name)] = {"score_only": _time_steps(c, ts2, q2f, q2tr, K, False, reps),
-                                                               "backtrace_hits": _time_steps(c, ts2, q2f, q2tr, K, True, max(3, reps // 2))}
+                out["Lq%d_%dk_%s" % (lq2, n2 // 1000, name)] = {"score_only": _time_steps(c, ts2, q2f, q2tr, K, False, reps, q_ss=q2_ss),
+                                                               "backtrace_hits": _time_steps(c, ts2, q2f, q2tr, K, True, max(3, reps // 2), q_ss=q2_ss)}
             c.set_ss_mode(4)
             try:
                 out["Lq%d_%dk_PRED_PRED" % (lq2, n2 // 1000)]["gpu_matches_cpu_on_sample"] = _check_ss(
@@ -232,11 +238,12 @@ def masked_round(torch, capi, dev_index, rec, rec_off, Ls, qf, qtr, K, local=0, 
         hits1 = c.hits(ts)
         off, pi, pj, pst, pS = c.hit_path_pool(ts)
         paths = [(k, int(hits1["nsteps"][k]), pi[off[k]: off[k] + hits1["nsteps"][k] + 1], pj[off[k]: off[k] + hits1["nsteps"][k] + 1]) for k in range(n10)]
+        packed = c.pack_celloff_paths(paths)   # (the host arrays hhv_set_celloff_paths takes: built once, outside the timing)
         t_mask, t_round, kms = [], [], []
         for it in range(reps + 1):
             c.sync()
             t0 = time.perf_counter()
-            c.set_celloff_paths(ts, paths)
+            c.set_celloff_paths_packed(ts, packed)
             c.sync()
             t1 = time.perf_counter()
             c.align_async(ts, celloff=True)
@@ -251,12 +258,12 @@ def masked_round(torch, capi, dev_index, rec, rec_off, Ls, qf, qtr, K, local=0, 
         cells = ts.cells()
         out.update({"masked_dp_cells_per_s": cells / (float(np.mean(kms)) * 1e-3), "dp_kernel_ms": float(np.mean(kms)),
                     "round_ms_dp_hits_topk": float(np.mean(t_round)) * 1e3, "cells_per_s_round": cells / float(np.mean(t_round)),
-                    "mask_build_ms_incl_h2d_of_paths": float(np.mean(t_mask)) * 1e3})
+                    "mask_build_ms_hhv_set_celloff_paths": float(np.mean(t_mask)) * 1e3,
+                    "path_steps_handed_over": int(packed[1][-1])})
         try:
             use_ref = pyoracle.have_ref()
             m = min(check if use_ref else 32, n10)
-            res2 = c.align(ts, celloff=False) if False else None
-            c.set_celloff_paths(ts, paths)
+            c.set_celloff_paths_packed(ts, packed)
             res2 = c.align(ts, celloff=True)
             hits2 = c.hits(ts)
             host = rec[: int(rec_off[m])].cpu().numpy()

@@ -82,6 +82,23 @@ walk("", d)
 print("masked_round", {k: v for k, v in d["masked_round"].items() if not isinstance(v, dict)})
 PY
   ;;
+dbg)   # dbg <args of tools/dbg_ss.py>
+  timeout 120 python tools/dbg_ss.py "$@" 2>&1 | tail -30
+  ;;
+r5c)   # probes: LDS-DMA beyond 64 KB, integer / SDWA / packed issue rates; which secondary-structure case faults; the non-SS suites on the header-record best
+  ./build/lds_dma_probe
+  ./build/valu_ubench int 2>&1 | grep -E "SIMD=(2|4)" > $OUT/valu_ubench_int.txt; cat $OUT/valu_ubench_int.txt
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_queue.py tests/test_gpu_pair.py -q -m gpu -x 2>&1 | tail -4
+  timeout 300 python -m pytest tests/test_gpu_ss.py -v -m gpu -x 2>&1 | grep -E "PASS|FAIL|Error|fault|passed|failed" | head -20
+  ;;
+r5b)   # the secondary-structure kernels as workgroups of eight wavefronts with the table in LDS (hhv_ss_kernel), best slots in the header records
+  timeout 900 python -m pytest tests/test_gpu_ss.py tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_queue.py tests/test_gpu_pair.py tests/test_gpu_errors.py tests/test_dropin_runner.py -q -m gpu -x 2>&1 | tail -6
+  bash tools/gpu_session.sh rows hip
+  for cfg in "" "--backtrace 1" "--local 1" "--lq 431 --templates 50000" "--lengths zipf --local 1 --templates 125000"; do
+    echo -n "== $cfg : "
+    timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
+  done
+  ;;
 r5a)   # round 5, first session: the device error word and the launch policy (tests), then the baseline of the new bench rows on HEAD~ kernels
   timeout 600 python -m pytest tests/test_gpu_errors.py tests/test_gpu_pair.py -q -m gpu -x 2>&1 | tail -5
   bash tools/gpu_session.sh rows hip

@@ -22,16 +22,28 @@ def quantize(a, rng, step):
     return (np.round(a / step) * step).astype(np.float32)
 
 
-def viterbi_family(orc, rng, budget):
+def viterbi_family(orc, rng, budget, with_ss=False):
+    """with_ss: the ...AndSS kernels (par.ssm = 2, a random table mode, random secondary-structure codes for query and templates,
+    random score tables) - the same cases otherwise: ties, dead transitions, masked rounds (AlignWithCellOffAndSS), thousands of
+    1-3-column templates back to back, queries of one to four strips and the short-query arrays"""
     t_end, cases, bad = time.time() + budget, 0, 0
     while time.time() < t_end:
         Lq = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 320, 321, 400, 512, 600, 700, 1000]))   # (321 ..: pair kernels, 641 ..: chains of them)
         local = int(rng.integers(0, 2))
         par = po.make_params(local=local, egq=float(rng.choice([0.0, 0.2])), egt=float(rng.choice([0.0, 0.1])),
-                             shift=float(rng.choice([-0.03, 0.0, 0.25])), ss_mode=0)
+                             shift=float(rng.choice([-0.03, 0.0, 0.25])), ss_mode=2 if with_ss else 0)
         qp, qtr = synth.make_query(int(rng.integers(1 << 30)), Lq)
         n = int(rng.integers(1, 12))
-        tps, ttrs, masks = [], [], []
+        tps, ttrs, masks, t_sss = [], [], [], []
+        ss = None
+        if with_ss:
+            par["ssw"] = float(rng.choice([0.11, 1.0, 0.0]))
+            tables = (rng.normal(0, 1, (8, 4, 11)).astype(np.float32), rng.normal(0, 1, (4, 11, 4, 11)).astype(np.float32),
+                      rng.normal(0, 1, (4, 11, 8)).astype(np.float32))
+            if rng.random() < 0.3:   # ties between the candidates of a cell survive the addition of a coarse table
+                tables = tuple(quantize(t, rng, 0.5) for t in tables)
+            q_ss = (rng.integers(0, 4, Lq + 1), rng.integers(0, 11, Lq + 1), rng.integers(0, 8, Lq + 1))
+            ss = po.SSInfo(int(rng.choice([4, 4, 2, 1])), *q_ss, *tables)
         for k in range(n):
             Lt = int(rng.choice([1, 2, 3, 31, 64, 130, 257]))
             tp, ttr = (synth.make_homolog(int(rng.integers(1 << 30)), qp, L=Lt) if rng.random() < 0.5 and Lq > 4 else
@@ -43,6 +55,7 @@ def viterbi_family(orc, rng, budget):
                 ttr[rng.integers(0, Lt + 1), rng.integers(0, 7)] = -100000.0
             tps.append(tp)
             ttrs.append(ttr)
+            t_sss.append((rng.integers(0, 4, Lt + 1), rng.integers(0, 11, Lt + 1), rng.integers(0, 8, Lt + 1)))
             masks.append((rng.random((Lq + 1, Lt + 1)) < rng.choice([0.0, 0.05, 0.5])).astype(np.uint8) if rng.random() < 0.4 else None)
         if rng.random() < 0.5:
             qtr = quantize(qtr, rng, 0.5)
@@ -56,9 +69,13 @@ def viterbi_family(orc, rng, budget):
             short = [k for k in range(n) if tps[k].shape[0] - 1 <= 3]
             if short:
                 idx = np.where(rng.random(idx.shape[0]) < 0.6, rng.choice(short, idx.shape[0]), idx)
-        c = capi.Context(local=local, egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"], ss_mode=0)
+        c = capi.Context(local=local, egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"], ssw=par["ssw"], ss_mode=par["ss_mode"])
         c.set_query(qp, qtr)
-        ts = c.upload([tps[k] for k in idx], [ttrs[k] for k in idx])
+        if with_ss:
+            c.set_ss_tables(ss.S73, ss.S33, ss.S37)
+            c.set_query_ss(ss.q_pred, ss.q_conf, ss.q_dssp)
+            c.set_ss_mode(ss.mode)
+        ts = c.upload([tps[k] for k in idx], [ttrs[k] for k in idx], [t_sss[k] for k in idx] if with_ss else None)
         use_mask = any(m is not None for m in masks)
         if use_mask:
             for e, k in enumerate(idx):
@@ -70,7 +87,8 @@ def viterbi_family(orc, rng, budget):
         with_bt = use_mask or rng.random() < 0.8
         res = c.align(ts, backtrace=with_bt, celloff=use_mask)
         hits = c.hits(ts) if with_bt else None
-        want = [orc.align(par, qp, qtr, tps[k], ttrs[k], celloff=masks[k] if use_mask else None, want_path=True) for k in range(n)]
+        want = [orc.align(par, qp, qtr, tps[k], ttrs[k], celloff=masks[k] if use_mask else None, ss=ss, t_ss=t_sss[k] if with_ss else None,
+                          want_path=True) for k in range(n)]
         bt_sample = set(range(len(idx))) if not many else set(int(e) for e in rng.integers(0, len(idx), 12))
         for e, k in enumerate(idx):
             a = want[k]
@@ -79,6 +97,8 @@ def viterbi_family(orc, rng, budget):
                 ok = ok and np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:] & 0x7F, a.bt[1:, 1:] & 0x7F)
             if with_bt:
                 ok = ok and int(hits["nsteps"][e]) == a.nsteps and np.float32(hits["score"][e]).tobytes() == np.float32(a.hit_score).tobytes()
+                if with_ss:
+                    ok = ok and np.float32(hits["score_ss"][e]) == np.float32(a.score_ss)
             cases += 1
             bad += int(not ok)
         ts.free()
@@ -373,10 +393,11 @@ def main():
     fam = sys.argv[3] if len(sys.argv) > 3 else "all"
     if fam != "all":
         print(json.dumps({fam: {"prefilter": prefilter_family, "mac": mac_family, "viterbi": viterbi_family, "prepare": prepare_family,
-                                "fast": fast_family, "long": long_family}[fam](orc, rng, budget)}))
+                                "fast": fast_family, "long": long_family, "ss": lambda o, r, b: viterbi_family(o, r, b, with_ss=True)}[fam](orc, rng, budget)}))
         return
     out = {"seconds_per_family": budget,
            "viterbi_backtrace_celloff": viterbi_family(orc, rng, budget),
+           "viterbi_secondary_structure": viterbi_family(orc, rng, budget, with_ss=True),
            "viterbi_long_profiles": long_family(orc, rng, budget),
            "prefilter": prefilter_family(orc, rng, budget),
            "mac_realign": mac_family(orc, rng, budget),

@@ -130,6 +130,35 @@ __global__ void __launch_bounds__(256) kx(float* out, int iters, float seed) {
     if (KIND == 25) asm volatile(REP8X(CH8("v_subrev_f32", ", %8")) OUTS);
     if (KIND == 26) asm volatile(REP8X(CH8("v_lshlrev_b32", ", %8")) OUTS);
     if (KIND == 27) asm volatile(REP8X(CH8("v_add3_u32", ", %8, %8")) OUTS);
+    // round 5: the instruction kinds of the prefilter kernels (hhv_prefilter.hip) - integer clamp / max forms, SDWA and DPP adds,
+    // packed 16-bit - and what a MIXED stream of a half-rate and a full-rate kind costs (do they overlap?)
+    if (KIND == 28) asm volatile(REP8X(CH8("v_med3_i32", ", 0, %8")) OUTS);
+    if (KIND == 29) asm volatile(REP8X(CH8("v_max3_i32", ", %8, %8")) OUTS);
+    if (KIND == 30) asm volatile(REP8X("v_add_u32_sdwa %0, sext(%8), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+                                       "v_add_u32_sdwa %1, sext(%8), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+                                       "v_add_u32_sdwa %2, sext(%8), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n"
+                                       "v_add_u32_sdwa %3, sext(%8), %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+                                       "v_add_u32_sdwa %4, sext(%8), %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+                                       "v_add_u32_sdwa %5, sext(%8), %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+                                       "v_add_u32_sdwa %6, sext(%8), %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n"
+                                       "v_add_u32_sdwa %7, sext(%8), %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n") OUTS);
+    if (KIND == 31) asm volatile(REP8X("v_add_u32_dpp %0, %0, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %1, %1, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                                       "v_add_u32_dpp %2, %2, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %3, %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                                       "v_add_u32_dpp %4, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %5, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                                       "v_add_u32_dpp %6, %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %7, %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n") OUTS);
+    if (KIND == 32) asm volatile(REP8X(CH8("v_cvt_f32_ubyte1", "")) OUTS);
+    if (KIND == 33) asm volatile(REP8X(CH8("v_pk_add_u16", ", %8")) OUTS);
+    if (KIND == 34) asm volatile(REP8X(CH8("v_pk_max_i16", ", %8")) OUTS);
+    if (KIND == 35) asm volatile(REP8X(CH8("v_pk_sub_u16", ", %8 clamp")) OUTS);
+    // mixed streams, 1 : 1 - if the two kinds used separate issue slots the pair would cost what the slower one costs alone
+    if (KIND == 36) asm volatile(REP8X("v_med3_i32 %0, %0, 0, %8\n v_add_f32 %1, %1, %8\n v_med3_i32 %2, %2, 0, %8\n v_add_f32 %3, %3, %8\n"
+                                       "v_med3_i32 %4, %4, 0, %8\n v_add_f32 %5, %5, %8\n v_med3_i32 %6, %6, 0, %8\n v_add_f32 %7, %7, %8\n") OUTS);
+    if (KIND == 37) asm volatile(REP8X("v_max_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                                       "v_max_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n") OUTS);
+    if (KIND == 38) asm volatile(REP8X("v_max_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                                       "v_max_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n") OUTS);  // 1 slow : 3 fast
+    if (KIND == 39) asm volatile(REP8X(CH8("v_sub_u32", ", %8")) OUTS);
+    if (KIND == 40) asm volatile(REP8X(CH8("v_min_u32", ", %8")) OUTS);
 #undef OUTS
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -192,7 +221,9 @@ static void sign_check() {
   printf("sign(b - a) == (a > b): %d pairs of %d special values, %u mismatches; NaN results OR-ed bits %08x\n", n * n, n, h[0], h[1]);
 }
 
-int main() {
+int main_int();
+int main(int argc, char** argv) {
+  if (argc > 1) return main_int();
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   printf("device %s  CUs %d  clock %.0f MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1e3);
@@ -241,5 +272,23 @@ int main() {
   RUNX("v_lshlrev_b32", 26);
   RUNX("v_add3_u32", 27);
   sign_check();
+  return 0;
+}
+
+int main_int() {
+  RUNX("v_med3_i32", 28);
+  RUNX("v_max3_i32", 29);
+  RUNX("v_add_u32_sdwa", 30);
+  RUNX("v_add_u32_dpp shr", 31);
+  RUNX("v_cvt_f32_ubyte1", 32);
+  RUNX("v_pk_add_u16", 33);
+  RUNX("v_pk_max_i16", 34);
+  RUNX("v_pk_sub_u16 clamp", 35);
+  RUNX("v_sub_u32", 39);
+  RUNX("v_min_u32", 40);
+  RUNX("v_add_u32", 18);
+  RUNX("med3 : add_f32 1:1", 36);
+  RUNX("max_f32 : add_f32 1:1", 37);
+  RUNX("max : add/mul 1:3", 38);
   return 0;
 }
