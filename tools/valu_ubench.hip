@@ -157,6 +157,30 @@ __global__ void __launch_bounds__(256) kx(float* out, int iters, float seed) {
                                        "v_max_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n") OUTS);
     if (KIND == 38) asm volatile(REP8X("v_max_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
                                        "v_max_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n") OUTS);  // 1 slow : 3 fast
+    // one residue of the gapless prefilter kernel (W = 5 cells per lane), the round-4 form and the round-5 form, 8 residues per statement
+#define PF_OLD "v_bfe_i32 %7, %8, 0, 8\n v_add_u32_sdwa %4, sext(%8), %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n" \
+               "v_add_u32_sdwa %3, sext(%8), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n" \
+               "v_add_u32_dpp %7, %4, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+               "v_add_u32_sdwa %2, sext(%8), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n" \
+               "v_add_u32_sdwa %1, sext(%8), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" \
+               "v_med3_i32 %4, %4, 0, s20\n v_med3_i32 %0, %7, 0, s20\n v_max3_i32 %5, %5, %0, %4\n v_med3_i32 %3, %3, 0, s20\n" \
+               "v_med3_i32 %2, %2, 0, s20\n v_med3_i32 %1, %1, 0, s20\n v_max3_i32 %5, %5, %1, %2\n v_max_i32 %5, %5, %3\n"
+#define PF_NEW "v_mov_b32 %7, s21\n v_mov_b32_dpp %7, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_lshrrev_b32 %6, 24, %8\n" \
+               "v_add_u32_sdwa %3, %8, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" \
+               "v_add_u32_sdwa %2, %8, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n" \
+               "v_and_b32 %1, 0xff, %8\n v_add_u32 %5, 0x80, %5\n v_add_u32 %7, %1, %7\n v_add_u32 %4, %8, %3\n v_mov_b32 %1, s22\n v_mov_b32 %0, s23\n" \
+               "v_med3_i32 %7, %7, %1, %0\n v_add_u32 %6, %6, %3\n v_max_i32 %5, %5, %7\n v_med3_i32 %3, %3, %1, %0\n v_med3_i32 %2, %2, %1, %0\n" \
+               "v_med3_i32 %4, %4, %1, %0\n v_med3_i32 %6, %6, %1, %0\n v_max3_i32 %5, %5, %2, %3\n v_max3_i32 %5, %5, %6, %4\n"
+    if (KIND == 41) asm volatile("s_mov_b32 s20, 205\n" REP8X(PF_OLD) OUTS : "s20");
+    if (KIND == 42) asm volatile("s_mov_b32 s21, 5\n s_mov_b32 s22, 7\n s_mov_b32 s23, 300\n" REP8X(PF_NEW) OUTS : "s21", "s22", "s23");
+    // the new form with its slow-kind instructions spread between the fast ones by hand
+#define PF_NEW2 "v_mov_b32 %7, s21\n v_mov_b32_dpp %7, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_lshrrev_b32 %6, 24, %8\n" \
+               "v_add_u32_sdwa %3, %8, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n v_and_b32 %1, 0xff, %8\n" \
+               "v_add_u32_sdwa %2, %8, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_add_u32 %5, 0x80, %5\n" \
+               "v_med3_i32 %3, %3, s22, %0\n v_add_u32 %7, %1, %7\n v_med3_i32 %2, %2, s22, %0\n v_add_u32 %4, %8, %3\n" \
+               "v_med3_i32 %7, %7, s22, %0\n v_add_u32 %6, %6, %3\n v_med3_i32 %4, %4, s22, %0\n v_mov_b32 %0, s23\n v_med3_i32 %6, %6, s22, %0\n" \
+               "v_mov_b32 %1, s22\n v_max3_i32 %5, %5, %2, %3\n v_mov_b32 %1, s22\n v_max3_i32 %5, %5, %6, %4\n v_mov_b32 %1, s22\n v_max_i32 %5, %5, %7\n"
+    if (KIND == 43) asm volatile("s_mov_b32 s21, 5\n s_mov_b32 s22, 7\n s_mov_b32 s23, 300\n" REP8X(PF_NEW2) OUTS : "s21", "s22", "s23");
     if (KIND == 39) asm volatile(REP8X(CH8("v_sub_u32", ", %8")) OUTS);
     if (KIND == 40) asm volatile(REP8X(CH8("v_min_u32", ", %8")) OUTS);
 #undef OUTS
@@ -290,5 +314,10 @@ int main_int() {
   RUNX("med3 : add_f32 1:1", 36);
   RUNX("max_f32 : add_f32 1:1", 37);
   RUNX("max : add/mul 1:3", 38);
+  // (a "wave-inst" of the next three is one of 64 statements' instructions: 8 residues x 14 / 20 / 22 instructions; the table's
+  // clk figure is per 1/64 of a statement - multiply by 64 / 8 for clk per RESIDUE)
+  RUNX("prefilter residue r4", 41);
+  RUNX("prefilter residue r5", 42);
+  RUNX("prefilter residue r5 spread", 43);
   return 0;
 }
