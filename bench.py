@@ -65,7 +65,7 @@ VALU_PEAK_FMA_TFLOPS = 157.3
 # measured: two waves per SIMD of a 64-thread / 248-VGPR kernel retire one v_add_f32 wave-instruction per 2.25 clk (nominal
 # 2.4 GHz) per SIMD - tools/gen_shape_ubench.py, profiles/r2_shape_ubench.txt
 MEASURED_ISSUE_CEILING = 256 * 4 * 64 / 2.25 * 2.4e9
-PROFILE_JSONS = ("r4_summary.json", "r3_summary.json", "r2_summary.json")   # newest committed PMC profile of the headline command first
+PROFILE_JSONS = ("r5_summary.json", "r4_summary.json", "r3_summary.json", "r2_summary.json")   # newest committed PMC profile of the headline command first
 REC_BYTES = 112
 OPS_PER_CELL = 92          # SURVEY.md 8d / BASELINE.md 5: fp32 operations per DP cell of the reference
 ZIPF_SEED = 0x21F          # the ONE seed of configs[4]'s global length vector
@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--topk", type=int, default=500)
     ap.add_argument("--local", type=int, default=0)
     ap.add_argument("--backtrace", type=int, default=0, help="1 = BASELINE configs[2] (backtrace + hit list)")
+    ap.add_argument("--ss", type=int, default=0, choices=[0, 1, 2, 4],
+                    help="secondary-structure scoring (SURVEY 8a A5, the ...AndSS kernels): 4 PRED_PRED, 2 DSSP_PRED, 1 PRED_DSSP - codes added to "
+                         "the stream's meta words, random score tables, the query's codes set per step (tools/bench_rows.py)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs1", action="store_true")
@@ -232,6 +235,15 @@ def main():
 
     ctx = capi.Context(local=args.local, device=dev_index)
     ctx.set_query(qf, qtr)
+    q_ss = None
+    if args.ss:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_rows
+        bench_rows.add_ss_codes(torch, rec, int(rec_off[-1]))
+        ctx.set_ss_tables(*bench_rows.ss_tables())
+        q_ss = bench_rows.query_ss(Lq)
+        ctx.set_query_ss(*q_ss)
+        ctx.set_ss_mode(args.ss)
     ts = ctx.adopt_device_stream(Ls, rec.data_ptr())
     cells_per_rank = ts.cells()
     K = args.topk
@@ -251,6 +263,8 @@ def main():
 
     def step(record_ms=True):
         ctx.set_query(qf, qtr)   # H2D of the query is part of a search
+        if q_ss is not None:
+            ctx.set_query_ss(*q_ss)   # (... and so are its secondary-structure codes: hhv_set_query forgets the previous query's)
         ctx.align_async(ts, backtrace=bt)
         if bt:
             ctx.hits(ts, fetch=False)
@@ -336,7 +350,7 @@ def main():
     traffic = None
     valu_wave_instr = None
     profile_json = None
-    headline = n_local == 100000 and Lq == 300 and Lt == 300 and not bt and args.lengths == "fixed" and not args.local
+    headline = n_local == 100000 and Lq == 300 and Lt == 300 and not bt and args.lengths == "fixed" and not args.local and not args.ss
     if headline:
         for name in PROFILE_JSONS:
             try:
@@ -368,7 +382,7 @@ def main():
         "config": {
             "workload": "Lq%d_vs_%dx_Lt%s_%s_%s" % (Lq, n_global, Lt if args.lengths == "fixed" else "zipf50-1000",
                                                      "local" if args.local else "global",
-                                                     "backtrace_hits_top%d" % K if bt else "score_only_top%d" % K),
+                                                     ("backtrace_hits_top%d" % K if bt else "score_only_top%d" % K) + ("_ss%d" % args.ss if args.ss else "")),
             "templates_total": n_global, "templates_per_gpu": n if args.virtual_shards == 1 else n_local,
             "Lq": Lq, "Lt": Lt if args.lengths == "fixed" else "zipf(1.2) 50..1000, seed 0x%X" % ZIPF_SEED, "topk": K,
             "parallelism": "template-db-shard x%d (hhv_shard_plan), one %s all_gather of top-K" % (world, "RCCL" if backend == "nccl" else backend)
@@ -426,7 +440,7 @@ def main():
         }
 
     single = rank == 0 and world == 1 and args.virtual_shards == 1
-    plain = not bt and args.lengths == "fixed"
+    plain = not bt and args.lengths == "fixed" and not args.ss
     if single and not args.no_configs1 and n >= 10000 and plain:
         # BASELINE configs[1]: the same query vs the first 10k templates of the resident stream
         ts10 = ctx.adopt_device_stream(np.full(10000, Lt, dtype=np.int32), rec.data_ptr())
@@ -664,7 +678,7 @@ def configs2(args, torch, ctx, ts, rec, rec_off, Ls, qf, qtr, Lq, Lt, K):
              "backtrace_bytes_written_per_launch": int(ts.records()) * 512}
         if ts.n == 100000 and Lq == 300 and Lt == 300:
             try:   # the backtrace kernel's executed VALU instructions and HBM traffic from its own committed counters
-                bt_json = "r4bt_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r4bt_summary.json")) else "r3bt_summary.json"
+                bt_json = next(n for n in ("r5bt_summary.json", "r4bt_summary.json", "r3bt_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
                 with open(os.path.join(ROOT, "profiles", bt_json)) as f:
                     prof = json.load(f)
                 lane_ops = prof["valu_wave_instr_per_launch"] * 64.0
@@ -673,10 +687,15 @@ def configs2(args, torch, ctx, ts, rec, rec_off, Ls, qf, qtr, Lq, Lt, K):
                                       "frac_of_issue_peak": lane_ops / (kms * 1e-3) / VALU_PEAK_LANEOPS,
                                       "frac_reference_flops": ts.cells() / (kms * 1e-3) * OPS_PER_CELL / VALU_PEAK_LANEOPS,
                                       "source": "profiles/%s (SQ_INSTS_VALU per launch) / dp_kernel_ms of this run" % bt_json}
-                e["roofline_hbm"] = {"traffic_bytes_per_launch": prof["traffic_bytes_per_launch"],
-                                     "algorithmic_bytes_per_launch": int(ts.records()) * REC_BYTES + ts.n * 16 + int(ts.cells()),
-                                     "achieved_GBs": prof["traffic_bytes_per_launch"] / (kms * 1e-3) / 1e9,
-                                     "frac_of_hbm_peak": prof["traffic_bytes_per_launch"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                algo = int(ts.records()) * 108 + ts.n * 12 + int(ts.cells())   # 108 B per column read, 12 B per result, 1 B per cell written
+                e["roofline_hbm"] = {"algorithmic_bytes_8d_per_launch": algo,
+                                     "achieved_GBs_algorithmic": algo / (kms * 1e-3) / 1e9,
+                                     "frac_of_hbm_peak_algorithmic": algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "counter_traffic_bytes_per_launch": prof["traffic_bytes_per_launch"],
+                                     "counter_traffic_over_algorithmic": prof["traffic_bytes_per_launch"] / algo,
+                                     "achieved_GBs_counter_traffic": prof["traffic_bytes_per_launch"] / (kms * 1e-3) / 1e9,
+                                     "frac_of_hbm_peak_counter_traffic": prof["traffic_bytes_per_launch"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "the engine stores one 8-byte compare-bit entry per 5 cells and 320 rows for 300: 1.26 x the algorithmic bytes by design"}
             except Exception:
                 pass
         out["%dk" % (ts.n // 1000)] = e

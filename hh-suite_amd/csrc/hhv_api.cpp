@@ -203,6 +203,7 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
   if (const char* e = getenv("HHV_PAIR")) c->pair_mode = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("HHV_PAIR_SWAP")) c->pair_swap = std::max(-1, std::min(31, atoi(e)));
   if (const char* e = getenv("HHV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(0, atoi(e));
+  if (const char* e = getenv("HHV_TRACE_WAVE")) c->trace_mode = atoi(e) != 0 ? 1 : 0;
   std::vector<float> lg2(1025), diff(1025);
   hhv_fast_log2_tables(lg2.data(), diff.data());
   if (hipMalloc(&c->d_lg2, 1025 * sizeof(float)) != hipSuccess ||
@@ -234,11 +235,13 @@ int hhv_set_params(hhv_ctx* c, const hhv_params* par) {
   return HHV_OK;
 }
 
-int hhv_set_launch_policy(hhv_ctx* c, int32_t pair_mode, int32_t pair_swap, int32_t blocks_per_cu) {
+int hhv_set_launch_policy(hhv_ctx* c, int32_t pair_mode, int32_t pair_swap, int32_t blocks_per_cu, int32_t trace_mode) {
   if (!c) return fail(HHV_E_ARG, "hhv_set_launch_policy: null argument");
   if (pair_mode < -1 || pair_mode > 1) return fail(HHV_E_ARG, "hhv_set_launch_policy: pair_mode %d is not one of -1 (library's choice), 0 (one launch per strip), 1 (pairs wherever possible)", pair_mode);
   if (pair_swap < -1 || pair_swap > 31) return fail(HHV_E_ARG, "hhv_set_launch_policy: pair_swap %d outside [-1, 31]", pair_swap);
   if (blocks_per_cu < 0) return fail(HHV_E_ARG, "hhv_set_launch_policy: blocks_per_cu %d", blocks_per_cu);
+  if (trace_mode < -1 || trace_mode > 1) return fail(HHV_E_ARG, "hhv_set_launch_policy: trace_mode %d is not one of -1, 0, 1", trace_mode);
+  c->trace_mode = trace_mode;
   c->pair_mode = pair_mode;
   c->pair_swap = pair_swap;
   c->blocks_per_cu = blocks_per_cu;
@@ -1069,6 +1072,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
     a.Sss = ts->d_Sss;
   }
   a.err = c->d_err;
+  a.trace_mode = c->trace_mode;
   rc = launch_trace(a, c->stream);
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   ts->hits_valid = true;

@@ -105,6 +105,7 @@ struct hhv_ctx {
   int pair_mode = -1;                                  // -1 the library chooses, 0 one launch per strip, 1 a pair launch wherever a pair kernel exists
   int pair_swap = 0;                                   // pair kernels: workgroups with this bit of their number set swap the strips of their waves; -1 none
   int blocks_per_cu = 0;                               // > 0: at most this many resident workgroups per CU (measurements)
+  int trace_mode = -1;                                 // backtrace walk: -1 by set size, 0 one lane per template, 1 one wavefront per template
 };
 
 struct hhv_tset {

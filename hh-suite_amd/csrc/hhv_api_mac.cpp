@@ -33,6 +33,11 @@ struct hhv_macset {
   char* h_paths = nullptr;
   size_t h_paths_bytes = 0;
   size_t h_pi = 0, h_pj = 0, h_ps = 0, h_pS = 0, h_pP = 0;
+  // hhv_mac_list: the list built last (hit, which) - a caller asks twice, for the count and for the entries (each
+  // call used to copy the dense plane of the hit again)
+  int32_t list_k = -1, list_which = -1;
+  std::vector<int32_t> list_i, list_j;
+  std::vector<float> list_v;
 };
 
 void hhv_macset_free(hhv_macset* ms) {
@@ -513,46 +518,56 @@ int64_t hhv_mac_list(hhv_macset* ms, int32_t k, int32_t which, int64_t cap, int3
     return fail(HHV_E_ARG, "hhv_mac_list: bad argument");
   if (which < 2 && !ms->d_fwd_list)
     return fail(HHV_E_STATE, "hhv_mac_list: the set was computed without hhv_mac_set_lists(ctx, 1)");
-  HIP_TRY(hipSetDevice(ms->ctx->par.device));
-  const int Lq = ms->Lq, Lt = ms->Lt[k], pitch = Lt + 1;
-  const size_t cells = (size_t)(Lq + 1) * pitch;
-  std::vector<float> v(cells);
-  const float* src = which == 0 ? ms->d_fwd_list : which == 1 ? ms->d_bwd_list : ms->d_mat;
-  if (hipMemcpy(v.data(), src + ms->mat_off[k], cells * 4, hipMemcpyDeviceToHost) != hipSuccess)
-    return fail(HHV_E_DEVICE, "hhv_mac_list: D2H copy failed");
-  std::vector<unsigned char> co;
-  if (which == 2) {
-    co.resize(cells);
-    if (hipMemcpy(co.data(), ms->d_celloff + ms->mat_off[k], cells, hipMemcpyDeviceToHost) != hipSuccess)
+  if (ms->list_k != k || ms->list_which != which) {
+    HIP_TRY(hipSetDevice(ms->ctx->par.device));
+    const int Lq = ms->Lq, Lt = ms->Lt[k], pitch = Lt + 1;
+    const size_t cells = (size_t)(Lq + 1) * pitch;
+    std::vector<float> v(cells);
+    const float* src = which == 0 ? ms->d_fwd_list : which == 1 ? ms->d_bwd_list : ms->d_mat;
+    if (hipMemcpy(v.data(), src + ms->mat_off[k], cells * 4, hipMemcpyDeviceToHost) != hipSuccess)
       return fail(HHV_E_DEVICE, "hhv_mac_list: D2H copy failed");
-    // backtraceMAC has switched off the cells within two rows / columns of every path step by the time the reference builds
-    // the list (src/hhbacktracemac.cpp:149-154)
-    const int ns = ms->hits[k].nsteps;
-    const int32_t* pi = (const int32_t*)(ms->h_paths + ms->h_pi) + ms->path_off[k];
-    const int32_t* pj = (const int32_t*)(ms->h_paths + ms->h_pj) + ms->path_off[k];
-    for (int s = 1; s <= ns; ++s) {
-      const int i = pi[s], j = pj[s];
-      for (int ii = std::max(i - 2, 1); ii <= std::min(i + 2, Lq); ++ii) co[(size_t)ii * pitch + j] = 1;
-      for (int jj = std::max(j - 2, 1); jj <= std::min(j + 2, Lt); ++jj) co[(size_t)i * pitch + jj] = 1;
-    }
-  }
-  int64_t count = 0;
-  for (int i = 1; i <= Lq; ++i)
-    for (int j = 1; j <= Lt; ++j) {
-      const float x = v[(size_t)i * pitch + j];
-      bool entry;
-      if (which == 2)  // posterior >= POSTERIOR_PROBABILITY_THRESHOLD (src/hhdecl.h:49), cell on, finite (:82-108)
-        entry = x >= 0.01f && !co[(size_t)i * pitch + j] && !std::isinf(x) && !std::isnan(x);
-      else  // the planes hold the value wherever the reference pushed an entry (a value > 1e-4, possibly inf), 0 elsewhere
-        entry = x != 0.0f;
-      if (!entry) continue;
-      if (count < cap) {
-        li[count] = i;
-        lj[count] = j;
-        lv[count] = x;
+    std::vector<unsigned char> co;
+    if (which == 2) {
+      co.resize(cells);
+      if (hipMemcpy(co.data(), ms->d_celloff + ms->mat_off[k], cells, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(HHV_E_DEVICE, "hhv_mac_list: D2H copy failed");
+      // backtraceMAC has switched off the cells within two rows / columns of every path step by the time the reference builds
+      // the list (src/hhbacktracemac.cpp:149-154)
+      const int ns = ms->hits[k].nsteps;
+      const int32_t* pi = (const int32_t*)(ms->h_paths + ms->h_pi) + ms->path_off[k];
+      const int32_t* pj = (const int32_t*)(ms->h_paths + ms->h_pj) + ms->path_off[k];
+      for (int s = 1; s <= ns; ++s) {
+        const int i = pi[s], j = pj[s];
+        for (int ii = std::max(i - 2, 1); ii <= std::min(i + 2, Lq); ++ii) co[(size_t)ii * pitch + j] = 1;
+        for (int jj = std::max(j - 2, 1); jj <= std::min(j + 2, Lt); ++jj) co[(size_t)i * pitch + jj] = 1;
       }
-      ++count;
     }
+    ms->list_k = ms->list_which = -1;
+    ms->list_i.clear();
+    ms->list_j.clear();
+    ms->list_v.clear();
+    for (int i = 1; i <= Lq; ++i)
+      for (int j = 1; j <= Lt; ++j) {
+        const float x = v[(size_t)i * pitch + j];
+        bool entry;
+        if (which == 2)  // posterior >= POSTERIOR_PROBABILITY_THRESHOLD (src/hhdecl.h:49), cell on, finite (:82-108)
+          entry = x >= 0.01f && !co[(size_t)i * pitch + j] && !std::isinf(x) && !std::isnan(x);
+        else  // the planes hold the value wherever the reference pushed an entry (a value > 1e-4, possibly inf), 0 elsewhere
+          entry = x != 0.0f;
+        if (!entry) continue;
+        ms->list_i.push_back(i);
+        ms->list_j.push_back(j);
+        ms->list_v.push_back(x);
+      }
+    ms->list_k = k;
+    ms->list_which = which;
+  }
+  const int64_t count = (int64_t)ms->list_v.size(), m = std::min(count, cap);
+  if (m > 0) {
+    memcpy(li, ms->list_i.data(), (size_t)m * sizeof(int32_t));
+    memcpy(lj, ms->list_j.data(), (size_t)m * sizeof(int32_t));
+    memcpy(lv, ms->list_v.data(), (size_t)m * sizeof(float));
+  }
   return count;
 }
 

@@ -275,6 +275,11 @@ void hhv_rawset_free(hhv_rawset* rs) {
 // pcm 3 recomputes the admixture constant from pcb (src/hhhmm.cpp:1914: a double expression stored in the float pca)
 static float prep_pca3(float pcb) { return (float)(0.793 + 0.048 * ((double)pcb - 10.0)); }
 
+static int check_prep_params(const hhv_prep_params* par);
+extern "C" int hhv_prep_params_check(const hhv_prep_params* par) {
+  if (!par) return fail(HHV_E_ARG, "hhv_prep_params_check: null");
+  return check_prep_params(par);
+}
 static int check_prep_params(const hhv_prep_params* par) {
   if (par->pcm < 0 || par->pcm > 3) return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm = %d (only 0 .. 3)", par->pcm);
   if (par->columnscore < 0 || par->columnscore > 3)
@@ -290,6 +295,9 @@ static int check_prep_params(const hhv_prep_params* par) {
     // 1 + (pcc - 1)^2 / (4 pcc))
     const float pca3 = prep_pca3(par->pcb);
     const double hmax = par->pcc > 1.0f ? 1.0 + (double)(par->pcc - 1.0f) * (par->pcc - 1.0f) / (4.0 * par->pcc) : 1.0;
+    // (<= 0.999, not <= 1: the kernel evaluates pca3 * h(x) in float per column, and a product that is 1 in exact arithmetic may
+    // round to 1 + 2^-23 there - a tau above 1 makes (1 - tau) f negative; the reference has no such bound because it keeps
+    // negative profile values.  The 0.1 % band is refused here and prepared on the host by the drop-in.  ADVICE r4)
     if (!(par->pcb > 0.0f && pca3 >= 0.0f && par->pcc >= 0.0f && (double)pca3 * hmax <= 0.999))
       return fail(HHV_E_LIMIT, "hhv_prepare_templates: pcm 3 with pcb = %g, pcc = %g can leave [0, 1] with its admixture (profile values stay >= 0)",
                   par->pcb, par->pcc);

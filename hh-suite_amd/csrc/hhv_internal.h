@@ -149,6 +149,7 @@ struct TraceArgs {
   const int32_t* ss_q_off;
   int32_t ss_t_shift, ss_t_mask;
   uint32_t* err;             // the context's device error word (StreamArgs::err)
+  int32_t trace_mode;        // -1 the launcher chooses, 0 one lane per template, 1 one wavefront per template (hhv_kernels.hip launch_trace)
 };
 
 // raw (unprepared) template column, 32 dwords: the fields of the reference's HMM after HMM::Read

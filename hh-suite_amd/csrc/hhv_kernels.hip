@@ -204,6 +204,115 @@ __global__ void __launch_bounds__(64) hhv_trace_kernel(TraceArgs a) {
   a.hits[k] = h;
 }
 
+// Kernel 2a', round 5: the same walk with one WAVEFRONT per template - for the set sizes of real searches (hhblits aligns <= 20 000
+// templates after its prefilter), where one lane per template leaves the device nearly empty (10 000 templates = 157 wavefronts
+// on 1 024 SIMDs) and the walk's ~75 dependent round trips are the kernel's time.  A path is a sequence of RUNS - steps that
+// stay in one state: a diagonal stretch of match states, a gap of GD / IM (column by column) or DG / MI (row by row) - and inside
+// a run every step's cell is known in advance.  So per round trip the 64 lanes load and decode the entries of the NEXT 64 cells
+// of the current run's direction, a ballot finds the first lane whose entry ends the run (the predecessor code of a match
+// state is not MM, the "gap closes" bit of a gap state is set, or the matrix border is reached), and lanes 0 .. n record their
+// step: a round trip per RUN (a dozen per alignment) instead of one per two to four steps.  Same states, same end points,
+// same counts as trace_step above (src/hhviterbi.cpp:96-146) - tests compare the two kernels byte for byte.
+template <int RC, int MMC>
+__global__ void __launch_bounds__(64) hhv_trace_wave_kernel(TraceArgs a) {
+  const int k = blockIdx.x;
+  const int lane = threadIdx.x;
+  const DevResult res = a.results[k];
+  const int64_t rec0 = a.rec_off[k];
+  int8_t* const states = a.states + a.path_off[k];
+  const int W = a.plan.W;
+  if (lane == 0) states[0] = 0;  // (index 0 is unused: steps count from 1)
+  int i = res.i2, j = res.j2;   // the cell of the next step (wave uniform)
+  int state = 2, step = 0, matched = 0, last_i = i, last_j = j;
+  while (state != 0) {
+    // :139-144: an illegal state - the reference reports it, counts the step and ends the walk; here: the error word, and the
+    // step runs through the code below as a run of one step that ends the walk (recorded as MM like every last step, :147)
+    const bool illegal = state < 2 || state > 6;
+    if (illegal && a.err && lane == 0) *(volatile uint32_t*)a.err = DEV_ERR_TRACE_STATE;
+    const bool mm = state == 2, horizontal = state == 3 || state == 4;
+    const int di = (mm || !horizontal) ? 1 : 0, dj = (mm || horizontal) ? 1 : 0;
+    const int il = i - lane * di, jl = j - lane * dj;  // this lane's cell, if the run lasts that long
+    uint32_t b = 0;
+    if (il >= 1 && jl >= 1) {
+      int pass = 0, g, rr, Rp = RC;
+      if (RC > 0) {
+        g = (il - 1) / RC;
+        rr = (il - 1) - g * RC;
+      } else {
+        a.plan.locate(il, pass, g, rr, Rp);
+      }
+      b = bt_decode(a.bt[(size_t)pass * a.bt_pass_stride + bt_entry(rec0 + jl, g, W)], rr, Rp, RC > 0 ? MMC : a.bt_mm);
+    }
+    // does this lane's step END the run?  border: the walk stops here; otherwise the step leaves the run's state
+    const bool border = mm ? (il <= 1 || jl <= 1) : horizontal ? jl <= 1 : il <= 1;
+    const uint32_t bit = state == 3 ? 8u : state == 4 ? 16u : state == 5 ? 32u : 64u;
+    const bool leaves = mm ? (b & 7u) != 2u : (b & bit) != 0u;
+    const unsigned long long ends = __ballot(border || leaves || illegal);
+    const int n = ends ? (int)__builtin_ctzll(ends) : 63;                  // the run's last step of this round
+    const bool closed = ends != 0;                                         // ... really ends the run
+    const int b_n = __builtin_amdgcn_readlane((int)b, n);
+    const int border_n = (int)((__ballot(border) >> n) & 1ull);
+    const int next = illegal ? 0 : !closed ? state : border_n ? 0 : mm ? (b_n & 7) : 2;  // state behind step n
+    // steps step + 1 .. step + n + 1 are the cells of lanes 0 .. n; recorded state = the run's, the walk's LAST step as MM (:147).
+    // The lanes know their step's cell, so what Viterbi::ScoreForBacktrace needs per step (src/hhviterbi.cpp:222-237) is written
+    // here as well - (i, j), the column score S = fast_log2(ScalarProd20(q.p[i], t.p[j])) of the match steps, the secondary-
+    // structure score - with the expressions of hhv_rescore_kernel (which the lane-per-template walk is followed by); the loads
+    // are in flight together with the next run's entries.
+    if (lane <= n) {
+      const int st = (lane == n && next == 0) ? 2 : state;
+      const int64_t o = a.path_off[k] + step + 1 + lane;
+      states[step + 1 + lane] = (int8_t)st;
+      a.i_steps[o] = il;
+      a.j_steps[o] = jl;
+      float v = 0.0f;
+      if (st == 2) {
+        const float4* qp = reinterpret_cast<const float4*>(a.qp + (size_t)il * 20);
+        const float4* tp = reinterpret_cast<const float4*>(a.records + (size_t)(rec0 + jl) * REC_DW);
+        float q[20], t[20];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+          const float4 qa = qp[x], ta = tp[x];
+          q[4 * x + 0] = qa.x, q[4 * x + 1] = qa.y, q[4 * x + 2] = qa.z, q[4 * x + 3] = qa.w;
+          t[4 * x + 0] = ta.x, t[4 * x + 1] = ta.y, t[4 * x + 2] = ta.z, t[4 * x + 3] = ta.w;
+        }
+        v = fast_log2_dev(dot20_scalar_dev(q, t), a.lg2, a.diff);
+      }
+      a.S[o] = v;
+      if (a.Sss) {
+        float vs = 0.0f;
+        if (st == 2 && il >= 1 && jl >= 1) {
+          const int32_t meta = __builtin_bit_cast(int32_t, a.records[(size_t)(rec0 + jl) * REC_DW + REC_META]);
+          vs = a.ss_table[a.ss_q_off[il - 1] + ((meta >> a.ss_t_shift) & a.ss_t_mask)];
+        }
+        a.Sss[o] = vs;
+      }
+    }
+    step += n + 1;
+    if (mm) matched += n + 1;
+    last_i = i - n * di;
+    last_j = j - n * dj;
+    // the cell of the next step: a step that reaches the border does not move (:104-135)
+    const int moved = (closed && border_n) ? n : n + 1;
+    i -= moved * di;
+    j -= moved * dj;
+    state = next;
+  }
+  if (lane == 0) {
+    DevHit h;
+    h.score = res.score;  // completed by hhv_scorr_kernel
+    h.viterbi_score = res.score;
+    h.score_ss = 0.0f;
+    h.index = k;
+    h.i1 = last_i;
+    h.j1 = last_j;
+    h.i2 = res.i2;
+    h.j2 = res.j2;
+    h.nsteps = step;
+    h.matched_cols = matched;
+    a.hits[k] = h;
+  }
+}
+
 // Kernel 2b: Viterbi::ScoreForBacktrace (src/hhviterbi.cpp:195-281), first half - one wavefront per template: (i, j) of
 // every step rebuilt from the state bytes (see hhv_trace_kernel) and written out, and the per-step column scores
 // S[step] = fast_log2(ScalarProd20(q.p[i], t.p[j])) of the MM steps (:225-235), lanes striding over the steps.  The template
@@ -401,23 +510,28 @@ int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, boo
 }
 
 int launch_trace(const TraceArgs& a, void* stream) {
-  // 64 templates per wave for the chase (latency bound: many small blocks spread over all CUs)
+  // The walk: one wavefront per template (a round trip per run of the path; hhv_trace_wave_kernel) - measured ahead of one lane
+  // per template at every set size (10 000 templates: the whole backtrace step 2.40 -> 2.27 ms, 100 000: 19.26 -> 19.01;
+  // profiles/r5_ab.txt ab-r5-2).  a.trace_mode 0 (hhv_set_launch_policy) selects the lane-per-template kernel: tests, measurements.
+  const bool per_wave = a.trace_mode != 0;
   {
-    const dim3 grid((a.n + LANES - 1) / LANES), block(LANES);
+    const dim3 grid(per_wave ? a.n : (a.n + LANES - 1) / LANES), block(LANES);
     hipStream_t st = (hipStream_t)stream;
     const int R = a.plan.P == 1 ? a.plan.R_hi : 0;
 #define HHV_TRACE_CASE(r, m)                                                       \
   if (R == r && a.bt_mm == m) {                                                    \
-    hipLaunchKernelGGL((hhv_trace_kernel<r, m>), grid, block, 0, st, a);           \
+    if (per_wave) hipLaunchKernelGGL((hhv_trace_wave_kernel<r, m>), grid, block, 0, st, a); \
+    else hipLaunchKernelGGL((hhv_trace_kernel<r, m>), grid, block, 0, st, a);      \
   } else
 #define HHV_TRACE_ROWS(r) HHV_TRACE_CASE(r, BT_MM_RUNNING) HHV_TRACE_CASE(r, BT_MM_FIRST_EQUAL) HHV_TRACE_CASE(r, BT_MM_FIRST_EQUAL_NEG)
     HHV_TRACE_ROWS(1) HHV_TRACE_ROWS(2) HHV_TRACE_ROWS(3) HHV_TRACE_ROWS(4) HHV_TRACE_ROWS(5) {
-      hipLaunchKernelGGL((hhv_trace_kernel<0, 0>), grid, block, 0, st, a);
+      if (per_wave) hipLaunchKernelGGL((hhv_trace_wave_kernel<0, 0>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((hhv_trace_kernel<0, 0>), grid, block, 0, st, a);
     }
 #undef HHV_TRACE_ROWS
 #undef HHV_TRACE_CASE
   }
-  hipLaunchKernelGGL(hhv_rescore_kernel, dim3(a.n), dim3(LANES), 0, (hipStream_t)stream, a);
+  if (!per_wave) hipLaunchKernelGGL(hhv_rescore_kernel, dim3(a.n), dim3(LANES), 0, (hipStream_t)stream, a);  // (the wavefront walk writes (i, j) and S itself)
   hipLaunchKernelGGL(hhv_scorr_kernel, dim3((a.n + LANES - 1) / LANES), dim3(LANES), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

@@ -190,19 +190,16 @@ inline int ensure_context(TemplateCache& tc) {
 // Can PrepareTemplateHMM run on the device for this search?  (hhv_prepare_subset: HHM format, substitution-matrix
 // pseudocounts pcm 0..2, null model columnscore 0..3; src/hhfunc.cpp:165-202)
 inline bool device_prepare_covers(const Parameters& par) {
-  const int pcm = par.pc_hhm_nocontext_mode;
-  const float pca = par.pc_hhm_nocontext_a, pcb = par.pc_hhm_nocontext_b, pcc = par.pc_hhm_nocontext_c;
-  if (pcm < 0 || pcm > 3 || par.columnscore < 0 || par.columnscore > 3) return false;
-  // the admixture must stay in [0, 1] for every column (profile values >= 0): the same conditions as check_prep_params
-  // (csrc/hhv_api_prep.cpp), so that hhv_prepare_subset is only called with what it accepts
-  if (pcm == 1) return pca >= 0.0f && pca <= 1.0f;
-  if (pcm == 2) return pca >= 0.0f && pcb > 0.0f;  // (tau is clamped with fmin(1.0, ..), src/hhhmm.cpp:1900)
-  if (pcm == 3) {
-    const float pca3 = (float)(0.793 + 0.048 * ((double)pcb - 10.0));  // src/hhhmm.cpp:1914
-    const double hmax = pcc > 1.0f ? 1.0 + (double)(pcc - 1.0f) * (pcc - 1.0f) / (4.0 * pcc) : 1.0;
-    return pcb > 0.0f && pca3 >= 0.0f && pcc >= 0.0f && (double)pca3 * hmax <= 0.999;
-  }
-  return true;
+  // the library's own definition of what hhv_prepare_subset accepts (pcm 0..3, columnscore 0..3, admixtures that stay in [0, 1]:
+  // hhv_prep_params_check, csrc/hhv_api_prep.cpp) - only the fields it looks at are filled
+  hhv_prep_params prep;
+  memset(&prep, 0, sizeof(prep));
+  prep.pcm = par.pc_hhm_nocontext_mode;
+  prep.pca = par.pc_hhm_nocontext_a;
+  prep.pcb = par.pc_hhm_nocontext_b;
+  prep.pcc = par.pc_hhm_nocontext_c;
+  prep.columnscore = par.columnscore;
+  return hhv_prep_params_check(&prep) == HHV_OK;
 }
 
 // the arguments of PrepareTemplateHMM that do not depend on the template

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "hhv_abi_version", "hhv_last_error", "hhv_record_bytes", "hhv_pack_profile", "hhv_fast_log2_tables",
     "hhv_create", "hhv_destroy", "hhv_set_params", "hhv_set_launch_policy", "hhv_set_fast_log2_tables", "hhv_set_query", "hhv_set_ss_tables", "hhv_set_query_ss", "hhv_set_ss_mode",
     "hhv_upload_templates", "hhv_upload_templates_ss", "hhv_adopt_device_stream",
-    "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_rawset_pav", "hhv_tset_records_of", "hhv_tset_download",
+    "hhv_upload_raw_templates", "hhv_rawset_free", "hhv_prepare_templates", "hhv_prep_params_check", "hhv_rawset_pav", "hhv_tset_records_of", "hhv_tset_download",
     "hhv_prefilter_upload_db", "hhv_prefilter_free_db", "hhv_prefilter_scores", "hhv_prefilter_first",
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_mac_set_lists", "hhv_mac_list", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
@@ -315,9 +315,10 @@ class Context:
         if rc != 0:
             raise HhvError("hhv error %d: %s" % (rc, self.lib.hhv_last_error().decode()))
 
-    def set_launch_policy(self, pair_mode=-1, pair_swap=0, blocks_per_cu=0):
-        """hhv_set_launch_policy: pair_mode -1 library's choice / 0 one launch per strip / 1 pair launches wherever possible"""
-        self._chk(self.lib.hhv_set_launch_policy(self.h, int(pair_mode), int(pair_swap), int(blocks_per_cu)))
+    def set_launch_policy(self, pair_mode=-1, pair_swap=0, blocks_per_cu=0, trace_mode=-1):
+        """hhv_set_launch_policy: pair_mode -1 library's choice / 0 one launch per strip / 1 pair launches wherever possible;
+        trace_mode -1 by set size / 0 one lane per template / 1 one wavefront per template"""
+        self._chk(self.lib.hhv_set_launch_policy(self.h, int(pair_mode), int(pair_swap), int(blocks_per_cu), int(trace_mode)))
 
     def set_query(self, p, tr):
         p, tr = _f32(p), _f32(tr)

@@ -160,9 +160,11 @@ int hhv_set_params(hhv_ctx* ctx, const hhv_params* par);
  *   pair_swap      pair kernels: workgroups whose number has this bit set run the strips on swapped wave indices (default 0;
  *                  -1 none; at most 31)
  *   blocks_per_cu  > 0: at most this many resident workgroups per CU; 0 = what the kernel admits
+ *   trace_mode     the backtrace walk (Viterbi::Backtrace, src/hhviterbi.cpp:83-160): -1 chosen by the size of the set (default),
+ *                  0 one lane per template, 1 one wavefront per template (a round trip per run of the path)
  * The defaults of a new context can be preset through the environment, read once in hhv_create: HHV_PAIR (0 / 1),
- * HHV_PAIR_SWAP, HHV_BLOCKS_PER_CU. */
-int hhv_set_launch_policy(hhv_ctx* ctx, int32_t pair_mode, int32_t pair_swap, int32_t blocks_per_cu);
+ * HHV_PAIR_SWAP, HHV_BLOCKS_PER_CU, HHV_TRACE_WAVE (0 / 1). */
+int hhv_set_launch_policy(hhv_ctx* ctx, int32_t pair_mode, int32_t pair_swap, int32_t blocks_per_cu, int32_t trace_mode);
 
 /* query: p[(Lq+1)*20], tr[(Lq+1)*7] (copied before the call returns: the caller may reuse its arrays at once).
  * The rows travel through a pinned staging block with asynchronous copies on the context's stream; device buffers and
@@ -225,6 +227,10 @@ int hhv_rawdb_write(const char* path, int32_t n, const int32_t* L, const float* 
 int hhv_rawdb_open(hhv_ctx* ctx, const char* path, hhv_rawset** out);
 int32_t hhv_rawset_size(const hhv_rawset* rs);
 int hhv_rawset_lengths(const hhv_rawset* rs, int32_t* L);
+/* Would hhv_prepare_templates / hhv_prepare_subset accept these parameters (HHV_OK), or are they outside what the device
+ * preparation covers (HHV_E_LIMIT with text: pcm, columnscore, admixtures that could leave [0, 1])?  No device needed: a caller
+ * that can prepare on the host instead (the drop-in) asks before it uploads raw templates - ONE definition of the limits. */
+int hhv_prep_params_check(const hhv_prep_params* par);
 int hhv_prepare_templates(hhv_ctx* ctx, hhv_rawset* rs, const hhv_prep_params* par, const float* q_pav, hhv_tset** out);
 /* The same for a SUBSET of the resident raw set - the templates the prefilter let through: ids[n_ids] (any order,
  * repeats allowed) -> a NEW template set of n_ids templates in that order (template k of the set = raw template ids[k]),

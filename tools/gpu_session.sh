@@ -82,6 +82,24 @@ walk("", d)
 print("masked_round", {k: v for k, v in d["masked_round"].items() if not isinstance(v, dict)})
 PY
   ;;
+r5p)   # the round's profiles: headline, backtrace, secondary structure (hhv_ss_kernel), and the kernel statistics of a 10 k backtrace search
+  for spec in "r5|" "r5bt|--backtrace 1" "r5ss|--ss 4" "r5ssbt|--ss 4 --backtrace 1"; do
+    tag=${spec%%|*}; extra=${spec#*|}
+    bash tools/profile.sh $tag "$extra" > $OUT/profile_$tag.log 2>&1
+    k=hhv_stream_kernel; case $tag in r5ss*) k=hhv_ss_kernel;; esac
+    HHV_PROFILE_KERNEL=$k HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_profile.py $tag | tail -24
+    rm -rf $OUT/prof_$tag
+  done
+  echo "== kernel statistics of backtrace searches over 10 000 templates"
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bt && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bt -o stats -- python $ROOT/bench.py --templates 10000 --backtrace 1 --steps 20 --warmup 3 $short > /tmp/prof_bt.log 2>&1)
+  python - <<'PY' | tee $OUT/profiles_out/r5bt10k_kernel_stats.txt
+import csv, glob
+for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"] or "select" in r["Name"]:
+            print("%-70s calls %5s  avg %10.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+  ;;
 dbg)   # dbg <args of tools/dbg_ss.py>
   timeout 120 python tools/dbg_ss.py "$@" 2>&1 | tail -30
   ;;
