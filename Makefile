@@ -93,14 +93,22 @@ clean:
 	rm -rf build $(LIBDIR) tests/emul/libwave_emul.so
 	$(MAKE) -C oracle clean
 
-.PHONY: example example_rccl all lib lib_fma lib_pto lib_variant oracle emul clean
+PHONY_EXTRA := rccl_runner
+.PHONY: example example_rccl rccl_runner all lib lib_fma lib_pto lib_variant oracle emul clean
 
 # plain-C++ use of the host classes (no Python): examples/search_example.cpp
 example: $(RUNNER)
 	g++ -O2 -std=c++14 -Wall -Iinclude -o build/search_example examples/search_example.cpp -L$(LIBDIR) -lhhv_runner -lhhviterbi_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
-# the sharded search as a native multi-process program: one rank per GPU, librccl directly (examples/sharded_search_rccl.cpp)
+# hhv::RcclShardedRunner (hh-suite_amd/host/rccl_runner.h): the sharded search for multi-process hosts, one process per GPU - the C
+# ABI + librccl (a library of its own: the C-ABI library itself does not depend on RCCL)
+RCCL_RUNNER := $(LIBDIR)/libhhv_rccl_runner.so
+rccl_runner: $(RCCL_RUNNER)
+$(RCCL_RUNNER): hh-suite_amd/host/rccl_runner.cpp hh-suite_amd/host/rccl_runner.h hh-suite_amd/host/viterbi_runner.h include/hhviterbi_hip.h $(LIB)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wall -fPIC -shared -Iinclude -o $@ hh-suite_amd/host/rccl_runner.cpp -L$(LIBDIR) -lhhviterbi_hip -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+
+# the sharded search as a native multi-process program on top of it (examples/sharded_search_rccl.cpp)
 example_rccl: build/sharded_search_rccl
-build/sharded_search_rccl: examples/sharded_search_rccl.cpp include/hhviterbi_hip.h $(LIB)
+build/sharded_search_rccl: examples/sharded_search_rccl.cpp examples/synth8d.h include/hhviterbi_hip.h $(RCCL_RUNNER)
 	@mkdir -p build
-	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wall -Iinclude -o build/sharded_search_rccl examples/sharded_search_rccl.cpp -L$(LIBDIR) -lhhviterbi_hip -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wall -Iinclude -o build/sharded_search_rccl examples/sharded_search_rccl.cpp -L$(LIBDIR) -lhhv_rccl_runner -lhhviterbi_hip -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
