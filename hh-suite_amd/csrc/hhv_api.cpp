@@ -802,7 +802,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     a.carry_mi = ts->d_carry_mi;
   }
   // Two strips (321 .. 640 query rows): ONE launch of two-wave workgroups, the first strip's bottom row handed to the second
-  // through LDS (hhv_stream_kernel.h PairLds) instead of two launches with the row in HBM.  Not for masked rounds, the ...AndSS
+  // through LDS (hhv_stream_kernel.h PairLds) instead of two launches with the row in HBM.  Not for masked rounds, five-row ...AndSS
   // builds and five-row backtrace strips (LDS-parked query rows).  Score-only strips of UNEQUAL height (4 + 3, 5 + 4 rows per
   // lane) stay two launches: the lock step of a heavy and a light wave costs the pair more than the HBM carry costs the
   // launches since the first strip has kernels of its own (Lq 431: 12.13 vs 11.77 ms, profiles/r4_ab.txt ab-r4-7); with
@@ -810,7 +810,7 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   // More than two strips: a CHAIN of launches - neighbouring strips two by two as pair launches (HBM carries only between the
   // links: half the launches, half the rows through HBM), a strip without a partner or without a pair kernel as a launch of its
   // own.  hhv_set_launch_policy pair_mode 0 / 1: never / whenever a pair kernel exists (tests, measurements).
-  const bool pairs_possible = queue && plan.P >= 2 && plan.W == LANES && !celloff && !ss && c->pair_mode != 0;
+  const bool pairs_possible = queue && plan.P >= 2 && plan.W == LANES && !celloff && c->pair_mode != 0;
   const bool pairs_forced = c->pair_mode == 1;
   a.pair_swap = c->pair_swap;
   a.err = c->d_err;
@@ -824,13 +824,16 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
     if (pairs_possible && pass + 1 < plan.P) {
       chain = (pass > 0 ? 1 : 0) | (pass + 2 < plan.P ? 2 : 0);
       const bool wanted = pairs_forced || plan.P > 2 || bt || plan.R(0) == plan.R(1);
-      if (wanted) pair_wgs = pair_kernel_occupancy(plan.R(pass), plan.R(pass + 1), local, bt, chain);
+      if (wanted) pair_wgs = pair_kernel_occupancy(plan.R(pass), plan.R(pass + 1), local, bt, chain, ss);
     }
     if (pair_wgs > 0) {
-      const int n_wg = std::max(1, std::min(c->num_cus * pair_wgs, ts->n_seg));
+      // (pairs = two-wave arrays; the ...AndSS kernels have four of them per workgroup: whole workgroups, a pair beyond the last
+      // segment returns at once)
+      const int ppw = pair_kernel_pairs_per_workgroup(ss);
+      const int n_wg = (std::max(1, std::min(c->num_cus * pair_wgs, ts->n_seg)) + ppw - 1) / ppw * ppw;
       a.pass_last = 0;  // (the kernel gives its two waves their own)
-      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // workgroup k starts with segment k
-      rc = launch_pair(plan.R(pass), plan.R(pass + 1), local, bt, chain, a, n_wg, c->stream);
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // pair k starts with segment k
+      rc = launch_pair(plan.R(pass), plan.R(pass + 1), local, bt, chain, ss, a, n_wg, c->stream);
       pass += 2;
     } else {
       a.pass_last = pass == plan.P - 1;

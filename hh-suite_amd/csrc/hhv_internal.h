@@ -323,8 +323,9 @@ int stream_kernel_waves(int W, bool ss);  // wavefronts per workgroup of the ker
 // per-W instantiation units (hhv_kernels.hip: 64, hhv_kernels_w32.hip, hhv_kernels_w16.hip)
 void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip);
 // two-strip queries as one launch of two-wave workgroups (hhv_kernels_pair.hip)
-int launch_pair(int R0, int R1, bool local, bool bt, int chain, const StreamArgs& a, int n_workgroups, void* stream);
-int pair_kernel_occupancy(int R0, int R1, bool local, bool bt, int chain);
+int launch_pair(int R0, int R1, bool local, bool bt, int chain, bool ss, const StreamArgs& a, int n_pairs, void* stream);
+int pair_kernel_pairs_per_workgroup(bool ss);
+int pair_kernel_occupancy(int R0, int R1, bool local, bool bt, int chain, bool ss);  // pairs (two-wave arrays) per CU, 0 = no such kernel
 void* stream_kernel_w32(int R, bool local, bool bt, bool celloff, bool ss);
 void* stream_kernel_w16(int R, bool local, bool bt, bool celloff, bool ss);
 // one template's mask bytes -> cell-off entries; entries -> the reference's backtrace byte matrix (hhv_topk.hip)

@@ -8,6 +8,15 @@
 
 namespace hhv {
 
+// the ...AndSS pair kernels (hhv_ss_pair_kernel: four pairs per workgroup around one LDS copy of the score table): strips of
+// three and four rows per lane (five-row strips have no registers left for the table values next to the FIFO row)
+template <bool LOCAL, bool BT, int CHAIN>
+static void* ss_pair_kernel_ptr(int R0, int R1) {
+  if (R0 == 3 && R1 == 3) return (void*)hhv_ss_pair_kernel<3, 3, LOCAL, BT, CHAIN>;
+  if (R0 == 4 && R1 == 3) return (void*)hhv_ss_pair_kernel<4, 3, LOCAL, BT, CHAIN>;
+  if (R0 == 4 && R1 == 4) return (void*)hhv_ss_pair_kernel<4, 4, LOCAL, BT, CHAIN>;
+  return nullptr;
+}
 template <bool LOCAL, bool BT, int CHAIN>
 static void* pair_kernel_ptr(int R0, int R1) {
   if (R0 == 3 && R1 == 3) return (void*)hhv_pair_kernel<3, 3, LOCAL, BT, CHAIN>;
@@ -22,42 +31,50 @@ static void* pair_kernel_ptr(int R0, int R1) {
   return nullptr;
 }
 template <int CHAIN>
-static void* pair_kernel_pick(int R0, int R1, bool local, bool bt) {
+static void* pair_kernel_pick(int R0, int R1, bool local, bool bt, bool ss) {
+  if (ss) {
+    if (bt) return local ? ss_pair_kernel_ptr<true, true, CHAIN>(R0, R1) : ss_pair_kernel_ptr<false, true, CHAIN>(R0, R1);
+    return local ? ss_pair_kernel_ptr<true, false, CHAIN>(R0, R1) : ss_pair_kernel_ptr<false, false, CHAIN>(R0, R1);
+  }
   if (bt) return local ? pair_kernel_ptr<true, true, CHAIN>(R0, R1) : pair_kernel_ptr<false, true, CHAIN>(R0, R1);
   return local ? pair_kernel_ptr<true, false, CHAIN>(R0, R1) : pair_kernel_ptr<false, false, CHAIN>(R0, R1);
 }
 
 // chain: bit 0 = not the first link of a chain of launches, bit 1 = not the last (hhv_pair_kernel)
-void* pair_kernel(int R0, int R1, bool local, bool bt, int chain) {
+void* pair_kernel(int R0, int R1, bool local, bool bt, int chain, bool ss) {
   switch (chain & 3) {
-    case 0: return pair_kernel_pick<0>(R0, R1, local, bt);
-    case 1: return pair_kernel_pick<1>(R0, R1, local, bt);
-    case 2: return pair_kernel_pick<2>(R0, R1, local, bt);
-    default: return pair_kernel_pick<3>(R0, R1, local, bt);
+    case 0: return pair_kernel_pick<0>(R0, R1, local, bt, ss);
+    case 1: return pair_kernel_pick<1>(R0, R1, local, bt, ss);
+    case 2: return pair_kernel_pick<2>(R0, R1, local, bt, ss);
+    default: return pair_kernel_pick<3>(R0, R1, local, bt, ss);
   }
 }
 
-int launch_pair(int R0, int R1, bool local, bool bt, int chain, const StreamArgs& a, int n_workgroups, void* stream) {
-  void* fn = pair_kernel(R0, R1, local, bt, chain);
+// n_pairs: two-wave systolic arrays to start (ss: four of them per workgroup - hhv_ss_pair_kernel; the caller rounds up)
+int launch_pair(int R0, int R1, bool local, bool bt, int chain, bool ss, const StreamArgs& a, int n_pairs, void* stream) {
+  void* fn = pair_kernel(R0, R1, local, bt, chain, ss);
   if (!fn) return -1;
   StreamArgs args = a;
   void* kargs[] = {&args};
-  const hipError_t e = hipLaunchKernel(fn, dim3(n_workgroups), dim3(2 * LANES), kargs, 0, (hipStream_t)stream);
+  const hipError_t e = ss ? hipLaunchKernel(fn, dim3((n_pairs + SS_PAIRS - 1) / SS_PAIRS), dim3(SS_WAVES * LANES), kargs, 0, (hipStream_t)stream)
+                          : hipLaunchKernel(fn, dim3(n_pairs), dim3(2 * LANES), kargs, 0, (hipStream_t)stream);
   return e == hipSuccess ? 0 : -(int)e;
 }
+int pair_kernel_pairs_per_workgroup(bool ss) { return ss ? SS_PAIRS : 1; }
 
-// workgroups (of two wavefronts) a CU holds; 0 = no pair kernel for these strips
-int pair_kernel_occupancy(int R0, int R1, bool local, bool bt, int chain) {
-  void* fn = pair_kernel(R0, R1, local, bt, chain);
+// PAIRS (two-wave systolic arrays) a CU holds; 0 = no pair kernel for these strips
+int pair_kernel_occupancy(int R0, int R1, bool local, bool bt, int chain, bool ss) {
+  void* fn = pair_kernel(R0, R1, local, bt, chain, ss);
   if (!fn) return 0;
   // asked once per kernel (every search of a multi-strip query comes through here; the devices of a process are of one kind).
   // Concurrent first calls store the same value.
-  static std::atomic<int> cache[6][6][2][2][4];
-  std::atomic<int>& slot = cache[R0][R1][local ? 1 : 0][bt ? 1 : 0][chain & 3];
+  static std::atomic<int> cache[6][6][2][2][4][2];
+  std::atomic<int>& slot = cache[R0][R1][local ? 1 : 0][bt ? 1 : 0][chain & 3][ss ? 1 : 0];
   int nb = slot.load(std::memory_order_relaxed) - 1;  // (0 = not asked yet)
   if (nb >= 0) return nb;
   nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 2 * LANES, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, ss ? SS_WAVES * LANES : 2 * LANES, 0) != hipSuccess) return 0;
+  nb *= ss ? SS_PAIRS : 1;
   slot.store(nb + 1, std::memory_order_relaxed);
   return nb;
 }

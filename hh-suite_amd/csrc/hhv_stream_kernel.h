@@ -520,7 +520,8 @@ struct StreamSmem {
 // one-launch-per-strip plan - known at compile time, so that its steps contain no code of the later strips (whose carry loads make
 // hipcc wait vmcnt(0) in every step of a body that contains them, whichever role it plays at run time).
 template <int R, bool LOCAL, bool BT, bool CELLOFF, bool MULTI, bool SS, int W, int PM>
-__device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0, float4* const smem, const uint32_t ss_tab = 0) {
+__device__ __forceinline__ void stream_body(const StreamArgs& a, const int array0, float4* const smem, const uint32_t ss_tab = 0,
+                                            PairLds* const pair_of_wave = nullptr) {
   const int lane = (int)(threadIdx.x & (LANES - 1));  // (the wavefront's lane: workgroups have one, two (pairs) or eight (hhv_ss_kernel) wavefronts)
   // PW0 / PW1: first / second wavefront of a pair.  PM 4 / 5 are the waves of a pair that is one link of a longer chain of
   // strips (queries of more than two strips run as a sequence of pair launches, round 4): 4 = first wave of a LATER pair - its
@@ -528,9 +529,9 @@ __device__ __forceinline__ void stream_body(const StreamArgs& a, const int array
   // 5 = second wave of a pair that is NOT the last - FIFO in, its own bottom row out to HBM for the next launch.
   constexpr bool PW0 = PM == 1 || PM == 4, PW1 = PM == 2 || PM == 5;
   constexpr bool PAIRED = PW0 || PW1;
-  static_assert(!PAIRED || (MULTI && W == LANES && !CELLOFF && !SS && !(BT && R == 5)), "pair variants: two strips, 64 lanes, no cell-off / SS, no LDS-parked query rows");
+  static_assert(!PAIRED || (MULTI && W == LANES && !CELLOFF && !(BT && R == 5)), "pair variants: two strips, 64 lanes, no cell-off, no LDS-parked query rows");
   static_assert(PM != 3 || MULTI, "first strip of a multi-strip plan");
-  PairLds* const pair = PAIRED ? pair_lds() : nullptr;
+  PairLds* const pair = PAIRED ? pair_of_wave : nullptr;  // (the FIFO and the control words of the two-wave workgroup / of this pair of the workgroup)
   const uint32_t pair_carry_addr = PAIRED ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&pair->carry[0][0] : 0u;
   static_assert(W == 64 || W == 32 || W == 16, "lanes per array");
   static_assert(!MULTI || W == LANES, "short-query arrays are single pass");
@@ -1101,7 +1102,7 @@ __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
     a0.pass_first = (CHAIN & 1) ? 0 : 1;
     a0.pass_last = 0;
     __shared__ float4 smem0[StreamSmem<R0, BT, LANES>::F4];
-    stream_body<R0, LOCAL, BT, false, true, false, LANES, ((CHAIN & 1) ? 4 : 1)>(a0, (int)blockIdx.x, smem0);
+    stream_body<R0, LOCAL, BT, false, true, false, LANES, ((CHAIN & 1) ? 4 : 1)>(a0, (int)blockIdx.x, smem0, 0, p);
   } else {
     StreamArgs a1 = a;
     a1.row_base = a.row_base + LANES * R0;
@@ -1110,7 +1111,49 @@ __global__ void __launch_bounds__(2 * LANES, 2) hhv_pair_kernel(StreamArgs a) {
     a1.pass_first = 0;
     a1.pass_last = (CHAIN & 2) ? 0 : 1;
     __shared__ float4 smem1[StreamSmem<R1, BT, LANES>::F4];
-    stream_body<R1, LOCAL, BT, false, true, false, LANES, ((CHAIN & 2) ? 5 : 2)>(a1, (int)blockIdx.x, smem1);
+    stream_body<R1, LOCAL, BT, false, true, false, LANES, ((CHAIN & 2) ? 5 : 2)>(a1, (int)blockIdx.x, smem1, 0, p);
+  }
+}
+
+// The same for the ...AndSS variants: FOUR pairs per workgroup (eight wavefronts, like hhv_ss_kernel) around one LDS copy of the
+// score table: 4 x (8 KB FIFO + 2 x 14 KB rings) + 7.6 KB = 152 KB.  Pair number = wavefront / 2; the pairs are independent of
+// each other (each has its PairLds, draws its own segments), the two waves of a pair work together exactly as in hhv_pair_kernel.
+constexpr int SS_PAIRS = SS_WAVES / 2;
+template <int R0, int R1, bool LOCAL, bool BT, int CHAIN = 0>
+__global__ void __launch_bounds__(SS_WAVES * LANES, 2) hhv_ss_pair_kernel(StreamArgs a) {
+  constexpr int F0 = StreamSmem<R0, BT, LANES>::F4, F1 = StreamSmem<R1, BT, LANES>::F4;
+  __shared__ PairLds pl[SS_PAIRS];
+  __shared__ float4 smem0[SS_PAIRS * F0];
+  __shared__ float4 smem1[SS_PAIRS * F1];
+  __shared__ float tab[SS_TAB_FLOATS];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = (int)threadIdx.x + k * SS_WAVES * LANES;
+    if (e < a.ss_tab_n) tab[e] = a.ss_table[e];
+  }
+  if (threadIdx.x < SS_PAIRS) {
+    pl[threadIdx.x].seg_count = 0;
+    pl[threadIdx.x].w0_done = 0;
+    pl[threadIdx.x].w1_done = 0;
+  }
+  __syncthreads();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pw = wv >> 1, pair_no = (int)blockIdx.x * SS_PAIRS + pw;
+  const int swap = a.pair_swap >= 0 ? (pair_no >> a.pair_swap) & 1 : 0;
+  const uint32_t tab_addr = lds_addr_of(tab);
+  if (((wv & 1) ^ swap) == 0) {
+    StreamArgs a0 = a;
+    a0.pass_first = (CHAIN & 1) ? 0 : 1;
+    a0.pass_last = 0;
+    stream_body<R0, LOCAL, BT, false, true, true, LANES, ((CHAIN & 1) ? 4 : 1)>(a0, pair_no, smem0 + pw * F0, tab_addr, &pl[pw]);
+  } else {
+    StreamArgs a1 = a;
+    a1.row_base = a.row_base + LANES * R0;
+    a1.qpack = a.qpack + (size_t)(LANES * R0) * REC_DW;
+    a1.bt_plane = a.bt_plane + 1;
+    a1.pass_first = 0;
+    a1.pass_last = (CHAIN & 2) ? 0 : 1;
+    stream_body<R1, LOCAL, BT, false, true, true, LANES, ((CHAIN & 2) ? 5 : 2)>(a1, pair_no, smem1 + pw * F1, tab_addr, &pl[pw]);
   }
 }
 // ---- kernel selection (instantiates the variants of one W in the including unit) --------------------------------------

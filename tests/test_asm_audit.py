@@ -12,4 +12,4 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_stream_kernel_isa_audit():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
-    assert "audited 358" in out.stdout, out.stdout   # W = 64: 60 + 30 (first-strip kernels) hhv_stream_kernel and as many hhv_ss_kernel; 60 each of W = 32 and W = 16; 58 pair kernels (16 x 4 chain positions - 6 that spill)
+    assert "audited 406" in out.stdout, out.stdout   # W = 64: 60 + 30 (first-strip kernels) hhv_stream_kernel and as many hhv_ss_kernel; 60 each of W = 32 and W = 16; 58 pair kernels (16 x 4 chain positions - 6 that spill) + 48 hhv_ss_pair_kernel (strips of three / four rows)

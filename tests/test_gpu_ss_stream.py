@@ -163,3 +163,46 @@ def test_ss_long_query(oracle, local):
             assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:]), (local, e)
     ts.free()
     c.close()
+
+
+@pytest.mark.parametrize("Lq,local", [(431, 0), (431, 1), (512, 1), (640, 0), (700, 1), (1000, 0)])
+def test_ss_pairs_equal_one_launch_per_strip(oracle, Lq, local):
+    """hhv_ss_pair_kernel (four two-wave pairs per workgroup around one LDS table; chains for more than two strips) against one
+    launch per strip (hhv_set_launch_policy pair_mode 0), bit for bit, on sets where every pair walks many segments - junctions,
+    the carry FIFO's wrap-around, 1-3-column templates back to back - and against the oracle on the distinct templates"""
+    from pyhhv import capi, synth
+    rng = np.random.default_rng(4000 + Lq + local)
+    par = make_params(local=local, ss_mode=2)
+    qf, qtr = synth.make_query(64000 + Lq, Lq)
+    tables, q_ss = ss_inputs(rng, Lq)
+    ss = SSInfo(4, *q_ss, *tables)
+    base = []
+    for k in range(40):
+        Lt = [1, 1, 2, 3, 1, 300, 64, 129, 130, 511][k % 10] + (k // 10 if k % 10 >= 5 else 0)
+        p, tr = synth.make_homolog(65000 + k, qf, L=Lt) if k % 3 == 0 and Lt >= 2 else synth.make_template(65000 + k, Lt)
+        base.append((p, tr, t_ss_of(rng, Lt)))
+    want = [oracle.align(par, qf, qtr, b[0], b[1], ss=ss, t_ss=b[2], want_path=True) for b in base]
+    for n in (20000, 500, 3):
+        pick = rng.integers(0, len(base), size=n)
+        c = capi.Context(local=local, ssw=par["ssw"], ss_mode=2)
+        c.set_query(qf, qtr)
+        c.set_ss_tables(*tables)
+        c.set_query_ss(*q_ss)
+        c.set_ss_mode(4)
+        ts = c.upload([base[p][0] for p in pick], [base[p][1] for p in pick], [base[p][2] for p in pick])
+        got = []
+        for mode in (1, 0):
+            c.set_launch_policy(pair_mode=mode)
+            so = c.align(ts).copy()
+            res = c.align(ts, backtrace=True).copy()
+            hits = c.hits(ts).copy()
+            got.append((so, res, hits))
+        c.set_launch_policy(pair_mode=-1)
+        (so1, res1, hits1), (so0, res0, hits0) = got
+        assert so1.tobytes() == so0.tobytes() and res1.tobytes() == res0.tobytes() and hits1.tobytes() == hits0.tobytes(), (Lq, local, n)
+        for e in range(min(n, 400)):
+            a = want[pick[e]]
+            assert (a.i2, a.j2) == (res1["i2"][e], res1["j2"][e]) and np.float32(a.score) == res1["score"][e] == so1["score"][e], (Lq, local, n, e)
+            assert hits1["nsteps"][e] == a.nsteps and np.float32(a.hit_score) == hits1["score"][e] and np.float32(a.score_ss) == hits1["score_ss"][e]
+        ts.free()
+        c.close()

@@ -63,7 +63,7 @@ def functions(lines):
     i = 0
     n = len(lines)
     while i < n:
-        m = re.match(r"^(_ZN3hhv1[753]hhv_(?:stream|pair|ss)_kernel\w+):", lines[i])
+        m = re.match(r"^(_ZN3hhv1[7538]hhv_(?:stream|pair|ss|ss_pair)_kernel\w+):", lines[i])
         if m:
             j = i
             while j < n and not lines[j].strip().startswith("s_endpgm"):
