@@ -269,6 +269,9 @@ void hhv_destroy(hhv_ctx* c) {
   if (c->mac_pinned_out) (void)hipHostFree(c->mac_pinned_out);
   if (c->q_stage) (void)hipHostFree(c->q_stage);
   if (c->ss_stage) (void)hipHostFree(c->ss_stage);
+  if (c->co_stage) (void)hipHostFree(c->co_stage);
+  dfree(c->d_co);
+  if (c->ev_co) (void)hipEventDestroy(c->ev_co);
   if (c->ev_ss) (void)hipEventDestroy(c->ev_ss);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->ev_q) (void)hipEventDestroy(c->ev_q);
@@ -399,6 +402,9 @@ static int ensure_ss(hhv_ctx* c) {
   }
   if (c->ss_stage_bytes < stage_bytes) {
     if (c->ss_stage) (void)hipHostFree(c->ss_stage);
+  if (c->co_stage) (void)hipHostFree(c->co_stage);
+  dfree(c->d_co);
+  if (c->ev_co) (void)hipEventDestroy(c->ev_co);
     c->ss_stage = nullptr;
     c->ss_stage_bytes = 0;
     HIP_TRY(hipHostMalloc(&c->ss_stage, stage_bytes, hipHostMallocDefault));
@@ -960,30 +966,51 @@ int hhv_set_celloff_paths(hhv_ctx* c, hhv_tset* ts, int32_t n_paths, const int32
   for (int r = 0; r < 2 * n_qranges; ++r) ranges.push_back(qranges[r]);
   for (int r = 0; r < 2 * n_tranges; ++r) ranges.push_back(tranges[r]);
   ranges.push_back(0);
-  // one scratch allocation: template_of | path_off | i | j | ranges
+  // One device block: template_of | path_off | i | j | ranges - and one pinned staging block of the same layout.  Both live in the
+  // context and only ever grow (round 5): an alternative-alignment round used to pay a hipMalloc, four copies out of pageable
+  // memory, a stream synchronisation and a hipFree (which waits for the whole device) per call - 10 ms for the 1.5 M path steps of
+  // 10 000 templates, four times the masked DP that follows.  Now the caller's arrays are copied into the staging block (the
+  // caller may reuse them when the call returns), the copies and the two kernels are enqueued on the context's stream and the
+  // call returns; the staging block is guarded by an event like the query's.
   const size_t b_t = (size_t)n_paths * 4, b_o = (size_t)(n_paths + 1) * 8, b_s = (size_t)steps * 4, b_r = ranges.size() * 4;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  char* d = nullptr;
-  HIP_TRY(hipMalloc(&d, al(b_t) + al(b_o) + 2 * al(b_s) + al(b_r) + 256));
-  char* d_t = d;
-  char* d_o = d_t + al(b_t);
-  char* d_i = d_o + al(b_o);
-  char* d_j = d_i + al(b_s);
-  char* d_r = d_j + al(b_s);
-  bool ok = hipMemcpyAsync(d_r, ranges.data(), b_r, hipMemcpyHostToDevice, c->stream) == hipSuccess;
-  if (n_paths)
-    ok = ok && hipMemcpyAsync(d_t, template_of, b_t, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-         hipMemcpyAsync(d_o, path_off, b_o, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-         hipMemcpyAsync(d_i, i_steps, b_s, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-         hipMemcpyAsync(d_j, j_steps, b_s, hipMemcpyHostToDevice, c->stream) == hipSuccess;
-  int lr = 0;
-  if (ok)
-    lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, (int64_t)bt_plane_entries(ts->n_records, c->plan.W), c->Lq, c->plan, ts->n, n_paths,
-                            (const int32_t*)d_t, (const int64_t*)d_o, (const int32_t*)d_i, (const int32_t*)d_j,
-                            (const int32_t*)d_r, n_qranges, n_tranges, c->stream);
-  const bool synced = hipStreamSynchronize(c->stream) == hipSuccess;
-  (void)hipFree(d);
-  if (!ok || lr != 0 || !synced) return fail(HHV_E_DEVICE, "hhv_set_celloff_paths: device operation failed");
+  const size_t o_t = 0, o_o = o_t + al(b_t), o_i = o_o + al(b_o), o_j = o_i + al(b_s), o_r = o_j + al(b_s), total = o_r + al(b_r) + 256;
+  if (c->co_busy) {
+    HIP_TRY(hipEventSynchronize(c->ev_co));
+    c->co_busy = false;
+  }
+  if (!c->ev_co) HIP_TRY(hipEventCreateWithFlags(&c->ev_co, hipEventDisableTiming));
+  if (c->co_bytes < total) {
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (kernels that still read the old block)
+    if (c->co_stage) (void)hipHostFree(c->co_stage);
+    dfree(c->d_co);
+    c->co_stage = nullptr;
+    c->co_bytes = 0;
+    const size_t cap = total + total / 4;
+    HIP_TRY(hipHostMalloc(&c->co_stage, cap, hipHostMallocDefault));
+    if (hipMalloc(&c->d_co, cap) != hipSuccess) {
+      (void)hipHostFree(c->co_stage);
+      c->co_stage = nullptr;
+      return fail(HHV_E_MEMORY, "hhv_set_celloff_paths: %zu bytes of device scratch", cap);
+    }
+    c->co_bytes = cap;
+  }
+  char* const h = (char*)c->co_stage;
+  char* const d = (char*)c->d_co;
+  memcpy(h + o_r, ranges.data(), b_r);
+  if (n_paths) {
+    memcpy(h + o_t, template_of, b_t);
+    memcpy(h + o_o, path_off, b_o);
+    memcpy(h + o_i, i_steps, b_s);
+    memcpy(h + o_j, j_steps, b_s);
+  }
+  HIP_TRY(hipMemcpyAsync(d, h, o_r + b_r, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_co, c->stream));
+  c->co_busy = true;
+  const int lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, (int64_t)bt_plane_entries(ts->n_records, c->plan.W), c->Lq, c->plan, ts->n,
+                                    n_paths, (const int32_t*)(d + o_t), (const int64_t*)(d + o_o), (const int32_t*)(d + o_i),
+                                    (const int32_t*)(d + o_j), (const int32_t*)(d + o_r), n_qranges, n_tranges, c->stream);
+  if (lr != 0) return fail(HHV_E_DEVICE, "hhv_set_celloff_paths: kernel launch failed");
   ts->bt_valid = false;
   ts->bt_dirty = false;  // the clear kernel rewrote every entry of every template
   return HHV_OK;

@@ -94,6 +94,12 @@ struct hhv_ctx {
   hipEvent_t ev_ss = nullptr;                          // the last staging block has left the host
   bool ss_stage_busy = false;
   int ss_tab_n = 0;                                    // floats of the current table
+  // hhv_set_celloff_paths: pinned staging + device scratch of the path arrays (grow-only), guarded by an event
+  void* co_stage = nullptr;
+  void* d_co = nullptr;
+  size_t co_bytes = 0;
+  hipEvent_t ev_co = nullptr;
+  bool co_busy = false;
   int ss_t_shift = 0, ss_t_mask = 0;
   void* d_merge = nullptr;                             // hhv_merge_hits: merge_cap records + one int
   int merge_cap = 0;

@@ -389,7 +389,8 @@ int hhv_set_celloff(hhv_ctx* ctx, hhv_tset* ts, int32_t k, const uint8_t* mask);
  * earlier alignments (path p belongs to template template_of[p]; steps path_off[p] .. path_off[p+1]-1 of i_steps/j_steps,
  * i.e. entries 1..nsteps of Hit::i / Hit::j - the last one is skipped like the reference does) switches off its +-40 cross,
  * and the -excl / -template_excl (lo, hi) ranges are applied.  Replaces one hhv_set_celloff (a (Lq+1)*(Lt+1) byte mask
- * built and copied by the host) per surviving template. */
+ * built and copied by the host) per surviving template.  The arrays are copied before the call returns (the caller may reuse
+ * them at once); the copies and the kernels are only enqueued on the context's stream - the call does not wait for the device. */
 int hhv_set_celloff_paths(hhv_ctx* ctx, hhv_tset* ts, int32_t n_paths, const int32_t* template_of, const int64_t* path_off,
                           const int32_t* i_steps, const int32_t* j_steps, int32_t n_qranges, const int32_t* qranges,
                           int32_t n_tranges, const int32_t* tranges);
