@@ -402,9 +402,6 @@ static int ensure_ss(hhv_ctx* c) {
   }
   if (c->ss_stage_bytes < stage_bytes) {
     if (c->ss_stage) (void)hipHostFree(c->ss_stage);
-  if (c->co_stage) (void)hipHostFree(c->co_stage);
-  dfree(c->d_co);
-  if (c->ev_co) (void)hipEventDestroy(c->ev_co);
     c->ss_stage = nullptr;
     c->ss_stage_bytes = 0;
     HIP_TRY(hipHostMalloc(&c->ss_stage, stage_bytes, hipHostMallocDefault));
@@ -1009,7 +1006,8 @@ int hhv_set_celloff_paths(hhv_ctx* c, hhv_tset* ts, int32_t n_paths, const int32
   c->co_busy = true;
   const int lr = celloff_from_paths(ts->d_bt, ts->d_rec_off, ts->d_L, (int64_t)bt_plane_entries(ts->n_records, c->plan.W), c->Lq, c->plan, ts->n,
                                     n_paths, (const int32_t*)(d + o_t), (const int64_t*)(d + o_o), (const int32_t*)(d + o_i),
-                                    (const int32_t*)(d + o_j), (const int32_t*)(d + o_r), n_qranges, n_tranges, c->stream);
+                                    (const int32_t*)(d + o_j), (const int32_t*)(d + o_r), n_qranges, n_tranges,
+                                    ts->n ? *std::max_element(ts->L.begin(), ts->L.end()) : 0, c->stream);
   if (lr != 0) return fail(HHV_E_DEVICE, "hhv_set_celloff_paths: kernel launch failed");
   ts->bt_valid = false;
   ts->bt_dirty = false;  // the clear kernel rewrote every entry of every template

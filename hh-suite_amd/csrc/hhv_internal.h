@@ -215,7 +215,7 @@ int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_bloc
 // cell-off masks of the alternative-alignment rounds from the earlier alignments' paths (hhv_topk.hip)
 int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan,
                        int n_templates, int n_paths, const int32_t* template_of, const int64_t* path_off, const int32_t* pi,
-                       const int32_t* pj, const int32_t* ranges, int n_q, int n_t, hipStream_t stream);
+                       const int32_t* pj, const int32_t* ranges, int n_q, int n_t, int max_Lt, hipStream_t stream);
 // device-side subset of a resident template set (hhv_topk.hip)
 int set_header_flags(float* records, const int64_t* rec_off, const unsigned char* flags, int n, hipStream_t stream);
 int tset_gather(const float* src, const int64_t* src_off, const int32_t* ids, const int64_t* dst_off, const int32_t* L, int n,

@@ -585,13 +585,92 @@ __global__ void __launch_bounds__(256) celloff_paths_kernel(CellOffGeom g, const
   }
 }
 
+// The same masks, entry by entry instead of cell by cell (round 5).  The crosses of neighbouring path steps overlap almost
+// completely: 146 steps x 162 cells = 23 600 atomics per path above, ~240 M for the second round of 10 000 templates - 10 ms,
+// four times the masked DP they prepare.  The union of the crosses has a closed form: the steps of a path that lie in one
+// column j are consecutive rows (a vertical run), so column j is switched off from (its first row - 40) to (its last row + 40);
+// likewise row i from (first column - 40) to (last column + 40).  One workgroup per path: the four range tables into LDS with
+// atomicMin / atomicMax (one pass over the steps), then every 8-byte entry of the template is evaluated once - threads walk the
+// buffer in ITS order (entries of one buffer row = 64 neighbouring lanes: contiguous) - and the non-zero ones are or-ed in with
+// ONE atomic each (several paths of a template meet in an entry).  A caller's "path" that is not one (steps that do not move to
+// a neighbouring cell) and profiles too long for the LDS tables take the kernel above.
+constexpr int CELLOFF_BAND_MAX = 8000;  // Lq + Lt: 2 x 4 bytes per row and per column in LDS (64 KB)
+__global__ void __launch_bounds__(256) celloff_band_kernel(CellOffGeom g, const int32_t* __restrict__ template_of,
+                                                           const int64_t* __restrict__ path_off, const int32_t* __restrict__ pi,
+                                                           const int32_t* __restrict__ pj) {
+  extern __shared__ int s_rng[];
+  const int p = blockIdx.x, t = template_of[p], Lt = g.L[t], Lq = g.Lq;
+  const int64_t o = path_off[p];
+  const int ns = (int)(path_off[p + 1] - o) - 1;  // the last step is skipped, like the reference (:65)
+  int* row_lo = s_rng;                  // [Lt + 1] first / last ROW of the path's steps in column j
+  int* row_hi = row_lo + (Lt + 1);
+  int* col_lo = row_hi + (Lt + 1);      // [Lq + 1] first / last COLUMN of the path's steps in row i
+  int* col_hi = col_lo + (Lq + 1);
+  __shared__ int irregular;
+  if (threadIdx.x == 0) irregular = 0;
+  for (int k = threadIdx.x; k <= Lt; k += 256) row_lo[k] = 0x7FFFFFFF, row_hi[k] = -1;
+  for (int k = threadIdx.x; k <= Lq; k += 256) col_lo[k] = 0x7FFFFFFF, col_hi[k] = -1;
+  __syncthreads();
+  for (int s = threadIdx.x; s < ns; s += 256) {
+    const int i = pi[o + s], j = pj[o + s];
+    if (s + 1 < ns) {  // a path moves to a neighbouring cell per step, never back (src/hhviterbi.cpp:96-146: i and j only fall)
+      const int di = pi[o + s + 1] - i, dj = pj[o + s + 1] - j;
+      if (di > 0 || di < -1 || dj > 0 || dj < -1) irregular = 1;
+    }
+    if (i < 1 || i > Lq || j < 1 || j > Lt) continue;
+    atomicMin(&row_lo[j], i);
+    atomicMax(&row_hi[j], i);
+    atomicMin(&col_lo[i], j);
+    atomicMax(&col_hi[i], j);
+  }
+  __syncthreads();
+  if (irregular) {  // not a path: cell by cell, as above
+    constexpr int CW = 2 * 40 + 1;
+    for (int w = threadIdx.x; w < ns * CW; w += 256) {
+      const int step = w / CW, d = w - step * CW - 40;
+      const int i = pi[o + step], j = pj[o + step];
+      if (i < 1 || i > Lq || j < 1 || j > Lt) continue;
+      if (i + d >= 1 && i + d <= Lq) celloff_set(g, t, i + d, j);
+      if (j + d >= 1 && j + d <= Lt) celloff_set(g, t, i, j + d);
+    }
+    return;
+  }
+  const int W = g.plan.W;
+  const int64_t rec0 = g.rec_off[t];
+  for (int pass = 0; pass < g.plan.P; ++pass) {
+    const int R = g.plan.R(pass), ilo = g.plan.base(pass) + 1;
+    uint64_t* e = g.bt + (size_t)pass * g.pass_stride;
+    // buffer rows rec0 + 1 .. rec0 + Lt + W - 1 hold the template's entries: (row rho, lane gl) = column rho - gl - rec0
+    for (int k = threadIdx.x; k < (Lt + W - 1) * W; k += 256) {
+      const int gl = k % W, j = 1 + k / W - gl;
+      if (j < 1 || j > Lt) continue;
+      uint64_t v = 0;
+      const int rlo = row_lo[j] - 40, rhi = row_hi[j] < 0 ? -1 : row_hi[j] + 40;
+      for (int r = 0; r < R; ++r) {
+        const int i = ilo + gl * R + r;
+        if (i > Lq) break;
+        const bool in_col = i >= rlo && i <= rhi;
+        const bool in_row = col_hi[i] >= 0 && j >= col_lo[i] - 40 && j <= col_hi[i] + 40;
+        if (in_col || in_row) v |= 0x80ull << (8 * r);
+      }
+      if (v) atomicOr((unsigned long long*)(e + bt_entry(rec0 + j, gl, W)), (unsigned long long)v);
+    }
+  }
+}
+
 int celloff_from_paths(uint64_t* bt, const int64_t* rec_off, const int32_t* L, int64_t pass_stride, int Lq, StripPlan plan,
                        int n_templates, int n_paths, const int32_t* template_of, const int64_t* path_off, const int32_t* pi,
-                       const int32_t* pj, const int32_t* ranges, int n_q, int n_t, hipStream_t stream) {
+                       const int32_t* pj, const int32_t* ranges, int n_q, int n_t, int max_Lt, hipStream_t stream) {
   CellOffGeom g{bt, rec_off, L, pass_stride, Lq, plan, 0};
   hipLaunchKernelGGL(celloff_clear_kernel, dim3(n_templates), dim3(256), 0, stream, g, ranges, n_q, n_t);
-  if (n_paths > 0)
-    hipLaunchKernelGGL(celloff_paths_kernel, dim3(n_paths), dim3(256), 0, stream, g, template_of, path_off, pi, pj);
+  if (n_paths > 0) {
+    if (Lq + max_Lt <= CELLOFF_BAND_MAX) {
+      const size_t lds = (size_t)2 * (Lq + max_Lt + 2) * sizeof(int);
+      hipLaunchKernelGGL(celloff_band_kernel, dim3(n_paths), dim3(256), lds, stream, g, template_of, path_off, pi, pj);
+    } else {
+      hipLaunchKernelGGL(celloff_paths_kernel, dim3(n_paths), dim3(256), 0, stream, g, template_of, path_off, pi, pj);
+    }
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
