@@ -24,7 +24,7 @@ check)
   timeout 300 python bench.py --force-dist --steps 20 --warmup 5 $short > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err; line < $OUT/bench_force_dist.json; tail -2 $OUT/bench_force_dist.err
   echo "== configs[4] as one of 8 shards would see it: --lengths zipf --local 1, 125k templates"
   timeout 300 python bench.py --lengths zipf --local 1 --templates 125000 --steps 10 --warmup 3 $short > $OUT/bench_zipf.json 2> $OUT/bench_zipf.err; line < $OUT/bench_zipf.json
-  for cfg in "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000" "--lq 1000 --lt 500 --templates 20000" "--lq 150 --templates 100000" "--lq 150 --templates 100000 --backtrace 1" "--lq 80 --templates 100000" "--lq 300 --templates 100000 --local 1" "--lq 300 --templates 100000 --backtrace 1"; do
+  for cfg in "--lq 431 --templates 50000" "--lq 431 --templates 50000 --backtrace 1" "--lq 512 --templates 50000" "--lq 1000 --lt 500 --templates 20000" "--lq 150 --templates 100000" "--lq 150 --templates 100000 --backtrace 1" "--lq 80 --templates 100000" "--lq 300 --templates 100000 --local 1" "--lq 300 --templates 100000 --backtrace 1" "--ss 4" "--ss 4 --backtrace 1" "--templates 10000 --backtrace 1" "--templates 20000 --backtrace 1"; do
     echo -n "== $cfg : "
     timeout 200 python bench.py $cfg --steps 10 --warmup 3 $short 2>/dev/null | line
   done
@@ -33,6 +33,8 @@ check)
   echo "== the native multi-rank program, one rank through RCCL (examples/sharded_search_rccl.cpp)"
   timeout 300 ./build/sharded_search_rccl --world 1 --templates 20000 --steps 5 --check 2>&1 | tail -4
   timeout 300 ./build/sharded_search_rccl --world 1 --templates 20000 --steps 5 --backtrace 2>&1 | tail -3
+  echo "== tools/scale8.sh (dry run on the GPUs visible)"
+  bash tools/scale8.sh 2>&1 | tail -3
   ;;
 ab)
   bash tools/gpu_ab.sh "$@"
