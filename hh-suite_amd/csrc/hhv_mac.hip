@@ -174,6 +174,60 @@ __device__ __forceinline__ void stage_ss(const HitView& h, float* sSs, int lane)
 // LDS row state: field f of row r at column j
 #define ROW(r, f, j) rows[((r)*5 + (f)) * stride + (j)]
 enum { F_MM = 0, F_GD = 1, F_IM = 2, F_DG = 3, F_MI = 4 };
+// behind the two rows: the operand arrays of the recurrence walk (below) - XB(0, j) / XB(1, j) the factor of the GD / IM chain
+// at column j, XB(2, j) the Pforward summand - and two constants of the walk (1.0 and the row's q[i][I2I])
+constexpr int MAC_ROW_FIELDS = 14;
+#define XB(k, j) rows[(10 + (k)) * stride + (j)]
+
+// The two first-order recurrences along a row (GD, IM) and the running total of Pforward, WALKED instead of swept (round 5).
+// Rounds 2-4 evaluated them with a DPP sweep: in step s every lane recomputes y = a + y(lane-1) * b from its left neighbour -
+// 64-lane instructions for a chain that advances by one column per step: per column 6 DPP moves (three doubles) + 6 fp64
+// operations = 12 instructions of a lone wavefront (~6 clk each): ~80 clk per column, 8 k of a row's 14.7 k clocks
+// (profiles/r3_next_rows_summary.txt).  Here the lanes write the chains' operands into LDS - the additive term into the slot the
+// result will take, the factor next to it - and THREE lanes walk the strip's active span, one chain each (lane 0: GD, lane 1:
+// IM, lane 2: the Pforward total), all with the one instruction sequence
+//     y = c[j] + (y * m1[j]) * m2[j]
+// whose operands are read with a per-lane base and a per-lane stride (0 = a constant): GD (m1, m2) = (t[j-1][D2D], 1),
+// IM (q[i][I2I], t[j-1][M2M]), total (1, 1).  x * 1.0 is exact, so every chain keeps the reference's operations in the
+// reference's order (src/hhforwardalgorithm.cpp:104-109,168; src/hhbackwardalgorithm.cpp:95-101) - three loads, three fp64
+// operations and one store per column, no cross-lane traffic at all.  Operands are fetched four columns ahead.
+// pc: the chain's c / result slots, p1 / p2: its factors; st*: element strides (in doubles; the backward walk runs towards
+// smaller columns: -1; constants: 0); n: columns; y: the value entering the span.  Returns the value leaving it.
+__device__ __forceinline__ double mac_walk(double* pc, const double* p1, const double* p2, int stc, int st1, int st2, int n, double y) {
+  int e = 0;
+  double c[4], m1[4], m2[4];
+  const int n4 = n & ~3;
+  if (n4 > 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = pc[u * stc], m1[u] = p1[u * st1], m2[u] = p2[u * st2];
+  }
+  for (; e < n4; e += 4) {
+    double cn[4], m1n[4], m2n[4];
+    const bool more = e + 8 <= n4;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cn[u] = pc[(e + 4 + u) * stc], m1n[u] = p1[(e + 4 + u) * st1], m2n[u] = p2[(e + 4 + u) * st2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double t = y * m1[u];
+      t = t * m2[u];
+      y = c[u] + t;
+      pc[(e + u) * stc] = y;
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = cn[u], m1[u] = m1n[u], m2[u] = m2n[u];
+    }
+  }
+  for (; e < n; ++e) {
+    double t = y * p1[e * st1];
+    t = t * p2[e * st2];
+    y = pc[e * stc] + t;
+    pc[e * stc] = y;
+  }
+  return y;
+}
 
 }  // namespace
 
@@ -184,10 +238,12 @@ template <bool LOCAL, bool STAGE, bool GROWS>
 __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = GROWS ? a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2) : reinterpret_cast<double*>(smem);
+  constexpr bool WALK = !GROWS;  // (row state in global memory: the operand round trips would cost more than the sweep)
   const int k = a.sel[blockIdx.x], lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
-  float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));  // layout sized for the longest template
+  float* sTp = reinterpret_cast<float*>(rows + (size_t)(GROWS ? 10 : MAC_ROW_FIELDS) * (a.lds_cols + 2));  // layout sized for the longest template
+  double* const wk = rows + (size_t)13 * (a.lds_cols + 2);  // WALK: {1.0, q[i][I2I]}
   float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
   // STAGE: the cell-off bytes of a row are fetched from HBM while the row BEFORE it is computed (registers), parked in LDS
   // at the end of that row and read from there - a strip without active cells costs a few dozen cycles, and with the
@@ -198,6 +254,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   const float* sstab = STAGE ? sSs : h.sstab;
   const double Cshift = a.Cshift;
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
+  if (WALK && lane == 0) wk[0] = 1.0;
   for (int e = lane; e < pitch; e += 64) h.mat[e] = 0.0f;  // row 0 of p_mm is never read
   if (STAGE) {
     stage_template(h, sTp, sTt, lane);
@@ -227,6 +284,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     const double qM2M = qt1[T_M2M], qI2M = qt1[T_I2M], qD2M = qt1[T_D2M], qM2D = qt1[T_M2D], qD2D = qt1[T_D2D];
     const double qM2I = qt[T_M2I], qI2I = qt[T_I2I];
     double Pmax = 0.0, carry_mm = 0.0, carry_gd = 0.0, carry_im = 0.0;
+    if (WALK && lane == 0) wk[1] = qI2I;  // (read by the walk of this row's strips; the previous row's walks are behind a barrier)
     unsigned char pre_co[MAC_PRE];
     if (STAGE) {
 #pragma unroll
@@ -296,7 +354,40 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const double a_gd = chain_on ? mm_left * tt1[T_M2D] : 0.0, b_gd = chain_on ? (double)tt1[T_D2D] : 0.0;
       const double c_im = chain_on ? mm_left * qM2I * tt1[T_M2M] : 0.0, b_im = chain_on ? (double)tt1[T_M2M] : 0.0;
       const double f_mm = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
-      // Sweep: inactive lanes hold 0 (resp. the incoming total) whatever their neighbour says, so the lanes left of the
+      double gd = 0.0, im = 0.0;
+      if (WALK) {
+        // operands into LDS (the additive terms into the slots the results will take; inactive lanes: 0, which IS their
+        // result), then three lanes walk the active span l0 .. l1 (mac_walk above); what enters the span: the carry of the
+        // previous strip when the span starts at lane 0, else 0 (an inactive neighbour) - the running total always
+        if (valid) {
+          ROW(cur, F_MM, j) = mm;
+          ROW(cur, F_GD, j) = a_gd;
+          ROW(cur, F_IM, j) = c_im;
+          ROW(cur, F_DG, j) = dg;
+          ROW(cur, F_MI, j) = mi;
+          XB(0, j) = b_gd;
+          XB(1, j) = b_im;
+          if (LOCAL) XB(2, j) = f_mm;
+          h.mat[(size_t)i * pitch + j] = (float)mm;
+        }
+        __syncthreads();
+        const int jf = 1 + s0 + l0, n = l1 - l0 + 1;
+        double y = 0.0;
+        if (lane < (LOCAL ? 3 : 2)) {
+          const double yin = lane == 0 ? (l0 == 0 ? carry_gd : 0.0) : lane == 1 ? (l0 == 0 ? carry_im : 0.0) : Pf;
+          double* pc = lane == 0 ? &ROW(cur, F_GD, jf) : lane == 1 ? &ROW(cur, F_IM, jf) : &XB(2, jf);
+          const double* p1 = lane == 0 ? &XB(0, jf) : lane == 1 ? wk + 1 : wk;
+          const double* p2 = lane == 1 ? &XB(1, jf) : wk;
+          y = mac_walk(pc, p1, p2, 1, lane == 0 ? 1 : 0, lane == 1 ? 1 : 0, n, yin);
+        }
+        __syncthreads();
+        carry_mm = lane_d(mm, 63);
+        carry_gd = l1 == 63 ? lane_d(y, 0) : 0.0;  // lane 63 is either inactive (0) or l1 (final)
+        carry_im = l1 == 63 ? lane_d(y, 1) : 0.0;
+        if (LOCAL) Pf = lane_d(y, 2);
+        continue;
+      }
+      // (GROWS) Sweep: inactive lanes hold 0 (resp. the incoming total) whatever their neighbour says, so the lanes left of the
       // first active one are final from the start and l1 - l0 + 1 steps finish everything up to the last active lane.
       // Lane 0's left neighbour is the carry of the previous strip, a constant of the sweep: its step is evaluated once,
       // with the operations of the loop body, and the loop shifts zeros into lane 0 (x + 0*b = x for the non-negative
@@ -305,7 +396,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
       const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
       const double f_mm_s = first_lane ? Pf + f_mm : f_mm;
-      double gd = 0.0, im = 0.0, acc = Pf;
+      double acc = Pf;
       const int n_steps = l1 - l0 + 1;
       for (int s = 0; s < n_steps; ++s) {
         const double gl = shr1_dz(gd), il = shr1_dz(im);
@@ -410,7 +501,9 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   const int k = a.sel[blockIdx.x], lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
-  float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));
+  constexpr bool WALK = !GROWS;  // the recurrences along the row are walked, see mac_walk
+  float* sTp = reinterpret_cast<float*>(rows + (size_t)(GROWS ? 10 : MAC_ROW_FIELDS) * (a.lds_cols + 2));
+  double* const wk = rows + (size_t)13 * (a.lds_cols + 2);  // WALK: {1.0, q[i][I2I]}
   float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
   // STAGE: mask bytes and F_MM of a row are fetched while the row processed before it is computed (see the forward kernel)
   unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + (size_t)(a.lds_cols + 2) * 8);  // [2][lds_cols + 2]
@@ -420,6 +513,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   const float* sstab = STAGE ? sSs : h.sstab;
   const double Cshift = a.Cshift, Pf = a.Pforward[k];
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
+  if (WALK && lane == 0) wk[0] = 1.0;
   if (STAGE) {
     stage_template(h, sTp, sTt, lane);
     stage_ss(h, sSs, lane);
@@ -500,6 +594,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
     const double qM2M = qt[T_M2M], qM2I = qt[T_M2I], qM2D = qt[T_M2D], qI2M = qt[T_I2M], qI2I = qt[T_I2I], qD2M = qt[T_D2M],
                  qD2D = qt[T_D2D];
     double carry_gd = 0.0, carry_im = 0.0;  // curr[Lt].gd = curr[Lt].im = 0
+    if (WALK && lane == 0) wk[1] = qI2I;
     for (int s0 = 0; s0 < Lt - 1; s0 += 64) {
       const int j = Lt - 1 - s0 - lane;  // descending: lane 0 is the rightmost column of the strip
       const bool valid = j >= 1;
@@ -537,24 +632,51 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       double mi = (+pmatch * qM2M * tt[T_I2M] + pmi * qM2M * tt[T_I2I] * sc);     // :108-111
       const double a_gd = off ? 0.0 : pmatch * qM2M * tt[T_D2M], b_gd = off ? 0.0 : (double)tt[T_D2D];  // :95-97
       const double c_im = off ? 0.0 : pmatch * qI2M * tM2M, b_im = off ? 0.0 : tM2M;                    // :99-101
-      const bool first_lane = lane == 0;  // its neighbour is the carry of the previous strip: folded, see the forward kernel
-      const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
-      const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
-      double gd = 0.0, im = 0.0;
-      const int n_steps = l1 - l0 + 1;
-      for (int s = 0; s < n_steps; ++s) {
-        const double gr = shr1_dz(gd), ir = shr1_dz(im);
-        gd = a_gd_s + gr * b_gd;
-        im = c_im_s + ir * qI2I * b_im;
+      double gd = 0.0, im = 0.0, gr, ir;
+      if (WALK) {
+        // as in the forward kernel, towards smaller columns: lane l0 is the span's rightmost column
+        if (valid) {
+          ROW(cur, F_GD, j) = a_gd;
+          ROW(cur, F_IM, j) = c_im;
+          XB(0, j) = b_gd;
+          XB(1, j) = b_im;
+        }
+        __syncthreads();
+        const int jf = Lt - 1 - s0 - l0, n = l1 - l0 + 1;
+        double y = 0.0;
+        if (lane < 2) {
+          const double yin = l0 == 0 ? (lane == 0 ? carry_gd : carry_im) : 0.0;
+          double* pc = lane == 0 ? &ROW(cur, F_GD, jf) : &ROW(cur, F_IM, jf);
+          const double* p1 = lane == 0 ? &XB(0, jf) : wk + 1;
+          const double* p2 = lane == 1 ? &XB(1, jf) : wk;
+          y = mac_walk(pc, p1, p2, -1, lane == 0 ? -1 : 0, lane == 1 ? -1 : 0, n, yin);
+        }
+        __syncthreads();
+        gr = ROW(cur, F_GD, jc + 1);  // curr[j+1].gd / .im (column Lt: 0, written above)
+        ir = ROW(cur, F_IM, jc + 1);
+        carry_gd = l1 == 63 ? lane_d(y, 0) : 0.0;
+        carry_im = l1 == 63 ? lane_d(y, 1) : 0.0;
+      } else {
+        const bool first_lane = lane == 0;  // its neighbour is the carry of the previous strip: folded, see the forward kernel
+        const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
+        const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
+        const int n_steps = l1 - l0 + 1;
+        for (int s = 0; s < n_steps; ++s) {
+          const double gl = shr1_dz(gd), il = shr1_dz(im);
+          gd = a_gd_s + gl * b_gd;
+          im = c_im_s + il * qI2I * b_im;
+        }
+        gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);  // curr[j+1].gd / .im
       }
-      const double gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);  // curr[j+1].gd / .im
       double mm = (+pmin + pmatch * qM2M * tM2M + gr * tt[T_M2D] + ir * qM2I * tM2M + pdg * qM2D * sc +
                    pmi * qM2M * tt[T_M2I] * sc);  // :86-93
       if (off) mm = dg = mi = 0.0;
       if (valid) {
         ROW(cur, F_MM, j) = mm;
-        ROW(cur, F_GD, j) = gd;
-        ROW(cur, F_IM, j) = im;
+        if (!WALK) {
+          ROW(cur, F_GD, j) = gd;
+          ROW(cur, F_IM, j) = im;
+        }
         ROW(cur, F_DG, j) = dg;
         ROW(cur, F_MI, j) = mi;
         row[j] = f_cur * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
@@ -567,8 +689,10 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
         const float v = (float)((double)sub * Cshift * mm / Pf * final_scale_prod / scale_prod);
         if (v > MAC_LIST_THRESHOLD) blist[(size_t)i * pitch + j] = v;
       }
-      carry_gd = lane_d(gd, 63);
-      carry_im = lane_d(im, 63);
+      if (!WALK) {
+        carry_gd = lane_d(gd, 63);
+        carry_im = lane_d(im, 63);
+      }
     }
     if (STAGE) {
       unsigned char* co_n = sCo + ((i - 1) & 1) * co_stride;
@@ -880,7 +1004,7 @@ int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
 size_t mac_rows_lds(int max_Lt, bool stage) {
   // staged: + the template (28 floats per column) + two rows of mask bytes + two rows of F_MM fetched a row ahead + the
   // secondary-structure table of the hit
-  return (size_t)10 * (max_Lt + 2) * sizeof(double) +
+  return (size_t)MAC_ROW_FIELDS * (max_Lt + 2) * sizeof(double) +
          (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) + (((size_t)2 * (max_Lt + 2) + 15) & ~(size_t)15) +
                       (size_t)2 * (max_Lt + 2) * sizeof(float) + 352 * sizeof(float) : 0);
 }

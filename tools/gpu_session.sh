@@ -84,6 +84,11 @@ walk("", d)
 print("masked_round", {k: v for k, v in d["masked_round"].items() if not isinstance(v, dict)})
 PY
   ;;
+mac)   # mac [soak_s]: the MAC realignment after a kernel change: its tests, a soak of its family, the 500-hit timing (fixed and mixed lengths)
+  timeout 900 python -m pytest tests/test_mac.py tests/test_dropin_realign.py tests/test_pipeline.py tests/test_dropin_apps.py -q -m gpu -x 2>&1 | tail -3
+  timeout 300 python tools/soak.py ${1:-40} 777 mac 2>$OUT/soak_mac.err | tail -3
+  for a in "500 300 300 50" "500 300 0 50" "500 700 0 20"; do timeout 300 python tools/bench_mac.py $a 2>>$OUT/bench_mac.err | tee -a $OUT/bench_mac.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('n_hits','Lq','Lt','gpu_kernels_ms','mismatches_vs_reference','checked')}, d['resident_set']['gpu_kernels_ms'])"; done
+  ;;
 r5p)   # the round's profiles: headline, backtrace, secondary structure (hhv_ss_kernel), and the kernel statistics of a 10 k backtrace search
   for spec in "r5|" "r5bt|--backtrace 1" "r5ss|--ss 4" "r5ssbt|--ss 4 --backtrace 1"; do
     tag=${spec%%|*}; extra=${spec#*|}
