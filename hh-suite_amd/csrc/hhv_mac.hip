@@ -174,60 +174,6 @@ __device__ __forceinline__ void stage_ss(const HitView& h, float* sSs, int lane)
 // LDS row state: field f of row r at column j
 #define ROW(r, f, j) rows[((r)*5 + (f)) * stride + (j)]
 enum { F_MM = 0, F_GD = 1, F_IM = 2, F_DG = 3, F_MI = 4 };
-// behind the two rows: the operand arrays of the recurrence walk (below) - XB(0, j) / XB(1, j) the factor of the GD / IM chain
-// at column j, XB(2, j) the Pforward summand - and two constants of the walk (1.0 and the row's q[i][I2I])
-constexpr int MAC_ROW_FIELDS = 14;
-#define XB(k, j) rows[(10 + (k)) * stride + (j)]
-
-// The two first-order recurrences along a row (GD, IM) and the running total of Pforward, WALKED instead of swept (round 5).
-// Rounds 2-4 evaluated them with a DPP sweep: in step s every lane recomputes y = a + y(lane-1) * b from its left neighbour -
-// 64-lane instructions for a chain that advances by one column per step: per column 6 DPP moves (three doubles) + 6 fp64
-// operations = 12 instructions of a lone wavefront (~6 clk each): ~80 clk per column, 8 k of a row's 14.7 k clocks
-// (profiles/r3_next_rows_summary.txt).  Here the lanes write the chains' operands into LDS - the additive term into the slot the
-// result will take, the factor next to it - and THREE lanes walk the strip's active span, one chain each (lane 0: GD, lane 1:
-// IM, lane 2: the Pforward total), all with the one instruction sequence
-//     y = c[j] + (y * m1[j]) * m2[j]
-// whose operands are read with a per-lane base and a per-lane stride (0 = a constant): GD (m1, m2) = (t[j-1][D2D], 1),
-// IM (q[i][I2I], t[j-1][M2M]), total (1, 1).  x * 1.0 is exact, so every chain keeps the reference's operations in the
-// reference's order (src/hhforwardalgorithm.cpp:104-109,168; src/hhbackwardalgorithm.cpp:95-101) - three loads, three fp64
-// operations and one store per column, no cross-lane traffic at all.  Operands are fetched four columns ahead.
-// pc: the chain's c / result slots, p1 / p2: its factors; st*: element strides (in doubles; the backward walk runs towards
-// smaller columns: -1; constants: 0); n: columns; y: the value entering the span.  Returns the value leaving it.
-__device__ __forceinline__ double mac_walk(double* pc, const double* p1, const double* p2, int stc, int st1, int st2, int n, double y) {
-  int e = 0;
-  double c[4], m1[4], m2[4];
-  const int n4 = n & ~3;
-  if (n4 > 0) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) c[u] = pc[u * stc], m1[u] = p1[u * st1], m2[u] = p2[u * st2];
-  }
-  for (; e < n4; e += 4) {
-    double cn[4], m1n[4], m2n[4];
-    const bool more = e + 8 <= n4;
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) cn[u] = pc[(e + 4 + u) * stc], m1n[u] = p1[(e + 4 + u) * st1], m2n[u] = p2[(e + 4 + u) * st2];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      double t = y * m1[u];
-      t = t * m2[u];
-      y = c[u] + t;
-      pc[(e + u) * stc] = y;
-    }
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) c[u] = cn[u], m1[u] = m1n[u], m2[u] = m2n[u];
-    }
-  }
-  for (; e < n; ++e) {
-    double t = y * p1[e * st1];
-    t = t * p2[e * st2];
-    y = pc[e * stc] + t;
-    pc[e * stc] = y;
-  }
-  return y;
-}
 
 }  // namespace
 
@@ -238,12 +184,10 @@ template <bool LOCAL, bool STAGE, bool GROWS>
 __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = GROWS ? a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2) : reinterpret_cast<double*>(smem);
-  constexpr bool WALK = !GROWS;  // (row state in global memory: the operand round trips would cost more than the sweep)
   const int k = a.sel[blockIdx.x], lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
-  float* sTp = reinterpret_cast<float*>(rows + (size_t)(GROWS ? 10 : MAC_ROW_FIELDS) * (a.lds_cols + 2));  // layout sized for the longest template
-  double* const wk = rows + (size_t)13 * (a.lds_cols + 2);  // WALK: {1.0, q[i][I2I]}
+  float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));  // layout sized for the longest template
   float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
   // STAGE: the cell-off bytes of a row are fetched from HBM while the row BEFORE it is computed (registers), parked in LDS
   // at the end of that row and read from there - a strip without active cells costs a few dozen cycles, and with the
@@ -254,7 +198,6 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   const float* sstab = STAGE ? sSs : h.sstab;
   const double Cshift = a.Cshift;
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
-  if (WALK && lane == 0) wk[0] = 1.0;
   for (int e = lane; e < pitch; e += 64) h.mat[e] = 0.0f;  // row 0 of p_mm is never read
   if (STAGE) {
     stage_template(h, sTp, sTt, lane);
@@ -284,7 +227,6 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     const double qM2M = qt1[T_M2M], qI2M = qt1[T_I2M], qD2M = qt1[T_D2M], qM2D = qt1[T_M2D], qD2D = qt1[T_D2D];
     const double qM2I = qt[T_M2I], qI2I = qt[T_I2I];
     double Pmax = 0.0, carry_mm = 0.0, carry_gd = 0.0, carry_im = 0.0;
-    if (WALK && lane == 0) wk[1] = qI2I;  // (read by the walk of this row's strips; the previous row's walks are behind a barrier)
     unsigned char pre_co[MAC_PRE];
     if (STAGE) {
 #pragma unroll
@@ -354,40 +296,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const double a_gd = chain_on ? mm_left * tt1[T_M2D] : 0.0, b_gd = chain_on ? (double)tt1[T_D2D] : 0.0;
       const double c_im = chain_on ? mm_left * qM2I * tt1[T_M2M] : 0.0, b_im = chain_on ? (double)tt1[T_M2M] : 0.0;
       const double f_mm = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
-      double gd = 0.0, im = 0.0;
-      if (WALK) {
-        // operands into LDS (the additive terms into the slots the results will take; inactive lanes: 0, which IS their
-        // result), then three lanes walk the active span l0 .. l1 (mac_walk above); what enters the span: the carry of the
-        // previous strip when the span starts at lane 0, else 0 (an inactive neighbour) - the running total always
-        if (valid) {
-          ROW(cur, F_MM, j) = mm;
-          ROW(cur, F_GD, j) = a_gd;
-          ROW(cur, F_IM, j) = c_im;
-          ROW(cur, F_DG, j) = dg;
-          ROW(cur, F_MI, j) = mi;
-          XB(0, j) = b_gd;
-          XB(1, j) = b_im;
-          if (LOCAL) XB(2, j) = f_mm;
-          h.mat[(size_t)i * pitch + j] = (float)mm;
-        }
-        __syncthreads();
-        const int jf = 1 + s0 + l0, n = l1 - l0 + 1;
-        double y = 0.0;
-        if (lane < (LOCAL ? 3 : 2)) {
-          const double yin = lane == 0 ? (l0 == 0 ? carry_gd : 0.0) : lane == 1 ? (l0 == 0 ? carry_im : 0.0) : Pf;
-          double* pc = lane == 0 ? &ROW(cur, F_GD, jf) : lane == 1 ? &ROW(cur, F_IM, jf) : &XB(2, jf);
-          const double* p1 = lane == 0 ? &XB(0, jf) : lane == 1 ? wk + 1 : wk;
-          const double* p2 = lane == 1 ? &XB(1, jf) : wk;
-          y = mac_walk(pc, p1, p2, 1, lane == 0 ? 1 : 0, lane == 1 ? 1 : 0, n, yin);
-        }
-        __syncthreads();
-        carry_mm = lane_d(mm, 63);
-        carry_gd = l1 == 63 ? lane_d(y, 0) : 0.0;  // lane 63 is either inactive (0) or l1 (final)
-        carry_im = l1 == 63 ? lane_d(y, 1) : 0.0;
-        if (LOCAL) Pf = lane_d(y, 2);
-        continue;
-      }
-      // (GROWS) Sweep: inactive lanes hold 0 (resp. the incoming total) whatever their neighbour says, so the lanes left of the
+      // Sweep: inactive lanes hold 0 (resp. the incoming total) whatever their neighbour says, so the lanes left of the
       // first active one are final from the start and l1 - l0 + 1 steps finish everything up to the last active lane.
       // Lane 0's left neighbour is the carry of the previous strip, a constant of the sweep: its step is evaluated once,
       // with the operations of the loop body, and the loop shifts zeros into lane 0 (x + 0*b = x for the non-negative
@@ -396,7 +305,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
       const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
       const double f_mm_s = first_lane ? Pf + f_mm : f_mm;
-      double acc = Pf;
+      double gd = 0.0, im = 0.0, acc = Pf;
       const int n_steps = l1 - l0 + 1;
       for (int s = 0; s < n_steps; ++s) {
         const double gl = shr1_dz(gd), il = shr1_dz(im);
@@ -501,9 +410,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   const int k = a.sel[blockIdx.x], lane = threadIdx.x;
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
-  constexpr bool WALK = !GROWS;  // the recurrences along the row are walked, see mac_walk
-  float* sTp = reinterpret_cast<float*>(rows + (size_t)(GROWS ? 10 : MAC_ROW_FIELDS) * (a.lds_cols + 2));
-  double* const wk = rows + (size_t)13 * (a.lds_cols + 2);  // WALK: {1.0, q[i][I2I]}
+  float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));
   float* sTt = sTp + (size_t)(a.lds_cols + 2) * 20;
   // STAGE: mask bytes and F_MM of a row are fetched while the row processed before it is computed (see the forward kernel)
   unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + (size_t)(a.lds_cols + 2) * 8);  // [2][lds_cols + 2]
@@ -513,7 +420,6 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   const float* sstab = STAGE ? sSs : h.sstab;
   const double Cshift = a.Cshift, Pf = a.Pforward[k];
   for (int e = lane; e < 10 * stride; e += 64) rows[e] = 0.0;
-  if (WALK && lane == 0) wk[0] = 1.0;
   if (STAGE) {
     stage_template(h, sTp, sTt, lane);
     stage_ss(h, sSs, lane);
@@ -594,7 +500,6 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
     const double qM2M = qt[T_M2M], qM2I = qt[T_M2I], qM2D = qt[T_M2D], qI2M = qt[T_I2M], qI2I = qt[T_I2I], qD2M = qt[T_D2M],
                  qD2D = qt[T_D2D];
     double carry_gd = 0.0, carry_im = 0.0;  // curr[Lt].gd = curr[Lt].im = 0
-    if (WALK && lane == 0) wk[1] = qI2I;
     for (int s0 = 0; s0 < Lt - 1; s0 += 64) {
       const int j = Lt - 1 - s0 - lane;  // descending: lane 0 is the rightmost column of the strip
       const bool valid = j >= 1;
@@ -632,51 +537,24 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       double mi = (+pmatch * qM2M * tt[T_I2M] + pmi * qM2M * tt[T_I2I] * sc);     // :108-111
       const double a_gd = off ? 0.0 : pmatch * qM2M * tt[T_D2M], b_gd = off ? 0.0 : (double)tt[T_D2D];  // :95-97
       const double c_im = off ? 0.0 : pmatch * qI2M * tM2M, b_im = off ? 0.0 : tM2M;                    // :99-101
-      double gd = 0.0, im = 0.0, gr, ir;
-      if (WALK) {
-        // as in the forward kernel, towards smaller columns: lane l0 is the span's rightmost column
-        if (valid) {
-          ROW(cur, F_GD, j) = a_gd;
-          ROW(cur, F_IM, j) = c_im;
-          XB(0, j) = b_gd;
-          XB(1, j) = b_im;
-        }
-        __syncthreads();
-        const int jf = Lt - 1 - s0 - l0, n = l1 - l0 + 1;
-        double y = 0.0;
-        if (lane < 2) {
-          const double yin = l0 == 0 ? (lane == 0 ? carry_gd : carry_im) : 0.0;
-          double* pc = lane == 0 ? &ROW(cur, F_GD, jf) : &ROW(cur, F_IM, jf);
-          const double* p1 = lane == 0 ? &XB(0, jf) : wk + 1;
-          const double* p2 = lane == 1 ? &XB(1, jf) : wk;
-          y = mac_walk(pc, p1, p2, -1, lane == 0 ? -1 : 0, lane == 1 ? -1 : 0, n, yin);
-        }
-        __syncthreads();
-        gr = ROW(cur, F_GD, jc + 1);  // curr[j+1].gd / .im (column Lt: 0, written above)
-        ir = ROW(cur, F_IM, jc + 1);
-        carry_gd = l1 == 63 ? lane_d(y, 0) : 0.0;
-        carry_im = l1 == 63 ? lane_d(y, 1) : 0.0;
-      } else {
-        const bool first_lane = lane == 0;  // its neighbour is the carry of the previous strip: folded, see the forward kernel
-        const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
-        const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
-        const int n_steps = l1 - l0 + 1;
-        for (int s = 0; s < n_steps; ++s) {
-          const double gl = shr1_dz(gd), il = shr1_dz(im);
-          gd = a_gd_s + gl * b_gd;
-          im = c_im_s + il * qI2I * b_im;
-        }
-        gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);  // curr[j+1].gd / .im
+      const bool first_lane = lane == 0;  // its neighbour is the carry of the previous strip: folded, see the forward kernel
+      const double a_gd_s = first_lane ? a_gd + carry_gd * b_gd : a_gd;
+      const double c_im_s = first_lane ? c_im + carry_im * qI2I * b_im : c_im;
+      double gd = 0.0, im = 0.0;
+      const int n_steps = l1 - l0 + 1;
+      for (int s = 0; s < n_steps; ++s) {
+        const double gr = shr1_dz(gd), ir = shr1_dz(im);
+        gd = a_gd_s + gr * b_gd;
+        im = c_im_s + ir * qI2I * b_im;
       }
+      const double gr = shr1_d(gd, carry_gd), ir = shr1_d(im, carry_im);  // curr[j+1].gd / .im
       double mm = (+pmin + pmatch * qM2M * tM2M + gr * tt[T_M2D] + ir * qM2I * tM2M + pdg * qM2D * sc +
                    pmi * qM2M * tt[T_M2I] * sc);  // :86-93
       if (off) mm = dg = mi = 0.0;
       if (valid) {
         ROW(cur, F_MM, j) = mm;
-        if (!WALK) {
-          ROW(cur, F_GD, j) = gd;
-          ROW(cur, F_IM, j) = im;
-        }
+        ROW(cur, F_GD, j) = gd;
+        ROW(cur, F_IM, j) = im;
         ROW(cur, F_DG, j) = dg;
         ROW(cur, F_MI, j) = mi;
         row[j] = f_cur * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
@@ -689,10 +567,8 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
         const float v = (float)((double)sub * Cshift * mm / Pf * final_scale_prod / scale_prod);
         if (v > MAC_LIST_THRESHOLD) blist[(size_t)i * pitch + j] = v;
       }
-      if (!WALK) {
-        carry_gd = lane_d(gd, 63);
-        carry_im = lane_d(im, 63);
-      }
+      carry_gd = lane_d(gd, 63);
+      carry_im = lane_d(im, 63);
     }
     if (STAGE) {
       unsigned char* co_n = sCo + ((i - 1) & 1) * co_stride;
@@ -708,6 +584,607 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
     }
     __syncthreads();
     cur = prv;
+  }
+}
+
+// ---- forward / backward as a dataflow of the wavefronts of one workgroup (round 5) ---------------------------------------
+// What bounds the single-wave kernels above is the LATENCY of the sweeps, not the number of their instructions: a sweep step of
+// the IM chain is shift -> multiply -> multiply -> add, four dependent instructions of a lone wave (~42 clocks measured), 64 steps
+// per strip, and the parallel part of the strip (operand loads, a 20-term dot product, some thirty fp64 operations per cell) waits
+// behind it.  Moving the chains to other wavefronts does not shorten them (measured: a lockstep pipeline of a parallel-part wave and
+// two sweep waves ran 1.72 ms where one wave needs 1.84); what does is having the sweeps of TWO ROWS in flight.  The dependencies
+// allow it: the parallel part of (row i, strip s) needs the chains of (row i-1, strips s and s-1) and - forward only - the rescaling
+// factor of row i-1, i.e. max_j F_MM over ALL strips of row i-1, which comes out of the parallel part alone.  So the sweep of
+// (i, s) may run one strip behind the sweep of (i-1, s), and (forward) row i+1 starts when the parallel part of row i is complete,
+// which needs the last strip of row i-1: rows overlap in pairs - two rows in the time of one.  Backward the scale factors are known
+// (the forward pass stored them) and the rows form a plain diagonal wavefront.
+// A hit gets a workgroup of six wavefronts, each running its own loop over its units (row, strip) and waiting on progress counters
+// in LDS (monotone, one per wave; LDS executes a wave's operations in order, so a counter written after the data is seen after it):
+//   P  (wave 0)      the parallel part of every unit in order: MM, DG, MI; the additive terms of the chains into the slots the
+//                    results will take (ROW(cur, F_GD / F_IM, j)), their factors into XB(0 / 1, j), the Pforward summand into
+//                    XB(2, j), the strip's mask of active lanes.  Waits for the sweeps (and the total) of the unit above.
+//   SG0 SI0 SG1 SI1  (waves 1-4) the GD / IM sweeps of the rows of one parity each; wait for P of their unit
+//   ST (wave 5)      forward: the running total of Pforward over all units in order (its own chain through the whole matrix);
+//   P2 (wave 5)      backward: B_MM from the swept chains (curr[j+1].gd / .im), the posterior F*B/Pforward, the -omat list entry;
+//                    backward P waits for P2 of the unit above instead of its sweeps.
+// Every value is computed by the operations of the single-wave kernels in their order (a chain's sweep IS the old sweep with the
+// other chain's instructions removed), so the results are the same bits.  Two row buffers are enough: a buffer is rewritten by
+// P two rows later, and P has by then waited for every reader of the old row (argued at each wait below).
+// Row state in global memory (GROWS) stays with the single-wave kernels.
+constexpr int MAC_ROW_FIELDS = 14;    // two rows of five states + XB(0..3)
+constexpr int MAC_DF_STRIPS = 24;     // strips per row the mask table holds (LDS limits the templates of these kernels to ~1420 columns)
+constexpr int MAC_CTL_DOUBLES = 64;   // behind the rows: masks [2][24], per-row ring [2], progress counters
+#define XB(k, j) rows[(10 + (k)) * stride + (j)]
+enum { DF_P = 0, DF_S = 1 /* [set][chain] */, DF_T = 5 };
+
+// progress counters: wave uniform, written by one lane
+__device__ __forceinline__ void df_wait(volatile int* cnt, int need, volatile int* dead) {
+  // bounded: a wave that never sees its counter gives up (the results are then wrong and the parity tests say so) instead of
+  // hanging the device; after the first time-out nobody waits any more
+  for (int g = 0; g < (1 << 18); ++g) {
+    if (__builtin_amdgcn_readfirstlane(*cnt) >= need) break;
+    if (__builtin_amdgcn_readfirstlane(*dead)) break;
+    if (g == (1 << 18) - 1) *dead = 1;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void df_post(volatile int* cnt, int v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) *cnt = v;
+}
+
+__device__ __forceinline__ void stage_template_wg(const HitView& h, float* sTp, float* sTt, int tid, int nt) {
+  for (int e = tid; e < (h.Lt + 1) * 20; e += nt) sTp[e] = h.tp[(size_t)(e / 20) * h.tps + (e % 20)];
+  for (int e = tid; e < (h.Lt + 1) * 8; e += nt) sTt[e] = (e & 7) < 7 ? h.ttr[(size_t)(e >> 3) * 7 + (e & 7)] : 0.0f;
+}
+
+template <bool LOCAL, bool STAGE>
+__global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* rows = reinterpret_cast<double*>(smem);
+  constexpr int NT = 384;
+  const int k = a.sel[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const HitView h = view(a, k);
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  const size_t cols = (size_t)a.lds_cols + 2;  // layout sized for the longest template of the launch
+  double* ctl = rows + MAC_ROW_FIELDS * cols;
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS] active lanes of (row & 1, strip)
+  double* rring = ctl + 2 * MAC_DF_STRIPS;                                 // [2] scale[i+1] of row i
+  volatile int* cnt = reinterpret_cast<volatile int*>(ctl + 2 * MAC_DF_STRIPS + 2);
+  float* sTp = reinterpret_cast<float*>(ctl + MAC_CTL_DOUBLES);
+  float* sTt = sTp + cols * 20;
+  unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + cols * 8);  // [2][cols]: the mask bytes of a row, fetched a row ahead (P only)
+  const int co_stride = (int)cols;
+  float* sSs = reinterpret_cast<float*>(sCo + (((size_t)2 * co_stride + 15) & ~(size_t)15)) + (size_t)2 * co_stride;  // [352]
+  const float* sstab = STAGE ? sSs : h.sstab;
+  const double Cshift = a.Cshift;
+  for (int e = tid; e < 10 * stride; e += NT) rows[e] = 0.0;
+  for (int e = tid; e < pitch; e += NT) h.mat[e] = 0.0f;  // row 0 of p_mm is never read
+  if (STAGE) {
+    stage_template_wg(h, sTp, sTt, tid, NT);
+    if (h.ssm)
+      for (int e = tid; e < 352; e += NT) sSs[e] = h.sstab[e];
+    for (int j = 1 + tid; j <= Lt; j += NT) sCo[co_stride + j] = h.co[(size_t)pitch + j];  // row 1 (buffer row & 1)
+  }
+  if (tid < 8) cnt[tid] = 0;
+  if (tid == 0) h.scale[0] = h.scale[1] = h.scale[2] = 1.0;
+  __syncthreads();
+  const int ns = (Lt + 63) >> 6;
+
+  if (wv == 0) {
+    // ---- P ----
+    unsigned char co_next = (!STAGE && 1 + lane <= Lt) ? h.co[(size_t)pitch + 1 + lane] : 1;
+    double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0, scale_i = 1.0;
+    for (int i = 1; i <= Lq; ++i) {
+      const int cur = i & 1, prv = cur ^ 1;
+      if (i >= 2) {
+        if (scale_prod < DBL_MIN * 100)
+          scale_prod = 0.0;
+        else
+          scale_prod *= scale_i;
+      }
+      const float* qi = h.qp + (size_t)i * 20;
+      const float* qt1 = h.qtr + (size_t)(i - 1) * 7;  // q.tr[i-1]
+      const double qM2M = qt1[T_M2M], qI2M = qt1[T_I2M], qD2M = qt1[T_D2M], qM2D = qt1[T_M2D], qD2D = qt1[T_D2D];
+      const double qM2I = h.qtr[(size_t)i * 7 + T_M2I];
+      double Pmax = 0.0, carry_mm = 0.0;
+      unsigned char pre_co[MAC_PRE];
+      if (STAGE) {
+#pragma unroll
+        for (int u = 0; u < MAC_PRE; ++u) {
+          const int jn = 1 + u * 64 + lane;
+          pre_co[u] = (i < Lq && jn <= Lt) ? h.co[(size_t)(i + 1) * pitch + jn] : 1;
+        }
+      }
+      const unsigned char* co_row = sCo + cur * co_stride;
+      const int above = ((i - 2) >> 1) * ns;  // units the sweep waves of row i-1's parity have finished before that row
+      for (int s = 0; s < ns; ++s) {
+        if (i >= 2) {
+          // row i-1's chains of this strip (and, in order, of the ones left of it) are final; its operands XB(.., strip s) and
+          // its mask are consumed (the sweeps and the total are done with them), and so is everything of row i-2, whose buffer
+          // this unit overwrites: this wave waited for the readers of row i-2 before every unit of row i-1
+          df_wait(cnt + DF_S + 2 * (prv) + 0, above + s + 1, cnt + 7);
+          df_wait(cnt + DF_S + 2 * (prv) + 1, above + s + 1, cnt + 7);
+          df_wait(cnt + DF_T, (i - 2) * ns + s + 1, cnt + 7);
+        }
+        const int s0 = s << 6, j = 1 + s0 + lane;
+        const bool valid = j <= Lt;
+        const int jc = valid ? j : Lt;
+        const bool off = !valid || (STAGE ? co_row[jc] != 0 : co_next != 0);
+        if (!STAGE) {
+          const bool last = s0 + 64 >= Lt;
+          const int ni = last ? i + 1 : i, nj = last ? 1 + lane : j + 64;
+          co_next = (ni <= Lq && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
+        }
+        const unsigned long long on_mask = __ballot(!off);
+        if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
+        if (on_mask == 0) {
+          // a strip without a single active cell: all five states are zero, the running sums are unchanged
+          if (valid) {
+            ROW(cur, F_MM, j) = 0.0;
+            ROW(cur, F_GD, j) = 0.0;
+            ROW(cur, F_IM, j) = 0.0;
+            ROW(cur, F_DG, j) = 0.0;
+            ROW(cur, F_MI, j) = 0.0;
+            h.mat[(size_t)i * pitch + j] = 0.0f;
+          }
+          carry_mm = 0.0;
+        } else {
+          float tpj[20], tt1[7], tt[7];
+          load_tp<STAGE>(h, sTp, jc, tpj);
+          load_tt<STAGE>(h, sTt, jc - 1, tt1);  // t.tr[j-1]
+          load_tt<STAGE>(h, sTt, jc, tt);       // t.tr[j]
+          const float pf = dot20(qi, tpj);
+          // fpow2(ScoreSS(q, t, i, j)); for column 1 the reference passes (1, j) with the stale loop variable j = t.L + 1 (:77)
+          float ssf = 1.0f;
+          if (h.ssm && i >= 2) ssf = j == 1 ? sstab[h.ssq[1] * h.sstw + h.sst[Lt + 1]] : sstab[h.ssq[i] * h.sstw + h.sst[jc]];
+          double mm, dg, mi;
+          if (i == 1) {
+            mm = pf * Cshift;  // :31
+            dg = mi = 0.0;
+          } else {
+            const double pm = ROW(prv, F_MM, jc), pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
+            if (j == 1) {
+              mm = scale_prod * ssf * pf * Cshift;  // :71-73
+            } else {
+              const double m1 = ROW(prv, F_MM, jc - 1), g1 = ROW(prv, F_GD, jc - 1), i1 = ROW(prv, F_IM, jc - 1),
+                           d1 = ROW(prv, F_DG, jc - 1), x1 = ROW(prv, F_MI, jc - 1);
+              mm = pf * Cshift * ssf * scale_i *
+                   (pmin + m1 * qM2M * tt1[T_M2M] + g1 * qM2M * tt1[T_D2M] + i1 * qI2M * tt1[T_M2M] + d1 * qD2M * tt1[T_M2M] +
+                    x1 * qM2M * tt1[T_I2M]);  // :94-103
+            }
+            dg = scale_i * (pm * qM2D + pdg * qD2D);                          // :110-112 / :79-81
+            mi = scale_i * (pm * qM2M * tt[T_M2I] + pmi * qM2M * tt[T_I2I]);  // :113-116 / :75-78
+          }
+          if (off) mm = dg = mi = 0.0;
+          if (i >= 2 && j >= 2 && !off) Pmax = fmax(Pmax, mm);
+          // the recurrences along the row (:104-109): gd = mm(j-1)*t[j-1][M2D] + gd(j-1)*t[j-1][D2D],
+          //                                           im = mm(j-1)*q[i][M2I]*t[j-1][M2M] + im(j-1)*q[i][I2I]*t[j-1][M2M]
+          const double mm_left = shr1_d(mm, carry_mm);
+          const bool chain_on = !off && (i == 1 || j >= 2);  // column 1 of rows >= 2: im = gd = 0 (:74)
+          const double a_gd = chain_on ? mm_left * tt1[T_M2D] : 0.0, b_gd = chain_on ? (double)tt1[T_D2D] : 0.0;
+          const double c_im = chain_on ? mm_left * qM2I * tt1[T_M2M] : 0.0, b_im = chain_on ? (double)tt1[T_M2M] : 0.0;
+          if (valid) {
+            ROW(cur, F_MM, j) = mm;
+            ROW(cur, F_GD, j) = a_gd;
+            ROW(cur, F_IM, j) = c_im;
+            ROW(cur, F_DG, j) = dg;
+            ROW(cur, F_MI, j) = mi;
+            XB(0, j) = b_gd;
+            XB(1, j) = b_im;
+            if (LOCAL) XB(2, j) = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
+            h.mat[(size_t)i * pitch + j] = (float)mm;
+          }
+          carry_mm = lane_d(mm, 63);
+        }
+        if (s == ns - 1) {
+          // the row's rescaling factor, before the unit is posted: the total reads it at the end of its row
+          if (lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
+          if (STAGE) {
+            unsigned char* co_nextrow = sCo + prv * co_stride;
+#pragma unroll
+            for (int u = 0; u < MAC_PRE; ++u) {
+              const int jn = 1 + u * 64 + lane;
+              if (jn <= Lt) co_nextrow[jn] = pre_co[u];
+            }
+          }
+          double scale_next = 1.0;
+          if (i >= 2) {
+            Pmax = wave_max_d(Pmax);
+            pmin *= scale_i;
+            if (pmin < DBL_MIN * 100) pmin = 0.0;
+            scale_next = 1.0 / (Pmax + 1.0);  // :155
+            if (lane == 0) h.scale[i + 1] = scale_next;
+          }
+          if (lane == 0) rring[cur] = scale_next;
+          scale_i = scale_next;
+        }
+        df_post(cnt + DF_P, (i - 1) * ns + s + 1, lane);
+      }
+    }
+  } else if (wv <= 4) {
+    // ---- SG / SI of the rows of one parity ----
+    const int par = (wv - 1) >> 1;
+    const bool gdw = ((wv - 1) & 1) == 0;
+    volatile int* mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
+    int done = 0;
+    for (int i = par ? 1 : 2; i <= Lq; i += 2) {
+      const int cur = i & 1;
+      const double qI2I = gdw ? 0.0 : (double)h.qtr[(size_t)i * 7 + T_I2I];
+      double carry = 0.0;
+      for (int s = 0; s < ns; ++s) {
+        df_wait(cnt + DF_P, (i - 1) * ns + s + 1, cnt + 7);
+        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+        const int j = 1 + (s << 6) + lane;
+        const bool valid = j <= Lt;
+        if (on_mask == 0) {
+          carry = 0.0;
+        } else {
+          const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
+          // Sweep: inactive lanes hold 0 whatever their neighbour says, so the lanes left of the first active one are final
+          // from the start and l1 - l0 + 1 steps finish everything up to the last active lane.  Lane 0's left neighbour is the
+          // carry of the previous strip, a constant of the sweep: its step is evaluated once, with the operations of the loop
+          // body, and the loop shifts zeros into lane 0 (x + 0*b = x for the non-negative finite values here).
+          const bool first_lane = lane == 0;
+          const int n_steps = l1 - l0 + 1;
+          double* slot = gdw ? &ROW(cur, F_GD, j) : &ROW(cur, F_IM, j);
+          const double c0 = valid ? *slot : 0.0, b = valid ? XB(gdw ? 0 : 1, j) : 0.0;
+          double y = 0.0;
+          if (gdw) {
+            const double a_gd_s = first_lane ? c0 + carry * b : c0;
+            for (int q = 0; q < n_steps; ++q) {
+              const double gl = shr1_dz(y);
+              y = a_gd_s + gl * b;
+            }
+          } else {
+            const double c_im_s = first_lane ? c0 + carry * qI2I * b : c0;
+            for (int q = 0; q < n_steps; ++q) {
+              const double il = shr1_dz(y);
+              y = c_im_s + il * qI2I * b;
+            }
+          }
+          if (valid) *slot = y;
+          carry = lane_d(y, 63);  // lane 63 is either inactive (0) or l1 (final)
+        }
+        df_post(mine, ++done, lane);
+      }
+    }
+  } else {
+    // ---- ST: total forward probability (:162-182), one chain through all units ----
+    double Pf = LOCAL ? 1.0 : 0.0;
+    for (int i = 1; i <= Lq; ++i) {
+      const int cur = i & 1;
+      for (int s = 0; s < ns; ++s) {
+        df_wait(cnt + DF_P, (i - 1) * ns + s + 1, cnt + 7);
+        if (LOCAL) {
+          const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+          if (on_mask != 0) {
+            const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
+            const int j = 1 + (s << 6) + lane;
+            const double f_mm = j <= Lt ? XB(2, j) : 0.0;
+            const double f_mm_s = lane == 0 ? Pf + f_mm : f_mm;
+            double acc = Pf;
+            const int n_steps = l1 - l0 + 1;
+            for (int q = 0; q < n_steps; ++q) acc = shr1_dz(acc) + f_mm_s;
+            Pf = lane_d(acc, l1);  // lanes right of l1 would only add zeros
+          }
+        }
+        if (s == ns - 1) {
+          const double scale_next = rring[cur];
+          if (LOCAL) {
+            Pf *= scale_next;
+          } else if (i < Lq) {
+            Pf = (Pf + (float)ROW(cur, F_MM, Lt) * scale_next);
+          }
+        }
+        df_post(cnt + DF_T, (i - 1) * ns + s + 1, lane);
+      }
+    }
+    if (!LOCAL) {
+      // + sum_j F(Lq, j) in column order, then * scale[Lq+1]
+      const int last = Lq & 1;
+      for (int s0 = 0; s0 < Lt; s0 += 64) {
+        const int j = 1 + s0 + lane;
+        const double f_mm = j <= Lt ? (double)(float)ROW(last, F_MM, j) : 0.0;
+        double acc = Pf;
+        for (int q = 0; q < 64; ++q) acc = shr1_d(acc, Pf) + f_mm;
+        Pf = lane_d(acc, 63);
+      }
+      Pf *= rring[Lq & 1];
+    }
+    if (lane == 0) a.Pforward[k] = Pf;
+  }
+}
+
+// Backward: P (wave 0) computes what depends on row i+1 only - pmatch, DG, MI, the chains' operands and, for B_MM, the partial
+// sum pmin + pmatch*q[M2M]*t[M2M] (into the F_MM slot) and the two last summands (XB(2 / 3, j)); the sweep waves follow; P2
+// (wave 5) completes B_MM = (((partial + gd(j+1)*t[M2D]) + im(j+1)*q[M2I]*t[M2M]) + XB2) + XB3 - the reference's left-to-right
+// sum (src/hhbackwardalgorithm.cpp:86-93) - and turns F_MM into the posterior.  P of (i-1, s) waits for P2 of (i, s).
+template <bool LOCAL, bool STAGE, bool LISTS>
+__global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* rows = reinterpret_cast<double*>(smem);
+  constexpr int NT = 384;
+  const int k = a.sel[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const HitView h = view(a, k);
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  const size_t cols = (size_t)a.lds_cols + 2;
+  double* ctl = rows + MAC_ROW_FIELDS * cols;
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS]
+  double* rring = ctl + 2 * MAC_DF_STRIPS;                                 // [2] mask byte of (i, Lt) != 0
+  volatile int* cnt = reinterpret_cast<volatile int*>(ctl + 2 * MAC_DF_STRIPS + 2);
+  float* sTp = reinterpret_cast<float*>(ctl + MAC_CTL_DOUBLES);
+  float* sTt = sTp + cols * 20;
+  // STAGE: the mask bytes (P) and F_MM (P2) of a row are fetched while the row processed before it is computed
+  unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + cols * 8);  // [2][cols]
+  const int co_stride = (int)cols;
+  float* sF = reinterpret_cast<float*>(sCo + (((size_t)2 * co_stride + 15) & ~(size_t)15));  // [2][cols]
+  float* sSs = sF + (size_t)2 * co_stride;                                                    // [352]
+  const float* sstab = STAGE ? sSs : h.sstab;
+  const double Cshift = a.Cshift, Pf = a.Pforward[k];
+  for (int e = tid; e < 10 * stride; e += NT) rows[e] = 0.0;
+  if (STAGE) {
+    stage_template_wg(h, sTp, sTt, tid, NT);
+    if (h.ssm)
+      for (int e = tid; e < 352; e += NT) sSs[e] = h.sstab[e];
+    if (Lq >= 2)
+      for (int j = 1 + tid; j <= Lt; j += NT) {  // row Lq - 1, the first one of the loops below
+        sCo[((Lq - 1) & 1) * co_stride + j] = h.co[(size_t)(Lq - 1) * pitch + j];
+        sF[((Lq - 1) & 1) * co_stride + j] = h.mat[(size_t)(Lq - 1) * pitch + j];
+      }
+  }
+  if (tid < 8) cnt[tid] = 0;
+  __syncthreads();
+  const double sL = h.scale[Lq + 1];
+  // row Lq (:19-29); row i lives in buffer i & 1
+  for (int j = 1 + tid; j <= Lt; j += NT) {
+    float* pv = h.mat + (size_t)Lq * pitch + j;
+    if (h.co[(size_t)Lq * pitch + j]) {
+      *pv = 0.0f;
+      ROW(Lq & 1, F_MM, j) = 0.0;
+    } else {
+      ROW(Lq & 1, F_MM, j) = sL;
+      *pv = (float)(*pv * sL / Pf);
+    }
+  }
+  __syncthreads();
+  const int ns = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 1;  // strips of columns Lt-1 .. 1 (Lt = 1: one strip without a valid lane)
+
+  if (wv == 0) {
+    // ---- P ----
+    double pmin = LOCAL ? sL : 0.0;
+    double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;  // scale[i+1] of the row, fetched a row ahead
+    unsigned char co_nx = (!STAGE && Lq >= 2 && Lt - 1 - lane >= 1) ? h.co[(size_t)(Lq - 1) * pitch + Lt - 1 - lane] : 1;
+    for (int i = Lq - 1; i >= 1; --i) {
+      const int cur = i & 1, prv = cur ^ 1;
+      const double sc = sc_next;
+      sc_next = i >= 2 ? h.scale[i] : 1.0;
+      pmin *= sc;
+      if (pmin < DBL_MIN * 100) pmin = 0.0;
+      const float* qn = h.qp + (size_t)(i + 1) * 20;
+      const float* qt = h.qtr + (size_t)i * 7;
+      const double qM2M = qt[T_M2M], qM2D = qt[T_M2D], qI2M = qt[T_I2M], qD2M = qt[T_D2M], qD2D = qt[T_D2D];
+      const unsigned char* corow = h.co + (size_t)i * pitch;
+      const unsigned char* co_l = sCo + cur * co_stride;
+      unsigned char pre_co[MAC_PRE];
+      if (STAGE) {
+#pragma unroll
+        for (int q = 0; q < MAC_PRE; ++q) {
+          const int jn = 1 + q * 64 + lane;
+          pre_co[q] = (i >= 2 && jn <= Lt) ? h.co[(size_t)(i - 1) * pitch + jn] : 1;
+        }
+      }
+      const unsigned char coL = STAGE ? co_l[Lt] : corow[Lt];  // the mask byte of column Lt, for P2's column-Lt step of this row
+      for (int s = 0; s < ns; ++s) {
+        // B_MM of row i+1 at this strip's columns and the one right of them is final; with it the sweeps of (i+1, s) are done
+        // with XB(0 / 1), P2 with XB(2 / 3), the mask and the per-row ring, and everything of row i+2 (whose buffer this unit
+        // overwrites) has been read: this wave waited for P2 of every unit of row i+2 before the units of row i+1
+        if (i <= Lq - 2) df_wait(cnt + DF_T, (Lq - 2 - i) * ns + s + 1, cnt + 7);
+        if (s == 0 && lane == 0) rring[cur] = coL ? 1.0 : 0.0;
+        const int j = Lt - 1 - (s << 6) - lane;  // descending: lane 0 is the rightmost column of the strip
+        const bool valid = j >= 1;
+        const int jc = valid ? j : 1;
+        const bool off = !valid || (STAGE ? co_l[jc] != 0 : co_nx != 0);
+        if (!STAGE) {
+          // the next unit of this wave: the next strip of the row, or the first strip of row i - 1
+          const bool last = s == ns - 1;
+          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - lane : j - 64;
+          co_nx = (ni >= 1 && nj >= 1) ? h.co[(size_t)ni * pitch + nj] : 1;
+        }
+        const unsigned long long on_mask = __ballot(!off);
+        if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
+        if (on_mask == 0) {
+          if (valid) {
+            ROW(cur, F_MM, j) = 0.0;
+            ROW(cur, F_GD, j) = 0.0;
+            ROW(cur, F_IM, j) = 0.0;
+            ROW(cur, F_DG, j) = 0.0;
+            ROW(cur, F_MI, j) = 0.0;
+          }
+        } else {
+          float tpn[20], tt[7];
+          load_tp<STAGE>(h, sTp, jc + 1, tpn);
+          load_tt<STAGE>(h, sTt, jc, tt);
+          const float pf = dot20(qn, tpn);
+          const float ssf = h.ssm ? sstab[h.ssq[i + 1] * h.sstw + h.sst[jc + 1]] : 1.0f;  // fpow2(ScoreSS(q, t, i+1, j+1))
+          const double pmatch = ROW(prv, F_MM, jc + 1) * pf * ssf * Cshift * sc;  // :80-83
+          const double pdg = ROW(prv, F_DG, jc), pmi = ROW(prv, F_MI, jc);
+          const double tM2M = tt[T_M2M];
+          double dg = (+pmatch * qD2M * tM2M + pdg * qD2D * sc);                    // :103-106
+          double mi = (+pmatch * qM2M * tt[T_I2M] + pmi * qM2M * tt[T_I2I] * sc);  // :108-111
+          const double a_gd = off ? 0.0 : pmatch * qM2M * tt[T_D2M], b_gd = off ? 0.0 : (double)tt[T_D2D];  // :95-97
+          const double c_im = off ? 0.0 : pmatch * qI2M * tM2M, b_im = off ? 0.0 : tM2M;                    // :99-101
+          const double t0 = (+pmin + pmatch * qM2M * tM2M);  // :86-93, the first two summands
+          const double e4 = pdg * qM2D * sc, e5 = pmi * qM2M * tt[T_M2I] * sc;
+          if (off) dg = mi = 0.0;
+          if (valid) {
+            ROW(cur, F_MM, j) = t0;
+            ROW(cur, F_GD, j) = a_gd;
+            ROW(cur, F_IM, j) = c_im;
+            ROW(cur, F_DG, j) = dg;
+            ROW(cur, F_MI, j) = mi;
+            XB(0, j) = b_gd;
+            XB(1, j) = b_im;
+            XB(2, j) = e4;
+            XB(3, j) = e5;
+          }
+        }
+        if (s == ns - 1 && STAGE) {
+          unsigned char* co_n = sCo + prv * co_stride;
+#pragma unroll
+          for (int q = 0; q < MAC_PRE; ++q) {
+            const int jn = 1 + q * 64 + lane;
+            if (jn <= Lt) co_n[jn] = pre_co[q];
+          }
+        }
+        df_post(cnt + DF_P, (Lq - 1 - i) * ns + s + 1, lane);
+      }
+    }
+  } else if (wv <= 4) {
+    // ---- SG / SI of the rows of one parity ----
+    const int par = (wv - 1) >> 1;
+    const bool gdw = ((wv - 1) & 1) == 0;
+    volatile int* mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
+    int done = 0;
+    for (int i = ((Lq - 1) & 1) == par ? Lq - 1 : Lq - 2; i >= 1; i -= 2) {
+      const int cur = i & 1;
+      const double qI2I = gdw ? 0.0 : (double)h.qtr[(size_t)i * 7 + T_I2I];
+      double carry = 0.0;  // curr[Lt].gd = curr[Lt].im = 0
+      for (int s = 0; s < ns; ++s) {
+        df_wait(cnt + DF_P, (Lq - 1 - i) * ns + s + 1, cnt + 7);
+        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+        const int j = Lt - 1 - (s << 6) - lane;
+        const bool valid = j >= 1;
+        const int jc = valid ? j : 1;
+        if (on_mask == 0) {
+          carry = 0.0;
+        } else {
+          const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
+          const bool first_lane = lane == 0;  // its neighbour is the carry of the previous strip: folded, see the forward kernel
+          const int n_steps = l1 - l0 + 1;
+          double* slot = gdw ? &ROW(cur, F_GD, jc) : &ROW(cur, F_IM, jc);
+          const double c0 = valid ? *slot : 0.0, b = valid ? XB(gdw ? 0 : 1, jc) : 0.0;
+          double y = 0.0;
+          if (gdw) {
+            const double a_gd_s = first_lane ? c0 + carry * b : c0;
+            for (int q = 0; q < n_steps; ++q) {
+              const double gl = shr1_dz(y);
+              y = a_gd_s + gl * b;
+            }
+          } else {
+            const double c_im_s = first_lane ? c0 + carry * qI2I * b : c0;
+            for (int q = 0; q < n_steps; ++q) {
+              const double il = shr1_dz(y);
+              y = c_im_s + il * qI2I * b;
+            }
+          }
+          if (valid) *slot = y;
+          carry = lane_d(y, 63);
+        }
+        df_post(mine, ++done, lane);
+      }
+    }
+  } else {
+    // ---- P2 ----
+    double scale_prod = sL;
+    double final_scale_prod = sL;  // :31-36
+    if (LISTS) {
+      // (64 factors per trip to memory: the other waves wait for this one's first unit)
+      for (int base = Lq - 1; base >= 1; base -= 64) {
+        const int ii = base - lane;
+        const double v = ii >= 1 ? h.scale[ii + 1] : 1.0;
+        const int n = base < 64 ? base : 64;
+        for (int l = 0; l < n; ++l) {
+          final_scale_prod *= lane_d(v, l);
+          if (final_scale_prod < DBL_MIN * 100) final_scale_prod = 0.0;
+        }
+      }
+    }
+    float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
+    double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;
+    float f_nx = (!STAGE && Lq >= 2 && Lt - 1 - lane >= 1) ? h.mat[(size_t)(Lq - 1) * pitch + Lt - 1 - lane] : 0.0f;
+    int done0 = 0, done1 = 0;  // units the sweep waves of either parity must have finished
+    for (int i = Lq - 1; i >= 1; --i) {
+      const int cur = i & 1;
+      const double sc = sc_next;
+      sc_next = i >= 2 ? h.scale[i] : 1.0;
+      scale_prod *= sc;
+      if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
+      const double qM2I = h.qtr[(size_t)i * 7 + T_M2I];
+      float* row = h.mat + (size_t)i * pitch;
+      const float* f_l = sF + cur * co_stride;
+      float pre_f[MAC_PRE];
+      if (STAGE) {
+#pragma unroll
+        for (int q = 0; q < MAC_PRE; ++q) {
+          const int jn = 1 + q * 64 + lane;
+          pre_f[q] = (i >= 2 && jn <= Lt) ? h.mat[(size_t)(i - 1) * pitch + jn] : 0.0f;
+        }
+      }
+      const float fL = STAGE ? f_l[Lt] : (lane == 0 ? row[Lt] : 0.0f);
+      for (int s = 0; s < ns; ++s) {
+        int& need = cur ? done1 : done0;
+        ++need;
+        df_wait(cnt + DF_S + 2 * cur + 0, need, cnt + 7);
+        df_wait(cnt + DF_S + 2 * cur + 1, need, cnt + 7);
+        if (s == 0 && lane == 0) {
+          // column Lt (:58-71)
+          if (rring[cur] != 0.0) {
+            row[Lt] = 0.0f;
+            ROW(cur, F_MM, Lt) = 0.0;
+          } else {
+            ROW(cur, F_MM, Lt) = scale_prod;
+            row[Lt] = (float)(fL * scale_prod / Pf);
+          }
+          ROW(cur, F_GD, Lt) = ROW(cur, F_IM, Lt) = ROW(cur, F_DG, Lt) = ROW(cur, F_MI, Lt) = 0.0;
+        }
+        const int j = Lt - 1 - (s << 6) - lane;
+        const bool valid = j >= 1;
+        const int jc = valid ? j : 1;
+        const float f_cur = STAGE ? (valid ? f_l[jc] : 0.0f) : f_nx;
+        if (!STAGE) {
+          const bool last = s == ns - 1;
+          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - lane : j - 64;
+          f_nx = (ni >= 1 && nj >= 1) ? h.mat[(size_t)ni * pitch + nj] : 0.0f;
+        }
+        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+        if (on_mask == 0) {
+          if (valid) row[j] = f_cur * (float)(0.0 / Pf);  // F * (float)(B / Pforward) with B = 0 (NaN if Pforward is 0, as in the reference)
+        } else {
+          const bool off = !((on_mask >> lane) & 1);
+          float tt[7];
+          load_tt<STAGE>(h, sTt, jc, tt);
+          const double tM2M = tt[T_M2M];
+          const double gr = ROW(cur, F_GD, jc + 1), ir = ROW(cur, F_IM, jc + 1);  // curr[j+1].gd / .im
+          double mm = (ROW(cur, F_MM, jc) + gr * tt[T_M2D] + ir * qM2I * tM2M + XB(2, jc) + XB(3, jc));  // :86-93
+          if (off) mm = 0.0;
+          if (valid) {
+            ROW(cur, F_MM, j) = mm;
+            row[j] = f_cur * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
+          }
+          if (LISTS && valid && !off) {
+            // :112-122: float = ProbFwd(q.p[i], t.p[j]) * Cshift * B_MM / Pforward * final_scale_prod / scale_prod, left to right
+            float tpj[20];
+            load_tp<STAGE>(h, sTp, jc, tpj);
+            const float sub = dot20(h.qp + (size_t)i * 20, tpj);
+            const float v = (float)((double)sub * Cshift * mm / Pf * final_scale_prod / scale_prod);
+            if (v > MAC_LIST_THRESHOLD) blist[(size_t)i * pitch + j] = v;
+          }
+        }
+        if (s == ns - 1 && STAGE) {
+          float* f_n = sF + (cur ^ 1) * co_stride;
+#pragma unroll
+          for (int q = 0; q < MAC_PRE; ++q) {
+            const int jn = 1 + q * 64 + lane;
+            if (jn <= Lt) f_n[jn] = pre_f[q];
+          }
+        }
+        df_post(cnt + DF_T, (Lq - 1 - i) * ns + s + 1, lane);
+      }
+    }
   }
 }
 
@@ -1004,7 +1481,7 @@ int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
 size_t mac_rows_lds(int max_Lt, bool stage) {
   // staged: + the template (28 floats per column) + two rows of mask bytes + two rows of F_MM fetched a row ahead + the
   // secondary-structure table of the hit
-  return (size_t)MAC_ROW_FIELDS * (max_Lt + 2) * sizeof(double) +
+  return ((size_t)MAC_ROW_FIELDS * (max_Lt + 2) + MAC_CTL_DOUBLES) * sizeof(double) +
          (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) + (((size_t)2 * (max_Lt + 2) + 15) & ~(size_t)15) +
                       (size_t)2 * (max_Lt + 2) * sizeof(float) + 352 * sizeof(float) : 0);
 }
@@ -1012,9 +1489,24 @@ constexpr size_t MAC_LDS_LIMIT = 160 * 1024;
 
 template <bool LOCAL, bool STAGE, bool GROWS>
 static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t stream) {
+  static const bool no_pipe = getenv("HHV_MAC_NO_PIPE") != nullptr;  // measurement aid: the single-wave kernels for every class
+  if (!GROWS && !no_pipe) {
+    // row state in LDS: the dataflow kernels (six wavefronts per hit)
+    (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, STAGE>), dim3(n), dim3(384), lds, stream, a);
+    if (a.fwd_list) {  // the -o_matrices lists were asked for (hhv_mac_set_lists)
+      hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
+      (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, true>), dim3(n), dim3(384), lds, stream, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, false>), dim3(n), dim3(384), lds, stream, a);
+    }
+    return;
+  }
   (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>), dim3(n), dim3(64), lds, stream, a);
-  if (a.fwd_list) {  // the -o_matrices lists were asked for (hhv_mac_set_lists)
+  if (a.fwd_list) {
     hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
     (void)hipFuncSetAttribute((const void*)hhv_mac_backward_kernel<LOCAL, STAGE, GROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE, GROWS, true>), dim3(n), dim3(64), lds, stream, a);

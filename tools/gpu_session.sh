@@ -88,6 +88,16 @@ mac)   # mac [soak_s]: the MAC realignment after a kernel change: its tests, a s
   timeout 900 python -m pytest tests/test_mac.py tests/test_dropin_realign.py tests/test_pipeline.py tests/test_dropin_apps.py -q -m gpu -x 2>&1 | tail -3
   timeout 300 python tools/soak.py ${1:-40} 777 mac 2>$OUT/soak_mac.err | tail -3
   for a in "500 300 300 50" "500 300 0 50" "500 700 0 20"; do timeout 300 python tools/bench_mac.py $a 2>>$OUT/bench_mac.err | tee -a $OUT/bench_mac.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('n_hits','Lq','Lt','gpu_kernels_ms','mismatches_vs_reference','checked')}, d['resident_set']['gpu_kernels_ms'])"; done
+  echo "single-wave kernels (HHV_MAC_NO_PIPE=1):"
+  for a in "500 300 300 0" "500 300 0 0"; do HHV_MAC_NO_PIPE=1 timeout 300 python tools/bench_mac.py $a 2>>$OUT/bench_mac.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('n_hits','Lq','Lt','gpu_kernels_ms')}, d['resident_set']['gpu_kernels_ms'])"; done
+  ;;
+macprof)   # kernel statistics of the MAC kernels: the wavefront pipeline and the single-wave kernels on the same 500 hits
+  cd /tmp && export TMPDIR=/tmp
+  for m in pipe single; do
+    e=""; [ $m = single ] && e="HHV_MAC_NO_PIPE=1"
+    env $e timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mac_$m -o stats -- python $ROOT/tools/bench_mac.py 500 300 ${1:-300} 0 > $OUT/prof_mac_$m.txt 2>&1
+    f=$(find $OUT/prof_mac_$m -name "*kernel_stats.csv" | head -1); echo "== $m"; head -9 "$f" | cut -d, -f1-7; cp "$f" $OUT/mac_${m}_kernel_stats.csv; rm -rf $OUT/prof_mac_$m
+  done
   ;;
 r5p)   # the round's profiles: headline, backtrace, secondary structure (hhv_ss_kernel), and the kernel statistics of a 10 k backtrace search
   for spec in "r5|" "r5bt|--backtrace 1" "r5ss|--ss 4" "r5ssbt|--ss 4 --backtrace 1"; do
