@@ -60,12 +60,22 @@ __device__ __forceinline__ float shr1_f(float y, float carry) {
 __device__ __forceinline__ double lane_d(double y, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), l), __builtin_amdgcn_readlane(__double2loint(y), l));
 }
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_d(double old, double y) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(y), CTRL, ROW_MASK, 0xF, BOUND);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(y), CTRL, ROW_MASK, 0xF, BOUND);
+  return __hiloint2double(hi, lo);
+}
+// maximum over the wave of NON-NEGATIVE values (0 is the fill of the shifts): DPP moves inside the rows of 16, two row
+// broadcasts across them.  (__shfl_xor is ds_bpermute: twelve dependent trips through LDS, ~2 k clocks of a lone wave per row.)
 __device__ __forceinline__ double wave_max_d(double v) {
-  for (int o = 32; o >= 1; o >>= 1) {
-    const double w = __hiloint2double(__shfl_xor(__double2hiint(v), o, 64), __shfl_xor(__double2loint(v), o, 64));
-    v = fmax(v, w);
-  }
-  return v;
+  v = fmax(v, dpp_d<0x111, 0xF, true>(0.0, v));  // row_shr:1
+  v = fmax(v, dpp_d<0x112, 0xF, true>(0.0, v));  // row_shr:2
+  v = fmax(v, dpp_d<0x114, 0xF, true>(0.0, v));  // row_shr:4
+  v = fmax(v, dpp_d<0x118, 0xF, true>(0.0, v));  // row_shr:8   -> lane 15 of every row holds the row's maximum
+  v = fmax(v, dpp_d<0x142, 0xA, false>(v, v));   // row_bcast:15 into rows 1 and 3
+  v = fmax(v, dpp_d<0x143, 0xC, false>(v, v));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+  return lane_d(v, 63);
 }
 // ScalarProd20 (src/hhhit-inl.h:116-122): plain left-to-right float sum of products
 __device__ __forceinline__ float dot20(const float* __restrict__ q, const float* __restrict__ t) {
@@ -615,44 +625,131 @@ constexpr int MAC_ROW_FIELDS = 14;    // two rows of five states + XB(0..3)
 constexpr int MAC_DF_STRIPS = 24;     // strips per row the mask table holds (LDS limits the templates of these kernels to ~1420 columns)
 constexpr int MAC_CTL_DOUBLES = 64;   // behind the rows: masks [2][24], per-row ring [2], progress counters
 #define XB(k, j) rows[(10 + (k)) * stride + (j)]
-enum { DF_P = 0, DF_S = 1 /* [set][chain] */, DF_T = 5 };
+enum { DF_P = 0 /* [2] */, DF_S = 2 /* [parity][chain] */, DF_T = 6, DF_R = 7, DF_DEAD = 8, DF_N = 12 };
+constexpr int MAC_DF_THREADS = 448;   // forward: seven wavefronts
+constexpr int MAC_DFB_THREADS = 512;  // backward: eight
 
 // progress counters: wave uniform, written by one lane
-__device__ __forceinline__ void df_wait(volatile int* cnt, int need, volatile int* dead) {
+#if defined(HHV_MAC_TIMING)  // measurement build (make lib_variant NAME=mt FLAGS=-DHHV_MAC_TIMING): where the waves of workgroup 0 wait
+#define DF_TIMING_DECL unsigned long long t_wait = 0, t_begin = __builtin_readcyclecounter(), t_sec[5] = {0, 0, 0, 0, 0}, t_mark = 0, ev_t[32]; int n_wait = 0, ev_n = 0, ev_c[32];
+constexpr int DF_EV_ROW = 150;
+#define DF_EVENT(code, i, s) if (blockIdx.x == 0 && (i) >= DF_EV_ROW && (i) <= DF_EV_ROW + 1 && ev_n < 32) { ev_t[ev_n] = __builtin_readcyclecounter(); ev_c[ev_n++] = (code) * 10000 + (i) * 10 + (s); }
+#define DF_MARK(k)
+#define DF_TIMING_REPORT(name)                                                                                              \
+  if (blockIdx.x == 0 && lane == 0)                                                                                         \
+    printf("%s wave %d: total %llu clk, waiting %llu clk in %d waits that did not pass at once; sections %llu %llu %llu %llu %llu\n", name, wv, \
+           (unsigned long long)(__builtin_readcyclecounter() - t_begin), t_wait, n_wait, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4]); \
+  if (blockIdx.x == 0 && lane == 0)                                                                                         \
+    for (int e_ = 0; e_ < ev_n; ++e_) printf("EV %s w%d code %d t %llu\n", name, wv, ev_c[e_], ev_t[e_]);
+#define DF_WAIT(...) { const unsigned long long t0_ = __builtin_readcyclecounter(); if (df_wait(__VA_ARGS__)) { ++n_wait; t_wait += __builtin_readcyclecounter() - t0_; } }
+#else
+#define DF_TIMING_DECL
+#define DF_EVENT(code, i, s)
+#define DF_MARK(k)
+#define DF_TIMING_REPORT(name)
+#define DF_WAIT(...) df_wait(__VA_ARGS__)
+#endif
+// (up to three counters at once: their reads go out together - one trip to LDS instead of three)
+__device__ __forceinline__ bool df_wait(volatile int* cnt, int need, volatile int* dead, volatile int* cnt2 = nullptr, int need2 = 0,
+                                        volatile int* cnt3 = nullptr, int need3 = 0) {
   // bounded: a wave that never sees its counter gives up (the results are then wrong and the parity tests say so) instead of
-  // hanging the device; after the first time-out nobody waits any more
+  // hanging the device; after the first time-out nobody waits any more.  Returns whether it had to wait.
+  bool waited = false;
   for (int g = 0; g < (1 << 18); ++g) {
-    if (__builtin_amdgcn_readfirstlane(*cnt) >= need) break;
-    if (__builtin_amdgcn_readfirstlane(*dead)) break;
+    const int v1 = *cnt, v2 = cnt2 ? *cnt2 : 0, v3 = cnt3 ? *cnt3 : 0, d = *dead;
+    const bool ok = v1 >= need && (!cnt2 || v2 >= need2) && (!cnt3 || v3 >= need3);
+    if (__builtin_amdgcn_readfirstlane(ok | (d != 0))) break;
     if (g == (1 << 18) - 1) *dead = 1;
+    waited = true;
     __builtin_amdgcn_s_sleep(1);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // (everything the waves hand each other lives in LDS, which executes the operations of a workgroup in order: a compiler
+  // barrier is all that is needed.  A workgroup-scope fence would also wait for this wave's global stores - F_MM, posteriors -
+  // to be acknowledged.)
+  asm volatile("" ::: "memory");
+  return waited;
 }
 __device__ __forceinline__ void df_post(volatile int* cnt, int v, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("" ::: "memory");
   if (lane == 0) *cnt = v;
 }
 
+// A chain WALKED by one lane instead of swept by 64 (tools/mac_chain_ubench.hip, one wave per SIMD: a sweep step costs 60 clocks for
+// the IM chain, 63 for GD, 45 for the total - the DPP move behind an fp64 result is slow - while the bare dependent fp64 operations
+// of a column take 21, 14 and 7).  The lane reads the operands the parallel part left in LDS four columns ahead of their use:
+//   KIND 0  y = c[e] + y * b[e]          (GD)       the result replaces c[e]
+//   KIND 1  y = c[e] + (y * q) * b[e]    (IM)       the result replaces c[e]
+//   KIND 2  y = y + c[e]                 (the running total of Pforward)
+// over n columns e = 0 .. n-1 at element stride DIR (backward walks towards smaller columns), the reference's operations in the
+// reference's order (src/hhforwardalgorithm.cpp:104-109,168, src/hhbackwardalgorithm.cpp:95-101).
+template <int DIR, int KIND>
+__device__ __forceinline__ double mac_walk(double* __restrict__ pc, const double* __restrict__ pb, int n, double y, double q) {
+  double cA[4], bA[4], cB[4], bB[4];
+#define MAC_WALK_LOAD(X, E)                       \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) { \
+    c##X[u] = pc[((E) + u) * DIR];                \
+    if (KIND != 2) b##X[u] = pb[((E) + u) * DIR]; \
+  }
+#define MAC_WALK_STEP(C, B, E)                       \
+  {                                                  \
+    if (KIND == 0) {                                 \
+      y = (C) + y * (B);                             \
+    } else if (KIND == 1) {                          \
+      double t = y * q;                              \
+      t = t * (B);                                   \
+      y = (C) + t;                                   \
+    } else {                                         \
+      y = y + (C);                                   \
+    }                                                \
+    if (KIND != 2) pc[(E) * DIR] = y;                \
+  }
+  int e = 0;
+  if (n >= 4) { MAC_WALK_LOAD(A, 0) }
+  while (e + 8 <= n) {
+    MAC_WALK_LOAD(B, e + 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) MAC_WALK_STEP(cA[u], bA[u], e + u)
+    if (e + 12 <= n) { MAC_WALK_LOAD(A, e + 8) }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) MAC_WALK_STEP(cB[u], bB[u], e + 4 + u)
+    e += 8;
+  }
+  if (e + 4 <= n) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) MAC_WALK_STEP(cA[u], bA[u], e + u)
+    e += 4;
+  }
+  for (; e < n; ++e) MAC_WALK_STEP(pc[e * DIR], (KIND != 2 ? pb[e * DIR] : 0.0), e)
+#undef MAC_WALK_LOAD
+#undef MAC_WALK_STEP
+  return y;
+}
+
+// The query row's constants of a P wave, fetched a ROW AHEAD: lane l < 20 holds q.p[row][l], lanes 20.. the transitions the
+// row needs; at the start of the row the values move to scalars with readlane (a scalar load at the start of every row cost the
+// wave a trip to L2 with nothing else to do).
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ void stage_template_wg(const HitView& h, float* sTp, float* sTt, int tid, int nt) {
   for (int e = tid; e < (h.Lt + 1) * 20; e += nt) sTp[e] = h.tp[(size_t)(e / 20) * h.tps + (e % 20)];
   for (int e = tid; e < (h.Lt + 1) * 8; e += nt) sTt[e] = (e & 7) < 7 ? h.ttr[(size_t)(e >> 3) * 7 + (e & 7)] : 0.0f;
 }
 
 template <bool LOCAL, bool STAGE>
-__global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
+__global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = reinterpret_cast<double*>(smem);
-  constexpr int NT = 384;
+  constexpr int NT = MAC_DF_THREADS;
   const int k = a.sel[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DF_TIMING_DECL
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   const size_t cols = (size_t)a.lds_cols + 2;  // layout sized for the longest template of the launch
   double* ctl = rows + MAC_ROW_FIELDS * cols;
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS] active lanes of (row & 1, strip)
   double* rring = ctl + 2 * MAC_DF_STRIPS;                                 // [2] scale[i+1] of row i
-  volatile int* cnt = reinterpret_cast<volatile int*>(ctl + 2 * MAC_DF_STRIPS + 2);
+  double* pmaxring = rring + 2;                                            // [2][2] max_j F_MM of row i over the strips of either P wave
+  volatile int* cnt = reinterpret_cast<volatile int*>(pmaxring + 4);
   float* sTp = reinterpret_cast<float*>(ctl + MAC_CTL_DOUBLES);
   float* sTt = sTp + cols * 20;
   unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + cols * 8);  // [2][cols]: the mask bytes of a row, fetched a row ahead (P only)
@@ -668,55 +765,94 @@ __global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
       for (int e = tid; e < 352; e += NT) sSs[e] = h.sstab[e];
     for (int j = 1 + tid; j <= Lt; j += NT) sCo[co_stride + j] = h.co[(size_t)pitch + j];  // row 1 (buffer row & 1)
   }
-  if (tid < 8) cnt[tid] = 0;
+  if (tid < DF_N) cnt[tid] = 0;
+  if (tid < 4) pmaxring[tid] = 0.0;
   if (tid == 0) h.scale[0] = h.scale[1] = h.scale[2] = 1.0;
   __syncthreads();
   const int ns = (Lt + 63) >> 6;
+  const int n_of[2] = {(ns + 1) >> 1, ns >> 1};  // strips of a row that P wave 0 / 1 works on (even / odd ones)
+  volatile int* dead = cnt + DF_DEAD;
+  // unit (i, s) of the parallel part is done when its wave's counter has reached ...
+#define P_DONE(i, s) cnt + DF_P + ((s)&1), ((i)-1) * n_of[(s)&1] + ((s) >> 1) + 1
 
-  if (wv == 0) {
-    // ---- P ----
-    unsigned char co_next = (!STAGE && 1 + lane <= Lt) ? h.co[(size_t)pitch + 1 + lane] : 1;
+  if (wv <= 1) {
+    // ---- P: wave w works on strips w, w+2, .. of every row ----
+    const int w = wv, no = n_of[w ^ 1];
+    unsigned char co_next = (!STAGE && w < ns && 1 + (w << 6) + lane <= Lt) ? h.co[(size_t)pitch + 1 + (w << 6) + lane] : 1;
     double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0, scale_i = 1.0;
-    for (int i = 1; i <= Lq; ++i) {
+    int own = 0;
+    // lanes 0-19: q.p[i], 20-24: q.tr[i-1][M2M, I2M, D2M, M2D, D2D], 25: q.tr[i][M2I]
+    auto qrow = [&](int i) -> float {
+      if (i > Lq || lane > 25) return 0.0f;
+      if (lane < 20) return h.qp[(size_t)i * 20 + lane];
+      const int tr = lane == 20 ? T_M2M : lane == 21 ? T_I2M : lane == 22 ? T_D2M : lane == 23 ? T_M2D : lane == 24 ? T_D2D : T_M2I;
+      return h.qtr[(size_t)(lane == 25 ? i : i - 1) * 7 + tr];
+    };
+    float q_next = qrow(1);
+    for (int i = 1; i <= Lq + 1; ++i) {
       const int cur = i & 1, prv = cur ^ 1;
       if (i >= 2) {
+        // the end of row i-1 (both waves, the same operations): its rescaling factor needs the other wave's strips too
+        if (no > 0) DF_WAIT(cnt + DF_P + (w ^ 1), (i - 1) * no, dead);
+        double scale_next = 1.0;
+        if (i - 1 >= 2) {
+          const double Pmax = fmax(pmaxring[prv * 2], pmaxring[prv * 2 + 1]);
+          pmin *= scale_i;
+          if (pmin < DBL_MIN * 100) pmin = 0.0;
+          scale_next = 1.0 / (Pmax + 1.0);  // :155
+        }
+        if (w == 0) {
+          if (lane == 0) {
+            if (i - 1 >= 2) h.scale[i] = scale_next;
+            rring[prv] = scale_next;
+          }
+          df_post(cnt + DF_R, i - 1, lane);  // the total reads it at the end of its row
+        }
+        scale_i = scale_next;
+        if (i > Lq) break;
         if (scale_prod < DBL_MIN * 100)
           scale_prod = 0.0;
         else
           scale_prod *= scale_i;
       }
-      const float* qi = h.qp + (size_t)i * 20;
-      const float* qt1 = h.qtr + (size_t)(i - 1) * 7;  // q.tr[i-1]
-      const double qM2M = qt1[T_M2M], qI2M = qt1[T_I2M], qD2M = qt1[T_D2M], qM2D = qt1[T_M2D], qD2D = qt1[T_D2D];
-      const double qM2I = h.qtr[(size_t)i * 7 + T_M2I];
-      double Pmax = 0.0, carry_mm = 0.0;
+      const float q_cur = q_next;
+      q_next = qrow(i + 1);
+      float qi[20];
+#pragma unroll
+      for (int e = 0; e < 20; ++e) qi[e] = rl_f(q_cur, e);
+      const double qM2M = rl_f(q_cur, 20), qI2M = rl_f(q_cur, 21), qD2M = rl_f(q_cur, 22), qM2D = rl_f(q_cur, 23), qD2D = rl_f(q_cur, 24);
+      const double qM2I = rl_f(q_cur, 25);
+      double Pmax = 0.0;
       unsigned char pre_co[MAC_PRE];
       if (STAGE) {
 #pragma unroll
         for (int u = 0; u < MAC_PRE; ++u) {
           const int jn = 1 + u * 64 + lane;
-          pre_co[u] = (i < Lq && jn <= Lt) ? h.co[(size_t)(i + 1) * pitch + jn] : 1;
+          pre_co[u] = ((u & 1) == w && i < Lq && jn <= Lt) ? h.co[(size_t)(i + 1) * pitch + jn] : 1;
         }
       }
+      if (w == 0 && lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
       const unsigned char* co_row = sCo + cur * co_stride;
       const int above = ((i - 2) >> 1) * ns;  // units the sweep waves of row i-1's parity have finished before that row
-      for (int s = 0; s < ns; ++s) {
+      for (int s = w; s < ns; s += 2) {
+        DF_MARK(-1)  // sections: 0 waits for the row above, 1 mask + operand loads + dot product, 2 states, 3 left neighbour + chain operands, 4 post + row ends
         if (i >= 2) {
           // row i-1's chains of this strip (and, in order, of the ones left of it) are final; its operands XB(.., strip s) and
-          // its mask are consumed (the sweeps and the total are done with them), and so is everything of row i-2, whose buffer
-          // this unit overwrites: this wave waited for the readers of row i-2 before every unit of row i-1
-          df_wait(cnt + DF_S + 2 * (prv) + 0, above + s + 1, cnt + 7);
-          df_wait(cnt + DF_S + 2 * (prv) + 1, above + s + 1, cnt + 7);
-          df_wait(cnt + DF_T, (i - 2) * ns + s + 1, cnt + 7);
+          // its mask are consumed (the chain waves and the total are done with them), and so is everything of row i-2, whose
+          // buffer this unit overwrites: both P waves finished row i-1 (above), and they waited for the readers of row i-2
+          // before every unit of row i-1
+          DF_WAIT(cnt + DF_S + 2 * (prv) + 0, above + s + 1, dead, cnt + DF_S + 2 * (prv) + 1, above + s + 1, cnt + DF_T, (i - 2) * ns + s + 1);
         }
+        DF_EVENT(1, i, s)
         const int s0 = s << 6, j = 1 + s0 + lane;
         const bool valid = j <= Lt;
         const int jc = valid ? j : Lt;
         const bool off = !valid || (STAGE ? co_row[jc] != 0 : co_next != 0);
         if (!STAGE) {
-          const bool last = s0 + 64 >= Lt;
-          const int ni = last ? i + 1 : i, nj = last ? 1 + lane : j + 64;
-          co_next = (ni <= Lq && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
+          // this wave's next unit: two strips on, or its first strip of the next row
+          const bool last = s + 2 >= ns;
+          const int ni = last ? i + 1 : i, nj = last ? 1 + (w << 6) + lane : j + 128;
+          co_next = (ni <= Lq && (!last || w < ns) && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
         }
         const unsigned long long on_mask = __ballot(!off);
         if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
@@ -730,7 +866,6 @@ __global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
             ROW(cur, F_MI, j) = 0.0;
             h.mat[(size_t)i * pitch + j] = 0.0f;
           }
-          carry_mm = 0.0;
         } else {
           float tpj[20], tt1[7], tt[7];
           load_tp<STAGE>(h, sTp, jc, tpj);
@@ -740,6 +875,7 @@ __global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
           // fpow2(ScoreSS(q, t, i, j)); for column 1 the reference passes (1, j) with the stale loop variable j = t.L + 1 (:77)
           float ssf = 1.0f;
           if (h.ssm && i >= 2) ssf = j == 1 ? sstab[h.ssq[1] * h.sstw + h.sst[Lt + 1]] : sstab[h.ssq[i] * h.sstw + h.sst[jc]];
+          DF_MARK(1)
           double mm, dg, mi;
           if (i == 1) {
             mm = pf * Cshift;  // :31
@@ -760,118 +896,104 @@ __global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
           }
           if (off) mm = dg = mi = 0.0;
           if (i >= 2 && j >= 2 && !off) Pmax = fmax(Pmax, mm);
+          if (valid) {
+            ROW(cur, F_MM, j) = mm;
+            ROW(cur, F_DG, j) = dg;
+            ROW(cur, F_MI, j) = mi;
+            if (LOCAL) XB(2, j) = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
+            h.mat[(size_t)i * pitch + j] = (float)mm;
+          }
           // the recurrences along the row (:104-109): gd = mm(j-1)*t[j-1][M2D] + gd(j-1)*t[j-1][D2D],
           //                                           im = mm(j-1)*q[i][M2I]*t[j-1][M2M] + im(j-1)*q[i][I2I]*t[j-1][M2M]
-          const double mm_left = shr1_d(mm, carry_mm);
+          // mm(j-1) of the strip's first column is the other wave's (the strip to the left)
+          DF_MARK(2)
+          double left = 0.0;
+          if (s > 0) {
+            DF_WAIT(P_DONE(i, s - 1), dead);
+            left = ROW(cur, F_MM, s0);
+          }
+          const double mm_left = shr1_d(mm, left);
           const bool chain_on = !off && (i == 1 || j >= 2);  // column 1 of rows >= 2: im = gd = 0 (:74)
           const double a_gd = chain_on ? mm_left * tt1[T_M2D] : 0.0, b_gd = chain_on ? (double)tt1[T_D2D] : 0.0;
           const double c_im = chain_on ? mm_left * qM2I * tt1[T_M2M] : 0.0, b_im = chain_on ? (double)tt1[T_M2M] : 0.0;
           if (valid) {
-            ROW(cur, F_MM, j) = mm;
             ROW(cur, F_GD, j) = a_gd;
             ROW(cur, F_IM, j) = c_im;
-            ROW(cur, F_DG, j) = dg;
-            ROW(cur, F_MI, j) = mi;
             XB(0, j) = b_gd;
             XB(1, j) = b_im;
-            if (LOCAL) XB(2, j) = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
-            h.mat[(size_t)i * pitch + j] = (float)mm;
           }
-          carry_mm = lane_d(mm, 63);
         }
-        if (s == ns - 1) {
-          // the row's rescaling factor, before the unit is posted: the total reads it at the end of its row
-          if (lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
+        DF_MARK(3)
+        if (s + 2 >= ns) {
+          // this wave's last strip of the row
           if (STAGE) {
             unsigned char* co_nextrow = sCo + prv * co_stride;
 #pragma unroll
             for (int u = 0; u < MAC_PRE; ++u) {
               const int jn = 1 + u * 64 + lane;
-              if (jn <= Lt) co_nextrow[jn] = pre_co[u];
+              if ((u & 1) == w && jn <= Lt) co_nextrow[jn] = pre_co[u];
             }
           }
-          double scale_next = 1.0;
-          if (i >= 2) {
-            Pmax = wave_max_d(Pmax);
-            pmin *= scale_i;
-            if (pmin < DBL_MIN * 100) pmin = 0.0;
-            scale_next = 1.0 / (Pmax + 1.0);  // :155
-            if (lane == 0) h.scale[i + 1] = scale_next;
-          }
-          if (lane == 0) rring[cur] = scale_next;
-          scale_i = scale_next;
+          Pmax = wave_max_d(Pmax);
+          if (lane == 0) pmaxring[cur * 2 + w] = Pmax;
         }
-        df_post(cnt + DF_P, (i - 1) * ns + s + 1, lane);
+        df_post(cnt + DF_P + w, ++own, lane);
+        DF_EVENT(2, i, s)
       }
     }
-  } else if (wv <= 4) {
-    // ---- SG / SI of the rows of one parity ----
-    const int par = (wv - 1) >> 1;
-    const bool gdw = ((wv - 1) & 1) == 0;
+  } else if (wv <= 5) {
+    // ---- the GD / IM chains of the rows of one parity ----
+    const int par = (wv - 2) >> 1;
+    const bool gdw = ((wv - 2) & 1) == 0;
     volatile int* mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
     int done = 0;
+    float qI2I_next = (!gdw && (par ? 1 : 2) <= Lq) ? h.qtr[(size_t)(par ? 1 : 2) * 7 + T_I2I] : 0.0f;  // fetched a row ahead
     for (int i = par ? 1 : 2; i <= Lq; i += 2) {
       const int cur = i & 1;
-      const double qI2I = gdw ? 0.0 : (double)h.qtr[(size_t)i * 7 + T_I2I];
+      const double qI2I = qI2I_next;
+      qI2I_next = (!gdw && i + 2 <= Lq) ? h.qtr[(size_t)(i + 2) * 7 + T_I2I] : 0.0f;
       double carry = 0.0;
       for (int s = 0; s < ns; ++s) {
-        df_wait(cnt + DF_P, (i - 1) * ns + s + 1, cnt + 7);
+        DF_WAIT(P_DONE(i, s), dead);
+        DF_EVENT(3, i, s)
         const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
-        const int j = 1 + (s << 6) + lane;
-        const bool valid = j <= Lt;
         if (on_mask == 0) {
           carry = 0.0;
         } else {
+          // lane 0 walks the active span l0 .. l1; what enters it is the carry of the previous strip when the span starts at the
+          // strip's first column, else 0 (an inactive neighbour); inactive columns inside the span hold c = b = 0 (y becomes 0,
+          // as in the sweep), the columns outside it hold c = 0, which is their result
           const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
-          // Sweep: inactive lanes hold 0 whatever their neighbour says, so the lanes left of the first active one are final
-          // from the start and l1 - l0 + 1 steps finish everything up to the last active lane.  Lane 0's left neighbour is the
-          // carry of the previous strip, a constant of the sweep: its step is evaluated once, with the operations of the loop
-          // body, and the loop shifts zeros into lane 0 (x + 0*b = x for the non-negative finite values here).
-          const bool first_lane = lane == 0;
-          const int n_steps = l1 - l0 + 1;
-          double* slot = gdw ? &ROW(cur, F_GD, j) : &ROW(cur, F_IM, j);
-          const double c0 = valid ? *slot : 0.0, b = valid ? XB(gdw ? 0 : 1, j) : 0.0;
-          double y = 0.0;
-          if (gdw) {
-            const double a_gd_s = first_lane ? c0 + carry * b : c0;
-            for (int q = 0; q < n_steps; ++q) {
-              const double gl = shr1_dz(y);
-              y = a_gd_s + gl * b;
-            }
-          } else {
-            const double c_im_s = first_lane ? c0 + carry * qI2I * b : c0;
-            for (int q = 0; q < n_steps; ++q) {
-              const double il = shr1_dz(y);
-              y = c_im_s + il * qI2I * b;
-            }
+          const int jf = 1 + (s << 6) + l0, n = l1 - l0 + 1;
+          if (lane == 0) {
+            const double yin = l0 == 0 ? carry : 0.0;
+            const double y = gdw ? mac_walk<1, 0>(&ROW(cur, F_GD, jf), &XB(0, jf), n, yin, 0.0)
+                                 : mac_walk<1, 1>(&ROW(cur, F_IM, jf), &XB(1, jf), n, yin, qI2I);
+            carry = l1 == 63 ? y : 0.0;
           }
-          if (valid) *slot = y;
-          carry = lane_d(y, 63);  // lane 63 is either inactive (0) or l1 (final)
         }
         df_post(mine, ++done, lane);
+        DF_EVENT(4, i, s)
       }
     }
   } else {
-    // ---- ST: total forward probability (:162-182), one chain through all units ----
+    // ---- the total forward probability (:162-182), one chain through all units ----
     double Pf = LOCAL ? 1.0 : 0.0;
     for (int i = 1; i <= Lq; ++i) {
       const int cur = i & 1;
       for (int s = 0; s < ns; ++s) {
-        df_wait(cnt + DF_P, (i - 1) * ns + s + 1, cnt + 7);
+        DF_WAIT(P_DONE(i, s), dead);
+        DF_EVENT(5, i, s)
         if (LOCAL) {
           const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
           if (on_mask != 0) {
+            // the summands of the active span in column order (inactive columns hold 0)
             const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
-            const int j = 1 + (s << 6) + lane;
-            const double f_mm = j <= Lt ? XB(2, j) : 0.0;
-            const double f_mm_s = lane == 0 ? Pf + f_mm : f_mm;
-            double acc = Pf;
-            const int n_steps = l1 - l0 + 1;
-            for (int q = 0; q < n_steps; ++q) acc = shr1_dz(acc) + f_mm_s;
-            Pf = lane_d(acc, l1);  // lanes right of l1 would only add zeros
+            if (lane == 0) Pf = mac_walk<1, 2>(&XB(2, 1 + (s << 6) + l0), nullptr, l1 - l0 + 1, Pf, 0.0);
           }
         }
         if (s == ns - 1) {
+          DF_WAIT(cnt + DF_R, i, dead);
           const double scale_next = rring[cur];
           if (LOCAL) {
             Pf *= scale_next;
@@ -880,8 +1002,10 @@ __global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
           }
         }
         df_post(cnt + DF_T, (i - 1) * ns + s + 1, lane);
+        DF_EVENT(6, i, s)
       }
     }
+    Pf = lane_d(Pf, 0);  // (lane 0 carried it)
     if (!LOCAL) {
       // + sum_j F(Lq, j) in column order, then * scale[Lq+1]
       const int last = Lq & 1;
@@ -896,6 +1020,8 @@ __global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
     }
     if (lane == 0) a.Pforward[k] = Pf;
   }
+  DF_TIMING_REPORT("forward")
+#undef P_DONE
 }
 
 // Backward: P (wave 0) computes what depends on row i+1 only - pmatch, DG, MI, the chains' operands and, for B_MM, the partial
@@ -903,19 +1029,20 @@ __global__ void __launch_bounds__(384) hhv_mac_forward_df_kernel(MacArgs a) {
 // (wave 5) completes B_MM = (((partial + gd(j+1)*t[M2D]) + im(j+1)*q[M2I]*t[M2M]) + XB2) + XB3 - the reference's left-to-right
 // sum (src/hhbackwardalgorithm.cpp:86-93) - and turns F_MM into the posterior.  P of (i-1, s) waits for P2 of (i, s).
 template <bool LOCAL, bool STAGE, bool LISTS>
-__global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
+__global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = reinterpret_cast<double*>(smem);
-  constexpr int NT = 384;
+  constexpr int NT = MAC_DFB_THREADS;
   const int k = a.sel[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DF_TIMING_DECL
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   const size_t cols = (size_t)a.lds_cols + 2;
   double* ctl = rows + MAC_ROW_FIELDS * cols;
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS]
   double* rring = ctl + 2 * MAC_DF_STRIPS;                                 // [2] mask byte of (i, Lt) != 0
-  volatile int* cnt = reinterpret_cast<volatile int*>(ctl + 2 * MAC_DF_STRIPS + 2);
+  volatile int* cnt = reinterpret_cast<volatile int*>(ctl + 2 * MAC_DF_STRIPS + 6);
   float* sTp = reinterpret_cast<float*>(ctl + MAC_CTL_DOUBLES);
   float* sTt = sTp + cols * 20;
   // STAGE: the mask bytes (P) and F_MM (P2) of a row are fetched while the row processed before it is computed
@@ -936,7 +1063,7 @@ __global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
         sF[((Lq - 1) & 1) * co_stride + j] = h.mat[(size_t)(Lq - 1) * pitch + j];
       }
   }
-  if (tid < 8) cnt[tid] = 0;
+  if (tid < DF_N) cnt[tid] = 0;
   __syncthreads();
   const double sL = h.scale[Lq + 1];
   // row Lq (:19-29); row i lives in buffer i & 1
@@ -952,21 +1079,38 @@ __global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
   }
   __syncthreads();
   const int ns = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 1;  // strips of columns Lt-1 .. 1 (Lt = 1: one strip without a valid lane)
+  const int n_of[2] = {(ns + 1) >> 1, ns >> 1};      // strips of a row that P wave 0 / 1 works on (even / odd ones)
+  volatile int* dead = cnt + DF_DEAD;
+  // unit (i, s) of the parallel part is done when its wave's counter has reached ...
+#define P_DONE(i, s) cnt + DF_P + ((s)&1), (Lq - 1 - (i)) * n_of[(s)&1] + ((s) >> 1) + 1
 
-  if (wv == 0) {
-    // ---- P ----
+  if (wv <= 1) {
+    // ---- P: wave w works on strips w, w+2, .. of every row (the units of a row do not depend on each other) ----
+    const int w = wv;
     double pmin = LOCAL ? sL : 0.0;
     double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;  // scale[i+1] of the row, fetched a row ahead
-    unsigned char co_nx = (!STAGE && Lq >= 2 && Lt - 1 - lane >= 1) ? h.co[(size_t)(Lq - 1) * pitch + Lt - 1 - lane] : 1;
+    unsigned char co_nx = (!STAGE && Lq >= 2 && w < ns && Lt - 1 - (w << 6) - lane >= 1) ? h.co[(size_t)(Lq - 1) * pitch + Lt - 1 - (w << 6) - lane] : 1;
+    int own = 0;
+    // lanes 0-19: q.p[i+1], 20-24: q.tr[i][M2M, M2D, I2M, D2M, D2D]
+    auto qrow = [&](int i) -> float {
+      if (i < 1 || lane > 24) return 0.0f;
+      if (lane < 20) return h.qp[(size_t)(i + 1) * 20 + lane];
+      const int tr = lane == 20 ? T_M2M : lane == 21 ? T_M2D : lane == 22 ? T_I2M : lane == 23 ? T_D2M : T_D2D;
+      return h.qtr[(size_t)i * 7 + tr];
+    };
+    float q_next = qrow(Lq - 1);
     for (int i = Lq - 1; i >= 1; --i) {
       const int cur = i & 1, prv = cur ^ 1;
       const double sc = sc_next;
       sc_next = i >= 2 ? h.scale[i] : 1.0;
       pmin *= sc;
       if (pmin < DBL_MIN * 100) pmin = 0.0;
-      const float* qn = h.qp + (size_t)(i + 1) * 20;
-      const float* qt = h.qtr + (size_t)i * 7;
-      const double qM2M = qt[T_M2M], qM2D = qt[T_M2D], qI2M = qt[T_I2M], qD2M = qt[T_D2M], qD2D = qt[T_D2D];
+      const float q_cur = q_next;
+      q_next = qrow(i - 1);
+      float qn[20];
+#pragma unroll
+      for (int e = 0; e < 20; ++e) qn[e] = rl_f(q_cur, e);
+      const double qM2M = rl_f(q_cur, 20), qM2D = rl_f(q_cur, 21), qI2M = rl_f(q_cur, 22), qD2M = rl_f(q_cur, 23), qD2D = rl_f(q_cur, 24);
       const unsigned char* corow = h.co + (size_t)i * pitch;
       const unsigned char* co_l = sCo + cur * co_stride;
       unsigned char pre_co[MAC_PRE];
@@ -974,24 +1118,34 @@ __global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
 #pragma unroll
         for (int q = 0; q < MAC_PRE; ++q) {
           const int jn = 1 + q * 64 + lane;
-          pre_co[q] = (i >= 2 && jn <= Lt) ? h.co[(size_t)(i - 1) * pitch + jn] : 1;
+          // (a wave stages the bytes of its own strips only - column Lt is wave 0's: every byte has one writer and one reader)
+          const bool own_col = jn <= Lt && (jn == Lt ? w == 0 : (((Lt - 1 - jn) >> 6) & 1) == w);
+          pre_co[q] = (i >= 2 && own_col) ? h.co[(size_t)(i - 1) * pitch + jn] : 1;
         }
       }
       const unsigned char coL = STAGE ? co_l[Lt] : corow[Lt];  // the mask byte of column Lt, for P2's column-Lt step of this row
-      for (int s = 0; s < ns; ++s) {
-        // B_MM of row i+1 at this strip's columns and the one right of them is final; with it the sweeps of (i+1, s) are done
-        // with XB(0 / 1), P2 with XB(2 / 3), the mask and the per-row ring, and everything of row i+2 (whose buffer this unit
-        // overwrites) has been read: this wave waited for P2 of every unit of row i+2 before the units of row i+1
-        if (i <= Lq - 2) df_wait(cnt + DF_T, (Lq - 2 - i) * ns + s + 1, cnt + 7);
+      for (int s = w; s < ns; s += 2) {
+        // B_MM of row i+1 at this strip's columns and the one right of them is final; with it the chain waves of (i+1, s) are
+        // done with XB(0 / 1), P2 with XB(2 / 3), the mask and the per-row ring.  Row i+2, whose buffer this unit overwrites,
+        // has been read by this wave's units of row i+1 and by P2 (this wave waited for P2 of (i+2, s) before (i+1, s)); the
+        // other P wave's unit (i+1, s+1) reads one column of strip s of row i+2: wait for it too
+        if (i <= Lq - 2) {
+          // (B_MM of the column right of the strip is the other P2 wave's, unit (i+1, s-1))
+          volatile int* tl = s > 0 ? cnt + DF_T + ((s - 1) & 1) : nullptr;
+          const int tl_need = s > 0 ? (Lq - 2 - i) * n_of[(s - 1) & 1] + ((s - 1) >> 1) + 1 : 0;
+          DF_WAIT(cnt + DF_T + (s & 1), (Lq - 2 - i) * n_of[s & 1] + (s >> 1) + 1, dead, tl, tl_need);
+          if (s + 1 < ns) DF_WAIT(P_DONE(i + 1, s + 1), dead);
+        }
+        DF_EVENT(1, i, s)
         if (s == 0 && lane == 0) rring[cur] = coL ? 1.0 : 0.0;
         const int j = Lt - 1 - (s << 6) - lane;  // descending: lane 0 is the rightmost column of the strip
         const bool valid = j >= 1;
         const int jc = valid ? j : 1;
         const bool off = !valid || (STAGE ? co_l[jc] != 0 : co_nx != 0);
         if (!STAGE) {
-          // the next unit of this wave: the next strip of the row, or the first strip of row i - 1
-          const bool last = s == ns - 1;
-          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - lane : j - 64;
+          // the next unit of this wave: two strips on, or its first strip of row i - 1
+          const bool last = s + 2 >= ns;
+          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (w << 6) - lane : j - 128;
           co_nx = (ni >= 1 && nj >= 1) ? h.co[(size_t)ni * pitch + nj] : 1;
         }
         const unsigned long long on_mask = __ballot(!off);
@@ -1032,88 +1186,83 @@ __global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
             XB(3, j) = e5;
           }
         }
-        if (s == ns - 1 && STAGE) {
+        if (s + 2 >= ns && STAGE) {
+          // this wave's last strip of the row
           unsigned char* co_n = sCo + prv * co_stride;
 #pragma unroll
           for (int q = 0; q < MAC_PRE; ++q) {
             const int jn = 1 + q * 64 + lane;
-            if (jn <= Lt) co_n[jn] = pre_co[q];
+            if (jn <= Lt && (jn == Lt ? w == 0 : (((Lt - 1 - jn) >> 6) & 1) == w)) co_n[jn] = pre_co[q];
           }
         }
-        df_post(cnt + DF_P, (Lq - 1 - i) * ns + s + 1, lane);
+        df_post(cnt + DF_P + w, ++own, lane);
+        DF_EVENT(2, i, s)
       }
     }
-  } else if (wv <= 4) {
-    // ---- SG / SI of the rows of one parity ----
-    const int par = (wv - 1) >> 1;
-    const bool gdw = ((wv - 1) & 1) == 0;
+  } else if (wv <= 5) {
+    // ---- the GD / IM chains of the rows of one parity ----
+    const int par = (wv - 2) >> 1;
+    const bool gdw = ((wv - 2) & 1) == 0;
     volatile int* mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
     int done = 0;
-    for (int i = ((Lq - 1) & 1) == par ? Lq - 1 : Lq - 2; i >= 1; i -= 2) {
+    const int i_first = ((Lq - 1) & 1) == par ? Lq - 1 : Lq - 2;
+    float qI2I_next = (!gdw && i_first >= 1) ? h.qtr[(size_t)i_first * 7 + T_I2I] : 0.0f;  // fetched a row ahead
+    for (int i = i_first; i >= 1; i -= 2) {
       const int cur = i & 1;
-      const double qI2I = gdw ? 0.0 : (double)h.qtr[(size_t)i * 7 + T_I2I];
+      const double qI2I = qI2I_next;
+      qI2I_next = (!gdw && i - 2 >= 1) ? h.qtr[(size_t)(i - 2) * 7 + T_I2I] : 0.0f;
       double carry = 0.0;  // curr[Lt].gd = curr[Lt].im = 0
       for (int s = 0; s < ns; ++s) {
-        df_wait(cnt + DF_P, (Lq - 1 - i) * ns + s + 1, cnt + 7);
+        DF_WAIT(P_DONE(i, s), dead);
+        DF_EVENT(3, i, s)
         const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
-        const int j = Lt - 1 - (s << 6) - lane;
-        const bool valid = j >= 1;
-        const int jc = valid ? j : 1;
         if (on_mask == 0) {
           carry = 0.0;
         } else {
+          // as in the forward kernel, towards smaller columns: lane l0 is the span's rightmost column
           const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
-          const bool first_lane = lane == 0;  // its neighbour is the carry of the previous strip: folded, see the forward kernel
-          const int n_steps = l1 - l0 + 1;
-          double* slot = gdw ? &ROW(cur, F_GD, jc) : &ROW(cur, F_IM, jc);
-          const double c0 = valid ? *slot : 0.0, b = valid ? XB(gdw ? 0 : 1, jc) : 0.0;
-          double y = 0.0;
-          if (gdw) {
-            const double a_gd_s = first_lane ? c0 + carry * b : c0;
-            for (int q = 0; q < n_steps; ++q) {
-              const double gl = shr1_dz(y);
-              y = a_gd_s + gl * b;
-            }
-          } else {
-            const double c_im_s = first_lane ? c0 + carry * qI2I * b : c0;
-            for (int q = 0; q < n_steps; ++q) {
-              const double il = shr1_dz(y);
-              y = c_im_s + il * qI2I * b;
-            }
+          const int jf = Lt - 1 - (s << 6) - l0, n = l1 - l0 + 1;
+          if (lane == 0) {
+            const double yin = l0 == 0 ? carry : 0.0;
+            const double y = gdw ? mac_walk<-1, 0>(&ROW(cur, F_GD, jf), &XB(0, jf), n, yin, 0.0)
+                                 : mac_walk<-1, 1>(&ROW(cur, F_IM, jf), &XB(1, jf), n, yin, qI2I);
+            carry = l1 == 63 ? y : 0.0;
           }
-          if (valid) *slot = y;
-          carry = lane_d(y, 63);
         }
         df_post(mine, ++done, lane);
+        DF_EVENT(4, i, s)
       }
     }
   } else {
-    // ---- P2 ----
+    // ---- P2: wave v works on strips v, v+2, .. of every row ----
+    const int v = wv - 6;
     double scale_prod = sL;
     double final_scale_prod = sL;  // :31-36
     if (LISTS) {
       // (64 factors per trip to memory: the other waves wait for this one's first unit)
       for (int base = Lq - 1; base >= 1; base -= 64) {
         const int ii = base - lane;
-        const double v = ii >= 1 ? h.scale[ii + 1] : 1.0;
+        const double sv = ii >= 1 ? h.scale[ii + 1] : 1.0;
         const int n = base < 64 ? base : 64;
         for (int l = 0; l < n; ++l) {
-          final_scale_prod *= lane_d(v, l);
+          final_scale_prod *= lane_d(sv, l);
           if (final_scale_prod < DBL_MIN * 100) final_scale_prod = 0.0;
         }
       }
     }
     float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
     double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;
-    float f_nx = (!STAGE && Lq >= 2 && Lt - 1 - lane >= 1) ? h.mat[(size_t)(Lq - 1) * pitch + Lt - 1 - lane] : 0.0f;
-    int done0 = 0, done1 = 0;  // units the sweep waves of either parity must have finished
+    float f_nx = (!STAGE && Lq >= 2 && v < ns && Lt - 1 - (v << 6) - lane >= 1) ? h.mat[(size_t)(Lq - 1) * pitch + Lt - 1 - (v << 6) - lane] : 0.0f;
+    int own = 0;
+    float qM2I_next = Lq >= 2 ? h.qtr[(size_t)(Lq - 1) * 7 + T_M2I] : 0.0f;  // fetched a row ahead
     for (int i = Lq - 1; i >= 1; --i) {
       const int cur = i & 1;
       const double sc = sc_next;
       sc_next = i >= 2 ? h.scale[i] : 1.0;
       scale_prod *= sc;
       if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
-      const double qM2I = h.qtr[(size_t)i * 7 + T_M2I];
+      const double qM2I = qM2I_next;
+      qM2I_next = i >= 2 ? h.qtr[(size_t)(i - 1) * 7 + T_M2I] : 0.0f;
       float* row = h.mat + (size_t)i * pitch;
       const float* f_l = sF + cur * co_stride;
       float pre_f[MAC_PRE];
@@ -1121,15 +1270,16 @@ __global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
 #pragma unroll
         for (int q = 0; q < MAC_PRE; ++q) {
           const int jn = 1 + q * 64 + lane;
-          pre_f[q] = (i >= 2 && jn <= Lt) ? h.mat[(size_t)(i - 1) * pitch + jn] : 0.0f;
+          // (a wave stages the values of its own strips only - column Lt is wave 0's)
+          const bool own_col = jn <= Lt && (jn == Lt ? v == 0 : (((Lt - 1 - jn) >> 6) & 1) == v);
+          pre_f[q] = (i >= 2 && own_col) ? h.mat[(size_t)(i - 1) * pitch + jn] : 0.0f;
         }
       }
       const float fL = STAGE ? f_l[Lt] : (lane == 0 ? row[Lt] : 0.0f);
-      for (int s = 0; s < ns; ++s) {
-        int& need = cur ? done1 : done0;
-        ++need;
-        df_wait(cnt + DF_S + 2 * cur + 0, need, cnt + 7);
-        df_wait(cnt + DF_S + 2 * cur + 1, need, cnt + 7);
+      for (int s = v; s < ns; s += 2) {
+        const int need = ((Lq - 1 - i) >> 1) * ns + s + 1;  // units of the chain waves of this row's parity
+        DF_WAIT(cnt + DF_S + 2 * cur + 0, need, dead, cnt + DF_S + 2 * cur + 1, need);
+        DF_EVENT(5, i, s)
         if (s == 0 && lane == 0) {
           // column Lt (:58-71)
           if (rring[cur] != 0.0) {
@@ -1146,46 +1296,51 @@ __global__ void __launch_bounds__(384) hhv_mac_backward_df_kernel(MacArgs a) {
         const int jc = valid ? j : 1;
         const float f_cur = STAGE ? (valid ? f_l[jc] : 0.0f) : f_nx;
         if (!STAGE) {
-          const bool last = s == ns - 1;
-          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - lane : j - 64;
+          const bool last = s + 2 >= ns;
+          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (v << 6) - lane : j - 128;
           f_nx = (ni >= 1 && nj >= 1) ? h.mat[(size_t)ni * pitch + nj] : 0.0f;
         }
         const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
-        if (on_mask == 0) {
-          if (valid) row[j] = f_cur * (float)(0.0 / Pf);  // F * (float)(B / Pforward) with B = 0 (NaN if Pforward is 0, as in the reference)
-        } else {
-          const bool off = !((on_mask >> lane) & 1);
+        const bool off = !((on_mask >> lane) & 1);
+        double mm = 0.0;
+        if (on_mask != 0) {
           float tt[7];
           load_tt<STAGE>(h, sTt, jc, tt);
           const double tM2M = tt[T_M2M];
           const double gr = ROW(cur, F_GD, jc + 1), ir = ROW(cur, F_IM, jc + 1);  // curr[j+1].gd / .im
-          double mm = (ROW(cur, F_MM, jc) + gr * tt[T_M2D] + ir * qM2I * tM2M + XB(2, jc) + XB(3, jc));  // :86-93
+          mm = (ROW(cur, F_MM, jc) + gr * tt[T_M2D] + ir * qM2I * tM2M + XB(2, jc) + XB(3, jc));  // :86-93
           if (off) mm = 0.0;
-          if (valid) {
-            ROW(cur, F_MM, j) = mm;
-            row[j] = f_cur * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
-          }
+          if (valid) ROW(cur, F_MM, j) = mm;
+        }
+        // B_MM is what the row below waits for: posted before the posterior is worked out
+        df_post(cnt + DF_T + v, ++own, lane);
+        DF_EVENT(6, i, s)
+        if (on_mask == 0) {
+          if (valid) row[j] = f_cur * (float)(0.0 / Pf);  // F * (float)(B / Pforward) with B = 0 (NaN if Pforward is 0, as in the reference)
+        } else {
+          if (valid) row[j] = f_cur * (float)(mm / Pf);  // multiplyPosteriorValue(i, jj, float) (:122-124)
           if (LISTS && valid && !off) {
             // :112-122: float = ProbFwd(q.p[i], t.p[j]) * Cshift * B_MM / Pforward * final_scale_prod / scale_prod, left to right
             float tpj[20];
             load_tp<STAGE>(h, sTp, jc, tpj);
             const float sub = dot20(h.qp + (size_t)i * 20, tpj);
-            const float v = (float)((double)sub * Cshift * mm / Pf * final_scale_prod / scale_prod);
-            if (v > MAC_LIST_THRESHOLD) blist[(size_t)i * pitch + j] = v;
+            const float lv = (float)((double)sub * Cshift * mm / Pf * final_scale_prod / scale_prod);
+            if (lv > MAC_LIST_THRESHOLD) blist[(size_t)i * pitch + j] = lv;
           }
         }
-        if (s == ns - 1 && STAGE) {
+        if (s + 2 >= ns && STAGE) {
           float* f_n = sF + (cur ^ 1) * co_stride;
 #pragma unroll
           for (int q = 0; q < MAC_PRE; ++q) {
             const int jn = 1 + q * 64 + lane;
-            if (jn <= Lt) f_n[jn] = pre_f[q];
+            if (jn <= Lt && (jn == Lt ? v == 0 : (((Lt - 1 - jn) >> 6) & 1) == v)) f_n[jn] = pre_f[q];
           }
         }
-        df_post(cnt + DF_T, (Lq - 1 - i) * ns + s + 1, lane);
       }
     }
   }
+  DF_TIMING_REPORT("backward")
+#undef P_DONE
 }
 
 // ---- maximum-accuracy DP ----------------------------------------------------------------------------------------------
@@ -1493,14 +1648,14 @@ static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t str
   if (!GROWS && !no_pipe) {
     // row state in LDS: the dataflow kernels (six wavefronts per hit)
     (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, STAGE>), dim3(n), dim3(384), lds, stream, a);
+    hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, STAGE>), dim3(n), dim3(MAC_DF_THREADS), lds, stream, a);
     if (a.fwd_list) {  // the -o_matrices lists were asked for (hhv_mac_set_lists)
       hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
       (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, true>), dim3(n), dim3(384), lds, stream, a);
+      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, true>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, a);
     } else {
       (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, false>), dim3(n), dim3(384), lds, stream, a);
+      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, false>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, a);
     }
     return;
   }
