@@ -4,7 +4,8 @@
 //   PosteriorDecoder::macAlgorithm       src/hhmacalgorithm.cpp:18-179       maximum-accuracy DP on the posteriors
 //   PosteriorDecoder::backtraceMAC       src/hhbacktracemac.cpp:113-240      path, per-step score and posterior
 //
-// One wavefront per hit.  The reference's arithmetic is double precision with a per-row rescaling
+// One workgroup per hit: one wavefront in the kernels right below (row state in global memory: the longest templates), seven or
+// eight in the dataflow kernels further down (row state in LDS).  The reference's arithmetic is double precision with a per-row rescaling
 // (scale[i+1] = 1 / (1 + max_j F_MM(i,j))), so rows are processed one after the other; inside a row
 //   * everything that depends only on the previous row (MM, DG, MI forward; pmatch, DG, MI backward) is computed by
 //     64 lanes for 64 columns at a time, with exactly the reference's expression trees (no FMA contraction);
@@ -20,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdlib.h>
+#include <stdio.h>
 
 #include <float.h>
 
@@ -598,36 +600,43 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
 }
 
 // ---- forward / backward as a dataflow of the wavefronts of one workgroup (round 5) ---------------------------------------
-// What bounds the single-wave kernels above is the LATENCY of the sweeps, not the number of their instructions: a sweep step of
-// the IM chain is shift -> multiply -> multiply -> add, four dependent instructions of a lone wave (~42 clocks measured), 64 steps
-// per strip, and the parallel part of the strip (operand loads, a 20-term dot product, some thirty fp64 operations per cell) waits
-// behind it.  Moving the chains to other wavefronts does not shorten them (measured: a lockstep pipeline of a parallel-part wave and
-// two sweep waves ran 1.72 ms where one wave needs 1.84); what does is having the sweeps of TWO ROWS in flight.  The dependencies
-// allow it: the parallel part of (row i, strip s) needs the chains of (row i-1, strips s and s-1) and - forward only - the rescaling
-// factor of row i-1, i.e. max_j F_MM over ALL strips of row i-1, which comes out of the parallel part alone.  So the sweep of
-// (i, s) may run one strip behind the sweep of (i-1, s), and (forward) row i+1 starts when the parallel part of row i is complete,
-// which needs the last strip of row i-1: rows overlap in pairs - two rows in the time of one.  Backward the scale factors are known
-// (the forward pass stored them) and the rows form a plain diagonal wavefront.
-// A hit gets a workgroup of six wavefronts, each running its own loop over its units (row, strip) and waiting on progress counters
-// in LDS (monotone, one per wave; LDS executes a wave's operations in order, so a counter written after the data is seen after it):
-//   P  (wave 0)      the parallel part of every unit in order: MM, DG, MI; the additive terms of the chains into the slots the
-//                    results will take (ROW(cur, F_GD / F_IM, j)), their factors into XB(0 / 1, j), the Pforward summand into
-//                    XB(2, j), the strip's mask of active lanes.  Waits for the sweeps (and the total) of the unit above.
-//   SG0 SI0 SG1 SI1  (waves 1-4) the GD / IM sweeps of the rows of one parity each; wait for P of their unit
-//   ST (wave 5)      forward: the running total of Pforward over all units in order (its own chain through the whole matrix);
-//   P2 (wave 5)      backward: B_MM from the swept chains (curr[j+1].gd / .im), the posterior F*B/Pforward, the -omat list entry;
-//                    backward P waits for P2 of the unit above instead of its sweeps.
-// Every value is computed by the operations of the single-wave kernels in their order (a chain's sweep IS the old sweep with the
-// other chain's instructions removed), so the results are the same bits.  Two row buffers are enough: a buffer is rewritten by
-// P two rows later, and P has by then waited for every reader of the old row (argued at each wait below).
+// A lone wave is latency-bound in BOTH halves of a unit (row, strip of 64 columns): the parallel part - operand loads, a 20-term
+// dot product, some thirty fp64 operations per cell, every step waiting for the one before - takes ~2 k clocks, and a sweep step of
+// the IM chain is shift -> multiply -> multiply -> add, four dependent instructions (60 clocks a step, tools/mac_chain_ubench.hip).
+// The dependencies leave room: the parallel part of (row i, strip s) needs the chains of (row i-1, strips s and s-1) and - forward
+// only - the rescaling factor of row i-1, i.e. max_j F_MM over ALL strips of row i-1, which comes out of the parallel part alone;
+// the units of one row are independent of each other but for one value (forward: F_MM of the column left of the strip).  So a hit
+// gets a workgroup of seven (backward: eight) wavefronts, each running its own loop over its units and waiting on progress
+// counters in LDS (monotone, one per wave; LDS executes a workgroup's operations in order, so a counter written after the data is
+// seen after it; the counters are read and written with explicit ds instructions, see df_wait):
+//   P   (waves 0 .. MAC_NP-1)  the parallel part of the strips s = w, w + MAC_NP, ..: MM, DG, MI; the additive terms of the chains
+//                    into the slots the results will take (ROW(cur, F_GD / F_IM, j)), their factors into XB(0 / 1, j), the
+//                    Pforward summand into XB(2, j), the strip's mask of active lanes.  Waits for the chains (and the total) of the
+//                    unit above; backward it also stages the next row's mask bytes and F_MM values for everybody.
+//   chains (4 waves) the GD / IM recurrences of the rows of one parity each, WALKED by one lane (mac_walk: 14 / 21 clocks a column
+//                    against 60 a sweep step); wait for P of their unit.  Two rows' chains are in flight.
+//   ST  (forward)    the running total of Pforward over all units in order (its own chain through the whole matrix), and the
+//                    global stores of F_MM: a wave that stores never waits for a load of its own
+//   P2  (backward, 2 waves: even / odd strips)  B_MM from the finished chains (curr[j+1].gd / .im), posted to the row below at
+//                    once, then the posterior F*B/Pforward and the -omat list entry; backward P waits for P2 of the unit above.
+// Every value is computed by the operations of the single-wave kernels in their order, so the results are the same bits (the GPU
+// suite and the soak compare them with the reference).  Two row buffers are enough: a buffer is rewritten by P two rows later, and
+// P has by then waited for every reader of the old row (argued at each wait below).
+// Measured (500 hits 300 x 300, one session): forward 1.84 -> 1.32 ms, backward 1.55 -> 1.37 ms; a launch with at most one hit per
+// CU: 1.14 ms.  What was tried on the way and did not pay: a lockstep pipeline (barriers per phase: 1.72 ms), sweeps instead of
+// walks in the chain waves, four P waves (no faster alone, and two such workgroups on a CU ran at half speed): NOTES_r5.md.
+// -DHHV_MAC_TIMING (make lib_variant NAME=mt FLAGS=-DHHV_MAC_TIMING) records when the waves of workgroup 0 pass their waits and
+// post their units for two rows and prints the table at the end of the kernel.
 // Row state in global memory (GROWS) stays with the single-wave kernels.
 constexpr int MAC_ROW_FIELDS = 14;    // two rows of five states + XB(0..3)
 constexpr int MAC_DF_STRIPS = 24;     // strips per row the mask table holds (LDS limits the templates of these kernels to ~1420 columns)
-constexpr int MAC_CTL_DOUBLES = 64;   // behind the rows: masks [2][24], per-row ring [2], progress counters
+constexpr int MAC_CTL_DOUBLES = 64;   // behind the rows: masks [2][24] (48), per-row rings (forward 2 + 2 x MAC_NP, backward 8), 12 counters (6)
+static_assert(2 * MAC_DF_STRIPS + 2 + 2 * 4 + 6 <= MAC_CTL_DOUBLES, "control block");
 #define XB(k, j) rows[(10 + (k)) * stride + (j)]
-enum { DF_P = 0 /* [2] */, DF_S = 2 /* [parity][chain] */, DF_T = 6, DF_R = 7, DF_DEAD = 8, DF_N = 12 };
-constexpr int MAC_DF_THREADS = 448;   // forward: seven wavefronts
-constexpr int MAC_DFB_THREADS = 512;  // backward: eight
+constexpr int MAC_NP = 2;  // wavefronts of the parallel part: wave w works on strips w, w + 4, .. of every row
+enum { DF_P = 0 /* [MAC_NP] */, DF_S = 4 /* [parity][chain] */, DF_T = 8 /* [2] */, DF_R = 10, DF_DEAD = 11, DF_N = 12 };
+constexpr int MAC_DF_THREADS = (MAC_NP + 5) * 64;   // forward: P waves, four chain waves, the total
+constexpr int MAC_DFB_THREADS = (MAC_NP + 6) * 64;  // backward: P waves, four chain waves, two posterior waves
 
 // progress counters: wave uniform, written by one lane
 #if defined(HHV_MAC_TIMING)  // measurement build (make lib_variant NAME=mt FLAGS=-DHHV_MAC_TIMING): where the waves of workgroup 0 wait
@@ -649,29 +658,51 @@ constexpr int DF_EV_ROW = 150;
 #define DF_TIMING_REPORT(name)
 #define DF_WAIT(...) df_wait(__VA_ARGS__)
 #endif
-// (up to three counters at once: their reads go out together - one trip to LDS instead of three)
-__device__ __forceinline__ bool df_wait(volatile int* cnt, int need, volatile int* dead, volatile int* cnt2 = nullptr, int need2 = 0,
-                                        volatile int* cnt3 = nullptr, int need3 = 0) {
-  // bounded: a wave that never sees its counter gives up (the results are then wrong and the parity tests say so) instead of
-  // hanging the device; after the first time-out nobody waits any more.  Returns whether it had to wait.
+// The counters are addressed as LDS explicitly (ds_read / ds_write through inline assembly): through a volatile generic pointer
+// the compiler emits FLAT accesses, whose completion is counted with the global-memory counter as well - every poll then waited
+// for the wave's outstanding global loads and stores (s_waitcnt vmcnt(0) in the wait loop, ~3-5 k clocks at every row boundary).
+struct LdsCnt {
+  uint32_t a;  // LDS byte address of a 32-bit counter (0 = none)
+  __device__ __forceinline__ LdsCnt operator+(int k) const { return LdsCnt{a + 4u * (uint32_t)k}; }
+};
+__device__ __forceinline__ LdsCnt lds_cnt(const void* p) { return LdsCnt{(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p}; }
+// up to three counters at once: their reads go out together - one trip to LDS instead of three.
+// Bounded: a wave that never sees its counter gives up (the results are then wrong and the parity tests say so) instead of
+// hanging the device; after the first time-out nobody waits any more.  Returns whether it had to wait.
+__device__ __forceinline__ bool df_wait(LdsCnt c, int need, LdsCnt dead, LdsCnt c2 = LdsCnt{0}, int need2 = 0, LdsCnt c3 = LdsCnt{0},
+                                        int need3 = 0) {
+  const uint32_t a2 = c2.a ? c2.a : c.a, a3 = c3.a ? c3.a : c.a;
+  if (!c2.a) need2 = need;
+  if (!c3.a) need3 = need;
   bool waited = false;
   for (int g = 0; g < (1 << 18); ++g) {
-    const int v1 = *cnt, v2 = cnt2 ? *cnt2 : 0, v3 = cnt3 ? *cnt3 : 0, d = *dead;
-    const bool ok = v1 >= need && (!cnt2 || v2 >= need2) && (!cnt3 || v3 >= need3);
-    if (__builtin_amdgcn_readfirstlane(ok | (d != 0))) break;
-    if (g == (1 << 18) - 1) *dead = 1;
+    // (one lane polls: with all 64 reading, the polls of a dozen waiting waves took half of the CU's LDS bandwidth from the
+    // waves that work - two hits on a CU ran as slowly as one after the other)
+    int ok = 0;
+    if ((threadIdx.x & 63) == 0) {
+      int v1, v2, v3, d;
+      asm volatile(
+          "ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(d)
+          : "v"(c.a), "v"(a2), "v"(a3), "v"(dead.a)
+          : "memory");
+      ok = ((v1 >= need && v2 >= need2 && v3 >= need3) || d != 0) ? 1 : 0;
+    }
+    asm volatile("" ::: "memory");
+    if (__builtin_amdgcn_readlane(ok, 0)) break;
+    if (g == (1 << 18) - 1) asm volatile("ds_write_b32 %0, %1" ::"v"(dead.a), "v"(1) : "memory");
     waited = true;
     __builtin_amdgcn_s_sleep(1);
   }
-  // (everything the waves hand each other lives in LDS, which executes the operations of a workgroup in order: a compiler
-  // barrier is all that is needed.  A workgroup-scope fence would also wait for this wave's global stores - F_MM, posteriors -
-  // to be acknowledged.)
-  asm volatile("" ::: "memory");
+  // (everything the waves hand each other lives in LDS, which executes the operations of a workgroup in order: the compiler
+  // barrier of the asm statements is all that is needed - no fence, which would wait for this wave's global stores too)
   return waited;
 }
-__device__ __forceinline__ void df_post(volatile int* cnt, int v, int lane) {
-  asm volatile("" ::: "memory");
-  if (lane == 0) *cnt = v;
+__device__ __forceinline__ void df_post(LdsCnt c, int v, int lane) {
+  if (lane == 0)
+    asm volatile("ds_write_b32 %0, %1" ::"v"(c.a), "v"(v) : "memory");
+  else
+    asm volatile("" ::: "memory");
 }
 
 // A chain WALKED by one lane instead of swept by 64 (tools/mac_chain_ubench.hip, one wave per SIMD: a sweep step costs 60 clocks for
@@ -748,8 +779,9 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
   double* ctl = rows + MAC_ROW_FIELDS * cols;
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS] active lanes of (row & 1, strip)
   double* rring = ctl + 2 * MAC_DF_STRIPS;                                 // [2] scale[i+1] of row i
-  double* pmaxring = rring + 2;                                            // [2][2] max_j F_MM of row i over the strips of either P wave
-  volatile int* cnt = reinterpret_cast<volatile int*>(pmaxring + 4);
+  double* pmaxring = rring + 2;                                            // [2][MAC_NP] max_j F_MM of row i over the strips of a P wave
+  int* cnt_mem = reinterpret_cast<int*>(pmaxring + 2 * MAC_NP);
+  const LdsCnt cnt = lds_cnt(cnt_mem);
   float* sTp = reinterpret_cast<float*>(ctl + MAC_CTL_DOUBLES);
   float* sTt = sTp + cols * 20;
   unsigned char* sCo = reinterpret_cast<unsigned char*>(sTt + cols * 8);  // [2][cols]: the mask bytes of a row, fetched a row ahead (P only)
@@ -765,19 +797,21 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       for (int e = tid; e < 352; e += NT) sSs[e] = h.sstab[e];
     for (int j = 1 + tid; j <= Lt; j += NT) sCo[co_stride + j] = h.co[(size_t)pitch + j];  // row 1 (buffer row & 1)
   }
-  if (tid < DF_N) cnt[tid] = 0;
-  if (tid < 4) pmaxring[tid] = 0.0;
+  if (tid < DF_N) cnt_mem[tid] = 0;
+  if (tid < 2 * MAC_NP) pmaxring[tid] = 0.0;
   if (tid == 0) h.scale[0] = h.scale[1] = h.scale[2] = 1.0;
   __syncthreads();
   const int ns = (Lt + 63) >> 6;
-  const int n_of[2] = {(ns + 1) >> 1, ns >> 1};  // strips of a row that P wave 0 / 1 works on (even / odd ones)
-  volatile int* dead = cnt + DF_DEAD;
+  // strips of a row that P wave w works on
+#define N_OF(w) (ns > (w) ? (ns - (w) + MAC_NP - 1) / MAC_NP : 0)
+  const LdsCnt dead = cnt + DF_DEAD;
   // unit (i, s) of the parallel part is done when its wave's counter has reached ...
-#define P_DONE(i, s) cnt + DF_P + ((s)&1), ((i)-1) * n_of[(s)&1] + ((s) >> 1) + 1
+#define P_DONE(i, s) cnt + DF_P + ((s) % MAC_NP), ((i)-1) * N_OF((s) % MAC_NP) + (s) / MAC_NP + 1
 
-  if (wv <= 1) {
-    // ---- P: wave w works on strips w, w+2, .. of every row ----
-    const int w = wv, no = n_of[w ^ 1];
+  if (wv < MAC_NP) {
+    // ---- P: wave w works on strips w, w + MAC_NP, .. of every row ----
+    const int w = wv, o1 = (w + 1) % MAC_NP, o2 = (w + 2) % MAC_NP, o3 = (w + 3) % MAC_NP;
+    static_assert(MAC_NP == 4 || MAC_NP == 2, "the row-end wait names the other waves (for two, all three names are the one)");
     unsigned char co_next = (!STAGE && w < ns && 1 + (w << 6) + lane <= Lt) ? h.co[(size_t)pitch + 1 + (w << 6) + lane] : 1;
     double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0, scale_i = 1.0;
     int own = 0;
@@ -793,10 +827,12 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       const int cur = i & 1, prv = cur ^ 1;
       if (i >= 2) {
         // the end of row i-1 (both waves, the same operations): its rescaling factor needs the other wave's strips too
-        if (no > 0) DF_WAIT(cnt + DF_P + (w ^ 1), (i - 1) * no, dead);
+        DF_WAIT(cnt + DF_P + o1, (i - 1) * N_OF(o1), dead, cnt + DF_P + o2, (i - 1) * N_OF(o2), cnt + DF_P + o3, (i - 1) * N_OF(o3));
         double scale_next = 1.0;
         if (i - 1 >= 2) {
-          const double Pmax = fmax(pmaxring[prv * 2], pmaxring[prv * 2 + 1]);
+          double Pmax = pmaxring[prv * MAC_NP];
+#pragma unroll
+          for (int e = 1; e < MAC_NP; ++e) Pmax = fmax(Pmax, pmaxring[prv * MAC_NP + e]);
           pmin *= scale_i;
           if (pmin < DBL_MIN * 100) pmin = 0.0;
           scale_next = 1.0 / (Pmax + 1.0);  // :155
@@ -828,13 +864,12 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
 #pragma unroll
         for (int u = 0; u < MAC_PRE; ++u) {
           const int jn = 1 + u * 64 + lane;
-          pre_co[u] = ((u & 1) == w && i < Lq && jn <= Lt) ? h.co[(size_t)(i + 1) * pitch + jn] : 1;
+          pre_co[u] = (u % MAC_NP == w && i < Lq && jn <= Lt) ? h.co[(size_t)(i + 1) * pitch + jn] : 1;
         }
       }
-      if (w == 0 && lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
       const unsigned char* co_row = sCo + cur * co_stride;
       const int above = ((i - 2) >> 1) * ns;  // units the sweep waves of row i-1's parity have finished before that row
-      for (int s = w; s < ns; s += 2) {
+      for (int s = w; s < ns; s += MAC_NP) {
         DF_MARK(-1)  // sections: 0 waits for the row above, 1 mask + operand loads + dot product, 2 states, 3 left neighbour + chain operands, 4 post + row ends
         if (i >= 2) {
           // row i-1's chains of this strip (and, in order, of the ones left of it) are final; its operands XB(.., strip s) and
@@ -849,9 +884,9 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
         const int jc = valid ? j : Lt;
         const bool off = !valid || (STAGE ? co_row[jc] != 0 : co_next != 0);
         if (!STAGE) {
-          // this wave's next unit: two strips on, or its first strip of the next row
-          const bool last = s + 2 >= ns;
-          const int ni = last ? i + 1 : i, nj = last ? 1 + (w << 6) + lane : j + 128;
+          // this wave's next unit: MAC_NP strips on, or its first strip of the next row
+          const bool last = s + MAC_NP >= ns;
+          const int ni = last ? i + 1 : i, nj = last ? 1 + (w << 6) + lane : j + 64 * MAC_NP;
           co_next = (ni <= Lq && (!last || w < ns) && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
         }
         const unsigned long long on_mask = __ballot(!off);
@@ -864,7 +899,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
             ROW(cur, F_IM, j) = 0.0;
             ROW(cur, F_DG, j) = 0.0;
             ROW(cur, F_MI, j) = 0.0;
-            h.mat[(size_t)i * pitch + j] = 0.0f;
+            XB(2, j) = 0.0;
           }
         } else {
           float tpj[20], tt1[7], tt[7];
@@ -900,8 +935,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
             ROW(cur, F_MM, j) = mm;
             ROW(cur, F_DG, j) = dg;
             ROW(cur, F_MI, j) = mi;
-            if (LOCAL) XB(2, j) = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168)
-            h.mat[(size_t)i * pitch + j] = (float)mm;
+            XB(2, j) = (double)(float)mm;  // what p_mm stores (float) and Pforward sums (:168): the total's wave stores it
           }
           // the recurrences along the row (:104-109): gd = mm(j-1)*t[j-1][M2D] + gd(j-1)*t[j-1][D2D],
           //                                           im = mm(j-1)*q[i][M2I]*t[j-1][M2M] + im(j-1)*q[i][I2I]*t[j-1][M2M]
@@ -924,28 +958,28 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           }
         }
         DF_MARK(3)
-        if (s + 2 >= ns) {
+        if (s + MAC_NP >= ns) {
           // this wave's last strip of the row
           if (STAGE) {
             unsigned char* co_nextrow = sCo + prv * co_stride;
 #pragma unroll
             for (int u = 0; u < MAC_PRE; ++u) {
               const int jn = 1 + u * 64 + lane;
-              if ((u & 1) == w && jn <= Lt) co_nextrow[jn] = pre_co[u];
+              if (u % MAC_NP == w && jn <= Lt) co_nextrow[jn] = pre_co[u];
             }
           }
           Pmax = wave_max_d(Pmax);
-          if (lane == 0) pmaxring[cur * 2 + w] = Pmax;
+          if (lane == 0) pmaxring[cur * MAC_NP + w] = Pmax;
         }
         df_post(cnt + DF_P + w, ++own, lane);
         DF_EVENT(2, i, s)
       }
     }
-  } else if (wv <= 5) {
+  } else if (wv < MAC_NP + 4) {
     // ---- the GD / IM chains of the rows of one parity ----
-    const int par = (wv - 2) >> 1;
-    const bool gdw = ((wv - 2) & 1) == 0;
-    volatile int* mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
+    const int par = (wv - MAC_NP) >> 1;
+    const bool gdw = ((wv - MAC_NP) & 1) == 0;
+    const LdsCnt mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
     int done = 0;
     float qI2I_next = (!gdw && (par ? 1 : 2) <= Lq) ? h.qtr[(size_t)(par ? 1 : 2) * 7 + T_I2I] : 0.0f;  // fetched a row ahead
     for (int i = par ? 1 : 2; i <= Lq; i += 2) {
@@ -984,6 +1018,12 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       for (int s = 0; s < ns; ++s) {
         DF_WAIT(P_DONE(i, s), dead);
         DF_EVENT(5, i, s)
+        {
+          // F_MM as the float the reference keeps (p_mm): stored by this wave, which never waits for global memory
+          const int j = 1 + (s << 6) + lane;
+          if (j <= Lt) h.mat[(size_t)i * pitch + j] = (float)XB(2, j);
+          if (s == 0 && lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
+        }
         if (LOCAL) {
           const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
           if (on_mask != 0) {
@@ -1041,8 +1081,9 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
   const size_t cols = (size_t)a.lds_cols + 2;
   double* ctl = rows + MAC_ROW_FIELDS * cols;
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS]
-  double* rring = ctl + 2 * MAC_DF_STRIPS;                                 // [2] mask byte of (i, Lt) != 0
-  volatile int* cnt = reinterpret_cast<volatile int*>(ctl + 2 * MAC_DF_STRIPS + 6);
+  double* prow = ctl + 2 * MAC_DF_STRIPS;  // [2][4] what the posterior waves need of row i: mask byte of (i, Lt) != 0, scale[i+1], q.tr[i][M2I]
+  int* cnt_mem = reinterpret_cast<int*>(prow + 8);
+  const LdsCnt cnt = lds_cnt(cnt_mem);
   float* sTp = reinterpret_cast<float*>(ctl + MAC_CTL_DOUBLES);
   float* sTt = sTp + cols * 20;
   // STAGE: the mask bytes (P) and F_MM (P2) of a row are fetched while the row processed before it is computed
@@ -1063,7 +1104,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
         sF[((Lq - 1) & 1) * co_stride + j] = h.mat[(size_t)(Lq - 1) * pitch + j];
       }
   }
-  if (tid < DF_N) cnt[tid] = 0;
+  if (tid < DF_N) cnt_mem[tid] = 0;
   __syncthreads();
   const double sL = h.scale[Lq + 1];
   // row Lq (:19-29); row i lives in buffer i & 1
@@ -1079,23 +1120,24 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
   }
   __syncthreads();
   const int ns = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 1;  // strips of columns Lt-1 .. 1 (Lt = 1: one strip without a valid lane)
-  const int n_of[2] = {(ns + 1) >> 1, ns >> 1};      // strips of a row that P wave 0 / 1 works on (even / odd ones)
-  volatile int* dead = cnt + DF_DEAD;
+  const LdsCnt dead = cnt + DF_DEAD;
   // unit (i, s) of the parallel part is done when its wave's counter has reached ...
-#define P_DONE(i, s) cnt + DF_P + ((s)&1), (Lq - 1 - (i)) * n_of[(s)&1] + ((s) >> 1) + 1
+#define P_DONE(i, s) cnt + DF_P + ((s) % MAC_NP), (Lq - 1 - (i)) * N_OF((s) % MAC_NP) + (s) / MAC_NP + 1
+  // ... and the posterior wave's (even / odd strips)
+#define T_DONE(i, s) cnt + DF_T + ((s)&1), (Lq - 1 - (i)) * ((ns + 1 - ((s)&1)) >> 1) + ((s) >> 1) + 1
 
-  if (wv <= 1) {
-    // ---- P: wave w works on strips w, w+2, .. of every row (the units of a row do not depend on each other) ----
+  if (wv < MAC_NP) {
+    // ---- P: wave w works on strips w, w + MAC_NP, .. of every row (the units of a row do not depend on each other) ----
     const int w = wv;
     double pmin = LOCAL ? sL : 0.0;
     double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;  // scale[i+1] of the row, fetched a row ahead
     unsigned char co_nx = (!STAGE && Lq >= 2 && w < ns && Lt - 1 - (w << 6) - lane >= 1) ? h.co[(size_t)(Lq - 1) * pitch + Lt - 1 - (w << 6) - lane] : 1;
     int own = 0;
-    // lanes 0-19: q.p[i+1], 20-24: q.tr[i][M2M, M2D, I2M, D2M, D2D]
+    // lanes 0-19: q.p[i+1], 20-25: q.tr[i][M2M, M2D, I2M, D2M, D2D, M2I]
     auto qrow = [&](int i) -> float {
-      if (i < 1 || lane > 24) return 0.0f;
+      if (i < 1 || lane > 25) return 0.0f;
       if (lane < 20) return h.qp[(size_t)(i + 1) * 20 + lane];
-      const int tr = lane == 20 ? T_M2M : lane == 21 ? T_M2D : lane == 22 ? T_I2M : lane == 23 ? T_D2M : T_D2D;
+      const int tr = lane == 20 ? T_M2M : lane == 21 ? T_M2D : lane == 22 ? T_I2M : lane == 23 ? T_D2M : lane == 24 ? T_D2D : T_M2I;
       return h.qtr[(size_t)i * 7 + tr];
     };
     float q_next = qrow(Lq - 1);
@@ -1114,38 +1156,47 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       const unsigned char* corow = h.co + (size_t)i * pitch;
       const unsigned char* co_l = sCo + cur * co_stride;
       unsigned char pre_co[MAC_PRE];
+      float pre_f[MAC_PRE];
       if (STAGE) {
 #pragma unroll
         for (int q = 0; q < MAC_PRE; ++q) {
           const int jn = 1 + q * 64 + lane;
-          // (a wave stages the bytes of its own strips only - column Lt is wave 0's: every byte has one writer and one reader)
-          const bool own_col = jn <= Lt && (jn == Lt ? w == 0 : (((Lt - 1 - jn) >> 6) & 1) == w);
+          // (a wave stages the mask bytes and the F_MM values of its own strips only - column Lt is wave 0's: every entry has
+          // one writer; the posterior waves, which store to global memory all the time, never have to wait for a load)
+          const bool own_col = jn <= Lt && (jn == Lt ? w == 0 : ((Lt - 1 - jn) >> 6) % MAC_NP == w);
           pre_co[q] = (i >= 2 && own_col) ? h.co[(size_t)(i - 1) * pitch + jn] : 1;
+          pre_f[q] = (i >= 2 && own_col) ? h.mat[(size_t)(i - 1) * pitch + jn] : 0.0f;
         }
       }
       const unsigned char coL = STAGE ? co_l[Lt] : corow[Lt];  // the mask byte of column Lt, for P2's column-Lt step of this row
-      for (int s = w; s < ns; s += 2) {
+      for (int s = w; s < ns; s += MAC_NP) {
         // B_MM of row i+1 at this strip's columns and the one right of them is final; with it the chain waves of (i+1, s) are
         // done with XB(0 / 1), P2 with XB(2 / 3), the mask and the per-row ring.  Row i+2, whose buffer this unit overwrites,
         // has been read by this wave's units of row i+1 and by P2 (this wave waited for P2 of (i+2, s) before (i+1, s)); the
         // other P wave's unit (i+1, s+1) reads one column of strip s of row i+2: wait for it too
         if (i <= Lq - 2) {
-          // (B_MM of the column right of the strip is the other P2 wave's, unit (i+1, s-1))
-          volatile int* tl = s > 0 ? cnt + DF_T + ((s - 1) & 1) : nullptr;
-          const int tl_need = s > 0 ? (Lq - 2 - i) * n_of[(s - 1) & 1] + ((s - 1) >> 1) + 1 : 0;
-          DF_WAIT(cnt + DF_T + (s & 1), (Lq - 2 - i) * n_of[s & 1] + (s >> 1) + 1, dead, tl, tl_need);
+          // (B_MM of the column right of the strip is the other posterior wave's, unit (i+1, s-1))
+          if (s > 0) {
+            DF_WAIT(T_DONE(i + 1, s), dead, T_DONE(i + 1, s - 1));
+          } else {
+            DF_WAIT(T_DONE(i + 1, s), dead);
+          }
           if (s + 1 < ns) DF_WAIT(P_DONE(i + 1, s + 1), dead);
         }
         DF_EVENT(1, i, s)
-        if (s == 0 && lane == 0) rring[cur] = coL ? 1.0 : 0.0;
+        if (s == 0 && lane == 0) {
+          prow[cur * 4 + 0] = coL ? 1.0 : 0.0;
+          prow[cur * 4 + 1] = sc;
+          prow[cur * 4 + 2] = rl_f(q_cur, 25);
+        }
         const int j = Lt - 1 - (s << 6) - lane;  // descending: lane 0 is the rightmost column of the strip
         const bool valid = j >= 1;
         const int jc = valid ? j : 1;
         const bool off = !valid || (STAGE ? co_l[jc] != 0 : co_nx != 0);
         if (!STAGE) {
-          // the next unit of this wave: two strips on, or its first strip of row i - 1
-          const bool last = s + 2 >= ns;
-          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (w << 6) - lane : j - 128;
+          // the next unit of this wave: MAC_NP strips on, or its first strip of row i - 1
+          const bool last = s + MAC_NP >= ns;
+          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (w << 6) - lane : j - 64 * MAC_NP;
           co_nx = (ni >= 1 && nj >= 1) ? h.co[(size_t)ni * pitch + nj] : 1;
         }
         const unsigned long long on_mask = __ballot(!off);
@@ -1186,24 +1237,26 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
             XB(3, j) = e5;
           }
         }
-        if (s + 2 >= ns && STAGE) {
-          // this wave's last strip of the row
+        if (s + MAC_NP >= ns && STAGE) {
+          // this wave's last strip of the row (the posterior waves are done with row i+1, whose values these replace: this
+          // wave waited for them before each of its units of row i)
           unsigned char* co_n = sCo + prv * co_stride;
+          float* f_n = sF + prv * co_stride;
 #pragma unroll
           for (int q = 0; q < MAC_PRE; ++q) {
             const int jn = 1 + q * 64 + lane;
-            if (jn <= Lt && (jn == Lt ? w == 0 : (((Lt - 1 - jn) >> 6) & 1) == w)) co_n[jn] = pre_co[q];
+            if (jn <= Lt && (jn == Lt ? w == 0 : ((Lt - 1 - jn) >> 6) % MAC_NP == w)) co_n[jn] = pre_co[q], f_n[jn] = pre_f[q];
           }
         }
         df_post(cnt + DF_P + w, ++own, lane);
         DF_EVENT(2, i, s)
       }
     }
-  } else if (wv <= 5) {
+  } else if (wv < MAC_NP + 4) {
     // ---- the GD / IM chains of the rows of one parity ----
-    const int par = (wv - 2) >> 1;
-    const bool gdw = ((wv - 2) & 1) == 0;
-    volatile int* mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
+    const int par = (wv - MAC_NP) >> 1;
+    const bool gdw = ((wv - MAC_NP) & 1) == 0;
+    const LdsCnt mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
     int done = 0;
     const int i_first = ((Lq - 1) & 1) == par ? Lq - 1 : Lq - 2;
     float qI2I_next = (!gdw && i_first >= 1) ? h.qtr[(size_t)i_first * 7 + T_I2I] : 0.0f;  // fetched a row ahead
@@ -1235,7 +1288,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
     }
   } else {
     // ---- P2: wave v works on strips v, v+2, .. of every row ----
-    const int v = wv - 6;
+    const int v = wv - (MAC_NP + 4);
     double scale_prod = sL;
     double final_scale_prod = sL;  // :31-36
     if (LISTS) {
@@ -1251,38 +1304,29 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       }
     }
     float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
-    double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;
     float f_nx = (!STAGE && Lq >= 2 && v < ns && Lt - 1 - (v << 6) - lane >= 1) ? h.mat[(size_t)(Lq - 1) * pitch + Lt - 1 - (v << 6) - lane] : 0.0f;
     int own = 0;
-    float qM2I_next = Lq >= 2 ? h.qtr[(size_t)(Lq - 1) * 7 + T_M2I] : 0.0f;  // fetched a row ahead
-    for (int i = Lq - 1; i >= 1; --i) {
+    // (a wave with units has one in every row - strip v - so its scale_prod sees every row's factor)
+    for (int i = Lq - 1; i >= 1 && v < ns; --i) {
       const int cur = i & 1;
-      const double sc = sc_next;
-      sc_next = i >= 2 ? h.scale[i] : 1.0;
-      scale_prod *= sc;
-      if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
-      const double qM2I = qM2I_next;
-      qM2I_next = i >= 2 ? h.qtr[(size_t)(i - 1) * 7 + T_M2I] : 0.0f;
+      double qM2I = 0.0;
       float* row = h.mat + (size_t)i * pitch;
-      const float* f_l = sF + cur * co_stride;
-      float pre_f[MAC_PRE];
-      if (STAGE) {
-#pragma unroll
-        for (int q = 0; q < MAC_PRE; ++q) {
-          const int jn = 1 + q * 64 + lane;
-          // (a wave stages the values of its own strips only - column Lt is wave 0's)
-          const bool own_col = jn <= Lt && (jn == Lt ? v == 0 : (((Lt - 1 - jn) >> 6) & 1) == v);
-          pre_f[q] = (i >= 2 && own_col) ? h.mat[(size_t)(i - 1) * pitch + jn] : 0.0f;
-        }
-      }
-      const float fL = STAGE ? f_l[Lt] : (lane == 0 ? row[Lt] : 0.0f);
+      const float* f_l = sF + cur * co_stride;  // STAGE: F_MM of the row, staged by the P waves
       for (int s = v; s < ns; s += 2) {
         const int need = ((Lq - 1 - i) >> 1) * ns + s + 1;  // units of the chain waves of this row's parity
         DF_WAIT(cnt + DF_S + 2 * cur + 0, need, dead, cnt + DF_S + 2 * cur + 1, need);
         DF_EVENT(5, i, s)
+        if (s == v) {
+          // the row's constants, left by the first P wave with its unit (i, 0), which the chain waves waited for
+          const double sc = prow[cur * 4 + 1];
+          scale_prod *= sc;
+          if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
+          qM2I = prow[cur * 4 + 2];
+        }
         if (s == 0 && lane == 0) {
           // column Lt (:58-71)
-          if (rring[cur] != 0.0) {
+          const float fL = STAGE ? f_l[Lt] : row[Lt];
+          if (prow[cur * 4 + 0] != 0.0) {
             row[Lt] = 0.0f;
             ROW(cur, F_MM, Lt) = 0.0;
           } else {
@@ -1328,19 +1372,13 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
             if (lv > MAC_LIST_THRESHOLD) blist[(size_t)i * pitch + j] = lv;
           }
         }
-        if (s + 2 >= ns && STAGE) {
-          float* f_n = sF + (cur ^ 1) * co_stride;
-#pragma unroll
-          for (int q = 0; q < MAC_PRE; ++q) {
-            const int jn = 1 + q * 64 + lane;
-            if (jn <= Lt && (jn == Lt ? v == 0 : (((Lt - 1 - jn) >> 6) & 1) == v)) f_n[jn] = pre_f[q];
-          }
-        }
       }
     }
   }
   DF_TIMING_REPORT("backward")
 #undef P_DONE
+#undef T_DONE
+#undef N_OF
 }
 
 // ---- maximum-accuracy DP ----------------------------------------------------------------------------------------------
@@ -1648,6 +1686,13 @@ static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t str
   if (!GROWS && !no_pipe) {
     // row state in LDS: the dataflow kernels (six wavefronts per hit)
     (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const bool dbg = getenv("HHV_MAC_DEBUG") != nullptr;  // measurement aid: resident workgroups per CU
+    if (dbg) {
+      int nf = 0, nb = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (const void*)hhv_mac_forward_df_kernel<LOCAL, STAGE>, MAC_DF_THREADS, lds);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, false>, MAC_DFB_THREADS, lds);
+      fprintf(stderr, "hhv_mac: %d hits, %zu B of LDS per workgroup: %d forward / %d backward workgroups resident per CU\n", n, lds, nf, nb);
+    }
     hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, STAGE>), dim3(n), dim3(MAC_DF_THREADS), lds, stream, a);
     if (a.fwd_list) {  // the -o_matrices lists were asked for (hhv_mac_set_lists)
       hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
