@@ -633,10 +633,16 @@ constexpr int MAC_DF_STRIPS = 24;     // strips per row the mask table holds (LD
 constexpr int MAC_CTL_DOUBLES = 64;   // behind the rows: masks [2][24] (48), per-row rings (forward 2 + 2 x MAC_NP, backward 8), 12 counters (6)
 static_assert(2 * MAC_DF_STRIPS + 2 + 2 * 4 + 6 <= MAC_CTL_DOUBLES, "control block");
 #define XB(k, j) rows[(10 + (k)) * stride + (j)]
-constexpr int MAC_NP = 2;  // wavefronts of the parallel part: wave w works on strips w, w + 4, .. of every row
+// Wavefronts of the parallel part (wave w works on strips w, w + MAC_NP, .. of every row): as many as keep the workgroup at EIGHT
+// wavefronts.  The kernels need ~100 VGPRs, i.e. four waves per SIMD, sixteen per CU: two workgroups of eight share a CU (500 hits on
+// 256 CUs), two of nine or ten do not - measured: four P waves forward 1.27 -> 1.8 ms, three backward 1.26 -> 1.63 ms.
+#define MAC_NP_FWD 3  // + four chain waves + the total
+#define MAC_NP_BWD 2  // + four chain waves + two posterior waves
+#define MAC_OWN ((13 + MAC_NP - 1) / MAC_NP)  // strips of a row one P wave owns at most in the staged classes (MAC_PRE / MAC_NP, rounded up)
 enum { DF_P = 0 /* [MAC_NP] */, DF_S = 4 /* [parity][chain] */, DF_T = 8 /* [2] */, DF_R = 10, DF_DEAD = 11, DF_N = 12 };
-constexpr int MAC_DF_THREADS = (MAC_NP + 5) * 64;   // forward: P waves, four chain waves, the total
-constexpr int MAC_DFB_THREADS = (MAC_NP + 6) * 64;  // backward: P waves, four chain waves, two posterior waves
+constexpr int MAC_DF_THREADS = (MAC_NP_FWD + 5) * 64;
+constexpr int MAC_DFB_THREADS = (MAC_NP_BWD + 6) * 64;
+#define MAC_NP MAC_NP_FWD
 
 // progress counters: wave uniform, written by one lane
 #if defined(HHV_MAC_TIMING)  // measurement build (make lib_variant NAME=mt FLAGS=-DHHV_MAC_TIMING): where the waves of workgroup 0 wait
@@ -811,7 +817,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
   if (wv < MAC_NP) {
     // ---- P: wave w works on strips w, w + MAC_NP, .. of every row ----
     const int w = wv, o1 = (w + 1) % MAC_NP, o2 = (w + 2) % MAC_NP, o3 = (w + 3) % MAC_NP;
-    static_assert(MAC_NP == 4 || MAC_NP == 2, "the row-end wait names the other waves (for two, all three names are the one)");
+    static_assert(MAC_NP >= 2 && MAC_NP <= 4, "the row-end wait names three waves (with fewer than four, some of them twice or this wave itself)");
     unsigned char co_next = (!STAGE && w < ns && 1 + (w << 6) + lane <= Lt) ? h.co[(size_t)pitch + 1 + (w << 6) + lane] : 1;
     double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0, scale_i = 1.0;
     int own = 0;
@@ -827,6 +833,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       const int cur = i & 1, prv = cur ^ 1;
       if (i >= 2) {
         // the end of row i-1 (both waves, the same operations): its rescaling factor needs the other wave's strips too
+        DF_EVENT(7, i, 7)
         DF_WAIT(cnt + DF_P + o1, (i - 1) * N_OF(o1), dead, cnt + DF_P + o2, (i - 1) * N_OF(o2), cnt + DF_P + o3, (i - 1) * N_OF(o3));
         double scale_next = 1.0;
         if (i - 1 >= 2) {
@@ -851,6 +858,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
         else
           scale_prod *= scale_i;
       }
+      DF_EVENT(7, i, 8)
       const float q_cur = q_next;
       q_next = qrow(i + 1);
       float qi[20];
@@ -858,15 +866,20 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       for (int e = 0; e < 20; ++e) qi[e] = rl_f(q_cur, e);
       const double qM2M = rl_f(q_cur, 20), qI2M = rl_f(q_cur, 21), qD2M = rl_f(q_cur, 22), qM2D = rl_f(q_cur, 23), qD2D = rl_f(q_cur, 24);
       const double qM2I = rl_f(q_cur, 25);
+      DF_EVENT(7, i, 9)
       double Pmax = 0.0;
-      unsigned char pre_co[MAC_PRE];
+      // the mask bytes of this wave's strips of the next row (entry q: strip w + q * MAC_NP), fetched now, parked in LDS at the
+      // end of the row
+      unsigned char pre_co[MAC_OWN];
       if (STAGE) {
 #pragma unroll
-        for (int u = 0; u < MAC_PRE; ++u) {
-          const int jn = 1 + u * 64 + lane;
-          pre_co[u] = (u % MAC_NP == w && i < Lq && jn <= Lt) ? h.co[(size_t)(i + 1) * pitch + jn] : 1;
+        for (int q = 0; q < MAC_OWN; ++q) {
+          const int u = w + q * MAC_NP, jn = 1 + u * 64 + lane;
+          pre_co[q] = 1;
+          if (u < ns && i < Lq && jn <= Lt) pre_co[q] = h.co[(size_t)(i + 1) * pitch + jn];
         }
       }
+      DF_EVENT(8, i, 0)
       const unsigned char* co_row = sCo + cur * co_stride;
       const int above = ((i - 2) >> 1) * ns;  // units the sweep waves of row i-1's parity have finished before that row
       for (int s = w; s < ns; s += MAC_NP) {
@@ -963,9 +976,9 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           if (STAGE) {
             unsigned char* co_nextrow = sCo + prv * co_stride;
 #pragma unroll
-            for (int u = 0; u < MAC_PRE; ++u) {
-              const int jn = 1 + u * 64 + lane;
-              if (u % MAC_NP == w && jn <= Lt) co_nextrow[jn] = pre_co[u];
+            for (int q = 0; q < MAC_OWN; ++q) {
+              const int u = w + q * MAC_NP, jn = 1 + u * 64 + lane;
+              if (u < ns && jn <= Lt) co_nextrow[jn] = pre_co[q];
             }
           }
           Pmax = wave_max_d(Pmax);
@@ -1064,6 +1077,8 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
 #undef P_DONE
 }
 
+#undef MAC_NP
+#define MAC_NP MAC_NP_BWD
 // Backward: P (wave 0) computes what depends on row i+1 only - pmatch, DG, MI, the chains' operands and, for B_MM, the partial
 // sum pmin + pmatch*q[M2M]*t[M2M] (into the F_MM slot) and the two last summands (XB(2 / 3, j)); the sweep waves follow; P2
 // (wave 5) completes B_MM = (((partial + gd(j+1)*t[M2D]) + im(j+1)*q[M2I]*t[M2M]) + XB2) + XB3 - the reference's left-to-right
@@ -1155,18 +1170,19 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       const double qM2M = rl_f(q_cur, 20), qM2D = rl_f(q_cur, 21), qI2M = rl_f(q_cur, 22), qD2M = rl_f(q_cur, 23), qD2D = rl_f(q_cur, 24);
       const unsigned char* corow = h.co + (size_t)i * pitch;
       const unsigned char* co_l = sCo + cur * co_stride;
-      unsigned char pre_co[MAC_PRE];
-      float pre_f[MAC_PRE];
+      // the mask bytes and the F_MM values of this wave's strips of the next row (entry q: strip w + q * MAC_NP; wave 0 lane 0 also
+      // column Lt): fetched now, parked in LDS at the end of the row.  Every entry has one writer, and the posterior waves, which
+      // store to global memory all the time, never have to wait for a load.
+      unsigned char pre_co[MAC_OWN], pre_coL = 1;
+      float pre_f[MAC_OWN], pre_fL = 0.0f;
       if (STAGE) {
 #pragma unroll
-        for (int q = 0; q < MAC_PRE; ++q) {
-          const int jn = 1 + q * 64 + lane;
-          // (a wave stages the mask bytes and the F_MM values of its own strips only - column Lt is wave 0's: every entry has
-          // one writer; the posterior waves, which store to global memory all the time, never have to wait for a load)
-          const bool own_col = jn <= Lt && (jn == Lt ? w == 0 : ((Lt - 1 - jn) >> 6) % MAC_NP == w);
-          pre_co[q] = (i >= 2 && own_col) ? h.co[(size_t)(i - 1) * pitch + jn] : 1;
-          pre_f[q] = (i >= 2 && own_col) ? h.mat[(size_t)(i - 1) * pitch + jn] : 0.0f;
+        for (int q = 0; q < MAC_OWN; ++q) {
+          const int u = w + q * MAC_NP, jn = Lt - 1 - (u << 6) - lane;
+          pre_co[q] = 1, pre_f[q] = 0.0f;
+          if (u < ns && i >= 2 && jn >= 1) pre_co[q] = h.co[(size_t)(i - 1) * pitch + jn], pre_f[q] = h.mat[(size_t)(i - 1) * pitch + jn];
         }
+        if (w == 0 && lane == 0 && i >= 2) pre_coL = h.co[(size_t)(i - 1) * pitch + Lt], pre_fL = h.mat[(size_t)(i - 1) * pitch + Lt];
       }
       const unsigned char coL = STAGE ? co_l[Lt] : corow[Lt];  // the mask byte of column Lt, for P2's column-Lt step of this row
       for (int s = w; s < ns; s += MAC_NP) {
@@ -1243,10 +1259,11 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
           unsigned char* co_n = sCo + prv * co_stride;
           float* f_n = sF + prv * co_stride;
 #pragma unroll
-          for (int q = 0; q < MAC_PRE; ++q) {
-            const int jn = 1 + q * 64 + lane;
-            if (jn <= Lt && (jn == Lt ? w == 0 : ((Lt - 1 - jn) >> 6) % MAC_NP == w)) co_n[jn] = pre_co[q], f_n[jn] = pre_f[q];
+          for (int q = 0; q < MAC_OWN; ++q) {
+            const int u = w + q * MAC_NP, jn = Lt - 1 - (u << 6) - lane;
+            if (u < ns && jn >= 1) co_n[jn] = pre_co[q], f_n[jn] = pre_f[q];
           }
+          if (w == 0 && lane == 0) co_n[Lt] = pre_coL, f_n[Lt] = pre_fL;
         }
         df_post(cnt + DF_P + w, ++own, lane);
         DF_EVENT(2, i, s)
@@ -1379,6 +1396,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
 #undef P_DONE
 #undef T_DONE
 #undef N_OF
+#undef MAC_NP
 }
 
 // ---- maximum-accuracy DP ----------------------------------------------------------------------------------------------
@@ -1672,18 +1690,20 @@ int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
 
 // LDS of the forward / backward kernels: two rows of state, plus - when it fits - the template itself
 size_t mac_rows_lds(int max_Lt, bool stage) {
-  // staged: + the template (28 floats per column) + two rows of mask bytes + two rows of F_MM fetched a row ahead + the
-  // secondary-structure table of the hit
+  // the dataflow kernels: 14 doubles per column + the control block; staged: + the template (28 floats per column) + two rows of
+  // mask bytes + two rows of F_MM fetched a row ahead + the secondary-structure table of the hit
   return ((size_t)MAC_ROW_FIELDS * (max_Lt + 2) + MAC_CTL_DOUBLES) * sizeof(double) +
          (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) + (((size_t)2 * (max_Lt + 2) + 15) & ~(size_t)15) +
                       (size_t)2 * (max_Lt + 2) * sizeof(float) + 352 * sizeof(float) : 0);
 }
+// the single-wave kernels with the row state in LDS (templates whose dataflow layout does not fit any more: 1459 .. 2046 columns)
+static size_t mac_rows_lds_single(int max_Lt) { return (size_t)10 * (max_Lt + 2) * sizeof(double); }
 constexpr size_t MAC_LDS_LIMIT = 160 * 1024;
 
 template <bool LOCAL, bool STAGE, bool GROWS>
-static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t stream) {
+static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t stream, bool dataflow = true) {
   static const bool no_pipe = getenv("HHV_MAC_NO_PIPE") != nullptr;  // measurement aid: the single-wave kernels for every class
-  if (!GROWS && !no_pipe) {
+  if (!GROWS && !no_pipe && dataflow) {
     // row state in LDS: the dataflow kernels (six wavefronts per hit)
     (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static const bool dbg = getenv("HHV_MAC_DEBUG") != nullptr;  // measurement aid: resident workgroups per CU
@@ -1718,7 +1738,10 @@ static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t str
 template <bool LOCAL>
 static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream) {
   if (cls <= 3) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
-  else if (cls <= 5) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream);
+  else if (cls <= 5) {
+    const bool df = mac_rows_lds(max_Lt, false) <= MAC_LDS_LIMIT;
+    launch_mac_rows<LOCAL, false, false>(a, n, df ? mac_rows_lds(max_Lt, false) : mac_rows_lds_single(max_Lt), stream, df);
+  }
   else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
   const size_t lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
   if (lds_dp <= MAC_LDS_LIMIT) {
@@ -1739,7 +1762,8 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
 // 4.68 (staged) / 5.01 (lean) / 4.90 (no LDS) - the sweeps' dependent chains, not the operand path, set the pace.
 int mac_staged_capacity(int max_Lt, int num_cus, bool stage) {
   const size_t lds = mac_rows_lds(max_Lt, stage);
-  return num_cus * (int)std::max<size_t>(1, MAC_LDS_LIMIT / std::max<size_t>(lds, 1));
+  // (round 5: the dataflow kernels are workgroups of eight wavefronts at ~100 VGPRs: two per CU whatever the LDS footprint)
+  return num_cus * (int)std::min<size_t>(2, std::max<size_t>(1, MAC_LDS_LIMIT / std::max<size_t>(lds, 1)));
 }
 int mac_length_class(int Lt, bool stage_allowed, bool lds_allowed) {
   static const bool no_stage = getenv("HHV_MAC_NO_STAGE") != nullptr;  // measurement aid: template operands from global memory for every length
@@ -1747,6 +1771,7 @@ int mac_length_class(int Lt, bool stage_allowed, bool lds_allowed) {
     return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : 3;
   static const bool no_lds = getenv("HHV_MAC_NO_LDS") != nullptr;  // measurement aid: row state in global memory for every length
   if (lds_allowed && !no_lds && mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT) return Lt <= 1022 ? 4 : 5;
+  if (lds_allowed && !no_lds && mac_rows_lds_single(Lt) <= MAC_LDS_LIMIT) return 5;  // (single-wave kernels, see launch_mac_class)
   return 6;
 }
 
