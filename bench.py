@@ -779,9 +779,10 @@ def next_rows():
     except Exception as e:
         out["N4_mac_realign"] = {"error": repr(e)}
     try:
-        # VALU-issue roofline of these kernels from the committed counters (profiles/r3_next_rows_summary.json, tools/profile_next.sh):
+        # VALU-issue roofline of these kernels from the committed counters (profiles/r5_next_rows_summary.json - r3's if absent -, tools/profile_next.sh):
         # executed VALU lane-instructions per cell x the rate measured here (prefilter), issue fraction of the profiled launch (MAC)
-        with open(os.path.join(ROOT, "profiles", "r3_next_rows_summary.json")) as f:
+        nr_name = next(n for n in ("r5_next_rows_summary.json", "r3_next_rows_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        with open(os.path.join(ROOT, "profiles", nr_name)) as f:
             k = json.load(f)["kernels"]
         rv = {}
         for name, key, rate in (("gapless", "hhv_pf_ungapped_kernel", out.get("N3_prefilter", {}).get("gapless_cells_per_s")),
@@ -795,7 +796,7 @@ def next_rows():
             if "mac_" in n:
                 rv[n.split("<")[0]] = {"frac_in_profiled_launch": v["frac_of_valu_issue_peak"], "avg_ms_profiled": v["avg_ms"]}
         out["roofline_valu"] = {"bound": "valu_issue", "peak_T_lane_ops_per_s": VALU_PEAK_LANEOPS / 1e12, "kernels": rv,
-                                "source": "profiles/r3_next_rows_summary.json (SQ_INSTS_VALU per launch) x the rates of this run"}
+                                "source": "profiles/%s (SQ_INSTS_VALU per launch) x the rates of this run" % nr_name}
     except Exception as e:
         out["roofline_valu"] = {"error": repr(e)}
     try:
