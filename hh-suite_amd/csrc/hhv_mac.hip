@@ -1400,7 +1400,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
 }
 
 // ---- maximum-accuracy DP ----------------------------------------------------------------------------------------------
-template <bool LOCAL, bool GROWS>
+template <bool LOCAL, bool GROWS, int DP_AHEAD>
 __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* S = GROWS ? reinterpret_cast<float*>(a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2))
@@ -1416,9 +1416,23 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
   int cur = 0;
   float best = -FLT_MAX;
   int best_i = 0, best_j = 0;
-  // mask byte and posterior of the next strip are fetched while the current one is swept (also across rows)
-  unsigned char co_nx = h.co[(size_t)pitch + min(1 + lane, Lt)];
-  float p_nx = h.mat[(size_t)pitch + min(1 + lane, Lt)];
+  // Mask byte and posterior of a strip are fetched DP_AHEAD strips before they are used (also across rows).  One strip ahead
+  // (rounds 2-4) is right where every strip of a row has active cells (500 hits of 300 columns: 0.83 ms; four ahead 0.98 ms -
+  // the extra register traffic of a lone, latency-bound wave); in long templates most strips of a row are masked out and take
+  // the wave a few hundred clocks, less than a trip to L2: four ahead took a batch of mixed lengths (40 .. 1 800 columns) from
+  // 14.4 to 11.9 ms.  The launcher picks by length class.  pf_i / pf_s0: the strip the next fetch is for.
+  unsigned char co_q[DP_AHEAD];
+  float p_q[DP_AHEAD];
+  int pf_i = 1, pf_s0 = 0;
+  auto fetch_next = [&](unsigned char& co, float& p) {
+    const int ni = min(pf_i, Lq), nj = min(1 + pf_s0 + lane, Lt);
+    co = h.co[(size_t)ni * pitch + nj];
+    p = h.mat[(size_t)ni * pitch + nj];
+    pf_s0 += 64;
+    if (pf_s0 >= Lt) pf_s0 = 0, ++pf_i;
+  };
+#pragma unroll
+  for (int e = 0; e < DP_AHEAD; ++e) fetch_next(co_q[e], p_q[e]);
   for (int i = 1; i <= Lq; ++i) {
     const int prv = cur ^ 1;
     const float* Sp = S + prv * stride;
@@ -1428,14 +1442,11 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
       const int j = 1 + s0 + lane;
       const bool valid = j <= Lt;
       const int jc = valid ? j : Lt;
-      const bool off = co_nx != 0;
-      const float p = p_nx;
-      {
-        const bool last = s0 + 64 >= Lt;
-        const int ni = min(last ? i + 1 : i, Lq), nj = min(last ? 1 + lane : j + 64, Lt);
-        co_nx = h.co[(size_t)ni * pitch + nj];
-        p_nx = h.mat[(size_t)ni * pitch + nj];
-      }
+      const bool off = co_q[0] != 0;
+      const float p = p_q[0];
+#pragma unroll
+      for (int e = 0; e + 1 < DP_AHEAD; ++e) co_q[e] = co_q[e + 1], p_q[e] = p_q[e + 1];
+      fetch_next(co_q[DP_AHEAD - 1], p_q[DP_AHEAD - 1]);
       const float term1 = p - mact;
       const float term2 = Sp[jc - 1] + p - mact;
       const float term3 = (float)(Sp[jc] - half);
@@ -1744,11 +1755,14 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
   }
   else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
   const size_t lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
-  if (lds_dp <= MAC_LDS_LIMIT) {
-    (void)hipFuncSetAttribute((const void*)hhv_mac_dp_kernel<LOCAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp);
-    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, false>), dim3(n), dim3(64), lds_dp, stream, a);
+  if (lds_dp > MAC_LDS_LIMIT) {
+    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, true, 4>), dim3(n), dim3(64), 0, stream, a);  // (class 6 only: row_scratch is there)
+  } else if (max_Lt <= 384) {
+    (void)hipFuncSetAttribute((const void*)hhv_mac_dp_kernel<LOCAL, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp);
+    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, false, 1>), dim3(n), dim3(64), lds_dp, stream, a);
   } else {
-    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, true>), dim3(n), dim3(64), 0, stream, a);  // (class 6 only: row_scratch is there)
+    (void)hipFuncSetAttribute((const void*)hhv_mac_dp_kernel<LOCAL, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dp);
+    hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, false, 4>), dim3(n), dim3(64), lds_dp, stream, a);
   }
 }
 
