@@ -39,9 +39,13 @@ lib_pto: $(LIBDIR)/libhhviterbi_hip_pto.so
 build/obj_pto/hhv_kernels_pair.o: $(CSRC)/hhv_kernels_pair.hip $(HDRS)
 	@mkdir -p build/obj_pto
 	$(HIPCC) $(HIPFLAGS) -DHHV_EXP_PAIR_TIMEOUT -fno-slp-vectorize -c $< -o $@
-$(LIBDIR)/libhhviterbi_hip_pto.so: $(OBJS) build/obj_pto/hhv_kernels_pair.o
+# ... and the MAC dataflow kernels with -DHHV_EXP_MAC_TIMEOUT (the first parallel-part wave never posts its units)
+build/obj_pto/hhv_mac.o: $(CSRC)/hhv_mac.hip $(HDRS)
+	@mkdir -p build/obj_pto
+	$(HIPCC) $(HIPFLAGS) -DHHV_EXP_MAC_TIMEOUT -c $< -o $@
+$(LIBDIR)/libhhviterbi_hip_pto.so: $(OBJS) build/obj_pto/hhv_kernels_pair.o build/obj_pto/hhv_mac.o
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter-out $(OBJDIR)/hhv_kernels_pair.o,$(OBJS)) build/obj_pto/hhv_kernels_pair.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter-out $(OBJDIR)/hhv_kernels_pair.o $(OBJDIR)/hhv_mac.o,$(OBJS)) build/obj_pto/hhv_kernels_pair.o build/obj_pto/hhv_mac.o
 
 # C++ host layer above the C ABI (mirror of the reference's ViterbiRunner); plain g++, links only the C ABI
 $(RUNNER): hh-suite_amd/host/viterbi_runner.cpp hh-suite_amd/host/viterbi_runner.h hh-suite_amd/host/prefilter.cpp hh-suite_amd/host/prefilter.h hh-suite_amd/host/posterior_decoder.cpp hh-suite_amd/host/posterior_decoder.h include/hhviterbi_hip.h $(LIB)

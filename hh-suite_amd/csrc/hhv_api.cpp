@@ -41,9 +41,10 @@ int sync_check(hhv_ctx* c, const char* who) {
     const uint32_t w = *(volatile uint32_t*)c->h_err;
     if (w) {
       *(volatile uint32_t*)c->h_err = 0;
-      return fail(HHV_E_DEVICE, "%s: device-side failure 0x%x:%s%s - the results of the launches since the last check are invalid", who, w,
+      return fail(HHV_E_DEVICE, "%s: device-side failure 0x%x:%s%s%s - the results of the launches since the last check are invalid", who, w,
                   (w & DEV_ERR_PAIR_TIMEOUT) ? " a wave of a two-wave workgroup waited in vain for its partner (pair kernel flow control)" : "",
-                  (w & DEV_ERR_TRACE_STATE) ? " illegal state in the backtrace walk (src/hhviterbi.cpp:139-144)" : "");
+                  (w & DEV_ERR_TRACE_STATE) ? " illegal state in the backtrace walk (src/hhviterbi.cpp:139-144)" : "",
+                  (w & DEV_ERR_MAC_TIMEOUT) ? " a wavefront of a MAC forward / backward workgroup waited in vain for another one's progress (dataflow kernels)" : "");
     }
   }
   return HHV_OK;

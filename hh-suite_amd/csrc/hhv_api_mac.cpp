@@ -324,6 +324,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   a.ss_mode = with_ss ? (const int32_t*)(base + o_ssmode) : nullptr;
   a.fwd_list = lists ? (float*)(base + o_fwl) : nullptr;
   a.bwd_list = lists ? (float*)(base + o_bwl) : nullptr;
+  a.err = c->d_err;
   ms->d_fwd_list = a.fwd_list;
   ms->d_bwd_list = a.bwd_list;
   // (the kernels write the cells the reference visits: rows 1 .. Lq [- 1], active cells; everything else reads as "no entry")
@@ -397,6 +398,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
                        hipMemcpyAsync(ms->h_paths, base + o_pi, path_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
                        hipStreamSynchronize(st) != hipSuccess))
     rc = fail(HHV_E_DEVICE, "hhv_mac_realign: kernels failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc == HHV_OK) rc = hhv::api::sync_check(c, "hhv_mac_realign");  // the device error word (a wave of a MAC workgroup that gave up waiting)
   if (rc != HHV_OK) {
     hhv_macset_free(ms);
     return rc;

@@ -122,6 +122,7 @@ struct StreamArgs {
 // sets a bit in the context's error word; every call that waits for the stream reports it as HHV_E_DEVICE (hhv_api.cpp).
 constexpr uint32_t DEV_ERR_PAIR_TIMEOUT = 1u;   // a wave of a two-wave workgroup waited in vain for its partner (hhv_stream_kernel.h pair_wait)
 constexpr uint32_t DEV_ERR_TRACE_STATE = 2u;    // hhv_trace_kernel met a state that is not one of STOP, MM, GD, IM, DG, MI
+constexpr uint32_t DEV_ERR_MAC_TIMEOUT = 4u;    // a wavefront of a MAC forward / backward workgroup waited in vain for another one's progress counter (hhv_mac.hip df_wait)
 
 struct TraceArgs {
   const float* records;
@@ -275,6 +276,7 @@ struct MacArgs {
   // list entry where it has one, 0 elsewhere; null = not wanted
   float* fwd_list;
   float* bwd_list;
+  uint32_t* err;             // the context's device error word (DEV_ERR_MAC_TIMEOUT), may be null
 };
 struct MacMaskArgs {
   const int4* ends;          // [n] i1, j1, i2, j2 of the Viterbi alignment

@@ -672,6 +672,11 @@ struct LdsCnt {
   __device__ __forceinline__ LdsCnt operator+(int k) const { return LdsCnt{a + 4u * (uint32_t)k}; }
 };
 __device__ __forceinline__ LdsCnt lds_cnt(const void* p) { return LdsCnt{(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p}; }
+#if defined(HHV_EXP_MAC_TIMEOUT)  // TEST build (make lib_pto, tests/test_gpu_errors.py): wave 0 never posts, the others give up at once
+constexpr int DF_WAIT_SPINS = 1 << 6;
+#else
+constexpr int DF_WAIT_SPINS = 1 << 18;  // x (a poll + s_sleep 1): tens of milliseconds
+#endif
 // up to three counters at once: their reads go out together - one trip to LDS instead of three.
 // Bounded: a wave that never sees its counter gives up (the results are then wrong and the parity tests say so) instead of
 // hanging the device; after the first time-out nobody waits any more.  Returns whether it had to wait.
@@ -681,7 +686,7 @@ __device__ __forceinline__ bool df_wait(LdsCnt c, int need, LdsCnt dead, LdsCnt 
   if (!c2.a) need2 = need;
   if (!c3.a) need3 = need;
   bool waited = false;
-  for (int g = 0; g < (1 << 18); ++g) {
+  for (int g = 0; g < DF_WAIT_SPINS; ++g) {
     // (one lane polls: with all 64 reading, the polls of a dozen waiting waves took half of the CU's LDS bandwidth from the
     // waves that work - two hits on a CU ran as slowly as one after the other)
     int ok = 0;
@@ -696,13 +701,20 @@ __device__ __forceinline__ bool df_wait(LdsCnt c, int need, LdsCnt dead, LdsCnt 
     }
     asm volatile("" ::: "memory");
     if (__builtin_amdgcn_readlane(ok, 0)) break;
-    if (g == (1 << 18) - 1) asm volatile("ds_write_b32 %0, %1" ::"v"(dead.a), "v"(1) : "memory");
+    if (g == DF_WAIT_SPINS - 1) asm volatile("ds_write_b32 %0, %1" ::"v"(dead.a), "v"(1) : "memory");
     waited = true;
     __builtin_amdgcn_s_sleep(1);
   }
   // (everything the waves hand each other lives in LDS, which executes the operations of a workgroup in order: the compiler
   // barrier of the asm statements is all that is needed - no fence, which would wait for this wave's global stores too)
   return waited;
+}
+// a wave that gave up: the results of the hit are wrong - say so in the context's error word (every call that waits for the
+// stream then answers HHV_E_DEVICE), once per wave at the end of the kernel
+__device__ __forceinline__ void df_report(LdsCnt dead, uint32_t* err, int lane) {
+  int d;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d) : "v"(dead.a) : "memory");
+  if (d != 0 && lane == 0 && err) __hip_atomic_fetch_or(err, DEV_ERR_MAC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void df_post(LdsCnt c, int v, int lane) {
   if (lane == 0)
@@ -984,6 +996,9 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           Pmax = wave_max_d(Pmax);
           if (lane == 0) pmaxring[cur * MAC_NP + w] = Pmax;
         }
+#if defined(HHV_EXP_MAC_TIMEOUT)
+        if (w != 0)
+#endif
         df_post(cnt + DF_P + w, ++own, lane);
         DF_EVENT(2, i, s)
       }
@@ -1073,6 +1088,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
     }
     if (lane == 0) a.Pforward[k] = Pf;
   }
+  df_report(dead, a.err, lane);
   DF_TIMING_REPORT("forward")
 #undef P_DONE
 }
@@ -1265,6 +1281,9 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
           }
           if (w == 0 && lane == 0) co_n[Lt] = pre_coL, f_n[Lt] = pre_fL;
         }
+#if defined(HHV_EXP_MAC_TIMEOUT)
+        if (w != 0)
+#endif
         df_post(cnt + DF_P + w, ++own, lane);
         DF_EVENT(2, i, s)
       }
@@ -1392,6 +1411,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       }
     }
   }
+  df_report(dead, a.err, lane);
   DF_TIMING_REPORT("backward")
 #undef P_DONE
 #undef T_DONE

@@ -216,3 +216,35 @@ def test_pair_flow_control_timeout_is_an_error_not_a_result():
         assert (a.i2, a.j2) == (int(res["i2"][e]), int(res["j2"][e])) and np.float32(a.score) == res["score"][e]
     ts.free()
     c.close()
+
+
+def test_mac_dataflow_timeout_is_an_error_not_a_result():
+    """The MAC forward / backward kernels are workgroups of eight wavefronts that wait for each other's progress counters in LDS,
+    with a bound.  A wave whose wait runs out must not pass for a result: libhhviterbi_hip_pto.so has these kernels compiled with
+    -DHHV_EXP_MAC_TIMEOUT (the first parallel-part wave never posts, short bound): hhv_mac_realign answers HHV_E_DEVICE with text,
+    the error word is cleared by the report and the context keeps working."""
+    import os
+    from pyhhv import capi
+    from pyoracle import Oracle, make_params
+    path = os.path.join(os.path.dirname(capi.LIB_PATH), "libhhviterbi_hip_pto.so")
+    if not os.path.exists(path):
+        pytest.skip("libhhviterbi_hip_pto.so not built (make lib_pto)")
+    c = capi.Context(local=1, lib_path=path)
+    qp, qtr = synth.make_query(5, 120)
+    tps, ttrs = zip(*[synth.make_template(70 + k, 100 + 30 * k) for k in range(6)])
+    tps, ttrs = list(tps), list(ttrs)
+    q_lin = capi.linear_transitions(qtr, True)
+    t_lins = [capi.linear_transitions(t, False) for t in ttrs]
+    with pytest.raises(capi.HhvError, match="MAC forward / backward workgroup waited in vain"):
+        c.mac_realign(qp, q_lin, tps, t_lins)
+    # the Viterbi path of the same context is untouched (one strip: no pair kernel of the test build involved)
+    ts = c.upload(tps, ttrs)
+    c.set_query(qp, qtr)
+    res = c.align(ts)
+    o = Oracle()
+    par = make_params(local=1)
+    for e in (0, 5):
+        a = o.align(par, qp, qtr, tps[e], ttrs[e], want_bt=False)
+        assert (a.i2, a.j2) == (int(res["i2"][e]), int(res["j2"][e])) and np.float32(a.score) == res["score"][e]
+    ts.free()
+    c.close()
