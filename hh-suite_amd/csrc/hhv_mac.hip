@@ -1794,6 +1794,8 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
 // The same one level further: a lean class (row state in LDS) with more hits than ITS residency runs with the row state in
 // global memory as well (class 6: no LDS, as many workgroups as the registers admit): 2 000 hits 10.6 -> 9.35 ms, 500 hits
 // 4.68 (staged) / 5.01 (lean) / 4.90 (no LDS) - the sweeps' dependent chains, not the operand path, set the pace.
+// (Numbers of the single-wave kernels, rounds 3-4.  Since round 5 the classes with LDS run the dataflow kernels - 500 hits 4.0 ms -
+// and hold two hits per CU; a batch beyond that still ends in class 6: 2 000 hits 9.23 ms, profiles/r5_next_rows_summary.txt.)
 int mac_staged_capacity(int max_Lt, int num_cus, bool stage) {
   const size_t lds = mac_rows_lds(max_Lt, stage);
   // (round 5: the dataflow kernels are workgroups of eight wavefronts at ~100 VGPRs: two per CU whatever the LDS footprint)
