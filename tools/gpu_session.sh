@@ -7,6 +7,9 @@
 #   ab <libdir>...   A/B of library builds on the fixed set of bench configurations (tools/gpu_ab.sh)
 #   profile          rocprofv3 kernel trace + PMC passes of the headline command and its backtrace twin (tools/profile.sh)
 #   next             the same for the prefilter / MAC kernels (tools/profile_next.sh)
+#   mac [soak_s]     after a change of the MAC kernels: their tests, a soak of their family, 500 hits of fixed and mixed lengths, the
+#                    single-wave kernels beside them (HHV_MAC_NO_PIPE=1)
+#   macprof          rocprofv3 kernel statistics of the MAC kernels, dataflow and single-wave
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
