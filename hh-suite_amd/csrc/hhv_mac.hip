@@ -733,7 +733,11 @@ __device__ __forceinline__ void df_post(LdsCnt c, int v, int lane) {
 // reference's order (src/hhforwardalgorithm.cpp:104-109,168, src/hhbackwardalgorithm.cpp:95-101).
 template <int DIR, int KIND>
 __device__ __forceinline__ double mac_walk(double* __restrict__ pc, const double* __restrict__ pb, int n, double y, double q) {
-  double cA[4], bA[4], cB[4], bB[4];
+  // blocks of four columns in three register sets: a block's operands are requested EIGHT columns (two blocks) before their use
+  // (one block ahead - ~90 clocks of fp64 chain - is less than a trip to LDS under load).  Measured against one block ahead:
+  // 256 hits 3.29 -> 3.26 ms, 500 hits unchanged - the walk's 48-60 clocks a column in place (21 in isolation) are not the operand
+  // latency alone (NOTES_r5 section 6)
+  double cA[4], bA[4], cB[4], bB[4], cC[4], bC[4];
 #define MAC_WALK_LOAD(X, E)                       \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) { \
     c##X[u] = pc[((E) + u) * DIR];                \
@@ -752,23 +756,42 @@ __device__ __forceinline__ double mac_walk(double* __restrict__ pc, const double
     }                                                \
     if (KIND != 2) pc[(E) * DIR] = y;                \
   }
+#define MAC_WALK_BLOCK(X, E) _Pragma("unroll") for (int u = 0; u < 4; ++u) MAC_WALK_STEP(c##X[u], b##X[u], (E) + u)
   int e = 0;
   if (n >= 4) { MAC_WALK_LOAD(A, 0) }
-  while (e + 8 <= n) {
-    MAC_WALK_LOAD(B, e + 4)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) MAC_WALK_STEP(cA[u], bA[u], e + u)
-    if (e + 12 <= n) { MAC_WALK_LOAD(A, e + 8) }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) MAC_WALK_STEP(cB[u], bB[u], e + 4 + u)
-    e += 8;
+  if (n >= 8) { MAC_WALK_LOAD(B, 4) }
+  // at the top: A holds block e (if it is a whole block), B block e + 4
+  while (e + 12 <= n) {
+    MAC_WALK_LOAD(C, e + 8)
+    MAC_WALK_BLOCK(A, e)
+    if (e + 16 <= n) { MAC_WALK_LOAD(A, e + 12) }
+    MAC_WALK_BLOCK(B, e + 4)
+    if (e + 20 <= n) { MAC_WALK_LOAD(B, e + 16) }
+    MAC_WALK_BLOCK(C, e + 8)
+    e += 12;
   }
   if (e + 4 <= n) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) MAC_WALK_STEP(cA[u], bA[u], e + u)
+    MAC_WALK_BLOCK(A, e)
     e += 4;
+    if (e + 4 <= n) {
+      MAC_WALK_BLOCK(B, e)
+      e += 4;
+    }
   }
-  for (; e < n; ++e) MAC_WALK_STEP(pc[e * DIR], (KIND != 2 ? pb[e * DIR] : 0.0), e)
+  // the last one to three columns: their operands in one go
+  const int r = n - e;
+  if (r > 0) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (u < r) {
+        cC[u] = pc[(e + u) * DIR];
+        if (KIND != 2) bC[u] = pb[(e + u) * DIR];
+      }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (u < r) MAC_WALK_STEP(cC[u], bC[u], e + u)
+  }
+#undef MAC_WALK_BLOCK
 #undef MAC_WALK_LOAD
 #undef MAC_WALK_STEP
   return y;
