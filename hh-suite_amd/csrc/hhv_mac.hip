@@ -1791,9 +1791,11 @@ static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t str
 }
 template <bool LOCAL>
 static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream) {
+  static_assert(MAC_PRE <= MAC_DF_STRIPS, "staged classes: at most MAC_PRE strips a row");
   if (cls <= 3) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
   else if (cls <= 5) {
-    const bool df = mac_rows_lds(max_Lt, false) <= MAC_LDS_LIMIT;
+    // (the dataflow kernels' mask table holds MAC_DF_STRIPS strips a row: implied by the LDS limit today, checked all the same)
+    const bool df = mac_rows_lds(max_Lt, false) <= MAC_LDS_LIMIT && (max_Lt + 63) / 64 <= MAC_DF_STRIPS;
     launch_mac_rows<LOCAL, false, false>(a, n, df ? mac_rows_lds(max_Lt, false) : mac_rows_lds_single(max_Lt), stream, df);
   }
   else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
