@@ -646,21 +646,19 @@ constexpr int MAC_DFB_THREADS = (MAC_NP_BWD + 6) * 64;
 
 // progress counters: wave uniform, written by one lane
 #if defined(HHV_MAC_TIMING)  // measurement build (make lib_variant NAME=mt FLAGS=-DHHV_MAC_TIMING): where the waves of workgroup 0 wait
-#define DF_TIMING_DECL unsigned long long t_wait = 0, t_begin = __builtin_readcyclecounter(), t_sec[5] = {0, 0, 0, 0, 0}, t_mark = 0, ev_t[32]; int n_wait = 0, ev_n = 0, ev_c[32];
+#define DF_TIMING_DECL unsigned long long t_wait = 0, t_begin = __builtin_readcyclecounter(), ev_t[32]; int n_wait = 0, ev_n = 0, ev_c[32];
 constexpr int DF_EV_ROW = 150;
 #define DF_EVENT(code, i, s) if (blockIdx.x == 0 && (i) >= DF_EV_ROW && (i) <= DF_EV_ROW + 1 && ev_n < 32) { ev_t[ev_n] = __builtin_readcyclecounter(); ev_c[ev_n++] = (code) * 10000 + (i) * 10 + (s); }
-#define DF_MARK(k)
 #define DF_TIMING_REPORT(name)                                                                                              \
   if (blockIdx.x == 0 && lane == 0)                                                                                         \
-    printf("%s wave %d: total %llu clk, waiting %llu clk in %d waits that did not pass at once; sections %llu %llu %llu %llu %llu\n", name, wv, \
-           (unsigned long long)(__builtin_readcyclecounter() - t_begin), t_wait, n_wait, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4]); \
+    printf("%s wave %d: total %llu clk, waiting %llu clk in %d waits that did not pass at once\n", name, wv,                 \
+           (unsigned long long)(__builtin_readcyclecounter() - t_begin), t_wait, n_wait);                                   \
   if (blockIdx.x == 0 && lane == 0)                                                                                         \
     for (int e_ = 0; e_ < ev_n; ++e_) printf("EV %s w%d code %d t %llu\n", name, wv, ev_c[e_], ev_t[e_]);
 #define DF_WAIT(...) { const unsigned long long t0_ = __builtin_readcyclecounter(); if (df_wait(__VA_ARGS__)) { ++n_wait; t_wait += __builtin_readcyclecounter() - t0_; } }
 #else
 #define DF_TIMING_DECL
 #define DF_EVENT(code, i, s)
-#define DF_MARK(k)
 #define DF_TIMING_REPORT(name)
 #define DF_WAIT(...) df_wait(__VA_ARGS__)
 #endif
@@ -918,7 +916,6 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       const unsigned char* co_row = sCo + cur * co_stride;
       const int above = ((i - 2) >> 1) * ns;  // units the sweep waves of row i-1's parity have finished before that row
       for (int s = w; s < ns; s += MAC_NP) {
-        DF_MARK(-1)  // sections: 0 waits for the row above, 1 mask + operand loads + dot product, 2 states, 3 left neighbour + chain operands, 4 post + row ends
         if (i >= 2) {
           // row i-1's chains of this strip (and, in order, of the ones left of it) are final; its operands XB(.., strip s) and
           // its mask are consumed (the chain waves and the total are done with them), and so is everything of row i-2, whose
@@ -958,7 +955,6 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           // fpow2(ScoreSS(q, t, i, j)); for column 1 the reference passes (1, j) with the stale loop variable j = t.L + 1 (:77)
           float ssf = 1.0f;
           if (h.ssm && i >= 2) ssf = j == 1 ? sstab[h.ssq[1] * h.sstw + h.sst[Lt + 1]] : sstab[h.ssq[i] * h.sstw + h.sst[jc]];
-          DF_MARK(1)
           double mm, dg, mi;
           if (i == 1) {
             mm = pf * Cshift;  // :31
@@ -988,7 +984,6 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           // the recurrences along the row (:104-109): gd = mm(j-1)*t[j-1][M2D] + gd(j-1)*t[j-1][D2D],
           //                                           im = mm(j-1)*q[i][M2I]*t[j-1][M2M] + im(j-1)*q[i][I2I]*t[j-1][M2M]
           // mm(j-1) of the strip's first column is the other wave's (the strip to the left)
-          DF_MARK(2)
           double left = 0.0;
           if (s > 0) {
             DF_WAIT(P_DONE(i, s - 1), dead);
@@ -1005,7 +1000,6 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
             XB(1, j) = b_im;
           }
         }
-        DF_MARK(3)
         if (s + MAC_NP >= ns) {
           // this wave's last strip of the row
           if (STAGE) {
