@@ -210,6 +210,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
                o_pj = carve((size_t)steps * 4), o_ps = carve((size_t)steps), o_pS = carve((size_t)steps * 4),
                o_pP = carve((size_t)steps * 4);
   const size_t path_bytes = total - o_pi;
+  const size_t o_rng = carve((size_t)n * (Lq + 2) * 8);  // active column range of every row (hhv_mac_rowrange_kernel)
   const size_t o_rows = carve((size_t)cls.n[MAC_CLASSES - 1] * 10 * (cls.max_Lt[MAC_CLASSES - 1] + 2) * 8);  // row state of the templates beyond LDS
   const bool lists = c->mac_lists;
   const size_t o_fwl = carve(lists ? (size_t)cells * 4 : 0), o_bwl = carve(lists ? (size_t)cells * 4 : 0);
@@ -325,6 +326,7 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   a.fwd_list = lists ? (float*)(base + o_fwl) : nullptr;
   a.bwd_list = lists ? (float*)(base + o_bwl) : nullptr;
   a.err = c->d_err;
+  a.row_rng = (int2*)(base + o_rng);
   ms->d_fwd_list = a.fwd_list;
   ms->d_bwd_list = a.bwd_list;
   // (the kernels write the cells the reference visits: rows 1 .. Lq [- 1], active cells; everything else reads as "no entry")

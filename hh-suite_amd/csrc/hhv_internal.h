@@ -277,6 +277,8 @@ struct MacArgs {
   float* fwd_list;
   float* bwd_list;
   uint32_t* err;             // the context's device error word (DEV_ERR_MAC_TIMEOUT), may be null
+  // [n][Lq+2] (first, last) unmasked template column of every query row (hhv_mac_rowrange_kernel), first > last = none
+  int2* row_rng;
 };
 struct MacMaskArgs {
   const int4* ends;          // [n] i1, j1, i2, j2 of the Viterbi alignment

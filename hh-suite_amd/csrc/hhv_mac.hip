@@ -1569,6 +1569,211 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
   }
 }
 
+// ---- per-row active ranges + cleared backtrace codes ----------------------------------------------------------------------
+// rng[i] = (first, last) template column of query row i whose mask byte is 0 (first > last: none), for rows 1 .. Lq of every
+// hit; the same pass clears the hit's plane of MAC backtrace codes (MAC_STOP = 0: what the reference leaves in every masked
+// cell, row 0 and column 0, src/hhmacalgorithm.cpp:48,66-70), so that hhv_mac_dp_diag_kernel only has to write inside the ranges.
+__global__ void __launch_bounds__(256) hhv_mac_rowrange_kernel(MacArgs a) {
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Lq = a.Lq, Lt = a.Lt[k], pitch = Lt + 1;
+  const unsigned char* co = a.celloff + a.mat_off[k];
+  unsigned char* bmm = a.bmm + a.mat_off[k];
+  int2* rng = a.row_rng + (size_t)k * (Lq + 2);
+  for (int i = wave; i <= Lq; i += 4) {
+    int lo = 0x7fffffff, hi = 0;
+    for (int j0 = 0; j0 <= Lt; j0 += 64) {
+      const int j = j0 + lane;
+      const bool on = i >= 1 && j >= 1 && j <= Lt && co[(size_t)i * pitch + j] == 0;
+      if (j <= Lt) bmm[(size_t)i * pitch + j] = MAC_STOP;
+      const unsigned long long m = __ballot(on);
+      if (m) {
+        lo = min(lo, j0 + (int)__builtin_ctzll(m));
+        hi = max(hi, j0 + 63 - (int)__builtin_clzll(m));
+      }
+    }
+    if (lane == 0) rng[i] = make_int2(lo, hi);
+  }
+}
+
+// ---- maximum-accuracy DP along anti-diagonals ----------------------------------------------------------------------------------
+// src/hhmacalgorithm.cpp:53-156.  Unlike forward / backward this recurrence has no per-row rescaling, so nothing forces rows
+// to be finished one after the other: the 64 lanes of the wavefront take 64 CONSECUTIVE QUERY ROWS (a strip) and walk along the
+// template, lane l one column behind lane l-1.  In step t lane l evaluates cell (i0 + 1 + l, jlo + t - l) from
+//   up   = S(i-1, j)    the value lane l-1 produced in the step before (one DPP move; lane 0: the last row of the strip above, Sb)
+//   diag = S(i-1, j-1)  the `up` of the step before
+//   left = S(i, j-1)    its own value of the step before
+// with the reference's float expressions and comparisons, literally (NaN posteriors included).  A strip costs Wd + 63 steps of
+// some fifty instructions instead of Lt/64 sweeps of up to 64 dependent steps per row (hhv_mac_dp_kernel above).
+// [jlo, jhi] = hull of the active ranges of the strip's rows (hhv_mac_rowrange_kernel): cells outside are masked in all 64
+// rows (S = -FLT_MIN, code STOP - already in the plane) and are not visited at all - a 300 x 1800 hit whose band is 200 wide
+// costs 5 x 263 steps.
+// Memory: a lane's cell is in another row AND column than its neighbour's, so posteriors / mask bytes / codes go through LDS
+// tiles [64 rows][2 x 64 columns]: row r of a column block is fetched by all lanes with one coalesced load (64 steps before lane
+// r gets there, parked in LDS eight steps later), every lane reads its own row at its own column (row pitch - 1 odd: no bank
+// conflict), codes take the way back, one coalesced row per step.  Sb: S of the last row of the strip above, per column.
+constexpr int DPD_PITCH = 130;   // floats per row of the posterior tile
+constexpr int DPD_BPITCH = 132;  // bytes per row of the mask and code tiles
+constexpr int DPD_AHEAD = 8;     // steps between a row's global load and its store into the tile (the loop is unrolled by it)
+constexpr size_t DPD_TILES = (size_t)64 * DPD_PITCH * sizeof(float) + (size_t)2 * 64 * DPD_BPITCH;
+template <bool LOCAL, bool GROWS>
+__global__ void __launch_bounds__(64) hhv_mac_dp_diag_kernel(MacArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* PT = reinterpret_cast<float*>(smem);
+  unsigned char* CO = smem + (size_t)64 * DPD_PITCH * sizeof(float);
+  unsigned char* CD = CO + (size_t)64 * DPD_BPITCH;
+  float* Sb = GROWS ? reinterpret_cast<float*>(a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2))
+                    : reinterpret_cast<float*>(smem + DPD_TILES);  // [Lt + 2]
+  const int k = a.sel[blockIdx.x], lane = threadIdx.x;
+  const HitView h = view(a, k);
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch;
+  const int2* rng = a.row_rng + (size_t)k * (Lq + 2);
+  const float mact = a.mact;
+  const float half_f = (float)(0.5 * (double)mact);  // exact (the launcher sends other values of mact to hhv_mac_dp_kernel)
+  for (int e = lane; e <= Lt + 1; e += 64) Sb[e] = 0.0f;  // row 0 (:44-45)
+  float best = -FLT_MAX;
+  int best_i = 0, best_j = 0;
+  for (int i0 = 0; i0 < Lq; i0 += 64) {
+    const int nr = min(64, Lq - i0);
+    const int my_i = i0 + 1 + lane;
+    const bool has_row = lane < nr;
+    int lo = 0x7fffffff, hi = 0;
+    if (has_row) {
+      const int2 r = rng[my_i];
+      lo = r.x;
+      hi = r.y;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, 64));
+      hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    const int jlo = __builtin_amdgcn_readfirstlane(lo), jhi = __builtin_amdgcn_readfirstlane(hi);
+    const bool none = jlo > jhi;  // no active cell in the whole strip
+    const int Wd = none ? 0 : jhi - jlo + 1;
+    __syncthreads();  // (GROWS: Sb is global memory, written and read by this one wavefront)
+    // S(i0, jlo - 1) for lane 0, before this strip's last row takes the place of the one above
+    const float diag0 = none ? 0.0f : Sb[jlo - 1];
+    __syncthreads();
+    for (int j = 1 + lane; j <= Lt; j += 64)
+      if (none || j < jlo || j > jhi) Sb[j] = -FLT_MIN;  // the last row of THIS strip outside the hull: masked cells (:66-67)
+    if (!none) {
+      const float v0 = jlo == 1 ? 0.0f : -FLT_MIN;  // S(i, jlo - 1): column 0 (:58) or a masked cell
+      float S = v0, diag = lane == 0 ? diag0 : v0, sbv = 0.0f;
+      const int Wd_l = has_row ? Wd : 0;
+      const int cl = (Wd - 1) >> 6;
+      const int t_end = 64 * cl + 128;  // exclusive; t_end + 64 steps, a multiple of DPD_AHEAD
+      const size_t row0 = (size_t)(i0 + 1) * pitch + jlo;
+      const int my_tile = lane * DPD_PITCH, my_btile = lane * DPD_BPITCH;
+      float qp[DPD_AHEAD];
+      unsigned char qc[DPD_AHEAD];
+#pragma unroll
+      for (int e = 0; e < DPD_AHEAD; ++e) qp[e] = 0.0f, qc[e] = 1;
+      for (int tb = -64; tb < t_end; tb += DPD_AHEAD) {
+#pragma unroll
+        for (int e = 0; e < DPD_AHEAD; ++e) {
+          const int t = tb + e;
+          const bool in_dp = t >= 0 && t < Wd + 63;
+          const int x = t - lane, xi = x & 127;
+          float p = 0.0f;
+          bool off = true;
+          if (in_dp) {  // this step's posterior and mask byte (parked at least 56 steps ago): issued first, used last
+            p = PT[my_tile + xi];
+            off = CO[my_btile + xi] != 0;
+            if ((t & 63) == 0) sbv = Sb[min(jlo + t + lane, Lt)];  // the row above, 64 columns at a time
+          }
+          {  // park the row fetched DPD_AHEAD steps ago
+            const int u = t + 64 - DPD_AHEAD;
+            if (u >= 0) {
+              const int r = u & 63, c = u >> 6, slot = (c & 1) * 64;
+              PT[r * DPD_PITCH + slot + lane] = qp[e];
+              CO[r * DPD_BPITCH + slot + lane] = (c * 64 + lane < Wd) ? qc[e] : (unsigned char)1;
+            }
+          }
+          {  // fetch row r of column block c: 64 steps before lane r starts on it
+            const int u = t + 64;
+            const int r = u & 63, c = u >> 6, xg = c * 64 + lane;
+            if (c <= cl && r < nr) {
+              const size_t idx = row0 + (size_t)r * pitch + (xg < Wd ? xg : 0);
+              qp[e] = h.mat[idx];
+              qc[e] = h.co[idx];
+            }
+          }
+          if (t >= 64) {  // codes of row rf, column block cf: complete since the step before
+            const int rf = t & 63, cf = (t >> 6) - 1, xg = cf * 64 + lane;
+            if (rf < nr && xg < Wd) h.bmm[row0 + (size_t)rf * pitch + xg] = CD[rf * DPD_BPITCH + (cf & 1) * 64 + lane];
+          }
+          if (in_dp) {
+            const bool active = (unsigned)x < (unsigned)Wd_l;
+            const float sb_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbv), t & 63));
+            const float up = shr1_f(S, sb_t);
+            const float term1 = p - mact;            // :76
+            const float term2 = (diag + p) - mact;   // :78
+            const float term3 = up - half_f;         // :79 (a float difference rounded once, see hhv_mac_dp_kernel)
+            const float term4 = S - half_f;          // :80
+            float mx;
+            int code;
+            if (term1 > term2) {
+              mx = term1;
+              code = MAC_STOP;
+            } else {
+              mx = term2;
+              code = MAC_MM;
+            }
+            if (term3 > mx) {
+              mx = term3;
+              code = MAC_MI;
+            }
+            if (term4 > mx) {
+              mx = term4;
+              code = MAC_IM;
+            }
+            if (off) {
+              mx = -FLT_MIN;
+              code = MAC_STOP;
+            }
+            diag = up;
+            if (active) {
+              S = mx;
+              CD[my_btile + xi] = (unsigned char)code;
+              const int j = jlo + x;
+              // :123-126 inside the row, :146-151 the last column of a global alignment (whatever its mask byte says)
+              const bool cand = LOCAL ? !off : ((my_i == Lq && !off) || j == Lt);
+              if (cand && mx > best) {
+                best = mx;
+                best_i = my_i;
+                best_j = j;
+              }
+              if (lane == 63) Sb[j] = mx;
+            }
+          }
+        }
+      }
+    }
+    if (!LOCAL && has_row && (none || jhi < Lt)) {
+      // global alignment: S(i, Lt) of a row whose last column lies outside the hull is -FLT_MIN (:146-151)
+      if (-FLT_MIN > best) {
+        best = -FLT_MIN;
+        best_i = my_i;
+        best_j = Lt;
+      }
+    }
+  }
+  // first maximum in the reference's visiting order: largest value, then smallest (i, j) (see hhv_mac_dp_kernel)
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64), oj = __shfl_xor(best_j, o, 64);
+    const bool take = ov > best || (ov == best && (oi < best_i || (oi == best_i && oj < best_j)));
+    if (take) {
+      best = ov;
+      best_i = oi;
+      best_j = oj;
+    }
+  }
+  if (lane == 0) {
+    a.hits[k].i2 = best_i;
+    a.hits[k].j2 = best_j;
+  }
+}
+
 // ---- MAC backtrace: one wavefront per hit --------------------------------------------------------------------------------
 // The walk itself is a pointer chase (src/hhbacktracemac.cpp:126-160) and every step used to cost one dependent trip to
 // L2 / HBM for a single code byte.  Now the wave fetches the 8 x 8 block of codes above-left of the current cell with one
@@ -1793,6 +1998,21 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
     launch_mac_rows<LOCAL, false, false>(a, n, df ? mac_rows_lds(max_Lt, false) : mac_rows_lds_single(max_Lt), stream, df);
   }
   else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
+  // maximum-accuracy DP: along anti-diagonals (hhv_mac_dp_diag_kernel) unless 0.5 * mact is not a float (its chain steps are
+  // float subtractions) or HHV_MAC_DP_ROWS asks for the row-by-row kernel (measurement aid)
+  static const bool dp_rows = getenv("HHV_MAC_DP_ROWS") != nullptr;
+  const double half = 0.5 * (double)a.mact;
+  if (!dp_rows && (double)(float)half == half) {
+    const size_t lds_diag = DPD_TILES + (size_t)(max_Lt + 2) * sizeof(float);
+    if (cls <= 5 && lds_diag <= MAC_LDS_LIMIT) {
+      (void)hipFuncSetAttribute((const void*)hhv_mac_dp_diag_kernel<LOCAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+      hipLaunchKernelGGL((hhv_mac_dp_diag_kernel<LOCAL, false>), dim3(n), dim3(64), lds_diag, stream, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)hhv_mac_dp_diag_kernel<LOCAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DPD_TILES);
+      hipLaunchKernelGGL((hhv_mac_dp_diag_kernel<LOCAL, true>), dim3(n), dim3(64), DPD_TILES, stream, a);
+    }
+    return;
+  }
   const size_t lds_dp = (size_t)2 * (max_Lt + 2) * sizeof(float);
   if (lds_dp > MAC_LDS_LIMIT) {
     hipLaunchKernelGGL((hhv_mac_dp_kernel<LOCAL, true, 4>), dim3(n), dim3(64), 0, stream, a);  // (class 6 only: row_scratch is there)
@@ -1838,6 +2058,8 @@ int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* strea
   int first = 0, non_empty = 0;
   for (int c = 0; c < MAC_CLASSES; ++c) non_empty += cls.n[c] > 0;
   const bool fork = side && non_empty > 1;
+  // active column range of every row + cleared code planes: ahead of all classes
+  hipLaunchKernelGGL(hhv_mac_rowrange_kernel, dim3(a0.n), dim3(256), 0, stream, a0);
   if (fork) (void)hipEventRecord((hipEvent_t)side->fork, stream);  // everything queued so far: inputs, masks
   bool main_used = false;
   bool joined[MAC_CLASSES] = {};

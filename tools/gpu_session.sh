@@ -102,6 +102,16 @@ macprof)   # kernel statistics of the MAC kernels: the wavefront pipeline and th
     f=$(find $OUT/prof_mac_$m -name "*kernel_stats.csv" | head -1); echo "== $m"; head -9 "$f" | cut -d, -f1-7; cp "$f" $OUT/mac_${m}_kernel_stats.csv; rm -rf $OUT/prof_mac_$m
   done
   ;;
+macprofx)   # macprofx "<n Lq Lt>" ...: rocprofv3 kernel statistics of tools/bench_mac.py for each shape given (dataflow kernels only)
+  cd /tmp && export TMPDIR=/tmp
+  i=0
+  for shape in "$@"; do
+    i=$((i+1)); tag=$(echo $shape | tr ' ' '_')
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_macx_$i -o stats -- python $ROOT/tools/bench_mac.py $shape 0 > $OUT/prof_macx_$tag.txt 2>&1
+    f=$(find $OUT/prof_macx_$i -name "*kernel_stats.csv" | head -1); echo "== $shape"; head -12 "$f" | cut -d, -f1-7; cp "$f" $OUT/macx_${tag}_kernel_stats.csv; rm -rf $OUT/prof_macx_$i
+    tail -1 $OUT/prof_macx_$tag.txt | cut -c1-400
+  done
+  ;;
 r5p)   # the round's profiles: headline, backtrace, secondary structure (hhv_ss_kernel), and the kernel statistics of a 10 k backtrace search
   for spec in "r5|" "r5bt|--backtrace 1" "r5ss|--ss 4" "r5ssbt|--ss 4 --backtrace 1"; do
     tag=${spec%%|*}; extra=${spec#*|}
