@@ -4,6 +4,7 @@
 // There is deliberately no CPU compute path here: every entry point that needs arithmetic launches a HIP kernel and
 // fails with HHV_E_DEVICE when no device is usable.
 #include "hhv_api_common.h"
+#include <stdlib.h>
 
 #include <atomic>
 #include <thread>
@@ -175,6 +176,12 @@ int hhv_shard_plan(int32_t n, const int32_t* L, int32_t n_shards, int32_t* shard
 int hhv_create(hhv_ctx** out, const hhv_params* par) {
   if (!out || !par) return fail(HHV_E_ARG, "hhv_create: null argument");
   *out = nullptr;
+  // The MAC realignment runs its template-length classes side by side in MAC_CHAINS streams (hhv_mac.hip launch_mac).  The HIP
+  // runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share one run one after the other:
+  // 500 hits of mixed lengths 9.2 ms with eight queues, 12.7 ms with four (tools/SESSIONS.md round 6).  The runtime reads the
+  // variable when it initialises, so this has an effect only in a process whose first HIP call is this one (the drop-in
+  // applications); hosts that initialise HIP earlier export it themselves (pyhhv/capi.py does).  An explicit setting is respected.
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)

@@ -1,6 +1,7 @@
 // hhv_api_mac.cpp -- C ABI of the MAC realignment.
 #include "hhv_api_common.h"
 
+#include <algorithm>
 #include <cmath>
 
 using namespace hhv;
@@ -114,6 +115,13 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
     int at[MAC_CLASSES] = {};
     for (int cl = 1; cl < MAC_CLASSES; ++cl) at[cl] = at[cl - 1] + cls.n[cl - 1];
     for (int k = 0; k < n; ++k) sel[(size_t)at[cls_of[k]]++] = k;
+    // inside a class the longest templates first: workgroups start in this order, and a hit takes a time that grows with its
+    // template - the last workgroups to find a CU should be the short ones (longest-processing-time-first)
+    int first = 0;
+    for (int cl = 0; cl < MAC_CLASSES; ++cl) {
+      std::stable_sort(sel.begin() + first, sel.begin() + first + cls.n[cl], [&](int32_t x, int32_t y) { return Lt[x] > Lt[y]; });
+      first += cls.n[cl];
+    }
   }
   const bool with_ss = c->mac_ss_pending;
   c->mac_ss_pending = false;  // one call only
@@ -360,11 +368,13 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
       m.res_i = any_resident ? mi->ts->d_i_steps : nullptr;
       m.res_j = any_resident ? mi->ts->d_j_steps : nullptr;
       lr = launch_mac_mask(a, m, st);
+    } else {
+      lr = launch_mac_rowrange(a, st);
     }
-    if (!c->mac_side_ready) {  // side streams of the length classes; without them the classes simply run one after the other
+    if (!c->mac_side_ready) {  // the streams the length classes are spread over; without them the classes simply run one after the other
       c->mac_side_ready = true;
       bool ok = hipEventCreateWithFlags((hipEvent_t*)&c->mac_side.fork, hipEventDisableTiming) == hipSuccess;
-      for (int k = 1; k < MAC_CLASSES && ok; ++k)
+      for (int k = 0; k < MAC_CLASSES && ok; ++k)  // (created one after the other: the runtime hands out its hardware queues round-robin)
         ok = hipStreamCreateWithFlags((hipStream_t*)&c->mac_side.s[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags((hipEvent_t*)&c->mac_side.join[k], hipEventDisableTiming) == hipSuccess;
       if (!ok)

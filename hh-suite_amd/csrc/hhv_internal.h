@@ -297,19 +297,21 @@ struct MacMaskArgs {
   const int32_t* ranges;     // n_qranges query row ranges, then n_tranges template column ranges, (lo, hi) pairs
   int32_t n_qranges, n_tranges;
 };
-int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream);
+int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream);  // + MacArgs::row_rng
+int launch_mac_rowrange(const MacArgs& a, void* stream);                     // MacArgs::row_rng of masks handed over by the host
 // Length classes of a batch of hits.  A lone wave per hit keeps its row state (and, if it fits, the template) in LDS, and the
 // LDS footprint of a launch is that of its longest template; one long template must not take the occupancy of the other
 // hits nor set their limits, so the hits are launched class by class, every class on a stream of its own (they overlap):
 //   0..3  template + row state + prefetch rows in LDS: up to 128 / 256 / 384 / ~800 columns (5 / 3 / 2 / 1 workgroups per CU)
-//   4, 5  row state in LDS, template operands from global memory: up to 1022 / 2046 columns
+//   4, 5  row state in LDS, template operands from global memory: up to 1022 / ~1450 columns (the dataflow kernels' LDS layout)
 //   6     row state in global memory too (any length)
 constexpr int MAC_CLASSES = 7;
 struct MacClasses {
   int n[MAC_CLASSES];       // hits per class; MacArgs::sel lists class 0 first, then 1, ...
   int max_Lt[MAC_CLASSES];  // longest template per class
 };
-// side streams of the class launches: s[c] for class c (null = the caller's stream), fork / join events
+// streams the class launches are spread over (launch_mac): s[0 .. MAC_CHAINS-1], fork / join events
+constexpr int MAC_CHAINS = 4;
 struct MacStreams {
   void* s[MAC_CLASSES];
   void* fork;

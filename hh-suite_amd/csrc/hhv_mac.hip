@@ -134,6 +134,15 @@ __device__ __forceinline__ HitView view(const MacArgs& a, int k) {
   return v;
 }
 
+// rows' active ranges (MacArgs::row_rng): does the strip of columns c_lo .. c_hi of a row with range r hold an active cell at all?
+// The kernels that fetch mask bytes (and F_MM) from global memory strip by strip ask this first: a strip outside the range is
+// masked without a trip to L2 - in a long template most strips of a row are (300 x 1800: 26 of 29).
+__device__ __forceinline__ bool rng_hits(int2 r, int c_lo, int c_hi) { return c_lo <= r.y && c_hi >= r.x; }
+__device__ __forceinline__ int2 rng_row(const MacArgs& a, int k, int i) {
+  const int2* p = a.row_rng + (size_t)k * (a.Lq + 2);
+  return p[i < 1 ? 1 : (i > a.Lq ? a.Lq : i)];
+}
+
 // Template operands of column j: from the LDS copy made at kernel start (STAGE; one hit's template is read Lq times and a
 // lone wave per SIMD cannot hide a trip to L2 per strip), or from global memory when the template does not fit.
 template <bool STAGE>
@@ -218,7 +227,8 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   }
   __syncthreads();
   // !STAGE: the cell-off byte of the next strip is fetched while the current one is swept (also across the row boundary)
-  unsigned char co_next = (!STAGE && 1 + lane <= Lt) ? h.co[(size_t)pitch + 1 + lane] : 1;
+  int2 rr_cur = rng_row(a, k, 1), rr_nxt = rr_cur;  // active ranges of rows i and i + 1 (!STAGE)
+  unsigned char co_next = (!STAGE && 1 + lane <= Lt && rng_hits(rr_cur, 1, 64)) ? h.co[(size_t)pitch + 1 + lane] : 1;
   int cur = 0;
   double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0;
   double Pf = LOCAL ? 1.0 : 0.0;
@@ -239,6 +249,10 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     const double qM2M = qt1[T_M2M], qI2M = qt1[T_I2M], qD2M = qt1[T_D2M], qM2D = qt1[T_M2D], qD2D = qt1[T_D2D];
     const double qM2I = qt[T_M2I], qI2I = qt[T_I2I];
     double Pmax = 0.0, carry_mm = 0.0, carry_gd = 0.0, carry_im = 0.0;
+    if (!STAGE) {
+      rr_cur = rr_nxt;
+      rr_nxt = rng_row(a, k, i + 1);
+    }
     unsigned char pre_co[MAC_PRE];
     if (STAGE) {
 #pragma unroll
@@ -256,7 +270,8 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       if (!STAGE) {
         const bool last = s0 + 64 >= Lt;
         const int ni = last ? i + 1 : i, nj = last ? 1 + lane : j + 64;
-        co_next = (ni <= Lq && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
+        const bool live = rng_hits(last ? rr_nxt : rr_cur, nj - lane, nj - lane + 63);
+        co_next = (ni <= Lq && nj <= Lt && live) ? h.co[(size_t)ni * pitch + nj] : 1;
       }
       const unsigned long long on_mask = __ballot(!off);
       if (on_mask == 0) {
@@ -467,6 +482,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
   unsigned char co_nx = 1;  // mask byte and F_MM of the next strip, fetched while the current one is swept
   float f_nx = 0.0f;
+  int2 rr_row = make_int2(1, 0), rr_nxt = rng_row(a, k, Lq - 1);
   for (int i = Lq - 1; i >= 1; --i) {
     const int prv = cur ^ 1;
     const double sc = h.scale[i + 1];
@@ -490,9 +506,13 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       }
     } else {
       // what the first strip of this row reads from HBM (mask byte, F_MM) and, lane 0, column Lt - issued together
+      // (a strip outside the row's active range: masked, and F_MM is the 0 the forward pass left there)
+      rr_row = rr_nxt;
+      rr_nxt = rng_row(a, k, i - 1);  // (a row ahead: a scalar load at the start of every row would be waited for)
       const int j0 = Lt - 1 - lane;
-      co_nx = j0 >= 1 ? corow[j0] : 1;
-      f_nx = j0 >= 1 ? row[j0] : 0.0f;
+      const bool live = rng_hits(rr_row, Lt - 64, Lt - 1);
+      co_nx = (j0 >= 1 && live) ? corow[j0] : 1;
+      f_nx = (j0 >= 1 && live) ? row[j0] : 0.0f;
     }
     // column Lt (:58-71)
     if (lane == 0) {
@@ -520,8 +540,9 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       const float f_cur = STAGE ? (valid ? f_l[jc] : 0.0f) : f_nx;
       if (!STAGE && s0 + 64 < Lt - 1) {
         const int jn = j - 64;
-        co_nx = jn >= 1 ? corow[jn] : 1;
-        f_nx = jn >= 1 ? row[jn] : 0.0f;
+        const bool live = rng_hits(rr_row, jn + lane - 63, jn + lane);
+        co_nx = (jn >= 1 && live) ? corow[jn] : 1;
+        f_nx = (jn >= 1 && live) ? row[jn] : 0.0f;
       }
       const unsigned long long on_mask = __ballot(!off);
       if (on_mask == 0) {
@@ -851,7 +872,8 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
     // ---- P: wave w works on strips w, w + MAC_NP, .. of every row ----
     const int w = wv, o1 = (w + 1) % MAC_NP, o2 = (w + 2) % MAC_NP, o3 = (w + 3) % MAC_NP;
     static_assert(MAC_NP >= 2 && MAC_NP <= 4, "the row-end wait names three waves (with fewer than four, some of them twice or this wave itself)");
-    unsigned char co_next = (!STAGE && w < ns && 1 + (w << 6) + lane <= Lt) ? h.co[(size_t)pitch + 1 + (w << 6) + lane] : 1;
+    int2 rr_cur = rng_row(a, k, 1), rr_nxt = rr_cur;  // active ranges of rows i and i + 1 (!STAGE)
+    unsigned char co_next = (!STAGE && w < ns && 1 + (w << 6) + lane <= Lt && rng_hits(rr_cur, 1 + (w << 6), 64 + (w << 6))) ? h.co[(size_t)pitch + 1 + (w << 6) + lane] : 1;
     double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0, scale_i = 1.0;
     int own = 0;
     // lanes 0-19: q.p[i], 20-24: q.tr[i-1][M2M, I2M, D2M, M2D, D2D], 25: q.tr[i][M2I]
@@ -892,6 +914,10 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           scale_prod *= scale_i;
       }
       DF_EVENT(7, i, 8)
+      if (!STAGE) {
+        rr_cur = rr_nxt;
+        rr_nxt = rng_row(a, k, i + 1);
+      }
       const float q_cur = q_next;
       q_next = qrow(i + 1);
       float qi[20];
@@ -932,7 +958,8 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           // this wave's next unit: MAC_NP strips on, or its first strip of the next row
           const bool last = s + MAC_NP >= ns;
           const int ni = last ? i + 1 : i, nj = last ? 1 + (w << 6) + lane : j + 64 * MAC_NP;
-          co_next = (ni <= Lq && (!last || w < ns) && nj <= Lt) ? h.co[(size_t)ni * pitch + nj] : 1;
+          const bool live = rng_hits(last ? rr_nxt : rr_cur, nj - lane, nj - lane + 63);
+          co_next = (ni <= Lq && (!last || w < ns) && nj <= Lt && live) ? h.co[(size_t)ni * pitch + nj] : 1;
         }
         const unsigned long long on_mask = __ballot(!off);
         if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
@@ -1179,7 +1206,9 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
     const int w = wv;
     double pmin = LOCAL ? sL : 0.0;
     double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;  // scale[i+1] of the row, fetched a row ahead
-    unsigned char co_nx = (!STAGE && Lq >= 2 && w < ns && Lt - 1 - (w << 6) - lane >= 1) ? h.co[(size_t)(Lq - 1) * pitch + Lt - 1 - (w << 6) - lane] : 1;
+    int2 rr_cur = rng_row(a, k, Lq - 1), rr_nxt = rr_cur;  // active ranges of rows i and i - 1 (!STAGE)
+    unsigned char co_nx = (!STAGE && Lq >= 2 && w < ns && Lt - 1 - (w << 6) - lane >= 1 && rng_hits(rr_cur, Lt - 64 - (w << 6), Lt - 1 - (w << 6)))
+                              ? h.co[(size_t)(Lq - 1) * pitch + Lt - 1 - (w << 6) - lane] : 1;
     int own = 0;
     // lanes 0-19: q.p[i+1], 20-25: q.tr[i][M2M, M2D, I2M, D2M, D2D, M2I]
     auto qrow = [&](int i) -> float {
@@ -1195,6 +1224,10 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       sc_next = i >= 2 ? h.scale[i] : 1.0;
       pmin *= sc;
       if (pmin < DBL_MIN * 100) pmin = 0.0;
+      if (!STAGE) {
+        rr_cur = rr_nxt;
+        rr_nxt = rng_row(a, k, i - 1);
+      }
       const float q_cur = q_next;
       q_next = qrow(i - 1);
       float qn[20];
@@ -1246,7 +1279,8 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
           // the next unit of this wave: MAC_NP strips on, or its first strip of row i - 1
           const bool last = s + MAC_NP >= ns;
           const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (w << 6) - lane : j - 64 * MAC_NP;
-          co_nx = (ni >= 1 && nj >= 1) ? h.co[(size_t)ni * pitch + nj] : 1;
+          const bool live = rng_hits(last ? rr_nxt : rr_cur, nj + lane - 63, nj + lane);
+          co_nx = (ni >= 1 && nj >= 1 && live) ? h.co[(size_t)ni * pitch + nj] : 1;
         }
         const unsigned long long on_mask = __ballot(!off);
         if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
@@ -1357,12 +1391,18 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       }
     }
     float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
-    float f_nx = (!STAGE && Lq >= 2 && v < ns && Lt - 1 - (v << 6) - lane >= 1) ? h.mat[(size_t)(Lq - 1) * pitch + Lt - 1 - (v << 6) - lane] : 0.0f;
+    int2 rr_cur = rng_row(a, k, Lq - 1), rr_nxt = rr_cur;  // (!STAGE) F_MM of a strip outside its row's active range: the 0 the forward pass left
+    float f_nx = (!STAGE && Lq >= 2 && v < ns && Lt - 1 - (v << 6) - lane >= 1 && rng_hits(rr_cur, Lt - 64 - (v << 6), Lt - 1 - (v << 6)))
+                     ? h.mat[(size_t)(Lq - 1) * pitch + Lt - 1 - (v << 6) - lane] : 0.0f;
     int own = 0;
     // (a wave with units has one in every row - strip v - so its scale_prod sees every row's factor)
     for (int i = Lq - 1; i >= 1 && v < ns; --i) {
       const int cur = i & 1;
       double qM2I = 0.0;
+      if (!STAGE) {
+        rr_cur = rr_nxt;
+        rr_nxt = rng_row(a, k, i - 1);
+      }
       float* row = h.mat + (size_t)i * pitch;
       const float* f_l = sF + cur * co_stride;  // STAGE: F_MM of the row, staged by the P waves
       for (int s = v; s < ns; s += 2) {
@@ -1395,7 +1435,8 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
         if (!STAGE) {
           const bool last = s + 2 >= ns;
           const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (v << 6) - lane : j - 128;
-          f_nx = (ni >= 1 && nj >= 1) ? h.mat[(size_t)ni * pitch + nj] : 0.0f;
+          const bool live = rng_hits(last ? rr_nxt : rr_cur, nj + lane - 63, nj + lane);
+          f_nx = (ni >= 1 && nj >= 1 && live) ? h.mat[(size_t)ni * pitch + nj] : 0.0f;
         }
         const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
         const bool off = !((on_mask >> lane) & 1);
@@ -1569,23 +1610,22 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_kernel(MacArgs a) {
   }
 }
 
-// ---- per-row active ranges + cleared backtrace codes ----------------------------------------------------------------------
-// rng[i] = (first, last) template column of query row i whose mask byte is 0 (first > last: none), for rows 1 .. Lq of every
-// hit; the same pass clears the hit's plane of MAC backtrace codes (MAC_STOP = 0: what the reference leaves in every masked
-// cell, row 0 and column 0, src/hhmacalgorithm.cpp:48,66-70), so that hhv_mac_dp_diag_kernel only has to write inside the ranges.
+// ---- per-row active ranges ---------------------------------------------------------------------------------------------------
+// rng[i] = (first, last) template column of query row i whose mask byte is 0 (first > last: none), rows 1 .. Lq of every hit.
+// hhv_mac_dp_diag_kernel visits only the hull of the ranges of its 64 rows, and the MAC backtrace takes cells outside their row's
+// range as STOP (what the reference leaves in every masked cell, src/hhmacalgorithm.cpp:66-70) without reading the code plane.
+// Any SUPERSET of the active cells will do (the kernels still read the mask bytes inside it): masks built on the device get
+// theirs from the geometry (hhv_mac_mask_kernel), this kernel scans masks handed over by the host.
 __global__ void __launch_bounds__(256) hhv_mac_rowrange_kernel(MacArgs a) {
   const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Lq = a.Lq, Lt = a.Lt[k], pitch = Lt + 1;
   const unsigned char* co = a.celloff + a.mat_off[k];
-  unsigned char* bmm = a.bmm + a.mat_off[k];
   int2* rng = a.row_rng + (size_t)k * (Lq + 2);
   for (int i = wave; i <= Lq; i += 4) {
     int lo = 0x7fffffff, hi = 0;
-    for (int j0 = 0; j0 <= Lt; j0 += 64) {
+    for (int j0 = 1; j0 <= Lt && i >= 1; j0 += 64) {
       const int j = j0 + lane;
-      const bool on = i >= 1 && j >= 1 && j <= Lt && co[(size_t)i * pitch + j] == 0;
-      if (j <= Lt) bmm[(size_t)i * pitch + j] = MAC_STOP;
-      const unsigned long long m = __ballot(on);
+      const unsigned long long m = __ballot(j <= Lt && co[(size_t)i * pitch + j] == 0);
       if (m) {
         lo = min(lo, j0 + (int)__builtin_ctzll(m));
         hi = max(hi, j0 + 63 - (int)__builtin_clzll(m));
@@ -1608,10 +1648,11 @@ __global__ void __launch_bounds__(256) hhv_mac_rowrange_kernel(MacArgs a) {
 // rows (S = -FLT_MIN, code STOP - already in the plane) and are not visited at all - a 300 x 1800 hit whose band is 200 wide
 // costs 5 x 263 steps.
 // Memory: a lane's cell is in another row AND column than its neighbour's, so posteriors / mask bytes / codes go through LDS
-// tiles [64 rows][2 x 64 columns]: row r of a column block is fetched by all lanes with one coalesced load (64 steps before lane
-// r gets there, parked in LDS eight steps later), every lane reads its own row at its own column (row pitch - 1 odd: no bank
-// conflict), codes take the way back, one coalesced row per step.  Sb: S of the last row of the strip above, per column.
-constexpr int DPD_PITCH = 130;   // floats per row of the posterior tile
+// tiles [64 rows][2 x 64 columns]: every fourth step FOUR rows of a column block are fetched by one load (16 lanes a row, 16
+// bytes of posteriors / 4 mask bytes a lane, 64 steps before their lanes get there), parked in LDS eight steps later; every lane
+// reads its own row at its own column (row pitch - 1 odd: no bank conflict); codes take the way back, four rows per store.
+// Sb: S of the last row of the strip above, per column.
+constexpr int DPD_PITCH = 132;   // floats per row of the posterior tile (rows 16-byte aligned)
 constexpr int DPD_BPITCH = 132;  // bytes per row of the mask and code tiles
 constexpr int DPD_AHEAD = 8;     // steps between a row's global load and its store into the tile (the loop is unrolled by it)
 constexpr size_t DPD_TILES = (size_t)64 * DPD_PITCH * sizeof(float) + (size_t)2 * 64 * DPD_BPITCH;
@@ -1660,13 +1701,14 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_diag_kernel(MacArgs a) {
       float S = v0, diag = lane == 0 ? diag0 : v0, sbv = 0.0f;
       const int Wd_l = has_row ? Wd : 0;
       const int cl = (Wd - 1) >> 6;
-      const int t_end = 64 * cl + 128;  // exclusive; t_end + 64 steps, a multiple of DPD_AHEAD
+      const int t_end = 64 * cl + 136;  // exclusive (the last codes leave at step 64 cl + 128); t_end + 64: a multiple of DPD_AHEAD
       const size_t row0 = (size_t)(i0 + 1) * pitch + jlo;
       const int my_tile = lane * DPD_PITCH, my_btile = lane * DPD_BPITCH;
-      float qp[DPD_AHEAD];
-      unsigned char qc[DPD_AHEAD];
+      const int g_row = lane >> 4, g_q4 = (lane & 15) * 4;  // a group of four rows: 16 lanes a row, four columns a lane
+      float4 qp[DPD_AHEAD / 4];
+      uint32_t qc[DPD_AHEAD / 4];
 #pragma unroll
-      for (int e = 0; e < DPD_AHEAD; ++e) qp[e] = 0.0f, qc[e] = 1;
+      for (int e = 0; e < DPD_AHEAD / 4; ++e) qp[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f), qc[e] = 0x01010101u;
       for (int tb = -64; tb < t_end; tb += DPD_AHEAD) {
 #pragma unroll
         for (int e = 0; e < DPD_AHEAD; ++e) {
@@ -1680,26 +1722,41 @@ __global__ void __launch_bounds__(64) hhv_mac_dp_diag_kernel(MacArgs a) {
             off = CO[my_btile + xi] != 0;
             if ((t & 63) == 0) sbv = Sb[min(jlo + t + lane, Lt)];  // the row above, 64 columns at a time
           }
-          {  // park the row fetched DPD_AHEAD steps ago
-            const int u = t + 64 - DPD_AHEAD;
-            if (u >= 0) {
-              const int r = u & 63, c = u >> 6, slot = (c & 1) * 64;
-              PT[r * DPD_PITCH + slot + lane] = qp[e];
-              CO[r * DPD_BPITCH + slot + lane] = (c * 64 + lane < Wd) ? qc[e] : (unsigned char)1;
+          if ((e & 3) == 0) {
+            constexpr int G = 0;
+            const int g = (e >> 2) + G;
+            {  // park the four rows fetched DPD_AHEAD steps ago
+              const int u = t + 64 - DPD_AHEAD;
+              if (u >= 0) {
+                const int r = (u & 63) + g_row, c = u >> 6, slot = (c & 1) * 64;
+                *reinterpret_cast<float4*>(&PT[r * DPD_PITCH + slot + g_q4]) = qp[g];
+                const int nv = Wd - (c * 64 + g_q4);  // columns of this lane inside the hull; the others read as masked
+                const uint32_t beyond = nv >= 4 ? 0u : (nv <= 0 ? 0x01010101u : 0x01010101u << (8 * nv));
+                *reinterpret_cast<uint32_t*>(&CO[r * DPD_BPITCH + slot + g_q4]) = qc[g] | beyond;
+              }
             }
-          }
-          {  // fetch row r of column block c: 64 steps before lane r starts on it
-            const int u = t + 64;
-            const int r = u & 63, c = u >> 6, xg = c * 64 + lane;
-            if (c <= cl && r < nr) {
-              const size_t idx = row0 + (size_t)r * pitch + (xg < Wd ? xg : 0);
-              qp[e] = h.mat[idx];
-              qc[e] = h.co[idx];
+            {  // fetch rows r .. r+3 of column block c: 64 steps before lane r starts on it
+              const int u = t + 64;
+              const int r = (u & 63) + g_row, c = u >> 6;
+              if (c <= cl && r < nr) {
+                const size_t idx = row0 + (size_t)r * pitch + c * 64 + g_q4;
+                __builtin_memcpy(&qp[g], h.mat + idx, 16);  // (rows start at any multiple of four bytes: dwordx4 needs no more)
+                __builtin_memcpy(&qc[g], h.co + idx, 4);    // (a dword at any address: the target's unaligned access mode)
+              }
             }
-          }
-          if (t >= 64) {  // codes of row rf, column block cf: complete since the step before
-            const int rf = t & 63, cf = (t >> 6) - 1, xg = cf * 64 + lane;
-            if (rf < nr && xg < Wd) h.bmm[row0 + (size_t)rf * pitch + xg] = CD[rf * DPD_BPITCH + (cf & 1) * 64 + lane];
+            if (t >= 68) {  // codes of rows rf .. rf+3, column block cf: complete since two steps ago
+              const int tf = t - 4;
+              const int rf = (tf & 63) + g_row, cf = (tf >> 6) - 1, xg = cf * 64 + g_q4;
+              if (rf < nr && xg < Wd) {
+                const uint32_t cv = *reinterpret_cast<const uint32_t*>(&CD[rf * DPD_BPITCH + (cf & 1) * 64 + g_q4]);
+                unsigned char* dst = h.bmm + row0 + (size_t)rf * pitch + xg;
+                if (xg + 3 < Wd) {
+                  __builtin_memcpy(dst, &cv, 4);
+                } else {  // the hull's last columns: byte by byte (the bytes behind them belong to the next row)
+                  for (int q = 0; q < Wd - xg; ++q) dst[q] = (unsigned char)(cv >> (8 * q));
+                }
+              }
+            }
           }
           if (in_dp) {
             const bool active = (unsigned)x < (unsigned)Wd_l;
@@ -1792,9 +1849,13 @@ __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
   int i = __builtin_amdgcn_readfirstlane(a.hits[k].i2), j = __builtin_amdgcn_readfirstlane(a.hits[k].j2);
   // the block of codes whose bottom-right corner is (bi, bj); :124-125: b[i][1] = b[1][j] = STOP
   int bi = i, bj = j, codes;
+  const int2* rng = a.row_rng + (size_t)k * (h.Lq + 2);
   auto load_block = [&]() {
     const int ti = bi - (lane >> 3), tj = bj - (lane & 7);
-    codes = (ti < 1 || tj < 1 || ti == 1 || tj == 1) ? (int)MAC_STOP : (int)h.bmm[(size_t)ti * pitch + tj];
+    // (cells outside the active range of their row are masked: STOP, and the DP kernel has not written their code)
+    const bool border = ti < 1 || tj < 1 || ti == 1 || tj == 1;
+    const int2 r = border ? make_int2(1, 0) : rng[ti];
+    codes = (border || tj < r.x || tj > r.y) ? (int)MAC_STOP : (int)h.bmm[(size_t)ti * pitch + tj];
   };
   load_block();
   int step = 0, state = MAC_MM, matched = 1;
@@ -1876,10 +1937,19 @@ __global__ void __launch_bounds__(64) hhv_mac_trace_kernel(MacArgs a) {
 //   (i2,j2); then +-40 rows / columns around every step of the Viterbi path on;   excludeMACAlignment (:245-262): the
 //   +-2 cross of every cell of the earlier MAC alignments off;   exclude_regions / exclude_template_regions (:121-149).
 // (Viterbi::InitializeForAlignment's minimum-overlap corners are overwritten by maskViterbiAlignment and left out.)
+// The kernel also leaves rng[i] (hhv_mac_rowrange_kernel) for every row, from the geometry: the two rectangles and the band are a
+// superset of the cells it switches on (the excluded cells and ranges only switch cells off).  LDS_RNG: the per-row minima and
+// maxima of the band are collected with LDS atomics (queries up to MAC_MASK_LDS_ROWS rows), else with global ones.
+constexpr int MAC_MASK_LDS_ROWS = 8000;
+template <bool LDS_RNG>
 __global__ void __launch_bounds__(256) hhv_mac_mask_kernel(MacArgs a, MacMaskArgs m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_lo = reinterpret_cast<int*>(smem);  // [Lq + 1]
+  int* s_hi = s_lo + (a.Lq + 1);
   const int k = blockIdx.x, tid = threadIdx.x;
   const int Lq = a.Lq, Lt = a.Lt[k], pitch = Lt + 1;
   unsigned char* co = const_cast<unsigned char*>(a.celloff) + a.mat_off[k];
+  int2* rng = a.row_rng + (size_t)k * (Lq + 2);
   // the Viterbi alignment of the hit: handed over by the host, or - resident hits - taken from the trace results of the
   // template set the Viterbi stage searched (hhv_hits)
   int4 e = m.ends[k];  // i1, j1, i2, j2
@@ -1894,20 +1964,59 @@ __global__ void __launch_bounds__(256) hhv_mac_mask_kernel(MacArgs a, MacMaskArg
     vi = m.res_i + m.res_path_off[t] + 1;  // entries 1..nsteps
     vj = m.res_j + m.res_path_off[t] + 1;
   }
+  // rows' ranges, first from the two rectangles
+  for (int i = tid; i <= Lq; i += 256) {
+    int lo = 0x7fffffff, hi = 0;
+    if (i >= 1 && i < e.x && e.y > 1) lo = 1, hi = min(e.y - 1, Lt);
+    if (i >= 1 && i > e.z && e.w < Lt) lo = min(lo, max(e.w + 1, 1)), hi = Lt;
+    if (LDS_RNG) s_lo[i] = lo, s_hi[i] = hi;
+    else rng[i] = make_int2(lo, hi);
+  }
+  // the plane four cells (one dword: the planes start at multiples of four bytes and are padded to one) at a time
   const int cells = (Lq + 1) * pitch;
-  for (int c = tid; c < cells; c += 256) {
-    const int i = c / pitch, j = c - i * pitch;
-    co[c] = (i >= 1 && j >= 1) ? !((i < e.x && j < e.y) || (i > e.z && j > e.w)) : 0;
+  uint32_t* co4 = reinterpret_cast<uint32_t*>(co);
+  for (int c = 4 * tid; c < cells; c += 4 * 256) {
+    int i = c / pitch, j = c - i * pitch;
+    uint32_t v = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t off = (i >= 1 && j >= 1 && i <= Lq) ? !((i < e.x && j < e.y) || (i > e.z && j > e.w)) : 0;
+      v |= off << (8 * q);
+      if (++j == pitch) j = 0, ++i;
+    }
+    co4[c >> 2] = v;
   }
   __syncthreads();
   constexpr int W = 2 * 40 + 1;  // FWD_BKW_PATHWITDH = 40 (src/hhdecl.h:37)
   for (int w = tid; w < ns * W; w += 256) {
     const int step = w / W, d = w - step * W - 40;
     const int pi = vi[step], pj = vj[step];
-    if (pi + d >= 1 && pi + d <= Lq && pj >= 1 && pj <= Lt) co[(size_t)(pi + d) * pitch + pj] = 0;
-    if (pj + d >= 1 && pj + d <= Lt && pi >= 1 && pi <= Lq) co[(size_t)pi * pitch + pj + d] = 0;
+    if (pi + d >= 1 && pi + d <= Lq && pj >= 1 && pj <= Lt) {
+      co[(size_t)(pi + d) * pitch + pj] = 0;
+      if (LDS_RNG) {
+        atomicMin(&s_lo[pi + d], pj);
+        atomicMax(&s_hi[pi + d], pj);
+      } else {
+        atomicMin(&rng[pi + d].x, pj);
+        atomicMax(&rng[pi + d].y, pj);
+      }
+    }
+    if (pj + d >= 1 && pj + d <= Lt && pi >= 1 && pi <= Lq) {
+      co[(size_t)pi * pitch + pj + d] = 0;
+      if (d == -40 || d == 40 || pj + d == 1 || pj + d == Lt) {  // the ends of the row segment
+        if (LDS_RNG) {
+          atomicMin(&s_lo[pi], pj + d);
+          atomicMax(&s_hi[pi], pj + d);
+        } else {
+          atomicMin(&rng[pi].x, pj + d);
+          atomicMax(&rng[pi].y, pj + d);
+        }
+      }
+    }
   }
   __syncthreads();
+  if (LDS_RNG)
+    for (int i = tid; i <= Lq; i += 256) rng[i] = make_int2(s_lo[i], s_hi[i]);
   const int64_t x0 = m.excl_off[k];
   const int nx = (int)(m.excl_off[k + 1] - x0);
   for (int w = tid; w < nx * 5; w += 256) {
@@ -1936,7 +2045,16 @@ __global__ void __launch_bounds__(256) hhv_mac_mask_kernel(MacArgs a, MacMaskArg
 }
 
 int launch_mac_mask(const MacArgs& a, const MacMaskArgs& m, void* stream) {
-  hipLaunchKernelGGL(hhv_mac_mask_kernel, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a, m);
+  if (a.Lq <= MAC_MASK_LDS_ROWS)
+    hipLaunchKernelGGL(hhv_mac_mask_kernel<true>, dim3(a.n), dim3(256), (size_t)2 * (a.Lq + 1) * sizeof(int), (hipStream_t)stream, a, m);
+  else
+    hipLaunchKernelGGL(hhv_mac_mask_kernel<false>, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a, m);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+// masks handed over by the host: their rows' ranges by a scan
+int launch_mac_rowrange(const MacArgs& a, void* stream) {
+  hipLaunchKernelGGL(hhv_mac_rowrange_kernel, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -1949,8 +2067,6 @@ size_t mac_rows_lds(int max_Lt, bool stage) {
          (stage ? (size_t)(max_Lt + 2) * 28 * sizeof(float) + (((size_t)2 * (max_Lt + 2) + 15) & ~(size_t)15) +
                       (size_t)2 * (max_Lt + 2) * sizeof(float) + 352 * sizeof(float) : 0);
 }
-// the single-wave kernels with the row state in LDS (templates whose dataflow layout does not fit any more: 1459 .. 2046 columns)
-static size_t mac_rows_lds_single(int max_Lt) { return (size_t)10 * (max_Lt + 2) * sizeof(double); }
 constexpr size_t MAC_LDS_LIMIT = 160 * 1024;
 
 template <bool LOCAL, bool STAGE, bool GROWS>
@@ -1992,11 +2108,7 @@ template <bool LOCAL>
 static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream) {
   static_assert(MAC_PRE <= MAC_DF_STRIPS, "staged classes: at most MAC_PRE strips a row");
   if (cls <= 3) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
-  else if (cls <= 5) {
-    // (the dataflow kernels' mask table holds MAC_DF_STRIPS strips a row: implied by the LDS limit today, checked all the same)
-    const bool df = mac_rows_lds(max_Lt, false) <= MAC_LDS_LIMIT && (max_Lt + 63) / 64 <= MAC_DF_STRIPS;
-    launch_mac_rows<LOCAL, false, false>(a, n, df ? mac_rows_lds(max_Lt, false) : mac_rows_lds_single(max_Lt), stream, df);
-  }
+  else if (cls <= 5) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream);  // (fits: mac_length_class)
   else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
   // maximum-accuracy DP: along anti-diagonals (hhv_mac_dp_diag_kernel) unless 0.5 * mact is not a float (its chain steps are
   // float subtractions) or HHV_MAC_DP_ROWS asks for the row-by-row kernel (measurement aid)
@@ -2004,7 +2116,7 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
   const double half = 0.5 * (double)a.mact;
   if (!dp_rows && (double)(float)half == half) {
     const size_t lds_diag = DPD_TILES + (size_t)(max_Lt + 2) * sizeof(float);
-    if (cls <= 5 && lds_diag <= MAC_LDS_LIMIT) {
+    if (lds_diag <= MAC_LDS_LIMIT) {  // (also the class without LDS for forward / backward: Sb of ~27 000 columns fits)
       (void)hipFuncSetAttribute((const void*)hhv_mac_dp_diag_kernel<LOCAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
       hipLaunchKernelGGL((hhv_mac_dp_diag_kernel<LOCAL, false>), dim3(n), dim3(64), lds_diag, stream, a);
     } else {
@@ -2045,8 +2157,10 @@ int mac_length_class(int Lt, bool stage_allowed, bool lds_allowed) {
   if (stage_allowed && !no_stage && mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64)
     return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : 3;
   static const bool no_lds = getenv("HHV_MAC_NO_LDS") != nullptr;  // measurement aid: row state in global memory for every length
-  if (lds_allowed && !no_lds && mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT) return Lt <= 1022 ? 4 : 5;
-  if (lds_allowed && !no_lds && mac_rows_lds_single(Lt) <= MAC_LDS_LIMIT) return 5;  // (single-wave kernels, see launch_mac_class)
+  // (round 6: templates beyond the dataflow kernels' LDS layout - ~1450 columns - go straight to the class without LDS: the
+  // single-wave kernels are no faster with their rows in LDS than in L2, and one such template no longer drags its whole class
+  // onto them)
+  if (lds_allowed && !no_lds && mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT && (Lt + 63) / 64 <= MAC_DF_STRIPS) return Lt <= 1022 ? 4 : 5;
   return 6;
 }
 
@@ -2055,33 +2169,50 @@ int mac_length_class(int Lt, bool stage_allowed, bool lds_allowed) {
 // before the backtrace of all hits.
 int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* stream_, const MacStreams* side) {
   hipStream_t stream = (hipStream_t)stream_;
-  int first = 0, non_empty = 0;
-  for (int c = 0; c < MAC_CLASSES; ++c) non_empty += cls.n[c] > 0;
-  const bool fork = side && non_empty > 1;
-  // active column range of every row + cleared code planes: ahead of all classes
-  hipLaunchKernelGGL(hhv_mac_rowrange_kernel, dim3(a0.n), dim3(256), 0, stream, a0);
-  if (fork) (void)hipEventRecord((hipEvent_t)side->fork, stream);  // everything queued so far: inputs, masks
-  bool main_used = false;
-  bool joined[MAC_CLASSES] = {};
+  int non_empty = 0, first_of[MAC_CLASSES], at = 0;
   for (int c = 0; c < MAC_CLASSES; ++c) {
+    non_empty += cls.n[c] > 0;
+    first_of[c] = at;  // MacArgs::sel lists class 0 first
+    at += cls.n[c];
+  }
+  // The classes run side by side in at most MAC_CHAINS streams: the runtime maps streams onto four hardware queues, and two classes
+  // that share one run one after the other (seven streams: the longest class's forward - backward - DP chain waited behind another
+  // class's, 500 mixed-length hits 10.0 -> 14.8 ms).  Classes of the longest templates first, each to the chain with the least
+  // work so far (cost ~ a hit's rows x columns; the hits of a class run concurrently).
+  const bool fork = side && non_empty > 1 && side->s[0];
+  static const int n_chains = [] { const char* e = getenv("HHV_MAC_CHAINS"); const int v = e ? atoi(e) : MAC_CHAINS; return v < 1 ? 1 : (v > MAC_CLASSES ? MAC_CLASSES : v); }();
+  int chain_of[MAC_CLASSES];
+  double load[MAC_CLASSES] = {};
+  for (int c = MAC_CLASSES - 1; c >= 0; --c) {
+    chain_of[c] = 0;
+    if (cls.n[c] == 0 || !fork) continue;
+    int best = 0;
+    for (int q = 1; q < n_chains; ++q)
+      if (load[q] < load[best]) best = q;
+    chain_of[c] = best;
+    load[best] += 256.0 + cls.max_Lt[c];
+  }
+  if (fork) (void)hipEventRecord((hipEvent_t)side->fork, stream);  // everything queued so far: inputs, masks
+  bool used[MAC_CLASSES] = {};
+  for (int c = MAC_CLASSES - 1; c >= 0; --c) {
     if (cls.n[c] == 0) continue;
     hipStream_t st = stream;
-    if (main_used && fork && side->s[c]) {
-      st = (hipStream_t)side->s[c];
-      (void)hipStreamWaitEvent(st, (hipEvent_t)side->fork, 0);
-      joined[c] = true;
+    if (fork && chain_of[c] > 0) {  // chain 0 is the caller's stream itself (it gets the longest class)
+      st = (hipStream_t)side->s[chain_of[c]];
+      if (!used[chain_of[c]]) (void)hipStreamWaitEvent(st, (hipEvent_t)side->fork, 0);
+      used[chain_of[c]] = true;
     }
-    main_used = true;
     MacArgs a = a0;
-    a.sel = a0.sel + first;
+    a.sel = a0.sel + first_of[c];
     a.lds_cols = cls.max_Lt[c];
     if (local) launch_mac_class<true>(a, c, cls.n[c], cls.max_Lt[c], st);
     else launch_mac_class<false>(a, c, cls.n[c], cls.max_Lt[c], st);
-    if (joined[c]) (void)hipEventRecord((hipEvent_t)side->join[c], st);
-    first += cls.n[c];
   }
-  for (int c = 0; c < MAC_CLASSES; ++c)
-    if (joined[c]) (void)hipStreamWaitEvent(stream, (hipEvent_t)side->join[c], 0);
+  for (int q = 0; q < MAC_CLASSES; ++q)
+    if (used[q]) {
+      (void)hipEventRecord((hipEvent_t)side->join[q], (hipStream_t)side->s[q]);
+      (void)hipStreamWaitEvent(stream, (hipEvent_t)side->join[q], 0);
+    }
   hipLaunchKernelGGL(hhv_mac_trace_kernel, dim3(a0.n), dim3(64), 0, stream, a0);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

@@ -10,6 +10,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# hardware queues for the streams of the MAC length classes (hhv_create's comment): exported here because a host that
+# loads torch has usually initialised HIP before the library sees its first call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = os.environ.get("HHV_LIB", os.path.join(os.path.dirname(HERE), "lib", "libhhviterbi_hip.so"))
 
 HHV_ALIGN_BACKTRACE = 1

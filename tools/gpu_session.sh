@@ -102,6 +102,10 @@ macprof)   # kernel statistics of the MAC kernels: the wavefront pipeline and th
     f=$(find $OUT/prof_mac_$m -name "*kernel_stats.csv" | head -1); echo "== $m"; head -9 "$f" | cut -d, -f1-7; cp "$f" $OUT/mac_${m}_kernel_stats.csv; rm -rf $OUT/prof_mac_$m
   done
   ;;
+prep)   # prep [n] [tag]: rocprofv3 statistics and counters of the on-device PrepareTemplateHMM (tools/profile_prep.sh)
+  bash tools/profile_prep.sh ${1:-100000} ${2:-r6} 2>&1 | tail -30
+  rm -rf $OUT/prof_prep/pmc_* $OUT/prof_prep/stats
+  ;;
 macprofx)   # macprofx "<n Lq Lt>" ...: rocprofv3 kernel statistics of tools/bench_mac.py for each shape given (dataflow kernels only)
   cd /tmp && export TMPDIR=/tmp
   i=0
