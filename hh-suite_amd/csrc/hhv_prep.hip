@@ -14,6 +14,7 @@
 // 28-dword records (+ header).  Longer templates take the same three steps as two kernels with the intermediate in HBM.
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <algorithm>
 
 #include "hhv_internal.h"
 #include "viterbi_lane.h"
@@ -51,7 +52,10 @@ __device__ __forceinline__ float fast_log2_p(float x, const float* __restrict__ 
 enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };
 
 // One raw column -> its prepared transitions T[7] and pseudocount-mixed profile P[20] (columns >= 1).
-__device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __restrict__ raw, const float* __restrict__ sR,
+// lg2 / diff: fast_log2's tables (the fused kernel keeps a copy in LDS: seven look-ups with a different index in every lane per
+// column - as global loads they kept the CU's address unit busy for a third of the kernel's time)
+__device__ __forceinline__ void prep_column(const PrepArgs& a, const float (&raw)[RAW_DW], int64_t raw_col, const float* __restrict__ sR,
+                                            const float* __restrict__ lg2, const float* __restrict__ diff,
                                             float* __restrict__ P, float* __restrict__ T) {
   const int i = __builtin_bit_cast(int32_t, raw[RAW_J]) & META_JMASK;
   const int L = __builtin_bit_cast(int32_t, raw[RAW_L]);
@@ -74,20 +78,20 @@ __device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __re
     float p2 = (nM - 1) * fpow2_dev(t[T_M2I]) + a.gapb * pM2I;
     if (i == 0 || i == L) p1 = p2 = 0;
     float sum = p0 + p1 + p2 + FLT_MIN;
-    t[T_M2M] = fast_log2_p(p0 / sum, a.lg2, a.diff);
-    t[T_M2D] = fast_log2_p(p1 / sum, a.lg2, a.diff) * a.gapf;
-    t[T_M2I] = fast_log2_p(p2 / sum, a.lg2, a.diff) * a.gapg;
+    t[T_M2M] = fast_log2_p(p0 / sum, lg2, diff);
+    t[T_M2D] = fast_log2_p(p1 / sum, lg2, diff) * a.gapf;
+    t[T_M2I] = fast_log2_p(p2 / sum, lg2, diff) * a.gapg;
     p0 = nI * fpow2_dev(t[T_I2M]) + a.gapb * pI2M;
     p1 = nI * fpow2_dev(t[T_I2I]) + a.gapb * pI2I;
     sum = p0 + p1 + FLT_MIN;
-    t[T_I2M] = fast_log2_p(p0 / sum, a.lg2, a.diff);
-    t[T_I2I] = fast_log2_p(p1 / sum, a.lg2, a.diff) * a.gapi;
+    t[T_I2M] = fast_log2_p(p0 / sum, lg2, diff);
+    t[T_I2I] = fast_log2_p(p1 / sum, lg2, diff) * a.gapi;
     p0 = nD * fpow2_dev(t[T_D2M]) + a.gapb * pD2M;
     p1 = nD * fpow2_dev(t[T_D2D]) + a.gapb * pD2D;
     if (i == L) p1 = 0;
     sum = p0 + p1 + FLT_MIN;
-    t[T_D2M] = fast_log2_p(p0 / sum, a.lg2, a.diff);
-    t[T_D2D] = fast_log2_p(p1 / sum, a.lg2, a.diff) * a.gaph;
+    t[T_D2M] = fast_log2_p(p0 / sum, lg2, diff);
+    t[T_D2D] = fast_log2_p(p1 / sum, lg2, diff) * a.gaph;
   }
 #pragma unroll
   for (int k = 0; k < 7; ++k) T[k] = t[k];
@@ -100,7 +104,7 @@ __device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __re
     float tau = 0.0f;
     if (a.pcm == 1) tau = a.pca;
     if (a.pcm == 2)  // :1898-1909; pcc != 1 needs libm's powf: the host has evaluated tau for every raw column
-      tau = a.tau ? a.tau[(raw - a.raw) / RAW_DW] : (float)fmin(1.0, (double)a.pca / (1. + (double)(raw[RAW_NEFF + 0] / a.pcb)));
+      tau = a.tau ? a.tau[raw_col] : (float)fmin(1.0, (double)a.pca / (1. + (double)(raw[RAW_NEFF + 0] / a.pcb)));
     if (a.pcm == 3) {  // :1911-1919, constant-diversity pseudocounts: float arithmetic, the maximum with the double 0.0
       const float x = raw[RAW_NEFF + 0] / a.pcb;
       tau = (float)fmax(0.0, (double)(a.pca * ((1.0f - x) + (a.pcc * x) * (1.0f - x))));
@@ -116,6 +120,19 @@ __device__ __forceinline__ void prep_column(const PrepArgs& a, const float* __re
         P[aa] = (float)((1. - (double)tau) * (double)f[aa] + (double)(tau * g));
       }
     }
+  }
+}
+
+// one raw column (128 bytes, 128-byte aligned) as eight 16-byte loads
+__device__ __forceinline__ void load_raw_column(const PrepArgs& a, int64_t col, float (&v)[RAW_DW]) {
+  const float4* src = reinterpret_cast<const float4*>(a.raw + (size_t)col * RAW_DW);
+#pragma unroll
+  for (int q = 0; q < RAW_DW / 4; ++q) {
+    const float4 x = src[q];
+    v[4 * q + 0] = x.x;
+    v[4 * q + 1] = x.y;
+    v[4 * q + 2] = x.z;
+    v[4 * q + 3] = x.w;
   }
 }
 
@@ -219,8 +236,11 @@ __global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
   const int k = a.ids[blockIdx.x];
   const int64_t rin = prep_rin(a, k);  // the intermediate is indexed like the raw block
   const int L = a.L[k];
-  for (int i = threadIdx.x; i <= L; i += 256)
-    prep_column(a, a.raw + (size_t)(rin + i) * RAW_DW, sR, a.p_tmp + (size_t)(rin + i) * 20, a.tr_tmp + (size_t)(rin + i) * 8);
+  for (int i = threadIdx.x; i <= L; i += 256) {
+    float rawv[RAW_DW];
+    load_raw_column(a, rin + i, rawv);
+    prep_column(a, rawv, rin + i, sR, a.lg2, a.diff, a.p_tmp + (size_t)(rin + i) * 20, a.tr_tmp + (size_t)(rin + i) * 8);
+  }
 }
 
 // ... and P2, one wavefront per template
@@ -236,29 +256,126 @@ __global__ void __launch_bounds__(64) hhv_prep_finalize_kernel(PrepArgs a) {
 
 // ---- fused path: one workgroup of 256 threads per template; the mixed profile p[L+1][20] (row stride 21 dwords:
 // conflict-free for one-dword-per-lane accesses) and the prepared transitions stay in LDS between the three steps, so
-// the only HBM traffic is the raw column (128 B) in and the packed record (112 B) out
+// the only HBM traffic is the raw column (128 B) in and the packed record (112 B) out.
+// Round 6: the three steps are spread over the four wavefronts BY COST.  Until then wave 0 ran two of the five 64-column chunks
+// of step 1 (300 columns), all of step 2 and its share of step 3 - twice the instructions of the other waves - and the wave 0 of
+// every resident workgroup sat on the same SIMD (4.36 ms per 100 000 templates = 0.25 of the VALU issue rate,
+// profiles/r6a_prep_summary.txt).  Now: chunk c of step 1 to wave c mod 4; step 2 (the 20 sequential sums) to the wave with the
+// least work so far; the chunks of step 3 greedily to the least loaded wave.  Step 3 itself works one LANE per column (20
+// divisions, the record assembled in registers, seven 16-byte stores) instead of one lane per dword of the record (three
+// divergent branches per record, 32 lanes for 28 dwords); the raw column comes in as eight 16-byte loads, and its secondary-
+// structure bits wait in the unused eighth slot of the column's transitions instead of being fetched again.
 constexpr int PREP_PS = 21;
-__global__ void __launch_bounds__(256) hhv_prep_fused_kernel(PrepArgs a) {
+constexpr int PREP_TAB = 1028;
+// NT templates per workgroup of 4 * NT wavefronts (NT = 2: the 8 KB of fast_log2 tables and R are shared by two templates, and
+// four templates stay resident per CU - with one template per workgroup the tables cost a quarter of the occupancy)
+// Who does what (static: a plan worked out per workgroup cost more scalar instructions than the kernel has vector ones), NW = 4 NT
+// wavefronts:
+//   step 1  work item q (the chunks of the workgroup's templates, in order) -> wave q mod NW: the low waves get the extra items
+//   step 2  template t -> wave NW - 1 - t (the high waves)
+//   step 3  work item q -> the waves that had no step 2, round-robin
+// (Measured, 100 000 templates of 300 columns, profiles/r6_prep_summary.txt: 4.36 ms before; lane-per-column emission + 16-byte loads
+// and stores + steps spread by cost 2.78; + tables in LDS, one template per workgroup, three workgroups per CU 2.95; two templates
+// per workgroup 2.60; ten wavefronts - one chunk each - 2.74: the balance inside a workgroup is not what limits it any more.)
+template <int NT>
+__global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_ids) {
+  const int NTH = blockDim.x, NW = NTH >> 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sR = reinterpret_cast<float*>(smem);  // [400]
-  float* s_pav = sR + 400;                     // [20]
-  float* s_pnul = s_pav + 20;                  // [20]
-  float* sT = s_pnul + 24;                     // [(maxL+1)][8]
-  float* sP = sT + (size_t)(a.lds_cols) * 8;   // [(maxL+1)][21]
-  for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
+  float* s_pav0 = sR + 400;                    // [NT][20]
+  float* s_pnul0 = s_pav0 + 20 * NT;           // [NT][20] (+ padding to a multiple of 16 bytes)
+  float* s_lg2 = s_pnul0 + 20 * NT + 4;        // [1028] fast_log2's tables
+  float* s_diff = s_lg2 + PREP_TAB;            // [1028]
+  float* sT0 = s_diff + PREP_TAB;              // [NT][(maxL+1)][8]: tr[7] + the column's meta bits
+  float* sP0 = sT0 + (size_t)NT * a.lds_cols * 8;  // [NT][(maxL+1)][21]
+  for (int q = threadIdx.x; q < 400; q += NTH) sR[q] = a.R[q];
+  for (int q = threadIdx.x; q < 1025; q += NTH) s_lg2[q] = a.lg2[q], s_diff[q] = a.diff[q];
   __syncthreads();
-  const int k = a.ids[blockIdx.x];
-  const int64_t rin = prep_rin(a, k);
-  const int L = a.L[k];
-  for (int i = threadIdx.x; i <= L; i += 256)
-    prep_column(a, a.raw + (size_t)(rin + i) * RAW_DW, sR, sP + (size_t)i * PREP_PS, sT + (size_t)i * 8);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int k[NT], L[NT], n_chunks[NT];
+  int64_t rin[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int slot = blockIdx.x * NT + t;
+    k[t] = slot < n_ids ? a.ids[slot] : -1;
+    L[t] = k[t] >= 0 ? a.L[k[t]] : 0;
+    rin[t] = k[t] >= 0 ? prep_rin(a, k[t]) : 0;
+    n_chunks[t] = k[t] >= 0 ? (L[t] + 1 + 63) >> 6 : 0;
+  }
+  const int W3_N = NW > NT ? NW - NT : NW;  // step 3 on the waves that had no step 2
+  // ---- step 1: one lane per raw column
+  {
+    int q = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float* sT = sT0 + (size_t)t * a.lds_cols * 8;
+      float* sP = sP0 + (size_t)t * a.lds_cols * PREP_PS;
+      for (int c = 0; c < n_chunks[t]; ++c, ++q) {
+        if ((q % NW) != wave) continue;
+        const int i = (c << 6) + lane;
+        if (i <= L[t]) {
+          float rawv[RAW_DW];
+          load_raw_column(a, rin[t] + i, rawv);
+          prep_column(a, rawv, rin[t] + i, sR, s_lg2, s_diff, sP + (size_t)i * PREP_PS, sT + (size_t)i * 8);
+          sT[(size_t)i * 8 + 7] = rawv[RAW_SS];
+        }
+      }
+    }
+  }
   __syncthreads();
-  if (threadIdx.x < 64) finalize_template<PREP_PS>(a, k, threadIdx.x, sP, sT, s_pav, s_pnul);
+  // ---- step 2: the column sums, in the reference's order
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (k[t] >= 0 && wave == NW - 1 - t)
+      finalize_template<PREP_PS>(a, k[t], lane, sP0 + (size_t)t * a.lds_cols * PREP_PS, sT0 + (size_t)t * a.lds_cols * 8, s_pav0 + 20 * t, s_pnul0 + 20 * t);
   __syncthreads();
-  emit_records<PREP_PS>(a, k, threadIdx.x, 256, sP, sT, s_pnul);
+  // ---- step 3: header + one record per column
+  int q3 = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (k[t] < 0) continue;
+    const float* sT = sT0 + (size_t)t * a.lds_cols * 8;
+    const float* sP = sP0 + (size_t)t * a.lds_cols * PREP_PS;
+    const float* s_pnul = s_pnul0 + 20 * t;
+    const int64_t c0 = a.rec_off[k[t]];
+    if (threadIdx.x < REC_DW) {
+      float v = 0.0f;
+      if (threadIdx.x == 0) v = __builtin_bit_cast(float, (int32_t)k[t]);
+      if (threadIdx.x == 1) v = __builtin_bit_cast(float, (int32_t)L[t]);
+      if (threadIdx.x == REC_META) v = __builtin_bit_cast(float, META_HDR);
+      a.records[(size_t)c0 * REC_DW + threadIdx.x] = v;
+    }
+    for (int c = 0; c < n_chunks[t]; ++c, ++q3) {
+      if ((q3 % W3_N) != wave) continue;
+      const int j = (c << 6) + lane;  // (column 0 has no record of its own: the header above)
+      if (j < 1 || j > L[t]) continue;
+      float rec[REC_DW];
+      const float* pj = sP + (size_t)j * PREP_PS;
+#pragma unroll
+      for (int q = 0; q < 20; ++q) rec[q] = pj[q] / s_pnul[q];
+      // [20..24] tr[j-1][M2M,M2D,D2M,D2D,I2M], [25..26] tr[j][I2I,M2I]
+      const float4* tq = reinterpret_cast<const float4*>(sT + (size_t)(j - 1) * 8);
+      const float4 m0 = tq[0], m1 = tq[1], n0 = tq[2], n1 = tq[3];  // tr[j-1][0..7], tr[j][0..7]
+      rec[REC_M2M] = m0.x;   // T_M2M = 0
+      rec[REC_M2D] = m0.z;   // T_M2D = 2
+      rec[REC_D2M] = m1.y;   // T_D2M = 5
+      rec[REC_D2D] = m1.z;   // T_D2D = 6
+      rec[REC_I2M] = m0.w;   // T_I2M = 3
+      rec[REC_I2I] = n1.x;   // T_I2I = 4
+      rec[REC_M2I] = n0.y;   // T_M2I = 1
+      int32_t meta = j | (__builtin_bit_cast(int32_t, n1.w) & 0x01FF0000);
+      if (j == L[t]) meta |= META_LAST;
+      rec[REC_META] = __builtin_bit_cast(float, meta);
+      float4* dst = reinterpret_cast<float4*>(a.records + (size_t)(c0 + j) * REC_DW);
+#pragma unroll
+      for (int q = 0; q < REC_DW / 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+    }
+  }
 }
 
-size_t prepare_fused_lds(int max_L) { return (size_t)(400 + 20 + 24 + (size_t)(max_L + 1) * (8 + PREP_PS)) * sizeof(float); }
+// (nt templates per workgroup)
+size_t prepare_fused_lds(int max_L, int nt) { return (size_t)(400 + 40 * nt + 4 + 2 * PREP_TAB + (size_t)nt * (max_L + 1) * (8 + PREP_PS)) * sizeof(float); }
+size_t prepare_fused_lds(int max_L) { return prepare_fused_lds(max_L, 1); }
 
 // Neff_M of every raw column, compacted (for the host's tau table when pcc != 1, hhv_api_prep.cpp ensure_tau)
 __global__ void __launch_bounds__(256) hhv_gather_neff_kernel(const float* __restrict__ raw, int64_t n_cols, float* __restrict__ out) {
@@ -280,9 +397,16 @@ int launch_prepare(const PrepArgs& a0, const int32_t* const ids[3], const int32_
     PrepArgs a = a0;
     a.ids = ids[cls];
     a.lds_cols = max_L[cls] + 1;
-    const size_t lds = prepare_fused_lds(max_L[cls]);
-    (void)hipFuncSetAttribute((const void*)hhv_prep_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(hhv_prep_fused_kernel, dim3(n_ids[cls]), dim3(256), lds, stream, a);
+    // two templates per workgroup where two such workgroups fit a CU's LDS (four templates resident, as with one template and no
+    // tables), else one
+    const size_t lds2 = prepare_fused_lds(max_L[cls], 2), lds1 = prepare_fused_lds(max_L[cls], 1);
+    if (lds2 <= 80 * 1024) {
+      (void)hipFuncSetAttribute((const void*)hhv_prep_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(hhv_prep_fused_kernel<2>, dim3((n_ids[cls] + 1) / 2), dim3(512), lds2, stream, a, n_ids[cls]);
+    } else {
+      (void)hipFuncSetAttribute((const void*)hhv_prep_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      hipLaunchKernelGGL(hhv_prep_fused_kernel<1>, dim3(n_ids[cls]), dim3(256), lds1, stream, a, n_ids[cls]);
+    }
   }
   if (n_ids[2]) {
     PrepArgs a = a0;
