@@ -66,7 +66,7 @@ VALU_PEAK_FMA_TFLOPS = 157.3
 # measured: two waves per SIMD of a 64-thread / 248-VGPR kernel retire one v_add_f32 wave-instruction per 2.25 clk (nominal
 # 2.4 GHz) per SIMD - tools/gen_shape_ubench.py, profiles/r2_shape_ubench.txt
 MEASURED_ISSUE_CEILING = 256 * 4 * 64 / 2.25 * 2.4e9
-PROFILE_JSONS = ("r5_summary.json", "r4_summary.json", "r3_summary.json", "r2_summary.json")   # newest committed PMC profile of the headline command first
+PROFILE_JSONS = ("r6_summary.json", "r5_summary.json", "r4_summary.json", "r3_summary.json", "r2_summary.json")   # newest committed PMC profile of the headline command first
 REC_BYTES = 112
 OPS_PER_CELL = 92          # SURVEY.md 8d / BASELINE.md 5: fp32 operations per DP cell of the reference
 ZIPF_SEED = 0x21F          # the ONE seed of configs[4]'s global length vector
@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--no-configs1", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the short measurements of the SURVEY 8f rows (N2-N4)")
     ap.add_argument("--no-configs2", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the `pipeline` entry (one hhblits-style search iteration, every stage on the device)")
+    ap.add_argument("--pipeline-db", type=int, default=200000, help="sequences of the pipeline entry's resident database (1 000 000: profiles/r6_pipeline.json)")
     ap.add_argument("--no-configs4", action="store_true")
     ap.add_argument("--no-upload", action="store_true", help="skip the template_upload entry (pack + H2D, packed-file open)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the fast_mode entry (the opt-in fused-emission build)")
@@ -395,8 +397,11 @@ def main():
                        "0.6 log2 U[0.01, 0.05], M2M = log2(1 - pI - pD), I2M = D2M = log2 0.6, I2I = D2D = 0.6 log2 0.4 (pyhhv/synth_stream.py)",
         },
         "roofline": {
-            "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            # achieved / frac: SURVEY.md 8(d)'s bytes (27 floats a column, 12 bytes a result); the engine's own records (28 dwords,
+            # 16-byte results: 3.7 % more) under achieved_engine_bytes / frac_engine_bytes
+            "bound": "hbm", "achieved": algo_bytes_8d / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": algo_bytes_8d / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "achieved_engine_bytes": achieved_gbs, "frac_engine_bytes": achieved_gbs / HBM_PEAK_GBS,
             "traffic_source": "profiles/%s (rocprofv3 PMC, bytes per launch)" % profile_json if traffic else None,
             "kernel": "hhv_stream_kernel", "kernel_ms": k_ms, "kernel_ms_min": float(np.min(kernel_ms)),
             "kernel_ms_median": float(np.median(kernel_ms)), "algorithmic_bytes_per_launch": algo_bytes,
@@ -424,6 +429,17 @@ def main():
                                    "imbalance_max_over_mean": float(shard_records.max() / shard_records.mean())}
     if world > 1 and ndev < world:
         out["config"]["oversubscribed"] = "%d ranks on %d device(s): correctness path, not a measurement" % (world, ndev)
+    if profile_json:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import srchash
+            with open(os.path.join(ROOT, "profiles", profile_json)) as f:
+                stamp = json.load(f).get("kernel_sources_sha1")
+            now = srchash.kernel_sources_sha1(srchash.VITERBI)
+            out["roofline"]["profile_sources_sha1"] = stamp
+            out["roofline"]["profile_stale"] = (stamp != now) if stamp else "unstamped (taken before round 6)"
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["profile_stale"] = "unknown: %r" % (e,)
     if valu_wave_instr:
         # executed VALU instructions from the SQ counters: issue slots used / issue slots available in the kernel's time
         lane_ops = valu_wave_instr * 64.0
@@ -466,6 +482,19 @@ def main():
 
     if single and not args.no_configs2 and n >= 10000 and plain:
         out["configs2_backtrace_top500"] = configs2(args, torch, ctx, ts, rec, rec_off, Ls, qf, qtr, Lq, Lt, K)
+    if isinstance(out.get("cpu_baseline"), dict):
+        # like for like: the reference's Viterbi::Align always writes its backtrace bytes, the GPU headline step does not
+        cb = out["cpu_baseline"]
+        cb["note"] = ("the CPU leg is Viterbi::Align WITH its backtrace matrix (the reference has no score-only mode); the GPU `value` is the "
+                      "score-only step.  The like-for-like ratio is gpu_backtrace_over_cpu (configs2_backtrace_top500, 100 k templates: DP with "
+                      "backtrace bytes + walk + Hit scores + top-K)")
+        try:
+            g = out["configs2_backtrace_top500"]["100k"]["cells_per_s"]
+            cb["gpu_backtrace_cells_per_s"] = g
+            cb["gpu_backtrace_over_cpu"] = g / cb["value"]
+            cb["gpu_score_only_over_cpu"] = value / cb["value"]
+        except Exception:
+            pass
 
     if single and not args.no_configs4 and plain:
         out["configs4_zipf"] = configs4(args, torch, capi, synth, device, dev_index, qf, qtr, Lq, K)
@@ -485,6 +514,8 @@ def main():
 
     if single and not args.no_next_rows and plain:
         out["next_rows"] = next_rows()
+    if single and not args.no_pipeline and plain:
+        out["pipeline"] = pipeline(args)
 
     if single and os.environ.get("HHV_DEBUG_CLK"):
         # measurement builds (-DHHV_EXP_TIMING) export the shader-clock totals of wave 0
@@ -759,8 +790,14 @@ def next_rows():
     out = {}
     try:
         import bench_prefilter
-        r = bench_prefilter.run(200000, 300, 1000)
+        cores = usable_cores()[0]
+        r = bench_prefilter.run(200000, 300, 1000, ref_threads=cores)
+        ref = r.get("reference") or {}
         out["N3_prefilter"] = {"db_sequences": r["n_db"], "db_residues": r["residues"], "Lq": r["Lq"],
+                               # the reference's AVX2 kernels with its own OpenMP loop over the database, on the host cores of this box
+                               "reference_gapless_cells_per_s": ref.get("gapless_cells_per_s"), "reference_sw_cells_per_s": ref.get("sw_cells_per_s"),
+                               "reference_cores": ref.get("threads"), "reference_kind": "reference (oracle/_ref, Prefilter::ungapped_sse_score / swStripedByte, AVX2 %s-byte vectors)" % ref.get("vector_bytes"),
+                               "reference_error": ref.get("error"),
                                "gapless_cells_per_s": r["ungapped"]["cells_per_s"], "gapless_kernel_ms": r["ungapped"]["kernel_ms"],
                                "sw_cells_per_s": r["gapped"]["cells_per_s"], "sw_kernel_ms": r["gapped"]["kernel_ms"],
                                "mismatches_vs_oracle": r["ungapped"]["mismatches"] + r["gapped"]["mismatches"],
@@ -769,20 +806,29 @@ def next_rows():
         out["N3_prefilter"] = {"error": repr(e)}
     try:
         import bench_mac
-        r = bench_mac.run(500, 300, 300, 100)
+        r = bench_mac.run(500, 300, 300, 100, ref_threads=usable_cores()[0])
+        ro = r.get("reference_openmp") or {}
         out["N4_mac_realign"] = {"hits": r["n_hits"], "Lq": r["Lq"], "Lt": r["Lt"], "kernels_ms": r["gpu_kernels_ms"],
                                  "end_to_end_ms_host_staged_profiles": r["gpu_wall_ms_incl_host_masks"],
                                  "end_to_end_ms_resident_set": r["resident_set"]["runner_ms"],
                                  "resident_identical_to_staged": r["resident_set"]["identical_to_staged"],
                                  "hits_per_s": r["gpu_hits_per_s"],
                                  "reference_hits_per_s_1core": r.get("ref_cpu_hits_per_s_1core"),
+                                 # PosteriorDecoderRunner's OpenMP loop over the templates (src/hhposteriordecoderrunner.cpp:76) on this box's cores
+                                 "reference_hits_per_s": ro.get("hits_per_s"), "reference_cores": ro.get("threads"), "reference_ms": ro.get("ms"),
+                                 "reference_error": ro.get("error"),
                                  "mismatches_vs_reference": r.get("mismatches_vs_reference"), "checked": r.get("checked")}
     except Exception as e:
         out["N4_mac_realign"] = {"error": repr(e)}
     try:
+        import bench_prepare
+        out["N2_prepare"] = bench_prepare.run(100000, ref_sample=256, ref_threads=usable_cores()[0])
+    except Exception as e:
+        out["N2_prepare"] = {"error": repr(e)}
+    try:
         # VALU-issue roofline of these kernels from the committed counters (profiles/r5_next_rows_summary.json - r3's if absent -, tools/profile_next.sh):
         # executed VALU lane-instructions per cell x the rate measured here (prefilter), issue fraction of the profiled launch (MAC)
-        nr_name = next(n for n in ("r5_next_rows_summary.json", "r3_next_rows_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        nr_name = next(n for n in ("r6_next_rows_summary.json", "r5_next_rows_summary.json", "r3_next_rows_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", nr_name)) as f:
             k = json.load(f)["kernels"]
         rv = {}
@@ -796,7 +842,14 @@ def next_rows():
         for n, v in k.items():
             if "mac_" in n:
                 rv[n.split("<")[0]] = {"frac_in_profiled_launch": v["frac_of_valu_issue_peak"], "avg_ms_profiled": v["avg_ms"]}
-        out["roofline_valu"] = {"bound": "valu_issue", "peak_T_lane_ops_per_s": VALU_PEAK_LANEOPS / 1e12, "kernels": rv,
+        stale = None
+        try:
+            import srchash
+            stamp = json.load(open(os.path.join(ROOT, "profiles", nr_name))).get("kernel_sources_sha1")
+            stale = (stamp != srchash.kernel_sources_sha1(srchash.NEXT_ROWS)) if stamp else "unstamped (taken before round 6)"
+        except Exception:
+            pass
+        out["roofline_valu"] = {"bound": "valu_issue", "peak_T_lane_ops_per_s": VALU_PEAK_LANEOPS / 1e12, "kernels": rv, "profile_stale": stale,
                                 "source": "profiles/%s (SQ_INSTS_VALU per launch) x the rates of this run" % nr_name}
     except Exception as e:
         out["roofline_valu"] = {"error": repr(e)}
@@ -823,6 +876,20 @@ def next_rows():
     except Exception as e:
         out["dropin_cold_process"] = {"error": repr(e)}
     return out
+
+
+def pipeline(args):
+    """One hhblits-style search iteration with every stage on the device (what HHblits::run does per round,
+    src/hhblits.cpp:1065-1415): gapless prefilter over the resident cs219 database -> Smith-Waterman + second selection ->
+    hhv_prepare_subset of the survivors from the resident raw HMMs -> Viterbi + backtrace + Hit scores -> top 500 -> MAC
+    realignment.  Per-stage wall times of the best of three iterations (tools/bench_pipeline.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import bench_pipeline
+        n_db = int(args.pipeline_db)
+        return bench_pipeline.run(n_db, 20000 if n_db >= 1000000 else 10000, 500)
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def cpu_baseline(args, rec, rec_off, Ls, ctx, ts, qf, qtr, n, Lq):

@@ -416,7 +416,10 @@ int hhv_prepare_templates(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par
   PrepArgs a;
   fill_prep_args(&a, c, rs, ts, par);
   a.pav_out = rs->d_pav;
+  (void)hipEventRecord(c->ev0, c->stream);  // hhv_last_kernel_ms: the prepare kernels of this call
   rc = launch_prepare(a, rs->d_ids, rs->n_ids, rs->max_L, c->stream);
+  (void)hipEventRecord(c->ev1, c->stream);
+  c->ev_valid = true;
   if (rc != 0) {
     if (!*out) hhv_tset_free(ts);
     return fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
@@ -481,7 +484,10 @@ int hhv_prepare_subset(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, c
     fill_prep_args(&a, c, rs, ts, par);
     a.src = d_scratch;
     a.pav_out = nullptr;
+    (void)hipEventRecord(c->ev0, c->stream);
     const int lr = launch_prepare(a, d_cls, n_cls, max_L, c->stream);
+    (void)hipEventRecord(c->ev1, c->stream);
+    c->ev_valid = true;
     if (lr != 0) rc = fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
   }
   if (rc == HHV_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(HHV_E_DEVICE, "hhv_prepare_subset: kernels failed");

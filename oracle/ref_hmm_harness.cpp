@@ -24,6 +24,7 @@
 #include "hhmatrices.h"
 #include "hhutil.h"
 
+#include <omp.h>
 extern "C" {
 
 // fast_log2 (src/util-inl.h:108-130) keeps its lookup table in function-local statics that the FIRST caller
@@ -197,6 +198,60 @@ int ref_prepare_raw(int role, int L, const float* f, const float* tr, const floa
   for (int a = 0; a < 20; ++a) out_pav[a] = h->pav[a];
   delete h;
   return 0;
+}
+
+// CPU BASELINE of bench.py (next_rows.N2_prepare.reference_*): PrepareTemplateHMM's call sequence (role 1 above) on n raw
+// templates of one length L, repeated `reps` times, on `threads` OpenMP threads (the reference prepares a template inside the
+// per-thread loops of its Viterbi / realignment runners, src/hhviterbirunner.cpp:117-140): seconds of the loop.
+// f[n][(L+2)*20], tr[n][(L+1)*7], neff[n][(L+1)*3], neff_hmm[n]
+double ref_prepare_raw_timed(int n, int reps, int L, const float* f, const float* tr, const float* neff, const float* neff_hmm,
+                             const float* q_pav, const float* gap, const float* pc, int columnscore, const float* pb_in, int threads,
+                             double* checksum) {
+  if (Log::reporting_level() > WARNING) Log::reporting_level() = WARNING;
+  Parameters par(0, NULL);
+  float pb[21];
+  float P[20][20], R[20][20], S[20][20], Sim[20][20];
+  SetSubstitutionMatrix(par.matrix, pb, P, R, S, Sim);
+  if (pb_in) memcpy(pb, pb_in, 20 * sizeof(float));
+  if (threads < 1) threads = 1;
+  fast_log2(1.0f);  // the table's first-caller initialisation outside the parallel region
+  double sum = 0.0;
+  const double t0 = omp_get_wtime();
+#pragma omp parallel num_threads(threads) reduction(+ : sum)
+  {
+    HMM* h = new HMM(MAXSEQDIS, L + 3);
+    HMM* q = new HMM(MAXSEQDIS, 8);
+    for (int a = 0; a < 20; ++a) q->pav[a] = q_pav[a];
+#pragma omp for schedule(static)
+    for (int e = 0; e < n * reps; ++e) {
+      const int k = e % n;
+      const float* fk = f + (size_t)k * (L + 2) * 20;
+      const float* trk = tr + (size_t)k * (L + 1) * 7;
+      const float* nk = neff + (size_t)k * (L + 1) * 3;
+      h->L = L;
+      h->Neff_HMM = neff_hmm[k];
+      h->trans_lin = 0;
+      for (int i = 0; i <= L + 1; ++i)
+        for (int a = 0; a < 20; ++a) h->f[i][a] = fk[i * 20 + a];
+      for (int i = 0; i <= L; ++i) {
+        for (int t = 0; t < 7; ++t) h->tr[i][t] = trk[i * 7 + t];
+        h->Neff_M[i] = nk[i * 3 + 0];
+        h->Neff_I[i] = nk[i * 3 + 1];
+        h->Neff_D[i] = nk[i * 3 + 2];
+      }
+      h->AddTransitionPseudocounts(gap[0], gap[1], gap[2], gap[3], gap[4], gap[5], gap[6], gap[6]);
+      h->PreparePseudocounts(R);
+      h->AddAminoAcidPseudocounts((char)pc[0], pc[1], pc[2], pc[3]);
+      h->CalculateAminoAcidBackground(pb);
+      h->IncludeNullModelInHMM(q, h, columnscore, par.half_window_size_local_aa_bg_freqs, pb);
+      sum += h->p[1][0] + h->tr[L][0];
+    }
+    delete q;
+    delete h;
+  }
+  const double dt = omp_get_wtime() - t0;
+  if (checksum) *checksum = sum;
+  return dt;
 }
 
 }  // extern "C"

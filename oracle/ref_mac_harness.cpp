@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <omp.h>
 
 #include "hhposteriordecoder.h"
 #include "hhviterbimatrix.h"
@@ -153,6 +154,91 @@ int ref_mac_realign(const float* q_p, const float* q_tr_log, int Lq, const float
   delete q;
   delete t;
   return 0;
+}
+
+// CPU BASELINE of bench.py (next_rows.N4_mac_realign.reference_hits_per_s): n hits of one query realigned by the reference's
+// member functions with the reference's parallelisation - PosteriorDecoderRunner::executeComputation's
+//   #pragma omp parallel for schedule(static) num_threads(m_n_threads)      (src/hhposteriordecoderrunner.cpp:76)
+// over the templates, one PosteriorDecoder + PosteriorMatrix + ViterbiMatrix per thread (:68, initializeConsumerThreads) -
+// and the call sequence of PosteriorDecoder::realign (src/hhposteriordecoder.cpp:86-119) per hit.  Template k: columns
+// col_off[k] .. of t_p ([.][20]) / t_tr_log ([.][7]), Viterbi path entries path_off[k] .. (entry 0 unused, 1 .. nsteps).
+// Returns the seconds the parallel loop took (templates are built before it: the reference reads them inside its loop, but
+// that is the database layer, not the realignment); *checksum = sum of the MAC alignments' step counts.
+double ref_mac_realign_timed(const float* q_p, const float* q_tr_log, int Lq, int n, const long* col_off, const int* Lt,
+                             const float* t_p, const float* t_tr_log, int local, float shift, float mact, float corr,
+                             const int* ends /* [n][4] i1 j1 i2 j2 */, const int* nsteps, const long* path_off, const int* v_i,
+                             const int* v_j, int threads, long* checksum) {
+  Log::reporting_level() = INFO;
+  HMM* q = make_hmm(q_p, q_tr_log, Lq);
+  q->Log2LinTransitionProbs(1.0);
+  q->tr[0][M2D] = q->tr[0][M2I] = 0.0f;
+  q->tr[0][I2M] = q->tr[0][I2I] = 0.0f;
+  q->tr[0][D2M] = q->tr[0][D2D] = 0.0f;
+  q->tr[Lq][M2M] = 1.0f;
+  q->tr[Lq][M2D] = q->tr[Lq][M2I] = 0.0f;
+  q->tr[Lq][I2M] = q->tr[Lq][I2I] = 0.0f;
+  q->tr[Lq][D2M] = 1.0f;
+  q->tr[Lq][D2D] = 0.0f;
+  int max_Lt = 1;
+  for (int k = 0; k < n; ++k) max_Lt = max_Lt > Lt[k] ? max_Lt : Lt[k];
+  std::vector<HMM*> ts(n);
+  for (int k = 0; k < n; ++k) {
+    ts[k] = make_hmm(t_p + (size_t)col_off[k] * 20, t_tr_log + (size_t)col_off[k] * 7, Lt[k]);
+    ts[k]->Log2LinTransitionProbs(1.0);
+  }
+  if (threads < 1) threads = 1;
+  std::vector<ViterbiMatrix*> vm(threads);
+  std::vector<PosteriorMatrix*> pm(threads);
+  std::vector<PosteriorDecoder*> dec(threads);
+  for (int t = 0; t < threads; ++t) {
+    vm[t] = new ViterbiMatrix();
+    vm[t]->AllocateBacktraceMatrix(Lq, max_Lt);
+    pm[t] = new PosteriorMatrix();
+    pm[t]->allocateMatrix(Lq, max_Lt);
+    dec[t] = new PosteriorDecoder(max_Lt, local != 0, Lq, 0.0f, zS73, zS33, zS37);
+  }
+  long sum = 0;
+  const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : sum)
+  for (int k = 0; k < n; ++k) {
+    const int th = omp_get_thread_num();
+    Hit hit;
+    hit.L = Lt[k];
+    hit.self = 0;
+    hit.ssm1 = hit.ssm2 = 0;
+    hit.i1 = ends[4 * k + 0];
+    hit.j1 = ends[4 * k + 1];
+    hit.i2 = ends[4 * k + 2];
+    hit.j2 = ends[4 * k + 3];
+    hit.nsteps = nsteps[k];
+    hit.i = new int[nsteps[k] + 2];
+    hit.j = new int[nsteps[k] + 2];
+    hit.states = new char[nsteps[k] + 2];
+    for (int s = 0; s <= nsteps[k]; ++s) {
+      hit.i[s] = v_i[path_off[k] + s];
+      hit.j[s] = v_j[path_off[k] + s];
+      hit.states[s] = 0;
+    }
+    hit.score = 1.0f;
+    HMM* t = ts[k];
+    dec[th]->memorizeHitValues(hit);
+    dec[th]->initializeForAlignment(*q, *t, hit, *vm[th], 0, t->L, 0);
+    dec[th]->forwardAlgorithm(*q, *t, hit, *pm[th], *vm[th], shift, 0);
+    dec[th]->backwardAlgorithm(*q, *t, hit, *pm[th], *vm[th], shift, 0);
+    dec[th]->macAlgorithm(*q, *t, hit, *pm[th], *vm[th], mact, 0);
+    dec[th]->backtraceMAC(*q, *t, *pm[th], *vm[th], 0, hit, corr);
+    sum += hit.nsteps;
+  }
+  const double dt = omp_get_wtime() - t0;
+  if (checksum) *checksum = sum;
+  for (int t = 0; t < threads; ++t) {
+    delete dec[t];
+    delete pm[t];
+    delete vm[t];
+  }
+  for (int k = 0; k < n; ++k) delete ts[k];
+  delete q;
+  return dt;
 }
 
 // list `which` (0 forward, 1 backward, 2 posterior) of the last ref_mac_realign call: returns the number of entries and

@@ -38,6 +38,8 @@ unsigned char* stripe(const unsigned char* plain, int Lq, int offset, int* W_out
 }
 }  // namespace
 
+#include <omp.h>
+#include <vector>
 extern "C" {
 
 int ref_prefilter_vecbytes() { return VECSIZE_INT * 4; }
@@ -60,6 +62,36 @@ int ref_prefilter_scores(const unsigned char* plain, int Lq, const unsigned char
   free(ws);
   free(qc);
   return 0;
+}
+
+// CPU BASELINE of bench.py (next_rows.N3_prefilter.reference_*_cells_per_s): the reference's two kernels over the database with
+// the reference's parallelisation (src/hhprefilter.cpp:466-479 and :528-556: #pragma omp parallel for schedule(static), one
+// workspace per thread).  which: 0 = ungapped_sse_score, 1 = swStripedByte.  Returns the seconds of the loop.
+double ref_prefilter_scores_timed(const unsigned char* plain, int Lq, const unsigned char* seqs, const long* offsets, int n_db,
+                                  int score_offset, int gap_init, int gap_extend, int which, int threads, long* checksum) {
+  int W;
+  unsigned char* qc = stripe(plain, Lq, score_offset, &W);
+  const int element_count = VECSIZE_INT * 4;
+  if (threads < 1) threads = 1;
+  std::vector<simd_int*> ws(threads);
+  for (int t = 0; t < threads; ++t) ws[t] = (simd_int*)malloc_simd_int(3 * (Lq + element_count));
+  Prefilter* pf = (Prefilter*)calloc(1, sizeof(Prefilter));
+  long sum = 0;
+  const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : sum)
+  for (int n = 0; n < n_db; ++n) {
+    simd_int* w = ws[omp_get_thread_num()];
+    unsigned char* s = const_cast<unsigned char*>(seqs + offsets[n]);
+    const int len = (int)(offsets[n + 1] - offsets[n]);
+    sum += which == 0 ? pf->ungapped_sse_score(qc, Lq, s, len, (unsigned char)score_offset, w)
+                      : pf->swStripedByte(qc, Lq, s, len, gap_init, gap_extend, w, w + W, w + 2 * W, score_offset);
+  }
+  const double dt = omp_get_wtime() - t0;
+  if (checksum) *checksum = sum;
+  for (int t = 0; t < threads; ++t) free(ws[t]);
+  free(pf);
+  free(qc);
+  return dt;
 }
 
 float ref_flog2(float x) { return flog2(x); }

@@ -15,7 +15,37 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from pyhhv import capi, synth  # noqa: E402
 
 
-def run(n=500, Lq=300, Lt=300, sample=16):
+def reference_rate(qp, qtr, tps, ttrs, hits, threads, local=1, shift=-0.03, mact=0.3501, corr=0.1):
+    """The reference's PosteriorDecoder on the given hits with PosteriorDecoderRunner's OpenMP loop over the templates
+    (oracle/ref_mac_harness.cpp ref_mac_realign_timed, oracle/_ref): seconds of the loop on `threads` host threads."""
+    import ctypes as C
+    from pyoracle import Ref
+    lib = Ref().lib
+    f = lib.ref_mac_realign_timed
+    f.restype = C.c_double
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    n = len(hits)
+    Lts = np.array([tps[h[0]].shape[0] - 1 for h in hits], np.int32)
+    col_off = np.zeros(n + 1, np.int64)
+    col_off[1:] = np.cumsum(Lts + 1)
+    tp = np.ascontiguousarray(np.concatenate([tps[h[0]] for h in hits]), np.float32)
+    ttr = np.ascontiguousarray(np.concatenate([ttrs[h[0]] for h in hits]), np.float32)
+    ends = np.ascontiguousarray([[h[2], h[3], h[4], h[5]] for h in hits], np.int32)
+    ns = np.array([h[6] for h in hits], np.int32)
+    path_off = np.zeros(n + 1, np.int64)
+    path_off[1:] = np.cumsum(ns + 1)
+    vi = np.ascontiguousarray(np.concatenate([np.asarray(h[7][:h[6] + 1], np.int32) for h in hits]))
+    vj = np.ascontiguousarray(np.concatenate([np.asarray(h[8][:h[6] + 1], np.int32) for h in hits]))
+    qp32, qtr32 = np.ascontiguousarray(qp, np.float32), np.ascontiguousarray(qtr, np.float32)
+    chk = C.c_long(0)
+    t = f(qp32.ctypes.data, qtr32.ctypes.data, qp32.shape[0] - 1, n, col_off.ctypes.data, Lts.ctypes.data, tp.ctypes.data, ttr.ctypes.data,
+          int(local), shift, mact, corr, ends.ctypes.data, ns.ctypes.data, path_off.ctypes.data, vi.ctypes.data, vj.ctypes.data,
+          int(threads), C.addressof(chk))
+    return t, int(chk.value)
+
+
+def run(n=500, Lq=300, Lt=300, sample=16, ref_threads=0):
     qp, qtr = synth.make_query(11, Lq)
     tps, ttrs = [], []
     lens = [Lt] * n
@@ -88,6 +118,14 @@ def run(n=500, Lq=300, Lt=300, sample=16):
         out["mismatches_vs_reference"] = bad
         out["ref_cpu_ms_per_hit_1core"] = round(t_ref / out["checked"] * 1e3, 3)
         out["ref_cpu_hits_per_s_1core"] = out["checked"] / t_ref
+    if ref_threads:
+        try:
+            # the whole batch on `ref_threads` host threads, the way the reference parallelises it (one template per thread at a time)
+            t_ref, chk = reference_rate(qp, qtr, tps, ttrs, hits, ref_threads)
+            out["reference_openmp"] = {"threads": ref_threads, "hits": n, "seconds": t_ref, "hits_per_s": n / t_ref, "ms": t_ref * 1e3,
+                                       "sum_nsteps": chk, "gpu_sum_nsteps": int(sc[:, 0].sum())}
+        except Exception as e:  # noqa: BLE001
+            out["reference_openmp"] = {"error": repr(e)}
     c.close()
     return out
 
@@ -97,7 +135,8 @@ def main():
     Lq = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     Lt = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     sample = int(sys.argv[4]) if len(sys.argv) > 4 else 16
-    print(json.dumps(run(n, Lq, Lt, sample)))
+    ref_threads = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    print(json.dumps(run(n, Lq, Lt, sample, ref_threads)))
 
 
 if __name__ == "__main__":

@@ -19,10 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from pyhhv import capi, synth  # noqa: E402
 
 
-def main():
-    n_db = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-    survivors = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-    n_realign = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+def run(n_db=200000, survivors=10000, n_realign=500):
     Lq, Lt, distinct = 300, 300, 512
     z = np.load(os.path.join(ROOT, "tests", "golden", "gonnet_pb_R.npz"))
     pb, R = z["pb"], z["R"]
@@ -109,10 +106,17 @@ def main():
            "stages_ms": {k: round(v, 2) for k, v in best.items() if k.endswith("_ms")},
            "survivors": best["survivors"], "realigned": best["realigned"], "related_in_top": best["related_in_top"],
            "mean_mac_cols": best["mean_mac_cols"]}
-    print(json.dumps(out))
     c.prefilter_free_db(pfdb)
     c.rawset_free(raw)
     c.close()
+    return out
+
+
+def main():
+    n_db = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+    survivors = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    n_realign = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+    print(json.dumps(run(n_db, survivors, n_realign)))
 
 
 if __name__ == "__main__":

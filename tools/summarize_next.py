@@ -57,7 +57,9 @@ def short(name):
 def main():
     os.makedirs(DST, exist_ok=True)
     pf, mac, mac2k = (last_json(os.path.join(SRC, n + ".txt")) for n in ("prefilter", "mac", "mac2k"))
-    summary = {"tag": TAG, "valu_issue_peak_lane_ops_per_s": PEAK, "bench_prefilter": pf, "bench_mac_500": mac, "bench_mac_2000": mac2k, "kernels": {}}
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import srchash
+    summary = {"tag": TAG, "kernel_sources_sha1": srchash.kernel_sources_sha1(srchash.NEXT_ROWS), "valu_issue_peak_lane_ops_per_s": PEAK, "bench_prefilter": pf, "bench_mac_500": mac, "bench_mac_2000": mac2k, "kernels": {}}
     txt = ["profiles/%s_next_rows_summary.txt -- rocprofv3 evidence for the widened rows (SURVEY.md 8f N3, N4), 1x MI355X" % TAG,
            "commands: tools/profile_next.sh (rocprofv3 --kernel-trace --stats; separate --pmc passes); summary by tools/summarize_next.py",
            "VALU-issue roofline: SQ_INSTS_VALU x 64 / kernel duration against %.1f T lane-ops/s" % (PEAK / 1e12), ""]

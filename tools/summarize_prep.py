@@ -8,7 +8,6 @@ import csv
 import glob
 import json
 import os
-import subprocess
 import sys
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r6"
@@ -33,11 +32,8 @@ def pmc(sub):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
 
 
-def head():
-    try:
-        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-    except Exception:
-        return os.environ.get("HHV_GIT_HEAD", "unknown")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import srchash  # noqa: E402
 
 
 stats = {}
@@ -56,7 +52,7 @@ for line in reversed(open(os.path.join(SRC, "stats.txt")).read().splitlines()):
         break
 cols = N * 301
 alg = cols * (128 + 112)
-out = {"tag": TAG, "git_head": head(), "templates": N, "Lt": 300, "algorithmic_bytes": alg, "bench_prepare": bench, "kernels": {}}
+out = {"tag": TAG, "kernel_sources_sha1": srchash.kernel_sources_sha1(srchash.PREP), "templates": N, "Lt": 300, "algorithmic_bytes": alg, "bench_prepare": bench, "kernels": {}}
 lines = ["%s_prep_summary -- on-device PrepareTemplateHMM (N2), %d templates x 300 columns, 1x MI355X (tools/profile_prep.sh)" % (TAG, N),
          "algorithmic HBM bytes per launch: %d columns x (128 B raw in + 112 B record out) = %.3f GB" % (cols, alg / 1e9)]
 for k, st in stats.items():

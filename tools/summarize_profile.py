@@ -22,7 +22,9 @@ def rows(pattern):
     return out
 
 
-summary = {"tag": tag, "kernel": KERNEL}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import srchash  # noqa: E402
+summary = {"tag": tag, "kernel": KERNEL, "kernel_sources_sha1": srchash.kernel_sources_sha1(srchash.VITERBI)}  # what the counters were taken on (bench.py: profile_stale)
 lines = []
 stats = rows("stats/**/*kernel_stats.csv")
 lines.append("== rocprofv3 --kernel-trace --stats (python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs1 ...)")
