@@ -140,3 +140,51 @@ def test_back_to_back_tiny_templates_ties_dead_transitions(hhv, oracle, Lq, loca
     assert np.array_equal(again.view(np.uint8), res.view(np.uint8))
     ts.free()
     c.close()
+
+
+@pytest.mark.parametrize("local", [0, 1])
+@pytest.mark.parametrize("Lq", [80, 300, 431])
+def test_subnormal_emission_products(hhv, oracle, Lq, local):
+    """Profile values around 2^-70: every product q.p[i][a] * t.p[j][a] of ScalarProd20Vec (src/hhviterbialgorithm.cpp:263-292
+    through simd.h) lies in [2^-149, 2^-126], i.e. is a SUBNORMAL float, and so is their sum - a build that flushed fp32
+    denormals (the kernels are compiled with .amdhsa_float_denorm_mode_32 3 = keep) would feed log2f4 a zero instead
+    (tools/soak.py's smallest values, 2^-99.999, have products that are zero in every arithmetic).  Score-only,
+    backtrace bytes, paths and Hit scores against the oracle and - where built - the reference's own Viterbi::Align."""
+    from pyhhv import synth
+    rng = np.random.default_rng(9000 + Lq + local)
+    par = make_params(local=local, shift=127.8)   # log2 of a column sum is ~ -128 +- 3: with this offset the alignments are real ones
+    qf, qtr = synth.make_query(52000 + Lq, Lq)
+    qf = (qf * np.float32(2.0 ** -66)).astype(np.float32)       # entries ~2^-70 .. 2^-66
+    lens = [1, 2, 3, 17, 64, 65, 130, 257, 300, 330]
+    tps, ttrs = [], []
+    for k, Lt in enumerate(lens):
+        p, tr = synth.make_homolog(53000 + 7 * k + Lq, (qf * np.float32(2.0 ** 66)).astype(np.float32), L=Lt) if k % 2 == 0 else synth.make_template(53000 + 7 * k + Lq, Lt)
+        scale = np.float32(2.0 ** -float(rng.integers(68, 72)))
+        tps.append((p * scale).astype(np.float32))
+        ttrs.append(tr)
+    # every product is subnormal and none is zero
+    assert np.float64(qf[1:].max()) * np.float64(max(t[1:].max() for t in tps)) < 2.0 ** -126
+    assert np.float64(qf[1:].min()) * np.float64(min(t[1:].min() for t in tps)) > 2.0 ** -149
+    c = hhv.Context(local=par["local"], egq=par["egq"], egt=par["egt"], shift=par["shift"], corr=par["corr"],
+                    ssw=par["ssw"], ss_mode=par["ss_mode"])
+    c.set_query(qf, qtr)
+    ts = c.upload(tps, ttrs)
+    res0 = c.align(ts)
+    res = c.align(ts, backtrace=True)
+    hits = c.hits(ts)
+    ref = Ref() if have_ref() else None
+    for e in range(len(lens)):
+        a = oracle.align(par, qf, qtr, tps[e], ttrs[e], want_path=True)
+        for r_, what in ((res0, "score-only"), (res, "backtrace")):
+            assert (a.i2, a.j2) == (r_["i2"][e], r_["j2"][e]), (what, Lq, local, e)
+            assert np.float32(a.score) == r_["score"][e], (what, Lq, local, e, a.score, r_["score"][e])
+        assert np.array_equal(c.backtrace_matrix(ts, e)[1:, 1:], a.bt[1:, 1:]), (Lq, local, e)
+        assert hits["nsteps"][e] == a.nsteps and hits["score"][e] == np.float32(a.hit_score)
+        ns, i_s, j_s, st, S = c.hit_path(ts, e)
+        assert np.array_equal(i_s[1:ns + 1], a.i_steps[1:ns + 1]) and np.array_equal(S[1:ns + 1], a.S[1:ns + 1])
+        if ref is not None:
+            r = ref.align_batch(par, qf, qtr, [tps[e]], [ttrs[e]], replicate=True, want_path=True)[0]
+            assert (r.i2, r.j2) == (a.i2, a.j2) and np.float32(r.score).tobytes() == np.float32(a.score).tobytes(), (Lq, local, e)
+            assert np.array_equal(r.bt[1:, 1:] & 0x7F, a.bt[1:, 1:] & 0x7F), (Lq, local, e)
+    ts.free()
+    c.close()

@@ -30,7 +30,10 @@ for N in 1 2 4 8; do
   [ $N -gt $MAXG ] && break
   echo "== N = $N" >&2
   timeout 900 python bench.py --gpus $N --steps 10 --warmup 3 $short > $OUT/bench_fixed_$N.json 2> $OUT/bench_fixed_$N.err
-  timeout 900 python bench.py --gpus $N --lengths zipf --local 1 --steps 10 --warmup 3 $short > $OUT/bench_zipf_$N.json 2> $OUT/bench_zipf_$N.err
+  timeout 900 python bench.py --gpus $N --lengths zipf --local 1 --steps 10 --warmup 3 $short --dump-topk $OUT/topk_zipf_ranks_$N.npy > $OUT/bench_zipf_$N.json 2> $OUT/bench_zipf_$N.err
+  # the verdict of the lease, not only its times: the merged top-K of N RANKS must be the list ONE rank gets from the same N
+  # shards run one after the other (--virtual-shards N: same hhv_shard_plan, same hhv_topk per shard, same hhv_merge_hits)
+  timeout 900 python bench.py --gpus 1 --virtual-shards $N --lengths zipf --local 1 --templates 125000 --steps 2 --warmup 1 $short --dump-topk $OUT/topk_zipf_virtual_$N.npy > $OUT/bench_zipf_virtual_$N.json 2> $OUT/bench_zipf_virtual_$N.err
   NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,P2P,NET timeout 900 ./build/sharded_search_rccl --world $N --templates $((20000 * N)) --steps 5 --check --json \
     > $OUT/native_$N.out 2> $OUT/native_$N.err
   NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,P2P,NET timeout 900 ./build/sharded_search_rccl --world $N --templates $((20000 * N)) --steps 5 --backtrace --json \
@@ -68,6 +71,13 @@ for n in (1, 2, 4, 8):
         if "config" in b:
             e[key]["workload"] = b["config"].get("workload")
             e[key]["shards"] = b["config"].get("shards")
+    try:
+        import numpy as np
+        a, b = np.load(os.path.join(out, "topk_zipf_ranks_%d.npy" % n)), np.load(os.path.join(out, "topk_zipf_virtual_%d.npy" % n))
+        e["merged_topk_equals_virtual_shards_on_one_gpu"] = bool(a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)))
+        e["merged_topk_records"] = int(a.shape[0])
+    except Exception as ex:
+        e["merged_topk_equals_virtual_shards_on_one_gpu"] = "not compared: %r" % (ex,)
     e["native_rccl"] = last_json(os.path.join(out, "native_%d.out" % n))
     e["native_rccl_backtrace"] = last_json(os.path.join(out, "native_bt_%d.out" % n))
     e["rccl_transport_lines"] = transport(os.path.join(out, "native_%d.err" % n))
@@ -79,6 +89,7 @@ import json
 d = json.load(open("gpurun_out/scale8.json"))
 for n, e in d["runs"].items():
     bf, bz, nr = e["bench_fixed"], e["bench_zipf"], e["native_rccl"]
-    print(n, "bench fixed %s cells/s | zipf %s | native %s (check %s, identical %s) | transport lines %d" % (
-        bf.get("value"), bz.get("value"), nr.get("cells_per_s"), nr.get("check_one_gpu"), nr.get("merged_identical_on_all_ranks"), len(e["rccl_transport_lines"])))
+    print(n, "bench fixed %s cells/s | zipf %s (top-K = virtual shards: %s) | native %s (check %s, identical %s) | transport lines %d" % (
+        bf.get("value"), bz.get("value"), e.get("merged_topk_equals_virtual_shards_on_one_gpu"), nr.get("cells_per_s"), nr.get("check_one_gpu"),
+        nr.get("merged_identical_on_all_ranks"), len(e["rccl_transport_lines"])))
 PY
