@@ -335,6 +335,11 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   a.bwd_list = lists ? (float*)(base + o_bwl) : nullptr;
   a.err = c->d_err;
   a.row_rng = (int2*)(base + o_rng);
+  {
+    // (measurement aid: HHV_MAC_SPARSE_MIN = 0 every hit sparse, a large number none)
+    static const int sparse_min = [] { const char* e = getenv("HHV_MAC_SPARSE_MIN"); return e ? atoi(e) : 385; }();
+    a.sparse_min_Lt = sparse_min;
+  }
   ms->d_fwd_list = a.fwd_list;
   ms->d_bwd_list = a.bwd_list;
   // (the kernels write the cells the reference visits: rows 1 .. Lq [- 1], active cells; everything else reads as "no entry")

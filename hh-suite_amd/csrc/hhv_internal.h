@@ -279,6 +279,9 @@ struct MacArgs {
   uint32_t* err;             // the context's device error word (DEV_ERR_MAC_TIMEOUT), may be null
   // [n][Lq+2] (first, last) unmasked template column of every query row (hhv_mac_rowrange_kernel), first > last = none
   int2* row_rng;
+  // hits whose template has this many columns or more run the dataflow kernels over the strips their rows' ranges need only
+  // (hhv_mac.hip StripSpan); their F_MM / posterior planes are cleared by the kernel that leaves row_rng
+  int32_t sparse_min_Lt;
 };
 struct MacMaskArgs {
   const int4* ends;          // [n] i1, j1, i2, j2 of the Viterbi alignment

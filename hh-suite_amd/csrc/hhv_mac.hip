@@ -143,6 +143,61 @@ __device__ __forceinline__ int2 rng_row(const MacArgs& a, int k, int i) {
   return p[i < 1 ? 1 : (i > a.Lq ? a.Lq : i)];
 }
 
+// SPARSE rows (round 6, hits whose template has MacArgs::sparse_min_Lt columns or more): the dataflow kernels visit, in row i, only
+// the strips [sa, sb] that can hold an active cell of the row OR that the next row will read (a masked cell there must read as
+// zero, and the buffer holds the row before last) - a 300 x 1400 hit whose band is 120 columns wide has 3-4 such strips a row
+// instead of 22.  Everything a unit reads is then either written by a visited unit of the row it reads or replaced by the zero
+// it stands for (the neighbour strip's last column, see `left`); the matrix planes are cleared beforehand (mask kernel), so
+// the cells nobody visits read as the reference's masked cells do.  The waves keep their DENSE unit numbers (counter value of
+// unit (i, s) as if every strip were visited) and post the row's last number when they leave a row: a waiter on a unit that
+// was skipped is released by the next post, and no wait changes its meaning.
+struct StripSpan {
+  int sa, sb;  // sa > sb: none
+};
+// forward geometry: strip s = columns 64 s + 1 .. 64 s + 64.  own: the row's active range; next: the next row's (empty = none)
+__device__ __forceinline__ StripSpan span_fwd(bool sparse, int2 own, int2 next, int ns) {
+  StripSpan r;
+  r.sa = 0;
+  r.sb = ns - 1;
+  if (!sparse) return r;
+  int lo = 0x7fffffff, hi = 0;
+  if (own.x <= own.y) lo = own.x, hi = own.y;
+  if (next.x <= next.y) lo = min(lo, max(1, next.x - 1)), hi = max(hi, next.y);  // row i+1 reads columns j-1 and j
+  if (lo > hi) {
+    r.sa = 1;
+    r.sb = 0;
+  } else {
+    r.sa = (lo - 1) >> 6;
+    r.sb = min(ns - 1, (hi - 1) >> 6);
+  }
+  return r;
+}
+// backward geometry: strip s = columns Lt - 1 - 64 s down to Lt - 64 - 64 s (column Lt is kept by the row's first step).
+// next: the range of row i - 1, which reads columns j and j + 1 of this row
+__device__ __forceinline__ StripSpan span_bwd(bool sparse, int2 own, int2 next, int ns, int Lt) {
+  StripSpan r;
+  r.sa = 0;
+  r.sb = ns - 1;
+  if (!sparse) return r;
+  int lo = 0x7fffffff, hi = 0;
+  if (own.x <= own.y) lo = own.x, hi = own.y;
+  if (next.x <= next.y) lo = min(lo, next.x), hi = max(hi, next.y + 1);
+  hi = min(hi, Lt - 1);
+  if (lo > hi) {
+    r.sa = 1;
+    r.sb = 0;
+  } else {
+    r.sa = (Lt - 1 - hi) >> 6;
+    r.sb = min(ns - 1, (Lt - 1 - lo) >> 6);
+  }
+  return r;
+}
+// the first strip >= sa that wave w of np owns (strips w, w + np, ..)
+__device__ __forceinline__ int first_own(int sa, int w, int np) { return sa + (((w - sa) % np) + np) % np; }
+__device__ __forceinline__ int2 rng_or_none(const MacArgs& a, int k, int i) {
+  return (i >= 1 && i <= a.Lq) ? (a.row_rng + (size_t)k * (a.Lq + 2))[i] : make_int2(1, 0);
+}
+
 // Template operands of column j: from the LDS copy made at kernel start (STAGE; one hit's template is read Lq times and a
 // lone wave per SIMD cannot hide a trip to L2 per strip), or from global memory when the template does not fit.
 template <bool STAGE>
@@ -862,20 +917,31 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
   if (tid == 0) h.scale[0] = h.scale[1] = h.scale[2] = 1.0;
   __syncthreads();
   const int ns = (Lt + 63) >> 6;
+  const bool sparse = Lt >= a.sparse_min_Lt;  // (see StripSpan)
   // strips of a row that P wave w works on
 #define N_OF(w) (ns > (w) ? (ns - (w) + MAC_NP - 1) / MAC_NP : 0)
   const LdsCnt dead = cnt + DF_DEAD;
   // unit (i, s) of the parallel part is done when its wave's counter has reached ...
-#define P_DONE(i, s) cnt + DF_P + ((s) % MAC_NP), ((i)-1) * N_OF((s) % MAC_NP) + (s) / MAC_NP + 1
+  // (a row takes N_OF + 1 numbers of a P wave's counter: its units, then "row finished" - the row's maximum is published between the
+  // last unit and that number, and the number of the last unit must not release those who wait for the maximum)
+#define P_DONE(i, s) cnt + DF_P + ((s) % MAC_NP), ((i)-1) * (N_OF((s) % MAC_NP) + 1) + (s) / MAC_NP + 1
+#define P_ROW_DONE(i, w_) cnt + DF_P + (w_), (i) * (N_OF(w_) + 1)
 
   if (wv < MAC_NP) {
     // ---- P: wave w works on strips w, w + MAC_NP, .. of every row ----
     const int w = wv, o1 = (w + 1) % MAC_NP, o2 = (w + 2) % MAC_NP, o3 = (w + 3) % MAC_NP;
     static_assert(MAC_NP >= 2 && MAC_NP <= 4, "the row-end wait names three waves (with fewer than four, some of them twice or this wave itself)");
-    int2 rr_cur = rng_row(a, k, 1), rr_nxt = rr_cur;  // active ranges of rows i and i + 1 (!STAGE)
-    unsigned char co_next = (!STAGE && w < ns && 1 + (w << 6) + lane <= Lt && rng_hits(rr_cur, 1 + (w << 6), 64 + (w << 6))) ? h.co[(size_t)pitch + 1 + (w << 6) + lane] : 1;
+    // active ranges of rows i .. i+3 (the last one requested a row before it is needed) and the strips of rows i, i+1
+    int2 rA = rng_or_none(a, k, 1), rB = rng_or_none(a, k, 2), rC = rng_or_none(a, k, 3), rD = rC;
+    StripSpan sp = span_fwd(sparse, rA, rB, ns), spn = sp;
+    // !STAGE: the mask byte of this wave's NEXT unit (fetched behind the unit before it, or at the end of the row before)
+    auto fetch_co = [&](int ni, int s_, int2 r) -> unsigned char {
+      const int nj = 1 + (s_ << 6) + lane;
+      return (ni <= Lq && nj <= Lt && rng_hits(r, 1 + (s_ << 6), 64 + (s_ << 6))) ? h.co[(size_t)ni * pitch + nj] : (unsigned char)1;
+    };
+    unsigned char co_next = 1;
+    if (!STAGE && first_own(sp.sa, w, MAC_NP) <= sp.sb) co_next = fetch_co(1, first_own(sp.sa, w, MAC_NP), rA);
     double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0, scale_i = 1.0;
-    int own = 0;
     // lanes 0-19: q.p[i], 20-24: q.tr[i-1][M2M, I2M, D2M, M2D, D2D], 25: q.tr[i][M2I]
     auto qrow = [&](int i) -> float {
       if (i > Lq || lane > 25) return 0.0f;
@@ -889,7 +955,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       if (i >= 2) {
         // the end of row i-1 (both waves, the same operations): its rescaling factor needs the other wave's strips too
         DF_EVENT(7, i, 7)
-        DF_WAIT(cnt + DF_P + o1, (i - 1) * N_OF(o1), dead, cnt + DF_P + o2, (i - 1) * N_OF(o2), cnt + DF_P + o3, (i - 1) * N_OF(o3));
+        DF_WAIT(P_ROW_DONE(i - 1, o1), dead, P_ROW_DONE(i - 1, o2), P_ROW_DONE(i - 1, o3));
         double scale_next = 1.0;
         if (i - 1 >= 2) {
           double Pmax = pmaxring[prv * MAC_NP];
@@ -914,10 +980,15 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           scale_prod *= scale_i;
       }
       DF_EVENT(7, i, 8)
-      if (!STAGE) {
-        rr_cur = rr_nxt;
-        rr_nxt = rng_row(a, k, i + 1);
+      if (i >= 2) {
+        rA = rB, rB = rC, rC = rD;
+        sp = spn;
       }
+      rD = rng_or_none(a, k, i + 3);
+      spn = span_fwd(sparse, rB, rC, ns);  // row i + 1
+      // sparse rows: this row's buffer held row i-2, whose chains (the waves of this row's parity) may have units that no unit
+      // of row i-1 waited for - they must be through before anything of row i is written (dense rows: implied by the unit waits)
+      if (sparse && i >= 3) DF_WAIT(cnt + DF_S + 2 * cur + 0, ((i - 1) >> 1) * ns, dead, cnt + DF_S + 2 * cur + 1, ((i - 1) >> 1) * ns);
       const float q_cur = q_next;
       q_next = qrow(i + 1);
       float qi[20];
@@ -941,7 +1012,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       DF_EVENT(8, i, 0)
       const unsigned char* co_row = sCo + cur * co_stride;
       const int above = ((i - 2) >> 1) * ns;  // units the sweep waves of row i-1's parity have finished before that row
-      for (int s = w; s < ns; s += MAC_NP) {
+      for (int s = first_own(sp.sa, w, MAC_NP); s <= sp.sb; s += MAC_NP) {
         if (i >= 2) {
           // row i-1's chains of this strip (and, in order, of the ones left of it) are final; its operands XB(.., strip s) and
           // its mask are consumed (the chain waves and the total are done with them), and so is everything of row i-2, whose
@@ -954,13 +1025,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
         const bool valid = j <= Lt;
         const int jc = valid ? j : Lt;
         const bool off = !valid || (STAGE ? co_row[jc] != 0 : co_next != 0);
-        if (!STAGE) {
-          // this wave's next unit: MAC_NP strips on, or its first strip of the next row
-          const bool last = s + MAC_NP >= ns;
-          const int ni = last ? i + 1 : i, nj = last ? 1 + (w << 6) + lane : j + 64 * MAC_NP;
-          const bool live = rng_hits(last ? rr_nxt : rr_cur, nj - lane, nj - lane + 63);
-          co_next = (ni <= Lq && (!last || w < ns) && nj <= Lt && live) ? h.co[(size_t)ni * pitch + nj] : 1;
-        }
+        if (!STAGE && s + MAC_NP <= sp.sb) co_next = fetch_co(i, s + MAC_NP, rA);  // this wave's next unit of the row
         const unsigned long long on_mask = __ballot(!off);
         if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
         if (on_mask == 0) {
@@ -1012,7 +1077,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           //                                           im = mm(j-1)*q[i][M2I]*t[j-1][M2M] + im(j-1)*q[i][I2I]*t[j-1][M2M]
           // mm(j-1) of the strip's first column is the other wave's (the strip to the left)
           double left = 0.0;
-          if (s > 0) {
+          if (s > sp.sa) {  // (the strip left of the row's first one holds no active cell: its F_MM is 0)
             DF_WAIT(P_DONE(i, s - 1), dead);
             left = ROW(cur, F_MM, s0);
           }
@@ -1027,39 +1092,46 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
             XB(1, j) = b_im;
           }
         }
-        if (s + MAC_NP >= ns) {
-          // this wave's last strip of the row
-          if (STAGE) {
-            unsigned char* co_nextrow = sCo + prv * co_stride;
-#pragma unroll
-            for (int q = 0; q < MAC_OWN; ++q) {
-              const int u = w + q * MAC_NP, jn = 1 + u * 64 + lane;
-              if (u < ns && jn <= Lt) co_nextrow[jn] = pre_co[q];
-            }
-          }
-          Pmax = wave_max_d(Pmax);
-          if (lane == 0) pmaxring[cur * MAC_NP + w] = Pmax;
-        }
 #if defined(HHV_EXP_MAC_TIMEOUT)
         if (w != 0)
 #endif
-        df_post(cnt + DF_P + w, ++own, lane);
+        df_post(cnt + DF_P + w, (i - 1) * (N_OF(w) + 1) + s / MAC_NP + 1, lane);
         DF_EVENT(2, i, s)
       }
+      // the end of this wave's row: the next row's mask bytes, the row's maximum, the row's last unit number
+      if (STAGE) {
+        unsigned char* co_nextrow = sCo + prv * co_stride;
+#pragma unroll
+        for (int q = 0; q < MAC_OWN; ++q) {
+          const int u = w + q * MAC_NP, jn = 1 + u * 64 + lane;
+          if (u < ns && jn <= Lt) co_nextrow[jn] = pre_co[q];
+        }
+      } else if (i < Lq && first_own(spn.sa, w, MAC_NP) <= spn.sb) {
+        co_next = fetch_co(i + 1, first_own(spn.sa, w, MAC_NP), rB);
+      }
+      Pmax = wave_max_d(Pmax);
+      if (lane == 0) pmaxring[cur * MAC_NP + w] = Pmax;
+#if defined(HHV_EXP_MAC_TIMEOUT)
+      if (w != 0)
+#endif
+      df_post(cnt + DF_P + w, i * (N_OF(w) + 1), lane);
     }
   } else if (wv < MAC_NP + 4) {
     // ---- the GD / IM chains of the rows of one parity ----
     const int par = (wv - MAC_NP) >> 1;
     const bool gdw = ((wv - MAC_NP) & 1) == 0;
     const LdsCnt mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
-    int done = 0;
     float qI2I_next = (!gdw && (par ? 1 : 2) <= Lq) ? h.qtr[(size_t)(par ? 1 : 2) * 7 + T_I2I] : 0.0f;  // fetched a row ahead
+    int2 rA = rng_or_none(a, k, par ? 1 : 2), rB = rng_or_none(a, k, par ? 2 : 3);  // ranges of rows i, i + 1 (a row of this wave ahead)
     for (int i = par ? 1 : 2; i <= Lq; i += 2) {
       const int cur = i & 1;
       const double qI2I = qI2I_next;
       qI2I_next = (!gdw && i + 2 <= Lq) ? h.qtr[(size_t)(i + 2) * 7 + T_I2I] : 0.0f;
+      const StripSpan sp = span_fwd(sparse, rA, rB, ns);
+      rA = rng_or_none(a, k, i + 2), rB = rng_or_none(a, k, i + 3);
+      const int base = ((i - 1) >> 1) * ns;  // units of this wave before row i
       double carry = 0.0;
-      for (int s = 0; s < ns; ++s) {
+      for (int s = sp.sa; s <= sp.sb; ++s) {
         DF_WAIT(P_DONE(i, s), dead);
         DF_EVENT(3, i, s)
         const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
@@ -1078,23 +1150,29 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
             carry = l1 == 63 ? y : 0.0;
           }
         }
-        df_post(mine, ++done, lane);
+        df_post(mine, base + s + 1, lane);
         DF_EVENT(4, i, s)
       }
+      df_post(mine, base + ns, lane);
     }
   } else {
     // ---- the total forward probability (:162-182), one chain through all units ----
     double Pf = LOCAL ? 1.0 : 0.0;
+    int2 rA = rng_or_none(a, k, 1), rB = rng_or_none(a, k, 2);
+    StripSpan sp_last = span_fwd(sparse, rA, rB, ns);
     for (int i = 1; i <= Lq; ++i) {
       const int cur = i & 1;
-      for (int s = 0; s < ns; ++s) {
+      const StripSpan sp = span_fwd(sparse, rA, rB, ns);
+      sp_last = sp;
+      rA = rB, rB = rng_or_none(a, k, i + 2);
+      if (lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
+      for (int s = sp.sa; s <= sp.sb; ++s) {
         DF_WAIT(P_DONE(i, s), dead);
         DF_EVENT(5, i, s)
         {
           // F_MM as the float the reference keeps (p_mm): stored by this wave, which never waits for global memory
           const int j = 1 + (s << 6) + lane;
           if (j <= Lt) h.mat[(size_t)i * pitch + j] = (float)XB(2, j);
-          if (s == 0 && lane == 0) h.mat[(size_t)i * pitch] = 0.0f;
         }
         if (LOCAL) {
           const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
@@ -1104,17 +1182,20 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
             if (lane == 0) Pf = mac_walk<1, 2>(&XB(2, 1 + (s << 6) + l0), nullptr, l1 - l0 + 1, Pf, 0.0);
           }
         }
-        if (s == ns - 1) {
-          DF_WAIT(cnt + DF_R, i, dead);
-          const double scale_next = rring[cur];
-          if (LOCAL) {
-            Pf *= scale_next;
-          } else if (i < Lq) {
-            Pf = (Pf + (float)ROW(cur, F_MM, Lt) * scale_next);
-          }
-        }
         df_post(cnt + DF_T, (i - 1) * ns + s + 1, lane);
         DF_EVENT(6, i, s)
+      }
+      {
+        // the end of the row (a sparse row's last strip need not be the template's: F_MM of column Lt is then 0)
+        DF_WAIT(cnt + DF_R, i, dead);
+        const double scale_next = rring[cur];
+        if (LOCAL) {
+          Pf *= scale_next;
+        } else if (i < Lq) {
+          const double fL = sp.sa <= sp.sb && sp.sb == ns - 1 ? ROW(cur, F_MM, Lt) : 0.0;
+          Pf = (Pf + (float)fL * scale_next);
+        }
+        df_post(cnt + DF_T, i * ns, lane);
       }
     }
     Pf = lane_d(Pf, 0);  // (lane 0 carried it)
@@ -1123,7 +1204,8 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       const int last = Lq & 1;
       for (int s0 = 0; s0 < Lt; s0 += 64) {
         const int j = 1 + s0 + lane;
-        const double f_mm = j <= Lt ? (double)(float)ROW(last, F_MM, j) : 0.0;
+        const bool seen = (s0 >> 6) >= sp_last.sa && (s0 >> 6) <= sp_last.sb;  // (strips row Lq did not visit hold an older row)
+        const double f_mm = (j <= Lt && seen) ? (double)(float)ROW(last, F_MM, j) : 0.0;
         double acc = Pf;
         for (int q = 0; q < 64; ++q) acc = shr1_d(acc, Pf) + f_mm;
         Pf = lane_d(acc, 63);
@@ -1135,6 +1217,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
   df_report(dead, a.err, lane);
   DF_TIMING_REPORT("forward")
 #undef P_DONE
+#undef P_ROW_DONE
 }
 
 #undef MAC_NP
@@ -1195,6 +1278,9 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
   }
   __syncthreads();
   const int ns = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 1;  // strips of columns Lt-1 .. 1 (Lt = 1: one strip without a valid lane)
+  // sparse rows (StripSpan); a hit whose Pforward is not a positive number keeps every strip: the reference's posterior is then
+  // F * (float)(B / Pforward) = NaN in EVERY cell, which only a visit writes
+  const bool sparse = Lt >= a.sparse_min_Lt && Pf > 0.0 && Pf < 1.0e300;
   const LdsCnt dead = cnt + DF_DEAD;
   // unit (i, s) of the parallel part is done when its wave's counter has reached ...
 #define P_DONE(i, s) cnt + DF_P + ((s) % MAC_NP), (Lq - 1 - (i)) * N_OF((s) % MAC_NP) + (s) / MAC_NP + 1
@@ -1206,10 +1292,16 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
     const int w = wv;
     double pmin = LOCAL ? sL : 0.0;
     double sc_next = Lq >= 2 ? h.scale[Lq] : 1.0;  // scale[i+1] of the row, fetched a row ahead
-    int2 rr_cur = rng_row(a, k, Lq - 1), rr_nxt = rr_cur;  // active ranges of rows i and i - 1 (!STAGE)
-    unsigned char co_nx = (!STAGE && Lq >= 2 && w < ns && Lt - 1 - (w << 6) - lane >= 1 && rng_hits(rr_cur, Lt - 64 - (w << 6), Lt - 1 - (w << 6)))
-                              ? h.co[(size_t)(Lq - 1) * pitch + Lt - 1 - (w << 6) - lane] : 1;
-    int own = 0;
+    // active ranges of rows i, i-1, i-2, i-3 (the last one requested a row before it is needed), strips of rows i and i-1
+    int2 rA = rng_or_none(a, k, Lq - 1), rB = rng_or_none(a, k, Lq - 2), rC = rng_or_none(a, k, Lq - 3), rD = rC;
+    StripSpan sp = span_bwd(sparse, rA, rB, ns, Lt), spn = sp;
+    // !STAGE: the mask byte of this wave's NEXT unit
+    auto fetch_co = [&](int ni, int s_, int2 r) -> unsigned char {
+      const int nj = Lt - 1 - (s_ << 6) - lane;
+      return (ni >= 1 && nj >= 1 && rng_hits(r, Lt - 64 - (s_ << 6), Lt - 1 - (s_ << 6))) ? h.co[(size_t)ni * pitch + nj] : (unsigned char)1;
+    };
+    unsigned char co_nx = 1;
+    if (!STAGE && Lq >= 2 && first_own(sp.sa, w, MAC_NP) <= sp.sb) co_nx = fetch_co(Lq - 1, first_own(sp.sa, w, MAC_NP), rA);
     // lanes 0-19: q.p[i+1], 20-25: q.tr[i][M2M, M2D, I2M, D2M, D2D, M2I]
     auto qrow = [&](int i) -> float {
       if (i < 1 || lane > 25) return 0.0f;
@@ -1224,10 +1316,12 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       sc_next = i >= 2 ? h.scale[i] : 1.0;
       pmin *= sc;
       if (pmin < DBL_MIN * 100) pmin = 0.0;
-      if (!STAGE) {
-        rr_cur = rr_nxt;
-        rr_nxt = rng_row(a, k, i - 1);
+      if (i <= Lq - 2) {
+        rA = rB, rB = rC, rC = rD;
+        sp = spn;
       }
+      rD = rng_or_none(a, k, i - 3);
+      spn = span_bwd(sparse, rB, rC, ns, Lt);  // row i - 1
       const float q_cur = q_next;
       q_next = qrow(i - 1);
       float qn[20];
@@ -1250,8 +1344,20 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
         }
         if (w == 0 && lane == 0 && i >= 2) pre_coL = h.co[(size_t)(i - 1) * pitch + Lt], pre_fL = h.mat[(size_t)(i - 1) * pitch + Lt];
       }
-      const unsigned char coL = STAGE ? co_l[Lt] : corow[Lt];  // the mask byte of column Lt, for P2's column-Lt step of this row
-      for (int s = w; s < ns; s += MAC_NP) {
+      // (!STAGE: column Lt outside the row's active range is masked - no trip to memory)
+      const unsigned char coL = STAGE ? co_l[Lt] : ((rA.x <= rA.y && Lt <= rA.y) ? corow[Lt] : (unsigned char)1);  // the mask byte of column Lt, for P2's column-Lt step of this row
+      if (w == 0) {
+        // the row's constants for the posterior waves.  The slot held row i+2's: both posterior waves are through with that row
+        // when they have started on row i+1, which the units of row i wait for - a wave without a unit in this (sparse) row waits here
+        if (i <= Lq - 3) DF_WAIT(cnt + DF_T + 0, (Lq - 2 - i) * ((ns + 1) >> 1), dead, cnt + DF_T + 1, (Lq - 2 - i) * (ns >> 1));
+        if (lane == 0) {
+          prow[cur * 4 + 0] = coL ? 1.0 : 0.0;
+          prow[cur * 4 + 1] = sc;
+          prow[cur * 4 + 2] = rl_f(q_cur, 25);
+        }
+        df_post(cnt + DF_R, Lq - i, lane);  // prow of row i is there (rows count from Lq - 1 = 1)
+      }
+      for (int s = first_own(sp.sa, w, MAC_NP); s <= sp.sb; s += MAC_NP) {
         // B_MM of row i+1 at this strip's columns and the one right of them is final; with it the chain waves of (i+1, s) are
         // done with XB(0 / 1), P2 with XB(2 / 3), the mask and the per-row ring.  Row i+2, whose buffer this unit overwrites,
         // has been read by this wave's units of row i+1 and by P2 (this wave waited for P2 of (i+2, s) before (i+1, s)); the
@@ -1266,22 +1372,11 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
           if (s + 1 < ns) DF_WAIT(P_DONE(i + 1, s + 1), dead);
         }
         DF_EVENT(1, i, s)
-        if (s == 0 && lane == 0) {
-          prow[cur * 4 + 0] = coL ? 1.0 : 0.0;
-          prow[cur * 4 + 1] = sc;
-          prow[cur * 4 + 2] = rl_f(q_cur, 25);
-        }
         const int j = Lt - 1 - (s << 6) - lane;  // descending: lane 0 is the rightmost column of the strip
         const bool valid = j >= 1;
         const int jc = valid ? j : 1;
         const bool off = !valid || (STAGE ? co_l[jc] != 0 : co_nx != 0);
-        if (!STAGE) {
-          // the next unit of this wave: MAC_NP strips on, or its first strip of row i - 1
-          const bool last = s + MAC_NP >= ns;
-          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (w << 6) - lane : j - 64 * MAC_NP;
-          const bool live = rng_hits(last ? rr_nxt : rr_cur, nj + lane - 63, nj + lane);
-          co_nx = (ni >= 1 && nj >= 1 && live) ? h.co[(size_t)ni * pitch + nj] : 1;
-        }
+        if (!STAGE && s + MAC_NP <= sp.sb) co_nx = fetch_co(i, s + MAC_NP, rA);  // this wave's next unit of the row
         const unsigned long long on_mask = __ballot(!off);
         if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
         if (on_mask == 0) {
@@ -1320,39 +1415,50 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
             XB(3, j) = e5;
           }
         }
-        if (s + MAC_NP >= ns && STAGE) {
-          // this wave's last strip of the row (the posterior waves are done with row i+1, whose values these replace: this
-          // wave waited for them before each of its units of row i)
-          unsigned char* co_n = sCo + prv * co_stride;
-          float* f_n = sF + prv * co_stride;
-#pragma unroll
-          for (int q = 0; q < MAC_OWN; ++q) {
-            const int u = w + q * MAC_NP, jn = Lt - 1 - (u << 6) - lane;
-            if (u < ns && jn >= 1) co_n[jn] = pre_co[q], f_n[jn] = pre_f[q];
-          }
-          if (w == 0 && lane == 0) co_n[Lt] = pre_coL, f_n[Lt] = pre_fL;
-        }
 #if defined(HHV_EXP_MAC_TIMEOUT)
         if (w != 0)
 #endif
-        df_post(cnt + DF_P + w, ++own, lane);
+        df_post(cnt + DF_P + w, (Lq - 1 - i) * N_OF(w) + s / MAC_NP + 1, lane);
         DF_EVENT(2, i, s)
       }
+      // the end of this wave's row
+      if (STAGE) {
+        // the next row's mask bytes and F_MM values replace row i+1's, which the posterior waves read: the units of row i waited
+        // for them strip by strip; a sparse row has not visited every strip, so wait for the end of their row i+1
+        if (sparse && i <= Lq - 2) DF_WAIT(cnt + DF_T + 0, (Lq - 1 - i) * ((ns + 1) >> 1), dead, cnt + DF_T + 1, (Lq - 1 - i) * (ns >> 1));
+        unsigned char* co_n = sCo + prv * co_stride;
+        float* f_n = sF + prv * co_stride;
+#pragma unroll
+        for (int q = 0; q < MAC_OWN; ++q) {
+          const int u = w + q * MAC_NP, jn = Lt - 1 - (u << 6) - lane;
+          if (u < ns && jn >= 1) co_n[jn] = pre_co[q], f_n[jn] = pre_f[q];
+        }
+        if (w == 0 && lane == 0) co_n[Lt] = pre_coL, f_n[Lt] = pre_fL;
+      } else if (i >= 2 && first_own(spn.sa, w, MAC_NP) <= spn.sb) {
+        co_nx = fetch_co(i - 1, first_own(spn.sa, w, MAC_NP), rB);
+      }
+#if defined(HHV_EXP_MAC_TIMEOUT)
+      if (w != 0)
+#endif
+      df_post(cnt + DF_P + w, (Lq - i) * N_OF(w), lane);
     }
   } else if (wv < MAC_NP + 4) {
     // ---- the GD / IM chains of the rows of one parity ----
     const int par = (wv - MAC_NP) >> 1;
     const bool gdw = ((wv - MAC_NP) & 1) == 0;
     const LdsCnt mine = cnt + DF_S + 2 * par + (gdw ? 0 : 1);
-    int done = 0;
     const int i_first = ((Lq - 1) & 1) == par ? Lq - 1 : Lq - 2;
     float qI2I_next = (!gdw && i_first >= 1) ? h.qtr[(size_t)i_first * 7 + T_I2I] : 0.0f;  // fetched a row ahead
+    int2 rA = rng_or_none(a, k, i_first), rB = rng_or_none(a, k, i_first - 1);  // ranges of rows i, i - 1 (a row of this wave ahead)
     for (int i = i_first; i >= 1; i -= 2) {
       const int cur = i & 1;
       const double qI2I = qI2I_next;
       qI2I_next = (!gdw && i - 2 >= 1) ? h.qtr[(size_t)(i - 2) * 7 + T_I2I] : 0.0f;
+      const StripSpan sp = span_bwd(sparse, rA, rB, ns, Lt);
+      rA = rng_or_none(a, k, i - 2), rB = rng_or_none(a, k, i - 3);
+      const int base = ((Lq - 1 - i) >> 1) * ns;  // units of this wave before row i
       double carry = 0.0;  // curr[Lt].gd = curr[Lt].im = 0
-      for (int s = 0; s < ns; ++s) {
+      for (int s = sp.sa; s <= sp.sb; ++s) {
         DF_WAIT(P_DONE(i, s), dead);
         DF_EVENT(3, i, s)
         const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
@@ -1369,9 +1475,10 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
             carry = l1 == 63 ? y : 0.0;
           }
         }
-        df_post(mine, ++done, lane);
+        df_post(mine, base + s + 1, lane);
         DF_EVENT(4, i, s)
       }
+      df_post(mine, base + ns, lane);
     }
   } else {
     // ---- P2: wave v works on strips v, v+2, .. of every row ----
@@ -1391,53 +1498,56 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       }
     }
     float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
-    int2 rr_cur = rng_row(a, k, Lq - 1), rr_nxt = rr_cur;  // (!STAGE) F_MM of a strip outside its row's active range: the 0 the forward pass left
-    float f_nx = (!STAGE && Lq >= 2 && v < ns && Lt - 1 - (v << 6) - lane >= 1 && rng_hits(rr_cur, Lt - 64 - (v << 6), Lt - 1 - (v << 6)))
-                     ? h.mat[(size_t)(Lq - 1) * pitch + Lt - 1 - (v << 6) - lane] : 0.0f;
-    int own = 0;
-    // (a wave with units has one in every row - strip v - so its scale_prod sees every row's factor)
-    for (int i = Lq - 1; i >= 1 && v < ns; --i) {
+    // (!STAGE) F_MM of this wave's NEXT unit; a strip outside its row's active range holds the 0 the forward pass left
+    int2 rA = rng_or_none(a, k, Lq - 1), rB = rng_or_none(a, k, Lq - 2), rC = rng_or_none(a, k, Lq - 3), rD = rC;
+    StripSpan sp = span_bwd(sparse, rA, rB, ns, Lt), spn = sp;
+    auto fetch_f = [&](int ni, int s_, int2 r) -> float {
+      const int nj = Lt - 1 - (s_ << 6) - lane;
+      return (ni >= 1 && nj >= 1 && rng_hits(r, Lt - 64 - (s_ << 6), Lt - 1 - (s_ << 6))) ? h.mat[(size_t)ni * pitch + nj] : 0.0f;
+    };
+    float f_nx = 0.0f;
+    if (!STAGE && Lq >= 2 && first_own(sp.sa, v, 2) <= sp.sb) f_nx = fetch_f(Lq - 1, first_own(sp.sa, v, 2), rA);
+    const int n_own = (ns + 1 - v) >> 1;  // strips of a row this wave owns
+    // (every row passes here, with or without units of this wave: scale_prod sees every row's factor)
+    for (int i = Lq - 1; i >= 1; --i) {
       const int cur = i & 1;
-      double qM2I = 0.0;
-      if (!STAGE) {
-        rr_cur = rr_nxt;
-        rr_nxt = rng_row(a, k, i - 1);
+      if (i <= Lq - 2) {
+        rA = rB, rB = rC, rC = rD;
+        sp = spn;
       }
+      rD = rng_or_none(a, k, i - 3);
+      spn = span_bwd(sparse, rB, rC, ns, Lt);  // row i - 1
       float* row = h.mat + (size_t)i * pitch;
       const float* f_l = sF + cur * co_stride;  // STAGE: F_MM of the row, staged by the P waves
-      for (int s = v; s < ns; s += 2) {
+      // the row's constants, left by the first P wave before its units of the row
+      DF_WAIT(cnt + DF_R, Lq - i, dead);
+      {
+        const double sc = prow[cur * 4 + 1];
+        scale_prod *= sc;
+        if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
+      }
+      const double qM2I = prow[cur * 4 + 2];
+      if (v == 0 && lane == 0) {
+        // column Lt (:58-71), ahead of every unit of the row (the row below reads it with its rightmost strip)
+        const float fL = STAGE ? f_l[Lt] : ((rA.x <= rA.y && Lt <= rA.y) ? row[Lt] : 0.0f);
+        if (prow[cur * 4 + 0] != 0.0) {
+          row[Lt] = 0.0f;
+          ROW(cur, F_MM, Lt) = 0.0;
+        } else {
+          ROW(cur, F_MM, Lt) = scale_prod;
+          row[Lt] = (float)(fL * scale_prod / Pf);
+        }
+        ROW(cur, F_GD, Lt) = ROW(cur, F_IM, Lt) = ROW(cur, F_DG, Lt) = ROW(cur, F_MI, Lt) = 0.0;
+      }
+      for (int s = first_own(sp.sa, v, 2); s <= sp.sb; s += 2) {
         const int need = ((Lq - 1 - i) >> 1) * ns + s + 1;  // units of the chain waves of this row's parity
         DF_WAIT(cnt + DF_S + 2 * cur + 0, need, dead, cnt + DF_S + 2 * cur + 1, need);
         DF_EVENT(5, i, s)
-        if (s == v) {
-          // the row's constants, left by the first P wave with its unit (i, 0), which the chain waves waited for
-          const double sc = prow[cur * 4 + 1];
-          scale_prod *= sc;
-          if (scale_prod < DBL_MIN * 100) scale_prod = 0.0;
-          qM2I = prow[cur * 4 + 2];
-        }
-        if (s == 0 && lane == 0) {
-          // column Lt (:58-71)
-          const float fL = STAGE ? f_l[Lt] : row[Lt];
-          if (prow[cur * 4 + 0] != 0.0) {
-            row[Lt] = 0.0f;
-            ROW(cur, F_MM, Lt) = 0.0;
-          } else {
-            ROW(cur, F_MM, Lt) = scale_prod;
-            row[Lt] = (float)(fL * scale_prod / Pf);
-          }
-          ROW(cur, F_GD, Lt) = ROW(cur, F_IM, Lt) = ROW(cur, F_DG, Lt) = ROW(cur, F_MI, Lt) = 0.0;
-        }
         const int j = Lt - 1 - (s << 6) - lane;
         const bool valid = j >= 1;
         const int jc = valid ? j : 1;
         const float f_cur = STAGE ? (valid ? f_l[jc] : 0.0f) : f_nx;
-        if (!STAGE) {
-          const bool last = s + 2 >= ns;
-          const int ni = last ? i - 1 : i, nj = last ? Lt - 1 - (v << 6) - lane : j - 128;
-          const bool live = rng_hits(last ? rr_nxt : rr_cur, nj + lane - 63, nj + lane);
-          f_nx = (ni >= 1 && nj >= 1 && live) ? h.mat[(size_t)ni * pitch + nj] : 0.0f;
-        }
+        if (!STAGE && s + 2 <= sp.sb) f_nx = fetch_f(i, s + 2, rA);
         const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
         const bool off = !((on_mask >> lane) & 1);
         double mm = 0.0;
@@ -1445,13 +1555,15 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
           float tt[7];
           load_tt<STAGE>(h, sTt, jc, tt);
           const double tM2M = tt[T_M2M];
-          const double gr = ROW(cur, F_GD, jc + 1), ir = ROW(cur, F_IM, jc + 1);  // curr[j+1].gd / .im
+          double gr = ROW(cur, F_GD, jc + 1), ir = ROW(cur, F_IM, jc + 1);  // curr[j+1].gd / .im
+          // (the strip right of a sparse row's first one holds no active cell - its chains are 0 - but was not visited)
+          if (lane == 0 && s == sp.sa && s > 0) gr = ir = 0.0;
           mm = (ROW(cur, F_MM, jc) + gr * tt[T_M2D] + ir * qM2I * tM2M + XB(2, jc) + XB(3, jc));  // :86-93
           if (off) mm = 0.0;
           if (valid) ROW(cur, F_MM, j) = mm;
         }
         // B_MM is what the row below waits for: posted before the posterior is worked out
-        df_post(cnt + DF_T + v, ++own, lane);
+        df_post(cnt + DF_T + v, (Lq - 1 - i) * n_own + (s >> 1) + 1, lane);
         DF_EVENT(6, i, s)
         if (on_mask == 0) {
           if (valid) row[j] = f_cur * (float)(0.0 / Pf);  // F * (float)(B / Pforward) with B = 0 (NaN if Pforward is 0, as in the reference)
@@ -1467,6 +1579,8 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
           }
         }
       }
+      if (!STAGE && i >= 2 && first_own(spn.sa, v, 2) <= spn.sb) f_nx = fetch_f(i - 1, first_own(spn.sa, v, 2), rB);
+      df_post(cnt + DF_T + v, (Lq - i) * n_own, lane);  // the row's last unit number
     }
   }
   df_report(dead, a.err, lane);
@@ -1621,6 +1735,10 @@ __global__ void __launch_bounds__(256) hhv_mac_rowrange_kernel(MacArgs a) {
   const int Lq = a.Lq, Lt = a.Lt[k], pitch = Lt + 1;
   const unsigned char* co = a.celloff + a.mat_off[k];
   int2* rng = a.row_rng + (size_t)k * (Lq + 2);
+  if (Lt >= a.sparse_min_Lt) {  // sparse rows: the cells nobody visits must read 0 (StripSpan)
+    float* mat = a.mat + a.mat_off[k];
+    for (int c = threadIdx.x; c < (Lq + 1) * pitch; c += 256) mat[c] = 0.0f;
+  }
   for (int i = wave; i <= Lq; i += 4) {
     int lo = 0x7fffffff, hi = 0;
     for (int j0 = 1; j0 <= Lt && i >= 1; j0 += 64) {
@@ -1985,6 +2103,10 @@ __global__ void __launch_bounds__(256) hhv_mac_mask_kernel(MacArgs a, MacMaskArg
       if (++j == pitch) j = 0, ++i;
     }
     co4[c >> 2] = v;
+  }
+  if (Lt >= a.sparse_min_Lt) {  // sparse rows: the cells nobody visits must read 0 (StripSpan)
+    float4* mat4 = reinterpret_cast<float4*>(a.mat + a.mat_off[k]);  // (the planes start at multiples of four elements and are padded to one)
+    for (int c = tid; c < (cells + 3) / 4; c += 256) mat4[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   __syncthreads();
   constexpr int W = 2 * 40 + 1;  // FWD_BKW_PATHWITDH = 40 (src/hhdecl.h:37)
