@@ -339,6 +339,8 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
     // (measurement aid: HHV_MAC_SPARSE_MIN = 0 every hit sparse, a large number none)
     static const int sparse_min = [] { const char* e = getenv("HHV_MAC_SPARSE_MIN"); return e ? atoi(e) : 385; }();
     a.sparse_min_Lt = sparse_min;
+    a.ring_min_Lt = 0;
+    a.ring_strips = 0;  // (set by launch_mac_class for the single-wave kernels of the longest class)
   }
   ms->d_fwd_list = a.fwd_list;
   ms->d_bwd_list = a.bwd_list;

@@ -282,6 +282,8 @@ struct MacArgs {
   // hits whose template has this many columns or more run the dataflow kernels over the strips their rows' ranges need only
   // (hhv_mac.hip StripSpan); their F_MM / posterior planes are cleared by the kernel that leaves row_rng
   int32_t sparse_min_Lt;
+  int32_t ring_min_Lt;       // ... and only templates of this many columns or more (shorter ones are in the class for capacity)
+  int32_t ring_strips;       // single-wave kernels of the class without LDS: hits whose widest row (row_rng[0].x) is at most this many strips belong to the ring kernels (0 = none)
 };
 struct MacMaskArgs {
   const int4* ends;          // [n] i1, j1, i2, j2 of the Viterbi alignment
@@ -314,7 +316,7 @@ struct MacClasses {
   int max_Lt[MAC_CLASSES];  // longest template per class
 };
 // streams the class launches are spread over (launch_mac): s[0 .. MAC_CHAINS-1], fork / join events
-constexpr int MAC_CHAINS = 4;
+constexpr int MAC_CHAINS = 7;  // (one per class: hhv_create asks the runtime for eight hardware queues)
 struct MacStreams {
   void* s[MAC_CLASSES];
   void* fork;

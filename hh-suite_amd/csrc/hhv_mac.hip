@@ -192,6 +192,47 @@ __device__ __forceinline__ StripSpan span_bwd(bool sparse, int2 own, int2 next, 
   }
   return r;
 }
+// RING (round 6: templates too long for the dataflow kernels' plain LDS layout, ~1450 columns): the row state lives in a ring of
+// MAC_RING_STRIPS strips of 64 columns - strip s in slot s mod MAC_RING_STRIPS, a strip's columns side by side - which holds any
+// row whose visited span is at most that many strips, wherever in the template it lies (sparse rows, above: a 300 x 1800 hit
+// needs 3-4 strips a row).  Hits with a wider row (a large rectangle beside the alignment) stay with the single-wave kernels:
+// the mask kernel leaves the widest span of the hit's rows in rng[0].x, and a workgroup of the kind that is not the hit's returns.
+constexpr int MAC_RING_STRIPS = 22;                    // 22 x 64 columns x 14 doubles = 154 KB
+constexpr int MAC_RING_COLS = MAC_RING_STRIPS * 64;    // slots 1 .. MAC_RING_COLS; slot MAC_RING_COLS + 1: column Lt of the backward pass
+template <bool RING>
+__device__ __forceinline__ int mac_col_f(int j) {  // forward geometry: strip of column j = (j - 1) >> 6
+  if (!RING) return j;
+  const int q = j - 1, st = q >> 6;
+  return j <= 0 ? 0 : (st % MAC_RING_STRIPS) * 64 + (q & 63) + 1;
+}
+template <bool RING>
+__device__ __forceinline__ int mac_col_b(int j, int Lt) {  // backward geometry: strip of column j <= Lt - 1 = (Lt - 1 - j) >> 6
+  if (!RING) return j;
+  const int q = Lt - 1 - j, st = q >> 6;
+  return q < 0 ? MAC_RING_COLS + 1 : (st % MAC_RING_STRIPS) * 64 + (63 - (q & 63)) + 1;
+}
+// the widest row of a hit in strips (forward and backward geometry), from the rows' ranges: what decides whether the ring holds it
+__device__ __forceinline__ int mac_row_span(int2 prev, int2 own, int2 next, int Lt) {
+  const int nsf = (Lt + 63) >> 6, nsb = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 1;
+  StripSpan f, b;
+  {
+    int lo = 0x7fffffff, hi = 0;
+    if (own.x <= own.y) lo = own.x, hi = own.y;
+    if (next.x <= next.y) lo = min(lo, max(1, next.x - 1)), hi = max(hi, next.y);
+    f.sa = lo > hi ? 1 : (lo - 1) >> 6;
+    f.sb = lo > hi ? 0 : min(nsf - 1, (hi - 1) >> 6);
+  }
+  {
+    int lo = 0x7fffffff, hi = 0;
+    if (own.x <= own.y) lo = own.x, hi = own.y;
+    if (prev.x <= prev.y) lo = min(lo, prev.x), hi = max(hi, prev.y + 1);
+    hi = min(hi, Lt - 1);
+    b.sa = lo > hi ? 1 : (Lt - 1 - hi) >> 6;
+    b.sb = lo > hi ? 0 : min(nsb - 1, (Lt - 1 - lo) >> 6);
+  }
+  return max(f.sb - f.sa + 1, b.sb - b.sa + 1);
+}
+
 // the first strip >= sa that wave w of np owns (strips w, w + np, ..)
 __device__ __forceinline__ int first_own(int sa, int w, int np) { return sa + (((w - sa) % np) + np) % np; }
 __device__ __forceinline__ int2 rng_or_none(const MacArgs& a, int k, int i) {
@@ -261,6 +302,7 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = GROWS ? a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2) : reinterpret_cast<double*>(smem);
   const int k = a.sel[blockIdx.x], lane = threadIdx.x;
+  if (GROWS && a.ring_strips > 0 && a.Lt[k] >= a.ring_min_Lt && (a.row_rng + (size_t)k * (a.Lq + 2))[0].x <= a.ring_strips) return;  // the ring kernels' hit (launch_mac_class)
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));  // layout sized for the longest template
@@ -490,6 +532,7 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = GROWS ? a.row_scratch + (size_t)blockIdx.x * 10 * (a.lds_cols + 2) : reinterpret_cast<double*>(smem);
   const int k = a.sel[blockIdx.x], lane = threadIdx.x;
+  if (GROWS && a.ring_strips > 0 && a.Lt[k] >= a.ring_min_Lt && (a.row_rng + (size_t)k * (a.Lq + 2))[0].x <= a.ring_strips) return;  // the ring kernels' hit (launch_mac_class)
   const HitView h = view(a, k);
   const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
   float* sTp = reinterpret_cast<float*>(rows + (size_t)10 * (a.lds_cols + 2));
@@ -708,7 +751,11 @@ constexpr int MAC_ROW_FIELDS = 14;    // two rows of five states + XB(0..3)
 constexpr int MAC_DF_STRIPS = 24;     // strips per row the mask table holds (LDS limits the templates of these kernels to ~1420 columns)
 constexpr int MAC_CTL_DOUBLES = 64;   // behind the rows: masks [2][24] (48), per-row rings (forward 2 + 2 x MAC_NP, backward 8), 12 counters (6)
 static_assert(2 * MAC_DF_STRIPS + 2 + 2 * 4 + 6 <= MAC_CTL_DOUBLES, "control block");
-#define XB(k, j) rows[(10 + (k)) * stride + (j)]
+// (the dataflow kernels address columns through DFC: the plain layout or the ring, mac_col_f / mac_col_b)
+#undef ROW
+#define ROW(r, f, j) rows[((r)*5 + (f)) * stride + DFC(j)]
+#define XB(k, j) rows[(10 + (k)) * stride + DFC(j)]
+#define MSK(s) (RING ? (s) % MAC_RING_STRIPS : (s))
 // Wavefronts of the parallel part (wave w works on strips w, w + MAC_NP, .. of every row): as many as keep the workgroup at EIGHT
 // wavefronts.  The kernels need ~100 VGPRs, i.e. four waves per SIMD, sixteen per CU: two workgroups of eight share a CU (500 hits on
 // 256 CUs), two of nine or ten do not - measured: four P waves forward 1.27 -> 1.8 ms, three backward 1.26 -> 1.63 ms.
@@ -880,16 +927,19 @@ __device__ __forceinline__ void stage_template_wg(const HitView& h, float* sTp, 
   for (int e = tid; e < (h.Lt + 1) * 8; e += nt) sTt[e] = (e & 7) < 7 ? h.ttr[(size_t)(e >> 3) * 7 + (e & 7)] : 0.0f;
 }
 
-template <bool LOCAL, bool STAGE>
+#define DFC(j) mac_col_f<RING>(j)
+template <bool LOCAL, bool STAGE, bool RING = false>
 __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacArgs a) {
+  static_assert(!(RING && STAGE), "the ring is for templates that do not fit LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = reinterpret_cast<double*>(smem);
   constexpr int NT = MAC_DF_THREADS;
   const int k = a.sel[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
+  if (RING && (a.Lt[k] < a.ring_min_Lt || (a.row_rng + (size_t)k * (a.Lq + 2))[0].x > MAC_RING_STRIPS)) return;  // a short template in this class for capacity, or a row wider than the ring: the single-wave kernels
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   DF_TIMING_DECL
   const HitView h = view(a, k);
-  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = RING ? MAC_RING_COLS + 2 : Lt + 2;
   const size_t cols = (size_t)a.lds_cols + 2;  // layout sized for the longest template of the launch
   double* ctl = rows + MAC_ROW_FIELDS * cols;
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS] active lanes of (row & 1, strip)
@@ -917,7 +967,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
   if (tid == 0) h.scale[0] = h.scale[1] = h.scale[2] = 1.0;
   __syncthreads();
   const int ns = (Lt + 63) >> 6;
-  const bool sparse = Lt >= a.sparse_min_Lt;  // (see StripSpan)
+  const bool sparse = RING || Lt >= a.sparse_min_Lt;  // (see StripSpan)
   // strips of a row that P wave w works on
 #define N_OF(w) (ns > (w) ? (ns - (w) + MAC_NP - 1) / MAC_NP : 0)
   const LdsCnt dead = cnt + DF_DEAD;
@@ -1027,7 +1077,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
         const bool off = !valid || (STAGE ? co_row[jc] != 0 : co_next != 0);
         if (!STAGE && s + MAC_NP <= sp.sb) co_next = fetch_co(i, s + MAC_NP, rA);  // this wave's next unit of the row
         const unsigned long long on_mask = __ballot(!off);
-        if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
+        if (lane == 0) masks[cur * MAC_DF_STRIPS + MSK(s)] = on_mask;
         if (on_mask == 0) {
           // a strip without a single active cell: all five states are zero, the running sums are unchanged
           if (valid) {
@@ -1134,7 +1184,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
       for (int s = sp.sa; s <= sp.sb; ++s) {
         DF_WAIT(P_DONE(i, s), dead);
         DF_EVENT(3, i, s)
-        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + MSK(s)];
         if (on_mask == 0) {
           carry = 0.0;
         } else {
@@ -1175,7 +1225,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
           if (j <= Lt) h.mat[(size_t)i * pitch + j] = (float)XB(2, j);
         }
         if (LOCAL) {
-          const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+          const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + MSK(s)];
           if (on_mask != 0) {
             // the summands of the active span in column order (inactive columns hold 0)
             const int l0 = __builtin_ctzll(on_mask), l1 = 63 - __builtin_clzll(on_mask);
@@ -1219,6 +1269,7 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
 #undef P_DONE
 #undef P_ROW_DONE
 }
+#undef DFC
 
 #undef MAC_NP
 #define MAC_NP MAC_NP_BWD
@@ -1226,16 +1277,19 @@ __global__ void __launch_bounds__(MAC_DF_THREADS) hhv_mac_forward_df_kernel(MacA
 // sum pmin + pmatch*q[M2M]*t[M2M] (into the F_MM slot) and the two last summands (XB(2 / 3, j)); the sweep waves follow; P2
 // (wave 5) completes B_MM = (((partial + gd(j+1)*t[M2D]) + im(j+1)*q[M2I]*t[M2M]) + XB2) + XB3 - the reference's left-to-right
 // sum (src/hhbackwardalgorithm.cpp:86-93) - and turns F_MM into the posterior.  P of (i-1, s) waits for P2 of (i, s).
-template <bool LOCAL, bool STAGE, bool LISTS>
+#define DFC(j) mac_col_b<RING>((j), Lt)
+template <bool LOCAL, bool STAGE, bool LISTS, bool RING = false>
 __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(MacArgs a) {
+  static_assert(!(RING && STAGE), "the ring is for templates that do not fit LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* rows = reinterpret_cast<double*>(smem);
   constexpr int NT = MAC_DFB_THREADS;
   const int k = a.sel[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
+  if (RING && (a.Lt[k] < a.ring_min_Lt || (a.row_rng + (size_t)k * (a.Lq + 2))[0].x > MAC_RING_STRIPS)) return;  // a short template in this class for capacity, or a row wider than the ring: the single-wave kernels
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   DF_TIMING_DECL
   const HitView h = view(a, k);
-  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = Lt + 2;
+  const int Lq = h.Lq, Lt = h.Lt, pitch = h.pitch, stride = RING ? MAC_RING_COLS + 2 : Lt + 2;
   const size_t cols = (size_t)a.lds_cols + 2;
   double* ctl = rows + MAC_ROW_FIELDS * cols;
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(ctl);  // [2][MAC_DF_STRIPS]
@@ -1265,22 +1319,29 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
   if (tid < DF_N) cnt_mem[tid] = 0;
   __syncthreads();
   const double sL = h.scale[Lq + 1];
-  // row Lq (:19-29); row i lives in buffer i & 1
-  for (int j = 1 + tid; j <= Lt; j += NT) {
-    float* pv = h.mat + (size_t)Lq * pitch + j;
-    if (h.co[(size_t)Lq * pitch + j]) {
-      *pv = 0.0f;
-      ROW(Lq & 1, F_MM, j) = 0.0;
-    } else {
-      ROW(Lq & 1, F_MM, j) = sL;
-      *pv = (float)(*pv * sL / Pf);
+  const int ns = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 1;  // strips of columns Lt-1 .. 1 (Lt = 1: one strip without a valid lane)
+  // row Lq (:19-29); row i lives in buffer i & 1.  (RING: only the strips row Lq-1 reads - and column Lt - have a slot)
+  {
+    const StripSpan spq = span_bwd(true, rng_or_none(a, k, Lq), rng_or_none(a, k, Lq - 1), ns, Lt);
+    for (int j = 1 + tid; j <= Lt; j += NT) {
+      float* pv = h.mat + (size_t)Lq * pitch + j;
+      const int sj = (Lt - 1 - j) >> 6;
+      const bool slot = !RING || j == Lt || (sj >= spq.sa && sj <= spq.sb);
+      if (h.co[(size_t)Lq * pitch + j]) {
+        *pv = 0.0f;
+        if (slot) ROW(Lq & 1, F_MM, j) = 0.0;
+      } else {
+        if (slot) ROW(Lq & 1, F_MM, j) = sL;
+        *pv = (float)(*pv * sL / Pf);
+      }
     }
   }
   __syncthreads();
-  const int ns = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 1;  // strips of columns Lt-1 .. 1 (Lt = 1: one strip without a valid lane)
   // sparse rows (StripSpan); a hit whose Pforward is not a positive number keeps every strip: the reference's posterior is then
   // F * (float)(B / Pforward) = NaN in EVERY cell, which only a visit writes
-  const bool sparse = Lt >= a.sparse_min_Lt && Pf > 0.0 && Pf < 1.0e300;
+  // (RING cannot keep every strip: its posterior waves fill the cells no unit visits with the value a visit would write)
+  const bool pf_ok = Pf > 0.0 && Pf < 1.0e300;
+  const bool sparse = RING || (Lt >= a.sparse_min_Lt && pf_ok);
   const LdsCnt dead = cnt + DF_DEAD;
   // unit (i, s) of the parallel part is done when its wave's counter has reached ...
 #define P_DONE(i, s) cnt + DF_P + ((s) % MAC_NP), (Lq - 1 - (i)) * N_OF((s) % MAC_NP) + (s) / MAC_NP + 1
@@ -1378,7 +1439,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
         const bool off = !valid || (STAGE ? co_l[jc] != 0 : co_nx != 0);
         if (!STAGE && s + MAC_NP <= sp.sb) co_nx = fetch_co(i, s + MAC_NP, rA);  // this wave's next unit of the row
         const unsigned long long on_mask = __ballot(!off);
-        if (lane == 0) masks[cur * MAC_DF_STRIPS + s] = on_mask;
+        if (lane == 0) masks[cur * MAC_DF_STRIPS + MSK(s)] = on_mask;
         if (on_mask == 0) {
           if (valid) {
             ROW(cur, F_MM, j) = 0.0;
@@ -1461,7 +1522,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
       for (int s = sp.sa; s <= sp.sb; ++s) {
         DF_WAIT(P_DONE(i, s), dead);
         DF_EVENT(3, i, s)
-        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + MSK(s)];
         if (on_mask == 0) {
           carry = 0.0;
         } else {
@@ -1548,7 +1609,7 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
         const int jc = valid ? j : 1;
         const float f_cur = STAGE ? (valid ? f_l[jc] : 0.0f) : f_nx;
         if (!STAGE && s + 2 <= sp.sb) f_nx = fetch_f(i, s + 2, rA);
-        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + s];
+        const unsigned long long on_mask = masks[cur * MAC_DF_STRIPS + MSK(s)];
         const bool off = !((on_mask >> lane) & 1);
         double mm = 0.0;
         if (on_mask != 0) {
@@ -1579,6 +1640,13 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
           }
         }
       }
+      if (RING && !pf_ok && v == 0) {
+        // F * (float)(B / Pforward) of a cell nobody visited: F = 0 (cleared plane), B = 0
+        const float fill = 0.0f * (float)(0.0 / Pf);
+        const int c_hi = sp.sa <= sp.sb ? Lt - 1 - (sp.sa << 6) : 0, c_lo = sp.sa <= sp.sb ? Lt - 64 - (sp.sb << 6) : 1;  // visited columns c_lo .. c_hi
+        for (int j = 1 + lane; j <= Lt - 1; j += 64)
+          if (j < c_lo || j > c_hi) row[j] = fill;
+      }
       if (!STAGE && i >= 2 && first_own(spn.sa, v, 2) <= spn.sb) f_nx = fetch_f(i - 1, first_own(spn.sa, v, 2), rB);
       df_post(cnt + DF_T + v, (Lq - i) * n_own, lane);  // the row's last unit number
     }
@@ -1590,6 +1658,8 @@ __global__ void __launch_bounds__(MAC_DFB_THREADS) hhv_mac_backward_df_kernel(Ma
 #undef N_OF
 #undef MAC_NP
 }
+#undef DFC
+#define DFC(j) (j)
 
 // ---- maximum-accuracy DP ----------------------------------------------------------------------------------------------
 template <bool LOCAL, bool GROWS, int DP_AHEAD>
@@ -1750,6 +1820,18 @@ __global__ void __launch_bounds__(256) hhv_mac_rowrange_kernel(MacArgs a) {
       }
     }
     if (lane == 0) rng[i] = make_int2(lo, hi);
+  }
+  __syncthreads();
+  {
+    __shared__ int s_span;  // the widest row in strips (see hhv_mac_mask_kernel)
+    if (threadIdx.x == 0) s_span = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int i = 1 + (int)threadIdx.x; i <= Lq; i += 256)
+      mx = max(mx, mac_row_span(i > 1 ? rng[i - 1] : make_int2(1, 0), rng[i], i < Lq ? rng[i + 1] : make_int2(1, 0), Lt));
+    atomicMax(&s_span, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) rng[0] = make_int2(s_span, 0);
   }
 }
 
@@ -2139,6 +2221,20 @@ __global__ void __launch_bounds__(256) hhv_mac_mask_kernel(MacArgs a, MacMaskArg
   __syncthreads();
   if (LDS_RNG)
     for (int i = tid; i <= Lq; i += 256) rng[i] = make_int2(s_lo[i], s_hi[i]);
+  __syncthreads();
+  {
+    // the widest row of the hit, in strips (mac_row_span): rng[0].x - which kind of kernel runs the hit when its template is too
+    // long for the plain LDS layout (RING)
+    __shared__ int s_span;
+    if (tid == 0) s_span = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int i = 1 + tid; i <= Lq; i += 256)
+      mx = max(mx, mac_row_span(i > 1 ? rng[i - 1] : make_int2(1, 0), rng[i], i < Lq ? rng[i + 1] : make_int2(1, 0), Lt));
+    atomicMax(&s_span, mx);
+    __syncthreads();
+    if (tid == 0) rng[0] = make_int2(s_span, 0);
+  }
   const int64_t x0 = m.excl_off[k];
   const int nx = (int)(m.excl_off[k + 1] - x0);
   for (int w = tid; w < nx * 5; w += 256) {
@@ -2231,7 +2327,40 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
   static_assert(MAC_PRE <= MAC_DF_STRIPS, "staged classes: at most MAC_PRE strips a row");
   if (cls <= 3) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
   else if (cls <= 5) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream);  // (fits: mac_length_class)
-  else launch_mac_rows<LOCAL, false, true>(a, n, 0, stream);
+  else {
+    // templates beyond the plain LDS layout: the dataflow kernels on a ring of strips for the hits whose rows all fit it, the
+    // single-wave kernels (row state in global memory) for the others - both launched over the whole class, a workgroup whose
+    // hit is of the other kind returns at once (the kind is decided on the device: rng[0].x, written with the masks)
+    static const bool no_ring = getenv("HHV_MAC_NO_RING") != nullptr || getenv("HHV_MAC_NO_PIPE") != nullptr;  // measurement aids
+    MacArgs ar = a, ag = a;
+    ar.lds_cols = MAC_RING_COLS;
+    ag.ring_strips = no_ring ? 0 : MAC_RING_STRIPS;
+    // (the class also takes the overflow of the shorter classes - more hits than are resident at once: those stay single-wave)
+    static const int ring_min = [] {
+      int L = 1;
+      while (mac_length_class(L) < MAC_CLASSES - 1 && L < (1 << 20)) ++L;
+      return L;
+    }();
+    ar.ring_min_Lt = ag.ring_min_Lt = ring_min;
+    const size_t lds = mac_rows_lds(MAC_RING_COLS, false);
+    if (!no_ring) {
+      (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, false, true>), dim3(n), dim3(MAC_DF_THREADS), lds, stream, ar);
+    }
+    hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, false, true>), dim3(n), dim3(64), 0, stream, ag);
+    if (a.fwd_list) hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
+    if (!no_ring) {
+      if (a.fwd_list) {
+        (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, true, true>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, ar);
+      } else {
+        (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, false, true>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, ar);
+      }
+    }
+    if (a.fwd_list) hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, false, true, true>), dim3(n), dim3(64), 0, stream, ag);
+    else hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, false, true, false>), dim3(n), dim3(64), 0, stream, ag);
+  }
   // maximum-accuracy DP: along anti-diagonals (hhv_mac_dp_diag_kernel) unless 0.5 * mact is not a float (its chain steps are
   // float subtractions) or HHV_MAC_DP_ROWS asks for the row-by-row kernel (measurement aid)
   static const bool dp_rows = getenv("HHV_MAC_DP_ROWS") != nullptr;
