@@ -244,9 +244,14 @@ int main(int argc, char** argv) {
     fprintf(stderr, "--world %d needs %d GPUs, %d visible (RCCL does not put two ranks on one device)\n", o.world, o.world, n_dev);
     return 7;
   }
+  // the id file lives in a directory of this run's own (mkdtemp: mode 0700, unpredictable name), not at a guessable path in /tmp
+  char dir[] = "/tmp/hhv_rccl_XXXXXX";
+  if (!mkdtemp(dir)) {
+    perror("mkdtemp");
+    return 4;
+  }
   char idf[256];
-  snprintf(idf, sizeof(idf), "/tmp/hhv_rccl_id_%d", (int)getpid());
-  unlink(idf);
+  snprintf(idf, sizeof(idf), "%s/id", dir);
   std::vector<pid_t> kids;
   for (int r = 0; r < o.world; ++r) {
     const pid_t pid = fork();
@@ -271,6 +276,8 @@ int main(int argc, char** argv) {
     if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = WIFEXITED(st) ? WEXITSTATUS(st) : 9;
   }
   unlink(idf);
+  unlink((std::string(idf) + ".tmp").c_str());
+  rmdir(dir);
   printf("%s\n", rc == 0 ? "sharded_search_rccl: OK" : "sharded_search_rccl: FAILED");
   return rc;
 }

@@ -35,9 +35,13 @@ int fail(int code, const char* fmt, ...) {
 }
 const char* last_error() { return g_err.c_str(); }
 
+static int error_word_check(hhv_ctx* c, const char* who);
 int sync_check(hhv_ctx* c, const char* who) {
   const hipError_t e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(HHV_E_DEVICE, "%s: %s", who, hipGetErrorString(e));
+  return error_word_check(c, who);
+}
+static int error_word_check(hhv_ctx* c, const char* who) {
   if (c->h_err) {
     const uint32_t w = *(volatile uint32_t*)c->h_err;
     if (w) {
@@ -50,6 +54,7 @@ int sync_check(hhv_ctx* c, const char* who) {
   }
   return HHV_OK;
 }
+int check_error_word(hhv_ctx* c, const char* who) { return error_word_check(c, who); }
 }  // namespace api
 }  // namespace hhv
 
@@ -872,6 +877,11 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
 int hhv_sync(hhv_ctx* c) {
   if (!c) return fail(HHV_E_ARG, "hhv_sync: null");
   return sync_check(c, "hhv_sync");
+}
+
+int hhv_check_error(hhv_ctx* c) {
+  if (!c) return fail(HHV_E_ARG, "hhv_check_error: null context");
+  return hhv::api::check_error_word(c, "hhv_check_error");
 }
 
 void* hhv_stream(hhv_ctx* c) { return c ? (void*)c->stream : nullptr; }

@@ -28,6 +28,7 @@ const char* last_error();
 // waited in vain for its partner, an illegal backtrace state) has set a bit there - HHV_E_DEVICE with text, the word is
 // cleared.  Every entry point that hands device results to the host comes through here.
 int sync_check(struct ::hhv_ctx* c, const char* who);
+int check_error_word(struct ::hhv_ctx* c, const char* who);  // the device error word alone, without waiting for the stream (hhv_check_error)
 
 template <typename T>
 inline void dfree(T*& p) {
@@ -111,7 +112,7 @@ struct hhv_ctx {
   int pair_mode = -1;                                  // -1 the library chooses, 0 one launch per strip, 1 a pair launch wherever a pair kernel exists
   int pair_swap = 0;                                   // pair kernels: workgroups with this bit of their number set swap the strips of their waves; -1 none
   int blocks_per_cu = 0;                               // > 0: at most this many resident workgroups per CU (measurements)
-  int trace_mode = -1;                                 // backtrace walk: -1 by set size, 0 one lane per template, 1 one wavefront per template
+  int trace_mode = -1;                                 // backtrace walk: -1 the library's choice (= 1 since round 5), 0 one lane per template, 1 one wavefront per template
 };
 
 struct hhv_tset {

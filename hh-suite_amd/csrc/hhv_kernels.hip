@@ -95,7 +95,7 @@ __device__ __forceinline__ void trace_step(int& state, int& i, int& j, int& matc
       }
       break;
     default:  // :139-144: the reference reports "unallowed state value" and ends the path; here the context's error word
-      if (err) *(volatile uint32_t*)err = DEV_ERR_TRACE_STATE;
+      if (err) __hip_atomic_fetch_or(err, DEV_ERR_TRACE_STATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       state = 0;
       break;
   }
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64) hhv_trace_wave_kernel(TraceArgs a) {
     // :139-144: an illegal state - the reference reports it, counts the step and ends the walk; here: the error word, and the
     // step runs through the code below as a run of one step that ends the walk (recorded as MM like every last step, :147)
     const bool illegal = state < 2 || state > 6;
-    if (illegal && a.err && lane == 0) *(volatile uint32_t*)a.err = DEV_ERR_TRACE_STATE;
+    if (illegal && a.err && lane == 0) __hip_atomic_fetch_or(a.err, DEV_ERR_TRACE_STATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const bool mm = state == 2, horizontal = state == 3 || state == 4;
     const int di = (mm || !horizontal) ? 1 : 0, dj = (mm || horizontal) ? 1 : 0;
     const int il = i - lane * di, jl = j - lane * dj;  // this lane's cell, if the run lasts that long

@@ -95,7 +95,7 @@ __device__ __forceinline__ void lds_poke(uint32_t addr, int v) {
 }
 // spin until the word at `addr` is >= need.  Bounded: a logic error (or a partner wave that is held up for tens of
 // milliseconds) must not hang the device - but it must not pass for a result either: when the bound is hit the wave sets
-// DEV_ERR_PAIR_TIMEOUT in the context's error word (host-mapped memory, a plain store: any non-zero word is a failure) and
+// DEV_ERR_PAIR_TIMEOUT in the context's error word (host-mapped memory, a system-scope atomic OR like every reporter) and
 // every call that waits for the stream answers HHV_E_DEVICE (hhv_api.cpp sync_check).  `dead` (wave
 // uniform, kept by the caller) makes the later waits of a wave that has given up return at once: its results are garbage
 // anyway, and a launch of thousands of chunks must not spend the bound thousands of times.
@@ -114,7 +114,7 @@ __device__ __forceinline__ void pair_wait(uint32_t addr, int need, uint32_t* err
     __builtin_amdgcn_s_sleep(4);
   }
   dead = 1;
-  if (err) *(volatile uint32_t*)err = DEV_ERR_PAIR_TIMEOUT;
+  if (err) __hip_atomic_fetch_or(err, DEV_ERR_PAIR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (an OR: concurrent reporters keep each other's bits)
 }
 
 // ---- work queue of the 64-lane variants (see the kernel: DQ) ------------------------------------

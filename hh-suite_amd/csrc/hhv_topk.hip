@@ -606,8 +606,8 @@ __global__ void __launch_bounds__(256) celloff_band_kernel(CellOffGeom g, const 
   int* row_hi = row_lo + (Lt + 1);
   int* col_lo = row_hi + (Lt + 1);      // [Lq + 1] first / last COLUMN of the path's steps in row i
   int* col_hi = col_lo + (Lq + 1);
-  __shared__ int irregular;
-  if (threadIdx.x == 0) irregular = 0;
+  __shared__ int irregular, j_min, j_max;
+  if (threadIdx.x == 0) irregular = 0, j_min = 0x7FFFFFFF, j_max = -1;
   for (int k = threadIdx.x; k <= Lt; k += 256) row_lo[k] = 0x7FFFFFFF, row_hi[k] = -1;
   for (int k = threadIdx.x; k <= Lq; k += 256) col_lo[k] = 0x7FFFFFFF, col_hi[k] = -1;
   __syncthreads();
@@ -622,9 +622,14 @@ __global__ void __launch_bounds__(256) celloff_band_kernel(CellOffGeom g, const 
     atomicMax(&row_hi[j], i);
     atomicMin(&col_lo[i], j);
     atomicMax(&col_hi[i], j);
+    atomicMin(&j_min, j);
+    atomicMax(&j_max, j);
   }
   __syncthreads();
-  if (irregular) {  // not a path: cell by cell, as above
+  // a short alignment in a large matrix (10 steps, Lq and Lt of thousands): its 162 cells per step are far fewer than the
+  // entries of the columns it touches - cell by cell then (an atomic costs about eight entry tests)
+  const bool few_cells = j_max >= 0 && (long long)ns * 162 * 8 < (long long)Lq * (j_max - j_min + 81);
+  if (irregular || few_cells) {  // not a path (or a very short one): cell by cell, as above
     constexpr int CW = 2 * 40 + 1;
     for (int w = threadIdx.x; w < ns * CW; w += 256) {
       const int step = w / CW, d = w - step * CW - 40;
@@ -640,10 +645,12 @@ __global__ void __launch_bounds__(256) celloff_band_kernel(CellOffGeom g, const 
   for (int pass = 0; pass < g.plan.P; ++pass) {
     const int R = g.plan.R(pass), ilo = g.plan.base(pass) + 1;
     uint64_t* e = g.bt + (size_t)pass * g.pass_stride;
-    // buffer rows rec0 + 1 .. rec0 + Lt + W - 1 hold the template's entries: (row rho, lane gl) = column rho - gl - rec0
-    for (int k = threadIdx.x; k < (Lt + W - 1) * W; k += 256) {
+    // buffer rows rec0 + 1 .. rec0 + Lt + W - 1 hold the template's entries: (row rho, lane gl) = column rho - gl - rec0;
+    // only columns within 40 of the path's can be touched: buffer rows j_lo .. j_hi + W - 1
+    const int j_lo = max(1, j_min - 40), j_hi = min(Lt, j_max + 40);
+    for (int k = (j_lo - 1) * W + threadIdx.x; k < (j_hi + W - 1) * W && j_max >= 0; k += 256) {
       const int gl = k % W, j = 1 + k / W - gl;
-      if (j < 1 || j > Lt) continue;
+      if (j < j_lo || j > j_hi) continue;
       uint64_t v = 0;
       const int rlo = row_lo[j] - 40, rhi = row_hi[j] < 0 ? -1 : row_hi[j] + 40;
       for (int r = 0; r < R; ++r) {

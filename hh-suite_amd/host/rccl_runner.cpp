@@ -37,13 +37,28 @@ RcclShardedRunner::RcclShardedRunner(int world, int rank, const void* id, int de
   ncclComm_t comm;
   nccl_ok(ncclCommInitRank(&comm, world, u, rank), "ncclCommInitRank");
   comm_ = comm;
-  hhv_params p = par;
-  p.device = device;
-  hhv_ok(hhv_create(&ctx_, &p), "hhv_create");
-  for (int k = 0; k < 4; ++k) {
-    hipEvent_t e;
-    hip_ok(hipEventCreate(&e), "hipEventCreate");
-    ev_[k] = e;
+  // from here on a failure must give back what exists already: the destructor does not run for a half-built object, and a
+  // communicator that is never destroyed leaves the other ranks of its (collective) initialisation hanging
+  try {
+    hhv_params p = par;
+    p.device = device;
+    hhv_ok(hhv_create(&ctx_, &p), "hhv_create");
+    for (int k = 0; k < 4; ++k) {
+      hipEvent_t e;
+      hip_ok(hipEventCreate(&e), "hipEventCreate");
+      ev_[k] = e;
+    }
+  } catch (...) {
+    for (void*& e : ev_)
+      if (e) {
+        (void)hipEventDestroy((hipEvent_t)e);
+        e = nullptr;
+      }
+    if (ctx_) hhv_destroy(ctx_);
+    ctx_ = nullptr;
+    (void)ncclCommAbort((ncclComm_t)comm_);
+    comm_ = nullptr;
+    throw;
   }
 }
 

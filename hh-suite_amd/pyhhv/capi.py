@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_mac_set_lists", "hhv_mac_list", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
-    "hhv_sync", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
+    "hhv_sync", "hhv_check_error", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
     "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan", "hhv_segment_plan",
     "hhv_tset_set_global_ids", "hhv_merge_hits",
 ]
@@ -157,6 +157,7 @@ def load(path=None):
     L.hhv_align.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.hhv_align_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.hhv_sync.argtypes = [C.c_void_p]
+    L.hhv_check_error.argtypes = [C.c_void_p]
     L.hhv_stream.argtypes = [C.c_void_p]
     L.hhv_stream.restype = C.c_void_p
     L.hhv_last_kernel_ms.argtypes = [C.c_void_p, c_float_p]

@@ -60,7 +60,11 @@ extern "C" {
 typedef enum {
   HHV_OK = 0,
   HHV_E_ARG = -1,     /* bad argument (reference: exit(4)/(6)) */
-  HHV_E_DEVICE = -2,  /* no HIP device / HIP runtime error */
+  HHV_E_DEVICE = -2,  /* no HIP device / HIP runtime error / a kernel reported a failure in the context's device error word.
+                       * Device-side failures (a wave that waited in vain for its partner, an illegal backtrace state) surface ONLY
+                       * through the calls that wait for the stream themselves - hhv_sync, hhv_align, hhv_hits, hhv_topk,
+                       * hhv_merge_hits, hhv_hit_path, hhv_backtrace_matrix, hhv_mac_realign* - : a caller that waits on
+                       * hhv_stream() or an event of its own (hhv_align_async with device results) calls hhv_check_error after it. */
   HHV_E_MEMORY = -3,  /* host or device allocation failed (reference: exit(3)) */
   HHV_E_STATE = -4,   /* call order (no query set, no backtrace computed, ...) */
   HHV_E_LIMIT = -5    /* size beyond what this build supports */
@@ -160,11 +164,16 @@ int hhv_set_params(hhv_ctx* ctx, const hhv_params* par);
  *   pair_swap      pair kernels: workgroups whose number has this bit set run the strips on swapped wave indices (default 0;
  *                  -1 none; at most 31)
  *   blocks_per_cu  > 0: at most this many resident workgroups per CU; 0 = what the kernel admits
- *   trace_mode     the backtrace walk (Viterbi::Backtrace, src/hhviterbi.cpp:83-160): -1 chosen by the size of the set (default),
- *                  0 one lane per template, 1 one wavefront per template (a round trip per run of the path)
+ *   trace_mode     the backtrace walk (Viterbi::Backtrace, src/hhviterbi.cpp:83-160): -1 the library's choice (default; since
+ *                  round 5 that is 1 at every set size - it measured ahead everywhere), 0 one lane per template,
+ *                  1 one wavefront per template (a round trip per run of the path)
  * The defaults of a new context can be preset through the environment, read once in hhv_create: HHV_PAIR (0 / 1),
  * HHV_PAIR_SWAP, HHV_BLOCKS_PER_CU, HHV_TRACE_WAVE (0 / 1). */
 int hhv_set_launch_policy(hhv_ctx* ctx, int32_t pair_mode, int32_t pair_swap, int32_t blocks_per_cu, int32_t trace_mode);
+/* The context's device error word, read WITHOUT waiting for the stream (for callers that synchronise themselves): HHV_OK, or
+ * HHV_E_DEVICE with the cause in hhv_last_error(); the word is cleared.  Reference analogue: the reference stops the process on an
+ * illegal backtrace state (src/hhviterbi.cpp:139-144). */
+int hhv_check_error(hhv_ctx* ctx);
 
 /* query: p[(Lq+1)*20], tr[(Lq+1)*7] (copied before the call returns: the caller may reuse its arrays at once).
  * The rows travel through a pinned staging block with asynchronous copies on the context's stream; device buffers and
