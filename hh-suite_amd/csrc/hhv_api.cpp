@@ -62,7 +62,9 @@ namespace hhv {
 size_t topk_temp_bytes(int n);
 void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t stream);
 int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit* d_out, uint64_t* keys, uint64_t* sorted,
-                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err);
+                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err, const float* rank = nullptr);
+void topk_rank_pvalue(const DevHit* d_hits, int n, const int32_t* d_L, const float* d_neff, int Lq, float q_neff, int local, float* d_rank,
+                      hipStream_t stream);
 int merge_hits_device(const DevHit* d_in, int m, int k, DevHit* d_out, int* d_n, hipStream_t stream, std::string* err);
 }
 
@@ -671,6 +673,8 @@ void hhv_tset_free(hhv_tset* ts) {
   dfree(ts->d_sort_temp);
   dfree(ts->d_raw_hits);
   dfree(ts->d_gids);
+  dfree(ts->d_neff);
+  dfree(ts->d_rank);
   delete ts;
 }
 
@@ -1236,8 +1240,9 @@ int hhv_hit_path_pool(hhv_ctx* c, hhv_tset* ts, const int64_t** path_off, const 
 int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, void* d_out, int32_t* n_out) {
   if (!c || !ts) return fail(HHV_E_ARG, "hhv_topk: null argument");
   if (k < 1) return fail(HHV_E_ARG, "hhv_topk: k = %d", k);
-  const bool raw = (flags & HHV_TOPK_RAW) != 0;
+  const bool raw = (flags & HHV_TOPK_RAW) != 0, pval = (flags & HHV_TOPK_PVALUE) != 0;
   if (!raw && !ts->hits_valid) return fail(HHV_E_STATE, "hhv_topk: call hhv_hits first (or pass HHV_TOPK_RAW)");
+  if (pval && (raw || !ts->d_neff)) return fail(HHV_E_STATE, "hhv_topk: HHV_TOPK_PVALUE needs hhv_hits and hhv_tset_set_neff (and not HHV_TOPK_RAW)");
   HIP_TRY(hipSetDevice(c->par.device));
   const int kk = std::min(k, ts->n);
   if (ts->topk_cap < k) {
@@ -1259,8 +1264,12 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
   }
   DevHit* dst = d_out ? (DevHit*)d_out : ts->d_topk;
   std::string err;
+  if (pval) {
+    if (!ts->d_rank) HIP_TRY(hipMalloc(&ts->d_rank, (size_t)std::max(ts->n, 1) * sizeof(float)));
+    topk_rank_pvalue(src, ts->n, ts->d_L, ts->d_neff, c->Lq, ts->q_neff, c->par.local, ts->d_rank, c->stream);
+  }
   if (topk_device(src, ts->n, kk, ts->d_gids, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
-                  &err) != 0)
+                  &err, pval ? ts->d_rank : nullptr) != 0)
     return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
   if (kk < k) HIP_TRY(hipMemsetAsync(dst + kk, 0xFF, (size_t)(k - kk) * sizeof(DevHit), c->stream));
   if (out) {
@@ -1274,6 +1283,17 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
   return HHV_OK;
 }
 
+int hhv_tset_set_neff(hhv_ctx* c, hhv_tset* ts, float q_neff, const float* t_neff) {
+  if (!c || !ts || !t_neff) return fail(HHV_E_ARG, "hhv_tset_set_neff: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_tset_set_neff: template set belongs to another context");
+  HIP_TRY(hipSetDevice(c->par.device));
+  if (!ts->d_neff) HIP_TRY(hipMalloc(&ts->d_neff, (size_t)std::max(ts->n, 1) * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(ts->d_neff, t_neff, (size_t)ts->n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  ts->q_neff = q_neff;
+  return HHV_OK;
+}
+
 int hhv_tset_set_global_ids(hhv_ctx* c, hhv_tset* ts, const int32_t* ids) {
   if (!c || !ts) return fail(HHV_E_ARG, "hhv_tset_set_global_ids: null argument");
   if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_tset_set_global_ids: template set belongs to another context");
@@ -1281,6 +1301,8 @@ int hhv_tset_set_global_ids(hhv_ctx* c, hhv_tset* ts, const int32_t* ids) {
   if (!ids) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     dfree(ts->d_gids);
+  dfree(ts->d_neff);
+  dfree(ts->d_rank);
     ts->d_gids = nullptr;
     return HHV_OK;
   }

@@ -169,6 +169,9 @@ struct hhv_tset {
   void* d_sort_temp = nullptr;
   size_t sort_temp_bytes = 0;
   hhv::DevHit* d_raw_hits = nullptr;
+  float* d_neff = nullptr;    // hhv_tset_set_neff: Neff_HMM of every template (HHV_TOPK_PVALUE)
+  float* d_rank = nullptr;    // ... and the ranking keys of the last such hhv_topk
+  float q_neff = 0.0f;
   int32_t* d_gids = nullptr;  // hhv_tset_set_global_ids: global template id of every entry (sharded databases)
 };
 

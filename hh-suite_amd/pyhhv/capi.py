@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_mac_set_lists", "hhv_mac_list", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
-    "hhv_sync", "hhv_check_error", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
+    "hhv_sync", "hhv_check_error", "hhv_tset_set_neff", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
     "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan", "hhv_segment_plan",
     "hhv_tset_set_global_ids", "hhv_merge_hits",
 ]
@@ -673,10 +673,18 @@ class Context:
         S = np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_float)), shape=(tot,)).copy()
         return off, i_steps, j_steps, states, S
 
-    def topk(self, ts, k, d_out=None, fetch=True, raw=False):
+    def set_neff(self, ts, q_neff, t_neff):
+        """hhv_tset_set_neff: the diversities the reference's ranking key needs (topk(..., pvalue=True))"""
+        t = _f32(t_neff)
+        if t.shape[0] != ts.n:
+            raise HhvError("set_neff: %d values for %d templates" % (t.shape[0], ts.n))
+        self.lib.hhv_tset_set_neff.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        self._chk(self.lib.hhv_tset_set_neff(self.h, ts.h, float(q_neff), t.ctypes.data))
+
+    def topk(self, ts, k, d_out=None, fetch=True, raw=False, pvalue=False):
         out = np.zeros(k, dtype=HIT_DTYPE) if fetch else None
         n = C.c_int32()
-        self._chk(self.lib.hhv_topk(self.h, ts.h, int(k), 1 if raw else 0, out.ctypes.data if fetch else None,
+        self._chk(self.lib.hhv_topk(self.h, ts.h, int(k), (1 if raw else 0) | (2 if pvalue else 0), out.ctypes.data if fetch else None,
                                  C.c_void_p(d_out) if d_out else None, C.byref(n)))
         return (out[:n.value] if fetch else None), n.value
 

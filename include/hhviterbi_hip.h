@@ -442,11 +442,21 @@ int hhv_hit_path_pool(hhv_ctx* ctx, hhv_tset* ts, const int64_t** path_off, cons
  * With out == NULL the call only enqueues work on the context's stream (hhv_stream) and does not wait for it: a caller
  * that consumes d_out on another stream orders the two with an event (bench.py: hhv_topk -> all_gather -> hhv_merge_hits). */
 #define HHV_TOPK_RAW 1u
+/* HHV_TOPK_PVALUE: rank by the reference's own sort key instead of Hit.score - score_aass, which HitList::CalculatePvalues
+ * (src/hhhitlist.cpp:499-531) derives from score and score_ss through the extreme-value distribution of the pair's lengths and
+ * diversities (lamda_NN / mu_NN, src/hhhitlist-inl.h:13-66; Hit::CalcEvalScoreProbab, src/hhhit.h:134-141; Hit::operator<,
+ * src/hhhit.h:116-126).  For sharded searches: a shard's K-cut by Hit.score can drop a hit the reference ranks inside the top K.
+ * Needs hhv_hits and hhv_tset_set_neff; the records come out in that order, their fields unchanged (the host recomputes the
+ * reference's numbers for them - the device's exp / log are within an ulp of libm's, not bit for bit). */
+#define HHV_TOPK_PVALUE 2u
 int hhv_topk(hhv_ctx* ctx, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, void* d_out, int32_t* n_out);
 /* Sharded databases (one hhv_ctx / hhv_tset per GPU, hhv_shard_plan): ids[k] >= 0 = the GLOBAL template id of entry k
  * of this shard (host array, ts->n entries, copied).  From then on hhv_topk reports ids[index] in hhv_hit.index, so that
  * its output can go straight into the exchange; NULL switches back to the index inside the set. */
 int hhv_tset_set_global_ids(hhv_ctx* ctx, hhv_tset* ts, const int32_t* ids);
+/* The diversities HHV_TOPK_PVALUE needs: q_neff = q->Neff_HMM, t_neff[k] = Neff_HMM of template k (HMM::Neff_HMM, src/hhhmm.h; the
+ * template lengths are the set's).  Host array of ts->n entries, copied. */
+int hhv_tset_set_neff(hhv_ctx* ctx, hhv_tset* ts, float q_neff, const float* t_neff);
 /* The merge half of the sharded top-K: d_in = DEVICE pointer to m hhv_hit records, the concatenation of every shard's
  * hhv_topk output after the all-gather (records with index < 0 are padding).  Returns the k best by score (descending,
  * ties by the smaller global id - the order the reference's caller gives the hit list, src/hhhit.h:116-126, after

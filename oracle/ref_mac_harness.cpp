@@ -18,6 +18,7 @@
 
 #include "hhposteriordecoder.h"
 #include "hhviterbimatrix.h"
+#include "hhhitlist-inl.h"
 
 namespace {
 HMM* make_hmm(const float* p, const float* tr_log, int L) {
@@ -239,6 +240,33 @@ double ref_mac_realign_timed(const float* q_p, const float* q_tr_log, int Lq, in
   for (int k = 0; k < n; ++k) delete ts[k];
   delete q;
   return dt;
+}
+
+// The reference's sort key of a hit (tests/test_gpu_topk_pvalue.py): what HitList::CalculatePvalues (src/hhhitlist.cpp:499-531)
+// leaves in Hit::score_aass - lamda_NN / mu_NN (src/hhhitlist-inl.h), logPvalue / Pvalue (src/hhhit-inl.h), CalcEvalScoreProbab
+// (src/hhhit.h:134-141) - for n hits given by score, score_ss, template length and diversity.
+int ref_score_aass(int n, const float* score, const float* score_ss, const int* Lt, const float* t_neff, int Lq, float q_neff, int loc,
+                   int N_searched, float* out_score_aass, double* out_logPval) {
+  const float log1000 = log(1000.0);
+  for (int k = 0; k < n; ++k) {
+    Hit hit;
+    float lamda = LAMDA_GLOB, mu = 3.0;
+    hit.score = score[k];
+    hit.score_ss = score_ss[k];
+    hit.L = Lt[k];
+    hit.Neff_HMM = t_neff[k];
+    hit.ssm1 = hit.ssm2 = 0;
+    if (loc) {
+      lamda = lamda_NN(log(Lq) / log1000, log(hit.L) / log1000, q_neff / 10.0, hit.Neff_HMM / 10.0);
+      mu = mu_NN(log(Lq) / log1000, log(hit.L) / log1000, q_neff / 10.0, hit.Neff_HMM / 10.0);
+    }
+    hit.logPval = logPvalue(hit.score, lamda, mu);
+    hit.Pval = Pvalue(hit.score, lamda, mu);
+    hit.CalcEvalScoreProbab(N_searched, lamda, (char)loc, 0, 0.0f);
+    out_score_aass[k] = hit.score_aass;
+    if (out_logPval) out_logPval[k] = hit.logPval;
+  }
+  return 0;
 }
 
 // list `which` (0 forward, 1 backward, 2 posterior) of the last ref_mac_realign call: returns the number of entries and

@@ -15,7 +15,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 stage=$1; shift
-short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload --no-fast-mode --no-rows"
+short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-pipeline --no-upload --no-fast-mode --no-rows"
 line() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); print('%.3e cells/s, %.2f ms/step, kernel %.2f ms (min %.2f)' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['kernel_ms_min']))"; }
 case $stage in
 check)
@@ -115,6 +115,19 @@ macprofx)   # macprofx "<n Lq Lt>" ...: rocprofv3 kernel statistics of tools/ben
     f=$(find $OUT/prof_macx_$i -name "*kernel_stats.csv" | head -1); echo "== $shape"; head -12 "$f" | cut -d, -f1-7; cp "$f" $OUT/macx_${tag}_kernel_stats.csv; rm -rf $OUT/prof_macx_$i
     tail -1 $OUT/prof_macx_$tag.txt | cut -c1-400
   done
+  ;;
+r6p)   # the round's profiles: headline + backtrace (PMC, stamped with the kernel-source hash), next rows (prefilter / MAC), prepare, the 1 M pipeline
+  for spec in "r6|" "r6bt|--backtrace 1"; do
+    tag=${spec%%|*}; extra=${spec#*|}
+    bash tools/profile.sh $tag "$extra" > $OUT/profile_$tag.log 2>&1
+    HHV_PROFILE_OUT=$OUT/profiles_out python tools/summarize_profile.py $tag | tail -24
+    rm -rf $OUT/prof_$tag
+  done
+  bash tools/gpu_session.sh next r6
+  bash tools/gpu_session.sh prep 100000 r6
+  echo "== pipeline, 1 M sequences"
+  timeout 900 python tools/bench_pipeline.py 1000000 20000 500 | tee $OUT/profiles_out/r6_pipeline_1M.json
+  timeout 600 python tools/bench_pipeline.py 200000 10000 500 | tee $OUT/profiles_out/r6_pipeline_200k.json
   ;;
 r5p)   # the round's profiles: headline, backtrace, secondary structure (hhv_ss_kernel), and the kernel statistics of a 10 k backtrace search
   for spec in "r5|" "r5bt|--backtrace 1" "r5ss|--ss 4" "r5ssbt|--ss 4 --backtrace 1"; do

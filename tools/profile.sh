@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload --no-fast-mode --no-rows $EXTRA"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-pipeline --no-upload --no-fast-mode --no-rows $EXTRA"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH --steps 20 --warmup 5 > $OUT/stats_bench.txt 2>&1
 timeout 600 rocprofv3 --kernel-include-regex "hhv_" --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH --steps 2 --warmup 0 > $OUT/pmc_fetch.txt 2>&1
 timeout 600 rocprofv3 --kernel-include-regex "hhv_" --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH --steps 2 --warmup 0 > $OUT/pmc_write.txt 2>&1

@@ -24,7 +24,7 @@ PY
 )
 MAXG=${1:-$NDEV}
 [ "$MAXG" -gt "$NDEV" ] && MAXG=$NDEV
-short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-upload --no-fast-mode --no-rows"
+short="--no-cpu-baseline --no-configs1 --no-configs2 --no-configs4 --no-next-rows --no-pipeline --no-upload --no-fast-mode --no-rows"
 echo "scale8: $NDEV GPU(s) visible, running up to $MAXG" >&2
 for N in 1 2 4 8; do
   [ $N -gt $MAXG ] && break
