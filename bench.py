@@ -43,7 +43,7 @@ except AttributeError:
     AFFINITY_CPUS = os.cpu_count() or 1
 # the cpu_baseline leg times OpenMP code (oracle/_ref): pin its threads to cores, one per core, before any OpenMP runtime
 # is loaded - unpinned threads of a dynamic schedule migrate and the number is not reproducible
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # streams of the MAC length classes (hhv_create): before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # streams of the MAC length classes (hhv_create): before HIP initialises
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 

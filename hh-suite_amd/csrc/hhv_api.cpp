@@ -185,10 +185,12 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
   *out = nullptr;
   // The MAC realignment runs its template-length classes side by side in MAC_CHAINS streams (hhv_mac.hip launch_mac).  The HIP
   // runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share one run one after the other:
-  // 500 hits of mixed lengths 9.2 ms with eight queues, 12.7 ms with four (tools/SESSIONS.md round 6).  The runtime reads the
-  // variable when it initialises, so this has an effect only in a process whose first HIP call is this one (the drop-in
-  // applications); hosts that initialise HIP earlier export it themselves (pyhhv/capi.py does).  An explicit setting is respected.
-  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // 500 hits of mixed lengths 9.2 ms with eight queues, 12.7 ms with four (tools/SESSIONS.md round 6); with eight the context's own
+  // stream, the null stream and the eight class streams still left two classes behind each other (4.9 -> 4.65 ms with sixteen).
+  // The runtime reads the variable when it initialises, so this has an effect only in a process whose first HIP call is this one
+  // (the drop-in applications); hosts that initialise HIP earlier export it themselves (pyhhv/capi.py does).  An explicit setting
+  // is respected.
+  (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
@@ -280,6 +282,8 @@ void hhv_destroy(hhv_ctx* c) {
     if (c->mac_side.join[k]) (void)hipEventDestroy((hipEvent_t)c->mac_side.join[k]);
   }
   if (c->mac_side.fork) (void)hipEventDestroy((hipEvent_t)c->mac_side.fork);
+  if (c->h_packed) (void)hipHostFree(c->h_packed);
+  dfree(c->d_packed);
   if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
   if (c->mac_pinned_out) (void)hipHostFree(c->mac_pinned_out);
   if (c->q_stage) (void)hipHostFree(c->q_stage);
@@ -1127,6 +1131,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   if (rc != 0) return fail(HHV_E_DEVICE, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   ts->hits_valid = true;
   ts->host_paths_valid = false;
+  ts->packed_valid = false;
   return HHV_OK;
 }
 
@@ -1234,6 +1239,62 @@ int hhv_hit_path_pool(hhv_ctx* c, hhv_tset* ts, const int64_t** path_off, const 
   *j_steps = ts->h_j_steps.data();
   *states = ts->h_states.data();
   *S = ts->h_S.data();
+  return HHV_OK;
+}
+
+int hhv_hit_paths_packed(hhv_ctx* c, hhv_tset* ts, const hhv_hit* hits, const int64_t** off, const uint16_t** i_steps,
+                         const uint16_t** j_steps, const int8_t** states, const float** S) {
+  if (!c || !ts || !hits || !off || !i_steps || !j_steps || !states || !S) return fail(HHV_E_ARG, "hhv_hit_paths_packed: null argument");
+  if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_hit_paths_packed: template set belongs to another context");
+  if (!ts->hits_valid) return fail(HHV_E_STATE, "hhv_hit_paths_packed: call hhv_hits first");
+  if (c->Lq > 0xFFFF) return fail(HHV_E_LIMIT, "hhv_hit_paths_packed: query of %d rows (16-bit path records)", c->Lq);
+  HIP_TRY(hipSetDevice(c->par.device));
+  const int n = ts->n;
+  // offsets of the compact records from the step counts the caller already holds (hhv_hits): entry 0 .. nsteps per hit
+  ts->pk_off.resize((size_t)n + 1);
+  ts->pk_off[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const int64_t cap = ts->path_off[k + 1] - ts->path_off[k];
+    if (hits[k].nsteps < 0 || hits[k].nsteps + 1 > cap) return fail(HHV_E_ARG, "hhv_hit_paths_packed: hits[%d].nsteps = %d is not this set's", k, hits[k].nsteps);
+    ts->pk_off[(size_t)k + 1] = ts->pk_off[k] + hits[k].nsteps + 1;
+  }
+  const size_t total = (size_t)ts->pk_off[n], pad = (total + 63) & ~(size_t)63;
+  // one block: [offsets n+1 x 8][i: u16][j: u16][S: f32][states: i8], every piece 256-byte aligned
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_off = 0, o_i = up((size_t)(n + 1) * 8), o_j = o_i + up(pad * 2), o_S = o_j + up(pad * 2), o_s = o_S + up(pad * 4),
+               bytes = o_s + up(pad);
+  if (c->d_packed_bytes < bytes) {
+    dfree(c->d_packed);
+    c->d_packed = nullptr;
+    c->d_packed_bytes = 0;
+    HIP_TRY(hipMalloc(&c->d_packed, bytes + bytes / 4));
+    c->d_packed_bytes = bytes + bytes / 4;
+  }
+  if (c->h_packed_bytes < bytes) {
+    if (c->h_packed) (void)hipHostFree(c->h_packed);
+    c->h_packed = nullptr;
+    c->h_packed_bytes = 0;
+    HIP_TRY(hipHostMalloc(&c->h_packed, bytes + bytes / 4, hipHostMallocDefault));
+    c->h_packed_bytes = bytes + bytes / 4;
+  }
+  char* d = (char*)c->d_packed;
+  char* h = (char*)c->h_packed;
+  memcpy(h + o_off, ts->pk_off.data(), (size_t)(n + 1) * 8);
+  HIP_TRY(hipMemcpyAsync(d + o_off, h + o_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  const int lr = launch_pack_paths(ts->d_hits, n, ts->d_path_off, ts->d_i_steps, ts->d_j_steps, ts->d_states, ts->d_S, (const int64_t*)(d + o_off),
+                                   (uint16_t*)(d + o_i), (uint16_t*)(d + o_j), (int8_t*)(d + o_s), (float*)(d + o_S), c->stream);
+  if (lr != 0) return fail(HHV_E_DEVICE, "hhv_hit_paths_packed: launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
+  HIP_TRY(hipMemcpyAsync(h + o_i, d + o_i, bytes - o_i, hipMemcpyDeviceToHost, c->stream));  // the four arrays in one copy
+  {
+    const int sc = sync_check(c, "hhv_hit_paths_packed");
+    if (sc != HHV_OK) return sc;
+  }
+  ts->packed_valid = true;
+  *off = ts->pk_off.data();
+  *i_steps = (const uint16_t*)(h + o_i);
+  *j_steps = (const uint16_t*)(h + o_j);
+  *states = (const int8_t*)(h + o_s);
+  *S = (const float*)(h + o_S);
   return HHV_OK;
 }
 

@@ -81,6 +81,11 @@ struct hhv_ctx {
   std::vector<int32_t> mac_ss_mode;
   hhv::MacStreams mac_side = {};                          // side streams of the MAC length classes (created at the first use)
   bool mac_side_ready = false;
+  // hhv_hit_paths_packed: device scratch and pinned mirror of the compact path records (grow-only, shared by the context's sets)
+  void* d_packed = nullptr;
+  size_t d_packed_bytes = 0;
+  void* h_packed = nullptr;
+  size_t h_packed_bytes = 0;
   void* mac_pinned = nullptr;                          // pinned staging buffer of the MAC inputs
   size_t mac_pinned_bytes = 0;
   void* mac_pinned_out = nullptr;                      // pinned buffer of the MAC paths coming back (recycled through hhv_macset_free)
@@ -161,6 +166,9 @@ struct hhv_tset {
   std::vector<float> h_S;
   std::vector<hhv::DevHit> h_hits;
   bool host_paths_valid = false;
+  // hhv_hit_paths_packed: the paths alone, compact, in a pinned buffer of the context (valid until the next call for any set)
+  std::vector<int64_t> pk_off;
+  bool packed_valid = false;
   // top-k scratch
   hhv::DevHit* d_topk = nullptr;
   int topk_cap = 0;

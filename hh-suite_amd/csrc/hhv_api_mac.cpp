@@ -83,27 +83,33 @@ static int mac_realign_impl(hhv_ctx* c, const float* q_p, const float* q_tr_lin,
   *out = nullptr;
   if (Lq < 1 || n < 1) return fail(HHV_E_ARG, "hhv_mac_realign: Lq = %d, n = %d", Lq, n);
   MacClasses cls = {};  // the launch is split by template length (hhv_internal.h)
-  // first by length alone; a staged class (template in LDS) with more hits than are resident at once gives its hits to the
-  // lean classes (template operands from global memory, three times the residency), and a lean class that is over-subscribed
-  // in turn to the class without LDS - see mac_staged_capacity
+  // first by length alone; then the longest hits keep their dataflow classes for as long as the GPU holds them at once
+  // (mac_dataflow_budget), the others go to the class without LDS
   std::vector<int8_t> cls_of((size_t)n);
   for (int k = 0; k < n; ++k) {
     if (Lt[k] < 1 || (!from_tset && !t_p[k]) || !t_tr_lin[k]) return fail(HHV_E_ARG, "hhv_mac_realign: bad template %d", k);
     cls_of[k] = (int8_t)mac_length_class(Lt[k]);
   }
-  for (int level = 0; level < 2; ++level) {  // level 0: staged -> lean, level 1: lean -> no LDS
+  for (int k = 0; k < n; ++k) cls.n_long += cls_of[k] == MAC_CLASSES - 1;
+  {
     MacClasses cnt = {};
-    for (int k = 0; k < n; ++k) {
-      cnt.n[cls_of[k]]++;
-      cnt.max_Lt[cls_of[k]] = std::max(cnt.max_Lt[cls_of[k]], Lt[k]);
-    }
-    for (int k = 0; k < n; ++k) {
-      const int cl = cls_of[k];
-      const bool staged = cl <= 3, lean = cl == 4 || cl == 5;
-      if (level == 0 && staged && cnt.n[cl] > mac_staged_capacity(cnt.max_Lt[cl], c->num_cus, true))
-        cls_of[k] = (int8_t)mac_length_class(Lt[k], false);
-      if (level == 1 && lean && cnt.n[cl] > mac_staged_capacity(cnt.max_Lt[cl], c->num_cus, false))
-        cls_of[k] = (int8_t)mac_length_class(Lt[k], false, false);
+    for (int k = 0; k < n; ++k) cnt.max_Lt[cls_of[k]] = std::max(cnt.max_Lt[cls_of[k]], Lt[k]);
+    int max_hits = 0, taken = 0;
+    size_t max_lds = 0, lds = 0;
+    mac_dataflow_budget(c->num_cus, &max_hits, &max_lds);
+    std::vector<int32_t> by_len((size_t)n);
+    for (int k = 0; k < n; ++k) by_len[k] = k;
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int32_t x, int32_t y) { return Lt[x] > Lt[y]; });
+    for (int r = 0; r < n; ++r) {
+      const int k = by_len[r], cl = cls_of[k];
+      if (cl == MAC_CLASSES - 1) continue;
+      const size_t need = mac_rows_lds(cnt.max_Lt[cl], false);
+      if (taken < max_hits && lds + need <= max_lds) {
+        ++taken;
+        lds += need;
+      } else {
+        cls_of[k] = (int8_t)(MAC_CLASSES - 1);
+      }
     }
   }
   for (int k = 0; k < n; ++k) {

@@ -314,6 +314,7 @@ constexpr int MAC_CLASSES = 7;
 struct MacClasses {
   int n[MAC_CLASSES];       // hits per class; MacArgs::sel lists class 0 first, then 1, ...
   int max_Lt[MAC_CLASSES];  // longest template per class
+  int n_long;               // hits of the last class that are there by their length (the others: beyond the dataflow classes' budget)
 };
 // streams the class launches are spread over (launch_mac): s[0 .. MAC_CHAINS-1], fork / join events
 constexpr int MAC_CHAINS = 7;  // (one per class: hhv_create asks the runtime for eight hardware queues)
@@ -322,8 +323,9 @@ struct MacStreams {
   void* fork;
   void* join[MAC_CLASSES];
 };
-int mac_length_class(int Lt, bool stage_allowed = true, bool lds_allowed = true);
-int mac_staged_capacity(int max_Lt, int num_cus, bool stage = true);  // hits of a staged (stage) / lean (!stage) class resident at once
+int mac_length_class(int Lt, bool lds_allowed = true);
+size_t mac_rows_lds(int max_Lt, bool stage);  // LDS of a forward / backward workgroup of a class whose longest template has max_Lt columns
+void mac_dataflow_budget(int num_cus, int* max_hits, size_t* max_lds);  // what the dataflow classes 0 .. 5 of one batch may take
 int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream, const MacStreams* side);
 
 // launchers implemented in hhv_kernels.hip
@@ -345,5 +347,7 @@ int celloff_from_mask(uint64_t* bt, const int64_t* rec_off, const int32_t* L, in
 int bt_matrix(const uint64_t* bt, const int64_t* rec_off, int64_t pass_stride, int Lq, StripPlan plan, int bt_mm, int t, int Lt,
               unsigned char* d_out /* (Lq+1) x (Lt+1) */, hipStream_t stream);
 int launch_trace(const TraceArgs& a, void* stream);
+int launch_pack_paths(const DevHit* hits, int n, const int64_t* path_off, const int32_t* pi, const int32_t* pj, const int8_t* ps,
+                      const float* pS, const int64_t* out_off, uint16_t* oi, uint16_t* oj, int8_t* os, float* oS, void* stream);
 
 }  // namespace hhv

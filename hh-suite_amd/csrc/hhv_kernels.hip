@@ -509,6 +509,34 @@ int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, boo
   return 0;
 }
 
+// ---- the paths of a set, packed for the host (hhv_hit_paths_packed) -----------------------------------------------------------
+// The trace pool holds Lq + Lt + 2 entries per template (its capacity), 13 bytes each in four arrays: 156 MB for 20 000 templates of
+// 300 columns, of which a third is path.  One wavefront per hit copies entries 0 .. nsteps of its path into ONE compact record
+// stream - i and j as 16-bit values (template columns end at 65 535, query rows at 32 767), the state byte, the score - at the
+// offset the host computed from the hits' step counts: 9 bytes per step to move instead of 13 per pool entry.
+__global__ void __launch_bounds__(64) hhv_pack_paths_kernel(const DevHit* __restrict__ hits, int n, const int64_t* __restrict__ path_off,
+                                                            const int32_t* __restrict__ pi, const int32_t* __restrict__ pj,
+                                                            const int8_t* __restrict__ ps, const float* __restrict__ pS,
+                                                            const int64_t* __restrict__ out_off, uint16_t* __restrict__ oi,
+                                                            uint16_t* __restrict__ oj, int8_t* __restrict__ os, float* __restrict__ oS) {
+  const int k = blockIdx.x;
+  if (k >= n) return;
+  const int ns = hits[k].nsteps;
+  const int64_t src = path_off[k], dst = out_off[k];
+  for (int e = threadIdx.x; e <= ns; e += 64) {
+    oi[dst + e] = e ? (uint16_t)pi[src + e] : (uint16_t)0;
+    oj[dst + e] = e ? (uint16_t)pj[src + e] : (uint16_t)0;
+    os[dst + e] = e ? ps[src + e] : (int8_t)0;
+    oS[dst + e] = e ? pS[src + e] : 0.0f;
+  }
+}
+int launch_pack_paths(const DevHit* hits, int n, const int64_t* path_off, const int32_t* pi, const int32_t* pj, const int8_t* ps,
+                      const float* pS, const int64_t* out_off, uint16_t* oi, uint16_t* oj, int8_t* os, float* oS, void* stream) {
+  hipLaunchKernelGGL(hhv_pack_paths_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, hits, n, path_off, pi, pj, ps, pS, out_off, oi, oj, os, oS);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 int launch_trace(const TraceArgs& a, void* stream) {
   // The walk: one wavefront per template (a round trip per run of the path; hhv_trace_wave_kernel) - measured ahead of one lane
   // per template at every set size (10 000 templates: the whole backtrace step 2.40 -> 2.27 ms, 100 000: 19.26 -> 19.01;

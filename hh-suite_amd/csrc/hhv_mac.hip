@@ -138,10 +138,6 @@ __device__ __forceinline__ HitView view(const MacArgs& a, int k) {
 // The kernels that fetch mask bytes (and F_MM) from global memory strip by strip ask this first: a strip outside the range is
 // masked without a trip to L2 - in a long template most strips of a row are (300 x 1800: 26 of 29).
 __device__ __forceinline__ bool rng_hits(int2 r, int c_lo, int c_hi) { return c_lo <= r.y && c_hi >= r.x; }
-__device__ __forceinline__ int2 rng_row(const MacArgs& a, int k, int i) {
-  const int2* p = a.row_rng + (size_t)k * (a.Lq + 2);
-  return p[i < 1 ? 1 : (i > a.Lq ? a.Lq : i)];
-}
 
 // SPARSE rows (round 6, hits whose template has MacArgs::sparse_min_Lt columns or more): the dataflow kernels visit, in row i, only
 // the strips [sa, sb] that can hold an active cell of the row OR that the next row will read (a masked cell there must read as
@@ -323,9 +319,20 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     for (int j = 1 + lane; j <= Lt; j += 64) sCo[j] = h.co[(size_t)pitch + j];  // row 1
   }
   __syncthreads();
-  // !STAGE: the cell-off byte of the next strip is fetched while the current one is swept (also across the row boundary)
-  int2 rr_cur = rng_row(a, k, 1), rr_nxt = rr_cur;  // active ranges of rows i and i + 1 (!STAGE)
-  unsigned char co_next = (!STAGE && 1 + lane <= Lt && rng_hits(rr_cur, 1, 64)) ? h.co[(size_t)pitch + 1 + lane] : 1;
+  // !STAGE: the cell-off byte of the next strip is fetched while the current one is swept (also across the row boundary).
+  // Sparse rows (StripSpan; the templates the mask kernel cleared the planes of): a row visits only the strips that hold an active
+  // cell of it or that the next row reads - a 300 x 1800 hit has 3-4 such strips in most rows instead of 29.  A strip left out
+  // holds the row before last in the row buffer; whoever reads it there is a masked cell of a visited strip and discards it.
+  const bool sparse = !STAGE && Lt >= a.sparse_min_Lt;
+  const int ns = (Lt + 63) >> 6;
+  int2 rr_cur = rng_or_none(a, k, 1), rr_nxt = rr_cur, rr_nn = rng_or_none(a, k, 2);  // active ranges of rows i, i + 1, i + 2 (!STAGE)
+  StripSpan sp = span_fwd(sparse, rr_cur, rr_nn, ns), spn = sp;                        // strips of row i and of row i + 1
+  // mask byte of this lane's column in strip ss of row ii (1 = off where the row has no active cell at all)
+  auto fetch_co = [&](int ii, int ss, int2 r) -> unsigned char {
+    const int jn = 1 + (ss << 6) + lane;
+    return (ii <= Lq && jn <= Lt && rng_hits(r, 1 + (ss << 6), 64 + (ss << 6))) ? h.co[(size_t)ii * pitch + jn] : (unsigned char)1;
+  };
+  unsigned char co_next = (!STAGE && sp.sa <= sp.sb) ? fetch_co(1, sp.sa, rr_cur) : (unsigned char)1;
   int cur = 0;
   double pmin = LOCAL ? 1.0 : 0.0, scale_prod = 1.0;
   double Pf = LOCAL ? 1.0 : 0.0;
@@ -347,8 +354,18 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     const double qM2I = qt[T_M2I], qI2I = qt[T_I2I];
     double Pmax = 0.0, carry_mm = 0.0, carry_gd = 0.0, carry_im = 0.0;
     if (!STAGE) {
-      rr_cur = rr_nxt;
-      rr_nxt = rng_row(a, k, i + 1);
+      if (i >= 2) {
+        rr_cur = rr_nxt;
+        rr_nxt = rr_nn;
+        rr_nn = rng_or_none(a, k, i + 2);
+        sp = spn;
+      } else {
+        rr_nxt = rr_nn;
+        rr_nn = rng_or_none(a, k, 3);
+      }
+      spn = span_fwd(sparse, rr_nxt, rr_nn, ns);  // row i + 1
+      // (a row without a strip: the mask byte of the next row's first strip is asked for here instead of in the row's last strip)
+      if (sp.sa > sp.sb) co_next = (i < Lq && spn.sa <= spn.sb) ? fetch_co(i + 1, spn.sa, rr_nxt) : (unsigned char)1;
     }
     unsigned char pre_co[MAC_PRE];
     if (STAGE) {
@@ -359,16 +376,15 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
       }
     }
     const unsigned char* co_row = sCo + ((i - 1) & 1) * co_stride;
-    for (int s0 = 0; s0 < Lt; s0 += 64) {
+    for (int s0 = (STAGE ? 0 : sp.sa << 6); STAGE ? s0 < Lt : s0 <= (sp.sb << 6); s0 += 64) {
       const int j = 1 + s0 + lane;
       const bool valid = j <= Lt;
       const int jc = valid ? j : Lt;
       const bool off = !valid || (STAGE ? co_row[jc] != 0 : co_next != 0);
       if (!STAGE) {
-        const bool last = s0 + 64 >= Lt;
-        const int ni = last ? i + 1 : i, nj = last ? 1 + lane : j + 64;
-        const bool live = rng_hits(last ? rr_nxt : rr_cur, nj - lane, nj - lane + 63);
-        co_next = (ni <= Lq && nj <= Lt && live) ? h.co[(size_t)ni * pitch + nj] : 1;
+        const bool last = (s0 >> 6) >= sp.sb;
+        if (!last) co_next = fetch_co(i, (s0 >> 6) + 1, rr_cur);
+        else co_next = (i < Lq && spn.sa <= spn.sb) ? fetch_co(i + 1, spn.sa, rr_nxt) : (unsigned char)1;
       }
       const unsigned long long on_mask = __ballot(!off);
       if (on_mask == 0) {
@@ -472,7 +488,9 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     if (LOCAL) {
       Pf *= scale_next;
     } else if (i < Lq) {
-      Pf = (Pf + (float)ROW(cur, F_MM, Lt) * scale_next);
+      // (a sparse row's last strip need not be the template's: F_MM of column Lt is then 0, the buffer holds an older row)
+      const double fL = (STAGE || (sp.sa <= sp.sb && sp.sb == ns - 1)) ? ROW(cur, F_MM, Lt) : 0.0;
+      Pf = (Pf + (float)fL * scale_next);
     }
     scale_i = scale_next;
     cur = prv;
@@ -482,7 +500,8 @@ __global__ void __launch_bounds__(64) hhv_mac_forward_kernel(MacArgs a) {
     const int last = cur ^ 1;
     for (int s0 = 0; s0 < Lt; s0 += 64) {
       const int j = 1 + s0 + lane;
-      const double f_mm = j <= Lt ? (double)(float)ROW(last, F_MM, j) : 0.0;
+      const bool seen = STAGE || ((s0 >> 6) >= sp.sa && (s0 >> 6) <= sp.sb);  // (strips row Lq did not visit hold an older row)
+      const double f_mm = (j <= Lt && seen) ? (double)(float)ROW(last, F_MM, j) : 0.0;
       double acc = Pf;
       for (int s = 0; s < 64; ++s) acc = shr1_d(acc, Pf) + f_mm;
       Pf = lane_d(acc, 63);
@@ -580,7 +599,11 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
   float* blist = LISTS ? a.bwd_list + a.mat_off[k] : nullptr;
   unsigned char co_nx = 1;  // mask byte and F_MM of the next strip, fetched while the current one is swept
   float f_nx = 0.0f;
-  int2 rr_row = make_int2(1, 0), rr_nxt = rng_row(a, k, Lq - 1);
+  // sparse rows as in the forward kernel (StripSpan, backward geometry); a hit whose Pforward is not a positive number keeps every
+  // strip: the reference's posterior is then NaN in EVERY cell, which only a visit writes
+  const bool sparse = !STAGE && Lt >= a.sparse_min_Lt && Pf > 0.0 && Pf < 1.0e300;
+  const int nsb = Lt >= 2 ? (Lt - 1 + 63) >> 6 : 0;
+  int2 rr_row = make_int2(1, 0), rr_nxt = rng_or_none(a, k, Lq - 1);
   for (int i = Lq - 1; i >= 1; --i) {
     const int prv = cur ^ 1;
     const double sc = h.scale[i + 1];
@@ -592,6 +615,9 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
     const unsigned char* corow = h.co + (size_t)i * pitch;
     unsigned char pre_co[MAC_PRE];
     float pre_f[MAC_PRE];
+    StripSpan sp;
+    sp.sa = 0;
+    sp.sb = nsb - 1;
     const unsigned char* co_l = sCo + (i & 1) * co_stride;
     const float* f_l = sF + (i & 1) * co_stride;
     if (STAGE) {
@@ -606,9 +632,10 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
       // what the first strip of this row reads from HBM (mask byte, F_MM) and, lane 0, column Lt - issued together
       // (a strip outside the row's active range: masked, and F_MM is the 0 the forward pass left there)
       rr_row = rr_nxt;
-      rr_nxt = rng_row(a, k, i - 1);  // (a row ahead: a scalar load at the start of every row would be waited for)
-      const int j0 = Lt - 1 - lane;
-      const bool live = rng_hits(rr_row, Lt - 64, Lt - 1);
+      rr_nxt = rng_or_none(a, k, i - 1);  // (a row ahead: a scalar load at the start of every row would be waited for)
+      sp = span_bwd(sparse, rr_row, rr_nxt, nsb, Lt);
+      const int j0 = Lt - 1 - (sp.sa << 6) - lane;
+      const bool live = sp.sa <= sp.sb && rng_hits(rr_row, j0 + lane - 63, j0 + lane);
       co_nx = (j0 >= 1 && live) ? corow[j0] : 1;
       f_nx = (j0 >= 1 && live) ? row[j0] : 0.0f;
     }
@@ -630,13 +657,13 @@ __global__ void __launch_bounds__(64) hhv_mac_backward_kernel(MacArgs a) {
     const double qM2M = qt[T_M2M], qM2I = qt[T_M2I], qM2D = qt[T_M2D], qI2M = qt[T_I2M], qI2I = qt[T_I2I], qD2M = qt[T_D2M],
                  qD2D = qt[T_D2D];
     double carry_gd = 0.0, carry_im = 0.0;  // curr[Lt].gd = curr[Lt].im = 0
-    for (int s0 = 0; s0 < Lt - 1; s0 += 64) {
+    for (int s0 = sp.sa << 6; s0 <= (sp.sb << 6); s0 += 64) {
       const int j = Lt - 1 - s0 - lane;  // descending: lane 0 is the rightmost column of the strip
       const bool valid = j >= 1;
       const int jc = valid ? j : 1;
       const bool off = !valid || (STAGE ? co_l[jc] != 0 : co_nx != 0);
       const float f_cur = STAGE ? (valid ? f_l[jc] : 0.0f) : f_nx;
-      if (!STAGE && s0 + 64 < Lt - 1) {
+      if (!STAGE && (s0 >> 6) < sp.sb) {
         const int jn = j - 64;
         const bool live = rng_hits(rr_row, jn + lane - 63, jn + lane);
         co_nx = (jn >= 1 && live) ? corow[jn] : 1;
@@ -2288,28 +2315,29 @@ size_t mac_rows_lds(int max_Lt, bool stage) {
 constexpr size_t MAC_LDS_LIMIT = 160 * 1024;
 
 template <bool LOCAL, bool STAGE, bool GROWS>
-static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t stream, bool dataflow = true) {
-  static const bool no_pipe = getenv("HHV_MAC_NO_PIPE") != nullptr;  // measurement aid: the single-wave kernels for every class
-  if (!GROWS && !no_pipe && dataflow) {
-    // row state in LDS: the dataflow kernels (six wavefronts per hit)
-    (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const bool dbg = getenv("HHV_MAC_DEBUG") != nullptr;  // measurement aid: resident workgroups per CU
-    if (dbg) {
-      int nf = 0, nb = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (const void*)hhv_mac_forward_df_kernel<LOCAL, STAGE>, MAC_DF_THREADS, lds);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, false>, MAC_DFB_THREADS, lds);
-      fprintf(stderr, "hhv_mac: %d hits, %zu B of LDS per workgroup: %d forward / %d backward workgroups resident per CU\n", n, lds, nf, nb);
+static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t stream, bool dataflow) {
+  if constexpr (!GROWS && !STAGE) {
+    if (dataflow) {
+      // row state in LDS: the dataflow kernels (eight wavefronts per hit), template operands from global memory
+      (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      static const bool dbg = getenv("HHV_MAC_DEBUG") != nullptr;  // measurement aid: resident workgroups per CU
+      if (dbg) {
+        int nf = 0, nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (const void*)hhv_mac_forward_df_kernel<LOCAL, false>, MAC_DF_THREADS, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)hhv_mac_backward_df_kernel<LOCAL, false, false>, MAC_DFB_THREADS, lds);
+        fprintf(stderr, "hhv_mac: %d hits, %zu B of LDS per workgroup: %d forward / %d backward workgroups resident per CU\n", n, lds, nf, nb);
+      }
+      hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, false>), dim3(n), dim3(MAC_DF_THREADS), lds, stream, a);
+      if (a.fwd_list) {  // the -o_matrices lists were asked for (hhv_mac_set_lists)
+        hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
+        (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, true>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, a);
+      } else {
+        (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, false>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, a);
+      }
+      return;
     }
-    hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, STAGE>), dim3(n), dim3(MAC_DF_THREADS), lds, stream, a);
-    if (a.fwd_list) {  // the -o_matrices lists were asked for (hhv_mac_set_lists)
-      hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
-      (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, true>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, STAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, STAGE, false>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, a);
-    }
-    return;
   }
   (void)hipFuncSetAttribute((const void*)hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, STAGE, GROWS>), dim3(n), dim3(64), lds, stream, a);
@@ -2322,16 +2350,28 @@ static void launch_mac_rows(const MacArgs& a, int n, size_t lds, hipStream_t str
     hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, STAGE, GROWS, false>), dim3(n), dim3(64), lds, stream, a);
   }
 }
+// aux / aux_join: a second stream (already waiting for the inputs) and its join event for the class whose hits are of two kinds
 template <bool LOCAL>
-static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream) {
+static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipStream_t stream, hipStream_t aux = nullptr,
+                             hipEvent_t aux_join = nullptr, int n_long = 0) {
   static_assert(MAC_PRE <= MAC_DF_STRIPS, "staged classes: at most MAC_PRE strips a row");
-  if (cls <= 3) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream);
-  else if (cls <= 5) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream);  // (fits: mac_length_class)
+  // classes 0 .. 5: the dataflow kernels with the template operands read from global memory (round 6: the copy of the template in LDS
+  // the single-wave kernels needed - STAGE - costs the dataflow kernels twice the footprint and is no faster: 500 hits 300 x 300
+  // 3.48 -> 3.32 ms without it, mixed lengths 6.2 -> 5.2 ms, where the LDS of the CUs is what limits the hits in flight).
+  // HHV_MAC_NO_PIPE (measurement aid): the single-wave kernels for every class, staged where the template fits.
+  static const bool no_pipe = getenv("HHV_MAC_NO_PIPE") != nullptr;
+  if (cls <= 5 && !no_pipe) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream, true);
+  else if (cls <= 3 && mac_rows_lds(max_Lt, true) <= MAC_LDS_LIMIT && max_Lt <= MAC_PRE * 64) launch_mac_rows<LOCAL, true, false>(a, n, mac_rows_lds(max_Lt, true), stream, false);
+  else if (cls <= 5) launch_mac_rows<LOCAL, false, false>(a, n, mac_rows_lds(max_Lt, false), stream, false);  // (fits: mac_length_class)
   else {
     // templates beyond the plain LDS layout: the dataflow kernels on a ring of strips for the hits whose rows all fit it, the
     // single-wave kernels (row state in global memory) for the others - both launched over the whole class, a workgroup whose
     // hit is of the other kind returns at once (the kind is decided on the device: rng[0].x, written with the masks)
-    static const bool no_ring = getenv("HHV_MAC_NO_RING") != nullptr || getenv("HHV_MAC_NO_PIPE") != nullptr;  // measurement aids
+    // (the ring kernels over the first n_long hits of the class only - the class lists its longest templates first -, the others
+    // are short templates beyond the dataflow budget: 1 500 workgroups asking for a whole CU's LDS just to return would wait for it)
+    static const bool ring_off = getenv("HHV_MAC_NO_RING") != nullptr || getenv("HHV_MAC_NO_PIPE") != nullptr;  // measurement aids
+    const bool no_ring = ring_off || n_long <= 0;
+    const int n_ring = n_long < n ? n_long : n;
     MacArgs ar = a, ag = a;
     ar.lds_cols = MAC_RING_COLS;
     ag.ring_strips = no_ring ? 0 : MAC_RING_STRIPS;
@@ -2343,23 +2383,30 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
     }();
     ar.ring_min_Lt = ag.ring_min_Lt = ring_min;
     const size_t lds = mac_rows_lds(MAC_RING_COLS, false);
+    // the two kinds side by side when there is a second stream and no forward list (hhv_mac_fwdlist_kernel runs over the whole class
+    // between the forward and the backward kernels of both kinds)
+    hipStream_t sw = (aux && aux_join && !a.fwd_list && !no_ring) ? aux : stream;
     if (!no_ring) {
       (void)hipFuncSetAttribute((const void*)hhv_mac_forward_df_kernel<LOCAL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, false, true>), dim3(n), dim3(MAC_DF_THREADS), lds, stream, ar);
+      hipLaunchKernelGGL((hhv_mac_forward_df_kernel<LOCAL, false, true>), dim3(n_ring), dim3(MAC_DF_THREADS), lds, stream, ar);
     }
-    hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, false, true>), dim3(n), dim3(64), 0, stream, ag);
+    hipLaunchKernelGGL((hhv_mac_forward_kernel<LOCAL, false, true>), dim3(n), dim3(64), 0, sw, ag);
     if (a.fwd_list) hipLaunchKernelGGL(hhv_mac_fwdlist_kernel, dim3(n), dim3(256), 0, stream, a);
     if (!no_ring) {
       if (a.fwd_list) {
         (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, true, true>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, ar);
+        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, true, true>), dim3(n_ring), dim3(MAC_DFB_THREADS), lds, stream, ar);
       } else {
         (void)hipFuncSetAttribute((const void*)hhv_mac_backward_df_kernel<LOCAL, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, false, true>), dim3(n), dim3(MAC_DFB_THREADS), lds, stream, ar);
+        hipLaunchKernelGGL((hhv_mac_backward_df_kernel<LOCAL, false, false, true>), dim3(n_ring), dim3(MAC_DFB_THREADS), lds, stream, ar);
       }
     }
-    if (a.fwd_list) hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, false, true, true>), dim3(n), dim3(64), 0, stream, ag);
-    else hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, false, true, false>), dim3(n), dim3(64), 0, stream, ag);
+    if (a.fwd_list) hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, false, true, true>), dim3(n), dim3(64), 0, sw, ag);
+    else hipLaunchKernelGGL((hhv_mac_backward_kernel<LOCAL, false, true, false>), dim3(n), dim3(64), 0, sw, ag);
+    if (sw != stream) {  // the DP below runs over the whole class
+      (void)hipEventRecord(aux_join, sw);
+      (void)hipStreamWaitEvent(stream, aux_join, 0);
+    }
   }
   // maximum-accuracy DP: along anti-diagonals (hhv_mac_dp_diag_kernel) unless 0.5 * mact is not a float (its chain steps are
   // float subtractions) or HHV_MAC_DP_ROWS asks for the row-by-row kernel (measurement aid)
@@ -2388,30 +2435,22 @@ static void launch_mac_class(const MacArgs& a, int cls, int n, int max_Lt, hipSt
   }
 }
 
-// hits of a staged class that are resident at once: the LDS footprint of the class's longest template decides how many
-// single-wave workgroups a CU holds.  A class with more hits than that runs in rounds; with the template operands read from
-// global memory instead (classes 4, 5: 80 B of LDS per column instead of 202) three times as many hits are resident, which more
-// than pays for the slower operand path: 2 000 hits of 300 columns 15.6 -> 10.6 ms of kernels, 500 hits 4.64 -> 5.00 ms
-// (tools/bench_mac.py, HHV_MAC_NO_STAGE; profiles/r3_next_rows_summary.txt).
-// The same one level further: a lean class (row state in LDS) with more hits than ITS residency runs with the row state in
-// global memory as well (class 6: no LDS, as many workgroups as the registers admit): 2 000 hits 10.6 -> 9.35 ms, 500 hits
-// 4.68 (staged) / 5.01 (lean) / 4.90 (no LDS) - the sweeps' dependent chains, not the operand path, set the pace.
-// (Numbers of the single-wave kernels, rounds 3-4.  Since round 5 the classes with LDS run the dataflow kernels - 500 hits 4.0 ms -
-// and hold two hits per CU; a batch beyond that still ends in class 6: 2 000 hits 9.23 ms, profiles/r5_next_rows_summary.txt.)
-int mac_staged_capacity(int max_Lt, int num_cus, bool stage) {
-  const size_t lds = mac_rows_lds(max_Lt, stage);
-  // (round 5: the dataflow kernels are workgroups of eight wavefronts at ~100 VGPRs: two per CU whatever the LDS footprint)
-  return num_cus * (int)std::min<size_t>(2, std::max<size_t>(1, MAC_LDS_LIMIT / std::max<size_t>(lds, 1)));
+// Which hits of a batch the dataflow kernels take (hhv_api_mac.cpp): a workgroup of theirs is eight wavefronts at ~100 VGPRs - two per
+// CU - with 112 B of LDS per template column of its class's longest template, and a batch that does not fit the GPU at once would run
+// in rounds of latency-bound workgroups.  The hits beyond the budget - the shortest ones - go to the class without LDS, whose
+// single-wave kernels run at up to sixteen hits per CU: slower per hit, more hits per second (2 000 hits of 300 columns: 8.6 ms
+// all single-wave; 500 hits 3.3 ms dataflow against 4.0 ms single-wave).
+void mac_dataflow_budget(int num_cus, int* max_hits, size_t* max_lds) {
+  static const int env_hits = [] { const char* e = getenv("HHV_MAC_DF_HITS"); return e ? atoi(e) : -1; }();  // measurement aid
+  *max_hits = env_hits >= 0 ? env_hits : 2 * num_cus;
+  *max_lds = (size_t)num_cus * MAC_LDS_LIMIT / 10 * 9;  // (the CUs' LDS is not filled to the last byte by workgroups of mixed sizes)
 }
-int mac_length_class(int Lt, bool stage_allowed, bool lds_allowed) {
-  static const bool no_stage = getenv("HHV_MAC_NO_STAGE") != nullptr;  // measurement aid: template operands from global memory for every length
-  if (stage_allowed && !no_stage && mac_rows_lds(Lt, true) <= MAC_LDS_LIMIT && Lt <= MAC_PRE * 64)
-    return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : 3;
+int mac_length_class(int Lt, bool lds_allowed) {
   static const bool no_lds = getenv("HHV_MAC_NO_LDS") != nullptr;  // measurement aid: row state in global memory for every length
-  // (round 6: templates beyond the dataflow kernels' LDS layout - ~1450 columns - go straight to the class without LDS: the
-  // single-wave kernels are no faster with their rows in LDS than in L2, and one such template no longer drags its whole class
-  // onto them)
-  if (lds_allowed && !no_lds && mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT && (Lt + 63) / 64 <= MAC_DF_STRIPS) return Lt <= 1022 ? 4 : 5;
+  // (templates beyond the dataflow kernels' LDS layout - ~1450 columns - go straight to the class without LDS: there the ring
+  // variants of the dataflow kernels take the hits whose rows fit their ring, the single-wave kernels the others)
+  if (lds_allowed && !no_lds && mac_rows_lds(Lt, false) <= MAC_LDS_LIMIT && (Lt + 63) / 64 <= MAC_DF_STRIPS)
+    return Lt <= 128 ? 0 : Lt <= 256 ? 1 : Lt <= 384 ? 2 : Lt <= 640 ? 3 : Lt <= 1022 ? 4 : 5;
   return 6;
 }
 
@@ -2430,7 +2469,13 @@ int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* strea
   // that share one run one after the other (seven streams: the longest class's forward - backward - DP chain waited behind another
   // class's, 500 mixed-length hits 10.0 -> 14.8 ms).  Classes of the longest templates first, each to the chain with the least
   // work so far (cost ~ a hit's rows x columns; the hits of a class run concurrently).
-  const bool fork = side && non_empty > 1 && side->s[0];
+  const bool fork = side && non_empty > 1 && side->s[1];
+  // stream 0 of the side streams: the single-wave kernels of the longest class (chain 0 is the caller's stream itself)
+  hipStream_t aux = (side && side->s[0] && cls.n[MAC_CLASSES - 1] > 0) ? (hipStream_t)side->s[0] : nullptr;
+  if (aux && !fork) {
+    (void)hipEventRecord((hipEvent_t)side->fork, stream);
+    (void)hipStreamWaitEvent(aux, (hipEvent_t)side->fork, 0);
+  }
   static const int n_chains = [] { const char* e = getenv("HHV_MAC_CHAINS"); const int v = e ? atoi(e) : MAC_CHAINS; return v < 1 ? 1 : (v > MAC_CLASSES ? MAC_CLASSES : v); }();
   int chain_of[MAC_CLASSES];
   double load[MAC_CLASSES] = {};
@@ -2443,7 +2488,10 @@ int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* strea
     chain_of[c] = best;
     load[best] += 256.0 + cls.max_Lt[c];
   }
-  if (fork) (void)hipEventRecord((hipEvent_t)side->fork, stream);  // everything queued so far: inputs, masks
+  if (fork) {
+    (void)hipEventRecord((hipEvent_t)side->fork, stream);  // everything queued so far: inputs, masks
+    if (aux) (void)hipStreamWaitEvent(aux, (hipEvent_t)side->fork, 0);
+  }
   bool used[MAC_CLASSES] = {};
   for (int c = MAC_CLASSES - 1; c >= 0; --c) {
     if (cls.n[c] == 0) continue;
@@ -2456,8 +2504,9 @@ int launch_mac(const MacArgs& a0, bool local, const MacClasses& cls, void* strea
     MacArgs a = a0;
     a.sel = a0.sel + first_of[c];
     a.lds_cols = cls.max_Lt[c];
-    if (local) launch_mac_class<true>(a, c, cls.n[c], cls.max_Lt[c], st);
-    else launch_mac_class<false>(a, c, cls.n[c], cls.max_Lt[c], st);
+    hipStream_t ax = c == MAC_CLASSES - 1 ? aux : nullptr;
+    if (local) launch_mac_class<true>(a, c, cls.n[c], cls.max_Lt[c], st, ax, ax ? (hipEvent_t)side->join[0] : nullptr, cls.n_long);
+    else launch_mac_class<false>(a, c, cls.n[c], cls.max_Lt[c], st, ax, ax ? (hipEvent_t)side->join[0] : nullptr, cls.n_long);
   }
   for (int q = 0; q < MAC_CLASSES; ++q)
     if (used[q]) {

@@ -75,6 +75,7 @@ struct PhaseTimer {
   bool on;
   double t_last;
   double acc[N];
+  std::vector<std::pair<const char*, double> > detail;  // the same seconds under finer labels (second line of the report)
   size_t cached, fresh, host_prepared, sidecar;
   PhaseTimer() : on(getenv("HHV_DROPIN_TIMING") != NULL), t_last(now()), cached(0), fresh(0), host_prepared(0), sidecar(0) {
     for (int k = 0; k < N; ++k) acc[k] = 0;
@@ -84,9 +85,15 @@ struct PhaseTimer {
     gettimeofday(&tv, NULL);
     return tv.tv_sec + 1e-6 * tv.tv_usec;
   }
-  void lap(int phase) {
+  void lap(int phase, const char* what = NULL) {
     const double t = now();
     acc[phase] += t - t_last;
+    if (on && what) {
+      size_t k = 0;
+      while (k < detail.size() && detail[k].first != what && strcmp(detail[k].first, what) != 0) ++k;
+      if (k == detail.size()) detail.push_back(std::make_pair(what, 0.0));
+      detail[k].second += t - t_last;
+    }
     t_last = t;
   }
   ~PhaseTimer() {
@@ -94,6 +101,11 @@ struct PhaseTimer {
       fprintf(stderr, "hhviterbirunner_hip: templates %zu cached + %zu read, %zu of them from the sidecar (+ %zu host-prepared); read %.3f s, upload %.3f s, "
               "device prepare %.3f s, masks %.3f s, align+hits %.3f s, paths+Hit %.3f s, other %.3f s\n",
               cached, fresh, sidecar, host_prepared, acc[READ], acc[UPLOAD], acc[PREPARE], acc[MASKS], acc[ALIGN], acc[PATHS], acc[OTHER]);
+    if (on && !detail.empty()) {
+      fprintf(stderr, "hhviterbirunner_hip:   in ms:");
+      for (size_t k = 0; k < detail.size(); ++k) fprintf(stderr, " %s %.2f,", detail[k].first, 1e3 * detail[k].second);
+      fprintf(stderr, "\n");
+    }
   }
 };
 
@@ -421,7 +433,7 @@ struct Search {
     hhv_ctx* ctx = tc.slots[dev].ctx;
     hhv_tset* ts = set;
     hhv_tset* sub = NULL;
-    if (timed) timer.lap(PhaseTimer::OTHER);
+    if (timed) timer.lap(PhaseTimer::OTHER, "groups");
     if (ids) {
       hip_check(hhv_tset_gather(ctx, set, ids, n, &sub), "hhv_tset_gather");
       ts = sub;
@@ -453,17 +465,24 @@ struct Search {
                 "hhv_set_celloff_paths");
     }
     std::vector<hhv_hit> hits(n);
-    if (timed) timer.lap(PhaseTimer::MASKS);
+    if (timed) timer.lap(PhaseTimer::MASKS, "gather+masks");
     hip_check(hhv_align(ctx, ts, masked ? HHV_ALIGN_CELLOFF : HHV_ALIGN_BACKTRACE, NULL), "hhv_align");
+    if (timed) timer.lap(PhaseTimer::ALIGN, "hhv_align");
     hip_check(hhv_hits(ctx, ts, hits.data()), "hhv_hits");
-    if (timed) timer.lap(PhaseTimer::ALIGN);
-    // the path pool in one piece (host mirror of the set); the Hit objects are filled by all threads
-    const int64_t* path_off = NULL;
+    if (timed) timer.lap(PhaseTimer::ALIGN, "hhv_hits");
+    // the paths in one piece: the compact records of hhv_hit_paths_packed (steps 0 .. nsteps of every hit, 16-bit i / j, in a
+    // pinned buffer of the context), else the host mirror of the whole pool, else hit by hit; the Hit objects are filled by all
+    // threads
+    const int64_t *pk_off = NULL, *path_off = NULL;
+    const uint16_t *pk_i = NULL, *pk_j = NULL;
     const int32_t *pool_i = NULL, *pool_j = NULL;
-    const int8_t* pool_states = NULL;
-    const float* pool_S = NULL;
-    const bool pooled = hhv_hit_path_pool(ctx, ts, &path_off, &pool_i, &pool_j, &pool_states, &pool_S) == HHV_OK;
-#pragma omp parallel for schedule(static) num_threads(threads) if (pooled && n > 256)
+    const int8_t *pk_states = NULL, *pool_states = NULL;
+    const float *pk_S = NULL, *pool_S = NULL;
+    const bool packed = hhv_hit_paths_packed(ctx, ts, hits.data(), &pk_off, &pk_i, &pk_j, &pk_states, &pk_S) == HHV_OK;
+    const bool pooled = !packed && hhv_hit_path_pool(ctx, ts, &path_off, &pool_i, &pool_j, &pool_states, &pool_S) == HHV_OK;
+    const bool with_ss = ss_hmm_mode != HMM::NO_SS_INFORMATION;
+    if (timed) timer.lap(PhaseTimer::PATHS, "paths to host");
+#pragma omp parallel for schedule(static) num_threads(threads) if ((packed || pooled) && n > 256)
     for (int k = 0; k < n; ++k) {
       const hhv_hit& h = hits[k];
       Hit& hit = *out[k];
@@ -478,7 +497,16 @@ struct Search {
       hit.states = new char[cap];
       hit.S = new float[cap];
       hit.S_ss = new float[cap];
-      if (pooled) {
+      if (packed) {
+        const int64_t po = pk_off[k];
+        const uint16_t *si = pk_i + po, *sj = pk_j + po;
+        for (int s = 0; s < cap; ++s) {
+          hit.i[s] = si[s];
+          hit.j[s] = sj[s];
+        }
+        memcpy(hit.states, pk_states + po, (size_t)cap);
+        memcpy(hit.S, pk_S + po, (size_t)cap * sizeof(float));
+      } else if (pooled) {
         const int64_t po = path_off[k];
         memcpy(hit.i, pool_i + po, (size_t)cap * sizeof(int));
         memcpy(hit.j, pool_j + po, (size_t)cap * sizeof(int));
@@ -491,10 +519,14 @@ struct Search {
       hit.i[0] = hit.j[0] = 0;
       hit.states[0] = 0;
       hit.S[0] = hit.S_ss[0] = 0.0f;
-      for (int step = 1; step <= h.nsteps; ++step)  // BacktraceScore.S_ss, src/hhviterbi.cpp:222-237
-        hit.S_ss[step] = (hit.states[step] == ViterbiMatrix::MM && ss_hmm_mode != HMM::NO_SS_INFORMATION)
-                             ? score_ss_step(tables, par.ssw, ss_hmm_mode, q_simd, hit.i[step], *tmpl[k]->ss, hit.j[step])
-                             : 0.0f;
+      if (with_ss) {
+        for (int step = 1; step <= h.nsteps; ++step)  // BacktraceScore.S_ss, src/hhviterbi.cpp:222-237
+          hit.S_ss[step] = hit.states[step] == ViterbiMatrix::MM
+                               ? score_ss_step(tables, par.ssw, ss_hmm_mode, q_simd, hit.i[step], *tmpl[k]->ss, hit.j[step])
+                               : 0.0f;
+      } else {
+        memset(hit.S_ss, 0, (size_t)cap * sizeof(float));
+      }
       hit.nsteps = h.nsteps;
       hit.matched_cols = h.matched_cols;
       hit.i1 = h.i1;
@@ -502,8 +534,9 @@ struct Search {
       hit.i2 = h.i2;
       hit.j2 = h.j2;
     }
+    if (timed) timer.lap(PhaseTimer::PATHS, "Hit arrays");
     if (sub) hhv_tset_free(sub);
-    if (timed) timer.lap(PhaseTimer::PATHS);
+    if (timed) timer.lap(PhaseTimer::PATHS, "free subset");
   }
 };
 
@@ -593,7 +626,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         const unsigned int cn = imin(m - c0, chunk_max);
         HHEntry** ent = &work[block_start + c0];
         Hit* hit0 = &ret_hits[first_hit_of_block + c0];
-        timer.lap(PhaseTimer::OTHER);
+        timer.lap(PhaseTimer::OTHER, "sort+Hit vector");
 
         if (alignment == 0) {
           // ---- which templates are already resident in raw form? ----
@@ -613,6 +646,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
             for (unsigned int k = 0; k < cn; ++k) to_read.push_back(k);
           }
           timer.cached += cn - to_read.size();
+          timer.lap(PhaseTimer::READ, "cache lookup");
 
           // ---- read the others with the reference's code (:144), one template per iteration; no device lock ----
           std::vector<HostTemplate> host(to_read.size());
@@ -744,7 +778,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
             }
             for (size_t x = 0; x < files.size(); ++x) files[x]->flush();
           }
-          timer.lap(PhaseTimer::READ);
+          timer.lap(PhaseTimer::READ, "read+parse");
 
           // ---- device section 1: new raw templates into the cache, host-prepared ones into a set of this search,
           //      PrepareTemplateHMM on the device for everything raw ----
@@ -922,13 +956,13 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 resident[ent[k]] = rt;
               }
             }
-            timer.lap(PhaseTimer::PREPARE);
+            timer.lap(PhaseTimer::PREPARE, "device prepare");
             // templates not read in this search: template information from the prototype
 #pragma omp parallel for schedule(static) num_threads(threads) if (cn > 256)
             for (unsigned int k = 0; k < cn; ++k)
               if (cached[k] && !hit0[k].name) copy_template_info(cached[k]->proto, &hit0[k]);
             for (unsigned int k = 0; k < cn; ++k) hit0[k].entry = ent[k];
-            timer.lap(PhaseTimer::PATHS);
+            timer.lap(PhaseTimer::PATHS, "prototype copies");
           }
         } else {
           for (unsigned int k = 0; k < cn; ++k) {
@@ -1001,6 +1035,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         }
       }
 
+      timer.lap(PhaseTimer::OTHER, "after run");
       // ---- merge_thread_results (:249-271) ----
       for (unsigned int k = 0; k < m; ++k) {
         Hit& h = ret_hits[first_hit_of_block + k];
@@ -1011,6 +1046,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         }
       }
       HH_LOG(INFO) << (block_start + m) << " alignments done" << std::endl;
+      timer.lap(PhaseTimer::OTHER, "merge");
 
       if (alignment == 0 && par.early_stopping_filter) {  // :178-188
         float early_stopping_sum = calculateEarlyStop(par, q, ret_hits, block_start);
@@ -1025,7 +1061,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
     work.swap(next_work);
   }
 
-  timer.lap(PhaseTimer::OTHER);
+  timer.lap(PhaseTimer::OTHER, "early stop");
   {
     std::lock_guard<std::mutex> lock(tc.device);
     for (size_t k = 0; k < search_sets.size(); ++k) hhv_tset_free(search_sets[k]);
@@ -1037,7 +1073,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
     delete t_hmm[k];
     delete t_hdr[k];
   }
-  timer.lap(PhaseTimer::OTHER);
+  timer.lap(PhaseTimer::OTHER, "free sets");
   std::vector<Hit> result;
   result.swap(ret_hits);
   return result;

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 # hardware queues for the streams of the MAC length classes (hhv_create's comment): exported here because a host that
 # loads torch has usually initialised HIP before the library sees its first call
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = os.environ.get("HHV_LIB", os.path.join(os.path.dirname(HERE), "lib", "libhhviterbi_hip.so"))
 
 HHV_ALIGN_BACKTRACE = 1
@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "hhv_mac_realign", "hhv_mac_realign_hits", "hhv_mac_realign_tset", "hhv_mac_set_ss", "hhv_mac_celloff", "hhv_mac_path", "hhv_mac_posterior", "hhv_mac_set_lists", "hhv_mac_list", "hhv_macset_free",
     "hhv_prepare_subset", "hhv_rawdb_write", "hhv_rawdb_open", "hhv_rawset_size", "hhv_rawset_lengths",
     "hhv_db_write", "hhv_db_open", "hhv_tset_gather", "hhv_tset_free", "hhv_tset_size", "hhv_tset_cells", "hhv_tset_records", "hhv_align", "hhv_align_async",
-    "hhv_sync", "hhv_check_error", "hhv_tset_set_neff", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
+    "hhv_sync", "hhv_check_error", "hhv_tset_set_neff", "hhv_hit_paths_packed", "hhv_stream", "hhv_last_kernel_ms", "hhv_set_celloff", "hhv_set_celloff_paths", "hhv_set_global_batch", "hhv_backtrace_matrix", "hhv_backtrace", "hhv_hits",
     "hhv_hit_path", "hhv_hit_path_pool", "hhv_topk", "hhv_device_count", "hhv_shard_plan", "hhv_segment_plan",
     "hhv_tset_set_global_ids", "hhv_merge_hits",
 ]
@@ -669,6 +669,21 @@ class Context:
         tot = int(off[n])
         i_steps = np.ctypeslib.as_array(C.cast(ptrs[1], C.POINTER(C.c_int32)), shape=(tot,)).copy()
         j_steps = np.ctypeslib.as_array(C.cast(ptrs[2], C.POINTER(C.c_int32)), shape=(tot,)).copy()
+        states = np.ctypeslib.as_array(C.cast(ptrs[3], C.POINTER(C.c_int8)), shape=(tot,)).copy()
+        S = np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_float)), shape=(tot,)).copy()
+        return off, i_steps, j_steps, states, S
+
+    def hit_paths_packed(self, ts, hits):
+        """hhv_hit_paths_packed: (off[n+1], i_steps u16, j_steps u16, states, S) - the paths of hhv_hits without the pool's unused
+        capacity (entry off[k] + s = step s of template k, s = 0..nsteps, entry 0 all zero); numpy copies of the pinned buffer."""
+        ptrs = [C.c_void_p() for _ in range(5)]
+        self.lib.hhv_hit_paths_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.POINTER(C.c_void_p)] * 5
+        self._chk(self.lib.hhv_hit_paths_packed(self.h, ts.h, hits.ctypes.data, *[C.byref(p) for p in ptrs]))
+        n = ts.n
+        off = np.ctypeslib.as_array(C.cast(ptrs[0], C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+        tot = int(off[n])
+        i_steps = np.ctypeslib.as_array(C.cast(ptrs[1], C.POINTER(C.c_uint16)), shape=(tot,)).copy()
+        j_steps = np.ctypeslib.as_array(C.cast(ptrs[2], C.POINTER(C.c_uint16)), shape=(tot,)).copy()
         states = np.ctypeslib.as_array(C.cast(ptrs[3], C.POINTER(C.c_int8)), shape=(tot,)).copy()
         S = np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_float)), shape=(tot,)).copy()
         return off, i_steps, j_steps, states, S

@@ -434,6 +434,13 @@ int hhv_hit_path(hhv_ctx* ctx, hhv_tset* ts, int32_t k, int32_t cap, int32_t* i_
  * one call instead of one hhv_hit_path per hit. */
 int hhv_hit_path_pool(hhv_ctx* ctx, hhv_tset* ts, const int64_t** path_off, const int32_t** i_steps, const int32_t** j_steps,
                       const int8_t** states, const float** S);
+/* The paths of the last hhv_hits WITHOUT the pool's unused capacity: one compact record stream, entries off[k] + 0 .. off[k] +
+ * hits[k].nsteps of hit k (entry 0 is the unused index 0 of BacktraceResult, all zero), i and j as 16-bit values.  hits = what
+ * hhv_hits returned for this set (its step counts size the records).  The arrays live in a pinned buffer of the CONTEXT and stay
+ * valid until the next hhv_hit_paths_packed call of any set of the context.  For callers that turn every path into a Hit
+ * (ViterbiRunner::alignment, src/hhviterbirunner.cpp:35-67): 9 bytes per path step cross PCIe instead of 13 per pool entry. */
+int hhv_hit_paths_packed(hhv_ctx* ctx, hhv_tset* ts, const hhv_hit* hits, const int64_t** off, const uint16_t** i_steps,
+                         const uint16_t** j_steps, const int8_t** states, const float** S);
 /* K best hits by hit score (descending, ties by smaller index), selected on the device.
  * flags: 0 = rank by Hit.score (needs hhv_hits); HHV_TOPK_RAW = rank by the raw Viterbi score of the
  * last hhv_align (score-only searches: the records carry viterbi_score, i2, j2, index; path fields 0).

@@ -4,7 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # as bench.py and pyhhv/capi.py: before torch brings up HIP (hhv_create's comment)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # as bench.py and pyhhv/capi.py: before torch brings up HIP (hhv_create's comment)
 for p in (os.path.join(ROOT, "hh-suite_amd"), os.path.join(ROOT, "oracle"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -66,6 +66,21 @@ def test_wave_walk_equals_lane_walk(oracle, Lq, local):
         a, b = int(off[e]) + 1, int(off[e]) + ns + 1
         for x, y in zip(p1[1:], p0[1:]):
             assert np.array_equal(x[a:b], y[a:b]), (Lq, local, e)
+    # the compact records of hhv_hit_paths_packed: steps 0 .. nsteps of every path and nothing else, entry 0 all zero
+    c.align(ts, backtrace=True)
+    hk = c.hits(ts).copy()
+    assert hk.tobytes() == h1.tobytes()
+    koff, ki, kj, kst, kS = c.hit_paths_packed(ts, hk)
+    assert int(koff[n]) == int(hk["nsteps"].sum()) + n
+    for e in range(n):
+        ns = int(hk["nsteps"][e])
+        a, o = int(off[e]), int(koff[e])
+        assert int(koff[e + 1]) - o == ns + 1
+        assert ki[o] == 0 and kj[o] == 0 and kst[o] == 0 and kS[o] == 0.0
+        assert np.array_equal(ki[o + 1:o + ns + 1].astype(np.int32), p1[1][a + 1:a + ns + 1]), (Lq, local, e)
+        assert np.array_equal(kj[o + 1:o + ns + 1].astype(np.int32), p1[2][a + 1:a + ns + 1])
+        assert np.array_equal(kst[o + 1:o + ns + 1], p1[3][a + 1:a + ns + 1])
+        assert kS[o + 1:o + ns + 1].tobytes() == p1[4][a + 1:a + ns + 1].tobytes()
     seen = {}
     for e in range(n):
         if pick[e] in seen:

@@ -339,9 +339,9 @@ def test_gpu_mac_length_classes(oracle, lengths):
 
 @pytest.mark.gpu
 def test_gpu_mac_more_hits_than_resident_workgroups(oracle):
-    """A staged length class (template in LDS) with more hits than its workgroups are resident at once hands its hits to the
-    lean classes (template operands from global memory, hhv_api_mac.cpp / mac_staged_capacity): 1 400 hits of 20-40 columns
-    (the class holds 5 x 256) together with a few long ones that stay staged; results must not depend on the class taken."""
+    """The dataflow classes take the longest hits of a batch up to what the GPU holds at once (hhv_api_mac.cpp /
+    mac_dataflow_budget), the shortest ones beyond it go to the single-wave kernels of the class without LDS: 1 400 hits of
+    20-40 columns together with a few long ones that stay in their dataflow classes; results must not depend on the class taken."""
     from pyhhv import capi
     Lq = 36
     qp, qtr = synth.make_query(91, Lq)

@@ -90,7 +90,7 @@ PY
 mac)   # mac [soak_s]: the MAC realignment after a kernel change: its tests, a soak of its family, the 500-hit timing (fixed and mixed lengths)
   timeout 900 python -m pytest tests/test_mac.py tests/test_dropin_realign.py tests/test_pipeline.py tests/test_dropin_apps.py -q -m gpu -x 2>&1 | tail -3
   timeout 300 python tools/soak.py ${1:-40} 777 mac 2>$OUT/soak_mac.err | tail -3
-  for a in "500 300 300 50" "500 300 0 50" "500 700 0 20"; do timeout 300 python tools/bench_mac.py $a 2>>$OUT/bench_mac.err | tee -a $OUT/bench_mac.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('n_hits','Lq','Lt','gpu_kernels_ms','mismatches_vs_reference','checked')}, d['resident_set']['gpu_kernels_ms'])"; done
+  for a in "500 300 300 50" "500 300 0 50" "500 700 0 20" "2000 300 300 20"; do timeout 300 python tools/bench_mac.py $a 2>>$OUT/bench_mac.err | tee -a $OUT/bench_mac.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('n_hits','Lq','Lt','gpu_kernels_ms','mismatches_vs_reference','checked')}, d['resident_set']['gpu_kernels_ms'])"; done
   echo "single-wave kernels (HHV_MAC_NO_PIPE=1):"
   for a in "500 300 300 0" "500 300 0 0"; do HHV_MAC_NO_PIPE=1 timeout 300 python tools/bench_mac.py $a 2>>$OUT/bench_mac.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('n_hits','Lq','Lt','gpu_kernels_ms')}, d['resident_set']['gpu_kernels_ms'])"; done
   ;;
@@ -146,6 +146,31 @@ for f in glob.glob("/tmp/prof_bt/**/*kernel_stats.csv", recursive=True):
         if "hhv" in r["Name"] or "topk" in r["Name"] or "merge" in r["Name"] or "select" in r["Name"]:
             print("%-70s calls %5s  avg %10.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
+  ;;
+mactl)   # mactl "<n Lq Lt>": timeline of the kernels of ONE timed realignment (kernel trace: start, duration, workgroups, stream)
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/prof_tl; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -o tl -- python $ROOT/tools/bench_mac.py $1 0 > $OUT/prof_mactl.txt 2>&1
+  python - <<'PY'
+import csv, glob
+f = glob.glob("/tmp/prof_tl/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the timed realignment = the run of MAC kernels that holds the LAST hhv_mac_trace_kernel before the resident-set repetition
+mac = [r for r in rows if "mac" in r["Kernel_Name"] or "stream_kernel" in r["Kernel_Name"]]
+t0 = int(mac[0]["Start_Timestamp"])
+last = None
+for r in mac:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if last is not None and s - last > 2000000: print("---- gap %.2f ms" % ((s - last) / 1e6))
+    last = max(last or 0, e)
+    name = r["Kernel_Name"].replace("hhv::", "").replace("void ", "")[:62]
+    print("%9.3f ms  +%8.3f ms  wg %5d x %4d  q %s  lds %6s  %s" % ((s - t0) / 1e6, (e - s) / 1e6, int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Workgroup_Size_X"]), r.get("Queue_Id", "?"), r.get("LDS_Block_Size", "?"), name))
+PY
+  tail -1 $OUT/prof_mactl.txt | cut -c1-300
+  ;;
+r6d)   # drop-in host path: the packed path records (tests), then alignment() of 20 000 resident templates with its phase timers
+  timeout 900 python -m pytest tests/test_gpu_trace.py tests/test_dropin_runner.py tests/test_dropin_apps.py -q -m gpu -x 2>&1 | tail -3
+  HHV_DROPIN_TIMING=1 timeout 600 python tools/bench_dropin.py ${1:-20000} 16 300 2>&1 | grep -v "^$" | tail -14
   ;;
 dbg)   # dbg <args of tools/dbg_ss.py>
   timeout 120 python tools/dbg_ss.py "$@" 2>&1 | tail -30
