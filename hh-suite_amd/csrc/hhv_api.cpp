@@ -11,6 +11,8 @@
 
 using namespace hhv;
 using hhv::api::dfree;
+using hhv::api::tfree;
+using hhv::api::tmalloc;
 using hhv::api::fail;
 using hhv::api::sync_check;
 using hhv::api::tset_init_common;
@@ -282,6 +284,7 @@ void hhv_destroy(hhv_ctx* c) {
     if (c->mac_side.join[k]) (void)hipEventDestroy((hipEvent_t)c->mac_side.join[k]);
   }
   if (c->mac_side.fork) (void)hipEventDestroy((hipEvent_t)c->mac_side.fork);
+  hhv::api::pool_release(c);
   if (c->h_packed) (void)hipHostFree(c->h_packed);
   dfree(c->d_packed);
   if (c->mac_pinned) (void)hipHostFree(c->mac_pinned);
@@ -463,6 +466,101 @@ static int ensure_ss(hhv_ctx* c) {
 
 }  // extern "C"
 
+hipError_t hhv::api::pool_malloc(hhv_ctx* c, void** p, size_t bytes) {
+  *p = nullptr;
+  const size_t want = (std::max<size_t>(bytes, 1) + 511) & ~(size_t)511;
+  if (!c) return hipMalloc(p, want);
+  DevPool& pool = c->pool;
+  {
+    std::unique_lock<std::mutex> lock(pool.m);
+    std::multimap<size_t, DevPool::Block>::iterator it = pool.free_blocks.lower_bound(want);
+    if (it != pool.free_blocks.end() && it->first <= std::max(2 * want, want + ((size_t)64 << 10))) {
+      const size_t have = it->first;
+      const DevPool::Block b = it->second;
+      pool.free_blocks.erase(it);
+      pool.cached -= have;
+      pool.live[b.p] = have;
+      lock.unlock();
+      if (b.ev) {
+        (void)hipEventSynchronize(b.ev);  // whatever the previous owner had queued on the context's stream
+        std::lock_guard<std::mutex> again(pool.m);
+        pool.spare.push_back(b.ev);
+      }
+      *p = b.p;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) {  // give the cached blocks back and try once more
+    (void)hipGetLastError();
+    pool_release(c);
+    e = hipMalloc(p, want);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(pool.m);
+    pool.live[*p] = want;
+  }
+  return e;
+}
+
+void hhv::api::pool_free(hhv_ctx* c, void* p) {
+  if (!p) return;
+  if (!c) {
+    (void)hipFree(p);
+    return;
+  }
+  DevPool& pool = c->pool;
+  size_t bytes = 0;
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(pool.m);
+    std::unordered_map<void*, size_t>::iterator it = pool.live.find(p);
+    if (it != pool.live.end()) {
+      bytes = it->second;
+      pool.live.erase(it);
+    }
+    if (bytes != 0 && bytes <= POOL_BLOCK_MAX && pool.cached + bytes <= POOL_TOTAL_MAX) {
+      if (!pool.spare.empty()) {
+        ev = pool.spare.back();
+        pool.spare.pop_back();
+      }
+    } else {
+      bytes = 0;
+    }
+  }
+  if (bytes == 0) {
+    (void)hipFree(p);
+    return;
+  }
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+  if (!ev || hipEventRecord(ev, c->stream) != hipSuccess) {  // no event to order the next owner behind: not cached
+    if (ev) (void)hipEventDestroy(ev);
+    (void)hipFree(p);
+    return;
+  }
+  std::lock_guard<std::mutex> lock(pool.m);
+  pool.free_blocks.insert(std::make_pair(bytes, DevPool::Block{p, ev}));
+  pool.cached += bytes;
+}
+
+void hhv::api::pool_release(hhv_ctx* c) {
+  if (!c) return;
+  DevPool& pool = c->pool;
+  std::multimap<size_t, DevPool::Block> blocks;
+  std::vector<hipEvent_t> spare;
+  {
+    std::lock_guard<std::mutex> lock(pool.m);
+    blocks.swap(pool.free_blocks);
+    spare.swap(pool.spare);
+    pool.cached = 0;
+  }
+  for (std::multimap<size_t, DevPool::Block>::iterator it = blocks.begin(); it != blocks.end(); ++it) {
+    if (it->second.ev) (void)hipEventDestroy(it->second.ev);
+    (void)hipFree(it->second.p);
+  }
+  for (size_t k = 0; k < spare.size(); ++k) (void)hipEventDestroy(spare[k]);
+}
+
 int hhv::api::tset_init_common(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_t* L) {
   ts->ctx = c;
   ts->n = n;
@@ -477,9 +575,9 @@ int hhv::api::tset_init_common(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_
   }
   ts->rec_off[n] = off;
   ts->n_records = off + 1;
-  HIP_TRY(hipMalloc(&ts->d_rec_off, (size_t)(n + 1) * sizeof(int64_t)));
-  HIP_TRY(hipMalloc(&ts->d_L, (size_t)n * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&ts->d_results, (size_t)n * sizeof(DevResult)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_rec_off, (size_t)(n + 1) * sizeof(int64_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_L, (size_t)n * sizeof(int32_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_results, (size_t)n * sizeof(DevResult)));
   HIP_TRY(hipMemcpy(ts->d_rec_off, ts->rec_off.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ts->d_L, ts->L.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
   return HHV_OK;
@@ -507,7 +605,7 @@ int hhv_upload_templates_ss(hhv_ctx* c, int32_t n, const int32_t* L, const float
     return rc;
   }
   const size_t total = (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW;
-  if (hipMalloc(&ts->d_records, total * sizeof(float)) != hipSuccess) {
+  if (tmalloc(ts->ctx, &ts->d_records, total * sizeof(float)) != hipSuccess) {
     hhv_tset_free(ts);
     return fail(HHV_E_MEMORY, "hhv_upload_templates: device allocation of %zu bytes failed", total * sizeof(float));
   }
@@ -655,30 +753,30 @@ int hhv_adopt_device_stream(hhv_ctx* c, int32_t n, const int32_t* L, const void*
 void hhv_tset_free(hhv_tset* ts) {
   if (!ts) return;
   if (ts->ctx) (void)hipSetDevice(ts->ctx->par.device);
-  if (ts->owns_records) dfree(ts->d_records);
-  dfree(ts->d_rec_off);
-  dfree(ts->d_L);
-  dfree(ts->d_results);
-  dfree(ts->d_wave_rec);
-  dfree(ts->d_seg);
-  dfree(ts->d_bt);
-  dfree(ts->d_carry);
-  dfree(ts->d_carry_mi);
-  dfree(ts->d_path_off);
-  dfree(ts->d_i_steps);
-  dfree(ts->d_j_steps);
-  dfree(ts->d_states);
-  dfree(ts->d_S);
-  dfree(ts->d_Sss);
-  dfree(ts->d_hits);
-  dfree(ts->d_topk);
-  dfree(ts->d_keys);
-  dfree(ts->d_sorted);
-  dfree(ts->d_sort_temp);
-  dfree(ts->d_raw_hits);
-  dfree(ts->d_gids);
-  dfree(ts->d_neff);
-  dfree(ts->d_rank);
+  if (ts->owns_records) tfree(ts->ctx, ts->d_records);
+  tfree(ts->ctx, ts->d_rec_off);
+  tfree(ts->ctx, ts->d_L);
+  tfree(ts->ctx, ts->d_results);
+  tfree(ts->ctx, ts->d_wave_rec);
+  tfree(ts->ctx, ts->d_seg);
+  tfree(ts->ctx, ts->d_bt);
+  tfree(ts->ctx, ts->d_carry);
+  tfree(ts->ctx, ts->d_carry_mi);
+  tfree(ts->ctx, ts->d_path_off);
+  tfree(ts->ctx, ts->d_i_steps);
+  tfree(ts->ctx, ts->d_j_steps);
+  tfree(ts->ctx, ts->d_states);
+  tfree(ts->ctx, ts->d_S);
+  tfree(ts->ctx, ts->d_Sss);
+  tfree(ts->ctx, ts->d_hits);
+  tfree(ts->ctx, ts->d_topk);
+  tfree(ts->ctx, ts->d_keys);
+  tfree(ts->ctx, ts->d_sorted);
+  tfree(ts->ctx, ts->d_sort_temp);
+  tfree(ts->ctx, ts->d_raw_hits);
+  tfree(ts->ctx, ts->d_gids);
+  tfree(ts->ctx, ts->d_neff);
+  tfree(ts->ctx, ts->d_rank);
   delete ts;
 }
 
@@ -700,7 +798,7 @@ int64_t hhv_tset_cells(const hhv_tset* ts, int32_t Lq) {
 static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_ranges, int n_slots) {
   // n_ranges ranges, padded with empty ones to n_slots (a wave of a short-query launch takes 64 / W ranges)
   if (ts->n_waves == n_ranges && ts->n_range_slots == n_slots && ts->d_wave_rec) return HHV_OK;
-  dfree(ts->d_wave_rec);
+  tfree(ts->ctx, ts->d_wave_rec);
   std::vector<int64_t> wr((size_t)n_slots + 1);
   const int64_t total = ts->rec_off[ts->n];
   int k = 0;
@@ -710,7 +808,7 @@ static int ensure_partition(hhv_ctx* c, hhv_tset* ts, int n_ranges, int n_slots)
     wr[w] = ts->rec_off[k];
   }
   for (int w = n_ranges; w <= n_slots; ++w) wr[w] = total;
-  HIP_TRY(hipMalloc(&ts->d_wave_rec, wr.size() * sizeof(int64_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_wave_rec, wr.size() * sizeof(int64_t)));
   HIP_TRY(hipMemcpyAsync(ts->d_wave_rec, wr.data(), wr.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   ts->n_waves = n_ranges;
@@ -724,7 +822,7 @@ static int ensure_segments(hhv_ctx* c, hhv_tset* ts) {
   if (ts->d_seg) return HHV_OK;
   std::vector<int64_t> seg;
   ts->n_seg = plan_segments(ts->rec_off.data(), ts->n, seg);
-  HIP_TRY(hipMalloc(&ts->d_seg, seg.size() * sizeof(int64_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_seg, seg.size() * sizeof(int64_t)));
   HIP_TRY(hipMemcpyAsync(ts->d_seg, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return HHV_OK;
@@ -732,9 +830,9 @@ static int ensure_segments(hhv_ctx* c, hhv_tset* ts) {
 
 static int ensure_bt(hhv_ctx* c, hhv_tset* ts) {
   if (ts->d_bt && ts->bt_plan == c->plan) return HHV_OK;
-  dfree(ts->d_bt);
+  tfree(ts->ctx, ts->d_bt);
   const size_t bytes = (size_t)c->plan.P * bt_plane_entries(ts->n_records, c->plan.W) * sizeof(uint64_t);
-  if (hipMalloc(&ts->d_bt, bytes) != hipSuccess)
+  if (tmalloc(ts->ctx, &ts->d_bt, bytes) != hipSuccess)
     return fail(HHV_E_MEMORY, "backtrace buffer of %zu bytes does not fit on the device", bytes);
   HIP_TRY(hipMemsetAsync(ts->d_bt, 0, bytes, c->stream));
   ts->bt_plan = c->plan;
@@ -819,8 +917,8 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   a.queue = c->d_queue;
   if (multi) {
     if (!ts->d_carry) {
-      HIP_TRY(hipMalloc(&ts->d_carry, (size_t)ts->n_records * sizeof(float4)));
-      HIP_TRY(hipMalloc(&ts->d_carry_mi, (size_t)ts->n_records * sizeof(float)));
+      HIP_TRY(tmalloc(ts->ctx, &ts->d_carry, (size_t)ts->n_records * sizeof(float4)));
+      HIP_TRY(tmalloc(ts->ctx, &ts->d_carry_mi, (size_t)ts->n_records * sizeof(float)));
     }
     a.carry = ts->d_carry;
     a.carry_mi = ts->d_carry_mi;
@@ -931,16 +1029,16 @@ int hhv_set_celloff(hhv_ctx* c, hhv_tset* ts, int32_t k, const uint8_t* mask) {
   unsigned char* d_mask = nullptr;
   if (mask) {
     const size_t bytes = (size_t)(Lq + 1) * (Lt + 1);
-    HIP_TRY(hipMalloc(&d_mask, bytes));
+    HIP_TRY(tmalloc(c, &d_mask, bytes));
     if (hipMemcpyAsync(d_mask, mask, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-      dfree(d_mask);
+      tfree(c, d_mask);
       return fail(HHV_E_DEVICE, "hhv_set_celloff: H2D copy failed");
     }
   }
   const int lr = celloff_from_mask(ts->d_bt, ts->d_rec_off, ts->d_L, (int64_t)bt_plane_entries(ts->n_records, c->plan.W), Lq,
                                    c->plan, k, d_mask, Lt, c->stream);
   const hipError_t e = hipStreamSynchronize(c->stream);
-  dfree(d_mask);
+  tfree(c, d_mask);
   if (lr != 0 || e != hipSuccess) return fail(HHV_E_DEVICE, "hhv_set_celloff: device operation failed");
   ts->bt_valid = false;
   return HHV_OK;
@@ -953,15 +1051,15 @@ int hhv_set_global_batch(hhv_ctx* c, hhv_tset* ts, const uint8_t* not_longest) {
   HIP_TRY(hipSetDevice(c->par.device));
   unsigned char* d_flags = nullptr;
   if (not_longest) {
-    HIP_TRY(hipMalloc(&d_flags, (size_t)ts->n));
+    HIP_TRY(tmalloc(c, &d_flags, (size_t)ts->n));
     if (hipMemcpyAsync(d_flags, not_longest, (size_t)ts->n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-      dfree(d_flags);
+      tfree(c, d_flags);
       return fail(HHV_E_DEVICE, "hhv_set_global_batch: H2D copy failed");
     }
   }
   const int lr = set_header_flags(ts->d_records, ts->d_rec_off, d_flags, ts->n, c->stream);
   const hipError_t e = hipStreamSynchronize(c->stream);
-  dfree(d_flags);
+  tfree(c, d_flags);
   if (lr != 0 || e != hipSuccess) return fail(HHV_E_DEVICE, "hhv_set_global_batch: kernel failed");
   return HHV_OK;
 }
@@ -1048,25 +1146,25 @@ int hhv_backtrace_matrix(hhv_ctx* c, hhv_tset* ts, int32_t k, uint8_t* out) {
   const int Lt = ts->L[k], Lq = ts->bt_Lq;
   const size_t bytes = (size_t)(Lq + 1) * (Lt + 1);
   unsigned char* d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_out, bytes));
+  HIP_TRY(tmalloc(c, &d_out, bytes));
   const int lr = bt_matrix(ts->d_bt, ts->d_rec_off, (int64_t)bt_plane_entries(ts->n_records, ts->bt_plan.W), Lq, ts->bt_plan, ts->bt_mm, k, Lt,
                            d_out, c->stream);
   hipError_t e = lr == 0 ? hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream) : hipErrorUnknown;
   const int sc = e == hipSuccess ? sync_check(c, "hhv_backtrace_matrix") : HHV_OK;
-  dfree(d_out);
+  tfree(c, d_out);
   if (e != hipSuccess) return fail(HHV_E_DEVICE, "hhv_backtrace_matrix: device operation failed");
   return sc;
 }
 
 static int ensure_paths(hhv_ctx* c, hhv_tset* ts) {
   if (ts->path_Lq == c->Lq && ts->d_hits) return HHV_OK;
-  dfree(ts->d_path_off);
-  dfree(ts->d_i_steps);
-  dfree(ts->d_j_steps);
-  dfree(ts->d_states);
-  dfree(ts->d_S);
-  dfree(ts->d_Sss);
-  dfree(ts->d_hits);
+  tfree(ts->ctx, ts->d_path_off);
+  tfree(ts->ctx, ts->d_i_steps);
+  tfree(ts->ctx, ts->d_j_steps);
+  tfree(ts->ctx, ts->d_states);
+  tfree(ts->ctx, ts->d_S);
+  tfree(ts->ctx, ts->d_Sss);
+  tfree(ts->ctx, ts->d_hits);
   ts->path_off.resize((size_t)ts->n + 1);
   int64_t off = 0;
   for (int k = 0; k < ts->n; ++k) {
@@ -1076,12 +1174,12 @@ static int ensure_paths(hhv_ctx* c, hhv_tset* ts) {
     off += ((int64_t)c->Lq + ts->L[k] + 2 + 3) & ~(int64_t)3;
   }
   ts->path_off[ts->n] = off;
-  HIP_TRY(hipMalloc(&ts->d_path_off, ts->path_off.size() * sizeof(int64_t)));
-  HIP_TRY(hipMalloc(&ts->d_i_steps, (size_t)off * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&ts->d_j_steps, (size_t)off * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&ts->d_states, (size_t)off * sizeof(int8_t)));
-  HIP_TRY(hipMalloc(&ts->d_S, ((size_t)off + 64) * sizeof(float)));  // (+ 64: hhv_scorr_kernel reads whole 64-step tiles)
-  HIP_TRY(hipMalloc(&ts->d_hits, (size_t)ts->n * sizeof(DevHit)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_path_off, ts->path_off.size() * sizeof(int64_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_i_steps, (size_t)off * sizeof(int32_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_j_steps, (size_t)off * sizeof(int32_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_states, (size_t)off * sizeof(int8_t)));
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_S, ((size_t)off + 64) * sizeof(float)));  // (+ 64: hhv_scorr_kernel reads whole 64-step tiles)
+  HIP_TRY(tmalloc(ts->ctx, &ts->d_hits, (size_t)ts->n * sizeof(DevHit)));
   HIP_TRY(hipMemcpy(ts->d_path_off, ts->path_off.data(), ts->path_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   ts->path_Lq = c->Lq;
   return HHV_OK;
@@ -1122,7 +1220,7 @@ static int run_trace(hhv_ctx* c, hhv_tset* ts) {
   a.ss_t_mask = c->ss_t_mask;
   a.Sss = nullptr;
   if (c->ss_hmm_mode) {  // the per-step secondary-structure scores: a second pool like S, allocated with the first search that has them
-    if (!ts->d_Sss) HIP_TRY(hipMalloc(&ts->d_Sss, ((size_t)ts->path_off[ts->n] + 64) * sizeof(float)));
+    if (!ts->d_Sss) HIP_TRY(tmalloc(ts->ctx, &ts->d_Sss, ((size_t)ts->path_off[ts->n] + 64) * sizeof(float)));
     a.Sss = ts->d_Sss;
   }
   a.err = c->d_err;
@@ -1307,26 +1405,26 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
   HIP_TRY(hipSetDevice(c->par.device));
   const int kk = std::min(k, ts->n);
   if (ts->topk_cap < k) {
-    dfree(ts->d_topk);
-    HIP_TRY(hipMalloc(&ts->d_topk, (size_t)k * sizeof(DevHit)));
+    tfree(ts->ctx, ts->d_topk);
+    HIP_TRY(tmalloc(ts->ctx, &ts->d_topk, (size_t)k * sizeof(DevHit)));
     ts->topk_cap = k;
   }
   if (!ts->d_keys) {
-    HIP_TRY(hipMalloc(&ts->d_keys, (size_t)ts->n * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&ts->d_sorted, (size_t)ts->n * sizeof(uint64_t)));
+    HIP_TRY(tmalloc(ts->ctx, &ts->d_keys, (size_t)ts->n * sizeof(uint64_t)));
+    HIP_TRY(tmalloc(ts->ctx, &ts->d_sorted, (size_t)ts->n * sizeof(uint64_t)));
     ts->sort_temp_bytes = topk_temp_bytes(ts->n);
-    HIP_TRY(hipMalloc(&ts->d_sort_temp, ts->sort_temp_bytes));
+    HIP_TRY(tmalloc(ts->ctx, &ts->d_sort_temp, ts->sort_temp_bytes));
   }
   const DevHit* src = ts->d_hits;
   if (raw) {
-    if (!ts->d_raw_hits) HIP_TRY(hipMalloc(&ts->d_raw_hits, (size_t)ts->n * sizeof(DevHit)));
+    if (!ts->d_raw_hits) HIP_TRY(tmalloc(ts->ctx, &ts->d_raw_hits, (size_t)ts->n * sizeof(DevHit)));
     results_to_hits(ts->d_results, ts->n, ts->d_raw_hits, c->stream);
     src = ts->d_raw_hits;
   }
   DevHit* dst = d_out ? (DevHit*)d_out : ts->d_topk;
   std::string err;
   if (pval) {
-    if (!ts->d_rank) HIP_TRY(hipMalloc(&ts->d_rank, (size_t)std::max(ts->n, 1) * sizeof(float)));
+    if (!ts->d_rank) HIP_TRY(tmalloc(ts->ctx, &ts->d_rank, (size_t)std::max(ts->n, 1) * sizeof(float)));
     topk_rank_pvalue(src, ts->n, ts->d_L, ts->d_neff, c->Lq, ts->q_neff, c->par.local, ts->d_rank, c->stream);
   }
   if (topk_device(src, ts->n, kk, ts->d_gids, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
@@ -1348,7 +1446,7 @@ int hhv_tset_set_neff(hhv_ctx* c, hhv_tset* ts, float q_neff, const float* t_nef
   if (!c || !ts || !t_neff) return fail(HHV_E_ARG, "hhv_tset_set_neff: null argument");
   if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_tset_set_neff: template set belongs to another context");
   HIP_TRY(hipSetDevice(c->par.device));
-  if (!ts->d_neff) HIP_TRY(hipMalloc(&ts->d_neff, (size_t)std::max(ts->n, 1) * sizeof(float)));
+  if (!ts->d_neff) HIP_TRY(tmalloc(ts->ctx, &ts->d_neff, (size_t)std::max(ts->n, 1) * sizeof(float)));
   HIP_TRY(hipMemcpyAsync(ts->d_neff, t_neff, (size_t)ts->n * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   ts->q_neff = q_neff;
@@ -1361,15 +1459,15 @@ int hhv_tset_set_global_ids(hhv_ctx* c, hhv_tset* ts, const int32_t* ids) {
   HIP_TRY(hipSetDevice(c->par.device));
   if (!ids) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dfree(ts->d_gids);
-  dfree(ts->d_neff);
-  dfree(ts->d_rank);
+    tfree(ts->ctx, ts->d_gids);
+  tfree(ts->ctx, ts->d_neff);
+  tfree(ts->ctx, ts->d_rank);
     ts->d_gids = nullptr;
     return HHV_OK;
   }
   for (int k = 0; k < ts->n; ++k)
     if (ids[k] < 0) return fail(HHV_E_ARG, "hhv_tset_set_global_ids: ids[%d] = %d (must be >= 0)", k, ids[k]);
-  if (!ts->d_gids) HIP_TRY(hipMalloc(&ts->d_gids, (size_t)std::max(ts->n, 1) * sizeof(int32_t)));
+  if (!ts->d_gids) HIP_TRY(tmalloc(ts->ctx, &ts->d_gids, (size_t)std::max(ts->n, 1) * sizeof(int32_t)));
   HIP_TRY(hipMemcpyAsync(ts->d_gids, ids, (size_t)ts->n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return HHV_OK;

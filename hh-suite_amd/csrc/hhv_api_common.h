@@ -8,8 +8,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hhviterbi_hip.h"
@@ -33,6 +36,37 @@ int check_error_word(struct ::hhv_ctx* c, const char* who);  // the device error
 template <typename T>
 inline void dfree(T*& p) {
   if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// Device blocks of a context's template sets, kept between sets (round 6).  A search makes and frees a set per stage - the
+// prepared subset, the gathered subset of a round, their results, backtrace planes and path pools: ~25 hipMalloc + hipFree
+// each, and hipFree waits for the whole device - 4 ms of a 24 ms ViterbiRunner::alignment over 20 000 resident templates.
+// tmalloc hands out a cached block of at least the size asked for (at most twice it) before it asks the runtime; tfree
+// keeps blocks up to POOL_BLOCK_MAX, POOL_TOTAL_MAX in all, and records an event on the context's stream that the next owner
+// waits for (the context's work is ordered by its one stream; a blocking copy into a recycled block is not).
+struct DevPool {
+  struct Block {
+    void* p;
+    hipEvent_t ev;
+  };
+  std::multimap<size_t, Block> free_blocks;     // by size
+  std::unordered_map<void*, size_t> live;       // blocks handed out by pool_malloc
+  std::vector<hipEvent_t> spare;
+  size_t cached = 0;
+  std::mutex m;
+};
+constexpr size_t POOL_BLOCK_MAX = (size_t)512 << 20, POOL_TOTAL_MAX = (size_t)4 << 30;
+hipError_t pool_malloc(struct ::hhv_ctx* c, void** p, size_t bytes);
+void pool_free(struct ::hhv_ctx* c, void* p);
+void pool_release(struct ::hhv_ctx* c);  // hands every cached block back to the runtime (hhv_destroy; an allocation that failed)
+template <typename T>
+inline hipError_t tmalloc(struct ::hhv_ctx* c, T** p, size_t bytes) {
+  return pool_malloc(c, reinterpret_cast<void**>(p), bytes);
+}
+template <typename T>
+inline void tfree(struct ::hhv_ctx* c, T*& p) {
+  if (p) pool_free(c, const_cast<void*>(static_cast<const void*>(p)));
   p = nullptr;
 }
 
@@ -81,6 +115,7 @@ struct hhv_ctx {
   std::vector<int32_t> mac_ss_mode;
   hhv::MacStreams mac_side = {};                          // side streams of the MAC length classes (created at the first use)
   bool mac_side_ready = false;
+  hhv::api::DevPool pool;                                 // device blocks of freed template sets (tmalloc / tfree)
   // hhv_hit_paths_packed: device scratch and pinned mirror of the compact path records (grow-only, shared by the context's sets)
   void* d_packed = nullptr;
   size_t d_packed_bytes = 0;

@@ -9,6 +9,8 @@
 
 using namespace hhv;
 using hhv::api::dfree;
+using hhv::api::tfree;
+using hhv::api::tmalloc;
 using hhv::api::fail;
 using hhv::api::tset_init_common;
 
@@ -102,7 +104,7 @@ int hhv_db_open(hhv_ctx* c, const char* path, hhv_tset** out) {
   }
   int rc = tset_init_common(c, ts, h.n, L.data());
   if (rc == HHV_OK && ts->n_records != h.n_records) rc = fail(HHV_E_ARG, "hhv_db_open: record count mismatch");
-  if (rc == HHV_OK && hipMalloc(&ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
+  if (rc == HHV_OK && tmalloc(ts->ctx, &ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
     rc = fail(HHV_E_MEMORY, "hhv_db_open: device allocation failed");
   if (rc == HHV_OK) {
     ts->owns_records = true;
@@ -252,8 +254,8 @@ int hhv_tset_gather(hhv_ctx* c, hhv_tset* ts, const int32_t* ids, int32_t n, hhv
   if (!sub) return fail(HHV_E_MEMORY, "out of host memory");
   int rc = tset_init_common(c, sub, n, L.data());
   int32_t* d_ids = nullptr;
-  if (rc == HHV_OK && (hipMalloc(&sub->d_records, (size_t)(sub->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess ||
-                       hipMalloc(&d_ids, (size_t)n * sizeof(int32_t)) != hipSuccess))
+  if (rc == HHV_OK && (tmalloc(c, &sub->d_records, (size_t)(sub->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess ||
+                       tmalloc(c, &d_ids, (size_t)n * sizeof(int32_t)) != hipSuccess))
     rc = fail(HHV_E_MEMORY, "hhv_tset_gather: device allocation failed");
   if (rc == HHV_OK) {
     sub->owns_records = true;
@@ -267,7 +269,7 @@ int hhv_tset_gather(hhv_ctx* c, hhv_tset* ts, const int32_t* ids, int32_t n, hhv
   if (rc == HHV_OK && tset_gather(ts->d_records, ts->d_rec_off, d_ids, sub->d_rec_off, sub->d_L, n, sub->d_records, c->stream) != 0)
     rc = fail(HHV_E_DEVICE, "hhv_tset_gather: kernel launch failed");
   if (rc == HHV_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(HHV_E_DEVICE, "hhv_tset_gather: kernel failed");
-  dfree(d_ids);
+  tfree(c, d_ids);
   if (rc != HHV_OK) {
     hhv_tset_free(sub);
     return rc;

@@ -1,12 +1,15 @@
 // hhv_api_prep.cpp -- C ABI of the on-device PrepareTemplateHMM and the raw template database file.
 #include "hhv_api_common.h"
 
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <thread>
 
 using namespace hhv;
 using hhv::api::dfree;
+using hhv::api::tfree;
+using hhv::api::tmalloc;
 using hhv::api::fail;
 using hhv::api::tset_init_common;
 
@@ -28,7 +31,27 @@ struct RawBlock {
 };
 }  // namespace
 
-// raw HMMs -> the 32-dword raw column block the prepare kernels read (hhv_internal.h RAW_*)
+// one raw HMM -> its L + 1 raw columns of 32 dwords (hhv_internal.h RAW_*) at w
+static void fill_raw_template(float* w0, int32_t Lk, const float* f, const float* tr, const float* neff, const int8_t* ss_pred,
+                              const int8_t* ss_conf, const int8_t* ss_dssp) {
+  for (int i = 0; i <= Lk; ++i) {
+    float* w = w0 + (size_t)i * RAW_DW;
+    memcpy(w + RAW_F, f + (size_t)i * 20, 20 * sizeof(float));
+    memcpy(w + RAW_TR, tr + (size_t)i * 7, 7 * sizeof(float));
+    memcpy(w + RAW_NEFF, neff + (size_t)i * 3, 3 * sizeof(float));
+    int32_t meta = i;
+    if (i >= 1) {
+      const int pr = ss_pred ? (unsigned char)ss_pred[i] : 0, cf = ss_conf ? ss_conf[i] : 0;
+      const int ds = ss_dssp ? (unsigned char)ss_dssp[i] : 0;
+      meta |= (int32_t)((unsigned char)(pr * 11 + cf) & META_PRED_MASK) << META_PRED_SHIFT;
+      meta |= (int32_t)(ds & META_DSSP_MASK) << META_DSSP_SHIFT;
+    }
+    memcpy(w + RAW_J, &meta, 4);
+    memcpy(w + RAW_L, &Lk, 4);
+  }
+}
+
+// raw HMMs -> the 32-dword raw column block the prepare kernels read
 static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, const float* const* tr, const float* const* neff,
                            const int8_t* const* ss_pred, const int8_t* const* ss_conf, const int8_t* const* ss_dssp,
                            RawBlock* host) {
@@ -41,24 +64,9 @@ static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, c
   std::vector<int64_t> start((size_t)n + 1, 0);
   for (int k = 0; k < n; ++k) start[k + 1] = start[k] + (int64_t)L[k] + 1;
   auto fill = [&](int k0, int k1) {
-    for (int k = k0; k < k1; ++k) {
-      for (int i = 0; i <= L[k]; ++i) {
-        float* w = host->data() + (size_t)(start[k] + i) * RAW_DW;
-        memcpy(w + RAW_F, f[k] + (size_t)i * 20, 20 * sizeof(float));
-        memcpy(w + RAW_TR, tr[k] + (size_t)i * 7, 7 * sizeof(float));
-        memcpy(w + RAW_NEFF, neff[k] + (size_t)i * 3, 3 * sizeof(float));
-        int32_t meta = i;
-        if (i >= 1) {
-          const int pr = ss_pred && ss_pred[k] ? (unsigned char)ss_pred[k][i] : 0, cf = ss_conf && ss_conf[k] ? ss_conf[k][i] : 0;
-          const int ds = ss_dssp && ss_dssp[k] ? (unsigned char)ss_dssp[k][i] : 0;
-          meta |= (int32_t)((unsigned char)(pr * 11 + cf) & META_PRED_MASK) << META_PRED_SHIFT;
-          meta |= (int32_t)(ds & META_DSSP_MASK) << META_DSSP_SHIFT;
-        }
-        memcpy(w + RAW_J, &meta, 4);
-        const int32_t Lk = L[k];
-        memcpy(w + RAW_L, &Lk, 4);
-      }
-    }
+    for (int k = k0; k < k1; ++k)
+      fill_raw_template(host->data() + (size_t)start[k] * RAW_DW, L[k], f[k], tr[k], neff[k], ss_pred ? ss_pred[k] : nullptr,
+                        ss_conf ? ss_conf[k] : nullptr, ss_dssp ? ss_dssp[k] : nullptr);
   };
   // a database upload is hundreds of megabytes of strided copies: spread the templates over a few host threads
   const int nt = (int)std::min<int64_t>(std::min<int64_t>(16, std::max(1u, std::thread::hardware_concurrency())), off / 65536 + 1);
@@ -72,50 +80,34 @@ static int build_raw_block(int32_t n, const int32_t* L, const float* const* f, c
   return HHV_OK;
 }
 
-// raw column block -> resident raw set (the block may come from build_raw_block or straight from a raw database file)
-static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const float* neff_hmm, float* block,
-                             size_t block_floats, hhv_rawset** out) {
-  HIP_TRY(hipSetDevice(c->par.device));
-  // Column frequencies are >= 0: what the prepare kernels make of them goes to the DP kernel, whose log2f4 takes the exponent
-  // of a column product with a plain shift (viterbi_lane.h).  A block from a file of another tool or build is checked like the
-  // packer checks host profiles: -0 becomes +0, a negative value is refused.
-  {
-    const size_t cols = block_floats / RAW_DW;
-    const int nt = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), cols / 65536 + 1);
-    std::vector<int64_t> bad((size_t)nt, -1);
-    auto scan = [&](int w) {
-      for (size_t col = cols * w / nt; col < cols * (w + 1) / nt; ++col) {
-        float* fw = block + col * RAW_DW + RAW_F;
-        int32_t meta;
-        memcpy(&meta, block + col * RAW_DW + RAW_J, 4);
-        if ((meta & META_JMASK) == 0) continue;  // row 0 of a template is not a column (nothing reads its frequencies)
-        for (int a = 0; a < 20; ++a) {
-          uint32_t u;
-          memcpy(&u, fw + a, 4);
-          if (!(u & 0x80000000u)) continue;
-          if (u == 0x80000000u) {
-            fw[a] = 0.0f;
-          } else if (bad[(size_t)w] < 0) {
-            bad[(size_t)w] = (int64_t)col;
-          }
-        }
+// Column frequencies are >= 0: what the prepare kernels make of them goes to the DP kernel, whose log2f4 takes the exponent
+// of a column product with a plain shift (viterbi_lane.h).  A block from a file of another tool or build is checked like the
+// packer checks host profiles: -0 becomes +0, a negative value is refused.  Returns the first bad column of
+// [col0, col1) or -1.
+static int64_t fix_raw_signs(float* block, size_t col0, size_t col1) {
+  int64_t bad = -1;
+  for (size_t col = col0; col < col1; ++col) {
+    float* fw = block + col * RAW_DW + RAW_F;
+    int32_t meta;
+    memcpy(&meta, block + col * RAW_DW + RAW_J, 4);
+    if ((meta & META_JMASK) == 0) continue;  // row 0 of a template is not a column (nothing reads its frequencies)
+    for (int a = 0; a < 20; ++a) {
+      uint32_t u;
+      memcpy(&u, fw + a, 4);
+      if (!(u & 0x80000000u)) continue;
+      if (u == 0x80000000u) {
+        fw[a] = 0.0f;
+      } else if (bad < 0) {
+        bad = (int64_t)col;
       }
-    };
-    if (nt <= 1) {
-      scan(0);
-    } else {
-      std::vector<std::thread> pool;
-      int started = 0;
-      try {
-        for (; started < nt; ++started) pool.emplace_back(scan, started);
-      } catch (...) {
-      }
-      for (int w = started; w < nt; ++w) scan(w);
-      for (auto& th : pool) th.join();
     }
-    for (int64_t b : bad)
-      if (b >= 0) return fail(HHV_E_ARG, "raw template set: raw column %lld has a negative frequency (f >= 0)", (long long)b);
   }
+  return bad;
+}
+
+// the resident raw set without its columns: lengths, offsets, class lists, device buffers (d_raw allocated, not filled)
+static int rawset_alloc(hhv_ctx* c, int32_t n, const int32_t* L, const float* neff_hmm, size_t block_floats, hhv_rawset** out) {
+  HIP_TRY(hipSetDevice(c->par.device));
   hhv_rawset* rs = new (std::nothrow) hhv_rawset();
   if (!rs) return fail(HHV_E_MEMORY, "out of host memory");
   rs->ctx = c;
@@ -162,9 +154,42 @@ static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const floa
             hipMalloc(&rs->d_pav, (size_t)n * 20 * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_pb, 20 * sizeof(float)) == hipSuccess && hipMalloc(&rs->d_R, 400 * sizeof(float)) == hipSuccess &&
             hipMalloc(&rs->d_qpav, 20 * sizeof(float)) == hipSuccess &&
-            hipMemcpy(rs->d_raw, block, block_floats * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(rs->d_neff_hmm, neff_hmm, (size_t)n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
+    hhv_rawset_free(rs);
+    return fail(HHV_E_MEMORY, "raw template set: device allocation/copy failed");
+  }
+  *out = rs;
+  return HHV_OK;
+}
+
+// raw column block (straight from a raw database file) -> resident raw set
+static int rawset_from_block(hhv_ctx* c, int32_t n, const int32_t* L, const float* neff_hmm, float* block,
+                             size_t block_floats, hhv_rawset** out) {
+  {
+    const size_t cols = block_floats / RAW_DW;
+    const int nt = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), cols / 65536 + 1);
+    std::vector<int64_t> bad((size_t)nt, -1);
+    auto scan = [&](int w) { bad[(size_t)w] = fix_raw_signs(block, cols * w / nt, cols * (w + 1) / nt); };
+    if (nt <= 1) {
+      scan(0);
+    } else {
+      std::vector<std::thread> pool;
+      int started = 0;
+      try {
+        for (; started < nt; ++started) pool.emplace_back(scan, started);
+      } catch (...) {
+      }
+      for (int w = started; w < nt; ++w) scan(w);
+      for (auto& th : pool) th.join();
+    }
+    for (int64_t b : bad)
+      if (b >= 0) return fail(HHV_E_ARG, "raw template set: raw column %lld has a negative frequency (f >= 0)", (long long)b);
+  }
+  hhv_rawset* rs = nullptr;
+  const int rc = rawset_alloc(c, n, L, neff_hmm, block_floats, &rs);
+  if (rc != HHV_OK) return rc;
+  if (hipMemcpy(rs->d_raw, block, block_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
     hhv_rawset_free(rs);
     return fail(HHV_E_MEMORY, "raw template set: device allocation/copy failed");
   }
@@ -178,18 +203,108 @@ int hhv_upload_raw_templates(hhv_ctx* c, int32_t n, const int32_t* L, const floa
   if (!c || !L || !f || !tr || !neff || !neff_hmm || !out) return fail(HHV_E_ARG, "hhv_upload_raw_templates: null argument");
   if (n < 1) return fail(HHV_E_ARG, "hhv_upload_raw_templates: n = %d", n);
   *out = nullptr;
-  RawBlock host;
   const bool timing = getenv("HHV_API_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = build_raw_block(n, L, f, tr, neff, ss_pred, ss_conf, ss_dssp, &host);
+  int64_t n_cols = 0;
+  size_t max_template = 0;
+  for (int k = 0; k < n; ++k) {
+    if (L[k] < 1 || L[k] > 0xFFFF || !f[k] || !tr[k] || !neff[k]) return fail(HHV_E_ARG, "raw template %d invalid", k);
+    n_cols += (int64_t)L[k] + 1;
+    max_template = std::max(max_template, (size_t)L[k] + 1);
+  }
+  hhv_rawset* rs = nullptr;
+  int rc = rawset_alloc(c, n, L, neff_hmm, (size_t)n_cols * RAW_DW, &rs);
   if (rc != HHV_OK) return rc;
   const auto t1 = std::chrono::steady_clock::now();
-  const int rc2 = rawset_from_block(c, n, L, neff_hmm, host.data(), host.size(), out);
+  // Columns packed and uploaded in slabs of <= 64 MiB, as hhv_upload_templates does: two pinned staging buffers used in turn - a
+  // slab is packed (and its signs checked) by a few host threads while the copy of the one before it is in flight.  (The whole
+  // block packed into pageable memory and one blocking copy: 2 GB/s, 1.9 s for 100 000 templates of 300 columns.)
+  const size_t slab_cols = (64u << 20) / (RAW_DW * sizeof(float));
+  const size_t stage_floats = std::max(std::min(slab_cols, (size_t)n_cols), max_template) * RAW_DW;
+  const int n_stage = (size_t)n_cols > slab_cols ? 2 : 1;
+  float* stage[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  auto release = [&]() {
+    for (int b = 0; b < 2; ++b) {
+      if (done[b]) (void)hipEventDestroy(done[b]);
+      if (stage[b]) (void)hipHostFree(stage[b]);
+    }
+  };
+  for (int b = 0; b < n_stage; ++b) {
+    if (hipHostMalloc(&stage[b], stage_floats * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) {
+      release();
+      hhv_rawset_free(rs);
+      return fail(HHV_E_MEMORY, "hhv_upload_raw_templates: pinned staging of %zu bytes failed", stage_floats * sizeof(float));
+    }
+  }
+  int n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("HHV_PACK_THREADS")) n_threads = std::max(1, std::min(64, atoi(e)));
+  int k = 0, slab = 0;
+  std::atomic<long long> bad_col(-1);
+  while (k < n && rc == HHV_OK) {
+    const int k0 = k;
+    size_t cols = 0;
+    while (k < n && (cols == 0 || cols + (size_t)L[k] + 1 <= slab_cols)) {
+      cols += (size_t)L[k] + 1;
+      ++k;
+    }
+    const int b = slab & 1;
+    if (slab >= 2 && hipEventSynchronize(done[b]) != hipSuccess) {
+      rc = fail(HHV_E_DEVICE, "hhv_upload_raw_templates: H2D copy failed");
+      break;
+    }
+    float* const buf = stage[b];
+    const int64_t base = rs->rec_off[k0];
+    auto pack_range = [&](int t0, int t1) {
+      for (int t = t0; t < t1; ++t) {
+        float* w = buf + (size_t)(rs->rec_off[t] - base) * RAW_DW;
+        fill_raw_template(w, L[t], f[t], tr[t], neff[t], ss_pred ? ss_pred[t] : nullptr, ss_conf ? ss_conf[t] : nullptr,
+                          ss_dssp ? ss_dssp[t] : nullptr);
+        const int64_t bad = fix_raw_signs(w, 0, (size_t)L[t] + 1);
+        if (bad >= 0) {
+          long long none = -1;
+          bad_col.compare_exchange_strong(none, (long long)(rs->rec_off[t] + bad));
+        }
+      }
+    };
+    const int nt = std::max(1, std::min(n_threads, (k - k0) / 64));
+    if (nt == 1) {
+      pack_range(k0, k);
+    } else {
+      std::vector<std::thread> pool;
+      int started = 0;
+      try {
+        for (; started < nt; ++started)
+          pool.emplace_back(pack_range, k0 + (int)((int64_t)(k - k0) * started / nt), k0 + (int)((int64_t)(k - k0) * (started + 1) / nt));
+      } catch (...) {  // no more threads to be had: the calling thread packs the shares that found none
+      }
+      for (int w = started; w < nt; ++w) pack_range(k0 + (int)((int64_t)(k - k0) * w / nt), k0 + (int)((int64_t)(k - k0) * (w + 1) / nt));
+      for (auto& th : pool) th.join();
+    }
+    if (bad_col.load() >= 0) {
+      rc = fail(HHV_E_ARG, "raw template set: raw column %lld has a negative frequency (f >= 0)", bad_col.load());
+      break;
+    }
+    if (hipMemcpyAsync(rs->d_raw + (size_t)base * RAW_DW, buf, cols * RAW_DW * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipEventRecord(done[b], c->stream) != hipSuccess) {
+      rc = fail(HHV_E_DEVICE, "hhv_upload_raw_templates: H2D copy failed");
+      break;
+    }
+    ++slab;
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess && rc == HHV_OK) rc = fail(HHV_E_DEVICE, "hhv_upload_raw_templates: H2D copy failed");
+  release();
+  if (rc != HHV_OK) {
+    hhv_rawset_free(rs);
+    return rc;
+  }
   if (timing)
-    fprintf(stderr, "hhv_upload_raw_templates: %d templates, %.1f MB: pack %.1f ms, allocate + copy %.1f ms\n", n,
-            host.size() * 4e-6, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+    fprintf(stderr, "hhv_upload_raw_templates: %d templates, %.1f MB: allocate %.1f ms, pack + copy in %d slabs %.1f ms\n", n,
+            (double)n_cols * RAW_DW * 4e-6, std::chrono::duration<double, std::milli>(t1 - t0).count(), slab,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
-  return rc2;
+  *out = rs;
+  return HHV_OK;
 }
 
 // Raw template database file (N1 for the N2 path): header, lengths, Neff_HMM, then the raw column block exactly as it
@@ -310,7 +425,7 @@ static int check_prep_params(const hhv_prep_params* par) {
 // allocates the record stream of a fresh template set and writes its terminal header
 static int tset_alloc_stream(hhv_ctx* c, hhv_tset* ts, int32_t n, const int32_t* L) {
   int rc = tset_init_common(c, ts, n, L);
-  if (rc == HHV_OK && hipMalloc(&ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
+  if (rc == HHV_OK && tmalloc(ts->ctx, &ts->d_records, (size_t)(ts->n_records + STREAM_PAD_RECS) * REC_DW * sizeof(float)) != hipSuccess)
     rc = fail(HHV_E_MEMORY, "hhv_prepare_templates: device allocation failed");
   if (rc != HHV_OK) return rc;
   ts->owns_records = true;
@@ -459,7 +574,7 @@ int hhv_prepare_subset(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, c
   if (!ts) return fail(HHV_E_MEMORY, "out of host memory");
   rc = tset_alloc_stream(c, ts, n_ids, L.data());
   int32_t* d_scratch = nullptr;  // src[n_ids] followed by the three slot lists
-  if (rc == HHV_OK && hipMalloc(&d_scratch, (size_t)2 * n_ids * sizeof(int32_t)) != hipSuccess)
+  if (rc == HHV_OK && tmalloc(c, &d_scratch, (size_t)2 * n_ids * sizeof(int32_t)) != hipSuccess)
     rc = fail(HHV_E_MEMORY, "hhv_prepare_subset: device allocation failed");
   const int32_t* d_cls[3] = {nullptr, nullptr, nullptr};
   if (rc == HHV_OK) {
@@ -491,7 +606,7 @@ int hhv_prepare_subset(hhv_ctx* c, hhv_rawset* rs, const hhv_prep_params* par, c
     if (lr != 0) rc = fail(HHV_E_DEVICE, "prepare kernel launch failed: %s", hipGetErrorString((hipError_t)(-lr)));
   }
   if (rc == HHV_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(HHV_E_DEVICE, "hhv_prepare_subset: kernels failed");
-  dfree(d_scratch);
+  tfree(c, d_scratch);
   if (rc != HHV_OK) {
     hhv_tset_free(ts);
     return rc;

@@ -48,6 +48,16 @@ __device__ __forceinline__ float fast_log2_p(float x, const float* __restrict__ 
   return ((float)aa + lg2[b]) + diff[b] * (float)c;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// R[a][b] in the pair layout prep_column reads (two rows of R side by side)
+__device__ __forceinline__ void stage_R_pairs(const float* __restrict__ R, float* __restrict__ sR, int tid, int nthreads) {
+  for (int q = tid; q < 400; q += nthreads) {
+    const int aa = q / 20, b = q - aa * 20;
+    sR[((aa >> 1) * 20 + b) * 2 + (aa & 1)] = R[q];
+  }
+}
+
 // reference enum order of tr[][7], src/hhdecl.h:68
 enum { T_M2M = 0, T_M2I = 1, T_M2D = 2, T_I2M = 3, T_I2I = 4, T_D2M = 5, T_D2D = 6 };
 
@@ -109,15 +119,26 @@ __device__ __forceinline__ void prep_column(const PrepArgs& a, const float (&raw
       const float x = raw[RAW_NEFF + 0] / a.pcb;
       tau = (float)fmax(0.0, (double)(a.pca * ((1.0f - x) + (a.pcc * x) * (1.0f - x))));
     }
-    for (int aa = 0; aa < 20; ++aa) {
-      if (a.pcm == 0) {
-        P[aa] = f[aa];
-      } else {
-        const float* Ra = sR + aa * 20;
-        float g = f[0] * Ra[0];  // ScalarProd20(R[a], f[i]): tj[0]*qi[0] + tj[1]*qi[1] + ... left to right
+    if (a.pcm == 0) {
 #pragma unroll
-        for (int b = 1; b < 20; ++b) g = g + f[b] * Ra[b];
-        P[aa] = (float)((1. - (double)tau) * (double)f[aa] + (double)(tau * g));
+      for (int aa = 0; aa < 20; ++aa) P[aa] = f[aa];
+    } else {
+      // g[a] = ScalarProd20(R[a], f[i]): tj[0]*qi[0] + tj[1]*qi[1] + ... left to right - for TWO rows a, a + 1 of R at a time with
+      // the packed fp32 multiply and add of gfx950 (v_pk_mul_f32 / v_pk_add_f32: two independent IEEE operations per lane and
+      // instruction, each rounded as the scalar one - no fused multiply-add): 400 instructions a column instead of 800.
+      // sR holds R as pairs: sR[(a / 2 * 20 + b) * 2 + (a & 1)] = R[a][b]
+      const f32x2* R2 = reinterpret_cast<const f32x2*>(sR);
+#pragma unroll
+      for (int ap = 0; ap < 10; ++ap) {
+        const f32x2* Ra = R2 + ap * 20;
+        // (the pairs are read from LDS here, ten 16-byte broadcast reads per two rows: left to itself the compiler keeps all of R in
+        // accumulation registers across the columns of a wave and pays a v_accvgpr_read per value and use)
+        asm volatile("" ::: "memory");
+        f32x2 g = f32x2{f[0], f[0]} * Ra[0];
+#pragma unroll
+        for (int b = 1; b < 20; ++b) g = g + f32x2{f[b], f[b]} * Ra[b];
+        P[2 * ap] = (float)((1. - (double)tau) * (double)f[2 * ap] + (double)(tau * g.x));
+        P[2 * ap + 1] = (float)((1. - (double)tau) * (double)f[2 * ap + 1] + (double)(tau * g.y));
       }
     }
   }
@@ -230,8 +251,8 @@ __device__ __forceinline__ void emit_records(const PrepArgs& a, int k, int tid, 
 // ---- split path (templates too long for the LDS of the fused kernel): P1 over the columns of the listed templates ...
 __global__ void __launch_bounds__(256) hhv_prep_columns_kernel(PrepArgs a) {
   // R[20][20] is read 400 times per column with wave-uniform indices: stage it in LDS (broadcast reads)
-  __shared__ float sR[400];
-  for (int q = threadIdx.x; q < 400; q += 256) sR[q] = a.R[q];
+  __shared__ __attribute__((aligned(16))) float sR[400];
+  stage_R_pairs(a.R, sR, threadIdx.x, 256);
   __syncthreads();
   const int k = a.ids[blockIdx.x];
   const int64_t rin = prep_rin(a, k);  // the intermediate is indexed like the raw block
@@ -288,7 +309,7 @@ __global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_
   float* s_diff = s_lg2 + PREP_TAB;            // [1028]
   float* sT0 = s_diff + PREP_TAB;              // [NT][(maxL+1)][8]: tr[7] + the column's meta bits
   float* sP0 = sT0 + (size_t)NT * a.lds_cols * 8;  // [NT][(maxL+1)][21]
-  for (int q = threadIdx.x; q < 400; q += NTH) sR[q] = a.R[q];
+  stage_R_pairs(a.R, sR, threadIdx.x, NTH);
   for (int q = threadIdx.x; q < 1025; q += NTH) s_lg2[q] = a.lg2[q], s_diff[q] = a.diff[q];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -587,6 +587,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
   std::unordered_map<HHEntry*, ResidentTemplate> resident;   // an entry listed twice is the same template
   std::vector<SsRecords*> own_ss;                  // ss records of host-prepared templates
   std::vector<HHEntry*> work(dbfiles.begin(), dbfiles.end());
+  resident.reserve(dbfiles.size());
 
   if (device_prepare) {  // the prototypes of the cache are valid for one (nseqdis, ssm, query ss presence) only
     std::lock_guard<std::mutex> lock(tc.device);
@@ -618,15 +619,19 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
       const unsigned int m = imin(n_work - block_start, block_size);
       sort(work.begin() + block_start, work.begin() + (block_start + m), HHDatabaseEntryCompare());  // :117-119
       const size_t first_hit_of_block = ret_hits.size();
+      timer.lap(PhaseTimer::OTHER, "sort");
+      // (a Hit is ~1.4 KB - four IDLEN strings: 20 000 of them are 28 MB, 2 ms of constructors on warm pages and 6-12 ms when the
+      // allocator has to map fresh ones; touching the pages from all threads first was measured and is slower)
       ret_hits.resize(first_hit_of_block + m);
 
       // chunks that are whole SIMD batches of the reference, so that host memory stays bounded
-      const unsigned int chunk_max = 16384;
+      // (32 768: hhblits' 20 000 templates of a round in one piece - every chunk is a round of launches, copies and waits)
+      const unsigned int chunk_max = 32768;
       for (unsigned int c0 = 0; c0 < m; c0 += chunk_max) {
         const unsigned int cn = imin(m - c0, chunk_max);
         HHEntry** ent = &work[block_start + c0];
         Hit* hit0 = &ret_hits[first_hit_of_block + c0];
-        timer.lap(PhaseTimer::OTHER, "sort+Hit vector");
+        timer.lap(PhaseTimer::OTHER, "Hit vector");
 
         if (alignment == 0) {
           // ---- which templates are already resident in raw form? ----
@@ -634,14 +639,18 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
           std::vector<unsigned int> to_read;
           if (device_prepare) {
             std::lock_guard<std::mutex> lock(tc.device);
+            // (lookups only - nobody writes the map while the lock is held - by all threads: key string, hash and the index
+            // search of the entry's name are ~0.25 us a template)
+#pragma omp parallel for schedule(static) num_threads(threads) if (cn > 256)
             for (unsigned int k = 0; k < cn; ++k) {
               std::unordered_map<std::string, CachedTemplate>::const_iterator it = tc.map.find(cache_key(ent[k]));
               // same name and length but another database entry (two databases, a rebuilt one): read it again, the new
               // upload takes the slot
               const hhv_dropin::EntryIdentity id = identify_entry(databases, ent[k]->getName());
               if (it != tc.map.end() && it->second.id == id) cached[k] = &it->second;  // std::unordered_map never moves its elements
-              else to_read.push_back(k);
             }
+            for (unsigned int k = 0; k < cn; ++k)
+              if (!cached[k]) to_read.push_back(k);
           } else {
             for (unsigned int k = 0; k < cn; ++k) to_read.push_back(k);
           }
