@@ -858,13 +858,17 @@ def next_rows():
         # for) against the drop-in translation unit, wall time of the call, hits compared (tools/bench_dropin.py)
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhhref_dropin.so")):
             import bench_dropin
-            r = bench_dropin.run(4000, min(32, usable_cores()[0]), 300, altalis=(1,))   # (threads the box really grants: 32 on a 16-CPU quota was noise)
+            # 20 000 templates: hhblits' maxnumdb, what one of its rounds hands to ViterbiRunner::alignment (src/hhdecl.cpp:13)
+            r = bench_dropin.run(20000, min(32, usable_cores()[0]), 300, altalis=(1,), phases=True)   # (threads the box really grants: 32 on a 16-CPU quota was noise)
             a = r["altali1"]
             out["dropin_ViterbiRunner_alignment"] = {"templates": r["n_templates"], "Lq": r["L"], "Lt": r["L"], "host_threads": r["threads"],
                                                      "reference_s": a["reference_s"], "dropin_cold_cache_s": a["dropin_cold_cache_s"],
                                                      "dropin_warm_cache_s": a["dropin_warm_cache_s"], "hits_identical": a["hits_identical"],
-                                                     "note": "cold = every template's HHM text parsed by the host's HMM::Read, as in the reference (the DP is ~1 ms of "
-                                                             "it); warm = templates resident on the device (second search of the process)"}
+                                                     "cold_phases_ms": a.get("cold_phases_ms"), "warm_phases_ms": a.get("warm_phases_ms"),
+                                                     "note": "cold = first call of the process: every template's HHM text parsed by the host's HMM::Read, as in the "
+                                                             "reference ('read+parse'), context creation and the first launches' code-object loads included; warm = "
+                                                             "templates resident on the device (second search of the process); phases: HHV_DROPIN_TIMING, "
+                                                             "hh-suite_amd/dropin/hhviterbirunner_hip.cpp PhaseTimer"}
     except Exception as e:
         out["dropin_ViterbiRunner_alignment"] = {"error": repr(e)}
     try:

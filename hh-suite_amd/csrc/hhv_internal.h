@@ -186,6 +186,7 @@ struct PrepArgs {
   const int32_t* src;        // [n slots] raw template of slot k, or null = identity (the whole raw set)
   const int64_t* raw_off;    // [n raw + 1] first column of every raw template in the raw block
   int32_t lds_cols;          // fused kernel: columns the LDS buffers hold (max L of the class + 1)
+  int32_t step3_all;         // fused kernel: step 3 on every wavefront (else on those that had no step 2)
 };
 
 size_t prepare_fused_lds(int max_L);

@@ -14,6 +14,8 @@
 // 28-dword records (+ header).  Longer templates take the same three steps as two kernels with the intermediate in HBM.
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 
 #include "hhv_internal.h"
@@ -298,6 +300,26 @@ constexpr int PREP_TAB = 1028;
 // (Measured, 100 000 templates of 300 columns, profiles/r6_prep_summary.txt: 4.36 ms before; lane-per-column emission + 16-byte loads
 // and stores + steps spread by cost 2.78; + tables in LDS, one template per workgroup, three workgroups per CU 2.95; two templates
 // per workgroup 2.60; ten wavefronts - one chunk each - 2.74: the balance inside a workgroup is not what limits it any more.)
+// (Later in round 6: R f as packed pairs 2.52 ms.  The timing build below - every wave's clocks per step - shows a workgroup spending
+// 8 % staging the tables, 45 % in step 1, 24 % in step 2 with six of its eight waves idle at the barrier - 300 dependent additions at
+// ~100 clocks each, because the SIMD the lone wave sits on is shared with three busy waves of the other workgroup -, 23 % in step 3.
+// A rewrite with persistent workgroups (tables staged once), the raw columns of a wave's next chunk requested a chunk ahead, the
+// profile transposed in LDS and step 2 reading 16 bytes at a time was bit-exact and SLOWER, 3.02 ms: the 32 registers of the
+// prefetch push the kernel past the 128 of four waves per SIMD (36 spilled), and step 2 stayed at ~100 clocks a column - it is issue
+// arbitration, not LDS latency.  profiles/r6_prep_steps.txt.)
+#ifdef HHV_PREP_TIMING
+// measurement build (make lib_variant NAME=pt FLAGS=-DHHV_PREP_TIMING): clocks every wavefront spends in the steps of the fused kernel
+// and at its barriers, summed per wave index: [wave][0 tables, 1 step 1, 2 barrier, 3 step 2, 4 barrier, 5 step 3], [wave][7] = count
+__device__ unsigned long long g_prep_clk[16 * 8];
+#define PREP_T(slot)                                                                      \
+  {                                                                                       \
+    const unsigned long long t_now = __builtin_readcyclecounter();                        \
+    if (lane == 0) atomicAdd(&g_prep_clk[wave * 8 + (slot)], t_now - t_last);             \
+    t_last = t_now;                                                                       \
+  }
+#else
+#define PREP_T(slot)
+#endif
 template <int NT>
 __global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_ids) {
   const int NTH = blockDim.x, NW = NTH >> 6;
@@ -309,10 +331,14 @@ __global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_
   float* s_diff = s_lg2 + PREP_TAB;            // [1028]
   float* sT0 = s_diff + PREP_TAB;              // [NT][(maxL+1)][8]: tr[7] + the column's meta bits
   float* sP0 = sT0 + (size_t)NT * a.lds_cols * 8;  // [NT][(maxL+1)][21]
+#ifdef HHV_PREP_TIMING
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
   stage_R_pairs(a.R, sR, threadIdx.x, NTH);
   for (int q = threadIdx.x; q < 1025; q += NTH) s_lg2[q] = a.lg2[q], s_diff[q] = a.diff[q];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PREP_T(0)
   int k[NT], L[NT], n_chunks[NT];
   int64_t rin[NT];
 #pragma unroll
@@ -323,7 +349,7 @@ __global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_
     rin[t] = k[t] >= 0 ? prep_rin(a, k[t]) : 0;
     n_chunks[t] = k[t] >= 0 ? (L[t] + 1 + 63) >> 6 : 0;
   }
-  const int W3_N = NW > NT ? NW - NT : NW;  // step 3 on the waves that had no step 2
+  const int W3_N = (NW > NT && !a.step3_all) ? NW - NT : NW;  // step 3 on the waves that had no step 2, or on all
   // ---- step 1: one lane per raw column
   {
     int q = 0;
@@ -343,13 +369,17 @@ __global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_
       }
     }
   }
+  PREP_T(1)
   __syncthreads();
+  PREP_T(2)
   // ---- step 2: the column sums, in the reference's order
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if (k[t] >= 0 && wave == NW - 1 - t)
       finalize_template<PREP_PS>(a, k[t], lane, sP0 + (size_t)t * a.lds_cols * PREP_PS, sT0 + (size_t)t * a.lds_cols * 8, s_pav0 + 20 * t, s_pnul0 + 20 * t);
+  PREP_T(3)
   __syncthreads();
+  PREP_T(4)
   // ---- step 3: header + one record per column
   int q3 = 0;
 #pragma unroll
@@ -392,6 +422,10 @@ __global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_
       for (int q = 0; q < REC_DW / 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
     }
   }
+  PREP_T(5)
+#ifdef HHV_PREP_TIMING
+  if (lane == 0) atomicAdd(&g_prep_clk[wave * 8 + 7], 1ull);
+#endif
 }
 
 // (nt templates per workgroup)
@@ -421,12 +455,18 @@ int launch_prepare(const PrepArgs& a0, const int32_t* const ids[3], const int32_
     // two templates per workgroup where two such workgroups fit a CU's LDS (four templates resident, as with one template and no
     // tables), else one
     const size_t lds2 = prepare_fused_lds(max_L[cls], 2), lds1 = prepare_fused_lds(max_L[cls], 1);
+    // measurement aids: wavefronts per template (4; 5 and 6 - one chunk of a 300-column template per wave - measured no faster:
+    // 2.51 / 2.60 / 2.46 ms), step 3 on every wave
+    static const int wpt_env = [] { const char* e = getenv("HHV_PREP_WAVES"); return e ? atoi(e) : 0; }();
+    static const int w3_env = [] { const char* e = getenv("HHV_PREP_W3ALL"); return e ? atoi(e) : -1; }();
+    const int wpt = wpt_env > 0 ? std::min(8, wpt_env) : 4;
+    a.step3_all = w3_env >= 0 ? w3_env : 0;
     if (lds2 <= 80 * 1024) {
       (void)hipFuncSetAttribute((const void*)hhv_prep_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL(hhv_prep_fused_kernel<2>, dim3((n_ids[cls] + 1) / 2), dim3(512), lds2, stream, a, n_ids[cls]);
+      hipLaunchKernelGGL(hhv_prep_fused_kernel<2>, dim3((n_ids[cls] + 1) / 2), dim3(2 * wpt * 64), lds2, stream, a, n_ids[cls]);
     } else {
       (void)hipFuncSetAttribute((const void*)hhv_prep_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-      hipLaunchKernelGGL(hhv_prep_fused_kernel<1>, dim3(n_ids[cls]), dim3(256), lds1, stream, a, n_ids[cls]);
+      hipLaunchKernelGGL(hhv_prep_fused_kernel<1>, dim3(n_ids[cls]), dim3(wpt * 64), lds1, stream, a, n_ids[cls]);
     }
   }
   if (n_ids[2]) {
@@ -435,6 +475,20 @@ int launch_prepare(const PrepArgs& a0, const int32_t* const ids[3], const int32_
     hipLaunchKernelGGL(hhv_prep_columns_kernel, dim3(n_ids[2]), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(hhv_prep_finalize_kernel, dim3(n_ids[2]), dim3(LANES), 0, stream, a);
   }
+#ifdef HHV_PREP_TIMING
+  {
+    (void)hipStreamSynchronize(stream);
+    unsigned long long h[16 * 8], z[16 * 8] = {};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prep_clk), sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prep_clk), z, sizeof(z));
+    fprintf(stderr, "hhv_prep_fused_kernel: mean clocks per wave: tables, step 1, barrier, step 2, barrier, step 3\n");
+    for (int w = 0; w < 16; ++w)
+      if (h[w * 8 + 7])
+        fprintf(stderr, "  wave %2d: %8.0f %8.0f %8.0f %8.0f %8.0f %8.0f   (%llu workgroups)\n", w, (double)h[w * 8] / h[w * 8 + 7],
+                (double)h[w * 8 + 1] / h[w * 8 + 7], (double)h[w * 8 + 2] / h[w * 8 + 7], (double)h[w * 8 + 3] / h[w * 8 + 7],
+                (double)h[w * 8 + 4] / h[w * 8 + 7], (double)h[w * 8 + 5] / h[w * 8 + 7], h[w * 8 + 7]);
+  }
+#endif
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

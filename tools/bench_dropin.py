@@ -19,7 +19,39 @@ def canonical(r):
     return ([r[0][k] for k in order],) + tuple(a[order] for a in r[1:])
 
 
-def run(n=4000, threads=32, L=300, altalis=(1, 4)):
+class _Stderr:
+    """the C-level stderr of this process into a file for the length of a `with` block (HHV_DROPIN_TIMING's report)"""
+    def __enter__(self):
+        import tempfile
+        sys.stderr.flush()
+        self.f = tempfile.TemporaryFile()
+        self.saved = os.dup(2)
+        os.dup2(self.f.fileno(), 2)
+        return self
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 2)
+        os.close(self.saved)
+        self.f.seek(0)
+        self.text = self.f.read().decode(errors="replace")
+        self.f.close()
+
+
+def _phases(text):
+    """the last 'in ms:' line of the drop-in's phase timer -> {label: ms}"""
+    lines = [l for l in text.splitlines() if "hhviterbirunner_hip:   in ms:" in l]
+    if not lines:
+        return None
+    out = {}
+    for item in lines[-1].split("in ms:")[1].split(","):
+        item = item.strip()
+        if item:
+            label, ms = item.rsplit(" ", 1)
+            out[label] = float(ms)
+    return out
+
+
+def run(n=4000, threads=32, L=300, altalis=(1, 4), phases=False):
     import hhm_text
     from test_dropin_runner import run as runner, compare, cache_clear
     uniq = min(n, 400)
@@ -37,13 +69,23 @@ def run(n=4000, threads=32, L=300, altalis=(1, 4)):
         res = {}
         cache_clear()
         for which, tag in (("hip", "dropin_cold"), ("cpu", "cpu"), ("hip", "dropin_warm"), ("cpu", "cpu"), ("hip", "dropin_warm")):
-            r = runner(which, q, texts, names, threads=threads, **kw)
+            if phases and which == "hip":
+                os.environ["HHV_DROPIN_TIMING"] = "1"
+                with _Stderr() as cap:
+                    r = runner(which, q, texts, names, threads=threads, **kw)
+                del os.environ["HHV_DROPIN_TIMING"]
+                res[tag + "_phases_ms"] = _phases(cap.text)
+            else:
+                r = runner(which, q, texts, names, threads=threads, **kw)
             res[tag] = (runner.last_alignment_seconds, r)     # the ViterbiRunner::alignment call alone
         compare(canonical(res["cpu"][1]), canonical(res["dropin_cold"][1]))
         compare(canonical(res["cpu"][1]), canonical(res["dropin_warm"][1]))
         out["altali%d" % altali] = {"reference_s": round(res["cpu"][0], 4), "dropin_cold_cache_s": round(res["dropin_cold"][0], 4),
                                     "dropin_warm_cache_s": round(res["dropin_warm"][0], 4),
                                     "hits": len(res["cpu"][1][0]), "hits_identical": True, "cells": int(n) * L * L}
+        if phases:
+            out["altali%d" % altali]["cold_phases_ms"] = res.get("dropin_cold_phases_ms")
+            out["altali%d" % altali]["warm_phases_ms"] = res.get("dropin_warm_phases_ms")
     cache_clear()
     return out
 
