@@ -375,8 +375,17 @@ __global__ void __launch_bounds__(1024) hhv_prep_fused_kernel(PrepArgs a, int n_
   // ---- step 2: the column sums, in the reference's order
 #pragma unroll
   for (int t = 0; t < NT; ++t)
-    if (k[t] >= 0 && wave == NW - 1 - t)
+    if (k[t] >= 0 && wave == NW - 1 - t) {
+      // the whole workgroup waits for this one chain of dependent additions: highest issue priority on its SIMD, which it shares
+      // with waves of the other resident workgroup (HHV_PREP_NO_PRIO in the environment of the build: without)
+#ifndef HHV_PREP_NO_PRIO
+      __builtin_amdgcn_s_setprio(3);
+#endif
       finalize_template<PREP_PS>(a, k[t], lane, sP0 + (size_t)t * a.lds_cols * PREP_PS, sT0 + (size_t)t * a.lds_cols * 8, s_pav0 + 20 * t, s_pnul0 + 20 * t);
+#ifndef HHV_PREP_NO_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
   PREP_T(3)
   __syncthreads();
   PREP_T(4)

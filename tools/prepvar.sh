@@ -5,6 +5,3 @@ run() { echo -n "$* : "; env "$@" timeout 300 python tools/bench_prepare.py 1000
 run A=1
 run A=1
 for w in 4 5 6; do for a in 0 1; do run HHV_PREP_WAVES=$w HHV_PREP_W3ALL=$a; done; done
-run HHV_PREP_WG_PER_CU=1
-run HHV_PREP_WG_PER_CU=3
-HHV_LIB=$GRAFT_REPO_ROOT/hh-suite_amd/lib/libhhviterbi_pt.so timeout 300 python tools/bench_prepare.py 100000 2>&1 | grep -A9 "mean clocks" | tail -10
