@@ -20,6 +20,7 @@
 // They need q - offset to fit int8 and the profile to fit LDS (Lq <= 512); anything else takes the generic kernel
 // (state in LDS, profile in LDS or global), which is the direct transcription of the AVX2 loops.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "hhv_internal.h"
 
@@ -173,6 +174,101 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_kernel(PrefilterArgs a) 
     }
     for (int o = 32; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o, 64));
     if (lane == 0) a.scores[slot] = (SLAB && a.q_base) ? max(vmax, a.scores[slot]) : vmax;
+  }
+}
+
+// ---- gapless score, TWO cells per register (round 6, queries up to 320 columns) ---------------------------------------
+// The cells of a lane as pairs of int16 - (S[2p], S[2p+1]) in one VGPR - and the profile as int16 pairs in LDS ([state][lane][W / 2]
+// words, the odd cell of W = 1, 3, 5 as a halfword array beside them: 221 x 64 x 10 B = 141 KB at W = 5).  A residue costs per pair
+// one v_alignbit (the pair shifted by one cell: (S[2p-1], S[2p])), one v_pk_add_i16 with clamp, one v_pk_max_i16 against 0 and one
+// v_pk_max_i16 into the running maximum: 4 instructions for two cells where the byte kernel above spends 3 per cell (add with a
+// byte select, med3, max) - on paper; with the shift, the carry and the address arithmetic it is 16 against 17 per residue at
+// W = 5, and slower in practice (see launch_prefilter_fast).  The UPPER clamp of the reference's saturating byte arithmetic (255 - offset) is not applied per cell:
+// a diagonal's values equal the clamped ones until the first of them passes the cap, at that cell the clamped chain holds
+// exactly the cap, so max over all cells, cut at the cap at the very end, is the same number; int16 saturation keeps an
+// unclamped chain from wrapping.  The slot beside the odd cell of an odd W carries a copy of that cell's previous value (its
+// profile operand is 0): never above the running maximum.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t x, uint32_t y) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(i16x2, x), __builtin_bit_cast(i16x2, y)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t x, uint32_t y) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), __builtin_bit_cast(i16x2, y)));
+}
+template <int W>
+__global__ void __launch_bounds__(1024) hhv_pf_ungapped_pk_kernel(PrefilterArgs a) {
+  constexpr int NP = W / 2, ODD = W & 1, NPR = NP + ODD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* spair = reinterpret_cast<uint32_t*>(smem);                                   // [221][64][NP]
+  uint16_t* sodd = reinterpret_cast<uint16_t*>(spair + (size_t)(PF_NULL + 1) * 64 * NP);  // [221][64], odd W only
+  auto cell = [&](int x, int k, int t) -> int {
+    const int pos = k * W + t;
+    return (x < PF_NULL && t < W && pos < a.Lq) ? (int)a.profile[(size_t)x * a.Lq + pos] - a.offset : 0;
+  };
+  constexpr int NPD = NP > 0 ? NP : 1;
+  for (int e = threadIdx.x; e < (PF_NULL + 1) * 64 * NP; e += 1024) {
+    const int p = e % NPD, k = (e / NPD) % 64, x = e / (NPD * 64);
+    spair[e] = ((uint32_t)cell(x, k, 2 * p) & 0xffffu) | ((uint32_t)cell(x, k, 2 * p + 1) << 16);
+  }
+  if (ODD)
+    for (int e = threadIdx.x; e < (PF_NULL + 1) * 64; e += 1024) sodd[e] = (uint16_t)cell(e / 64, e % 64, W - 1);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int cap = 255 - a.offset;
+  const int wave = blockIdx.x * 16 + (threadIdx.x >> 6), n_waves = gridDim.x * 16;
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(a.seqs);
+
+  for (int64_t job = wave; job < a.n_jobs; job += n_waves) {
+    const int slot = __builtin_amdgcn_readfirstlane(a.order ? a.order[job] : (int)job);
+    const int sid = __builtin_amdgcn_readfirstlane(a.subset ? a.subset[slot] : slot);
+    const int64_t beg = a.offsets[sid], end = a.offsets[sid + 1];
+    const int64_t w0 = beg >> 2;
+    const int nw = __builtin_amdgcn_readfirstlane((int)(((end + 3) >> 2) - w0));
+    const int head = __builtin_amdgcn_readfirstlane((int)(beg & 3));
+    const int tail = __builtin_amdgcn_readfirstlane((int)(end - ((w0 + nw - 1) << 2)));  // residues in the last word
+    uint32_t P[NPR], vm = 0;
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) P[p] = 0;
+    uint32_t chunk_next = words[w0 + max(min(lane, nw - 1), 0)];
+    for (int c0 = 0; c0 < nw; c0 += 64) {
+      const uint32_t chunk = chunk_next;
+      chunk_next = words[w0 + min(c0 + 64 + lane, nw - 1)];
+      const int n_here = min(64, nw - c0);
+      for (int wl = 0; wl < n_here; ++wl) {
+        uint32_t word = __builtin_amdgcn_readlane(chunk, wl);
+        const int wi = c0 + wl;
+        if (wi == 0 || wi == nw - 1) word = mask_word(word, wi == 0 ? head : 0, wi == nw - 1 ? tail : 4);
+        uint32_t q[4][NPR];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int x = (word >> (8 * b)) & 0xff;
+          if (NP > 0) {
+            uint32_t t[NP > 0 ? NP : 1];
+            read_cells<(NP > 0 ? NP : 1)>(spair + ((size_t)x * 64 + lane) * NP, t);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) q[b][p] = t[p];
+          }
+          if (ODD) q[b][NPR - 1] = sodd[x * 64 + lane];  // (q, 0)
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          // the last cell of the lane on the left: low half of its last pair (odd W) or high half (even W); lane 0: row 0's zero
+          const uint32_t sl = (uint32_t)wave_shr1_zero((int)P[NPR - 1]);
+          uint32_t sh[NPR];
+#pragma unroll
+          for (int p = NPR - 1; p >= 1; --p) sh[p] = __builtin_amdgcn_alignbit(P[p], P[p - 1], 16);  // (S[2p-1], S[2p])
+          sh[0] = ODD ? __builtin_amdgcn_perm(P[0], sl, 0x05040100u) : __builtin_amdgcn_alignbit(P[0], sl, 16);  // (carry, S[0])
+#pragma unroll
+          for (int p = 0; p < NPR; ++p) {
+            P[p] = pk_max(pk_add_sat(sh[p], q[b][p]), 0u);
+            vm = pk_max(vm, P[p]);
+          }
+        }
+      }
+    }
+    int vmax = max((int)(short)(vm & 0xffffu), (int)(short)(vm >> 16));
+    for (int o = 32; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0) a.scores[slot] = min(vmax, cap);
   }
 }
 
@@ -383,6 +479,22 @@ int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_bloc
   const size_t lds = prefilter_fast_lds(gapped, W);
   if (!gapped) {
     const bool slab = a.carry_in != nullptr || a.carry_out != nullptr || a.q_base != 0;
+    // two cells per register: measured against the byte kernel in one session (profiles/r6_ab.txt, 1 M sequences): W = 2 (queries
+    // of 65 .. 128 columns) 4.90 -> 4.24 ms; W = 4 7.5 = 7.5; W = 5 (300 columns) 9.6 -> 10.3 ms - the odd cell's halfword read,
+    // its mask and the byte permute for the carry cost what the pairs save.  So: W = 2 only.  HHV_PF_PACKED=1 / 0 (measurement
+    // aid): every W up to 5 / none.
+    static const int packed_env = [] { const char* e = getenv("HHV_PF_PACKED"); return e ? atoi(e) : -1; }();
+    const bool packed = packed_env < 0 ? W == 2 : packed_env != 0;
+    if (packed && !slab && W <= 5) {
+      const size_t lds_pk = (size_t)(PF_NULL + 1) * 64 * ((W / 2) * 4 + (W & 1) * 2);
+      switch (W) {
+        case 1: return launch_one(hhv_pf_ungapped_pk_kernel<1>, a, n_blocks, 1024, lds_pk, stream);
+        case 2: return launch_one(hhv_pf_ungapped_pk_kernel<2>, a, n_blocks, 1024, lds_pk, stream);
+        case 3: return launch_one(hhv_pf_ungapped_pk_kernel<3>, a, n_blocks, 1024, lds_pk, stream);
+        case 4: return launch_one(hhv_pf_ungapped_pk_kernel<4>, a, n_blocks, 1024, lds_pk, stream);
+        case 5: return launch_one(hhv_pf_ungapped_pk_kernel<5>, a, n_blocks, 1024, lds_pk, stream);
+      }
+    }
     switch (W) {
 #define HHV_PF_CASE(w) \
   case w:              \
