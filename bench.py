@@ -541,7 +541,9 @@ def fast_mode(args, capi, ctx, ts, rec, Ls, qf, qtr, dev_index, K):
     multiply-adds, viterbi_lane.h HHV_EMISSION_FMA) - what it gains and what it changes against the bit-exact default build
     on ALL templates of the set: end points, scores, top-K, and with backtrace the alignments and Hit scores."""
     out = {"library": "libhhviterbi_hip_fma.so", "what": "emission with v_fmac_f32 (16 of the 20 products accumulate fused, log2f4's "
-           "polynomial fused): one rounding per term instead of two; opt-in build, the default library has no FMA"}
+           "polynomial fused): one rounding per term instead of two; opt-in build, the default library has no FMA.  NOT within the 1e-4 "
+           "tolerance on every template: log2f4 jumps by 3.93e-4 at powers of two (1.2e7 templates: max |dscore| 3.98e-4, 12 end points "
+           "changed - profiles/r6_fast_mode_bound.json)"}
     try:
         cf = capi.Context(local=args.local, device=dev_index, lib_path=capi.FMA_LIB_PATH)
         cf.set_query(qf, qtr)

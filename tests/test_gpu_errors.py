@@ -248,3 +248,41 @@ def test_mac_dataflow_timeout_is_an_error_not_a_result():
         assert (a.i2, a.j2) == (int(res["i2"][e]), int(res["j2"][e])) and np.float32(a.score) == res["score"][e]
     ts.free()
     c.close()
+
+
+def test_packed_paths_errors_and_block_pool_reuse():
+    """hhv_hit_paths_packed refuses step counts that are not the set's and a set without hits; the context's pool of device
+    blocks (tmalloc / tfree, round 6) hands the blocks of a freed set to the next one: sets made, searched and freed in a loop
+    give the same results every time and do not grow the device's memory in use."""
+    import torch
+    from pyhhv import capi
+    c = capi.Context(local=1)
+    qp, qtr = synth.make_query(3, 60)
+    c.set_query(qp, qtr)
+    tps, ttrs = zip(*[synth.make_homolog(100 + k, qp, L=30 + 7 * k) for k in range(12)])
+    ts = c.upload(list(tps), list(ttrs))
+    c.align(ts)
+    with pytest.raises(capi.HhvError):                       # no backtrace / hits yet
+        c.hit_paths_packed(ts, np.zeros(ts.n, dtype=capi.HIT_DTYPE))
+    c.align(ts, backtrace=True)
+    hits = c.hits(ts).copy()
+    bad = hits.copy()
+    bad["nsteps"][3] = 10 ** 6                                # beyond the pool's capacity for that template
+    with pytest.raises(capi.HhvError, match="nsteps"):
+        c.hit_paths_packed(ts, bad)
+    off, pi, pj, st, S = c.hit_paths_packed(ts, hits)         # the context survived
+    want = (hits.tobytes(), off.tobytes(), pi.tobytes(), pj.tobytes(), st.tobytes(), S.tobytes())
+    ts.free()
+    torch.cuda.synchronize()
+    used = []
+    for rep in range(6):
+        t2 = c.upload(list(tps), list(ttrs))
+        c.align(t2, backtrace=True)
+        h2 = c.hits(t2).copy()
+        got = (h2.tobytes(),) + tuple(a.tobytes() for a in c.hit_paths_packed(t2, h2))
+        assert got == want, rep
+        t2.free()
+        free_b, total_b = torch.cuda.mem_get_info()
+        used.append(total_b - free_b)
+    assert used[-1] <= used[1], used                           # the blocks of the freed sets are reused, not added to
+    c.close()

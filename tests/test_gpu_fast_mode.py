@@ -5,8 +5,10 @@ It computes the emission score with fused multiply-adds (one rounding per term i
 instructions per DP step.  Two checks (-m gpu):
   * bit for bit against the oracle's restatement of exactly that arithmetic (hho_set_emission_mode(2)): the build is as
     deterministic and as testable as the default one - score bits, end points, every backtrace byte, paths, Hit scores;
-  * against the reference's arithmetic (mode 0): end points, paths and top-K order unchanged, Viterbi scores within
-    2e-4 (BASELINE.json's tolerance is 1e-4; the measured maximum is reported by bench.py `fast_mode`)."""
+  * against the reference's arithmetic (mode 0) ON THIS SAMPLE: end points, paths and top-K order unchanged, Viterbi scores within
+    2e-4.  That is a property of the sample, not of the build: log2f4 jumps by 3.93e-4 at every power of two, and over 1.2e7
+    templates the fused build's largest score difference was 3.98e-4 with 12 end points changed (tools/fast_mode_bound.py,
+    profiles/r6_fast_mode_bound.json) - outside BASELINE.json's 1e-4, which is why the build is opt-in."""
 import numpy as np
 import pytest
 

@@ -70,6 +70,7 @@ def main():
         out["sets"] += 1
         out["endpoint_mismatches"] += em
         out["scores_changed"] += int(np.sum(f["score"] != d["score"]))
+        out["scores_beyond_1e-4"] = out.get("scores_beyond_1e-4", 0) + int(np.sum(diff > 1e-4))
         out["max_abs_viterbi_score_diff"] = max(out["max_abs_viterbi_score_diff"], float(diff.max()) if diff.size else 0.0)
         out["max_rel_viterbi_score_diff"] = max(out["max_rel_viterbi_score_diff"], float(rel.max()) if rel.size else 0.0)
         if bt:
@@ -81,6 +82,7 @@ def main():
         del rec
         torch.cuda.empty_cache()
     out["seconds"] = round(time.time() - t0, 1)
+    out["log2f4_jump_at_powers_of_two"] = 0.0003930330276489258   # log2f4(2) - log2f4(nextafter(2, 0)), src/hhutil-inl.h:509-541
     out["note"] = ("empirical running maxima of |fused - default| over the sets listed; end-point / alignment mismatches are templates "
                    "whose best cell or path differs (ties broken by a last-bit change)")
     print(json.dumps(out))
