@@ -15,6 +15,18 @@ using hhv::api::tfree;
 using hhv::api::tmalloc;
 using hhv::api::fail;
 using hhv::api::sync_check;
+
+// contexts that exist: a set freed after its context (against the header's rule) must not touch the context's pool
+namespace {
+std::mutex g_live_m;
+std::vector<hhv_ctx*> g_live;
+bool ctx_alive(hhv_ctx* c) {
+  std::lock_guard<std::mutex> lock(g_live_m);
+  return std::find(g_live.begin(), g_live.end(), c) != g_live.end();
+}
+}  // namespace
+bool hhv::api::context_alive(hhv_ctx* c) { return c && ctx_alive(c); }
+
 using hhv::api::tset_init_common;
 
 static_assert(sizeof(hhv_result) == sizeof(DevResult), "hhv_result layout");
@@ -232,6 +244,10 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
     hhv_destroy(c);
     return fail(HHV_E_DEVICE, "hhv_create: table upload failed");
   }
+  {
+    std::lock_guard<std::mutex> lock(g_live_m);
+    g_live.push_back(c);
+  }
   *out = c;
   return HHV_OK;
 }
@@ -269,6 +285,10 @@ int hhv_set_launch_policy(hhv_ctx* c, int32_t pair_mode, int32_t pair_swap, int3
 
 void hhv_destroy(hhv_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lock(g_live_m);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
+  }
   (void)hipSetDevice(c->par.device);
   dfree(c->d_qpack);
   dfree(c->d_queue);
@@ -469,7 +489,7 @@ static int ensure_ss(hhv_ctx* c) {
 hipError_t hhv::api::pool_malloc(hhv_ctx* c, void** p, size_t bytes) {
   *p = nullptr;
   const size_t want = (std::max<size_t>(bytes, 1) + 511) & ~(size_t)511;
-  if (!c) return hipMalloc(p, want);
+  if (!c || !ctx_alive(c)) return hipMalloc(p, want);
   DevPool& pool = c->pool;
   {
     std::unique_lock<std::mutex> lock(pool.m);
@@ -505,7 +525,7 @@ hipError_t hhv::api::pool_malloc(hhv_ctx* c, void** p, size_t bytes) {
 
 void hhv::api::pool_free(hhv_ctx* c, void* p) {
   if (!p) return;
-  if (!c) {
+  if (!c || !ctx_alive(c)) {
     (void)hipFree(p);
     return;
   }
@@ -752,7 +772,7 @@ int hhv_adopt_device_stream(hhv_ctx* c, int32_t n, const int32_t* L, const void*
 
 void hhv_tset_free(hhv_tset* ts) {
   if (!ts) return;
-  if (ts->ctx) (void)hipSetDevice(ts->ctx->par.device);
+  if (hhv::api::context_alive(ts->ctx)) (void)hipSetDevice(ts->ctx->par.device);
   if (ts->owns_records) tfree(ts->ctx, ts->d_records);
   tfree(ts->ctx, ts->d_rec_off);
   tfree(ts->ctx, ts->d_L);

@@ -59,6 +59,7 @@ struct DevPool {
 constexpr size_t POOL_BLOCK_MAX = (size_t)512 << 20, POOL_TOTAL_MAX = (size_t)4 << 30;
 hipError_t pool_malloc(struct ::hhv_ctx* c, void** p, size_t bytes);
 void pool_free(struct ::hhv_ctx* c, void* p);
+bool context_alive(struct ::hhv_ctx* c);  // created and not yet destroyed (a set freed after its context frees its blocks directly)
 void pool_release(struct ::hhv_ctx* c);  // hands every cached block back to the runtime (hhv_destroy; an allocation that failed)
 template <typename T>
 inline hipError_t tmalloc(struct ::hhv_ctx* c, T** p, size_t bytes) {

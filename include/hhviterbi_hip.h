@@ -152,6 +152,9 @@ int hhv_create(hhv_ctx** out, const hhv_params* par);
  * process as the reference's code (the drop-in translation units) reads the tables the process actually has and hands them
  * over, so that per-column scores - and with them Hit.score - match to the last bit in every kind of run. */
 int hhv_set_fast_log2_tables(hhv_ctx* ctx, const float* lg2, const float* diff);
+/* Frees the context, its streams and the device blocks it keeps for reuse (the blocks of freed template sets are cached per
+ * context, round 6).  The template, raw, prefilter and MAC sets of a context are freed BEFORE it (hhv_tset_free & co. return
+ * their blocks to the context they came from). */
 void hhv_destroy(hhv_ctx* ctx);
 /* New search parameters for an existing context (par->device must be the context's device): what a process-wide
  * context that outlives one ViterbiRunner::alignment call needs (hh-suite_amd/dropin/hhviterbirunner_hip.cpp keeps the

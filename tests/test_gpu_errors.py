@@ -285,4 +285,6 @@ def test_packed_paths_errors_and_block_pool_reuse():
         free_b, total_b = torch.cuda.mem_get_info()
         used.append(total_b - free_b)
     assert used[-1] <= used[1], used                           # the blocks of the freed sets are reused, not added to
+    late = c.upload(list(tps), list(ttrs))
     c.close()
+    late.free()                                                # against the header's rule (sets first): must not touch the dead pool
