@@ -33,7 +33,8 @@ for N in 1 2 4 8; do
   timeout 900 python bench.py --gpus $N --lengths zipf --local 1 --steps 10 --warmup 3 $short --dump-topk $OUT/topk_zipf_ranks_$N.npy > $OUT/bench_zipf_$N.json 2> $OUT/bench_zipf_$N.err
   # the verdict of the lease, not only its times: the merged top-K of N RANKS must be the list ONE rank gets from the same N
   # shards run one after the other (--virtual-shards N: same hhv_shard_plan, same hhv_topk per shard, same hhv_merge_hits)
-  timeout 900 python bench.py --gpus 1 --virtual-shards $N --lengths zipf --local 1 --templates 125000 --steps 2 --warmup 1 $short --dump-topk $OUT/topk_zipf_virtual_$N.npy > $OUT/bench_zipf_virtual_$N.json 2> $OUT/bench_zipf_virtual_$N.err
+  PER_GPU=125000; [ $N -eq 1 ] && PER_GPU=100000   # bench.py's per-GPU default of the run above
+  timeout 900 python bench.py --gpus 1 --virtual-shards $N --lengths zipf --local 1 --templates $PER_GPU --steps 2 --warmup 1 $short --dump-topk $OUT/topk_zipf_virtual_$N.npy > $OUT/bench_zipf_virtual_$N.json 2> $OUT/bench_zipf_virtual_$N.err
   NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,P2P,NET timeout 900 ./build/sharded_search_rccl --world $N --templates $((20000 * N)) --steps 5 --check --json \
     > $OUT/native_$N.out 2> $OUT/native_$N.err
   NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,P2P,NET timeout 900 ./build/sharded_search_rccl --world $N --templates $((20000 * N)) --steps 5 --backtrace --json \
