@@ -77,6 +77,8 @@ size_t topk_temp_bytes(int n);
 void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t stream);
 int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit* d_out, uint64_t* keys, uint64_t* sorted,
                 void* temp, size_t temp_bytes, hipStream_t stream, std::string* err, const float* rank = nullptr);
+int topk_small_device(const DevHit* d_hits, const DevResult* d_results, int n, int k, const int32_t* gids, DevHit* d_out, hipStream_t stream,
+                      std::string* err, const float* rank);
 void topk_rank_pvalue(const DevHit* d_hits, int n, const int32_t* d_L, const float* d_neff, int Lq, float q_neff, int local, float* d_rank,
                       hipStream_t stream);
 int merge_hits_device(const DevHit* d_in, int m, int k, DevHit* d_out, int* d_n, hipStream_t stream, std::string* err);
@@ -224,12 +226,13 @@ int hhv_create(hhv_ctx** out, const hhv_params* par) {
     hhv_destroy(c);
     return fail(HHV_E_DEVICE, "hhv_create: stream/event creation failed");
   }
-  if (hipHostMalloc((void**)&c->h_err, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+  if (hipHostMalloc((void**)&c->h_err, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||  // [0] error word, [1] query upload done
       hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0) != hipSuccess) {
     hhv_destroy(c);
     return fail(HHV_E_DEVICE, "hhv_create: error word allocation failed");
   }
-  *c->h_err = 0;
+  c->h_err[0] = c->h_err[1] = 0;
+  if (const char* e = getenv("HHV_QUERY_COPY")) c->q_by_copy = atoi(e) == 1;
   // launch-policy defaults from the environment, read once per context (hhv_set_launch_policy overrides them)
   if (const char* e = getenv("HHV_PAIR")) c->pair_mode = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("HHV_PAIR_SWAP")) c->pair_swap = std::max(-1, std::min(31, atoi(e)));
@@ -290,9 +293,8 @@ void hhv_destroy(hhv_ctx* c) {
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
   }
   (void)hipSetDevice(c->par.device);
-  dfree(c->d_qpack);
+  dfree(c->d_qpack);  // (d_qp points into the same block)
   dfree(c->d_queue);
-  dfree(c->d_qp);
   dfree(c->d_lg2);
   dfree(c->d_diff);
   dfree(c->d_ss_table);
@@ -323,6 +325,22 @@ void hhv_destroy(hhv_ctx* c) {
   delete c;
 }
 
+}  // extern "C"
+// The staging block of hhv_set_query (pinned host memory, device-visible) -> the context's device block, by ONE workgroup; the same
+// launch sets the ticket counter of the stream kernel that follows (what a fill operation did) and, when everything has been read,
+// tells the host through a host-mapped word that the staging block is free again (what an event did: on the stream of a search
+// loop every event record and every copy / fill operation between two kernels costs 4 - 6 us, tools/trace10k.sh).
+__global__ void __launch_bounds__(1024) query_upload_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n4, uint32_t* __restrict__ queue,
+                                                            uint32_t queue_value, uint32_t* __restrict__ done_flag, uint32_t seq) {
+  for (int i = threadIdx.x; i < n4; i += 1024) dst[i] = src[i];
+  __syncthreads();  // (every thread's loads have returned: its stores depend on them)
+  if (threadIdx.x == 0) {
+    if (queue) *queue = queue_value;
+    __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+extern "C" {
+
 int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   if (!c || !p || !tr) return fail(HHV_E_ARG, "hhv_set_query: null argument");
   if (Lq < 1) return fail(HHV_E_ARG, "hhv_set_query: Lq = %d", Lq);
@@ -341,7 +359,17 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
   c->Lq = 0;  // no query until the new one is in place (a failure below must not leave the old geometry with freed buffers)
   c->ss_dirty = true;
   if (c->q_stage_busy) {
-    HIP_TRY(hipEventSynchronize(c->ev_q));
+    if (c->q_by_copy) {
+      HIP_TRY(hipEventSynchronize(c->ev_q));
+    } else {
+      // the upload kernel of the previous query reports through h_err[1] (a stream that makes no progress for seconds: the runtime's wait)
+      volatile uint32_t* flag = c->h_err + 1;
+      for (long spin = 0; *flag != c->q_seq; ++spin)
+        if (spin > 200000000L) {
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          break;
+        }
+    }
     c->q_stage_busy = false;
   }
   if (c->q_stage_bytes < stage_bytes) {
@@ -351,30 +379,37 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
     HIP_TRY(hipHostMalloc(&c->q_stage, stage_bytes, hipHostMallocDefault));
     c->q_stage_bytes = stage_bytes;
   }
-  if (c->qpack_cap < n_qpack) {
+  // ONE device block behind both arrays (the layout of the staging block), so that a query is one copy operation on the stream
+  if (c->qpack_cap < n_qpack + n_qp) {
     HIP_TRY(hipStreamSynchronize(c->stream));  // (a launch that still reads the old rows)
     dfree(c->d_qpack);
+    c->d_qp = nullptr;
     c->qpack_cap = 0;
-    HIP_TRY(hipMalloc(&c->d_qpack, n_qpack * sizeof(float)));
-    c->qpack_cap = n_qpack;
+    const size_t cap = n_qpack + n_qp + (n_qpack + n_qp) / 4;  // (a slightly longer query next time: no reallocation)
+    HIP_TRY(hipMalloc(&c->d_qpack, cap * sizeof(float)));
+    c->qpack_cap = cap;
   }
-  if (c->qp_cap < n_qp) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dfree(c->d_qp);
-    c->qp_cap = 0;
-    HIP_TRY(hipMalloc(&c->d_qp, n_qp * sizeof(float)));
-    c->qp_cap = n_qp;
-  }
+  c->d_qp = c->d_qpack + n_qpack;  // (n_qpack is a multiple of 64 * 28 floats: 16-byte aligned)
   float* const h_qpack = (float*)c->q_stage;
   float* const h_qp = h_qpack + n_qpack;
   memset(h_qpack, 0, n_qpack * sizeof(float));
   if (!pack_columns(p, tr, Lq, h_qpack))
     return fail(HHV_E_ARG, "hhv_set_query: negative profile value (profile values are probabilities)");
   memcpy(h_qp, p, n_qp * sizeof(float));
-  HIP_TRY(hipMemcpyAsync(c->d_qpack, h_qpack, n_qpack * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->d_qp, h_qp, n_qp * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipEventRecord(c->ev_q, c->stream));
-  c->q_stage_busy = true;
+  // The block reaches the device through a KERNEL that reads the pinned staging block over the bus (query_upload_kernel), not
+  // through a copy operation: on the stream of a search loop a copy sits between kernels, and the hand-over from the compute
+  // queue to the copy engine and back costs more than moving 58 KB does (10 000-template step, tools/trace10k.sh: 26 us between
+  // the merge kernel's end and the next launch with two hipMemcpyAsync).  The kernel is launched by the next hhv_align_async
+  // (flush_query: the only readers of the block are that launch and the hhv_hits behind it), together with the ticket counter.
+  // HHV_QUERY_COPY=1 (read when the context is created): the copy operation, at once.
+  c->q_n4 = (n_qpack + n_qp) / 4;  // (both counts are multiples of four floats)
+  if (c->q_by_copy) {
+    HIP_TRY(hipMemcpyAsync(c->d_qpack, h_qpack, (n_qpack + n_qp) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_q, c->stream));
+    c->q_stage_busy = true;
+  } else {
+    c->q_dirty = true;
+  }
   c->Lq = Lq;
   c->plan = plan;
   c->q_pred.clear();
@@ -861,6 +896,17 @@ static int ensure_bt(hhv_ctx* c, hhv_tset* ts) {
   return HHV_OK;
 }
 
+// hhv_set_query left the packed query in the pinned staging block: one launch moves it to the device (see there)
+static int flush_query(hhv_ctx* c, uint32_t* d_queue, uint32_t queue_value) {
+  c->q_seq += 1;
+  hipLaunchKernelGGL(query_upload_kernel, dim3(1), dim3(1024), 0, c->stream, (const float4*)c->q_stage, (float4*)c->d_qpack, (int)c->q_n4,
+                     d_queue, queue_value, c->d_err + 1, c->q_seq);
+  HIP_TRY(hipGetLastError());
+  c->q_dirty = false;
+  c->q_stage_busy = true;
+  return HHV_OK;
+}
+
 int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   if (!c || !ts) return fail(HHV_E_ARG, "hhv_align: null argument");
   if (ts->ctx != c) return fail(HHV_E_ARG, "hhv_align: template set belongs to another context");
@@ -956,30 +1002,51 @@ int hhv_align_async(hhv_ctx* c, hhv_tset* ts, uint32_t flags, void* d_out) {
   const bool pairs_forced = c->pair_mode == 1;
   a.pair_swap = c->pair_swap;
   a.err = c->d_err;
+  // the launch of the pass (or of the pair of passes) that starts at `pass`: pair workgroups (0 = a launch of its own), chain bits
+  auto geometry = [&](int pass, int* chain, int* n_wg) {
+    int pair_wgs = 0;
+    *chain = 0;
+    *n_wg = 0;
+    if (pairs_possible && pass + 1 < plan.P) {
+      *chain = (pass > 0 ? 1 : 0) | (pass + 2 < plan.P ? 2 : 0);
+      const bool wanted = pairs_forced || plan.P > 2 || bt || plan.R(0) == plan.R(1);
+      if (wanted) pair_wgs = pair_kernel_occupancy(plan.R(pass), plan.R(pass + 1), local, bt, *chain, ss);
+    }
+    if (pair_wgs > 0) {
+      // (pairs = two-wave arrays; the ...AndSS kernels have four of them per workgroup: whole workgroups, a pair beyond the last
+      // segment returns at once)
+      const int ppw = pair_kernel_pairs_per_workgroup(ss);
+      *n_wg = (std::max(1, std::min(c->num_cus * pair_wgs, ts->n_seg)) + ppw - 1) / ppw * ppw;
+    }
+    return pair_wgs;
+  };
+  // a query that is still in the staging block goes up now, and the same launch sets the first pass's ticket counter
+  bool queue_set = false;
+  if (c->q_dirty) {
+    int chain0 = 0, n_wg0 = 0;
+    const int pw0 = geometry(0, &chain0, &n_wg0);
+    const bool has_q = pw0 > 0 || queue;
+    rc = flush_query(c, has_q ? c->d_queue : nullptr, pw0 > 0 ? (uint32_t)n_wg0 : (uint32_t)(n_waves * arrays));
+    if (rc != HHV_OK) return rc;
+    queue_set = has_q;
+  }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int pass = 0; pass < plan.P;) {
     a.row_base = plan.base(pass);
     a.bt_plane = pass;
     a.qpack = c->d_qpack + (size_t)a.row_base * REC_DW;
     a.pass_first = pass == 0;
-    int pair_wgs = 0, chain = 0;
-    if (pairs_possible && pass + 1 < plan.P) {
-      chain = (pass > 0 ? 1 : 0) | (pass + 2 < plan.P ? 2 : 0);
-      const bool wanted = pairs_forced || plan.P > 2 || bt || plan.R(0) == plan.R(1);
-      if (wanted) pair_wgs = pair_kernel_occupancy(plan.R(pass), plan.R(pass + 1), local, bt, chain, ss);
-    }
+    int chain = 0, n_wg = 0;
+    const int pair_wgs = geometry(pass, &chain, &n_wg);
+    const bool set_here = !(pass == 0 && queue_set);  // (pass 0: flush_query may have set the counter)
     if (pair_wgs > 0) {
-      // (pairs = two-wave arrays; the ...AndSS kernels have four of them per workgroup: whole workgroups, a pair beyond the last
-      // segment returns at once)
-      const int ppw = pair_kernel_pairs_per_workgroup(ss);
-      const int n_wg = (std::max(1, std::min(c->num_cus * pair_wgs, ts->n_seg)) + ppw - 1) / ppw * ppw;
       a.pass_last = 0;  // (the kernel gives its two waves their own)
-      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // pair k starts with segment k
+      if (set_here) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_wg, 1, c->stream));  // pair k starts with segment k
       rc = launch_pair(plan.R(pass), plan.R(pass + 1), local, bt, chain, ss, a, n_wg, c->stream);
       pass += 2;
     } else {
       a.pass_last = pass == plan.P - 1;
-      if (queue) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves * arrays, 1, c->stream));  // array k starts with segment k
+      if (queue && set_here) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_queue, n_waves * arrays, 1, c->stream));  // array k starts with segment k
       rc = launch_stream(plan.W, plan.R(pass), local, bt, celloff, multi, ss, a, n_waves, c->stream);
       pass += 1;
     }
@@ -1429,27 +1496,33 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
     HIP_TRY(tmalloc(ts->ctx, &ts->d_topk, (size_t)k * sizeof(DevHit)));
     ts->topk_cap = k;
   }
-  if (!ts->d_keys) {
-    HIP_TRY(tmalloc(ts->ctx, &ts->d_keys, (size_t)ts->n * sizeof(uint64_t)));
-    HIP_TRY(tmalloc(ts->ctx, &ts->d_sorted, (size_t)ts->n * sizeof(uint64_t)));
-    ts->sort_temp_bytes = topk_temp_bytes(ts->n);
-    HIP_TRY(tmalloc(ts->ctx, &ts->d_sort_temp, ts->sort_temp_bytes));
-  }
-  const DevHit* src = ts->d_hits;
-  if (raw) {
-    if (!ts->d_raw_hits) HIP_TRY(tmalloc(ts->ctx, &ts->d_raw_hits, (size_t)ts->n * sizeof(DevHit)));
-    results_to_hits(ts->d_results, ts->n, ts->d_raw_hits, c->stream);
-    src = ts->d_raw_hits;
-  }
   DevHit* dst = d_out ? (DevHit*)d_out : ts->d_topk;
   std::string err;
   if (pval) {
     if (!ts->d_rank) HIP_TRY(tmalloc(ts->ctx, &ts->d_rank, (size_t)std::max(ts->n, 1) * sizeof(float)));
-    topk_rank_pvalue(src, ts->n, ts->d_L, ts->d_neff, c->Lq, ts->q_neff, c->par.local, ts->d_rank, c->stream);
+    topk_rank_pvalue(ts->d_hits, ts->n, ts->d_L, ts->d_neff, c->Lq, ts->q_neff, c->par.local, ts->d_rank, c->stream);
   }
-  if (topk_device(src, ts->n, kk, ts->d_gids, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
-                  &err, pval ? ts->d_rank : nullptr) != 0)
-    return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
+  // a small set: one launch, raw results read in place (no hit records built for the templates that are not selected)
+  const int small = topk_small_device(ts->d_hits, raw ? ts->d_results : nullptr, ts->n, kk, ts->d_gids, dst, c->stream, &err,
+                                      pval ? ts->d_rank : nullptr);
+  if (small < 0) return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
+  if (small > 0) {
+    if (!ts->d_keys) {
+      HIP_TRY(tmalloc(ts->ctx, &ts->d_keys, (size_t)ts->n * sizeof(uint64_t)));
+      HIP_TRY(tmalloc(ts->ctx, &ts->d_sorted, (size_t)ts->n * sizeof(uint64_t)));
+      ts->sort_temp_bytes = topk_temp_bytes(ts->n);
+      HIP_TRY(tmalloc(ts->ctx, &ts->d_sort_temp, ts->sort_temp_bytes));
+    }
+    const DevHit* src = ts->d_hits;
+    if (raw) {
+      if (!ts->d_raw_hits) HIP_TRY(tmalloc(ts->ctx, &ts->d_raw_hits, (size_t)ts->n * sizeof(DevHit)));
+      results_to_hits(ts->d_results, ts->n, ts->d_raw_hits, c->stream);
+      src = ts->d_raw_hits;
+    }
+    if (topk_device(src, ts->n, kk, ts->d_gids, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
+                    &err, pval ? ts->d_rank : nullptr) != 0)
+      return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
+  }
   if (kk < k) HIP_TRY(hipMemsetAsync(dst + kk, 0xFF, (size_t)(k - kk) * sizeof(DevHit), c->stream));
   if (out) {
     HIP_TRY(hipMemcpyAsync(out, dst, (size_t)k * sizeof(DevHit), hipMemcpyDeviceToHost, c->stream));
@@ -1480,8 +1553,6 @@ int hhv_tset_set_global_ids(hhv_ctx* c, hhv_tset* ts, const int32_t* ids) {
   if (!ids) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     tfree(ts->ctx, ts->d_gids);
-  tfree(ts->ctx, ts->d_neff);
-  tfree(ts->ctx, ts->d_rank);
     ts->d_gids = nullptr;
     return HHV_OK;
   }

@@ -92,12 +92,16 @@ struct hhv_ctx {
   hhv::StripPlan plan;
   float* d_qpack = nullptr;  // [plan.rows()][28]
   uint32_t* d_queue = nullptr;  // ticket counter of the stream kernel's work queue (set in front of each launch)
-  float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring
-  size_t qpack_cap = 0, qp_cap = 0;  // floats allocated behind d_qpack / d_qp (kept between queries)
+  float* d_qp = nullptr;     // [(Lq+1)][20] AoS, for the backtrace rescoring: behind the rows in the same device block
+  size_t qpack_cap = 0;      // floats allocated behind d_qpack (kept between queries)
   void* q_stage = nullptr;           // pinned staging block of hhv_set_query
   size_t q_stage_bytes = 0;
   hipEvent_t ev_q = nullptr;         // the last query's copies have left the staging block
   bool q_stage_busy = false;
+  bool q_dirty = false;              // the query is packed in the staging block, not yet on the device (flush_query, hhv_align_async)
+  bool q_by_copy = false;            // HHV_QUERY_COPY=1: hipMemcpyAsync + ev_q in hhv_set_query instead of the upload kernel
+  uint32_t q_seq = 0;                // number of upload kernels launched; the kernel writes it to h_err[1] when it has read the block
+  size_t q_n4 = 0;                   // float4s of the staged query (rows + AoS profile)
   // fast_log2 tables (src/util-inl.h:108-130)
   float* d_lg2 = nullptr;
   float* d_diff = nullptr;

@@ -32,7 +32,9 @@ def _expected(rec, k):
 
 
 @pytest.mark.parametrize("m,k,n_pad", [(500, 500, 0), (500, 500, 37), (4000, 500, 400), (4096, 1000, 0), (10000, 500, 1200),
-                                      (1, 5, 0), (3, 2, 3), (6000, 6000, 100)])
+                                      (1, 5, 0), (3, 2, 3), (6000, 6000, 100),
+                                      # at most 1024 records: the one-key-per-thread kernel (merge_hits_small_kernel)
+                                      (64, 64, 0), (65, 10, 3), (700, 500, 0), (1000, 700, 50), (1024, 1500, 10), (1025, 500, 0)])
 def test_merge_hits_equals_reference_order(m, k, n_pad):
     import torch
     from pyhhv import capi
@@ -96,7 +98,11 @@ def test_topk_reports_global_ids():
 
 
 @pytest.mark.parametrize("n,ks", [(4096, (1, 500)), (4097, (1, 7, 500, 1024)), (20000, (500, 1024, 1025, 3000)),
-                                  (70000, (1, 64, 500)), (300000, (500, 1024))])
+                                  (70000, (1, 64, 500)), (300000, (500, 1024)),
+                                  # one launch for n <= 16 384, K <= 1024 (topk_small_kernel): the candidate bound (K 1 .. 600) and
+                                  # its radix branch (K near 1024: more than 1024 keys above the bound), few keys per thread
+                                  (10000, (1, 2, 63, 64, 65, 500, 600, 1000, 1024)), (16384, (500, 900, 1024)), (16385, (500,)),
+                                  (1500, (1, 1000, 1024, 1400)), (100, (1, 64, 100)), (1024, (1024,))])
 def test_topk_selection_equals_a_full_sort(n, ks):
     """hhv_topk selects (chunks of 16 384 keys radix-selected in registers, levels until 4096 keys are left, one bitonic
     sort) instead of sorting everything: every path - final sort only (n <= 4096), one level, two levels (300 000 x 1024),
@@ -123,3 +129,19 @@ def test_topk_selection_equals_a_full_sort(n, ks):
     # fewer templates than K: all of them, the rest padding
     ts.free()
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_topk_small_set_switches(mode):
+    """HHV_TOPK_SMALL = 0 (the multi-launch path of round 4) and = 2 (the one-launch kernel forced through its radix branch)
+    give the records of the default path: the selection test above in a process of its own, the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HHV_TOPK_SMALL=mode)
+    sel = "tests/test_gpu_merge.py::test_topk_selection_equals_a_full_sort"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", sel, "tests/test_gpu_merge.py::test_merge_hits_equals_reference_order",
+                        "-k", "10000 or 1500 or 4096 or 700 or 500"],
+                       cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
