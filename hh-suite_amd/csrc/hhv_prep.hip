@@ -307,6 +307,14 @@ constexpr int PREP_TAB = 1028;
 // profile transposed in LDS and step 2 reading 16 bytes at a time was bit-exact and SLOWER, 3.02 ms: the 32 registers of the
 // prefetch push the kernel past the 128 of four waves per SIMD (36 spilled), and step 2 stayed at ~100 clocks a column - it is issue
 // arbitration, not LDS latency.  profiles/r6_prep_steps.txt.)
+// (Last session of round 6, three more probes, A/B in one call each.  (a) The templates' ids / offsets and the raw column of a wave's
+// first chunk requested BEFORE the tables are staged, so that the HBM latency runs under the staging - bit-exact, 2.74 ms against
+// 2.51: slower, reproducibly.  (b) The tables' seven loads per thread sent at once instead of load - wait - write rounds: 2.50 = 2.51.
+// (c) Step 2 cut to 16 columns (wrong sums, timing only): 2.46 against 2.59 in that call - the lone chain wave that a quarter of the
+// timing build's clocks point at is worth 5 %, the other resident workgroup fills the CU meanwhile.  What the kernel costs is its
+// instruction mix: ~1 490 vector instructions per column and lane, of them 780 packed fp32 at ~4.4 clocks and ~250 fp64 / division
+// steps - about 1.1 ms of issue at 16 waves per CU - plus 0.9-1.15 ms of HBM time that the two resident workgroups overlap only
+// partly (2.5 ms ~ the sum).  NOTES_r6.md section 10.)
 #ifdef HHV_PREP_TIMING
 // measurement build (make lib_variant NAME=pt FLAGS=-DHHV_PREP_TIMING): clocks every wavefront spends in the steps of the fused kernel
 // and at its barriers, summed per wave index: [wave][0 tables, 1 step 1, 2 barrier, 3 step 2, 4 barrier, 5 step 3], [wave][7] = count

@@ -179,8 +179,13 @@ int hhv_set_launch_policy(hhv_ctx* ctx, int32_t pair_mode, int32_t pair_swap, in
 int hhv_check_error(hhv_ctx* ctx);
 
 /* query: p[(Lq+1)*20], tr[(Lq+1)*7] (copied before the call returns: the caller may reuse its arrays at once).
- * The rows travel through a pinned staging block with asynchronous copies on the context's stream; device buffers and
- * staging are kept between queries, so a loop that sets one query per search does not wait for the device. */
+ * The call packs the rows into a pinned staging block; the next hhv_align / hhv_align_async moves the block to the device with
+ * one kernel on the context's stream (no copy operation, no event: on the stream of a search loop each of those costs more than
+ * the 58 KB do).  Device block and staging are kept between queries, and the call waits only for the PREVIOUS query's upload
+ * kernel, so a loop that sets one query per search does not wait for the device.  Setting a second query before any alignment
+ * replaces the first; hhv_hits behind an alignment works with the query of that alignment even if the next one - of the same
+ * length: another length is refused with HHV_E_STATE - has been set.  HHV_QUERY_COPY=1 in the environment
+ * of hhv_create: hipMemcpyAsync + event at once, as in the earlier rounds. */
 int hhv_set_query(hhv_ctx* ctx, const float* p, const float* tr, int32_t Lq);
 
 /* secondary structure (all optional; without them the engine runs the reference's no-SS kernels).
