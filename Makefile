@@ -98,7 +98,7 @@ clean:
 	$(MAKE) -C oracle clean
 
 PHONY_EXTRA := rccl_runner
-.PHONY: example example_rccl rccl_runner all lib lib_fma lib_pto lib_variant oracle emul clean
+.PHONY: topk_fuzz example example_rccl rccl_runner all lib lib_fma lib_pto lib_variant oracle emul clean
 
 # plain-C++ use of the host classes (no Python): examples/search_example.cpp
 example: $(RUNNER)
@@ -116,3 +116,10 @@ example_rccl: build/sharded_search_rccl
 build/sharded_search_rccl: examples/sharded_search_rccl.cpp examples/synth8d.h include/hhviterbi_hip.h $(RCCL_RUNNER)
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wall -Iinclude -o build/sharded_search_rccl examples/sharded_search_rccl.cpp -L$(LIBDIR) -lhhv_rccl_runner -lhhviterbi_hip -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+# TEST program: the one-launch top-K / merge kernels of hhv_topk.hip on their own - timing of the phases and a fuzzer against
+# std::sort (tools/topk_ubench.hip, tests/test_gpu_topk_fuzz.py); includes the kernel source, links nothing of the product
+topk_fuzz: build/topk_ubench
+build/topk_ubench: tools/topk_ubench.hip $(CSRC)/hhv_topk.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -DHHV_TOPK_TIMING -Wno-unused-value -I$(CSRC) -Iinclude -o $@ tools/topk_ubench.hip

@@ -86,6 +86,7 @@ struct hhv_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  bool ev_records = true;   // HHV_EVENT_RECORDS=0: the DP's events attached to the launches (hipExtLaunchKernel) instead of recorded on the stream
   int num_cus = 0;
   // query: plan.P passes of 64 * plan.R(p) rows (one pass up to Lq = 320)
   int Lq = 0;

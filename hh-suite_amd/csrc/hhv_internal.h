@@ -331,13 +331,15 @@ int launch_mac(const MacArgs& a, bool local, const MacClasses& cls, void* stream
 
 // launchers implemented in hhv_kernels.hip
 // W = lanes per systolic array (64, 32, 16): W < 64 variants exist for single-pass queries only (multi = false)
-int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream);
+int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves, void* stream,
+                  void* ev_start = nullptr, void* ev_stop = nullptr);
 int stream_kernel_occupancy(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, int* blocks_per_cu, int* vgprs);
 int stream_kernel_waves(int W, bool ss);  // wavefronts per workgroup of the kernel launch_stream starts (8 for hhv_ss_kernel)
 // per-W instantiation units (hhv_kernels.hip: 64, hhv_kernels_w32.hip, hhv_kernels_w16.hip)
 void* stream_kernel_w64(int R, bool local, bool bt, bool celloff, bool multi, bool ss, bool first_strip);
 // two-strip queries as one launch of two-wave workgroups (hhv_kernels_pair.hip)
-int launch_pair(int R0, int R1, bool local, bool bt, int chain, bool ss, const StreamArgs& a, int n_pairs, void* stream);
+int launch_pair(int R0, int R1, bool local, bool bt, int chain, bool ss, const StreamArgs& a, int n_pairs, void* stream, void* ev_start = nullptr,
+                void* ev_stop = nullptr);
 int pair_kernel_pairs_per_workgroup(bool ss);
 int pair_kernel_occupancy(int R0, int R1, bool local, bool bt, int chain, bool ss);  // pairs (two-wave arrays) per CU, 0 = no such kernel
 void* stream_kernel_w32(int R, bool local, bool bt, bool celloff, bool ss);

@@ -14,6 +14,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (fp contraction would change results).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "hhv_internal.h"
 #include "hhv_stream_kernel.h"
@@ -476,8 +477,10 @@ static void* pick(int W, int R, bool local, bool bt, bool celloff, bool multi, b
   return nullptr;
 }
 
+// ev_start / ev_stop (hipEvent_t or null): attached to the kernel's own dispatch (hipExtLaunchKernel) - its begin and end time stamps,
+// without the barrier packets of hipEventRecord in front of and behind the launch (5 - 6 us each between two kernels of a stream)
 int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, bool ss, const StreamArgs& a, int n_waves,
-                  void* stream) {
+                  void* stream, void* ev_start, void* ev_stop) {
   // (the first strip of a multi-strip plan has a kernel of its own: no code of the later strips in its steps)
   void* fn = pick(W, R, local, bt, celloff, multi, ss, multi && a.pass_first != 0);
   if (!fn) return -1;
@@ -485,8 +488,9 @@ int launch_stream(int W, int R, bool local, bool bt, bool celloff, bool multi, b
   void* kargs[] = {&args};
   // (the 64-lane secondary-structure variants are workgroups of SS_WAVES wavefronts sharing one LDS table: hhv_ss_kernel)
   const bool wide = ss && W == LANES;
-  hipError_t e = hipLaunchKernel(fn, dim3(wide ? (n_waves + SS_WAVES - 1) / SS_WAVES : n_waves), dim3(wide ? SS_WAVES * LANES : LANES), kargs, 0,
-                                 (hipStream_t)stream);
+  const dim3 grid(wide ? (n_waves + SS_WAVES - 1) / SS_WAVES : n_waves), block(wide ? SS_WAVES * LANES : LANES);
+  hipError_t e = (ev_start || ev_stop) ? hipExtLaunchKernel(fn, grid, block, kargs, 0, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0)
+                                       : hipLaunchKernel(fn, grid, block, kargs, 0, (hipStream_t)stream);
   return e == hipSuccess ? 0 : -(int)e;
 }
 

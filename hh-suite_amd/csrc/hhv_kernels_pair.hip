@@ -51,13 +51,16 @@ void* pair_kernel(int R0, int R1, bool local, bool bt, int chain, bool ss) {
 }
 
 // n_pairs: two-wave systolic arrays to start (ss: four of them per workgroup - hhv_ss_pair_kernel; the caller rounds up)
-int launch_pair(int R0, int R1, bool local, bool bt, int chain, bool ss, const StreamArgs& a, int n_pairs, void* stream) {
+int launch_pair(int R0, int R1, bool local, bool bt, int chain, bool ss, const StreamArgs& a, int n_pairs, void* stream, void* ev_start,
+                void* ev_stop) {
   void* fn = pair_kernel(R0, R1, local, bt, chain, ss);
   if (!fn) return -1;
   StreamArgs args = a;
   void* kargs[] = {&args};
-  const hipError_t e = ss ? hipLaunchKernel(fn, dim3((n_pairs + SS_PAIRS - 1) / SS_PAIRS), dim3(SS_WAVES * LANES), kargs, 0, (hipStream_t)stream)
-                          : hipLaunchKernel(fn, dim3(n_pairs), dim3(2 * LANES), kargs, 0, (hipStream_t)stream);
+  const dim3 grid(ss ? (n_pairs + SS_PAIRS - 1) / SS_PAIRS : n_pairs), block(ss ? SS_WAVES * LANES : 2 * LANES);
+  // (events on the kernel's own dispatch: launch_stream)
+  const hipError_t e = (ev_start || ev_stop) ? hipExtLaunchKernel(fn, grid, block, kargs, 0, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0)
+                                             : hipLaunchKernel(fn, grid, block, kargs, 0, (hipStream_t)stream);
   return e == hipSuccess ? 0 : -(int)e;
 }
 int pair_kernel_pairs_per_workgroup(bool ss) { return ss ? SS_PAIRS : 1; }
