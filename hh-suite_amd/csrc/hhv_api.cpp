@@ -76,7 +76,8 @@ namespace hhv {
 size_t topk_temp_bytes(int n);
 void results_to_hits(const DevResult* d_res, int n, DevHit* d_hits, hipStream_t stream);
 int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit* d_out, uint64_t* keys, uint64_t* sorted,
-                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err, const float* rank = nullptr);
+                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err, const float* rank, const DevResult* d_results);
+bool topk_small_enabled();  // HHV_TOPK_SMALL != 0
 int topk_small_device(const DevHit* d_hits, const DevResult* d_results, int n, int k, const int32_t* gids, DevHit* d_out, hipStream_t stream,
                       std::string* err, const float* rank);
 void topk_rank_pvalue(const DevHit* d_hits, int n, const int32_t* d_L, const float* d_neff, int Lq, float q_neff, int local, float* d_rank,
@@ -1531,13 +1532,15 @@ int hhv_topk(hhv_ctx* c, hhv_tset* ts, int32_t k, uint32_t flags, hhv_hit* out, 
       HIP_TRY(tmalloc(ts->ctx, &ts->d_sort_temp, ts->sort_temp_bytes));
     }
     const DevHit* src = ts->d_hits;
-    if (raw) {
+    // score-only results: read in place by the selection (K <= 1024); only the full sort of a larger K works on hit records
+    const bool in_place = raw && kk <= 1024 && topk_small_enabled();
+    if (raw && !in_place) {
       if (!ts->d_raw_hits) HIP_TRY(tmalloc(ts->ctx, &ts->d_raw_hits, (size_t)ts->n * sizeof(DevHit)));
       results_to_hits(ts->d_results, ts->n, ts->d_raw_hits, c->stream);
       src = ts->d_raw_hits;
     }
     if (topk_device(src, ts->n, kk, ts->d_gids, dst, ts->d_keys, ts->d_sorted, ts->d_sort_temp, ts->sort_temp_bytes, c->stream,
-                    &err, pval ? ts->d_rank : nullptr) != 0)
+                    &err, pval ? ts->d_rank : nullptr, in_place ? ts->d_results : nullptr) != 0)
       return fail(HHV_E_DEVICE, "hhv_topk: %s", err.c_str());
   }
   if (kk < k) HIP_TRY(hipMemsetAsync(dst + kk, 0xFF, (size_t)(k - kk) * sizeof(DevHit), c->stream));

@@ -102,9 +102,13 @@ __device__ __forceinline__ uint64_t radix_select_threshold(const uint64_t (&key)
 }
 
 // rank: the ranking key of every hit when it is not Hit.score (hhv_topk with HHV_TOPK_PVALUE), else null
-template <bool FROM_HITS>
+// SRC: SEL_KEYS = the keys a level before wrote, SEL_HITS = hit records (with `rank`), SEL_RESULTS = the DP kernel's result records
+// (HHV_TOPK_RAW: `hits` points at them - no hit record is built for a template that is not selected)
+enum { SEL_KEYS = 0, SEL_HITS = 1, SEL_RESULTS = 2 };
+template <int SRC>
 __global__ void __launch_bounds__(SEL_THREADS) topk_select_kernel(const DevHit* __restrict__ hits, const uint64_t* __restrict__ in_keys,
                                                                   int n, int k, uint64_t* __restrict__ out_keys, const float* __restrict__ rank) {
+  constexpr bool FROM_HITS = SRC != SEL_KEYS;
   __shared__ SelShared sh;
   __shared__ uint32_t sh_valid, sh_out;
   const int base = blockIdx.x * SEL_CHUNK;
@@ -116,7 +120,9 @@ __global__ void __launch_bounds__(SEL_THREADS) topk_select_kernel(const DevHit* 
 #pragma unroll
     for (int e = 0; e < SEL_PER_THREAD; ++e) {
       const int i = min(base + e * SEL_THREADS + (int)threadIdx.x, n - 1);  // coalesced
-      if (FROM_HITS)
+      if (SRC == SEL_RESULTS)
+        sc[e] = reinterpret_cast<const DevResult*>(hits)[i].score;
+      else if (SRC == SEL_HITS)
         sc[e] = rank ? rank[i] : hits[i].score;
       else
         key[e] = in_keys[i];
@@ -271,9 +277,11 @@ __device__ __forceinline__ int candidate_scan(const uint64_t (&key)[SEL_PER_THRE
   return base + incl - c;
 }
 
-template <int SRC>
+// KEYS_IN: the last level of a large set - n keys a selection level wrote (0 = padding), the records gathered from `src`
+template <int SRC, bool KEYS_IN = false>
 __global__ void __launch_bounds__(SEL_THREADS) topk_small_kernel(const void* __restrict__ src, const float* __restrict__ rank, int n, int k,
-                                                                 const int32_t* __restrict__ gids, DevHit* __restrict__ out, int force_radix) {
+                                                                 const int32_t* __restrict__ gids, DevHit* __restrict__ out, int force_radix,
+                                                                 const uint64_t* __restrict__ in_keys = nullptr) {
   __shared__ SelShared sh;
   __shared__ SortLds sl;
   __shared__ uint64_t cand[SEL_THREADS];
@@ -284,7 +292,13 @@ __global__ void __launch_bounds__(SEL_THREADS) topk_small_kernel(const void* __r
   const int t = (int)threadIdx.x;
   TOPK_T(0)
   uint64_t key[SEL_PER_THREAD];
-  {
+  if (KEYS_IN) {
+#pragma unroll
+    for (int e = 0; e < SEL_PER_THREAD; ++e) key[e] = in_keys[min(e * SEL_THREADS + t, n - 1)];
+#pragma unroll
+    for (int e = 0; e < SEL_PER_THREAD; ++e)
+      if (e * SEL_THREADS + t >= n) key[e] = 0;
+  } else {
     // (all loads first, from an index clamped into the array: a load under `if (i < n)` waits for its own data before the next is sent)
     float sc[SEL_PER_THREAD];
 #pragma unroll
@@ -704,30 +718,49 @@ int topk_small_device(const DevHit* d_hits, const DevResult* d_results, int n, i
   return 0;
 }
 
+bool topk_small_enabled() {
+  const char* e = getenv("HHV_TOPK_SMALL");
+  return !(e && atoi(e) == 0);
+}
+
 // keys/sorted: n uint64 each, temp: topk_temp_bytes(n) (used by the full-sort path only).  Asynchronous on `stream`; k <= n.
+// d_results != null (HHV_TOPK_RAW, k <= SEL_KMAX): the selection reads the DP kernel's result records in place, d_hits is not used.
 int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit* d_out, uint64_t* keys, uint64_t* sorted,
-                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err, const float* rank) {
+                void* temp, size_t temp_bytes, hipStream_t stream, std::string* err, const float* rank, const DevResult* d_results) {
   const int threads = 256;
   hipError_t e = hipSuccess;
-  if (n <= SORT_MAX) {
+  static const bool small_off = [] {
+    const char* ev = getenv("HHV_TOPK_SMALL");
+    return ev && atoi(ev) == 0;
+  }();
+  if (n <= SORT_MAX && !d_results) {
     hipLaunchKernelGGL(topk_final_kernel<true>, dim3(1), dim3(1024), 0, stream, d_hits, (const uint64_t*)nullptr, n, k, gids, d_out, rank);
   } else if (k <= SEL_KMAX) {
-    // levels of selection: n keys -> chunks x k -> ... -> at most SORT_MAX, the buffers used in turn
+    // levels of selection: n keys -> chunks x k -> ... until one workgroup can finish (at most SEL_CHUNK keys for the one-key-per-
+    // thread kernel, SORT_MAX for the LDS network of round 4 - HHV_TOPK_SMALL=0), the buffers used in turn
+    const int last_max = (small_off && !d_results) ? SORT_MAX : SEL_CHUNK;
     int m = n;
     uint64_t* buf[2] = {keys, sorted};
     int cur = 0;
     const uint64_t* src = nullptr;
-    while (m > SORT_MAX) {
+    while (m > last_max || src == nullptr) {
       const int chunks = (m + SEL_CHUNK - 1) / SEL_CHUNK;
-      if (src == nullptr)
-        hipLaunchKernelGGL(topk_select_kernel<true>, dim3(chunks), dim3(SEL_THREADS), 0, stream, d_hits, (const uint64_t*)nullptr, m, k, buf[cur], rank);
+      if (src == nullptr && d_results)
+        hipLaunchKernelGGL(topk_select_kernel<SEL_RESULTS>, dim3(chunks), dim3(SEL_THREADS), 0, stream, (const DevHit*)d_results, (const uint64_t*)nullptr, m, k, buf[cur], (const float*)nullptr);
+      else if (src == nullptr)
+        hipLaunchKernelGGL(topk_select_kernel<SEL_HITS>, dim3(chunks), dim3(SEL_THREADS), 0, stream, d_hits, (const uint64_t*)nullptr, m, k, buf[cur], rank);
       else
-        hipLaunchKernelGGL(topk_select_kernel<false>, dim3(chunks), dim3(SEL_THREADS), 0, stream, (const DevHit*)nullptr, src, m, k, buf[cur], (const float*)nullptr);
+        hipLaunchKernelGGL(topk_select_kernel<SEL_KEYS>, dim3(chunks), dim3(SEL_THREADS), 0, stream, (const DevHit*)nullptr, src, m, k, buf[cur], (const float*)nullptr);
       src = buf[cur];
       cur ^= 1;
       m = chunks * k;
     }
-    hipLaunchKernelGGL(topk_final_kernel<false>, dim3(1), dim3(1024), 0, stream, d_hits, src, m, k, gids, d_out, (const float*)nullptr);
+    if (d_results)
+      hipLaunchKernelGGL((topk_small_kernel<SRC_RESULTS, true>), dim3(1), dim3(SEL_THREADS), 0, stream, (const void*)d_results, (const float*)nullptr, m, k, gids, d_out, 0, src);
+    else if (!small_off)
+      hipLaunchKernelGGL((topk_small_kernel<SRC_HITS, true>), dim3(1), dim3(SEL_THREADS), 0, stream, (const void*)d_hits, (const float*)nullptr, m, k, gids, d_out, 0, src);
+    else
+      hipLaunchKernelGGL(topk_final_kernel<false>, dim3(1), dim3(1024), 0, stream, d_hits, src, m, k, gids, d_out, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL(topk_keys_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, d_hits, n, keys, rank);
     e = hipcub::DeviceRadixSort::SortKeysDescending(temp, temp_bytes, keys, sorted, n, 0, 64, stream);
