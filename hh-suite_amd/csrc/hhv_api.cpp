@@ -376,11 +376,15 @@ int hhv_set_query(hhv_ctx* c, const float* p, const float* tr, int32_t Lq) {
     } else {
       // the upload kernel of the previous query reports through h_err[1] (a stream that makes no progress for seconds: the runtime's wait)
       volatile uint32_t* flag = c->h_err + 1;
-      for (long spin = 0; *flag != c->q_seq; ++spin)
-        if (spin > 200000000L) {
+      for (long spin = 0; *flag != c->q_seq; ++spin) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if (spin > 100000000L) {
           HIP_TRY(hipStreamSynchronize(c->stream));
           break;
         }
+      }
     }
     c->q_stage_busy = false;
   }
