@@ -461,17 +461,28 @@ def main():
     if single and not args.no_configs1 and n >= 10000 and plain:
         # BASELINE configs[1]: the same query vs the first 10k templates of the resident stream
         ts10 = ctx.adopt_device_stream(np.full(10000, Lt, dtype=np.int32), rec.data_ptr())
-        for _ in range(2):
-            ctx.align_async(ts10)
-        ctx.sync()
-        t1 = time.perf_counter()
-        reps = 20                   # (a launch that follows an idle device runs ~0.2 ms longer, tools/SESSIONS.md call 43:
-        for _ in range(reps):       #  twenty searches back to back, nothing waited for in between, like the headline loop)
+        ctx.set_global_ids(ts10, np.arange(10000, dtype=np.int32))
+        buf10 = torch.zeros((2 * K, shard.REC_I32), dtype=torch.int32, device=device)
+
+        def step10():   # the headline's step on the smaller set: query H2D, DP, top-K, merge of the rank's own list
             ctx.set_query(qf, qtr)
             ctx.align_async(ts10)
+            ctx.topk(ts10, K, d_out=buf10.data_ptr(), fetch=False, raw=True)
+            ctx.merge_hits(buf10.data_ptr(), K, K, d_out=buf10[K:].data_ptr(), fetch=False, count=False)
+
+        for _ in range(5):
+            step10()
+        ctx.sync()
+        t1 = time.perf_counter()
+        reps = 100                  # (a launch that follows an idle device runs ~0.2 ms longer, tools/SESSIONS.md call 43:
+        k10 = []                    #  a hundred searches back to back, nothing waited for in between, like the headline loop)
+        for _ in range(reps):
+            step10()
+            k10.append(ctx.last_kernel_ms())   # (waits for the DP kernel's end event only: the top-K and the merge are still queued)
         ctx.sync()
         d10 = time.perf_counter() - t1
-        out["configs1_10k_templates"] = {"cells_per_s": 10000 * Lq * Lt * reps / d10, "kernel_ms": ctx.last_kernel_ms()}
+        out["configs1_10k_templates"] = {"cells_per_s": 10000 * Lq * Lt * reps / d10, "ms_per_step": d10 / reps * 1e3, "kernel_ms": float(np.mean(k10)),
+                                         "steps": reps, "step": "as the headline's: hhv_set_query + hhv_align_async + hhv_topk + hhv_merge_hits"}
         ts10.free()
 
     if single and not args.no_cpu_baseline:   # the contract: rank 0 at N = 1 only
@@ -865,7 +876,7 @@ def next_rows():
             a = r["altali1"]
             out["dropin_ViterbiRunner_alignment"] = {"templates": r["n_templates"], "Lq": r["L"], "Lt": r["L"], "host_threads": r["threads"],
                                                      "reference_s": a["reference_s"], "dropin_cold_cache_s": a["dropin_cold_cache_s"],
-                                                     "dropin_warm_cache_s": a["dropin_warm_cache_s"], "hits_identical": a["hits_identical"],
+                                                     "dropin_warm_cache_s": a["dropin_warm_cache_s"], "dropin_warm_calls_s": a.get("dropin_warm_calls_s"), "hits_identical": a["hits_identical"],
                                                      "cold_phases_ms": a.get("cold_phases_ms"), "warm_phases_ms": a.get("warm_phases_ms"),
                                                      "note": "cold = first call of the process: every template's HHM text parsed by the host's HMM::Read, as in the "
                                                              "reference ('read+parse'), context creation and the first launches' code-object loads included; warm = "

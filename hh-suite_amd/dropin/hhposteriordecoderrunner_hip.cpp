@@ -244,7 +244,10 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
   hhv_ctx* ctx = tc.slots[0].ctx;  // the realign stage works on the primary device
   if (n_read < n_groups) {
     // PrepareTemplateHMM on the device (hhv_prepare_subset), one launch per raw set, and the prepared records back in one copy
-    const hhv_prep_params prep = hhv_dropin::prepare_params(par, pb, R);
+    // against the background the cached templates were read with (their files' NULL line, hhv_template_cache.h null_pb) - the
+    // reference reads every template again here and HMM::Read puts that line into pb right before PrepareTemplateHMM (:98-99); the
+    // caller's pb may hold the COMPO line of an HMMER-format template the Viterbi stage read last
+    const hhv_prep_params prep = hhv_dropin::prepare_params(par, tc.null_pb_set ? tc.null_pb : pb, R);
     std::map<hhv_rawset*, std::vector<int> > by_raw;
     for (int g = 0; g < n_groups; ++g)
       if (cached[g]) by_raw[cached[g]->raw].push_back(g);
@@ -492,5 +495,8 @@ void PosteriorDecoderRunner::executeComputation(HMM& q, std::vector<Hit*> hits, 
     hits[i]->alt_i->clear();
     hits[i]->alt_j->clear();
   }
+  // the caller's pb as the reference leaves it with one thread: the background of the template it read last - the last group (a
+  // cached one is not read here; a group that was read has left its own)
+  if (n_groups > 0 && cached[n_groups - 1] && tc.null_pb_set) memcpy(pb, tc.null_pb, sizeof(tc.null_pb));
   if (use_cache) tc.active--;  // (the device lock is still held)
 }

@@ -101,8 +101,15 @@ struct TemplateCache {
   // ... and what reading a template from an ALIGNMENT depends on (HHEntry::getTemplateHMM, src/hhdatabase.cpp:299-460): a
   // change empties the cache like a change of nseqdis does
   uint64_t read_param_hash;
+  // The background every cached template was read with: HMM::Read overwrites the process-wide `pb` with the NULL line of the file
+  // it reads (src/hhhmm.cpp, "NULL" record), and PrepareTemplateHMM runs right behind the read - a template is prepared against ITS
+  // OWN file's background, whatever an HMMER-format file read before it (ReadHMMer3 stores the COMPO line in pb, :1399-1404) left
+  // there.  Only templates whose NULL line equals this one are cached, and cached templates are always prepared against it - not
+  // against whatever the caller's pb holds when the stage starts.
+  float null_pb[20];
+  bool null_pb_set;
   TemplateCache() : calls(0), active(0), enabled(true), max_columns(0), columns(0), nseqdis(-1), ssm(-1), q_has_pred(-1),
-                    q_has_dssp(-1), read_param_hash(0) {
+                    q_has_dssp(-1), read_param_hash(0), null_pb_set(false) {
     const char* e = getenv("HHV_TEMPLATE_CACHE");
     enabled = !(e && atoi(e) == 0);
     const char* g = getenv("HHV_TEMPLATE_CACHE_GB");
@@ -121,6 +128,7 @@ struct TemplateCache {
       slots[d].columns = 0;
     }
     columns = 0;
+    null_pb_set = false;
   }
 };
 

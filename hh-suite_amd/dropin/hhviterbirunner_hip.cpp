@@ -268,6 +268,7 @@ struct ResidentTemplate {
   int ss_pair_mode;
   size_t first_hit;     // index of its first-round Hit in the result vector (source of the template information)
   const SsRecords* ss;  // in the cache entry or in `own_ss`
+  bool raw;             // prepared on the device from raw columns (background pb0), not by the host's PrepareTemplateHMM
 };
 
 const int kCacheToEnum[7] = {4 /*I2I*/, 1 /*M2I*/, 0 /*M2M*/, 2 /*M2D*/, 5 /*D2M*/, 6 /*D2D*/, 3 /*I2M*/};
@@ -573,9 +574,14 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
 
   bool device_prepare = tc.enabled && hhv_dropin::device_prepare_covers(par);
   const bool use_sidecar = device_prepare && hhv_dropin::sidecar_enabled();
-  float pb0[20];  // the background the caller hands in; HMM::Read overwrites pb with the NULL line of every file it reads
+  // The background raw (device-prepared) templates are prepared against.  HMM::Read overwrites pb with the NULL line of every file it
+  // reads, ReadHMMer / ReadHMMer3 with the file's NULE / COMPO line, and PrepareTemplateHMM follows the read: every template meets
+  // its own file's background.  A template is taken raw when that background is the cache's (hhv_template_cache.h null_pb; the
+  // caller's pb when the cache is empty) - the others are prepared by the host with theirs.  (Until the last session of round 6
+  // this was the caller's pb at entry: after a search that had read an HMMER-format template last, cached templates were prepared
+  // against that file's COMPO line - tests/test_dropin_apps.py::test_hhsearch_database_with_hmmer3_templates.)
+  float pb0[20];
   memcpy(pb0, pb, sizeof(pb0));
-  hhv_prep_params prep = hhv_dropin::prepare_params(par, pb0, R);
 
   // scratch HMMs, one per thread (the reference keeps VECSIZE_FLOAT per thread, :84-95), allocated when a template
   // has to be read
@@ -605,8 +611,12 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         device_prepare = false;  // a concurrent search of another kind is using the cache: this one prepares on the host
       }
     }
-    if (device_prepare) tc.active++;
+    if (device_prepare) {
+      tc.active++;
+      if (tc.null_pb_set) memcpy(pb0, tc.null_pb, sizeof(pb0));
+    }
   }
+  hhv_prep_params prep = hhv_dropin::prepare_params(par, pb0, R);
 
   for (int alignment = 0; alignment < par.altali; alignment++) {
     HH_LOG(INFO) << "Alternative alignment: " << alignment << std::endl;
@@ -855,6 +865,10 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
               }
               for (size_t u = 0; u < uploads.size(); ++u) uploads[u].join();
               tc.columns += cols;
+              if (!tc.null_pb_set) {  // (every raw template of this search was read with pb0, see h.raw)
+                memcpy(tc.null_pb, pb0, sizeof(tc.null_pb));
+                tc.null_pb_set = true;
+              }
               std::vector<CachedTemplate*> slot(n);
               // the same key twice in one chunk (an entry listed twice): both x share ONE CachedTemplate; the later upload
               // owns it and only that x fills it below (two fills would race on ct.proto under the parallel loop)
@@ -921,7 +935,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
                 ss->conf.swap(h.ss.conf);
                 ss->dssp.swap(h.ss.dssp);
                 own_ss.push_back(ss);
-                ResidentTemplate rt = {set, 0, (int32_t)x, h.L, h.ss_pair_mode, first_hit_of_block + c0 + prep_k[x], ss};
+                ResidentTemplate rt = {set, 0, (int32_t)x, h.L, h.ss_pair_mode, first_hit_of_block + c0 + prep_k[x], ss, false};
                 resident[ent[prep_k[x]]] = rt;
               }
             }
@@ -961,7 +975,7 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
               for (size_t x = 0; x < mem.size(); ++x) {
                 const unsigned int k = mem[x];
                 const CachedTemplate* ct = cached[k];
-                ResidentTemplate rt = {set, ct->dev, (int32_t)x, ct->L, ct->ss_pair_mode, first_hit_of_block + c0 + k, &ct->ss};
+                ResidentTemplate rt = {set, ct->dev, (int32_t)x, ct->L, ct->ss_pair_mode, first_hit_of_block + c0 + k, &ct->ss, true};
                 resident[ent[k]] = rt;
               }
             }
@@ -983,6 +997,11 @@ std::vector<Hit> ViterbiRunner::alignment(Parameters& par, HMMSimd* q_simd, std:
         // ---- the ss mode of every SIMD batch of the reference (:14-22), then one launch per (set, mode) ----
         std::vector<const ResidentTemplate*> rt(cn);  // one table lookup per template and round
         for (unsigned int k = 0; k < cn; ++k) rt[k] = &resident[ent[k]];
+        // The caller's pb as the reference leaves it with one thread: the background of the template it read LAST - every round
+        // reads its templates again there (:144), in the order of the sorted block.  A raw template (cached, from the sidecar or
+        // read in this round) carries pb0; behind a host-prepared one of round 0 pb still holds what its read left (later rounds do
+        // not read again here: for an HMMER-format template at the end of a later round's block pb keeps the value of round 0).
+        if (rt[cn - 1]->raw) memcpy(pb, pb0, sizeof(pb0));
         std::vector<int> batch_mode(cn);
         std::vector<uint8_t> shorter(cn, 0);  // shorter than the longest template of its batch (HMMSimd::L, src/hhhmmsimd.cpp:97)
         for (unsigned int b = 0; b < cn; b += VECSIZE_FLOAT) {

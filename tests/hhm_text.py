@@ -90,3 +90,45 @@ def random_ss(seed, L):
     r = _rng(seed ^ 0x77)
     return {"dssp": "".join(r.choice(list("-HECSTGB"), L)), "pred": "".join(r.choice(list("HEC"), L)),
             "conf": "".join(r.choice(list("0123456789"), L))}
+
+
+def hmmer3_text(name, f, seed, stars=True, effn=None):
+    """The same kind of profile as HMMER3 TEXT (what hmmbuild writes and HMM::ReadHMMer3 parses, src/hhhmm.cpp:1208-1716): natural-log
+    costs with five decimals, '*' for probability zero, a COMPO line (the reader OVERWRITES the process-wide background pb with it,
+    :1399-1404), node 0, then match / insert / transition lines per node.  f: [L, 20] in the internal amino-acid order.
+    stars: the '*' entries hmmbuild writes (node 0: d->d; node L: m->d, d->d) - the reader turns them into log2(0) = -inf."""
+    r = _rng(seed ^ 0x3C3C)
+    L = f.shape[0]
+
+    def cost(p):
+        return "*" if p <= 0 else "%.5f" % max(0.0, -np.log(p))
+
+    def row(vals):
+        return "  ".join(cost(float(p)) for p in vals)
+
+    compo = f.mean(axis=0)[S2A]
+    compo = 0.7 * compo / compo.sum() + 0.3 / 20
+    ins = np.full(20, 0.05)
+    lines = ["HMMER3/f [3.1b2 | February 2015]", "NAME  %s" % name, "LENG  %d" % L, "ALPH  amino", "NSEQ  %d" % (3 + seed % 20),
+             "EFFN  %.6f" % (float(effn) if effn is not None else 0.6 + 4.0 * r.random()), "STATS LOCAL MSV      -10.0000  0.70000",
+             "HMM          " + "        ".join(SORTED), "            m->m     m->i     m->d     i->m     i->i     d->m     d->d",
+             "  COMPO   " + row(compo), "          " + row(ins)]
+
+    def trans(last, first):
+        pI, pD = 0.002 + 0.06 * r.random(), 0.002 + 0.06 * r.random()
+        pII, pDD = 0.1 + 0.6 * r.random(), 0.1 + 0.6 * r.random()
+        t = [1 - pI - pD, pI, pD, 1 - pII, pII, 1 - pDD, pDD]
+        if last:
+            t = [1 - pI, pI, 0.0 if stars else 1e-9, 1 - pII, pII, 1.0, 0.0 if stars else 1e-9]
+        if first:
+            t[5], t[6] = 1.0, (0.0 if stars else 1e-9)
+        return "          " + "  ".join(cost(p) for p in t)
+
+    lines.append(trans(False, True))
+    fs = f[:, S2A]
+    for i in range(L):
+        lines.append("%7d   %s %6d - -" % (i + 1, row(np.maximum(fs[i], 1e-6)), i + 1))
+        lines.append("          " + row(ins))
+        lines.append(trans(i == L - 1, False))
+    lines.append("//")
+    return ("\n".join(lines) + "\n").encode()

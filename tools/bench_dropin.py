@@ -77,6 +77,13 @@ def run(n=4000, threads=32, L=300, altalis=(1, 4), phases=False):
                 res[tag + "_phases_ms"] = _phases(cap.text)
             else:
                 r = runner(which, q, texts, names, threads=threads, **kw)
+            if tag == "dropin_warm":
+                res.setdefault("warm_all_s", []).append(round(runner.last_alignment_seconds, 4))
+                if "dropin_warm" in res and res["dropin_warm"][0] <= runner.last_alignment_seconds:
+                    continue      # (the faster of the warm calls stands: the host side of a call varies by several ms - fresh pages for
+                                  #  20 000 Hit objects after the reference's run in between, the OpenMP team's wake-up)
+                if phases:
+                    res["dropin_warm_best_phases_ms"] = res.get("dropin_warm_phases_ms")
             res[tag] = (runner.last_alignment_seconds, r)     # the ViterbiRunner::alignment call alone
         compare(canonical(res["cpu"][1]), canonical(res["dropin_cold"][1]))
         compare(canonical(res["cpu"][1]), canonical(res["dropin_warm"][1]))
@@ -85,7 +92,8 @@ def run(n=4000, threads=32, L=300, altalis=(1, 4), phases=False):
                                     "hits": len(res["cpu"][1][0]), "hits_identical": True, "cells": int(n) * L * L}
         if phases:
             out["altali%d" % altali]["cold_phases_ms"] = res.get("dropin_cold_phases_ms")
-            out["altali%d" % altali]["warm_phases_ms"] = res.get("dropin_warm_phases_ms")
+            out["altali%d" % altali]["warm_phases_ms"] = res.get("dropin_warm_best_phases_ms") or res.get("dropin_warm_phases_ms")
+        out["altali%d" % altali]["dropin_warm_calls_s"] = res.get("warm_all_s")
     cache_clear()
     return out
 
