@@ -117,8 +117,10 @@ def test_hhsearch_with_replaced_units_writes_the_same_files(tmp_path, case):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
-@pytest.mark.parametrize("stars", [False, True])
-def test_hhsearch_database_with_hmmer3_templates(tmp_path, stars):
+@pytest.mark.parametrize("stars,app,extra", [(False, "hhsearch", []), (True, "hhsearch", []), (True, "hhblits", ["-n", "1"]),
+                                             (True, "hhsearch", ["-alt", "3"])])   # (hhblits -n 2: the reference itself stops with a
+                                                                                    #  segmentation fault when it merges hits of such a database)
+def test_hhsearch_database_with_hmmer3_templates(tmp_path, stars, app, extra):
     """HMMER-format templates (VERDICT r5 missing #4).  HMM::ReadHMMer3 overwrites the process-wide background `pb` with the file's
     COMPO line (src/hhhmm.cpp:1399-1404), so every template read AFTER such a file - HHM ones included - is prepared against that
     background (src/hhfunc.cpp:165-202): the result of a run depends on the read order.  The drop-in notices the changed `pb` and
@@ -132,9 +134,9 @@ def test_hhsearch_database_with_hmmer3_templates(tmp_path, stars):
         f = hhm_text.mutate_columns(9100 + k, hhm_text.random_columns(431 * 7 + 1, 200)[20:20 + L], mut=0.35) if k % 2 else hhm_text.random_columns(9000 + k, L)
         t[k] = hhm_text.hmmer3_text(names[k], f, 9000 + k, stars=stars)
     base, qpath = build_db(str(tmp_path), q, t, names, 4)
-    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "1"]
-    cpu = run_app("hhsearch_cpu", args, str(tmp_path / "cpu"))
-    hip = run_app("hhsearch_hip", args, str(tmp_path / "hip"))
+    args = ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "1"] + extra
+    cpu = run_app(app + "_cpu", args, str(tmp_path / "cpu"))
+    hip = run_app(app + "_hip", args, str(tmp_path / "hip"))
     assert any(names[1] in l for l in cpu["scores"])
     compare_outputs(cpu, hip)
 
