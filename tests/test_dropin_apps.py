@@ -96,6 +96,24 @@ def test_reference_hhsearch_runs_on_the_synthetic_database(tmp_path):
     assert len(hits) >= 8
 
 
+@pytest.mark.skipif(not have("hhsearch_cpu"), reason="oracle/_ref/hhsearch_cpu not built (needs /root/reference at build time)")
+def test_reference_hhsearch_reads_the_hmmer3_texts(tmp_path):
+    """CPU only: tests/hhm_text.py::hmmer3_text is HMMER3 text as HMM::ReadHMMer3 parses it (src/hhhmm.cpp:1208-1716) - the reference's
+    hhsearch finds the homologs written in that format, with their stated lengths"""
+    q, t, names = make_db(431, 200, 12, 80, 160)
+    qf = hhm_text.random_columns(431 * 7 + 1, 200)
+    Ls = {}
+    for k in range(0, len(t), 3):
+        Ls[names[k]] = 70 + 10 * k
+        t[k] = hhm_text.hmmer3_text(names[k], hhm_text.mutate_columns(9200 + k, qf[10:10 + Ls[names[k]]], mut=0.3), 9200 + k)
+    base, qpath = build_db(str(tmp_path), q, t, names, 5)
+    out = run_app("hhsearch_cpu", ["-i", qpath, "-d", base, "-nocontxt", "-premerge", "0", "-cpu", "1"], str(tmp_path / "cpu"))
+    top = [l for l in out["hhr"] if l[:4].strip().isdigit()][:8]
+    for n, L in Ls.items():
+        line = [l for l in top if n in l]
+        assert line and line[0].rstrip().endswith("(%d)" % L), (n, L, top)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not have("hhsearch_hip"), reason="oracle/_ref/hhsearch_hip not built (needs /root/reference at build time)")
 @pytest.mark.parametrize("case", ["configs0", "ragged_global", "ss"])
