@@ -40,7 +40,8 @@ struct SelShared {
   uint32_t hist[256];
   uint32_t digit, krem, all;
 };
-__device__ __forceinline__ uint64_t radix_select_threshold(const uint64_t (&key)[SEL_PER_THREAD], int k, SelShared& sh) {
+template <int PT>
+__device__ __forceinline__ uint64_t radix_select_threshold(const uint64_t (&key)[PT], int k, SelShared& sh) {
   uint64_t prefix = 0;
   uint32_t krem = (uint32_t)k;
   for (int p = 0; p < 8; ++p) {
@@ -48,7 +49,7 @@ __device__ __forceinline__ uint64_t radix_select_threshold(const uint64_t (&key)
     if (threadIdx.x < 256) sh.hist[threadIdx.x] = 0;
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < SEL_PER_THREAD; ++e) {
+    for (int e = 0; e < PT; ++e) {
       // still a candidate for the K-th key: a real key whose bytes above this one equal the prefix
       bool act = key[e] != 0 && (p == 0 || (key[e] >> (shift + 8)) == (prefix >> (shift + 8)));
       const uint32_t d = (uint32_t)(key[e] >> shift) & 255u;
@@ -105,10 +106,14 @@ __device__ __forceinline__ uint64_t radix_select_threshold(const uint64_t (&key)
 // SRC: SEL_KEYS = the keys a level before wrote, SEL_HITS = hit records (with `rank`), SEL_RESULTS = the DP kernel's result records
 // (HHV_TOPK_RAW: `hits` points at them - no hit record is built for a template that is not selected)
 enum { SEL_KEYS = 0, SEL_HITS = 1, SEL_RESULTS = 2 };
-template <int SRC>
+// PT keys per thread: a chunk is SEL_THREADS x PT keys.  16 for the levels of a very large set; 4 where the survivors of ONE level of
+// smaller chunks still fit the last level's workgroup (100 000 templates, K = 500: 25 workgroups of 4096 keys instead of 7 of 16 384 -
+// the level is one CU's issue per chunk, 26 -> 9 us)
+template <int SRC, int PT>
 __global__ void __launch_bounds__(SEL_THREADS) topk_select_kernel(const DevHit* __restrict__ hits, const uint64_t* __restrict__ in_keys,
                                                                   int n, int k, uint64_t* __restrict__ out_keys, const float* __restrict__ rank) {
   constexpr bool FROM_HITS = SRC != SEL_KEYS;
+  constexpr int SEL_PER_THREAD = PT, SEL_CHUNK = SEL_THREADS * PT;
   __shared__ SelShared sh;
   __shared__ uint32_t sh_valid, sh_out;
   const int base = blockIdx.x * SEL_CHUNK;
@@ -744,13 +749,22 @@ int topk_device(const DevHit* d_hits, int n, int k, const int32_t* gids, DevHit*
     int cur = 0;
     const uint64_t* src = nullptr;
     while (m > last_max || src == nullptr) {
-      const int chunks = (m + SEL_CHUNK - 1) / SEL_CHUNK;
+      // small chunks when their survivors fit the last level at once (and are no more than the input), else chunks of 16 384
+      const int chunks4 = (m + SEL_THREADS * 4 - 1) / (SEL_THREADS * 4);
+      const bool small_chunks = !small_off && (long)chunks4 * k <= last_max && (long)chunks4 * k < m;
+      const int chunks = small_chunks ? chunks4 : (m + SEL_CHUNK - 1) / SEL_CHUNK;
+#define HHV_SELECT(SRCMODE, ...)                                                                                                        \
+  do {                                                                                                                                   \
+    if (small_chunks) hipLaunchKernelGGL((topk_select_kernel<SRCMODE, 4>), dim3(chunks), dim3(SEL_THREADS), 0, stream, __VA_ARGS__);     \
+    else hipLaunchKernelGGL((topk_select_kernel<SRCMODE, SEL_PER_THREAD>), dim3(chunks), dim3(SEL_THREADS), 0, stream, __VA_ARGS__);     \
+  } while (0)
       if (src == nullptr && d_results)
-        hipLaunchKernelGGL(topk_select_kernel<SEL_RESULTS>, dim3(chunks), dim3(SEL_THREADS), 0, stream, (const DevHit*)d_results, (const uint64_t*)nullptr, m, k, buf[cur], (const float*)nullptr);
+        HHV_SELECT(SEL_RESULTS, (const DevHit*)d_results, (const uint64_t*)nullptr, m, k, buf[cur], (const float*)nullptr);
       else if (src == nullptr)
-        hipLaunchKernelGGL(topk_select_kernel<SEL_HITS>, dim3(chunks), dim3(SEL_THREADS), 0, stream, d_hits, (const uint64_t*)nullptr, m, k, buf[cur], rank);
+        HHV_SELECT(SEL_HITS, d_hits, (const uint64_t*)nullptr, m, k, buf[cur], rank);
       else
-        hipLaunchKernelGGL(topk_select_kernel<SEL_KEYS>, dim3(chunks), dim3(SEL_THREADS), 0, stream, (const DevHit*)nullptr, src, m, k, buf[cur], (const float*)nullptr);
+        HHV_SELECT(SEL_KEYS, (const DevHit*)nullptr, src, m, k, buf[cur], (const float*)nullptr);
+#undef HHV_SELECT
       src = buf[cur];
       cur ^= 1;
       m = chunks * k;

@@ -111,6 +111,39 @@ static int fuzz(double seconds, unsigned seed) {
     }
     ++cases;
     radix_cases += force;
+    // ---- the last level of a large set: keys a selection level wrote (with padding zeros), records gathered from the source
+    {
+      const int nk = std::min(n, 1 + (int)(rng() % NMAX));               // real keys
+      const int m2 = std::min(NMAX, nk + (int)(rng() % (1 + nk / 2)));    // slots, the rest padding
+      std::vector<int> pick(n);
+      for (int i = 0; i < n; ++i) pick[i] = i;
+      std::shuffle(pick.begin(), pick.end(), rng);
+      std::vector<uint64_t> kin(m2, 0);
+      std::vector<int> slots(m2);
+      for (int i = 0; i < m2; ++i) slots[i] = i;
+      std::shuffle(slots.begin(), slots.end(), rng);
+      for (int i = 0; i < nk; ++i) kin[slots[i]] = host_key(score[pick[i]], (uint32_t)pick[i]);
+      const int k2 = 1 + (int)(rng() % std::min(nk, (int)SEL_KMAX));
+      static uint64_t* d_kin = nullptr;
+      if (!d_kin) (void)hipMalloc(&d_kin, NMAX * sizeof(uint64_t));
+      (void)hipMemcpy(d_kin, kin.data(), m2 * sizeof(uint64_t), hipMemcpyHostToDevice);
+      (void)hipMemset(d_out, 0xEE, k2 * sizeof(DevHit));
+      const bool from_res = rng() % 2;
+      if (from_res)
+        hipLaunchKernelGGL((topk_small_kernel<SRC_RESULTS, true>), dim3(1), dim3(SEL_THREADS), 0, 0, (const void*)d_res, (const float*)nullptr, m2, k2, (const int32_t*)nullptr, d_out, force, (const uint64_t*)d_kin);
+      else
+        hipLaunchKernelGGL((topk_small_kernel<SRC_HITS, true>), dim3(1), dim3(SEL_THREADS), 0, 0, (const void*)d_hits, (const float*)nullptr, m2, k2, (const int32_t*)nullptr, d_out, force, (const uint64_t*)d_kin);
+      (void)hipMemcpy(out.data(), d_out, k2 * sizeof(DevHit), hipMemcpyDeviceToHost);
+      std::sort(kin.begin(), kin.end(), std::greater<uint64_t>());
+      for (int t = 0; t < k2; ++t) {
+        const int idx = (int)(0xFFFFFFFFu - (uint32_t)(kin[t] & 0xFFFFFFFFu));
+        if (out[t].index != idx || memcmp(&out[t].score, &score[idx], 4) != 0 || out[t].i2 != res[idx].i2) {
+          printf("{\"mismatch\": \"topk keys-in\", \"slots\": %d, \"keys\": %d, \"k\": %d, \"force_radix\": %d, \"rank\": %d, \"got_index\": %d, \"want_index\": %d, \"cases\": %ld}\n",
+                 m2, nk, k2, force, t, out[t].index, idx, cases);
+          return 1;
+        }
+      }
+    }
     // ---- merge of m records (some of them padding), k of them wanted
     {
       const int m = (rng() % 2) ? 1 + (int)(rng() % 1024) : 1 + (int)(rng() % 4096);
