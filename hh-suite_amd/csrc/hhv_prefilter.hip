@@ -273,7 +273,20 @@ __global__ void __launch_bounds__(1024) hhv_pf_ungapped_pk_kernel(PrefilterArgs 
 }
 
 // ---- striped Smith-Waterman: one 32-lane half per sequence, H and E in registers ---------------------------------
-template <int W>
+// SCAN (round 6, last session): the lazy-F correction as a prefix scan instead of the reference's loop.  What the loop computes
+// (src/hhprefilter.cpp:176-203) is the vertical-gap value entering every stripe element from the elements above it,
+//   Fin(k) = max(0, max over k' < k of ( Fend(k') - (k - 1 - k') * W * ge )),     Fend = the main pass's F behind its last row,
+// then H[j] = max(H[j], Fin - j * ge) down the element's W rows: the loop finds it by shifting F one element per pass and stops at
+// the first row where no element needs a correction - from there on nothing can change (the main pass's own F chain dominates:
+// F <= H[j] - go gives F - ge <= H[j] - go <= the main pass's F of row j + 1 <= H[j + 1]; gap open >= gap extend, the host checks).
+// The rows the loop never visits are rows the closed form does not change, so H - all that leaves a column - is the same; the
+// column maximum is not touched by either (a corrected cell is below the cell its F came from); E is not updated in the loop (:175).
+// The scan is a max-plus prefix over the 32 elements of a half (G = Fend + k W ge: four row_shr steps, one row_bcast:15 into the
+// half's second row) - ~35 instructions a residue WHEN any element needs a correction (the loop's first test, kept as the one
+// wave-uniform branch), whatever the sequence; the loop costs ~12 instructions per row it visits, 40-60 rows behind a high-scoring
+// cell: the survivors of the gapless stage - homologs, what this kernel exists for - took 5.5 x the time of random sequences
+// (20 000 x 300: 6.7 vs 1.2 ms; the reference's AVX2 loop 1.9 x), tools/bench_sw_homologs.py.
+template <int W, bool SCAN>
 __global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WQ = (W + 3) / 4;
@@ -334,9 +347,29 @@ __global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
       // The loop's first test - does any element need a correction at segment row 0 - fails for most residues, for both halves:
       // it is taken out of the loop as ONE wave-uniform test, so that the common case jumps over the whole (unrolled,
       // predicated) loop body with a single scalar branch instead of walking its W guarded blocks.
+      const int Fend = F;
       F = half_shr1_zero(F, k);
       bool active = true;
-      if (__ballot(sat_sub(F, sat_sub(H[0], go)) != 0) != 0)
+      if (__ballot(sat_sub(F, sat_sub(H[0], go)) != 0) != 0) {
+      if (SCAN) {
+        // inclusive max-scan of G over the half: rows of 16 lanes (row_shr 1, 2, 4, 8; a lane without a source keeps its own
+        // value), then the first row's last lane into the half's second row (row_bcast:15, rows 1 and 3 only)
+        const int koff = k * (W * ge);
+        int G = Fend + koff;
+        G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x111, 0xF, 0xF, false));
+        G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x112, 0xF, 0xF, false));
+        G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x114, 0xF, 0xF, false));
+        G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x118, 0xF, 0xF, false));
+        G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x142, 0xA, 0xF, false));
+        // exclusive: the element above; element 0 of a half has nothing above it
+        const int up = __builtin_amdgcn_update_dpp(0, G, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+        int f = k == 0 ? 0 : max(up - (koff - W * ge), 0);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          H[j] = max(H[j], f);
+          f = sat_sub(f, ge);
+        }
+      } else
       for (;;) {
         bool done = false;
 #pragma unroll
@@ -357,6 +390,7 @@ __global__ void __launch_bounds__(512) hhv_pf_sw_kernel(PrefilterArgs a) {
         if (done) break;
         const int Fs = half_shr1_zero(F, k);
         if (active) F = Fs;
+      }
       }
       }  // b
     }    // wi
@@ -505,10 +539,15 @@ int launch_prefilter_fast(const PrefilterArgs& a, bool gapped, int W, int n_bloc
     }
     return -(int)hipErrorInvalidValue;
   }
+  // the scan form of the lazy-F correction needs gap open >= gap extend (always so in HH-suite: 20 / 4, src/hhdecl.cpp); HHV_PF_LAZY_LOOP=1:
+  // the reference's loop (A/B, tests)
+  static const bool lazy_loop = [] { const char* e = getenv("HHV_PF_LAZY_LOOP"); return e && atoi(e) == 1; }();
+  const bool scan = !lazy_loop && a.gap_init >= a.gap_extend;
   switch (W) {
 #define HHV_PF_CASE(w) \
   case w:              \
-    return launch_one(hhv_pf_sw_kernel<w>, a, n_blocks, 512, lds, stream);
+    return scan ? launch_one(hhv_pf_sw_kernel<w, true>, a, n_blocks, 512, lds, stream) \
+                : launch_one(hhv_pf_sw_kernel<w, false>, a, n_blocks, 512, lds, stream);
     HHV_PF_CASE(1) HHV_PF_CASE(2) HHV_PF_CASE(3) HHV_PF_CASE(4) HHV_PF_CASE(5) HHV_PF_CASE(6) HHV_PF_CASE(7) HHV_PF_CASE(8)
     HHV_PF_CASE(9) HHV_PF_CASE(10) HHV_PF_CASE(11) HHV_PF_CASE(12) HHV_PF_CASE(13) HHV_PF_CASE(14) HHV_PF_CASE(15)
     HHV_PF_CASE(16) HHV_PF_CASE(17) HHV_PF_CASE(18) HHV_PF_CASE(19) HHV_PF_CASE(20)

@@ -121,6 +121,58 @@ def test_gpu_prefilter_long_queries(oracle, Lq, monkeypatch):
     c.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_sw_on_homologs_for_any_gap_parameters(oracle, seed):
+    """The sequences Smith-Waterman really sees - survivors of the gapless stage: long stretches that follow the profile's best
+    states, scores up to the cap - under many gap parameters and query lengths (1 .. 16 cells per stripe element).  This is where
+    the lazy-F correction works hardest (40-60 rows behind a high-scoring cell); the kernel computes it as a prefix scan when
+    gap_init >= gap_extend and with the reference's loop otherwise (hhv_pf_sw_kernel<W, SCAN>): both against the oracle, which is
+    pinned to Prefilter::swStripedByte for any gap parameters (test_oracle_sw_matches_reference_for_any_gap_parameters)."""
+    from pyhhv import capi
+    rng = np.random.default_rng(4200 + seed)
+    Lq = int(rng.choice([7, 31, 32, 33, 64, 100, 160, 257, 300, 320, 383, 448, 512]))
+    off = int(rng.choice([0, 20, 50]))
+    prof = np.clip(rng.normal(off - 6, 10, (220, Lq)), 0, 255).astype(np.uint8)
+    best = rng.integers(0, 219, Lq)
+    prof[best, np.arange(Lq)] = np.clip(off + rng.integers(3, 30, Lq), 0, 255)
+    n = 240
+    lens = rng.integers(1, 700, n)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    seqs = rng.integers(0, 219, offs[-1]).astype(np.uint8)
+    for k in range(n):
+        if k % 4 == 3:
+            continue                      # (a quarter stays random)
+        L, q, t = int(lens[k]), int(rng.integers(0, max(1, Lq // 2))), 0
+        frac = (0.3, 0.7, 0.95)[k % 3]
+        while t < L:
+            r = rng.random()
+            if r < 0.03:
+                q += int(rng.integers(1, 12))     # a deletion: the vertical gaps the lazy-F correction is about
+            elif r < 0.06:
+                t += int(rng.integers(1, 6))
+                continue
+            if q >= Lq:
+                q = int(rng.integers(0, max(1, Lq // 2)))   # a second copy (repeat)
+            if rng.random() < frac:
+                seqs[offs[k] + t] = best[q]
+            t += 1
+            q += 1
+    c = capi.Context()
+    db = c.prefilter_upload_db(seqs, offs)
+    seen_cap = False
+    for go, ge in ((24, 4), (20, 4), (4, 4), (9, 9), (60, 1), (5, 0), (0, 0), (3, 4), (0, 9), (30, 30)):
+        want = np.array([oracle.lib.hho_sw_score(u8(prof), Lq, u8(np.ascontiguousarray(seqs[offs[k]:offs[k + 1]])), int(lens[k]), go, ge,
+                                                 off, 32) for k in range(n)], dtype=np.int32)
+        got = c.prefilter_scores(db, prof, off, gapped=True, gap_init=go, gap_extend=ge)
+        assert np.array_equal(got, want), (Lq, off, go, ge, int((got != want).sum()), np.flatnonzero(got != want)[:5])
+        seen_cap = seen_cap or int(want.max()) == 255 - off
+    assert seen_cap or Lq < 31
+    c.prefilter_free_db(db)
+    c.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_oracle_sw_matches_reference_for_any_gap_parameters(oracle, ref, seed):
     """gap_init < gap_extend never happens in hhblits (gap_init = open + extend), but the striped algorithm is defined
