@@ -1,7 +1,7 @@
 """Smith-Waterman prefilter on the sequences a real search sends through it - the survivors of the gapless stage, i.e. homologs - against
 random sequences: GPU kernel time (hhv_pf_sw_kernel) and the reference's AVX2 swStripedByte on the host's threads for the same sets.
 The lazy-F loop of the striped algorithm (src/hhprefilter.cpp:176-203) runs longer the more similar a sequence is to the query.
-usage: python tools/bench_sw_homologs.py [n_seq] [ref_threads]  -> JSON"""
+usage: python tools/bench_sw_homologs.py [n_seq] [ref_threads] [Lq = Lt]  -> JSON"""
 import ctypes as C
 import json
 import os
@@ -20,7 +20,7 @@ from pyhhv import capi, synth  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    Lq = Lt = 300
+    Lq = Lt = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     z = np.load(os.path.join(ROOT, "tests", "golden", "gonnet_pb_R.npz"))
     pb, R = z["pb"], z["R"]
     lib = np.load(os.path.join(ROOT, "tests", "golden", "cs219_probs.npz"))["lib"]
