@@ -459,11 +459,33 @@ __global__ void __launch_bounds__(256) hhv_pf_generic_kernel(PrefilterArgs a) {
           F = max(max(0, F - ge), H);
           H = Hb[j * 32 + k];
         }
-        // lazy-F loop (:176-203)
+        // lazy-F correction (:176-203).  gap open >= gap extend: as a prefix scan over the half's 32 stripe elements (see
+        // hhv_pf_sw_kernel: the same H in every row), the rows walked once and only while the incoming F is above zero - for
+        // other gap parameters the reference's loop, whose exit test then prunes the chain
         int j = 0;
         H = Ha[k];
+        const int Fend = F;
         F = half_shr1_zero(F, k);
         bool need = max(0, F - max(0, H - go)) != 0;
+        if (go >= ge) {
+          if (((__ballot(need) >> (threadIdx.x & 32)) & 0xFFFFFFFFull) != 0) {   // (a half without a correction at row 0 has none at all)
+            const int koff = k * (W * ge);
+            int G = Fend + koff;
+            G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x111, 0xF, 0xF, false));
+            G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x112, 0xF, 0xF, false));
+            G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x114, 0xF, 0xF, false));
+            G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x118, 0xF, 0xF, false));
+            G = max(G, __builtin_amdgcn_update_dpp(G, G, 0x142, 0xA, 0xF, false));
+            const int up = __builtin_amdgcn_update_dpp(0, G, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+            int f = k == 0 ? 0 : max(up - (koff - W * ge), 0);
+            for (j = 0; j < W && f > 0; ++j) {
+              const int h0 = Ha[j * 32 + k];
+              if (f > h0) Ha[j * 32 + k] = (unsigned char)f;
+              f = ge > 0 ? max(0, f - ge) : f;
+            }
+          }
+          need = false;
+        }
         while (((__ballot(need) >> (threadIdx.x & 32)) & 0xFFFFFFFFull) != 0) {
           H = max(H, F);
           vmax = max(vmax, H);
