@@ -818,6 +818,15 @@ def next_rows():
     except Exception as e:  # the headline line must not depend on the side measurements
         out["N3_prefilter"] = {"error": repr(e)}
     try:
+        # Smith-Waterman on what a search sends through it - the survivors of the gapless stage, i.e. homologs - beside random
+        # sequences: the lazy-F correction (src/hhprefilter.cpp:176-203) is where the two differ (tools/bench_sw_homologs.py)
+        import bench_sw_homologs
+        h = bench_sw_homologs.run(20000, usable_cores()[0], 300, 200)
+        if isinstance(out.get("N3_prefilter"), dict):
+            out["N3_prefilter"]["sw_on_homologs_20000x300"] = {k: h[k] for k in ("random", "homologs_30pct", "homologs_70pct")}
+    except Exception as e:
+        out.setdefault("N3_prefilter", {})["sw_on_homologs_error"] = repr(e)
+    try:
         import bench_mac
         r = bench_mac.run(500, 300, 300, 100, ref_threads=usable_cores()[0])
         ro = r.get("reference_openmp") or {}

@@ -17,10 +17,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from pyhhv import capi, synth  # noqa: E402
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    Lq = Lt = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+def run(n=20000, threads=16, L=300, check=200):
+    Lq = Lt = L
     z = np.load(os.path.join(ROOT, "tests", "golden", "gonnet_pb_R.npz"))
     pb, R = z["pb"], z["R"]
     lib = np.load(os.path.join(ROOT, "tests", "golden", "cs219_probs.npz"))["lib"]
@@ -48,6 +46,14 @@ def main():
         sc = c.prefilter_scores(db, prof, 50, gapped=True, gap_init=24, gap_extend=4, subset=sub)
         kms = c.last_kernel_ms()
         e = {"gpu_kernel_ms": round(kms, 3), "gpu_cells_per_s": Lq * n * Lt / (kms * 1e-3), "score_mean": float(sc.mean()), "score_max": int(sc.max())}
+        if check:   # a sample against the oracle (pinned to Prefilter::swStripedByte)
+            u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
+            p8 = np.ascontiguousarray(prof)
+            bad = 0
+            for q in (np.arange(check) * 97) % n:
+                sq = np.ascontiguousarray(seqs[q * Lt:(q + 1) * Lt])
+                bad += int(orc.lib.hho_sw_score(u8(p8), Lq, u8(sq), Lt, 24, 4, 50, 32) != sc[q])
+            e["checked"], e["mismatches_vs_oracle"] = check, bad
         if po.have_ref() and threads:
             rl = po.Ref().lib
             f = rl.ref_prefilter_scores_timed
@@ -60,8 +66,10 @@ def main():
             e["gpu_over_reference"] = t * 1e3 / kms
         out[name] = e
         c.prefilter_free_db(db)
-    print(json.dumps(out))
+    c.close()
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    a = [int(x) for x in sys.argv[1:]]
+    print(json.dumps(run(*a)))
