@@ -251,7 +251,27 @@ def prefilter_family(orc, rng, budget):
         offs = np.zeros(n + 1, np.int64)
         offs[1:] = np.cumsum(lens)
         seqs = rng.integers(0, 220, offs[-1]).astype(np.uint8)
-        go, ge = int(rng.choice([24, 5, 0, 40])), int(rng.choice([4, 1, 0, 9]))
+        # every second sequence a homolog: it follows the profile's best states along a diagonal, with insertions, deletions and
+        # repeats - high scores up to the cap, where the Smith-Waterman kernel's lazy-F correction (a prefix scan for gap open >=
+        # gap extend, the reference's loop otherwise) has 40-60 rows to repair behind every strong cell
+        best = prof[:219].argmax(axis=0).astype(np.uint8)
+        for k in range(0, n, 2):
+            L, q, t = int(lens[k]), int(rng.integers(0, max(1, Lq // 2))), 0
+            frac = float(rng.choice([0.3, 0.7, 0.95]))
+            while t < L:
+                r = rng.random()
+                if r < 0.04:
+                    q += int(rng.integers(1, 15))
+                elif r < 0.08:
+                    t += int(rng.integers(1, 6))
+                    continue
+                if q >= Lq:
+                    q = int(rng.integers(0, max(1, Lq // 2)))
+                if rng.random() < frac:
+                    seqs[offs[k] + t] = best[q]
+                t += 1
+                q += 1
+        go, ge = int(rng.choice([24, 20, 5, 0, 40, 9])), int(rng.choice([4, 1, 0, 9]))
         db = c.prefilter_upload_db(seqs, offs)
         ung = c.prefilter_scores(db, prof, off, gapped=False)
         gap = c.prefilter_scores(db, prof, off, gapped=True, gap_init=go, gap_extend=ge)
